@@ -1,0 +1,210 @@
+"""ctypes front-end of the CPU oracle (oracle/libgpb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by gpboost_amd/.  See gpb_oracle.c for the
+reference file:line each routine restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COV_TYPES = {"exponential": 0, "matern_0.5": 0, "matern_1.5": 1, "matern_2.5": 2}
+
+
+def cov_type_id(cov_function, shape=0.5):
+    """'exponential' == Matern(0.5) (include/GPBoost/cov_fcts.h:113-203)."""
+    if cov_function == "exponential":
+        return 0
+    if cov_function == "matern":
+        return {0.5: 0, 1.5: 1, 2.5: 2}[float(shape)]
+    raise ValueError(cov_function)
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgpb_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def transform_cov_pars(cov_type, pars_orig):
+    out = np.empty(3)
+    lib().orc_transform_cov_pars(C.c_int(cov_type), _p(_f64(pars_orig), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def shuffle(n, seed):
+    idx = np.empty(n, dtype=np.int32)
+    lib().orc_shuffle(C.c_int(n), C.c_int(seed), _p(idx, C.c_int))
+    return idx
+
+
+def sort_indices(v):
+    v = _f64(v)
+    idx = np.empty(v.size, dtype=np.int32)
+    lib().orc_sort_indices(_p(v, C.c_double), C.c_int(v.size), _p(idx, C.c_int))
+    return idx
+
+
+def coords_sum(coords):
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    out = np.empty(n)
+    lib().orc_coords_sum(_p(cm, C.c_double), C.c_int(n), C.c_int(d), _p(out, C.c_double))
+    return out
+
+
+def neighbors(coords, m, want_sqd=False):
+    """coords: (n, d) in Vecchia order.  Returns int32 (n, m'), -1 padded (m' = min(m, n-1))."""
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    m = min(m, n - 1)
+    ss = sort_indices(coords_sum(cm))
+    nn = np.empty((n, m), dtype=np.int32)
+    sqd = np.full((n, m), np.inf) if want_sqd else None
+    lib().orc_vecchia_neighbors(_p(cm, C.c_double), C.c_int(n), C.c_int(d), C.c_int(m),
+                                _p(ss, C.c_int), _p(nn, C.c_int), _p(sqd, C.c_double))
+    return (nn, sqd) if want_sqd else nn
+
+
+def vecchia_factor(coords, nn, cov_type, var, a, gauss=True, grad=False):
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    m = nn.shape[1]
+    A = np.empty((n, m)); D = np.empty(n)
+    Ag = np.empty((2, n, m)) if grad else None
+    Dg = np.empty((2, n)) if grad else None
+    bad = lib().orc_vecchia_factor(_p(cm, C.c_double), C.c_int(n), C.c_int(d), _p(nn, C.c_int), C.c_int(m),
+                                   C.c_int(cov_type), C.c_double(var), C.c_double(a), C.c_int(1 if gauss else 0),
+                                   _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double))
+    return (A, D, Ag, Dg, bad) if grad else (A, D, bad)
+
+
+def vecchia_nll(coords, nn, cov_type, pars_trans, y):
+    """Returns (yTPsiInvy, logdet, negll).  pars_trans = (sigma2, var, a)."""
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    out = np.empty(3)
+    lib().orc_vecchia_nll(_p(cm, C.c_double), C.c_int(n), C.c_int(d), _p(nn, C.c_int), C.c_int(nn.shape[1]),
+                          C.c_int(cov_type), _p(_f64(pars_trans), C.c_double), _p(_f64(y), C.c_double),
+                          _p(out, C.c_double))
+    return out
+
+
+def vecchia_nll_grad(coords, nn, cov_type, pars_trans, y):
+    """Returns (out3, grad3) -- grad wrt log(sigma2), log(var), log(a) as CalcGradPars does."""
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    out = np.empty(3); g = np.empty(3)
+    lib().orc_vecchia_nll_grad(_p(cm, C.c_double), C.c_int(n), C.c_int(d), _p(nn, C.c_int), C.c_int(nn.shape[1]),
+                               C.c_int(cov_type), _p(_f64(pars_trans), C.c_double), _p(_f64(y), C.c_double),
+                               _p(out, C.c_double), _p(g, C.c_double))
+    return out, g
+
+
+def vecchia_yaux(A, D, nn, y):
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, m = nn.shape
+    out = np.empty(n)
+    lib().orc_vecchia_yaux(_p(_f64(A), C.c_double), _p(_f64(D), C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+                           _p(_f64(y), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def exact_nll(coords, cov_type, pars_trans, y, want_yaux=False):
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    out = np.empty(3)
+    ya = np.empty(n) if want_yaux else None
+    rc = lib().orc_exact_nll(_p(cm, C.c_double), C.c_int(n), C.c_int(d), C.c_int(cov_type),
+                             _p(_f64(pars_trans), C.c_double), _p(_f64(y), C.c_double), _p(out, C.c_double),
+                             _p(ya, C.c_double))
+    if rc != 0:
+        raise FloatingPointError("matrix not SPD")
+    return (out, ya) if want_yaux else out
+
+
+def hist_build(bins, bin_offsets, data_indices, grad, hess=None, const_hess=1.0):
+    """bins: (F, n) uint8.  Returns (hist_grad, hist_cnt(uint64), hist_hess)."""
+    bins = np.ascontiguousarray(bins, dtype=np.uint8)
+    F, n = bins.shape
+    bo = np.ascontiguousarray(bin_offsets, dtype=np.int32)
+    di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+    nd = n if di is None else di.size
+    tot = int(bo[-1])
+    hg = np.empty(tot); hc = np.empty(tot, dtype=np.uint64); hh = np.empty(tot)
+    h = None if hess is None else _f64(hess)
+    lib().orc_hist_build(_p(bins, C.c_uint8), C.c_int(n), C.c_int(F), _p(bo, C.c_int), _p(di, C.c_int), C.c_int(nd),
+                         _p(_f64(grad), C.c_double), _p(h, C.c_double), C.c_double(const_hess),
+                         _p(hg, C.c_double), _p(hc, C.c_uint64), _p(hh, C.c_double))
+    return hg, hc, hh
+
+
+# ---------------------------------------------------------------------------
+# High-level mirror of GPModel(gp_approx="vecchia").neg_log_likelihood for tests
+# ---------------------------------------------------------------------------
+def vecchia_setup(coords, m, ordering="random", seed=0):
+    """Ordering + neighbour search (src/GPBoost/Vecchia_utils.cpp:1095-1221).
+    Returns (perm, coords_ordered, nn)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    n = coords.shape[0]
+    perm = shuffle(n, seed) if ordering == "random" else np.arange(n, dtype=np.int32)
+    co = coords[perm]
+    return perm, co, neighbors(co, m)
+
+
+def gp_nll(coords, y, cov_pars, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=0,
+           setup=None):
+    ct = cov_type_id(cov_function, shape)
+    pt = transform_cov_pars(ct, cov_pars)
+    perm, co, nn = setup if setup is not None else vecchia_setup(coords, m, ordering, seed)
+    return vecchia_nll(co, nn, ct, pt, np.asarray(y, dtype=np.float64)[perm])[2]
+
+
+# ---------------------------------------------------------------------------
+# The R test-suite's deterministic fixture
+# (R-package/tests/testthat/test_GPModel_gaussian_process.R:36-60)
+# ---------------------------------------------------------------------------
+def sim_rand_unif(n, init_c):
+    """LCG x_{k+1} = (22695477 x_k + 1) mod 2^32, x_0 = floor(init_c 2^32); returns x / 2^32.
+    NB: R evaluates this in *double* arithmetic (the product exceeds 2^53 and is rounded), so the
+    recursion is done in float64 here too -- exact integer arithmetic gives a different sequence."""
+    s = np.empty(n)
+    s[0] = np.floor(init_c * 2 ** 32)
+    for i in range(1, n):
+        s[i] = (22695477 * s[i - 1] + 1) % 2 ** 32
+    return s / 2 ** 32
+
+
+def r_fixture():
+    from scipy.spatial.distance import cdist
+    from scipy.stats import norm
+    n, d = 100, 2
+    coords = sim_rand_unif(n * d, 0.1).reshape((n, d), order="F")
+    Sigma = np.exp(-cdist(coords, coords) / 0.1) + 1e-20 * np.eye(n)
+    Cc = np.linalg.cholesky(Sigma)
+    y = Cc @ norm.ppf(sim_rand_unif(n, 0.8)) + norm.ppf(sim_rand_unif(n, 0.1)) / 5
+    return coords, y
