@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's ``gpboost.GPModel`` for the MI355X hot path.
+
+Same constructor argument names, same ``neg_log_likelihood(cov_pars, y, fixed_effects)`` call and the
+same error type as ``python-package/gpboost/basic.py`` (class GPModel :4172, ``neg_log_likelihood``
+:5640-5700, ``_safe_call`` :136-145), bound with ctypes to the SAME C symbols
+(``GPB_CreateREModel`` / ``GPB_EvalNegLogLikelihood`` / ``GPB_REModelFree`` / ``LGBM_GetLastError``), so the
+parity tests read like the reference's own.  Only the model slice the hot path covers is accepted
+(see include/gpboost_c_api_subset.h); everything else raises ``GPBoostError`` -- there is no fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from .libpath import load_lib
+
+_LIB = None
+
+
+class GPBoostError(Exception):
+    """Error thrown by the library (same name as the reference's, basic.py:131)."""
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load_lib()
+        _LIB.LGBM_GetLastError.restype = ctypes.c_char_p
+        _LIB.gpb_hip_get_last_error.restype = ctypes.c_char_p
+        _LIB.GPB_HIP_GetVecchiaHandle.restype = ctypes.c_void_p
+        _LIB.GPB_HIP_GetVecchiaHandle.argtypes = [ctypes.c_void_p]
+    return _LIB
+
+
+def _safe_call(ret):
+    if ret != 0:
+        raise GPBoostError(_lib().LGBM_GetLastError().decode("utf-8"))
+
+
+def _shim_call(ret):
+    if ret != 0:
+        raise GPBoostError(_lib().gpb_hip_get_last_error().decode("utf-8"))
+
+
+def c_str(string):
+    return ctypes.c_char_p(string.encode("utf-8"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _lib().gpb_hip_device_count(ctypes.byref(n))
+    return n.value
+
+
+def set_device(device):
+    _shim_call(_lib().gpb_hip_set_device(ctypes.c_int(int(device))))
+
+
+def selftest():
+    """Runs the on-device check of the fp64 DPP primitives."""
+    _shim_call(_lib().gpb_hip_selftest())
+
+
+class GPModel(object):
+    """Gaussian-process model evaluated on an MI355X (Vecchia approximation, Gaussian likelihood)."""
+
+    def __init__(self, likelihood="gaussian", group_data=None, group_rand_coef_data=None,
+                 ind_effect_group_rand_coef=None, drop_intercept_group_rand_effect=None, gp_coords=None,
+                 gp_rand_coef_data=None, cov_function="matern", cov_fct_shape=1.5, gp_approx="none",
+                 num_parallel_threads=None, GPU_use=True, matrix_inversion_method="default", weights=None,
+                 likelihood_learning_rate=1., cov_fct_taper_range=1., cov_fct_taper_shape=1., num_neighbors=None,
+                 vecchia_ordering="random", ind_points_selection="kmeans++", num_ind_points=None,
+                 cover_tree_radius=1., seed=0, cluster_ids=None, num_data=None, likelihood_additional_param=None):
+        self.handle = ctypes.c_void_p()
+        if group_data is not None or group_rand_coef_data is not None:
+            raise GPBoostError("grouped random effects are not on the MI355X hot path of this library")
+        if gp_coords is None:
+            raise ValueError("'gp_coords' is required")
+        if gp_rand_coef_data is not None:
+            raise GPBoostError("GP random coefficients are not on the MI355X hot path of this library")
+        gp_coords = np.asarray(gp_coords, dtype=np.float64)
+        if gp_coords.ndim == 1:
+            gp_coords = gp_coords.reshape(-1, 1)
+        self.num_data = gp_coords.shape[0]
+        self.dim_coords = gp_coords.shape[1]
+        self.cov_function = cov_function
+        self.cov_fct_shape = float(cov_fct_shape)
+        self.gp_approx = gp_approx
+        self.vecchia_ordering = vecchia_ordering
+        self.seed = int(seed)
+        self.likelihood = likelihood
+        self.num_cov_pars = 3   # error variance, GP variance, range (Gaussian likelihood, one GP)
+        if num_neighbors is None or num_neighbors <= 0:
+            num_neighbors = 20   # the library default for gp_approx="vecchia" (re_model_template.h:288-294)
+        self.num_neighbors = int(num_neighbors)
+        coords_c = np.asfortranarray(gp_coords)   # column-major, basic.py:5075-5081
+        cluster_c = ctypes.c_void_p()
+        if cluster_ids is not None:
+            cid = np.ascontiguousarray(cluster_ids, dtype=np.int32)
+            cluster_c = cid.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        weights_c = ctypes.c_void_p()
+        lap = -999. if likelihood_additional_param is None else float(likelihood_additional_param)
+        _safe_call(_lib().GPB_CreateREModel(
+            ctypes.c_int(self.num_data), cluster_c, ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_void_p(),
+            ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_void_p(), ctypes.c_int(1), _dptr(coords_c),
+            ctypes.c_int(self.dim_coords), ctypes.c_void_p(), ctypes.c_int(0), c_str(cov_function),
+            ctypes.c_double(self.cov_fct_shape), c_str(gp_approx), ctypes.c_double(cov_fct_taper_range),
+            ctypes.c_double(cov_fct_taper_shape), ctypes.c_int(self.num_neighbors), c_str(vecchia_ordering),
+            ctypes.c_int(-1 if num_ind_points is None else int(num_ind_points)), ctypes.c_double(cover_tree_radius),
+            c_str(ind_points_selection), c_str(likelihood), ctypes.c_double(lap), c_str(matrix_inversion_method),
+            ctypes.c_int(self.seed), ctypes.c_int(-1 if num_parallel_threads is None else int(num_parallel_threads)),
+            ctypes.c_bool(bool(GPU_use)), ctypes.c_bool(weights is not None), weights_c,
+            ctypes.c_double(likelihood_learning_rate), ctypes.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value is not None:
+                _safe_call(_lib().GPB_REModelFree(self.handle))
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # --- reference surface -------------------------------------------------------------------
+    def neg_log_likelihood(self, cov_pars, y, fixed_effects=None, aux_pars=None):
+        """Evaluate the negative log-likelihood (reference: basic.py:5640-5700)."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if y.shape[0] != self.num_data:
+            raise ValueError("Incorrect number of data points in 'y'")
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        if cov_pars.shape[0] != self.num_cov_pars:
+            raise ValueError("'cov_pars' does not contain the correct number of parameters")
+        fe_c = ctypes.c_void_p()
+        if fixed_effects is not None:
+            fixed_effects = np.ascontiguousarray(fixed_effects, dtype=np.float64).reshape(-1)
+            if fixed_effects.shape[0] != self.num_data:
+                raise ValueError("Length of 'fixed_effects' is not correct ")
+            fe_c = _dptr(fixed_effects)
+        negll = ctypes.c_double(0)
+        _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, _dptr(y), _dptr(cov_pars), fe_c, ctypes.byref(negll)))
+        return negll.value
+
+    def get_current_neg_log_likelihood(self):
+        negll = ctypes.c_double(0)
+        _safe_call(_lib().GPB_GetCurrentNegLogLikelihood(self.handle, ctypes.byref(negll)))
+        return negll.value
+
+    def _get_likelihood_name(self):
+        buf = ctypes.create_string_buffer(256)
+        num = ctypes.c_int(0)
+        _safe_call(_lib().GPB_GetLikelihoodName(self.handle, buf, ctypes.byref(num)))
+        return buf.value.decode("utf-8")
+
+    # --- additions used by tests / bench (no reference C entry point exists for these) --------
+    def neg_log_likelihood_and_gradient(self, cov_pars, y, fixed_effects=None):
+        """(nll, gradient wrt log(sigma2), log(sigma1_2/sigma2), log(transformed range)): what
+        ``CalcGradPars`` hands to the reference's optimisers (re_model_template.h:1988-2011)."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        fe_c = ctypes.c_void_p()
+        if fixed_effects is not None:
+            fixed_effects = np.ascontiguousarray(fixed_effects, dtype=np.float64).reshape(-1)
+            fe_c = _dptr(fixed_effects)
+        negll = ctypes.c_double(0)
+        grad = np.empty(3)
+        _safe_call(_lib().GPB_HIP_EvalNegLogLikelihoodAndGrad(self.handle, _dptr(y), _dptr(cov_pars), fe_c,
+                                                              ctypes.byref(negll), _dptr(grad)))
+        return negll.value, grad
+
+    def y_aux(self, cov_pars, y):
+        """Psi^-1 y in data order (the boosting gradient, re_model_template.h:3298-3321)."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        out = np.empty(self.num_data)
+        _safe_call(_lib().GPB_HIP_CalcYAux(self.handle, _dptr(y), _dptr(cov_pars), _dptr(out)))
+        return out
+
+    def vecchia_structure(self):
+        """(perm, nn): Vecchia ordering and the (n, m) neighbour table, -1 padded."""
+        m = ctypes.c_int(0)
+        perm = np.empty(self.num_data, dtype=np.int32)
+        _safe_call(_lib().GPB_HIP_GetVecchiaStructure(self.handle, perm.ctypes.data_as(ctypes.c_void_p), None,
+                                                      ctypes.byref(m)))
+        nn = np.empty((self.num_data, max(m.value, 1)), dtype=np.int32)
+        _safe_call(_lib().GPB_HIP_GetVecchiaStructure(self.handle, None, nn.ctypes.data_as(ctypes.c_void_p), None))
+        return perm, nn
+
+    def vecchia_handle(self):
+        return ctypes.c_void_p(_lib().GPB_HIP_GetVecchiaHandle(self.handle))

@@ -1,0 +1,135 @@
+// gpboost_amd/csrc/dev_common.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Everything here is written for CDNA4 (gfx950) only: 64-lane wavefronts, DPP
+// row_newbcast on the fp64 pipe, v_rsq_f64 / v_ldexp_f64.  No other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+namespace gpb {
+
+// ---- compile-time loop: f(integral_constant<int, I>) for I in [B, E) ------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// descending: I = E-1 ... B
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_down(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, E - 1>{});
+    static_for_down<B, E - 1>(f);
+  }
+}
+
+// ---- fp64 DPP within a row of 16 lanes ------------------------------------
+// gfx90a+ allows DPP on the DP ALU only with row_newbcast:N (lane N of each
+// 16-lane row is broadcast to the row).  There is no clang builtin for the
+// 64-bit form, hence inline asm.  The compiler neither sees the DPP nor pads
+// its hazard ("VALU writes VGPR -> DPP reads that VGPR: 2 wait states"), so each
+// statement opens with s_nop 1.  All 64 lanes must be active (a disabled source
+// lane would read as 0): the kernels below never early-exit a lane.
+template <int LANE>
+__device__ __forceinline__ double row_bcast(double x) {
+  static_assert(LANE >= 0 && LANE < 16, "row_newbcast lane");
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+      : "=v"(r)
+      : "v"(x), "n"(LANE));
+  return r;
+}
+// acc -= bcast<LANE>(b) * own      (one v_fmac_f64 with the broadcast folded in)
+template <int LANE>
+__device__ __forceinline__ void row_fnma(double& acc, double b, double own) {
+  static_assert(LANE >= 0 && LANE < 16, "row_newbcast lane");
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(b), "v"(own), "n"(LANE));
+}
+// Portable-in-HIP variant of the same two primitives (two 32-bit DPP movs that the
+// compiler schedules and pads itself).  Used by the self-test kernel to validate the
+// asm forms on the device, and selectable with -DGPB_DPP_VIA_BUILTIN for debugging.
+template <int LANE>
+__device__ __forceinline__ double row_bcast_builtin(double x) {
+  const long long v = __builtin_bit_cast(long long, x);
+  int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + LANE, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + LANE, 0xf, 0xf, false);
+  const long long r = ((long long)hi << 32) | (unsigned long long)(unsigned int)lo;
+  return __builtin_bit_cast(double, r);
+}
+#ifdef GPB_DPP_VIA_BUILTIN
+#define GPB_ROW_BCAST(L, x) ::gpb::row_bcast_builtin<L>(x)
+#define GPB_ROW_FNMA(L, acc, b, own) (acc) = __builtin_fma(-::gpb::row_bcast_builtin<L>(b), (own), (acc))
+#else
+#define GPB_ROW_BCAST(L, x) ::gpb::row_bcast<L>(x)
+#define GPB_ROW_FNMA(L, acc, b, own) ::gpb::row_fnma<L>((acc), (b), (own))
+#endif
+
+// ---- fast fp64 elementary functions (relative error ~1e-15, far inside the
+// 1e-8 parity budget; no denormal/NaN special-casing beyond what is noted) ----
+
+// 1/sqrt(x), x > 0: v_rsq_f64 (~2^-26) + one Newton step.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y0, y0, 1.0);
+  return __builtin_fma(0.5 * y0, e, y0);
+}
+// sqrt(x), x >= 0 (x == 0 allowed: clamped to 1e-300 first).
+__device__ __forceinline__ double fast_sqrt(double x) {
+  x = __builtin_fmax(x, 1e-300);
+  const double y0 = __builtin_amdgcn_rsq(x);
+  double g = x * y0;            // ~sqrt(x)
+  const double h = 0.5 * y0;
+  const double e = __builtin_fma(-h, g, 0.5);
+  return __builtin_fma(g, e, g);
+}
+// 1/x: v_rcp_f64 + one Newton step.
+__device__ __forceinline__ double fast_rcp(double x) {
+  const double y0 = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y0, 1.0);
+  return __builtin_fma(y0, e, y0);
+}
+
+// exp(x) for x <= 0 (clamped at -800 -> 0).  x = (64 e + j) ln2/64 + r,
+// |r| <= ln2/128;  exp(x) = 2^e * 2^(j/64) * P5(r).  tab = 64-entry 2^(j/64) table in LDS.
+#define GPB_EXP_TAB_SIZE 64
+__device__ __forceinline__ double fast_exp_neg(double x, const double* __restrict__ tab) {
+  x = __builtin_fmax(x, -800.0);
+  const double kf = __builtin_rint(x * 92.332482616893656877);  // 64/ln2
+  double r = __builtin_fma(kf, -0.010830424696249145, x);       // ln2/64 rounded to double (fma: one rounding)
+  r = __builtin_fma(kf, -3.623510646634843e-19, r);             // ln2/64 - double(ln2/64)
+  const int k = (int)kf;
+  const double t = tab[k & 63];
+  // P5(r) = 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120   (|r|^6/720 < 4e-17)
+  double p = __builtin_fma(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  p = __builtin_fma(p, r, 1.66666666666666667e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(t * p, k >> 6);
+}
+// Fill the table (call by the first 64 threads of a block, then __syncthreads()).
+__device__ __forceinline__ void fill_exp_table(double* tab, const double* __restrict__ gtab) {
+  if (threadIdx.x < GPB_EXP_TAB_SIZE) tab[threadIdx.x] = gtab[threadIdx.x];
+}
+
+// ---- isotropic Matern kernels on the transformed scale --------------------
+// reference: include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5)
+enum CovType : int { kMatern05 = 0, kMatern15 = 1, kMatern25 = 2 };
+
+template <int COV>
+__device__ __forceinline__ double matern_cov(double dist, double var, double a, const double* tab) {
+  const double r = a * dist;
+  const double e = fast_exp_neg(-r, tab);
+  if constexpr (COV == kMatern05) return var * e;
+  else if constexpr (COV == kMatern15) return var * __builtin_fma(1.0, r, 1.0) * e;
+  else return var * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0) * e;
+}
+
+}  // namespace gpb

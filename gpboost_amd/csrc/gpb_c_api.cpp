@@ -1,0 +1,265 @@
+// gpboost_amd/csrc/gpb_c_api.cpp -- the hot-path slice of the reference C API
+// (include/gpboost_c_api_subset.h) on top of the gfx950 shim (include/gpb_hip.h).
+//
+// What lives here is exactly the host-side pre/post-processing the reference does around its
+// per-point loop, re-stated for one Gaussian Vecchia GP:
+//   ordering          src/GPBoost/Vecchia_utils.cpp:1129-1138  (std::shuffle(std::mt19937(seed)))
+//   TransformCovPars  src/GPBoost/re_model.cpp:768-778 -> include/GPBoost/cov_fcts.h:485-516
+//   nugget bound      include/GPBoost/re_model_template.h:7849-7874
+//   SetY permutation  include/GPBoost/re_model_template.h:6185-6222
+//   negll formula     include/GPBoost/re_model_template.h:3132
+//   gradient assembly include/GPBoost/re_model_template.h:1988-2011
+// All per-point arithmetic happens on the device.
+#include "../../include/gpboost_c_api_subset.h"
+#include "../../include/gpb_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_last_error[512] = "Everything is fine";   // c_api.h:1837-1849
+
+int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+int shim_error() { return set_error("%s", gpb_hip_get_last_error()); }
+
+constexpr double kMinNuggetVarRatio = 1e-10;   // re_model_template.h:5668
+
+struct REModelHip {
+  int n = 0, d = 0, m = 0;
+  int cov_type = 0;
+  std::vector<int> perm;        // data_indices_per_cluster_: Vecchia position -> data index
+  gpb_hip_vecchia_t* vh = nullptr;
+  std::vector<double> ybuf;     // y in Vecchia order
+  double cur_negll = 0.;
+  bool negll_valid = false;
+  bool has_duplicates = false;
+  bool trace = false;
+  std::string likelihood = "gaussian";
+  ~REModelHip() { if (vh) gpb_hip_vecchia_free(vh); }
+};
+
+bool near(double a, double b) { return std::fabs(a - b) < 1e-10 * std::max({1.0, std::fabs(a), std::fabs(b)}); }  // utils.h:55
+
+// (sigma2, sigma1_2, rho) -> (sigma2, sigma1_2 / sigma2, sqrt(2 nu) / rho), with the nugget lower bound
+int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr) {
+  double sigma2 = cov_pars[0];
+  const double sigma1_2 = cov_pars[1], rho = cov_pars[2];
+  if (!(sigma2 > 0.) || !(sigma1_2 > 0.) || !(rho > 0.))
+    return set_error("Covariance parameters need to be positive (found %g, %g, %g)", sigma2, sigma1_2, rho);
+  const double nugget_min = kMinNuggetVarRatio / (1. - kMinNuggetVarRatio) * sigma1_2;   // :7866
+  if (sigma2 < nugget_min) sigma2 = nugget_min;
+  tr[0] = sigma2;
+  tr[1] = sigma1_2 / sigma2;
+  const double c = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
+  tr[2] = c / rho;
+  return 0;
+}
+
+int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
+  if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
+  const int n = mdl->n;
+  mdl->ybuf.resize(n);
+  if (fixed_effects) {
+    for (int k = 0; k < n; ++k) { const int id = mdl->perm[k]; mdl->ybuf[k] = y_data[id] - fixed_effects[id]; }   // :2909-2915
+  } else {
+    for (int k = 0; k < n; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]];
+  }
+  if (gpb_hip_vecchia_set_y(mdl->vh, mdl->ybuf.data())) return shim_error();
+  return 0;
+}
+
+double negll_from_terms(int n, double yPy, double logdet, double sigma2) {
+  return yPy / 2. / sigma2 + logdet / 2. + n / 2. * (std::log(sigma2) + std::log(2 * M_PI));   // :3132
+}
+
+}  // namespace
+
+#define C_API_BEGIN() try {
+#define C_API_END()                                                         \
+  }                                                                         \
+  catch (const std::exception& ex) { return set_error("%s", ex.what()); }   \
+  catch (...) { return set_error("unknown exception"); }                    \
+  return 0;
+
+extern "C" {
+
+const char* LGBM_GetLastError() { return g_last_error; }
+
+int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const char* /*re_group_data*/,
+                      int32_t num_re_group, const double* /*re_group_rand_coef_data*/,
+                      const int32_t* /*ind_effect_group_rand_coef*/, int32_t num_re_group_rand_coef,
+                      const int* /*drop_intercept_group_rand_effect*/, int32_t num_gp, const double* gp_coords_data,
+                      const int dim_gp_coords, const double* /*gp_rand_coef_data*/, int32_t num_gp_rand_coef,
+                      const char* cov_fct, double cov_fct_shape, const char* gp_approx, double /*cov_fct_taper_range*/,
+                      double /*cov_fct_taper_shape*/, int num_neighbors, const char* vecchia_ordering,
+                      int /*num_ind_points*/, double /*cover_tree_radius*/, const char* /*ind_points_selection*/,
+                      const char* likelihood, double /*likelihood_additional_param*/,
+                      const char* /*matrix_inversion_method*/, int seed, int /*num_parallel_threads*/, bool /*GPU_use*/,
+                      bool has_weights, const double* /*weights*/, double /*likelihood_learning_rate*/,
+                      REModelHandle* out) {
+  C_API_BEGIN();
+  if (!out) return set_error("GPB_CreateREModel: out is NULL");
+  *out = nullptr;
+  const char* scope = "is not on the MI355X hot path of this library (one Gaussian Vecchia GP; see include/gpboost_c_api_subset.h)";
+  if (num_re_group > 0 || num_re_group_rand_coef > 0) return set_error("GPB_CreateREModel: grouped random effects %s", scope);
+  if (num_gp != 1 || num_gp_rand_coef > 0) return set_error("GPB_CreateREModel: num_gp = %d / num_gp_rand_coef = %d %s", num_gp, num_gp_rand_coef, scope);
+  if (cluster_ids_data) {
+    for (int i = 1; i < num_data; ++i)
+      if (cluster_ids_data[i] != cluster_ids_data[0]) return set_error("GPB_CreateREModel: more than one cluster %s", scope);
+  }
+  if (has_weights) return set_error("GPB_CreateREModel: sample weights %s", scope);
+  if (!gp_coords_data) return set_error("GPB_CreateREModel: gp_coords_data is NULL");
+  const std::string cov = cov_fct ? cov_fct : "";
+  const std::string approx = gp_approx ? gp_approx : "";
+  const std::string ordering = vecchia_ordering ? vecchia_ordering : "";
+  const std::string lik = likelihood ? likelihood : "";
+  int cov_type = -1;
+  if (cov == "exponential") cov_type = 0;
+  else if (cov == "matern") {
+    if (near(cov_fct_shape, 0.5)) cov_type = 0;
+    else if (near(cov_fct_shape, 1.5)) cov_type = 1;
+    else if (near(cov_fct_shape, 2.5)) cov_type = 2;
+  }
+  if (cov_type < 0) return set_error("GPB_CreateREModel: cov_fct '%s' (shape %g) %s", cov.c_str(), cov_fct_shape, scope);
+  if (approx != "vecchia") return set_error("GPB_CreateREModel: gp_approx '%s' %s", approx.c_str(), scope);
+  if (lik != "gaussian") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
+  if (num_data < 2) return set_error("GPB_CreateREModel: num_data = %d", num_data);
+  if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
+
+  auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type;
+  mdl->perm.resize(num_data);
+  std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
+  if (ordering == "random") {
+    std::mt19937 rng(seed);                                        // re_model_template.h:161, type_defs.h:52
+    std::shuffle(mdl->perm.begin(), mdl->perm.end(), rng);         // Vecchia_utils.cpp:1129-1131
+  }
+  std::vector<double> coords((size_t)num_data * dim_gp_coords);
+  for (int j = 0; j < dim_gp_coords; ++j)                          // Vecchia_utils.cpp:1132-1138
+    for (int k = 0; k < num_data; ++k) coords[(size_t)j * num_data + k] = gp_coords_data[(size_t)j * num_data + mdl->perm[k]];
+  if (gpb_hip_vecchia_create(num_data, dim_gp_coords, num_neighbors, coords.data(), &mdl->vh)) return shim_error();
+  int dup = 0;
+  if (gpb_hip_vecchia_find_neighbors(mdl->vh, &dup)) return shim_error();
+  mdl->has_duplicates = dup != 0;
+  mdl->m = std::min(num_neighbors, num_data - 1);
+  *out = mdl.release();
+  C_API_END();
+}
+
+int GPB_REModelFree(REModelHandle handle) {
+  C_API_BEGIN();
+  delete reinterpret_cast<REModelHip*>(handle);
+  C_API_END();
+}
+
+int GPB_SetOptimConfig(REModelHandle handle, double*, double, double, int, double, bool, int, bool trace, const char*, int,
+                       const char*, int num_covariates, double*, double, double, const char*, int, int, double, int, bool,
+                       const char*, int, int, double*, bool, bool, const int*, int, double) {
+  C_API_BEGIN();
+  if (!handle) return set_error("GPB_SetOptimConfig: null handle");
+  if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
+  reinterpret_cast<REModelHip*>(handle)->trace = trace;
+  C_API_END();
+}
+
+int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double* cov_pars, const double* fixed_effects,
+                             double* negll) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
+  if (!cov_pars) return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (initial-value heuristics live in the reference's optimiser, not on the hot path)");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (upload_y(mdl, y_data, fixed_effects)) return -1;
+  double t3[3];
+  if (gpb_hip_vecchia_nll_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], 1, t3)) return shim_error();
+  mdl->cur_negll = negll_from_terms(mdl->n, t3[0], t3[1], tr[0]);
+  mdl->negll_valid = true;
+  *negll = mdl->cur_negll;
+  C_API_END();
+}
+
+int GPB_GetCurrentNegLogLikelihood(REModelHandle handle, double* negll) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !negll) return set_error("GPB_GetCurrentNegLogLikelihood: null argument");
+  if (!mdl->negll_valid) return set_error("The negative log-likelihood has not been evaluated yet");
+  *negll = mdl->cur_negll;
+  C_API_END();
+}
+
+int GPB_GetLikelihoodName(REModelHandle handle, char* out_str, int* num_char) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !out_str || !num_char) return set_error("GPB_GetLikelihoodName: null argument");
+  *num_char = (int)mdl->likelihood.size() + 1;   // c_api.cpp: size + 1, then memcpy incl. terminator
+  std::memcpy(out_str, mdl->likelihood.c_str(), mdl->likelihood.size() + 1);
+  C_API_END();
+}
+
+int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_data, double* cov_pars,
+                                        const double* fixed_effects, double* negll, double* grad3) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !negll || !grad3 || !cov_pars) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: null argument");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (upload_y(mdl, y_data, fixed_effects)) return -1;
+  double t7[7];
+  if (gpb_hip_vecchia_grad_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], t7)) return shim_error();
+  mdl->cur_negll = negll_from_terms(mdl->n, t7[0], t7[1], tr[0]);
+  mdl->negll_valid = true;
+  *negll = mdl->cur_negll;
+  grad3[0] = -1. * t7[0] / tr[0] / 2. + mdl->n / 2.;   // re_model_template.h:1994
+  grad3[1] = t7[3] / tr[0] + t7[4];                    // :2004
+  grad3[2] = t7[5] / tr[0] + t7[6];
+  C_API_END();
+}
+
+int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_pars, double* y_aux) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !y_aux || !cov_pars) return set_error("GPB_HIP_CalcYAux: null argument");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (upload_y(mdl, y_data, nullptr)) return -1;
+  if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
+  std::vector<double> ya(mdl->n);
+  if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
+  for (int k = 0; k < mdl->n; ++k) y_aux[mdl->perm[k]] = ya[k];   // back to data order (GetYAux, :6430)
+  C_API_END();
+}
+
+int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_HIP_GetVecchiaStructure: null handle");
+  if (perm) std::copy(mdl->perm.begin(), mdl->perm.end(), perm);
+  if (m_out) *m_out = mdl->m;
+  if (nn && gpb_hip_vecchia_get_neighbors(mdl->vh, nn)) return shim_error();
+  C_API_END();
+}
+
+void* GPB_HIP_GetVecchiaHandle(REModelHandle handle) {
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  return mdl ? mdl->vh : nullptr;
+}
+
+}  // extern "C"

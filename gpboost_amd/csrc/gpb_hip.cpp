@@ -1,0 +1,598 @@
+// gpboost_amd/csrc/gpb_hip.cpp -- host side of the C ABI declared in include/gpb_hip.h.
+//
+// Owns device memory, streams and launch sequencing for the gfx950 kernels; contains no
+// numerical code of its own except the libstdc++-dependent argsort the reference performs on
+// the host as well (include/GPBoost/utils.h:230-238).  There is deliberately no CPU fallback:
+// without a gfx950 device every entry point fails with a message.
+#include "../../include/gpb_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "hist_kernels.h"
+#include "nn_kernels.h"
+#include "vecchia_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "everything is fine";
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+#define HIP_OK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define API_BEGIN() try {
+#define API_END()                                                        \
+  }                                                                      \
+  catch (const std::exception& ex) { return fail("%s", ex.what()); }     \
+  catch (...) { return fail("unknown exception"); }                      \
+  return 0;
+
+template <class T>
+void dev_free(T*& p) {
+  if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+int check_device() {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    return fail("no HIP device available (%s): the gfx950 hot path has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  return 0;
+}
+
+std::vector<double> exp_table() {
+  std::vector<double> t(64);
+  for (int j = 0; j < 64; ++j) t[j] = std::exp2((double)j / 64.0);
+  return t;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+struct gpb_hip_vecchia {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = true;
+  int n = 0, d = 0, m = 0;
+  int i_begin = 0, i_end = 0;
+  double4* d_pts = nullptr;
+  int* d_nn = nullptr;
+  double* d_exp_tab = nullptr;
+  double* d_partials = nullptr;
+  double* d_out = nullptr;   // GPB_NUM_PARTIALS + 1
+  double* h_out = nullptr;   // pinned
+  double* d_A = nullptr; double* d_D = nullptr; double* d_u = nullptr; double* d_v = nullptr; double* d_w = nullptr;
+  double* d_ystage = nullptr;
+  int* d_tptr = nullptr; int* d_tpos = nullptr;
+  int* d_flag = nullptr;
+  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false;
+  std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
+  std::vector<int> nn_host;
+};
+
+struct gpb_hip_hist {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n = 0, F = 0, fpad = 0, total_bins = 0;
+  uint8_t* d_bins_rm = nullptr;
+  int* d_bin_offsets = nullptr;
+  double* d_grad = nullptr; double* d_hess = nullptr;
+  bool has_hess = false, has_grad = false;
+  int* d_idx = nullptr; int idx_cap = 0;
+  double* d_part_grad = nullptr; double* d_part_hess = nullptr; uint32_t* d_part_cnt = nullptr; int part_chunks = 0;
+  double* d_hist = nullptr; unsigned long long* d_cnt = nullptr;
+};
+
+extern "C" {
+
+const char* gpb_hip_get_last_error(void) { return g_err; }
+
+int gpb_hip_device_count(int* count) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess) { cnt = 0; (void)hipGetLastError(); }
+  *count = cnt;
+  return 0;
+}
+
+int gpb_hip_set_device(int device) {
+  API_BEGIN();
+  if (check_device()) return -1;
+  HIP_OK(hipSetDevice(device));
+  API_END();
+}
+
+int gpb_hip_device_is_gfx950(int* yes) {
+  API_BEGIN();
+  if (check_device()) return -1;
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, dev));
+  *yes = (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+  API_END();
+}
+
+int gpb_hip_selftest(void) {
+  API_BEGIN();
+  if (check_device()) return -1;
+  std::vector<double> in(192), out(256);
+  for (int t = 0; t < 192; ++t) in[t] = std::sin(0.37 * t) + 1.5;
+  double *d_in = nullptr, *d_out = nullptr;
+  HIP_OK(hipMalloc(&d_in, 192 * sizeof(double)));
+  HIP_OK(hipMalloc(&d_out, 256 * sizeof(double)));
+  HIP_OK(hipMemcpy(d_in, in.data(), 192 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_OK(gpb::launch_dpp_selftest(d_in, d_out, nullptr));
+  HIP_OK(hipMemcpy(out.data(), d_out, 256 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  for (int t = 0; t < 64; ++t) {
+    const int row = t & ~15;
+    const double eb = in[row + 5], ef = in[128 + t] - in[row + 11] * in[64 + t];
+    if (out[4 * t] != eb || out[4 * t + 1] != eb)
+      return fail("fp64 DPP row_newbcast self-test failed at lane %d: asm %.17g builtin %.17g expected %.17g", t, out[4 * t], out[4 * t + 1], eb);
+    if (out[4 * t + 2] != out[4 * t + 3] || std::fabs(out[4 * t + 2] - ef) > 1e-15 * std::fabs(ef) + 1e-300)
+      return fail("fp64 DPP fmac self-test failed at lane %d: asm %.17g builtin %.17g expected %.17g", t, out[4 * t + 2], out[4 * t + 3], ef);
+  }
+  API_END();
+}
+
+// ------------------------------------------------------------------------------------------
+int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const double* coords_colmajor,
+                           gpb_hip_vecchia_t** out) {
+  API_BEGIN();
+  if (!out) return fail("gpb_hip_vecchia_create: out is NULL");
+  *out = nullptr;
+  if (check_device()) return -1;
+  if (n < 1) return fail("gpb_hip_vecchia_create: n = %d", n);
+  if (d < 1 || d > 3) return fail("gpb_hip_vecchia_create: coordinate dimension %d not supported by the HIP hot path (1..3)", d);
+  if (!coords_colmajor) return fail("gpb_hip_vecchia_create: coords is NULL");
+  int m = num_neighbors;
+  if (m > n - 1) m = n - 1;   // Vecchia_utils.cpp:755-758
+  if (m < 0) m = 0;
+  if (num_neighbors < 1 && n > 1) return fail("gpb_hip_vecchia_create: num_neighbors = %d", num_neighbors);
+  if (m > GPB_MAX_NEIGHBORS) return fail("gpb_hip_vecchia_create: num_neighbors = %d exceeds the supported maximum %d", m, GPB_MAX_NEIGHBORS);
+  auto* h = new gpb_hip_vecchia();
+  h->n = n; h->d = d; h->m = m < 1 ? 1 : m;   // n == 1: one (empty, -1) column keeps indexing uniform
+  h->i_begin = 0; h->i_end = n;
+  h->coords.assign(coords_colmajor, coords_colmajor + (size_t)n * d);
+  HIP_OK(hipGetDevice(&h->device));
+  HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  std::vector<double4> pts(n);
+  for (int i = 0; i < n; ++i) {
+    pts[i].x = coords_colmajor[i];
+    pts[i].y = d > 1 ? coords_colmajor[(size_t)n + i] : 0.0;
+    pts[i].z = d > 2 ? coords_colmajor[(size_t)2 * n + i] : 0.0;
+    pts[i].w = 0.0;
+  }
+  HIP_OK(hipMalloc(&h->d_pts, sizeof(double4) * (size_t)n));
+  HIP_OK(hipMemcpy(h->d_pts, pts.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_nn, sizeof(int) * (size_t)n * h->m));
+  const std::vector<double> tab = exp_table();
+  HIP_OK(hipMalloc(&h->d_exp_tab, 64 * sizeof(double)));
+  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+  const int nblocks = (n + 15) / 16;
+  HIP_OK(hipMalloc(&h->d_partials, sizeof(double) * (size_t)nblocks * GPB_NUM_PARTIALS));
+  HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 8));
+  HIP_OK(hipHostMalloc(&h->h_out, sizeof(double) * 8));
+  HIP_OK(hipMalloc(&h->d_flag, sizeof(int)));
+  *out = h;
+  API_END();
+}
+
+int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
+  API_BEGIN();
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream || !h->owns_stream) { (void)hipStreamSynchronize(h->stream); if (h->owns_stream) (void)hipStreamDestroy(h->stream); }
+  dev_free(h->d_pts); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out);
+  dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage);
+  dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  delete h;
+  API_END();
+}
+
+int gpb_hip_vecchia_set_stream(gpb_hip_vecchia_t* h, void* hip_stream) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->owns_stream = false;
+  API_END();
+}
+
+int gpb_hip_vecchia_sync(gpb_hip_vecchia_t* h) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipSetDevice(h->device));
+  const int n = h->n, d = h->d, m = h->m;
+  // coordinate sums and their argsort, on the host exactly as Vecchia_utils.cpp:774-786 does
+  std::vector<double> csum(n);
+  for (int i = 0; i < n; ++i) {
+    double s = h->coords[i];
+    for (int c = 1; c < d; ++c) s += h->coords[(size_t)c * n + i];
+    csum[i] = s;
+  }
+  std::vector<int> sort_sum(n);
+  std::iota(sort_sum.begin(), sort_sum.end(), 0);
+  const double* v = csum.data();
+  std::sort(sort_sum.begin(), sort_sum.end(), [v](int i1, int i2) { return v[i1] < v[i2]; });
+  std::vector<double4> rec(n);
+  for (int k = 0; k < n; ++k) {
+    const int i = sort_sum[k];
+    rec[k].x = h->coords[i];
+    rec[k].y = d > 1 ? h->coords[(size_t)n + i] : 0.0;
+    rec[k].z = d > 2 ? h->coords[(size_t)2 * n + i] : 0.0;
+    rec[k].w = csum[i];
+  }
+  double4* d_rec = nullptr; int* d_idx = nullptr;
+  HIP_OK(hipMalloc(&d_rec, sizeof(double4) * (size_t)n));
+  HIP_OK(hipMalloc(&d_idx, sizeof(int) * (size_t)n));
+  HIP_OK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(d_idx, sort_sum.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+  gpb::NNKernelArgs a;
+  a.sorted_rec = d_rec; a.sorted_idx = d_idx; a.pts = h->d_pts; a.nn = h->d_nn; a.has_duplicates = h->d_flag; a.n = n; a.m = m;
+  if (n == 1) {
+    HIP_OK(hipMemsetAsync(h->d_nn, 0xff, sizeof(int) * (size_t)n * m, h->stream));
+  } else {
+    HIP_OK(gpb::launch_vecchia_nn(d, a, h->stream));
+  }
+  int flag = 0;
+  HIP_OK(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_rec); (void)hipFree(d_idx);
+  if (has_duplicates) *has_duplicates = flag;
+  h->has_nn = true; h->has_transpose = false; h->has_factor = false; h->nn_host.clear();
+  API_END();
+}
+
+int gpb_hip_vecchia_set_neighbors(gpb_hip_vecchia_t* h, const int32_t* nn) {
+  API_BEGIN();
+  if (!h || !nn) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  const size_t cnt = (size_t)h->n * h->m;
+  for (size_t t = 0; t < cnt; ++t) {
+    const int i = (int)(t / h->m);
+    if (nn[t] >= i || nn[t] < -1) return fail("gpb_hip_vecchia_set_neighbors: row %d has neighbour %d (must be < row index)", i, nn[t]);
+  }
+  HIP_OK(hipMemcpyAsync(h->d_nn, nn, sizeof(int) * cnt, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->nn_host.assign(nn, nn + cnt);
+  h->has_nn = true; h->has_transpose = false; h->has_factor = false;
+  API_END();
+}
+
+int gpb_hip_vecchia_get_neighbors(gpb_hip_vecchia_t* h, int32_t* nn) {
+  API_BEGIN();
+  if (!h || !nn) return fail("null argument");
+  if (!h->has_nn) return fail("neighbours have not been determined");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpyAsync(nn, h->d_nn, sizeof(int) * (size_t)h->n * h->m, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_begin, int32_t i_end) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (i_begin < 0 || i_end > h->n || i_begin >= i_end) return fail("gpb_hip_vecchia_set_shard: invalid range [%d, %d) for n = %d", i_begin, i_end, h->n);
+  h->i_begin = i_begin; h->i_end = i_end;
+  h->has_factor = false;
+  API_END();
+}
+
+int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev) {
+  API_BEGIN();
+  if (!h || !y_dev) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(gpb::launch_pack_y(h->d_pts, y_dev, h->n, h->stream));
+  h->has_y = true; h->has_factor = false;
+  API_END();
+}
+
+int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) {
+  API_BEGIN();
+  if (!h || !y_host) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->d_ystage) HIP_OK(hipMalloc(&h->d_ystage, sizeof(double) * (size_t)h->n));
+  HIP_OK(hipMemcpyAsync(h->d_ystage, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(gpb::launch_pack_y(h->d_pts, h->d_ystage, h->n, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));   // y_host is borrowed for the call only
+  h->has_y = true; h->has_factor = false;
+  API_END();
+}
+
+static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss, double* out_dev,
+                          int nout, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  if (!h) return fail("null handle");
+  if (!h->has_nn) return fail("neighbours have not been determined (call gpb_hip_vecchia_find_neighbors / _set_neighbors)");
+  if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
+  if (cov_type < 0 || cov_type > 2) return fail("covariance type %d is not on the HIP hot path (Matern 0.5/1.5/2.5 only)", cov_type);
+  if (!(var > 0.) || !(a > 0.)) return fail("covariance parameters must be positive (var = %g, range = %g)", var, a);
+  HIP_OK(hipSetDevice(h->device));
+  gpb::VecchiaKernelArgs k;
+  k.pts = h->d_pts; k.nn = h->d_nn; k.exp_tab = h->d_exp_tab; k.partials = h->d_partials;
+  k.A = h->d_A; k.D = h->d_D; k.u = h->d_u;
+  k.m = h->m; k.i_begin = h->i_begin; k.i_end = h->i_end;
+  k.var = var; k.a = a;
+  k.diag_nn = gauss ? var + 1.0 : var * (1.0 + 1e-10);   // Vecchia_utils.cpp:1599-1609
+  k.diag_i = gauss ? var + 1.0 : var;                    // :1410-1417 + :1555-1563
+  k.nugget = gauss ? 1.0 : 0.0;
+  if (ev0) HIP_OK(hipEventRecord(ev0, h->stream));
+  HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
+  if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
+  const int nblocks = (h->i_end - h->i_begin + 15) / 16;
+  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, h->d_out, h->stream));
+  if (out_dev) {
+    // reorder to the documented layout {quad, logdet, bad, ...}
+    // d_out = {logdet, quad, bad, g1v, g2v, g1r, g2r}
+    HIP_OK(hipMemcpyAsync(out_dev, h->d_out + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(out_dev + 1, h->d_out, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (nout > 2) HIP_OK(hipMemcpyAsync(out_dev + 2, h->d_out + 2, sizeof(double) * (nout - 2), hipMemcpyDeviceToDevice, h->stream));
+  }
+  return 0;
+}
+
+static int vecchia_fetch(gpb_hip_vecchia_t* h, double* out_host, int nout) {
+  HIP_OK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * GPB_NUM_PARTIALS, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  out_host[0] = h->h_out[gpb::GPB_P_QUAD];
+  out_host[1] = h->h_out[gpb::GPB_P_LOGDET];
+  for (int t = 2; t < nout; ++t) out_host[t] = h->h_out[t];
+  return 0;
+}
+
+int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int gauss_likelihood,
+                              double* out3_host) {
+  API_BEGIN();
+  if (!out3_host) return fail("null output");
+  if (vecchia_launch(h, gpb::MODE_NLL, cov_type, var, a, gauss_likelihood, nullptr, 0)) return -1;
+  if (vecchia_fetch(h, out3_host, 3)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_nll_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int gauss_likelihood,
+                                  double* out3_dev) {
+  API_BEGIN();
+  if (!out3_dev) return fail("null output");
+  if (vecchia_launch(h, gpb::MODE_NLL, cov_type, var, a, gauss_likelihood, out3_dev, 3)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a, double* out7_host) {
+  API_BEGIN();
+  if (!out7_host) return fail("null output");
+  if (vecchia_launch(h, gpb::MODE_GRAD, cov_type, var, a, 1, nullptr, 0)) return -1;
+  if (vecchia_fetch(h, out7_host, 7)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_grad_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a, double* out7_dev) {
+  API_BEGIN();
+  if (!out7_dev) return fail("null output");
+  if (vecchia_launch(h, gpb::MODE_GRAD, cov_type, var, a, 1, out7_dev, 7)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_bench(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int warmup, int steps,
+                          double* ms_total, double* ms_point_kernel_avg, double* out7_host) {
+  API_BEGIN();
+  if (!h || !ms_total || !ms_point_kernel_avg) return fail("null argument");
+  if (mode != gpb::MODE_NLL && mode != gpb::MODE_GRAD) return fail("gpb_hip_vecchia_bench: mode must be 0 (nll) or 2 (grad)");
+  if (steps < 1 || steps > 100000) return fail("gpb_hip_vecchia_bench: steps = %d", steps);
+  HIP_OK(hipSetDevice(h->device));
+  for (int w = 0; w < warmup; ++w)
+    if (vecchia_launch(h, mode, cov_type, var * (1. + 1e-3 * (w + 1)), a, 1, nullptr, 0)) return -1;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  std::vector<hipEvent_t> e0(steps), e1(steps);
+  hipEvent_t t0, t1;
+  HIP_OK(hipEventCreate(&t0)); HIP_OK(hipEventCreate(&t1));
+  for (int s = 0; s < steps; ++s) { HIP_OK(hipEventCreate(&e0[s])); HIP_OK(hipEventCreate(&e1[s])); }
+  HIP_OK(hipEventRecord(t0, h->stream));
+  for (int s = 0; s < steps; ++s)   // parameters change every step: nothing can be cached between evaluations
+    if (vecchia_launch(h, mode, cov_type, var * (1. + 1e-3 * (s + 1)), a * (1. - 1e-3 * (s % 7)), 1, nullptr, 0, e0[s], e1[s])) return -1;
+  HIP_OK(hipEventRecord(t1, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+  *ms_total = ms;
+  double acc = 0.;
+  for (int s = 0; s < steps; ++s) { HIP_OK(hipEventElapsedTime(&ms, e0[s], e1[s])); acc += ms; }
+  *ms_point_kernel_avg = acc / steps;
+  for (int s = 0; s < steps; ++s) { (void)hipEventDestroy(e0[s]); (void)hipEventDestroy(e1[s]); }
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+  if (out7_host && vecchia_fetch(h, out7_host, 7)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int gauss_likelihood) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->d_A) {
+    HIP_OK(hipMalloc(&h->d_A, sizeof(double) * (size_t)h->n * h->m));
+    HIP_OK(hipMalloc(&h->d_D, sizeof(double) * (size_t)h->n));
+    HIP_OK(hipMalloc(&h->d_u, sizeof(double) * (size_t)h->n));
+  }
+  if (vecchia_launch(h, gpb::MODE_FACTOR, cov_type, var, a, gauss_likelihood, nullptr, 0)) return -1;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->has_factor = true;
+  API_END();
+}
+
+int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_host, double* D_host, double* u_host) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (!h->has_factor) return fail("the factor has not been computed (call gpb_hip_vecchia_factor)");
+  HIP_OK(hipSetDevice(h->device));
+  if (A_host) HIP_OK(hipMemcpyAsync(A_host, h->d_A, sizeof(double) * (size_t)h->n * h->m, hipMemcpyDeviceToHost, h->stream));
+  if (D_host) HIP_OK(hipMemcpyAsync(D_host, h->d_D, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  if (u_host) HIP_OK(hipMemcpyAsync(u_host, h->d_u, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+// Transposed neighbour index (columns of B): built once per neighbour table, on the host (counting sort).
+static int build_transpose(gpb_hip_vecchia_t* h) {
+  const int n = h->n, m = h->m;
+  if (h->nn_host.empty()) {
+    h->nn_host.resize((size_t)n * m);
+    HIP_OK(hipMemcpyAsync(h->nn_host.data(), h->d_nn, sizeof(int) * (size_t)n * m, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+  }
+  std::vector<int> ptr(n + 1, 0);
+  for (size_t e = 0; e < (size_t)n * m; ++e) if (h->nn_host[e] >= 0) ptr[h->nn_host[e] + 1]++;
+  for (int j = 0; j < n; ++j) ptr[j + 1] += ptr[j];
+  std::vector<int> pos(ptr[n] > 0 ? ptr[n] : 1), fill(ptr.begin(), ptr.end() - 1);
+  for (size_t e = 0; e < (size_t)n * m; ++e) if (h->nn_host[e] >= 0) pos[fill[h->nn_host[e]]++] = (int)e;
+  dev_free(h->d_tptr); dev_free(h->d_tpos);
+  HIP_OK(hipMalloc(&h->d_tptr, sizeof(int) * (size_t)(n + 1)));
+  HIP_OK(hipMalloc(&h->d_tpos, sizeof(int) * pos.size()));
+  HIP_OK(hipMemcpy(h->d_tptr, ptr.data(), sizeof(int) * (size_t)(n + 1), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->d_tpos, pos.data(), sizeof(int) * pos.size(), hipMemcpyHostToDevice));
+  h->has_transpose = true;
+  return 0;
+}
+
+int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) {
+  API_BEGIN();
+  if (!h || !yaux_host) return fail("null argument");
+  if (!h->has_factor) return fail("the factor has not been computed (call gpb_hip_vecchia_factor)");
+  if (h->i_begin != 0 || h->i_end != h->n) return fail("gpb_hip_vecchia_yaux needs the full factor on this device (shard is [%d,%d))", h->i_begin, h->i_end);
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->has_transpose && build_transpose(h)) return -1;
+  if (!h->d_v) { HIP_OK(hipMalloc(&h->d_v, sizeof(double) * (size_t)h->n)); HIP_OK(hipMalloc(&h->d_w, sizeof(double) * (size_t)h->n)); }
+  HIP_OK(gpb::launch_scale_by_Dinv(h->d_u, h->d_D, h->n, h->d_v, h->stream));
+  HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->d_v, h->d_w, h->stream));
+  HIP_OK(hipMemcpyAsync(yaux_host, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+// ------------------------------------------------------------------------------------------
+int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins, const int32_t* bin_offsets,
+                        gpb_hip_hist_t** out) {
+  API_BEGIN();
+  if (!out) return fail("gpb_hip_hist_create: out is NULL");
+  *out = nullptr;
+  if (check_device()) return -1;
+  if (n < 1 || num_features < 1 || !bins || !bin_offsets) return fail("gpb_hip_hist_create: invalid arguments");
+  for (int f = 0; f < num_features; ++f) {
+    const int nb = bin_offsets[f + 1] - bin_offsets[f];
+    if (nb < 1 || nb > GPB_HIST_MAX_BIN) return fail("gpb_hip_hist_create: feature %d has %d bins (1..256 supported)", f, nb);
+  }
+  auto* h = new gpb_hip_hist();
+  h->n = n; h->F = num_features; h->fpad = ((num_features + 15) / 16) * 16; h->total_bins = bin_offsets[num_features];
+  HIP_OK(hipGetDevice(&h->device));
+  HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  uint8_t* d_fm = nullptr;
+  HIP_OK(hipMalloc(&d_fm, (size_t)n * num_features));
+  HIP_OK(hipMemcpy(d_fm, bins, (size_t)n * num_features, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_bins_rm, (size_t)n * h->fpad));
+  HIP_OK(gpb::launch_bins_transpose(d_fm, h->d_bins_rm, n, num_features, h->fpad, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_fm);
+  HIP_OK(hipMalloc(&h->d_bin_offsets, sizeof(int) * (size_t)(num_features + 1)));
+  HIP_OK(hipMemcpy(h->d_bin_offsets, bin_offsets, sizeof(int) * (size_t)(num_features + 1), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_grad, sizeof(double) * (size_t)n));
+  HIP_OK(hipMalloc(&h->d_hess, sizeof(double) * (size_t)n));
+  HIP_OK(hipMalloc(&h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins));
+  HIP_OK(hipMalloc(&h->d_cnt, sizeof(unsigned long long) * (size_t)h->total_bins));
+  *out = h;
+  API_END();
+}
+
+int gpb_hip_hist_free(gpb_hip_hist_t* h) {
+  API_BEGIN();
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
+  dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
+  delete h;
+  API_END();
+}
+
+int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const double* hess) {
+  API_BEGIN();
+  if (!h || !grad) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpyAsync(h->d_grad, grad, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  if (hess) HIP_OK(hipMemcpyAsync(h->d_hess, hess, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->has_hess = hess != nullptr; h->has_grad = true;
+  API_END();
+}
+
+int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
+                       double* hist_out, uint64_t* cnt_out) {
+  API_BEGIN();
+  if (!h || !hist_out) return fail("null argument");
+  if (!h->has_grad) return fail("gradients have not been set (call gpb_hip_hist_set_gradients)");
+  if (!data_indices) num_data = h->n;
+  if (num_data < 0 || num_data > h->n) return fail("gpb_hip_hist_build: num_data = %d", num_data);
+  HIP_OK(hipSetDevice(h->device));
+  if (data_indices) {
+    if (h->idx_cap < num_data) { dev_free(h->d_idx); HIP_OK(hipMalloc(&h->d_idx, sizeof(int) * (size_t)h->n)); h->idx_cap = h->n; }
+    HIP_OK(hipMemcpyAsync(h->d_idx, data_indices, sizeof(int) * (size_t)num_data, hipMemcpyHostToDevice, h->stream));
+  }
+  // chunking: enough workgroups to fill 256 CUs, at least 1024 rows per chunk
+  const int groups = h->fpad / GPB_HIST_FG;
+  int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, 2048 / groups)));
+  const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
+  if (rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
+  if (nchunks < 1) nchunks = 1;
+  if (h->part_chunks < nchunks) {
+    dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt);
+    const size_t cnt = (size_t)nchunks * h->fpad * GPB_HIST_MAX_BIN;
+    HIP_OK(hipMalloc(&h->d_part_grad, sizeof(double) * cnt));
+    HIP_OK(hipMalloc(&h->d_part_hess, sizeof(double) * cnt));
+    HIP_OK(hipMalloc(&h->d_part_cnt, sizeof(uint32_t) * cnt));
+    h->part_chunks = nchunks;
+  }
+  gpb::HistKernelArgs a;
+  a.bins_rm = h->d_bins_rm; a.data_indices = data_indices ? h->d_idx : nullptr; a.grad = h->d_grad;
+  a.hess = h->has_hess ? h->d_hess : nullptr;
+  a.part_grad = h->d_part_grad; a.part_hess = h->d_part_hess; a.part_cnt = h->d_part_cnt;
+  a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks;
+  HIP_OK(gpb::launch_hist_build(a, h->stream));
+  gpb::HistReduceArgs r;
+  r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
+  r.hist_out = h->d_hist; r.cnt_out = h->d_cnt; r.fpad = h->fpad; r.nchunks = nchunks; r.num_features = h->F;
+  r.const_hess = const_hess; r.has_hess = h->has_hess ? 1 : 0;
+  HIP_OK(gpb::launch_hist_reduce(r, h->stream));
+  HIP_OK(hipMemcpyAsync(hist_out, h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  if (cnt_out) HIP_OK(hipMemcpyAsync(cnt_out, h->d_cnt, sizeof(unsigned long long) * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// gpboost_amd/csrc/hist_kernels.h -- launch interface of hist_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpb {
+
+#define GPB_HIST_FG 16          // features per workgroup (one per lane of a 16-lane row)
+#define GPB_HIST_MAX_BIN 256    // uint8 bins
+
+struct HistKernelArgs {
+  const uint8_t* bins_rm;   // [n][fpad] row-major bins, fpad = multiple of 16
+  const int* data_indices;  // leaf rows or nullptr
+  const double* grad;       // [n]
+  const double* hess;       // [n] or nullptr (constant hessian)
+  double* part_grad;        // [nchunks][fpad][256]
+  double* part_hess;        // [nchunks][fpad][256]   (non-constant hessian)
+  uint32_t* part_cnt;       // [nchunks][fpad][256]
+  int fpad, num_data, rows_per_chunk, nchunks;
+};
+
+struct HistReduceArgs {
+  const double* part_grad; const double* part_hess; const uint32_t* part_cnt;
+  const int* bin_offsets;   // [F+1]
+  double* hist_out;         // [total_bins][2]  {grad, hess}
+  unsigned long long* cnt_out;  // [total_bins]
+  int fpad, nchunks, num_features;
+  double const_hess; int has_hess;
+};
+
+hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
+hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
+hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
+
+}  // namespace gpb

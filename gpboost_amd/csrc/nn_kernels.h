@@ -1,0 +1,18 @@
+// gpboost_amd/csrc/nn_kernels.h -- launch interface of nn_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpb {
+
+struct NNKernelArgs {
+  const double4* sorted_rec;  // [n] {x0,x1,x2,coords_sum} in coordinate-sum order
+  const int* sorted_idx;      // [n] sort_sum: original index of the k-th smallest coordinate sum
+  const double4* pts;         // [n] records in Vecchia order (head rows' duplicate check)
+  int* nn;                    // [n][m] out
+  int* has_duplicates;        // out flag (atomicOr)
+  int n, m;
+};
+
+hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st);
+
+}  // namespace gpb

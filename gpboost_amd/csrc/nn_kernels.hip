@@ -1,0 +1,125 @@
+// gpboost_amd/csrc/nn_kernels.hip
+//
+// Ordered nearest-neighbour search for the Vecchia approximation on gfx950, bit-identical to
+// the reference's CPU search (src/GPBoost/Vecchia_utils.cpp:1029-1093,
+// find_nearest_neighbors_fast_internal): candidates are visited outward from the query in
+// coordinate-sum order, alternating down/up; a direction stops at the first candidate whose
+// squared sum-distance exceeds d * (current m-th smallest squared distance); a candidate replaces
+// the current worst only if strictly closer, then bubbles up with strict '<'
+// (include/GPBoost/utils.h:250-262).  Because ties and the pruning test make the result depend on
+// visiting order and on every rounding, each query is scanned sequentially by ONE lane with the
+// same fp64 operation order as the x86-64 (non-FMA) reference build: this file is compiled with
+// floating-point contraction OFF.
+//
+// MI355X mapping: queries are assigned to lanes in coordinate-sum order, so the 64 lanes of a
+// wavefront walk overlapping windows of the *sorted* record array {x0,x1,x2,sum} (32 B, one sector
+// per candidate) that stay L1/L2 resident; the per-lane top-m lists live in LDS, laid out
+// [slot][lane] so that the insertion shifts are bank-conflict free.
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "nn_kernels.h"
+
+namespace gpb {
+
+template <int D>
+__device__ __forceinline__ double sq_dist_seq(const double4& c, const double4& q) {
+  // (coords(c, :) - coords(i, :)).squaredNorm(): sequential left-to-right sum (Vecchia_utils.cpp:1064)
+  const double d0 = c.x - q.x;
+  double s = d0 * d0;
+  if constexpr (D >= 2) { const double d1 = c.y - q.y; s = s + d1 * d1; }
+  if constexpr (D >= 3) { const double d2 = c.z - q.z; s = s + d2 * d2; }
+  return s;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
+  extern __shared__ unsigned char smem[];
+  const int m = a.m;
+  double* s_sq = reinterpret_cast<double*>(smem);              // [m][64]
+  int* s_id = reinterpret_cast<int*>(smem + (size_t)m * 64 * 8);  // [m][64]
+  const int lane = threadIdx.x;
+  const int pos = blockIdx.x * 64 + lane;                      // position in coordinate-sum order
+  if (pos >= a.n) return;
+  const int i = a.sorted_idx[pos];                             // original (Vecchia-order) index of the query
+  if (i <= m) return;                                          // first m+1 points: all predecessors (:788-813)
+  const double4 q = a.sorted_rec[pos];
+  const int n = a.n;
+  const int end_search_at = n - 2;                             // :752-754
+  const double dd = (double)D;
+  for (int j = 0; j < m; ++j) s_sq[j * 64 + lane] = INFINITY;  // :1041-1043
+  double worst = INFINITY;
+  bool down = true, up = true;
+  int up_i = pos, down_i = pos;
+  auto visit = [&](int p, bool& dir) {
+    const int c = a.sorted_idx[p];
+    if (c < i && c <= end_search_at) {
+      const double4 r = a.sorted_rec[p];
+      const double ds = r.w - q.w;                             // coords_sum[c] - coords_sum[i]
+      const double smd = ds * ds;                              // std::pow(.,2)
+      if (smd > dd * worst) {
+        dir = false;
+      } else {
+        const double sed = sq_dist_seq<D>(r, q);
+        if (sed < worst) {
+          int k = m - 1;                                       // replace the worst, bubble up with strict '<'
+          while (k > 0 && sed < s_sq[(k - 1) * 64 + lane]) {
+            s_sq[k * 64 + lane] = s_sq[(k - 1) * 64 + lane];
+            s_id[k * 64 + lane] = s_id[(k - 1) * 64 + lane];
+            --k;
+          }
+          s_sq[k * 64 + lane] = sed;
+          s_id[k * 64 + lane] = c;
+          worst = s_sq[(m - 1) * 64 + lane];
+        }
+      }
+    }
+  };
+  while (up || down) {                                         // :1049-1092
+    if (down_i == 0) down = false;
+    if (up_i == n - 1) up = false;
+    if (down) { --down_i; visit(down_i, down); }
+    if (up) { ++up_i; visit(up_i, up); }
+  }
+  int* out = a.nn + (size_t)i * m;
+  bool dup = false;
+  for (int j = 0; j < m; ++j) {
+    out[j] = s_id[j * 64 + lane];
+    if (sqrt(s_sq[j * 64 + lane]) < 1e-10) dup = true;          // EPSILON_NUMBERS, :905-909
+  }
+  if (dup) atomicOr(a.has_duplicates, 1);
+}
+
+// rows 0..m: neighbours are all predecessors in index order, -1 padded (:788-813)
+__global__ void vecchia_nn_head_kernel(NNKernelArgs a, int d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.n, m = a.m;
+  const int rows = (n < m + 1) ? n : m + 1;
+  if (t >= rows * m) return;
+  const int i = t / m, j = t % m;
+  a.nn[(size_t)i * m + j] = (j < i) ? j : -1;
+  if (j < i) {                                                  // duplicate check of :799-811
+    const double4 p = a.pts[j], q = a.pts[i];
+    double s = (p.x - q.x) * (p.x - q.x);
+    if (d >= 2) s = s + (p.y - q.y) * (p.y - q.y);
+    if (d >= 3) s = s + (p.z - q.z) * (p.z - q.z);
+    if (sqrt(s) < 1e-10) atomicOr(a.has_duplicates, 1);
+  }
+}
+
+hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st) {
+  const int m = a.m;
+  hipLaunchKernelGGL(vecchia_nn_head_kernel, dim3(((m + 1) * m + 255) / 256), dim3(256), 0, st, a, d);
+  if (a.n <= m + 1) return hipGetLastError();
+  const size_t shmem = (size_t)m * 64 * 12;
+  const int nblocks = (a.n + 63) / 64;
+  switch (d) {
+    case 1: hipLaunchKernelGGL(vecchia_nn_kernel<1>, dim3(nblocks), dim3(64), shmem, st, a); break;
+    case 2: hipLaunchKernelGGL(vecchia_nn_kernel<2>, dim3(nblocks), dim3(64), shmem, st, a); break;
+    case 3: hipLaunchKernelGGL(vecchia_nn_kernel<3>, dim3(nblocks), dim3(64), shmem, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gpb

@@ -1,0 +1,55 @@
+// gpboost_amd/csrc/vecchia_kernels.h -- host-visible launch interface of vecchia_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpb {
+
+enum : int { MODE_NLL = 0, MODE_FACTOR = 1, MODE_GRAD = 2 };
+
+// per-workgroup partial sums (fixed layout, reduced by reduce_partials_kernel)
+enum : int {
+  GPB_P_LOGDET = 0,   // sum log D_i
+  GPB_P_QUAD = 1,     // sum u_i^2 / D_i
+  GPB_P_BAD = 2,      // #(D_i <= 0)
+  GPB_P_G1_VAR = 3,   // sum (dB_var y)_i u'_i - 0.5 u'_i^2 dD_var,i
+  GPB_P_G2_VAR = 4,   // sum 0.5 dD_var,i / D_i
+  GPB_P_G1_RNG = 5,
+  GPB_P_G2_RNG = 6,
+};
+#define GPB_NUM_PARTIALS 7
+
+// Padded neighbour counts the kernels are instantiated for (m is rounded up to the next one).
+#ifndef GPB_MT_LIST
+#define GPB_MT_LIST 10, 20, 30, 40, 50, 62
+#define GPB_MT_CASES GPB_CASE(10) GPB_CASE(20) GPB_CASE(30) GPB_CASE(40) GPB_CASE(50) GPB_CASE(62)
+#endif
+#define GPB_MAX_NEIGHBORS 62
+
+struct VecchiaKernelArgs {
+  const double4* pts;      // [n] {x0, x1, x2, y} in Vecchia order
+  const int* nn;           // [n][m] neighbour indices, -1 padded
+  const double* exp_tab;   // [64] 2^(j/64)
+  double* partials;        // [nblocks][GPB_NUM_PARTIALS]
+  double* A;               // MODE_FACTOR: [n][m]
+  double* D;               // MODE_FACTOR: [n]
+  double* u;               // MODE_FACTOR: [n]  (B y)
+  int m;                   // actual number of neighbours per row
+  int i_begin, i_end;      // points [i_begin, i_end) of the ordering handled by this launch (shard)
+  double var;              // sigma1^2 / sigma^2
+  double a;                // transformed range
+  double diag_nn;          // diagonal of C_nn:   Gaussian var + 1;          else var * (1 + 1e-10)
+  double diag_i;           // first summand of D: Gaussian var + 1;          else var
+  double nugget;           // Gaussian 1, else 0
+};
+
+int vecchia_padded_m(int m);
+hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t st);
+hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
+hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
+hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, const double* v, double* w,
+                     hipStream_t st);
+hipError_t launch_scale_by_Dinv(const double* u, const double* D, int n, double* v, hipStream_t st);
+hipError_t launch_dpp_selftest(const double* in, double* out, hipStream_t st);
+
+}  // namespace gpb

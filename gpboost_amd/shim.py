@@ -1,0 +1,173 @@
+"""ctypes view of the low-level C ABI (include/gpb_hip.h): what the reference's C++ host would call.
+
+``VecchiaState`` and ``HistBuilder`` are thin RAII wrappers; every method is one C call.  Used by the
+parity tests and by bench.py (resident and sharded evaluation); the high-level mirror of the
+reference's Python API is :class:`gpboost_amd.GPModel`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .basic import GPBoostError, _lib, _shim_call
+
+MODE_NLL, MODE_FACTOR, MODE_GRAD = 0, 1, 2
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class VecchiaState(object):
+    """coords: (n, d) array ALREADY in Vecchia order; m: number of neighbours."""
+
+    def __init__(self, coords, m):
+        coords = np.asarray(coords, dtype=np.float64)
+        if coords.ndim == 1:
+            coords = coords.reshape(-1, 1)
+        self.n, self.d = coords.shape
+        self.m = max(min(int(m), self.n - 1), 1)
+        cm = np.asfortranarray(coords)
+        self.h = C.c_void_p()
+        _shim_call(_lib().gpb_hip_vecchia_create(C.c_int(self.n), C.c_int(self.d), C.c_int(int(m)), _p(cm),
+                                                 C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value is not None:
+            _lib().gpb_hip_vecchia_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_handle(cls, ptr, n, d, m):
+        """Non-owning view of a gpb_hip_vecchia_t* owned by a GPModel (GPB_HIP_GetVecchiaHandle)."""
+        self = cls.__new__(cls)
+        self.n, self.d, self.m = int(n), int(d), int(m)
+        self.h = C.c_void_p(ptr.value if isinstance(ptr, C.c_void_p) else int(ptr))
+        self.close = lambda: None
+        return self
+
+    def set_stream(self, hip_stream_ptr):
+        _shim_call(_lib().gpb_hip_vecchia_set_stream(self.h, C.c_void_p(int(hip_stream_ptr))))
+
+    def find_neighbors(self):
+        dup = C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_find_neighbors(self.h, C.byref(dup)))
+        return bool(dup.value)
+
+    def set_neighbors(self, nn):
+        nn = np.ascontiguousarray(nn, dtype=np.int32)
+        assert nn.shape == (self.n, self.m), (nn.shape, self.n, self.m)
+        _shim_call(_lib().gpb_hip_vecchia_set_neighbors(self.h, _p(nn, C.c_int32)))
+
+    def get_neighbors(self):
+        nn = np.empty((self.n, self.m), dtype=np.int32)
+        _shim_call(_lib().gpb_hip_vecchia_get_neighbors(self.h, _p(nn, C.c_int32)))
+        return nn
+
+    def set_shard(self, i_begin, i_end):
+        _shim_call(_lib().gpb_hip_vecchia_set_shard(self.h, C.c_int(int(i_begin)), C.c_int(int(i_end))))
+
+    def set_y(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.shape == (self.n,)
+        _shim_call(_lib().gpb_hip_vecchia_set_y(self.h, _p(y)))
+
+    def set_y_dev(self, y_dev_ptr):
+        _shim_call(_lib().gpb_hip_vecchia_set_y_dev(self.h, C.c_void_p(int(y_dev_ptr))))
+
+    def sync(self):
+        _shim_call(_lib().gpb_hip_vecchia_sync(self.h))
+
+    def nll_terms(self, cov_type, var, a, gauss=True):
+        """-> array {y^T Psi^-1 y, log|Psi|, #bad} over this handle's shard."""
+        out = np.empty(3)
+        _shim_call(_lib().gpb_hip_vecchia_nll_terms(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                    C.c_int(1 if gauss else 0), _p(out)))
+        return out
+
+    def nll_terms_dev(self, cov_type, var, a, out_dev_ptr, gauss=True):
+        _shim_call(_lib().gpb_hip_vecchia_nll_terms_dev(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                        C.c_int(1 if gauss else 0), C.c_void_p(int(out_dev_ptr))))
+
+    def grad_terms(self, cov_type, var, a):
+        out = np.empty(7)
+        _shim_call(_lib().gpb_hip_vecchia_grad_terms(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(out)))
+        return out
+
+    def grad_terms_dev(self, cov_type, var, a, out_dev_ptr):
+        _shim_call(_lib().gpb_hip_vecchia_grad_terms_dev(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                         C.c_void_p(int(out_dev_ptr))))
+
+    def bench(self, mode, cov_type, var, a, warmup, steps):
+        """-> (ms_total, ms_point_kernel_avg, last_terms[7])"""
+        t = C.c_double(0); k = C.c_double(0); out = np.empty(7)
+        _shim_call(_lib().gpb_hip_vecchia_bench(self.h, C.c_int(mode), C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                C.c_int(warmup), C.c_int(steps), C.byref(t), C.byref(k), _p(out)))
+        return t.value, k.value, out
+
+    def factor(self, cov_type, var, a, gauss=True):
+        _shim_call(_lib().gpb_hip_vecchia_factor(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                 C.c_int(1 if gauss else 0)))
+
+    def get_factor(self):
+        A = np.empty((self.n, self.m)); D = np.empty(self.n); u = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_vecchia_get_factor(self.h, _p(A), _p(D), _p(u)))
+        return A, D, u
+
+    def yaux(self):
+        out = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_vecchia_yaux(self.h, _p(out)))
+        return out
+
+
+def nll_from_terms(n, yPy, logdet, sigma2):
+    """include/GPBoost/re_model_template.h:3132"""
+    return yPy / 2. / sigma2 + logdet / 2. + n / 2. * (np.log(sigma2) + np.log(2 * np.pi))
+
+
+def grad_from_terms(n, t7, sigma2):
+    """include/GPBoost/re_model_template.h:1994,2004 -> d nll / d log(sigma2, var, a)"""
+    return np.array([-t7[0] / sigma2 / 2. + n / 2., t7[3] / sigma2 + t7[4], t7[5] / sigma2 + t7[6]])
+
+
+class HistBuilder(object):
+    """bins: (F, n) uint8 feature-major; bin_offsets: F+1 prefix sums."""
+
+    def __init__(self, bins, bin_offsets):
+        bins = np.ascontiguousarray(bins, dtype=np.uint8)
+        self.F, self.n = bins.shape
+        self.bin_offsets = np.ascontiguousarray(bin_offsets, dtype=np.int32)
+        self.total_bins = int(self.bin_offsets[-1])
+        self.h = C.c_void_p()
+        _shim_call(_lib().gpb_hip_hist_create(C.c_int(self.n), C.c_int(self.F), _p(bins, C.c_uint8),
+                                              _p(self.bin_offsets, C.c_int32), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value is not None:
+            _lib().gpb_hip_hist_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_gradients(self, grad, hess=None):
+        grad = np.ascontiguousarray(grad, dtype=np.float64)
+        hess = None if hess is None else np.ascontiguousarray(hess, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_hist_set_gradients(self.h, _p(grad), _p(hess)))
+
+    def build(self, data_indices=None, const_hess=1.0):
+        """-> (hist[total_bins, 2] = {grad sum, hess sum}, cnt[total_bins] uint64)"""
+        di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+        nd = self.n if di is None else di.size
+        hist = np.empty((self.total_bins, 2)); cnt = np.empty(self.total_bins, dtype=np.uint64)
+        _shim_call(_lib().gpb_hip_hist_build(self.h, _p(di, C.c_int32), C.c_int(nd), C.c_double(const_hess), _p(hist),
+                                             _p(cnt, C.c_uint64)))
+        return hist, cnt

@@ -1,0 +1,148 @@
+/*
+ * include/gpb_hip.h -- C ABI of the MI355X (gfx950) GP + histogram hot path.
+ *
+ * This is the `extern "C"` shim the reference's host C++ calls instead of running its
+ * per-point OpenMP loops; plain pointers and sizes only, no C++/torch types.  Each
+ * entry point cites the reference interface it replaces (paths relative to the
+ * fabsig/GPBoost v1.7.3 tree).  INTEGRATION.md shows the call sites a maintainer patches.
+ *
+ * Conventions (same as the reference's C API, include/LightGBM/c_api.h:1837-1849):
+ *   - every function returns 0 on success, -1 on failure; the message is kept in a
+ *     thread-local buffer read with gpb_hip_get_last_error();
+ *   - never aborts/exits; any HIP error becomes a -1 (the reference host then raises
+ *     through Log::REFatal, include/LightGBM/utils/log.h:149,190);
+ *   - one host thread per handle (REModel has no locking); several handles
+ *     may be alive; a handle is bound to the HIP device current at creation time;
+ *   - host input arrays are borrowed for the duration of the call only;
+ *   - "dev" variants take device pointers valid on the handle's device and are enqueued
+ *     on the handle's stream without synchronising (use gpb_hip_vecchia_sync()).
+ *
+ * The library needs a gfx950 device: gpb_hip_device_count() == 0 makes every *_create
+ * fail loudly (there is no CPU fallback in this library by design).
+ */
+#ifndef GPB_HIP_H_
+#define GPB_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPB_HIP_EXPORT __attribute__((visibility("default")))
+
+/* covariance functions of the hot path: include/GPBoost/cov_fcts.h:2100-2118 */
+enum { GPB_HIP_COV_MATERN_0_5 = 0 /* == "exponential" */, GPB_HIP_COV_MATERN_1_5 = 1, GPB_HIP_COV_MATERN_2_5 = 2 };
+
+/* number of doubles gpb_hip_vecchia_grad_terms writes */
+#define GPB_HIP_NUM_TERMS 7
+
+typedef struct gpb_hip_vecchia gpb_hip_vecchia_t;
+typedef struct gpb_hip_hist gpb_hip_hist_t;
+
+GPB_HIP_EXPORT const char* gpb_hip_get_last_error(void);
+GPB_HIP_EXPORT int gpb_hip_device_count(int* count);
+/* Make `device` current for the calling thread (handles bind to the device current at their creation). */
+GPB_HIP_EXPORT int gpb_hip_set_device(int device);
+/* 1 if the current device is gfx950 */
+GPB_HIP_EXPORT int gpb_hip_device_is_gfx950(int* yes);
+/* Runs the fp64-DPP primitives against their compiler-scheduled equivalents on the device. */
+GPB_HIP_EXPORT int gpb_hip_selftest(void);
+
+/* ------------------------------------------------------------------------------------
+ * Vecchia state: replaces what CreateREComponentsVecchia builds on the host
+ * (src/GPBoost/Vecchia_utils.cpp:1095-1289): coordinates in Vecchia order + neighbour table.
+ *   coords_colmajor  n x d, column-major (as RECompGP::coords_, include/GPBoost/re_comp.h:837),
+ *                    ALREADY in Vecchia order; d in {1,2,3}
+ *   num_neighbors    m <= 62
+ * ---------------------------------------------------------------------------------- */
+GPB_HIP_EXPORT int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const double* coords_colmajor,
+                                          gpb_hip_vecchia_t** out);
+GPB_HIP_EXPORT int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h);
+GPB_HIP_EXPORT int gpb_hip_vecchia_sync(gpb_hip_vecchia_t* h);
+/* Run this handle's work on a caller-owned hipStream_t (e.g. the stream an RCCL all-reduce of the partial
+ * terms is enqueued on), instead of the handle's private stream.  NULL = the legacy default stream. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_stream(gpb_hip_vecchia_t* h, void* hip_stream);
+
+/* Ordered nearest-neighbour search on the device, bit-identical to
+ * find_nearest_neighbors_Vecchia_fast(neighbor_selection = "nearest", start_at = 0, end_search_at = -1)
+ * (src/GPBoost/Vecchia_utils.cpp:733-985, inner loop :1029-1093).  The coordinate-sum argsort is done
+ * on the host with std::sort and the reference's comparator (include/GPBoost/utils.h:230-238) because
+ * its tie order is libstdc++-specific.  has_duplicates (may be NULL) receives the flag of :812,:905. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates);
+/* Alternatively hand over a neighbour table computed elsewhere: n x m int32, row-major, -1 padded. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_neighbors(gpb_hip_vecchia_t* h, const int32_t* nn);
+GPB_HIP_EXPORT int gpb_hip_vecchia_get_neighbors(gpb_hip_vecchia_t* h, int32_t* nn);
+
+/* Multi-GPU: this handle evaluates points [i_begin, i_end) of the ordering only (default: all).
+ * Coordinates, y and the neighbour table stay replicated. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_begin, int32_t i_end);
+
+/* y in Vecchia order (REModelTemplate::SetY, include/GPBoost/re_model_template.h:6185-6222). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev);
+
+/* Fused factor + likelihood terms: replaces CalcCovFactorGradientVecchia(calc_cov_factor = true,
+ * calc_gradient = false) (src/GPBoost/Vecchia_utils.cpp:1367-1699) followed by CalcYTPsiIInvY
+ * (include/GPBoost/re_model_template.h:9960-9968) and the log-determinant (:2946-2948).
+ *   var = sigma1^2 / sigma^2, a = transformed range (re_model.cpp:768-778, cov_fcts.h:500-516)
+ *   gauss_likelihood: 1 -> nugget 1 on the diagonal (:1601), 0 -> diag *= 1 + 1e-10 (:1608)
+ *   out3 = { y^T Psi^-1 y, log|Psi|, #points with D_i <= 0 (:1685-1698) }  (sums over this handle's shard) */
+GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                             int gauss_likelihood, double* out3_host);
+/* Enqueue only; out3_dev is a device pointer (3 doubles). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                                 int gauss_likelihood, double* out3_dev);
+
+/* Same launch shape plus the covariance-parameter gradient pieces: replaces
+ * CalcCovFactorGradientVecchia(calc_gradient = true) + the Vecchia branch of CalcGradPars
+ * (include/GPBoost/re_model_template.h:1988-2011), Gaussian likelihood, transf_scale = true.
+ *   out7 = { yPy, logdet, #bad, G1_var, G2_var, G1_range, G2_range } with
+ *   d nll / d log(par_p) = G1_p / sigma2 + G2_p          (the :2004 expression, summed over the shard) */
+GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                              double* out7_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                                  double* out7_dev);
+
+/* Measurement helper (bench.py): `steps` back-to-back evaluations (mode 0 = nll terms, 2 = gradient terms) on the
+ * handle's stream after `warmup` untimed ones, covariance parameters perturbed every step.  ms_total: HIP events
+ * around the whole timed region (point kernel + final reduction, no host sync inside); ms_point_kernel_avg: mean of
+ * per-launch event pairs around the fused point kernel alone; out7_host (may be NULL): terms of the last step. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_bench(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int warmup,
+                                         int steps, double* ms_total, double* ms_point_kernel_avg, double* out7_host);
+
+/* Materialise the factor on the device: A (n x m, B = I - A, Vecchia_utils.cpp:1620-1622), D (the
+ * reference keeps D^-1, :1682) and u = B y.  Needed by y_aux / prediction-type consumers only. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                          int gauss_likelihood);
+GPB_HIP_EXPORT int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_host, double* D_host, double* u_host);
+
+/* y_aux = B^T D^-1 B y (CalcYAux, include/GPBoost/re_model_template.h:9771-9773), Vecchia order.
+ * Requires gpb_hip_vecchia_factor() with the current y. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host);
+
+/* ------------------------------------------------------------------------------------
+ * LightGBM feature histograms: replaces Dataset::ConstructHistogramsInner for dense uint8
+ * features (src/LightGBM/io/dataset.cpp:1143-1245 -> DenseBin<uint8_t>::ConstructHistogramInner,
+ * src/LightGBM/io/dense_bin.hpp:98-141), i.e. what a HIP TreeLearner's ConstructHistograms
+ * (src/LightGBM/treelearner/serial_tree_learner.cpp:351-373) calls.
+ *   bins         F x n uint8, feature-major (the col-wise DenseBin storage)
+ *   bin_offsets  F+1 prefix sums of #bins per feature (<= 256 each)
+ * ---------------------------------------------------------------------------------- */
+GPB_HIP_EXPORT int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins,
+                                       const int32_t* bin_offsets, gpb_hip_hist_t** out);
+GPB_HIP_EXPORT int gpb_hip_hist_free(gpb_hip_hist_t* h);
+/* gradients/hessians of all n rows (score_t = double, include/LightGBM/meta.h:32-40); hess may be NULL
+ * for a constant hessian (RegressionL2loss::IsConstantHessian, regression_objective.hpp:230). */
+GPB_HIP_EXPORT int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const double* hess);
+/* Build the histogram of one leaf.  data_indices (int32, num_data of them; NULL = all rows).
+ * hist_out: sum(bins) entries of {double grad_sum; double hess_sum} (hist_t pairs, include/LightGBM/bin.h:33-39);
+ * with a constant hessian hess_sum = count * const_hess (dataset.cpp:1223-1226).
+ * cnt_out (may be NULL): sum(bins) uint64 exact row counts. */
+GPB_HIP_EXPORT int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data,
+                                      double const_hess, double* hist_out, uint64_t* cnt_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPB_HIP_H_ */

@@ -1,0 +1,50 @@
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference (oracle/_ref, built by
+oracle/Makefile.ref from /root/reference) through oracle/ref_driver.cpp.
+
+    python oracle/make_golden.py
+
+The fixtures are small (inputs are regenerated from seeds by tests/cases.py; only outputs are stored)
+and are what the oracle (gpb_oracle.c) and the HIP path are pinned against on machines where
+/root/reference does not exist.  TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refdrv          # noqa: E402
+from tests import cases            # noqa: E402
+
+
+def main():
+    if not refdrv.available():
+        raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, c in cases.GOLDEN_CASES.items():
+        coords, y = cases.make_data(c)
+        mdl = refdrv.RefModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+        perm = mdl.perm()
+        nn = mdl.neighbors()
+        res = {"perm": perm.astype(np.int32), "nn": nn.astype(np.int32)}
+        for k, cp in enumerate(c["cov_pars"]):
+            nll, g, pt = mdl.nll_grad(y, np.asarray(cp, dtype=np.float64))
+            A, D, ya = mdl.factor()
+            res["nll_%d" % k] = np.float64(nll)
+            res["grad_%d" % k] = g
+            res["pars_trans_%d" % k] = pt
+            res["D_%d" % k] = D
+            res["yaux_%d" % k] = ya
+            if mdl.n <= 500:
+                res["A_%d" % k] = A
+            else:   # keep fixtures small: a strided sample of rows
+                res["A_rows_%d" % k] = np.arange(0, mdl.n, max(1, mdl.n // 200))
+                res["A_%d" % k] = A[res["A_rows_%d" % k]]
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+        print("wrote", name, "n=%d m=%d" % (mdl.n, mdl.m), "nll0=%.10f" % res["nll_0"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A thin extern "C" window onto the *unmodified reference* (headers included from
+ * /root/reference, linked against oracle/_ref/lib_gpboost_ref.so) that exposes the
+ * intermediate quantities the reference's public C API does not: the Vecchia
+ * ordering and neighbour lists, B = I - A and D^-1, y_aux, and the covariance
+ * parameter gradient of CalcGradPars.  oracle/make_golden.py uses it to produce the
+ * fixtures in tests/golden/; the parity tests use it (when oracle/_ref is present)
+ * to check gpb_oracle.c and the HIP path against the reference itself.
+ *
+ * Private members are reached by re-declaring the access specifiers for this
+ * translation unit only; no reference source is copied or modified.
+ */
+#include <sstream>
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+#define private public
+#define protected public
+#include <GPBoost/re_model.h>
+#undef private
+#undef protected
+
+using namespace GPBoost;
+
+extern "C" {
+
+__attribute__((visibility("default")))
+void* refdrv_create(int n, const double* coords_colmajor, int d, const char* cov_fct, double shape, int m,
+                    const char* ordering, int seed, const char* likelihood, int num_threads) {
+  try {
+    auto* mdl = new REModel(n, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, coords_colmajor, d, nullptr, 0,
+                            cov_fct, shape, m > 0 ? "vecchia" : "none", 1., 0., m > 0 ? m : 20, ordering, 500, 1., "kmeans++",
+                            likelihood, 1., "cholesky", seed, num_threads, false, false, nullptr, 1.);
+    return mdl;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_create: %s\n", e.what());
+    return nullptr;
+  }
+}
+
+__attribute__((visibility("default")))
+void refdrv_free(void* h) { delete reinterpret_cast<REModel*>(h); }
+
+/* Vecchia order: perm[k] = original index of the k-th point of the ordering */
+__attribute__((visibility("default")))
+int refdrv_get_perm(void* h, int* perm) {
+  auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+  const auto& idx = t->data_indices_per_cluster_[t->unique_clusters_[0]];
+  for (size_t i = 0; i < idx.size(); ++i) perm[i] = idx[i];
+  return (int)idx.size();
+}
+
+__attribute__((visibility("default")))
+int refdrv_get_neighbors(void* h, int m, int* nn) {
+  auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+  const auto& v = t->nearest_neighbors_[t->unique_clusters_[0]][0];
+  for (size_t i = 0; i < v.size(); ++i)
+    for (int j = 0; j < m; ++j) nn[i * m + j] = (j < (int)v[i].size()) ? v[i][j] : -1;
+  return (int)v.size();
+}
+
+/* nll + gradient wrt log of the transformed parameters (sigma2, sigma1_2/sigma2, a), exactly the
+ * sequence of the L-BFGS functor (include/GPBoost/optim_utils.h:299-338). */
+__attribute__((visibility("default")))
+int refdrv_nll_grad(void* h, const double* y, const double* cov_pars_orig, double* nll, double* grad3,
+                    double* cov_pars_trans_out) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    t->SetY(y);
+    vec_t orig = Eigen::Map<const vec_t>(cov_pars_orig, 3), trafo(3);
+    t->TransformCovPars(orig, trafo);
+    for (int k = 0; k < 3; ++k) cov_pars_trans_out[k] = trafo[k];
+    if ((int)t->estimate_cov_par_index_.size() != 3) t->estimate_cov_par_index_ = std::vector<int>(3, 1);
+    t->CalcCovFactorOrModeAndNegLL(trafo, nullptr);
+    *nll = t->GetNegLogLikelihood();
+    vec_t grad_cov, grad_beta;
+    t->CalcGradPars(trafo, trafo[0], true, false, grad_cov, grad_beta, true, false, nullptr, false);
+    for (int k = 0; k < 3; ++k) grad3[k] = grad_cov[k];
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_nll_grad: %s\n", e.what());
+    return -1;
+  }
+}
+
+/* after refdrv_nll_grad: A (n x m, aligned with the neighbour table), D^-1 diagonal, y_aux in Vecchia order */
+__attribute__((visibility("default")))
+int refdrv_get_factor(void* h, int m, double* A, double* Dinv, double* yaux) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    const int c0 = t->unique_clusters_[0];
+    const sp_mat_t& B = t->B_[c0][0];
+    const sp_mat_t& Di = t->D_inv_[c0][0];
+    const auto& nn = t->nearest_neighbors_[c0][0];
+    const int n = (int)nn.size();
+    for (int i = 0; i < n; ++i) {
+      Dinv[i] = Di.coeff(i, i);
+      for (int j = 0; j < m; ++j) A[(size_t)i * m + j] = (j < (int)nn[i].size()) ? -B.coeff(i, nn[i][j]) : 0.;
+    }
+    if (yaux) {
+      t->CalcYAux(1., false);
+      const vec_t& ya = t->y_aux_[c0];
+      for (int i = 0; i < n; ++i) yaux[i] = ya[i];
+    }
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_get_factor: %s\n", e.what());
+    return -1;
+  }
+}
+
+}  // extern "C"

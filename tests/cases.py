@@ -1,0 +1,64 @@
+"""Seeded synthetic inputs shared by the golden-fixture generator, the CPU tests and the GPU parity tests."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# name -> case.  "data": "r_fixture" = the reference's R test fixture
+# (R-package/tests/testthat/test_GPModel_gaussian_process.R:36-60); otherwise uniform coords from default_rng(seed_data).
+GOLDEN_CASES = {
+    "r_exp_m30_none": dict(data="r_fixture", cov_function="exponential", shape=0.5, m=30, ordering="none", seed=0,
+                           cov_pars=[(0.1, 1.6, 0.2), (0.5, 0.9, 0.05)]),
+    "r_mat15_m30_random": dict(data="r_fixture", cov_function="matern", shape=1.5, m=30, ordering="random", seed=0,
+                               cov_pars=[(0.1, 1.6, 0.2)]),
+    "r_mat25_m99_none": dict(data="r_fixture", cov_function="matern", shape=2.5, m=99, ordering="none", seed=0,
+                             cov_pars=[(0.1, 1.6, 0.2)]),
+    "u2d_n3000_exp_m30": dict(data="uniform", n=3000, d=2, seed_data=11, cov_function="exponential", shape=0.5, m=30,
+                              ordering="random", seed=1, cov_pars=[(0.1, 1.0, 0.1)]),
+    "u3d_n3000_mat25_m40": dict(data="uniform", n=3000, d=3, seed_data=12, cov_function="matern", shape=2.5, m=40,
+                                ordering="random", seed=1, cov_pars=[(0.1, 1.0, 0.1)]),
+    "u1d_n1000_mat15_m10": dict(data="uniform", n=1000, d=1, seed_data=13, cov_function="matern", shape=1.5, m=10,
+                                ordering="random", seed=3, cov_pars=[(0.2, 1.3, 0.05)]),
+    "grid2d_n1024_exp_m20": dict(data="grid", n=1024, d=2, seed_data=14, cov_function="exponential", shape=0.5, m=20,
+                                 ordering="random", seed=2, cov_pars=[(0.1, 1.0, 0.15)]),
+    "dup2d_n600_exp_m15": dict(data="duplicates", n=600, d=2, seed_data=15, cov_function="exponential", shape=0.5, m=15,
+                               ordering="random", seed=5, cov_pars=[(0.3, 1.0, 0.2)]),
+    "tiny_n8_m30": dict(data="uniform", n=8, d=2, seed_data=16, cov_function="exponential", shape=0.5, m=30,
+                        ordering="none", seed=0, cov_pars=[(0.1, 1.0, 0.3)]),
+}
+
+
+def make_data(c):
+    """-> (coords (n, d), y (n,)) in DATA order."""
+    if c["data"] == "r_fixture":
+        from oracle import orc
+        return orc.r_fixture()
+    rng = np.random.default_rng(c["seed_data"])
+    n, d = c["n"], c["d"]
+    if c["data"] == "uniform":
+        coords = rng.uniform(size=(n, d))
+    elif c["data"] == "grid":            # exact ties in distances and coordinate sums
+        k = int(round(n ** (1. / d)))
+        assert k ** d == n
+        ax = np.arange(k) / k
+        coords = np.stack(np.meshgrid(*([ax] * d), indexing="ij"), axis=-1).reshape(n, d)
+        coords = coords[rng.permutation(n)]
+    elif c["data"] == "duplicates":      # every location observed three times
+        base = rng.uniform(size=(n // 3, d))
+        coords = np.concatenate([base, base, base])[rng.permutation(n)]
+    else:
+        raise ValueError(c["data"])
+    y = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
+    return coords, y
+
+
+def synthetic(n, d, seed=1):
+    """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    coords = rng.uniform(size=(n, d))
+    y = rng.standard_normal(n)
+    return coords, y

@@ -1,0 +1,54 @@
+"""GPU (MI355X): LightGBM feature-histogram build through the C ABI against the oracle.
+Bin counts are bit-exact; fp64 gradient/hessian sums are order-dependent in the reference too
+(per-thread block buffers, train_share_states.h:46-109) and are compared to 1e-10 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, F, seed, max_bin=255):
+    rng = np.random.default_rng(seed)
+    nb = rng.integers(2, max_bin + 2, size=F)
+    nb[0] = 256; nb[-1] = 2
+    bo = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
+    bins = np.stack([rng.integers(0, nb[f], size=n) for f in range(F)]).astype(np.uint8)
+    return bins, bo, rng.standard_normal(n), rng.uniform(0.5, 2.0, size=n), rng
+
+
+@pytest.mark.parametrize("n,F", [(100000, 50), (4097, 3), (1000, 17), (50, 64)])
+def test_histogram_counts_exact_and_sums_close(lib_built, orc, n, F):
+    from gpboost_amd import shim
+    bins, bo, grad, hess, rng = _case(n, F, seed=n + F)
+    hb = shim.HistBuilder(bins, bo)
+    leaf = np.sort(rng.choice(n, size=max(1, n // 3), replace=False)).astype(np.int32)
+    shuffled = rng.permutation(leaf).astype(np.int32)     # data_indices need not be sorted
+    for hs in (None, hess):
+        hb.set_gradients(grad, hs)
+        for di in (None, leaf, shuffled, leaf[:1]):
+            hist, cnt = hb.build(di, const_hess=1.0)
+            hg, hc, hh = orc.hist_build(bins, bo, di, grad, hs, const_hess=1.0)
+            assert np.array_equal(cnt, hc), "bin counts must be bit-exact"
+            scale = np.abs(hg).max() + 1.0
+            np.testing.assert_allclose(hist[:, 0], hg, rtol=0, atol=1e-10 * scale)
+            if hs is None:
+                assert np.array_equal(hist[:, 1], hh), "constant hessian: count * hess is exact"
+            else:
+                np.testing.assert_allclose(hist[:, 1], hh, rtol=0, atol=1e-10 * (np.abs(hh).max() + 1.0))
+
+
+def test_histogram_is_reproducible_and_subtractable(lib_built, orc):
+    """larger = parent - smaller (serial_tree_learner.cpp:419-421) holds exactly for counts."""
+    from gpboost_amd import shim
+    n, F = 200000, 50
+    bins, bo, grad, hess, rng = _case(n, F, seed=5)
+    hb = shim.HistBuilder(bins, bo); hb.set_gradients(grad, None)
+    parent, pc = hb.build(None)
+    again, pc2 = hb.build(None)
+    assert np.array_equal(parent, again) and np.array_equal(pc, pc2)
+    mask = rng.uniform(size=n) < 0.37
+    left = np.nonzero(mask)[0].astype(np.int32); right = np.nonzero(~mask)[0].astype(np.int32)
+    hl, cl = hb.build(left); hr, cr = hb.build(right)
+    assert np.array_equal(cl + cr, pc)
+    np.testing.assert_allclose(hl[:, 0] + hr[:, 0], parent[:, 0], rtol=0, atol=1e-9)
+    assert int(pc[bo[0]:bo[1]].sum()) == n

@@ -1,0 +1,89 @@
+"""CPU: the oracle (oracle/gpb_oracle.c) against (i) the golden numbers hard-coded in the reference's R
+test-suite and (ii) the fixtures produced by the compiled reference (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# R-package/tests/testthat/test_GPModel_gaussian_process.R:86-120 (exact GP) and :1104-1148 (Vecchia)
+R_GOLDEN_EXACT = [("exponential", 0.5, 124.2549533), ("matern", 1.5, 141.3502172), ("matern", 2.5, 158.1111626)]
+R_COV_PARS = np.array([0.1, 1.6, 0.2])
+R_TOL = 1e-6   # the goldens carry 7 decimals; the R tests use TOLERANCE_STRICT = 1e-5
+
+
+def test_r_golden_exact_and_vecchia_full(orc):
+    coords, y = orc.r_fixture()
+    for cf, sh, gold in R_GOLDEN_EXACT:
+        ct = orc.cov_type_id(cf, sh)
+        pt = orc.transform_cov_pars(ct, R_COV_PARS)
+        assert abs(orc.exact_nll(coords, ct, pt, y)[2] - gold) < R_TOL
+        # Vecchia with m = n-1 equals the exact GP (:1104-1111)
+        assert abs(orc.gp_nll(coords, y, R_COV_PARS, cf, sh, m=99, ordering="none") - gold) < R_TOL
+
+
+def test_r_golden_vecchia_m30(orc):
+    coords, y = orc.r_fixture()
+    nll = orc.gp_nll(coords, y, R_COV_PARS, "exponential", 0.5, m=30, ordering="none")
+    assert abs(nll - 124.2252524) < R_TOL      # :1144-1148
+
+
+@pytest.mark.parametrize("name", sorted(cases.GOLDEN_CASES))
+def test_oracle_matches_reference_fixture(orc, name):
+    c = cases.GOLDEN_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    coords, y = cases.make_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    assert np.array_equal(perm, g["perm"]), "Vecchia ordering differs from the reference"
+    assert np.array_equal(nn, g["nn"]), "neighbour table differs from the reference (bit-exact requirement)"
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    for k, cp in enumerate(c["cov_pars"]):
+        pt = orc.transform_cov_pars(ct, np.asarray(cp, dtype=np.float64))
+        np.testing.assert_allclose(pt, g["pars_trans_%d" % k], rtol=1e-15)
+        out, grad = orc.vecchia_nll_grad(co, nn, ct, pt, y[perm])
+        assert abs(out[2] - g["nll_%d" % k]) <= 1e-10 * abs(g["nll_%d" % k])
+        np.testing.assert_allclose(grad, g["grad_%d" % k], rtol=1e-8, atol=1e-9)
+        A, D, bad = orc.vecchia_factor(co, nn, ct, pt[1], pt[2])
+        assert bad == 0
+        np.testing.assert_allclose(D, g["D_%d" % k], rtol=1e-10)
+        rows = g["A_rows_%d" % k] if ("A_rows_%d" % k) in g else np.arange(len(D))
+        np.testing.assert_allclose(A[rows], g["A_%d" % k], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(orc.vecchia_yaux(A, D, nn, y[perm]), g["yaux_%d" % k], rtol=1e-9, atol=1e-10)
+
+
+def test_oracle_gradient_is_derivative_of_nll(orc):
+    coords, y = cases.synthetic(400, 2, seed=3)
+    perm, co, nn = orc.vecchia_setup(coords, 15, "random", 1)
+    for ct in (0, 1, 2):
+        pt = orc.transform_cov_pars(ct, np.array([0.2, 1.1, 0.15]))
+        _, g = orc.vecchia_nll_grad(co, nn, ct, pt, y[perm])
+        eps = 1e-6
+        for k in range(3):
+            pp = pt.copy(); pp[k] *= np.exp(eps)
+            pm = pt.copy(); pm[k] *= np.exp(-eps)
+            fd = (orc.vecchia_nll(co, nn, ct, pp, y[perm])[2] - orc.vecchia_nll(co, nn, ct, pm, y[perm])[2]) / (2 * eps)
+            assert abs(fd - g[k]) < 1e-5 * max(1., abs(g[k]))
+
+
+def test_oracle_histogram_against_numpy(orc):
+    rng = np.random.default_rng(0)
+    n, F = 5000, 7
+    nb = np.array([255, 16, 64, 256, 3, 100, 200])
+    bo = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
+    bins = np.stack([rng.integers(0, nb[f], size=n) for f in range(F)]).astype(np.uint8)
+    grad = rng.standard_normal(n); hess = rng.uniform(0.5, 2., size=n)
+    idx = np.sort(rng.choice(n, size=1700, replace=False)).astype(np.int32)
+    for di in (None, idx):
+        rows = np.arange(n) if di is None else di
+        hg, hc, hh = orc.hist_build(bins, bo, di, grad, hess)
+        hg2, hc2, hh2 = orc.hist_build(bins, bo, di, grad, None, const_hess=1.0)
+        for f in range(F):
+            cnt = np.bincount(bins[f, rows], minlength=nb[f])
+            assert np.array_equal(hc[bo[f]:bo[f + 1]], cnt.astype(np.uint64))
+            assert np.array_equal(hc2[bo[f]:bo[f + 1]], cnt.astype(np.uint64))
+            np.testing.assert_allclose(hg[bo[f]:bo[f + 1]], np.bincount(bins[f, rows], weights=grad[rows], minlength=nb[f]), atol=1e-10)
+            np.testing.assert_allclose(hh[bo[f]:bo[f + 1]], np.bincount(bins[f, rows], weights=hess[rows], minlength=nb[f]), atol=1e-10)
+            np.testing.assert_array_equal(hh2[bo[f]:bo[f + 1]], cnt.astype(np.float64))

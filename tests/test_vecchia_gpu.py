@@ -1,0 +1,238 @@
+"""GPU (MI355X): parity of the HIP Vecchia path, through the C ABI, against the CPU oracle and the
+reference-generated golden fixtures.  Tolerances follow BASELINE.json's north_star: neighbour indices
+bit-exact; fp64 nll and covariance-parameter gradients within 1e-8 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-8      # north_star tolerance on nll / gradients
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+def test_device_is_gfx950_and_dpp_selftest(gpb):
+    import ctypes
+    yes = ctypes.c_int(0)
+    from gpboost_amd.basic import _lib
+    assert _lib().gpb_hip_device_is_gfx950(ctypes.byref(yes)) == 0
+    assert yes.value == 1
+    gpb.selftest()
+
+
+# ---- golden fixtures (reference outputs) ---------------------------------------------------------------
+GPU_GOLDEN = [n for n, c in sorted(cases.GOLDEN_CASES.items()) if c["m"] <= 62]
+
+
+@pytest.mark.parametrize("name", GPU_GOLDEN)
+def test_against_reference_fixture(gpb, name):
+    c = cases.GOLDEN_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    coords, y = cases.make_data(c)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    perm, nn = mdl.vecchia_structure()
+    assert np.array_equal(perm, g["perm"]), "Vecchia ordering differs from the reference"
+    assert np.array_equal(nn, g["nn"]), "neighbour table is not bit-identical to the reference"
+    for k, cp in enumerate(c["cov_pars"]):
+        cp = np.asarray(cp, dtype=np.float64)
+        nll = mdl.neg_log_likelihood(cov_pars=cp, y=y)
+        assert abs(nll - g["nll_%d" % k]) <= RTOL * abs(g["nll_%d" % k]), (nll, g["nll_%d" % k])
+        assert mdl.get_current_neg_log_likelihood() == nll
+        nll2, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+        assert abs(nll2 - g["nll_%d" % k]) <= RTOL * abs(g["nll_%d" % k])
+        np.testing.assert_allclose(grad, g["grad_%d" % k], rtol=RTOL, atol=RTOL * np.abs(g["grad_%d" % k]).max())
+        ya = mdl.y_aux(cp, y)
+        np.testing.assert_allclose(ya[perm], g["yaux_%d" % k], rtol=1e-7, atol=1e-9)
+
+
+def test_r_suite_golden_values(gpb, orc):
+    """R-package/tests/testthat/test_GPModel_gaussian_process.R:1144-1148 (Vecchia m=30, ordering none: 124.2252524)."""
+    coords, y = orc.r_fixture()
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30,
+                      vecchia_ordering="none")
+    assert abs(mdl.neg_log_likelihood(cov_pars=np.array([0.1, 1.6, 0.2]), y=y) - 124.2252524) < 1e-6
+    # fixed effects are subtracted from y (EvalNegLogLikelihoodGauss :2905-2916)
+    fe = 0.3 * np.cos(np.arange(100.))
+    a = mdl.neg_log_likelihood(cov_pars=np.array([0.1, 1.6, 0.2]), y=y + fe, fixed_effects=fe)
+    assert abs(a - 124.2252524) < 1e-6
+
+
+# ---- oracle on seeded inputs ---------------------------------------------------------------------------
+ORACLE_CASES = [
+    # n, d, m, cov_function, shape, ordering
+    (20000, 2, 30, "exponential", 0.5, "random"),
+    (20000, 3, 40, "matern", 2.5, "random"),
+    (5000, 2, 20, "matern", 1.5, "none"),
+    (3000, 1, 5, "exponential", 0.5, "random"),
+    (4000, 3, 10, "matern", 1.5, "random"),
+    (2000, 2, 50, "exponential", 0.5, "random"),
+    (2000, 2, 62, "matern", 2.5, "random"),
+    (1500, 2, 1, "exponential", 0.5, "random"),
+    (777, 2, 33, "matern", 1.5, "random"),      # m not an instantiated size: padded to 40
+    (40, 2, 30, "exponential", 0.5, "random"),   # mostly short rows
+    (2, 2, 30, "exponential", 0.5, "none"),      # smallest model
+]
+
+
+@pytest.mark.parametrize("n,d,m,cf,sh,ordering", ORACLE_CASES)
+def test_against_oracle(gpb, orc, n, d, m, cf, sh, ordering):
+    coords, y = cases.synthetic(n, d, seed=n + m)
+    cp = np.array([0.1, 1.0, 0.1])
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m,
+                      vecchia_ordering=ordering, seed=1)
+    perm, nn = mdl.vecchia_structure()
+    perm_o, co, nn_o = orc.vecchia_setup(coords, m, ordering, 1)
+    assert np.array_equal(perm, perm_o)
+    assert np.array_equal(nn, nn_o), "neighbour indices must be bit-exact"
+    ct = orc.cov_type_id(cf, sh)
+    pt = orc.transform_cov_pars(ct, cp)
+    out, grad_o = orc.vecchia_nll_grad(co, nn_o, ct, pt, y[perm])
+    nll, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+    assert abs(nll - out[2]) <= RTOL * abs(out[2])
+    assert abs(mdl.neg_log_likelihood(cp, y) - out[2]) <= RTOL * abs(out[2])
+    np.testing.assert_allclose(grad, grad_o, rtol=RTOL, atol=RTOL * np.abs(grad_o).max())
+
+
+def test_factor_A_D_u_and_yaux_against_oracle(gpb, orc):
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(6000, 2, seed=9)
+    perm, co, nn = orc.vecchia_setup(coords, 30, "random", 2)
+    st = shim.VecchiaState(co, 30)
+    st.set_neighbors(nn)
+    st.set_y(y[perm])
+    for ct, gauss in ((0, True), (2, True), (1, False)):
+        var, a = 7.5, 11.0
+        st.factor(ct, var, a, gauss=gauss)
+        A, D, u = st.get_factor()
+        Ao, Do, bad = orc.vecchia_factor(co, nn, ct, var, a, gauss=gauss)
+        np.testing.assert_allclose(D, Do, rtol=1e-10)
+        np.testing.assert_allclose(A, Ao, rtol=0, atol=1e-10)
+        uo = y[perm] - np.einsum("ij,ij->i", Ao, np.where(nn >= 0, y[perm][np.maximum(nn, 0)], 0.))
+        np.testing.assert_allclose(u, uo, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(st.yaux(), orc.vecchia_yaux(Ao, Do, nn, y[perm]), rtol=1e-9, atol=1e-10)
+        t = st.nll_terms(ct, var, a, gauss=gauss)
+        assert abs(t[0] - np.sum(uo ** 2 / Do)) <= 1e-10 * abs(t[0])
+        assert abs(t[1] - np.sum(np.log(Do))) <= 1e-10 * max(1., abs(t[1]))
+        assert t[2] == 0
+
+
+def test_device_neighbor_search_equals_host_table(gpb, orc):
+    """find_neighbors (device) == set_neighbors(oracle table): both routes give identical likelihood terms."""
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(9000, 3, seed=21)
+    perm, co, nn = orc.vecchia_setup(coords, 25, "random", 4)
+    a = shim.VecchiaState(co, 25); dup = a.find_neighbors()
+    assert not dup
+    assert np.array_equal(a.get_neighbors(), nn)
+    b = shim.VecchiaState(co, 25); b.set_neighbors(nn)
+    a.set_y(y[perm]); b.set_y(y[perm])
+    assert np.array_equal(a.nll_terms(2, 3.0, 9.0), b.nll_terms(2, 3.0, 9.0))   # deterministic reduction: bitwise
+
+
+def test_duplicates_flag_and_ties(gpb, orc):
+    from gpboost_amd import shim
+    c = cases.GOLDEN_CASES["dup2d_n600_exp_m15"]
+    coords, y = cases.make_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, 15, "random", 5)
+    st = shim.VecchiaState(co, 15)
+    assert st.find_neighbors() is True
+    assert np.array_equal(st.get_neighbors(), nn)
+
+
+def test_shards_add_up_and_results_are_reproducible(gpb, orc):
+    from gpboost_amd import shim, parallel
+    coords, y = cases.synthetic(30011, 2, seed=33)
+    perm, co, nn = orc.vecchia_setup(coords, 30, "random", 1)
+    st = shim.VecchiaState(co, 30); st.set_neighbors(nn); st.set_y(y[perm])
+    full = st.grad_terms(0, 10.0, 10.0)
+    again = st.grad_terms(0, 10.0, 10.0)
+    assert np.array_equal(full, again), "fixed-order reductions must be bit-reproducible"
+    for world in (2, 3, 8):
+        acc = np.zeros(7)
+        for r in range(world):
+            i0, i1 = parallel.shard_range(st.n, r, world)
+            st.set_shard(i0, i1)
+            acc += st.grad_terms(0, 10.0, 10.0)
+        st.set_shard(0, st.n)
+        np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-9)
+
+
+def test_full_size_properties_n1e6(gpb, orc):
+    """BASELINE.json's metric size (n = 1e6, m = 30, d = 2, exponential): properties that need no oracle pass --
+    the quadratic form is quadratic in y, the log-determinant does not depend on y, shards add up, and a
+    strided sample of rows of the factor matches the oracle evaluated on those rows only."""
+    from gpboost_amd import shim, parallel
+    n, m = 1_000_000, 30
+    coords, y = cases.synthetic(n, 2, seed=1)
+    st = shim.VecchiaState(coords, m)          # ordering "none": coords already in (random) order
+    assert st.find_neighbors() is False
+    nn = st.get_neighbors()
+    # neighbour rows: strictly earlier indices, sorted by distance, and exact on a sample (brute force)
+    assert (nn[m + 1:] < np.arange(m + 1, n)[:, None]).all() and (nn[m + 1:] >= 0).all()
+    rng = np.random.default_rng(0)
+    for i in rng.integers(m + 1, n, size=25):
+        d2 = ((coords[:i] - coords[i]) ** 2).sum(1)
+        assert set(np.argsort(d2, kind="stable")[:m]) == set(nn[i]), i
+        assert (np.diff(d2[nn[i]]) >= 0).all()
+    var, a = 10.0, 10.0
+    st.set_y(y)
+    t1 = st.nll_terms(0, var, a)
+    st.set_y(2.0 * y)
+    t2 = st.nll_terms(0, var, a)
+    assert t1[2] == 0 and t2[2] == 0
+    assert abs(t2[0] - 4.0 * t1[0]) <= 1e-12 * abs(t2[0])
+    assert t2[1] == t1[1]
+    st.set_y(y)
+    acc = np.zeros(3)
+    for r in range(8):
+        st.set_shard(*parallel.shard_range(n, r, 8)); acc += st.nll_terms(0, var, a)
+    st.set_shard(0, n)
+    np.testing.assert_allclose(acc[:2], t1[:2], rtol=1e-12)
+    # sample rows against the oracle (oracle evaluates only the sampled rows: sub-problem with remapped indices)
+    rows = rng.integers(0, n, size=300)
+    st.factor(0, var, a)
+    A, D, u = st.get_factor()
+    for i in rows:
+        idx = nn[i][nn[i] >= 0]
+        sub = np.concatenate([coords[idx], coords[i:i + 1]])
+        k = len(idx)
+        nn_sub = np.full((k + 1, max(k, 1)), -1, dtype=np.int32)
+        nn_sub[k, :k] = np.arange(k)
+        Ao, Do, _ = orc.vecchia_factor(sub, nn_sub, 0, var, a)
+        assert abs(D[i] - Do[k]) <= 1e-10 * Do[k]
+        np.testing.assert_allclose(A[i, :k], Ao[k, :k], rtol=0, atol=1e-10)
+
+
+def test_errors_are_loud(gpb):
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(300, 2, seed=2)
+    with pytest.raises(gpb.GPBoostError):
+        gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=80)   # > 62
+    with pytest.raises(gpb.GPBoostError):
+        gpb.GPModel(gp_coords=np.random.default_rng(0).uniform(size=(100, 4)), cov_function="exponential",
+                    gp_approx="vecchia", num_neighbors=10)                                            # d > 3
+    st = shim.VecchiaState(coords, 10)
+    with pytest.raises(gpb.GPBoostError):
+        st.nll_terms(0, 1.0, 1.0)        # neighbours not set
+    st.find_neighbors()
+    with pytest.raises(gpb.GPBoostError):
+        st.nll_terms(0, 1.0, 1.0)        # y not set
+    st.set_y(y)
+    with pytest.raises(gpb.GPBoostError):
+        st.nll_terms(0, -1.0, 1.0)
+    with pytest.raises(gpb.GPBoostError):
+        st.yaux()                        # factor not computed
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
+    with pytest.raises(gpb.GPBoostError):
+        mdl.neg_log_likelihood(cov_pars=np.array([0.1, -1.0, 0.1]), y=y)
