@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- neg-log-likelihood evaluations per second of the Gaussian Vecchia GP on MI355X.
+
+Metric (BASELINE.json): neg-log-lik evals/sec, n = 1e6, Vecchia m = 30, fp64, on 1/2/4/8 GPUs; % of roofline.
+A "step" is ONE evaluation of the whole job's likelihood at fresh covariance parameters: every rank runs the
+fused point kernel on its contiguous shard of the Vecchia ordering (inputs resident in HBM), the <= 3 partial
+sums are all-reduced over RCCL (N > 1), and the value is delivered to the host (as an optimiser would need it).
+Model creation (ordering + device neighbour search) is set-up and reported separately, as in BASELINE.md.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (vecchia_point_kernel, MODE_NLL): its
+average duration is measured live with HIP events on the stream it is launched on (gpb_hip_vecchia_bench);
+`cpu_baseline` (rank 0, N = 1 only) times the unmodified reference (oracle/_ref, kind "reference") -- or the C
+restatement (kind "port") when oracle/_ref is absent -- on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
+
+
+def algorithmic_bytes_per_point(m, d):
+    """neighbour indices + gathered coords of the point and its m neighbours + gathered y."""
+    return 4 * m + 8 * d * (m + 1) + 8 * (m + 1)
+
+
+def algorithmic_flops_per_point(m, d, cov_type):
+    """m^3/3 + 2 m^2 + m(m+1)/2 (3d + c_k) + 4m, each exp/sqrt/div counted as 1."""
+    ck = {0: 3, 1: 5, 2: 8}[cov_type]
+    return m ** 3 / 3.0 + 2 * m * m + (m * (m + 1) / 2.0) * (3 * d + ck) + 4 * m
+
+
+def cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n_full):
+    """Reference CPU path on a bounded sample (first n_s points), scaled linearly in n to the metric's unit."""
+    n_s = min(len(y), 100000)
+    cores = os.cpu_count() or 1
+    from oracle import refdrv
+    if refdrv.available():
+        mdl = refdrv.RefCAPIModel(coords[:n_s], cov_function, shape, m, "random", 1, threads=-1)
+        f = lambda cp: mdl.neg_log_likelihood(cp, y[:n_s])
+        kind = "reference"
+    else:
+        from oracle import orc
+        ct = orc.cov_type_id(cov_function, shape)
+        setup = orc.vecchia_setup(coords[:n_s], m, "random", 1)
+        f = lambda cp: orc.gp_nll(coords[:n_s], y[:n_s], cp, cov_function, shape, m, setup=setup)
+        kind = "port"
+    f(cov_pars)   # warm-up
+    ts = []
+    for k in range(3):
+        cp = cov_pars * (1.0 + 0.01 * (k + 1))
+        t0 = time.perf_counter(); f(cp); ts.append(time.perf_counter() - t0)
+    s_per_eval = float(np.median(ts))
+    return {"value": (1.0 / s_per_eval) * (n_s / float(n_full)), "unit": "evals/s", "cores": cores, "kind": kind,
+            "sample": "n=%d subset of the same synthetic data (m=%d, same kernel), median of 3 evals = %.3f s, "
+                      "scaled by %d/%d to n=%d (cost is linear in n)" % (n_s, m, s_per_eval, n_s, n_full, n_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--m", type=int, default=30)
+    ap.add_argument("--d", type=int, default=2)
+    ap.add_argument("--cov", default="exponential", choices=["exponential", "matern_1.5", "matern_2.5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and rank == 0 and distributed:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    torch = dist = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import gpboost_amd
+    from gpboost_amd import parallel, shim
+    if not distributed:
+        gpboost_amd.set_device(0)
+
+    cov_function, shape = {"exponential": ("exponential", 0.5), "matern_1.5": ("matern", 1.5),
+                           "matern_2.5": ("matern", 2.5)}[args.cov]
+    ct = {0.5: 0, 1.5: 1, 2.5: 2}[shape]
+    n, m, d = args.n, args.m, args.d
+    rng = np.random.default_rng(1)                     # BASELINE.md section 2 inputs
+    coords = rng.uniform(size=(n, d))
+    y = rng.standard_normal(n)
+    cov_pars = np.array([0.1, 1.0, 0.1])               # (sigma2, sigma1_2, rho)
+    sigma2 = cov_pars[0]
+    var0 = cov_pars[1] / cov_pars[0]
+    a0 = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cov_pars[2]
+
+    t0 = time.perf_counter()
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function=cov_function, cov_fct_shape=shape, gp_approx="vecchia",
+                              num_neighbors=m, vecchia_ordering="random", seed=1)
+    t_setup = time.perf_counter() - t0
+    perm, _ = mdl.vecchia_structure()
+    st = shim.VecchiaState.from_handle(mdl.vecchia_handle(), n, d, m)
+    st.set_y(y[perm])                                  # resident in HBM before the timed region
+    i0, i1 = parallel.shard_range(n, rank, world)
+    st.set_shard(i0, i1)
+
+    tdev = None
+    if distributed:
+        st.set_stream(torch.cuda.current_stream().cuda_stream)
+        tdev = torch.zeros(3, dtype=torch.float64, device="cuda")
+
+    def one_eval(k):
+        # covariance parameters change every evaluation (perturbed by <= 1 %): nothing is reusable between steps
+        var = var0 * (1.0 + 0.002 * ((k % 11) - 5))
+        a = a0 * (1.0 + 0.002 * ((k % 7) - 3))
+        if distributed:
+            st.nll_terms_dev(ct, var, a, tdev.data_ptr())
+            dist.all_reduce(tdev)
+            t = tdev.cpu().numpy()
+        else:
+            t = st.nll_terms(ct, var, a)
+        return parallel.nll_from_terms(n, t[0], t[1], sigma2)
+
+    def sync():
+        if distributed:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            st.sync()
+
+    for k in range(args.warmup):
+        one_eval(k)
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = one_eval(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel, measured with HIP events on its own stream (this rank's shard)
+    ms_total, ms_kernel, _ = st.bench(shim.MODE_NLL, ct, var0, a0, 1, max(3, min(args.steps, 20)))
+    ms_gtotal, ms_gkernel, _ = st.bench(shim.MODE_GRAD, ct, var0, a0, 1, 3)
+    npts = i1 - i0
+    bytes_launch = npts * algorithmic_bytes_per_point(m, d)
+    flops_launch = npts * algorithmic_flops_per_point(m, d, ct)
+    achieved_gbs = bytes_launch / (ms_kernel * 1e-3) / 1e9
+    achieved_tflops = flops_launch / (ms_kernel * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "neg-log-lik evals/sec, n=%d Vecchia(m=%d) fp64" % (n, m),
+            "value": args.steps / dt,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "Vecchia GP Gaussian nll, n=%d, d=%d, %s, m=%d, vecchia_ordering=random" % (n, d, args.cov, m),
+                       "shard_points_per_gpu": npts, "parallelism": "points sharded x%d, all-reduce of 3 fp64" % world,
+                       "setup_s_model_creation_incl_device_neighbor_search": round(t_setup, 3),
+                       "last_negll": last,
+                       "grad_eval_ms_kernel": round(ms_gkernel, 4)},
+            "roofline": {"bound": "hbm", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "kernel is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)
+            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,9 @@
 //     l, so the 4 rows a wavefront processes per step never collide on an LDS histogram except when
 //     two rows share a bin of the same feature;
 //   * sub-histograms are privatised in LDS (ds_add_f64 / ds_add_u32), written out per chunk and
-//     summed over chunks in a fixed order by a second kernel: counts are exact, fp64 sums are
-//     reproducible run to run.
+//     summed over chunks in a fixed order by a second kernel: counts are exact (and therefore
+//     reproducible); the fp64 sums depend on the LDS-atomic arrival order inside a chunk, i.e. they
+//     are order-dependent exactly as the reference's per-thread block buffers are.
 #include "hist_kernels.h"
 
 namespace gpb {

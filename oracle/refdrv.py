@@ -74,3 +74,40 @@ class RefModel(object):
         if rc != 0:
             raise RuntimeError("refdrv_get_factor failed")
         return A, 1. / Di, ya
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's own public C API (lib_gpboost_ref.so), bound the way python-package/gpboost/basic.py:5206-5240
+# binds it: used as the "reference" CPU baseline of bench.py.
+# ---------------------------------------------------------------------------------------------
+class RefCAPIModel(object):
+    def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1):
+        self.L = C.CDLL(os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
+        self.L.LGBM_GetLastError.restype = C.c_char_p
+        cm = np.asfortranarray(coords, dtype=np.float64)
+        self.n, self.d = cm.shape
+        self.h = C.c_void_p()
+        s = lambda x: C.c_char_p(x.encode())
+        rc = self.L.GPB_CreateREModel(
+            C.c_int(self.n), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
+            C.c_int(1), _P(cm), C.c_int(self.d), C.c_void_p(), C.c_int(0), s(cov_function), C.c_double(shape), s("vecchia"),
+            C.c_double(1.), C.c_double(0.), C.c_int(m), s(ordering), C.c_int(500), C.c_double(1.), s("kmeans++"),
+            s("gaussian"), C.c_double(-999.), s("cholesky"), C.c_int(seed), C.c_int(threads), C.c_bool(False),
+            C.c_bool(False), C.c_void_p(), C.c_double(1.), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+
+    def neg_log_likelihood(self, cov_pars, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        cp = np.ascontiguousarray(cov_pars, dtype=np.float64)
+        out = C.c_double(0)
+        rc = self.L.GPB_EvalNegLogLikelihood(self.h, _P(y), _P(cp), C.c_void_p(), C.byref(out))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out.value
+
+    def __del__(self):
+        try:
+            self.L.GPB_REModelFree(self.h)
+        except Exception:
+            pass
