@@ -82,7 +82,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # GPB_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL init, shared stream, all-reduce) with one rank
+    distributed = world > 1 or os.environ.get("GPB_BENCH_FORCE_DIST", "0") == "1"
     if args.gpus != world and rank == 0 and distributed:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 

@@ -1,0 +1,306 @@
+// gpboost_amd/csrc/dense_kernels.hip
+//
+// Exact (non-approximated) GP path for gfx950 -- SURVEY.md section 8 row a10 / BASELINE config 1:
+//   Psi = Sigma + I on the transformed scale   include/GPBoost/re_model_template.h:8151 (CalcSigmaComps),
+//                                              :9273-9287 (CalcZSigmaZt), cov_fcts.h:634-755
+//   Psi = L L^T (dense, fp64)                  :6491-6494 (CalcChol, Eigen::LLT)
+//   y^T Psi^-1 y, log|Psi| = 2 sum log L_ii    :9894, :3127, :3132
+//   y_aux = Psi^-1 y                           :9894
+//
+// Kernels (matrix row-major, lower triangle, leading dimension np = n rounded up to 64; the padding
+// rows/columns are the identity so they change neither the log-determinant nor the solves):
+//   dense_cov_lower_kernel   covariance assembly, one 64x64 tile per workgroup, 32-byte stores per lane:
+//                            the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
+//   potrf_diag_kernel        64x64 diagonal block, LDS resident, one workgroup
+//   trsm_panel_kernel        L21 = A21 L11^-T, one thread per row, L11 broadcast from LDS
+//   syrk_mfma_kernel         A22 -= L21 L21^T on the lower tiles with v_mfma_f64_16x16x4_f64
+//                            (one wavefront per 64x64 tile, 16 accumulator tiles, K = 64 per panel)
+//   trsv_lower_kernel        forward (and optionally backward) substitution + y^T Psi^-1 y + log-det
+#include "dev_common.h"
+#include "dense_kernels.h"
+
+namespace gpb {
+
+namespace {
+constexpr int TB = 64;            // tile / panel width
+constexpr int LDSS = 66;          // LDS row stride (doubles): 16 rows x 4 k of an MFMA fragment hit 64 distinct banks
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int COV>
+__device__ __forceinline__ double matern_plain(double dist, double var, double a, const double* tab) {
+  return matern_cov<COV>(dist, var, a, tab);
+}
+}  // namespace
+
+// ---- covariance assembly ----------------------------------------------------------------
+// grid = lower tiles (ti >= tj) flattened; block = 256 threads, thread (tx, ty) computes a 4x4 sub-block.
+template <int COV, bool D3>
+__global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __restrict__ pts, int n, int np, double var,
+                                                              double a, double nugget, const double* __restrict__ gtab,
+                                                              double* __restrict__ P) {
+  __shared__ double s_tab[GPB_EXP_TAB_SIZE];
+  __shared__ double4 s_row[TB], s_col[TB];
+  fill_exp_table(s_tab, gtab);
+  // tile index -> (ti, tj), ti >= tj
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > t) --ti;
+  const int tj = t - (int)((long long)ti * (ti + 1) / 2);
+  const int tid = threadIdx.x;
+  if (tid < TB) {
+    const int r = ti * TB + tid;
+    s_row[tid] = r < n ? pts[r] : make_double4(0, 0, 0, 0);
+  } else if (tid < 2 * TB) {
+    const int c = tj * TB + tid - TB;
+    s_col[tid - TB] = c < n ? pts[c] : make_double4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int lr = ty * 4 + rr, r = ti * TB + lr;
+    const double4 p = s_row[lr];
+    double v[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int lc = tx * 4 + cc, c = tj * TB + lc;
+      const double4 q = s_col[lc];
+      const double dx = p.x - q.x, dy = p.y - q.y;
+      double d2 = dx * dx;
+      d2 = __builtin_fma(dy, dy, d2);
+      if (D3) { const double dz = p.z - q.z; d2 = __builtin_fma(dz, dz, d2); }
+      double val = matern_plain<COV>(fast_sqrt(d2), var, a, s_tab);
+      if (r == c) val = var + nugget;
+      if (r >= n || c >= n) val = (r == c) ? 1.0 : 0.0;     // identity padding
+      v[cc] = val;
+    }
+    double4* dst = reinterpret_cast<double4*>(P + (size_t)r * np + (size_t)tj * TB + tx * 4);
+    *dst = make_double4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---- diagonal block factorisation -----------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ P, int np, int k0, int* __restrict__ info) {
+  __shared__ double s[TB][TB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < TB * TB; e += 256) {
+    const int i = e / TB, j = e % TB;
+    s[i][j] = (j <= i) ? P[(size_t)(k0 + i) * np + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < TB; ++k) {
+    if (tid == 0) {
+      const double d = s[k][k];
+      if (!(d > 0.0)) atomicOr(info, 1);
+      s[k][k] = sqrt(d);
+    }
+    __syncthreads();
+    const double dk = s[k][k];
+    if (tid > k && tid < TB) s[tid][k] = s[tid][k] / dk;
+    __syncthreads();
+    const int w = TB - k - 1;
+    for (int e = tid; e < w * w; e += 256) {
+      const int i = k + 1 + e / w, j = k + 1 + e % w;
+      if (j <= i) s[i][j] = __builtin_fma(-s[i][k], s[j][k], s[i][j]);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < TB * TB; e += 256) {
+    const int i = e / TB, j = e % TB;
+    if (j <= i) P[(size_t)(k0 + i) * np + k0 + j] = s[i][j];
+  }
+}
+
+// ---- panel solve: rows below the diagonal block ------------------------------------------------
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ P, int np, int k0) {
+  __shared__ double sL[TB][TB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < TB * TB; e += 64) {
+    const int i = e / TB, j = e % TB;
+    sL[i][j] = (j <= i) ? P[(size_t)(k0 + i) * np + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int i = k0 + TB + blockIdx.x * 64 + tid;
+  if (i >= np) return;
+  double* row = P + (size_t)i * np + k0;
+  double x[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) x[j] = row[j];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    double t = x[j];
+#pragma unroll
+    for (int p = 0; p < j; ++p) t = __builtin_fma(-x[p], sL[j][p], t);
+    x[j] = t / sL[j][j];
+  }
+#pragma unroll
+  for (int j = 0; j < TB; ++j) row[j] = x[j];
+}
+
+// ---- trailing update with fp64 MFMA -------------------------------------------------------------
+// One wavefront per 64x64 tile (ti >= tj) of the trailing matrix: C -= A B^T, A = L21[rows of ti], B = L21[rows of tj].
+__global__ __launch_bounds__(64) void syrk_mfma_kernel(double* __restrict__ P, int np, int k0) {
+  __shared__ double sA[TB * LDSS], sB[TB * LDSS];
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > t) --ti;
+  const int tj = t - (int)((long long)ti * (ti + 1) / 2);
+  const int r0 = k0 + TB + ti * TB, c0 = k0 + TB + tj * TB;
+  const int lane = threadIdx.x;
+  // stage both 64x64 panels: lane reads 2 doubles (16 B) per row step; row-major source, 512 B per row
+  for (int e = lane; e < TB * TB / 2; e += 64) {
+    const int i = e / (TB / 2), j2 = (e % (TB / 2)) * 2;
+    const double2 va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + k0 + j2);
+    const double2 vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + k0 + j2);
+    sA[i * LDSS + j2] = va.x; sA[i * LDSS + j2 + 1] = va.y;
+    sB[i * LDSS + j2] = vb.x; sB[i * LDSS + j2 + 1] = vb.y;
+  }
+  __syncthreads();
+  double4v acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (double4v){0.0, 0.0, 0.0, 0.0};
+  const int fr = lane & 15, fk = lane >> 4;   // fragment row / k within the 16x4 (A) and 4x16 (B) operands
+#pragma unroll 4
+  for (int kk = 0; kk < TB / 4; ++kk) {
+    double af[4], bf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      af[q] = sA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
+      bf[q] = sB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L21[j][k]
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+  }
+  // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = r0 + 16 * mi + fk + 4 * r, gj = c0 + 16 * nj + fr;
+        if (gj <= gi) P[(size_t)gi * np + gj] -= acc[mi][nj][r];
+      }
+}
+
+// ---- triangular solves + reductions, one workgroup ----------------------------------------------
+// z = L^-1 y; out[0] = z^T z (= y^T Psi^-1 y), out[1] = 2 sum log L_ii; if x_out: x = L^-T z (= Psi^-1 y)
+__global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restrict__ P, int n, int np,
+                                                          const double* __restrict__ y, double* __restrict__ z,
+                                                          double* __restrict__ out, double* __restrict__ x_out) {
+  __shared__ double sz[TB];
+  __shared__ double sred[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < np; i += 1024) z[i] = i < n ? y[i] : 0.0;
+  __syncthreads();
+  for (int b0 = 0; b0 < np; b0 += TB) {
+    // diagonal block: 64 sequential steps by the first wavefront
+    if (tid < TB) {
+      double zi = z[b0 + tid];
+      for (int k = 0; k < TB; ++k) {
+        const double lkk = P[(size_t)(b0 + k) * np + b0 + k];
+        const double zk = __shfl(zi, k, 64) / lkk;
+        if (tid == k) zi = zk;
+        if (tid > k) zi = __builtin_fma(-P[(size_t)(b0 + tid) * np + b0 + k], zk, zi);
+      }
+      sz[tid] = zi; z[b0 + tid] = zi;
+    }
+    __syncthreads();
+    // rows below: z[i] -= L[i][b0:b0+64] . z_block   (4 threads per row, 16 columns each)
+    const int sub = tid & 3;
+    for (int i = b0 + TB + (tid >> 2); i < np; i += 256) {
+      const double* row = P + (size_t)i * np + b0 + sub * 16;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = __builtin_fma(row[k], sz[sub * 16 + k], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (sub == 0) z[i] -= acc;
+    }
+    __syncthreads();
+  }
+  double q = 0.0, ld = 0.0;
+  for (int i = tid; i < n; i += 1024) { q = __builtin_fma(z[i], z[i], q); ld += log(P[(size_t)i * np + i]); }
+  sred[tid] = q; __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) { if (tid < w) sred[tid] += sred[tid + w]; __syncthreads(); }
+  if (tid == 0) out[0] = sred[0];
+  __syncthreads();
+  sred[tid] = ld; __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) { if (tid < w) sred[tid] += sred[tid + w]; __syncthreads(); }
+  if (tid == 0) out[1] = 2.0 * sred[0];
+  if (x_out == nullptr) return;
+  __syncthreads();
+  // backward: L^T x = z, blocks from the bottom; x overwrites z
+  for (int b0 = np - TB; b0 >= 0; b0 -= TB) {
+    if (tid < TB) {
+      double xi = z[b0 + tid];
+      for (int k = TB - 1; k >= 0; --k) {
+        const double lkk = P[(size_t)(b0 + k) * np + b0 + k];
+        const double xk = __shfl(xi, k, 64) / lkk;
+        if (tid == k) xi = xk;
+        if (tid < k) xi = __builtin_fma(-P[(size_t)(b0 + k) * np + b0 + tid], xk, xi);
+      }
+      sz[tid] = xi; z[b0 + tid] = xi;
+    }
+    __syncthreads();
+    // rows above: z[i] -= sum_k L[b0+k][i] x[b0+k]  (column access of L: coalesced across i)
+    for (int i = tid; i < b0; i += 1024) {
+      double acc = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < TB; ++k) acc = __builtin_fma(P[(size_t)(b0 + k) * np + i], sz[k], acc);
+      z[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) x_out[i] = z[i];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+template <int COV>
+static void launch_cov(bool d3, const double4* pts, int n, int np, double var, double a, double nugget, const double* gtab,
+                       double* P, hipStream_t st) {
+  const int nt = np / TB;
+  const int ntiles = nt * (nt + 1) / 2;
+  if (d3) hipLaunchKernelGGL((dense_cov_lower_kernel<COV, true>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);
+  else hipLaunchKernelGGL((dense_cov_lower_kernel<COV, false>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);
+}
+
+hipError_t launch_dense_cov(int cov, bool d3, const double4* pts, int n, int np, double var, double a, double nugget,
+                            const double* gtab, double* P, hipStream_t st) {
+  switch (cov) {
+    case kMatern05: launch_cov<kMatern05>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
+    case kMatern15: launch_cov<kMatern15>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
+    case kMatern25: launch_cov<kMatern25>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st) {
+  const int nt = np / TB;
+  for (int kb = 0; kb < nt; ++kb) {
+    const int k0 = kb * TB;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, P, np, k0, info);
+    const int rows_below = np - k0 - TB;
+    if (rows_below <= 0) break;
+    hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
+    const int ntr = rows_below / TB;
+    hipLaunchKernelGGL(syrk_mfma_kernel, dim3(ntr * (ntr + 1) / 2), dim3(64), 0, st, P, np, k0);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_solve(const double* P, int n, int np, const double* y, double* z, double* out, double* x_out,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(trsv_lower_kernel, dim3(1), dim3(1024), 0, st, P, n, np, y, z, out, x_out);
+  return hipGetLastError();
+}
+
+}  // namespace gpb

@@ -28,29 +28,43 @@ __device__ __forceinline__ void static_for_down(F&& f) {
 }
 
 // ---- fp64 DPP within a row of 16 lanes ------------------------------------
-// gfx90a+ allows DPP on the DP ALU only with row_newbcast:N (lane N of each
-// 16-lane row is broadcast to the row).  There is no clang builtin for the
-// 64-bit form, hence inline asm.  The compiler neither sees the DPP nor pads
-// its hazard ("VALU writes VGPR -> DPP reads that VGPR: 2 wait states"), so each
-// statement opens with s_nop 1.  All 64 lanes must be active (a disabled source
-// lane would read as 0): the kernels below never early-exit a lane.
+// gfx90a+ allows DPP on the DP ALU only with row_newbcast:N (lane N of each 16-lane row is broadcast to
+// the row).  There is no clang builtin for the 64-bit form, hence inline asm.  Measured on MI355X
+// (scripts/ubench/fp64_rates.hip): v_fmac_f64_dpp issues at the plain v_fmac_f64 rate (4 cycles per wave).
+//
+// Hazard: "VALU writes VGPR -> DPP reads that VGPR" needs 2 wait states, and the compiler neither sees the
+// DPP inside an asm statement nor pads for it.  row_bcast() therefore opens with s_nop 1.  row_fnma() -- issued
+// ~600 times per point, where the nops cost ~12 % of the kernel -- carries NO padding: the statements are
+// `volatile` (program order is kept) and the elimination is written so that a DPP source register is always
+// produced several instructions earlier; scripts/check_dpp_hazards.py verifies that property on the generated
+// ISA of every translation unit at build time and fails the build otherwise.
+// All 64 lanes must be active (a disabled source lane would read as 0): the kernels never early-exit a lane.
 template <int LANE>
 __device__ __forceinline__ double row_bcast(double x) {
   static_assert(LANE >= 0 && LANE < 16, "row_newbcast lane");
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-      : "=v"(r)
-      : "v"(x), "n"(LANE));
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+               : "=v"(r)
+               : "v"(x), "n"(LANE));
   return r;
 }
 // acc -= bcast<LANE>(b) * own      (one v_fmac_f64 with the broadcast folded in)
 template <int LANE>
 __device__ __forceinline__ void row_fnma(double& acc, double b, double own) {
   static_assert(LANE >= 0 && LANE < 16, "row_newbcast lane");
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc)
-      : "v"(b), "v"(own), "n"(LANE));
+#ifdef GPB_DPP_PAD_EVERY_FMAC
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(b), "v"(own), "n"(LANE));
+#else
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(b), "v"(own), "n"(LANE));
+#endif
 }
+// Explicit hazard fence: makes the listed values opaque (they must exist before this point) and supplies the two
+// wait states, so that DPP reads of them further down are safe whatever the compiler scheduled just before.
+__device__ __forceinline__ void dpp_fence(double& a) { asm volatile("s_nop 1" : "+v"(a)); }
 // Portable-in-HIP variant of the same two primitives (two 32-bit DPP movs that the
 // compiler schedules and pads itself).  Used by the self-test kernel to validate the
 // asm forms on the device, and selectable with -DGPB_DPP_VIA_BUILTIN for debugging.

@@ -45,13 +45,14 @@ struct REModelHip {
   int cov_type = 0;
   std::vector<int> perm;        // data_indices_per_cluster_: Vecchia position -> data index
   gpb_hip_vecchia_t* vh = nullptr;
+  gpb_hip_exact_t* eh = nullptr;   // gp_approx == "none": dense path, data order (no Vecchia ordering)
   std::vector<double> ybuf;     // y in Vecchia order
   double cur_negll = 0.;
   bool negll_valid = false;
   bool has_duplicates = false;
   bool trace = false;
   std::string likelihood = "gaussian";
-  ~REModelHip() { if (vh) gpb_hip_vecchia_free(vh); }
+  ~REModelHip() { if (vh) gpb_hip_vecchia_free(vh); if (eh) gpb_hip_exact_free(eh); }
 };
 
 bool near(double a, double b) { return std::fabs(a - b) < 1e-10 * std::max({1.0, std::fabs(a), std::fabs(b)}); }  // utils.h:55
@@ -80,6 +81,7 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects)
   } else {
     for (int k = 0; k < n; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]];
   }
+  if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); return 0; }
   if (gpb_hip_vecchia_set_y(mdl->vh, mdl->ybuf.data())) return shim_error();
   return 0;
 }
@@ -137,7 +139,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     else if (near(cov_fct_shape, 2.5)) cov_type = 2;
   }
   if (cov_type < 0) return set_error("GPB_CreateREModel: cov_fct '%s' (shape %g) %s", cov.c_str(), cov_fct_shape, scope);
-  if (approx != "vecchia") return set_error("GPB_CreateREModel: gp_approx '%s' %s", approx.c_str(), scope);
+  if (approx != "vecchia" && approx != "none") return set_error("GPB_CreateREModel: gp_approx '%s' %s", approx.c_str(), scope);
   if (lik != "gaussian") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
   if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
   if (num_data < 2) return set_error("GPB_CreateREModel: num_data = %d", num_data);
@@ -147,6 +149,12 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type;
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
+  if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
+    if (gpb_hip_exact_create(num_data, dim_gp_coords, gp_coords_data, &mdl->eh)) return shim_error();
+    mdl->m = 0;
+    *out = mdl.release();
+    return 0;
+  }
   if (ordering == "random") {
     std::mt19937 rng(seed);                                        // re_model_template.h:161, type_defs.h:52
     std::shuffle(mdl->perm.begin(), mdl->perm.end(), rng);         // Vecchia_utils.cpp:1129-1131
@@ -188,8 +196,9 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
-  double t3[3];
-  if (gpb_hip_vecchia_nll_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], 1, t3)) return shim_error();
+  double t3[3] = {0., 0., 0.};
+  if (mdl->eh) { if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t3, nullptr, nullptr)) return shim_error(); }
+  else if (gpb_hip_vecchia_nll_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], 1, t3)) return shim_error();
   mdl->cur_negll = negll_from_terms(mdl->n, t3[0], t3[1], tr[0]);
   mdl->negll_valid = true;
   *negll = mdl->cur_negll;
@@ -219,6 +228,7 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll || !grad3 || !cov_pars) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: null argument");
+  if (mdl->eh) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the exact (dense) GP are not on the MI355X hot path of this library yet");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
@@ -240,6 +250,11 @@ int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_par
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, nullptr)) return -1;
+  if (mdl->eh) {
+    double t2[2];
+    if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t2, y_aux, nullptr)) return shim_error();
+    return 0;
+  }
   if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
   std::vector<double> ya(mdl->n);
   if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
@@ -251,6 +266,7 @@ int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl) return set_error("GPB_HIP_GetVecchiaStructure: null handle");
+  if (mdl->eh) return set_error("GPB_HIP_GetVecchiaStructure: the model is an exact GP (gp_approx = 'none')");
   if (perm) std::copy(mdl->perm.begin(), mdl->perm.end(), perm);
   if (m_out) *m_out = mdl->m;
   if (nn && gpb_hip_vecchia_get_neighbors(mdl->vh, nn)) return shim_error();

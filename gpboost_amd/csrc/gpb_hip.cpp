@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "dense_kernels.h"
 #include "hist_kernels.h"
 #include "nn_kernels.h"
 #include "vecchia_kernels.h"
@@ -87,6 +88,17 @@ struct gpb_hip_vecchia {
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false;
   std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
   std::vector<int> nn_host;
+};
+
+struct gpb_hip_exact {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n = 0, d = 0, np = 0;
+  double4* d_pts = nullptr;
+  double* d_P = nullptr; double* d_y = nullptr; double* d_z = nullptr; double* d_x = nullptr; double* d_out = nullptr;
+  double* d_exp_tab = nullptr;
+  int* d_info = nullptr;
+  bool has_y = false;
 };
 
 struct gpb_hip_hist {
@@ -352,7 +364,7 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
   if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
   const int nblocks = (h->i_end - h->i_begin + 15) / 16;
-  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, h->d_out, h->stream));
+  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, h->stream));
   if (out_dev) {
     // reorder to the documented layout {quad, logdet, bad, ...}
     // d_out = {logdet, quad, bad, g1v, g2v, g1r, g2r}
@@ -496,6 +508,90 @@ int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) {
   HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->d_v, h->d_w, h->stream));
   HIP_OK(hipMemcpyAsync(yaux_host, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+// ------------------------------------------------------------------------------------------
+int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gpb_hip_exact_t** out) {
+  API_BEGIN();
+  if (!out) return fail("gpb_hip_exact_create: out is NULL");
+  *out = nullptr;
+  if (check_device()) return -1;
+  if (n < 1 || d < 1 || d > 3 || !coords_colmajor) return fail("gpb_hip_exact_create: invalid arguments (n = %d, d = %d; d in 1..3)", n, d);
+  if (n > 100000) return fail("gpb_hip_exact_create: n = %d is too large for the dense path (use gp_approx = 'vecchia')", n);
+  auto* h = new gpb_hip_exact();
+  h->n = n; h->d = d; h->np = ((n + 63) / 64) * 64;
+  HIP_OK(hipGetDevice(&h->device));
+  HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  std::vector<double4> pts(n);
+  for (int i = 0; i < n; ++i) {
+    pts[i].x = coords_colmajor[i];
+    pts[i].y = d > 1 ? coords_colmajor[(size_t)n + i] : 0.0;
+    pts[i].z = d > 2 ? coords_colmajor[(size_t)2 * n + i] : 0.0;
+    pts[i].w = 0.0;
+  }
+  HIP_OK(hipMalloc(&h->d_pts, sizeof(double4) * (size_t)n));
+  HIP_OK(hipMemcpy(h->d_pts, pts.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_P, sizeof(double) * (size_t)h->np * h->np));
+  HIP_OK(hipMalloc(&h->d_y, sizeof(double) * (size_t)h->np));
+  HIP_OK(hipMalloc(&h->d_z, sizeof(double) * (size_t)h->np));
+  HIP_OK(hipMalloc(&h->d_x, sizeof(double) * (size_t)h->np));
+  HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 2));
+  HIP_OK(hipMalloc(&h->d_info, sizeof(int)));
+  const std::vector<double> tab = exp_table();
+  HIP_OK(hipMalloc(&h->d_exp_tab, 64 * sizeof(double)));
+  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+  *out = h;
+  API_END();
+}
+
+int gpb_hip_exact_free(gpb_hip_exact_t* h) {
+  API_BEGIN();
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  dev_free(h->d_pts); dev_free(h->d_P); dev_free(h->d_y); dev_free(h->d_z); dev_free(h->d_x); dev_free(h->d_out);
+  dev_free(h->d_exp_tab); dev_free(h->d_info);
+  delete h;
+  API_END();
+}
+
+int gpb_hip_exact_set_y(gpb_hip_exact_t* h, const double* y_host) {
+  API_BEGIN();
+  if (!h || !y_host) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpyAsync(h->d_y, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->has_y = true;
+  API_END();
+}
+
+int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double a, double* out2_host, double* yaux_host,
+                            double* ms3) {
+  API_BEGIN();
+  if (!h || !out2_host) return fail("null argument");
+  if (!h->has_y) return fail("response data has not been set (call gpb_hip_exact_set_y)");
+  if (cov_type < 0 || cov_type > 2) return fail("covariance type %d is not on the HIP hot path (Matern 0.5/1.5/2.5 only)", cov_type);
+  if (!(var > 0.) || !(a > 0.)) return fail("covariance parameters must be positive (var = %g, range = %g)", var, a);
+  HIP_OK(hipSetDevice(h->device));
+  hipEvent_t e[4];
+  for (auto& ev : e) HIP_OK(hipEventCreate(&ev));
+  HIP_OK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  HIP_OK(hipEventRecord(e[0], h->stream));
+  HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, h->np, var, a, 1.0, h->d_exp_tab, h->d_P, h->stream));   // Psi = Sigma + I (:9273-9287)
+  HIP_OK(hipEventRecord(e[1], h->stream));
+  HIP_OK(gpb::launch_dense_cholesky(h->d_P, h->np, h->d_info, h->stream));
+  HIP_OK(hipEventRecord(e[2], h->stream));
+  HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream));
+  HIP_OK(hipEventRecord(e[3], h->stream));
+  int info = 0;
+  HIP_OK(hipMemcpyAsync(out2_host, h->d_out, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (yaux_host) HIP_OK(hipMemcpyAsync(yaux_host, h->d_x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (ms3) for (int t = 0; t < 3; ++t) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e[t], e[t + 1])); ms3[t] = ms; }
+  for (auto& ev : e) (void)hipEventDestroy(ev);
+  if (info != 0) return fail("the covariance matrix is not positive definite (dense Cholesky failed)");
   API_END();
 }
 

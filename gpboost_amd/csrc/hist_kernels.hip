@@ -10,9 +10,9 @@
 //   * bins are re-laid out once, at create time, from the reference's feature-major storage to
 //     row-major [n][fpad]: a leaf's (gathered) rows then cost one 16-byte access per 16 features
 //     instead of one byte per cache line;
-//   * a workgroup owns 16 features x one chunk of rows; lane l of every 16-lane row handles feature
-//     l, so the 4 rows a wavefront processes per step never collide on an LDS histogram except when
-//     two rows share a bin of the same feature;
+//   * a workgroup owns 16 features x one chunk of rows; one lane = one row: a 16-byte load brings the
+//     row's 16 bins, then the lane issues 16 LDS atomics -- at any instant all lanes of a wavefront update
+//     the SAME feature's sub-histogram, so they only collide when two rows share a bin;
 //   * sub-histograms are privatised in LDS (ds_add_f64 / ds_add_u32), written out per chunk and
 //     summed over chunks in a fixed order by a second kernel: counts are exact (and therefore
 //     reproducible); the fp64 sums depend on the LDS-atomic arrival order inside a chunk, i.e. they
@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
   __shared__ double s_hess[HAS_HESS ? GPB_HIST_FG : 1][HAS_HESS ? GPB_HIST_MAX_BIN + 1 : 1];
   __shared__ uint32_t s_cnt[GPB_HIST_FG][GPB_HIST_MAX_BIN + 1];
   const int tid = threadIdx.x;
-  const int f = tid & 15, rsub = tid >> 4;
-  const int chunk = blockIdx.x, fg = blockIdx.y;
+  const int fg = blockIdx.x, chunk = blockIdx.y;   // the feature groups of one chunk are adjacent in dispatch order:
+                                                   // they read the same 64-byte row segments while those are cache-hot
   for (int t = tid; t < GPB_HIST_FG * (GPB_HIST_MAX_BIN + 1); t += 256) {
     (&s_grad[0][0])[t] = 0.0;
     (&s_cnt[0][0])[t] = 0u;
@@ -37,21 +37,32 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
   __syncthreads();
   const int r0 = chunk * a.rows_per_chunk;
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
-  const uint8_t* col = a.bins_rm + (size_t)fg * GPB_HIST_FG + f;
-  for (int r = r0 + rsub; r < r1; r += 16) {
+  const uint8_t* base = a.bins_rm + (size_t)fg * GPB_HIST_FG;
+  // one lane = one row: a 16-byte load brings the row's 16 bins of this feature group, the gradient load is
+  // coalesced across the wavefront (or gathered through data_indices for a leaf)
+  for (int r = r0 + tid; r < r1; r += 256) {
     const int row = HAS_IDX ? a.data_indices[r] : r;
-    const int b = col[(size_t)row * a.fpad];
-    atomicAdd(&s_grad[f][b], a.grad[row]);
-    atomicAdd(&s_cnt[f][b], 1u);
-    if constexpr (HAS_HESS) atomicAdd(&s_hess[f][b], a.hess[row]);
+    const uint4 bv = *reinterpret_cast<const uint4*>(base + (size_t)row * a.fpad);
+    const double g = a.grad[row];
+    double h = 0.0;
+    if constexpr (HAS_HESS) h = a.hess[row];
+    const uint32_t w[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int f = 0; f < GPB_HIST_FG; ++f) {
+      const int b = (w[f >> 2] >> (8 * (f & 3))) & 0xff;
+      atomicAdd(&s_grad[f][b], g);
+      if constexpr (HAS_HESS) atomicAdd(&s_hess[f][b], h);
+      else atomicAdd(&s_cnt[f][b], 1u);
+      if constexpr (HAS_HESS) atomicAdd(&s_cnt[f][b], 1u);
+    }
   }
   __syncthreads();
-  const size_t base = ((size_t)chunk * a.fpad + (size_t)fg * GPB_HIST_FG) * GPB_HIST_MAX_BIN;
+  const size_t pbase = ((size_t)chunk * a.fpad + (size_t)fg * GPB_HIST_FG) * GPB_HIST_MAX_BIN;
   for (int t = tid; t < GPB_HIST_FG * GPB_HIST_MAX_BIN; t += 256) {
     const int ff = t >> 8, b = t & 255;
-    a.part_grad[base + t] = s_grad[ff][b];
-    a.part_cnt[base + t] = s_cnt[ff][b];
-    if constexpr (HAS_HESS) a.part_hess[base + t] = s_hess[ff][b];
+    a.part_grad[pbase + t] = s_grad[ff][b];
+    a.part_cnt[pbase + t] = s_cnt[ff][b];
+    if constexpr (HAS_HESS) a.part_hess[pbase + t] = s_hess[ff][b];
   }
 }
 
@@ -94,7 +105,7 @@ __global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* _
 }
 
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
-  dim3 grid(a.nchunks, a.fpad / GPB_HIST_FG), block(256);
+  dim3 grid(a.fpad / GPB_HIST_FG, a.nchunks), block(256);
   const bool hh = a.hess != nullptr, hi = a.data_indices != nullptr;
   if (hh && hi) hipLaunchKernelGGL((hist_build_kernel<true, true>), grid, block, 0, st, a);
   else if (hh) hipLaunchKernelGGL((hist_build_kernel<true, false>), grid, block, 0, st, a);

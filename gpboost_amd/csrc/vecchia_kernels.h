@@ -29,7 +29,7 @@ struct VecchiaKernelArgs {
   const double4* pts;      // [n] {x0, x1, x2, y} in Vecchia order
   const int* nn;           // [n][m] neighbour indices, -1 padded
   const double* exp_tab;   // [64] 2^(j/64)
-  double* partials;        // [nblocks][GPB_NUM_PARTIALS]
+  double* partials;        // [GPB_NUM_PARTIALS][nblocks]  (term-major)
   double* A;               // MODE_FACTOR: [n][m]
   double* D;               // MODE_FACTOR: [n]
   double* u;               // MODE_FACTOR: [n]  (B y)
@@ -44,7 +44,7 @@ struct VecchiaKernelArgs {
 
 int vecchia_padded_m(int m);
 hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
-hipError_t launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, const double* v, double* w,

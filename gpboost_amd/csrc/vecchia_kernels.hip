@@ -37,43 +37,114 @@ namespace gpb {
 
 namespace {
 
-// Dummy neighbours sit kDummySpacing apart: far enough that every kernel value underflows to exactly 0
-// (a * 1e30 >> 745, checked on the host), small enough that r^3 stays finite in the Matern-2.5 derivative.
-constexpr double kDummySpacing = 1e30;
+// Dummy (padding) neighbours are placed kDummyCoord * (row + 1) away in *scaled* coordinates: the
+// scaled distance r' >= 1e30 makes every kernel value underflow to exactly 0 (v_cvt_i32_f64 saturates,
+// v_ldexp_f64 flushes), while r'^3 stays finite for the Matern-2.5 derivative.
+constexpr double kDummyCoord = 1e30;
+constexpr double kLn2Over64 = 0.010830424696249145;   // ln2 / 64
+constexpr double k64OverLn2 = 92.332482616893657;     // 64 / ln2
+
+// Row r of the augmented system lives in register slot r/16 and, inside its 16-lane DPP row, in lane
+// r%16 for even slots and 15 - r%16 for odd slots.  Reversing the odd slots makes the triangular part of
+// slot s (valid lanes: the upper ones) and of slot s+1 (valid lanes: the lower ones) complementary, so one
+// kernel evaluation per lane fills both (see assemble()).
+__host__ __device__ constexpr int lane_of_row(int r) { return ((r / 16) & 1) ? 15 - (r % 16) : (r % 16); }
 
 template <int MT>
 struct Layout {
   static_assert(MT >= 1 && MT <= 62, "1 <= MT <= 62");
   static_assert(MT % 16 != 15, "row MT and row MT+1 must share a register slot");
-  static constexpr int R = MT + 2;                 // rows
+  static constexpr int R = MT + 2;                 // rows 0..MT-1 neighbours, MT the point, MT+1 the responses
   static constexpr int NS = (R + 15) / 16;         // register slots per lane
-  static constexpr int PS = MT / 16, PL = MT % 16; // slot / lane of the point's own row
-  static constexpr int YS = (MT + 1) / 16, YL = (MT + 1) % 16;  // y-row
+  static constexpr int PS = MT / 16, PL = lane_of_row(MT);            // slot / lane of the point's own row
+  static constexpr int YS = (MT + 1) / 16, YL = lane_of_row(MT + 1);  // slot / lane of the response row
   static constexpr int NCOL = MT + 1;              // columns 0..MT
+  static constexpr int PTS_STRIDE = NS * 16 + 1;   // LDS records per point group (+1: bank spread)
   __host__ __device__ static constexpr int cmax(int s) { return (16 * s + 15 < MT) ? 16 * s + 15 : MT; }
 };
 
+struct Rec { double x, y, z, w; };   // scaled, centred coordinates + response (w)
+
+// scaled squared distance + 1e-300 (keeps rsq finite for duplicates)
 template <bool D3>
-__device__ __forceinline__ double sq_dist(const double4& p, const double4& q) {
-  const double dx = p.x - q.x, dy = p.y - q.y;
-  double d2 = dx * dx;
+__device__ __forceinline__ double sq_dist_s(double px, double py, double pz, double qx, double qy, double qz) {
+  const double dx = px - qx, dy = py - qy;
+  double d2 = __builtin_fma(dx, dx, 1e-300);
   d2 = __builtin_fma(dy, dy, d2);
   if constexpr (D3) {
-    const double dz = p.z - q.z;
+    const double dz = pz - qz;
     d2 = __builtin_fma(dz, dz, d2);
   }
   return d2;
 }
 
-// d/d log(a) of the kernel, transformed scale (transf_scale == true):
-// include/GPBoost/cov_fcts.h:2182-2193 (cm) and :2535-2554.
+// Everything a kernel evaluation needs, from the scaled squared distance d2s = (a d 64/ln2)^2:
+//   ev = var * exp(-a d)   (tabv already carries var),   rp = a d 64/ln2
+struct KernEval { double ev, rp; };
+__device__ __forceinline__ KernEval exp_of_scaled(double d2s, const double* __restrict__ tabv) {
+  const double rs = __builtin_amdgcn_rsq(d2s);
+  const double g = d2s * rs, h = 0.5 * rs;
+  const double e = __builtin_fma(-h, g, 0.5);
+  const double rp = __builtin_fma(g, e, g);                 // sqrt(d2s), one Newton step on v_rsq_f64
+  const double kf = __builtin_rint(-rp);
+  const double rr = -rp - kf;                               // exact; |rr| <= 1/2, in units of ln2/64
+  const int k = (int)kf;                                    // saturates for the dummy rows
+  // exp(rr ln2/64) = sum_j (ln2/64)^j rr^j / j!, j <= 5  (remainder < 2e-17)
+  double p = __builtin_fma(rr, 1.2417843701716925e-12, 5.732851688640402e-10);
+  p = __builtin_fma(p, rr, 2.1173137155464776e-07);
+  p = __builtin_fma(p, rr, 5.86490495505617e-05);
+  p = __builtin_fma(p, rr, kLn2Over64);
+  p = __builtin_fma(p, rr, 1.0);
+  KernEval o;
+  o.ev = __builtin_ldexp(tabv[k & 63] * p, k >> 6);
+  o.rp = rp;
+  return o;
+}
+// include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5), transformed scale
 template <int COV>
-__device__ __forceinline__ double matern_dlog_range(double dist, double var, double a, const double* tab) {
-  const double r = a * dist;
-  const double e = fast_exp_neg(-r, tab);
-  if constexpr (COV == kMatern05) return -r * var * e;                       // cm d sigma, cm = -a
-  else if constexpr (COV == kMatern15) return -var * r * r * e;              // cm d^2 e^{-ad}, cm = -var a^2
-  else return -var * (1.0 / 3.0) * r * r * __builtin_fma(1.0, r, 1.0) * e;   // cm/3 d^2 (1+ad) e^{-ad}
+__device__ __forceinline__ double matern_cov_s(double d2s, const double* __restrict__ tabv) {
+  const KernEval k = exp_of_scaled(d2s, tabv);
+  if constexpr (COV == kMatern05) return k.ev;
+  else if constexpr (COV == kMatern15) return k.ev * __builtin_fma(k.rp, kLn2Over64, 1.0);
+  else { const double r = k.rp * kLn2Over64; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
+}
+// d/d log(a) of the kernel (transf_scale == true): include/GPBoost/cov_fcts.h:2182-2193 (cm), :2535-2554
+template <int COV>
+__device__ __forceinline__ double matern_dlog_range_s(double d2s, const double* __restrict__ tabv) {
+  const KernEval k = exp_of_scaled(d2s, tabv);
+  const double r = k.rp * kLn2Over64;
+  if constexpr (COV == kMatern05) return -r * k.ev;                                 // cm d sigma, cm = -a
+  else if constexpr (COV == kMatern15) return -(r * r) * k.ev;                      // cm d^2 e^{-ad}, cm = -var a^2
+  else return -(1.0 / 3.0) * (r * r) * __builtin_fma(1.0, r, 1.0) * k.ev;           // cm/3 d^2 (1+ad) e^{-ad}
+}
+
+// Visits every strictly-lower entry (row r <= MT, column c < r) of the augmented system exactly once per owning
+// lane, as a list of compile-time "steps"; in a step every lane evaluates ONE entry:
+//   rect(s, c)                : all 16 lanes of slot s, column c < 16 s
+//   pair(sA, cA, sB, cB, J)   : lanes l <= J take entry (slot sA, column cA), lanes l > J take (slot sB, column cB)
+//   solo(s, c)                : slot s, column c inside the slot's own triangle (only lanes whose row > c are meaningful)
+template <int MT, class FR, class FP, class FS>
+__device__ __forceinline__ void for_each_lower_step(FR&& rect, FP&& pair, FS&& solo) {
+  using L = Layout<MT>;
+  static_for<1, L::NS>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    static_for<0, 16 * s>([&](auto c_) { rect(s_, c_); });
+  });
+  static_for<0, L::NS>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    if constexpr ((s & 1) == 1) {
+      static_for<0, 15>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        constexpr int cA = 16 * s + j, cB = 16 * (s - 1) + 14 - j;
+        if constexpr (cA <= MT - 1) pair(s_, std::integral_constant<int, cA>{}, std::integral_constant<int, s - 1>{},
+                                         std::integral_constant<int, cB>{}, std::integral_constant<int, 14 - j>{});
+        else solo(std::integral_constant<int, s - 1>{}, std::integral_constant<int, cB>{});
+      });
+    } else if constexpr (s == L::NS - 1) {   // unpaired last (even) slot
+      constexpr int chi = (16 * s + 14 < MT - 1) ? 16 * s + 14 : MT - 1;
+      static_for<16 * s, chi + 1>([&](auto c_) { solo(s_, c_); });
+    }
+  });
 }
 
 }  // namespace
@@ -86,73 +157,111 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   using L = Layout<MT>;
   constexpr int NS = L::NS;
   constexpr bool kNeedSolve = (MODE != MODE_NLL);
+  constexpr int NP = (MODE == MODE_GRAD) ? GPB_NUM_PARTIALS : 3;
 
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
-  __shared__ double4 s_pts[16][NS * 16];
+  __shared__ Rec s_pts[16][L::PTS_STRIDE];
   __shared__ double s_red[GPB_NUM_PARTIALS][16];
-  __shared__ double s_inv[kNeedSolve ? 16 : 1][kNeedSolve ? MT : 1];
-  __shared__ double s_A[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? MT + 2 : 1];
-  __shared__ double s_b[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? MT + 2 : 1];
+  __shared__ double s_A[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? NS * 16 + 1 : 1];
+  __shared__ double s_b[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? NS * 16 + 1 : 1];
 
   const int tid = threadIdx.x;
   const int g = tid >> 4;   // point within the workgroup
   const int l = tid & 15;   // lane within the point's DPP row
-  fill_exp_table(s_tab, args.exp_tab);
+  if (tid < GPB_EXP_TAB_SIZE) s_tab[tid] = args.exp_tab[tid] * args.var;   // var * 2^(j/64)
 
   const long long i_raw = (long long)args.i_begin + (long long)blockIdx.x * 16 + g;
   const bool active = i_raw < (long long)args.i_end;
   const int i = active ? (int)i_raw : args.i_end - 1;   // inactive groups redo the last point, contribute 0
   const int m = args.m;
-  const double var = args.var, a = args.a;
+  const double sc = args.a * k64OverLn2;                // coordinates are scaled so that exp(-a d) = 2^(-r'/64)
 
-  // ---- gather the rows' records ------------------------------------------------
-  double4 own[NS];
+  // ---- gather the rows' records: centred on the point (differences of nearby points stay accurate for
+  //      coordinates with a large offset), scaled, staged in LDS for the column operands ------------------
+  const double4 ctr = args.pts[i];
+  Rec own[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int r = 16 * s + l;
+    const int r = 16 * s + ((s & 1) ? 15 - l : l);
     int idx = -1;
     if (r < m) idx = args.nn[(size_t)i * m + r];
     else if (r == MT) idx = i;
-    double4 p;
-    if (idx >= 0) p = args.pts[idx];
-    else p = make_double4(kDummySpacing * (double)(r + 1), 0.0, 0.0, 0.0);
+    Rec p;
+    if (idx >= 0) {
+      const double4 q = args.pts[idx];
+      p.x = (q.x - ctr.x) * sc; p.y = (q.y - ctr.y) * sc; p.z = D3 ? (q.z - ctr.z) * sc : 0.0; p.w = q.w;
+    } else {
+      p.x = kDummyCoord * (double)(r + 1); p.y = 0.0; p.z = 0.0; p.w = 0.0;
+    }
     own[s] = p;
     s_pts[g][r] = p;
   }
   __syncthreads();
+  const double* tabv = s_tab;
+  const Rec* gp = s_pts[g];
 
   // ---- assemble the augmented matrix, row-per-lane, in registers ----------------
   // include/GPBoost/cov_fcts.h:634-755 (CalculateCovMat) + Vecchia_utils.cpp:1599-1609
   double M[NS][L::NCOL];
+  for_each_lower_step<MT>(
+      [&](auto s_, auto c_) {                                     // rect
+        constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
+        const Rec q = gp[c];
+        M[s][c] = matern_cov_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+      },
+      [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_) {      // pair
+        constexpr int sA = decltype(sA_)::value, cA = decltype(cA_)::value, sB = decltype(sB_)::value,
+                      cB = decltype(cB_)::value, J = decltype(J_)::value;
+        const bool selA = l <= J;
+        const Rec q = gp[selA ? cA : cB];
+        const double ox = selA ? own[sA].x : own[sB].x, oy = selA ? own[sA].y : own[sB].y;
+        const double oz = D3 ? (selA ? own[sA].z : own[sB].z) : 0.0;
+        const double v = matern_cov_s<COV>(sq_dist_s<D3>(ox, oy, oz, q.x, q.y, q.z), tabv);
+        M[sA][cA] = v;    // lanes of the other half hold entries above the diagonal there: never read
+        M[sB][cB] = v;
+      },
+      [&](auto s_, auto c_) {                                     // solo
+        constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
+        const Rec q = gp[c];
+        M[s][c] = matern_cov_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+      });
+  // diagonal: nugget / jitter (Vecchia_utils.cpp:1599-1609) and the first summand of D_i (:1555-1563)
   static_for<0, NS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
-    static_for<0, L::cmax(s) + 1>([&](auto c_) {
+    static_for<16 * s, L::cmax(s) + 1>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
-      const double4 q = s_pts[g][c];
-      double v = matern_cov<COV>(fast_sqrt(sq_dist<D3>(own[s], q)), var, a, s_tab);
-      if constexpr (c >= 16 * s) v = (l == c - 16 * s) ? ((c == MT) ? args.diag_i : args.diag_nn) : v;
-      if constexpr (s == L::YS) v = (l == L::YL) ? q.w : v;
-      M[s][c] = v;
+      const double dg = (c == MT) ? args.diag_i : args.diag_nn;
+      if constexpr (c == 16 * s + 15 || c == MT) M[s][c] = dg;     // column never evaluated: plain init
+      else M[s][c] = (l == lane_of_row(c)) ? dg : M[s][c];
     });
   });
+  // response row: entries are the gathered y's (only lane YL of slot YS; exec-masked, no DPP inside)
+  if (l == L::YL) {
+    static_for<0, MT + 1>([&](auto c_) { M[L::YS][decltype(c_)::value] = gp[decltype(c_)::value].w; });
+  }
 
-  // ---- right-looking elimination of columns 0..MT-1 -----------------------------
-  // stands in for Eigen LLT + solve (Vecchia_utils.cpp:1617-1623)
+  // ---- right-looking LDL^T elimination of columns 0..MT-1 ------------------------
+  // stands in for Eigen LLT + solve (Vecchia_utils.cpp:1617-1623); leaves unit-lower L (scaled) in M[.][k<MT],
+  // D_i in entry (MT, MT) and u_i = (B y)_i in entry (MT+1, MT)
   static_for<0, MT>([&](auto k_) {
     constexpr int k = decltype(k_)::value;
-    constexpr int sk = k / 16, lk = k % 16;
+    constexpr int sk = k / 16, lk = lane_of_row(k);
+    // column-k registers become DPP sources in this sweep: fence them (they were last written by the assembly
+    // for k == 0, by sweep k-1's first fmacs otherwise -- the verifier checks the generated code either way)
+    if constexpr (k == 0) static_for<0, NS>([&](auto s_) { dpp_fence(M[decltype(s_)::value][0]); });
     const double piv = GPB_ROW_BCAST(lk, M[sk][k]);
-    const double inv = fast_rsqrt(piv);
-    if constexpr (kNeedSolve) { if (l == 0) s_inv[g][k] = inv; }
-    static_for<sk, NS>([&](auto s_) { M[decltype(s_)::value][k] *= inv; });
+    const double inv = fast_rcp(piv);
+    double T[NS];
+    static_for<sk, NS>([&](auto s_) { T[decltype(s_)::value] = M[decltype(s_)::value][k] * inv; });
     static_for<k + 1, MT + 1>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
-      constexpr int sc = c / 16, lc = c % 16;
-      static_for<sc, NS>([&](auto s_) {
+      constexpr int sc_ = c / 16, lc = lane_of_row(c);
+      static_for<sc_, NS>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
-        GPB_ROW_FNMA(lc, M[s][c], M[sc][k], M[s][k]);
+        GPB_ROW_FNMA(lc, M[s][c], M[sc_][k], T[s]);   // M[r][c] -= (L[c][k] d_k) * L[r][k]
       });
     });
+    if constexpr (kNeedSolve) static_for<sk, NS>([&](auto s_) { M[decltype(s_)::value][k] = T[decltype(s_)::value]; });
   });
 
   const double Dv = GPB_ROW_BCAST(L::PL, M[L::PS][MT]);   // D_i  (Vecchia_utils.cpp:1623; the reference stores 1/D_i, :1682)
@@ -167,21 +276,21 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   red[GPB_P_BAD] = (Dv > 0.0) ? 0.0 : 1.0;
 
   if constexpr (kNeedSolve) {
-    // ---- back-substitution x = L^-T (row), for the point's row (-> A_i) and the y-row (-> b_i = C^-1 y_nn)
+    // ---- back-substitution x = L^-T (row of L), L unit lower: for the point's row (-> A_i, Vecchia_utils.cpp:1618)
+    //      and, in the same instructions, the response row (-> b_i = C^-1 y_nn) ------------------------------
     double X[MT];
     static_for<0, MT>([&](auto k_) { X[decltype(k_)::value] = M[L::PS][decltype(k_)::value]; });
-    __syncthreads();   // s_inv visible
+    // the scaled L columns were written by plain multiplies (compiler-scheduled): fence before the DPP reads
+    static_for<0, MT>([&](auto k_) { static_for<0, NS>([&](auto s_) { if constexpr (decltype(k_)::value <= L::cmax(decltype(s_)::value)) dpp_fence(M[decltype(s_)::value][decltype(k_)::value]); }); });
     static_for_down<0, MT>([&](auto j_) {
       constexpr int j = decltype(j_)::value;
-      constexpr int sj = j / 16, lj = j % 16;
-      const double xj = X[j] * s_inv[g][j];
-      X[j] = xj;
+      constexpr int sj = j / 16, lj = lane_of_row(j);
       static_for<0, j>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
-        GPB_ROW_FNMA(lj, X[k], M[sj][k], xj);
+        GPB_ROW_FNMA(lj, X[k], M[sj][k], X[j]);
       });
     });
-    // lane PL now holds A_i (Vecchia_utils.cpp:1618), lane YL holds b_i.  No DPP below this line.
+    // lane PL now holds A_i, lane YL holds b_i.  No DPP below this line.
     if constexpr (MODE == MODE_FACTOR) {
       if (active && l == L::PL) {
         double* Arow = args.A + (size_t)i * m;
@@ -193,31 +302,58 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
       if (active && l == 0) { args.D[i] = Dv; args.u[i] = uv; }
     }
     if constexpr (MODE == MODE_GRAD) {
-      // extended vectors over rows 0..MT: At = (A, -1), bt = (b, 0); y-row gets (0, 0)
+      // extended vectors over rows 0..MT+1: At = (A, -1, 0), bt = (b, 0, 0)
       if (l == L::PL) { static_for<0, MT>([&](auto k_) { s_A[g][decltype(k_)::value] = X[decltype(k_)::value]; }); s_A[g][MT] = -1.0; s_A[g][MT + 1] = 0.0; }
       if (l == L::YL) { static_for<0, MT>([&](auto k_) { s_b[g][decltype(k_)::value] = X[decltype(k_)::value]; }); s_b[g][MT] = 0.0; s_b[g][MT + 1] = 0.0; }
+      if (l == 0) { for (int r = MT + 2; r < NS * 16; ++r) { s_A[g][r] = 0.0; s_b[g][r] = 0.0; } }
       __syncthreads();
       // range parameter: accD = sum_{c<r<=MT} dK_rc At_r At_c ; accU = sum dK_rc (bt_r At_c + bt_c At_r)
       // (dD_range = 2 accD, (dB_range y)_i = accU; derivation in DESIGN.md, restating
       //  Vecchia_utils.cpp:1640-1652 without forming dA_i)
-      double accD = 0.0, accU = 0.0, sAA = 0.0, sbA = 0.0;
+      double Ar[NS], br[NS];
+      double sAA = 0.0, sbA = 0.0;
       static_for<0, NS>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
-        const int r = 16 * s + l;
-        const double Ar = s_A[g][r < MT + 2 ? r : MT + 1];
-        const double br = s_b[g][r < MT + 2 ? r : MT + 1];
-        if (r < MT) { sAA = __builtin_fma(Ar, Ar, sAA); sbA = __builtin_fma(br, Ar, sbA); }
-        constexpr int CM = (16 * s + 14 < MT - 1) ? 16 * s + 14 : MT - 1;   // strictly-lower columns
-        static_for<0, CM + 1>([&](auto c_) {
-          constexpr int c = decltype(c_)::value;
-          const double4 q = s_pts[g][c];
-          double dk = matern_dlog_range<COV>(fast_sqrt(sq_dist<D3>(own[s], q)), var, a, s_tab);
-          if constexpr (c >= 16 * s) dk = (l > c - 16 * s) ? dk : 0.0;      // keep c < r only
-          const double Ac = s_A[g][c], bc = s_b[g][c];
-          accD = __builtin_fma(dk * Ar, Ac, accD);
-          accU = __builtin_fma(dk, __builtin_fma(br, Ac, bc * Ar), accU);
-        });
+        const int r = 16 * s + ((s & 1) ? 15 - l : l);
+        Ar[s] = s_A[g][r]; br[s] = s_b[g][r];
+        if (r < MT) { sAA = __builtin_fma(Ar[s], Ar[s], sAA); sbA = __builtin_fma(br[s], Ar[s], sbA); }
       });
+      double accD = 0.0, accU = 0.0;
+      const double* gA = s_A[g];
+      const double* gb = s_b[g];
+      for_each_lower_step<MT>(
+          [&](auto s_, auto c_) {
+            constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
+            const Rec q = gp[c];
+            const double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+            const double Ac = gA[c], bc = gb[c];
+            accD = __builtin_fma(dk * Ar[s], Ac, accD);
+            accU = __builtin_fma(dk, __builtin_fma(br[s], Ac, bc * Ar[s]), accU);
+          },
+          [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_) {
+            constexpr int sA = decltype(sA_)::value, cA = decltype(cA_)::value, sB = decltype(sB_)::value,
+                          cB = decltype(cB_)::value, J = decltype(J_)::value;
+            const bool selA = l <= J;
+            const int c = selA ? cA : cB;
+            const Rec q = gp[c];
+            const double ox = selA ? own[sA].x : own[sB].x, oy = selA ? own[sA].y : own[sB].y;
+            const double oz = D3 ? (selA ? own[sA].z : own[sB].z) : 0.0;
+            const double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(ox, oy, oz, q.x, q.y, q.z), tabv);
+            const double Arr = selA ? Ar[sA] : Ar[sB], brr = selA ? br[sA] : br[sB];
+            const double Ac = gA[c], bc = gb[c];
+            accD = __builtin_fma(dk * Arr, Ac, accD);
+            accU = __builtin_fma(dk, __builtin_fma(brr, Ac, bc * Arr), accU);
+          },
+          [&](auto s_, auto c_) {
+            constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
+            const Rec q = gp[c];
+            double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+            const int r = 16 * s + ((s & 1) ? 15 - l : l);
+            dk = (r > c) ? dk : 0.0;                                 // entries on/above the diagonal do not exist
+            const double Ac = gA[c], bc = gb[c];
+            accD = __builtin_fma(dk * Ar[s], Ac, accD);
+            accU = __builtin_fma(dk, __builtin_fma(br[s], Ac, bc * Ar[s]), accU);
+          });
       // reduce the four accumulators over the 16 lanes of the row (xor butterflies stay inside the row)
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) {
@@ -239,43 +375,42 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
     }
   }
 
-  // ---- workgroup partial sums, fixed order ---------------------------------------
+  // ---- workgroup partial sums, fixed order; layout [term][workgroup] ---------------
   if (l == 0) {
 #pragma unroll
-    for (int t = 0; t < GPB_NUM_PARTIALS; ++t) s_red[t][g] = active ? red[t] : 0.0;
+    for (int t = 0; t < NP; ++t) s_red[t][g] = active ? red[t] : 0.0;
   }
   __syncthreads();
-  if (tid < GPB_NUM_PARTIALS) {
+  if (tid < NP) {
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc += s_red[tid][q];
-    args.partials[(size_t)blockIdx.x * GPB_NUM_PARTIALS + tid] = acc;
+    args.partials[(size_t)tid * gridDim.x + blockIdx.x] = acc;
   }
 }
 
 #ifndef GPB_INSTANTIATE_MT
-// Deterministic final reduction: one workgroup, each thread strides over the block partials,
-// then a fixed-shape tree.  out[t] = sum_b partials[b][t].
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                              double* __restrict__ out) {
-  __shared__ double s[256];
-  for (int t = 0; t < GPB_NUM_PARTIALS; ++t) {
-    double acc = 0.0, comp = 0.0;   // Kahan: 62,500 block partials at n = 1e6
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-      const double v = partials[(size_t)b * GPB_NUM_PARTIALS + t] - comp;
-      const double tmp = acc + v;
-      comp = (tmp - acc) - v;
-      acc = tmp;
-    }
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-      if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[t] = s[0];
+// Deterministic final reduction: one workgroup per term; each thread sums a strided subset of the block partials
+// (layout [term][nblocks], contiguous per term) in a fixed order, then a fixed-shape tree.  out[t] = sum_b partials[t][b].
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
+                                                               double* __restrict__ out) {
+  __shared__ double s[1024];
+  const int t = blockIdx.x;
+  const double* p = partials + (size_t)t * nblocks;
+  double acc = 0.0, comp = 0.0;   // Kahan on the per-thread chain
+  for (int b = threadIdx.x; b < nblocks; b += 1024) {
+    const double v = p[b] - comp;
+    const double tmp = acc + v;
+    comp = (tmp - acc) - v;
+    acc = tmp;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
     __syncthreads();
   }
+  if (threadIdx.x == 0) out[t] = s[0];
 }
 
 // pts[i].w = y[i]
@@ -390,8 +525,8 @@ hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const Vecchia
   }
 }
 
-hipError_t launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, out);
+hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out);
   return hipGetLastError();
 }
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {

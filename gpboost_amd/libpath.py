@@ -7,7 +7,8 @@ LIB_NAME = "lib_gpboost_amd.so"
 
 
 def find_lib_path():
-    cand = [os.path.join(_HERE, LIB_NAME), os.path.join(_HERE, "csrc", LIB_NAME)]
+    override = os.environ.get("GPBOOST_AMD_LIB")   # development builds (e.g. a single-MT library)
+    cand = ([override] if override else []) + [os.path.join(_HERE, LIB_NAME), os.path.join(_HERE, "csrc", LIB_NAME)]
     found = [p for p in cand if os.path.isfile(p)]
     if not found:
         raise FileNotFoundError(

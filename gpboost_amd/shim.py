@@ -125,6 +125,43 @@ class VecchiaState(object):
         return out
 
 
+class ExactState(object):
+    """Exact (dense) GP: coords (n, d) in data order."""
+
+    def __init__(self, coords):
+        coords = np.asarray(coords, dtype=np.float64)
+        if coords.ndim == 1:
+            coords = coords.reshape(-1, 1)
+        self.n, self.d = coords.shape
+        cm = np.asfortranarray(coords)
+        self.h = C.c_void_p()
+        _shim_call(_lib().gpb_hip_exact_create(C.c_int(self.n), C.c_int(self.d), _p(cm), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value is not None:
+            _lib().gpb_hip_exact_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_y(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.shape == (self.n,)
+        _shim_call(_lib().gpb_hip_exact_set_y(self.h, _p(y)))
+
+    def nll_terms(self, cov_type, var, a, want_yaux=False):
+        """-> (array {y^T Psi^-1 y, log|Psi|}, yaux or None, ms {assembly, factorisation, solves})"""
+        out = np.empty(2); ms = np.empty(3)
+        ya = np.empty(self.n) if want_yaux else None
+        _shim_call(_lib().gpb_hip_exact_nll_terms(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(out),
+                                                  _p(ya), _p(ms)))
+        return out, ya, ms
+
+
 def nll_from_terms(n, yPy, logdet, sigma2):
     """include/GPBoost/re_model_template.h:3132"""
     return yPy / 2. / sigma2 + logdet / 2. + n / 2. * (np.log(sigma2) + np.log(2 * np.pi))

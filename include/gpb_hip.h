@@ -39,6 +39,7 @@ enum { GPB_HIP_COV_MATERN_0_5 = 0 /* == "exponential" */, GPB_HIP_COV_MATERN_1_5
 
 typedef struct gpb_hip_vecchia gpb_hip_vecchia_t;
 typedef struct gpb_hip_hist gpb_hip_hist_t;
+typedef struct gpb_hip_exact gpb_hip_exact_t;
 
 GPB_HIP_EXPORT const char* gpb_hip_get_last_error(void);
 GPB_HIP_EXPORT int gpb_hip_device_count(int* count);
@@ -120,6 +121,20 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_ho
 /* y_aux = B^T D^-1 B y (CalcYAux, include/GPBoost/re_model_template.h:9771-9773), Vecchia order.
  * Requires gpb_hip_vecchia_factor() with the current y. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host);
+
+/* ------------------------------------------------------------------------------------
+ * Exact (dense) GP, Gaussian likelihood -- BASELINE config 1: replaces CalcSigmaComps / CalcZSigmaZt / CalcChol /
+ * chol.solve(y) / log-det (include/GPBoost/re_model_template.h:8151, :9273-9287, :6491-6494, :9894, :3127).
+ * Covariance assembly (HBM-write-bound), blocked Cholesky with fp64 MFMA trailing updates, triangular solves.
+ *   coords_colmajor n x d in DATA order, d in {1,2,3}
+ *   out2 = { y^T Psi^-1 y, log|Psi| } with Psi = Sigma(var, a) + I;  yaux (may be NULL) = Psi^-1 y
+ *   ms3 (may be NULL) = HIP-event durations {assembly, factorisation, solves} of this call
+ * ---------------------------------------------------------------------------------- */
+GPB_HIP_EXPORT int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gpb_hip_exact_t** out);
+GPB_HIP_EXPORT int gpb_hip_exact_free(gpb_hip_exact_t* h);
+GPB_HIP_EXPORT int gpb_hip_exact_set_y(gpb_hip_exact_t* h, const double* y_host);
+GPB_HIP_EXPORT int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double a, double* out2_host,
+                                           double* yaux_host, double* ms3);
 
 /* ------------------------------------------------------------------------------------
  * LightGBM feature histograms: replaces Dataset::ConstructHistogramsInner for dense uint8

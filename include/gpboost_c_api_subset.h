@@ -11,8 +11,9 @@
  *
  * Supported model slice (anything else returns -1 with a message, never a silent fallback):
  *   one GP, no grouped effects / random coefficients / clusters / weights, d <= 3,
- *   cov_fct "exponential" or "matern" with shape 0.5 / 1.5 / 2.5, gp_approx "vecchia",
- *   num_neighbors <= 62, vecchia_ordering "none" | "random", likelihood "gaussian".
+ *   cov_fct "exponential" or "matern" with shape 0.5 / 1.5 / 2.5, likelihood "gaussian", and either
+ *   gp_approx "vecchia" (num_neighbors <= 62, vecchia_ordering "none" | "random") or gp_approx "none"
+ *   (exact GP, dense Cholesky; likelihood and y_aux only).
  */
 #ifndef GPBOOST_C_API_SUBSET_H_
 #define GPBOOST_C_API_SUBSET_H_

@@ -70,7 +70,7 @@ def test_no_gpu_means_loud_failure_not_fallback(lib_built):
 def test_out_of_scope_models_are_rejected_with_a_message(lib_built):
     import gpboost_amd
     coords = np.random.default_rng(0).uniform(size=(50, 2))
-    for kw in (dict(gp_approx="none"), dict(gp_approx="vecchia", cov_function="gaussian"),
+    for kw in (dict(gp_approx="fitc"), dict(gp_approx="vecchia", cov_function="gaussian"),
                dict(gp_approx="vecchia", likelihood="bernoulli_logit"), dict(gp_approx="vecchia", cov_fct_shape=0.7),
                dict(gp_approx="vecchia", vecchia_ordering="time")):
         args = dict(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, num_neighbors=10)

@@ -236,3 +236,28 @@ def test_errors_are_loud(gpb):
     mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
     with pytest.raises(gpb.GPBoostError):
         mdl.neg_log_likelihood(cov_pars=np.array([0.1, -1.0, 0.1]), y=y)
+
+
+# ---- exact GP (BASELINE config 1) -------------------------------------------------------------------------
+def test_exact_gp_r_suite_golden_values(gpb, orc):
+    """R-package/tests/testthat/test_GPModel_gaussian_process.R:86-120: 124.2549533, 141.3502172, 158.1111626."""
+    coords, y = orc.r_fixture()
+    for cf, sh, gold in (("exponential", 0.5, 124.2549533), ("matern", 1.5, 141.3502172), ("matern", 2.5, 158.1111626)):
+        mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="none")
+        assert abs(mdl.neg_log_likelihood(cov_pars=np.array([0.1, 1.6, 0.2]), y=y) - gold) < 1e-6
+
+
+@pytest.mark.parametrize("n,d,ct", [(2000, 2, 1), (777, 3, 2), (64, 1, 0), (130, 2, 0)])
+def test_exact_gp_against_oracle(gpb, orc, n, d, ct):
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(n, d, seed=n)
+    var, a = 10.0, 10.0 * [1., 3. ** .5, 5. ** .5][ct]
+    st = shim.ExactState(coords); st.set_y(y)
+    out, ya, ms = st.nll_terms(ct, var, a, want_yaux=True)
+    o, yo = orc.exact_nll(coords, ct, np.array([0.1, var, a]), y, want_yaux=True)
+    assert abs(out[0] - o[0]) <= RTOL * abs(o[0]) and abs(out[1] - o[1]) <= RTOL * max(1., abs(o[1]))
+    np.testing.assert_allclose(ya, yo, rtol=1e-7, atol=1e-9 * np.abs(yo).max())
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=[0.5, 1.5, 2.5][ct], gp_approx="none")
+    cp = np.array([0.1, 1.0, [1., 3. ** .5, 5. ** .5][ct] / a])
+    assert abs(mdl.neg_log_likelihood(cp, y) - o[2]) <= RTOL * abs(o[2])
+    np.testing.assert_allclose(mdl.y_aux(cp, y), yo, rtol=1e-7, atol=1e-9 * np.abs(yo).max())
