@@ -650,10 +650,28 @@ int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const doub
   API_END();
 }
 
+static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg);
+
 int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
                        double* hist_out, uint64_t* cnt_out) {
   API_BEGIN();
   if (!h || !hist_out) return fail("null argument");
+  if (hist_build_impl(h, data_indices, num_data, const_hess, hist_out, cnt_out, 1, nullptr)) return -1;
+  API_END();
+}
+
+int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess, int reps,
+                       double* ms_avg) {
+  API_BEGIN();
+  if (!h || !ms_avg || reps < 1) return fail("invalid argument");
+  if (hist_build_impl(h, data_indices, num_data, const_hess, nullptr, nullptr, reps, ms_avg)) return -1;
+  API_END();
+}
+
+static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg) {
+  {
   if (!h->has_grad) return fail("gradients have not been set (call gpb_hip_hist_set_gradients)");
   if (!data_indices) num_data = h->n;
   if (num_data < 0 || num_data > h->n) return fail("gpb_hip_hist_build: num_data = %d", num_data);
@@ -681,16 +699,23 @@ int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t n
   a.hess = h->has_hess ? h->d_hess : nullptr;
   a.part_grad = h->d_part_grad; a.part_hess = h->d_part_hess; a.part_cnt = h->d_part_cnt;
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks;
-  HIP_OK(gpb::launch_hist_build(a, h->stream));
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
   r.hist_out = h->d_hist; r.cnt_out = h->d_cnt; r.fpad = h->fpad; r.nchunks = nchunks; r.num_features = h->F;
   r.const_hess = const_hess; r.has_hess = h->has_hess ? 1 : 0;
-  HIP_OK(gpb::launch_hist_reduce(r, h->stream));
-  HIP_OK(hipMemcpyAsync(hist_out, h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms_avg) { HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventRecord(e0, h->stream)); }
+  for (int rep = 0; rep < reps; ++rep) {
+    HIP_OK(gpb::launch_hist_build(a, h->stream));
+    HIP_OK(gpb::launch_hist_reduce(r, h->stream));
+  }
+  if (ms_avg) HIP_OK(hipEventRecord(e1, h->stream));
+  if (hist_out) HIP_OK(hipMemcpyAsync(hist_out, h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
   if (cnt_out) HIP_OK(hipMemcpyAsync(cnt_out, h->d_cnt, sizeof(unsigned long long) * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  API_END();
+  if (ms_avg) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); *ms_avg = ms / reps; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  }
+  return 0;
 }
 
 }  // extern "C"

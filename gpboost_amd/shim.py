@@ -200,6 +200,15 @@ class HistBuilder(object):
         hess = None if hess is None else np.ascontiguousarray(hess, dtype=np.float64)
         _shim_call(_lib().gpb_hip_hist_set_gradients(self.h, _p(grad), _p(hess)))
 
+    def bench(self, data_indices=None, const_hess=1.0, reps=10):
+        """mean ms of one leaf build (kernels only, HIP events)"""
+        di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+        nd = self.n if di is None else di.size
+        ms = C.c_double(0)
+        _shim_call(_lib().gpb_hip_hist_bench(self.h, _p(di, C.c_int32), C.c_int(nd), C.c_double(const_hess), C.c_int(reps),
+                                             C.byref(ms)))
+        return ms.value
+
     def build(self, data_indices=None, const_hess=1.0):
         """-> (hist[total_bins, 2] = {grad sum, hess sum}, cnt[total_bins] uint64)"""
         di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)

@@ -157,6 +157,11 @@ GPB_HIP_EXPORT int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* g
 GPB_HIP_EXPORT int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data,
                                       double const_hess, double* hist_out, uint64_t* cnt_out);
 
+/* Measurement helper: `reps` back-to-back leaf histogram builds (build + chunk reduction kernels, no D2H),
+ * mean duration from HIP events on the handle's stream. */
+GPB_HIP_EXPORT int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
+                                      int reps, double* ms_avg);
+
 #ifdef __cplusplus
 }
 #endif
