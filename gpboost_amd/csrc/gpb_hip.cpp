@@ -364,14 +364,9 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
   if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
   const int nblocks = (h->i_end - h->i_begin + 15) / 16;
-  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, h->stream));
-  if (out_dev) {
-    // reorder to the documented layout {quad, logdet, bad, ...}
-    // d_out = {logdet, quad, bad, g1v, g2v, g1r, g2r}
-    HIP_OK(hipMemcpyAsync(out_dev, h->d_out + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIP_OK(hipMemcpyAsync(out_dev + 1, h->d_out, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (nout > 2) HIP_OK(hipMemcpyAsync(out_dev + 2, h->d_out + 2, sizeof(double) * (nout - 2), hipMemcpyDeviceToDevice, h->stream));
-  }
+  // the final reduction also writes the caller's device buffer (documented order), no extra copies on the stream
+  (void)nout;
+  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream));
   return 0;
 }
 

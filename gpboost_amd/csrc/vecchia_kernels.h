@@ -44,7 +44,8 @@ struct VecchiaKernelArgs {
 
 int vecchia_padded_m(int m);
 hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
-hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
+                                  hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, const double* v, double* w,

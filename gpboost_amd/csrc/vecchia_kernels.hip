@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
 // Deterministic final reduction: one workgroup per term; each thread sums a strided subset of the block partials
 // (layout [term][nblocks], contiguous per term) in a fixed order, then a fixed-shape tree.  out[t] = sum_b partials[t][b].
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                               double* __restrict__ out) {
+                                                               double* __restrict__ out, double* __restrict__ out2) {
   __shared__ double s[1024];
   const int t = blockIdx.x;
   const double* p = partials + (size_t)t * nblocks;
@@ -410,7 +410,11 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __r
     if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[t] = s[0];
+  if (threadIdx.x == 0) {
+    out[t] = s[0];
+    // caller-facing layout {quad, logdet, bad, g1v, g2v, g1r, g2r}: terms 0 and 1 swapped w.r.t. GPB_P_*
+    if (out2) out2[t == GPB_P_LOGDET ? 1 : (t == GPB_P_QUAD ? 0 : t)] = s[0];
+  }
 }
 
 // pts[i].w = y[i]
@@ -525,8 +529,9 @@ hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const Vecchia
   }
 }
 
-hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out);
+hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user);
   return hipGetLastError();
 }
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {

@@ -8,8 +8,9 @@ import gpboost_amd
 from gpboost_amd import shim
 from tests import cases
 
+SECTIONS = set(sys.argv[1:]) or {"exact", "hist", "pcie", "c5"}
 print("== exact GP (dense) ==", flush=True)
-for n in (2000, 8192, 16384):
+for n in ((2000, 8192, 16384) if "exact" in SECTIONS else ()):
     coords, y = cases.synthetic(n, 2, seed=1)
     st = shim.ExactState(coords); st.set_y(y)
     st.nll_terms(1, 10.0, 17.3)
@@ -21,7 +22,7 @@ for n in (2000, 8192, 16384):
     st.close()
 
 print("== histogram ==", flush=True)
-for n, F in ((100000, 50), (10000000, 50)):
+for n, F in (((100000, 50), (10000000, 50)) if "hist" in SECTIONS else ()):
     rng = np.random.default_rng(0)
     bins = rng.integers(0, 255, size=(F, n), dtype=np.uint8)
     bo = (np.arange(F + 1) * 255).astype(np.int32)
@@ -38,6 +39,8 @@ for n, F in ((100000, 50), (10000000, 50)):
     hb.close()
 
 print("== PCIe-inclusive likelihood rate (host y uploaded every call) ==", flush=True)
+if "pcie" not in SECTIONS and "c5" not in SECTIONS:
+    sys.exit(0)
 n, m = 1000000, 30
 coords, y = cases.synthetic(n, 2, seed=1)
 mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=m, vecchia_ordering="random", seed=1)
