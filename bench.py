@@ -26,6 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+# (r01_b_kernel_v2_rocprofv3_summary.txt: FETCH_SIZE 1.24776e6 KB + WRITE_SIZE 5.86e3 KB per dispatch, separate --pmc passes,
+# n = 1e6, m = 30, d = 2, one GPU; gathers are 32-byte records, so the guide's 2x correction for wide coalesced streams is
+# not applied).  Reported only for exactly that configuration; otherwise null.
+PROFILED_TRAFFIC_BYTES = {(1000000, 30, 2, 1): (1.24776e6 + 5.86e3) * 1024}
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
 
@@ -188,7 +193,7 @@ def main():
                        "last_negll": last,
                        "grad_eval_ms_kernel": round(ms_gkernel, 4)},
             "roofline": {"bound": "hbm", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": PROFILED_TRAFFIC_BYTES.get((n, m, d, world)),
                          "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "kernel is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_fp64"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -11,10 +11,11 @@
 // rows/columns are the identity so they change neither the log-determinant nor the solves):
 //   dense_cov_lower_kernel   covariance assembly, one 64x64 tile per workgroup, 32-byte stores per lane:
 //                            the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
-//   potrf_diag_kernel        64x64 diagonal block, LDS resident, one workgroup
-//   trsm_panel_kernel        L21 = A21 L11^-T, one thread per row, L11 broadcast from LDS
+//   potrf_diag_kernel        64x64 diagonal block, one wavefront, row-per-lane in registers, v_readlane broadcasts
+//   trsm_panel_kernel        L21 = A21 L11^-T, one lane per row, L11 through scalar (wave-uniform) loads
 //   syrk_mfma_kernel         A22 -= L21 L21^T on the lower tiles with v_mfma_f64_16x16x4_f64
-//                            (one wavefront per 64x64 tile, 16 accumulator tiles, K = 64 per panel)
+//                            (one workgroup per 128x128 tile, one wavefront per 64x64 quadrant = 16 accumulator
+//                            tiles, K = 64 per panel, both panels staged once in 135 KB of LDS)
 //   trsv_lower_kernel        forward (and optionally backward) substitution + y^T Psi^-1 y + log-det
 #include "dev_common.h"
 #include "dense_kernels.h"
@@ -81,83 +82,96 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
 }
 
 // ---- diagonal block factorisation -----------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ P, int np, int k0, int* __restrict__ info) {
-  __shared__ double s[TB][TB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < TB * TB; e += 256) {
-    const int i = e / TB, j = e % TB;
-    s[i][j] = (j <= i) ? P[(size_t)(k0 + i) * np + k0 + j] : 0.0;
-  }
-  __syncthreads();
-  for (int k = 0; k < TB; ++k) {
-    if (tid == 0) {
-      const double d = s[k][k];
-      if (!(d > 0.0)) atomicOr(info, 1);
-      s[k][k] = sqrt(d);
-    }
-    __syncthreads();
-    const double dk = s[k][k];
-    if (tid > k && tid < TB) s[tid][k] = s[tid][k] / dk;
-    __syncthreads();
-    const int w = TB - k - 1;
-    for (int e = tid; e < w * w; e += 256) {
-      const int i = k + 1 + e / w, j = k + 1 + e % w;
-      if (j <= i) s[i][j] = __builtin_fma(-s[i][k], s[j][k], s[i][j]);
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < TB * TB; e += 256) {
-    const int i = e / TB, j = e % TB;
-    if (j <= i) P[(size_t)(k0 + i) * np + k0 + j] = s[i][j];
-  }
+// One wavefront, row-per-lane: lane r holds row r of the 64x64 block in registers (M[c], c <= r).  The pivot and the
+// column multipliers are wave-uniform, so they travel through v_readlane into SGPRs and feed v_fma_f64 directly
+// (2016 readlane pairs + FMAs, ~7 us) -- no LDS, no barriers.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+
+__global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ P, int np, int k0, int* __restrict__ info) {
+  const int r = threadIdx.x;
+  double* row = P + (size_t)(k0 + r) * np + k0;
+  double M[TB];
+#pragma unroll
+  for (int c = 0; c < TB; ++c) M[c] = row[c];        // entries c > r are never used meaningfully
+  bool bad = false;
+  static_for<0, TB>([&](auto k_) {
+    constexpr int k = decltype(k_)::value;
+    const double piv = readlane_f64(M[k], k);
+    if (!(piv > 0.0)) bad = true;
+    const double inv = 1.0 / sqrt(piv);                // wave-uniform
+    M[k] = (r == k) ? piv * inv : M[k] * inv;           // L[r][k] (L[k][k] = sqrt(piv))
+    static_for<k + 1, TB>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      const double lck = readlane_f64(M[k], c);         // L[c][k], wave-uniform
+      M[c] = __builtin_fma(-M[k], lck, M[c]);           // rows r >= c are the meaningful ones
+    });
+  });
+#pragma unroll
+  for (int c = 0; c < TB; ++c) if (c <= r) row[c] = M[c];
+  if (bad && r == 0) atomicOr(info, 1);
 }
 
 // ---- panel solve: rows below the diagonal block ------------------------------------------------
+// One lane per row, the row's 64 entries in registers; L11 is read with wave-uniform addresses (scalar loads).
 __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ P, int np, int k0) {
-  __shared__ double sL[TB][TB + 1];
   const int tid = threadIdx.x;
-  for (int e = tid; e < TB * TB; e += 64) {
-    const int i = e / TB, j = e % TB;
-    sL[i][j] = (j <= i) ? P[(size_t)(k0 + i) * np + k0 + j] : 0.0;
-  }
-  __syncthreads();
   const int i = k0 + TB + blockIdx.x * 64 + tid;
-  if (i >= np) return;
-  double* row = P + (size_t)i * np + k0;
+  const bool live = i < np;
+  double* row = P + (size_t)(live ? i : k0 + TB) * np + k0;
+  const double* __restrict__ L11 = P + (size_t)k0 * np + k0;
   double x[TB];
 #pragma unroll
   for (int j = 0; j < TB; ++j) x[j] = row[j];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) {
+  static_for<0, TB>([&](auto j_) {
+    constexpr int j = decltype(j_)::value;
     double t = x[j];
+    static_for<0, j>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      t = __builtin_fma(-x[p], L11[(size_t)j * np + p], t);
+    });
+    x[j] = t / L11[(size_t)j * np + j];
+  });
+  if (live) {
 #pragma unroll
-    for (int p = 0; p < j; ++p) t = __builtin_fma(-x[p], sL[j][p], t);
-    x[j] = t / sL[j][j];
+    for (int j = 0; j < TB; ++j) row[j] = x[j];
   }
-#pragma unroll
-  for (int j = 0; j < TB; ++j) row[j] = x[j];
 }
 
 // ---- trailing update with fp64 MFMA -------------------------------------------------------------
-// One wavefront per 64x64 tile (ti >= tj) of the trailing matrix: C -= A B^T, A = L21[rows of ti], B = L21[rows of tj].
-__global__ __launch_bounds__(64) void syrk_mfma_kernel(double* __restrict__ P, int np, int k0) {
-  __shared__ double sA[TB * LDSS], sB[TB * LDSS];
+// One workgroup (4 wavefronts, one per SIMD) per 128x128 tile (TI >= TJ) of the trailing matrix:
+// C -= A B^T with A = L21[rows of TI], B = L21[rows of TJ], K = 64 (one panel).  Both panels are staged once in LDS
+// (2 x 128 x 66 doubles = 135 KB); each wavefront owns a 64x64 quadrant = 4x4 MFMA tiles of v_mfma_f64_16x16x4_f64.
+__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, int np, int k0) {
+  __shared__ double sA[128 * LDSS], sB[128 * LDSS];   // 135,168 B static LDS: one workgroup per CU
   const int t = blockIdx.x;
   int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while ((long long)ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - (int)((long long)ti * (ti + 1) / 2);
-  const int r0 = k0 + TB + ti * TB, c0 = k0 + TB + tj * TB;
-  const int lane = threadIdx.x;
-  // stage both 64x64 panels: lane reads 2 doubles (16 B) per row step; row-major source, 512 B per row
-  for (int e = lane; e < TB * TB / 2; e += 64) {
+  const int base = k0 + TB;
+  const int r0 = base + ti * 128, c0 = base + tj * 128;
+  const int tid = threadIdx.x;
+  // stage: 128 rows x 64 doubles per panel, 16-byte loads, rows past the matrix read as zero
+  for (int e = tid; e < 128 * (TB / 2); e += 256) {
     const int i = e / (TB / 2), j2 = (e % (TB / 2)) * 2;
-    const double2 va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + k0 + j2);
-    const double2 vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + k0 + j2);
+    double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+    if (r0 + i < np) va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + k0 + j2);
+    if (c0 + i < np) vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + k0 + j2);
     sA[i * LDSS + j2] = va.x; sA[i * LDSS + j2 + 1] = va.y;
     sB[i * LDSS + j2] = vb.x; sB[i * LDSS + j2 + 1] = vb.y;
   }
   __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wi = wave >> 1, wj = wave & 1;
+  if (ti == tj && wj > wi) return;                      // quadrant strictly above the diagonal
+  if (r0 + 64 * wi >= np || c0 + 64 * wj >= np) return;  // quadrant outside the matrix (ragged edge)
+  const double* qA = sA + (64 * wi) * LDSS;
+  const double* qB = sB + (64 * wj) * LDSS;
   double4v acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -169,8 +183,8 @@ __global__ __launch_bounds__(64) void syrk_mfma_kernel(double* __restrict__ P, i
     double af[4], bf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      af[q] = sA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
-      bf[q] = sB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L21[j][k]
+      af[q] = qA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
+      bf[q] = qB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L21[j][k]
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -179,13 +193,14 @@ __global__ __launch_bounds__(64) void syrk_mfma_kernel(double* __restrict__ P, i
         acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
   }
   // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int gr0 = r0 + 64 * wi, gc0 = c0 + 64 * wj;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = r0 + 16 * mi + fk + 4 * r, gj = c0 + 16 * nj + fr;
+        const int gi = gr0 + 16 * mi + fk + 4 * r, gj = gc0 + 16 * nj + fr;
         if (gj <= gi) P[(size_t)gi * np + gj] -= acc[mi][nj][r];
       }
 }
@@ -287,12 +302,12 @@ hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st) {
   const int nt = np / TB;
   for (int kb = 0; kb < nt; ++kb) {
     const int k0 = kb * TB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, P, np, k0, info);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
     const int rows_below = np - k0 - TB;
     if (rows_below <= 0) break;
     hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
-    const int ntr = rows_below / TB;
-    hipLaunchKernelGGL(syrk_mfma_kernel, dim3(ntr * (ntr + 1) / 2), dim3(64), 0, st, P, np, k0);
+    const int ntr = (rows_below + 127) / 128;
+    hipLaunchKernelGGL(syrk_mfma_kernel, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, P, np, k0);
   }
   return hipGetLastError();
 }

@@ -265,3 +265,23 @@ def test_exact_gp_against_oracle(gpb, orc, n, d, ct):
     cp = np.array([0.1, 1.0, [1., 3. ** .5, 5. ** .5][ct] / a])
     assert abs(mdl.neg_log_likelihood(cp, y) - o[2]) <= RTOL * abs(o[2])
     np.testing.assert_allclose(mdl.y_aux(cp, y), yo, rtol=1e-7, atol=1e-9 * np.abs(yo).max())
+
+
+def test_several_models_alive_and_interleaved(gpb, orc):
+    """REModel has no locking but several handles may be alive (e.g. the temporary model of
+    InitCoefAuxParsFromIidModel, re_model.cpp:402-409): interleaved calls must not disturb each other."""
+    c1, y1 = cases.synthetic(3000, 2, seed=101)
+    c2, y2 = cases.synthetic(2500, 3, seed=102)
+    m1 = gpb.GPModel(gp_coords=c1, cov_function="exponential", gp_approx="vecchia", num_neighbors=20, seed=3)
+    m2 = gpb.GPModel(gp_coords=c2, cov_function="matern", cov_fct_shape=2.5, gp_approx="vecchia", num_neighbors=35, seed=4)
+    m3 = gpb.GPModel(gp_coords=c1[:500], cov_function="matern", cov_fct_shape=1.5, gp_approx="none")
+    cp = np.array([0.2, 1.0, 0.15])
+    a1 = m1.neg_log_likelihood(cp, y1); a2 = m2.neg_log_likelihood(cp, y2); a3 = m3.neg_log_likelihood(cp, y1[:500])
+    for _ in range(3):
+        assert m2.neg_log_likelihood(cp, y2) == a2
+        assert m1.neg_log_likelihood(cp, y1) == a1
+        assert m3.neg_log_likelihood(cp, y1[:500]) == a3
+    assert abs(a1 - orc.gp_nll(c1, y1, cp, "exponential", 0.5, 20, "random", 3)) <= RTOL * abs(a1)
+    assert abs(a2 - orc.gp_nll(c2, y2, cp, "matern", 2.5, 35, "random", 4)) <= RTOL * abs(a2)
+    del m1
+    assert m2.neg_log_likelihood(cp, y2) == a2
