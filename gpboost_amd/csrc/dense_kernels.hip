@@ -9,8 +9,8 @@
 //
 // Kernels (matrix row-major, lower triangle, leading dimension np = n rounded up to 64; the padding
 // rows/columns are the identity so they change neither the log-determinant nor the solves):
-//   dense_cov_lower_kernel   covariance assembly, one 64x64 tile per workgroup, 32-byte stores per lane:
-//                            the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
+//   dense_cov_lower_kernel   covariance assembly, one 128x128 tile per workgroup, 8x8 entries per lane, 32-byte
+//                            stores: the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
 //   potrf_diag_kernel        64x64 diagonal block, one wavefront, row-per-lane in registers, v_readlane broadcasts
 //   trsm_panel_kernel        L21 = A21 L11^-T, one lane per row, L11 through scalar (wave-uniform) loads
 //   syrk_mfma_kernel         A22 -= L21 L21^T on the lower tiles with v_mfma_f64_16x16x4_f64
@@ -27,57 +27,66 @@ constexpr int TB = 64;            // tile / panel width
 constexpr int LDSS = 66;          // LDS row stride (doubles): 16 rows x 4 k of an MFMA fragment hit 64 distinct banks
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-template <int COV>
-__device__ __forceinline__ double matern_plain(double dist, double var, double a, const double* tab) {
-  return matern_cov<COV>(dist, var, a, tab);
-}
 }  // namespace
 
 // ---- covariance assembly ----------------------------------------------------------------
-// grid = lower tiles (ti >= tj) flattened; block = 256 threads, thread (tx, ty) computes a 4x4 sub-block.
+// grid = lower 128x128 tiles (ti >= tj) flattened; block = 256 threads, thread (tx, ty) computes an 8x8 sub-block
+// (64 kernel evaluations per lane amortise the prologue).  Coordinates are staged in LDS already multiplied by
+// a * 64/ln2 (dev_common.h), the 64-entry table carries the variance.  Stores: 2 x 32 bytes per lane and row,
+// 16 lanes cover 1 KB of a row contiguously.
+constexpr int CT = 128;
 template <int COV, bool D3>
 __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __restrict__ pts, int n, int np, double var,
                                                               double a, double nugget, const double* __restrict__ gtab,
                                                               double* __restrict__ P) {
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
-  __shared__ double4 s_row[TB], s_col[TB];
-  fill_exp_table(s_tab, gtab);
-  // tile index -> (ti, tj), ti >= tj
+  __shared__ double s_rx[CT], s_ry[CT], s_rz[CT], s_cx[CT], s_cy[CT], s_cz[CT];
+  const int tid = threadIdx.x;
+  if (tid < GPB_EXP_TAB_SIZE) s_tab[tid] = gtab[tid] * var;
   const int t = blockIdx.x;
   int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while ((long long)ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - (int)((long long)ti * (ti + 1) / 2);
-  const int tid = threadIdx.x;
-  if (tid < TB) {
-    const int r = ti * TB + tid;
-    s_row[tid] = r < n ? pts[r] : make_double4(0, 0, 0, 0);
-  } else if (tid < 2 * TB) {
-    const int c = tj * TB + tid - TB;
-    s_col[tid - TB] = c < n ? pts[c] : make_double4(0, 0, 0, 0);
+  const double sc = a * k64OverLn2;
+  if (tid < CT) {
+    const int r = ti * CT + tid;
+    const double4 p = r < n ? pts[r] : make_double4(0, 0, 0, 0);
+    s_rx[tid] = p.x * sc; s_ry[tid] = p.y * sc; s_rz[tid] = p.z * sc;
+  } else {
+    const int c = tj * CT + tid - CT;
+    const double4 p = c < n ? pts[c] : make_double4(0, 0, 0, 0);
+    s_cx[tid - CT] = p.x * sc; s_cy[tid - CT] = p.y * sc; s_cz[tid - CT] = p.z * sc;
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
+  double qx[8], qy[8], qz[8];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int lr = ty * 4 + rr, r = ti * TB + lr;
-    const double4 p = s_row[lr];
-    double v[4];
+  for (int cc = 0; cc < 8; ++cc) { qx[cc] = s_cx[tx * 8 + cc]; qy[cc] = s_cy[tx * 8 + cc]; qz[cc] = D3 ? s_cz[tx * 8 + cc] : 0.0; }
+  const double diag = var + nugget;
+#pragma unroll 2
+  for (int rr = 0; rr < 8; ++rr) {
+    const int lr = ty * 8 + rr, r = ti * CT + lr;
+    if (r >= np) break;
+    const double px = s_rx[lr], py = s_ry[lr], pz = D3 ? s_rz[lr] : 0.0;
+    double v[8];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int lc = tx * 4 + cc, c = tj * TB + lc;
-      const double4 q = s_col[lc];
-      const double dx = p.x - q.x, dy = p.y - q.y;
-      double d2 = dx * dx;
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = tj * CT + tx * 8 + cc;
+      const double dx = px - qx[cc], dy = py - qy[cc];
+      double d2 = __builtin_fma(dx, dx, 1e-300);
       d2 = __builtin_fma(dy, dy, d2);
-      if (D3) { const double dz = p.z - q.z; d2 = __builtin_fma(dz, dz, d2); }
-      double val = matern_plain<COV>(fast_sqrt(d2), var, a, s_tab);
-      if (r == c) val = var + nugget;
+      if (D3) { const double dz = pz - qz[cc]; d2 = __builtin_fma(dz, dz, d2); }
+      double val = matern_cov_s<COV>(d2, s_tab);
+      if (r == c) val = diag;
       if (r >= n || c >= n) val = (r == c) ? 1.0 : 0.0;     // identity padding
       v[cc] = val;
     }
-    double4* dst = reinterpret_cast<double4*>(P + (size_t)r * np + (size_t)tj * TB + tx * 4);
-    *dst = make_double4(v[0], v[1], v[2], v[3]);
+    if (tj * CT + tx * 8 < np) {
+      double4* dst = reinterpret_cast<double4*>(P + (size_t)r * np + (size_t)tj * CT + tx * 8);
+      dst[0] = make_double4(v[0], v[1], v[2], v[3]);
+      dst[1] = make_double4(v[4], v[5], v[6], v[7]);
+    }
   }
 }
 
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
 template <int COV>
 static void launch_cov(bool d3, const double4* pts, int n, int np, double var, double a, double nugget, const double* gtab,
                        double* P, hipStream_t st) {
-  const int nt = np / TB;
+  const int nt = (np + CT - 1) / CT;
   const int ntiles = nt * (nt + 1) / 2;
   if (d3) hipLaunchKernelGGL((dense_cov_lower_kernel<COV, true>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);
   else hipLaunchKernelGGL((dense_cov_lower_kernel<COV, false>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);

@@ -146,4 +146,50 @@ __device__ __forceinline__ double matern_cov(double dist, double var, double a, 
   else return var * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0) * e;
 }
 
+// ---- scaled-distance form used by the hot kernels -------------------------------------------
+// Coordinates are pre-multiplied by a * 64/ln2, so that exp(-a d) = 2^(-r'/64) with r' the scaled distance:
+// no multiply by the range, no Cody-Waite reduction, the polynomial absorbs ln2/64, the table absorbs the variance.
+constexpr double kLn2Over64 = 0.010830424696249145;   // ln2 / 64
+constexpr double k64OverLn2 = 92.332482616893657;     // 64 / ln2
+
+// Everything a kernel evaluation needs, from the scaled squared distance d2s = (a d 64/ln2)^2:
+//   ev = var * exp(-a d)   (tabv already carries var),   rp = a d 64/ln2
+struct KernEval { double ev, rp; };
+__device__ __forceinline__ KernEval exp_of_scaled(double d2s, const double* __restrict__ tabv) {
+  const double rs = __builtin_amdgcn_rsq(d2s);
+  const double g = d2s * rs, h = 0.5 * rs;
+  const double e = __builtin_fma(-h, g, 0.5);
+  const double rp = __builtin_fma(g, e, g);                 // sqrt(d2s), one Newton step on v_rsq_f64
+  const double kf = __builtin_rint(-rp);
+  const double rr = -rp - kf;                               // exact; |rr| <= 1/2, in units of ln2/64
+  const int k = (int)kf;                                    // saturates for the dummy rows
+  // exp(rr ln2/64) = sum_j (ln2/64)^j rr^j / j!, j <= 5  (remainder < 2e-17)
+  double p = __builtin_fma(rr, 1.2417843701716925e-12, 5.732851688640402e-10);
+  p = __builtin_fma(p, rr, 2.1173137155464776e-07);
+  p = __builtin_fma(p, rr, 5.86490495505617e-05);
+  p = __builtin_fma(p, rr, kLn2Over64);
+  p = __builtin_fma(p, rr, 1.0);
+  KernEval o;
+  o.ev = __builtin_ldexp(tabv[k & 63] * p, k >> 6);
+  o.rp = rp;
+  return o;
+}
+// include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5), transformed scale
+template <int COV>
+__device__ __forceinline__ double matern_cov_s(double d2s, const double* __restrict__ tabv) {
+  const KernEval k = exp_of_scaled(d2s, tabv);
+  if constexpr (COV == kMatern05) return k.ev;
+  else if constexpr (COV == kMatern15) return k.ev * __builtin_fma(k.rp, kLn2Over64, 1.0);
+  else { const double r = k.rp * kLn2Over64; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
+}
+// d/d log(a) of the kernel (transf_scale == true): include/GPBoost/cov_fcts.h:2182-2193 (cm), :2535-2554
+template <int COV>
+__device__ __forceinline__ double matern_dlog_range_s(double d2s, const double* __restrict__ tabv) {
+  const KernEval k = exp_of_scaled(d2s, tabv);
+  const double r = k.rp * kLn2Over64;
+  if constexpr (COV == kMatern05) return -r * k.ev;                                 // cm d sigma, cm = -a
+  else if constexpr (COV == kMatern15) return -(r * r) * k.ev;                      // cm d^2 e^{-ad}, cm = -var a^2
+  else return -(1.0 / 3.0) * (r * r) * __builtin_fma(1.0, r, 1.0) * k.ev;           // cm/3 d^2 (1+ad) e^{-ad}
+}
+
 }  // namespace gpb

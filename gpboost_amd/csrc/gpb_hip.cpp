@@ -144,6 +144,25 @@ int gpb_hip_device_is_gfx950(int* yes) {
   API_END();
 }
 
+int gpb_hip_dev_alloc(uint64_t bytes, void** out) {
+  API_BEGIN();
+  if (!out) return fail("null argument");
+  if (check_device()) return -1;
+  HIP_OK(hipMalloc(out, bytes ? bytes : 8));
+  API_END();
+}
+int gpb_hip_dev_free(void* p) {
+  API_BEGIN();
+  if (p) HIP_OK(hipFree(p));
+  API_END();
+}
+int gpb_hip_dev_to_host(void* dst_host, const void* src_dev, uint64_t bytes) {
+  API_BEGIN();
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  API_END();
+}
+
 int gpb_hip_selftest(void) {
   API_BEGIN();
   if (check_device()) return -1;
@@ -491,18 +510,31 @@ static int build_transpose(gpb_hip_vecchia_t* h) {
   return 0;
 }
 
-int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) {
-  API_BEGIN();
-  if (!h || !yaux_host) return fail("null argument");
+static int yaux_enqueue(gpb_hip_vecchia_t* h) {
   if (!h->has_factor) return fail("the factor has not been computed (call gpb_hip_vecchia_factor)");
-  if (h->i_begin != 0 || h->i_end != h->n) return fail("gpb_hip_vecchia_yaux needs the full factor on this device (shard is [%d,%d))", h->i_begin, h->i_end);
   HIP_OK(hipSetDevice(h->device));
   if (!h->has_transpose && build_transpose(h)) return -1;
   if (!h->d_v) { HIP_OK(hipMalloc(&h->d_v, sizeof(double) * (size_t)h->n)); HIP_OK(hipMalloc(&h->d_w, sizeof(double) * (size_t)h->n)); }
-  HIP_OK(gpb::launch_scale_by_Dinv(h->d_u, h->d_D, h->n, h->d_v, h->stream));
-  HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->d_v, h->d_w, h->stream));
+  HIP_OK(gpb::launch_scale_by_Dinv(h->d_u, h->d_D, h->n, h->i_begin, h->i_end, h->d_v, h->stream));
+  HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->i_begin, h->i_end, h->d_v, h->d_w, h->stream));
+  return 0;
+}
+
+int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) {
+  API_BEGIN();
+  if (!h || !yaux_host) return fail("null argument");
+  if (h->i_begin != 0 || h->i_end != h->n) return fail("gpb_hip_vecchia_yaux needs the full factor on this device (shard is [%d,%d)); use gpb_hip_vecchia_yaux_partial_dev + an all-reduce", h->i_begin, h->i_end);
+  if (yaux_enqueue(h)) return -1;
   HIP_OK(hipMemcpyAsync(yaux_host, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev) {
+  API_BEGIN();
+  if (!h || !w_dev) return fail("null argument");
+  if (yaux_enqueue(h)) return -1;
+  HIP_OK(hipMemcpyAsync(w_dev, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
   API_END();
 }
 

@@ -1,0 +1,123 @@
+// gpboost_amd/csrc/vecchia_aux_kernels.hip
+//
+// The small, HBM-bound companions of vecchia_point_kernel (kept in their own translation unit so that touching them
+// does not recompile the 18 heavy instantiations): final reduction of the per-workgroup partial sums, packing of the
+// response into the point records, sparse products with B = I - A and B^T, and the fp64-DPP self-test.
+#include "dev_common.h"
+#include "vecchia_kernels.h"
+
+namespace gpb {
+
+// Deterministic final reduction: one workgroup per term; each thread sums a strided subset of the block partials
+// (layout [term][nblocks], contiguous per term) in a fixed order, then a fixed-shape tree.  out[t] = sum_b partials[t][b].
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
+                                                               double* __restrict__ out, double* __restrict__ out2) {
+  __shared__ double s[1024];
+  const int t = blockIdx.x;
+  const double* p = partials + (size_t)t * nblocks;
+  double acc = 0.0, comp = 0.0;   // Kahan on the per-thread chain
+  for (int b = threadIdx.x; b < nblocks; b += 1024) {
+    const double v = p[b] - comp;
+    const double tmp = acc + v;
+    comp = (tmp - acc) - v;
+    acc = tmp;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[t] = s[0];
+    // caller-facing layout {quad, logdet, bad, g1v, g2v, g1r, g2r}: terms 0 and 1 swapped w.r.t. GPB_P_*
+    if (out2) out2[t == GPB_P_LOGDET ? 1 : (t == GPB_P_QUAD ? 0 : t)] = s[0];
+  }
+}
+
+// pts[i].w = y[i]
+__global__ void pack_y_kernel(double4* __restrict__ pts, const double* __restrict__ y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pts[i].w = y[i];
+}
+
+// u = B y from a stored factor (re_model_template.h:9965)
+__global__ void vecchia_By_kernel(const double* __restrict__ A, const int* __restrict__ nn, int n, int m,
+                                  const double* __restrict__ y, double* __restrict__ u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = y[i];
+  for (int j = 0; j < m; ++j) {
+    const int c = nn[(size_t)i * m + j];
+    if (c >= 0) s = __builtin_fma(-A[(size_t)i * m + j], y[c], s);
+  }
+  u[i] = s;
+}
+
+// w = B^T v via the transposed index (CSR over columns): w_j = v_j - sum_{e in T[j]} A_flat[e] v[e / m]
+// With a shard [i0, i1) only the rows of B owned by this device contribute (the caller all-reduces the n-vector).
+__global__ void vecchia_Bt_kernel(const double* __restrict__ A, const int* __restrict__ t_ptr,
+                                  const int* __restrict__ t_pos, int n, int m, int i0, int i1,
+                                  const double* __restrict__ v, double* __restrict__ w) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = (j >= i0 && j < i1) ? v[j] : 0.0;
+  const int e0 = t_ptr[j], e1 = t_ptr[j + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int pos = t_pos[e];
+    const int row = pos / m;
+    if (row >= i0 && row < i1) s = __builtin_fma(-A[pos], v[row], s);
+  }
+  w[j] = s;
+}
+
+// v = u / D elementwise
+__global__ void scale_by_Dinv_kernel(const double* __restrict__ u, const double* __restrict__ D, int n, int i0, int i1,
+                                     double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (i >= i0 && i < i1) ? u[i] / D[i] : 0.0;
+}
+
+// ---- on-device self-test of the fp64 DPP primitives -----------------------------
+// out[lane] = {asm bcast, builtin bcast, asm fnma, fma-with-builtin-bcast} for LANE = 5 and 11
+__global__ void dpp_selftest_kernel(const double* __restrict__ in, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  const double x = in[t], y = in[64 + t], z = in[128 + t];
+  const double b1 = row_bcast<5>(x);
+  const double b2 = row_bcast_builtin<5>(x);
+  double acc1 = z;
+  row_fnma<11>(acc1, x, y);
+  const double acc2 = __builtin_fma(-row_bcast_builtin<11>(x), y, z);
+  out[t * 4 + 0] = b1; out[t * 4 + 1] = b2; out[t * 4 + 2] = acc1; out[t * 4 + 3] = acc2;
+}
+
+
+hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user);
+  return hipGetLastError();
+}
+hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
+  hipLaunchKernelGGL(pack_y_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, y, n);
+  return hipGetLastError();
+}
+hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st) {
+  hipLaunchKernelGGL(vecchia_By_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, nn, n, m, y, u);
+  return hipGetLastError();
+}
+hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,
+                     double* w, hipStream_t st) {
+  hipLaunchKernelGGL(vecchia_Bt_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, t_ptr, t_pos, n, m, i0, i1, v, w);
+  return hipGetLastError();
+}
+hipError_t launch_scale_by_Dinv(const double* u, const double* D, int n, int i0, int i1, double* v, hipStream_t st) {
+  hipLaunchKernelGGL(scale_by_Dinv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, u, D, n, i0, i1, v);
+  return hipGetLastError();
+}
+hipError_t launch_dpp_selftest(const double* in, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(dpp_selftest_kernel, dim3(1), dim3(64), 0, st, in, out);
+  return hipGetLastError();
+}
+
+
+}  // namespace gpb

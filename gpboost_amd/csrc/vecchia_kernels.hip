@@ -41,8 +41,6 @@ namespace {
 // scaled distance r' >= 1e30 makes every kernel value underflow to exactly 0 (v_cvt_i32_f64 saturates,
 // v_ldexp_f64 flushes), while r'^3 stays finite for the Matern-2.5 derivative.
 constexpr double kDummyCoord = 1e30;
-constexpr double kLn2Over64 = 0.010830424696249145;   // ln2 / 64
-constexpr double k64OverLn2 = 92.332482616893657;     // 64 / ln2
 
 // Row r of the augmented system lives in register slot r/16 and, inside its 16-lane DPP row, in lane
 // r%16 for even slots and 15 - r%16 for odd slots.  Reversing the odd slots makes the triangular part of
@@ -76,46 +74,6 @@ __device__ __forceinline__ double sq_dist_s(double px, double py, double pz, dou
     d2 = __builtin_fma(dz, dz, d2);
   }
   return d2;
-}
-
-// Everything a kernel evaluation needs, from the scaled squared distance d2s = (a d 64/ln2)^2:
-//   ev = var * exp(-a d)   (tabv already carries var),   rp = a d 64/ln2
-struct KernEval { double ev, rp; };
-__device__ __forceinline__ KernEval exp_of_scaled(double d2s, const double* __restrict__ tabv) {
-  const double rs = __builtin_amdgcn_rsq(d2s);
-  const double g = d2s * rs, h = 0.5 * rs;
-  const double e = __builtin_fma(-h, g, 0.5);
-  const double rp = __builtin_fma(g, e, g);                 // sqrt(d2s), one Newton step on v_rsq_f64
-  const double kf = __builtin_rint(-rp);
-  const double rr = -rp - kf;                               // exact; |rr| <= 1/2, in units of ln2/64
-  const int k = (int)kf;                                    // saturates for the dummy rows
-  // exp(rr ln2/64) = sum_j (ln2/64)^j rr^j / j!, j <= 5  (remainder < 2e-17)
-  double p = __builtin_fma(rr, 1.2417843701716925e-12, 5.732851688640402e-10);
-  p = __builtin_fma(p, rr, 2.1173137155464776e-07);
-  p = __builtin_fma(p, rr, 5.86490495505617e-05);
-  p = __builtin_fma(p, rr, kLn2Over64);
-  p = __builtin_fma(p, rr, 1.0);
-  KernEval o;
-  o.ev = __builtin_ldexp(tabv[k & 63] * p, k >> 6);
-  o.rp = rp;
-  return o;
-}
-// include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5), transformed scale
-template <int COV>
-__device__ __forceinline__ double matern_cov_s(double d2s, const double* __restrict__ tabv) {
-  const KernEval k = exp_of_scaled(d2s, tabv);
-  if constexpr (COV == kMatern05) return k.ev;
-  else if constexpr (COV == kMatern15) return k.ev * __builtin_fma(k.rp, kLn2Over64, 1.0);
-  else { const double r = k.rp * kLn2Over64; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
-}
-// d/d log(a) of the kernel (transf_scale == true): include/GPBoost/cov_fcts.h:2182-2193 (cm), :2535-2554
-template <int COV>
-__device__ __forceinline__ double matern_dlog_range_s(double d2s, const double* __restrict__ tabv) {
-  const KernEval k = exp_of_scaled(d2s, tabv);
-  const double r = k.rp * kLn2Over64;
-  if constexpr (COV == kMatern05) return -r * k.ev;                                 // cm d sigma, cm = -a
-  else if constexpr (COV == kMatern15) return -(r * r) * k.ev;                      // cm d^2 e^{-ad}, cm = -var a^2
-  else return -(1.0 / 3.0) * (r * r) * __builtin_fma(1.0, r, 1.0) * k.ev;           // cm/3 d^2 (1+ad) e^{-ad}
 }
 
 // Visits every strictly-lower entry (row r <= MT, column c < r) of the augmented system exactly once per owning
@@ -389,89 +347,6 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   }
 }
 
-#ifndef GPB_INSTANTIATE_MT
-// Deterministic final reduction: one workgroup per term; each thread sums a strided subset of the block partials
-// (layout [term][nblocks], contiguous per term) in a fixed order, then a fixed-shape tree.  out[t] = sum_b partials[t][b].
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                               double* __restrict__ out, double* __restrict__ out2) {
-  __shared__ double s[1024];
-  const int t = blockIdx.x;
-  const double* p = partials + (size_t)t * nblocks;
-  double acc = 0.0, comp = 0.0;   // Kahan on the per-thread chain
-  for (int b = threadIdx.x; b < nblocks; b += 1024) {
-    const double v = p[b] - comp;
-    const double tmp = acc + v;
-    comp = (tmp - acc) - v;
-    acc = tmp;
-  }
-  s[threadIdx.x] = acc;
-  __syncthreads();
-  for (int w = 512; w >= 1; w >>= 1) {
-    if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out[t] = s[0];
-    // caller-facing layout {quad, logdet, bad, g1v, g2v, g1r, g2r}: terms 0 and 1 swapped w.r.t. GPB_P_*
-    if (out2) out2[t == GPB_P_LOGDET ? 1 : (t == GPB_P_QUAD ? 0 : t)] = s[0];
-  }
-}
-
-// pts[i].w = y[i]
-__global__ void pack_y_kernel(double4* __restrict__ pts, const double* __restrict__ y, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pts[i].w = y[i];
-}
-
-// u = B y from a stored factor (re_model_template.h:9965)
-__global__ void vecchia_By_kernel(const double* __restrict__ A, const int* __restrict__ nn, int n, int m,
-                                  const double* __restrict__ y, double* __restrict__ u) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = y[i];
-  for (int j = 0; j < m; ++j) {
-    const int c = nn[(size_t)i * m + j];
-    if (c >= 0) s = __builtin_fma(-A[(size_t)i * m + j], y[c], s);
-  }
-  u[i] = s;
-}
-
-// w = B^T v via the transposed index (CSR over columns): w_j = v_j - sum_{e in T[j]} A_flat[e] v[e / m]
-__global__ void vecchia_Bt_kernel(const double* __restrict__ A, const int* __restrict__ t_ptr,
-                                  const int* __restrict__ t_pos, int n, int m, const double* __restrict__ v,
-                                  double* __restrict__ w) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double s = v[j];
-  const int e0 = t_ptr[j], e1 = t_ptr[j + 1];
-  for (int e = e0; e < e1; ++e) {
-    const int pos = t_pos[e];
-    s = __builtin_fma(-A[pos], v[pos / m], s);
-  }
-  w[j] = s;
-}
-
-// v = u / D elementwise
-__global__ void scale_by_Dinv_kernel(const double* __restrict__ u, const double* __restrict__ D, int n,
-                                     double* __restrict__ v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = u[i] / D[i];
-}
-
-// ---- on-device self-test of the fp64 DPP primitives -----------------------------
-// out[lane] = {asm bcast, builtin bcast, asm fnma, fma-with-builtin-bcast} for LANE = 5 and 11
-__global__ void dpp_selftest_kernel(const double* __restrict__ in, double* __restrict__ out) {
-  const int t = threadIdx.x;
-  const double x = in[t], y = in[64 + t], z = in[128 + t];
-  const double b1 = row_bcast<5>(x);
-  const double b2 = row_bcast_builtin<5>(x);
-  double acc1 = z;
-  row_fnma<11>(acc1, x, y);
-  const double acc2 = __builtin_fma(-row_bcast_builtin<11>(x), y, z);
-  out[t * 4 + 0] = b1; out[t * 4 + 1] = b2; out[t * 4 + 2] = acc1; out[t * 4 + 3] = acc2;
-}
-
-#endif  // !GPB_INSTANTIATE_MT
 
 // ---- launchers --------------------------------------------------------------------
 // The heavy template is compiled once per padded neighbour count in its own translation unit
@@ -527,33 +402,6 @@ hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const Vecchia
 #undef GPB_CASE
     default: return hipErrorInvalidValue;
   }
-}
-
-hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
-                                  hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user);
-  return hipGetLastError();
-}
-hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
-  hipLaunchKernelGGL(pack_y_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, y, n);
-  return hipGetLastError();
-}
-hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st) {
-  hipLaunchKernelGGL(vecchia_By_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, nn, n, m, y, u);
-  return hipGetLastError();
-}
-hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, const double* v, double* w,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(vecchia_Bt_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, t_ptr, t_pos, n, m, v, w);
-  return hipGetLastError();
-}
-hipError_t launch_scale_by_Dinv(const double* u, const double* D, int n, double* v, hipStream_t st) {
-  hipLaunchKernelGGL(scale_by_Dinv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, u, D, n, v);
-  return hipGetLastError();
-}
-hipError_t launch_dpp_selftest(const double* in, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(dpp_selftest_kernel, dim3(1), dim3(64), 0, st, in, out);
-  return hipGetLastError();
 }
 
 #endif  // GPB_INSTANTIATE_MT

@@ -124,6 +124,36 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_yaux(self.h, _p(out)))
         return out
 
+    def yaux_partial_dev(self, w_dev_ptr):
+        """This shard's contribution to y_aux as a full n-vector on the device (sum over ranks = y_aux)."""
+        _shim_call(_lib().gpb_hip_vecchia_yaux_partial_dev(self.h, C.c_void_p(int(w_dev_ptr))))
+
+
+class DeviceBuffer(object):
+    """n doubles of device memory (gpb_hip_dev_alloc); .ptr is what the *_dev entry points take."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self.p = C.c_void_p()
+        _shim_call(_lib().gpb_hip_dev_alloc(C.c_uint64(8 * self.n), C.byref(self.p)))
+
+    @property
+    def ptr(self):
+        return self.p.value
+
+    def to_host(self):
+        out = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_dev_to_host(_p(out), self.p, C.c_uint64(8 * self.n)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.p.value:
+                _lib().gpb_hip_dev_free(self.p)
+                self.p = C.c_void_p()
+        except Exception:
+            pass
+
 
 class ExactState(object):
     """Exact (dense) GP: coords (n, d) in data order."""

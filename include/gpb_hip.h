@@ -47,6 +47,11 @@ GPB_HIP_EXPORT int gpb_hip_device_count(int* count);
 GPB_HIP_EXPORT int gpb_hip_set_device(int device);
 /* 1 if the current device is gfx950 */
 GPB_HIP_EXPORT int gpb_hip_device_is_gfx950(int* yes);
+/* Plain device-buffer helpers for hosts that have no allocator of their own (the "_dev" entry points take such
+ * pointers; a torch/RCCL host passes tensor.data_ptr() instead). gpb_hip_dev_to_host synchronises the device first. */
+GPB_HIP_EXPORT int gpb_hip_dev_alloc(uint64_t bytes, void** out);
+GPB_HIP_EXPORT int gpb_hip_dev_free(void* p);
+GPB_HIP_EXPORT int gpb_hip_dev_to_host(void* dst_host, const void* src_dev, uint64_t bytes);
 /* Runs the fp64-DPP primitives against their compiler-scheduled equivalents on the device. */
 GPB_HIP_EXPORT int gpb_hip_selftest(void);
 
@@ -121,6 +126,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_ho
 /* y_aux = B^T D^-1 B y (CalcYAux, include/GPBoost/re_model_template.h:9771-9773), Vecchia order.
  * Requires gpb_hip_vecchia_factor() with the current y. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host);
+/* Multi-GPU form: this handle's shard contributes w = B_s^T D_s^-1 B_s y (rows of the shard only) as a full n-vector
+ * in device memory (enqueued on the handle's stream); the sum over ranks (one all-reduce of n doubles)
+ * is y_aux.  Requires gpb_hip_vecchia_factor() on the same shard. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev);
 
 /* ------------------------------------------------------------------------------------
  * Exact (dense) GP, Gaussian likelihood -- BASELINE config 1: replaces CalcSigmaComps / CalcZSigmaZt / CalcChol /

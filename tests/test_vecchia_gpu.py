@@ -285,3 +285,30 @@ def test_several_models_alive_and_interleaved(gpb, orc):
     assert abs(a2 - orc.gp_nll(c2, y2, cp, "matern", 2.5, 35, "random", 4)) <= RTOL * abs(a2)
     del m1
     assert m2.neg_log_likelihood(cp, y2) == a2
+
+
+def test_sharded_yaux_and_dev_entry_points(gpb, orc):
+    """Multi-GPU composition on one device: per-shard partial y_aux vectors add up to y_aux; the *_dev entry points
+    (device output buffers, asynchronous) agree with the host-returning ones."""
+    from gpboost_amd import shim, parallel
+    coords, y = cases.synthetic(20011, 2, seed=77)
+    perm, co, nn = orc.vecchia_setup(coords, 30, "random", 1)
+    st = shim.VecchiaState(co, 30); st.set_neighbors(nn); st.set_y(y[perm])
+    var, a = 10.0, 10.0
+    st.factor(0, var, a)
+    full = st.yaux()
+    Ao, Do, _ = orc.vecchia_factor(co, nn, 0, var, a)
+    np.testing.assert_allclose(full, orc.vecchia_yaux(Ao, Do, nn, y[perm]), rtol=1e-9, atol=1e-10)
+    buf = shim.DeviceBuffer(st.n)
+    acc = np.zeros(st.n)
+    for r in range(4):
+        st.set_shard(*parallel.shard_range(st.n, r, 4))
+        st.factor(0, var, a)
+        st.yaux_partial_dev(buf.ptr)
+        acc += buf.to_host()
+    st.set_shard(0, st.n)
+    np.testing.assert_allclose(acc, full, rtol=1e-11, atol=1e-12)
+    t3 = shim.DeviceBuffer(3); t7 = shim.DeviceBuffer(7)
+    st.nll_terms_dev(0, var, a, t3.ptr); st.grad_terms_dev(0, var, a, t7.ptr)
+    assert np.array_equal(t3.to_host(), st.nll_terms(0, var, a))
+    assert np.array_equal(t7.to_host(), st.grad_terms(0, var, a))
