@@ -199,6 +199,25 @@ def main():
             "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops_launch},
         }
+        if world == 1:
+            # the one HBM-bound kernel of the path: dense covariance assembly (exact GP), measured live
+            try:
+                ne = 16384
+                ex = shim.ExactState(coords[:ne]); ex.set_y(y[:ne])
+                ex.nll_terms(ct, var0, a0)
+                _, _, ms3 = ex.nll_terms(ct, var0, a0)
+                nt = (ne + 127) // 128
+                wbytes = nt * (nt + 1) // 2 * 128 * 128 * 8          # lower 128x128 tiles actually written
+                out["roofline_cov_assembly"] = {
+                    "bound": "hbm", "kernel": "dense_cov_lower_kernel", "achieved": wbytes / (ms3[0] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wbytes / (ms3[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel_ms": float(ms3[0]), "algorithmic_bytes_per_launch": wbytes,
+                    "workload": "exact GP covariance assembly, n=%d (lower triangle, 8 B written per Matern evaluation)" % ne,
+                    "dense_cholesky_ms": float(ms3[1]), "dense_cholesky_tflops": ne ** 3 / 3.0 / (ms3[1] * 1e-3) / 1e12,
+                    "fp64_mfma_peak_tflops": FP64_PEAK_TFLOPS}
+                ex.close()
+            except Exception as e:
+                out["roofline_cov_assembly"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)

@@ -32,8 +32,8 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // ---- covariance assembly ----------------------------------------------------------------
 // grid = lower 128x128 tiles (ti >= tj) flattened; block = 256 threads, thread (tx, ty) computes an 8x8 sub-block
 // (64 kernel evaluations per lane amortise the prologue).  Coordinates are staged in LDS already multiplied by
-// a * 64/ln2 (dev_common.h), the 64-entry table carries the variance.  Stores: 2 x 32 bytes per lane and row,
-// 16 lanes cover 1 KB of a row contiguously.
+// a * 64/ln2 (dev_common.h), the 64-entry table carries the variance.  Stores: 2 x 32 bytes per lane and row; each
+// store instruction covers 512 contiguous bytes of a row with its 16 lanes (write-combining friendly).
 constexpr int CT = 128;
 template <int COV, bool D3>
 __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __restrict__ pts, int n, int np, double var,
@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
   const int tx = tid & 15, ty = tid >> 4;
   double qx[8], qy[8], qz[8];
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc) { qx[cc] = s_cx[tx * 8 + cc]; qy[cc] = s_cy[tx * 8 + cc]; qz[cc] = D3 ? s_cz[tx * 8 + cc] : 0.0; }
+  for (int cc = 0; cc < 8; ++cc) {   // columns tx*4..+3 and 64+tx*4..+3: every store instruction is contiguous across the 16 lanes
+    const int lc = (cc < 4) ? tx * 4 + cc : 64 + tx * 4 + (cc - 4);
+    qx[cc] = s_cx[lc]; qy[cc] = s_cy[lc]; qz[cc] = D3 ? s_cz[lc] : 0.0;
+  }
   const double diag = var + nugget;
 #pragma unroll 2
   for (int rr = 0; rr < 8; ++rr) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
     double v[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const int c = tj * CT + tx * 8 + cc;
+      const int c = tj * CT + ((cc < 4) ? tx * 4 + cc : 64 + tx * 4 + (cc - 4));
       const double dx = px - qx[cc], dy = py - qy[cc];
       double d2 = __builtin_fma(dx, dx, 1e-300);
       d2 = __builtin_fma(dy, dy, d2);
@@ -82,11 +85,9 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
       if (r >= n || c >= n) val = (r == c) ? 1.0 : 0.0;     // identity padding
       v[cc] = val;
     }
-    if (tj * CT + tx * 8 < np) {
-      double4* dst = reinterpret_cast<double4*>(P + (size_t)r * np + (size_t)tj * CT + tx * 8);
-      dst[0] = make_double4(v[0], v[1], v[2], v[3]);
-      dst[1] = make_double4(v[4], v[5], v[6], v[7]);
-    }
+    double* rowp = P + (size_t)r * np + (size_t)tj * CT + tx * 4;
+    if (tj * CT + tx * 4 < np) *reinterpret_cast<double4*>(rowp) = make_double4(v[0], v[1], v[2], v[3]);
+    if (tj * CT + 64 + tx * 4 < np) *reinterpret_cast<double4*>(rowp + 64) = make_double4(v[4], v[5], v[6], v[7]);
   }
 }
 

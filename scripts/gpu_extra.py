@@ -16,7 +16,8 @@ for n in ((2000, 8192, 16384) if "exact" in SECTIONS else ()):
     st.nll_terms(1, 10.0, 17.3)
     out, _, ms = st.nll_terms(1, 10.0, 17.3)
     np_ = ((n + 63) // 64) * 64
-    wbytes = (np_ // 64) * (np_ // 64 + 1) // 2 * 64 * 64 * 8
+    nt = (np_ + 127) // 128
+    wbytes = nt * (nt + 1) // 2 * 128 * 128 * 8
     print("n=%d: assembly %.3f ms (%.1f GB/s written, lower tiles) | cholesky %.3f ms (%.2f TFLOP/s) | solves %.3f ms | terms %s" % (
         n, ms[0], wbytes / ms[0] / 1e6, ms[1], n ** 3 / 3.0 / ms[1] / 1e9, ms[2], out), flush=True)
     st.close()
