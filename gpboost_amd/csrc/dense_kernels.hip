@@ -13,9 +13,9 @@
 //                            stores: the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
 //   potrf_diag_kernel        64x64 diagonal block, one wavefront, row-per-lane in registers, v_readlane broadcasts
 //   trsm_panel_kernel        L21 = A21 L11^-T, one lane per row, L11 through scalar (wave-uniform) loads
-//   syrk_mfma_kernel         A22 -= L21 L21^T on the lower tiles with v_mfma_f64_16x16x4_f64
-//                            (one workgroup per 128x128 tile, one wavefront per 64x64 quadrant = 16 accumulator
-//                            tiles, K = 64 per panel, both panels staged once in 135 KB of LDS)
+//   syrk_mfma_kernel         C -= L L^T on lower 128x128 tiles with v_mfma_f64_16x16x4_f64 (one wavefront per 64x64
+//                            quadrant = 16 accumulator tiles kept across the K loop, K staged through LDS in chunks of
+//                            64); used "narrow" (K = 64, inside a 512-wide block column) and "wide" (K = 512)
 //   trsv_lower_kernel        forward (and optionally backward) substitution + y^T Psi^-1 y + log-det
 #include "dev_common.h"
 #include "dense_kernels.h"
@@ -153,33 +153,25 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ P, 
 }
 
 // ---- trailing update with fp64 MFMA -------------------------------------------------------------
-// One workgroup (4 wavefronts, one per SIMD) per 128x128 tile (TI >= TJ) of the trailing matrix:
-// C -= A B^T with A = L21[rows of TI], B = L21[rows of TJ], K = 64 (one panel).  Both panels are staged once in LDS
-// (2 x 128 x 66 doubles = 135 KB); each wavefront owns a 64x64 quadrant = 4x4 MFMA tiles of v_mfma_f64_16x16x4_f64.
-__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, int np, int k0) {
+// C[r][c] -= sum_{k in [kp0, kp0+K)} L[r][k] L[c][k]   for r in [r_base, np), c in [c_base, c_lim), c <= r.
+// One workgroup (4 wavefronts, one per SIMD) per 128x128 tile; each wavefront owns a 64x64 quadrant = 4x4 MFMA
+// tiles of v_mfma_f64_16x16x4_f64 whose accumulators stay in registers across the whole K loop; K is consumed in
+// chunks of 64 columns staged through LDS (2 x 128 x 66 doubles = 135 KB).  The factorisation calls it twice per
+// step: "narrow" (K = 64, only the columns of the current 512-wide block column) and "wide" (K = 512, the whole
+// trailing matrix, once per block column) -- the wide call reads and writes every C tile once per 512 columns
+// instead of once per 64, which is what lifts the arithmetic intensity from ~5 to ~40 flop/B.
+__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, int np, int kp0, int K, int r_base,
+                                                        int c_base, int c_lim, int ntj) {
   __shared__ double sA[128 * LDSS], sB[128 * LDSS];   // 135,168 B static LDS: one workgroup per CU
-  const int t = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
-  while ((long long)ti * (ti + 1) / 2 > t) --ti;
-  const int tj = t - (int)((long long)ti * (ti + 1) / 2);
-  const int base = k0 + TB;
-  const int r0 = base + ti * 128, c0 = base + tj * 128;
+  const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+  const int r0 = r_base + ti * 128, c0 = c_base + tj * 128;
+  if (c0 > r0 + 127) return;                            // tile strictly above the diagonal
   const int tid = threadIdx.x;
-  // stage: 128 rows x 64 doubles per panel, 16-byte loads, rows past the matrix read as zero
-  for (int e = tid; e < 128 * (TB / 2); e += 256) {
-    const int i = e / (TB / 2), j2 = (e % (TB / 2)) * 2;
-    double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
-    if (r0 + i < np) va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + k0 + j2);
-    if (c0 + i < np) vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + k0 + j2);
-    sA[i * LDSS + j2] = va.x; sA[i * LDSS + j2 + 1] = va.y;
-    sB[i * LDSS + j2] = vb.x; sB[i * LDSS + j2 + 1] = vb.y;
-  }
-  __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int wi = wave >> 1, wj = wave & 1;
-  if (ti == tj && wj > wi) return;                      // quadrant strictly above the diagonal
-  if (r0 + 64 * wi >= np || c0 + 64 * wj >= np) return;  // quadrant outside the matrix (ragged edge)
+  const int gr0 = r0 + 64 * wi, gc0 = c0 + 64 * wj;
+  // quadrant-level skips (wave-uniform); the wavefront still takes part in the staging and the barriers
+  const bool quad_live = (gc0 <= gr0 + 63) && gr0 < np && gc0 < c_lim;
   const double* qA = sA + (64 * wi) * LDSS;
   const double* qB = sB + (64 * wj) * LDSS;
   double4v acc[4][4];
@@ -188,22 +180,36 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, 
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (double4v){0.0, 0.0, 0.0, 0.0};
   const int fr = lane & 15, fk = lane >> 4;   // fragment row / k within the 16x4 (A) and 4x16 (B) operands
-#pragma unroll 4
-  for (int kk = 0; kk < TB / 4; ++kk) {
-    double af[4], bf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      af[q] = qA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
-      bf[q] = qB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L21[j][k]
+  for (int kc = 0; kc < K; kc += TB) {
+    __syncthreads();                                    // previous chunk fully consumed
+    for (int e = tid; e < 128 * (TB / 2); e += 256) {   // stage 128 rows x 64 doubles per panel, 16-byte loads
+      const int i = e / (TB / 2), j2 = (e % (TB / 2)) * 2;
+      double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+      if (r0 + i < np) va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + kp0 + kc + j2);
+      if (c0 + i < np) vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + kp0 + kc + j2);
+      sA[i * LDSS + j2] = va.x; sA[i * LDSS + j2 + 1] = va.y;
+      sB[i * LDSS + j2] = vb.x; sB[i * LDSS + j2 + 1] = vb.y;
     }
+    __syncthreads();
+    if (quad_live) {
+#pragma unroll 4
+      for (int kk = 0; kk < TB / 4; ++kk) {
+        double af[4], bf[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int q = 0; q < 4; ++q) {
+          af[q] = qA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
+          bf[q] = qB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L[j][k]
+        }
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj)
-        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj)
+            acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+      }
+    }
   }
+  if (!quad_live) return;
   // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-  const int gr0 = r0 + 64 * wi, gc0 = c0 + 64 * wj;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = gr0 + 16 * mi + fk + 4 * r, gj = gc0 + 16 * nj + fr;
-        if (gj <= gi) P[(size_t)gi * np + gj] -= acc[mi][nj][r];
+        if (gj <= gi && gi < np && gj < c_lim) P[(size_t)gi * np + gj] -= acc[mi][nj][r];
       }
 }
 
@@ -308,16 +314,26 @@ hipError_t launch_dense_cov(int cov, bool d3, const double4* pts, int n, int np,
   return hipGetLastError();
 }
 
+static void launch_update(double* P, int np, int kp0, int K, int r_base, int c_base, int c_lim, hipStream_t st) {
+  if (r_base >= np || c_base >= c_lim) return;
+  const int nti = (np - r_base + 127) / 128, ntj = (c_lim - c_base + 127) / 128;
+  hipLaunchKernelGGL(syrk_mfma_kernel, dim3(nti * ntj), dim3(256), 0, st, P, np, kp0, K, r_base, c_base, c_lim, ntj);
+}
+
+// Blocked right-looking Cholesky with two levels: 64-column panels (potrf + trsm + narrow update inside the current
+// 512-wide block column) and one wide K = 512 update of the remaining trailing matrix per block column.
 hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st) {
-  const int nt = np / TB;
-  for (int kb = 0; kb < nt; ++kb) {
-    const int k0 = kb * TB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
-    const int rows_below = np - k0 - TB;
-    if (rows_below <= 0) break;
-    hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
-    const int ntr = (rows_below + 127) / 128;
-    hipLaunchKernelGGL(syrk_mfma_kernel, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, P, np, k0);
+  constexpr int OB = 512;
+  for (int J0 = 0; J0 < np; J0 += OB) {
+    const int Jend = (J0 + OB < np) ? J0 + OB : np;
+    for (int k0 = J0; k0 < Jend; k0 += TB) {
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
+      const int rows_below = np - k0 - TB;
+      if (rows_below <= 0) break;
+      hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
+      launch_update(P, np, k0, TB, k0 + TB, k0 + TB, Jend, st);            // narrow: columns of this block column only
+    }
+    launch_update(P, np, J0, Jend - J0, Jend, Jend, np, st);               // wide: K = 512, whole trailing matrix
   }
   return hipGetLastError();
 }
