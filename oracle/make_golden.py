@@ -44,6 +44,19 @@ def main():
                 res["A_%d" % k] = A[res["A_rows_%d" % k]]
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
         print("wrote", name, "n=%d m=%d" % (mdl.n, mdl.m), "nll0=%.10f" % res["nll_0"])
+    hist_fixture(out_dir)
+
+
+def hist_fixture(out_dir):
+    X, g, h, leaf = cases.make_hist_data()
+    res = {}
+    for li, di in enumerate((None, leaf)):
+        for hi, hs in enumerate((None, h)):
+            bins, gnb, hist = refdrv.ref_histogram(X, cases.HIST_CASE["max_bin"], di, g, hs, 1.0)
+            res["bins"] = bins; res["group_num_bin"] = gnb
+            res["hist_leaf%d_hess%d" % (li, hi)] = hist
+    np.savez_compressed(os.path.join(out_dir, "hist_ref.npz"), **res)
+    print("wrote hist_ref: groups", len(res["group_num_bin"]), "bins", res["group_num_bin"])
 
 
 if __name__ == "__main__":

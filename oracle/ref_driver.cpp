@@ -20,6 +20,10 @@
 #define private public
 #define protected public
 #include <GPBoost/re_model.h>
+#include <LightGBM/c_api.h>
+#include <LightGBM/dataset.h>
+#include <LightGBM/feature_group.h>
+#include <LightGBM/train_share_states.h>
 #undef private
 #undef protected
 
@@ -108,6 +112,47 @@ int refdrv_get_factor(void* h, int m, double* A, double* Dinv, double* yaux) {
     return 0;
   } catch (std::exception& e) {
     fprintf(stderr, "refdrv_get_factor: %s\n", e.what());
+    return -1;
+  }
+}
+
+/* Histogram of one leaf built by the reference itself: LGBM_DatasetCreateFromMat (the reference's own binning, no
+ * feature bundling, col-wise) followed by Dataset::ConstructHistograms (include/LightGBM/dataset.h:471-500 ->
+ * src/LightGBM/io/dataset.cpp:1143-1245).  Returns the reference's STORED group bins (what DenseBin holds, bin 0 =
+ * most-frequent-bin placeholder) and the raw histogram (grad, hess) pairs laid out by group_bin_boundaries_. */
+__attribute__((visibility("default")))
+int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* data_indices, int num_data,
+                const double* grad, const double* hess, double const_hess, int* num_groups_out, int* group_num_bin,
+                unsigned char* bins_out, double* hist_out) {
+  try {
+    using namespace LightGBM;
+    char params[256];
+    snprintf(params, sizeof(params), "max_bin=%d min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=4", max_bin);
+    DatasetHandle dh = nullptr;
+    if (LGBM_DatasetCreateFromMat(X_rowmajor, C_API_DTYPE_FLOAT64, n, F, 1, params, nullptr, &dh) != 0) {
+      fprintf(stderr, "refdrv_hist: %s\n", LGBM_GetLastError());
+      return -1;
+    }
+    Dataset* ds = reinterpret_cast<Dataset*>(dh);
+    const int ng = ds->num_groups_;
+    *num_groups_out = ng;
+    for (int g = 0; g < ng; ++g) {
+      group_num_bin[g] = ds->feature_groups_[g]->num_total_bin_;
+      std::unique_ptr<BinIterator> it(ds->feature_groups_[g]->bin_data_->GetIterator(0, group_num_bin[g] - 1, 0));
+      it->Reset(0);
+      for (int i = 0; i < n; ++i) bins_out[(size_t)g * n + i] = (unsigned char)it->RawGet(i);
+    }
+    std::vector<score_t> g_all(grad, grad + n), h_all(n, const_hess), og(n), oh(n);
+    if (hess) std::copy(hess, hess + n, h_all.begin());
+    std::vector<int8_t> used(ds->num_features(), 1);
+    std::unique_ptr<TrainingShareStates> share(ds->GetShareStates(og.data(), oh.data(), used, hess == nullptr, true, false));
+    std::vector<hist_t> hist((size_t)ds->NumTotalBin() * 2 + 16, 0.);
+    ds->ConstructHistograms(used, data_indices, num_data, g_all.data(), h_all.data(), og.data(), oh.data(), share.get(), hist.data());
+    std::copy(hist.begin(), hist.begin() + (size_t)ds->NumTotalBin() * 2, hist_out);
+    LGBM_DatasetFree(dh);
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_hist: %s\n", e.what());
     return -1;
   }
 }

@@ -111,3 +111,25 @@ class RefCAPIModel(object):
             self.L.GPB_REModelFree(self.h)
         except Exception:
             pass
+
+
+def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0):
+    """The reference's own binning + Dataset::ConstructHistograms for one leaf.
+    Returns (bins uint8 (G, n) = the reference's stored group bins, group_num_bin (G,), hist (sum bins, 2))."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, F = X.shape
+    di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+    nd = n if di is None else di.size
+    g = np.ascontiguousarray(grad, dtype=np.float64)
+    h = None if hess is None else np.ascontiguousarray(hess, dtype=np.float64)
+    ng = C.c_int(0)
+    gnb = np.zeros(F, dtype=np.int32)
+    bins = np.zeros((F, n), dtype=np.uint8)
+    hist = np.zeros((F * (max_bin + 2), 2))
+    rc = _lib().refdrv_hist(C.c_int(n), C.c_int(F), _P(X), C.c_int(max_bin), None if di is None else _P(di), C.c_int(nd), _P(g),
+                            None if h is None else _P(h), C.c_double(const_hess), C.byref(ng), _P(gnb), _P(bins), _P(hist))
+    if rc != 0:
+        raise RuntimeError("refdrv_hist failed")
+    G = ng.value
+    tot = int(gnb[:G].sum())
+    return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy()

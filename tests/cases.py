@@ -62,3 +62,19 @@ def synthetic(n, d, seed=1):
     coords = rng.uniform(size=(n, d))
     y = rng.standard_normal(n)
     return coords, y
+
+
+# Histogram fixture: inputs for the reference's own binning + Dataset::ConstructHistograms (oracle/ref_driver.cpp:refdrv_hist)
+HIST_CASE = dict(n=20000, F=6, seed=3, max_bin=255, leaf_size=7000)
+
+
+def make_hist_data(c=HIST_CASE):
+    rng = np.random.default_rng(c["seed"])
+    n, F = c["n"], c["F"]
+    X = rng.uniform(size=(n, F))
+    X[:, 2] = np.round(X[:, 2] * 10) / 10                             # 11 distinct values
+    X[:, 4] = (rng.uniform(size=n) < 0.7) * rng.uniform(size=n)        # 30 % exact zeros (most-frequent bin)
+    g = rng.standard_normal(n)
+    h = rng.uniform(0.5, 2, size=n)
+    leaf = np.sort(rng.choice(n, size=c["leaf_size"], replace=False)).astype(np.int32)
+    return X, g, h, leaf

@@ -55,3 +55,26 @@ def test_histogram_is_reproducible_and_subtractable(lib_built, orc):
     assert np.array_equal(cl + cr, pc)
     np.testing.assert_allclose(hl[:, 0] + hr[:, 0], parent[:, 0], rtol=0, atol=1e-9)
     assert int(pc[bo[0]:bo[1]].sum()) == n
+
+
+def test_histogram_against_reference_fixture(lib_built):
+    """The reference's own stored bins and its Dataset::ConstructHistograms output (tests/golden/hist_ref.npz)."""
+    import os
+    from gpboost_amd import shim
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hist_ref.npz"))
+    X, grad, hess, leaf = cases.make_hist_data()
+    bins, gnb = g["bins"], g["group_num_bin"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    for hi, hs in enumerate((None, hess)):
+        hb.set_gradients(grad, hs)
+        for li, di in enumerate((None, leaf)):
+            ref = g["hist_leaf%d_hess%d" % (li, hi)]
+            hist, cnt = hb.build(di, const_hess=1.0)
+            np.testing.assert_allclose(hist[:, 0], ref[:, 0], rtol=0, atol=1e-10 * (np.abs(ref[:, 0]).max() + 1))
+            if hs is None:
+                assert np.array_equal(hist[:, 1], ref[:, 1]), "count * hess must be bit-exact"
+                assert np.array_equal(cnt.astype(np.float64), ref[:, 1])
+            else:
+                np.testing.assert_allclose(hist[:, 1], ref[:, 1], rtol=0, atol=1e-10 * (np.abs(ref[:, 1]).max() + 1))

@@ -87,3 +87,21 @@ def test_oracle_histogram_against_numpy(orc):
             np.testing.assert_allclose(hg[bo[f]:bo[f + 1]], np.bincount(bins[f, rows], weights=grad[rows], minlength=nb[f]), atol=1e-10)
             np.testing.assert_allclose(hh[bo[f]:bo[f + 1]], np.bincount(bins[f, rows], weights=hess[rows], minlength=nb[f]), atol=1e-10)
             np.testing.assert_array_equal(hh2[bo[f]:bo[f + 1]], cnt.astype(np.float64))
+
+
+def test_oracle_histogram_matches_reference_fixture(orc):
+    """tests/golden/hist_ref.npz = the reference's own binning + Dataset::ConstructHistograms (dataset.cpp:1143-1245) through
+    oracle/ref_driver.cpp:refdrv_hist; the oracle accumulates in the same per-feature row order, so even the fp64 sums are
+    bit-identical."""
+    g = np.load(os.path.join(GOLD, "hist_ref.npz"))
+    X, grad, hess, leaf = cases.make_hist_data()
+    bins, gnb = g["bins"], g["group_num_bin"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    for li, di in enumerate((None, leaf)):
+        for hi, hs in enumerate((None, hess)):
+            ref = g["hist_leaf%d_hess%d" % (li, hi)]
+            hg, hc, hh = orc.hist_build(bins, bo, di, grad, hs, 1.0)
+            assert np.array_equal(hg, ref[:, 0])
+            assert np.array_equal(hh, ref[:, 1])
+            if hs is None:
+                assert np.array_equal(hc.astype(np.float64), ref[:, 1])     # count * 1.0 (dataset.cpp:1223-1226)
