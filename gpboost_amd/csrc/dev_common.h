@@ -85,24 +85,8 @@ __device__ __forceinline__ double row_bcast_builtin(double x) {
 #define GPB_ROW_FNMA(L, acc, b, own) ::gpb::row_fnma<L>((acc), (b), (own))
 #endif
 
-// ---- fast fp64 elementary functions (relative error ~1e-15, far inside the
-// 1e-8 parity budget; no denormal/NaN special-casing beyond what is noted) ----
+// ---- fast fp64 elementary functions (relative error ~1e-15, far inside the 1e-8 parity budget) ----
 
-// 1/sqrt(x), x > 0: v_rsq_f64 (~2^-26) + one Newton step.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  const double y0 = __builtin_amdgcn_rsq(x);
-  const double e = __builtin_fma(-x * y0, y0, 1.0);
-  return __builtin_fma(0.5 * y0, e, y0);
-}
-// sqrt(x), x >= 0 (x == 0 allowed: clamped to 1e-300 first).
-__device__ __forceinline__ double fast_sqrt(double x) {
-  x = __builtin_fmax(x, 1e-300);
-  const double y0 = __builtin_amdgcn_rsq(x);
-  double g = x * y0;            // ~sqrt(x)
-  const double h = 0.5 * y0;
-  const double e = __builtin_fma(-h, g, 0.5);
-  return __builtin_fma(g, e, g);
-}
 // 1/x: v_rcp_f64 + one Newton step.
 __device__ __forceinline__ double fast_rcp(double x) {
   const double y0 = __builtin_amdgcn_rcp(x);
@@ -110,41 +94,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return __builtin_fma(y0, e, y0);
 }
 
-// exp(x) for x <= 0 (clamped at -800 -> 0).  x = (64 e + j) ln2/64 + r,
-// |r| <= ln2/128;  exp(x) = 2^e * 2^(j/64) * P5(r).  tab = 64-entry 2^(j/64) table in LDS.
-#define GPB_EXP_TAB_SIZE 64
-__device__ __forceinline__ double fast_exp_neg(double x, const double* __restrict__ tab) {
-  x = __builtin_fmax(x, -800.0);
-  const double kf = __builtin_rint(x * 92.332482616893656877);  // 64/ln2
-  double r = __builtin_fma(kf, -0.010830424696249145, x);       // ln2/64 rounded to double (fma: one rounding)
-  r = __builtin_fma(kf, -3.623510646634843e-19, r);             // ln2/64 - double(ln2/64)
-  const int k = (int)kf;
-  const double t = tab[k & 63];
-  // P5(r) = 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120   (|r|^6/720 < 4e-17)
-  double p = __builtin_fma(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
-  p = __builtin_fma(p, r, 1.66666666666666667e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(t * p, k >> 6);
-}
-// Fill the table (call by the first 64 threads of a block, then __syncthreads()).
-__device__ __forceinline__ void fill_exp_table(double* tab, const double* __restrict__ gtab) {
-  if (threadIdx.x < GPB_EXP_TAB_SIZE) tab[threadIdx.x] = gtab[threadIdx.x];
-}
+#define GPB_EXP_TAB_SIZE 64   // 2^(j/64), j = 0..63 (filled on the host, pre-multiplied by the variance in the kernels)
 
 // ---- isotropic Matern kernels on the transformed scale --------------------
 // reference: include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5)
 enum CovType : int { kMatern05 = 0, kMatern15 = 1, kMatern25 = 2 };
-
-template <int COV>
-__device__ __forceinline__ double matern_cov(double dist, double var, double a, const double* tab) {
-  const double r = a * dist;
-  const double e = fast_exp_neg(-r, tab);
-  if constexpr (COV == kMatern05) return var * e;
-  else if constexpr (COV == kMatern15) return var * __builtin_fma(1.0, r, 1.0) * e;
-  else return var * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0) * e;
-}
 
 // ---- scaled-distance form used by the hot kernels -------------------------------------------
 // Coordinates are pre-multiplied by a * 64/ln2, so that exp(-a d) = 2^(-r'/64) with r' the scaled distance:

@@ -7,6 +7,7 @@
 #include "../../include/gpb_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -86,6 +87,9 @@ struct gpb_hip_vecchia {
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false;
+  ncclComm_t comm = nullptr;      // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init)
+  int comm_rank = 0, comm_world = 1;
+  double* d_red = nullptr;        // 8 doubles: all-reduce buffer in the caller-facing term order
   std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
   std::vector<int> nn_host;
 };
@@ -237,7 +241,8 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   if (h->stream || !h->owns_stream) { (void)hipStreamSynchronize(h->stream); if (h->owns_stream) (void)hipStreamDestroy(h->stream); }
   dev_free(h->d_pts); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out);
   dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage);
-  dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag);
+  dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
   API_END();
@@ -412,6 +417,63 @@ int gpb_hip_vecchia_nll_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var
   API_BEGIN();
   if (!out3_dev) return fail("null output");
   if (vecchia_launch(h, gpb::MODE_NLL, cov_type, var, a, gauss_likelihood, out3_dev, 3)) return -1;
+  API_END();
+}
+
+// ---- in-library RCCL reduction of the per-shard terms (one process per GPU) ---------------------------------------
+#define NCCL_OK(expr)                                                                                   \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+int gpb_hip_comm_get_unique_id(unsigned char* id128) {
+  API_BEGIN();
+  if (!id128) return fail("null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCL_OK(ncclGetUniqueId(&id));
+  std::memcpy(id128, &id, 128);
+  API_END();
+}
+
+int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, int rank, int world) {
+  API_BEGIN();
+  if (!h || !id128) return fail("null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail("gpb_hip_vecchia_comm_init: rank %d / world %d", rank, world);
+  HIP_OK(hipSetDevice(h->device));
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  NCCL_OK(ncclCommInitRank(&h->comm, world, id, rank));
+  h->comm_rank = rank; h->comm_world = world;
+  if (!h->d_red) HIP_OK(hipMalloc(&h->d_red, sizeof(double) * 8));
+  API_END();
+}
+
+// point kernel + fixed-order reduction + ncclAllReduce(sum) of the 3 / 7 terms on the handle's stream, result to the host
+static int vecchia_allreduce_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss,
+                                   double* out_host, int nout) {
+  if (!h || !out_host) return fail("null argument");
+  if (!h->comm) return fail("no communicator: call gpb_hip_vecchia_comm_init first");
+  if (vecchia_launch(h, mode, cov_type, var, a, gauss, h->d_red, nout)) return -1;
+  NCCL_OK(ncclAllReduce(h->d_red, h->d_red, (size_t)nout, ncclDouble, ncclSum, h->comm, h->stream));
+  HIP_OK(hipMemcpyAsync(h->h_out, h->d_red, sizeof(double) * nout, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  for (int t = 0; t < nout; ++t) out_host[t] = h->h_out[t];
+  return 0;
+}
+
+int gpb_hip_vecchia_nll_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int gauss_likelihood,
+                                        double* out3_host) {
+  API_BEGIN();
+  if (vecchia_allreduce_terms(h, gpb::MODE_NLL, cov_type, var, a, gauss_likelihood, out3_host, 3)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_grad_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a, double* out7_host) {
+  API_BEGIN();
+  if (vecchia_allreduce_terms(h, gpb::MODE_GRAD, cov_type, var, a, 1, out7_host, 7)) return -1;
   API_END();
 }
 

@@ -103,6 +103,22 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_grad_terms_dev(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
                                                          C.c_void_p(int(out_dev_ptr))))
 
+    def comm_init(self, id128, rank, world):
+        """Collective: bootstrap the in-library RCCL communicator from the 128-byte unique id of rank 0."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        _shim_call(_lib().gpb_hip_vecchia_comm_init(self.h, buf, C.c_int(int(rank)), C.c_int(int(world))))
+
+    def nll_terms_allreduce(self, cov_type, var, a, gauss=True):
+        out = np.empty(3)
+        _shim_call(_lib().gpb_hip_vecchia_nll_terms_allreduce(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
+                                                              C.c_int(1 if gauss else 0), _p(out)))
+        return out
+
+    def grad_terms_allreduce(self, cov_type, var, a):
+        out = np.empty(7)
+        _shim_call(_lib().gpb_hip_vecchia_grad_terms_allreduce(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(out)))
+        return out
+
     def bench(self, mode, cov_type, var, a, warmup, steps):
         """-> (ms_total, ms_point_kernel_avg, last_terms[7])"""
         t = C.c_double(0); k = C.c_double(0); out = np.empty(7)
@@ -190,6 +206,13 @@ class ExactState(object):
         _shim_call(_lib().gpb_hip_exact_nll_terms(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(out),
                                                   _p(ya), _p(ms)))
         return out, ya, ms
+
+
+def comm_unique_id():
+    """128-byte ncclUniqueId (call on rank 0, broadcast to the other ranks)."""
+    buf = (C.c_ubyte * 128)()
+    _shim_call(_lib().gpb_hip_comm_get_unique_id(buf))
+    return bytes(buf)
 
 
 def nll_from_terms(n, yPy, logdet, sigma2):

@@ -110,6 +110,17 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov_type
 GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
                                                   double* out7_dev);
 
+/* In-library RCCL reduction over the ranks of a node (one process per GPU; xGMI): the communicator is bootstrapped from a
+ * 128-byte ncclUniqueId made on rank 0 and handed to every rank by the host (e.g. a torch.distributed broadcast).
+ * The *_allreduce calls run point kernel -> fixed-order reduction -> ncclAllReduce(sum) of the 3 / 7 terms on the handle's
+ * stream and deliver the job-wide terms to every rank's host -- one launch sequence, one collective, one sync per evaluation. */
+GPB_HIP_EXPORT int gpb_hip_comm_get_unique_id(unsigned char* id128);
+GPB_HIP_EXPORT int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, int rank, int world);
+GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                                       int gauss_likelihood, double* out3_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
+                                                        double* out7_host);
+
 /* Measurement helper (bench.py): `steps` back-to-back evaluations (mode 0 = nll terms, 2 = gradient terms) on the
  * handle's stream after `warmup` untimed ones, covariance parameters perturbed every step.  ms_total: HIP events
  * around the whole timed region (point kernel + final reduction, no host sync inside); ms_point_kernel_avg: mean of

@@ -312,3 +312,53 @@ def test_sharded_yaux_and_dev_entry_points(gpb, orc):
     st.nll_terms_dev(0, var, a, t3.ptr); st.grad_terms_dev(0, var, a, t7.ptr)
     assert np.array_equal(t3.to_host(), st.nll_terms(0, var, a))
     assert np.array_equal(t7.to_host(), st.grad_terms(0, var, a))
+
+
+@pytest.mark.parametrize("offset,scale", [(5.0e6, 1.0e3), (0.0, 1.0e-6), (-3.0e4, 1.0), (1.0e9, 1.0e5)])
+def test_coordinate_offsets_and_scales(gpb, orc, offset, scale):
+    """Projected coordinates (large common offset, metre-scale differences) and tiny/huge units: the kernel centres every
+    neighbourhood on its point before scaling, so accuracy follows the neighbourhood size, not the absolute coordinates."""
+    coords, y = cases.synthetic(4000, 2, seed=5)
+    coords = offset + scale * coords
+    rho = 0.1 * scale
+    cp = np.array([0.1, 1.0, rho])
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=30, seed=2)
+    perm, nn = mdl.vecchia_structure()
+    perm_o, co, nn_o = orc.vecchia_setup(coords, 30, "random", 2)
+    assert np.array_equal(perm, perm_o) and np.array_equal(nn, nn_o)
+    out, grad_o = orc.vecchia_nll_grad(co, nn_o, 1, orc.transform_cov_pars(1, cp), y[perm])
+    nll, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+    assert abs(nll - out[2]) <= RTOL * abs(out[2])
+    np.testing.assert_allclose(grad, grad_o, rtol=RTOL, atol=RTOL * np.abs(grad_o).max())
+
+
+@pytest.mark.parametrize("cp", [(1e-3, 5.0, 0.5), (10.0, 0.01, 0.001), (0.5, 1.0, 50.0), (1e-6, 1.0, 0.05)])
+def test_extreme_covariance_parameters(gpb, orc, cp):
+    """Tiny nugget (ill-conditioned blocks), tiny signal, very long and very short ranges."""
+    coords, y = cases.synthetic(3000, 2, seed=8)
+    cp = np.array(cp)
+    for cf, sh, ct in (("exponential", 0.5, 0), ("matern", 2.5, 2)):
+        mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=20, seed=1)
+        perm, nn = mdl.vecchia_structure()
+        out, grad_o = orc.vecchia_nll_grad(coords[perm], nn, ct, orc.transform_cov_pars(ct, cp), y[perm])
+        nll, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+        # conditioning of the m x m blocks scales with sigma1^2/sigma^2: allow 1e-8 relative up to ratio 1e4, looser beyond
+        tol = RTOL * max(1.0, cp[1] / cp[0] / 1e4)
+        assert abs(nll - out[2]) <= tol * abs(out[2]), (cf, nll, out[2])
+        np.testing.assert_allclose(grad, grad_o, rtol=tol, atol=tol * np.abs(grad_o).max())
+
+
+def test_in_library_rccl_allreduce_single_rank(gpb, orc):
+    """The RCCL path with a 1-rank communicator: unique id -> ncclCommInitRank -> kernel + reduction + ncclAllReduce on one
+    stream; must reproduce the plain evaluation bit for bit (multi-rank composition: tests/test_distributed_cpu.py + bench.py)."""
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(5000, 2, seed=12)
+    perm, co, nn = orc.vecchia_setup(coords, 30, "random", 1)
+    st = shim.VecchiaState(co, 30); st.set_neighbors(nn); st.set_y(y[perm])
+    uid = shim.comm_unique_id()
+    assert len(uid) == 128
+    st.comm_init(uid, 0, 1)
+    assert np.array_equal(st.nll_terms_allreduce(0, 10.0, 10.0), st.nll_terms(0, 10.0, 10.0))
+    assert np.array_equal(st.grad_terms_allreduce(0, 10.0, 10.0), st.grad_terms(0, 10.0, 10.0))
+    with pytest.raises(gpb.GPBoostError):
+        shim.VecchiaState(co, 30).nll_terms_allreduce(0, 10.0, 10.0)      # no neighbours / no communicator
