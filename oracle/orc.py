@@ -163,6 +163,31 @@ def hist_build(bins, bin_offsets, data_indices, grad, hess=None, const_hess=1.0)
     return hg, hc, hh
 
 
+def gen_rand_normal(n, t, seed=1, run_id=0):
+    """GenRandVecNormalParallel (CG_utils.cpp:978-994): (n, t) Fortran-ordered N(0,1) probes."""
+    out = np.empty((n, t), order="F")
+    lib().orc_gen_rand_normal(C.c_int(seed), C.c_ulonglong(run_id), C.c_int(n), C.c_int(t), _p(out, C.c_double))
+    return out
+
+
+def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
+                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None):
+    """Approximate negative log marginal likelihood of a Bernoulli-logit Vecchia GP (Laplace, iterative, 'vadu').
+    Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
+    A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, m = nn.shape
+    yi = np.ascontiguousarray(y01, dtype=np.int32)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0) if rand_vec is None else np.asfortranarray(rand_vec)
+    out = np.empty(6); mode = np.empty(n)
+    rc = lib().orc_vecchia_laplace_logit(_p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+                                         _p(yi, C.c_int), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
+                                         C.c_int(cg_max_num_it_tridiag), C.c_double(cg_delta_conv), C.c_double(delta_conv_mode),
+                                         _p(out, C.c_double), _p(mode, C.c_double))
+    return -out[0], dict(rc=rc, newton_it=int(out[1]), cg_it=int(out[2]), log_det=out[3], lanczos_it=int(out[4]),
+                         mll_no_det=out[5], mode=mode, A=A, D=D)
+
+
 # ---------------------------------------------------------------------------
 # High-level mirror of GPModel(gp_approx="vecchia").neg_log_likelihood for tests
 # ---------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #include <numeric>
 #include <random>
 #include <vector>
+#include <cstdint>
 
 extern "C" {
 
@@ -39,3 +40,17 @@ void orc_shuffle(int n, int seed, int* idx) {
 }
 
 }  // extern "C"
+
+/* GenRandVecNormalParallel -- src/GPBoost/CG_utils.cpp:978-994: column col_i of the n x t matrix is drawn from
+ * std::normal_distribution<double>(0,1) on a std::mt19937 seeded with std::seed_seq{base_seed, run_id lo, run_id hi, col_i}.
+ * out is column-major n x t. */
+extern "C" __attribute__((visibility("default")))
+void orc_gen_rand_normal(int base_seed, unsigned long long run_id, int n, int t, double* out) {
+  const uint32_t b32 = static_cast<uint32_t>(base_seed);
+  for (int col_i = 0; col_i < t; ++col_i) {
+    std::normal_distribution<double> ndist(0.0, 1.0);
+    std::seed_seq seq{ b32, static_cast<uint32_t>(run_id), static_cast<uint32_t>(run_id >> 32), static_cast<uint32_t>(col_i) };
+    std::mt19937 generator(seq);
+    for (int row_i = 0; row_i < n; ++row_i) out[(size_t)col_i * n + row_i] = ndist(generator);
+  }
+}

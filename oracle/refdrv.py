@@ -81,7 +81,8 @@ class RefModel(object):
 # binds it: used as the "reference" CPU baseline of bench.py.
 # ---------------------------------------------------------------------------------------------
 class RefCAPIModel(object):
-    def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1):
+    def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1,
+                 likelihood="gaussian"):
         self.L = C.CDLL(os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
         self.L.LGBM_GetLastError.restype = C.c_char_p
         cm = np.asfortranarray(coords, dtype=np.float64)
@@ -92,7 +93,7 @@ class RefCAPIModel(object):
             C.c_int(self.n), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
             C.c_int(1), _P(cm), C.c_int(self.d), C.c_void_p(), C.c_int(0), s(cov_function), C.c_double(shape), s("vecchia"),
             C.c_double(1.), C.c_double(0.), C.c_int(m), s(ordering), C.c_int(500), C.c_double(1.), s("kmeans++"),
-            s("gaussian"), C.c_double(-999.), s("cholesky"), C.c_int(seed), C.c_int(threads), C.c_bool(False),
+            s(likelihood), C.c_double(-999.), s("default"), C.c_int(seed), C.c_int(threads), C.c_bool(False),
             C.c_bool(False), C.c_void_p(), C.c_double(1.), C.byref(self.h))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
