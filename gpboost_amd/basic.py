@@ -65,7 +65,8 @@ def selftest():
 
 
 class GPModel(object):
-    """Gaussian-process model evaluated on an MI355X (Vecchia approximation, Gaussian likelihood)."""
+    """Gaussian-process model evaluated on an MI355X (Vecchia approximation or exact GP with a Gaussian likelihood;
+    Vecchia-Laplace approximation with likelihood="bernoulli_logit")."""
 
     def __init__(self, likelihood="gaussian", group_data=None, group_rand_coef_data=None,
                  ind_effect_group_rand_coef=None, drop_intercept_group_rand_effect=None, gp_coords=None,
@@ -92,7 +93,8 @@ class GPModel(object):
         self.vecchia_ordering = vecchia_ordering
         self.seed = int(seed)
         self.likelihood = likelihood
-        self.num_cov_pars = 3   # error variance, GP variance, range (Gaussian likelihood, one GP)
+        # Gaussian: error variance, GP variance, range; non-Gaussian: GP variance, range (basic.py:4618-4624)
+        self.num_cov_pars = 3 if likelihood == "gaussian" else 2
         if num_neighbors is None or num_neighbors <= 0:
             num_neighbors = 20   # the library default for gp_approx="vecchia" (re_model_template.h:288-294)
         self.num_neighbors = int(num_neighbors)
@@ -141,6 +143,36 @@ class GPModel(object):
         negll = ctypes.c_double(0)
         _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, _dptr(y), _dptr(cov_pars), fe_c, ctypes.byref(negll)))
         return negll.value
+
+    def set_optim_params(self, params):
+        """Settings that act ON the hot path (reference: basic.py:5238-5420 -> GPB_SetOptimConfig): 'trace' and, for
+        non-Gaussian likelihoods, 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
+        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'.  Optimiser settings are rejected:
+        the optimiser is the reference's own host code."""
+        known = {"trace": False, "cg_max_num_it": -999, "cg_max_num_it_tridiag": -999, "cg_delta_conv": -999.,
+                 "num_rand_vec_trace": -999, "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999.,
+                 "cg_preconditioner_type": ""}
+        for k in params:
+            if k not in known:
+                raise GPBoostError("set_optim_params: '%s' is not a hot-path setting of this library" % k)
+        known.update(params)
+        _safe_call(_lib().GPB_SetOptimConfig(
+            self.handle, ctypes.c_void_p(), ctypes.c_double(-1.), ctypes.c_double(-1.), ctypes.c_int(-1), ctypes.c_double(-1.),
+            ctypes.c_bool(False), ctypes.c_int(-1), ctypes.c_bool(bool(known["trace"])), ctypes.c_void_p(), ctypes.c_int(-1),
+            ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_void_p(), ctypes.c_double(-1.), ctypes.c_double(-1.), ctypes.c_void_p(),
+            ctypes.c_int(int(known["cg_max_num_it"])), ctypes.c_int(int(known["cg_max_num_it_tridiag"])),
+            ctypes.c_double(float(known["cg_delta_conv"])), ctypes.c_int(int(known["num_rand_vec_trace"])), ctypes.c_bool(True),
+            c_str(known["cg_preconditioner_type"]), ctypes.c_int(int(known["seed_rand_vec_trace"])), ctypes.c_int(-1),
+            ctypes.c_void_p(), ctypes.c_bool(False), ctypes.c_bool(False), ctypes.c_void_p(), ctypes.c_int(-1),
+            ctypes.c_double(float(known["delta_conv_mode_finding"]))))
+        return self
+
+    def laplace_info(self):
+        """Diagnostics of the last Laplace evaluation (GPB_HIP_GetLaplaceInfo)."""
+        o = np.empty(9)
+        _safe_call(_lib().GPB_HIP_GetLaplaceInfo(self.handle, _dptr(o)))
+        return dict(mll=o[0], newton_it=int(o[1]), cg_it=int(o[2]), log_det=o[3], lanczos_it=int(o[4]), mll_no_det=o[5],
+                    ms_factor=o[6], ms_mode=o[7], ms_logdet=o[8])
 
     def get_current_neg_log_likelihood(self):
         negll = ctypes.c_double(0)

@@ -9,6 +9,10 @@
 //   SetY permutation  include/GPBoost/re_model_template.h:6185-6222
 //   negll formula     include/GPBoost/re_model_template.h:3132
 //   gradient assembly include/GPBoost/re_model_template.h:1988-2011
+// and, for likelihood = "bernoulli_logit" (Vecchia-Laplace, iterative methods; BASELINE config 4):
+//   label check       include/GPBoost/likelihoods.h:1321-1329 (CheckY)
+//   mode reset + sign include/GPBoost/re_model_template.h:3191-3212 (EvalLaplaceApproxNegLogLikelihood)
+//   CG / SLQ settings include/GPBoost/re_model_template.h:863-891, :943-948, defaults :5860-5876, :5507
 // All per-point arithmetic happens on the device.
 #include "../../include/gpboost_c_api_subset.h"
 #include "../../include/gpb_hip.h"
@@ -52,6 +56,11 @@ struct REModelHip {
   bool has_duplicates = false;
   bool trace = false;
   std::string likelihood = "gaussian";
+  // iterative-method settings of the Laplace path (re_model_template.h:5860-5876, :5507)
+  int cg_max_num_it = 1000, cg_max_num_it_tridiag = 1000, num_rand_vec_trace = 50, seed_rand_vec_trace = 1;
+  double cg_delta_conv = 1e-2, delta_conv_mode_finding = 1e-8;
+  std::vector<int> labels;      // y in {0,1}, Vecchia order
+  double lap_info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   ~REModelHip() { if (vh) gpb_hip_vecchia_free(vh); if (eh) gpb_hip_exact_free(eh); }
 };
 
@@ -112,7 +121,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
                       double /*cov_fct_taper_shape*/, int num_neighbors, const char* vecchia_ordering,
                       int /*num_ind_points*/, double /*cover_tree_radius*/, const char* /*ind_points_selection*/,
                       const char* likelihood, double /*likelihood_additional_param*/,
-                      const char* /*matrix_inversion_method*/, int seed, int /*num_parallel_threads*/, bool /*GPU_use*/,
+                      const char* matrix_inversion_method, int seed, int /*num_parallel_threads*/, bool /*GPU_use*/,
                       bool has_weights, const double* /*weights*/, double /*likelihood_learning_rate*/,
                       REModelHandle* out) {
   C_API_BEGIN();
@@ -140,13 +149,19 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   }
   if (cov_type < 0) return set_error("GPB_CreateREModel: cov_fct '%s' (shape %g) %s", cov.c_str(), cov_fct_shape, scope);
   if (approx != "vecchia" && approx != "none") return set_error("GPB_CreateREModel: gp_approx '%s' %s", approx.c_str(), scope);
-  if (lik != "gaussian") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (lik != "gaussian" && lik != "bernoulli_logit") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (lik == "bernoulli_logit") {
+    const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
+    if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood 'bernoulli_logit' with gp_approx '%s' %s", approx.c_str(), scope);
+    // "default" resolves to "iterative" for a non-Gaussian Vecchia model (re_model_template.h:5722-5735)
+    if (inv != "default" && inv != "iterative") return set_error("GPB_CreateREModel: matrix_inversion_method '%s' for likelihood 'bernoulli_logit' %s", inv.c_str(), scope);
+  }
   if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
   if (num_data < 2) return set_error("GPB_CreateREModel: num_data = %d", num_data);
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
-  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type;
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik;
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
@@ -178,12 +193,32 @@ int GPB_REModelFree(REModelHandle handle) {
 }
 
 int GPB_SetOptimConfig(REModelHandle handle, double*, double, double, int, double, bool, int, bool trace, const char*, int,
-                       const char*, int num_covariates, double*, double, double, const char*, int, int, double, int, bool,
-                       const char*, int, int, double*, bool, bool, const int*, int, double) {
+                       const char*, int num_covariates, double*, double, double, const char*, int cg_max_num_it,
+                       int cg_max_num_it_tridiag, double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/,
+                       const char* cg_preconditioner_type, int seed_rand_vec_trace, int, double*, bool, bool, const int*, int,
+                       double delta_conv_mode_finding) {
   C_API_BEGIN();
   if (!handle) return set_error("GPB_SetOptimConfig: null handle");
   if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
-  reinterpret_cast<REModelHip*>(handle)->trace = trace;
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  mdl->trace = trace;
+  // re_model_template.h:863-891, :943-948 (-999 = keep the default)
+  if (num_rand_vec_trace > 0) mdl->num_rand_vec_trace = num_rand_vec_trace;
+  else if (num_rand_vec_trace != -999) return set_error("num_rand_vec_trace is not > 0, found = %d ", num_rand_vec_trace);
+  mdl->seed_rand_vec_trace = seed_rand_vec_trace;
+  if (cg_max_num_it > 0) mdl->cg_max_num_it = cg_max_num_it;
+  else if (cg_max_num_it != -999) return set_error("cg_max_num_it is not > 0, found = %d ", cg_max_num_it);
+  if (cg_max_num_it_tridiag > 0) mdl->cg_max_num_it_tridiag = cg_max_num_it_tridiag;
+  else if (cg_max_num_it_tridiag != -999) return set_error("cg_max_num_it_tridiag is not > 0, found = %d ", cg_max_num_it_tridiag);
+  if (cg_delta_conv > 0.) mdl->cg_delta_conv = cg_delta_conv;
+  else if (!near(cg_delta_conv, -999.)) return set_error("cg_delta_conv is not > 0, found = %g ", cg_delta_conv);
+  if (delta_conv_mode_finding > 0.) mdl->delta_conv_mode_finding = delta_conv_mode_finding;
+  else if (!near(delta_conv_mode_finding, -999.)) return set_error("delta_conv_mode_finding is not > 0, found = %g ", delta_conv_mode_finding);
+  if (cg_preconditioner_type && mdl->likelihood != "gaussian") {
+    const std::string pc = cg_preconditioner_type;
+    if (pc != "" && pc != "vadu" && pc != "Sigma_inv_plus_BtWB" && pc != "vecchia_approximation_with_replicates")   // ParsePreconditionerAlias
+      return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library (only 'vadu')", pc.c_str());
+  }
   C_API_END();
 }
 
@@ -193,6 +228,28 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
   if (!cov_pars) return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (initial-value heuristics live in the reference's optimiser, not on the hot path)");
+  if (mdl->likelihood == "bernoulli_logit") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
+    if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
+    if (fixed_effects) return set_error("GPB_EvalNegLogLikelihood: fixed_effects with likelihood 'bernoulli_logit' are not on the MI355X hot path of this library yet");
+    const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
+    if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
+    mdl->labels.resize(mdl->n);
+    for (int k = 0; k < mdl->n; ++k) {
+      const double yk = y_data[mdl->perm[k]];
+      if (std::fabs(yk) >= 1e-10 && !near(yk, 1.))       // likelihoods.h:1321-1329
+        return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
+      mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
+    }
+    if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
+    const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
+    if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
+                                      mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,
+                                      1 /* mode reset to 0, :3199-3201 */, mdl->lap_info, nullptr)) return shim_error();
+    mdl->cur_negll = -mdl->lap_info[0];
+    mdl->negll_valid = true;
+    *negll = mdl->cur_negll;
+    return 0;
+  }
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
@@ -228,6 +285,7 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll || !grad3 || !cov_pars) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: null argument");
+  if (mdl->likelihood != "gaussian") return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the Laplace approximation are not on the MI355X hot path of this library yet");
   if (mdl->eh) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the exact (dense) GP are not on the MI355X hot path of this library yet");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
@@ -247,6 +305,7 @@ int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_par
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !y_aux || !cov_pars) return set_error("GPB_HIP_CalcYAux: null argument");
+  if (mdl->likelihood != "gaussian") return set_error("GPB_HIP_CalcYAux: only defined for the Gaussian likelihood");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, nullptr)) return -1;
@@ -270,6 +329,15 @@ int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn
   if (perm) std::copy(mdl->perm.begin(), mdl->perm.end(), perm);
   if (m_out) *m_out = mdl->m;
   if (nn && gpb_hip_vecchia_get_neighbors(mdl->vh, nn)) return shim_error();
+  C_API_END();
+}
+
+int GPB_HIP_GetLaplaceInfo(REModelHandle handle, double* out9) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !out9) return set_error("GPB_HIP_GetLaplaceInfo: null argument");
+  if (mdl->likelihood == "gaussian" || !mdl->negll_valid) return set_error("GPB_HIP_GetLaplaceInfo: no Laplace approximation has been evaluated");
+  std::copy(mdl->lap_info, mdl->lap_info + 9, out9);
   C_API_END();
 }
 

@@ -70,6 +70,9 @@ std::vector<double> exp_table() {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+struct LaplaceState;                                   // gpb_laplace.inc (Vecchia-Laplace workspace, row a13)
+static void laplace_state_free(LaplaceState* s);
+
 struct gpb_hip_vecchia {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -86,7 +89,8 @@ struct gpb_hip_vecchia {
   double* d_ystage = nullptr;
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
-  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false;
+  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false;
+  LaplaceState* lap = nullptr;
   ncclComm_t comm = nullptr;      // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init)
   int comm_rank = 0, comm_world = 1;
   double* d_red = nullptr;        // 8 doubles: all-reduce buffer in the caller-facing term order
@@ -243,6 +247,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage);
   dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+  laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
   API_END();
@@ -307,7 +312,7 @@ int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
   HIP_OK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_rec); (void)hipFree(d_idx);
   if (has_duplicates) *has_duplicates = flag;
-  h->has_nn = true; h->has_transpose = false; h->has_factor = false; h->nn_host.clear();
+  h->has_nn = true; h->has_transpose = false; h->has_levels = false; h->has_factor = false; h->nn_host.clear();
   API_END();
 }
 
@@ -323,7 +328,7 @@ int gpb_hip_vecchia_set_neighbors(gpb_hip_vecchia_t* h, const int32_t* nn) {
   HIP_OK(hipMemcpyAsync(h->d_nn, nn, sizeof(int) * cnt, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   h->nn_host.assign(nn, nn + cnt);
-  h->has_nn = true; h->has_transpose = false; h->has_factor = false;
+  h->has_nn = true; h->has_transpose = false; h->has_levels = false; h->has_factor = false;
   API_END();
 }
 
@@ -808,3 +813,6 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+#include "gpb_laplace.inc"

@@ -140,6 +140,22 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_yaux(self.h, _p(out)))
         return out
 
+    def laplace_set_labels(self, y01):
+        y01 = np.ascontiguousarray(y01, dtype=np.int32)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_labels(self.h, _p(y01, C.c_int)))
+
+    def laplace_logit(self, cov_type, var, a, num_rand_vec=50, seed_rand_vec=1, cg_max_num_it=1000, cg_max_num_it_tridiag=1000,
+                      cg_delta_conv=1e-2, delta_conv_mode_finding=1e-8, reset_mode=True, want_mode=False):
+        """-> (negll, info): Vecchia-Laplace approximation, Bernoulli-logit, iterative methods (gpb_hip_vecchia_laplace_logit)."""
+        o = np.empty(9)
+        mode = np.empty(self.n) if want_mode else None
+        _shim_call(_lib().gpb_hip_vecchia_laplace_logit(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), C.c_int(num_rand_vec),
+                                                        C.c_int(seed_rand_vec), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
+                                                        C.c_double(cg_delta_conv), C.c_double(delta_conv_mode_finding),
+                                                        C.c_int(1 if reset_mode else 0), _p(o), _p(mode)))
+        return -o[0], dict(newton_it=int(o[1]), cg_it=int(o[2]), log_det=o[3], lanczos_it=int(o[4]), mll_no_det=o[5],
+                           ms_factor=o[6], ms_mode=o[7], ms_logdet=o[8], mode=mode)
+
     def yaux_partial_dev(self, w_dev_ptr):
         """This shard's contribution to y_aux as a full n-vector on the device (sum over ranks = y_aux)."""
         _shim_call(_lib().gpb_hip_vecchia_yaux_partial_dev(self.h, C.c_void_p(int(w_dev_ptr))))

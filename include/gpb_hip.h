@@ -143,6 +143,30 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host)
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev);
 
 /* ------------------------------------------------------------------------------------
+ * Vecchia-Laplace approximation, Bernoulli-logit likelihood, iterative methods ("vadu" preconditioner) --
+ * BASELINE config 4 / SURVEY.md 8 row a13.  Replaces, for one evaluation of the approximate marginal likelihood,
+ *   Likelihood::FindModePostRandEffCalcMLLVecchia          include/GPBoost/likelihoods.h:3773-4059
+ *   Likelihood::Inv_SigmaI_plus_ZtWZ_Vecchia_iterative     :16264-16348  -> CGVecchiaLaplaceVec, src/GPBoost/CG_utils.cpp:21-108
+ *   Likelihood::CalcLogDetStochVecchia                     :16376-16525  -> CGTridiagVecchiaLaplace, CG_utils.cpp:110-229,
+ *                                                                           LogDetStochTridiag, :1035-1051
+ *   GenRandVecNormalParallel                               CG_utils.cpp:978-994 (probes; same libstdc++ engine/distribution)
+ * on top of the device factor (gpb_hip_vecchia_factor with gauss_likelihood = 0, computed inside).
+ *   set_labels  y in {0,1}, Vecchia order (likelihoods.h:1046-1052 rejects anything else)
+ *   logit       var = sigma_1^2 (no nugget), a = transformed range; num_rand_vec / seed_rand_vec / cg_* / delta_conv_*
+ *               as in GPB_SetOptimConfig (c_api.h:1437-1467; reference defaults 50 / 1 / 1000 / 1000 / 1e-2 / 1e-8);
+ *               reset_mode != 0 starts Newton's method at 0 (first evaluation of a model), 0 warm-starts at the last mode.
+ *               out9_host = { approximate marginal LOG-likelihood (the reference returns its negative),
+ *                             #Newton iterations, total #CG iterations in the mode finding, log|Sigma W + I|,
+ *                             #CG-Lanczos iterations, log p(y|mode) - 0.5 mode^T Sigma^-1 mode,
+ *                             ms factor, ms mode finding, ms log-determinant (host wall clock) };
+ *               mode_host (optional) receives the mode, Vecchia order. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y01);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int num_rand_vec,
+                                                 int seed_rand_vec, int cg_max_num_it, int cg_max_num_it_tridiag,
+                                                 double cg_delta_conv, double delta_conv_mode_finding, int reset_mode,
+                                                 double* out9_host, double* mode_host);
+
+/* ------------------------------------------------------------------------------------
  * Exact (dense) GP, Gaussian likelihood -- BASELINE config 1: replaces CalcSigmaComps / CalcZSigmaZt / CalcChol /
  * chol.solve(y) / log-det (include/GPBoost/re_model_template.h:8151, :9273-9287, :6491-6494, :9894, :3127).
  * Covariance assembly (HBM-write-bound), blocked Cholesky with fp64 MFMA trailing updates, triangular solves.

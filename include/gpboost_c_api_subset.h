@@ -13,7 +13,10 @@
  *   one GP, no grouped effects / random coefficients / clusters / weights, d <= 3,
  *   cov_fct "exponential" or "matern" with shape 0.5 / 1.5 / 2.5, likelihood "gaussian", and either
  *   gp_approx "vecchia" (num_neighbors <= 62, vecchia_ordering "none" | "random") or gp_approx "none"
- *   (exact GP, dense Cholesky; likelihood and y_aux only).
+ *   (exact GP, dense Cholesky; likelihood and y_aux only);
+ *   likelihood "bernoulli_logit" with gp_approx "vecchia" and matrix_inversion_method "default" | "iterative"
+ *   (Vecchia-Laplace approximation, "vadu"-preconditioned CG + stochastic Lanczos quadrature: the reference's
+ *   defaults for that model; likelihood evaluation only, cov_pars = (sigma1_2, rho), y in {0, 1}).
  */
 #ifndef GPBOOST_C_API_SUBSET_H_
 #define GPBOOST_C_API_SUBSET_H_
@@ -70,7 +73,9 @@ GPBOOST_C_EXPORT int GPB_CreateREModel(int32_t num_data,
 /* c_api.h:1398 */
 GPBOOST_C_EXPORT int GPB_REModelFree(REModelHandle handle);
 
-/* c_api.h:1437-1467 -- accepted and recorded; the optimiser itself is host code outside this library */
+/* c_api.h:1437-1467 -- the optimiser itself is host code outside this library; what IS used on the path: trace, and for
+ * the Laplace path cg_max_num_it, cg_max_num_it_tridiag, cg_delta_conv, num_rand_vec_trace, seed_rand_vec_trace,
+ * delta_conv_mode_finding (-999 keeps the reference's default) and cg_preconditioner_type (only "vadu") */
 GPBOOST_C_EXPORT int GPB_SetOptimConfig(REModelHandle handle,
     double* init_cov_pars,
     double lr,
@@ -104,7 +109,9 @@ GPBOOST_C_EXPORT int GPB_SetOptimConfig(REModelHandle handle,
     double delta_conv_mode_finding);
 
 /* c_api.h:1505-1509 -- THE metric's unit of work: cov_pars on the original scale
- * (sigma2, sigma1_2, rho); y in data order; fixed_effects optional (subtracted from y) */
+ * (sigma2, sigma1_2, rho); y in data order; fixed_effects optional (subtracted from y).
+ * likelihood "bernoulli_logit": cov_pars = (sigma1_2, rho), y in {0,1}, the posterior mode restarts at 0 on every call
+ * (re_model_template.h:3191-3212) and the value is minus the Laplace-approximated marginal log-likelihood. */
 GPBOOST_C_EXPORT int GPB_EvalNegLogLikelihood(REModelHandle handle,
     const double* y_data,
     double* cov_pars,
@@ -128,6 +135,9 @@ GPBOOST_C_EXPORT int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, c
 GPBOOST_C_EXPORT int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_pars, double* y_aux);
 /* Vecchia ordering (perm[k] = data index of the k-th point) and neighbour table (n x m, -1 padded) */
 GPBOOST_C_EXPORT int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out);
+/* Diagnostics of the last Laplace evaluation (likelihood != "gaussian"): the nine values documented at
+ * gpb_hip_vecchia_laplace_logit (include/gpb_hip.h) -- iteration counts, log-determinant, phase times */
+GPBOOST_C_EXPORT int GPB_HIP_GetLaplaceInfo(REModelHandle handle, double* out9);
 /* The underlying gpb_hip_vecchia_t* (include/gpb_hip.h) for resident / sharded use */
 GPBOOST_C_EXPORT void* GPB_HIP_GetVecchiaHandle(REModelHandle handle);
 

@@ -45,6 +45,20 @@ def main():
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
         print("wrote", name, "n=%d m=%d" % (mdl.n, mdl.m), "nll0=%.10f" % res["nll_0"])
     hist_fixture(out_dir)
+    laplace_fixture(out_dir)
+
+
+def laplace_fixture(out_dir):
+    """Reference GPB_EvalNegLogLikelihood for likelihood = 'bernoulli_logit', gp_approx = 'vecchia' (iterative, vadu)."""
+    res = {}
+    for name, c in cases.LAPLACE_CASES.items():
+        coords, y = cases.make_binary_data(c)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8,
+                                  likelihood="bernoulli_logit")
+        for k, cp in enumerate(c["cov_pars"]):
+            res["%s_negll_%d" % (name, k)] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
+            print("laplace", name, cp, "negll = %.12f" % res["%s_negll_%d" % (name, k)])
+    np.savez_compressed(os.path.join(out_dir, "laplace_ref.npz"), **res)
 
 
 def hist_fixture(out_dir):
@@ -60,4 +74,7 @@ def hist_fixture(out_dir):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
+        laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    else:
+        main()

@@ -233,3 +233,16 @@ def r_fixture():
     Cc = np.linalg.cholesky(Sigma)
     y = Cc @ norm.ppf(sim_rand_unif(n, 0.8)) + norm.ppf(sim_rand_unif(n, 0.1)) / 5
     return coords, y
+
+
+def r_fixture_logit():
+    """Binary fixture of R-package/tests/testthat/test_GPModel_non_Gaussian_data.R:52-62, 2510-2513 (same coords / L / b_1
+    as above; y = 1{u < sigmoid(L b_1)} with u from the LCG started at 0.2341)."""
+    from scipy.spatial.distance import cdist
+    from scipy.stats import norm
+    n, d = 100, 2
+    coords = sim_rand_unif(n * d, 0.1).reshape((n, d), order="F")
+    Sigma = np.exp(-cdist(coords, coords) / 0.1) + 1e-20 * np.eye(n)
+    Cc = np.linalg.cholesky(Sigma)
+    probs = 1.0 / (1.0 + np.exp(-(Cc @ norm.ppf(sim_rand_unif(n, 0.8)))))
+    return coords, (sim_rand_unif(n, 0.2341) < probs).astype(np.float64)

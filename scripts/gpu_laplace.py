@@ -1,0 +1,32 @@
+"""Timing of the Vecchia-Laplace path (BASELINE config 4) on the MI355X, with the reference on the host beside it.
+    python scripts/gpu_laplace.py [n] [m] [--ref]"""
+import os, sys, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gpboost_amd
+from tests import cases
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 100000
+m = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 30
+coords, y = cases.synthetic_binary(n, 2, seed=1)
+t0 = time.perf_counter()
+mdl = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
+                          num_neighbors=m, vecchia_ordering="random", seed=1)
+print("setup %.3f s" % (time.perf_counter() - t0), flush=True)
+cp = np.array([1.0, 0.1])
+res = {}
+for k in range(3):
+    t0 = time.perf_counter()
+    v = mdl.neg_log_likelihood(cp * (1 + 0.01 * k), y)
+    dt = time.perf_counter() - t0
+    info = mdl.laplace_info()
+    print("eval %d: negll %.10f  %.3f s  %s" % (k, v, dt, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in info.items()}), flush=True)
+    res["gpu_s_%d" % k] = dt; res["negll_%d" % k] = v
+if "--ref" in sys.argv:
+    from oracle import refdrv
+    if refdrv.available():
+        rm = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, likelihood="bernoulli_logit")
+        for k in range(2):
+            t0 = time.perf_counter(); rv = rm.neg_log_likelihood(cp * (1 + 0.01 * k), y); dt = time.perf_counter() - t0
+            print("reference eval %d: negll %.10f  %.3f s  rel diff %.3e  cores %d" % (k, rv, dt, abs(rv - res["negll_%d" % k]) / abs(rv), os.cpu_count()), flush=True)

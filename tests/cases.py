@@ -56,6 +56,33 @@ def make_data(c):
     return coords, y
 
 
+# Vecchia-Laplace (Bernoulli-logit, iterative methods) cases -- BASELINE config 4.  Outputs of the reference's
+# GPB_EvalNegLogLikelihood are stored in tests/golden/laplace_ref.npz (oracle/make_golden.py).
+LAPLACE_CASES = {
+    "lap_u2d_n2000_exp_m20": dict(n=2000, d=2, seed_data=21, cov_function="exponential", shape=0.5, m=20, ordering="random",
+                                  seed=1, cov_pars=[(1.0, 0.1), (2.5, 0.05)]),
+    "lap_u2d_n1500_mat15_m30": dict(n=1500, d=2, seed_data=22, cov_function="matern", shape=1.5, m=30, ordering="random",
+                                    seed=2, cov_pars=[(1.0, 0.15)]),
+    "lap_u3d_n1200_mat25_m15": dict(n=1200, d=3, seed_data=23, cov_function="matern", shape=2.5, m=15, ordering="none",
+                                    seed=0, cov_pars=[(0.7, 0.3)]),
+}
+
+
+def make_binary_data(c):
+    """-> (coords (n, d), y01 (n,) float 0/1) in DATA order: Bernoulli draws around a smooth latent surface."""
+    rng = np.random.default_rng(c["seed_data"])
+    n, d = c["n"], c["d"]
+    coords = rng.uniform(size=(n, d))
+    latent = 1.5 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.3
+    y = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-latent))).astype(np.float64)
+    return coords, y
+
+
+def synthetic_binary(n, d, seed=1):
+    """BASELINE config 4 inputs: coords U[0,1]^d, labels Bernoulli(sigmoid(smooth surface)), default_rng(seed)."""
+    return make_binary_data(dict(n=n, d=d, seed_data=seed))
+
+
 def synthetic(n, d, seed=1):
     """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
     rng = np.random.default_rng(seed)
