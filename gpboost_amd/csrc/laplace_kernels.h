@@ -4,31 +4,36 @@
 
 namespace gpb {
 
-struct LapMat {            // B = I - A of the Vecchia factor and its transposed index
-  const double* A; const double* D; const int* nn; const int* t_ptr; const int* t_pos; int n, m;
+struct alignas(16) LapEnt { double val; int src; int pad; };   // one matrix entry: coefficient, source row (storage index)
+struct LapTri {            // one level-scheduled triangular solve; matrix stored in LEVEL ORDER as slots (position q)
+  const int* ptr;          // [nlev + 1] level boundaries (slot positions)
+  const int* lsplit;       // [nlev + 1] 1 if the level holds a row that is split over several slots
+  const int4* meta;        // [nslots] {row (storage index) of the slot's first... or -1, #slots of the row if first slot else 0,
+                           //           begin, end of the slot's overflow entries}
+  const LapEnt* hent;      // [nslots * 32] head entries (padding: source 0, coefficient 0); .val refreshed per evaluation
+  const LapEnt* oent;      // [max(novf, 1)] overflow entries 33.. of a slot (a slot holds <= 64 unless its row has > 4096)
+  int nlev, nslots;
 };
-struct LapTri {            // one level-scheduled triangular solve; rows stored in LEVEL ORDER (position q)
-  const int* ptr;          // [nlev + 1] level boundaries (positions)
-  const int* rows;         // [n] row index of position q
-  const int* hsrc;         // [n * 32] head: source row of the entry (-1 = none)
-  const int* optr;         // [n + 1] overflow CSR (entries 33.. of a row)
-  const int* osrc;         // [max(novf, 1)]
-  const double* hval;      // [n * 32] matrix entries in head layout (refreshed per evaluation by lap_permute_factor)
-  const double* oval;      // [max(novf, 1)]
-  int nlev;
+constexpr int kTriThreads = 512;        // workgroup of the level-scheduled solves
+constexpr int kTriRowsPerRound = 64;    // rows it handles per round (32 groups of 16 lanes x 2)
+struct LapSeg { int L0, L1, nsplit, nrounds; };   // levels [L0, L1) in one launch, nrounds rounds per workgroup; nsplit > 1: one wide level, one round per workgroup
+struct LapLevels {                        // fwd: (D^-1 + W) B z = t;  bwd: B^T t = r;  launch segments of each (host arrays)
+  LapTri fwd, bwd;
+  const LapSeg* fseg; int n_fseg;
+  const LapSeg* bseg; int n_bseg;
 };
-struct LapLevels { LapTri fwd, bwd; };   // fwd: (D^-1 + W) B z = t;  bwd: B^T t = r
 struct CgScalars {         // per-column CG scalars on the device
   double* a; double* a_old; double* b; double* rz_old; double* rnorm; double* Td; double* Ts;
 };
 
-hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, hipStream_t st);
-hipError_t lap_apply(const LapMat& B, const double* W, const double* h, double* v, double* tmp, int ncol, hipStream_t st);
-hipError_t lap_B(const LapMat& B, const double* x, double* out, int ncol, hipStream_t st);
-hipError_t lap_Bt(const LapMat& B, const double* x, double* out, int ncol, hipStream_t st);
+hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st);
+hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, hipStream_t st);
+hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st);
+hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st);
+hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st);
 hipError_t lap_objective(const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st);
-hipError_t lap_vadu(const LapMat& B, const LapLevels& lv, const double* dw, const double* r, double* z, double* t, int ncol, hipStream_t st);
-hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, double* hval, double* oval, hipStream_t st);
+hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, hipStream_t st);
+hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st);
 hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, const CgScalars& sc, hipStream_t st);
 hipError_t lap_cg_update(double* u, double* r, const double* h, const double* v, int n, int ncol, const CgScalars& sc, hipStream_t st);
 hipError_t lap_cg_beta(const double* r, const double* z, double* h, int n, int ncol, const CgScalars& sc, int j, int p_max, hipStream_t st);

@@ -15,7 +15,10 @@
 //     rows are grouped by dependency depth once per neighbour table (depth ~ 400 at n = 1e5, m = 30), one workgroup per
 //     right-hand side walks the levels with a barrier in between; the 50 probe vectors of the stochastic Lanczos
 //     quadrature are 50 concurrent workgroups;
-//   * B x is a row gather (A row contiguous, 30 x 8 B), B^T x uses the transposed neighbour index built for y_aux.
+//   * B x and B^T x use the same level-ordered head / overflow storage as the solves (16 lanes per row);
+//   * all vectors of this workspace live in a STORAGE ORDER sigma = Morton rank of the coordinates (not the random Vecchia
+//     ordering): a point's neighbours are spatially close, so their entries of x share cache lines -- the gathers of one
+//     row touch a few lines instead of m, which is what bounds these kernels (one line per clock and CU).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "laplace_kernels.h"
@@ -45,44 +48,18 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
 }
 }  // namespace
 
-// W = p (1 - p), grad = y - p, rhs = W mode + grad, dw = 1/D + W     (likelihoods.h:3882-3891, :12477, :13307, :16330)
+// W = p (1 - p), grad = y - p, rhs = W mode + grad, dw = 1/D + W, rdw = 1/dw     (likelihoods.h:3882-3891, :12477, :13307, :16330)
 __global__ void logit_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ D,
-                                          int n, double* __restrict__ W, double* __restrict__ rhs, double* __restrict__ dw) {
+                                          int n, double* __restrict__ W, double* __restrict__ rhs, double* __restrict__ dw, double* __restrict__ rdw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double p = sigmoid_stable(mode[i]);
   const double w = p * (1.0 - p);
   W[i] = w;
   if (rhs) rhs[i] = w * mode[i] + ((double)y[i] - p);
-  dw[i] = 1.0 / D[i] + w;
-}
-
-// out(:, c) = B x(:, c) [optionally scaled by 1/D]
-__global__ void lap_B_kernel(const double* __restrict__ A, const int* __restrict__ nn, const double* __restrict__ D, int n, int m,
-                             const double* __restrict__ x, double* __restrict__ out, int scale_dinv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t off = (size_t)blockIdx.y * n;
-  const double* xc = x + off;
-  double s = xc[i];
-  const double* Ai = A + (size_t)i * m;
-  const int* ni = nn + (size_t)i * m;
-  for (int j = 0; j < m; ++j) { const int c = ni[j]; if (c >= 0) s = __builtin_fma(-Ai[j], xc[c], s); }
-  out[off + i] = scale_dinv ? s * (1.0 / D[i]) : s;
-}
-
-// v(:, c) = B^T tmp(:, c) + W .* h(:, c)     (W may be NULL)
-__global__ void lap_Bt_plus_kernel(const double* __restrict__ A, const int* __restrict__ t_ptr, const int* __restrict__ t_pos, int n, int m,
-                                   const double* __restrict__ tmp, const double* __restrict__ W, const double* __restrict__ h,
-                                   double* __restrict__ v) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const size_t off = (size_t)blockIdx.y * n;
-  const double* tc = tmp + off;
-  double s = tc[j];
-  for (int e = t_ptr[j]; e < t_ptr[j + 1]; ++e) { const int pos = t_pos[e]; s = __builtin_fma(-A[pos], tc[pos / m], s); }
-  if (W) s = __builtin_fma(W[j], h[off + j], s);
-  v[off + j] = s;
+  const double v = 1.0 / D[i] + w;
+  dw[i] = v;
+  rdw[i] = 1.0 / v;       // the preconditioner's diagonal solve multiplies by this
 }
 
 // one workgroup: out2 = { sum_i y_i x_i - softplus(x_i),  sum_i Bx_i^2 / D_i }   (likelihoods.h:3808-3812, :3955-3959)
@@ -154,18 +131,23 @@ __global__ __launch_bounds__(1024) void cg_beta_kernel(const double* __restrict_
 }
 
 // ---- level-scheduled sparse triangular solves of the VADU preconditioner -----------------------------------------
-// x_row = rhs_row [/ dw_row] + sum_e val_e x[src_e] with rows grouped by dependency depth.  The depth is ~ 400 at n = 1e5
+// x_row = rhs_row [* rdw_row] + sum_e val_e x[src_e] with rows grouped by dependency depth.  The depth is ~ 400 at n = 1e5
 // (the first m points form a dense chain) and more than half of the levels hold fewer than 64 rows, so the solves are
 // LATENCY bound: what matters is the number of dependent memory round trips per level.  Layout and schedule are built for
 // exactly one:
-//   * rows are stored in LEVEL ORDER (position q): a 32-wide head (src = -1 padded) plus an overflow CSR for longer rows, so
-//     the address of all matrix data depends on q only, never on a row-index load;
-//   * 16 lanes (one DPP row) share a matrix row: its gathers are all in flight at once and the partial products are summed
-//     with 4 DPP steps in a fixed order (bit-reproducible);
-//   * a 1024-lane workgroup (64 groups x 2 rows) walks the rounds of all levels as a 3-stage software pipeline: while round r
-//     gathers the solution entries it depends on, the matrix data / right-hand sides of round r+1 and the row indices of
-//     round r+2 are already being fetched; after a level's barrier only the gather of freshly written entries remains.
-// One workgroup per right-hand side; the 50 probe vectors of the stochastic Lanczos quadrature run as 50 workgroups.
+//   * the matrix is stored in LEVEL ORDER as SLOTS (position q): a 32-wide head (src = -1 padded) plus an overflow CSR, so the
+//     address of all matrix data depends on q only, never on a row-index load.  A row with more than 64 entries (the early
+//     points of B^T have hundreds) is split into consecutive slots of <= 64 entries that always share a round; their
+//     partial sums meet in LDS, so no lane ever walks a long row serially;
+//   * 16 lanes (one DPP row) share a slot: its gathers are all in flight at once and the partial products are summed with 4
+//     DPP steps in a fixed order (bit-reproducible);
+//   * a 512-lane workgroup (32 groups x 2 slots; 8 wavefronts, so each may hold the ~150 VGPRs of the pipeline state) walks the
+//     rounds of all levels as a 3-stage software pipeline: while round r gathers the solution entries it depends on, the
+//     matrix data / right-hand sides of round r+1 and the row indices of round r+2 are already being fetched; after a level's
+//     barrier only the gather of freshly written entries remains.  The loop is unrolled over the pipeline's period (6) so
+//     that loaded values are never copied between registers (a copy would wait for the prefetches just issued).
+// Runs of narrow levels: one workgroup per right-hand side (50 for the probe block of the stochastic Lanczos quadrature);
+// wide levels: own launch, ceil(slots / 64) workgroups per right-hand side (the kernel boundary is the level barrier).
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   const long long b = __builtin_bit_cast(long long, v);
@@ -184,103 +166,240 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 namespace {
-constexpr int TRI_R = 2;                 // rows per 16-lane group and round
-constexpr int TRI_ROWS = 64 * TRI_R;     // rows per round of the workgroup
-struct TriRound { int L, qb, b1; };      // level, first position of the round, end of the level
-struct TriA { int i[TRI_R], ob[TRI_R], oe[TRI_R]; };
+// base[idx] with the BYTE offset formed in 32 bits: the load then takes its base from SGPRs and one VGPR of offset
+// (global_load ... v_off, s[base:base+1]) instead of a 64-bit VGPR address computed per load (host guards the 4 GB range)
+template <class Tp>
+__device__ __forceinline__ Tp ldu(const Tp* __restrict__ base, unsigned idx) {
+  return *reinterpret_cast<const Tp*>(reinterpret_cast<const char*>(base) + (idx * (unsigned)sizeof(Tp)));
+}
+template <int V> struct IntC { static constexpr int value = V; };
+template <class F> __device__ __forceinline__ void static_for6(F&& f) { f(IntC<0>{}); f(IntC<1>{}); f(IntC<2>{}); f(IntC<3>{}); f(IntC<4>{}); f(IntC<5>{}); }
+constexpr int TRI_R = 2;                       // slots per 16-lane group and round
+constexpr int TRI_GROUPS = kTriThreads / 16;   // 16-lane groups per workgroup
+constexpr int TRI_ROWS = kTriRowsPerRound;     // slots per round of the workgroup
+static_assert(TRI_ROWS == TRI_GROUPS * TRI_R, "round size");
+struct TriRound { int L, qb, b1, split; };   // level, first position of the round, end of the level, level has split rows
+struct TriA { int i[TRI_R], ns[TRI_R], ob[TRI_R], oe[TRI_R]; };
 struct TriB { int hs[TRI_R][2], os[TRI_R][2]; double ha[TRI_R][2], oa[TRI_R][2], num[TRI_R], den[TRI_R]; };
 }  // namespace
 
+// Levels [L0, L1) of the solve, `nrounds` rounds for this workgroup.  nsplit == 1: one workgroup per right-hand side walks all
+// rounds of these levels (barrier after each level).  nsplit > 1 (then L1 == L0 + 1, a "wide" level launched on its own so
+// the kernel boundary orders it against its neighbours): workgroup `part` of the nsplit takes round `part` of that level.
+//
+// What bounds a round is the number of vector-memory INSTRUCTIONS the CU issues (its address unit takes ~16 clocks per
+// 64-lane load, shared by all wavefronts), not latency.  Hence: the slot descriptor is one 16-byte record (one load instead
+// of four), matrix entries are 16-byte {coefficient, source} records (one load instead of two), a wavefront whose groups
+// have no slot in rounds r .. r+2 issues nothing, and rounds of at most 32 slots run a one-slot-per-group body.
 template <bool SCALE>
-__global__ __launch_bounds__(1024) void lap_sptrsv_kernel(LapTri T, int n, const double* __restrict__ rhs, const double* __restrict__ dw,
-                                                          double* x) {
-  const size_t off = (size_t)blockIdx.x * n;
+__global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const int* __restrict__ lv_ptr, const int* __restrict__ lv_split,
+                                                                 int n, int L0, int L1, int nsplit, int nrounds,
+                                                                 const double* __restrict__ rhs, const double* __restrict__ rdw, double* x) {
+  // lv_ptr / lv_split (= T.ptr / T.lsplit) are separate __restrict__ arguments so that the level bookkeeping compiles to
+  // scalar loads: as vector loads their results would have to be waited for with vmcnt(0), draining the prefetches
+  __shared__ double s_part[2][TRI_ROWS];
+  const int col = blockIdx.x / nsplit, part = blockIdx.x - col * nsplit;
+  const size_t off = (size_t)col * n;
   const double* __restrict__ rc = rhs + off;
   double* xc = x + off;
   const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int nlev = T.nlev;
+  const int wgrp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4;     // first group of this wavefront (scalar)
+  const int nlev = T.nlev, nslots = T.nslots;
+  const int stride = TRI_ROWS * nsplit, first = TRI_ROWS * part;
   // next round; ptr_next = T.ptr[d.L + 2] (fetched by the caller a whole round earlier: no load on the critical path)
-  auto advance = [&](TriRound d, int ptr_next) -> TriRound {
+  auto advance = [&](TriRound d, int ptr_next, int split_next) -> TriRound {
     TriRound o = d;
-    o.qb = d.qb + TRI_ROWS;
-    if (o.qb >= d.b1 && d.L < nlev) { o.L = d.L + 1; o.qb = d.b1; o.b1 = (o.L < nlev) ? ptr_next : d.b1; }
+    o.qb = d.qb + stride;
+    if (o.qb >= d.b1 && d.L < L1) { o.L = d.L + 1; o.qb = d.b1 + first; o.b1 = (o.L < nlev) ? ptr_next : d.b1; o.split = split_next; }
     return o;
   };
-  auto ptr_at = [&](int l) -> int { return T.ptr[l < nlev ? l : nlev]; };
-  auto slot = [&](const TriRound& d, int s) -> int { const int q = d.qb + grp + 64 * s; return q < n ? q : n - 1; };
-  auto issueA = [&](const TriRound& d, TriA& a) {
+  auto ptr_at = [&](int l) -> int { return lv_ptr[l < nlev ? l : nlev]; };
+  auto split_at = [&](int l) -> int { return lv_split[l < nlev ? l : nlev]; };
+  // does this wavefront hold any slot of round d?  (scalar: a wavefront without slots in rounds r, r+1, r+2 skips the whole
+  // phase except its barriers -- no loads at all; most levels of the narrow runs occupy one or two wavefronts)
+  auto wave_live = [&](const TriRound& d) -> bool { return d.L < L1 && d.qb + wgrp < d.b1; };
+  // does round d use the second slot of the groups (more than 32 slots)?  Phases whose three rounds do not run the one-slot body.
+  auto two_slots = [&](const TriRound& d) -> bool { return d.L < L1 && d.qb + TRI_GROUPS < d.b1; };
+  // all device arrays are indexed with 32-bit unsigned offsets from uniform bases (one VGPR of address per load)
+  auto slot = [&](const TriRound& d, int s) -> unsigned { const int q = d.qb + grp + TRI_GROUPS * s; return (unsigned)(q < nslots ? q : nslots - 1); };
+  // Inside a body everything is straight-line (clamped, unconditional loads): the compiler's wait counts are exact there, and
+  // the branches between bodies only merge at phase boundaries, where the next gathers need all prefetches anyway.
+  auto issueA = [&](auto NS, const TriRound& d, TriA& a) {
 #pragma unroll
-    for (int s = 0; s < TRI_R; ++s) {
-      const int q = slot(d, s);
-      a.i[s] = T.rows[q]; a.ob[s] = T.optr[q]; a.oe[s] = T.optr[q + 1];
+    for (int s = 0; s < decltype(NS)::value; ++s) {
+      const int4 m = ldu(T.meta, slot(d, s));
+      a.i[s] = m.x; a.ns[s] = m.y; a.ob[s] = m.z; a.oe[s] = m.w;
     }
   };
-  auto issueB = [&](const TriRound& d, const TriA& a, TriB& b) {
+  auto issueB = [&](auto NS, const TriRound& d, const TriA& a, TriB& b) {
 #pragma unroll
-    for (int s = 0; s < TRI_R; ++s) {
-      const int q = slot(d, s);
+    for (int s = 0; s < decltype(NS)::value; ++s) {
+      const unsigned hq = slot(d, s) * 32u + (unsigned)lane;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        b.hs[s][k] = T.hsrc[(size_t)q * 32 + lane + 16 * k];
-        b.ha[s][k] = T.hval[(size_t)q * 32 + lane + 16 * k];
+        const LapEnt h = ldu(T.hent, hq + 16u * k);
+        b.hs[s][k] = h.src; b.ha[s][k] = h.val;
         const int e = a.ob[s] + lane + 16 * k;
         const bool in = e < a.oe[s];
-        const int ec = in ? e : 0;
-        const int src = T.osrc[ec];
-        const double val = T.oval[ec];
-        b.os[s][k] = in ? src : -1;
-        b.oa[s][k] = in ? val : 0.0;
+        const LapEnt o = ldu(T.oent, in ? (unsigned)e : 0u);      // masked: any valid entry, coefficient forced to 0
+        b.os[s][k] = o.src;
+        b.oa[s][k] = in ? o.val : 0.0;
       }
-      b.num[s] = rc[a.i[s]];
-      b.den[s] = SCALE ? dw[a.i[s]] : 1.0;
+      const unsigned row = a.i[s] >= 0 ? (unsigned)a.i[s] : 0u;      // padding slots and continuation slots never use it
+      b.num[s] = ldu(rc, row);
+      b.den[s] = SCALE ? ldu(rdw, row) : 1.0;
     }
   };
-  auto finish = [&](const TriRound& d, const TriA& a, const TriB& b) {
-    double acc[TRI_R];
+  // part 1 of a round: gathers, prefetches, slot sums, partial sums to LDS
+  auto body1 = [&](auto NS, const TriRound& d, const TriA& a, const TriB& b, int parity, const TriRound& dn, const TriA& an, TriB& bn,
+                   const TriRound& dnn, TriA& ann, double (&tot)[TRI_R]) {
+    constexpr int ns = decltype(NS)::value;
+    // (1) the gathers this round waits for go first ...
+    double g[TRI_R][4];
 #pragma unroll
-    for (int s = 0; s < TRI_R; ++s) {
-      double g[4];
+    for (int s = 0; s < ns; ++s) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        g[k] = xc[b.hs[s][k] >= 0 ? b.hs[s][k] : 0];
-        g[2 + k] = xc[b.os[s][k] >= 0 ? b.os[s][k] : 0];
+        g[s][k] = ldu((const double*)xc, (unsigned)b.hs[s][k]);
+        g[s][2 + k] = ldu((const double*)xc, (unsigned)b.os[s][k]);
       }
+    }
+    // (2) ... then the prefetches of the next two rounds (independent of x)
+    issueA(NS, dnn, ann);
+    issueB(NS, dn, an, bn);
+    // (3) slot sums; padding entries: coefficient 0 times a finite x (the workspace is zero-initialised)
+#pragma unroll
+    for (int s = 0; s < ns; ++s) {
       double sum = 0.0;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {        // masked slots read x[0], which may hold anything (even NaN): select, don't multiply by 0
-        sum = __builtin_fma(b.ha[s][k], b.hs[s][k] >= 0 ? g[k] : 0.0, sum);
-        sum = __builtin_fma(b.oa[s][k], b.os[s][k] >= 0 ? g[2 + k] : 0.0, sum);
+      for (int k = 0; k < 2; ++k) {
+        sum = __builtin_fma(b.ha[s][k], g[s][k], sum);
+        sum = __builtin_fma(b.oa[s][k], g[s][2 + k], sum);
       }
-      acc[s] = sum;
-    }
+      // slots longer than 64 entries exist only when a row has > 4096 entries
+      for (int e0 = a.ob[s] + 32 + lane; e0 - lane < a.oe[s]; e0 += 64) {
+        LapEnt o[4]; double gg[4];
 #pragma unroll
-    for (int s = 0; s < TRI_R; ++s) {          // rows longer than 64 entries (rare): the remaining overflow entries
-      for (int e = a.ob[s] + 32 + lane; e < a.oe[s]; e += 16) acc[s] = __builtin_fma(T.oval[e], xc[T.osrc[e]], acc[s]);
-    }
+        for (int k = 0; k < 4; ++k) {
+          const int e = e0 + 16 * k;
+          const bool in = e < a.oe[s];
+          o[k] = ldu(T.oent, in ? (unsigned)e : (unsigned)a.ob[s]);
+          if (!in) o[k].val = 0.0;
+        }
 #pragma unroll
-    for (int s = 0; s < TRI_R; ++s) {
-      const double tot = row16_sum(acc[s]);
-      const bool live = d.L < nlev && d.qb + grp + 64 * s < d.b1;
-      if (lane == 0 && live) xc[a.i[s]] = (SCALE ? b.num[s] / b.den[s] : b.num[s]) + tot;
+        for (int k = 0; k < 4; ++k) gg[k] = ldu((const double*)xc, (unsigned)o[k].src);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum = __builtin_fma(o[k].val, gg[k], sum);
+      }
+      tot[s] = row16_sum(sum);
+    }
+    // (4) partial sums of split rows meet in LDS (only in levels that have any; double-buffered by round parity)
+    if (d.split) {
+#pragma unroll
+      for (int s = 0; s < ns; ++s) if (lane == 0) s_part[parity][grp + TRI_GROUPS * s] = tot[s];
     }
   };
-  TriRound d0{0, T.ptr[0], T.ptr[1]};
-  TriRound d1 = advance(d0, ptr_at(2));
-  TriRound d2 = advance(d1, ptr_at(d1.L + 2));
-  TriA a0, a1, a2;
-  TriB b0, b1;
-  issueA(d0, a0);
-  issueB(d0, a0, b0);
-  issueA(d1, a1);
-  while (d0.L < nlev) {
-    const int ptr_next = ptr_at(d2.L + 2);
-    issueA(d2, a2);
-    issueB(d1, a1, b1);
-    finish(d0, a0, b0);
-    if (d0.qb + TRI_ROWS >= d0.b1) __syncthreads();      // last round of its level
-    a0 = a1; b0 = b1; a1 = a2;
-    d0 = d1; d1 = d2; d2 = advance(d2, ptr_next);
+  // part 2 (after the exchange barrier): the first slot of a row adds the partial sums of its other slots and stores
+  auto body2 = [&](auto NS, const TriRound& d, const TriA& a, const TriB& b, int parity, const double (&tot)[TRI_R]) {
+#pragma unroll
+    for (int s = 0; s < decltype(NS)::value; ++s) {
+      const bool live = d.L < L1 && d.qb + grp + TRI_GROUPS * s < d.b1 && a.ns[s] > 0;
+      if (lane == 0 && live) {
+        double v = tot[s];
+        // the continuation slots of a row follow its first slot: positions (q - qb) + 1 ... inside the same round
+        for (int k = 1; k < a.ns[s]; ++k) v += s_part[parity][grp + TRI_GROUPS * s + k];
+        xc[(unsigned)a.i[s]] = (SCALE ? __builtin_fma(b.num[s], b.den[s], v) : b.num[s] + v);
+      }
+    }
+  };
+  // 3-stage software pipeline, unrolled over its period (3 descriptor / stage-A buffers x 2 stage-B buffers = 6 phases) so that
+  // no loaded value is ever copied between registers: a copy would make the wave wait for the prefetches it just issued
+  // (zero-initialised: a wavefront that joins in executes the bodies of rounds it holds no slot of with whatever its
+  // buffers contain -- zeros or the data of an older round, always valid indices)
+  TriRound d[3];
+  TriA a[3] = {};
+  TriB b[2] = {};
+  d[0] = TriRound{L0, lv_ptr[L0] + first, lv_ptr[L0 + 1], lv_split[L0]};
+  d[1] = advance(d[0], ptr_at(L0 + 2), split_at(L0 + 1));
+  d[2] = advance(d[1], ptr_at(d[1].L + 2), split_at(d[1].L + 1));
+  issueA(IntC<2>{}, d[0], a[0]);
+  issueB(IntC<2>{}, d[0], a[0], b[0]);
+  issueA(IntC<2>{}, d[1], a[1]);
+  for (int r0 = 0; r0 < nrounds; r0 += 6) {
+    static_for6([&](auto P) {
+      constexpr int p = decltype(P)::value;
+      if (r0 + p < nrounds) {
+        const TriRound& dc = d[p % 3];
+        const TriRound& dn = d[(p + 1) % 3];
+        const TriRound& dnn = d[(p + 2) % 3];
+        const int ptr_next = ptr_at(dnn.L + 2), split_next = split_at(dnn.L + 1);
+        const bool mine = wave_live(dc) || wave_live(dn) || wave_live(dnn);
+        const bool wide = two_slots(dc) || two_slots(dn) || two_slots(dnn);
+        double tot[TRI_R] = {0.0, 0.0};
+        if (mine) {
+          if (wide) body1(IntC<2>{}, dc, a[p % 3], b[p % 2], p & 1, dn, a[(p + 1) % 3], b[(p + 1) % 2], dnn, a[(p + 2) % 3], tot);
+          else body1(IntC<1>{}, dc, a[p % 3], b[p % 2], p & 1, dn, a[(p + 1) % 3], b[(p + 1) % 2], dnn, a[(p + 2) % 3], tot);
+        }
+        if (dc.split) __syncthreads();
+        if (mine) {
+          if (wide) body2(IntC<2>{}, dc, a[p % 3], b[p % 2], p & 1, tot);
+          else body2(IntC<1>{}, dc, a[p % 3], b[p % 2], p & 1, tot);
+        }
+        if (dc.qb + stride >= dc.b1) __syncthreads();      // last round of its level
+        d[p % 3] = advance(dnn, ptr_next, split_next);
+      }
+    });
   }
+}
+
+// Row-parallel products with the same level-ordered storage: 16 lanes per row (the group of a row's first slot walks all its
+// slots), 16 slots per workgroup.
+//   MODE 0: out = B x      MODE 1: out = D^-1 B x      MODE 2: out = B^T x + W .* h  (W may be NULL)
+// (B x)_i = x_i - sum_j A_ij x[nn_ij] with T = fwd;  (B^T x)_j = x_j - sum_{i : j in N(i)} A_ij x_i with T = bwd.
+template <int MODE>
+__global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, const double* __restrict__ x, const double* __restrict__ D,
+                                                           const double* __restrict__ W, const double* __restrict__ h, double* __restrict__ out) {
+  const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int q0 = blockIdx.x * 16 + grp;
+  if (q0 >= T.nslots) return;              // whole 16-lane groups leave together
+  const int4 m0 = T.meta[q0];
+  const int row = m0.x, nseg = m0.y;
+  if (nseg <= 0) return;                   // continuation or padding slot
+  const size_t off = (size_t)blockIdx.y * n;
+  const double* __restrict__ xc = x + off;
+  double sum = 0.0;
+  for (int q = q0; q < q0 + nseg; ++q) {
+    LapEnt e[2]; double g[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) e[k] = ldu(T.hent, (unsigned)q * 32u + lane + 16u * k);
+    const int4 mq = T.meta[q];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) g[k] = xc[e[k].src];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) sum = __builtin_fma(e[k].val, g[k], sum);
+    for (int j = mq.z + lane; j < mq.w; j += 16) { const LapEnt o = T.oent[j]; sum = __builtin_fma(o.val, xc[o.src], sum); }
+  }
+  const double tot = row16_sum(sum);
+  if (lane == 0) {
+    double v = xc[row] - tot;
+    if (MODE == 1) v *= 1.0 / D[row];
+    if (MODE == 2 && W) v = __builtin_fma(W[row], h[off + row], v);
+    out[off + row] = v;
+  }
+}
+
+// once per evaluation: the factor's A into the level-ordered entry records of a solve
+__global__ void lap_permute_factor_kernel(const double* __restrict__ A, const int* __restrict__ hpos, const int* __restrict__ opos, size_t nh,
+                                          size_t novf, LapEnt* __restrict__ hent, LapEnt* __restrict__ oent) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < nh) { const int pos = hpos[g]; hent[g].val = pos >= 0 ? A[pos] : 0.0; }
+  if (g < novf) oent[g].val = A[opos[g]];
+}
+
+// out[sigma[i]] = in[i]: Vecchia order -> storage order of the Laplace workspace
+__global__ void lap_scatter_kernel(const double* __restrict__ in, const int* __restrict__ sigma, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[sigma[i]] = in[i];
 }
 
 // once per evaluation: the factor's A in the level-ordered head / overflow layout of a solve
@@ -322,36 +441,48 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 
 // ---- launchers --------------------------------------------------------------------------------------------
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256)
-hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, hipStream_t st) {
-  hipLaunchKernelGGL(logit_newton_setup_kernel, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw);
+hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
+  hipLaunchKernelGGL(logit_newton_setup_kernel, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
   return hipGetLastError();
 }
-hipError_t lap_apply(const LapMat& B, const double* W, const double* h, double* v, double* tmp, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_B_kernel, dim3((B.n + 255) / 256, ncol), dim3(256), 0, st, B.A, B.nn, B.D, B.n, B.m, h, tmp, 1);
-  hipLaunchKernelGGL(lap_Bt_plus_kernel, dim3((B.n + 255) / 256, ncol), dim3(256), 0, st, B.A, B.t_ptr, B.t_pos, B.n, B.m, tmp, W, h, v);
+hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, hipStream_t st) {
+  const dim3 grid((lv.fwd.nslots + 15) / 16, ncol), gridb((lv.bwd.nslots + 15) / 16, ncol);
+  hipLaunchKernelGGL(lap_tri_spmv_kernel<1>, grid, dim3(256), 0, st, lv.fwd, n, h, D, (const double*)nullptr, (const double*)nullptr, tmp);
+  hipLaunchKernelGGL(lap_tri_spmv_kernel<2>, gridb, dim3(256), 0, st, lv.bwd, n, (const double*)tmp, (const double*)nullptr, W, h, v);
   return hipGetLastError();
 }
-hipError_t lap_B(const LapMat& B, const double* x, double* out, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_B_kernel, dim3((B.n + 255) / 256, ncol), dim3(256), 0, st, B.A, B.nn, B.D, B.n, B.m, x, out, 0);
+hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st) {
+  hipLaunchKernelGGL(lap_tri_spmv_kernel<0>, dim3((lv.fwd.nslots + 15) / 16, ncol), dim3(256), 0, st, lv.fwd, n, x, (const double*)nullptr, (const double*)nullptr,
+                     (const double*)nullptr, out);
   return hipGetLastError();
 }
-hipError_t lap_Bt(const LapMat& B, const double* x, double* out, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_Bt_plus_kernel, dim3((B.n + 255) / 256, ncol), dim3(256), 0, st, B.A, B.t_ptr, B.t_pos, B.n, B.m, x,
-                     (const double*)nullptr, (const double*)nullptr, out);
+hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st) {
+  hipLaunchKernelGGL(lap_tri_spmv_kernel<2>, dim3((lv.bwd.nslots + 15) / 16, ncol), dim3(256), 0, st, lv.bwd, n, x, (const double*)nullptr, (const double*)nullptr,
+                     (const double*)nullptr, out);
+  return hipGetLastError();
+}
+hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(lap_scatter_kernel, GRID1(n), 0, st, in, sigma, n, out);
   return hipGetLastError();
 }
 hipError_t lap_objective(const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
   hipLaunchKernelGGL(logit_objective_kernel, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
   return hipGetLastError();
 }
-hipError_t lap_vadu(const LapMat& B, const LapLevels& lv, const double* dw, const double* r, double* z, double* t, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_sptrsv_kernel<false>, dim3(ncol), dim3(1024), 0, st, lv.bwd, B.n, r, (const double*)nullptr, t);   // B^T t = r
-  hipLaunchKernelGGL(lap_sptrsv_kernel<true>, dim3(ncol), dim3(1024), 0, st, lv.fwd, B.n, t, dw, z);                         // (D^-1 + W) B z = t
+hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, hipStream_t st) {
+  for (int k = 0; k < lv.n_bseg; ++k) {       // B^T t = r
+    const LapSeg& sg = lv.bseg[k];
+    hipLaunchKernelGGL(lap_sptrsv_kernel<false>, dim3(ncol * sg.nsplit), dim3(kTriThreads), 0, st, lv.bwd, lv.bwd.ptr, lv.bwd.lsplit, n, sg.L0, sg.L1, sg.nsplit, sg.nrounds, r, (const double*)nullptr, t);
+  }
+  for (int k = 0; k < lv.n_fseg; ++k) {       // (D^-1 + W) B z = t
+    const LapSeg& sg = lv.fseg[k];
+    hipLaunchKernelGGL(lap_sptrsv_kernel<true>, dim3(ncol * sg.nsplit), dim3(kTriThreads), 0, st, lv.fwd, lv.fwd.ptr, lv.fwd.lsplit, n, sg.L0, sg.L1, sg.nsplit, sg.nrounds, t, rdw, z);
+  }
   return hipGetLastError();
 }
-hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, double* hval, double* oval, hipStream_t st) {
+hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st) {
   const size_t cnt = nh > novf ? nh : novf;
-  hipLaunchKernelGGL(lap_permute_factor_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, hpos, opos, nh, novf, hval, oval);
+  hipLaunchKernelGGL(lap_permute_factor_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, hpos, opos, nh, novf, hent, oent);
   return hipGetLastError();
 }
 hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, const CgScalars& sc, hipStream_t st) {

@@ -9,7 +9,12 @@ from tests import cases
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 100000
 m = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 30
-coords, y = cases.synthetic_binary(n, 2, seed=1)
+if "--surface" in sys.argv:      # labels around a smooth latent surface (as in the parity tests)
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+else:                            # coords U[0,1]^2, y ~ Bernoulli(0.5), default_rng(1)
+    rng = np.random.default_rng(1)
+    coords = rng.uniform(size=(n, 2))
+    y = (rng.uniform(size=n) < 0.5).astype(np.float64)
 t0 = time.perf_counter()
 mdl = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
                           num_neighbors=m, vecchia_ordering="random", seed=1)
