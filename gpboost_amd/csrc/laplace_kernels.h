@@ -12,7 +12,7 @@ struct LapTri {            // one level-scheduled triangular solve; matrix store
                            //           begin, end of the slot's overflow entries}
   const LapEnt* hent;      // [nslots * 32] head entries (padding: source 0, coefficient 0); .val refreshed per evaluation
   const LapEnt* oent;      // [max(novf, 1)] overflow entries 33.. of a slot (a slot holds <= 64 unless its row has > 4096)
-  int nlev, nslots;
+  int nlev, nslots, has_ovf;
 };
 constexpr int kTriThreads = 512;        // workgroup of the level-scheduled solves
 constexpr int kTriRowsPerRound = 64;    // rows it handles per round (32 groups of 16 lanes x 2)

@@ -191,7 +191,7 @@ struct TriB { int hs[TRI_R][2], os[TRI_R][2]; double ha[TRI_R][2], oa[TRI_R][2],
 // 64-lane load, shared by all wavefronts), not latency.  Hence: the slot descriptor is one 16-byte record (one load instead
 // of four), matrix entries are 16-byte {coefficient, source} records (one load instead of two), a wavefront whose groups
 // have no slot in rounds r .. r+2 issues nothing, and rounds of at most 32 slots run a one-slot-per-group body.
-template <bool SCALE>
+template <bool SCALE, bool OVF>
 __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const int* __restrict__ lv_ptr, const int* __restrict__ lv_split,
                                                                  int n, int L0, int L1, int nsplit, int nrounds,
                                                                  const double* __restrict__ rhs, const double* __restrict__ rdw, double* x) {
@@ -239,11 +239,13 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
       for (int k = 0; k < 2; ++k) {
         const LapEnt h = ldu(T.hent, hq + 16u * k);
         b.hs[s][k] = h.src; b.ha[s][k] = h.val;
-        const int e = a.ob[s] + lane + 16 * k;
-        const bool in = e < a.oe[s];
-        const LapEnt o = ldu(T.oent, in ? (unsigned)e : 0u);      // masked: any valid entry, coefficient forced to 0
-        b.os[s][k] = o.src;
-        b.oa[s][k] = in ? o.val : 0.0;
+        if (OVF) {
+          const int e = a.ob[s] + lane + 16 * k;
+          const bool in = e < a.oe[s];
+          const LapEnt o = ldu(T.oent, in ? (unsigned)e : 0u);      // masked: any valid entry, coefficient forced to 0
+          b.os[s][k] = o.src;
+          b.oa[s][k] = in ? o.val : 0.0;
+        }
       }
       const unsigned row = a.i[s] >= 0 ? (unsigned)a.i[s] : 0u;      // padding slots and continuation slots never use it
       b.num[s] = ldu(rc, row);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         g[s][k] = ldu((const double*)xc, (unsigned)b.hs[s][k]);
-        g[s][2 + k] = ldu((const double*)xc, (unsigned)b.os[s][k]);
+        if (OVF) g[s][2 + k] = ldu((const double*)xc, (unsigned)b.os[s][k]);
       }
     }
     // (2) ... then the prefetches of the next two rounds (independent of x)
@@ -274,10 +276,10 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         sum = __builtin_fma(b.ha[s][k], g[s][k], sum);
-        sum = __builtin_fma(b.oa[s][k], g[s][2 + k], sum);
+        if (OVF) sum = __builtin_fma(b.oa[s][k], g[s][2 + k], sum);
       }
       // slots longer than 64 entries exist only when a row has > 4096 entries
-      for (int e0 = a.ob[s] + 32 + lane; e0 - lane < a.oe[s]; e0 += 64) {
+      if (OVF) for (int e0 = a.ob[s] + 32 + lane; e0 - lane < a.oe[s]; e0 += 64) {
         LapEnt o[4]; double gg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -469,15 +471,19 @@ hipError_t lap_objective(const double* x, const int* y, const double* Bx, const 
   hipLaunchKernelGGL(logit_objective_kernel, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
   return hipGetLastError();
 }
+// OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out
+#define LAP_TRSV(SCALE, T_, SEG, RHS, RDW, X)                                                                                         \
+  do {                                                                                                                                \
+    if ((T_).has_ovf)                                                                                                                 \
+      hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, true>), dim3(ncol * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, (T_).ptr,        \
+                         (T_).lsplit, n, (SEG).L0, (SEG).L1, (SEG).nsplit, (SEG).nrounds, RHS, RDW, X);                               \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, false>), dim3(ncol * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, (T_).ptr,       \
+                         (T_).lsplit, n, (SEG).L0, (SEG).L1, (SEG).nsplit, (SEG).nrounds, RHS, RDW, X);                               \
+  } while (0)
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, hipStream_t st) {
-  for (int k = 0; k < lv.n_bseg; ++k) {       // B^T t = r
-    const LapSeg& sg = lv.bseg[k];
-    hipLaunchKernelGGL(lap_sptrsv_kernel<false>, dim3(ncol * sg.nsplit), dim3(kTriThreads), 0, st, lv.bwd, lv.bwd.ptr, lv.bwd.lsplit, n, sg.L0, sg.L1, sg.nsplit, sg.nrounds, r, (const double*)nullptr, t);
-  }
-  for (int k = 0; k < lv.n_fseg; ++k) {       // (D^-1 + W) B z = t
-    const LapSeg& sg = lv.fseg[k];
-    hipLaunchKernelGGL(lap_sptrsv_kernel<true>, dim3(ncol * sg.nsplit), dim3(kTriThreads), 0, st, lv.fwd, lv.fwd.ptr, lv.fwd.lsplit, n, sg.L0, sg.L1, sg.nsplit, sg.nrounds, t, rdw, z);
-  }
+  for (int k = 0; k < lv.n_bseg; ++k) LAP_TRSV(false, lv.bwd, lv.bseg[k], r, (const double*)nullptr, t);     // B^T t = r
+  for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], (const double*)t, rdw, z);            // (D^-1 + W) B z = t
   return hipGetLastError();
 }
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st) {
