@@ -242,6 +242,28 @@ def main():
                 ex.close()
             except Exception as e:
                 out["roofline_cov_assembly"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1:
+            # BASELINE config 4: Vecchia-Laplace, Bernoulli-logit, n = 1e5, m = 30 -- seconds per evaluation
+            try:
+                n4 = 100000
+                rng4 = np.random.default_rng(1)
+                c4 = rng4.uniform(size=(n4, 2))
+                y4 = (rng4.uniform(size=n4) < 0.5).astype(np.float64)
+                m4 = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=c4, cov_function="exponential", gp_approx="vecchia",
+                                         num_neighbors=30, vecchia_ordering="random", seed=1)
+                m4.neg_log_likelihood(np.array([1.0, 0.1]), y4)          # builds the level schedules and probe vectors
+                t4 = time.perf_counter()
+                v4 = m4.neg_log_likelihood(np.array([1.01, 0.1]), y4)
+                s4 = time.perf_counter() - t4
+                i4 = m4.laplace_info()
+                out["config4_vecchia_laplace"] = {
+                    "workload": "Bernoulli-logit Vecchia-Laplace nll (Newton + vadu-CG + SLQ, 50 probes), n=%d, m=30, exponential" % n4,
+                    "s_per_eval": s4, "negll": v4, "newton_it": i4["newton_it"], "cg_it": i4["cg_it"], "lanczos_it": i4["lanczos_it"],
+                    "ms_mode_finding": i4["ms_mode"], "ms_logdet": i4["ms_logdet"],
+                    "reference_s_per_eval": {"value": 24.6, "cores": 8, "where": "same inputs class, this repo's container (DESIGN.md 4.6)"}}
+                del m4
+            except Exception as e:
+                out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)
