@@ -209,6 +209,18 @@ class GPModel(object):
         _safe_call(_lib().GPB_HIP_CalcYAux(self.handle, _dptr(y), _dptr(cov_pars), _dptr(out)))
         return out
 
+    def newton_update_leaf_values(self, cov_pars, y, data_leaf_index, num_leaves):
+        """Leaf values of the Newton step of the GPBoost algorithm (REModel::NewtonUpdateLeafValues); y = F - y, data order."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        leaf = np.ascontiguousarray(data_leaf_index, dtype=np.int32).reshape(-1)
+        if leaf.shape[0] != self.num_data or y.shape[0] != self.num_data:
+            raise ValueError("Incorrect number of data points")
+        out = np.empty(int(num_leaves))
+        _safe_call(_lib().GPB_HIP_NewtonUpdateLeafValues(self.handle, _dptr(y), _dptr(cov_pars),
+                                                         leaf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(num_leaves)), _dptr(out)))
+        return out
+
     def vecchia_structure(self):
         """(perm, nn): Vecchia ordering and the (n, m) neighbour table, -1 padded."""
         m = ctypes.c_int(0)

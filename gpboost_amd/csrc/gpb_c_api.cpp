@@ -321,6 +321,25 @@ int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_par
   C_API_END();
 }
 
+int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, double* cov_pars, const int32_t* data_leaf_index,
+                                   int32_t num_leaves, double* leaf_values) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !cov_pars || !data_leaf_index || !leaf_values) return set_error("GPB_HIP_NewtonUpdateLeafValues: null argument");
+  if (mdl->likelihood != "gaussian") return set_error("Newton updates for leaf values is only supported for Gaussian data");   // re_model_template.h:4986-4988
+  if (mdl->eh) return set_error("GPB_HIP_NewtonUpdateLeafValues: the exact (dense) GP is not on the MI355X hot path of this library for this call");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (upload_y(mdl, y_data, nullptr)) return -1;
+  if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
+  std::vector<double> ya(mdl->n);
+  if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
+  std::vector<int32_t> leaf(mdl->n);
+  for (int k = 0; k < mdl->n; ++k) leaf[k] = data_leaf_index[mdl->perm[k]];     // :4999 (data_indices_per_cluster_)
+  if (gpb_hip_vecchia_newton_leaf_values(mdl->vh, leaf.data(), num_leaves, leaf_values)) return shim_error();
+  C_API_END();
+}
+
 int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);

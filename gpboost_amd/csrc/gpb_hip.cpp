@@ -20,6 +20,7 @@
 
 #include "dense_kernels.h"
 #include "hist_kernels.h"
+#include "leaf_kernels.h"
 #include "nn_kernels.h"
 #include "vecchia_kernels.h"
 
@@ -89,7 +90,8 @@ struct gpb_hip_vecchia {
   double* d_ystage = nullptr;
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
-  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false;
+  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false;
+  int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   ncclComm_t comm = nullptr;      // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init)
   int comm_rank = 0, comm_world = 1;
@@ -120,6 +122,8 @@ struct gpb_hip_hist {
   int* d_idx = nullptr; int idx_cap = 0;
   double* d_part_grad = nullptr; double* d_part_hess = nullptr; uint32_t* d_part_cnt = nullptr; int part_chunks = 0;
   double* d_hist = nullptr; unsigned long long* d_cnt = nullptr;
+  double* d_pool = nullptr; int nslots = 0;                 // resident leaf histograms (HistogramPool), 2 * total_bins doubles each
+  int* d_fix = nullptr; bool has_fix = false;              // view_offset[F], num_bin[F], most_freq_bin[F]
 };
 
 extern "C" {
@@ -246,6 +250,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   dev_free(h->d_pts); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out);
   dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage);
   dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
+  dev_free(h->d_leaf); dev_free(h->d_leaf_part); dev_free(h->d_leaf_out);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
@@ -356,7 +361,7 @@ int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev) {
   if (!h || !y_dev) return fail("null argument");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(gpb::launch_pack_y(h->d_pts, y_dev, h->n, h->stream));
-  h->has_y = true; h->has_factor = false;
+  h->has_y = true; h->has_yaux = false; h->has_factor = false;
   API_END();
 }
 
@@ -368,7 +373,7 @@ int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) {
   HIP_OK(hipMemcpyAsync(h->d_ystage, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   HIP_OK(gpb::launch_pack_y(h->d_pts, h->d_ystage, h->n, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));   // y_host is borrowed for the call only
-  h->has_y = true; h->has_factor = false;
+  h->has_y = true; h->has_yaux = false; h->has_factor = false;
   API_END();
 }
 
@@ -537,6 +542,7 @@ int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, doubl
     HIP_OK(hipMalloc(&h->d_D, sizeof(double) * (size_t)h->n));
     HIP_OK(hipMalloc(&h->d_u, sizeof(double) * (size_t)h->n));
   }
+  h->has_yaux = false;
   if (vecchia_launch(h, gpb::MODE_FACTOR, cov_type, var, a, gauss_likelihood, nullptr, 0)) return -1;
   HIP_OK(hipStreamSynchronize(h->stream));
   h->has_factor = true;
@@ -584,6 +590,7 @@ static int yaux_enqueue(gpb_hip_vecchia_t* h) {
   if (!h->d_v) { HIP_OK(hipMalloc(&h->d_v, sizeof(double) * (size_t)h->n)); HIP_OK(hipMalloc(&h->d_w, sizeof(double) * (size_t)h->n)); }
   HIP_OK(gpb::launch_scale_by_Dinv(h->d_u, h->d_D, h->n, h->i_begin, h->i_end, h->d_v, h->stream));
   HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->i_begin, h->i_end, h->d_v, h->d_w, h->stream));
+  h->has_yaux = true;
   return 0;
 }
 
@@ -602,6 +609,47 @@ int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev) {
   if (!h || !w_dev) return fail("null argument");
   if (yaux_enqueue(h)) return -1;
   HIP_OK(hipMemcpyAsync(w_dev, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  API_END();
+}
+
+int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, const int32_t* leaf_index, int32_t num_leaves, double* leaf_values) {
+  API_BEGIN();
+  if (!h || !leaf_index || !leaf_values) return fail("null argument");
+  if (!h->has_factor || !h->has_yaux) return fail("gpb_hip_vecchia_newton_leaf_values needs the factor and y_aux of F - y (call gpb_hip_vecchia_factor and gpb_hip_vecchia_yaux first)");
+  if (h->i_begin != 0 || h->i_end != h->n) return fail("gpb_hip_vecchia_newton_leaf_values needs the whole factor on this device (shard is [%d,%d))", h->i_begin, h->i_end);
+  if (num_leaves < 1 || num_leaves > 64) return fail("gpb_hip_vecchia_newton_leaf_values: num_leaves = %d is outside the supported range 1..64", num_leaves);
+  const int n = h->n, L = num_leaves;
+  for (int i = 0; i < n; ++i)
+    if (leaf_index[i] < 0 || leaf_index[i] >= L) return fail("leaf index %d at position %d is outside [0, %d)", leaf_index[i], i, L);
+  HIP_OK(hipSetDevice(h->device));
+  const int LP = L <= 16 ? 16 : (L <= 32 ? 32 : 64), len = LP * LP + LP;
+  const size_t need = (size_t)gpb::leaf_num_workgroups(n) * len;
+  if (!h->d_leaf) HIP_OK(hipMalloc(&h->d_leaf, sizeof(int) * (size_t)n));
+  if (!h->d_leaf_out) HIP_OK(hipMalloc(&h->d_leaf_out, sizeof(double) * (64 * 64 + 64)));
+  if (h->leaf_part_cap < need) { dev_free(h->d_leaf_part); HIP_OK(hipMalloc(&h->d_leaf_part, sizeof(double) * need)); h->leaf_part_cap = need; }
+  HIP_OK(hipMemcpyAsync(h->d_leaf, leaf_index, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(gpb::launch_leaf_gram(LP, h->d_A, h->d_D, h->d_nn, h->d_w, h->d_leaf, n, h->m, h->d_leaf_part, h->d_leaf_out, h->stream));
+  std::vector<double> mr(len);
+  HIP_OK(hipMemcpyAsync(mr.data(), h->d_leaf_out, sizeof(double) * len, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  // L x L Cholesky solve on the host (HTPsiInvH.llt().solve(HTYAux), re_model_template.h:5057)
+  std::vector<double> G((size_t)L * L);
+  for (int i = 0; i < L; ++i) for (int j = 0; j < L; ++j) G[(size_t)i * L + j] = mr[(size_t)i * LP + j];
+  const double* rhs = mr.data() + (size_t)LP * LP;
+  for (int j = 0; j < L; ++j) {
+    double s = G[(size_t)j * L + j];
+    for (int k = 0; k < j; ++k) s -= G[(size_t)j * L + k] * G[(size_t)j * L + k];
+    if (!(s > 0.)) return fail("H^T Psi^-1 H is not positive definite (leaf %d holds no data point?)", j);
+    const double g = std::sqrt(s);
+    G[(size_t)j * L + j] = g;
+    for (int i = j + 1; i < L; ++i) {
+      double t = G[(size_t)i * L + j];
+      for (int k = 0; k < j; ++k) t -= G[(size_t)i * L + k] * G[(size_t)j * L + k];
+      G[(size_t)i * L + j] = t / g;
+    }
+  }
+  for (int i = 0; i < L; ++i) { double t = rhs[i]; for (int k = 0; k < i; ++k) t -= G[(size_t)i * L + k] * leaf_values[k]; leaf_values[i] = t / G[(size_t)i * L + i]; }
+  for (int i = L - 1; i >= 0; --i) { double t = leaf_values[i]; for (int k = i + 1; k < L; ++k) t -= G[(size_t)k * L + i] * leaf_values[k]; leaf_values[i] = t / G[(size_t)i * L + i]; }
   API_END();
 }
 
@@ -729,6 +777,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
+  dev_free(h->d_pool); dev_free(h->d_fix);
   delete h;
   API_END();
 }
@@ -745,7 +794,7 @@ int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const doub
 }
 
 static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
-                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg);
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target = nullptr);
 
 int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
                        double* hist_out, uint64_t* cnt_out) {
@@ -764,7 +813,7 @@ int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t n
 }
 
 static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
-                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg) {
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target) {
   {
   if (!h->has_grad) return fail("gradients have not been set (call gpb_hip_hist_set_gradients)");
   if (!data_indices) num_data = h->n;
@@ -795,7 +844,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks;
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
-  r.hist_out = h->d_hist; r.cnt_out = h->d_cnt; r.fpad = h->fpad; r.nchunks = nchunks; r.num_features = h->F;
+  r.hist_out = d_target ? d_target : h->d_hist; r.cnt_out = h->d_cnt; r.fpad = h->fpad; r.nchunks = nchunks; r.num_features = h->F;
   r.const_hess = const_hess; r.has_hess = h->has_hess ? 1 : 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ms_avg) { HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventRecord(e0, h->stream)); }
@@ -804,12 +853,88 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
     HIP_OK(gpb::launch_hist_reduce(r, h->stream));
   }
   if (ms_avg) HIP_OK(hipEventRecord(e1, h->stream));
-  if (hist_out) HIP_OK(hipMemcpyAsync(hist_out, h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  if (hist_out) HIP_OK(hipMemcpyAsync(hist_out, d_target ? d_target : h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
   if (cnt_out) HIP_OK(hipMemcpyAsync(cnt_out, h->d_cnt, sizeof(unsigned long long) * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   if (ms_avg) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); *ms_avg = ms / reps; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   }
   return 0;
+}
+
+// ---- resident leaf histograms: build into a slot, FixHistogram, parent - smaller (row a12) ------------------
+int gpb_hip_hist_pool_resize(gpb_hip_hist_t* h, int32_t num_slots) {
+  API_BEGIN();
+  if (!h || num_slots < 1) return fail("gpb_hip_hist_pool_resize: invalid arguments");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  dev_free(h->d_pool);
+  HIP_OK(hipMalloc(&h->d_pool, sizeof(double) * 2 * (size_t)h->total_bins * num_slots));
+  HIP_OK(hipMemset(h->d_pool, 0, sizeof(double) * 2 * (size_t)h->total_bins * num_slots));
+  h->nslots = num_slots;
+  API_END();
+}
+
+int gpb_hip_hist_set_fix_info(gpb_hip_hist_t* h, const int32_t* view_offset, const int32_t* num_bin, const int32_t* most_freq_bin) {
+  API_BEGIN();
+  if (!h || !view_offset || !num_bin || !most_freq_bin) return fail("null argument");
+  for (int f = 0; f < h->F; ++f) {
+    if (most_freq_bin[f] <= 0) continue;
+    if (num_bin[f] < 1 || view_offset[f] < 0 || view_offset[f] + num_bin[f] > h->total_bins || most_freq_bin[f] >= num_bin[f])
+      return fail("gpb_hip_hist_set_fix_info: feature %d: view [%d, %d) / most_freq_bin %d outside the histogram of %d bins", f,
+                  view_offset[f], view_offset[f] + num_bin[f], most_freq_bin[f], h->total_bins);
+  }
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->d_fix) HIP_OK(hipMalloc(&h->d_fix, sizeof(int) * 3 * (size_t)h->F));
+  HIP_OK(hipMemcpy(h->d_fix, view_offset, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->d_fix + h->F, num_bin, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->d_fix + 2 * (size_t)h->F, most_freq_bin, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
+  h->has_fix = true;
+  API_END();
+}
+
+static double* hist_slot(gpb_hip_hist_t* h, int slot) {
+  return (h->d_pool && slot >= 0 && slot < h->nslots) ? h->d_pool + 2 * (size_t)h->total_bins * slot : nullptr;
+}
+
+int gpb_hip_hist_build_slot(gpb_hip_hist_t* h, int32_t slot, const int32_t* data_indices, int32_t num_data, double const_hess) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  double* dst = hist_slot(h, slot);
+  if (!dst) return fail("gpb_hip_hist_build_slot: slot %d outside the pool of %d (call gpb_hip_hist_pool_resize)", slot, h->nslots);
+  if (hist_build_impl(h, data_indices, num_data, const_hess, nullptr, nullptr, 1, nullptr, dst)) return -1;
+  API_END();
+}
+
+int gpb_hip_hist_fix_slot(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  double* dst = hist_slot(h, slot);
+  if (!dst) return fail("gpb_hip_hist_fix_slot: slot %d outside the pool of %d", slot, h->nslots);
+  if (!h->has_fix) return fail("gpb_hip_hist_fix_slot: the feature views have not been set (call gpb_hip_hist_set_fix_info)");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(gpb::launch_hist_fix(dst, h->F, h->d_fix, h->d_fix + h->F, h->d_fix + 2 * (size_t)h->F, sum_gradient, sum_hessian, h->stream));
+  API_END();
+}
+
+int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent_slot, int32_t smaller_slot, int32_t out_slot) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  double *p = hist_slot(h, parent_slot), *sm = hist_slot(h, smaller_slot), *o = hist_slot(h, out_slot);
+  if (!p || !sm || !o) return fail("gpb_hip_hist_subtract_slots: slot outside the pool of %d", h->nslots);
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(gpb::launch_hist_subtract(p, sm, o, 2 * h->total_bins, h->stream));
+  API_END();
+}
+
+int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out) {
+  API_BEGIN();
+  if (!h || !hist_out) return fail("null argument");
+  double* src = hist_slot(h, slot);
+  if (!src) return fail("gpb_hip_hist_get_slot: slot %d outside the pool of %d", slot, h->nslots);
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpyAsync(hist_out, src, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
 }
 
 }  // extern "C"

@@ -30,6 +30,9 @@ struct HistReduceArgs {
 
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
+hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offset, const int* num_bin, const int* most_freq_bin,
+                           double sum_gradient, double sum_hessian, hipStream_t st);
+hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st);
 hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
 
 }  // namespace gpb

@@ -125,4 +125,36 @@ hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n
   return hipGetLastError();
 }
 
+// ---- row a12: Dataset::FixHistogram (src/LightGBM/io/dataset.cpp:1272-1290) and FeatureHistogram::Subtract
+// (src/LightGBM/treelearner/feature_histogram.hpp:79-83) on device-resident histograms -------------------------------
+// One lane per feature walks its bins in ascending order: the same subtraction order as the reference's loop, so the
+// reconstructed most-frequent-bin entry is bit-identical given the same histogram.
+__global__ void hist_fix_kernel(double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
+                                const int* __restrict__ num_bin, const int* __restrict__ most_freq_bin, double sum_gradient,
+                                double sum_hessian) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_features) return;
+  const int mfb = most_freq_bin[f];
+  if (mfb <= 0) return;
+  double* v = hist + (size_t)view_offset[f] * 2;
+  double g = sum_gradient, h = sum_hessian;
+  const int nb = num_bin[f];
+  for (int i = 0; i < nb; ++i) if (i != mfb) { g -= v[2 * i]; h -= v[2 * i + 1]; }
+  v[2 * mfb] = g; v[2 * mfb + 1] = h;
+}
+__global__ void hist_subtract_kernel(const double* __restrict__ parent, const double* __restrict__ smaller, double* __restrict__ out, int len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) out[i] = parent[i] - smaller[i];
+}
+hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offset, const int* num_bin, const int* most_freq_bin,
+                           double sum_gradient, double sum_hessian, hipStream_t st) {
+  hipLaunchKernelGGL(hist_fix_kernel, dim3((num_features + 63) / 64), dim3(64), 0, st, hist, num_features, view_offset, num_bin,
+                     most_freq_bin, sum_gradient, sum_hessian);
+  return hipGetLastError();
+}
+hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st) {
+  hipLaunchKernelGGL(hist_subtract_kernel, dim3((len + 255) / 256), dim3(256), 0, st, parent, smaller, out, len);
+  return hipGetLastError();
+}
+
 }  // namespace gpb

@@ -140,6 +140,13 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_yaux(self.h, _p(out)))
         return out
 
+    def newton_leaf_values(self, leaf_index, num_leaves):
+        """Needs factor(gauss=True) and yaux() for the current y = F - y; leaf_index in Vecchia order."""
+        leaf = np.ascontiguousarray(leaf_index, dtype=np.int32)
+        out = np.empty(int(num_leaves))
+        _shim_call(_lib().gpb_hip_vecchia_newton_leaf_values(self.h, _p(leaf, C.c_int), C.c_int(int(num_leaves)), _p(out)))
+        return out
+
     def laplace_set_labels(self, y01):
         y01 = np.ascontiguousarray(y01, dtype=np.int32)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_labels(self.h, _p(y01, C.c_int)))
@@ -277,6 +284,31 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_bench(self.h, _p(di, C.c_int32), C.c_int(nd), C.c_double(const_hess), C.c_int(reps),
                                              C.byref(ms)))
         return ms.value
+
+    # ---- resident leaf histograms (row a12) ----
+    def pool_resize(self, num_slots):
+        _shim_call(_lib().gpb_hip_hist_pool_resize(self.h, C.c_int(int(num_slots))))
+
+    def set_fix_info(self, view_offset, num_bin, most_freq_bin):
+        vo = np.ascontiguousarray(view_offset, dtype=np.int32); nb = np.ascontiguousarray(num_bin, dtype=np.int32)
+        mf = np.ascontiguousarray(most_freq_bin, dtype=np.int32)
+        _shim_call(_lib().gpb_hip_hist_set_fix_info(self.h, _p(vo, C.c_int), _p(nb, C.c_int), _p(mf, C.c_int)))
+
+    def build_slot(self, slot, data_indices=None, const_hess=1.0):
+        idx = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+        nd = self.n if idx is None else idx.size
+        _shim_call(_lib().gpb_hip_hist_build_slot(self.h, C.c_int(int(slot)), _p(idx, C.c_int), C.c_int(nd), C.c_double(const_hess)))
+
+    def fix_slot(self, slot, sum_gradient, sum_hessian):
+        _shim_call(_lib().gpb_hip_hist_fix_slot(self.h, C.c_int(int(slot)), C.c_double(sum_gradient), C.c_double(sum_hessian)))
+
+    def subtract_slots(self, parent, smaller, out):
+        _shim_call(_lib().gpb_hip_hist_subtract_slots(self.h, C.c_int(int(parent)), C.c_int(int(smaller)), C.c_int(int(out))))
+
+    def get_slot(self, slot):
+        out = np.empty((self.total_bins, 2))
+        _shim_call(_lib().gpb_hip_hist_get_slot(self.h, C.c_int(int(slot)), _p(out)))
+        return out
 
     def build(self, data_indices=None, const_hess=1.0):
         """-> (hist[total_bins, 2] = {grad sum, hess sum}, cnt[total_bins] uint64)"""

@@ -142,6 +142,16 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host)
  * is y_aux.  Requires gpb_hip_vecchia_factor() on the same shard. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev);
 
+/* Newton update of the tree leaf values in the GPBoost algorithm: replaces
+ * REModelTemplate::NewtonUpdateLeafValues, Vecchia branch (include/GPBoost/re_model_template.h:4982-5063; B H and
+ * (B H)^T D^-1 (B H) at :5005-5008, the L x L solve at :5056-5062).
+ *   leaf_index   leaf of every point, VECCHIA order, values in [0, num_leaves), num_leaves <= 64
+ *   leaf_values  out: (H^T Psi^-1 H)^-1 (- H^T y_aux)
+ * Precondition (as in the reference, :4989): gpb_hip_vecchia_factor(gauss_likelihood = 1) and gpb_hip_vecchia_yaux have run for
+ * the current y = F - y (the objective's gradient call, regression_objective.hpp:153-201, does exactly that). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, const int32_t* leaf_index, int32_t num_leaves,
+                                                      double* leaf_values);
+
 /* ------------------------------------------------------------------------------------
  * Vecchia-Laplace approximation, Bernoulli-logit likelihood, iterative methods ("vadu" preconditioner) --
  * BASELINE config 4 / SURVEY.md 8 row a13.  Replaces, for one evaluation of the approximate marginal likelihood,
@@ -205,6 +215,26 @@ GPB_HIP_EXPORT int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_ind
  * mean duration from HIP events on the handle's stream. */
 GPB_HIP_EXPORT int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
                                       int reps, double* ms_avg);
+
+/* Resident leaf histograms (the role of HistogramPool, src/LightGBM/treelearner/feature_histogram.hpp:1086-1330) and the two
+ * per-leaf post-processing steps of SerialTreeLearner::FindBestSplitsFromHistograms (serial_tree_learner.cpp:375-449) -- SURVEY.md 8
+ * row a12:
+ *   pool_resize     num_slots histograms of 2 * total_bins doubles in HBM
+ *   set_fix_info    per feature: first bin of its view of the histogram (FeatureHistogram::data_, train_share_states.cpp:296-300),
+ *                   BinMapper::num_bin(), BinMapper::GetMostFreqBin() (<= 0: nothing to fix)
+ *   build_slot      gpb_hip_hist_build into a slot, no copy to the host
+ *   fix_slot        Dataset::FixHistogram for every feature (src/LightGBM/io/dataset.cpp:1272-1290): view[mfb] = leaf sum -
+ *                   sum of the other bins, subtracted in ascending bin order as the reference does (bit-identical given the histogram)
+ *   subtract_slots  out = parent - smaller, FeatureHistogram::Subtract (feature_histogram.hpp:79-83); out may be parent
+ *   get_slot        copy one slot to the host, (grad, hess) pairs */
+GPB_HIP_EXPORT int gpb_hip_hist_pool_resize(gpb_hip_hist_t* h, int32_t num_slots);
+GPB_HIP_EXPORT int gpb_hip_hist_set_fix_info(gpb_hip_hist_t* h, const int32_t* view_offset, const int32_t* num_bin,
+                                             const int32_t* most_freq_bin);
+GPB_HIP_EXPORT int gpb_hip_hist_build_slot(gpb_hip_hist_t* h, int32_t slot, const int32_t* data_indices, int32_t num_data,
+                                           double const_hess);
+GPB_HIP_EXPORT int gpb_hip_hist_fix_slot(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian);
+GPB_HIP_EXPORT int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent_slot, int32_t smaller_slot, int32_t out_slot);
+GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out);
 
 #ifdef __cplusplus
 }

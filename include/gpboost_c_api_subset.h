@@ -133,6 +133,12 @@ GPBOOST_C_EXPORT int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, c
     double* cov_pars, const double* fixed_effects, double* negll, double* grad3);
 /* y_aux = Psi^-1 y in data order at cov_pars (CalcGradientF / GetYAux, re_model_template.h:3298-3321,6430) */
 GPBOOST_C_EXPORT int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_pars, double* y_aux);
+/* Newton update of the leaf values (REModel::NewtonUpdateLeafValues, re_model.cpp:1298-1310 ->
+ * re_model_template.h:4982-5063; the reference calls it from the objective, it has no C entry point of its own):
+ * y_data = F - y in data order (what the objective hands to CalcGradientF), data_leaf_index = leaf of every data point;
+ * factor + y_aux + H^T Psi^-1 H + solve in one call. */
+GPBOOST_C_EXPORT int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, double* cov_pars,
+    const int32_t* data_leaf_index, int32_t num_leaves, double* leaf_values);
 /* Vecchia ordering (perm[k] = data index of the k-th point) and neighbour table (n x m, -1 padded) */
 GPBOOST_C_EXPORT int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out);
 /* Diagnostics of the last Laplace evaluation (likelihood != "gaussian"): the nine values documented at

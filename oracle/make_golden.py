@@ -37,6 +37,9 @@ def main():
             res["pars_trans_%d" % k] = pt
             res["D_%d" % k] = D
             res["yaux_%d" % k] = ya
+            if k == 0 and name in cases.LEAF_CASES:      # NewtonUpdateLeafValues at the first parameter set, y = "F - y"
+                leaf, L = cases.make_leaf_index(name, mdl.n)
+                res["leaf_values_0"] = mdl.newton_leaf_values(leaf, L, cp[0])
             if mdl.n <= 500:
                 res["A_%d" % k] = A
             else:   # keep fixtures small: a strided sample of rows
@@ -66,15 +69,21 @@ def hist_fixture(out_dir):
     res = {}
     for li, di in enumerate((None, leaf)):
         for hi, hs in enumerate((None, h)):
-            bins, gnb, hist = refdrv.ref_histogram(X, cases.HIST_CASE["max_bin"], di, g, hs, 1.0)
+            bins, gnb, hist, fx = refdrv.ref_histogram(X, cases.HIST_CASE["max_bin"], di, g, hs, 1.0, with_fix=True)
             res["bins"] = bins; res["group_num_bin"] = gnb
             res["hist_leaf%d_hess%d" % (li, hi)] = hist
+            # Dataset::FixHistogram on every feature (row a12): inputs of the call + result
+            res["fix_view_offset"] = fx["view_offset"]; res["fix_num_bin"] = fx["num_bin"]; res["fix_most_freq_bin"] = fx["most_freq_bin"]
+            res["fix_sums_leaf%d_hess%d" % (li, hi)] = fx["sums"]
+            res["hist_fixed_leaf%d_hess%d" % (li, hi)] = fx["hist_fixed"]
     np.savez_compressed(os.path.join(out_dir, "hist_ref.npz"), **res)
-    print("wrote hist_ref: groups", len(res["group_num_bin"]), "bins", res["group_num_bin"])
+    print("wrote hist_ref: groups", len(res["group_num_bin"]), "bins", res["group_num_bin"], "most_freq_bin", res["fix_most_freq_bin"])
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "hist":
+        hist_fixture(os.path.join(ROOT, "tests", "golden"))
     else:
         main()

@@ -163,6 +163,39 @@ def hist_build(bins, bin_offsets, data_indices, grad, hess=None, const_hess=1.0)
     return hg, hc, hh
 
 
+def hist_fix(hist, view_offset, num_bin, most_freq_bin, sum_gradient, sum_hessian):
+    """Dataset::FixHistogram for every feature; hist (total_bins, 2), returns a fixed copy."""
+    out = np.ascontiguousarray(hist, dtype=np.float64).copy()
+    vo = np.ascontiguousarray(view_offset, dtype=np.int32); nb = np.ascontiguousarray(num_bin, dtype=np.int32)
+    mf = np.ascontiguousarray(most_freq_bin, dtype=np.int32)
+    lib().orc_hist_fix(_p(out, C.c_double), C.c_int(vo.size), _p(vo, C.c_int), _p(nb, C.c_int), _p(mf, C.c_int),
+                       C.c_double(sum_gradient), C.c_double(sum_hessian))
+    return out
+
+
+def hist_subtract(parent, smaller):
+    """FeatureHistogram::Subtract: larger = parent - smaller, entry by entry."""
+    out = np.ascontiguousarray(parent, dtype=np.float64).copy()
+    sm = np.ascontiguousarray(smaller, dtype=np.float64)
+    lib().orc_hist_subtract(_p(out, C.c_double), _p(sm, C.c_double), C.c_int(out.shape[0]))
+    return out
+
+
+def newton_leaf_values(A, D, nn, yaux, leaf, num_leaves):
+    """REModelTemplate::NewtonUpdateLeafValues, Vecchia branch: leaf values of the Newton step.  A, D from
+    vecchia_factor(gauss=True); yaux = B^T D^-1 B (F - y); leaf = leaf index per point; all in Vecchia order."""
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, m = nn.shape
+    A = np.ascontiguousarray(A, dtype=np.float64); D = np.ascontiguousarray(D, dtype=np.float64)
+    ya = np.ascontiguousarray(yaux, dtype=np.float64); lf = np.ascontiguousarray(leaf, dtype=np.int32)
+    out = np.zeros(num_leaves)
+    rc = lib().orc_newton_leaf_values(_p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+                                      _p(ya, C.c_double), _p(lf, C.c_int), C.c_int(num_leaves), _p(out, C.c_double))
+    if rc != 0:
+        raise RuntimeError("H^T Psi^-1 H is not positive definite")
+    return out
+
+
 def gen_rand_normal(n, t, seed=1, run_id=0):
     """GenRandVecNormalParallel (CG_utils.cpp:978-994): (n, t) Fortran-ordered N(0,1) probes."""
     out = np.empty((n, t), order="F")

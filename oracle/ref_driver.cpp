@@ -116,6 +116,23 @@ int refdrv_get_factor(void* h, int m, double* A, double* Dinv, double* yaux) {
   }
 }
 
+/* after refdrv_nll_grad (factor at the given parameters, y = F - y set): the reference's own
+ * REModelTemplate::NewtonUpdateLeafValues (include/GPBoost/re_model_template.h:4982-5063, Vecchia branch :5002-5008),
+ * preceded by CalcYAux exactly as CalcGradientF does it (:3313-3316).  leaf index per DATA point. */
+__attribute__((visibility("default")))
+int refdrv_newton_leaf(void* h, const int* data_leaf_index, int num_leaves, double marg_variance, double* leaf_values) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    t->CalcYAux(marg_variance, false);
+    t->y_aux_has_been_calculated_ = true;
+    t->NewtonUpdateLeafValues(data_leaf_index, num_leaves, leaf_values, marg_variance);
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_newton_leaf: %s\n", e.what());
+    return -1;
+  }
+}
+
 /* Histogram of one leaf built by the reference itself: LGBM_DatasetCreateFromMat (the reference's own binning, no
  * feature bundling, col-wise) followed by Dataset::ConstructHistograms (include/LightGBM/dataset.h:471-500 ->
  * src/LightGBM/io/dataset.cpp:1143-1245).  Returns the reference's STORED group bins (what DenseBin holds, bin 0 =
@@ -123,7 +140,8 @@ int refdrv_get_factor(void* h, int m, double* A, double* Dinv, double* yaux) {
 __attribute__((visibility("default")))
 int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* data_indices, int num_data,
                 const double* grad, const double* hess, double const_hess, int* num_groups_out, int* group_num_bin,
-                unsigned char* bins_out, double* hist_out) {
+                unsigned char* bins_out, double* hist_out, int* feat_view_offset, int* feat_num_bin, int* feat_most_freq_bin,
+                double* sums2, double* hist_fixed_out) {
   try {
     using namespace LightGBM;
     char params[256];
@@ -149,6 +167,23 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
     std::vector<hist_t> hist((size_t)ds->NumTotalBin() * 2 + 16, 0.);
     ds->ConstructHistograms(used, data_indices, num_data, g_all.data(), h_all.data(), og.data(), oh.data(), share.get(), hist.data());
     std::copy(hist.begin(), hist.begin() + (size_t)ds->NumTotalBin() * 2, hist_out);
+    /* Dataset::FixHistogram (src/LightGBM/io/dataset.cpp:1272-1290) on every feature, called the way
+     * SerialTreeLearner::FindBestSplitsFromHistograms does (serial_tree_learner.cpp:400-403): data = the feature's view of the
+     * leaf histogram (one bin past the start of its group: the group's bin 0 is the most-frequent-bin placeholder), sums = the
+     * leaf's gradient / hessian totals */
+    if (hist_fixed_out) {
+      double sg = 0., sh = 0.;
+      for (int k = 0; k < num_data; ++k) { const int i = data_indices ? data_indices[k] : k; sg += g_all[i]; sh += h_all[i]; }
+      sums2[0] = sg; sums2[1] = sh;
+      for (int f = 0; f < ds->num_features(); ++f) {
+        const int g = ds->feature2group_[f];
+        const BinMapper* bm = ds->FeatureBinMapper(f);
+        const int off = (int)ds->group_bin_boundaries_[g] + 1;   /* FeatureHistogram::data_ (train_share_states.cpp:296-300, feature_group.h bin_offsets_[0] = 1) */
+        feat_view_offset[f] = off; feat_num_bin[f] = bm->num_bin(); feat_most_freq_bin[f] = (int)bm->GetMostFreqBin();
+        ds->FixHistogram(f, sg, sh, hist.data() + (size_t)off * 2);
+      }
+      std::copy(hist.begin(), hist.begin() + (size_t)ds->NumTotalBin() * 2, hist_fixed_out);
+    }
     LGBM_DatasetFree(dh);
     return 0;
   } catch (std::exception& e) {

@@ -75,6 +75,15 @@ class RefModel(object):
             raise RuntimeError("refdrv_get_factor failed")
         return A, 1. / Di, ya
 
+    def newton_leaf_values(self, data_leaf_index, num_leaves, marg_variance):
+        """The reference's NewtonUpdateLeafValues for the state of the last nll_grad call (y passed there = F - y)."""
+        lf = np.ascontiguousarray(data_leaf_index, dtype=np.int32)
+        out = np.empty(num_leaves)
+        rc = _lib().refdrv_newton_leaf(self.h, _P(lf), C.c_int(num_leaves), C.c_double(marg_variance), _P(out))
+        if rc != 0:
+            raise RuntimeError("refdrv_newton_leaf failed")
+        return out
+
 
 # ---------------------------------------------------------------------------------------------
 # The reference's own public C API (lib_gpboost_ref.so), bound the way python-package/gpboost/basic.py:5206-5240
@@ -114,9 +123,11 @@ class RefCAPIModel(object):
             pass
 
 
-def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0):
+def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False):
     """The reference's own binning + Dataset::ConstructHistograms for one leaf.
-    Returns (bins uint8 (G, n) = the reference's stored group bins, group_num_bin (G,), hist (sum bins, 2))."""
+    Returns (bins uint8 (G, n) = the reference's stored group bins, group_num_bin (G,), hist (sum bins, 2)); with_fix=True adds
+    a dict with the per-feature view offsets / num_bin / most_freq_bin, the leaf sums and the histogram after
+    Dataset::FixHistogram on every feature."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     n, F = X.shape
     di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
@@ -127,10 +138,16 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0):
     gnb = np.zeros(F, dtype=np.int32)
     bins = np.zeros((F, n), dtype=np.uint8)
     hist = np.zeros((F * (max_bin + 2), 2))
+    voff = np.zeros(F, dtype=np.int32); nbin = np.zeros(F, dtype=np.int32); mfb = np.zeros(F, dtype=np.int32)
+    sums = np.zeros(2); hfix = np.zeros((F * (max_bin + 2), 2))
     rc = _lib().refdrv_hist(C.c_int(n), C.c_int(F), _P(X), C.c_int(max_bin), None if di is None else _P(di), C.c_int(nd), _P(g),
-                            None if h is None else _P(h), C.c_double(const_hess), C.byref(ng), _P(gnb), _P(bins), _P(hist))
+                            None if h is None else _P(h), C.c_double(const_hess), C.byref(ng), _P(gnb), _P(bins), _P(hist),
+                            _P(voff), _P(nbin), _P(mfb), _P(sums), _P(hfix) if with_fix else None)
     if rc != 0:
         raise RuntimeError("refdrv_hist failed")
     G = ng.value
     tot = int(gnb[:G].sum())
+    if with_fix:
+        return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy(), dict(view_offset=voff, num_bin=nbin, most_freq_bin=mfb,
+                                                                       sums=sums, hist_fixed=hfix[:tot].copy())
     return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy()

@@ -83,6 +83,21 @@ def synthetic_binary(n, d, seed=1):
     return make_binary_data(dict(n=n, d=d, seed_data=seed))
 
 
+# Newton leaf update (row a9): leaf assignment per DATA point for the golden cases that carry a "leaf_values_*" entry
+LEAF_CASES = {"r_exp_m30_none": 7, "u2d_n3000_exp_m30": 31, "u1d_n1000_mat15_m10": 16}   # case -> number of leaves
+
+
+def make_leaf_index(name, n):
+    """Half of the points get a spatially coherent leaf (as a tree split would), half a random one."""
+    L = LEAF_CASES[name]
+    rng = np.random.default_rng(1000 + L)
+    coords, _ = make_data(GOLDEN_CASES[name])
+    leaf = (np.floor(coords[:, 0] * L).astype(np.int64) % L)
+    rnd = rng.uniform(size=n) < 0.5
+    leaf[rnd] = rng.integers(0, L, size=int(rnd.sum()))
+    return leaf.astype(np.int32), L
+
+
 def synthetic(n, d, seed=1):
     """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
     rng = np.random.default_rng(seed)
@@ -101,6 +116,8 @@ def make_hist_data(c=HIST_CASE):
     X = rng.uniform(size=(n, F))
     X[:, 2] = np.round(X[:, 2] * 10) / 10                             # 11 distinct values
     X[:, 4] = (rng.uniform(size=n) < 0.7) * rng.uniform(size=n)        # 30 % exact zeros (most-frequent bin)
+    X[:, 1] = 2.0 * X[:, 1] - 1.0                                     # zero (default) bin in the middle: most_freq_bin > 0
+    X[:, 3] = np.where(rng.uniform(size=n) < 0.8, 0.3, X[:, 3])       # 80 % one non-zero value: most_freq_bin > 0, dominant
     g = rng.standard_normal(n)
     h = rng.uniform(0.5, 2, size=n)
     leaf = np.sort(rng.choice(n, size=c["leaf_size"], replace=False)).astype(np.int32)

@@ -78,3 +78,44 @@ def test_histogram_against_reference_fixture(lib_built):
                 assert np.array_equal(cnt.astype(np.float64), ref[:, 1])
             else:
                 np.testing.assert_allclose(hist[:, 1], ref[:, 1], rtol=0, atol=1e-10 * (np.abs(ref[:, 1]).max() + 1))
+
+
+def test_fix_histogram_and_subtraction_against_reference_fixture(lib_built, orc):
+    """Row a12 on device-resident histograms: Dataset::FixHistogram for every feature (two of the six features have a most
+    frequent bin > 0) and FeatureHistogram::Subtract, against the reference's own output (tests/golden/hist_ref.npz)."""
+    import os
+    import gpboost_amd
+    from gpboost_amd import shim
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hist_ref.npz"))
+    X, grad, hess, leaf = cases.make_hist_data()
+    bins, gnb = g["bins"], g["group_num_bin"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    with pytest.raises(gpboost_amd.GPBoostError):
+        hb.build_slot(0, None)                       # no pool yet
+    hb.pool_resize(3)
+    hb.set_gradients(grad, hess)
+    with pytest.raises(gpboost_amd.GPBoostError):
+        hb.fix_slot(0, 0.0, 0.0)                     # feature views not set
+    hb.set_fix_info(g["fix_view_offset"], g["fix_num_bin"], g["fix_most_freq_bin"])
+    for slot, (li, di) in enumerate(((0, None), (1, leaf))):
+        key = "leaf%d_hess1" % li
+        hb.build_slot(slot, di)
+        raw = hb.get_slot(slot)
+        sums = g["fix_sums_" + key]
+        hb.fix_slot(slot, sums[0], sums[1])
+        fixed = hb.get_slot(slot)
+        # bit-identical to the reference's FixHistogram applied to THIS histogram (same subtraction order) ...
+        assert np.array_equal(fixed, orc.hist_fix(raw, g["fix_view_offset"], g["fix_num_bin"], g["fix_most_freq_bin"], sums[0], sums[1]))
+        # ... and equal to the reference's fixed histogram up to the summation order of the build (fp64 atomics)
+        ref = g["hist_fixed_" + key]
+        np.testing.assert_allclose(fixed, ref, rtol=0, atol=1e-9 * (np.abs(ref).max() + 1))
+        assert not np.array_equal(fixed, raw)
+    hb.subtract_slots(0, 1, 2)                       # larger = parent - smaller
+    assert np.array_equal(hb.get_slot(2), hb.get_slot(0) - hb.get_slot(1))
+    hb.subtract_slots(0, 1, 0)                       # in place, as FeatureHistogram::Subtract does
+    assert np.array_equal(hb.get_slot(0), hb.get_slot(2))
+    with pytest.raises(gpboost_amd.GPBoostError):
+        hb.get_slot(3)
+    hb.close()

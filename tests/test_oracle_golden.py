@@ -153,3 +153,37 @@ def test_r_golden_logit_mode_finding(orc):
     # defaults (cg_delta_conv = 1e-2): the mode is only that sharp, the value moves in the 5th decimal
     negll_d, info_d = orc.vecchia_laplace_logit(co, nn, 0, 0.9, 1.0 / 0.2, y)
     assert abs(-(info_d["mll_no_det"] - 0.5 * logdet) - 66.299571) < 1e-3
+
+
+# ---- Newton update of the leaf values (row a9) ---------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.LEAF_CASES))
+def test_oracle_newton_leaf_values_match_reference(orc, name):
+    """orc_newton_leaf_values against the reference's own REModelTemplate::NewtonUpdateLeafValues (Vecchia branch)."""
+    c = cases.GOLDEN_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    coords, y = cases.make_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    pt = orc.transform_cov_pars(ct, np.asarray(c["cov_pars"][0], dtype=np.float64))
+    A, D, bad = orc.vecchia_factor(co, nn, ct, pt[1], pt[2])
+    yaux = orc.vecchia_yaux(A, D, nn, y[perm])
+    leaf, L = cases.make_leaf_index(name, len(y))
+    vals = orc.newton_leaf_values(A, D, nn, yaux, leaf[perm], L)
+    np.testing.assert_allclose(vals, g["leaf_values_0"], rtol=1e-9, atol=1e-11)
+
+
+# ---- FixHistogram / histogram subtraction (row a12) -------------------------------------------------------------
+def test_oracle_fix_histogram_matches_reference_fixture(orc):
+    """orc_hist_fix against the reference's own Dataset::FixHistogram on its own histograms (bit-identical: same subtraction
+    order), for features whose most frequent bin is > 0 (two of the six in the fixture); subtraction is exact by construction."""
+    g = np.load(os.path.join(GOLD, "hist_ref.npz"))
+    assert (g["fix_most_freq_bin"] > 0).sum() >= 2
+    for li in (0, 1):
+        for hi in (0, 1):
+            key = "leaf%d_hess%d" % (li, hi)
+            sums = g["fix_sums_" + key]
+            fixed = orc.hist_fix(g["hist_" + key], g["fix_view_offset"], g["fix_num_bin"], g["fix_most_freq_bin"], sums[0], sums[1])
+            assert np.array_equal(fixed, g["hist_fixed_" + key])
+            assert not np.array_equal(fixed, g["hist_" + key])
+    parent, small = g["hist_fixed_leaf0_hess1"], g["hist_fixed_leaf1_hess1"]
+    assert np.array_equal(orc.hist_subtract(parent, small), parent - small)

@@ -362,3 +362,45 @@ def test_in_library_rccl_allreduce_single_rank(gpb, orc):
     assert np.array_equal(st.grad_terms_allreduce(0, 10.0, 10.0), st.grad_terms(0, 10.0, 10.0))
     with pytest.raises(gpb.GPBoostError):
         shim.VecchiaState(co, 30).nll_terms_allreduce(0, 10.0, 10.0)      # no neighbours / no communicator
+
+
+# ---- Newton update of the leaf values (row a9) ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.LEAF_CASES))
+def test_newton_leaf_values_against_reference_fixture(gpb, name):
+    """GPB_HIP_NewtonUpdateLeafValues (factor + y_aux + H^T Psi^-1 H on the device, L x L solve on the host) against the
+    reference's own REModelTemplate::NewtonUpdateLeafValues (tests/golden, oracle/ref_driver.cpp:refdrv_newton_leaf)."""
+    c = cases.GOLDEN_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    coords, y = cases.make_data(c)
+    leaf, L = cases.make_leaf_index(name, len(y))
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    vals = mdl.newton_update_leaf_values(np.asarray(c["cov_pars"][0], dtype=np.float64), y, leaf, L)
+    np.testing.assert_allclose(vals, g["leaf_values_0"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,m,L", [(20000, 30, 31), (5000, 20, 64), (3000, 10, 3)])
+def test_newton_leaf_values_against_oracle(gpb, orc, n, m, L):
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(n, 2, seed=7 + L)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 2)
+    rng = np.random.default_rng(L)
+    leaf = rng.integers(0, L, size=n).astype(np.int32)
+    var, a = 8.0, 1.0 / 0.07
+    st = shim.VecchiaState(co, m)
+    st.set_neighbors(nn)
+    st.set_y(y[perm])
+    with pytest.raises(gpb.GPBoostError):
+        st.newton_leaf_values(leaf, L)               # factor / y_aux missing
+    st.factor(0, var, a)
+    ya = st.yaux()
+    vals = st.newton_leaf_values(leaf, L)
+    A, D, bad = orc.vecchia_factor(co, nn, 0, var, a)
+    ref = orc.newton_leaf_values(A, D, nn, orc.vecchia_yaux(A, D, nn, y[perm]), leaf, L)
+    np.testing.assert_allclose(vals, ref, rtol=1e-8, atol=1e-10)
+    assert np.array_equal(vals, st.newton_leaf_values(leaf, L))          # reproducible
+    with pytest.raises(gpb.GPBoostError):
+        st.newton_leaf_values(leaf, 65)
+    with pytest.raises(gpb.GPBoostError):
+        st.newton_leaf_values(leaf + 1, L)           # an index == L
+    st.close()
