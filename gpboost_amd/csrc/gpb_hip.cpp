@@ -90,7 +90,7 @@ struct gpb_hip_vecchia {
   double* d_ystage = nullptr;
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
-  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false;
+  bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false, nn_partial = false;
   int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   ncclComm_t comm = nullptr;      // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init)
@@ -122,6 +122,7 @@ struct gpb_hip_hist {
   int* d_idx = nullptr; int idx_cap = 0;
   double* d_part_grad = nullptr; double* d_part_hess = nullptr; uint32_t* d_part_cnt = nullptr; int part_chunks = 0;
   double* d_hist = nullptr; unsigned long long* d_cnt = nullptr;
+  ncclComm_t comm = nullptr;                               // optional: data-parallel histogram all-reduce (rows sharded per rank)
   double* d_pool = nullptr; int nslots = 0;                 // resident leaf histograms (HistogramPool), 2 * total_bins doubles each
   int* d_fix = nullptr; bool has_fix = false;              // view_offset[F], num_bin[F], most_freq_bin[F]
 };
@@ -275,9 +276,9 @@ int gpb_hip_vecchia_sync(gpb_hip_vecchia_t* h) {
   API_END();
 }
 
-int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
-  API_BEGIN();
-  if (!h) return fail("null handle");
+// Neighbour search for the positions (coordinate-sum order) [pos0, pos1); rows of other queries are left at INT_MIN when the
+// range is not the whole table (multi-GPU: one block of positions per rank, merged by a max-all-reduce -- a valid entry is >= -1).
+static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* has_duplicates) {
   HIP_OK(hipSetDevice(h->device));
   const int n = h->n, d = h->d, m = h->m;
   // coordinate sums and their argsort, on the host exactly as Vecchia_utils.cpp:774-786 does
@@ -307,6 +308,10 @@ int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
   HIP_OK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
   gpb::NNKernelArgs a;
   a.sorted_rec = d_rec; a.sorted_idx = d_idx; a.pts = h->d_pts; a.nn = h->d_nn; a.has_duplicates = h->d_flag; a.n = n; a.m = m;
+  // positions are in coordinate-sum order, i.e. random with respect to the index that decides a query's cost: equal blocks of
+  // positions are balanced (SURVEY.md 8e suggested cyclic assignment for index-ordered blocks; not needed here)
+  a.pos0 = (int)((long long)n * part / nparts); a.pos1 = (int)((long long)n * (part + 1) / nparts);
+  if (nparts > 1) HIP_OK(hipMemsetAsync(h->d_nn, 0x80, sizeof(int) * (size_t)n * m, h->stream));     // 0x80808080 < -1: "not mine"
   if (n == 1) {
     HIP_OK(hipMemsetAsync(h->d_nn, 0xff, sizeof(int) * (size_t)n * m, h->stream));
   } else {
@@ -317,7 +322,23 @@ int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
   HIP_OK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_rec); (void)hipFree(d_idx);
   if (has_duplicates) *has_duplicates = flag;
-  h->has_nn = true; h->has_transpose = false; h->has_levels = false; h->has_factor = false; h->nn_host.clear();
+  h->has_nn = nparts == 1; h->nn_partial = nparts > 1;
+  h->has_transpose = false; h->has_levels = false; h->has_factor = false; h->nn_host.clear();
+  return 0;
+}
+
+int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (find_neighbors_impl(h, 0, 1, has_duplicates)) return -1;
+  API_END();
+}
+
+int gpb_hip_vecchia_find_neighbors_part(gpb_hip_vecchia_t* h, int32_t part, int32_t nparts, int* has_duplicates) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (nparts < 1 || part < 0 || part >= nparts) return fail("gpb_hip_vecchia_find_neighbors_part: part %d of %d", part, nparts);
+  if (find_neighbors_impl(h, part, nparts, has_duplicates)) return -1;
   API_END();
 }
 
@@ -340,7 +361,7 @@ int gpb_hip_vecchia_set_neighbors(gpb_hip_vecchia_t* h, const int32_t* nn) {
 int gpb_hip_vecchia_get_neighbors(gpb_hip_vecchia_t* h, int32_t* nn) {
   API_BEGIN();
   if (!h || !nn) return fail("null argument");
-  if (!h->has_nn) return fail("neighbours have not been determined");
+  if (!h->has_nn && !h->nn_partial) return fail("neighbours have not been determined");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipMemcpyAsync(nn, h->d_nn, sizeof(int) * (size_t)h->n * h->m, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -472,6 +493,37 @@ static int vecchia_allreduce_terms(gpb_hip_vecchia_t* h, int mode, int cov_type,
   HIP_OK(hipStreamSynchronize(h->stream));
   for (int t = 0; t < nout; ++t) out_host[t] = h->h_out[t];
   return 0;
+}
+
+static int yaux_enqueue(gpb_hip_vecchia_t* h);
+// multi-GPU neighbour search: every rank searched its block of positions (gpb_hip_vecchia_find_neighbors_part(rank, world));
+// the table is completed by one max-all-reduce (rows a rank did not search hold a value < -1), the duplicates flag by another
+int gpb_hip_vecchia_neighbors_allreduce(gpb_hip_vecchia_t* h, int* has_duplicates) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("no communicator: call gpb_hip_vecchia_comm_init first");
+  if (!h->nn_partial && !h->has_nn) return fail("no neighbour search has run on this handle");
+  HIP_OK(hipSetDevice(h->device));
+  NCCL_OK(ncclAllReduce(h->d_nn, h->d_nn, (size_t)h->n * h->m, ncclInt32, ncclMax, h->comm, h->stream));
+  NCCL_OK(ncclAllReduce(h->d_flag, h->d_flag, 1, ncclInt32, ncclMax, h->comm, h->stream));
+  int flag = 0;
+  HIP_OK(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (has_duplicates) *has_duplicates = flag;
+  h->has_nn = true; h->nn_partial = false;
+  API_END();
+}
+
+// multi-GPU y_aux: this shard's contribution, summed over the ranks in place (one all-reduce of n doubles), to the host
+int gpb_hip_vecchia_yaux_allreduce(gpb_hip_vecchia_t* h, double* yaux_host) {
+  API_BEGIN();
+  if (!h || !yaux_host) return fail("null argument");
+  if (!h->comm) return fail("no communicator: call gpb_hip_vecchia_comm_init first");
+  if (yaux_enqueue(h)) return -1;
+  NCCL_OK(ncclAllReduce(h->d_w, h->d_w, (size_t)h->n, ncclDouble, ncclSum, h->comm, h->stream));
+  HIP_OK(hipMemcpyAsync(yaux_host, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
 }
 
 int gpb_hip_vecchia_nll_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int gauss_likelihood,
@@ -778,6 +830,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
   dev_free(h->d_pool); dev_free(h->d_fix);
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   delete h;
   API_END();
 }
@@ -859,6 +912,35 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   if (ms_avg) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); *ms_avg = ms / reps; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   }
   return 0;
+}
+
+// ---- data-parallel histograms (mirrors DataParallelTreeLearner, data_parallel_tree_learner.cpp:155-173): every
+// rank holds a shard of the rows and builds the leaf histogram of ITS rows; one all-reduce of total_bins (grad, hess) pairs
+// (+ the integer counts) completes it.  Counts and count * hess sum exactly; fp64 gradient sums are order-dependent as always.
+int gpb_hip_hist_comm_init(gpb_hip_hist_t* h, const unsigned char* id128, int rank, int world) {
+  API_BEGIN();
+  if (!h || !id128) return fail("null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail("gpb_hip_hist_comm_init: rank %d / world %d", rank, world);
+  HIP_OK(hipSetDevice(h->device));
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  NCCL_OK(ncclCommInitRank(&h->comm, world, id, rank));
+  API_END();
+}
+
+int gpb_hip_hist_build_allreduce(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess, double* hist_out,
+                                 uint64_t* cnt_out) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (!h->comm) return fail("no communicator: call gpb_hip_hist_comm_init first");
+  if (hist_build_impl(h, data_indices, num_data, const_hess, nullptr, nullptr, 1, nullptr)) return -1;
+  NCCL_OK(ncclAllReduce(h->d_hist, h->d_hist, 2 * (size_t)h->total_bins, ncclDouble, ncclSum, h->comm, h->stream));
+  NCCL_OK(ncclAllReduce(h->d_cnt, h->d_cnt, (size_t)h->total_bins, ncclUint64, ncclSum, h->comm, h->stream));
+  if (hist_out) HIP_OK(hipMemcpyAsync(hist_out, h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  if (cnt_out) HIP_OK(hipMemcpyAsync(cnt_out, h->d_cnt, sizeof(unsigned long long) * (size_t)h->total_bins, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
 }
 
 // ---- resident leaf histograms: build into a slot, FixHistogram, parent - smaller (row a12) ------------------

@@ -11,6 +11,7 @@ struct NNKernelArgs {
   int* nn;                    // [n][m] out
   int* has_duplicates;        // out flag (atomicOr)
   int n, m;
+  int pos0, pos1;             // positions (coordinate-sum order) this launch searches for: [pos0, pos1) -- multi-GPU: a block per rank
 };
 
 hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st);

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
   double* s_sq = reinterpret_cast<double*>(smem);              // [m][64]
   int* s_id = reinterpret_cast<int*>(smem + (size_t)m * 64 * 8);  // [m][64]
   const int lane = threadIdx.x;
-  const int pos = blockIdx.x * 64 + lane;                      // position in coordinate-sum order
-  if (pos >= a.n) return;
+  const int pos = a.pos0 + blockIdx.x * 64 + lane;             // position in coordinate-sum order
+  if (pos >= a.pos1) return;
   const int i = a.sorted_idx[pos];                             // original (Vecchia-order) index of the query
   if (i <= m) return;                                          // first m+1 points: all predecessors (:788-813)
   const double4 q = a.sorted_rec[pos];
@@ -112,7 +112,8 @@ hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(vecchia_nn_head_kernel, dim3(((m + 1) * m + 255) / 256), dim3(256), 0, st, a, d);
   if (a.n <= m + 1) return hipGetLastError();
   const size_t shmem = (size_t)m * 64 * 12;
-  const int nblocks = (a.n + 63) / 64;
+  const int nblocks = (a.pos1 - a.pos0 + 63) / 64;
+  if (nblocks <= 0) return hipGetLastError();
   switch (d) {
     case 1: hipLaunchKernelGGL(vecchia_nn_kernel<1>, dim3(nblocks), dim3(64), shmem, st, a); break;
     case 2: hipLaunchKernelGGL(vecchia_nn_kernel<2>, dim3(nblocks), dim3(64), shmem, st, a); break;

@@ -108,6 +108,21 @@ class VecchiaState(object):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
         _shim_call(_lib().gpb_hip_vecchia_comm_init(self.h, buf, C.c_int(int(rank)), C.c_int(int(world))))
 
+    def find_neighbors_part(self, part, nparts):
+        dup = C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_find_neighbors_part(self.h, C.c_int(int(part)), C.c_int(int(nparts)), C.byref(dup)))
+        return bool(dup.value)
+
+    def neighbors_allreduce(self):
+        dup = C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_neighbors_allreduce(self.h, C.byref(dup)))
+        return bool(dup.value)
+
+    def yaux_allreduce(self):
+        out = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_vecchia_yaux_allreduce(self.h, _p(out)))
+        return out
+
     def nll_terms_allreduce(self, cov_type, var, a, gauss=True):
         out = np.empty(3)
         _shim_call(_lib().gpb_hip_vecchia_nll_terms_allreduce(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a),
@@ -284,6 +299,19 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_bench(self.h, _p(di, C.c_int32), C.c_int(nd), C.c_double(const_hess), C.c_int(reps),
                                              C.byref(ms)))
         return ms.value
+
+    def comm_init(self, id128, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        _shim_call(_lib().gpb_hip_hist_comm_init(self.h, buf, C.c_int(int(rank)), C.c_int(int(world))))
+
+    def build_allreduce(self, data_indices=None, const_hess=1.0):
+        """Local leaf histogram of this rank's rows + all-reduce over the ranks -> (hist (total_bins, 2), cnt)."""
+        idx = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+        nd = self.n if idx is None else idx.size
+        hist = np.empty((self.total_bins, 2)); cnt = np.empty(self.total_bins, dtype=np.uint64)
+        _shim_call(_lib().gpb_hip_hist_build_allreduce(self.h, _p(idx, C.c_int), C.c_int(nd), C.c_double(const_hess), _p(hist),
+                                                       _p(cnt, C.c_uint64)))
+        return hist, cnt
 
     # ---- resident leaf histograms (row a12) ----
     def pool_resize(self, num_slots):

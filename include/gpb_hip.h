@@ -116,6 +116,16 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_dev(gpb_hip_vecchia_t* h, int cov_
  * stream and deliver the job-wide terms to every rank's host -- one launch sequence, one collective, one sync per evaluation. */
 GPB_HIP_EXPORT int gpb_hip_comm_get_unique_id(unsigned char* id128);
 GPB_HIP_EXPORT int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, int rank, int world);
+/* Multi-GPU neighbour search: rank r searches the r-th of `nparts` equal blocks of query positions in
+ * coordinate-sum order (balanced: that order is random with respect to the index that decides a query's cost), rows of the other
+ * queries are left at a value < -1; gpb_hip_vecchia_neighbors_allreduce completes the table on every rank with ONE
+ * ncclAllReduce(max) of n x m int32 (and the duplicates flag).  Without a communicator the parts can be merged by the host
+ * (elementwise max of gpb_hip_vecchia_get_neighbors) and handed back through gpb_hip_vecchia_set_neighbors. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_find_neighbors_part(gpb_hip_vecchia_t* h, int32_t part, int32_t nparts, int* has_duplicates);
+GPB_HIP_EXPORT int gpb_hip_vecchia_neighbors_allreduce(gpb_hip_vecchia_t* h, int* has_duplicates);
+/* Multi-GPU y_aux: the shard's contribution (gpb_hip_vecchia_yaux_partial_dev) summed over the ranks with one all-reduce of n
+ * doubles, delivered to the host of every rank. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_allreduce(gpb_hip_vecchia_t* h, double* yaux_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
                                                        int gauss_likelihood, double* out3_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_allreduce(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
@@ -215,6 +225,14 @@ GPB_HIP_EXPORT int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_ind
  * mean duration from HIP events on the handle's stream. */
 GPB_HIP_EXPORT int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
                                       int reps, double* ms_avg);
+
+/* Data-parallel histograms (the scheme of DataParallelTreeLearner, data_parallel_tree_learner.cpp:155-173): each
+ * rank's handle holds a shard of the rows (all features); build_allreduce = local leaf histogram + ONE ncclAllReduce(sum) of the
+ * (grad, hess) pairs and one of the uint64 counts, every rank receives the complete histogram.  Communicator bootstrap as for
+ * gpb_hip_vecchia_comm_init (128-byte ncclUniqueId from gpb_hip_comm_get_unique_id on rank 0). */
+GPB_HIP_EXPORT int gpb_hip_hist_comm_init(gpb_hip_hist_t* h, const unsigned char* id128, int rank, int world);
+GPB_HIP_EXPORT int gpb_hip_hist_build_allreduce(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
+                                                double* hist_out, uint64_t* cnt_out);
 
 /* Resident leaf histograms (the role of HistogramPool, src/LightGBM/treelearner/feature_histogram.hpp:1086-1330) and the two
  * per-leaf post-processing steps of SerialTreeLearner::FindBestSplitsFromHistograms (serial_tree_learner.cpp:375-449) -- SURVEY.md 8

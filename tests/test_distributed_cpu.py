@@ -67,6 +67,75 @@ def test_two_rank_sharded_nll_and_gradient_match_single_process():
         np.testing.assert_allclose(r[5], r[6], rtol=1e-9, atol=1e-9)
 
 
+def _worker_other(rank, world, port, q):
+    """The other sharded pieces of SURVEY.md 8e with the oracle standing in for the kernels: data-parallel histograms (rows per
+    rank, sum-all-reduce), y_aux (row shards of B, sum-all-reduce of n doubles) and the neighbour search (blocks of positions in
+    coordinate-sum order per rank, rows of other queries below -1, max-all-reduce)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gpboost_amd import parallel
+    from oracle import orc
+    from tests import cases
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # histograms
+    rng = np.random.default_rng(3)
+    n, F = 5000, 5
+    nb = rng.integers(2, 257, size=F); bo = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
+    bins = np.stack([rng.integers(0, nb[f], size=n) for f in range(F)]).astype(np.uint8)
+    g = rng.standard_normal(n)
+    leaf = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)
+    r0, r1 = parallel.shard_range(n, rank, world)
+    mine = leaf[(leaf >= r0) & (leaf < r1)]
+    hg, hc, hh = orc.hist_build(bins, bo, mine, g, None)
+    tg = torch.from_numpy(hg.copy()); tc = torch.from_numpy(hc.astype(np.int64))
+    dist.all_reduce(tg); dist.all_reduce(tc)
+    fg, fc, fh = orc.hist_build(bins, bo, leaf, g, None)
+    ok_hist = bool(np.array_equal(tc.numpy(), fc.astype(np.int64)) and np.allclose(tg.numpy(), fg, atol=1e-10))
+    # y_aux and neighbour table
+    coords, y = cases.synthetic(900, 2, seed=8)
+    perm, co, nn = orc.vecchia_setup(coords, 10, "random", 1)
+    A, D, bad = orc.vecchia_factor(co, nn, 0, 10.0, 10.0)
+    yv = y[perm]
+    i0, i1 = parallel.shard_range(len(yv), rank, world)
+    u = yv - np.einsum("ij,ij->i", A, np.where(nn >= 0, yv[np.maximum(nn, 0)], 0.))
+    v = np.zeros_like(u); v[i0:i1] = u[i0:i1] / D[i0:i1]
+    w = v.copy()
+    for i in range(i0, i1):
+        for j in range(nn.shape[1]):
+            if nn[i, j] >= 0:
+                w[nn[i, j]] -= A[i, j] * v[i]
+    tw = torch.from_numpy(w); dist.all_reduce(tw)
+    ok_yaux = bool(np.allclose(tw.numpy(), orc.vecchia_yaux(A, D, nn, yv), atol=1e-10))
+    order = orc.sort_indices(co.sum(axis=1))                       # coordinate-sum order
+    p0, p1 = len(yv) * rank // world, len(yv) * (rank + 1) // world
+    part = np.full(nn.shape, np.iinfo(np.int32).min, dtype=np.int32)
+    rows = np.concatenate([order[p0:p1], np.arange(min(len(yv), nn.shape[1] + 1))])     # my block + the head rows
+    part[rows] = nn[rows]
+    tp = torch.from_numpy(part); dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+    ok_nn = bool(np.array_equal(tp.numpy(), nn))
+    q.put((rank, ok_hist, ok_yaux, ok_nn))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_histogram_yaux_and_neighbor_table_compose():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_other, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[3], r
+
+
 def test_shard_range_covers_everything():
     from gpboost_amd import parallel
     for n in (1, 7, 16, 1000, 10 ** 6 + 3):

@@ -119,3 +119,24 @@ def test_fix_histogram_and_subtraction_against_reference_fixture(lib_built, orc)
     with pytest.raises(gpboost_amd.GPBoostError):
         hb.get_slot(3)
     hb.close()
+
+
+def test_histogram_rccl_allreduce_single_rank(lib_built):
+    """Data-parallel histogram path with a 1-rank communicator: local build + ncclAllReduce(sum) of pairs and counts must
+    reproduce the plain build (the 2-rank composition runs on CPU/gloo in tests/test_distributed_cpu.py)."""
+    import gpboost_amd
+    from gpboost_amd import shim
+    rng = np.random.default_rng(5)
+    n, F = 20000, 7
+    nb = rng.integers(2, 257, size=F); bo = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
+    bins = np.stack([rng.integers(0, nb[f], size=n) for f in range(F)]).astype(np.uint8)
+    hb = shim.HistBuilder(bins, bo); hb.set_gradients(rng.standard_normal(n), None)
+    leaf = np.sort(rng.choice(n, size=n // 2, replace=False)).astype(np.int32)
+    with pytest.raises(gpboost_amd.GPBoostError):
+        hb.build_allreduce(leaf)                           # no communicator
+    hb.comm_init(shim.comm_unique_id(), 0, 1)
+    h1, c1 = hb.build_allreduce(leaf)
+    h0, c0 = hb.build(leaf)
+    assert np.array_equal(c1, c0) and np.array_equal(h1[:, 1], h0[:, 1])
+    np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=0, atol=1e-10)
+    hb.close()

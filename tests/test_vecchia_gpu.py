@@ -404,3 +404,30 @@ def test_newton_leaf_values_against_oracle(gpb, orc, n, m, L):
     with pytest.raises(gpb.GPBoostError):
         st.newton_leaf_values(leaf + 1, L)           # an index == L
     st.close()
+
+
+# ---- multi-GPU pieces on one device: parts of the neighbour search, 1-rank RCCL merges -------------------
+def test_neighbor_search_parts_and_rccl_merges_single_rank(gpb, orc):
+    from gpboost_amd import shim
+    n, m = 30000, 20
+    coords, y = cases.synthetic(n, 2, seed=21)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 3)
+    st = shim.VecchiaState(co, m)
+    merged = np.full((n, m), np.iinfo(np.int32).min, dtype=np.int32)
+    for part in range(3):                                  # what three ranks would compute, merged as the max-all-reduce does
+        st.find_neighbors_part(part, 3)
+        tab = st.get_neighbors()
+        merged = np.maximum(merged, tab)
+        searched = (tab >= -1).all(axis=1)
+        assert n / 3 - m - 2 <= searched[m + 1:].sum() <= n / 3 + 1      # equal blocks of positions (minus head rows)
+        with pytest.raises(gpb.GPBoostError):
+            st.nll_terms(0, 10.0, 10.0)                    # a partial table is not usable
+    assert np.array_equal(merged, nn)
+    # 1-rank communicator: part 0 of 1 + max-all-reduce == plain search; y_aux all-reduce == y_aux
+    st.comm_init(shim.comm_unique_id(), 0, 1)
+    st.find_neighbors_part(0, 1)
+    st.neighbors_allreduce()
+    assert np.array_equal(st.get_neighbors(), nn)
+    st.set_y(y[perm]); st.factor(0, 10.0, 10.0)
+    assert np.array_equal(st.yaux_allreduce(), st.yaux())
+    st.close()
