@@ -26,6 +26,13 @@
 namespace gpb {
 
 namespace {
+// NC doubles of one row of an NC-column chunk (block vectors of the probe block are stored [chunk][row][NC]: the NC columns
+// of a chunk share every index / coefficient load of the solves and products, and one 32-byte sector serves a whole gather)
+template <int NC> struct alignas(NC >= 2 ? 16 : 8) VecN { double v[NC]; };
+template <int NC, int LS = NC>        // LS = doubles per row of the layout (NC < LS: one column of a wider chunk)
+__device__ __forceinline__ VecN<NC> ldvec(const double* base, unsigned row) {
+  return *reinterpret_cast<const VecN<NC>*>(reinterpret_cast<const char*>(base) + row * (unsigned)(8 * LS));
+}
 __device__ __forceinline__ double sigmoid_stable(double x) {   // include/GPBoost/DF_utils.h:37-46
   if (x >= 0.0) { const double t = exp(-x); return 1.0 / (1.0 + t); }
   const double t = exp(x);
@@ -75,59 +82,132 @@ __global__ __launch_bounds__(1024) void logit_objective_kernel(const double* __r
   if (threadIdx.x == 0) { out2[0] = ll; out2[1] = q; }
 }
 
-// column c: rz = r.z, hv = h.v, a = rz / hv; keeps a_old, rz_old          (CG_utils.cpp:73-75 / :170-171)
-__global__ __launch_bounds__(1024) void cg_alpha_kernel(const double* __restrict__ r, const double* __restrict__ z, const double* __restrict__ h,
-                                                        const double* __restrict__ v, int n, CgScalars sc) {
+// ---- CG vector kernels --------------------------------------------------------------------------------------------
+// Block vectors are stored [chunk][row][NC] (NC = 1: plain columns).  Every pass over the vectors is split over P workgroups per
+// chunk (grid = (P, chunks)); dot products leave P partial sums per column in sc.part / sc.part2, and the NEXT kernel of the
+// sequence adds them up in a fixed order before it uses the scalar (no atomics, no grid barrier, bit-reproducible):
+//   cg_dots_kernel      partial r.z and h.v                                       (CG_utils.cpp:73-75 / :170-171)
+//   cg_update_kernel    a = rz / hv from the partials; u += a h, r -= a v; partial r.r   (:76-79 / :172-175)
+//   cg_rnorm_kernel     rnorm = sqrt(sum of the partial r.r)  (one value per column, read by the host)
+//   cg_dots_kernel      partial r.z (after the preconditioner)
+//   cg_hupdate_kernel   b = rz / rz_old from the partials, Lanczos coefficients, h = z + b h      (:97-99 / :205-213)
+namespace {
+__device__ __forceinline__ void slice_of(int n, int& lo, int& hi) {     // this workgroup's rows
+  const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  lo = (int)blockIdx.x * per; hi = lo + per < n ? lo + per : n;
+}
+}  // namespace
+
+template <int NC, bool HV>
+__global__ __launch_bounds__(1024) void cg_dots_kernel(const double* __restrict__ r, const double* __restrict__ z, const double* __restrict__ h,
+                                                       const double* __restrict__ v, int n, CgScalars sc) {
   __shared__ double s[2048];
-  const int c = blockIdx.x;
-  const size_t off = (size_t)c * n;
-  double rz = 0.0, hv = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) { rz = __builtin_fma(r[off + i], z[off + i], rz); hv = __builtin_fma(h[off + i], v[off + i], hv); }
-  block_reduce2(rz, hv, s);
-  if (threadIdx.x == 0) { sc.a_old[c] = sc.a[c]; sc.a[c] = rz / hv; sc.rz_old[c] = rz; }
+  const size_t off = (size_t)blockIdx.y * n * NC;
+  int lo, hi; slice_of(n, lo, hi);
+  double rz[NC], hv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { rz[c] = 0.0; hv[c] = 0.0; }
+  for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    const VecN<NC> a = ldvec<NC>(r + off, i), b = ldvec<NC>(z + off, i);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) rz[c] = __builtin_fma(a.v[c], b.v[c], rz[c]);
+    if (HV) {
+      const VecN<NC> e = ldvec<NC>(h + off, i), f = ldvec<NC>(v + off, i);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) hv[c] = __builtin_fma(e.v[c], f.v[c], hv[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    block_reduce2(rz[c], hv[c], s);
+    if (threadIdx.x == 0) {
+      double* p = sc.part + ((size_t)(blockIdx.y * NC + c) * gridDim.x + blockIdx.x) * 2;
+      p[0] = rz[c]; p[1] = hv[c];
+    }
+  }
 }
 
-// column c: u += a h, r -= a v, rnorm[c] = ||r||                            (CG_utils.cpp:76-79 / :172-175)
+template <int NC>
 __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ u, double* __restrict__ r, const double* __restrict__ h,
                                                          const double* __restrict__ v, int n, CgScalars sc) {
   __shared__ double s[2048];
-  const int c = blockIdx.x;
-  const size_t off = (size_t)c * n;
-  const double a = sc.a[c];
-  double rr = 0.0, dummy = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    if (u) u[off + i] = __builtin_fma(a, h[off + i], u[off + i]);
-    const double ri = __builtin_fma(-a, v[off + i], r[off + i]);
-    r[off + i] = ri;
-    rr = __builtin_fma(ri, ri, rr);
+  __shared__ double s_a[NC];
+  const size_t off = (size_t)blockIdx.y * n * NC;
+  if (threadIdx.x < NC) {
+    const int col = blockIdx.y * NC + threadIdx.x;
+    const double* p = sc.part + (size_t)col * gridDim.x * 2;
+    double rz = 0.0, hv = 0.0;
+    for (unsigned k = 0; k < gridDim.x; ++k) { rz += p[2 * k]; hv += p[2 * k + 1]; }
+    const double a = rz / hv;
+    s_a[threadIdx.x] = a;
+    if (blockIdx.x == 0) { sc.a_old[col] = sc.a[col]; sc.a[col] = a; sc.rz_old[col] = rz; }
   }
-  block_reduce2(rr, dummy, s);
-  if (threadIdx.x == 0) sc.rnorm[c] = sqrt(rr);
+  __syncthreads();
+  double a[NC], rr[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { a[c] = s_a[c]; rr[c] = 0.0; }
+  int lo, hi; slice_of(n, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    const VecN<NC> hv = ldvec<NC>(h + off, i), vv = ldvec<NC>(v + off, i);
+    VecN<NC> rv = ldvec<NC>(r + off, i);
+    if (u) {
+      VecN<NC> uv = ldvec<NC>(u + off, i);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) uv.v[c] = __builtin_fma(a[c], hv.v[c], uv.v[c]);
+      *reinterpret_cast<VecN<NC>*>(u + off + (size_t)i * NC) = uv;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { rv.v[c] = __builtin_fma(-a[c], vv.v[c], rv.v[c]); rr[c] = __builtin_fma(rv.v[c], rv.v[c], rr[c]); }
+    *reinterpret_cast<VecN<NC>*>(r + off + (size_t)i * NC) = rv;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    double dummy = 0.0;
+    block_reduce2(rr[c], dummy, s);
+    if (threadIdx.x == 0) sc.part2[(size_t)(blockIdx.y * NC + c) * gridDim.x + blockIdx.x] = rr[c];
+  }
 }
 
-// column c: b = (r.z) / rz_old, h = z + b h; Lanczos coefficients of iteration j (CG_utils.cpp:97-99 / :205-213)
-__global__ __launch_bounds__(1024) void cg_beta_kernel(const double* __restrict__ r, const double* __restrict__ z, double* __restrict__ h, int n,
-                                                       CgScalars sc, int j, int p_max) {
-  __shared__ double s[2048];
-  __shared__ double s_b;
-  const int c = blockIdx.x;
-  const size_t off = (size_t)c * n;
-  double rz = 0.0, dummy = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) rz = __builtin_fma(r[off + i], z[off + i], rz);
-  block_reduce2(rz, dummy, s);
-  if (threadIdx.x == 0) {
-    const double b_old = sc.b[c];
-    const double b = rz / sc.rz_old[c];
-    sc.b[c] = b;
-    s_b = b;
-    if (sc.Td) {
-      sc.Td[(size_t)c * p_max + j] = 1.0 / sc.a[c] + b_old / sc.a_old[c];
-      if (j > 0) sc.Ts[(size_t)c * p_max + j - 1] = sqrt(b_old) / sc.a_old[c];
+__global__ void cg_rnorm_kernel(CgScalars sc, int ncols, int P) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  double rr = 0.0;
+  for (int k = 0; k < P; ++k) rr += sc.part2[(size_t)col * P + k];
+  sc.rnorm[col] = sqrt(rr);
+}
+
+template <int NC>
+__global__ __launch_bounds__(1024) void cg_hupdate_kernel(const double* __restrict__ z, double* __restrict__ h, int n, CgScalars sc, int j, int p_max) {
+  __shared__ double s_b[NC];
+  const size_t off = (size_t)blockIdx.y * n * NC;
+  if (threadIdx.x < NC) {
+    const int col = blockIdx.y * NC + threadIdx.x;
+    const double* p = sc.part + (size_t)col * gridDim.x * 2;
+    double rz = 0.0;
+    for (unsigned k = 0; k < gridDim.x; ++k) rz += p[2 * k];
+    const double b = rz / sc.rz_old[col];
+    s_b[threadIdx.x] = b;
+    if (blockIdx.x == 0) {
+      const double b_old = sc.b[col];
+      sc.b[col] = b;
+      if (sc.Td) {
+        sc.Td[(size_t)col * p_max + j] = 1.0 / sc.a[col] + b_old / sc.a_old[col];
+        if (j > 0) sc.Ts[(size_t)col * p_max + j - 1] = sqrt(b_old) / sc.a_old[col];
+      }
     }
   }
   __syncthreads();
-  const double b = s_b;
-  for (int i = threadIdx.x; i < n; i += 1024) h[off + i] = __builtin_fma(b, h[off + i], z[off + i]);
+  double b[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) b[c] = s_b[c];
+  int lo, hi; slice_of(n, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    const VecN<NC> zv = ldvec<NC>(z + off, i);
+    VecN<NC> hv = ldvec<NC>(h + off, i);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) hv.v[c] = __builtin_fma(b[c], hv.v[c], zv.v[c]);
+    *reinterpret_cast<VecN<NC>*>(h + off + (size_t)i * NC) = hv;
+  }
 }
 
 // ---- level-scheduled sparse triangular solves of the VADU preconditioner -----------------------------------------
@@ -180,7 +260,7 @@ constexpr int TRI_ROWS = kTriRowsPerRound;     // slots per round of the workgro
 static_assert(TRI_ROWS == TRI_GROUPS * TRI_R, "round size");
 struct TriRound { int L, qb, b1, split; };   // level, first position of the round, end of the level, level has split rows
 struct TriA { int i[TRI_R], ns[TRI_R], ob[TRI_R], oe[TRI_R]; };
-struct TriB { int hs[TRI_R][2], os[TRI_R][2]; double ha[TRI_R][2], oa[TRI_R][2], num[TRI_R], den[TRI_R]; };
+template <int NC> struct TriB { int hs[TRI_R][2], os[TRI_R][2]; double ha[TRI_R][2], oa[TRI_R][2], num[TRI_R][NC], den[TRI_R]; };
 }  // namespace
 
 // Levels [L0, L1) of the solve, `nrounds` rounds for this workgroup.  nsplit == 1: one workgroup per right-hand side walks all
@@ -191,15 +271,17 @@ struct TriB { int hs[TRI_R][2], os[TRI_R][2]; double ha[TRI_R][2], oa[TRI_R][2],
 // 64-lane load, shared by all wavefronts), not latency.  Hence: the slot descriptor is one 16-byte record (one load instead
 // of four), matrix entries are 16-byte {coefficient, source} records (one load instead of two), a wavefront whose groups
 // have no slot in rounds r .. r+2 issues nothing, and rounds of at most 32 slots run a one-slot-per-group body.
-template <bool SCALE, bool OVF>
+template <bool SCALE, bool OVF, int NC, int LS>
 __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const int* __restrict__ lv_ptr, const int* __restrict__ lv_split,
                                                                  int n, int L0, int L1, int nsplit, int nrounds,
                                                                  const double* __restrict__ rhs, const double* __restrict__ rdw, double* x) {
   // lv_ptr / lv_split (= T.ptr / T.lsplit) are separate __restrict__ arguments so that the level bookkeeping compiles to
   // scalar loads: as vector loads their results would have to be waited for with vmcnt(0), draining the prefetches
-  __shared__ double s_part[2][TRI_ROWS];
+  __shared__ double s_part[2][TRI_ROWS][NC];
+  // col = index of the NC-column unit this workgroup solves for; the vectors are stored [chunk][row][LS] (NC == LS: a whole
+  // chunk; NC = 1 < LS: one column of a chunk -- the narrow-level runs of the probe block, where workgroups run side by side)
   const int col = blockIdx.x / nsplit, part = blockIdx.x - col * nsplit;
-  const size_t off = (size_t)col * n;
+  const size_t off = (size_t)(col * NC / LS) * n * LS + (size_t)(col * NC % LS);
   const double* __restrict__ rc = rhs + off;
   double* xc = x + off;
   const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -231,7 +313,7 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
       a.i[s] = m.x; a.ns[s] = m.y; a.ob[s] = m.z; a.oe[s] = m.w;
     }
   };
-  auto issueB = [&](auto NS, const TriRound& d, const TriA& a, TriB& b) {
+  auto issueB = [&](auto NS, const TriRound& d, const TriA& a, TriB<NC>& b) {
 #pragma unroll
     for (int s = 0; s < decltype(NS)::value; ++s) {
       const unsigned hq = slot(d, s) * 32u + (unsigned)lane;
@@ -248,22 +330,24 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
         }
       }
       const unsigned row = a.i[s] >= 0 ? (unsigned)a.i[s] : 0u;      // padding slots and continuation slots never use it
-      b.num[s] = ldu(rc, row);
+      const VecN<NC> nv = ldvec<NC, LS>(rc, row);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) b.num[s][c] = nv.v[c];
       b.den[s] = SCALE ? ldu(rdw, row) : 1.0;
     }
   };
   // part 1 of a round: gathers, prefetches, slot sums, partial sums to LDS
-  auto body1 = [&](auto NS, const TriRound& d, const TriA& a, const TriB& b, int parity, const TriRound& dn, const TriA& an, TriB& bn,
-                   const TriRound& dnn, TriA& ann, double (&tot)[TRI_R]) {
+  auto body1 = [&](auto NS, const TriRound& d, const TriA& a, const TriB<NC>& b, int parity, const TriRound& dn, const TriA& an,
+                   TriB<NC>& bn, const TriRound& dnn, TriA& ann, double (&tot)[TRI_R][NC]) {
     constexpr int ns = decltype(NS)::value;
     // (1) the gathers this round waits for go first ...
-    double g[TRI_R][4];
+    VecN<NC> g[TRI_R][4];
 #pragma unroll
     for (int s = 0; s < ns; ++s) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        g[s][k] = ldu((const double*)xc, (unsigned)b.hs[s][k]);
-        if (OVF) g[s][2 + k] = ldu((const double*)xc, (unsigned)b.os[s][k]);
+        g[s][k] = ldvec<NC, LS>((const double*)xc, (unsigned)b.hs[s][k]);
+        if (OVF) g[s][2 + k] = ldvec<NC, LS>((const double*)xc, (unsigned)b.os[s][k]);
       }
     }
     // (2) ... then the prefetches of the next two rounds (independent of x)
@@ -272,45 +356,57 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
     // (3) slot sums; padding entries: coefficient 0 times a finite x (the workspace is zero-initialised)
 #pragma unroll
     for (int s = 0; s < ns; ++s) {
-      double sum = 0.0;
+      double sum[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] = 0.0;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        sum = __builtin_fma(b.ha[s][k], g[s][k], sum);
-        if (OVF) sum = __builtin_fma(b.oa[s][k], g[s][2 + k], sum);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          sum[c] = __builtin_fma(b.ha[s][k], g[s][k].v[c], sum[c]);
+          if (OVF) sum[c] = __builtin_fma(b.oa[s][k], g[s][2 + k].v[c], sum[c]);
+        }
       }
       // slots longer than 64 entries exist only when a row has > 4096 entries
       if (OVF) for (int e0 = a.ob[s] + 32 + lane; e0 - lane < a.oe[s]; e0 += 64) {
-        LapEnt o[4]; double gg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int e = e0 + 16 * k;
           const bool in = e < a.oe[s];
-          o[k] = ldu(T.oent, in ? (unsigned)e : (unsigned)a.ob[s]);
-          if (!in) o[k].val = 0.0;
+          LapEnt o = ldu(T.oent, in ? (unsigned)e : (unsigned)a.ob[s]);
+          if (!in) o.val = 0.0;
+          const VecN<NC> gg = ldvec<NC, LS>((const double*)xc, (unsigned)o.src);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) sum[c] = __builtin_fma(o.val, gg.v[c], sum[c]);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gg[k] = ldu((const double*)xc, (unsigned)o[k].src);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sum = __builtin_fma(o[k].val, gg[k], sum);
       }
-      tot[s] = row16_sum(sum);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) tot[s][c] = row16_sum(sum[c]);
     }
     // (4) partial sums of split rows meet in LDS (only in levels that have any; double-buffered by round parity)
     if (d.split) {
 #pragma unroll
-      for (int s = 0; s < ns; ++s) if (lane == 0) s_part[parity][grp + TRI_GROUPS * s] = tot[s];
+      for (int s = 0; s < ns; ++s) if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s_part[parity][grp + TRI_GROUPS * s][c] = tot[s][c];
+      }
     }
   };
   // part 2 (after the exchange barrier): the first slot of a row adds the partial sums of its other slots and stores
-  auto body2 = [&](auto NS, const TriRound& d, const TriA& a, const TriB& b, int parity, const double (&tot)[TRI_R]) {
+  auto body2 = [&](auto NS, const TriRound& d, const TriA& a, const TriB<NC>& b, int parity, const double (&tot)[TRI_R][NC]) {
 #pragma unroll
     for (int s = 0; s < decltype(NS)::value; ++s) {
       const bool live = d.L < L1 && d.qb + grp + TRI_GROUPS * s < d.b1 && a.ns[s] > 0;
       if (lane == 0 && live) {
-        double v = tot[s];
-        // the continuation slots of a row follow its first slot: positions (q - qb) + 1 ... inside the same round
-        for (int k = 1; k < a.ns[s]; ++k) v += s_part[parity][grp + TRI_GROUPS * s + k];
-        xc[(unsigned)a.i[s]] = (SCALE ? __builtin_fma(b.num[s], b.den[s], v) : b.num[s] + v);
+        VecN<NC> out;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          double v = tot[s][c];
+          // the continuation slots of a row follow its first slot: positions (q - qb) + 1 ... inside the same round
+          for (int k = 1; k < a.ns[s]; ++k) v += s_part[parity][grp + TRI_GROUPS * s + k][c];
+          out.v[c] = (SCALE ? __builtin_fma(b.num[s][c], b.den[s], v) : b.num[s][c] + v);
+        }
+        *reinterpret_cast<VecN<NC>*>(xc + (size_t)(unsigned)a.i[s] * LS) = out;
       }
     }
   };
@@ -320,7 +416,7 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
   // buffers contain -- zeros or the data of an older round, always valid indices)
   TriRound d[3];
   TriA a[3] = {};
-  TriB b[2] = {};
+  TriB<NC> b[2] = {};
   d[0] = TriRound{L0, lv_ptr[L0] + first, lv_ptr[L0 + 1], lv_split[L0]};
   d[1] = advance(d[0], ptr_at(L0 + 2), split_at(L0 + 1));
   d[2] = advance(d[1], ptr_at(d[1].L + 2), split_at(d[1].L + 1));
@@ -337,7 +433,7 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
         const int ptr_next = ptr_at(dnn.L + 2), split_next = split_at(dnn.L + 1);
         const bool mine = wave_live(dc) || wave_live(dn) || wave_live(dnn);
         const bool wide = two_slots(dc) || two_slots(dn) || two_slots(dnn);
-        double tot[TRI_R] = {0.0, 0.0};
+        double tot[TRI_R][NC] = {};
         if (mine) {
           if (wide) body1(IntC<2>{}, dc, a[p % 3], b[p % 2], p & 1, dn, a[(p + 1) % 3], b[(p + 1) % 2], dnn, a[(p + 2) % 3], tot);
           else body1(IntC<1>{}, dc, a[p % 3], b[p % 2], p & 1, dn, a[(p + 1) % 3], b[(p + 1) % 2], dnn, a[(p + 2) % 3], tot);
@@ -358,7 +454,7 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
 // slots), 16 slots per workgroup.
 //   MODE 0: out = B x      MODE 1: out = D^-1 B x      MODE 2: out = B^T x + W .* h  (W may be NULL)
 // (B x)_i = x_i - sum_j A_ij x[nn_ij] with T = fwd;  (B^T x)_j = x_j - sum_{i : j in N(i)} A_ij x_i with T = bwd.
-template <int MODE>
+template <int MODE, int NC>
 __global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, const double* __restrict__ x, const double* __restrict__ D,
                                                            const double* __restrict__ W, const double* __restrict__ h, double* __restrict__ out) {
   const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -367,26 +463,45 @@ __global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, cons
   const int4 m0 = T.meta[q0];
   const int row = m0.x, nseg = m0.y;
   if (nseg <= 0) return;                   // continuation or padding slot
-  const size_t off = (size_t)blockIdx.y * n;
+  const size_t off = (size_t)blockIdx.y * n * NC;      // blockIdx.y = chunk of NC columns
   const double* __restrict__ xc = x + off;
-  double sum = 0.0;
+  double sum[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) sum[c] = 0.0;
   for (int q = q0; q < q0 + nseg; ++q) {
-    LapEnt e[2]; double g[2];
+    LapEnt e[2]; VecN<NC> g[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) e[k] = ldu(T.hent, (unsigned)q * 32u + lane + 16u * k);
     const int4 mq = T.meta[q];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) g[k] = xc[e[k].src];
+    for (int k = 0; k < 2; ++k) g[k] = ldvec<NC>(xc, (unsigned)e[k].src);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) sum = __builtin_fma(e[k].val, g[k], sum);
-    for (int j = mq.z + lane; j < mq.w; j += 16) { const LapEnt o = T.oent[j]; sum = __builtin_fma(o.val, xc[o.src], sum); }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] = __builtin_fma(e[k].val, g[k].v[c], sum[c]);
+    for (int j = mq.z + lane; j < mq.w; j += 16) {
+      const LapEnt o = T.oent[j];
+      const VecN<NC> go = ldvec<NC>(xc, (unsigned)o.src);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] = __builtin_fma(o.val, go.v[c], sum[c]);
+    }
   }
-  const double tot = row16_sum(sum);
+  double tot[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) tot[c] = row16_sum(sum[c]);
   if (lane == 0) {
-    double v = xc[row] - tot;
-    if (MODE == 1) v *= 1.0 / D[row];
-    if (MODE == 2 && W) v = __builtin_fma(W[row], h[off + row], v);
-    out[off + row] = v;
+    const VecN<NC> xr = ldvec<NC>(xc, (unsigned)row);
+    VecN<NC> hr;
+    if (MODE == 2 && W) hr = ldvec<NC>(h + off, (unsigned)row);
+    VecN<NC> o;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double v = xr.v[c] - tot[c];
+      if (MODE == 1) v *= 1.0 / D[row];
+      if (MODE == 2 && W) v = __builtin_fma(W[row], hr.v[c], v);
+      o.v[c] = v;
+    }
+    *reinterpret_cast<VecN<NC>*>(out + off + (size_t)row * NC) = o;
   }
 }
 
@@ -417,12 +532,12 @@ __global__ void lap_lincomb_kernel(double* __restrict__ out, const double* __res
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = cx * x[i] + cy * y[i];
 }
-// probes: R(:, c) <- sqrt(dw) .* randvec(:, c)      (likelihoods.h:16481-16487, before the B^T product)
-__global__ void lap_scale_probes_kernel(const double* __restrict__ rv, const double* __restrict__ dw, int n, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t off = (size_t)blockIdx.y * n;
-  out[off + i] = sqrt(dw[i]) * rv[off + i];
+// probes: R(:, c) <- sqrt(dw) .* randvec(:, c)      (likelihoods.h:16481-16487, before the B^T product); chunked layout, nc = NC
+__global__ void lap_scale_probes_kernel(const double* __restrict__ rv, const double* __restrict__ dw, int n, int nc, double* __restrict__ out) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const size_t off = (size_t)blockIdx.y * n * nc;
+  out[off + g] = sqrt(dw[g / nc]) * rv[off + g];
 }
 // out2 = { sum log(1/D), sum log(dw) }
 __global__ __launch_bounds__(1024) void lap_logsums_kernel(const double* __restrict__ D, const double* __restrict__ dw, int n, double* __restrict__ out2) {
@@ -447,20 +562,24 @@ hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, i
   hipLaunchKernelGGL(logit_newton_setup_kernel, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
   return hipGetLastError();
 }
-hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, hipStream_t st) {
-  const dim3 grid((lv.fwd.nslots + 15) / 16, ncol), gridb((lv.bwd.nslots + 15) / 16, ncol);
-  hipLaunchKernelGGL(lap_tri_spmv_kernel<1>, grid, dim3(256), 0, st, lv.fwd, n, h, D, (const double*)nullptr, (const double*)nullptr, tmp);
-  hipLaunchKernelGGL(lap_tri_spmv_kernel<2>, gridb, dim3(256), 0, st, lv.bwd, n, (const double*)tmp, (const double*)nullptr, W, h, v);
+// nc = columns per chunk of the block layout (1: plain column-major; 4: the probe block), ncol = number of chunks
+#define LAP_SPMV(MODE, T_, X, D_, W_, H_, OUT)                                                                                              \
+  do {                                                                                                                                      \
+    const dim3 grid_((T_.nslots + 15) / 16, ncol);                                                                                          \
+    if (nc == 4) hipLaunchKernelGGL((lap_tri_spmv_kernel<MODE, 4>), grid_, dim3(256), 0, st, T_, n, X, D_, W_, H_, OUT);                    \
+    else hipLaunchKernelGGL((lap_tri_spmv_kernel<MODE, 1>), grid_, dim3(256), 0, st, T_, n, X, D_, W_, H_, OUT);                            \
+  } while (0)
+hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, int nc, hipStream_t st) {
+  LAP_SPMV(1, lv.fwd, h, D, (const double*)nullptr, (const double*)nullptr, tmp);
+  LAP_SPMV(2, lv.bwd, (const double*)tmp, (const double*)nullptr, W, h, v);
   return hipGetLastError();
 }
-hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_tri_spmv_kernel<0>, dim3((lv.fwd.nslots + 15) / 16, ncol), dim3(256), 0, st, lv.fwd, n, x, (const double*)nullptr, (const double*)nullptr,
-                     (const double*)nullptr, out);
+hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st) {
+  LAP_SPMV(0, lv.fwd, x, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, out);
   return hipGetLastError();
 }
-hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, hipStream_t st) {
-  hipLaunchKernelGGL(lap_tri_spmv_kernel<2>, dim3((lv.bwd.nslots + 15) / 16, ncol), dim3(256), 0, st, lv.bwd, n, x, (const double*)nullptr, (const double*)nullptr,
-                     (const double*)nullptr, out);
+hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st) {
+  LAP_SPMV(2, lv.bwd, x, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, out);
   return hipGetLastError();
 }
 hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st) {
@@ -472,16 +591,19 @@ hipError_t lap_objective(const double* x, const int* y, const double* Bx, const 
   return hipGetLastError();
 }
 // OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out
-#define LAP_TRSV(SCALE, T_, SEG, RHS, RDW, X)                                                                                         \
+#define LAP_TRSV_NC(SCALE, OVF_, NC_, LS_, T_, SEG, RHS, RDW, X)                                                                     \
+  hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, OVF_, NC_, LS_>), dim3(ncol * (LS_ / NC_) * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, \
+                     (T_).ptr, (T_).lsplit, n, (SEG).L0, (SEG).L1, (SEG).nsplit, (SEG).nrounds, RHS, RDW, X)
+// block layout (nc == 4): a wide level (own launch, work-bound) handles a whole chunk per workgroup -- the 4 columns share every
+// index / coefficient load and each 32-byte sector of x; a run of narrow levels (latency-bound) keeps one workgroup per column
+#define LAP_TRSV_O(SCALE, OVF_, T_, SEG, RHS, RDW, X)                                                                                 \
   do {                                                                                                                                \
-    if ((T_).has_ovf)                                                                                                                 \
-      hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, true>), dim3(ncol * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, (T_).ptr,        \
-                         (T_).lsplit, n, (SEG).L0, (SEG).L1, (SEG).nsplit, (SEG).nrounds, RHS, RDW, X);                               \
-    else                                                                                                                              \
-      hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, false>), dim3(ncol * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, (T_).ptr,       \
-                         (T_).lsplit, n, (SEG).L0, (SEG).L1, (SEG).nsplit, (SEG).nrounds, RHS, RDW, X);                               \
+    if (nc == 4) { if ((SEG).nsplit > 1) LAP_TRSV_NC(SCALE, OVF_, 4, 4, T_, SEG, RHS, RDW, X); else LAP_TRSV_NC(SCALE, OVF_, 1, 4, T_, SEG, RHS, RDW, X); } \
+    else LAP_TRSV_NC(SCALE, OVF_, 1, 1, T_, SEG, RHS, RDW, X);                                                                        \
   } while (0)
-hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, hipStream_t st) {
+#define LAP_TRSV(SCALE, T_, SEG, RHS, RDW, X)                                                                                         \
+  do { if ((T_).has_ovf) LAP_TRSV_O(SCALE, true, T_, SEG, RHS, RDW, X); else LAP_TRSV_O(SCALE, false, T_, SEG, RHS, RDW, X); } while (0)
+hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
   for (int k = 0; k < lv.n_bseg; ++k) LAP_TRSV(false, lv.bwd, lv.bseg[k], r, (const double*)nullptr, t);     // B^T t = r
   for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], (const double*)t, rdw, z);            // (D^-1 + W) B z = t
   return hipGetLastError();
@@ -491,24 +613,37 @@ hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos,
   hipLaunchKernelGGL(lap_permute_factor_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, hpos, opos, nh, novf, hent, oent);
   return hipGetLastError();
 }
-hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, const CgScalars& sc, hipStream_t st) {
-  hipLaunchKernelGGL(cg_alpha_kernel, dim3(ncol), dim3(1024), 0, st, r, z, h, v, n, sc);
+int lap_cg_parts(int n) { const int p = (n + 4095) / 4096; return p < 1 ? 1 : (p > 64 ? 64 : p); }
+hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st) {
+  const dim3 grid(lap_cg_parts(n), ncol);
+  if (nc == 4) hipLaunchKernelGGL((cg_dots_kernel<4, true>), grid, dim3(1024), 0, st, r, z, h, v, n, sc);
+  else hipLaunchKernelGGL((cg_dots_kernel<1, true>), grid, dim3(1024), 0, st, r, z, h, v, n, sc);
   return hipGetLastError();
 }
-hipError_t lap_cg_update(double* u, double* r, const double* h, const double* v, int n, int ncol, const CgScalars& sc, hipStream_t st) {
-  hipLaunchKernelGGL(cg_update_kernel, dim3(ncol), dim3(1024), 0, st, u, r, h, v, n, sc);
+hipError_t lap_cg_update(double* u, double* r, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st) {
+  const dim3 grid(lap_cg_parts(n), ncol);
+  if (nc == 4) hipLaunchKernelGGL(cg_update_kernel<4>, grid, dim3(1024), 0, st, u, r, h, v, n, sc);
+  else hipLaunchKernelGGL(cg_update_kernel<1>, grid, dim3(1024), 0, st, u, r, h, v, n, sc);
+  hipLaunchKernelGGL(cg_rnorm_kernel, dim3((ncol * nc + 63) / 64), dim3(64), 0, st, sc, ncol * nc, lap_cg_parts(n));
   return hipGetLastError();
 }
-hipError_t lap_cg_beta(const double* r, const double* z, double* h, int n, int ncol, const CgScalars& sc, int j, int p_max, hipStream_t st) {
-  hipLaunchKernelGGL(cg_beta_kernel, dim3(ncol), dim3(1024), 0, st, r, z, h, n, sc, j, p_max);
+hipError_t lap_cg_beta(const double* r, const double* z, double* h, int n, int ncol, int nc, const CgScalars& sc, int j, int p_max, hipStream_t st) {
+  const dim3 grid(lap_cg_parts(n), ncol);
+  if (nc == 4) {
+    hipLaunchKernelGGL((cg_dots_kernel<4, false>), grid, dim3(1024), 0, st, r, z, (const double*)nullptr, (const double*)nullptr, n, sc);
+    hipLaunchKernelGGL(cg_hupdate_kernel<4>, grid, dim3(1024), 0, st, z, h, n, sc, j, p_max);
+  } else {
+    hipLaunchKernelGGL((cg_dots_kernel<1, false>), grid, dim3(1024), 0, st, r, z, (const double*)nullptr, (const double*)nullptr, n, sc);
+    hipLaunchKernelGGL(cg_hupdate_kernel<1>, grid, dim3(1024), 0, st, z, h, n, sc, j, p_max);
+  }
   return hipGetLastError();
 }
 hipError_t lap_lincomb(double* out, const double* x, const double* y, double cx, double cy, int n, hipStream_t st) {
   hipLaunchKernelGGL(lap_lincomb_kernel, GRID1(n), 0, st, out, x, y, cx, cy, n);
   return hipGetLastError();
 }
-hipError_t lap_scale_probes(const double* rv, const double* dw, int n, int ncol, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(lap_scale_probes_kernel, dim3((n + 255) / 256, ncol), dim3(256), 0, st, rv, dw, n, out);
+hipError_t lap_scale_probes(const double* rv, const double* dw, int n, int ncol, int nc, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(lap_scale_probes_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, rv, dw, n, nc, out);
   return hipGetLastError();
 }
 hipError_t lap_logsums(const double* D, const double* dw, int n, double* out2, hipStream_t st) {
