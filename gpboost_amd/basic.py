@@ -221,6 +221,25 @@ class GPModel(object):
                                                          leaf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(num_leaves)), _dptr(out)))
         return out
 
+    def predict(self, y, gp_coords_pred, cov_pars, predict_var=True, predict_response=False, num_neighbors_pred=None):
+        """Predictive mean / variance at new locations for vecchia_pred_type = "order_obs_first_cond_obs_only" (reference:
+        GPModel.predict, basic.py:5702-6050 -> GPB_PredictREModel -> CalcPredVecchiaObservedFirstOrder).  Returns {'mu', 'var'}."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        cp = np.asarray(gp_coords_pred, dtype=np.float64)
+        if cp.ndim == 1:
+            cp = cp.reshape(-1, 1)
+        if cp.shape[1] != self.dim_coords:
+            raise ValueError("Incorrect dimension of 'gp_coords_pred'")
+        cpc = np.asfortranarray(cp)
+        npred = cp.shape[0]
+        mu = np.empty(npred); var = np.empty(npred)
+        _safe_call(_lib().GPB_HIP_PredictVecchiaObsOnly(
+            self.handle, _dptr(y), _dptr(cov_pars), ctypes.c_int(npred), _dptr(cpc),
+            ctypes.c_int(-1 if num_neighbors_pred is None else int(num_neighbors_pred)), ctypes.c_bool(bool(predict_response)),
+            _dptr(mu), _dptr(var) if predict_var else None))
+        return {"mu": mu, "var": var if predict_var else None}
+
     def vecchia_structure(self):
         """(perm, nn): Vecchia ordering and the (n, m) neighbour table, -1 padded."""
         m = ctypes.c_int(0)

@@ -340,6 +340,25 @@ int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, d
   C_API_END();
 }
 
+int GPB_HIP_PredictVecchiaObsOnly(REModelHandle handle, const double* y_data, double* cov_pars, int32_t num_data_pred,
+                                  const double* gp_coords_data_pred, int32_t num_neighbors_pred, bool predict_response,
+                                  double* out_mean, double* out_var) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !cov_pars || !gp_coords_data_pred || !out_mean) return set_error("GPB_HIP_PredictVecchiaObsOnly: null argument");
+  if (mdl->likelihood != "gaussian" || mdl->eh) return set_error("GPB_HIP_PredictVecchiaObsOnly: only the Gaussian Vecchia model is on the MI355X hot path of this library");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (upload_y(mdl, y_data, nullptr)) return -1;
+  if (num_neighbors_pred <= 0) num_neighbors_pred = mdl->m;          // re_model_template.h: num_neighbors_pred_ defaults to num_neighbors_
+  std::vector<double> D(num_data_pred);
+  if (gpb_hip_vecchia_predict_obs_only(mdl->vh, num_data_pred, gp_coords_data_pred, num_neighbors_pred, mdl->cov_type, tr[1], tr[2],
+                                       out_mean, D.data(), nullptr)) return shim_error();
+  if (out_var)
+    for (int k = 0; k < num_data_pred; ++k) out_var[k] = tr[0] * (predict_response ? D[k] : D[k] - 1.);
+  C_API_END();
+}
+
 int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);

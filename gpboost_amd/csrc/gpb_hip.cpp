@@ -310,6 +310,7 @@ static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* 
   a.sorted_rec = d_rec; a.sorted_idx = d_idx; a.pts = h->d_pts; a.nn = h->d_nn; a.has_duplicates = h->d_flag; a.n = n; a.m = m;
   // positions are in coordinate-sum order, i.e. random with respect to the index that decides a query's cost: equal blocks of
   // positions are balanced (SURVEY.md 8e suggested cyclic assignment for index-ordered blocks; not needed here)
+  a.start_at = 0; a.end_search_at = n - 2;
   a.pos0 = (int)((long long)n * part / nparts); a.pos1 = (int)((long long)n * (part + 1) / nparts);
   if (nparts > 1) HIP_OK(hipMemsetAsync(h->d_nn, 0x80, sizeof(int) * (size_t)n * m, h->stream));     // 0x80808080 < -1: "not mine"
   if (n == 1) {
@@ -661,6 +662,76 @@ int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev) {
   if (!h || !w_dev) return fail("null argument");
   if (yaux_enqueue(h)) return -1;
   HIP_OK(hipMemcpyAsync(w_dev, h->d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  API_END();
+}
+
+// Prediction at new locations, every prediction point conditioning on its nearest OBSERVED points only:
+// CalcPredVecchiaObservedFirstOrder(CondObsOnly = true), src/GPBoost/Vecchia_utils.cpp:1701-2060, Gaussian likelihood.
+// The reference appends the prediction coordinates to the observed ones, searches neighbours with start_at = n_obs and
+// end_search_at = n_obs - 1 (:1792-1799), and runs the same per-point local factorisation as the likelihood (:1883-1975):
+// pred_mean = A_p y_nn, Dp = 1 + sigma1^2/sigma^2 - A_p c.  Here that is one launch of the neighbour-search kernel and one of
+// vecchia_point_kernel<MODE_FACTOR> over the appended rows (their own response slot is 0, so u = -A_p y_nn).
+int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                     int cov_type, double var, double a, double* pred_mean, double* pred_D, int* has_duplicates) {
+  API_BEGIN();
+  if (!h || !coords_pred_colmajor || !pred_mean || !pred_D) return fail("null argument");
+  if (n_pred < 1) return fail("gpb_hip_vecchia_predict_obs_only: n_pred = %d", n_pred);
+  if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
+  const int n_obs = h->n, d = h->d, n_all = n_obs + n_pred;
+  int m = num_neighbors_pred;
+  if (m > n_obs) m = n_obs;                                   // :755-758 with end_search_at = n_obs - 1
+  if (m < 1 || m > GPB_MAX_NEIGHBORS) return fail("gpb_hip_vecchia_predict_obs_only: num_neighbors_pred = %d (1..%d supported)", num_neighbors_pred, GPB_MAX_NEIGHBORS);
+  if (n_obs <= m) return fail("gpb_hip_vecchia_predict_obs_only: needs more observed points (%d) than neighbours (%d)", n_obs, m);
+  HIP_OK(hipSetDevice(h->device));
+  // [observed (Vecchia order); prediction] as one temporary state; the observed records (coordinates + y) are copied on the device
+  std::vector<double> call((size_t)n_all * d);
+  for (int c = 0; c < d; ++c) {
+    std::copy(h->coords.begin() + (size_t)c * n_obs, h->coords.begin() + (size_t)(c + 1) * n_obs, call.begin() + (size_t)c * n_all);
+    std::copy(coords_pred_colmajor + (size_t)c * n_pred, coords_pred_colmajor + (size_t)(c + 1) * n_pred, call.begin() + (size_t)c * n_all + n_obs);
+  }
+  gpb_hip_vecchia_t* t = nullptr;
+  if (gpb_hip_vecchia_create(n_all, d, m, call.data(), &t)) return -1;
+  struct Guard { gpb_hip_vecchia_t* p; ~Guard() { gpb_hip_vecchia_free(p); } } guard{t};
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(t->d_pts, h->d_pts, sizeof(double4) * (size_t)n_obs, hipMemcpyDeviceToDevice));   // pred rows keep y = 0
+  t->has_y = true;
+  // neighbour search for the appended rows only
+  {
+    std::vector<double> csum(n_all);
+    for (int i = 0; i < n_all; ++i) { double s = call[i]; for (int c = 1; c < d; ++c) s += call[(size_t)c * n_all + i]; csum[i] = s; }
+    std::vector<int> sort_sum(n_all);
+    std::iota(sort_sum.begin(), sort_sum.end(), 0);
+    const double* v = csum.data();
+    std::sort(sort_sum.begin(), sort_sum.end(), [v](int i1, int i2) { return v[i1] < v[i2]; });
+    std::vector<double4> rec(n_all);
+    for (int k = 0; k < n_all; ++k) {
+      const int i = sort_sum[k];
+      rec[k].x = call[i]; rec[k].y = d > 1 ? call[(size_t)n_all + i] : 0.0; rec[k].z = d > 2 ? call[(size_t)2 * n_all + i] : 0.0; rec[k].w = csum[i];
+    }
+    double4* d_rec = nullptr; int* d_idx = nullptr;
+    HIP_OK(hipMalloc(&d_rec, sizeof(double4) * (size_t)n_all));
+    HIP_OK(hipMalloc(&d_idx, sizeof(int) * (size_t)n_all));
+    HIP_OK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double4) * (size_t)n_all, hipMemcpyHostToDevice, t->stream));
+    HIP_OK(hipMemcpyAsync(d_idx, sort_sum.data(), sizeof(int) * (size_t)n_all, hipMemcpyHostToDevice, t->stream));
+    HIP_OK(hipMemsetAsync(t->d_flag, 0, sizeof(int), t->stream));
+    HIP_OK(hipMemsetAsync(t->d_nn, 0xff, sizeof(int) * (size_t)n_all * t->m, t->stream));
+    gpb::NNKernelArgs na;
+    na.sorted_rec = d_rec; na.sorted_idx = d_idx; na.pts = t->d_pts; na.nn = t->d_nn; na.has_duplicates = t->d_flag; na.n = n_all; na.m = t->m;
+    na.start_at = n_obs; na.end_search_at = n_obs - 1; na.pos0 = 0; na.pos1 = n_all;
+    HIP_OK(gpb::launch_vecchia_nn(d, na, t->stream));
+    int flag = 0;
+    HIP_OK(hipMemcpyAsync(&flag, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
+    HIP_OK(hipStreamSynchronize(t->stream));
+    (void)hipFree(d_rec); (void)hipFree(d_idx);
+    if (has_duplicates) *has_duplicates = flag;
+    t->has_nn = true;
+  }
+  t->i_begin = n_obs; t->i_end = n_all;
+  if (gpb_hip_vecchia_factor(t, cov_type, var, a, 1)) return -1;
+  std::vector<double> u(n_all);
+  HIP_OK(hipMemcpy(u.data(), t->d_u, sizeof(double) * (size_t)n_all, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n_pred; ++k) pred_mean[k] = -u[n_obs + k];
+  HIP_OK(hipMemcpy(pred_D, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
   API_END();
 }
 

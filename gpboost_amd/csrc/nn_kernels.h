@@ -11,6 +11,7 @@ struct NNKernelArgs {
   int* nn;                    // [n][m] out
   int* has_duplicates;        // out flag (atomicOr)
   int n, m;
+  int start_at, end_search_at; // rows [start_at, n) are searched; candidates have index < i and <= end_search_at (Vecchia_utils.cpp:739-754)
   int pos0, pos1;             // positions (coordinate-sum order) this launch searches for: [pos0, pos1) -- multi-GPU: a block per rank
 };
 

@@ -42,10 +42,10 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
   const int pos = a.pos0 + blockIdx.x * 64 + lane;             // position in coordinate-sum order
   if (pos >= a.pos1) return;
   const int i = a.sorted_idx[pos];                             // original (Vecchia-order) index of the query
-  if (i <= m) return;                                          // first m+1 points: all predecessors (:788-813)
+  if (i <= m || i < a.start_at) return;                        // first m+1 points: all predecessors (:788-813); rows below start_at: not asked for
   const double4 q = a.sorted_rec[pos];
   const int n = a.n;
-  const int end_search_at = n - 2;                             // :752-754
+  const int end_search_at = a.end_search_at;                   // :752-754 (n - 2 unless a prediction run restricts the candidates)
   const double dd = (double)D;
   for (int j = 0; j < m; ++j) s_sq[j * 64 + lane] = INFINITY;  // :1041-1043
   double worst = INFINITY;
@@ -97,6 +97,7 @@ __global__ void vecchia_nn_head_kernel(NNKernelArgs a, int d) {
   const int rows = (n < m + 1) ? n : m + 1;
   if (t >= rows * m) return;
   const int i = t / m, j = t % m;
+  if (i < a.start_at) return;
   a.nn[(size_t)i * m + j] = (j < i) ? j : -1;
   if (j < i) {                                                  // duplicate check of :799-811
     const double4 p = a.pts[j], q = a.pts[i];

@@ -155,6 +155,17 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_yaux(self.h, _p(out)))
         return out
 
+    def predict_obs_only(self, coords_pred, num_neighbors_pred, cov_type, var, a):
+        """-> (pred_mean, Dp, has_duplicates) for prediction points conditioning on the observed points only."""
+        cp = np.asarray(coords_pred, dtype=np.float64)
+        if cp.ndim == 1:
+            cp = cp.reshape(-1, 1)
+        cm = np.asfortranarray(cp)
+        mu = np.empty(cp.shape[0]); Dp = np.empty(cp.shape[0]); dup = C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_predict_obs_only(self.h, C.c_int(cp.shape[0]), _p(cm), C.c_int(int(num_neighbors_pred)),
+                                                           C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(mu), _p(Dp), C.byref(dup)))
+        return mu, Dp, bool(dup.value)
+
     def newton_leaf_values(self, leaf_index, num_leaves):
         """Needs factor(gauss=True) and yaux() for the current y = F - y; leaf_index in Vecchia order."""
         leaf = np.ascontiguousarray(leaf_index, dtype=np.int32)

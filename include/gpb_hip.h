@@ -152,6 +152,19 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host)
  * is y_aux.  Requires gpb_hip_vecchia_factor() on the same shard. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev);
 
+/* Prediction at new locations with vecchia_pred_type = "order_obs_first_cond_obs_only", Gaussian likelihood:
+ * replaces CalcPredVecchiaObservedFirstOrder(CondObsOnly = true) (src/GPBoost/Vecchia_utils.cpp:1701-2060): neighbour search of the
+ * prediction points among the OBSERVED points only (find_nearest_neighbors_Vecchia_fast with start_at = n_obs, end_search_at =
+ * n_obs - 1, :1792-1799, bit-identical) + the per-point factorisation (:1883-1975) on the device.
+ *   h                    the fitted state: observed coordinates (Vecchia order) and y (gpb_hip_vecchia_set_y)
+ *   coords_pred_colmajor n_pred x d, column-major
+ *   pred_mean            out: A_p y_nn  (= -Bpo y, :1989)
+ *   pred_D               out: Dp on the transformed scale, nugget 1 included (:1875-1877): predictive variance of the response is
+ *                        sigma^2 * Dp, of the latent process sigma^2 * (Dp - 1) */
+GPB_HIP_EXPORT int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor,
+                                                    int32_t num_neighbors_pred, int cov_type, double var, double a, double* pred_mean,
+                                                    double* pred_D, int* has_duplicates);
+
 /* Newton update of the tree leaf values in the GPBoost algorithm: replaces
  * REModelTemplate::NewtonUpdateLeafValues, Vecchia branch (include/GPBoost/re_model_template.h:4982-5063; B H and
  * (B H)^T D^-1 (B H) at :5005-5008, the L x L solve at :5056-5062).

@@ -139,6 +139,11 @@ GPBOOST_C_EXPORT int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data
  * factor + y_aux + H^T Psi^-1 H + solve in one call. */
 GPBOOST_C_EXPORT int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, double* cov_pars,
     const int32_t* data_leaf_index, int32_t num_leaves, double* leaf_values);
+/* Predictive mean and variance at new locations, vecchia_pred_type "order_obs_first_cond_obs_only" (the slice of
+ * GPB_PredictREModel, c_api.h:1640-1668, that runs CalcPredVecchiaObservedFirstOrder(CondObsOnly = true)): gp_coords_data_pred
+ * column-major num_data_pred x d; out_var (may be NULL) includes the error variance iff predict_response. */
+GPBOOST_C_EXPORT int GPB_HIP_PredictVecchiaObsOnly(REModelHandle handle, const double* y_data, double* cov_pars, int32_t num_data_pred,
+    const double* gp_coords_data_pred, int32_t num_neighbors_pred, bool predict_response, double* out_mean, double* out_var);
 /* Vecchia ordering (perm[k] = data index of the k-th point) and neighbour table (n x m, -1 padded) */
 GPBOOST_C_EXPORT int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn, int32_t* m_out);
 /* Diagnostics of the last Laplace evaluation (likelihood != "gaussian"): the nine values documented at

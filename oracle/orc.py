@@ -87,6 +87,35 @@ def neighbors(coords, m, want_sqd=False):
     return (nn, sqd) if want_sqd else nn
 
 
+def neighbors_range(coords, m, start_at, end_search_at):
+    """find_nearest_neighbors_Vecchia_fast with its start_at / end_search_at arguments; returns all n rows (rows < start_at = -1)."""
+    cm = np.asfortranarray(coords, dtype=np.float64)
+    n, d = cm.shape
+    m = min(m, (n - 2 if end_search_at < 0 else end_search_at) + 1)
+    ss = sort_indices(coords_sum(cm))
+    nn = np.empty((n, m), dtype=np.int32)
+    lib().orc_vecchia_neighbors_range(_p(cm, C.c_double), C.c_int(n), C.c_int(d), C.c_int(m), _p(ss, C.c_int), C.c_int(start_at),
+                                      C.c_int(end_search_at), _p(nn, C.c_int), None)
+    return nn
+
+
+def predict_obs_only(coords_obs, y_obs, coords_pred, cov_type, pars_trans, m_pred, predict_response=False):
+    """Vecchia prediction 'order_obs_first_cond_obs_only', Gaussian likelihood (CalcPredVecchiaObservedFirstOrder with
+    CondObsOnly = true, src/GPBoost/Vecchia_utils.cpp:1701-2060): every prediction point conditions on its m_pred nearest OBSERVED
+    points.  coords_obs / y_obs in Vecchia order; pars_trans = (sigma2, sigma1_2 / sigma2, a).  Returns (mean, var): var includes the
+    error variance iff predict_response (re_model_template.h: the nugget is added in the factor and subtracted again otherwise)."""
+    co = np.asarray(coords_obs, dtype=np.float64); cp = np.asarray(coords_pred, dtype=np.float64)
+    n_obs, n_pred = co.shape[0], cp.shape[0]
+    call = np.vstack([co, cp])
+    nn = neighbors_range(call, m_pred, n_obs, n_obs - 1)
+    A, D, bad = vecchia_factor(call, nn, cov_type, pars_trans[1], pars_trans[2], gauss=True)
+    yall = np.concatenate([np.asarray(y_obs, dtype=np.float64), np.zeros(n_pred)])
+    rows = slice(n_obs, n_obs + n_pred)
+    mean = np.einsum("ij,ij->i", A[rows], np.where(nn[rows] >= 0, yall[np.maximum(nn[rows], 0)], 0.))
+    var = pars_trans[0] * (D[rows] if predict_response else D[rows] - 1.0)
+    return mean, var
+
+
 def vecchia_factor(coords, nn, cov_type, var, a, gauss=True, grad=False):
     cm = np.asfortranarray(coords, dtype=np.float64)
     n, d = cm.shape

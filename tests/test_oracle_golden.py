@@ -187,3 +187,21 @@ def test_oracle_fix_histogram_matches_reference_fixture(orc):
             assert not np.array_equal(fixed, g["hist_" + key])
     parent, small = g["hist_fixed_leaf0_hess1"], g["hist_fixed_leaf1_hess1"]
     assert np.array_equal(orc.hist_subtract(parent, small), parent - small)
+
+
+# ---- Vecchia prediction, prediction points conditioning on observed points only ----------------------
+R_PRED_COV_PARS = np.array([0.03297349, 1.07691542, 0.11378505])       # the fitted parameters of :1319-1321
+R_PRED_COORDS = np.array([[0.1, 0.9], [0.10001, 0.90001], [0.7, 0.55]])  # :1326
+R_PRED_MU = np.array([0.06968068, 0.06967750, 0.44208925])               # :1329
+R_PRED_VAR = np.array([0.6214955, 0.6215069, 0.4199531])                 # diagonal of :1330-1331 (response scale)
+
+
+def test_r_golden_vecchia_prediction(orc):
+    """test_GPModel_gaussian_process.R:1326-1333: vecchia_pred_type = 'order_obs_first_cond_obs_only', num_neighbors_pred = 30."""
+    coords, y = orc.r_fixture()
+    pt = orc.transform_cov_pars(0, R_PRED_COV_PARS)
+    mu, var = orc.predict_obs_only(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=True)
+    assert np.abs(mu - R_PRED_MU).sum() < R_TOL
+    assert np.abs(var - R_PRED_VAR).sum() < R_TOL
+    mu2, var_latent = orc.predict_obs_only(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=False)
+    np.testing.assert_allclose(var - var_latent, R_PRED_COV_PARS[0], rtol=1e-12)

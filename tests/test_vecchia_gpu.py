@@ -431,3 +431,40 @@ def test_neighbor_search_parts_and_rccl_merges_single_rank(gpb, orc):
     st.set_y(y[perm]); st.factor(0, 10.0, 10.0)
     assert np.array_equal(st.yaux_allreduce(), st.yaux())
     st.close()
+
+
+# ---- prediction at new locations, conditioning on the observed points only --------------------------
+def test_prediction_r_suite_golden_values(gpb):
+    """test_GPModel_gaussian_process.R:1326-1333 (mean and response variance at three locations, two of them 1e-5 apart)."""
+    from tests.test_oracle_golden import R_PRED_COV_PARS, R_PRED_COORDS, R_PRED_MU, R_PRED_VAR
+    from oracle import orc
+    coords, y = orc.r_fixture()
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none")
+    pred = mdl.predict(y, R_PRED_COORDS, R_PRED_COV_PARS, predict_var=True, predict_response=True, num_neighbors_pred=30)
+    assert np.abs(pred["mu"] - R_PRED_MU).sum() < 1e-6
+    assert np.abs(pred["var"] - R_PRED_VAR).sum() < 1e-6
+    lat = mdl.predict(y, R_PRED_COORDS, R_PRED_COV_PARS, predict_var=True, predict_response=False)
+    np.testing.assert_allclose(pred["var"] - lat["var"], R_PRED_COV_PARS[0], rtol=1e-10)
+
+
+@pytest.mark.parametrize("n,npred,d,m,ct,ordering", [(20000, 5000, 2, 30, 0, "random"), (3000, 700, 3, 15, 2, "random"), (500, 33, 1, 10, 1, "none")])
+def test_prediction_against_oracle(gpb, orc, n, npred, d, m, ct, ordering):
+    cf, sh = {0: ("exponential", 0.5), 1: ("matern", 1.5), 2: ("matern", 2.5)}[ct]
+    coords, y = cases.synthetic(n, d, seed=31 + n)
+    rng = np.random.default_rng(n)
+    cpred = rng.uniform(size=(npred, d))
+    cpred[:3] = coords[:3]                                   # a few prediction points ON observed points
+    cp = np.array([0.2, 1.1, 0.15])
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m,
+                      vecchia_ordering=ordering, seed=4)
+    pred = mdl.predict(y, cpred, cp, predict_var=True, predict_response=False, num_neighbors_pred=m)
+    perm, _ = mdl.vecchia_structure()
+    mu, var = orc.predict_obs_only(coords[perm], y[perm], cpred, ct, orc.transform_cov_pars(ct, cp), m, predict_response=False)
+    np.testing.assert_allclose(pred["mu"], mu, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(pred["var"], var, rtol=1e-8, atol=1e-10)
+    # neighbour tables of the prediction rows are bit-identical to the reference's search (through the shim)
+    from gpboost_amd import shim
+    st = shim.VecchiaState.from_handle(mdl.vecchia_handle(), n, d, m)
+    mu2, Dp, dup = st.predict_obs_only(cpred, m, ct, cp[1] / cp[0], {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[2])
+    assert dup                                               # the three coinciding points
+    np.testing.assert_allclose(mu2, mu, rtol=1e-8, atol=1e-10)
