@@ -243,6 +243,28 @@ def main():
             except Exception as e:
                 out["roofline_cov_assembly"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1:
+            # LightGBM feature-histogram build at a size where GB/s means something (8d: n = 1e7 rows, F = 50,
+            # 255 bins, constant hessian): algorithmic bytes = rows * (F + 8 + 4) in + F * bins * 16 out
+            try:
+                nh, Fh, nbh = 10000000, 50, 255
+                rngh = np.random.default_rng(2)
+                binsh = rngh.integers(0, nbh, size=(Fh, nh), dtype=np.uint8)
+                boh = (np.arange(Fh + 1) * nbh).astype(np.int32)
+                hb = shim.HistBuilder(binsh, boh)
+                hb.set_gradients(rngh.standard_normal(nh), None)
+                del binsh
+                hb.bench(None, 1.0, 2)
+                ms_h = hb.bench(None, 1.0, 10)
+                hbytes = nh * (Fh + 8 + 4) + Fh * nbh * 16
+                out["roofline_histogram"] = {
+                    "bound": "hbm", "kernel": "hist_build_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
+                    "algorithmic_bytes_per_launch": hbytes,
+                    "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
+                    "note": "bounded by LDS fp64 atomics (2 per row and feature), not by HBM: see DESIGN.md 4.4"}
+                hb.close()
+            except Exception as e:
+                out["roofline_histogram"] = {"error": "%s: %s" % (type(e).__name__, e)}
             # BASELINE config 4: Vecchia-Laplace, Bernoulli-logit, n = 1e5, m = 30 -- seconds per evaluation
             try:
                 n4 = 100000

@@ -48,7 +48,9 @@ struct REModelHip {
   int n = 0, d = 0, m = 0;
   int cov_type = 0;
   std::vector<int> perm;        // data_indices_per_cluster_: Vecchia position -> data index
-  gpb_hip_vecchia_t* vh = nullptr;
+  gpb_hip_vecchia_t* vh = nullptr;          // cluster 0 (the only one unless cluster_ids distinguishes independent realisations)
+  std::vector<gpb_hip_vecchia_t*> vhs;      // one Vecchia state per cluster, in order of first appearance (re_model_template.h:6820-6852)
+  std::vector<int> cl_off;                  // offsets of the clusters in perm / ybuf (size #clusters + 1)
   gpb_hip_exact_t* eh = nullptr;   // gp_approx == "none": dense path, data order (no Vecchia ordering)
   std::vector<double> ybuf;     // y in Vecchia order
   double cur_negll = 0.;
@@ -61,7 +63,7 @@ struct REModelHip {
   double cg_delta_conv = 1e-2, delta_conv_mode_finding = 1e-8;
   std::vector<int> labels;      // y in {0,1}, Vecchia order
   double lap_info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  ~REModelHip() { if (vh) gpb_hip_vecchia_free(vh); if (eh) gpb_hip_exact_free(eh); }
+  ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); }
 };
 
 bool near(double a, double b) { return std::fabs(a - b) < 1e-10 * std::max({1.0, std::fabs(a), std::fabs(b)}); }  // utils.h:55
@@ -91,7 +93,8 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects)
     for (int k = 0; k < n; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]];
   }
   if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); return 0; }
-  if (gpb_hip_vecchia_set_y(mdl->vh, mdl->ybuf.data())) return shim_error();
+  for (size_t k = 0; k < mdl->vhs.size(); ++k)
+    if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf.data() + mdl->cl_off[k])) return shim_error();
   return 0;
 }
 
@@ -130,10 +133,6 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   const char* scope = "is not on the MI355X hot path of this library (one Gaussian Vecchia GP; see include/gpboost_c_api_subset.h)";
   if (num_re_group > 0 || num_re_group_rand_coef > 0) return set_error("GPB_CreateREModel: grouped random effects %s", scope);
   if (num_gp != 1 || num_gp_rand_coef > 0) return set_error("GPB_CreateREModel: num_gp = %d / num_gp_rand_coef = %d %s", num_gp, num_gp_rand_coef, scope);
-  if (cluster_ids_data) {
-    for (int i = 1; i < num_data; ++i)
-      if (cluster_ids_data[i] != cluster_ids_data[0]) return set_error("GPB_CreateREModel: more than one cluster %s", scope);
-  }
   if (has_weights) return set_error("GPB_CreateREModel: sample weights %s", scope);
   if (!gp_coords_data) return set_error("GPB_CreateREModel: gp_coords_data is NULL");
   const std::string cov = cov_fct ? cov_fct : "";
@@ -165,23 +164,50 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
+    if (cluster_ids_data)
+      for (int i = 1; i < num_data; ++i)
+        if (cluster_ids_data[i] != cluster_ids_data[0]) return set_error("GPB_CreateREModel: more than one cluster with gp_approx 'none' %s", scope);
     if (gpb_hip_exact_create(num_data, dim_gp_coords, gp_coords_data, &mdl->eh)) return shim_error();
     mdl->m = 0;
     *out = mdl.release();
     return 0;
   }
-  if (ordering == "random") {
-    std::mt19937 rng(seed);                                        // re_model_template.h:161, type_defs.h:52
-    std::shuffle(mdl->perm.begin(), mdl->perm.end(), rng);         // Vecchia_utils.cpp:1129-1131
+  // clusters = independent realisations of the GP, in order of first appearance (SetUpClusterIds, re_model_template.h:6820-6852)
+  std::vector<std::vector<int>> clusters;
+  if (cluster_ids_data) {
+    std::vector<int32_t> ids;
+    for (int i = 0; i < num_data; ++i) {
+      size_t k = 0;
+      while (k < ids.size() && ids[k] != cluster_ids_data[i]) ++k;
+      if (k == ids.size()) { ids.push_back(cluster_ids_data[i]); clusters.emplace_back(); }
+      if (ids.size() > 4096) return set_error("GPB_CreateREModel: more than 4096 clusters %s", scope);
+      clusters[k].push_back(i);
+    }
+  } else {
+    clusters.emplace_back(mdl->perm);
   }
-  std::vector<double> coords((size_t)num_data * dim_gp_coords);
-  for (int j = 0; j < dim_gp_coords; ++j)                          // Vecchia_utils.cpp:1132-1138
-    for (int k = 0; k < num_data; ++k) coords[(size_t)j * num_data + k] = gp_coords_data[(size_t)j * num_data + mdl->perm[k]];
-  if (gpb_hip_vecchia_create(num_data, dim_gp_coords, num_neighbors, coords.data(), &mdl->vh)) return shim_error();
-  int dup = 0;
-  if (gpb_hip_vecchia_find_neighbors(mdl->vh, &dup)) return shim_error();
-  mdl->has_duplicates = dup != 0;
-  mdl->m = std::min(num_neighbors, num_data - 1);
+  if (clusters.size() > 1 && lik != "gaussian") return set_error("GPB_CreateREModel: several clusters with likelihood '%s' %s", lik.c_str(), scope);
+  std::mt19937 rng(seed);                                          // ONE generator for all clusters (re_model_template.h:161, type_defs.h:52)
+  mdl->perm.clear(); mdl->cl_off.assign(1, 0);
+  mdl->m = 0;
+  for (auto& idx : clusters) {
+    const int nc = (int)idx.size();
+    if (nc < 2) return set_error("GPB_CreateREModel: a cluster with %d data point(s) %s", nc, scope);
+    if (ordering == "random") std::shuffle(idx.begin(), idx.end(), rng);   // Vecchia_utils.cpp:1129-1131
+    std::vector<double> coords((size_t)nc * dim_gp_coords);
+    for (int j = 0; j < dim_gp_coords; ++j)                          // Vecchia_utils.cpp:1132-1138
+      for (int k = 0; k < nc; ++k) coords[(size_t)j * nc + k] = gp_coords_data[(size_t)j * num_data + idx[k]];
+    gpb_hip_vecchia_t* vh = nullptr;
+    if (gpb_hip_vecchia_create(nc, dim_gp_coords, num_neighbors, coords.data(), &vh)) return shim_error();
+    mdl->vhs.push_back(vh);
+    int dup = 0;
+    if (gpb_hip_vecchia_find_neighbors(vh, &dup)) return shim_error();
+    mdl->has_duplicates = mdl->has_duplicates || dup != 0;
+    mdl->m = std::max(mdl->m, std::min(num_neighbors, nc - 1));
+    mdl->perm.insert(mdl->perm.end(), idx.begin(), idx.end());
+    mdl->cl_off.push_back((int)mdl->perm.size());
+  }
+  mdl->vh = mdl->vhs[0];
   *out = mdl.release();
   C_API_END();
 }
@@ -255,7 +281,13 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
   double t3[3] = {0., 0., 0.};
   if (mdl->eh) { if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t3, nullptr, nullptr)) return shim_error(); }
-  else if (gpb_hip_vecchia_nll_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], 1, t3)) return shim_error();
+  else {
+    for (auto* v : mdl->vhs) {      // block-diagonal Psi: the quadratic forms and log-determinants of the clusters add up
+      double t[3];
+      if (gpb_hip_vecchia_nll_terms(v, mdl->cov_type, tr[1], tr[2], 1, t)) return shim_error();
+      t3[0] += t[0]; t3[1] += t[1]; t3[2] += t[2];
+    }
+  }
   mdl->cur_negll = negll_from_terms(mdl->n, t3[0], t3[1], tr[0]);
   mdl->negll_valid = true;
   *negll = mdl->cur_negll;
@@ -290,8 +322,12 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
-  double t7[7];
-  if (gpb_hip_vecchia_grad_terms(mdl->vh, mdl->cov_type, tr[1], tr[2], t7)) return shim_error();
+  double t7[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (auto* v : mdl->vhs) {
+    double t[7];
+    if (gpb_hip_vecchia_grad_terms(v, mdl->cov_type, tr[1], tr[2], t)) return shim_error();
+    for (int q = 0; q < 7; ++q) t7[q] += t[q];
+  }
   mdl->cur_negll = negll_from_terms(mdl->n, t7[0], t7[1], tr[0]);
   mdl->negll_valid = true;
   *negll = mdl->cur_negll;
@@ -314,9 +350,11 @@ int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_par
     if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t2, y_aux, nullptr)) return shim_error();
     return 0;
   }
-  if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
   std::vector<double> ya(mdl->n);
-  if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
+  for (size_t c = 0; c < mdl->vhs.size(); ++c) {
+    if (gpb_hip_vecchia_factor(mdl->vhs[c], mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
+    if (gpb_hip_vecchia_yaux(mdl->vhs[c], ya.data() + mdl->cl_off[c])) return shim_error();
+  }
   for (int k = 0; k < mdl->n; ++k) y_aux[mdl->perm[k]] = ya[k];   // back to data order (GetYAux, :6430)
   C_API_END();
 }
@@ -328,6 +366,7 @@ int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, d
   if (!mdl || !cov_pars || !data_leaf_index || !leaf_values) return set_error("GPB_HIP_NewtonUpdateLeafValues: null argument");
   if (mdl->likelihood != "gaussian") return set_error("Newton updates for leaf values is only supported for Gaussian data");   // re_model_template.h:4986-4988
   if (mdl->eh) return set_error("GPB_HIP_NewtonUpdateLeafValues: the exact (dense) GP is not on the MI355X hot path of this library for this call");
+  if (mdl->vhs.size() != 1) return set_error("GPB_HIP_NewtonUpdateLeafValues: models with several clusters are not on the MI355X hot path of this library for this call");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, nullptr)) return -1;
@@ -346,7 +385,7 @@ int GPB_HIP_PredictVecchiaObsOnly(REModelHandle handle, const double* y_data, do
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !cov_pars || !gp_coords_data_pred || !out_mean) return set_error("GPB_HIP_PredictVecchiaObsOnly: null argument");
-  if (mdl->likelihood != "gaussian" || mdl->eh) return set_error("GPB_HIP_PredictVecchiaObsOnly: only the Gaussian Vecchia model is on the MI355X hot path of this library");
+  if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_HIP_PredictVecchiaObsOnly: only the one-cluster Gaussian Vecchia model is on the MI355X hot path of this library");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, nullptr)) return -1;
@@ -364,6 +403,7 @@ int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* perm, int32_t* nn
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl) return set_error("GPB_HIP_GetVecchiaStructure: null handle");
   if (mdl->eh) return set_error("GPB_HIP_GetVecchiaStructure: the model is an exact GP (gp_approx = 'none')");
+  if (mdl->vhs.size() != 1) return set_error("GPB_HIP_GetVecchiaStructure: the model has %d clusters (one neighbour table per cluster)", (int)mdl->vhs.size());
   if (perm) std::copy(mdl->perm.begin(), mdl->perm.end(), perm);
   if (m_out) *m_out = mdl->m;
   if (nn && gpb_hip_vecchia_get_neighbors(mdl->vh, nn)) return shim_error();
@@ -381,7 +421,7 @@ int GPB_HIP_GetLaplaceInfo(REModelHandle handle, double* out9) {
 
 void* GPB_HIP_GetVecchiaHandle(REModelHandle handle) {
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
-  return mdl ? mdl->vh : nullptr;
+  return (mdl && mdl->vhs.size() == 1) ? mdl->vh : nullptr;
 }
 
 }  // extern "C"

@@ -49,6 +49,7 @@ def main():
         print("wrote", name, "n=%d m=%d" % (mdl.n, mdl.m), "nll0=%.10f" % res["nll_0"])
     hist_fixture(out_dir)
     laplace_fixture(out_dir)
+    cluster_fixture(out_dir)
 
 
 def laplace_fixture(out_dir):
@@ -62,6 +63,17 @@ def laplace_fixture(out_dir):
             res["%s_negll_%d" % (name, k)] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
             print("laplace", name, cp, "negll = %.12f" % res["%s_negll_%d" % (name, k)])
     np.savez_compressed(os.path.join(out_dir, "laplace_ref.npz"), **res)
+
+
+def cluster_fixture(out_dir):
+    """Reference nll of a model with several clusters (independent GP realisations), random Vecchia ordering: pins the cluster
+    order (first appearance) and the ONE shared std::mt19937 that shuffles cluster after cluster."""
+    c = cases.CLUSTER_CASE
+    coords, y, ids = cases.make_cluster_data()
+    mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, cluster_ids=ids)
+    nll = mdl.neg_log_likelihood(np.asarray(c["cov_pars"], dtype=np.float64), y)
+    np.savez_compressed(os.path.join(out_dir, "clusters_ref.npz"), nll=np.float64(nll))
+    print("clusters: nll = %.12f" % nll)
 
 
 def hist_fixture(out_dir):
@@ -83,6 +95,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "clusters":
+        cluster_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "hist":
         hist_fixture(os.path.join(ROOT, "tests", "golden"))
     else:

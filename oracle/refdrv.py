@@ -91,15 +91,16 @@ class RefModel(object):
 # ---------------------------------------------------------------------------------------------
 class RefCAPIModel(object):
     def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1,
-                 likelihood="gaussian"):
+                 likelihood="gaussian", cluster_ids=None):
         self.L = C.CDLL(os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
         self.L.LGBM_GetLastError.restype = C.c_char_p
         cm = np.asfortranarray(coords, dtype=np.float64)
         self.n, self.d = cm.shape
         self.h = C.c_void_p()
         s = lambda x: C.c_char_p(x.encode())
+        cid = None if cluster_ids is None else np.ascontiguousarray(cluster_ids, dtype=np.int32)
         rc = self.L.GPB_CreateREModel(
-            C.c_int(self.n), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
+            C.c_int(self.n), C.c_void_p() if cid is None else _P(cid), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
             C.c_int(1), _P(cm), C.c_int(self.d), C.c_void_p(), C.c_int(0), s(cov_function), C.c_double(shape), s("vecchia"),
             C.c_double(1.), C.c_double(0.), C.c_int(m), s(ordering), C.c_int(500), C.c_double(1.), s("kmeans++"),
             s(likelihood), C.c_double(-999.), s("default"), C.c_int(seed), C.c_int(threads), C.c_bool(False),

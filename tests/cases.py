@@ -98,6 +98,19 @@ def make_leaf_index(name, n):
     return leaf.astype(np.int32), L
 
 
+# Several independent realisations of the GP (cluster_ids): reference GPB_EvalNegLogLikelihood stored in tests/golden/clusters_ref.npz
+CLUSTER_CASE = dict(n=1500, d=2, seed_data=41, num_clusters=3, cov_function="exponential", shape=0.5, m=12, ordering="random", seed=7,
+                    cov_pars=(0.2, 1.3, 0.1))
+
+
+def make_cluster_data(c=CLUSTER_CASE):
+    rng = np.random.default_rng(c["seed_data"])
+    coords = rng.uniform(size=(c["n"], c["d"]))
+    y = np.cos(3 * coords[:, 0]) + 0.4 * rng.standard_normal(c["n"])
+    ids = rng.integers(10, 10 + c["num_clusters"], size=c["n"]).astype(np.int32)      # interleaved, labels 10, 11, 12
+    return coords, y, ids
+
+
 def synthetic(n, d, seed=1):
     """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
     rng = np.random.default_rng(seed)

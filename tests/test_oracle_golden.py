@@ -205,3 +205,20 @@ def test_r_golden_vecchia_prediction(orc):
     assert np.abs(var - R_PRED_VAR).sum() < R_TOL
     mu2, var_latent = orc.predict_obs_only(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=False)
     np.testing.assert_allclose(var - var_latent, R_PRED_COV_PARS[0], rtol=1e-12)
+
+
+# ---- several clusters (independent realisations of the GP) ---------------------------------------------------------------------
+def test_r_golden_vecchia_cluster_ids(orc):
+    """test_GPModel_gaussian_process.R:1638-1648: cluster_ids = 40 x 1, 60 x 2; nll 129.3761486 at the fitted parameters
+    (stationary point of the fit: the 8-digit rounding of the parameters does not move the value at that precision)."""
+    coords, y = orc.r_fixture()
+    pt = orc.transform_cov_pars(0, np.array([0.05870373, 1.05572659, 0.12775754]))
+    ids = np.r_[np.ones(40), 2 * np.ones(60)]
+    quad = logdet = 0.0
+    for c in (1, 2):
+        sel = ids == c
+        perm, co, nn = orc.vecchia_setup(coords[sel], 30, "none", 0)
+        out = orc.vecchia_nll(co, nn, 0, pt, y[sel][perm])
+        quad += out[0]; logdet += out[1]
+    nll = quad / 2 / pt[0] + logdet / 2 + len(y) / 2 * (np.log(pt[0]) + np.log(2 * np.pi))
+    assert abs(nll - 129.3761486) < R_TOL

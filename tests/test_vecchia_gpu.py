@@ -468,3 +468,35 @@ def test_prediction_against_oracle(gpb, orc, n, npred, d, m, ct, ordering):
     mu2, Dp, dup = st.predict_obs_only(cpred, m, ct, cp[1] / cp[0], {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[2])
     assert dup                                               # the three coinciding points
     np.testing.assert_allclose(mu2, mu, rtol=1e-8, atol=1e-10)
+
+
+# ---- several clusters (independent realisations of the GP, cluster_ids) -------------------------------------------------------
+def test_cluster_ids_r_golden_and_reference_fixture(gpb, orc):
+    coords, y = orc.r_fixture()
+    ids = np.r_[np.ones(40), 2 * np.ones(60)].astype(np.int32)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none",
+                      cluster_ids=ids)
+    nll = mdl.neg_log_likelihood(np.array([0.05870373, 1.05572659, 0.12775754]), y)
+    assert abs(nll - 129.3761486) < 1e-6                      # test_GPModel_gaussian_process.R:1638-1648
+    # random ordering: clusters in order of first appearance, shuffled one after the other by ONE std::mt19937(seed)
+    c = cases.CLUSTER_CASE
+    coords, y, ids = cases.make_cluster_data()
+    ref = float(np.load(os.path.join(GOLD, "clusters_ref.npz"))["nll"])
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"], cluster_ids=ids)
+    cp = np.asarray(c["cov_pars"], dtype=np.float64)
+    nll = mdl.neg_log_likelihood(cp, y)
+    assert abs(nll - ref) <= RTOL * abs(ref)
+    # gradient and y_aux add up over clusters too: finite-difference check of the gradient, y_aux . y = quadratic form
+    nll2, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+    assert nll2 == nll
+    eps = 1e-6
+    lp = np.log(np.array([cp[0], cp[1] / cp[0], 1.0 / cp[2]]))
+    def f(l):
+        s2, v, a = np.exp(l)
+        return mdl.neg_log_likelihood(np.array([s2, v * s2, 1.0 / a]), y)
+    for k in range(3):
+        e = np.zeros(3); e[k] = eps
+        assert abs((f(lp + e) - f(lp - e)) / (2 * eps) - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
+    with pytest.raises(gpb.GPBoostError):
+        mdl.vecchia_structure()
