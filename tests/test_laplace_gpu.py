@@ -42,7 +42,7 @@ def test_against_reference_fixture(gpb, name):
     assert again == first
 
 
-@pytest.mark.parametrize("n,d,m,ct", [(5000, 2, 30, 0), (3000, 2, 10, 1), (700, 1, 5, 2)])
+@pytest.mark.parametrize("n,d,m,ct", [(5000, 2, 30, 0), (3000, 2, 10, 1), (700, 1, 5, 2), (4000, 3, 40, 0), (90, 2, 62, 1)])
 def test_against_oracle_with_details(gpb, orc, n, d, m, ct):
     """Same Newton path, mode, log-determinant as the oracle (the CG / Lanczos paths are identical up to rounding)."""
     from gpboost_amd import shim
