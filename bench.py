@@ -282,7 +282,7 @@ def main():
                     "workload": "Bernoulli-logit Vecchia-Laplace nll (Newton + vadu-CG + SLQ, 50 probes), n=%d, m=30, exponential" % n4,
                     "s_per_eval": s4, "negll": v4, "newton_it": i4["newton_it"], "cg_it": i4["cg_it"], "lanczos_it": i4["lanczos_it"],
                     "ms_mode_finding": i4["ms_mode"], "ms_logdet": i4["ms_logdet"],
-                    "reference_s_per_eval": {"value": 24.6, "cores": 8, "where": "same inputs class, this repo's container (DESIGN.md 4.6)"}}
+                    "reference_s_per_eval": {"value": 26.3, "cores": 8, "where": "same inputs, unmodified reference in this repo's build container (DESIGN.md 4.6)"}}
                 del m4
             except Exception as e:
                 out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
