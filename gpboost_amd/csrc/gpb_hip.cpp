@@ -125,6 +125,10 @@ struct gpb_hip_hist {
   ncclComm_t comm = nullptr;                               // optional: data-parallel histogram all-reduce (rows sharded per rank)
   double* d_pool = nullptr; int nslots = 0;                 // resident leaf histograms (HistogramPool), 2 * total_bins doubles each
   int* d_fix = nullptr; bool has_fix = false;              // view_offset[F], num_bin[F], most_freq_bin[F]
+  int* d_meta3 = nullptr; bool has_split_info = false;     // per feature: FeatureMetainfo::offset, default_bin, missing_type
+  std::vector<int> h_fix, h_meta3, h_bin_offsets;          // host copies for the scalar arguments of the partition kernel
+  int* d_part = nullptr; int part_cap = 0;                 // partition workspace: block counts / offsets, lte, gt
+  double* d_split = nullptr; int* d_split_i = nullptr; signed char* d_used = nullptr;   // split search outputs: F x 10, F + 1 ints
 };
 
 extern "C" {
@@ -885,6 +889,7 @@ int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins, co
   (void)hipFree(d_fm);
   HIP_OK(hipMalloc(&h->d_bin_offsets, sizeof(int) * (size_t)(num_features + 1)));
   HIP_OK(hipMemcpy(h->d_bin_offsets, bin_offsets, sizeof(int) * (size_t)(num_features + 1), hipMemcpyHostToDevice));
+  h->h_bin_offsets.assign(bin_offsets, bin_offsets + num_features + 1);
   HIP_OK(hipMalloc(&h->d_grad, sizeof(double) * (size_t)n));
   HIP_OK(hipMalloc(&h->d_hess, sizeof(double) * (size_t)n));
   HIP_OK(hipMalloc(&h->d_hist, sizeof(double) * 2 * (size_t)h->total_bins));
@@ -900,7 +905,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
-  dev_free(h->d_pool); dev_free(h->d_fix);
+  dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   delete h;
   API_END();
@@ -1041,6 +1046,8 @@ int gpb_hip_hist_set_fix_info(gpb_hip_hist_t* h, const int32_t* view_offset, con
   HIP_OK(hipMemcpy(h->d_fix, view_offset, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->d_fix + h->F, num_bin, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->d_fix + 2 * (size_t)h->F, most_freq_bin, sizeof(int) * (size_t)h->F, hipMemcpyHostToDevice));
+  h->h_fix.assign(view_offset, view_offset + h->F); h->h_fix.insert(h->h_fix.end(), num_bin, num_bin + h->F);
+  h->h_fix.insert(h->h_fix.end(), most_freq_bin, most_freq_bin + h->F);
   h->has_fix = true;
   API_END();
 }
@@ -1076,6 +1083,83 @@ int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent_slot, int32_t 
   if (!p || !sm || !o) return fail("gpb_hip_hist_subtract_slots: slot outside the pool of %d", h->nslots);
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(gpb::launch_hist_subtract(p, sm, o, 2 * h->total_bins, h->stream));
+  API_END();
+}
+
+int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const int32_t* default_bin, const int32_t* missing_type) {
+  API_BEGIN();
+  if (!h || !offset || !default_bin || !missing_type) return fail("null argument");
+  std::vector<int> m3((size_t)h->F * 3);
+  for (int f = 0; f < h->F; ++f) {
+    if (offset[f] < 0 || offset[f] > 1 || missing_type[f] < 0 || missing_type[f] > 2)
+      return fail("gpb_hip_hist_set_split_info: feature %d: offset %d / missing type %d", f, offset[f], missing_type[f]);
+    m3[3 * f] = offset[f]; m3[3 * f + 1] = default_bin[f]; m3[3 * f + 2] = missing_type[f];
+  }
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->d_meta3) HIP_OK(hipMalloc(&h->d_meta3, sizeof(int) * m3.size()));
+  HIP_OK(hipMemcpy(h->d_meta3, m3.data(), sizeof(int) * m3.size(), hipMemcpyHostToDevice));
+  h->h_meta3 = m3;
+  h->has_split_info = true;
+  API_END();
+}
+
+int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data, double lambda_l2,
+                                 int32_t min_data_in_leaf, double min_sum_hessian_in_leaf, double min_gain_to_split,
+                                 const int8_t* is_feature_used, int32_t* best_feature, double* per_feature_out10,
+                                 int32_t* per_feature_default_left) {
+  API_BEGIN();
+  if (!h || !best_feature) return fail("null argument");
+  double* src = hist_slot(h, slot);
+  if (!src) return fail("gpb_hip_hist_find_best_split: slot %d outside the pool of %d", slot, h->nslots);
+  if (!h->has_fix || !h->has_split_info) return fail("gpb_hip_hist_find_best_split: feature views / metas have not been set (gpb_hip_hist_set_fix_info, gpb_hip_hist_set_split_info)");
+  HIP_OK(hipSetDevice(h->device));
+  const int F = h->F;
+  if (!h->d_split) {
+    HIP_OK(hipMalloc(&h->d_split, sizeof(double) * (size_t)F * 10));
+    HIP_OK(hipMalloc(&h->d_split_i, sizeof(int) * (size_t)(F + 1)));
+    HIP_OK(hipMalloc(&h->d_used, (size_t)F));
+  }
+  if (is_feature_used) HIP_OK(hipMemcpyAsync(h->d_used, is_feature_used, (size_t)F, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(gpb::launch_hist_best_split(src, F, h->d_fix, h->d_fix + F, h->d_meta3, sum_gradient, sum_hessian, num_data, lambda_l2,
+                                     min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split, is_feature_used ? h->d_used : nullptr,
+                                     h->d_split, h->d_split_i, h->d_split_i + F, h->stream));
+  std::vector<int> ints(F + 1);
+  HIP_OK(hipMemcpyAsync(ints.data(), h->d_split_i, sizeof(int) * (size_t)(F + 1), hipMemcpyDeviceToHost, h->stream));
+  if (per_feature_out10) HIP_OK(hipMemcpyAsync(per_feature_out10, h->d_split, sizeof(double) * (size_t)F * 10, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *best_feature = ints[F];
+  if (per_feature_default_left) std::copy(ints.begin(), ints.begin() + F, per_feature_default_left);
+  API_END();
+}
+
+int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature, uint32_t threshold,
+                            int default_left, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count) {
+  API_BEGIN();
+  if (!h || !lte_out || !gt_out || !lte_count) return fail("null argument");
+  if (!h->has_fix || !h->has_split_info) return fail("gpb_hip_hist_split_leaf: feature metas have not been set (gpb_hip_hist_set_fix_info, gpb_hip_hist_set_split_info)");
+  if (feature < 0 || feature >= h->F) return fail("gpb_hip_hist_split_leaf: feature %d of %d", feature, h->F);
+  if (!data_indices) cnt = h->n;
+  if (cnt < 0 || cnt > h->n) return fail("gpb_hip_hist_split_leaf: cnt = %d", cnt);
+  *lte_count = 0;
+  if (cnt == 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  const int nblk = (cnt + 1023) / 1024;
+  const int need = 2 * (nblk + 1) + 3 * h->n;
+  if (h->part_cap < need) { dev_free(h->d_part); HIP_OK(hipMalloc(&h->d_part, sizeof(int) * (size_t)need)); h->part_cap = need; }
+  int *blk_cnt = h->d_part, *blk_off = blk_cnt + nblk + 1, *d_idx = blk_off + nblk + 1, *d_lte = d_idx + h->n, *d_gt = d_lte + h->n;
+  if (data_indices) HIP_OK(hipMemcpyAsync(d_idx, data_indices, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+  const int F = h->F;
+  const int max_bin = h->h_bin_offsets[feature + 1] - h->h_bin_offsets[feature] - 1;      // stored bins of the (single-feature) group - 1
+  HIP_OK(gpb::launch_hist_partition(h->d_bins_rm, h->fpad, feature, max_bin, h->h_meta3[3 * feature + 1], h->h_fix[2 * F + feature],
+                                    h->h_meta3[3 * feature + 2], default_left ? 1 : 0, threshold, data_indices ? d_idx : nullptr, cnt,
+                                    blk_cnt, blk_off, d_lte, d_gt, h->stream));
+  int nl = 0;
+  HIP_OK(hipMemcpyAsync(&nl, blk_off + nblk, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (nl > 0) HIP_OK(hipMemcpyAsync(lte_out, d_lte, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, h->stream));
+  if (cnt - nl > 0) HIP_OK(hipMemcpyAsync(gt_out, d_gt, sizeof(int) * (size_t)(cnt - nl), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *lte_count = nl;
   API_END();
 }
 

@@ -32,6 +32,13 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
 hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offset, const int* num_bin, const int* most_freq_bin,
                            double sum_gradient, double sum_hessian, hipStream_t st);
+hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
+                                  double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
+                                  double min_sum_hessian, double min_gain_to_split, const signed char* is_feature_used, double* out10,
+                                  int* out_default_left, int* best_feature, hipStream_t st);
+hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
+                                 int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
+                                 int* blk_off, int* lte, int* gt, hipStream_t st);
 hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st);
 hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
 

@@ -157,4 +157,245 @@ hipError_t launch_hist_subtract(const double* parent, const double* smaller, dou
   return hipGetLastError();
 }
 
+// ---- split search on a device-resident leaf histogram -----------------------------------------------
+// FeatureHistogram::FindBestThreshold for numerical features on the default regularisation path (lambda_l1 = 0, max_delta_step = 0,
+// path_smooth = 0, no monotone constraints, no extra_trees): src/LightGBM/treelearner/feature_histogram.hpp:85-95, :97-114, :163-207,
+// :857-1084, :797-836, :741-763; the winner among features as SerialTreeLearner::ComputeBestSplitForFeature +
+// SplitInfo::operator> pick it (serial_tree_learner.cpp:725-756, split_info.hpp:126-153).  One lane per feature walks its bins in the
+// reference's order with the reference's operations (contraction off: `hess * cnt_factor + 0.5f` must round twice), so every field of
+// the result is bit-identical given the same histogram; 50 features x 256 bins are microseconds.
+namespace {
+struct SplitOut { double gain, left_output, right_output, lsg, lsh, rsg, rsh; unsigned threshold; int left_count, right_count, default_left; };
+#pragma clang fp contract(off)
+__device__ void split_scan(const double* __restrict__ data, int num_bin, int offset, int default_bin, bool reverse, bool skip_default,
+                           int na_as_missing, double sum_gradient, double sum_hessian, int num_data, double min_gain_shift, double l2,
+                           int min_data_in_leaf, double min_sum_hessian, bool& is_splittable, SplitOut& output) {
+#pragma clang fp contract(off)
+  const double kEps = (double)1e-15f;                      // include/LightGBM/meta.h:54
+  double best_slg = NAN, best_slh = NAN, best_gain = -INFINITY;
+  int best_left_count = 0;
+  unsigned best_threshold = (unsigned)num_bin;
+  const double cnt_factor = num_data / sum_hessian;
+  if (reverse) {
+    double srg = 0.0, srh = kEps;
+    int right_count = 0;
+    int t = num_bin - 1 - offset - na_as_missing;
+    const int t_end = 1 - offset;
+    for (; t >= t_end; --t) {
+      if (skip_default && (t + offset) == default_bin) continue;
+      const double grad = data[2 * t], hess = data[2 * t + 1];
+      const int cnt = (int)(hess * cnt_factor + 0.5f);      // Common::RoundInt, utils/common.h:920-922
+      srg += grad; srh += hess; right_count += cnt;
+      if (right_count < min_data_in_leaf || srh < min_sum_hessian) continue;
+      const int left_count = num_data - right_count;
+      if (left_count < min_data_in_leaf) break;
+      const double slh = sum_hessian - srh;
+      if (slh < min_sum_hessian) break;
+      const double slg = sum_gradient - srg;
+      const double current_gain = (slg * slg) / (slh + l2) + (srg * srg) / (srh + l2);
+      if (current_gain <= min_gain_shift) continue;
+      is_splittable = true;
+      if (current_gain > best_gain) {
+        best_left_count = left_count; best_slg = slg; best_slh = slh;
+        best_threshold = (unsigned)(t - 1 + offset);
+        best_gain = current_gain;
+      }
+    }
+  } else {
+    double slg = 0.0, slh = kEps;
+    int left_count = 0;
+    int t = 0;
+    const int t_end = num_bin - 2 - offset;
+    if (na_as_missing && offset == 1) {
+      slg = sum_gradient; slh = sum_hessian - kEps; left_count = num_data;
+      for (int i = 0; i < num_bin - offset; ++i) {
+        const double grad = data[2 * i], hess = data[2 * i + 1];
+        slg -= grad; slh -= hess; left_count -= (int)(hess * cnt_factor + 0.5f);
+      }
+      t = -1;
+    }
+    for (; t <= t_end; ++t) {
+      if (skip_default && (t + offset) == default_bin) continue;
+      if (t >= 0) {
+        slg += data[2 * t]; slh += data[2 * t + 1];
+        left_count += (int)(data[2 * t + 1] * cnt_factor + 0.5f);
+      }
+      if (left_count < min_data_in_leaf || slh < min_sum_hessian) continue;
+      const int right_count = num_data - left_count;
+      if (right_count < min_data_in_leaf) break;
+      const double srh = sum_hessian - slh;
+      if (srh < min_sum_hessian) break;
+      const double srg = sum_gradient - slg;
+      const double current_gain = (slg * slg) / (slh + l2) + (srg * srg) / (srh + l2);
+      if (current_gain <= min_gain_shift) continue;
+      is_splittable = true;
+      if (current_gain > best_gain) {
+        best_left_count = left_count; best_slg = slg; best_slh = slh;
+        best_threshold = (unsigned)(t + offset);
+        best_gain = current_gain;
+      }
+    }
+  }
+  if (is_splittable && best_gain > output.gain + min_gain_shift) {
+    output.threshold = best_threshold;
+    output.left_output = -best_slg / (best_slh + l2);
+    output.left_count = best_left_count;
+    output.lsg = best_slg; output.lsh = best_slh - kEps;
+    output.right_output = -(sum_gradient - best_slg) / (sum_hessian - best_slh + l2);
+    output.right_count = num_data - best_left_count;
+    output.rsg = sum_gradient - best_slg; output.rsh = sum_hessian - best_slh - kEps;
+    output.gain = best_gain - min_gain_shift;
+    output.default_left = reverse ? 1 : 0;
+  }
+}
+}  // namespace
+
+__global__ void hist_best_split_kernel(const double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
+                                       const int* __restrict__ num_bin, const int* __restrict__ meta3 /* offset, default_bin, missing */,
+                                       double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2, int min_data_in_leaf,
+                                       double min_sum_hessian, double min_gain_to_split, double* __restrict__ out10,
+                                       int* __restrict__ out_default_left) {
+#pragma clang fp contract(off)
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_features) return;
+  const double kEps = (double)1e-15f;
+  const double* data = hist + (size_t)view_offset[f] * 2;
+  const int nb = num_bin[f], offset = meta3[3 * f], default_bin = meta3[3 * f + 1], missing = meta3[3 * f + 2];
+  const double sum_hessian = sum_hessian_leaf + 2 * kEps;
+  SplitOut o;
+  o.gain = -INFINITY; o.left_output = 0.0; o.right_output = 0.0; o.lsg = 0.0; o.lsh = 0.0; o.rsg = 0.0; o.rsh = 0.0;
+  o.threshold = 0; o.left_count = 0; o.right_count = 0; o.default_left = 1;
+  bool splittable = false;
+  const double min_gain_shift = (sum_gradient * sum_gradient) / (sum_hessian + lambda_l2) + min_gain_to_split;
+  if (nb > 2 && missing != 0) {
+    const bool zero = missing == 1;
+    split_scan(data, nb, offset, default_bin, true, zero, zero ? 0 : 1, sum_gradient, sum_hessian, num_data, min_gain_shift, lambda_l2,
+               min_data_in_leaf, min_sum_hessian, splittable, o);
+    split_scan(data, nb, offset, default_bin, false, zero, zero ? 0 : 1, sum_gradient, sum_hessian, num_data, min_gain_shift, lambda_l2,
+               min_data_in_leaf, min_sum_hessian, splittable, o);
+  } else {
+    split_scan(data, nb, offset, default_bin, true, false, 0, sum_gradient, sum_hessian, num_data, min_gain_shift, lambda_l2,
+               min_data_in_leaf, min_sum_hessian, splittable, o);
+    if (missing == 2) o.default_left = 0;
+  }
+  double* r = out10 + (size_t)f * 10;
+  r[0] = o.gain; r[1] = (double)o.threshold; r[2] = o.left_count; r[3] = o.right_count; r[4] = o.left_output; r[5] = o.right_output;
+  r[6] = o.lsg; r[7] = o.lsh; r[8] = o.rsg; r[9] = o.rsh;
+  out_default_left[f] = o.default_left;
+}
+
+// the winner: larger gain, equal gains -> smaller feature index; features masked out by is_feature_used never win
+__global__ void hist_pick_split_kernel(const double* __restrict__ out10, int num_features, const signed char* __restrict__ is_feature_used,
+                                       int* __restrict__ best_feature) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int best_f = 2147483647;
+  double best_gain = -INFINITY;
+  for (int f = 0; f < num_features; ++f) {
+    if (is_feature_used && !is_feature_used[f]) continue;
+    const double g = out10[(size_t)f * 10];
+    if (g != best_gain ? g > best_gain : f < best_f) { best_gain = g; best_f = f; }
+  }
+  *best_feature = best_f == 2147483647 ? -1 : best_f;
+}
+
+hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
+                                  double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
+                                  double min_sum_hessian, double min_gain_to_split, const signed char* is_feature_used, double* out10,
+                                  int* out_default_left, int* best_feature, hipStream_t st) {
+  hipLaunchKernelGGL(hist_best_split_kernel, dim3((num_features + 63) / 64), dim3(64), 0, st, hist, num_features, view_offset, num_bin, meta3,
+                     sum_gradient, sum_hessian, num_data, lambda_l2, min_data_in_leaf, min_sum_hessian, min_gain_to_split, out10,
+                     out_default_left);
+  hipLaunchKernelGGL(hist_pick_split_kernel, dim3(1), dim3(64), 0, st, (const double*)out10, num_features, is_feature_used, best_feature);
+  return hipGetLastError();
+}
+
+// ---- partition of a leaf's rows by a numerical split (second half of SURVEY.md 8f rank 2) ---------------------------------
+// DataPartition::Split -> Dataset::Split -> DenseBin::Split / SplitInner (src/LightGBM/io/dense_bin.hpp:176-307, single-feature
+// group: min_bin = 1, USE_MIN_BIN = false).  A stable partition: both sides keep the order of data_indices, as the reference's
+// per-thread blocks do when they are concatenated.  Three small kernels: per-block count of rows going left, exclusive scan of
+// the block counts, classify again + scatter (1024 rows per block, 4 consecutive rows per lane).
+namespace {
+struct SplitRule { int max_bin, t_zero_bin, th, miss_zero, miss_na, mfb_zero, mfb_na, default_goes_left, missing_goes_left; };
+__device__ __forceinline__ bool goes_left(const SplitRule& r, int bin) {
+  if (1 < r.max_bin) {
+    if ((r.miss_zero && !r.mfb_zero && bin == r.t_zero_bin) || (r.miss_na && !r.mfb_na && bin == r.max_bin)) return r.missing_goes_left;
+    if (bin == 0) return ((r.miss_na && r.mfb_na) || (r.miss_zero && r.mfb_zero)) ? r.missing_goes_left : r.default_goes_left;
+    return !(bin > r.th);
+  }
+  if (r.miss_zero && !r.mfb_zero && bin == r.t_zero_bin) return r.missing_goes_left;
+  if (bin != r.max_bin) return ((r.miss_na && r.mfb_na) || (r.miss_zero && r.mfb_zero)) ? r.missing_goes_left : r.default_goes_left;
+  return (r.miss_na && !r.mfb_na) ? r.missing_goes_left : (r.max_bin <= r.th);
+}
+}  // namespace
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void hist_partition_kernel(const uint8_t* __restrict__ bins_rm, int fpad, int feature, SplitRule rule,
+                                                             const int* __restrict__ data_indices, int cnt, int* __restrict__ blk_cnt,
+                                                             const int* __restrict__ blk_off, int* __restrict__ lte, int* __restrict__ gt) {
+  __shared__ int s_scan[256];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 1024 + tid * 4;
+  int idx[4]; bool left[4];
+  int nl = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = base + k;
+    left[k] = false; idx[k] = 0;
+    if (p < cnt) {
+      idx[k] = data_indices ? data_indices[p] : p;
+      left[k] = goes_left(rule, (int)bins_rm[(size_t)idx[k] * fpad + feature]);
+      nl += left[k] ? 1 : 0;
+    }
+  }
+  s_scan[tid] = nl;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {            // inclusive scan of the per-lane counts
+    const int v = tid >= o ? s_scan[tid - o] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  if (!SCATTER) {
+    if (tid == 255) blk_cnt[blockIdx.x] = s_scan[255];
+    return;
+  }
+  int l = blk_off[blockIdx.x] + s_scan[tid] - nl;                      // rows going left before this lane's first row
+  int g = (blockIdx.x * 1024 + tid * 4) - l;                           // rows going right before it = position - lefts
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < cnt) { if (left[k]) lte[l++] = idx[k]; else gt[g++] = idx[k]; }
+  }
+}
+
+// exclusive scan of the block counts (one block; nblk is small: cnt / 1024), total written to off[nblk]
+__global__ void hist_partition_scan_kernel(const int* __restrict__ blk_cnt, int nblk, int* __restrict__ off) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int run = 0;
+  for (int b = 0; b < nblk; ++b) { off[b] = run; run += blk_cnt[b]; }
+  off[nblk] = run;
+}
+
+hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
+                                 int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
+                                 int* blk_off, int* lte, int* gt, hipStream_t st) {
+  SplitRule r;
+  r.max_bin = max_bin;
+  r.miss_zero = missing_type == 1; r.miss_na = missing_type == 2;
+  r.mfb_zero = r.miss_zero && default_bin == most_freq_bin;                          // dense_bin.hpp:268-272
+  r.mfb_na = r.miss_na && (max_bin == most_freq_bin + 1 && most_freq_bin > 0);       // :294-298 with min_bin = 1
+  int th = (int)((threshold + 1u) & 0xffu), tz = (1 + default_bin) & 0xff;           // VAL_T = uint8_t arithmetic (:182-187)
+  if (most_freq_bin == 0) { th = (th - 1) & 0xff; tz = (tz - 1) & 0xff; }
+  r.th = th; r.t_zero_bin = tz;
+  r.default_goes_left = (unsigned)most_freq_bin <= threshold;                        // :196-199
+  r.missing_goes_left = (r.miss_zero || r.miss_na) && default_left;                  // :200-205
+  const int nblk = (cnt + 1023) / 1024;
+  if (nblk == 0) return hipSuccess;
+  hipLaunchKernelGGL(hist_partition_kernel<false>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, data_indices, cnt, blk_cnt,
+                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(hist_partition_scan_kernel, dim3(1), dim3(64), 0, st, (const int*)blk_cnt, nblk, blk_off);
+  hipLaunchKernelGGL(hist_partition_kernel<true>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, data_indices, cnt, blk_cnt,
+                     (const int*)blk_off, lte, gt);
+  return hipGetLastError();
+}
+
 }  // namespace gpb

@@ -344,6 +344,30 @@ class HistBuilder(object):
     def subtract_slots(self, parent, smaller, out):
         _shim_call(_lib().gpb_hip_hist_subtract_slots(self.h, C.c_int(int(parent)), C.c_int(int(smaller)), C.c_int(int(out))))
 
+    def set_split_info(self, offset, default_bin, missing_type):
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (offset, default_bin, missing_type)]
+        _shim_call(_lib().gpb_hip_hist_set_split_info(self.h, *[_p(x, C.c_int) for x in a]))
+
+    def find_best_split(self, slot, sum_gradient, sum_hessian, num_data, lambda_l2=0.0, min_data_in_leaf=20,
+                        min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, is_feature_used=None):
+        """-> (best_feature, out (F, 10), default_left (F,)): FeatureHistogram::FindBestThreshold per feature + the winner."""
+        out = np.empty((self.F, 10)); dl = np.empty(self.F, dtype=np.int32); best = C.c_int(-1)
+        used = None if is_feature_used is None else np.ascontiguousarray(is_feature_used, dtype=np.int8)
+        _shim_call(_lib().gpb_hip_hist_find_best_split(self.h, C.c_int(int(slot)), C.c_double(sum_gradient), C.c_double(sum_hessian),
+                                                       C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
+                                                       C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split),
+                                                       _p(used, C.c_int8), C.byref(best), _p(out), _p(dl, C.c_int)))
+        return best.value, out, dl
+
+    def split_leaf(self, data_indices, feature, threshold, default_left):
+        """-> (lte_indices, gt_indices), both in the order of data_indices (None = all rows)."""
+        idx = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
+        cnt = self.n if idx is None else idx.size
+        lte = np.empty(cnt, dtype=np.int32); gt = np.empty(cnt, dtype=np.int32); nl = C.c_int(0)
+        _shim_call(_lib().gpb_hip_hist_split_leaf(self.h, _p(idx, C.c_int), C.c_int(cnt), C.c_int(int(feature)), C.c_uint(int(threshold)),
+                                                  C.c_int(int(bool(default_left))), _p(lte, C.c_int), _p(gt, C.c_int), C.byref(nl)))
+        return lte[:nl.value].copy(), gt[:cnt - nl.value].copy()
+
     def get_slot(self, slot):
         out = np.empty((self.total_bins, 2))
         _shim_call(_lib().gpb_hip_hist_get_slot(self.h, C.c_int(int(slot)), _p(out)))

@@ -267,6 +267,30 @@ GPB_HIP_EXPORT int gpb_hip_hist_fix_slot(gpb_hip_hist_t* h, int32_t slot, double
 GPB_HIP_EXPORT int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent_slot, int32_t smaller_slot, int32_t out_slot);
 GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out);
 
+/* Split search on a device-resident (fixed) leaf histogram -- SURVEY.md 8f rank 2: FeatureHistogram::FindBestThreshold for every
+ * numerical feature (src/LightGBM/treelearner/feature_histogram.hpp:85-95, :857-1084; all three missing-value types :163-207) and the
+ * choice among features (serial_tree_learner.cpp:725-756, split_info.hpp:126-153), default regularisation path only (lambda_l1 = 0,
+ * max_delta_step = 0, path_smooth = 0, no monotone constraints / extra_trees / CEGB).  Bit-identical to the reference given the histogram.
+ *   set_split_info   per feature: FeatureMetainfo::offset (1 iff most_freq_bin == 0), BinMapper::GetDefaultBin(), missing type
+ *                    (0 None, 1 Zero, 2 NaN; include/LightGBM/bin.h:27-31); views / num_bin come from gpb_hip_hist_set_fix_info
+ *   find_best_split  leaf totals sum_gradient / sum_hessian / num_data as LeafSplits holds them; config values lambda_l2,
+ *                    min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split; is_feature_used (may be NULL) as in :753
+ *                    best_feature: inner feature index (-1 if the mask is empty); per_feature_out10 (may be NULL): F x 10 doubles =
+ *                    SplitInfo {gain, threshold, left_count, right_count, left_output, right_output, left_sum_gradient,
+ *                    left_sum_hessian, right_sum_gradient, right_sum_hessian}; per_feature_default_left (may be NULL) */
+/* Partition of a leaf's rows by a numerical split: DataPartition::Split (src/LightGBM/treelearner/data_partition.hpp:101-130) ->
+ * Dataset::Split (dataset.h:506-516) -> DenseBin::Split / SplitInner (src/LightGBM/io/dense_bin.hpp:176-307; single-feature groups,
+ * all missing-value variants).  Stable: lte_out and gt_out (each sized cnt by the caller) keep the order of data_indices
+ * (NULL = all rows); *lte_count = rows going left.  threshold / default_left as SplitInfo holds them (inner feature index). */
+GPB_HIP_EXPORT int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature,
+                                           uint32_t threshold, int default_left, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count);
+GPB_HIP_EXPORT int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const int32_t* default_bin,
+                                               const int32_t* missing_type);
+GPB_HIP_EXPORT int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data,
+                                                double lambda_l2, int32_t min_data_in_leaf, double min_sum_hessian_in_leaf,
+                                                double min_gain_to_split, const int8_t* is_feature_used, int32_t* best_feature,
+                                                double* per_feature_out10, int32_t* per_feature_default_left);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ def main():
     hist_fixture(out_dir)
     laplace_fixture(out_dir)
     cluster_fixture(out_dir)
+    split_fixture(out_dir)
 
 
 def laplace_fixture(out_dir):
@@ -63,6 +64,33 @@ def laplace_fixture(out_dir):
             res["%s_negll_%d" % (name, k)] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
             print("laplace", name, cp, "negll = %.12f" % res["%s_negll_%d" % (name, k)])
     np.savez_compressed(os.path.join(out_dir, "laplace_ref.npz"), **res)
+
+
+def split_fixture(out_dir):
+    """The reference's FeatureHistogram::FindBestThreshold on its own (fixed) histograms: all inputs of the call + its outputs."""
+    res = {}
+    for name in cases.SPLIT_DATA:
+        X, g, h, leaf = cases.make_split_data(name)
+        for ci, cfg in enumerate(cases.SPLIT_CFGS):
+            for li, di in enumerate((None, leaf)):
+                for hi, hs in enumerate((None, h)):
+                    bins, gnb, hist, fx = refdrv.ref_histogram(X, 63, di, g, hs, 1.0, with_fix=True,
+                                                               extra_params=cases.SPLIT_DATA[name]["params"], split_cfg=cfg)
+                    key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                    res[name + "_bins"] = bins; res[name + "_group_num_bin"] = gnb
+                    res[name + "_view_offset"] = fx["view_offset"]; res[name + "_num_bin"] = fx["num_bin"]
+                    res[name + "_most_freq_bin"] = fx["most_freq_bin"]; res[name + "_meta3"] = fx["meta3"]
+                    res[key + "_hist_fixed"] = fx["hist_fixed"]; res[key + "_sums"] = fx["sums"]
+                    res[key + "_split"] = fx["split"]; res[key + "_default_left"] = fx["split_default_left"]
+        # Dataset::Split of the leaf's rows for a grid of (feature, threshold, default_left)
+        req = cases.split_partition_requests(res[name + "_num_bin"])
+        _, _, _, fx = refdrv.ref_histogram(X, 63, leaf, g, None, 1.0, with_fix=True, extra_params=cases.SPLIT_DATA[name]["params"],
+                                           partitions=req)
+        res[name + "_part_req"] = np.asarray(req, dtype=np.int32)
+        res[name + "_part_lte_count"] = np.asarray([len(a) for a in fx["part_lte"]], dtype=np.int32)
+        res[name + "_part_lte"] = np.concatenate(fx["part_lte"]).astype(np.int32)
+        print("split fixture", name, "missing types", res[name + "_meta3"][:, 2], "num_bin", res[name + "_num_bin"])
+    np.savez_compressed(os.path.join(out_dir, "split_ref.npz"), **res)
 
 
 def cluster_fixture(out_dir):
@@ -95,6 +123,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "split":
+        split_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "clusters":
         cluster_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "hist":

@@ -210,6 +210,34 @@ def hist_subtract(parent, smaller):
     return out
 
 
+def find_best_split(hist, view_offset, num_bin, offset, default_bin, missing, sum_gradient, sum_hessian, num_data, lambda_l2=0.0,
+                    min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0):
+    """FeatureHistogram::FindBestThreshold for every (numerical) feature + the choice among features.
+    -> (best_feature, out (F, 10), default_left (F,)); columns of out: gain, threshold, left_count, right_count, left_output,
+    right_output, left_sum_gradient, left_sum_hessian, right_sum_gradient, right_sum_hessian."""
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (view_offset, num_bin, offset, default_bin, missing)]
+    F = arrs[0].size
+    out = np.zeros((F, 10)); dl = np.zeros(F, dtype=np.int32)
+    lib().orc_find_best_split.restype = C.c_int
+    best = lib().orc_find_best_split(_p(h, C.c_double), C.c_int(F), *[_p(a, C.c_int) for a in arrs], C.c_double(sum_gradient),
+                                     C.c_double(sum_hessian), C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
+                                     C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), _p(out, C.c_double), _p(dl, C.c_int))
+    return best, out, dl
+
+
+def split_leaf(bins_f, max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, data_indices):
+    """DenseBin::Split for a single-feature group: (lte_indices, gt_indices), both in the order of data_indices."""
+    b = np.ascontiguousarray(bins_f, dtype=np.uint8)
+    di = np.ascontiguousarray(data_indices, dtype=np.int32)
+    lte = np.empty(di.size, dtype=np.int32); gt = np.empty(di.size, dtype=np.int32)
+    lib().orc_split_leaf.restype = C.c_int
+    nl = lib().orc_split_leaf(_p(b, C.c_ubyte), C.c_int(int(max_bin)), C.c_int(int(default_bin)), C.c_int(int(most_freq_bin)),
+                              C.c_int(int(missing_type)), C.c_int(int(bool(default_left))), C.c_uint(int(threshold)), _p(di, C.c_int),
+                              C.c_int(di.size), _p(lte, C.c_int), _p(gt, C.c_int))
+    return lte[:nl].copy(), gt[:di.size - nl].copy()
+
+
 def newton_leaf_values(A, D, nn, yaux, leaf, num_leaves):
     """REModelTemplate::NewtonUpdateLeafValues, Vecchia branch: leaf values of the Newton step.  A, D from
     vecchia_factor(gauss=True); yaux = B^T D^-1 B (F - y); leaf = leaf index per point; all in Vecchia order."""

@@ -24,6 +24,9 @@
 #include <LightGBM/dataset.h>
 #include <LightGBM/feature_group.h>
 #include <LightGBM/train_share_states.h>
+#include <LightGBM/config.h>
+#include <LightGBM/tree.h>
+#include <LightGBM/treelearner/feature_histogram.hpp>   /* src/LightGBM/treelearner (Makefile.ref adds -I$(REF)/src) */
 #undef private
 #undef protected
 
@@ -141,11 +144,14 @@ __attribute__((visibility("default")))
 int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* data_indices, int num_data,
                 const double* grad, const double* hess, double const_hess, int* num_groups_out, int* group_num_bin,
                 unsigned char* bins_out, double* hist_out, int* feat_view_offset, int* feat_num_bin, int* feat_most_freq_bin,
-                double* sums2, double* hist_fixed_out) {
+                double* sums2, double* hist_fixed_out, const char* extra_params, const double* split_cfg4, int* feat_meta3,
+                double* split_out10, int* split_default_left, int num_part, const int* part_ftd3, int* part_lte_out,
+                int* part_lte_count) {
   try {
     using namespace LightGBM;
     char params[256];
-    snprintf(params, sizeof(params), "max_bin=%d min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=4", max_bin);
+    snprintf(params, sizeof(params), "max_bin=%d min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=4 %s", max_bin,
+             extra_params ? extra_params : "");
     DatasetHandle dh = nullptr;
     if (LGBM_DatasetCreateFromMat(X_rowmajor, C_API_DTYPE_FLOAT64, n, F, 1, params, nullptr, &dh) != 0) {
       fprintf(stderr, "refdrv_hist: %s\n", LGBM_GetLastError());
@@ -183,6 +189,41 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
         ds->FixHistogram(f, sg, sh, hist.data() + (size_t)off * 2);
       }
       std::copy(hist.begin(), hist.begin() + (size_t)ds->NumTotalBin() * 2, hist_fixed_out);
+      /* FeatureHistogram::FindBestThreshold of every feature on the fixed histogram, exactly as
+       * SerialTreeLearner::ComputeBestSplitForFeature calls it (serial_tree_learner.cpp:736-740); feature metas from the
+       * reference's own HistogramPool::SetFeatureInfo (feature_histogram.hpp:1146-1182).
+       * split_cfg4 = { lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split } */
+      if (split_out10) {
+        Config config;
+        config.lambda_l2 = split_cfg4[0]; config.min_data_in_leaf = (int)split_cfg4[1];
+        config.min_sum_hessian_in_leaf = split_cfg4[2]; config.min_gain_to_split = split_cfg4[3];
+        std::vector<FeatureMetainfo> metas;
+        HistogramPool::SetFeatureInfo<true, true>(ds, &config, &metas);
+        /* root leaf: parent_output as GetParentOutput computes it (serial_tree_learner.cpp:758-770); unused without smoothing */
+        const double parent_output = -sg / (sh + config.lambda_l2);
+        for (int f = 0; f < ds->num_features(); ++f) {
+          feat_meta3[3 * f] = metas[f].offset; feat_meta3[3 * f + 1] = (int)metas[f].default_bin; feat_meta3[3 * f + 2] = (int)metas[f].missing_type;
+          FeatureHistogram fh;
+          fh.Init(hist.data() + (size_t)feat_view_offset[f] * 2, &metas[f]);
+          SplitInfo si;
+          fh.FindBestThreshold(sg, sh, num_data, nullptr, parent_output, &si);
+          double* r = split_out10 + (size_t)f * 10;
+          r[0] = si.gain; r[1] = (double)si.threshold; r[2] = si.left_count; r[3] = si.right_count; r[4] = si.left_output;
+          r[5] = si.right_output; r[6] = si.left_sum_gradient; r[7] = si.left_sum_hessian; r[8] = si.right_sum_gradient; r[9] = si.right_sum_hessian;
+          split_default_left[f] = si.default_left ? 1 : 0;
+        }
+      }
+    }
+    /* Dataset::Split (include/LightGBM/dataset.h:506-516 -> FeatureGroup::Split, feature_group.h:345-376 -> DenseBin::Split /
+     * SplitInner, src/LightGBM/io/dense_bin.hpp:176-282) of the leaf's rows for num_part (feature, threshold, default_left)
+     * triples; the lte list of request p goes to part_lte_out + p * num_data (gt = the remaining rows in their original order) */
+    for (int p = 0; p < num_part; ++p) {
+      std::vector<data_size_t> idx(num_data), lte(num_data), gt(num_data);
+      for (int k = 0; k < num_data; ++k) idx[k] = data_indices ? data_indices[k] : k;
+      const uint32_t th = (uint32_t)part_ftd3[3 * p + 1];
+      const data_size_t nl = ds->Split(part_ftd3[3 * p], &th, 1, part_ftd3[3 * p + 2] != 0, idx.data(), num_data, lte.data(), gt.data());
+      part_lte_count[p] = nl;
+      std::copy(lte.begin(), lte.begin() + nl, part_lte_out + (size_t)p * num_data);
     }
     LGBM_DatasetFree(dh);
     return 0;

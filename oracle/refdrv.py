@@ -124,11 +124,14 @@ class RefCAPIModel(object):
             pass
 
 
-def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False):
+def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False, extra_params="", split_cfg=None,
+                  partitions=None):
     """The reference's own binning + Dataset::ConstructHistograms for one leaf.
     Returns (bins uint8 (G, n) = the reference's stored group bins, group_num_bin (G,), hist (sum bins, 2)); with_fix=True adds
     a dict with the per-feature view offsets / num_bin / most_freq_bin, the leaf sums and the histogram after
-    Dataset::FixHistogram on every feature."""
+    Dataset::FixHistogram on every feature; split_cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split)
+    also runs the reference's FeatureHistogram::FindBestThreshold per feature (dict keys meta3, split, split_default_left);
+    partitions = [(feature, threshold, default_left), ...] runs Dataset::Split of the leaf for each (dict key part_lte: list of arrays)."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     n, F = X.shape
     di = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
@@ -138,17 +141,28 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
     ng = C.c_int(0)
     gnb = np.zeros(F, dtype=np.int32)
     bins = np.zeros((F, n), dtype=np.uint8)
-    hist = np.zeros((F * (max_bin + 2), 2))
+    hist = np.zeros((F * (max_bin + 3), 2))
     voff = np.zeros(F, dtype=np.int32); nbin = np.zeros(F, dtype=np.int32); mfb = np.zeros(F, dtype=np.int32)
-    sums = np.zeros(2); hfix = np.zeros((F * (max_bin + 2), 2))
+    sums = np.zeros(2); hfix = np.zeros((F * (max_bin + 3), 2))
+    cfg = None if split_cfg is None else np.ascontiguousarray(split_cfg, dtype=np.float64)
+    meta3 = np.zeros((F, 3), dtype=np.int32); sp = np.zeros((F, 10)); sdl = np.zeros(F, dtype=np.int32)
+    npart = 0 if partitions is None else len(partitions)
+    ftd = np.ascontiguousarray(partitions if npart else np.zeros((1, 3)), dtype=np.int32)
+    plte = np.zeros((max(npart, 1), nd), dtype=np.int32); pcnt = np.zeros(max(npart, 1), dtype=np.int32)
     rc = _lib().refdrv_hist(C.c_int(n), C.c_int(F), _P(X), C.c_int(max_bin), None if di is None else _P(di), C.c_int(nd), _P(g),
                             None if h is None else _P(h), C.c_double(const_hess), C.byref(ng), _P(gnb), _P(bins), _P(hist),
-                            _P(voff), _P(nbin), _P(mfb), _P(sums), _P(hfix) if with_fix else None)
+                            _P(voff), _P(nbin), _P(mfb), _P(sums), _P(hfix) if (with_fix or cfg is not None) else None,
+                            C.c_char_p(extra_params.encode()), None if cfg is None else _P(cfg), _P(meta3),
+                            None if cfg is None else _P(sp), _P(sdl), C.c_int(npart), _P(ftd), _P(plte), _P(pcnt))
     if rc != 0:
         raise RuntimeError("refdrv_hist failed")
     G = ng.value
     tot = int(gnb[:G].sum())
-    if with_fix:
-        return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy(), dict(view_offset=voff, num_bin=nbin, most_freq_bin=mfb,
-                                                                       sums=sums, hist_fixed=hfix[:tot].copy())
+    if with_fix or cfg is not None:
+        out = dict(view_offset=voff, num_bin=nbin, most_freq_bin=mfb, sums=sums, hist_fixed=hfix[:tot].copy())
+        if cfg is not None:
+            out.update(meta3=meta3, split=sp, split_default_left=sdl)
+        if npart:
+            out["part_lte"] = [plte[p, :pcnt[p]].copy() for p in range(npart)]
+        return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy(), out
     return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy()

@@ -83,6 +83,42 @@ def synthetic_binary(n, d, seed=1):
     return make_binary_data(dict(n=n, d=d, seed_data=seed))
 
 
+# Split search (FeatureHistogram::FindBestThreshold) fixtures: three data sets x two configurations, tests/golden/split_ref.npz
+SPLIT_DATA = {"plain": dict(seed=51, params=""),                       # no missing values: MissingType::None, one reverse scan
+              "zero_missing": dict(seed=52, params="zero_as_missing=true"),   # MissingType::Zero, both scans, default bin skipped
+              "nan": dict(seed=53, params="")}                           # NaNs in two features: MissingType::NaN, both scans
+SPLIT_CFGS = [(0.0, 20, 1e-3, 0.0), (1.5, 5, 1e-3, 0.1)]              # lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split
+
+
+def split_partition_requests(num_bin):
+    """(feature, threshold, default_left) triples exercised by the partition fixture: a low, a middle and the highest admissible
+    threshold of every feature, both default directions."""
+    req = []
+    for f, nb in enumerate(num_bin):
+        for th in sorted({0, max(0, nb // 2 - 1), max(0, nb - 2)}):
+            for dl in (0, 1):
+                req.append((f, th, dl))
+    return req
+
+
+def make_split_data(name):
+    c = SPLIT_DATA[name]
+    rng = np.random.default_rng(c["seed"])
+    n, F = 6000, 6
+    X = rng.uniform(size=(n, F))
+    X[:, 1] = 2.0 * X[:, 1] - 1.0
+    X[:, 2] = np.round(X[:, 2] * 12) / 12
+    X[:, 3] = np.where(rng.uniform(size=n) < 0.75, 0.4, X[:, 3])
+    X[:, 4] = (rng.uniform(size=n) < 0.6) * rng.uniform(size=n)
+    if name == "nan":
+        X[rng.uniform(size=n) < 0.07, 0] = np.nan
+        X[rng.uniform(size=n) < 0.3, 5] = np.nan
+    g = np.sin(6 * np.nan_to_num(X[:, 0])) + 0.7 * (np.nan_to_num(X[:, 1]) > 0.2) - 0.5 * np.nan_to_num(X[:, 4]) + 0.3 * rng.standard_normal(n)
+    h = rng.uniform(0.5, 2.0, size=n)
+    leaf = np.sort(rng.choice(n, size=2500, replace=False)).astype(np.int32)
+    return X, g, h, leaf
+
+
 # Newton leaf update (row a9): leaf assignment per DATA point for the golden cases that carry a "leaf_values_*" entry
 LEAF_CASES = {"r_exp_m30_none": 7, "u2d_n3000_exp_m30": 31, "u1d_n1000_mat15_m10": 16}   # case -> number of leaves
 

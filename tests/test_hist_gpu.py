@@ -140,3 +140,77 @@ def test_histogram_rccl_allreduce_single_rank(lib_built):
     assert np.array_equal(c1, c0) and np.array_equal(h1[:, 1], h0[:, 1])
     np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=0, atol=1e-10)
     hb.close()
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_missing", "nan"])
+def test_split_search_against_reference_fixture(lib_built, orc, name):
+    """SURVEY.md 8f rank 2: FeatureHistogram::FindBestThreshold per feature + the winner, on device-resident histograms, against the
+    reference's own output (tests/golden/split_ref.npz): (i) on the reference's fixed histogram uploaded as is -> every SplitInfo field
+    bit-identical; (ii) end to end from the bins (build -> fix -> search) -> same winner and threshold, sums to the build's 1e-10."""
+    import os
+    from gpboost_amd import shim
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_ref.npz"))
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3 = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(2)
+    hb.set_fix_info(g[name + "_view_offset"], g[name + "_num_bin"], g[name + "_most_freq_bin"])
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    for ci, cfg in enumerate(cases.SPLIT_CFGS):
+        for li, di in enumerate((None, leaf)):
+            for hi, hs in enumerate((None, hess)):
+                key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums, ref, ref_dl = g[key + "_sums"], g[key + "_split"], g[key + "_default_left"]
+                nd = bins.shape[1] if di is None else di.size
+                # end to end on the device
+                hb.set_gradients(grad, hs)
+                hb.build_slot(0, di)
+                hb.fix_slot(0, sums[0], sums[1])
+                best, out, dl = hb.find_best_split(0, sums[0], sums[1], nd, *cfg)
+                raw = hb.get_slot(0)
+                obest, oout, odl = orc.find_best_split(raw, g[name + "_view_offset"], g[name + "_num_bin"], meta3[:, 0], meta3[:, 1],
+                                                       meta3[:, 2], sums[0], sums[1], nd, *cfg)
+                assert best == obest and np.array_equal(out, oout) and np.array_equal(dl, odl)      # bit-identical given the histogram
+                assert best == int(np.argmax(ref[:, 0]))
+                assert out[best, 1] == ref[best, 1] and dl[best] == ref_dl[best]                    # same threshold, same default side
+                np.testing.assert_allclose(out[best, [0, 4, 5, 6, 7, 8, 9]], ref[best, [0, 4, 5, 6, 7, 8, 9]], rtol=1e-9, atol=1e-9)
+    # a masked-out winner never wins; an empty mask yields -1
+    used = np.ones(hb.F, dtype=np.int8); used[best] = 0
+    b2, _, _ = hb.find_best_split(0, sums[0], sums[1], nd, *cfg, is_feature_used=used)
+    assert b2 != best and b2 >= 0
+    b3, _, _ = hb.find_best_split(0, sums[0], sums[1], nd, *cfg, is_feature_used=np.zeros(hb.F, dtype=np.int8))
+    assert b3 == -1
+    hb.close()
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_missing", "nan"])
+def test_leaf_partition_against_reference_fixture(lib_built, name):
+    """DataPartition::Split on the device against the reference's own Dataset::Split: identical lists, order included."""
+    import os
+    from gpboost_amd import shim
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_ref.npz"))
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3 = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.set_fix_info(g[name + "_view_offset"], g[name + "_num_bin"], g[name + "_most_freq_bin"])
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    req, cnts, flat = g[name + "_part_req"], g[name + "_part_lte_count"], g[name + "_part_lte"]
+    pos = 0
+    for (f, th, dl), nl in zip(req, cnts):
+        lte, gt = hb.split_leaf(leaf, f, th, dl)
+        assert np.array_equal(lte, flat[pos:pos + nl]), (name, f, th, dl)
+        assert np.array_equal(np.sort(np.concatenate([lte, gt])), leaf) and np.all(np.diff(gt) > 0)
+        pos += nl
+    # all rows (data_indices = NULL) and an unsorted index list: stable in the given order
+    lte_all, gt_all = hb.split_leaf(None, 0, 20, 1)
+    assert lte_all.size + gt_all.size == bins.shape[1] and np.all(np.diff(lte_all) > 0)
+    perm = np.random.default_rng(1).permutation(leaf).astype(np.int32)
+    lte_p, gt_p = hb.split_leaf(perm, 1, 30, 0)
+    l0, g0 = hb.split_leaf(leaf, 1, 30, 0)
+    inl = np.isin(perm, l0)
+    assert np.array_equal(lte_p, perm[inl]) and np.array_equal(gt_p, perm[~inl])
+    hb.close()

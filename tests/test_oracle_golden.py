@@ -222,3 +222,49 @@ def test_r_golden_vecchia_cluster_ids(orc):
         quad += out[0]; logdet += out[1]
     nll = quad / 2 / pt[0] + logdet / 2 + len(y) / 2 * (np.log(pt[0]) + np.log(2 * np.pi))
     assert abs(nll - 129.3761486) < R_TOL
+
+
+# ---- split search on a leaf histogram ----------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+def test_oracle_split_search_matches_reference_fixture(orc, name):
+    """orc_find_best_split against the reference's own FeatureHistogram::FindBestThreshold (all three missing-value types, two
+    regularisation settings, root and leaf, constant and per-row hessians): every field of SplitInfo bit-identical."""
+    g = np.load(os.path.join(GOLD, "split_ref.npz"))
+    meta3 = g[name + "_meta3"]
+    n_all = g[name + "_bins"].shape[1]
+    checked = 0
+    for ci, cfg in enumerate(cases.SPLIT_CFGS):
+        for li in (0, 1):
+            for hi in (0, 1):
+                key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums = g[key + "_sums"]
+                num_data = n_all if li == 0 else 2500
+                best, out, dl = orc.find_best_split(g[key + "_hist_fixed"], g[name + "_view_offset"], g[name + "_num_bin"], meta3[:, 0],
+                                                    meta3[:, 1], meta3[:, 2], sums[0], sums[1], num_data, *cfg)
+                ref = g[key + "_split"]
+                assert np.array_equal(out, ref), (key, np.abs(out - ref).max())
+                assert np.array_equal(dl, g[key + "_default_left"])
+                gains = ref[:, 0]
+                assert best == int(np.argmax(gains)) and np.isfinite(gains.max())
+                checked += int(np.isfinite(gains).sum())
+    assert checked >= 30        # most features are splittable in every setting
+
+
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+def test_oracle_leaf_partition_matches_reference_fixture(orc, name):
+    """orc_split_leaf against the reference's own Dataset::Split (DenseBin::SplitInner, all missing-value variants): the lists of
+    rows going left / right are identical, order included."""
+    g = np.load(os.path.join(GOLD, "split_ref.npz"))
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3, mfb = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"], g[name + "_most_freq_bin"]
+    req, cnts, flat = g[name + "_part_req"], g[name + "_part_lte_count"], g[name + "_part_lte"]
+    pos = 0
+    sides = set()
+    for (f, th, dl), nl in zip(req, cnts):
+        lte, gt = orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], dl, th, leaf)
+        assert np.array_equal(lte, flat[pos:pos + nl]), (name, f, th, dl)
+        assert np.array_equal(np.sort(np.concatenate([lte, gt])), leaf)
+        assert np.all(np.diff(gt) > 0) and np.all(np.diff(lte) > 0)           # both sides keep the (sorted) input order
+        sides.add((len(lte) > 0, len(gt) > 0))
+        pos += nl
+    assert pos == flat.size and (True, True) in sides
