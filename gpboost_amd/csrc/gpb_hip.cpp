@@ -1106,7 +1106,7 @@ int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const 
 int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data, double lambda_l2,
                                  int32_t min_data_in_leaf, double min_sum_hessian_in_leaf, double min_gain_to_split,
                                  const int8_t* is_feature_used, int32_t* best_feature, double* per_feature_out10,
-                                 int32_t* per_feature_default_left) {
+                                 int32_t* per_feature_default_left, int32_t* per_feature_splittable) {
   API_BEGIN();
   if (!h || !best_feature) return fail("null argument");
   double* src = hist_slot(h, slot);
@@ -1128,7 +1128,10 @@ int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gra
   if (per_feature_out10) HIP_OK(hipMemcpyAsync(per_feature_out10, h->d_split, sizeof(double) * (size_t)F * 10, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   *best_feature = ints[F];
-  if (per_feature_default_left) std::copy(ints.begin(), ints.begin() + F, per_feature_default_left);
+  for (int f = 0; f < F; ++f) {
+    if (per_feature_default_left) per_feature_default_left[f] = ints[f] & 1;
+    if (per_feature_splittable) per_feature_splittable[f] = (ints[f] >> 1) & 1;
+  }
   API_END();
 }
 

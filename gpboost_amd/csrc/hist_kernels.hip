@@ -281,7 +281,7 @@ __global__ void hist_best_split_kernel(const double* __restrict__ hist, int num_
   double* r = out10 + (size_t)f * 10;
   r[0] = o.gain; r[1] = (double)o.threshold; r[2] = o.left_count; r[3] = o.right_count; r[4] = o.left_output; r[5] = o.right_output;
   r[6] = o.lsg; r[7] = o.lsh; r[8] = o.rsg; r[9] = o.rsh;
-  out_default_left[f] = o.default_left;
+  out_default_left[f] = o.default_left | (splittable ? 2 : 0);      // bit 1: FeatureHistogram::is_splittable() after the search
 }
 
 // the winner: larger gain, equal gains -> smaller feature index; features masked out by is_feature_used never win

@@ -350,13 +350,16 @@ class HistBuilder(object):
 
     def find_best_split(self, slot, sum_gradient, sum_hessian, num_data, lambda_l2=0.0, min_data_in_leaf=20,
                         min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, is_feature_used=None):
-        """-> (best_feature, out (F, 10), default_left (F,)): FeatureHistogram::FindBestThreshold per feature + the winner."""
+        """-> (best_feature, out (F, 10), default_left (F,)): FeatureHistogram::FindBestThreshold per feature + the winner;
+        self.last_splittable holds is_splittable() per feature."""
         out = np.empty((self.F, 10)); dl = np.empty(self.F, dtype=np.int32); best = C.c_int(-1)
+        self.last_splittable = np.empty(self.F, dtype=np.int32)
         used = None if is_feature_used is None else np.ascontiguousarray(is_feature_used, dtype=np.int8)
         _shim_call(_lib().gpb_hip_hist_find_best_split(self.h, C.c_int(int(slot)), C.c_double(sum_gradient), C.c_double(sum_hessian),
                                                        C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
                                                        C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split),
-                                                       _p(used, C.c_int8), C.byref(best), _p(out), _p(dl, C.c_int)))
+                                                       _p(used, C.c_int8), C.byref(best), _p(out), _p(dl, C.c_int),
+                                                       _p(self.last_splittable, C.c_int)))
         return best.value, out, dl
 
     def split_leaf(self, data_indices, feature, threshold, default_left):

@@ -277,7 +277,9 @@ GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double
  *                    min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split; is_feature_used (may be NULL) as in :753
  *                    best_feature: inner feature index (-1 if the mask is empty); per_feature_out10 (may be NULL): F x 10 doubles =
  *                    SplitInfo {gain, threshold, left_count, right_count, left_output, right_output, left_sum_gradient,
- *                    left_sum_hessian, right_sum_gradient, right_sum_hessian}; per_feature_default_left (may be NULL) */
+ *                    left_sum_hessian, right_sum_gradient, right_sum_hessian}; per_feature_default_left (may be NULL);
+ *                    per_feature_splittable (may be NULL): FeatureHistogram::is_splittable() after the search -- the children of a
+ *                    leaf skip the features that were not splittable in it (serial_tree_learner.cpp:328-334) */
 /* Partition of a leaf's rows by a numerical split: DataPartition::Split (src/LightGBM/treelearner/data_partition.hpp:101-130) ->
  * Dataset::Split (dataset.h:506-516) -> DenseBin::Split / SplitInner (src/LightGBM/io/dense_bin.hpp:176-307; single-feature groups,
  * all missing-value variants).  Stable: lte_out and gt_out (each sized cnt by the caller) keep the order of data_indices
@@ -289,7 +291,8 @@ GPB_HIP_EXPORT int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t*
 GPB_HIP_EXPORT int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data,
                                                 double lambda_l2, int32_t min_data_in_leaf, double min_sum_hessian_in_leaf,
                                                 double min_gain_to_split, const int8_t* is_feature_used, int32_t* best_feature,
-                                                double* per_feature_out10, int32_t* per_feature_default_left);
+                                                double* per_feature_out10, int32_t* per_feature_default_left,
+                                                int32_t* per_feature_splittable);
 
 #ifdef __cplusplus
 }

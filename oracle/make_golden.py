@@ -51,6 +51,7 @@ def main():
     laplace_fixture(out_dir)
     cluster_fixture(out_dir)
     split_fixture(out_dir)
+    tree_fixture(out_dir)
 
 
 def laplace_fixture(out_dir):
@@ -93,6 +94,20 @@ def split_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "split_ref.npz"), **res)
 
 
+def tree_fixture(out_dir):
+    """Whole trees grown by the reference's SerialTreeLearner (constant and per-row hessians)."""
+    res = {}
+    for name in cases.TREE_CASES:
+        data, params, L, cfg = cases.tree_params(name)
+        X, g, h, leaf = cases.make_split_data(data)
+        for hi, hs in enumerate((None, h)):
+            t = refdrv.ref_train_tree(X, params, g, hs, max_leaves=L)
+            for k, v in t.items():
+                res["%s_hess%d_%s" % (name, hi, k)] = np.asarray(v)
+            print("tree", name, "hess%d" % hi, "leaves", t["num_leaves"], "root split feature", t["split_feature_inner"][0], "thr", t["threshold_in_bin"][0])
+    np.savez_compressed(os.path.join(out_dir, "tree_ref.npz"), **res)
+
+
 def cluster_fixture(out_dir):
     """Reference nll of a model with several clusters (independent GP realisations), random Vecchia ordering: pins the cluster
     order (first appearance) and the ONE shared std::mt19937 that shuffles cluster after cluster."""
@@ -123,6 +138,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "tree":
+        tree_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "split":
         split_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "clusters":

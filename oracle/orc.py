@@ -223,7 +223,8 @@ def find_best_split(hist, view_offset, num_bin, offset, default_bin, missing, su
     best = lib().orc_find_best_split(_p(h, C.c_double), C.c_int(F), *[_p(a, C.c_int) for a in arrs], C.c_double(sum_gradient),
                                      C.c_double(sum_hessian), C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
                                      C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), _p(out, C.c_double), _p(dl, C.c_int))
-    return best, out, dl
+    find_best_split.last_splittable = (dl >> 1) & 1
+    return best, out, dl & 1
 
 
 def split_leaf(bins_f, max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, data_indices):

@@ -26,6 +26,8 @@
 #include <LightGBM/train_share_states.h>
 #include <LightGBM/config.h>
 #include <LightGBM/tree.h>
+#include <LightGBM/tree_learner.h>
+#include <omp.h>
 #include <LightGBM/treelearner/feature_histogram.hpp>   /* src/LightGBM/treelearner (Makefile.ref adds -I$(REF)/src) */
 #undef private
 #undef protected
@@ -229,6 +231,71 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
     return 0;
   } catch (std::exception& e) {
     fprintf(stderr, "refdrv_hist: %s\n", e.what());
+    return -1;
+  }
+}
+
+/* One tree grown by the reference's own SerialTreeLearner (src/LightGBM/treelearner/serial_tree_learner.cpp:159-210) on its own
+ * Dataset, for given gradients / hessians (hess == NULL: constant hessian 1, the GPBoost Gaussian case).  One OpenMP thread, so
+ * that the root sums (leaf_splits.hpp:73-86) are a plain left-to-right summation.  params: LightGBM parameter string (num_leaves,
+ * lambda_l2, min_data_in_leaf, ...).  Outputs sized num_leaves: per internal node k < num_leaves - 1: split_feature_inner,
+ * threshold_in_bin, default_left, left_child, right_child, split_gain, internal_count; per leaf: leaf_value, leaf_count.
+ * Also returns the stored group bins and the feature metas the device side needs (as refdrv_hist does). */
+__attribute__((visibility("default")))
+int refdrv_train_tree(int n, int F, const double* X_rowmajor, const char* params, const double* grad, const double* hess,
+                      int* num_groups_out, int* group_num_bin, unsigned char* bins_out, int* feat_view_offset, int* feat_num_bin,
+                      int* feat_most_freq_bin, int* feat_meta3, int* num_leaves_out, int* split_feature_inner, int* threshold_in_bin,
+                      int* default_left, int* left_child, int* right_child, double* split_gain, int* internal_count,
+                      double* leaf_value, int* leaf_count) {
+  try {
+    using namespace LightGBM;
+    omp_set_num_threads(1);
+    DatasetHandle dh = nullptr;
+    if (LGBM_DatasetCreateFromMat(X_rowmajor, C_API_DTYPE_FLOAT64, n, F, 1, params, nullptr, &dh) != 0) {
+      fprintf(stderr, "refdrv_train_tree: %s\n", LGBM_GetLastError());
+      return -1;
+    }
+    Dataset* ds = reinterpret_cast<Dataset*>(dh);
+    const int ng = ds->num_groups_;
+    *num_groups_out = ng;
+    for (int g = 0; g < ng; ++g) {
+      group_num_bin[g] = ds->feature_groups_[g]->num_total_bin_;
+      std::unique_ptr<BinIterator> it(ds->feature_groups_[g]->bin_data_->GetIterator(0, group_num_bin[g] - 1, 0));
+      it->Reset(0);
+      for (int i = 0; i < n; ++i) bins_out[(size_t)g * n + i] = (unsigned char)it->RawGet(i);
+    }
+    Config config;
+    config.Set(Config::Str2Map(params));
+    std::vector<FeatureMetainfo> metas;
+    HistogramPool::SetFeatureInfo<true, true>(ds, &config, &metas);
+    for (int f = 0; f < ds->num_features(); ++f) {
+      const BinMapper* bm = ds->FeatureBinMapper(f);
+      feat_view_offset[f] = (int)ds->group_bin_boundaries_[ds->feature2group_[f]] + 1;
+      feat_num_bin[f] = bm->num_bin(); feat_most_freq_bin[f] = (int)bm->GetMostFreqBin();
+      feat_meta3[3 * f] = metas[f].offset; feat_meta3[3 * f + 1] = (int)metas[f].default_bin; feat_meta3[3 * f + 2] = (int)metas[f].missing_type;
+    }
+    std::vector<score_t> g_all(grad, grad + n), h_all(n, 1.0);
+    if (hess) std::copy(hess, hess + n, h_all.begin());
+    std::unique_ptr<TreeLearner> tl(TreeLearner::CreateTreeLearner("serial", "cpu", &config));
+    tl->Init(ds, hess == nullptr);
+    const json11::Json no_forced_splits;                 /* GBDT::Init hands the learner a null Json (gbdt.cpp:115): the member is otherwise uninitialised */
+    tl->SetForcedSplit(&no_forced_splits);
+    std::unique_ptr<Tree> tree(tl->Train(g_all.data(), h_all.data(), true));
+
+    const int nl = tree->num_leaves_;
+    *num_leaves_out = nl;
+    for (int k = 0; k < nl - 1; ++k) {
+      split_feature_inner[k] = tree->split_feature_inner_[k]; threshold_in_bin[k] = (int)tree->threshold_in_bin_[k];
+      default_left[k] = Tree::GetDecisionType(tree->decision_type_[k], kDefaultLeftMask) ? 1 : 0;
+      left_child[k] = tree->left_child_[k]; right_child[k] = tree->right_child_[k];
+      split_gain[k] = tree->split_gain_[k]; internal_count[k] = tree->internal_count_[k];
+    }
+    for (int k = 0; k < nl; ++k) { leaf_value[k] = tree->leaf_value_[k]; leaf_count[k] = tree->leaf_count_[k]; }
+    tl.reset();
+    LGBM_DatasetFree(dh);
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_train_tree: %s\n", e.what());
     return -1;
   }
 }

@@ -166,3 +166,33 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
             out["part_lte"] = [plte[p, :pcnt[p]].copy() for p in range(npart)]
         return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy(), out
     return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy()
+
+
+def ref_train_tree(X, params, grad, hess=None, max_leaves=64):
+    """One tree grown by the reference's own SerialTreeLearner::Train (single OpenMP thread) on its own Dataset.
+    Returns a dict: bins (G, n), group_num_bin, view_offset / num_bin / most_freq_bin / meta3 per feature, num_leaves, and the tree
+    arrays split_feature_inner, threshold_in_bin, default_left, left_child, right_child, split_gain, internal_count (num_leaves - 1)
+    and leaf_value, leaf_count (num_leaves)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, F = X.shape
+    g = np.ascontiguousarray(grad, dtype=np.float64)
+    h = None if hess is None else np.ascontiguousarray(hess, dtype=np.float64)
+    ng = C.c_int(0); nl = C.c_int(0)
+    gnb = np.zeros(F, dtype=np.int32); bins = np.zeros((F, n), dtype=np.uint8)
+    voff = np.zeros(F, dtype=np.int32); nbin = np.zeros(F, dtype=np.int32); mfb = np.zeros(F, dtype=np.int32); meta3 = np.zeros((F, 3), dtype=np.int32)
+    L = int(max_leaves)
+    ia = {k: np.zeros(L, dtype=np.int32) for k in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child",
+                                                    "internal_count", "leaf_count")}
+    gain = np.zeros(L); lv = np.zeros(L)
+    rc = _lib().refdrv_train_tree(C.c_int(n), C.c_int(F), _P(X), C.c_char_p(params.encode()), _P(g), None if h is None else _P(h),
+                                  C.byref(ng), _P(gnb), _P(bins), _P(voff), _P(nbin), _P(mfb), _P(meta3), C.byref(nl),
+                                  _P(ia["split_feature_inner"]), _P(ia["threshold_in_bin"]), _P(ia["default_left"]), _P(ia["left_child"]),
+                                  _P(ia["right_child"]), _P(gain), _P(ia["internal_count"]), _P(lv), _P(ia["leaf_count"]))
+    if rc != 0:
+        raise RuntimeError("refdrv_train_tree failed")
+    G, nlv = ng.value, nl.value
+    out = dict(bins=bins[:G].copy(), group_num_bin=gnb[:G].copy(), view_offset=voff, num_bin=nbin, most_freq_bin=mfb, meta3=meta3,
+               num_leaves=nlv, split_gain=gain[:nlv - 1].copy(), leaf_value=lv[:nlv].copy(), leaf_count=ia["leaf_count"][:nlv].copy())
+    for k in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count"):
+        out[k] = ia[k][:nlv - 1].copy()
+    return out

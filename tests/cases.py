@@ -119,6 +119,23 @@ def make_split_data(name):
     return X, g, h, leaf
 
 
+# One whole tree (SerialTreeLearner::Train) -- tests/golden/tree_ref.npz.  name -> (split data set, LightGBM parameter string)
+TREE_CASES = {
+    "plain_l31": ("plain", "max_bin=255 num_leaves=31 min_data_in_leaf=20 lambda_l2=0"),
+    "plain_l15_reg": ("plain", "max_bin=63 num_leaves=15 min_data_in_leaf=40 lambda_l2=2.5 min_gain_to_split=0.05"),
+    "nan_l20": ("nan", "max_bin=63 num_leaves=20 min_data_in_leaf=10 lambda_l2=0.1"),
+    "zero_missing_l12": ("zero_missing", "max_bin=63 num_leaves=12 min_data_in_leaf=25 lambda_l2=0 zero_as_missing=true"),
+}
+TREE_COMMON = " min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=1 min_sum_hessian_in_leaf=0.001"
+
+
+def tree_params(name):
+    data, p = TREE_CASES[name]
+    kv = dict(t.split("=") for t in p.split())
+    cfg = (float(kv.get("lambda_l2", 0.0)), int(kv.get("min_data_in_leaf", 20)), 1e-3, float(kv.get("min_gain_to_split", 0.0)))
+    return data, p + TREE_COMMON, int(kv["num_leaves"]), cfg
+
+
 # Newton leaf update (row a9): leaf assignment per DATA point for the golden cases that carry a "leaf_values_*" entry
 LEAF_CASES = {"r_exp_m30_none": 7, "u2d_n3000_exp_m30": 31, "u1d_n1000_mat15_m10": 16}   # case -> number of leaves
 

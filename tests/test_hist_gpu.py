@@ -214,3 +214,44 @@ def test_leaf_partition_against_reference_fixture(lib_built, name):
     inl = np.isin(perm, l0)
     assert np.array_equal(lte_p, perm[inl]) and np.array_equal(gt_p, perm[~inl])
     hb.close()
+
+
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12"])
+@pytest.mark.parametrize("hi", [0, 1])
+def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
+    """The five device primitives (leaf histogram, FixHistogram, parent - smaller, split search, leaf partition), driven by the control
+    flow of SerialTreeLearner::Train (tests/tree_harness.py), grow the tree the reference's own SerialTreeLearner grows on its own
+    Dataset (tests/golden/tree_ref.npz): same splits, thresholds, default directions and counts; leaf values / gains to the summation
+    order of the histogram build."""
+    import os
+    from gpboost_amd import shim
+    from tests import cases
+    from tests import tree_harness as th
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    k = "%s_hess%d_" % (name, hi)
+    hs = hess if hi else None
+    be = th.GpuBackend(shim, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
+                       g[k + "meta3"], grad, hs, L)
+    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg)
+    be.close()
+    assert t["num_leaves"] == int(g[k + "num_leaves"])
+    for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):
+        assert np.array_equal(t[key], g[k + key]), key
+    np.testing.assert_allclose(t["leaf_value"], g[k + "leaf_value"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(t["split_gain"], g[k + "split_gain"], rtol=1e-6)
+    # default_left: for features with a missing-value type the reverse and the forward scan find the SAME split whenever the leaf holds
+    # no missing rows; which of the two (mathematically equal) gains is larger is decided in the last bit of the histogram sums, so the
+    # flag may differ from the reference's there.  Every such node must be one where the direction is void: both directions give the
+    # identical partition of the node's rows (checked with the oracle's DenseBin::SplitInner).  Without missing-value types there is
+    # one scan and the flag is exact.
+    flipped = np.flatnonzero(t["default_left"] != g[k + "default_left"])
+    if data == "plain":
+        assert flipped.size == 0
+    from oracle import orc
+    bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+    for nd in flipped:
+        f, thr, rows = int(t["split_feature_inner"][nd]), int(t["threshold_in_bin"][nd]), t["node_rows"][nd]
+        parts = [orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], dl, thr, rows) for dl in (0, 1)]
+        assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1]), nd

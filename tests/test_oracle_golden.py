@@ -268,3 +268,26 @@ def test_oracle_leaf_partition_matches_reference_fixture(orc, name):
         sides.add((len(lte) > 0, len(gt) > 0))
         pos += nl
     assert pos == flat.size and (True, True) in sides
+
+
+# ---- a whole tree: the hot-path primitives composed the way SerialTreeLearner::Train composes them -------------------------------
+@pytest.mark.parametrize("name", sorted(cases.TREE_CASES))
+@pytest.mark.parametrize("hi", [0, 1])
+def test_oracle_primitives_grow_the_reference_tree(orc, name, hi):
+    """Leaf histogram + FixHistogram + subtraction + split search + partition (all oracle restatements), driven by the control flow of
+    SerialTreeLearner::Train (tests/tree_harness.py), reproduce the tree the reference's own SerialTreeLearner grows on its own Dataset
+    (tests/golden/tree_ref.npz): structure, thresholds, default directions, counts exactly; leaf values and gains bit for bit."""
+    from tests import tree_harness as th
+    g = np.load(os.path.join(GOLD, "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    k = "%s_hess%d_" % (name, hi)
+    hs = hess if hi else None
+    be = th.OracleBackend(orc, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
+                          g[k + "meta3"], grad, hs)
+    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg)
+    assert t["num_leaves"] == int(g[k + "num_leaves"])
+    for key in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count", "leaf_count"):
+        assert np.array_equal(t[key], g[k + key]), key
+    assert np.array_equal(t["leaf_value"], g[k + "leaf_value"])
+    assert np.array_equal(t["split_gain"], g[k + "split_gain"])
