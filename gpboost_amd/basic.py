@@ -126,14 +126,19 @@ class GPModel(object):
             pass
 
     # --- reference surface -------------------------------------------------------------------
-    def neg_log_likelihood(self, cov_pars, y, fixed_effects=None, aux_pars=None):
+    def neg_log_likelihood(self, cov_pars=None, y=None, fixed_effects=None, aux_pars=None):
         """Evaluate the negative log-likelihood (reference: basic.py:5640-5700)."""
+        if y is None:
+            raise ValueError("'y' is required: the likelihood is evaluated at the response passed in")
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         if y.shape[0] != self.num_data:
             raise ValueError("Incorrect number of data points in 'y'")
-        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
-        if cov_pars.shape[0] != self.num_cov_pars:
-            raise ValueError("'cov_pars' does not contain the correct number of parameters")
+        cp_c = ctypes.c_void_p()       # None: the stored (initial or estimated) parameters, as in the reference
+        if cov_pars is not None:
+            cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+            if cov_pars.shape[0] != self.num_cov_pars:
+                raise ValueError("'cov_pars' does not contain the correct number of parameters")
+            cp_c = _dptr(cov_pars)
         fe_c = ctypes.c_void_p()
         if fixed_effects is not None:
             fixed_effects = np.ascontiguousarray(fixed_effects, dtype=np.float64).reshape(-1)
@@ -141,31 +146,90 @@ class GPModel(object):
                 raise ValueError("Length of 'fixed_effects' is not correct ")
             fe_c = _dptr(fixed_effects)
         negll = ctypes.c_double(0)
-        _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, _dptr(y), _dptr(cov_pars), fe_c, ctypes.byref(negll)))
+        _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, _dptr(y), cp_c, fe_c, ctypes.byref(negll)))
         return negll.value
 
+    _OPTIM_DEFAULTS = {   # basic.py:4528-4570 (self.params) -> GPB_SetOptimConfig; -999 / "" / "default" = the library's default
+        "init_cov_pars": None, "lr_cov": -999., "acc_rate_cov": -999., "maxit": -999, "delta_rel_conv": -999.,
+        "use_nesterov_acc": True, "nesterov_schedule_version": -999, "trace": False, "optimizer_cov": "", "momentum_offset": -999,
+        "convergence_criterion": "default", "m_lbfgs": -999,
+        "cg_max_num_it": -999, "cg_max_num_it_tridiag": -999, "cg_delta_conv": -999., "num_rand_vec_trace": -999,
+        "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999., "cg_preconditioner_type": ""}
+
     def set_optim_params(self, params):
-        """Settings that act ON the hot path (reference: basic.py:5238-5420 -> GPB_SetOptimConfig): 'trace' and, for
-        non-Gaussian likelihoods, 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
-        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'.  Optimiser settings are rejected:
-        the optimiser is the reference's own host code."""
-        known = {"trace": False, "cg_max_num_it": -999, "cg_max_num_it_tridiag": -999, "cg_delta_conv": -999.,
-                 "num_rand_vec_trace": -999, "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999.,
-                 "cg_preconditioner_type": ""}
+        """Optimiser and iterative-method settings (reference: GPModel.set_optim_params, basic.py:5238-5420 -> GPB_SetOptimConfig).
+        Estimation: 'optimizer_cov' ("lbfgs" | "gradient_descent"), 'init_cov_pars', 'lr_cov', 'acc_rate_cov', 'maxit',
+        'delta_rel_conv', 'use_nesterov_acc', 'nesterov_schedule_version', 'momentum_offset', 'convergence_criterion', 'm_lbfgs',
+        'trace'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
+        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'.  Anything else raises: no silent ignore."""
+        if not hasattr(self, "_optim_params"):
+            self._optim_params = dict(self._OPTIM_DEFAULTS)
         for k in params:
-            if k not in known:
-                raise GPBoostError("set_optim_params: '%s' is not a hot-path setting of this library" % k)
-        known.update(params)
+            if k not in self._optim_params:
+                raise GPBoostError("set_optim_params: '%s' is not a setting of the MI355X path of this library" % k)
+        o = dict(self._optim_params)
+        o.update(params)
+        init_c = ctypes.c_void_p()
+        if o["init_cov_pars"] is not None:
+            init = np.ascontiguousarray(o["init_cov_pars"], dtype=np.float64).reshape(-1)
+            if init.shape[0] != self.num_cov_pars:
+                raise ValueError("'init_cov_pars' does not contain the correct number of parameters")
+            init_c = _dptr(init)
+        est = np.array([-1], dtype=np.int32)
         _safe_call(_lib().GPB_SetOptimConfig(
-            self.handle, ctypes.c_void_p(), ctypes.c_double(-1.), ctypes.c_double(-1.), ctypes.c_int(-1), ctypes.c_double(-1.),
-            ctypes.c_bool(False), ctypes.c_int(-1), ctypes.c_bool(bool(known["trace"])), ctypes.c_void_p(), ctypes.c_int(-1),
-            ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_void_p(), ctypes.c_double(-1.), ctypes.c_double(-1.), ctypes.c_void_p(),
-            ctypes.c_int(int(known["cg_max_num_it"])), ctypes.c_int(int(known["cg_max_num_it_tridiag"])),
-            ctypes.c_double(float(known["cg_delta_conv"])), ctypes.c_int(int(known["num_rand_vec_trace"])), ctypes.c_bool(True),
-            c_str(known["cg_preconditioner_type"]), ctypes.c_int(int(known["seed_rand_vec_trace"])), ctypes.c_int(-1),
-            ctypes.c_void_p(), ctypes.c_bool(False), ctypes.c_bool(False), ctypes.c_void_p(), ctypes.c_int(-1),
-            ctypes.c_double(float(known["delta_conv_mode_finding"]))))
+            self.handle, init_c, ctypes.c_double(float(o["lr_cov"])), ctypes.c_double(float(o["acc_rate_cov"])), ctypes.c_int(int(o["maxit"])),
+            ctypes.c_double(float(o["delta_rel_conv"])), ctypes.c_bool(bool(o["use_nesterov_acc"])),
+            ctypes.c_int(int(o["nesterov_schedule_version"])), ctypes.c_bool(bool(o["trace"])), c_str(o["optimizer_cov"]),
+            ctypes.c_int(int(o["momentum_offset"])), c_str(o["convergence_criterion"]), ctypes.c_int(0), ctypes.c_void_p(),
+            ctypes.c_double(-999.), ctypes.c_double(-999.), c_str(""),
+            ctypes.c_int(int(o["cg_max_num_it"])), ctypes.c_int(int(o["cg_max_num_it_tridiag"])),
+            ctypes.c_double(float(o["cg_delta_conv"])), ctypes.c_int(int(o["num_rand_vec_trace"])), ctypes.c_bool(True),
+            c_str(o["cg_preconditioner_type"]), ctypes.c_int(int(o["seed_rand_vec_trace"])), ctypes.c_int(-999),
+            ctypes.c_void_p(), ctypes.c_bool(False), ctypes.c_bool(False), est.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(o["m_lbfgs"])),
+            ctypes.c_double(float(o["delta_conv_mode_finding"]))))
+        self._optim_params = o          # only settings the library accepted are remembered
         return self
+
+    def fit(self, y, X=None, params=None, fixed_effects=None):
+        """Maximum-likelihood estimation of the covariance parameters (reference: GPModel.fit, basic.py:5422-5560 ->
+        GPB_OptimCovPar).  y is uploaded once; every likelihood / gradient evaluation of the fit runs on the device."""
+        if X is not None:
+            raise GPBoostError("linear regression covariates are not on the MI355X hot path of this library")
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if y.shape[0] != self.num_data:
+            raise ValueError("Incorrect number of data points in 'y'")
+        if params is not None:
+            self.set_optim_params(params)
+        fe_c = ctypes.c_void_p()
+        if fixed_effects is not None:
+            fixed_effects = np.ascontiguousarray(fixed_effects, dtype=np.float64).reshape(-1)
+            if fixed_effects.shape[0] != self.num_data:
+                raise ValueError("Length of 'fixed_effects' is not correct ")
+            fe_c = _dptr(fixed_effects)
+        _safe_call(_lib().GPB_OptimCovPar(self.handle, _dptr(y), fe_c))
+        return self
+
+    def get_cov_pars(self, std_err=False):
+        """(error variance, GP variance, range) on the original scale (reference: GPModel.get_cov_pars, basic.py:6290-6330)."""
+        out = np.empty(self.num_cov_pars * (2 if std_err else 1))
+        _safe_call(_lib().GPB_GetCovPar(self.handle, _dptr(out), ctypes.c_bool(bool(std_err))))
+        return out
+
+    def _get_init_cov_pars(self):
+        out = np.empty(self.num_cov_pars)
+        _safe_call(_lib().GPB_GetInitCovPar(self.handle, _dptr(out)))
+        return out
+
+    def get_num_optim_iter(self):
+        n = ctypes.c_int(0)
+        _safe_call(_lib().GPB_GetNumIt(self.handle, ctypes.byref(n)))
+        return n.value
+
+    def optim_info(self):
+        """Device launches of the last fit: likelihood-only, with gradient sums; final learning rate (GPB_HIP_GetOptimInfo)."""
+        a = ctypes.c_int(0); b = ctypes.c_int(0); lr = ctypes.c_double(0)
+        _safe_call(_lib().GPB_HIP_GetOptimInfo(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(lr)))
+        return dict(num_ll_evals=a.value, num_grad_evals=b.value, lr_cov_final=lr.value)
 
     def laplace_info(self):
         """Diagnostics of the last Laplace evaluation (GPB_HIP_GetLaplaceInfo)."""

@@ -16,6 +16,7 @@
 // All per-point arithmetic happens on the device.
 #include "../../include/gpboost_c_api_subset.h"
 #include "../../include/gpb_hip.h"
+#include "gpb_optim.h"
 
 #include <algorithm>
 #include <cmath>
@@ -63,6 +64,16 @@ struct REModelHip {
   double cg_delta_conv = 1e-2, delta_conv_mode_finding = 1e-8;
   std::vector<int> labels;      // y in {0,1}, Vecchia order
   double lap_info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // parameter estimation (REModel members of re_model.h: cov_pars_, init_cov_pars_, num_it_; all on the TRANSFORMED scale)
+  std::mt19937 rng;             // rng_ of the reference: orderings first, then the sub-sample of FindInitCovPar
+  std::vector<double> coords0;  // coordinates of the first cluster in Vecchia order, column-major (for FindInitCovPar)
+  int n0 = 0;
+  GpbOptimConfig optim;
+  bool optimizer_unsupported_alias = false;
+  double cov_pars_tr[3] = {0, 0, 0}, init_cov_pars_tr[3] = {0, 0, 0};
+  bool cov_pars_initialized = false, init_cov_pars_provided = false;
+  int num_it = 0;
+  GpbOptimResult last_fit;
   ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); }
 };
 
@@ -96,6 +107,93 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects)
   for (size_t k = 0; k < mdl->vhs.size(); ++k)
     if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf.data() + mdl->cl_off[k])) return shim_error();
   return 0;
+}
+
+double range_const(const REModelHip* mdl) { return mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.)); }
+
+// REModelTemplate::FindInitCovPar (re_model_template.h:4849-4968) -> RECompGP::FindInitCovPar (re_comp.h:1249-1267) ->
+// CovFunction::FindInitCovPar (cov_fcts.h:1422-1683) for one Gaussian Matern GP.  The result is used as cov_pars_ directly, i.e. it
+// is on the TRANSFORMED scale: (var(y) / 2, 1, a) with a such that the correlation is ~0.05 at half the median distance.
+int find_init_cov_par(REModelHip* mdl, const double* y_data, const double* fixed_effects, double* theta) {
+  const int n = mdl->n;
+  double mean = 0., var = 0.;
+  for (int i = 0; i < n; ++i) mean += fixed_effects ? y_data[i] - fixed_effects[i] : y_data[i];
+  mean /= n;
+  for (int i = 0; i < n; ++i) { const double r = (fixed_effects ? y_data[i] - fixed_effects[i] : y_data[i]) - mean; var += r * r; }
+  var /= (n - 1);
+  theta[0] = var / 2.;
+  theta[1] = 1.;                                   // init_marg_var = 1 for the Gaussian likelihood (:4865, :4912)
+  const int MAX_POINTS_INIT_RANGE = 1000;          // cov_fcts.h:1444
+  const int nd = mdl->n0, d = mdl->d;
+  const int ns = nd > MAX_POINTS_INIT_RANGE ? MAX_POINTS_INIT_RANGE : nd;
+  std::vector<int> sample_ind;
+  if (ns < nd) {
+    std::uniform_int_distribution<> dis(0, nd - 1);
+    sample_ind.resize(ns);
+    for (int i = 0; i < ns; ++i) sample_ind[i] = dis(mdl->rng);
+  }
+  std::vector<double> distances((size_t)(ns * (ns - 1) / 2.));
+  const double* c = mdl->coords0.data();
+  for (int i = 0; i < ns - 1; ++i) {
+    const int ii = sample_ind.empty() ? i : sample_ind[i];
+    for (int j = i + 1; j < ns; ++j) {
+      const int jj = sample_ind.empty() ? j : sample_ind[j];
+      double s2 = 0.;
+      for (int k = 0; k < d; ++k) { const double df = c[(size_t)k * nd + ii] - c[(size_t)k * nd + jj]; s2 += df * df; }
+      distances[(size_t)i * (2 * ns - i - 1) / 2 + j - (i + 1)] = std::sqrt(s2);
+    }
+  }
+  // CalculateMedianPartiallySortInput (utils.h:191-204)
+  const size_t num_el = distances.size(), pos_med = num_el / 2;
+  std::nth_element(distances.begin(), distances.begin() + pos_med, distances.end());
+  double med = distances[pos_med];
+  if (num_el % 2 == 0) {
+    std::nth_element(distances.begin(), distances.begin() + pos_med - 1, distances.end());
+    med = (med + distances[pos_med - 1]) / 2.;
+  }
+  if (med < 1e-10) {                               // EPSILON_NUMBERS: fall back to the mean distance
+    double sum = 0.;
+    for (double v : distances) sum += v;
+    med = sum / num_el;
+  }
+  if (med < 1e-10)
+    return set_error("Cannot find an initial value for the range parameter since both the median and the average distances among coordinates are zero %s",
+                     sample_ind.empty() ? "" : "on a random sub-sample of size 1000 ");
+  theta[2] = mdl->cov_type == 0 ? 2. * 3. / med : (mdl->cov_type == 1 ? 2. * 4.7 / med : 2. * 5.9 / med);   // cov_fcts.h:1601-1611
+  return 0;
+}
+
+// REModel::InitializeCovParsIfNotDefined (re_model.cpp:1312-1334)
+int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
+  if (mdl->cov_pars_initialized) return 0;
+  if (mdl->init_cov_pars_provided) {
+    std::copy(mdl->init_cov_pars_tr, mdl->init_cov_pars_tr + 3, mdl->cov_pars_tr);
+  } else {
+    if (!y_data) return set_error("y_data is NULL: initial covariance parameters cannot be determined");
+    if (find_init_cov_par(mdl, y_data, fixed_effects, mdl->cov_pars_tr)) return -1;
+    std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, mdl->init_cov_pars_tr);
+  }
+  mdl->cov_pars_initialized = true;
+  return 0;
+}
+
+// the optimiser's window on the device: the shard sums of all clusters at (ratio, a); y is already resident
+int device_terms(void* ctx, double ratio, double a, int with_grad, double* t7) {
+  auto* mdl = reinterpret_cast<REModelHip*>(ctx);
+  for (int q = 0; q < 7; ++q) t7[q] = 0.;
+  for (auto* v : mdl->vhs) {
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (with_grad ? gpb_hip_vecchia_grad_terms(v, mdl->cov_type, ratio, a, t) : gpb_hip_vecchia_nll_terms(v, mdl->cov_type, ratio, a, 1, t))
+      return shim_error();
+    for (int q = 0; q < (with_grad ? 7 : 3); ++q) t7[q] += t[q];
+  }
+  return 0;
+}
+
+void transform_back(const REModelHip* mdl, const double* tr, double* orig) {   // TransformBackCovPars (cov_fcts.h:560-600)
+  orig[0] = tr[0];
+  orig[1] = tr[1] * tr[0];
+  orig[2] = range_const(mdl) / tr[2];
 }
 
 double negll_from_terms(int n, double yPy, double logdet, double sigma2) {
@@ -187,7 +285,8 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     clusters.emplace_back(mdl->perm);
   }
   if (clusters.size() > 1 && lik != "gaussian") return set_error("GPB_CreateREModel: several clusters with likelihood '%s' %s", lik.c_str(), scope);
-  std::mt19937 rng(seed);                                          // ONE generator for all clusters (re_model_template.h:161, type_defs.h:52)
+  mdl->rng = std::mt19937(seed);                                   // ONE generator for all clusters (re_model_template.h:161, type_defs.h:52)
+  std::mt19937& rng = mdl->rng;
   mdl->perm.clear(); mdl->cl_off.assign(1, 0);
   mdl->m = 0;
   for (auto& idx : clusters) {
@@ -199,6 +298,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
       for (int k = 0; k < nc; ++k) coords[(size_t)j * nc + k] = gp_coords_data[(size_t)j * num_data + idx[k]];
     gpb_hip_vecchia_t* vh = nullptr;
     if (gpb_hip_vecchia_create(nc, dim_gp_coords, num_neighbors, coords.data(), &vh)) return shim_error();
+    if (mdl->vhs.empty()) { mdl->coords0 = coords; mdl->n0 = nc; }
     mdl->vhs.push_back(vh);
     int dup = 0;
     if (gpb_hip_vecchia_find_neighbors(vh, &dup)) return shim_error();
@@ -218,17 +318,63 @@ int GPB_REModelFree(REModelHandle handle) {
   C_API_END();
 }
 
-int GPB_SetOptimConfig(REModelHandle handle, double*, double, double, int, double, bool, int, bool trace, const char*, int,
-                       const char*, int num_covariates, double*, double, double, const char*, int cg_max_num_it,
-                       int cg_max_num_it_tridiag, double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/,
-                       const char* cg_preconditioner_type, int seed_rand_vec_trace, int, double*, bool, bool, const int*, int,
+int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, double acc_rate_cov, int max_iter, double delta_rel_conv,
+                       bool use_nesterov_acc, int nesterov_schedule_version, bool trace, const char* optimizer, int momentum_offset,
+                       const char* convergence_criterion, int num_covariates, double* /*init_coef*/, double /*lr_coef*/,
+                       double /*acc_rate_coef*/, const char* /*optimizer_coef*/, int cg_max_num_it, int cg_max_num_it_tridiag,
+                       double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/, const char* cg_preconditioner_type,
+                       int seed_rand_vec_trace, int /*piv_chol_rank*/, double* /*init_aux_pars*/, bool estimate_aux_pars,
+                       bool /*init_coef_aux_pars_from_iid_model*/, const int* estimate_cov_par_index, int m_lbfgs,
                        double delta_conv_mode_finding) {
   C_API_BEGIN();
   if (!handle) return set_error("GPB_SetOptimConfig: null handle");
   if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
+  if (estimate_aux_pars) return set_error("GPB_SetOptimConfig: estimate_aux_pars is not on the MI355X hot path of this library");
+  if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0)
+    return set_error("GPB_SetOptimConfig: holding covariance parameters fixed (estimate_cov_par_index) is not on the MI355X hot path of this library");
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   mdl->trace = trace;
-  // re_model_template.h:863-891, :943-948 (-999 = keep the default)
+  // REModel::SetOptimConfig (re_model.cpp:301-318): initial values are kept on the transformed scale
+  if (init_cov_pars) {
+    if (mdl->likelihood != "gaussian") return set_error("GPB_SetOptimConfig: init_cov_pars for likelihood '%s' (no parameter estimation for it on the MI355X path yet)", mdl->likelihood.c_str());
+    double tr[3];
+    if (transform_cov_pars(mdl, init_cov_pars, tr)) return -1;
+    std::copy(tr, tr + 3, mdl->init_cov_pars_tr);
+    std::copy(tr, tr + 3, mdl->cov_pars_tr);
+    mdl->cov_pars_initialized = true;
+    mdl->init_cov_pars_provided = true;
+  }
+  // REModelTemplate::SetOptimConfig (re_model_template.h:743-960); -999 = keep the default
+  GpbOptimConfig& oc = mdl->optim;
+  oc.trace = trace;
+  if (acc_rate_cov > 0.) oc.acc_rate_cov = acc_rate_cov;
+  else if (!near(acc_rate_cov, -999.)) return set_error("acc_rate_cov is not > 0, found = %g ", acc_rate_cov);
+  if (max_iter >= 0) oc.max_iter = max_iter;
+  else if (max_iter != -999) return set_error("max_iter is not >= 0, found = %d ", max_iter);
+  oc.use_nesterov_acc = use_nesterov_acc;
+  if (nesterov_schedule_version == 0 || nesterov_schedule_version == 1) oc.nesterov_schedule_version = nesterov_schedule_version;
+  else if (nesterov_schedule_version != -999) return set_error("nesterov_schedule_version is not 0 or 1, found = %d ", nesterov_schedule_version);
+  if (optimizer && std::string(optimizer) != "") {
+    std::string o = optimizer;
+    mdl->optimizer_unsupported_alias = (o == "gradient_descent_constant_change" || o == "gradient_descent_reset_lr");   // change the step rule (:788-818)
+    if (o == "gradient_descent_constant_change" || o == "gradient_descent_increase_lr" || o == "gradient_descent_reset_lr") o = "gradient_descent";
+    if (o == "lbfgs_not_profile_out_nugget") mdl->optimizer_unsupported_alias = true;
+    oc.optimizer = o;
+  }
+  if (momentum_offset >= 0) oc.momentum_offset = momentum_offset;
+  else if (momentum_offset != -999) return set_error("momentum_offset is not >= 0, found = %d ", momentum_offset);
+  if (convergence_criterion && std::string(convergence_criterion) != "default") {
+    const std::string cc = convergence_criterion;
+    if (cc != "relative_change_in_log_likelihood" && cc != "relative_change_in_parameters")
+      return set_error("Convergence criterion '%s' is not supported.", cc.c_str());
+    oc.convergence_criterion = cc;
+  }
+  if (delta_rel_conv > 0.) oc.delta_rel_conv_init = delta_rel_conv;
+  else if (!near(delta_rel_conv, -999.)) return set_error("delta_rel_conv is not > 0, found = %g ", delta_rel_conv);
+  if (lr > 0.) oc.lr_cov_init = lr;
+  else if (!near(lr, -999.)) return set_error("lr_cov is not > 0, found = %g ", lr);
+  if (m_lbfgs > 0) oc.m_lbfgs = m_lbfgs;
+  else if (m_lbfgs != -999) return set_error("m_lbfgs is not > 0, found = %d ", m_lbfgs);
   if (num_rand_vec_trace > 0) mdl->num_rand_vec_trace = num_rand_vec_trace;
   else if (num_rand_vec_trace != -999) return set_error("num_rand_vec_trace is not > 0, found = %d ", num_rand_vec_trace);
   mdl->seed_rand_vec_trace = seed_rand_vec_trace;
@@ -253,7 +399,7 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
-  if (!cov_pars) return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (initial-value heuristics live in the reference's optimiser, not on the hot path)");
+  if (!cov_pars && mdl->likelihood != "gaussian") return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (no initial-value heuristics for likelihood '%s' on the MI355X path)", mdl->likelihood.c_str());
   if (mdl->likelihood == "bernoulli_logit") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
     if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
     if (fixed_effects) return set_error("GPB_EvalNegLogLikelihood: fixed_effects with likelihood 'bernoulli_logit' are not on the MI355X hot path of this library yet");
@@ -277,7 +423,11 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     return 0;
   }
   double tr[3];
-  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  if (cov_pars) { if (transform_cov_pars(mdl, cov_pars, tr)) return -1; }
+  else {                                            // re_model.cpp:759-766: the stored (initial or estimated) parameters
+    if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+    std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, tr);
+  }
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
   double t3[3] = {0., 0., 0.};
   if (mdl->eh) { if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t3, nullptr, nullptr)) return shim_error(); }
@@ -291,6 +441,108 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   mdl->cur_negll = negll_from_terms(mdl->n, t3[0], t3[1], tr[0]);
   mdl->negll_valid = true;
   *negll = mdl->cur_negll;
+  C_API_END();
+}
+
+/* ---- parameter estimation: the direct caller of the hot path ---- */
+int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fixed_effects) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_OptimCovPar: null handle");
+  const char* scope = "is not on the MI355X path of this library yet (parameter estimation: Gaussian likelihood, gp_approx 'vecchia')";
+  if (mdl->likelihood != "gaussian") return set_error("GPB_OptimCovPar: likelihood '%s' %s", mdl->likelihood.c_str(), scope);
+  if (mdl->eh) return set_error("GPB_OptimCovPar: gp_approx 'none' %s", scope);
+  if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
+  if (!y_data) return set_error("GPB_OptimCovPar: y_data is NULL");
+  for (int i = 0; i < mdl->n; ++i)
+    if (!std::isfinite(y_data[i])) return set_error("NaN or Inf in response variable / label ");   // re_model_template.h:1090-1094
+  if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;                    // re_model.cpp:487-491
+  if (upload_y(mdl, y_data, fixed_effects)) return -1;   // ONE H2D of y for the whole fit (SetY, re_model_template.h:1204-1206, :1324-1331)
+  GpbOptimConfig cfg = mdl->optim;
+  cfg.range_const = range_const(mdl);
+  char err[512] = "";
+  GpbOptimResult res;
+  if (gpb_optimize_gaussian_cov_pars(cfg, mdl->n, device_terms, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err)))
+    return err[0] ? set_error("%s", err) : -1;
+  if (cfg.max_iter > 0) {
+    std::copy(res.theta, res.theta + 3, mdl->cov_pars_tr);
+    mdl->cur_negll = res.negll;
+    mdl->negll_valid = true;
+  }
+  mdl->num_it = res.num_it;
+  mdl->last_fit = res;
+  C_API_END();
+}
+
+int GPB_GetCovPar(REModelHandle handle, double* optim_cov_pars, bool calc_std_dev) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !optim_cov_pars) return set_error("GPB_GetCovPar: null argument");
+  if (mdl->likelihood != "gaussian" || !mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or correctly set ");   // re_model.cpp:922-924
+  if (calc_std_dev) return set_error("GPB_GetCovPar: standard deviations (Fisher information, re_model_template.h:10137) are not on the MI355X path of this library yet");
+  transform_back(mdl, mdl->cov_pars_tr, optim_cov_pars);
+  C_API_END();
+}
+
+int GPB_GetInitCovPar(REModelHandle handle, double* init_cov_pars) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !init_cov_pars) return set_error("GPB_GetInitCovPar: null argument");
+  if (mdl->likelihood != "gaussian" || !(mdl->cov_pars_initialized || mdl->init_cov_pars_provided)) {
+    for (int j = 0; j < 3; ++j) init_cov_pars[j] = -1.;   // re_model.cpp GetInitCovPar: -1 if not available
+    return 0;
+  }
+  transform_back(mdl, mdl->init_cov_pars_tr, init_cov_pars);
+  C_API_END();
+}
+
+int GPB_GetNumIt(REModelHandle handle, int* num_it) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !num_it) return set_error("GPB_GetNumIt: null argument");
+  *num_it = mdl->num_it;
+  C_API_END();
+}
+
+int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_evals, double* lr_cov_final) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_HIP_GetOptimInfo: null handle");
+  if (num_ll_evals) *num_ll_evals = mdl->last_fit.num_ll_evals;
+  if (num_grad_evals) *num_grad_evals = mdl->last_fit.num_grad_evals;
+  if (lr_cov_final) *lr_cov_final = mdl->last_fit.lr_cov_final;
+  C_API_END();
+}
+
+/* Test seam: the same host optimiser with a caller-supplied evaluation callback (tests/ drives it with the CPU oracle, so the
+   control flow is checked against the reference's trajectories without a GPU).  init_theta / theta_out: TRANSFORMED scale. */
+int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_theta, const char* optimizer, double lr_cov, double acc_rate_cov,
+                                         int max_iter, double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version,
+                                         int momentum_offset, const char* convergence_criterion, int m_lbfgs, double range_const_,
+                                         int (*terms)(void*, double, double, int, double*), void* ctx, double* theta_out, int* num_it,
+                                         double* negll, int* num_evals2) {
+  C_API_BEGIN();
+  if (!init_theta || !terms || !theta_out) return set_error("GPB_HIP_OptimizeGaussianWithCallback: null argument");
+  GpbOptimConfig cfg;
+  if (optimizer && optimizer[0]) cfg.optimizer = optimizer;
+  if (lr_cov > 0.) cfg.lr_cov_init = lr_cov;
+  if (acc_rate_cov > 0.) cfg.acc_rate_cov = acc_rate_cov;
+  if (max_iter >= 0) cfg.max_iter = max_iter;
+  if (delta_rel_conv > 0.) cfg.delta_rel_conv_init = delta_rel_conv;
+  cfg.use_nesterov_acc = use_nesterov_acc;
+  if (nesterov_schedule_version >= 0) cfg.nesterov_schedule_version = nesterov_schedule_version;
+  if (momentum_offset >= 0) cfg.momentum_offset = momentum_offset;
+  if (convergence_criterion && convergence_criterion[0] && std::string(convergence_criterion) != "default") cfg.convergence_criterion = convergence_criterion;
+  if (m_lbfgs > 0) cfg.m_lbfgs = m_lbfgs;
+  cfg.range_const = range_const_;
+  char err[512] = "";
+  GpbOptimResult res;
+  if (gpb_optimize_gaussian_cov_pars(cfg, num_data, terms, ctx, init_theta, &res, err, (int)sizeof(err)))
+    return set_error("%s", err[0] ? err : "evaluation callback failed");
+  std::copy(res.theta, res.theta + 3, theta_out);
+  if (num_it) *num_it = res.num_it;
+  if (negll) *negll = res.negll;
+  if (num_evals2) { num_evals2[0] = res.num_ll_evals; num_evals2[1] = res.num_grad_evals; }
   C_API_END();
 }
 

@@ -1,0 +1,338 @@
+// gpboost_amd/csrc/gpb_optim.cpp -- see gpb_optim.h for the reference functions each block follows.
+#include "gpb_optim.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <limits>
+#include <vector>
+
+namespace {
+
+constexpr double kMinNuggetVarRatio = 1e-10;          // re_model_template.h:5668
+constexpr double kLrShrinkageFactor = 0.5;            // :5750
+constexpr int kMaxNumberLrShrinkageSteps = 30;        // :5746
+constexpr double kCArmijo = 1e-4, kCArmijoMom = 1e-4; // :5809-5811
+const double kMaxGradientUpdateLogScale = std::log(100.);   // :5780-5782
+
+struct Fail {
+  char* err; int errlen;
+  int operator()(const char* fmt, ...) const {
+    va_list ap; va_start(ap, fmt); vsnprintf(err, errlen, fmt, ap); va_end(ap);
+    return -1;
+  }
+};
+
+// The model state the reference's optimiser works on (members of REModelTemplate), reduced to one Gaussian GP.
+struct State {
+  const GpbOptimConfig& cfg;
+  int n; gpb_terms_fn fn; void* ctx;
+  double cur_r = 0., cur_a = 0.;     // parameters of the factor that is "current" (SetCovParsComps + CalcCovFactor)
+  bool have_factor = false, have_grad = false;
+  double yPy = 0., logdet = 0.;      // yTPsiInvy_, log_det_Psi_
+  double g[4] = {0., 0., 0., 0.};    // gradient shard sums of the current factor
+  double sigma2 = 0., sigma2_lag1 = 0.;
+  double negll = 0.;                 // neg_log_likelihood_
+  int n_ll = 0, n_grad = 0;
+
+  // ApplyGaussianNuggetLowerBound on the transformed scale (:7849-7874): TransformBack, bound, Transform again
+  void nugget_bound(double th[3]) const {
+    const double sigma2_o = th[0], var_o = th[1] * th[0], rho_o = cfg.range_const / th[2];
+    if (!std::isfinite(var_o) || var_o <= 0.) return;
+    const double nugget_min = kMinNuggetVarRatio / (1. - kMinNuggetVarRatio) * var_o;
+    if (std::isfinite(nugget_min) && sigma2_o < nugget_min) {
+      th[0] = nugget_min;
+      th[1] = var_o / nugget_min;
+      th[2] = cfg.range_const / rho_o;
+    }
+  }
+  double negll_at(double s2) const {   // :3132 / :3142
+    return yPy / 2. / s2 + logdet / 2. + n / 2. * (std::log(s2) + std::log(2 * M_PI));
+  }
+  // CalcCovFactorOrModeAndNegLL (:2832-2852).  with_grad: also fetch the gradient sums in the same launch.
+  int calc(const double th_in[3], bool with_grad) {
+    double th[3] = {th_in[0], th_in[1], th_in[2]};
+    nugget_bound(th);
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (fn(ctx, th[1], th[2], with_grad ? 1 : 0, t)) return -1;
+    if (with_grad) ++n_grad; else ++n_ll;
+    cur_r = th[1]; cur_a = th[2]; have_factor = true;
+    yPy = t[0]; logdet = t[1];
+    have_grad = with_grad;
+    if (with_grad) { g[0] = t[3]; g[1] = t[4]; g[2] = t[5]; g[3] = t[6]; }
+    negll = negll_at(th[0]);
+    return 0;
+  }
+  // CalcGradPars(cov_pars, ., true, false, ., ., include_error_var = false) (:1988-2011): gradient of the CURRENT factor wrt
+  // (log ratio, log a), with cov_pars[0] = s2 in the divisions
+  int grad(double s2, double out[2]) {
+    if (!have_grad) {
+      double t[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (fn(ctx, cur_r, cur_a, 1, t)) return -1;
+      ++n_grad;
+      g[0] = t[3]; g[1] = t[4]; g[2] = t[5]; g[3] = t[6];
+      have_grad = true;
+    }
+    out[0] = g[0] / s2 + g[1];
+    out[1] = g[2] / s2 + g[3];
+    return 0;
+  }
+  void profile_out_sigma2(double th[3]) {   // :2640-2650
+    sigma2 = yPy / n;
+    th[0] = sigma2;
+    nugget_bound(th);
+    sigma2 = th[0];
+  }
+};
+
+double nesterov_schedule(int iter, int version, double acc_rate, int momentum_offset) {   // :6143-6158
+  if (iter < momentum_offset) return 0.;
+  if (version == 0) return acc_rate;
+  return 1. - (3. / (6. + iter));
+}
+
+bool finite3(const double* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// internal optimiser "gradient_descent" (+ Nesterov acceleration): OptimLinRegrCoefCovPar :1436-1704
+// ---------------------------------------------------------------------------------------------------------------------
+int run_gradient_descent(State& st, const GpbOptimConfig& cfg, double th[3], GpbOptimResult* out, const Fail& fail) {
+  double lr_cov = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 0.1;
+  const double delta_rel_conv = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-6;
+  const bool nesterov = cfg.use_nesterov_acc;
+  if (nesterov && cfg.nesterov_schedule_version == 1)   // :8701-8703 (armijo_condition_ is always true)
+    return fail("Armijo condition backtracking is not implemented when nesterov_schedule_version = 1 ");
+  st.sigma2 = th[0];
+  st.sigma2_lag1 = st.sigma2;
+  if (st.calc(th, true)) return -1;
+  if (!std::isfinite(st.negll))
+    return fail("%s occurred in initial negative log-likelihood. Possible solutions: try other initial values ('init_cov_pars')",
+                std::isnan(st.negll) ? "NaN" : "Inf");
+  double aux[3] = {th[0], th[1], th[2]}, aux_lag1[3] = {th[0], th[1], th[2]};   // cov_pars_after_grad_aux(_lag1)
+  double th_lag1[3];
+  int num_it = cfg.max_iter;
+  for (int it = 0; it < cfg.max_iter; ++it) {
+    const double negll_lag1 = st.negll;
+    std::copy(th, th + 3, th_lag1);
+    const double negll_after_lin_coef_update = negll_lag1;           // no covariates (:1511)
+    st.profile_out_sigma2(th);                                       // :1518-1520
+    double grad[2];
+    if (st.grad(th[0], grad)) return -1;                             // :1524
+    // AvoidTooLargeLearningRatesCovAuxPars
+    const double max_lr = kMaxGradientUpdateLogScale / std::max(std::fabs(grad[0]), std::fabs(grad[1]));
+    if (lr_cov > max_lr) lr_cov = max_lr;
+    // CalcDirDerivArmijoAndLearningRateConstChangeCovAuxPars (armijo_condition_ = true)
+    const double dir_deriv = -(grad[0] * grad[0] + grad[1] * grad[1]);
+    double mom_dir_deriv = 0.;
+    if (nesterov) {
+      const double d1 = std::log(th[1]) - std::log(aux[1]), d2 = std::log(th[2]) - std::log(aux[2]);
+      mom_dir_deriv = grad[0] * d1 + grad[1] * d2;
+    }
+    // UpdateCovAuxPars
+    double th_new[3] = {th[0], 0., 0.};
+    double lr = lr_cov, acc = cfg.acc_rate_cov;
+    bool decrease_found = false, halving_done = false;
+    for (int ih = 0; ih < kMaxNumberLrShrinkageSteps; ++ih) {
+      th_new[0] = th[0];
+      th_new[1] = std::exp(std::log(th[1]) - lr * grad[0]);          // update on the log-scale
+      th_new[2] = std::exp(std::log(th[2]) - lr * grad[1]);
+      st.nugget_bound(th_new);
+      if (nesterov) {
+        std::copy(th_new, th_new + 3, aux);
+        const double mu = nesterov_schedule(it, cfg.nesterov_schedule_version, acc, cfg.momentum_offset);   // ApplyMomentumStep
+        th_new[0] = aux[0];
+        th_new[1] = std::exp((mu + 1.) * std::log(aux[1]) - mu * std::log(aux_lag1[1]));
+        th_new[2] = std::exp((mu + 1.) * std::log(aux[2]) - mu * std::log(aux_lag1[2]));
+        st.nugget_bound(th_new);
+      }
+      if (st.calc(th_new, ih == 0)) return -1;                       // first trial: gradient sums in the same launch
+      const double mu = nesterov ? nesterov_schedule(it, cfg.nesterov_schedule_version, acc, cfg.momentum_offset) : 0.;
+      if (st.negll <= negll_after_lin_coef_update + kCArmijo * lr * dir_deriv + kCArmijoMom * mu * mom_dir_deriv) decrease_found = true;
+      if (decrease_found) break;
+      halving_done = true;
+      lr *= kLrShrinkageFactor;
+      acc *= 0.5;
+    }
+    if (halving_done) lr_cov = lr;                                   // permanent for gradient descent (:8824)
+    if (nesterov) std::copy(aux, aux + 3, aux_lag1);
+    std::copy(th_new, th_new + 3, th);
+    if (cfg.trace)
+      fprintf(stderr, "[gpboost_amd] it %d: cov pars (transformed) %.10g %.10g %.10g negll %.10g lr %g\n", it + 1, th[0], th[1], th[2],
+              st.negll, lr_cov);
+    if (!std::isfinite(st.negll) || !finite3(th))
+      return fail("NaN or Inf occurred in covariance parameter optimization using 'gradient_descent' (the reference restarts with "
+                  "'nelder_mead' here, which is not on the MI355X path); try a smaller learning rate or other initial values");
+    // CheckOptimizerHasConverged
+    bool terminate = false;
+    if (cfg.convergence_criterion == "relative_change_in_parameters") {
+      double d = 0., r = 0.;
+      for (int i = 0; i < 3; ++i) { d += (th[i] - th_lag1[i]) * (th[i] - th_lag1[i]); r += th_lag1[i] * th_lag1[i]; }
+      terminate = std::sqrt(d) <= delta_rel_conv * std::sqrt(r);
+    } else {
+      terminate = (negll_lag1 - st.negll) <= delta_rel_conv * std::max(std::fabs(negll_lag1), 1.);
+    }
+    if (terminate) { num_it = it + 1; break; }
+  }
+  out->num_it = num_it;
+  out->lr_cov_final = lr_cov;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "lbfgs" (the default): LBFGSSolver<double, LineSearchBacktracking> on x = log(theta[1:]) with the nugget profiled out
+// ---------------------------------------------------------------------------------------------------------------------
+struct BfgsMat {     // BFGSMat.h:69-186 for n = 2
+  int m; double theta = 1.; int ncorr = 0, ptr;
+  std::vector<double> s, y, ys, alpha;   // s, y: column j at [2 j, 2 j + 1]
+  explicit BfgsMat(int m_) : m(m_), ptr(m_), s(2 * m_), y(2 * m_), ys(m_), alpha(m_) {}
+  void add_correction(const double* sv, const double* yv) {
+    const int loc = ptr % m;
+    s[2 * loc] = sv[0]; s[2 * loc + 1] = sv[1];
+    y[2 * loc] = yv[0]; y[2 * loc + 1] = yv[1];
+    const double d = sv[0] * yv[0] + sv[1] * yv[1];
+    ys[loc] = d;
+    theta = (yv[0] * yv[0] + yv[1] * yv[1]) / d;
+    if (ncorr < m) ++ncorr;
+    ptr = loc + 1;
+  }
+  void apply_Hv(const double* v, double a, double* res) {
+    res[0] = a * v[0]; res[1] = a * v[1];
+    int j = ptr % m;
+    for (int i = 0; i < ncorr; ++i) {
+      j = (j + m - 1) % m;
+      alpha[j] = (s[2 * j] * res[0] + s[2 * j + 1] * res[1]) / ys[j];
+      res[0] -= alpha[j] * y[2 * j]; res[1] -= alpha[j] * y[2 * j + 1];
+    }
+    res[0] /= theta; res[1] /= theta;
+    for (int i = 0; i < ncorr; ++i) {
+      const double beta = (y[2 * j] * res[0] + y[2 * j + 1] * res[1]) / ys[j];
+      res[0] += (alpha[j] - beta) * s[2 * j]; res[1] += (alpha[j] - beta) * s[2 * j + 1];
+      j = (j + 1) % m;
+    }
+  }
+};
+
+// EvalLLforLBFGSpp::operator() (optim_utils.h:283-420) for learn_cov_aux_pars, profile_out_error_variance, no covariates
+int lbfgs_objective(State& st, const double x[2], bool eval_likelihood, bool calc_gradient, bool grad_in_same_launch, double* fx,
+                    double grad[2]) {
+  double th[3] = {st.sigma2, std::exp(x[0]), std::exp(x[1])};
+  if (eval_likelihood) {
+    if (st.calc(th, grad_in_same_launch)) return -1;
+    st.profile_out_sigma2(th);
+    *fx = st.negll_at(th[0]);                         // EvalNegLogLikelihoodOnlyUpdateNuggetVariance
+  }
+  if (calc_gradient && st.grad(th[0], grad)) return -1;
+  return 0;
+}
+
+int run_lbfgs(State& st, const GpbOptimConfig& cfg, double th[3], GpbOptimResult* out, const Fail& fail) {
+  const double delta = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-6;
+  const double initial_step_factor = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 1.;
+  const double epsilon = 1e-20, epsilon_rel = 1e-20, ftol = 1e-4;     // optim_utils.h:655-661, Param.h:188
+  const int max_linesearch = 20;
+  constexpr double eps = std::numeric_limits<double>::epsilon();
+  st.sigma2 = th[0];
+  st.sigma2_lag1 = st.sigma2;                                           // SetLag1ProfiledOutVariables (:1352)
+  BfgsMat bfgs(cfg.m_lbfgs);
+  double x[2] = {std::log(th[1]), std::log(th[2])}, xp[2], grad[2], gradp[2], drt[2];
+  double fx = 1e99;
+  if (lbfgs_objective(st, x, true, true, true, &fx, grad)) return -1;
+  if (!std::isfinite(fx))
+    return fail("%s occurred in initial negative log-likelihood. Possible solutions: try other initial values ('init_cov_pars')",
+                std::isnan(fx) ? "NaN" : "Inf");
+  double gnorm = std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]);
+  double fx_past = fx;                                                  // m_fx[0] (past = 1)
+  int k = 1;
+  bool done = gnorm <= epsilon || gnorm <= epsilon_rel * std::sqrt(x[0] * x[0] + x[1] * x[1]);
+  if (!done) {
+    drt[0] = -grad[0]; drt[1] = -grad[1];
+    double step = initial_step_factor / std::sqrt(drt[0] * drt[0] + drt[1] * drt[1]);
+    for (;;) {
+      xp[0] = x[0]; xp[1] = x[1]; gradp[0] = grad[0]; gradp[1] = grad[1];
+      const double max_lr = kMaxGradientUpdateLogScale / std::max(std::fabs(drt[0]), std::fabs(drt[1]));   // GetMaximalLearningRate
+      if (max_lr < step) step = max_lr;
+      // LineSearchBacktracking (Armijo)
+      {
+        if (step <= 0.) return fail("GPModel lbfgs: 'step' must be positive");
+        const double fx_init = fx, dg_init = grad[0] * drt[0] + grad[1] * drt[1];
+        if (dg_init > 0.) return fail("GPModel lbfgs: the moving direction increases the objective function value");
+        const double test_decr = ftol * dg_init;
+        int iter;
+        for (iter = 0; iter < max_linesearch; ++iter) {
+          x[0] = xp[0] + step * drt[0]; x[1] = xp[1] + step * drt[1];
+          if (lbfgs_objective(st, x, true, false, iter == 0, &fx, grad)) return -1;
+          double width;
+          if (fx > fx_init + step * test_decr || (fx != fx)) {
+            width = ((fx - fx_init) > 2. * std::max(std::fabs(fx_init), 1.)) ? 0.5 / 16. : 0.5;
+          } else {
+            break;                                                      // Armijo condition is met
+          }
+          step *= width;
+        }
+        if (iter >= max_linesearch) {
+          x[0] = xp[0]; x[1] = xp[1];
+          st.sigma2 = st.sigma2_lag1;                                   // ResetProfiledOutVariablesToLag1
+          fx = fx_init;
+          step = 0.;
+        }
+      }
+      double dummy;
+      if (lbfgs_objective(st, x, false, true, false, &dummy, grad)) return -1;   // gradient of the CURRENT factor
+      gnorm = std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]);
+      bool has_converged = gnorm <= epsilon || gnorm <= epsilon_rel * std::sqrt(x[0] * x[0] + x[1] * x[1]);
+      if ((fx_past - fx) <= delta * std::max(std::fabs(fx_past), 1.)) has_converged = true;
+      if (cfg.max_iter != 0 && k >= cfg.max_iter) has_converged = true;
+      st.sigma2_lag1 = st.sigma2;                                       // SetLag1ProfiledOutVariables
+      if (cfg.trace)
+        fprintf(stderr, "[gpboost_amd] lbfgs it %d: sigma2 %.10g ratio %.10g a %.10g negll %.10g step %g\n", k, st.sigma2, std::exp(x[0]),
+                std::exp(x[1]), fx, step);
+      if (has_converged) break;
+      const double sv[2] = {x[0] - xp[0], x[1] - xp[1]}, yv[2] = {grad[0] - gradp[0], grad[1] - gradp[1]};
+      if (sv[0] * yv[0] + sv[1] * yv[1] > eps * (yv[0] * yv[0] + yv[1] * yv[1])) bfgs.add_correction(sv, yv);
+      step = 1.;
+      bfgs.apply_Hv(grad, -1., drt);
+      fx_past = fx;
+      ++k;
+    }
+  }
+  if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
+    return fail("NaN or Inf occurred in covariance parameter optimization using 'lbfgs' (the reference restarts with 'nelder_mead' here, "
+                "which is not on the MI355X path); try other initial values");
+  th[0] = st.sigma2; th[1] = std::exp(x[0]); th[2] = std::exp(x[1]);   // OptimExternal :690-693
+  st.negll = fx;
+  out->num_it = k;
+  out->lr_cov_final = initial_step_factor;
+  return 0;
+}
+
+}  // namespace
+
+int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_terms_fn fn, void* ctx, const double theta_init[3],
+                                   GpbOptimResult* out, char* err, int errlen) {
+  const Fail fail{err, errlen};
+  if (err && errlen > 0) err[0] = 0;
+  if (!fn || !out || !theta_init) return fail("gpb_optimize_gaussian_cov_pars: null argument");
+  if (!(theta_init[0] > 0.) || !(theta_init[1] > 0.) || !(theta_init[2] > 0.))
+    return fail("Initial covariance parameters need to be positive (found %g, %g, %g on the transformed scale)", theta_init[0], theta_init[1],
+                theta_init[2]);
+  State st{cfg, num_data, fn, ctx};
+  double th[3] = {theta_init[0], theta_init[1], theta_init[2]};
+  *out = GpbOptimResult();
+  int rc = 0;
+  if (cfg.max_iter > 0) {
+    if (cfg.optimizer == "gradient_descent") rc = run_gradient_descent(st, cfg, th, out, fail);
+    else if (cfg.optimizer == "lbfgs") rc = run_lbfgs(st, cfg, th, out, fail);
+    else
+      return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent')", cfg.optimizer.c_str());
+    if (rc) {
+      if (!err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation");
+      return -1;
+    }
+  }
+  std::copy(th, th + 3, out->theta);
+  out->negll = st.negll;
+  out->num_ll_evals = st.n_ll;
+  out->num_grad_evals = st.n_grad;
+  return 0;
+}

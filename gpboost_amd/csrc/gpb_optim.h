@@ -1,0 +1,57 @@
+// gpboost_amd/csrc/gpb_optim.h -- the caller of the hot path: covariance-parameter estimation for one Gaussian GP
+// (SURVEY.md section 8f rank 1).  Host control flow only; every likelihood / gradient evaluation goes through a
+// callback that returns the seven shard sums of the device kernels (include/gpb_hip.h: gpb_hip_vecchia_grad_terms),
+// so y, the coordinates and the neighbour table stay resident in HBM for the whole fit and 3 or 7 doubles cross
+// PCIe per evaluation.
+//
+// Restates, for gauss_likelihood_ && !has_covariates_ && one GP component:
+//   REModelTemplate::OptimLinRegrCoefCovPar   include/GPBoost/re_model_template.h:972-1802   (internal "gradient_descent" loop)
+//   UpdateCovAuxPars / ApplyMomentumStep      :8691-8846, :5077-5100, NesterovSchedule :6143-6158
+//   AvoidTooLargeLearningRatesCovAuxPars      :8353-8375, MaximalLearningRateCovAuxPars :5413-5421
+//   CalcDirDerivArmijo...CovAuxPars           :8425-8476
+//   ProfileOutSigma2                          :2640-2650, EvalNegLogLikelihoodOnlyUpdateNuggetVariance :3140-3143
+//   CheckOptimizerHasConverged                :1928-1949
+//   ApplyGaussianNuggetLowerBound             :7849-7874
+//   OptimExternal / EvalLLforLBFGSpp          include/GPBoost/optim_utils.h:244-420, :575-711  ("lbfgs", the default)
+//   LBFGSSolver::minimize                     external_libs/LBFGSpp/include/LBFGS.h:86-300 (GPBoost's modified copy)
+//   LineSearchBacktracking::LineSearch        external_libs/LBFGSpp/include/LBFGSpp/LineSearchBacktracking.h:44-143
+//   BFGSMat::add_correction / apply_Hv        external_libs/LBFGSpp/include/LBFGSpp/BFGSMat.h:89-186
+// The parameter vector is the reference's TRANSFORMED one (re_model.cpp:301-318): theta = (sigma2, sigma1_2 / sigma2, a).
+#ifndef GPB_OPTIM_H_
+#define GPB_OPTIM_H_
+
+#include <string>
+
+// t7 = { y' Psi^-1 y, log det Psi, (unused), dB-term and dD-term of the variance parameter, the same two for the range }
+// (the layout of gpb_hip_vecchia_grad_terms); with_grad == 0 only needs t7[0..1].  Returns 0 on success.
+typedef int (*gpb_terms_fn)(void* ctx, double ratio, double a, int with_grad, double* t7);
+
+struct GpbOptimConfig {                      // defaults: re_model_template.h:5689-5851
+  std::string optimizer = "lbfgs";           // InitializeOptimSettings :8277-8280
+  double lr_cov_init = -999.;                // 0.1 for gradient_descent, 1 otherwise (SetInitialValueLRCov :8318-8335)
+  double acc_rate_cov = 0.5;
+  double delta_rel_conv_init = -999.;        // 1e-6 (SetInitialValueDeltaRelConv :8338-8347)
+  int max_iter = 1000;
+  bool use_nesterov_acc = true;
+  int nesterov_schedule_version = 0;
+  int momentum_offset = 2;
+  std::string convergence_criterion = "relative_change_in_log_likelihood";
+  int m_lbfgs = 6;
+  double range_const = 1.;                   // sqrt(2 nu): only used by the nugget-bound round trip (TransformBack -> Transform)
+  bool trace = false;
+};
+
+struct GpbOptimResult {
+  double theta[3];          // transformed scale
+  int num_it = 0;
+  double negll = 0.;
+  int num_ll_evals = 0;     // device launches without / with gradient terms
+  int num_grad_evals = 0;
+  double lr_cov_final = 0.;
+};
+
+// 0 = ok, -1 = error (message in err, at most errlen bytes)
+int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_terms_fn fn, void* ctx, const double theta_init[3],
+                                   GpbOptimResult* out, char* err, int errlen);
+
+#endif  // GPB_OPTIM_H_

@@ -74,9 +74,11 @@ GPBOOST_C_EXPORT int GPB_CreateREModel(int32_t num_data,
 /* c_api.h:1398 */
 GPBOOST_C_EXPORT int GPB_REModelFree(REModelHandle handle);
 
-/* c_api.h:1437-1467 -- the optimiser itself is host code outside this library; what IS used on the path: trace, and for
- * the Laplace path cg_max_num_it, cg_max_num_it_tridiag, cg_delta_conv, num_rand_vec_trace, seed_rand_vec_trace,
- * delta_conv_mode_finding (-999 keeps the reference's default) and cg_preconditioner_type (only "vadu") */
+/* c_api.h:1437-1467 -- used: init_cov_pars, lr, acc_rate_cov, max_iter, delta_rel_conv, use_nesterov_acc,
+ * nesterov_schedule_version, trace, optimizer ("lbfgs" = default | "gradient_descent"), momentum_offset, convergence_criterion,
+ * m_lbfgs (GPB_OptimCovPar below); for the Laplace path cg_max_num_it, cg_max_num_it_tridiag, cg_delta_conv, num_rand_vec_trace,
+ * seed_rand_vec_trace, delta_conv_mode_finding and cg_preconditioner_type (only "vadu").  -999 / "" / "default" keep the
+ * reference's defaults.  num_covariates > 0, estimate_aux_pars and estimate_cov_par_index[0] >= 0 return -1. */
 GPBOOST_C_EXPORT int GPB_SetOptimConfig(REModelHandle handle,
     double* init_cov_pars,
     double lr,
@@ -122,6 +124,20 @@ GPBOOST_C_EXPORT int GPB_EvalNegLogLikelihood(REModelHandle handle,
 /* c_api.h:1517 */
 GPBOOST_C_EXPORT int GPB_GetCurrentNegLogLikelihood(REModelHandle handle, double* negll);
 
+/* c_api.h:1476-1478 -- maximum-likelihood estimation of (sigma2, sigma1_2, rho): the direct caller of the hot path
+ * (REModel::OptimCovPar, re_model.cpp:483-546 -> REModelTemplate::OptimLinRegrCoefCovPar, re_model_template.h:972-1802).
+ * Gaussian likelihood + gp_approx "vecchia"; optimizer_cov "lbfgs" (default; LBFGSpp with the backtracking Armijo line search,
+ * nugget profiled out) or "gradient_descent" (Nesterov acceleration, Armijo step halving, nugget profiled out).  y is uploaded
+ * ONCE; every likelihood / gradient evaluation of the fit returns 3 or 7 doubles from the device.  Without init_cov_pars the
+ * initial values are the reference's (FindInitCovPar, re_model_template.h:4849-4968, cov_fcts.h:1422-1683). */
+GPBOOST_C_EXPORT int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fixed_effects);
+/* c_api.h:1534-1536 -- (sigma2, sigma1_2, rho) on the original scale; calc_std_dev = true (Fisher information) returns -1 */
+GPBOOST_C_EXPORT int GPB_GetCovPar(REModelHandle handle, double* optim_cov_pars, bool calc_std_dev);
+/* c_api.h:1545-1546 -- -1 in every entry while no initial values exist */
+GPBOOST_C_EXPORT int GPB_GetInitCovPar(REModelHandle handle, double* init_cov_pars);
+/* c_api.h:1567-1568 */
+GPBOOST_C_EXPORT int GPB_GetNumIt(REModelHandle handle, int* num_it);
+
 /* c_api.h:1686-1688 */
 GPBOOST_C_EXPORT int GPB_GetLikelihoodName(REModelHandle handle, char* out_str, int* num_char);
 
@@ -150,6 +166,16 @@ GPBOOST_C_EXPORT int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* 
 /* Diagnostics of the last Laplace evaluation (likelihood != "gaussian"): the nine values documented at
  * gpb_hip_vecchia_laplace_logit (include/gpb_hip.h) -- iteration counts, log-determinant, phase times */
 GPBOOST_C_EXPORT int GPB_HIP_GetLaplaceInfo(REModelHandle handle, double* out9);
+/* Launch counts of the last GPB_OptimCovPar (likelihood-only launches, launches with gradient sums) and the final learning rate */
+GPBOOST_C_EXPORT int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_evals, double* lr_cov_final);
+/* Test seam: the host optimiser of GPB_OptimCovPar with a caller-supplied evaluation callback
+ * terms(ctx, sigma1_2 / sigma2, a, with_grad, t7) -> 0 | -1 that fills the seven shard sums of gpb_hip_vecchia_grad_terms
+ * (t7[0..1] only when with_grad == 0).  init_theta / theta_out = (sigma2, sigma1_2 / sigma2, a): the reference's transformed
+ * scale (re_model.cpp:301-318).  range_const = sqrt(2 nu).  num_evals2 = {likelihood-only calls, calls with gradient}. */
+GPBOOST_C_EXPORT int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_theta, const char* optimizer,
+    double lr_cov, double acc_rate_cov, int max_iter, double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version,
+    int momentum_offset, const char* convergence_criterion, int m_lbfgs, double range_const,
+    int (*terms)(void*, double, double, int, double*), void* ctx, double* theta_out, int* num_it, double* negll, int* num_evals2);
 /* The underlying gpb_hip_vecchia_t* (include/gpb_hip.h) for resident / sharded use */
 GPBOOST_C_EXPORT void* GPB_HIP_GetVecchiaHandle(REModelHandle handle);
 

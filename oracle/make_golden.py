@@ -108,6 +108,23 @@ def tree_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "tree_ref.npz"), **res)
 
 
+def optim_fixture(out_dir):
+    """The reference's own GPB_SetOptimConfig + GPB_OptimCovPar (one OpenMP thread) for tests/cases.py:OPTIM_CASES."""
+    res = {}
+    for name in cases.OPTIM_CASES:
+        coords, y, ids, mc, init, cfg = cases.optim_case(name)
+        mdl = refdrv.RefCAPIModel(coords, mc["cov_function"], mc["shape"], mc["m"], mc["ordering"], mc["seed"], threads=1, cluster_ids=ids)
+        if init is not None or cfg:
+            mdl.set_optim_config(init_cov_pars=init, **cfg)
+        mdl.optim_cov_par(y)
+        res[name + "_cov_pars"] = mdl.get_cov_par()
+        res[name + "_init_cov_pars"] = mdl.get_init_cov_par()
+        res[name + "_num_it"] = np.int32(mdl.get_num_it())
+        res[name + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        print("optim", name, res[name + "_init_cov_pars"], "->", res[name + "_cov_pars"], res[name + "_num_it"], res[name + "_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "optim_ref.npz"), **res)
+
+
 def cluster_fixture(out_dir):
     """Reference nll of a model with several clusters (independent GP realisations), random Vecchia ordering: pins the cluster
     order (first appearance) and the ONE shared std::mt19937 that shuffles cluster after cluster."""
@@ -138,6 +155,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "optim":
+        optim_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "tree":
         tree_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "split":

@@ -117,6 +117,52 @@ class RefCAPIModel(object):
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
         return out.value
 
+    def set_optim_config(self, init_cov_pars=None, lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
+                         use_nesterov_acc=True, nesterov_schedule_version=-999, trace=False, optimizer_cov="", momentum_offset=-999,
+                         convergence_criterion="default", m_lbfgs=-999):
+        """GPB_SetOptimConfig with the argument order of include/LightGBM/c_api.h:1437-1467 (basic.py:5460-5496 binds it the same way)."""
+        s = lambda x: C.c_char_p(x.encode())
+        ic = None if init_cov_pars is None else np.ascontiguousarray(init_cov_pars, dtype=np.float64)
+        est = np.array([-1], dtype=np.int32)
+        rc = self.L.GPB_SetOptimConfig(
+            self.h, C.c_void_p() if ic is None else _P(ic), C.c_double(lr_cov), C.c_double(acc_rate_cov), C.c_int(max_iter),
+            C.c_double(delta_rel_conv), C.c_bool(use_nesterov_acc), C.c_int(nesterov_schedule_version), C.c_bool(trace), s(optimizer_cov),
+            C.c_int(momentum_offset), s(convergence_criterion), C.c_int(0), C.c_void_p(), C.c_double(-999.), C.c_double(-999.), s(""),
+            C.c_int(-999), C.c_int(-999), C.c_double(-999.), C.c_int(-999), C.c_bool(True), s("vadu"), C.c_int(1), C.c_int(-999),
+            C.c_void_p(), C.c_bool(False), C.c_bool(False), _P(est), C.c_int(m_lbfgs), C.c_double(-999.))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+
+    def optim_cov_par(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        rc = self.L.GPB_OptimCovPar(self.h, _P(y), C.c_void_p())
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+
+    def get_cov_par(self):
+        out = np.empty(3)
+        rc = self.L.GPB_GetCovPar(self.h, _P(out), C.c_bool(False))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out
+
+    def get_init_cov_par(self):
+        out = np.empty(3)
+        rc = self.L.GPB_GetInitCovPar(self.h, _P(out))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out
+
+    def get_num_it(self):
+        out = C.c_int(0)
+        self.L.GPB_GetNumIt(self.h, C.byref(out))
+        return out.value
+
+    def current_neg_log_likelihood(self):
+        out = C.c_double(0)
+        self.L.GPB_GetCurrentNegLogLikelihood(self.h, C.byref(out))
+        return out.value
+
     def __del__(self):
         try:
             self.L.GPB_REModelFree(self.h)

@@ -164,6 +164,47 @@ def make_cluster_data(c=CLUSTER_CASE):
     return coords, y, ids
 
 
+# Parameter estimation (GPB_OptimCovPar): model / data of a GOLDEN_CASES entry (or "clusters" = CLUSTER_CASE) + optimiser settings.
+# init = "r" -> (var(y)/2, var(y)/2, mean(dist)/3) as in R-package/tests/testthat/test_GPModel_gaussian_process.R:1096; None ->
+# the reference's own FindInitCovPar.  Outputs of the reference's GPB_OptimCovPar are stored in tests/golden/optim_ref.npz.
+R_GD = dict(optimizer_cov="gradient_descent", lr_cov=0.1, acc_rate_cov=0.5, delta_rel_conv=1e-6, use_nesterov_acc=True)
+OPTIM_CASES = {
+    # the R suite's own fit: 378 iterations, (0.03297349, 1.07691542, 0.11378505), nll 122.7680889 (test_GPModel_gaussian_process.R:1316-1324)
+    "r_gd_nesterov_parcrit": dict(model="r_exp_m30_none", init="r", cpu=True, cfg=dict(R_GD, convergence_criterion="relative_change_in_parameters")),
+    "r_gd_nesterov_llcrit": dict(model="r_exp_m30_none", init=None, cpu=True, cfg=dict(R_GD)),
+    "r_gd_plain": dict(model="r_exp_m30_none", init=None, cpu=True, cfg=dict(optimizer_cov="gradient_descent", use_nesterov_acc=False)),
+    "r_gd_offset0_lr1": dict(model="r_exp_m30_none", init="r", cpu=True,
+                             cfg=dict(optimizer_cov="gradient_descent", lr_cov=1.0, acc_rate_cov=0.7, momentum_offset=0)),   # step halving
+    "r_gd_maxiter7": dict(model="r_exp_m30_none", init=None, cpu=True, cfg=dict(R_GD, max_iter=7)),
+    "r_lbfgs_default": dict(model="r_exp_m30_none", init=None, cpu=True, cfg=dict()),
+    "r_lbfgs_init_m3": dict(model="r_exp_m30_none", init="r", cpu=True, cfg=dict(optimizer_cov="lbfgs", m_lbfgs=3, delta_rel_conv=1e-9)),
+    "r_mat15_lbfgs": dict(model="r_mat15_m30_random", init=None, cpu=True, cfg=dict()),
+    "r_mat25_gd": dict(model="r_mat25_m99_none", init=None, cpu=True, cfg=dict(R_GD)),
+    "u1d_n1000_mat15_lbfgs": dict(model="u1d_n1000_mat15_m10", init=None, cpu=True, cfg=dict()),
+    "dup2d_n600_gd": dict(model="dup2d_n600_exp_m15", init=None, cpu=False, cfg=dict(R_GD)),
+    "u2d_n3000_lbfgs": dict(model="u2d_n3000_exp_m30", init=None, cpu=True, cfg=dict()),          # n > 1000: sub-sampled FindInitCovPar
+    "u3d_n3000_mat25_gd": dict(model="u3d_n3000_mat25_m40", init=None, cpu=False, cfg=dict(R_GD)),
+    "clusters_lbfgs": dict(model="clusters", init=None, cpu=False, cfg=dict()),
+}
+
+
+def optim_case(name):
+    """-> (coords, y, cluster_ids | None, model dict, init_cov_pars | None, cfg dict)"""
+    c = OPTIM_CASES[name]
+    if c["model"] == "clusters":
+        mc = CLUSTER_CASE
+        coords, y, ids = make_cluster_data(mc)
+    else:
+        mc = GOLDEN_CASES[c["model"]]
+        coords, y = make_data(mc)
+        ids = None
+    init = None
+    if c["init"] == "r":
+        from scipy.spatial.distance import pdist
+        init = np.array([np.var(y, ddof=1) / 2, np.var(y, ddof=1) / 2, pdist(coords).mean() / 3])
+    return coords, y, ids, mc, init, c["cfg"]
+
+
 def synthetic(n, d, seed=1):
     """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
     rng = np.random.default_rng(seed)

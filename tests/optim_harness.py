@@ -1,0 +1,46 @@
+"""Test harness: the product's host optimiser (gpboost_amd/csrc/gpb_optim.cpp, entry GPB_HIP_OptimizeGaussianWithCallback) driven by
+the CPU oracle's likelihood / gradient instead of the device kernels, so that its control flow can be compared with the reference's
+own optimisation trajectories without a GPU.  TEST INFRASTRUCTURE."""
+import ctypes as C
+
+import numpy as np
+
+TERMS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double))
+
+
+def oracle_terms(orc, coords_ord, nn, cov_type, y_ord):
+    """Callback returning the seven shard sums from the oracle: grad_k(s) = t_k1 / s + t_k2 evaluated at s = 1 and s = 2."""
+    calls = []
+
+    def fn(ctx, ratio, a, with_grad, t7):
+        calls.append((ratio, a, with_grad))
+        if with_grad:
+            o1, g1 = orc.vecchia_nll_grad(coords_ord, nn, cov_type, (1.0, ratio, a), y_ord)
+            o2, g2 = orc.vecchia_nll_grad(coords_ord, nn, cov_type, (2.0, ratio, a), y_ord)
+            t7[0], t7[1], t7[2] = o1[0], o1[1], 0.0
+            for k in (1, 2):
+                ta = 2.0 * (g1[k] - g2[k])
+                t7[1 + 2 * k], t7[2 + 2 * k] = ta, g1[k] - ta
+        else:
+            o1 = orc.vecchia_nll(coords_ord, nn, cov_type, (1.0, ratio, a), y_ord)
+            t7[0], t7[1], t7[2] = o1[0], o1[1], 0.0
+        return 0
+    return TERMS_FN(fn), calls
+
+
+def optimize(lib, n, init_theta, terms_cb, optimizer="lbfgs", lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
+             use_nesterov_acc=True, nesterov_schedule_version=-999, momentum_offset=-999, convergence_criterion="default", m_lbfgs=-999,
+             range_const=1.0):
+    th0 = np.ascontiguousarray(init_theta, dtype=np.float64)
+    out = np.empty(3); nit = C.c_int(0); nll = C.c_double(0); ne = np.zeros(2, dtype=np.int32)
+    lib.GPB_HIP_OptimizeGaussianWithCallback.argtypes = [
+        C.c_int32, C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_bool, C.c_int, C.c_int, C.c_char_p, C.c_int,
+        C.c_double, TERMS_FN, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
+    lib.LGBM_GetLastError.restype = C.c_char_p
+    rc = lib.GPB_HIP_OptimizeGaussianWithCallback(
+        n, th0.ctypes.data, optimizer.encode(), lr_cov, acc_rate_cov, max_iter, delta_rel_conv, use_nesterov_acc, nesterov_schedule_version,
+        momentum_offset, convergence_criterion.encode(), m_lbfgs, range_const, terms_cb, None, out.ctypes.data, C.byref(nit),
+        C.byref(nll), ne.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(lib.LGBM_GetLastError().decode())
+    return out, nit.value, nll.value, ne

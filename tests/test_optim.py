@@ -1,0 +1,121 @@
+"""Parameter estimation (GPB_OptimCovPar -- the direct caller of the hot path).
+
+Pins: tests/golden/optim_ref.npz = the reference's own GPB_SetOptimConfig + GPB_OptimCovPar on tests/cases.py:OPTIM_CASES
+(oracle/make_golden.py optim), and the R suite's golden fit (378 iterations, test_GPModel_gaussian_process.R:1316-1324).
+CPU tests drive the product's host optimiser with the oracle's likelihood / gradient; GPU tests run the whole path on the MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "optim_ref.npz")
+CPU_CASES = [k for k, c in cases.OPTIM_CASES.items() if c["cpu"]]
+
+
+def _cfg_kwargs(cfg):
+    m = dict(cfg)
+    if "optimizer_cov" in m:
+        m["optimizer"] = m.pop("optimizer_cov")
+    return m
+
+
+def _check(name, g, cov_pars, num_it, negll):
+    # identical control flow: same number of iterations; parameters / likelihood to the accuracy of the evaluations (1e-8 relative
+    # per evaluation, accumulated over the trajectory)
+    assert num_it == int(g[name + "_num_it"]), (num_it, int(g[name + "_num_it"]))
+    np.testing.assert_allclose(cov_pars, g[name + "_cov_pars"], rtol=2e-6)
+    np.testing.assert_allclose(negll, float(g[name + "_negll"]), rtol=1e-9)
+
+
+def test_r_suite_golden_is_in_the_fixture():
+    """test_GPModel_gaussian_process.R:1316-1324 (fit of the Vecchia model with 30 neighbours)."""
+    g = np.load(GOLDEN)
+    assert int(g["r_gd_nesterov_parcrit_num_it"]) == 378
+    np.testing.assert_allclose(g["r_gd_nesterov_parcrit_cov_pars"], [0.03297349, 1.07691542, 0.11378505], atol=1e-6)
+    assert abs(float(g["r_gd_nesterov_parcrit_negll"]) - 122.7680889) < 1e-6
+
+
+@pytest.mark.parametrize("name", CPU_CASES)
+def test_host_optimiser_follows_the_reference_trajectory(lib_built, name):
+    from oracle import orc
+    from tests import optim_harness as oh
+    g = np.load(GOLDEN)
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    assert ids is None
+    ct = orc.cov_type_id(mc["cov_function"], mc["shape"])
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    th0 = orc.transform_cov_pars(ct, g[name + "_init_cov_pars"])          # FindInitCovPar itself is checked on the GPU (needs a model)
+    if init is not None:
+        np.testing.assert_allclose(g[name + "_init_cov_pars"], init, rtol=1e-12)
+    cb, calls = oh.oracle_terms(orc, co, nn, ct, y[perm])
+    lib = C.CDLL(lib_built)
+    th, nit, nll, ne = oh.optimize(lib, coords.shape[0], th0, cb, range_const=[1.0, np.sqrt(3.0), np.sqrt(5.0)][ct], **_cfg_kwargs(cfg))
+    cov_pars = np.array([th[0], th[1] * th[0], [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct] / th[2]])
+    _check(name, g, cov_pars, nit, nll)
+    assert ne[0] + ne[1] == len(calls)
+
+
+def test_host_optimiser_errors(lib_built):
+    from tests import optim_harness as oh
+    lib = C.CDLL(lib_built)
+    cb = oh.TERMS_FN(lambda ctx, r, a, wg, t7: -1)
+    with pytest.raises(RuntimeError, match="not on the MI355X path"):
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="nelder_mead")
+    with pytest.raises(RuntimeError, match="nesterov_schedule_version = 1"):
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="gradient_descent", nesterov_schedule_version=1)
+    with pytest.raises(RuntimeError, match="positive"):
+        oh.optimize(lib, 10, [1.0, -1.0, 1.0], cb)
+    with pytest.raises(RuntimeError):                      # failing evaluation callback -> -1, no crash
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb)
+
+    def nan_terms(ctx, r, a, wg, t7):
+        for q in range(7):
+            t7[q] = float("nan")
+        return 0
+    with pytest.raises(RuntimeError, match="NaN occurred in initial"):
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], oh.TERMS_FN(nan_terms), optimizer="gradient_descent")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.OPTIM_CASES))
+def test_fit_on_device_matches_the_reference(lib_built, name):
+    import gpboost_amd
+    g = np.load(GOLDEN)
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    if mc["m"] > 62:
+        pytest.skip("num_neighbors > 62 is outside the device kernel's instantiations (covered by the CPU trajectory test)")
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function=mc["cov_function"], cov_fct_shape=mc["shape"], gp_approx="vecchia",
+                              num_neighbors=mc["m"], vecchia_ordering=mc["ordering"], seed=mc["seed"], cluster_ids=ids)
+    params = {("maxit" if k == "max_iter" else k): v for k, v in cfg.items()}
+    if init is not None:
+        params["init_cov_pars"] = init
+    assert np.all(mdl._get_init_cov_pars() == -1.0) or init is not None
+    mdl.fit(y, params=params if params else None)
+    np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-10)    # FindInitCovPar (or the given values)
+    _check(name, g, mdl.get_cov_pars(), mdl.get_num_optim_iter(), mdl.get_current_neg_log_likelihood())
+    info = mdl.optim_info()
+    assert info["num_grad_evals"] >= mdl.get_num_optim_iter()
+    # the stored parameters are the estimates: evaluating the likelihood there reproduces the optimum
+    nll = mdl.neg_log_likelihood(cov_pars=mdl.get_cov_pars(), y=y)
+    assert abs(nll - mdl.get_current_neg_log_likelihood()) <= 1e-9 * abs(nll)
+    assert abs(mdl.neg_log_likelihood(y=y) - nll) <= 1e-9 * abs(nll)
+
+
+@pytest.mark.gpu
+def test_fit_errors_on_device(lib_built):
+    import gpboost_amd
+    coords, y = cases.make_data(cases.GOLDEN_CASES["r_exp_m30_none"])
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10, vecchia_ordering="none")
+    with pytest.raises(gpboost_amd.GPBoostError, match="not on the MI355X path"):
+        mdl.fit(y, params={"optimizer_cov": "fisher_scoring"})
+    with pytest.raises(gpboost_amd.GPBoostError, match="standard deviations"):
+        mdl.fit(y, params={"optimizer_cov": "lbfgs"}).get_cov_pars(std_err=True)
+    yb = y.copy(); yb[3] = np.nan
+    with pytest.raises(gpboost_amd.GPBoostError, match="NaN or Inf in response"):
+        mdl.fit(yb)
+    ex = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="none")
+    with pytest.raises(gpboost_amd.GPBoostError, match="gp_approx 'none'"):
+        ex.fit(y)
