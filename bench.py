@@ -286,6 +286,24 @@ def main():
                 del m4
             except Exception as e:
                 out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1:
+            # the direct caller of the hot path: a complete maximum-likelihood fit of (sigma2, sigma1_2, rho) on the
+            # bench model -- y uploaded once, 3 / 7 doubles back per evaluation.  y = smooth signal + noise so that the optimum is interior.
+            try:
+                yf = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
+                st.set_shard(0, n)
+                tf = time.perf_counter()
+                mdl.fit(yf, params={"optimizer_cov": "lbfgs"})
+                sf = time.perf_counter() - tf
+                oi = mdl.optim_info()
+                out["fit_covariance_parameters"] = {
+                    "workload": "GPB_OptimCovPar, lbfgs (reference default), n=%d, m=%d, %s: the bench model, y = sin(4 x0) + 0.5 eps" % (n, m, args.cov),
+                    "s_per_fit": sf, "num_it": mdl.get_num_optim_iter(), "launches_likelihood_only": oi["num_ll_evals"],
+                    "launches_with_gradient": oi["num_grad_evals"], "cov_pars": [float(v) for v in mdl.get_cov_pars()],
+                    "negll": mdl.get_current_neg_log_likelihood(),
+                    "reference": "DESIGN.md 4.10: unmodified reference, same data recipe at n=1e5, this repo's build container"}
+            except Exception as e:
+                out["fit_covariance_parameters"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)
