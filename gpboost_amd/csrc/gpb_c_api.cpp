@@ -183,8 +183,14 @@ int device_terms(void* ctx, double ratio, double a, int with_grad, double* t7) {
   for (int q = 0; q < 7; ++q) t7[q] = 0.;
   for (auto* v : mdl->vhs) {
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (with_grad ? gpb_hip_vecchia_grad_terms(v, mdl->cov_type, ratio, a, t) : gpb_hip_vecchia_nll_terms(v, mdl->cov_type, ratio, a, 1, t))
-      return shim_error();
+    int world = 0;
+    if (gpb_hip_vecchia_comm_info(v, nullptr, &world)) return shim_error();
+    int rc;
+    if (world > 0)      // sharded handle: job-wide sums on every rank (one ncclAllReduce of 3 / 7 doubles per evaluation)
+      rc = with_grad ? gpb_hip_vecchia_grad_terms_allreduce(v, mdl->cov_type, ratio, a, t) : gpb_hip_vecchia_nll_terms_allreduce(v, mdl->cov_type, ratio, a, 1, t);
+    else
+      rc = with_grad ? gpb_hip_vecchia_grad_terms(v, mdl->cov_type, ratio, a, t) : gpb_hip_vecchia_nll_terms(v, mdl->cov_type, ratio, a, 1, t);
+    if (rc) return shim_error();
     for (int q = 0; q < (with_grad ? 7 : 3); ++q) t7[q] += t[q];
   }
   return 0;

@@ -487,6 +487,14 @@ int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, 
   API_END();
 }
 
+int gpb_hip_vecchia_comm_info(gpb_hip_vecchia_t* h, int* rank, int* world) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  if (rank) *rank = h->comm ? h->comm_rank : 0;
+  if (world) *world = h->comm ? h->comm_world : 0;
+  API_END();
+}
+
 // point kernel + fixed-order reduction + ncclAllReduce(sum) of the 3 / 7 terms on the handle's stream, result to the host
 static int vecchia_allreduce_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss,
                                    double* out_host, int nout) {

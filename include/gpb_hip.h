@@ -116,6 +116,9 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_grad_terms_dev(gpb_hip_vecchia_t* h, int cov_
  * stream and deliver the job-wide terms to every rank's host -- one launch sequence, one collective, one sync per evaluation. */
 GPB_HIP_EXPORT int gpb_hip_comm_get_unique_id(unsigned char* id128);
 GPB_HIP_EXPORT int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, int rank, int world);
+/* rank / world of the handle's communicator; world = 0 while there is none.  GPB_OptimCovPar (gpboost_c_api_subset.h) evaluates
+ * through the *_allreduce forms whenever a communicator exists, so a sharded fit is the same host loop on every rank. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_comm_info(gpb_hip_vecchia_t* h, int* rank, int* world);
 /* Multi-GPU neighbour search: rank r searches the r-th of `nparts` equal blocks of query positions in
  * coordinate-sum order (balanced: that order is random with respect to the index that decides a query's cost), rows of the other
  * queries are left at a value < -1; gpb_hip_vecchia_neighbors_allreduce completes the table on every rank with ONE

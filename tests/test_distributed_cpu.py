@@ -146,3 +146,65 @@ def test_shard_range_covers_everything():
                 assert a[1] == b[0]
             sizes = [e[1] - e[0] for e in edges]
             assert max(sizes) - min(sizes) <= 16 * w
+
+
+def _worker_fit(rank, world, port, q):
+    """Sharded parameter estimation: every rank runs the product's host optimiser (GPB_HIP_OptimizeGaussianWithCallback); its
+    evaluation callback returns the all-reduced (gloo) shard sums, the oracle standing in for the per-shard kernel."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from gpboost_amd import parallel
+    from gpboost_amd.libpath import find_lib_path
+    from oracle import orc
+    from tests import cases, optim_harness as oh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    name = "r_lbfgs_default"
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "optim_ref.npz"))
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    yv = y[perm]
+    i0, i1 = parallel.shard_range(len(yv), rank, world)
+    sl = slice(i0, i1)
+    ynn = np.where(nn >= 0, yv[np.maximum(nn, 0)], 0.)
+
+    def terms(ctx, ratio, a, with_grad, t7):
+        A, D, Ag, Dg, bad = orc.vecchia_factor(co, nn, 0, ratio, a, grad=True)
+        u = yv - np.einsum("ij,ij->i", A, ynn)
+        up = u / D
+        uk = [-np.einsum("ij,ij->i", Ag[p], ynn) for p in range(2)]
+        loc = np.array([np.sum(u[sl] ** 2 / D[sl]), np.sum(np.log(D[sl])), 0.,
+                        np.sum(uk[0][sl] * up[sl] - 0.5 * up[sl] ** 2 * Dg[0][sl]), np.sum(0.5 * Dg[0][sl] / D[sl]),
+                        np.sum(uk[1][sl] * up[sl] - 0.5 * up[sl] ** 2 * Dg[1][sl]), np.sum(0.5 * Dg[1][sl] / D[sl])])
+        tot = parallel.allreduce_terms(torch.from_numpy(loc)).numpy()
+        for k in range(7):
+            t7[k] = tot[k]
+        return 0
+    lib = C.CDLL(find_lib_path())
+    th0 = orc.transform_cov_pars(0, g[name + "_init_cov_pars"])
+    th, nit, nll, ne = oh.optimize(lib, len(yv), th0, oh.TERMS_FN(terms))
+    q.put((rank, [th[0], th[1] * th[0], 1.0 / th[2]], nit, nll, g[name + "_cov_pars"].tolist(), int(g[name + "_num_it"]), float(g[name + "_negll"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_fit_follows_the_reference_trajectory():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fit, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2] and res[0][3] == res[1][3]      # identical decisions on both ranks
+    for r in res:
+        assert r[2] == r[5]
+        np.testing.assert_allclose(r[1], r[4], rtol=2e-6)
+        assert abs(r[3] - r[6]) <= 1e-9 * abs(r[6])

@@ -105,6 +105,23 @@ def test_fit_on_device_matches_the_reference(lib_built, name):
 
 
 @pytest.mark.gpu
+def test_fit_through_the_rccl_path_single_rank(lib_built):
+    """A sharded fit is the same host loop on every rank over all-reduced sums: with a 1-rank communicator on the model's handle
+    GPB_OptimCovPar evaluates through kernel + reduction + ncclAllReduce and must reproduce the plain fit exactly."""
+    import gpboost_amd
+    from gpboost_amd import shim
+    g = np.load(GOLDEN)
+    name = "u2d_n3000_lbfgs"
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function=mc["cov_function"], cov_fct_shape=mc["shape"], gp_approx="vecchia",
+                              num_neighbors=mc["m"], vecchia_ordering=mc["ordering"], seed=mc["seed"])
+    st = shim.VecchiaState.from_handle(mdl.vecchia_handle(), len(y), coords.shape[1], mc["m"])
+    st.comm_init(shim.comm_unique_id(), 0, 1)
+    mdl.fit(y)
+    _check(name, g, mdl.get_cov_pars(), mdl.get_num_optim_iter(), mdl.get_current_neg_log_likelihood())
+
+
+@pytest.mark.gpu
 def test_fit_errors_on_device(lib_built):
     import gpboost_amd
     coords, y = cases.make_data(cases.GOLDEN_CASES["r_exp_m30_none"])
