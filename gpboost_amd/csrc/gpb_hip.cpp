@@ -115,6 +115,7 @@ struct gpb_hip_hist {
   int device = 0;
   hipStream_t stream = nullptr;
   int n = 0, F = 0, fpad = 0, total_bins = 0;
+  int num_cu = 0;                                          // compute units of the device (chunking of the build kernel)
   uint8_t* d_bins_rm = nullptr;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
@@ -960,9 +961,11 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
     if (h->idx_cap < num_data) { dev_free(h->d_idx); HIP_OK(hipMalloc(&h->d_idx, sizeof(int) * (size_t)h->n)); h->idx_cap = h->n; }
     HIP_OK(hipMemcpyAsync(h->d_idx, data_indices, sizeof(int) * (size_t)num_data, hipMemcpyHostToDevice, h->stream));
   }
-  // chunking: enough workgroups to fill 256 CUs, at least 1024 rows per chunk
+  // chunking: three workgroups (49 KB of LDS each) are resident per CU; 3 full rounds of them (2304 workgroups on 256 CUs, no
+  // partial last round), at least 1024 rows per chunk
   const int groups = h->fpad / GPB_HIST_FG;
-  int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, 2048 / groups)));
+  if (h->num_cu <= 0) { HIP_OK(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, h->device)); if (h->num_cu <= 0) h->num_cu = 256; }
+  int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, 9 * h->num_cu / groups)));
   const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
   if (rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
   if (nchunks < 1) nchunks = 1;

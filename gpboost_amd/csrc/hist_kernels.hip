@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
   const uint8_t* base = a.bins_rm + (size_t)fg * GPB_HIST_FG;
   // one lane = one row: a 16-byte load brings the row's 16 bins of this feature group, the gradient load is
-  // coalesced across the wavefront (or gathered through data_indices for a leaf)
+  // coalesced across the wavefront (or gathered through data_indices for a leaf).  (An explicit software pipeline of the
+  // next row's loads changes nothing: 12 resident wavefronts per CU already hide the HBM latency; the kernel is bound by
+  // the LDS atomics, scripts/ubench/lds_atomics.hip.)
   for (int r = r0 + tid; r < r1; r += 256) {
     const int row = HAS_IDX ? a.data_indices[r] : r;
     const uint4 bv = *reinterpret_cast<const uint4*>(base + (size_t)row * a.fpad);
@@ -69,21 +71,43 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
   }
 }
 
-// one thread per (feature, bin): sum the chunk partials in chunk order
-__global__ void hist_reduce_kernel(HistReduceArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int f = t >> 8, b = t & 255;
-  if (f >= a.num_features) return;
+// Sum of the chunk partials, in a FIXED order (reproducible for a given chunking): a workgroup owns 64 bins of one feature;
+// its 16 slices of 64 lanes take the chunks ch = slice, slice + 16, ... (coalesced 512-byte segments, 4 loads in flight per lane),
+// the slice totals are added in slice order.  200 workgroups x 1024 threads for F = 50 (the first version -- one thread per
+// (feature, bin) walking all chunks, 50 workgroups -- took 207 us of a 760 us root pass at n = 1e7).
+__global__ __launch_bounds__(1024) void hist_reduce_kernel(HistReduceArgs a) {
+  __shared__ double s_g[16][64];
+  __shared__ double s_h[16][64];
+  __shared__ unsigned long long s_c[16][64];
+  const int f = blockIdx.x, b = blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
   const int nb = a.bin_offsets[f + 1] - a.bin_offsets[f];
-  if (b >= nb) return;
   double g = 0.0, h = 0.0;
   unsigned long long c = 0;
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    const size_t p = ((size_t)ch * a.fpad + f) * GPB_HIST_MAX_BIN + b;
+  const size_t stride = (size_t)a.fpad * GPB_HIST_MAX_BIN;
+  const size_t p0 = (size_t)f * GPB_HIST_MAX_BIN + b;
+  int ch = sl;
+  for (; ch + 48 < a.nchunks; ch += 64) {
+    const size_t p = p0 + (size_t)ch * stride;
+    const double g0 = a.part_grad[p], g1 = a.part_grad[p + 16 * stride], g2 = a.part_grad[p + 32 * stride], g3 = a.part_grad[p + 48 * stride];
+    const uint32_t c0 = a.part_cnt[p], c1 = a.part_cnt[p + 16 * stride], c2 = a.part_cnt[p + 32 * stride], c3 = a.part_cnt[p + 48 * stride];
+    g += g0; g += g1; g += g2; g += g3;
+    c += c0; c += c1; c += c2; c += c3;
+    if (a.has_hess) {
+      const double h0 = a.part_hess[p], h1 = a.part_hess[p + 16 * stride], h2 = a.part_hess[p + 32 * stride], h3 = a.part_hess[p + 48 * stride];
+      h += h0; h += h1; h += h2; h += h3;
+    }
+  }
+  for (; ch < a.nchunks; ch += 16) {
+    const size_t p = p0 + (size_t)ch * stride;
     g += a.part_grad[p];
     c += a.part_cnt[p];
     if (a.has_hess) h += a.part_hess[p];
   }
+  s_g[sl][threadIdx.x & 63] = g; s_h[sl][threadIdx.x & 63] = h; s_c[sl][threadIdx.x & 63] = c;
+  __syncthreads();
+  if (sl != 0 || b >= nb) return;
+  g = 0.0; h = 0.0; c = 0;
+  for (int k = 0; k < 16; ++k) { g += s_g[k][threadIdx.x]; h += s_h[k][threadIdx.x]; c += s_c[k][threadIdx.x]; }
   const size_t o = (size_t)a.bin_offsets[f] + b;
   a.hist_out[2 * o] = g;
   a.hist_out[2 * o + 1] = a.has_hess ? h : (double)c * a.const_hess;
@@ -117,7 +141,7 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(hist_reduce_kernel, dim3(a.num_features), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(hist_reduce_kernel, dim3(a.num_features, GPB_HIST_MAX_BIN / 64), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st) {
