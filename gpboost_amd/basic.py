@@ -285,24 +285,67 @@ class GPModel(object):
                                                          leaf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(num_leaves)), _dptr(out)))
         return out
 
-    def predict(self, y, gp_coords_pred, cov_pars, predict_var=True, predict_response=False, num_neighbors_pred=None):
-        """Predictive mean / variance at new locations for vecchia_pred_type = "order_obs_first_cond_obs_only" (reference:
-        GPModel.predict, basic.py:5702-6050 -> GPB_PredictREModel -> CalcPredVecchiaObservedFirstOrder).  Returns {'mu', 'var'}."""
-        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
-        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
-        cp = np.asarray(gp_coords_pred, dtype=np.float64)
-        if cp.ndim == 1:
-            cp = cp.reshape(-1, 1)
-        if cp.shape[1] != self.dim_coords:
-            raise ValueError("Incorrect dimension of 'gp_coords_pred'")
-        cpc = np.asfortranarray(cp)
-        npred = cp.shape[0]
-        mu = np.empty(npred); var = np.empty(npred)
-        _safe_call(_lib().GPB_HIP_PredictVecchiaObsOnly(
-            self.handle, _dptr(y), _dptr(cov_pars), ctypes.c_int(npred), _dptr(cpc),
-            ctypes.c_int(-1 if num_neighbors_pred is None else int(num_neighbors_pred)), ctypes.c_bool(bool(predict_response)),
-            _dptr(mu), _dptr(var) if predict_var else None))
-        return {"mu": mu, "var": var if predict_var else None}
+    def set_prediction_data(self, gp_coords_pred=None, vecchia_pred_type=None, num_neighbors_pred=None):
+        """Reference: GPModel.set_prediction_data (basic.py:6052-6200) -> GPB_SetPredictionData."""
+        cp_c = ctypes.c_void_p(); npred = 0
+        if gp_coords_pred is not None:
+            cp = np.asarray(gp_coords_pred, dtype=np.float64)
+            if cp.ndim == 1:
+                cp = cp.reshape(-1, 1)
+            if cp.shape[1] != self.dim_coords:
+                raise ValueError("Incorrect dimension of 'gp_coords_pred'")
+            cpc = np.asfortranarray(cp); cp_c = _dptr(cpc); npred = cp.shape[0]
+            self._num_data_pred_saved = npred
+        _safe_call(_lib().GPB_SetPredictionData(
+            self.handle, ctypes.c_int(npred), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), cp_c, ctypes.c_void_p(),
+            ctypes.c_void_p(), ctypes.c_void_p() if vecchia_pred_type is None else c_str(vecchia_pred_type),
+            ctypes.c_int(-1 if num_neighbors_pred is None else int(num_neighbors_pred)), ctypes.c_double(-1.), ctypes.c_int(-1), ctypes.c_int(-1)))
+        return self
+
+    def predict(self, y=None, gp_coords_pred=None, cov_pars=None, predict_var=False, predict_cov_mat=False, predict_response=True,
+                num_neighbors_pred=None, vecchia_pred_type=None, use_saved_data=False):
+        """Predictive mean / variances / covariance matrix at new locations (reference: GPModel.predict, basic.py:5702-6050 ->
+        GPB_PredictREModel -> CalcPredVecchiaObservedFirstOrder); vecchia_pred_type "order_obs_first_cond_obs_only".  cov_pars=None
+        uses the estimated parameters, y=None the response of the last fit / evaluation.  Returns {'mu', 'var', 'cov'}."""
+        if num_neighbors_pred is not None or vecchia_pred_type is not None:
+            self.set_prediction_data(vecchia_pred_type=vecchia_pred_type, num_neighbors_pred=num_neighbors_pred)
+        y_c = ctypes.c_void_p()
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+            if y.shape[0] != self.num_data:
+                raise ValueError("Incorrect number of data points in 'y'")
+            y_c = _dptr(y)
+        cp_c = ctypes.c_void_p()
+        if cov_pars is not None:
+            cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+            if cov_pars.shape[0] != self.num_cov_pars:
+                raise ValueError("'cov_pars' does not contain the correct number of parameters")
+            cp_c = _dptr(cov_pars)
+        crd_c = ctypes.c_void_p(); npred = 0
+        if not use_saved_data:
+            if gp_coords_pred is None:
+                raise ValueError("'gp_coords_pred' is required")
+            cp = np.asarray(gp_coords_pred, dtype=np.float64)
+            if cp.ndim == 1:
+                cp = cp.reshape(-1, 1)
+            if cp.shape[1] != self.dim_coords:
+                raise ValueError("Incorrect dimension of 'gp_coords_pred'")
+            cpc = np.asfortranarray(cp); crd_c = _dptr(cpc); npred = cp.shape[0]
+        else:
+            npred = int(getattr(self, "_num_data_pred_saved", 0))
+        n_out = npred * (1 + npred) if predict_cov_mat else (2 * npred if predict_var else npred)
+        out = np.empty(max(n_out, 1))
+        _safe_call(_lib().GPB_PredictREModel(
+            self.handle, y_c, ctypes.c_int(npred), _dptr(out), ctypes.c_bool(bool(predict_cov_mat)), ctypes.c_bool(bool(predict_var)),
+            ctypes.c_bool(bool(predict_response)), ctypes.c_bool(False), ctypes.c_bool(False), ctypes.c_int(0), ctypes.c_int(0),
+            ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), crd_c, ctypes.c_void_p(), cp_c, ctypes.c_void_p(),
+            ctypes.c_bool(bool(use_saved_data)), ctypes.c_void_p(), ctypes.c_void_p()))
+        res = {"mu": out[:npred].copy(), "var": None, "cov": None}
+        if predict_var:
+            res["var"] = out[npred:2 * npred].copy()
+        if predict_cov_mat:
+            res["cov"] = out[npred:].reshape(npred, npred, order="F").copy()
+        return res
 
     def vecchia_structure(self):
         """(perm, nn): Vecchia ordering and the (n, m) neighbour table, -1 padded."""

@@ -47,6 +47,7 @@ constexpr double kMinNuggetVarRatio = 1e-10;   // re_model_template.h:5668
 
 struct REModelHip {
   int n = 0, d = 0, m = 0;
+  int num_neighbors = 0;        // num_neighbors_ as given (re_model_template.h:288-299); num_neighbors_pred_ defaults to twice this
   int cov_type = 0;
   std::vector<int> perm;        // data_indices_per_cluster_: Vecchia position -> data index
   gpb_hip_vecchia_t* vh = nullptr;          // cluster 0 (the only one unless cluster_ids distinguishes independent realisations)
@@ -72,6 +73,11 @@ struct REModelHip {
   bool optimizer_unsupported_alias = false;
   double cov_pars_tr[3] = {0, 0, 0}, init_cov_pars_tr[3] = {0, 0, 0};
   bool cov_pars_initialized = false, init_cov_pars_provided = false;
+  bool y_set = false;           // y_has_been_set_: ybuf / the device copy hold the response of the last call that passed one
+  // GPB_SetPredictionData (re_model_template.h:3337-3400)
+  std::vector<double> coords_pred; int num_data_pred = 0;
+  std::string vecchia_pred_type = "order_obs_first_cond_obs_only";   // default for the Gaussian likelihood (:7112-7115)
+  int num_neighbors_pred = 0;   // 0 = default (2 * num_neighbors_, :299)
   int num_it = 0;
   GpbOptimResult last_fit;
   ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); }
@@ -103,9 +109,10 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects)
   } else {
     for (int k = 0; k < n; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]];
   }
-  if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); return 0; }
+  if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); mdl->y_set = true; return 0; }
   for (size_t k = 0; k < mdl->vhs.size(); ++k)
     if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf.data() + mdl->cl_off[k])) return shim_error();
+  mdl->y_set = true;
   return 0;
 }
 
@@ -264,7 +271,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
-  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik;
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik; mdl->num_neighbors = num_neighbors;
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
@@ -552,6 +559,77 @@ int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_th
   C_API_END();
 }
 
+/* c_api.h:1588-1610 -- only what the obs-only Vecchia prediction needs is kept: coordinates, prediction type, #neighbours */
+int GPB_SetPredictionData(REModelHandle handle, int32_t num_data_pred, const int32_t* cluster_ids_data_pred, const char* re_group_data_pred,
+                          const double* re_group_rand_coef_data_pred, double* gp_coords_data_pred, const double* gp_rand_coef_data_pred,
+                          const double* covariate_data_pred, const char* vecchia_pred_type, int num_neighbors_pred,
+                          double /*cg_delta_conv_pred*/, int /*nsim_var_pred*/, int /*rank_pred_approx_matrix_lanczos*/) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_SetPredictionData: null handle");
+  const char* scope = "is not on the MI355X path of this library";
+  if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred)
+    return set_error("GPB_SetPredictionData: cluster ids / grouped effects / random coefficients / covariates for prediction %s", scope);
+  if (vecchia_pred_type && vecchia_pred_type[0]) {
+    const std::string t = vecchia_pred_type;
+    // SUPPORTED_VECCHIA_PRED_TYPES_GAUSS_ of the reference; only the first is implemented on the device
+    if (t != "order_obs_first_cond_obs_only" && t != "order_obs_first_cond_all" && t != "order_pred_first" &&
+        t != "latent_order_obs_first_cond_obs_only" && t != "latent_order_obs_first_cond_all")
+      return set_error("Prediction type '%s' is not supported for the Veccia approximation ", t.c_str());
+    mdl->vecchia_pred_type = t;
+  }
+  if (num_neighbors_pred > 0) mdl->num_neighbors_pred = num_neighbors_pred;
+  if (gp_coords_data_pred) {
+    if (num_data_pred <= 0) return set_error("GPB_SetPredictionData: num_data_pred = %d", num_data_pred);
+    mdl->coords_pred.assign(gp_coords_data_pred, gp_coords_data_pred + (size_t)num_data_pred * mdl->d);
+    mdl->num_data_pred = num_data_pred;
+  }
+  C_API_END();
+}
+
+/* c_api.h:1640-1660 -- predictive mean and variances (or the, here diagonal, covariance matrix) at new locations for the Gaussian
+ * one-cluster Vecchia model, vecchia_pred_type "order_obs_first_cond_obs_only" (REModel::Predict, re_model.cpp:1083-1215 ->
+ * CalcPredVecchiaObservedFirstOrder(CondObsOnly = true), Vecchia_utils.cpp:1701-2060) */
+int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_data_pred, double* out_predict, bool predict_cov_mat,
+                       bool predict_var, bool predict_response, bool sample_posterior, bool sample_prior, int /*num_post_samples*/,
+                       int /*num_prior_samples*/, const int32_t* cluster_ids_data_pred, const char* re_group_data_pred,
+                       const double* re_group_rand_coef_data_pred, double* gp_coords_data_pred, const double* gp_rand_coef_data_pred,
+                       const double* cov_pars, const double* covariate_data_pred, bool use_saved_data, const double* /*fixed_effects*/,
+                       const double* /*fixed_effects_pred*/) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !out_predict) return set_error("GPB_PredictREModel: null argument");
+  const char* scope = "is not on the MI355X path of this library (prediction: one-cluster Gaussian Vecchia model, 'order_obs_first_cond_obs_only')";
+  if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_PredictREModel: this model %s", scope);
+  if (sample_posterior || sample_prior) return set_error("GPB_PredictREModel: posterior / prior samples %s", scope);
+  if (predict_cov_mat && predict_var) return set_error("Calculation of both the predictive covariance matrix and variances is not supported. Choose one option (predict_cov_mat or predict_var)");   // re_model.cpp Predict
+  if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred)
+    return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients / covariates for prediction %s", scope);
+  if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only") return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", mdl->vecchia_pred_type.c_str(), scope);
+  const double* cp = gp_coords_data_pred;
+  int np = num_data_pred;
+  if (use_saved_data) { cp = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); np = mdl->num_data_pred; }
+  if (!cp || np <= 0) return set_error("GPB_PredictREModel: no coordinates for prediction (gp_coords_data_pred / GPB_SetPredictionData)");
+  double tr[3];
+  if (cov_pars) { double c3[3] = {cov_pars[0], cov_pars[1], cov_pars[2]}; if (transform_cov_pars(mdl, c3, tr)) return -1; }
+  else {
+    if (!mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or are not given.");   // re_model.cpp:1119-1121
+    std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, tr);
+  }
+  if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
+  else if (!mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
+  int nnp = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;
+  std::vector<double> D(np);
+  if (gpb_hip_vecchia_predict_obs_only(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], out_predict, D.data(), nullptr)) return shim_error();
+  if (predict_var)
+    for (int k = 0; k < np; ++k) out_predict[np + k] = tr[0] * (predict_response ? D[k] : D[k] - 1.);
+  if (predict_cov_mat) {                       // neighbours are observed points only: Bp = I, the predictive covariance is diag(Dp)
+    std::fill(out_predict + np, out_predict + np + (size_t)np * np, 0.);
+    for (int k = 0; k < np; ++k) out_predict[np + (size_t)k * np + k] = tr[0] * (predict_response ? D[k] : D[k] - 1.);
+  }
+  C_API_END();
+}
+
 int GPB_GetCurrentNegLogLikelihood(REModelHandle handle, double* negll) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
@@ -647,7 +725,7 @@ int GPB_HIP_PredictVecchiaObsOnly(REModelHandle handle, const double* y_data, do
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, nullptr)) return -1;
-  if (num_neighbors_pred <= 0) num_neighbors_pred = mdl->m;          // re_model_template.h: num_neighbors_pred_ defaults to num_neighbors_
+  if (num_neighbors_pred <= 0) num_neighbors_pred = 2 * mdl->num_neighbors;   // re_model_template.h:299: num_neighbors_pred_ = 2 * num_neighbors_
   std::vector<double> D(num_data_pred);
   if (gpb_hip_vecchia_predict_obs_only(mdl->vh, num_data_pred, gp_coords_data_pred, num_neighbors_pred, mdl->cov_type, tr[1], tr[2],
                                        out_mean, D.data(), nullptr)) return shim_error();

@@ -138,6 +138,48 @@ GPBOOST_C_EXPORT int GPB_GetInitCovPar(REModelHandle handle, double* init_cov_pa
 /* c_api.h:1567-1568 */
 GPBOOST_C_EXPORT int GPB_GetNumIt(REModelHandle handle, int* num_it);
 
+/* c_api.h:1588-1610 -- kept: gp_coords_data_pred (column-major), vecchia_pred_type, num_neighbors_pred (default 2 x num_neighbors,
+ * re_model_template.h:299); cluster ids / grouped effects / random coefficients / covariates return -1 */
+GPBOOST_C_EXPORT int GPB_SetPredictionData(REModelHandle handle,
+    int32_t num_data_pred,
+    const int32_t* cluster_ids_data_pred,
+    const char* re_group_data_pred,
+    const double* re_group_rand_coef_data_pred,
+    double* gp_coords_data_pred,
+    const double* gp_rand_coef_data_pred,
+    const double* covariate_data_pred,
+    const char* vecchia_pred_type,
+    int num_neighbors_pred,
+    double cg_delta_conv_pred,
+    int nsim_var_pred,
+    int rank_pred_approx_matrix_lanczos);
+
+/* c_api.h:1640-1660 -- out_predict: num_data_pred means, then the variances (predict_var) or the num_data_pred^2 covariance matrix
+ * (predict_cov_mat; diagonal for this prediction type).  One-cluster Gaussian Vecchia model, vecchia_pred_type
+ * "order_obs_first_cond_obs_only" (the reference's default for a Gaussian likelihood); cov_pars NULL = the estimated / stored
+ * parameters, y_data NULL = the response of the last call; samples, other prediction types and models return -1. */
+GPBOOST_C_EXPORT int GPB_PredictREModel(REModelHandle handle,
+    const double* y_data,
+    int32_t num_data_pred,
+    double* out_predict,
+    bool predict_cov_mat,
+    bool predict_var,
+    bool predict_response,
+    bool sample_posterior,
+    bool sample_prior,
+    int num_post_samples,
+    int num_prior_samples,
+    const int32_t* cluster_ids_data_pred,
+    const char* re_group_data_pred,
+    const double* re_group_rand_coef_data_pred,
+    double* gp_coords_data_pred,
+    const double* gp_rand_coef_data_pred,
+    const double* cov_pars,
+    const double* covariate_data_pred,
+    bool use_saved_data,
+    const double* fixed_effects,
+    const double* fixed_effects_pred);
+
 /* c_api.h:1686-1688 */
 GPBOOST_C_EXPORT int GPB_GetLikelihoodName(REModelHandle handle, char* out_str, int* num_char);
 

@@ -105,6 +105,32 @@ def test_fit_on_device_matches_the_reference(lib_built, name):
 
 
 @pytest.mark.gpu
+def test_r_suite_fit_then_predict_end_to_end(lib_built):
+    """test_GPModel_gaussian_process.R:1310-1334 as one chain on the device, through the reference's own entry points: fit (378
+    iterations) -> set_prediction_data -> predict from the FITTED model (cov_pars and y not passed again) with predict_cov_mat."""
+    import gpboost_amd
+    from oracle import orc
+    coords, y, ids, mc, init, cfg = cases.optim_case("r_gd_nesterov_parcrit")
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none")
+    mdl.fit(y, params=dict(cfg, init_cov_pars=init))
+    assert mdl.get_num_optim_iter() == 378
+    assert np.abs(mdl.get_cov_pars() - np.array([0.03297349, 1.07691542, 0.11378505])).sum() < 1e-6
+    assert abs(mdl.get_current_neg_log_likelihood() - 122.7680889) < 1e-6
+    coord_test = np.array([[0.1, 0.9], [0.10001, 0.90001], [0.7, 0.55]])
+    mdl.set_prediction_data(vecchia_pred_type="order_obs_first_cond_obs_only", num_neighbors_pred=30)
+    pred = mdl.predict(y=y, gp_coords_pred=coord_test, predict_cov_mat=True)
+    assert np.abs(pred["mu"] - np.array([0.06968068, 0.06967750, 0.44208925])).sum() < 1e-6
+    exp_cov = np.array([0.6214955, 0, 0, 0, 0.6215069, 0, 0, 0, 0.4199531]).reshape(3, 3)
+    assert np.abs(pred["cov"] - exp_cov).sum() < 1e-6
+    again = mdl.predict(gp_coords_pred=coord_test, predict_var=True)          # y of the fit is still resident
+    np.testing.assert_allclose(again["var"], np.diag(pred["cov"]), rtol=1e-12)
+    with pytest.raises(gpboost_amd.GPBoostError, match="not on the MI355X path"):
+        mdl.predict(gp_coords_pred=coord_test, vecchia_pred_type="order_obs_first_cond_all")
+    with pytest.raises(gpboost_amd.GPBoostError, match="not supported for the Veccia"):
+        mdl.set_prediction_data(vecchia_pred_type="nonsense")
+
+
+@pytest.mark.gpu
 def test_fit_through_the_rccl_path_single_rank(lib_built):
     """A sharded fit is the same host loop on every rank over all-reduced sums: with a 1-rank communicator on the model's handle
     GPB_OptimCovPar evaluates through kernel + reduction + ncclAllReduce and must reproduce the plain fit exactly."""
