@@ -259,19 +259,22 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   }
   if (cov_type < 0) return set_error("GPB_CreateREModel: cov_fct '%s' (shape %g) %s", cov.c_str(), cov_fct_shape, scope);
   if (approx != "vecchia" && approx != "none") return set_error("GPB_CreateREModel: gp_approx '%s' %s", approx.c_str(), scope);
-  if (lik != "gaussian" && lik != "bernoulli_logit") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
-  if (lik == "bernoulli_logit") {
+  std::string lik_name = lik;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
+  if (lik == "binary_probit") lik_name = "bernoulli_probit";
+  if (lik == "binary" || lik == "binary_logit") lik_name = "bernoulli_logit";
+  if (lik_name != "gaussian" && lik_name != "bernoulli_logit" && lik_name != "bernoulli_probit") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
-    if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood 'bernoulli_logit' with gp_approx '%s' %s", approx.c_str(), scope);
+    if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
     // "default" resolves to "iterative" for a non-Gaussian Vecchia model (re_model_template.h:5722-5735)
-    if (inv != "default" && inv != "iterative") return set_error("GPB_CreateREModel: matrix_inversion_method '%s' for likelihood 'bernoulli_logit' %s", inv.c_str(), scope);
+    if (inv != "default" && inv != "iterative") return set_error("GPB_CreateREModel: matrix_inversion_method '%s' for likelihood '%s' %s", inv.c_str(), lik_name.c_str(), scope);
   }
   if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
   if (num_data < 2) return set_error("GPB_CreateREModel: num_data = %d", num_data);
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
-  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik; mdl->num_neighbors = num_neighbors;
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_neighbors = num_neighbors;
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
@@ -297,7 +300,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   } else {
     clusters.emplace_back(mdl->perm);
   }
-  if (clusters.size() > 1 && lik != "gaussian") return set_error("GPB_CreateREModel: several clusters with likelihood '%s' %s", lik.c_str(), scope);
+  if (clusters.size() > 1 && lik_name != "gaussian") return set_error("GPB_CreateREModel: several clusters with likelihood '%s' %s", lik.c_str(), scope);
   mdl->rng = std::mt19937(seed);                                   // ONE generator for all clusters (re_model_template.h:161, type_defs.h:52)
   std::mt19937& rng = mdl->rng;
   mdl->perm.clear(); mdl->cl_off.assign(1, 0);
@@ -413,9 +416,9 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
   if (!cov_pars && mdl->likelihood != "gaussian") return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (no initial-value heuristics for likelihood '%s' on the MI355X path)", mdl->likelihood.c_str());
-  if (mdl->likelihood == "bernoulli_logit") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
+  if (mdl->likelihood != "gaussian") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
     if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
-    if (fixed_effects) return set_error("GPB_EvalNegLogLikelihood: fixed_effects with likelihood 'bernoulli_logit' are not on the MI355X hot path of this library yet");
+    if (fixed_effects) return set_error("GPB_EvalNegLogLikelihood: fixed_effects with likelihood '%s' are not on the MI355X hot path of this library yet", mdl->likelihood.c_str());
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
     mdl->labels.resize(mdl->n);
@@ -425,6 +428,7 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
         return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
       mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
     }
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : 0)) return shim_error();
     if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,

@@ -41,6 +41,45 @@ __device__ __forceinline__ double sigmoid_stable(double x) {   // include/GPBoos
 __device__ __forceinline__ double softplus(double x) {         // DF_utils.h:57-60
   return log1p(exp(-fabs(x))) + fmax(x, 0.0);
 }
+// Bernoulli-probit (likelihood id 1): log Phi(x) exactly as GPBoost::normalLogCDF (DF_utils.h:74-92) and the inverse Mills ratio
+// phi(z) / Phi(z) as InvMillsRatioNormalPhi (:94-98); with z = x for y = 1 and z = -x for y = 0:
+//   log p(y | x) = log Phi(z)                          (LogLikBernoulliProbit, likelihoods.h:11385-11392)
+//   d/dx         = +- phi(z) / Phi(z)                   (FirstDerivLogLikBernoulliProbit, :12459-12466)
+//   -d2/dx2      = r (z + r), r = phi(z) / Phi(z)       (SecondDerivNegLogLikBernoulliProbit, :13282-13291)
+__device__ __forceinline__ double normal_log_cdf(double x) {
+  if (x < 0.0) {
+    const double e = erfc(-x * 0.70710678118654752440);
+    if (e > 0.0) return log(0.5) + log(e);
+    const double u = -x, u2 = u * u;
+    const double series = 1.0 - 1.0 / u2 + 3.0 / (u2 * u2);
+    return -0.5 * u2 - log(u) - 0.5 * log(2 * 3.14159265358979323846) + log(series);
+  }
+  const double Q = 0.5 * erfc(x * 0.70710678118654752440);
+  if (Q == 0.0) return 0.0;
+  return log1p(-Q);
+}
+__device__ __forceinline__ double inv_mills_phi(double z) {
+  return exp((-z * z / 2. - 0.91893853320467274178) - normal_log_cdf(z));
+}
+// per-observation pieces of the two supported likelihoods: LINK 0 = Bernoulli-logit, 1 = Bernoulli-probit
+template <int LINK>
+__device__ __forceinline__ void lik_grad_info(int y, double x, double& grad, double& w) {
+  if constexpr (LINK == 0) {
+    const double p = sigmoid_stable(x);
+    grad = (double)y - p;                 // likelihoods.h:12477
+    w = p * (1.0 - p);                    // :13307
+  } else {
+    const double z = y ? x : -x;
+    const double r = inv_mills_phi(z);
+    grad = y ? r : -r;
+    w = r * (z + r);
+  }
+}
+template <int LINK>
+__device__ __forceinline__ double lik_loglik(int y, double x) {
+  if constexpr (LINK == 0) return (double)y * x - softplus(x);      // likelihoods.h:11401-11403
+  else return normal_log_cdf(y ? x : -x);
+}
 // fixed-order block reduction of two values; result valid in thread 0
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
   const int tid = threadIdx.x;
@@ -55,27 +94,29 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
 }
 }  // namespace
 
-// W = p (1 - p), grad = y - p, rhs = W mode + grad, dw = 1/D + W, rdw = 1/dw     (likelihoods.h:3882-3891, :12477, :13307, :16330)
-__global__ void logit_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ D,
+// W = information, grad = first derivative, rhs = W mode + grad, dw = 1/D + W, rdw = 1/dw     (likelihoods.h:3882-3891, :16330)
+template <int LINK>
+__global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ D,
                                           int n, double* __restrict__ W, double* __restrict__ rhs, double* __restrict__ dw, double* __restrict__ rdw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double p = sigmoid_stable(mode[i]);
-  const double w = p * (1.0 - p);
+  double gr, w;
+  lik_grad_info<LINK>(y[i], mode[i], gr, w);
   W[i] = w;
-  if (rhs) rhs[i] = w * mode[i] + ((double)y[i] - p);
+  if (rhs) rhs[i] = w * mode[i] + gr;
   const double v = 1.0 / D[i] + w;
   dw[i] = v;
   rdw[i] = 1.0 / v;       // the preconditioner's diagonal solve multiplies by this
 }
 
-// one workgroup: out2 = { sum_i y_i x_i - softplus(x_i),  sum_i Bx_i^2 / D_i }   (likelihoods.h:3808-3812, :3955-3959)
-__global__ __launch_bounds__(1024) void logit_objective_kernel(const double* __restrict__ x, const int* __restrict__ y, const double* __restrict__ Bx,
+// one workgroup: out2 = { sum_i log p(y_i | x_i),  sum_i Bx_i^2 / D_i }   (likelihoods.h:3808-3812, :3955-3959)
+template <int LINK>
+__global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __restrict__ x, const int* __restrict__ y, const double* __restrict__ Bx,
                                                                const double* __restrict__ D, int n, double* __restrict__ out2) {
   __shared__ double s[2048];
   double ll = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    ll += (double)y[i] * x[i] - softplus(x[i]);
+    ll += lik_loglik<LINK>(y[i], x[i]);
     if (Bx) q = __builtin_fma(Bx[i] * (1.0 / D[i]), Bx[i], q);
   }
   block_reduce2(ll, q, s);
@@ -558,8 +599,9 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 
 // ---- launchers --------------------------------------------------------------------------------------------
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256)
-hipError_t lap_newton_setup(const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
-  hipLaunchKernelGGL(logit_newton_setup_kernel, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
+hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
+  else hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
   return hipGetLastError();
 }
 // nc = columns per chunk of the block layout (1: plain column-major; 4: the probe block), ncol = number of chunks
@@ -586,8 +628,9 @@ hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, h
   hipLaunchKernelGGL(lap_scatter_kernel, GRID1(n), 0, st, in, sigma, n, out);
   return hipGetLastError();
 }
-hipError_t lap_objective(const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
-  hipLaunchKernelGGL(logit_objective_kernel, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
+hipError_t lap_objective(int link, const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
+  else hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
   return hipGetLastError();
 }
 // OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out

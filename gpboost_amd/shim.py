@@ -173,6 +173,10 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_newton_leaf_values(self.h, _p(leaf, C.c_int), C.c_int(int(num_leaves)), _p(out)))
         return out
 
+    def laplace_set_likelihood(self, likelihood):
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1}[likelihood]
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
+
     def laplace_set_labels(self, y01):
         y01 = np.ascontiguousarray(y01, dtype=np.int32)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_labels(self.h, _p(y01, C.c_int)))

@@ -196,6 +196,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, cons
  *                             #CG-Lanczos iterations, log p(y|mode) - 0.5 mode^T Sigma^-1 mode,
  *                             ms factor, ms mode finding, ms log-determinant (host wall clock) };
  *               mode_host (optional) receives the mode, Vecchia order. */
+/* Likelihood of the Laplace path: 0 = "bernoulli_logit" (default), 1 = "bernoulli_probit" (LogLikBernoulliProbit /
+ * FirstDerivLogLikBernoulliProbit / SecondDerivNegLogLikBernoulliProbit, likelihoods.h:11385-11392, :12459-12466, :13282-13291,
+ * with GPBoost::normalLogCDF, DF_utils.h:74-92).  gpb_hip_vecchia_laplace_logit then evaluates that likelihood. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int likelihood_id);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y01);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int num_rand_vec,
                                                  int seed_rand_vec, int cg_max_num_it, int cg_max_num_it_tridiag,

@@ -55,15 +55,22 @@ def main():
 
 
 def laplace_fixture(out_dir):
-    """Reference GPB_EvalNegLogLikelihood for likelihood = 'bernoulli_logit', gp_approx = 'vecchia' (iterative, vadu)."""
+    """Reference GPB_EvalNegLogLikelihood for likelihood = 'bernoulli_logit' / 'bernoulli_probit', gp_approx = 'vecchia' (iterative, vadu)."""
+    from oracle import orc
     res = {}
     for name, c in cases.LAPLACE_CASES.items():
         coords, y = cases.make_binary_data(c)
-        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8,
-                                  likelihood="bernoulli_logit")
-        for k, cp in enumerate(c["cov_pars"]):
-            res["%s_negll_%d" % (name, k)] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
-            print("laplace", name, cp, "negll = %.12f" % res["%s_negll_%d" % (name, k)])
+        for lik, tag in (("bernoulli_logit", ""), ("bernoulli_probit", "probit_")):
+            mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=lik)
+            for k, cp in enumerate(c["cov_pars"]):
+                key = "%s_%snegll_%d" % (name, tag, k)
+                res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
+                print("laplace", lik, name, cp, "negll = %.12f" % res[key])
+    # the R suite's probit fixture through the Vecchia approximation conditioning on all predecessors, iterative methods
+    coords, y = orc.r_fixture_probit()
+    mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 99, "none", 0, threads=8, likelihood="bernoulli_probit")
+    res["r_probit_m99_negll"] = np.float64(mdl.neg_log_likelihood(np.array([1.0, 0.2]), y))
+    print("laplace r probit fixture (exact-GP golden 67.18342059): %.10f" % res["r_probit_m99_negll"])
     np.savez_compressed(os.path.join(out_dir, "laplace_ref.npz"), **res)
 
 

@@ -262,19 +262,20 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
 
 
 def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
-                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None):
-    """Approximate negative log marginal likelihood of a Bernoulli-logit Vecchia GP (Laplace, iterative, 'vadu').
-    Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
+                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit"):
+    """Approximate negative log marginal likelihood of a Bernoulli-logit (or, likelihood="bernoulli_probit", -probit) Vecchia GP
+    (Laplace, iterative, 'vadu').  Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
+    link = {"bernoulli_logit": 0, "bernoulli_probit": 1}[likelihood]
     A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
     yi = np.ascontiguousarray(y01, dtype=np.int32)
     rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0) if rand_vec is None else np.asfortranarray(rand_vec)
     out = np.empty(6); mode = np.empty(n)
-    rc = lib().orc_vecchia_laplace_logit(_p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
-                                         _p(yi, C.c_int), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
-                                         C.c_int(cg_max_num_it_tridiag), C.c_double(cg_delta_conv), C.c_double(delta_conv_mode),
-                                         _p(out, C.c_double), _p(mode, C.c_double))
+    rc = lib().orc_vecchia_laplace_binary(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+                                          _p(yi, C.c_int), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
+                                          C.c_int(cg_max_num_it_tridiag), C.c_double(cg_delta_conv), C.c_double(delta_conv_mode),
+                                          _p(out, C.c_double), _p(mode, C.c_double))
     return -out[0], dict(rc=rc, newton_it=int(out[1]), cg_it=int(out[2]), log_det=out[3], lanczos_it=int(out[4]),
                          mll_no_det=out[5], mode=mode, A=A, D=D)
 
@@ -337,3 +338,17 @@ def r_fixture_logit():
     Cc = np.linalg.cholesky(Sigma)
     probs = 1.0 / (1.0 + np.exp(-(Cc @ norm.ppf(sim_rand_unif(n, 0.8)))))
     return coords, (sim_rand_unif(n, 0.2341) < probs).astype(np.float64)
+
+
+def r_fixture_probit():
+    """Binary fixture of R-package/tests/testthat/test_GPModel_non_Gaussian_data.R:52-62, 1391-1392 (same coords / L / b_1;
+    y = 1{u < Phi(L b_1)} with u from the LCG started at 0.19341); expected nll 67.18342059 at cov_pars (1, 0.2) (:1405, :1426)."""
+    from scipy.spatial.distance import cdist
+    from scipy.stats import norm
+    n, d = 100, 2
+    coords = sim_rand_unif(n * d, 0.1).reshape((n, d), order="F")
+    Sigma = np.exp(-cdist(coords, coords) / 0.1) + 1e-20 * np.eye(n)
+    Cc = np.linalg.cholesky(Sigma)
+    probs = norm.cdf(Cc @ norm.ppf(sim_rand_unif(n, 0.8)))
+    return coords, (sim_rand_unif(n, 0.19341) < probs).astype(np.float64)
+

@@ -109,6 +109,35 @@ def test_oracle_histogram_matches_reference_fixture(orc):
 
 # ---- Vecchia-Laplace, Bernoulli-logit (BASELINE config 4) ------------------------------------------------
 @pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_oracle_laplace_probit_matches_reference_fixture(orc, name):
+    """Same stack with the Bernoulli-probit pieces (normalLogCDF, inverse Mills ratios) against the reference's
+    GPB_EvalNegLogLikelihood(likelihood='bernoulli_probit')."""
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_ref.npz"))
+    coords, y = cases.make_binary_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    for k, cp in enumerate(c["cov_pars"]):
+        a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+        negll, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood="bernoulli_probit")
+        ref = float(g["%s_probit_negll_%d" % (name, k)])
+        assert info["rc"] == 0
+        assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref, info["newton_it"], info["cg_it"], info["lanczos_it"])
+
+
+def test_r_probit_fixture_oracle_vs_reference(orc):
+    """R suite probit data, Vecchia on all predecessors (m = n - 1), iterative methods: oracle == reference (1e-8); both within the
+    stochastic log-determinant's accuracy of the exact-GP golden 67.18342059 (test_GPModel_non_Gaussian_data.R:1405, :1426)."""
+    g = np.load(os.path.join(GOLD, "laplace_ref.npz"))
+    coords, y = orc.r_fixture_probit()
+    perm, co, nn = orc.vecchia_setup(coords, 99, "none", 0)
+    negll, info = orc.vecchia_laplace_logit(co, nn, 0, 1.0, 1.0 / 0.2, y, likelihood="bernoulli_probit")
+    ref = float(g["r_probit_m99_negll"])
+    assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
+    assert abs(ref - 67.18342059) < 0.3
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
 def test_oracle_laplace_matches_reference_fixture(orc, name):
     """orc_vecchia_laplace_logit (Newton + vadu-CG + SLQ with the reference's probe vectors) against the reference's
     GPB_EvalNegLogLikelihood(likelihood='bernoulli_logit').  The CG stopping rules make the value a discontinuous function
