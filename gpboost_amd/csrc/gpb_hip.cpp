@@ -130,6 +130,9 @@ struct gpb_hip_hist {
   std::vector<int> h_fix, h_meta3, h_bin_offsets;          // host copies for the scalar arguments of the partition kernel
   int* d_part = nullptr; int part_cap = 0;                 // partition workspace: block counts / offsets, lte, gt
   double* d_split = nullptr; int* d_split_i = nullptr; signed char* d_used = nullptr;   // split search outputs: F x 10, F + 1 ints
+  // gpb_hip_hist_grow_tree: resident row lists of the leaves, two sets of search outputs (device + pinned host)
+  int* d_rows = nullptr; double* d_split2 = nullptr; int* d_split2_i = nullptr; signed char* d_used2 = nullptr;
+  double* h_split2 = nullptr; int* h_split2_i = nullptr;
 };
 
 extern "C" {
@@ -915,6 +918,9 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
+  dev_free(h->d_rows); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
+  if (h->h_split2) (void)hipHostFree(h->h_split2);
+  if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   delete h;
   API_END();
@@ -932,7 +938,8 @@ int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const doub
 }
 
 static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
-                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target = nullptr);
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target = nullptr,
+                           const int* dev_indices = nullptr, bool dev_all_rows = false);
 
 int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
                        double* hist_out, uint64_t* cnt_out) {
@@ -951,10 +958,12 @@ int gpb_hip_hist_bench(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t n
 }
 
 static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
-                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target) {
+                           double* hist_out, uint64_t* cnt_out, int reps, double* ms_avg, double* d_target, const int* dev_indices,
+                           bool dev_all_rows) {
   {
   if (!h->has_grad) return fail("gradients have not been set (call gpb_hip_hist_set_gradients)");
-  if (!data_indices) num_data = h->n;
+  if (!data_indices && !dev_indices) num_data = h->n;      // dev_all_rows: the caller's resident list is still the identity
+  (void)dev_all_rows;
   if (num_data < 0 || num_data > h->n) return fail("gpb_hip_hist_build: num_data = %d", num_data);
   HIP_OK(hipSetDevice(h->device));
   if (data_indices) {
@@ -978,7 +987,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
     h->part_chunks = nchunks;
   }
   gpb::HistKernelArgs a;
-  a.bins_rm = h->d_bins_rm; a.data_indices = data_indices ? h->d_idx : nullptr; a.grad = h->d_grad;
+  a.bins_rm = h->d_bins_rm; a.data_indices = dev_indices ? dev_indices : (data_indices ? h->d_idx : nullptr); a.grad = h->d_grad;
   a.hess = h->has_hess ? h->d_hess : nullptr;
   a.part_grad = h->d_part_grad; a.part_hess = h->d_part_hess; a.part_cnt = h->d_part_cnt;
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks;
@@ -1192,3 +1201,4 @@ int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out) {
 
 // ------------------------------------------------------------------------------------------
 #include "gpb_laplace.inc"
+#include "gpb_tree.inc"

@@ -39,6 +39,7 @@ hipError_t launch_hist_best_split(const double* hist, int num_features, const in
 hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                  int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
                                  int* blk_off, int* lte, int* gt, hipStream_t st);
+hipError_t launch_hist_label_rows(const int* rows, int n, const int* seg_begin, const int* seg_leaf, int nseg, int* out, hipStream_t st);
 hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st);
 hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
 

@@ -131,6 +131,20 @@ __global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* _
   }
 }
 
+// leaf id of every row from the resident row lists: position p of `rows` belongs to the segment with the largest begin <= p
+__global__ void hist_label_rows_kernel(const int* __restrict__ rows, int n, const int* __restrict__ seg_begin, const int* __restrict__ seg_leaf,
+                                       int nseg, int* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_begin[mid] <= p) lo = mid; else hi = mid - 1; }
+  out[rows[p]] = seg_leaf[lo];
+}
+hipError_t launch_hist_label_rows(const int* rows, int n, const int* seg_begin, const int* seg_leaf, int nseg, int* out, hipStream_t st) {
+  hipLaunchKernelGGL(hist_label_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, seg_begin, seg_leaf, nseg, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
   dim3 grid(a.fpad / GPB_HIST_FG, a.nchunks), block(256);
   const bool hh = a.hess != nullptr, hi = a.data_indices != nullptr;

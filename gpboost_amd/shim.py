@@ -375,6 +375,28 @@ class HistBuilder(object):
                                                   C.c_int(int(bool(default_left))), _p(lte, C.c_int), _p(gt, C.c_int), C.byref(nl)))
         return lte[:nl.value].copy(), gt[:cnt - nl.value].copy()
 
+    def grow_tree(self, num_leaves, sum_gradient, sum_hessian, lambda_l2=0.0, min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3,
+                  min_gain_to_split=0.0, const_hess=1.0, want_leaf_index=True):
+        """One leaf-wise tree with device-resident row lists (gpb_hip_hist_grow_tree).  Returns the arrays of tests/tree_harness.grow_tree
+        plus 'data_leaf_index'."""
+        L = int(num_leaves)
+        nl = C.c_int(0)
+        ia = {k: np.zeros(L, dtype=np.int32) for k in ("split_feature_inner", "default_left", "left_child", "right_child", "internal_count", "leaf_count")}
+        thr = np.zeros(L, dtype=np.uint32); gain = np.zeros(L); lv = np.zeros(L)
+        dli = np.empty(self.n, dtype=np.int32) if want_leaf_index else None
+        _shim_call(_lib().gpb_hip_hist_grow_tree(
+            self.h, C.c_int(L), C.c_double(sum_gradient), C.c_double(sum_hessian), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
+            C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), C.c_double(const_hess), C.byref(nl),
+            _p(ia["split_feature_inner"], C.c_int), _p(thr, C.c_uint32), _p(ia["default_left"], C.c_int), _p(ia["left_child"], C.c_int),
+            _p(ia["right_child"], C.c_int), _p(gain), _p(ia["internal_count"], C.c_int), _p(lv), _p(ia["leaf_count"], C.c_int),
+            None if dli is None else _p(dli, C.c_int)))
+        k = nl.value
+        out = dict(num_leaves=k, threshold_in_bin=thr[:k - 1].astype(np.int64), split_gain=gain[:k - 1].copy(), leaf_value=lv[:k].copy(),
+                   leaf_count=ia["leaf_count"][:k].copy(), data_leaf_index=dli)
+        for key in ("split_feature_inner", "default_left", "left_child", "right_child", "internal_count"):
+            out[key] = ia[key][:k - 1].copy()
+        return out
+
     def get_slot(self, slot):
         out = np.empty((self.total_bins, 2))
         _shim_call(_lib().gpb_hip_hist_get_slot(self.h, C.c_int(int(slot)), _p(out)))

@@ -272,6 +272,22 @@ GPB_HIP_EXPORT int gpb_hip_hist_build_slot(gpb_hip_hist_t* h, int32_t slot, cons
                                            double const_hess);
 GPB_HIP_EXPORT int gpb_hip_hist_fix_slot(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian);
 GPB_HIP_EXPORT int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent_slot, int32_t smaller_slot, int32_t out_slot);
+/* One regression tree grown leaf-wise on the primitives above with the leaves' row lists RESIDENT on the device (the reference keeps
+ * them in DataPartition on the host): restates the control flow of SerialTreeLearner::Train (serial_tree_learner.cpp:159-210, :283-323,
+ * :325-449, :565-690; DataPartition::Split, data_partition.hpp:101-130; SplitInfo::operator>, split_info.hpp:126-153) for numerical
+ * features and the default regularisation path.  Needs set_gradients, set_fix_info, set_split_info and a pool of >= num_leaves slots.
+ *   sum_gradient / sum_hessian   root sums as LeafSplits::Init computes them (leaf_splits.hpp:73-86); sum_hessian = n * const_hess for a
+ *                                constant hessian
+ *   outputs                      the arrays of include/LightGBM/tree.h: per node (num_leaves - 1) split_feature_inner, threshold_in_bin,
+ *                                default_left, left_child / right_child (~leaf for leaves), split_gain, internal_count; per leaf
+ *                                (num_leaves) leaf_value (before shrinkage), leaf_count; data_leaf_index (n, optional): leaf of every row
+ * Per split only the left count and the F x 10 split candidates of the two children cross PCIe. */
+GPB_HIP_EXPORT int gpb_hip_hist_grow_tree(gpb_hip_hist_t* h, int32_t num_leaves, double sum_gradient, double sum_hessian, double lambda_l2,
+                                          int32_t min_data_in_leaf, double min_sum_hessian_in_leaf, double min_gain_to_split,
+                                          double const_hess, int32_t* out_num_leaves, int32_t* split_feature_inner,
+                                          uint32_t* threshold_in_bin, int32_t* default_left, int32_t* left_child, int32_t* right_child,
+                                          double* split_gain, int32_t* internal_count, double* leaf_value, int32_t* leaf_count,
+                                          int32_t* data_leaf_index);
 GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out);
 
 /* Split search on a device-resident (fixed) leaf histogram -- SURVEY.md 8f rank 2: FeatureHistogram::FindBestThreshold for every

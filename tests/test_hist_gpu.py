@@ -255,3 +255,58 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
         f, thr, rows = int(t["split_feature_inner"][nd]), int(t["threshold_in_bin"][nd]), t["node_rows"][nd]
         parts = [orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], dl, thr, rows) for dl in (0, 1)]
         assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1]), nd
+
+
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12"])
+@pytest.mark.parametrize("hi", [0, 1])
+def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
+    """gpb_hip_hist_grow_tree (row lists of the leaves resident on the device, control flow in C++) against the reference's own
+    SerialTreeLearner tree (tests/golden/tree_ref.npz) and against the single-step harness."""
+    import os
+    from gpboost_amd import shim
+    from oracle import orc
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    n = X.shape[0]
+    k = "%s_hess%d_" % (name, hi)
+    hs = hess if hi else None
+    bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(L + 1)
+    hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    hb.set_gradients(grad, hs)
+    sg = float(np.cumsum(grad)[-1]); sh = float(np.cumsum(np.ones(n) if hs is None else hs)[-1])
+    t = hb.grow_tree(L, sg, sh, *cfg)
+    assert t["num_leaves"] == int(g[k + "num_leaves"])
+    for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):
+        assert np.array_equal(t[key], g[k + key]), key
+    np.testing.assert_allclose(t["leaf_value"], g[k + "leaf_value"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(t["split_gain"], g[k + "split_gain"], rtol=1e-6)
+    if data == "plain":
+        assert np.array_equal(t["default_left"], g[k + "default_left"])
+    # leaf of every row: sizes equal the leaf counts, and replaying the tree's splits on the bins reproduces the labels
+    dli = t["data_leaf_index"]
+    assert np.array_equal(np.bincount(dli, minlength=t["num_leaves"]), t["leaf_count"])
+    lab = np.zeros(n, dtype=np.int32)
+    leaf_of_node = {0: 0}
+    nleaves = 1
+    for nd in range(t["num_leaves"] - 1):
+        lf = leaf_of_node[nd]
+        rows = np.flatnonzero(lab == lf).astype(np.int32)
+        f = int(t["split_feature_inner"][nd])
+        lte, gt = orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], int(t["default_left"][nd]), int(t["threshold_in_bin"][nd]), rows)
+        lab[gt] = nleaves
+        if t["left_child"][nd] >= 0:
+            leaf_of_node[int(t["left_child"][nd])] = lf
+        if t["right_child"][nd] >= 0:
+            leaf_of_node[int(t["right_child"][nd])] = nleaves
+        nleaves += 1
+    assert np.array_equal(lab, dli)
+    # a second tree on the same handle (workspaces are reused) gives the same result
+    t2 = hb.grow_tree(L, sg, sh, *cfg)
+    assert np.array_equal(t2["data_leaf_index"], dli) and np.array_equal(t2["threshold_in_bin"], t["threshold_in_bin"])
+    hb.close()
