@@ -274,13 +274,20 @@ class GPModel(object):
         return out
 
     def newton_update_leaf_values(self, cov_pars, y, data_leaf_index, num_leaves):
-        """Leaf values of the Newton step of the GPBoost algorithm (REModel::NewtonUpdateLeafValues); y = F - y, data order."""
-        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
-        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        """Leaf values of the Newton step of the GPBoost algorithm (REModel::NewtonUpdateLeafValues); y = F - y, data order.
+        cov_pars = y = None reuses the factor and y_aux of the preceding y_aux() call, as the reference does."""
         leaf = np.ascontiguousarray(data_leaf_index, dtype=np.int32).reshape(-1)
-        if leaf.shape[0] != self.num_data or y.shape[0] != self.num_data:
+        if leaf.shape[0] != self.num_data:
             raise ValueError("Incorrect number of data points")
         out = np.empty(int(num_leaves))
+        if y is None and cov_pars is None:
+            _safe_call(_lib().GPB_HIP_NewtonUpdateLeafValues(self.handle, None, None, leaf.ctypes.data_as(ctypes.c_void_p),
+                                                             ctypes.c_int(int(num_leaves)), _dptr(out)))
+            return out
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        if y.shape[0] != self.num_data:
+            raise ValueError("Incorrect number of data points")
         _safe_call(_lib().GPB_HIP_NewtonUpdateLeafValues(self.handle, _dptr(y), _dptr(cov_pars),
                                                          leaf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(num_leaves)), _dptr(out)))
         return out

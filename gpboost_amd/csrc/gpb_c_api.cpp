@@ -73,6 +73,7 @@ struct REModelHip {
   bool optimizer_unsupported_alias = false;
   double cov_pars_tr[3] = {0, 0, 0}, init_cov_pars_tr[3] = {0, 0, 0};
   bool cov_pars_initialized = false, init_cov_pars_provided = false;
+  bool yaux_valid = false;      // y_aux_has_been_calculated_: factor + y_aux of the last GPB_HIP_CalcYAux are still on the device
   bool y_set = false;           // y_has_been_set_: ybuf / the device copy hold the response of the last call that passed one
   // GPB_SetPredictionData (re_model_template.h:3337-3400)
   std::vector<double> coords_pred; int num_data_pred = 0;
@@ -109,6 +110,7 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects)
   } else {
     for (int k = 0; k < n; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]];
   }
+  mdl->yaux_valid = false;
   if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); mdl->y_set = true; return 0; }
   for (size_t k = 0; k < mdl->vhs.size(); ++k)
     if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf.data() + mdl->cl_off[k])) return shim_error();
@@ -622,6 +624,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   }
   if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
   else if (!mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
+  mdl->yaux_valid = false;
   int nnp = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;
   std::vector<double> D(np);
   if (gpb_hip_vecchia_predict_obs_only(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], out_predict, D.data(), nullptr)) return shim_error();
@@ -696,6 +699,7 @@ int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_par
     if (gpb_hip_vecchia_yaux(mdl->vhs[c], ya.data() + mdl->cl_off[c])) return shim_error();
   }
   for (int k = 0; k < mdl->n; ++k) y_aux[mdl->perm[k]] = ya[k];   // back to data order (GetYAux, :6430)
+  mdl->yaux_valid = mdl->vhs.size() == 1;
   C_API_END();
 }
 
@@ -703,16 +707,21 @@ int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, d
                                    int32_t num_leaves, double* leaf_values) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
-  if (!mdl || !cov_pars || !data_leaf_index || !leaf_values) return set_error("GPB_HIP_NewtonUpdateLeafValues: null argument");
+  if (!mdl || !data_leaf_index || !leaf_values) return set_error("GPB_HIP_NewtonUpdateLeafValues: null argument");
+  if ((y_data == nullptr) != (cov_pars == nullptr)) return set_error("GPB_HIP_NewtonUpdateLeafValues: pass both y_data and cov_pars, or neither (= reuse the state of the last GPB_HIP_CalcYAux)");
   if (mdl->likelihood != "gaussian") return set_error("Newton updates for leaf values is only supported for Gaussian data");   // re_model_template.h:4986-4988
   if (mdl->eh) return set_error("GPB_HIP_NewtonUpdateLeafValues: the exact (dense) GP is not on the MI355X hot path of this library for this call");
   if (mdl->vhs.size() != 1) return set_error("GPB_HIP_NewtonUpdateLeafValues: models with several clusters are not on the MI355X hot path of this library for this call");
-  double tr[3];
-  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
-  if (upload_y(mdl, y_data, nullptr)) return -1;
-  if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
-  std::vector<double> ya(mdl->n);
-  if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
+  if (!cov_pars) {      // the reference's own contract (re_model_template.h:4989: CHECK(y_aux_has_been_calculated_)): the gradient call ran before
+    if (!mdl->yaux_valid) return set_error("GPB_HIP_NewtonUpdateLeafValues: y_aux has not been calculated (call GPB_HIP_CalcYAux first, or pass y_data and cov_pars)");
+  } else {
+    double tr[3];
+    if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+    if (upload_y(mdl, y_data, nullptr)) return -1;
+    if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, tr[1], tr[2], 1)) return shim_error();
+    std::vector<double> ya(mdl->n);
+    if (gpb_hip_vecchia_yaux(mdl->vh, ya.data())) return shim_error();
+  }
   std::vector<int32_t> leaf(mdl->n);
   for (int k = 0; k < mdl->n; ++k) leaf[k] = data_leaf_index[mdl->perm[k]];     // :4999 (data_indices_per_cluster_)
   if (gpb_hip_vecchia_newton_leaf_values(mdl->vh, leaf.data(), num_leaves, leaf_values)) return shim_error();

@@ -196,7 +196,8 @@ GPBOOST_C_EXPORT int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data
 /* Newton update of the leaf values (REModel::NewtonUpdateLeafValues, re_model.cpp:1298-1310 ->
  * re_model_template.h:4982-5063; the reference calls it from the objective, it has no C entry point of its own):
  * y_data = F - y in data order (what the objective hands to CalcGradientF), data_leaf_index = leaf of every data point;
- * factor + y_aux + H^T Psi^-1 H + solve in one call. */
+ * factor + y_aux + H^T Psi^-1 H + solve in one call.  y_data = cov_pars = NULL: the reference's own contract (:4989,
+ * CHECK(y_aux_has_been_calculated_)) -- reuse the factor and y_aux that the preceding GPB_HIP_CalcYAux left on the device. */
 GPBOOST_C_EXPORT int GPB_HIP_NewtonUpdateLeafValues(REModelHandle handle, const double* y_data, double* cov_pars,
     const int32_t* data_leaf_index, int32_t num_leaves, double* leaf_values);
 /* Predictive mean and variance at new locations, vecchia_pred_type "order_obs_first_cond_obs_only" (the slice of

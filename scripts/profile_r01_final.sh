@@ -9,6 +9,11 @@ timeout 120 python scripts/gpu_pcie.py > $OUT/pcie.log 2>&1; tail -1 $OUT/pcie.l
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_bench -o bench -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace_bench.err
 timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/trace_lap -o lap -- python scripts/gpu_laplace.py 100000 30 > $OUT/laplace_traced.log 2> $OUT/trace_lap.err
 timeout 100 python scripts/gpu_laplace.py 100000 30 > $OUT/laplace.log 2>&1; tail -2 $OUT/laplace.log
+timeout 100 python scripts/fit_bench.py --n 100000 > $OUT/fit_n1e5.json 2>&1; tail -n 1 $OUT/fit_n1e5.json | head -c 300; echo
+timeout 100 python scripts/fit_bench.py --n 1000000 > $OUT/fit_n1e6.json 2>&1; tail -n 1 $OUT/fit_n1e6.json | head -c 300; echo
+timeout 100 python scripts/gpu_boost_iter.py 100000 8 > $OUT/boost_iter_n1e5.json 2>&1; tail -n 1 $OUT/boost_iter_n1e5.json | tail -c 420; echo
+timeout 100 python scripts/gpu_boost_iter.py 1000000 8 > $OUT/boost_iter_n1e6.json 2>&1; tail -n 1 $OUT/boost_iter_n1e6.json | tail -c 420; echo
+timeout 100 python scripts/gpu_hist_bench.py > $OUT/hist_bench.log 2>&1; cat $OUT/hist_bench.log
 python - <<'PY'
 import sqlite3, glob
 for tag in ("trace_bench", "trace_lap"):

@@ -377,6 +377,12 @@ def test_newton_leaf_values_against_reference_fixture(gpb, name):
                       num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
     vals = mdl.newton_update_leaf_values(np.asarray(c["cov_pars"][0], dtype=np.float64), y, leaf, L)
     np.testing.assert_allclose(vals, g["leaf_values_0"], rtol=1e-8, atol=1e-10)
+    # the reference's calling sequence: the gradient call (y_aux) leaves factor and y_aux behind, the leaf update reuses them
+    with pytest.raises(gpb.GPBoostError, match="y_aux has not been calculated"):
+        mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y)
+        mdl.newton_update_leaf_values(None, None, leaf, L)
+    mdl.y_aux(np.asarray(c["cov_pars"][0], dtype=np.float64), y)
+    assert np.array_equal(mdl.newton_update_leaf_values(None, None, leaf, L), vals)
 
 
 @pytest.mark.parametrize("n,m,L", [(20000, 30, 31), (5000, 20, 64), (3000, 10, 3)])
