@@ -133,6 +133,7 @@ struct gpb_hip_hist {
   // gpb_hip_hist_grow_tree: resident row lists of the leaves, two sets of search outputs (device + pinned host)
   int* d_rows = nullptr; double* d_split2 = nullptr; int* d_split2_i = nullptr; signed char* d_used2 = nullptr;
   double* h_split2 = nullptr; int* h_split2_i = nullptr;
+  double* d_tree_red = nullptr;                            // 4 doubles: root sums / left count of the data-parallel tree grower
 };
 
 extern "C" {
@@ -918,7 +919,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
-  dev_free(h->d_rows); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
+  dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
   if (h->h_split2) (void)hipHostFree(h->h_split2);
   if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }

@@ -281,7 +281,11 @@ GPB_HIP_EXPORT int gpb_hip_hist_subtract_slots(gpb_hip_hist_t* h, int32_t parent
  *   outputs                      the arrays of include/LightGBM/tree.h: per node (num_leaves - 1) split_feature_inner, threshold_in_bin,
  *                                default_left, left_child / right_child (~leaf for leaves), split_gain, internal_count; per leaf
  *                                (num_leaves) leaf_value (before shrinkage), leaf_count; data_leaf_index (n, optional): leaf of every row
- * Per split only the left count and the F x 10 split candidates of the two children cross PCIe. */
+ * Per split only the left count and the F x 10 split candidates of the two children cross PCIe.
+ * Data-parallel form: with a communicator on the handle (gpb_hip_hist_comm_init) the rows are a shard, sum_gradient / sum_hessian the
+ * LOCAL root sums; root sums, every freshly built histogram and every left count are all-reduced (DataParallelTreeLearner's scheme,
+ * data_parallel_tree_learner.cpp:55-80, :155-173, :240-260), all ranks return the same tree with GLOBAL counts, data_leaf_index
+ * covers the rank's own rows. */
 GPB_HIP_EXPORT int gpb_hip_hist_grow_tree(gpb_hip_hist_t* h, int32_t num_leaves, double sum_gradient, double sum_hessian, double lambda_l2,
                                           int32_t min_data_in_leaf, double min_sum_hessian_in_leaf, double min_gain_to_split,
                                           double const_hess, int32_t* out_num_leaves, int32_t* split_feature_inner,

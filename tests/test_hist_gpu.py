@@ -309,4 +309,10 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     # a second tree on the same handle (workspaces are reused) gives the same result
     t2 = hb.grow_tree(L, sg, sh, *cfg)
     assert np.array_equal(t2["data_leaf_index"], dli) and np.array_equal(t2["threshold_in_bin"], t["threshold_in_bin"])
+    # data-parallel form with a 1-rank communicator: root sums, every new histogram and every left count go through ncclAllReduce
+    hb.comm_init(shim.comm_unique_id(), 0, 1)
+    t3 = hb.grow_tree(L, sg, sh, *cfg)
+    for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "data_leaf_index"):
+        assert np.array_equal(t3[key], t[key]), key                     # (default_left: void ties, see the harness test above)
+    np.testing.assert_allclose(t3["leaf_value"], t["leaf_value"], rtol=1e-10, atol=1e-13)
     hb.close()
