@@ -420,7 +420,6 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   if (!cov_pars && mdl->likelihood != "gaussian") return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (no initial-value heuristics for likelihood '%s' on the MI355X path)", mdl->likelihood.c_str());
   if (mdl->likelihood != "gaussian") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
     if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
-    if (fixed_effects) return set_error("GPB_EvalNegLogLikelihood: fixed_effects with likelihood '%s' are not on the MI355X hot path of this library yet", mdl->likelihood.c_str());
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
     mdl->labels.resize(mdl->n);
@@ -432,6 +431,11 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     }
     if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : 0)) return shim_error();
     if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
+    if (fixed_effects) {                                  // location parameter = mode + fixed effects, Vecchia order
+      std::vector<double> fe(mdl->n);
+      for (int k = 0; k < mdl->n; ++k) fe[k] = fixed_effects[mdl->perm[k]];
+      if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, fe.data())) return shim_error();
+    } else if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, nullptr)) return shim_error();
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
                                       mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,

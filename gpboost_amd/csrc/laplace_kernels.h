@@ -27,13 +27,13 @@ struct CgScalars {         // per-column CG scalars on the device; part / part2:
 };
 int lap_cg_parts(int n);
 
-hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st);
+hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st);
 // ncol = number of column chunks, nc = columns per chunk (1: plain columns; 4: block vectors stored [chunk][row][4])
 hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, int nc, hipStream_t st);
 hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);
 hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);
 hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st);
-hipError_t lap_objective(int link, const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st);
+hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st);
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st);
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st);
 hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st);

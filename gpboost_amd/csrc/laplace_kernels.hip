@@ -96,12 +96,12 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
 
 // W = information, grad = first derivative, rhs = W mode + grad, dw = 1/D + W, rdw = 1/dw     (likelihoods.h:3882-3891, :16330)
 template <int LINK>
-__global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ D,
+__global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ D,
                                           int n, double* __restrict__ W, double* __restrict__ rhs, double* __restrict__ dw, double* __restrict__ rdw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double gr, w;
-  lik_grad_info<LINK>(y[i], mode[i], gr, w);
+  lik_grad_info<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i], gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
   W[i] = w;
   if (rhs) rhs[i] = w * mode[i] + gr;
   const double v = 1.0 / D[i] + w;
@@ -111,12 +111,12 @@ __global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const i
 
 // one workgroup: out2 = { sum_i log p(y_i | x_i),  sum_i Bx_i^2 / D_i }   (likelihoods.h:3808-3812, :3955-3959)
 template <int LINK>
-__global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __restrict__ x, const int* __restrict__ y, const double* __restrict__ Bx,
+__global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __restrict__ x, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ Bx,
                                                                const double* __restrict__ D, int n, double* __restrict__ out2) {
   __shared__ double s[2048];
   double ll = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    ll += lik_loglik<LINK>(y[i], x[i]);
+    ll += lik_loglik<LINK>(y[i], fe ? x[i] + fe[i] : x[i]);
     if (Bx) q = __builtin_fma(Bx[i] * (1.0 / D[i]), Bx[i], q);
   }
   block_reduce2(ll, q, s);
@@ -599,9 +599,9 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 
 // ---- launchers --------------------------------------------------------------------------------------------
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256)
-hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
-  if (link == 0) hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
-  else hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, D, n, W, rhs, dw, rdw);
+hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
+  else hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
   return hipGetLastError();
 }
 // nc = columns per chunk of the block layout (1: plain column-major; 4: the probe block), ncol = number of chunks
@@ -628,9 +628,9 @@ hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, h
   hipLaunchKernelGGL(lap_scatter_kernel, GRID1(n), 0, st, in, sigma, n, out);
   return hipGetLastError();
 }
-hipError_t lap_objective(int link, const double* x, const int* y, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
-  if (link == 0) hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
-  else hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, Bx, D, n, out2);
+hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
+  else hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
   return hipGetLastError();
 }
 // OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out

@@ -200,6 +200,9 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, cons
  * FirstDerivLogLikBernoulliProbit / SecondDerivNegLogLikBernoulliProbit, likelihoods.h:11385-11392, :12459-12466, :13282-13291,
  * with GPBoost::normalLogCDF, DF_utils.h:74-92).  gpb_hip_vecchia_laplace_logit then evaluates that likelihood. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int likelihood_id);
+/* Fixed effects F (offset of the location parameter, Vecchia order; NULL removes them): the likelihood is evaluated at mode + F
+ * (likelihoods.h:3861-3870), which is how the GPBoost algorithm passes the tree ensemble's scores for non-Gaussian data. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fixed_effects);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y01);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int num_rand_vec,
                                                  int seed_rand_vec, int cg_max_num_it, int cg_max_num_it_tridiag,

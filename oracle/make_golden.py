@@ -66,6 +66,10 @@ def laplace_fixture(out_dir):
                 key = "%s_%snegll_%d" % (name, tag, k)
                 res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
                 print("laplace", lik, name, cp, "negll = %.12f" % res[key])
+            # with fixed effects (the offset the GPBoost algorithm passes for non-Gaussian data), first parameter set
+            key = "%s_fe_%snegll_0" % (name, tag)
+            res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y, cases.laplace_fixed_effects(coords)))
+            print("laplace", lik, name, "fixed effects negll = %.12f" % res[key])
     # the R suite's probit fixture through the Vecchia approximation conditioning on all predecessors, iterative methods
     coords, y = orc.r_fixture_probit()
     mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 99, "none", 0, threads=8, likelihood="bernoulli_probit")

@@ -262,7 +262,7 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
 
 
 def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
-                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit"):
+                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit", fixed_effects=None):
     """Approximate negative log marginal likelihood of a Bernoulli-logit (or, likelihood="bernoulli_probit", -probit) Vecchia GP
     (Laplace, iterative, 'vadu').  Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
     link = {"bernoulli_logit": 0, "bernoulli_probit": 1}[likelihood]
@@ -272,8 +272,9 @@ def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, se
     yi = np.ascontiguousarray(y01, dtype=np.int32)
     rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0) if rand_vec is None else np.asfortranarray(rand_vec)
     out = np.empty(6); mode = np.empty(n)
-    rc = lib().orc_vecchia_laplace_binary(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
-                                          _p(yi, C.c_int), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
+    fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+    rc = lib().orc_vecchia_laplace_binary_fe(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+                                          _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
                                           C.c_int(cg_max_num_it_tridiag), C.c_double(cg_delta_conv), C.c_double(delta_conv_mode),
                                           _p(out, C.c_double), _p(mode, C.c_double))
     return -out[0], dict(rc=rc, newton_it=int(out[1]), cg_it=int(out[2]), log_det=out[3], lanczos_it=int(out[4]),

@@ -108,11 +108,12 @@ class RefCAPIModel(object):
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 
-    def neg_log_likelihood(self, cov_pars, y):
+    def neg_log_likelihood(self, cov_pars, y, fixed_effects=None):
         y = np.ascontiguousarray(y, dtype=np.float64)
         cp = np.ascontiguousarray(cov_pars, dtype=np.float64)
+        fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
         out = C.c_double(0)
-        rc = self.L.GPB_EvalNegLogLikelihood(self.h, _P(y), _P(cp), C.c_void_p(), C.byref(out))
+        rc = self.L.GPB_EvalNegLogLikelihood(self.h, _P(y), _P(cp), C.c_void_p() if fe is None else _P(fe), C.byref(out))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
         return out.value

@@ -78,6 +78,11 @@ def make_binary_data(c):
     return coords, y
 
 
+def laplace_fixed_effects(coords):
+    """Offset of the location parameter used by the fixed-effects Laplace fixtures (data order)."""
+    return 0.8 * np.cos(6 * coords[:, -1]) - 0.3
+
+
 def synthetic_binary(n, d, seed=1):
     """BASELINE config 4 inputs: coords U[0,1]^d, labels Bernoulli(sigmoid(smooth surface)), default_rng(seed)."""
     return make_binary_data(dict(n=n, d=d, seed_data=seed))

@@ -37,6 +37,11 @@ def test_against_reference_fixture(gpb, name, lik):
         info = mdl.laplace_info()
         assert abs(negll - ref) <= RTOL * abs(ref), (negll, ref, info)
         assert mdl.get_current_neg_log_likelihood() == negll
+    # with fixed effects (offset of the location parameter), then without again
+    fe = cases.laplace_fixed_effects(coords)
+    ref_fe = float(g["%s_fe_%snegll_0" % (name, "probit_" if lik == "bernoulli_probit" else "")])
+    v_fe = mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y, fixed_effects=fe)
+    assert abs(v_fe - ref_fe) <= RTOL * abs(ref_fe), (v_fe, ref_fe)
     # evaluating again at the first parameters reproduces the value bit for bit (mode restarts at 0, fixed reduction order)
     again = mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y)
     first = mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y)

@@ -125,6 +125,23 @@ def test_oracle_laplace_probit_matches_reference_fixture(orc, name):
         assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref, info["newton_it"], info["cg_it"], info["lanczos_it"])
 
 
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit"])
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_oracle_laplace_with_fixed_effects_matches_reference_fixture(orc, name, lik):
+    """Location parameter = mode + fixed effects (likelihoods.h:3861-3870): how the GPBoost algorithm passes the ensemble's scores."""
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_ref.npz"))
+    coords, y = cases.make_binary_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    fe = cases.laplace_fixed_effects(coords)
+    negll, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=lik, fixed_effects=fe[perm])
+    ref = float(g["%s_fe_%snegll_0" % (name, "probit_" if lik == "bernoulli_probit" else "")])
+    assert info["rc"] == 0 and abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
+
+
 def test_r_probit_fixture_oracle_vs_reference(orc):
     """R suite probit data, Vecchia on all predecessors (m = n - 1), iterative methods: oracle == reference (1e-8); both within the
     stochastic log-determinant's accuracy of the exact-GP golden 67.18342059 (test_GPModel_non_Gaussian_data.R:1405, :1426)."""
