@@ -264,7 +264,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   std::string lik_name = lik;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
   if (lik == "binary_probit") lik_name = "bernoulli_probit";
   if (lik == "binary" || lik == "binary_logit") lik_name = "bernoulli_logit";
-  if (lik_name != "gaussian" && lik_name != "bernoulli_logit" && lik_name != "bernoulli_probit") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (lik_name != "gaussian" && lik_name != "bernoulli_logit" && lik_name != "bernoulli_probit" && lik_name != "poisson") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
   if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
     if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
@@ -423,13 +423,22 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
     mdl->labels.resize(mdl->n);
+    const bool poisson = mdl->likelihood == "poisson";
     for (int k = 0; k < mdl->n; ++k) {
       const double yk = y_data[mdl->perm[k]];
+      if (poisson) {                                        // likelihoods.h:1338-1350
+        double intpart;
+        if (yk < 0.) return set_error(" Must have y >= 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
+        if (std::modf(yk, &intpart) != 0.0) return set_error("Found non-integer response variable ('y'). Response variable can only be integer valued for likelihood = '%s' ", mdl->likelihood.c_str());
+        if (yk > 2147483647.) return set_error("response %g is too large for likelihood = '%s'", yk, mdl->likelihood.c_str());
+        mdl->labels[k] = (int)yk;
+        continue;
+      }
       if (std::fabs(yk) >= 1e-10 && !near(yk, 1.))       // likelihoods.h:1321-1329
         return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
       mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
     }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : 0)) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : (poisson ? 2 : 0))) return shim_error();
     if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
     if (fixed_effects) {                                  // location parameter = mode + fixed effects, Vecchia order
       std::vector<double> fe(mdl->n);

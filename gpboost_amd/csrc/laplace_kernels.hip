@@ -61,24 +61,31 @@ __device__ __forceinline__ double normal_log_cdf(double x) {
 __device__ __forceinline__ double inv_mills_phi(double z) {
   return exp((-z * z / 2. - 0.91893853320467274178) - normal_log_cdf(z));
 }
-// per-observation pieces of the two supported likelihoods: LINK 0 = Bernoulli-logit, 1 = Bernoulli-probit
+// per-observation pieces of the supported likelihoods: LINK 0 = Bernoulli-logit, 1 = Bernoulli-probit, 2 = Poisson (log link:
+// LogLikPoisson without the normalising constant, FirstDerivLogLikPoisson, SecondDerivNegLogLikPoisson; likelihoods.h:11407-11415,
+// :12481-12483, :13315-13317)
 template <int LINK>
 __device__ __forceinline__ void lik_grad_info(int y, double x, double& grad, double& w) {
   if constexpr (LINK == 0) {
     const double p = sigmoid_stable(x);
     grad = (double)y - p;                 // likelihoods.h:12477
     w = p * (1.0 - p);                    // :13307
-  } else {
+  } else if constexpr (LINK == 1) {
     const double z = y ? x : -x;
     const double r = inv_mills_phi(z);
     grad = y ? r : -r;
     w = r * (z + r);
+  } else {
+    const double e = exp(x);
+    grad = (double)y - e;
+    w = e;
   }
 }
 template <int LINK>
 __device__ __forceinline__ double lik_loglik(int y, double x) {
   if constexpr (LINK == 0) return (double)y * x - softplus(x);      // likelihoods.h:11401-11403
-  else return normal_log_cdf(y ? x : -x);
+  else if constexpr (LINK == 1) return normal_log_cdf(y ? x : -x);
+  else return (double)y * x - exp(x);
 }
 // fixed-order block reduction of two values; result valid in thread 0
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
@@ -601,7 +608,8 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256)
 hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st) {
   if (link == 0) hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
-  else hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
+  else if (link == 1) hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
+  else hipLaunchKernelGGL(lik_newton_setup_kernel<2>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw);
   return hipGetLastError();
 }
 // nc = columns per chunk of the block layout (1: plain column-major; 4: the probe block), ncol = number of chunks
@@ -630,7 +638,8 @@ hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, h
 }
 hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st) {
   if (link == 0) hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
-  else hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
+  else if (link == 1) hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
+  else hipLaunchKernelGGL(lik_objective_kernel<2>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2);
   return hipGetLastError();
 }
 // OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out

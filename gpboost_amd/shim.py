@@ -174,7 +174,7 @@ class VecchiaState(object):
         return out
 
     def laplace_set_likelihood(self, likelihood):
-        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1}[likelihood]
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
 
     def laplace_set_labels(self, y01):

@@ -196,7 +196,9 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, cons
  *                             #CG-Lanczos iterations, log p(y|mode) - 0.5 mode^T Sigma^-1 mode,
  *                             ms factor, ms mode finding, ms log-determinant (host wall clock) };
  *               mode_host (optional) receives the mode, Vecchia order. */
-/* Likelihood of the Laplace path: 0 = "bernoulli_logit" (default), 1 = "bernoulli_probit" (LogLikBernoulliProbit /
+/* Likelihood of the Laplace path (set it BEFORE the labels, which are validated against it): 2 = "poisson" (counts >= 0; LogLikPoisson,
+ * FirstDerivLogLikPoisson, SecondDerivNegLogLikPoisson, likelihoods.h:11407-11415, :12481-12483, :13315-13317, and the normalising
+ * constant -sum log(y!), :10750-10757), 0 = "bernoulli_logit" (default), 1 = "bernoulli_probit" (LogLikBernoulliProbit /
  * FirstDerivLogLikBernoulliProbit / SecondDerivNegLogLikBernoulliProbit, likelihoods.h:11385-11392, :12459-12466, :13282-13291,
  * with GPBoost::normalLogCDF, DF_utils.h:74-92).  gpb_hip_vecchia_laplace_logit then evaluates that likelihood. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int likelihood_id);

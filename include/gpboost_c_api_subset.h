@@ -16,7 +16,7 @@
  *   gp_approx "vecchia" (num_neighbors <= 62, vecchia_ordering "none" | "random") or gp_approx "none"
  *   (exact GP, dense Cholesky; likelihood and y_aux only); parameter estimation (GPB_OptimCovPar) and prediction
  *   (GPB_PredictREModel, "order_obs_first_cond_obs_only") for the Gaussian Vecchia model;
- *   likelihood "bernoulli_logit" or "bernoulli_probit" (aliases "binary", "binary_logit", "binary_probit") with gp_approx "vecchia" and matrix_inversion_method "default" | "iterative"
+ *   likelihood "bernoulli_logit", "bernoulli_probit" (aliases "binary", "binary_logit", "binary_probit") or "poisson" with gp_approx "vecchia" and matrix_inversion_method "default" | "iterative"
  *   (Vecchia-Laplace approximation, "vadu"-preconditioned CG + stochastic Lanczos quadrature: the reference's
  *   defaults for that model; likelihood evaluation only, cov_pars = (sigma1_2, rho), y in {0, 1}).
  */

@@ -70,6 +70,16 @@ def laplace_fixture(out_dir):
             key = "%s_fe_%snegll_0" % (name, tag)
             res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y, cases.laplace_fixed_effects(coords)))
             print("laplace", lik, name, "fixed effects negll = %.12f" % res[key])
+        # Poisson counts on the same coordinates
+        coords, yc = cases.make_count_data(c)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood="poisson")
+        for k, cp in enumerate(c["cov_pars"]):
+            key = "%s_poisson_negll_%d" % (name, k)
+            res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), yc))
+            print("laplace poisson", name, cp, "negll = %.12f" % res[key])
+        key = "%s_fe_poisson_negll_0" % name
+        res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), yc, cases.laplace_fixed_effects(coords)))
+        print("laplace poisson", name, "fixed effects negll = %.12f" % res[key])
     # the R suite's probit fixture through the Vecchia approximation conditioning on all predecessors, iterative methods
     coords, y = orc.r_fixture_probit()
     mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 99, "none", 0, threads=8, likelihood="bernoulli_probit")

@@ -265,7 +265,7 @@ def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, se
                           cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit", fixed_effects=None):
     """Approximate negative log marginal likelihood of a Bernoulli-logit (or, likelihood="bernoulli_probit", -probit) Vecchia GP
     (Laplace, iterative, 'vadu').  Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
-    link = {"bernoulli_logit": 0, "bernoulli_probit": 1}[likelihood]
+    link = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
     A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape

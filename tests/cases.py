@@ -78,6 +78,16 @@ def make_binary_data(c):
     return coords, y
 
 
+def make_count_data(c):
+    """-> (coords, y counts as float) in DATA order: Poisson draws with log-mean = a smooth surface (same coords as make_binary_data)."""
+    rng = np.random.default_rng(c["seed_data"])
+    n, d = c["n"], c["d"]
+    coords = rng.uniform(size=(n, d))
+    latent = 1.2 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.4
+    y = rng.poisson(np.exp(latent)).astype(np.float64)
+    return coords, y
+
+
 def laplace_fixed_effects(coords):
     """Offset of the location parameter used by the fixed-effects Laplace fixtures (data order)."""
     return 0.8 * np.cos(6 * coords[:, -1]) - 0.3

@@ -48,6 +48,26 @@ def test_against_reference_fixture(gpb, name, lik):
     assert again == first
 
 
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_poisson_against_reference_fixture(gpb, name):
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_ref.npz"))
+    coords, y = cases.make_count_data(c)
+    mdl = gpb.GPModel(likelihood="poisson", gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    for k, cp in enumerate(c["cov_pars"]):
+        ref = float(g["%s_poisson_negll_%d" % (name, k)])
+        negll = mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y)
+        assert abs(negll - ref) <= RTOL * abs(ref), (negll, ref, mdl.laplace_info())
+    ref = float(g["%s_fe_poisson_negll_0" % name])
+    negll = mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y, fixed_effects=cases.laplace_fixed_effects(coords))
+    assert abs(negll - ref) <= RTOL * abs(ref), (negll, ref)
+    with pytest.raises(gpb.GPBoostError, match="y >= 0"):
+        mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y - 1.0)
+    with pytest.raises(gpb.GPBoostError, match="non-integer"):
+        mdl.neg_log_likelihood(np.asarray(c["cov_pars"][0], dtype=np.float64), y + 0.5)
+
+
 def test_probit_r_suite_fixture(gpb):
     """The R suite's probit data (test_GPModel_non_Gaussian_data.R:1391-1405; exact-GP golden nll 67.18342059 at (1, 0.2)) through
     the Vecchia approximation on all predecessors with the iterative methods: equal to the reference's own value for that model
@@ -130,7 +150,7 @@ def test_errors_are_loud(gpb):
         gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
                     matrix_inversion_method="cholesky")
     with pytest.raises(gpb.GPBoostError):
-        gpb.GPModel(likelihood="poisson", gp_coords=coords, cov_function="exponential", gp_approx="vecchia")
+        gpb.GPModel(likelihood="gamma", gp_coords=coords, cov_function="exponential", gp_approx="vecchia")
     with pytest.raises(gpb.GPBoostError, match="vadu"):
         mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky"})
     mdl.set_optim_params({"num_rand_vec_trace": 20, "cg_delta_conv": 1e-3})

@@ -142,6 +142,28 @@ def test_oracle_laplace_with_fixed_effects_matches_reference_fixture(orc, name, 
     assert info["rc"] == 0 and abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
 
 
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_oracle_laplace_poisson_matches_reference_fixture(orc, name):
+    """Poisson likelihood (log link; the normalising constant -sum log(y!) is part of every LogLikelihood value) against the
+    reference's GPB_EvalNegLogLikelihood(likelihood='poisson'), without and with fixed effects."""
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_ref.npz"))
+    coords, y = cases.make_count_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    for k, cp in enumerate(c["cov_pars"]):
+        a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+        negll, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood="poisson")
+        ref = float(g["%s_poisson_negll_%d" % (name, k)])
+        assert info["rc"] == 0 and abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref, info["newton_it"], info["cg_it"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    fe = cases.laplace_fixed_effects(coords)
+    negll, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood="poisson", fixed_effects=fe[perm])
+    ref = float(g["%s_fe_poisson_negll_0" % name])
+    assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
+
+
 def test_r_probit_fixture_oracle_vs_reference(orc):
     """R suite probit data, Vecchia on all predecessors (m = n - 1), iterative methods: oracle == reference (1e-8); both within the
     stochastic log-determinant's accuracy of the exact-GP golden 67.18342059 (test_GPModel_non_Gaussian_data.R:1405, :1426)."""
