@@ -131,6 +131,33 @@ def test_r_suite_fit_then_predict_end_to_end(lib_built):
 
 
 @pytest.mark.gpu
+def test_fit_at_the_metric_size_reaches_a_stationary_point(lib_built):
+    """n = 1e6, m = 30 (BASELINE.json's metric size; no oracle can follow there): the lbfgs fit decreases the likelihood from the
+    initial values, ends where the gradient wrt (log sigma1_2/sigma2, log a) is small against the likelihood's scale, the profiled
+    nugget satisfies its closed form sigma2 = y' Psi^-1 y / n, and a second fit started at the optimum stops at once."""
+    import gpboost_amd
+    n = 1000000
+    rng = np.random.default_rng(7)
+    coords = rng.uniform(size=(n, 2))
+    y = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="random", seed=1)
+    nll_init = mdl.neg_log_likelihood(y=y)                      # at the reference's initial values (FindInitCovPar)
+    init = mdl._get_init_cov_pars()
+    mdl.fit(y)
+    cp, nll = mdl.get_cov_pars(), mdl.get_current_neg_log_likelihood()
+    assert nll < nll_init and 1 < mdl.get_num_optim_iter() < 60
+    v, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+    assert abs(v - nll) <= 1e-9 * abs(nll)
+    assert np.abs(grad).max() < 1e-4 * abs(nll)                 # all three log-scale derivatives (the nugget's through the profile)
+    assert abs(grad[0]) < 1e-6 * n                              # d nll / d log sigma2 = n/2 - y'Psi^-1 y / (2 sigma2) = 0 at the profile
+    mdl.fit(y, params={"init_cov_pars": cp})
+    assert mdl.get_num_optim_iter() <= 2                        # relative change of the likelihood below 1e-6 at once
+    assert abs(mdl.get_current_neg_log_likelihood() - nll) <= 2e-6 * abs(nll)
+    np.testing.assert_allclose(mdl.get_cov_pars(), cp, rtol=0.05)   # the likelihood is flat along the range at that tolerance
+    assert not np.allclose(init, cp)
+
+
+@pytest.mark.gpu
 def test_fit_through_the_rccl_path_single_rank(lib_built):
     """A sharded fit is the same host loop on every rank over all-reduced sums: with a 1-rank communicator on the model's handle
     GPB_OptimCovPar evaluates through kernel + reduction + ncclAllReduce and must reproduce the plain fit exactly."""
