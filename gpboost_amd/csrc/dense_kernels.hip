@@ -322,8 +322,17 @@ static void launch_update(double* P, int np, int kp0, int K, int r_base, int c_b
 
 // Blocked right-looking Cholesky with two levels: 64-column panels (potrf + trsm + narrow update inside the current
 // 512-wide block column) and one wide K = 512 update of the remaining trailing matrix per block column.
-hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st) {
+// Look-ahead (st2 != nullptr): the wide update of block column J is split into the STRIP that the next block column needs
+// (columns [J1, J1 + 512), stream st) and the REST (columns >= J1 + 512, stream st2); the latency-bound panel kernels of block
+// column J + 1 then run concurrently with REST_J.  Hazards, all read-modify-write on C tiles:
+//   REST_J  reads the L columns of block J                      -> waits for the panels of J (event ev_panels)
+//   STRIP_J touches columns REST_{J-1} also updates             -> waits for REST_{J-1}     (event ev_rest)
+//   panels of J + 1 touch only columns [J1, J1 + 512)           -> disjoint from REST_J, ordered after STRIP_J on st
+//   REST_J and REST_{J-1} overlap                               -> same stream st2, in order
+hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st, hipStream_t st2, hipEvent_t ev_panels, hipEvent_t ev_rest) {
   constexpr int OB = 512;
+  const bool lookahead = st2 != nullptr && ev_panels != nullptr && ev_rest != nullptr && np > 2 * OB;
+  bool rest_pending = false;
   for (int J0 = 0; J0 < np; J0 += OB) {
     const int Jend = (J0 + OB < np) ? J0 + OB : np;
     for (int k0 = J0; k0 < Jend; k0 += TB) {
@@ -333,8 +342,23 @@ hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st) {
       hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
       launch_update(P, np, k0, TB, k0 + TB, k0 + TB, Jend, st);            // narrow: columns of this block column only
     }
-    launch_update(P, np, J0, Jend - J0, Jend, Jend, np, st);               // wide: K = 512, whole trailing matrix
+    if (Jend >= np) break;
+    if (!lookahead) {
+      launch_update(P, np, J0, Jend - J0, Jend, Jend, np, st);             // wide: K = 512, whole trailing matrix
+      continue;
+    }
+    const int Send = (Jend + OB < np) ? Jend + OB : np;                     // strip = the next block column
+    (void)hipEventRecord(ev_panels, st);
+    if (rest_pending) (void)hipStreamWaitEvent(st, ev_rest, 0);             // STRIP_J after REST_{J-1}
+    launch_update(P, np, J0, Jend - J0, Jend, Jend, Send, st);
+    if (Send < np) {
+      (void)hipStreamWaitEvent(st2, ev_panels, 0);                          // REST_J after the panels of J
+      launch_update(P, np, J0, Jend - J0, Send, Send, np, st2);
+      (void)hipEventRecord(ev_rest, st2);
+      rest_pending = true;
+    }
   }
+  if (rest_pending) (void)hipStreamWaitEvent(st, ev_rest, 0);               // everything is ordered on st again
   return hipGetLastError();
 }
 

@@ -109,6 +109,7 @@ struct gpb_hip_exact {
   double* d_exp_tab = nullptr;
   int* d_info = nullptr;
   bool has_y = false;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_panels = nullptr, ev_rest = nullptr;   // look-ahead of the blocked Cholesky
 };
 
 struct gpb_hip_hist {
@@ -832,6 +833,9 @@ int gpb_hip_exact_free(gpb_hip_exact_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  if (h->ev_panels) (void)hipEventDestroy(h->ev_panels);
+  if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
   dev_free(h->d_pts); dev_free(h->d_P); dev_free(h->d_y); dev_free(h->d_z); dev_free(h->d_x); dev_free(h->d_out);
   dev_free(h->d_exp_tab); dev_free(h->d_info);
   delete h;
@@ -862,7 +866,12 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   HIP_OK(hipEventRecord(e[0], h->stream));
   HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, h->np, var, a, 1.0, h->d_exp_tab, h->d_P, h->stream));   // Psi = Sigma + I (:9273-9287)
   HIP_OK(hipEventRecord(e[1], h->stream));
-  HIP_OK(gpb::launch_dense_cholesky(h->d_P, h->np, h->d_info, h->stream));
+  if (!h->stream2) {
+    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
+  }
+  HIP_OK(gpb::launch_dense_cholesky(h->d_P, h->np, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest));
   HIP_OK(hipEventRecord(e[2], h->stream));
   HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream));
   HIP_OK(hipEventRecord(e[3], h->stream));
