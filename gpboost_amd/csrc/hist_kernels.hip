@@ -396,7 +396,8 @@ hipError_t launch_hist_best_split(const double* hist, int num_features, const in
   hipLaunchKernelGGL(hist_best_split_kernel, dim3(num_features), dim3(256), 0, st, hist, num_features, view_offset, num_bin, meta3,
                      sum_gradient, sum_hessian, num_data, lambda_l2, min_data_in_leaf, min_sum_hessian, min_gain_to_split, out10,
                      out_default_left);
-  hipLaunchKernelGGL(hist_pick_split_kernel, dim3(1), dim3(64), 0, st, (const double*)out10, num_features, is_feature_used, best_feature);
+  if (best_feature)      // the tree grower picks on the host from the per-feature candidates it needs anyway
+    hipLaunchKernelGGL(hist_pick_split_kernel, dim3(1), dim3(64), 0, st, (const double*)out10, num_features, is_feature_used, best_feature);
   return hipGetLastError();
 }
 
