@@ -123,8 +123,8 @@ double range_const(const REModelHip* mdl) { return mdl->cov_type == 0 ? 1. : (md
 // REModelTemplate::FindInitCovPar (re_model_template.h:4849-4968) -> RECompGP::FindInitCovPar (re_comp.h:1249-1267) ->
 // CovFunction::FindInitCovPar (cov_fcts.h:1422-1683) for one Gaussian Matern GP.  The result is used as cov_pars_ directly, i.e. it
 // is on the TRANSFORMED scale: (var(y) / 2, 1, a) with a such that the correlation is ~0.05 at half the median distance.
-int find_init_cov_par(REModelHip* mdl, const double* y_data, const double* fixed_effects, double* theta) {
-  const int n = mdl->n;
+int find_init_cov_par_core(int n, const double* y_data, const double* fixed_effects, int nd, int d, const double* c /* column-major nd x d */,
+                           int cov_type, std::mt19937& rng, double* theta) {
   double mean = 0., var = 0.;
   for (int i = 0; i < n; ++i) mean += fixed_effects ? y_data[i] - fixed_effects[i] : y_data[i];
   mean /= n;
@@ -133,16 +133,14 @@ int find_init_cov_par(REModelHip* mdl, const double* y_data, const double* fixed
   theta[0] = var / 2.;
   theta[1] = 1.;                                   // init_marg_var = 1 for the Gaussian likelihood (:4865, :4912)
   const int MAX_POINTS_INIT_RANGE = 1000;          // cov_fcts.h:1444
-  const int nd = mdl->n0, d = mdl->d;
   const int ns = nd > MAX_POINTS_INIT_RANGE ? MAX_POINTS_INIT_RANGE : nd;
   std::vector<int> sample_ind;
   if (ns < nd) {
     std::uniform_int_distribution<> dis(0, nd - 1);
     sample_ind.resize(ns);
-    for (int i = 0; i < ns; ++i) sample_ind[i] = dis(mdl->rng);
+    for (int i = 0; i < ns; ++i) sample_ind[i] = dis(rng);
   }
   std::vector<double> distances((size_t)(ns * (ns - 1) / 2.));
-  const double* c = mdl->coords0.data();
   for (int i = 0; i < ns - 1; ++i) {
     const int ii = sample_ind.empty() ? i : sample_ind[i];
     for (int j = i + 1; j < ns; ++j) {
@@ -168,8 +166,12 @@ int find_init_cov_par(REModelHip* mdl, const double* y_data, const double* fixed
   if (med < 1e-10)
     return set_error("Cannot find an initial value for the range parameter since both the median and the average distances among coordinates are zero %s",
                      sample_ind.empty() ? "" : "on a random sub-sample of size 1000 ");
-  theta[2] = mdl->cov_type == 0 ? 2. * 3. / med : (mdl->cov_type == 1 ? 2. * 4.7 / med : 2. * 5.9 / med);   // cov_fcts.h:1601-1611
+  theta[2] = cov_type == 0 ? 2. * 3. / med : (cov_type == 1 ? 2. * 4.7 / med : 2. * 5.9 / med);   // cov_fcts.h:1601-1611
   return 0;
+}
+
+int find_init_cov_par(REModelHip* mdl, const double* y_data, const double* fixed_effects, double* theta) {
+  return find_init_cov_par_core(mdl->n, y_data, fixed_effects, mdl->n0, mdl->d, mdl->coords0.data(), mdl->cov_type, mdl->rng, theta);
 }
 
 // REModel::InitializeCovParsIfNotDefined (re_model.cpp:1312-1334)
@@ -543,6 +545,21 @@ int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_
   if (num_ll_evals) *num_ll_evals = mdl->last_fit.num_ll_evals;
   if (num_grad_evals) *num_grad_evals = mdl->last_fit.num_grad_evals;
   if (lr_cov_final) *lr_cov_final = mdl->last_fit.lr_cov_final;
+  C_API_END();
+}
+
+/* Test seam: FindInitCovPar (re_model_template.h:4849-4968, cov_fcts.h:1422-1683) on host data alone.  coords0_colmajor = the first
+   cluster's coordinates in Vecchia order; the generator is seeded with `seed` and advanced by one std::shuffle of `shuffle_len`
+   elements when shuffle_len > 0 (what vecchia_ordering = "random" does to a one-cluster model before the initial values are drawn).
+   theta3 = (sigma2, sigma1_2 / sigma2, a) on the transformed scale. */
+int GPB_HIP_FindInitCovParHost(int32_t num_data, const double* y_data, const double* fixed_effects, int32_t n0, int32_t dim,
+                               const double* coords0_colmajor, int cov_type, int seed, int32_t shuffle_len, double* theta3) {
+  C_API_BEGIN();
+  if (!y_data || !coords0_colmajor || !theta3 || num_data < 2 || n0 < 2 || dim < 1 || cov_type < 0 || cov_type > 2)
+    return set_error("GPB_HIP_FindInitCovParHost: invalid argument");
+  std::mt19937 rng(seed);
+  if (shuffle_len > 0) { std::vector<int> idx(shuffle_len); std::iota(idx.begin(), idx.end(), 0); std::shuffle(idx.begin(), idx.end(), rng); }
+  if (find_init_cov_par_core(num_data, y_data, fixed_effects, n0, dim, coords0_colmajor, cov_type, rng, theta3)) return -1;
   C_API_END();
 }
 

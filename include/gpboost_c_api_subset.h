@@ -212,6 +212,12 @@ GPBOOST_C_EXPORT int GPB_HIP_GetVecchiaStructure(REModelHandle handle, int32_t* 
 GPBOOST_C_EXPORT int GPB_HIP_GetLaplaceInfo(REModelHandle handle, double* out9);
 /* Launch counts of the last GPB_OptimCovPar (likelihood-only launches, launches with gradient sums) and the final learning rate */
 GPBOOST_C_EXPORT int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_evals, double* lr_cov_final);
+/* Test seam: the initial values GPB_OptimCovPar uses when none are given (FindInitCovPar, re_model_template.h:4849-4968 ->
+ * cov_fcts.h:1422-1683), computed from host data alone: coords0_colmajor = the first cluster's coordinates in Vecchia order (n0 x dim);
+ * the generator starts at `seed` and is advanced by one std::shuffle of shuffle_len elements when shuffle_len > 0 (the ordering step of a
+ * one-cluster model with vecchia_ordering = "random").  theta3 = (sigma2, sigma1_2 / sigma2, a), transformed scale. */
+GPBOOST_C_EXPORT int GPB_HIP_FindInitCovParHost(int32_t num_data, const double* y_data, const double* fixed_effects, int32_t n0, int32_t dim,
+    const double* coords0_colmajor, int cov_type, int seed, int32_t shuffle_len, double* theta3);
 /* Test seam: the host optimiser of GPB_OptimCovPar with a caller-supplied evaluation callback
  * terms(ctx, sigma1_2 / sigma2, a, with_grad, t7) -> 0 | -1 that fills the seven shard sums of gpb_hip_vecchia_grad_terms
  * (t7[0..1] only when with_grad == 0).  init_theta / theta_out = (sigma2, sigma1_2 / sigma2, a): the reference's transformed

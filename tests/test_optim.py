@@ -58,6 +58,28 @@ def test_host_optimiser_follows_the_reference_trajectory(lib_built, name):
     assert ne[0] + ne[1] == len(calls)
 
 
+@pytest.mark.parametrize("name", [k for k, c in cases.OPTIM_CASES.items() if c["init"] is None and c["model"] != "clusters"])
+def test_initial_values_match_the_reference(lib_built, name):
+    """FindInitCovPar (var(y)/2, ratio 1, range from the median pairwise distance; 1000 points drawn from the model's generator AFTER
+    the ordering shuffle when n > 1000) through the host-only seam against the reference's GPB_GetInitCovPar."""
+    from oracle import orc
+    g = np.load(GOLDEN)
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    ct = orc.cov_type_id(mc["cov_function"], mc["shape"])
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    cm = np.asfortranarray(co)
+    th = np.empty(3)
+    lib = C.CDLL(lib_built)
+    lib.LGBM_GetLastError.restype = C.c_char_p
+    n = len(y)
+    rc = lib.GPB_HIP_FindInitCovParHost(C.c_int(n), y.ctypes.data_as(C.c_void_p), None, C.c_int(n), C.c_int(coords.shape[1]),
+                                        cm.ctypes.data_as(C.c_void_p), C.c_int(ct), C.c_int(mc["seed"]),
+                                        C.c_int(n if mc["ordering"] == "random" else 0), th.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.LGBM_GetLastError()
+    rc_ = [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct]
+    np.testing.assert_allclose([th[0], th[1] * th[0], rc_ / th[2]], g[name + "_init_cov_pars"], rtol=1e-10)
+
+
 def test_host_optimiser_errors(lib_built):
     from tests import optim_harness as oh
     lib = C.CDLL(lib_built)
