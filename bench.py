@@ -309,6 +309,47 @@ def main():
                     "reference": "DESIGN.md 4.10: unmodified reference, same data recipe at n=1e5, this repo's build container"}
             except Exception as e:
                 out["fit_covariance_parameters"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1:
+            # BASELINE config 3: the device work of one GPBoost iteration (Gaussian likelihood, Vecchia m = 30, n = 1e5; tree of 31 leaves
+            # on F = 50 features x 255 bins), every step through the C ABI with host arrays in and out (scripts/gpu_boost_iter.py)
+            try:
+                n3, F3, nb3, L3 = 100000, 50, 255, 31
+                rng3 = np.random.default_rng(1)
+                c3 = rng3.uniform(size=(n3, 2)); X3 = rng3.uniform(size=(n3, F3))
+                y3 = np.sin(4 * X3[:, 0]) + X3[:, 1] ** 2 + 0.5 * rng3.standard_normal(n3)
+                bins3 = np.minimum((X3 * (nb3 - 1)).astype(np.int64) + 1, nb3 - 1).astype(np.uint8).T.copy()
+                gnb3 = np.full(F3, nb3, dtype=np.int32)
+                bo3 = np.concatenate([[0], np.cumsum(gnb3)]).astype(np.int32)
+                m3 = gpboost_amd.GPModel(gp_coords=c3, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="random", seed=1)
+                cp3 = np.array([0.25, 0.1, 0.1])
+                m3.set_optim_params({"optimizer_cov": "gradient_descent", "maxit": 1, "init_cov_pars": cp3})
+                hb3 = shim.HistBuilder(bins3, bo3)
+                hb3.pool_resize(L3 + 1)
+                hb3.set_fix_info((bo3[:-1] + 1).astype(np.int32), np.full(F3, nb3, dtype=np.int32), np.zeros(F3, dtype=np.int32))
+                hb3.set_split_info(np.ones(F3, dtype=np.int32), np.zeros(F3, dtype=np.int32), np.zeros(F3, dtype=np.int32))
+                score = np.zeros(n3); t3 = {}
+                for it3 in range(5):
+                    ta = time.perf_counter()
+                    grad3 = m3.y_aux(m3.get_cov_pars() if it3 else cp3, score - y3)
+                    tb = time.perf_counter()
+                    hb3.set_gradients(grad3, None)
+                    tree3 = hb3.grow_tree(L3, float(np.cumsum(grad3)[-1]), float(n3), 0.0, 20, 1e-3, 0.0)
+                    tc = time.perf_counter()
+                    vals3 = m3.newton_update_leaf_values(None, None, tree3["data_leaf_index"], tree3["num_leaves"])
+                    td = time.perf_counter()
+                    score = score + 0.1 * vals3[tree3["data_leaf_index"]]
+                    te = time.perf_counter()
+                    m3.fit(y3 - score)
+                    tf3 = time.perf_counter()
+                    t3 = {"gradient_yaux_ms": (tb - ta) * 1e3, "tree_31_leaves_ms": (tc - tb) * 1e3, "newton_leaf_values_ms": (td - tc) * 1e3,
+                          "cov_par_step_ms": (tf3 - te) * 1e3}
+                t3["total_ms"] = sum(t3.values())
+                out["config3_boosting_iteration"] = dict(
+                    workload="one GPBoost iteration, n=%d, F=%d, %d bins, %d leaves, Vecchia m=30 (5th iteration; synthetic bins in the reference's layout)" % (n3, F3, nb3, L3),
+                    reference_s_per_iteration={"value": 21.0, "cores": 8, "where": "SURVEY.md section 0 (survey box)"}, **{k: round(v, 3) for k, v in t3.items()})
+                hb3.close(); del m3
+            except Exception as e:
+                out["config3_boosting_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)
