@@ -14,6 +14,7 @@ timeout 100 python scripts/fit_bench.py --n 1000000 > $OUT/fit_n1e6.json 2>&1; t
 timeout 100 python scripts/gpu_boost_iter.py 100000 8 > $OUT/boost_iter_n1e5.json 2>&1; tail -n 1 $OUT/boost_iter_n1e5.json | tail -c 420; echo
 timeout 100 python scripts/gpu_boost_iter.py 1000000 8 > $OUT/boost_iter_n1e6.json 2>&1; tail -n 1 $OUT/boost_iter_n1e6.json | tail -c 420; echo
 timeout 100 python scripts/gpu_hist_bench.py > $OUT/hist_bench.log 2>&1; cat $OUT/hist_bench.log
+timeout 100 python scripts/gpu_exact_bench.py 2000 16384 > $OUT/exact_bench.log 2>&1; cat $OUT/exact_bench.log
 python - <<'PY'
 import sqlite3, glob
 for tag in ("trace_bench", "trace_lap"):
