@@ -31,6 +31,9 @@ if ROOT not in sys.path:
 # n = 1e6, m = 30, d = 2, one GPU; gathers are 32-byte records, so the guide's 2x correction for wide coalesced streams is
 # not applied).  Reported only for exactly that configuration; otherwise null.
 PROFILED_TRAFFIC_BYTES = {(1000000, 30, 2, 1): (1.24776e6 + 5.86e3) * 1024}
+# hist_build_kernel<const hessian, all rows> at n = 1e7, F = 50 (profiles/r01_i_hist_pmc_summary.txt: FETCH_SIZE 631486 KB + WRITE_SIZE
+# 110592 KB per dispatch, separate --pmc passes; before the XCD-aware workgroup order FETCH_SIZE was 1.41e6 KB)
+PROFILED_HIST_TRAFFIC_BYTES = {(10000000, 50): (631486 + 110592) * 1024}
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
 
@@ -264,7 +267,7 @@ def main():
                 out["roofline_histogram"] = {
                     "bound": "hbm", "kernel": "hist_build_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
-                    "algorithmic_bytes_per_launch": hbytes,
+                    "algorithmic_bytes_per_launch": hbytes, "traffic": PROFILED_HIST_TRAFFIC_BYTES.get((nh, Fh)),
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
                     "note": "bounded by LDS fp64 atomics (2 per row and feature), not by HBM: see DESIGN.md 4.4"}
                 hb.close()

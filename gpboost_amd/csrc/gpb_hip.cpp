@@ -985,8 +985,9 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   const int groups = h->fpad / GPB_HIST_FG;
   if (h->num_cu <= 0) { HIP_OK(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, h->device)); if (h->num_cu <= 0) h->num_cu = 256; }
   int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, 9 * h->num_cu / groups)));
+  if (nchunks >= 16) nchunks &= ~7;                 // multiples of 8: the XCD-aware workgroup order of hist_build_kernel
   const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
-  if (rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
+  if (nchunks < 16 && rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
   if (nchunks < 1) nchunks = 1;
   if (h->part_chunks < nchunks) {
     dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt);
