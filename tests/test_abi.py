@@ -46,7 +46,8 @@ def test_reference_signature_is_kept_for_on_path_functions():
             out[n] = [re.sub(r"\s*\b\w+$", "", a) for a in args]   # drop parameter names
         return out
     names = ["GPB_CreateREModel", "GPB_REModelFree", "GPB_SetOptimConfig", "GPB_EvalNegLogLikelihood",
-             "GPB_GetCurrentNegLogLikelihood", "GPB_GetLikelihoodName"]
+             "GPB_GetCurrentNegLogLikelihood", "GPB_GetLikelihoodName", "GPB_OptimCovPar", "GPB_GetCovPar", "GPB_GetInitCovPar",
+             "GPB_GetNumIt", "GPB_SetPredictionData", "GPB_PredictREModel"]
     a = protos(ref, "GPBOOST_C_EXPORT", names)
     b = protos(os.path.join(ROOT, "include", "gpboost_c_api_subset.h"), "GPBOOST_C_EXPORT", names)
     for n in names:
@@ -84,6 +85,6 @@ def test_product_never_imports_the_oracle():
     """The shipped package must not reference oracle/ (it is test infrastructure)."""
     for dp, _, fs in os.walk(os.path.join(ROOT, "gpboost_amd")):
         for f in fs:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libgpb_oracle" not in txt, f
