@@ -55,7 +55,8 @@ struct REModelHip {
   std::vector<gpb_hip_vecchia_t*> vhs;      // one Vecchia state per cluster, in order of first appearance (re_model_template.h:6820-6852)
   std::vector<int> cl_off;                  // offsets of the clusters in perm / ybuf (size #clusters + 1)
   gpb_hip_exact_t* eh = nullptr;   // gp_approx == "none": dense path, data order (no Vecchia ordering)
-  std::vector<double> ybuf;     // y in Vecchia order
+  double* ybuf = nullptr;       // y in Vecchia order, page-locked (uploaded on every host-pointer call)
+  size_t ybuf_cap = 0;
   double cur_negll = 0.;
   bool negll_valid = false;
   bool has_duplicates = false;
@@ -82,7 +83,7 @@ struct REModelHip {
   int num_neighbors_pred = 0;   // 0 = default (2 * num_neighbors_, :299)
   int num_it = 0;
   GpbOptimResult last_fit;
-  ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); }
+  ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); if (ybuf) gpb_hip_pinned_free(ybuf); }
 };
 
 // The host-pointer entry points permute n-vectors between data order and Vecchia order (gathers / scatters over 8 MB at n = 1e6:
@@ -120,16 +121,21 @@ int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr
 int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   const int n = mdl->n;
-  mdl->ybuf.resize(n);
+  if (mdl->ybuf_cap < (size_t)n) {
+    if (mdl->ybuf) { gpb_hip_pinned_free(mdl->ybuf); mdl->ybuf = nullptr; mdl->ybuf_cap = 0; }
+    void* p = nullptr;
+    if (gpb_hip_pinned_alloc(sizeof(double) * (size_t)n, &p)) return shim_error();
+    mdl->ybuf = static_cast<double*>(p); mdl->ybuf_cap = (size_t)n;
+  }
   if (fixed_effects) {
     parallel_for(n, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) { const int id = mdl->perm[k]; mdl->ybuf[k] = y_data[id] - fixed_effects[id]; } });   // :2909-2915
   } else {
     parallel_for(n, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]]; });
   }
   mdl->yaux_valid = false;
-  if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf.data())) return shim_error(); mdl->y_set = true; return 0; }
+  if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf)) return shim_error(); mdl->y_set = true; return 0; }
   for (size_t k = 0; k < mdl->vhs.size(); ++k)
-    if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf.data() + mdl->cl_off[k])) return shim_error();
+    if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf + mdl->cl_off[k])) return shim_error();
   mdl->y_set = true;
   return 0;
 }

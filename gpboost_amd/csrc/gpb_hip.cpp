@@ -397,6 +397,20 @@ int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev) {
   API_END();
 }
 
+int gpb_hip_pinned_alloc(size_t bytes, void** out) {
+  API_BEGIN();
+  if (!out) return fail("null argument");
+  *out = nullptr;
+  HIP_OK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  API_END();
+}
+
+int gpb_hip_pinned_free(void* p) {
+  API_BEGIN();
+  if (p) HIP_OK(hipHostFree(p));
+  API_END();
+}
+
 int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) {
   API_BEGIN();
   if (!h || !y_host) return fail("null argument");

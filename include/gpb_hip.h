@@ -23,6 +23,7 @@
 #ifndef GPB_HIP_H_
 #define GPB_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -84,6 +85,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_get_neighbors(gpb_hip_vecchia_t* h, int32_t* 
  * Coordinates, y and the neighbour table stay replicated. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_begin, int32_t i_end);
 
+/* Page-locked host memory for staging buffers that are uploaded every call (the C API host keeps y in Vecchia order there: an
+ * 8 MB upload from pinned memory takes about half the time of one from pageable memory). */
+GPB_HIP_EXPORT int gpb_hip_pinned_alloc(size_t bytes, void** out);
+GPB_HIP_EXPORT int gpb_hip_pinned_free(void* p);
 /* y in Vecchia order (REModelTemplate::SetY, include/GPBoost/re_model_template.h:6185-6222). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev);
