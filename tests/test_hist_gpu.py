@@ -57,6 +57,34 @@ def test_histogram_is_reproducible_and_subtractable(lib_built, orc):
     assert int(pc[bo[0]:bo[1]].sum()) == n
 
 
+def test_full_size_properties_n1e7(lib_built):
+    """SURVEY.md 8d's histogram size (n = 1e7 rows, F = 50, 255 bins): properties that need no oracle pass -- every feature's counts
+    sum to the rows of the leaf, two features equal numpy's bincount exactly (counts) / to 1e-9 (sums), every feature's gradient sums
+    add up to the total gradient, and parent = left + right holds exactly for counts and to rounding for the sums."""
+    from gpboost_amd import shim
+    n, F, nb = 10000000, 50, 255
+    rng = np.random.default_rng(9)
+    bins = rng.integers(0, nb, size=(F, n), dtype=np.uint8)
+    bo = (np.arange(F + 1) * nb).astype(np.int32)
+    grad = rng.standard_normal(n)
+    hb = shim.HistBuilder(bins, bo); hb.set_gradients(grad, None)
+    hist, cnt = hb.build(None)
+    assert np.array_equal(cnt.reshape(F, nb).sum(axis=1), np.full(F, n, dtype=np.uint64))
+    tot = grad.sum()
+    np.testing.assert_allclose(hist[:, 0].reshape(F, nb).sum(axis=1), tot, rtol=0, atol=1e-8 * np.abs(grad).sum())
+    for f in (0, 37):
+        assert np.array_equal(cnt[bo[f]:bo[f + 1]], np.bincount(bins[f], minlength=nb).astype(np.uint64))
+        ref = np.bincount(bins[f], weights=grad, minlength=nb)
+        np.testing.assert_allclose(hist[bo[f]:bo[f + 1], 0], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    left = np.flatnonzero(bins[3] < 100).astype(np.int32)
+    right = np.flatnonzero(bins[3] >= 100).astype(np.int32)
+    hl, cl = hb.build(left); hr, cr = hb.build(right)
+    assert np.array_equal(cl + cr, cnt)
+    assert cl[bo[3] + 100:bo[4]].sum() == 0 and cr[bo[3]:bo[3] + 100].sum() == 0        # the split feature separates cleanly
+    np.testing.assert_allclose(hl[:, 0] + hr[:, 0], hist[:, 0], rtol=0, atol=1e-9 * np.abs(hist[:, 0]).max())
+    hb.close()
+
+
 def test_histogram_against_reference_fixture(lib_built):
     """The reference's own stored bins and its Dataset::ConstructHistograms output (tests/golden/hist_ref.npz)."""
     import os
