@@ -88,6 +88,20 @@ def laplace_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_ref.npz"), **res)
 
 
+def laplace_grad_fixture(out_dir):
+    """Gradients of the reference's approximate negative marginal log-likelihood wrt (log sigma1^2, log a), read off one plain
+    gradient-descent step of its optimiser (oracle/refdrv.py: ref_laplace_gradient) -- the pin of orc_vecchia_laplace_grad."""
+    res = {}
+    for name, c in cases.LAPLACE_CASES.items():
+        for lik in ("bernoulli_logit", "bernoulli_probit", "poisson"):
+            coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+            cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+            g = refdrv.ref_laplace_gradient(coords, y, cp, lik, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+            res["%s_%s_grad" % (name, lik)] = g
+            print("laplace grad", name, lik, g, flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
+
+
 def split_fixture(out_dir):
     """The reference's FeatureHistogram::FindBestThreshold on its own (fixed) histograms: all inputs of the call + its outputs."""
     res = {}
@@ -176,6 +190,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":
+        laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim":
         optim_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "tree":

@@ -281,6 +281,27 @@ def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, se
                          mll_no_det=out[5], mode=mode, A=A, D=D)
 
 
+def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000, cg_max_num_it_tridiag=1000,
+                         cg_delta_conv=1e-2, delta_conv_mode=1e-8, likelihood="bernoulli_logit", fixed_effects=None):
+    """(negll, gradient of negll wrt (log sigma1^2, log a)) of the Vecchia-Laplace approximation, iterative methods, 'vadu'
+    (orc_vecchia_laplace_grad: round-2 groundwork, no device path consumes it yet)."""
+    link = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
+    A, D, Ag, Dg, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False, grad=True)
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, m = nn.shape
+    yi = np.ascontiguousarray(y01, dtype=np.int32)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0)
+    fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+    out = np.empty(6); g = np.empty(2)
+    rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double),
+                                        _p(nn, C.c_int), C.c_int(n), C.c_int(m), _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double),
+                                        _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
+                                        C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double))
+    if rc != 0:
+        raise RuntimeError("orc_vecchia_laplace_grad failed")
+    return -out[0], g
+
+
 # ---------------------------------------------------------------------------
 # High-level mirror of GPModel(gp_approx="vecchia").neg_log_likelihood for tests
 # ---------------------------------------------------------------------------

@@ -140,8 +140,8 @@ class RefCAPIModel(object):
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 
-    def get_cov_par(self):
-        out = np.empty(3)
+    def get_cov_par(self, num_cov_pars=3):
+        out = np.empty(num_cov_pars)
         rc = self.L.GPB_GetCovPar(self.h, _P(out), C.c_bool(False))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
@@ -169,6 +169,24 @@ class RefCAPIModel(object):
             self.L.GPB_REModelFree(self.h)
         except Exception:
             pass
+
+
+def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, lr=1e-3,
+                         threads=8):
+    """Gradient of the reference's approximate negative marginal log-likelihood wrt (log sigma1^2, log a) at cov_pars = (sigma1^2, rho),
+    read off ONE plain gradient-descent step of its own optimiser: theta_1 = exp(log theta_0 - lr * grad) (re_model_template.h:8737-8742),
+    so grad = -(log theta_1 - log theta_0) / lr exactly, provided the step was not halved -- checked by repeating with lr / 2."""
+    res = []
+    for step in (lr, lr / 2):
+        mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
+        mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), lr_cov=step, max_iter=1, use_nesterov_acc=False,
+                             optimizer_cov="gradient_descent")
+        mdl.optim_cov_par(y)
+        th1 = mdl.get_cov_par(2)
+        res.append(np.array([-(np.log(th1[0]) - np.log(cov_pars[0])) / step, (np.log(th1[1]) - np.log(cov_pars[1])) / step]))
+    if not np.allclose(res[0], res[1], rtol=1e-6):
+        raise RuntimeError("the reference halved its step: %s vs %s" % (res[0], res[1]))
+    return res[1]
 
 
 def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False, extra_params="", split_cfg=None,

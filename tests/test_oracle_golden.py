@@ -164,6 +164,25 @@ def test_oracle_laplace_poisson_matches_reference_fixture(orc, name):
     assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
 
 
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_oracle_laplace_gradient_matches_reference(orc, name, lik):
+    """orc_vecchia_laplace_grad (stochastic trace estimators with the vadu control variates, implicit derivative through the mode)
+    against the gradient the reference's own optimiser used for one plain gradient-descent step (tests/golden/laplace_grad_ref.npz,
+    oracle/refdrv.py: ref_laplace_gradient).  Groundwork for the device path of round 2.  The extraction is exact up to log / exp
+    rounding over a step of 5e-4 (~1e-8); the gradient itself contains a CG solve that stops at |r| < 1e-2, whose iteration count can
+    shift with rounding (seen: 2e-6 relative on one case), hence 1e-5."""
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_grad_ref.npz"))
+    coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    negll, grad = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik)
+    np.testing.assert_allclose(grad, g["%s_%s_grad" % (name, lik)], rtol=1e-5, atol=1e-5)
+
+
 def test_r_probit_fixture_oracle_vs_reference(orc):
     """R suite probit data, Vecchia on all predecessors (m = n - 1), iterative methods: oracle == reference (1e-8); both within the
     stochastic log-determinant's accuracy of the exact-GP golden 67.18342059 (test_GPModel_non_Gaussian_data.R:1405, :1426)."""
