@@ -570,6 +570,36 @@ int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_
   C_API_END();
 }
 
+/* Test seam (and the host half of the round-2 device path): the optimiser for non-Gaussian likelihoods -- theta = (sigma1_2, a), the
+   Laplace approximation evaluated by a stateful callback (ops documented at gpb_laplace_fn in gpb_optim.h). */
+int GPB_HIP_OptimizeLaplaceWithCallback(const double* init_theta2, const char* optimizer, double lr_cov, double acc_rate_cov, int max_iter,
+                                        double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version, int momentum_offset,
+                                        const char* convergence_criterion, int m_lbfgs, int (*eval)(void*, int, double, double, double*),
+                                        void* ctx, double* theta_out2, int* num_it, double* negll, int* num_evals) {
+  C_API_BEGIN();
+  if (!init_theta2 || !eval || !theta_out2) return set_error("GPB_HIP_OptimizeLaplaceWithCallback: null argument");
+  GpbOptimConfig cfg;
+  if (optimizer && optimizer[0]) cfg.optimizer = optimizer;
+  if (lr_cov > 0.) cfg.lr_cov_init = lr_cov;
+  if (acc_rate_cov > 0.) cfg.acc_rate_cov = acc_rate_cov;
+  if (max_iter >= 0) cfg.max_iter = max_iter;
+  if (delta_rel_conv > 0.) cfg.delta_rel_conv_init = delta_rel_conv;
+  cfg.use_nesterov_acc = use_nesterov_acc;
+  if (nesterov_schedule_version >= 0) cfg.nesterov_schedule_version = nesterov_schedule_version;
+  if (momentum_offset >= 0) cfg.momentum_offset = momentum_offset;
+  if (convergence_criterion && convergence_criterion[0] && std::string(convergence_criterion) != "default") cfg.convergence_criterion = convergence_criterion;
+  if (m_lbfgs > 0) cfg.m_lbfgs = m_lbfgs;
+  char err[512] = "";
+  GpbLaplaceOptimResult res;
+  if (gpb_optimize_laplace_cov_pars(cfg, eval, ctx, init_theta2, &res, err, (int)sizeof(err)))
+    return set_error("%s", err[0] ? err : "evaluation callback failed");
+  theta_out2[0] = res.theta[0]; theta_out2[1] = res.theta[1];
+  if (num_it) *num_it = res.num_it;
+  if (negll) *negll = res.negll;
+  if (num_evals) *num_evals = res.num_evals;
+  C_API_END();
+}
+
 /* Test seam: FindInitCovPar (re_model_template.h:4849-4968, cov_fcts.h:1422-1683) on host data alone.  coords0_colmajor = the first
    cluster's coordinates in Vecchia order; the generator is seeded with `seed` and advanced by one std::shuffle of `shuffle_len`
    elements when shuffle_len > 0 (what vecchia_ordering = "random" does to a one-cluster model before the initial values are drawn).

@@ -306,6 +306,174 @@ int run_lbfgs(State& st, const GpbOptimConfig& cfg, double th[3], GpbOptimResult
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// non-Gaussian likelihoods: the same two optimisers on theta = (sigma1_2, a); the objective is the Laplace approximation with a
+// warm-started mode (EvalLLforLBFGSpp, optim_utils.h:340-344, :395-414; OptimLinRegrCoefCovPar non-Gaussian branches :1380-1410,
+// :1514-1550; UpdateCovAuxPars :8737-8742, :8806-8812)
+// ---------------------------------------------------------------------------------------------------------------------
+struct LapState {
+  gpb_laplace_fn fn; void* ctx;
+  int n_evals = 0;
+  double negll = 0.;
+  int eval(const double th[2], bool with_grad, bool first_update, double* grad) {
+    double o[3] = {0, 0, 0};
+    if (fn(ctx, (with_grad ? 1 : 0) | (first_update ? 16 : 0), th[0], th[1], o)) return -1;
+    ++n_evals;
+    negll = o[0];
+    if (with_grad && grad) { grad[0] = o[1]; grad[1] = o[2]; }
+    return 0;
+  }
+  int grad_current(const double th[2], double* grad) {
+    double o[3] = {0, 0, 0};
+    if (fn(ctx, 2, th[0], th[1], o)) return -1;
+    grad[0] = o[1]; grad[1] = o[2];
+    return 0;
+  }
+  int reset_mode() { double o[3]; return fn(ctx, 3, 0., 0., o); }
+};
+
+int run_gradient_descent_laplace(LapState& st, const GpbOptimConfig& cfg, double th[2], GpbLaplaceOptimResult* out, const Fail& fail) {
+  double lr_cov = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 0.1;
+  const double delta_rel_conv = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-6;
+  const bool nesterov = cfg.use_nesterov_acc;
+  if (nesterov && cfg.nesterov_schedule_version == 1)
+    return fail("Armijo condition backtracking is not implemented when nesterov_schedule_version = 1 ");
+  double grad[2];
+  if (st.eval(th, true, false, grad)) return -1;
+  if (!std::isfinite(st.negll))
+    return fail("%s occurred in initial approximate negative marginal log-likelihood. Possible solutions: try other initial values ('init_cov_pars')",
+                std::isnan(st.negll) ? "NaN" : "Inf");
+  double aux[2] = {th[0], th[1]}, aux_lag1[2] = {th[0], th[1]}, th_lag1[2];
+  int num_it = cfg.max_iter;
+  bool have_grad = true;
+  for (int it = 0; it < cfg.max_iter; ++it) {
+    const double negll_lag1 = st.negll;
+    th_lag1[0] = th[0]; th_lag1[1] = th[1];
+    if (!have_grad && st.grad_current(th, grad)) return -1;
+    const double max_lr = kMaxGradientUpdateLogScale / std::max(std::fabs(grad[0]), std::fabs(grad[1]));
+    if (lr_cov > max_lr) lr_cov = max_lr;
+    const double dir_deriv = -(grad[0] * grad[0] + grad[1] * grad[1]);
+    double mom_dir_deriv = 0.;
+    if (nesterov) mom_dir_deriv = grad[0] * (std::log(th[0]) - std::log(aux[0])) + grad[1] * (std::log(th[1]) - std::log(aux[1]));
+    double th_new[2], gnew[2];
+    double lr = lr_cov, acc = cfg.acc_rate_cov;
+    bool decrease_found = false, halving_done = false, new_grad = false;
+    for (int ih = 0; ih < kMaxNumberLrShrinkageSteps; ++ih) {
+      th_new[0] = std::exp(std::log(th[0]) - lr * grad[0]);
+      th_new[1] = std::exp(std::log(th[1]) - lr * grad[1]);
+      if (nesterov) {
+        aux[0] = th_new[0]; aux[1] = th_new[1];
+        const double mu = nesterov_schedule(it, cfg.nesterov_schedule_version, acc, cfg.momentum_offset);
+        th_new[0] = std::exp((mu + 1.) * std::log(aux[0]) - mu * std::log(aux_lag1[0]));       // momentum on the log-scale, all parameters
+        th_new[1] = std::exp((mu + 1.) * std::log(aux[1]) - mu * std::log(aux_lag1[1]));
+      }
+      new_grad = ih == 0;
+      if (st.eval(th_new, new_grad, it == 0, gnew)) return -1;
+      const double mu = nesterov ? nesterov_schedule(it, cfg.nesterov_schedule_version, acc, cfg.momentum_offset) : 0.;
+      if (st.negll <= negll_lag1 + kCArmijo * lr * dir_deriv + kCArmijoMom * mu * mom_dir_deriv) decrease_found = true;
+      if (decrease_found) break;
+      halving_done = true;
+      lr *= kLrShrinkageFactor;
+      acc *= 0.5;
+      if (st.reset_mode()) return -1;                                // the parameters are discarded, so is the mode found for them
+    }
+    if (halving_done) lr_cov = lr;
+    if (nesterov) { aux_lag1[0] = aux[0]; aux_lag1[1] = aux[1]; }
+    th[0] = th_new[0]; th[1] = th_new[1];
+    have_grad = decrease_found && new_grad;
+    if (have_grad) { grad[0] = gnew[0]; grad[1] = gnew[1]; }
+    if (cfg.trace)
+      fprintf(stderr, "[gpboost_amd] it %d: cov pars (transformed) %.10g %.10g negll %.10g lr %g\n", it + 1, th[0], th[1], st.negll, lr_cov);
+    if (!std::isfinite(st.negll) || !std::isfinite(th[0]) || !std::isfinite(th[1]))
+      return fail("NaN or Inf occurred in covariance parameter optimization using 'gradient_descent' (the reference restarts with "
+                  "'nelder_mead' here, which is not on the MI355X path); try a smaller learning rate or other initial values");
+    bool terminate = false;
+    if (cfg.convergence_criterion == "relative_change_in_parameters") {
+      const double d = std::sqrt((th[0] - th_lag1[0]) * (th[0] - th_lag1[0]) + (th[1] - th_lag1[1]) * (th[1] - th_lag1[1]));
+      terminate = d <= delta_rel_conv * std::sqrt(th_lag1[0] * th_lag1[0] + th_lag1[1] * th_lag1[1]);
+    } else {
+      terminate = (negll_lag1 - st.negll) <= delta_rel_conv * std::max(std::fabs(negll_lag1), 1.);
+    }
+    if (terminate) { num_it = it + 1; break; }
+  }
+  out->num_it = num_it;
+  return 0;
+}
+
+int run_lbfgs_laplace(LapState& st, const GpbOptimConfig& cfg, double th[2], GpbLaplaceOptimResult* out, const Fail& fail) {
+  const double delta = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-6;
+  const double initial_step_factor = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 1.;
+  const double epsilon = 1e-20, epsilon_rel = 1e-20, ftol = 1e-4;
+  const int max_linesearch = 20;
+  constexpr double eps = std::numeric_limits<double>::epsilon();
+  BfgsMat bfgs(cfg.m_lbfgs);
+  double x[2] = {std::log(th[0]), std::log(th[1])}, xp[2], grad[2], gradp[2], drt[2], thx[2];
+  auto at = [&](const double* xx) { thx[0] = std::exp(xx[0]); thx[1] = std::exp(xx[1]); };
+  at(x);
+  if (st.eval(thx, true, false, grad)) return -1;
+  double fx = st.negll;
+  if (!std::isfinite(fx))
+    return fail("%s occurred in initial approximate negative marginal log-likelihood. Possible solutions: try other initial values ('init_cov_pars')",
+                std::isnan(fx) ? "NaN" : "Inf");
+  double gnorm = std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]);
+  double fx_past = fx;
+  int k = 1;
+  if (!(gnorm <= epsilon || gnorm <= epsilon_rel * std::sqrt(x[0] * x[0] + x[1] * x[1]))) {
+    drt[0] = -grad[0]; drt[1] = -grad[1];
+    double step = initial_step_factor / std::sqrt(drt[0] * drt[0] + drt[1] * drt[1]);
+    for (;;) {
+      xp[0] = x[0]; xp[1] = x[1]; gradp[0] = grad[0]; gradp[1] = grad[1];
+      const double max_lr = kMaxGradientUpdateLogScale / std::max(std::fabs(drt[0]), std::fabs(drt[1]));
+      if (max_lr < step) step = max_lr;
+      bool grad_is_current = false;
+      {
+        if (step <= 0.) return fail("GPModel lbfgs: 'step' must be positive");
+        const double fx_init = fx, dg_init = grad[0] * drt[0] + grad[1] * drt[1];
+        if (dg_init > 0.) return fail("GPModel lbfgs: the moving direction increases the objective function value");
+        const double test_decr = ftol * dg_init;
+        double gtrial[2];
+        int iter;
+        for (iter = 0; iter < max_linesearch; ++iter) {
+          x[0] = xp[0] + step * drt[0]; x[1] = xp[1] + step * drt[1];
+          at(x);
+          if (st.eval(thx, iter == 0, false, gtrial)) return -1;    // first trial: gradient in the same evaluation (accepted most of the time)
+          fx = st.negll;
+          if (fx > fx_init + step * test_decr || (fx != fx)) {
+            if (fx != fx && st.reset_mode()) return -1;             // NaN: ResetLaplaceApproxModeToPreviousValue (optim_utils.h:405-407)
+            step *= ((fx - fx_init) > 2. * std::max(std::fabs(fx_init), 1.)) ? 0.5 / 16. : 0.5;
+          } else {
+            if (iter == 0) { grad[0] = gtrial[0]; grad[1] = gtrial[1]; grad_is_current = true; }
+            break;
+          }
+        }
+        if (iter >= max_linesearch) { x[0] = xp[0]; x[1] = xp[1]; fx = fx_init; step = 0.; }
+      }
+      at(x);
+      if (!grad_is_current && st.grad_current(thx, grad)) return -1;          // gradient of the CURRENT state (last trial's mode)
+      gnorm = std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]);
+      bool has_converged = gnorm <= epsilon || gnorm <= epsilon_rel * std::sqrt(x[0] * x[0] + x[1] * x[1]);
+      if ((fx_past - fx) <= delta * std::max(std::fabs(fx_past), 1.)) has_converged = true;
+      if (cfg.max_iter != 0 && k >= cfg.max_iter) has_converged = true;
+      if (cfg.trace)
+        fprintf(stderr, "[gpboost_amd] lbfgs it %d: var %.10g a %.10g negll %.10g step %g\n", k, std::exp(x[0]), std::exp(x[1]), fx, step);
+      if (has_converged) break;
+      const double sv[2] = {x[0] - xp[0], x[1] - xp[1]}, yv[2] = {grad[0] - gradp[0], grad[1] - gradp[1]};
+      if (sv[0] * yv[0] + sv[1] * yv[1] > eps * (yv[0] * yv[0] + yv[1] * yv[1])) bfgs.add_correction(sv, yv);
+      step = 1.;
+      bfgs.apply_Hv(grad, -1., drt);
+      fx_past = fx;
+      ++k;
+    }
+  }
+  if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
+    return fail("NaN or Inf occurred in covariance parameter optimization using 'lbfgs' (the reference restarts with 'nelder_mead' here, "
+                "which is not on the MI355X path); try other initial values");
+  th[0] = std::exp(x[0]); th[1] = std::exp(x[1]);
+  st.negll = fx;
+  out->num_it = k;
+  return 0;
+}
+
 }  // namespace
 
 int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_terms_fn fn, void* ctx, const double theta_init[3],
@@ -334,5 +502,28 @@ int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_
   out->negll = st.negll;
   out->num_ll_evals = st.n_ll;
   out->num_grad_evals = st.n_grad;
+  return 0;
+}
+
+int gpb_optimize_laplace_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fn fn, void* ctx, const double theta_init[2],
+                                  GpbLaplaceOptimResult* out, char* err, int errlen) {
+  const Fail fail{err, errlen};
+  if (err && errlen > 0) err[0] = 0;
+  if (!fn || !out || !theta_init) return fail("gpb_optimize_laplace_cov_pars: null argument");
+  if (!(theta_init[0] > 0.) || !(theta_init[1] > 0.))
+    return fail("Initial covariance parameters need to be positive (found %g, %g on the transformed scale)", theta_init[0], theta_init[1]);
+  LapState st{fn, ctx};
+  double th[2] = {theta_init[0], theta_init[1]};
+  *out = GpbLaplaceOptimResult();
+  if (cfg.max_iter > 0) {
+    int rc;
+    if (cfg.optimizer == "gradient_descent") rc = run_gradient_descent_laplace(st, cfg, th, out, fail);
+    else if (cfg.optimizer == "lbfgs") rc = run_lbfgs_laplace(st, cfg, th, out, fail);
+    else return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent')", cfg.optimizer.c_str());
+    if (rc) { if (!err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation"); return -1; }
+  }
+  out->theta[0] = th[0]; out->theta[1] = th[1];
+  out->negll = st.negll;
+  out->num_evals = st.n_evals;
   return 0;
 }

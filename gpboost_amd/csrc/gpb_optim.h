@@ -54,4 +54,24 @@ struct GpbOptimResult {
 int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_terms_fn fn, void* ctx, const double theta_init[3],
                                    GpbOptimResult* out, char* err, int errlen);
 
+// ---- non-Gaussian likelihoods (Laplace approximation): theta = (sigma1_2, a), no nugget, nothing profiled out ----
+// The approximate marginal likelihood is evaluated by mode finding that is WARM-STARTED from the previous evaluation's mode
+// (likelihoods.h:3790-3797), so the evaluator is stateful:
+//   op 0 / 1  find the mode at (var, a) starting from the current mode, return the negative approximate marginal log-likelihood in
+//             out3[0]; op 1 also returns its gradient wrt (log var, log a) in out3[1..2]
+//   op 2      gradient of the CURRENT state only (parameters and mode of the last op 0 / 1; no new mode finding)
+//   op 3      reset the mode to its value before the last mode finding (Likelihood::ResetModeToPreviousValue, likelihoods.h:997-1004)
+//   + 16      first_update: the reference divides cg_max_num_it(_tridiag) by 3 in the first gradient-descent update (likelihoods.h:3833-3836)
+typedef int (*gpb_laplace_fn)(void* ctx, int op, double var, double a, double* out3);
+
+struct GpbLaplaceOptimResult {
+  double theta[2];
+  int num_it = 0;
+  double negll = 0.;
+  int num_evals = 0;
+};
+
+int gpb_optimize_laplace_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fn fn, void* ctx, const double theta_init[2],
+                                  GpbLaplaceOptimResult* out, char* err, int errlen);
+
 #endif  // GPB_OPTIM_H_

@@ -160,6 +160,24 @@ def optim_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "optim_ref.npz"), **res)
 
 
+def optim_laplace_fixture(out_dir):
+    """The reference's own GPB_OptimCovPar for non-Gaussian Vecchia models (iterative methods, vadu): tests/cases.py:OPTIM_LAPLACE_CASES."""
+    res = {}
+    for name, oc in cases.OPTIM_LAPLACE_CASES.items():
+        c = cases.LAPLACE_CASES[oc["model"]]
+        coords, y = cases.make_count_data(c) if oc["lik"] == "poisson" else cases.make_binary_data(c)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=oc["lik"])
+        if oc["cfg"]:
+            mdl.set_optim_config(**oc["cfg"])
+        mdl.optim_cov_par(y)
+        res[name + "_cov_pars"] = mdl.get_cov_par(2)
+        res[name + "_init_cov_pars"] = mdl.get_init_cov_par()[:2].copy()
+        res[name + "_num_it"] = np.int32(mdl.get_num_it())
+        res[name + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        print("optim laplace", name, res[name + "_init_cov_pars"], "->", res[name + "_cov_pars"], res[name + "_num_it"], res[name + "_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "optim_laplace_ref.npz"), **res)
+
+
 def cluster_fixture(out_dir):
     """Reference nll of a model with several clusters (independent GP realisations), random Vecchia ordering: pins the cluster
     order (first appearance) and the ONE shared std::mt19937 that shuffles cluster after cluster."""
@@ -190,6 +208,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "optim_laplace":
+        optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":
         laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim":

@@ -203,6 +203,21 @@ OPTIM_CASES = {
 }
 
 
+# Parameter estimation for the non-Gaussian likelihoods (Vecchia-Laplace): LAPLACE_CASES entry, likelihood, optimiser settings.
+# Outputs of the reference's GPB_OptimCovPar: tests/golden/optim_laplace_ref.npz.  exact_it: the iteration count must match exactly
+# (otherwise +-2: a preconditioned CG that stops at |r| < 1e-2 sits inside every evaluation).
+OPTIM_LAPLACE_CASES = {
+    "logit_n1500_lbfgs": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", cfg=dict(), exact_it=True),
+    "logit_n1500_gd_nesterov": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", cfg=dict(optimizer_cov="gradient_descent"), exact_it=True),
+    "logit_n1500_gd_plain": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit",
+                                 cfg=dict(optimizer_cov="gradient_descent", use_nesterov_acc=False, lr_cov=0.05), exact_it=True),
+    "probit_n1500_lbfgs": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_probit", cfg=dict(), exact_it=True),
+    "poisson_n1500_lbfgs": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(), exact_it=True),
+    "poisson_n1500_gd_nesterov": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(optimizer_cov="gradient_descent"), exact_it=False),
+    "logit_u3d_n1200_lbfgs": dict(model="lap_u3d_n1200_mat25_m15", lik="bernoulli_logit", cfg=dict(), exact_it=True),
+}
+
+
 def optim_case(name):
     """-> (coords, y, cluster_ids | None, model dict, init_cov_pars | None, cfg dict)"""
     c = OPTIM_CASES[name]

@@ -44,3 +44,54 @@ def optimize(lib, n, init_theta, terms_cb, optimizer="lbfgs", lr_cov=-999., acc_
     if rc != 0:
         raise RuntimeError(lib.LGBM_GetLastError().decode())
     return out, nit.value, nll.value, ne
+
+
+LAPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double))
+
+
+class OracleLaplaceEvaluator(object):
+    """Stateful evaluator of the Laplace approximation for GPB_HIP_OptimizeLaplaceWithCallback with the oracle behind it: keeps the
+    mode (warm start), its previous value (op 3) and the gradient of the current state (op 2)."""
+
+    def __init__(self, orc, coords_ord, nn, cov_type, y_ord, likelihood, cg_max_num_it=1000, cg_max_num_it_tridiag=1000):
+        self.orc, self.co, self.nn, self.ct, self.y, self.lik = orc, coords_ord, nn, cov_type, y_ord, likelihood
+        self.cg, self.cgt = cg_max_num_it, cg_max_num_it_tridiag
+        self.mode = None; self.mode_prev = None; self.grad = None
+        self.calls = []
+        self.cb = LAPLACE_FN(self._fn)
+
+    def _fn(self, ctx, op, var, a, out3):
+        first_update = bool(op & 16); op &= 15
+        self.calls.append((op, first_update, var, a))
+        if op == 3:
+            self.mode = None if self.mode_prev is None else self.mode_prev.copy()
+            return 0
+        if op == 2:
+            out3[1], out3[2] = self.grad
+            return 0
+        div = 3.0 if first_update else 1.0
+        self.mode_prev = None if self.mode is None else self.mode.copy()
+        nll, g, mode = self.orc.vecchia_laplace_grad(self.co, self.nn, self.ct, var, a, self.y, likelihood=self.lik, mode_init=self.mode,
+                                                     want_mode=True, cg_max_num_it=int(round(self.cg / div)),
+                                                     cg_max_num_it_tridiag=int(round(self.cgt / div)))
+        if self.mode_prev is None:
+            self.mode_prev = np.zeros_like(mode)            # InitializeModeAvec: mode and its previous value start at 0
+        self.mode, self.grad = mode, (g[0], g[1])
+        out3[0], out3[1], out3[2] = nll, g[0], g[1]
+        return 0
+
+
+def optimize_laplace(lib, init_theta2, evaluator, optimizer="lbfgs", lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
+                     use_nesterov_acc=True, nesterov_schedule_version=-999, momentum_offset=-999, convergence_criterion="default", m_lbfgs=-999):
+    th0 = np.ascontiguousarray(init_theta2, dtype=np.float64)
+    out = np.empty(2); nit = C.c_int(0); nll = C.c_double(0); ne = C.c_int(0)
+    lib.GPB_HIP_OptimizeLaplaceWithCallback.argtypes = [
+        C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_bool, C.c_int, C.c_int, C.c_char_p, C.c_int, LAPLACE_FN,
+        C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.LGBM_GetLastError.restype = C.c_char_p
+    rc = lib.GPB_HIP_OptimizeLaplaceWithCallback(
+        th0.ctypes.data, optimizer.encode(), lr_cov, acc_rate_cov, max_iter, delta_rel_conv, use_nesterov_acc, nesterov_schedule_version,
+        momentum_offset, convergence_criterion.encode(), m_lbfgs, evaluator.cb, None, out.ctypes.data, C.byref(nit), C.byref(nll), C.byref(ne))
+    if rc != 0:
+        raise RuntimeError(lib.LGBM_GetLastError().decode())
+    return out, nit.value, nll.value, ne.value
