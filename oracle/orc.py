@@ -283,7 +283,7 @@ def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, se
 
 def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000, cg_max_num_it_tridiag=1000,
                          cg_delta_conv=1e-2, delta_conv_mode=1e-8, likelihood="bernoulli_logit", fixed_effects=None, mode_init=None,
-                         want_mode=False):
+                         want_mode=False, want_parts=False):
     """(negll, gradient of negll wrt (log sigma1^2, log a)) of the Vecchia-Laplace approximation, iterative methods, 'vadu'
     (orc_vecchia_laplace_grad: round-2 groundwork, no device path consumes it yet).  mode_init: start Newton's method there (the
     warm start of the reference's optimiser); want_mode: also return the mode found."""
@@ -296,13 +296,17 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     out = np.empty(6); g = np.empty(2)
     mode = np.zeros(n) if mode_init is None else np.ascontiguousarray(mode_init, dtype=np.float64).copy()
+    dbg = np.zeros(2 * n + 8) if want_parts else None
     rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double),
                                         _p(nn, C.c_int), C.c_int(n), C.c_int(m), _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double),
                                         _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
                                         C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double),
-                                        _p(mode, C.c_double), C.c_int(0 if mode_init is None else 1))
+                                        _p(mode, C.c_double), C.c_int(0 if mode_init is None else 1), None if dbg is None else _p(dbg, C.c_double))
     if rc != 0:
         raise RuntimeError("orc_vecchia_laplace_grad failed")
+    if want_parts:      # intermediate values for device parity tests
+        parts = dict(dlogdet_dmode=dbg[:n].copy(), implicit_solve=dbg[n:2 * n].copy(), per_par=dbg[2 * n:].reshape(2, 4).copy(), mode=mode)
+        return -out[0], g, parts
     return (-out[0], g, mode) if want_mode else (-out[0], g)
 
 
