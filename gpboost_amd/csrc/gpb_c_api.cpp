@@ -67,6 +67,8 @@ struct REModelHip {
   double cg_delta_conv = 1e-2, delta_conv_mode_finding = 1e-8;
   std::vector<int> labels;      // y in {0,1}, Vecchia order
   double lap_info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool lap_fit_first_eval = true;
+  GpbLaplaceOptimResult last_fit_lap;
   // parameter estimation (REModel members of re_model.h: cov_pars_, init_cov_pars_, num_it_; all on the TRANSFORMED scale)
   std::mt19937 rng;             // rng_ of the reference: orderings first, then the sub-sample of FindInitCovPar
   std::vector<double> coords0;  // coordinates of the first cluster in Vecchia order, column-major (for FindInitCovPar)
@@ -115,6 +117,59 @@ int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr
   tr[1] = sigma1_2 / sigma2;
   const double c = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
   tr[2] = c / rho;
+  return 0;
+}
+
+// response (validated against the likelihood) and fixed effects of the Vecchia-Laplace path, Vecchia order
+int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
+  if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
+  mdl->labels.resize(mdl->n);
+  const bool poisson = mdl->likelihood == "poisson";
+  for (int k = 0; k < mdl->n; ++k) {
+    const double yk = y_data[mdl->perm[k]];
+    if (poisson) {                                        // likelihoods.h:1338-1350
+      double intpart;
+      if (yk < 0.) return set_error(" Must have y >= 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
+      if (std::modf(yk, &intpart) != 0.0) return set_error("Found non-integer response variable ('y'). Response variable can only be integer valued for likelihood = '%s' ", mdl->likelihood.c_str());
+      if (yk > 2147483647.) return set_error("response %g is too large for likelihood = '%s'", yk, mdl->likelihood.c_str());
+      mdl->labels[k] = (int)yk;
+      continue;
+    }
+    if (std::fabs(yk) >= 1e-10 && !near(yk, 1.))       // likelihoods.h:1321-1329
+      return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
+    mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
+  }
+  if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : (poisson ? 2 : 0))) return shim_error();
+  if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
+  if (fixed_effects) {                                  // location parameter = mode + fixed effects, Vecchia order
+    std::vector<double> fe(mdl->n);
+    for (int k = 0; k < mdl->n; ++k) fe[k] = fixed_effects[mdl->perm[k]];
+    if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, fe.data())) return shim_error();
+  } else if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, nullptr)) return shim_error();
+  return 0;
+}
+
+// gpb_laplace_fn (gpb_optim.h) on the device: the stateful evaluator behind GPB_OptimCovPar for non-Gaussian likelihoods.  The mode stays
+// in HBM between evaluations (warm start, likelihoods.h:3790-3797); 3 doubles cross PCIe per evaluation.
+int device_laplace(void* ctx, int op_in, double var, double a, double* out3) {
+  auto* mdl = static_cast<REModelHip*>(ctx);
+  const bool first_update = (op_in & 16) != 0;
+  const int op = op_in & 15;
+  if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
+  // first gradient-descent update: cg_max_num_it(_tridiag) / 3 (likelihoods.h:3833-3836)
+  const int cg = first_update ? (int)std::round(mdl->cg_max_num_it / 3.) : mdl->cg_max_num_it;
+  const int cgt = first_update ? (int)std::round(mdl->cg_max_num_it_tridiag / 3.) : mdl->cg_max_num_it_tridiag;
+  if (op == 0 || op == 1) {
+    const int reset = mdl->lap_fit_first_eval ? 1 : 0;        // the fit starts from mode 0 (InitializeModeAvec), then warm-starts
+    if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(cg, 1),
+                                     std::max(cgt, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
+    mdl->lap_fit_first_eval = false;
+    out3[0] = -mdl->lap_info[0];
+    if (op == 0) return 0;
+  }
+  double g2[2];
+  if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(cg, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
+  out3[1] = g2[0]; out3[2] = g2[1];
   return 0;
 }
 
@@ -378,13 +433,20 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   mdl->trace = trace;
   // REModel::SetOptimConfig (re_model.cpp:301-318): initial values are kept on the transformed scale
   if (init_cov_pars) {
-    if (mdl->likelihood != "gaussian") return set_error("GPB_SetOptimConfig: init_cov_pars for likelihood '%s' (no parameter estimation for it on the MI355X path yet)", mdl->likelihood.c_str());
+    if (mdl->likelihood != "gaussian") {        // (sigma1_2, rho) -> (sigma1_2, a): no error variance (re_model.cpp:301-318 with gauss_likelihood_ = false)
+      if (!(init_cov_pars[0] > 0.) || !(init_cov_pars[1] > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", init_cov_pars[0], init_cov_pars[1]);
+      mdl->init_cov_pars_tr[0] = init_cov_pars[0]; mdl->init_cov_pars_tr[1] = range_const(mdl) / init_cov_pars[1]; mdl->init_cov_pars_tr[2] = 0.;
+      std::copy(mdl->init_cov_pars_tr, mdl->init_cov_pars_tr + 3, mdl->cov_pars_tr);
+      mdl->cov_pars_initialized = true;
+      mdl->init_cov_pars_provided = true;
+    } else {
     double tr[3];
     if (transform_cov_pars(mdl, init_cov_pars, tr)) return -1;
     std::copy(tr, tr + 3, mdl->init_cov_pars_tr);
     std::copy(tr, tr + 3, mdl->cov_pars_tr);
     mdl->cov_pars_initialized = true;
     mdl->init_cov_pars_provided = true;
+    }
   }
   // REModelTemplate::SetOptimConfig (re_model_template.h:743-960); -999 = keep the default
   GpbOptimConfig& oc = mdl->optim;
@@ -446,29 +508,7 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
-    mdl->labels.resize(mdl->n);
-    const bool poisson = mdl->likelihood == "poisson";
-    for (int k = 0; k < mdl->n; ++k) {
-      const double yk = y_data[mdl->perm[k]];
-      if (poisson) {                                        // likelihoods.h:1338-1350
-        double intpart;
-        if (yk < 0.) return set_error(" Must have y >= 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
-        if (std::modf(yk, &intpart) != 0.0) return set_error("Found non-integer response variable ('y'). Response variable can only be integer valued for likelihood = '%s' ", mdl->likelihood.c_str());
-        if (yk > 2147483647.) return set_error("response %g is too large for likelihood = '%s'", yk, mdl->likelihood.c_str());
-        mdl->labels[k] = (int)yk;
-        continue;
-      }
-      if (std::fabs(yk) >= 1e-10 && !near(yk, 1.))       // likelihoods.h:1321-1329
-        return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
-      mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
-    }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : (poisson ? 2 : 0))) return shim_error();
-    if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
-    if (fixed_effects) {                                  // location parameter = mode + fixed effects, Vecchia order
-      std::vector<double> fe(mdl->n);
-      for (int k = 0; k < mdl->n; ++k) fe[k] = fixed_effects[mdl->perm[k]];
-      if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, fe.data())) return shim_error();
-    } else if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, nullptr)) return shim_error();
+    if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
                                       mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,
@@ -506,7 +546,27 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl) return set_error("GPB_OptimCovPar: null handle");
   const char* scope = "is not on the MI355X path of this library yet (parameter estimation: Gaussian likelihood, gp_approx 'vecchia')";
-  if (mdl->likelihood != "gaussian") return set_error("GPB_OptimCovPar: likelihood '%s' %s", mdl->likelihood.c_str(), scope);
+  if (mdl->likelihood != "gaussian") {     // theta = (sigma1_2, a), Laplace approximation + its gradient on the device (gpb_optim.h: gpb_laplace_fn)
+    if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
+    if (!mdl->init_cov_pars_provided) return set_error("GPB_OptimCovPar: likelihood '%s' needs init_cov_pars (the initial-value heuristics for non-Gaussian likelihoods are not on the MI355X path of this library yet)", mdl->likelihood.c_str());
+    if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
+    std::copy(mdl->init_cov_pars_tr, mdl->init_cov_pars_tr + 3, mdl->cov_pars_tr);
+    mdl->lap_fit_first_eval = true;
+    GpbOptimConfig cfg = mdl->optim;
+    cfg.range_const = range_const(mdl);
+    char err[512] = "";
+    GpbLaplaceOptimResult res;
+    if (gpb_optimize_laplace_cov_pars(cfg, device_laplace, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err)))
+      return err[0] ? set_error("%s", err) : shim_error();
+    if (cfg.max_iter > 0) {
+      mdl->cov_pars_tr[0] = res.theta[0]; mdl->cov_pars_tr[1] = res.theta[1];
+      mdl->cur_negll = res.negll;
+      mdl->negll_valid = true;
+    }
+    mdl->num_it = res.num_it;
+    mdl->last_fit_lap = res;
+    return 0;
+  }
   if (mdl->eh) return set_error("GPB_OptimCovPar: gp_approx 'none' %s", scope);
   if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
   if (!y_data) return set_error("GPB_OptimCovPar: y_data is NULL");
@@ -534,7 +594,12 @@ int GPB_GetCovPar(REModelHandle handle, double* optim_cov_pars, bool calc_std_de
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !optim_cov_pars) return set_error("GPB_GetCovPar: null argument");
-  if (mdl->likelihood != "gaussian" || !mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or correctly set ");   // re_model.cpp:922-924
+  if (!mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or correctly set ");   // re_model.cpp:922-924
+  if (mdl->likelihood != "gaussian") {     // two parameters: (sigma1_2, rho)
+    if (calc_std_dev) return set_error("GPB_GetCovPar: standard deviations are not on the MI355X path of this library yet");
+    optim_cov_pars[0] = mdl->cov_pars_tr[0]; optim_cov_pars[1] = range_const(mdl) / mdl->cov_pars_tr[1];
+    return 0;
+  }
   if (calc_std_dev) return set_error("GPB_GetCovPar: standard deviations (Fisher information, re_model_template.h:10137) are not on the MI355X path of this library yet");
   transform_back(mdl, mdl->cov_pars_tr, optim_cov_pars);
   C_API_END();
@@ -544,7 +609,12 @@ int GPB_GetInitCovPar(REModelHandle handle, double* init_cov_pars) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !init_cov_pars) return set_error("GPB_GetInitCovPar: null argument");
-  if (mdl->likelihood != "gaussian" || !(mdl->cov_pars_initialized || mdl->init_cov_pars_provided)) {
+  if (mdl->likelihood != "gaussian") {
+    if (!mdl->init_cov_pars_provided) { init_cov_pars[0] = -1.; init_cov_pars[1] = -1.; return 0; }
+    init_cov_pars[0] = mdl->init_cov_pars_tr[0]; init_cov_pars[1] = range_const(mdl) / mdl->init_cov_pars_tr[1];
+    return 0;
+  }
+  if (!(mdl->cov_pars_initialized || mdl->init_cov_pars_provided)) {
     for (int j = 0; j < 3; ++j) init_cov_pars[j] = -1.;   // re_model.cpp GetInitCovPar: -1 if not available
     return 0;
   }

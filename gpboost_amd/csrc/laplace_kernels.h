@@ -43,5 +43,13 @@ hipError_t lap_lincomb(double* out, const double* x, const double* y, double cx,
 hipError_t lap_scale_probes(const double* rv, const double* dw, int n, int ncol, int nc, double* out, hipStream_t st);
 hipError_t lap_logsums(const double* D, const double* dw, int n, double* out2, hipStream_t st);
 hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStream_t st);
+// ---- gradient of the approximate marginal likelihood (block vectors: ncol chunks of nc columns, as above) ----
+hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st);
+hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st);
+hipError_t lap_mul(const LapTri& T, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);       // plain product with T's entries
+hipError_t lap_row_stats(const double* U, const double* PIZ, const double* BPIZ, const double* dW3, const double* rdw, int n, int t, int nc, double* dld, hipStream_t st);
+hipError_t lap_coldots(const double* X, const double* Y, const double* T, int n, int ncol, int nc, double* out, hipStream_t st);
+hipError_t lap_deriv_mid(const double* R, const double* Z, const double* D, const double* dD, const double* W, int n, int ncol, int nc, int sel, double* H, double* V, hipStream_t st);
+hipError_t lap_sums3(const double* rdw, const double* D, const double* dD, int n, double* out3, hipStream_t st);
 
 }  // namespace gpb

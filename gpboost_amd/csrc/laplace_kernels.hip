@@ -501,6 +501,8 @@ __global__ __launch_bounds__(kTriThreads) void lap_sptrsv_kernel(LapTri T, const
 // Row-parallel products with the same level-ordered storage: 16 lanes per row (the group of a row's first slot walks all its
 // slots), 16 slots per workgroup.
 //   MODE 0: out = B x      MODE 1: out = D^-1 B x      MODE 2: out = B^T x + W .* h  (W may be NULL)
+//   MODE 3: out = the plain product with the stored entries, no identity part: with the entries of dA/dtheta this is (dA) x (T = fwd
+//           layout) or (dA)^T x (T = bwd layout) -- the B_grad = -dA products of the Laplace gradient
 // (B x)_i = x_i - sum_j A_ij x[nn_ij] with T = fwd;  (B^T x)_j = x_j - sum_{i : j in N(i)} A_ij x_i with T = bwd.
 template <int MODE, int NC>
 __global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, const double* __restrict__ x, const double* __restrict__ D,
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, cons
     VecN<NC> o;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      double v = xr.v[c] - tot[c];
+      double v = (MODE == 3) ? tot[c] : xr.v[c] - tot[c];
       if (MODE == 1) v *= 1.0 / D[row];
       if (MODE == 2 && W) v = __builtin_fma(W[row], hr.v[c], v);
       o.v[c] = v;
@@ -565,14 +567,6 @@ __global__ void lap_permute_factor_kernel(const double* __restrict__ A, const in
 __global__ void lap_scatter_kernel(const double* __restrict__ in, const int* __restrict__ sigma, int n, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[sigma[i]] = in[i];
-}
-
-// once per evaluation: the factor's A in the level-ordered head / overflow layout of a solve
-__global__ void lap_permute_factor_kernel(const double* __restrict__ A, const int* __restrict__ hpos, const int* __restrict__ opos, size_t nh,
-                                          size_t novf, double* __restrict__ hval, double* __restrict__ oval) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < nh) { const int pos = hpos[g]; hval[g] = pos >= 0 ? A[pos] : 0.0; }
-  if (g < novf) oval[g] = A[opos[g]];
 }
 
 // misc elementwise
@@ -602,6 +596,191 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
   for (int i = threadIdx.x; i < n; i += 1024) { a = __builtin_fma(x[i], y[i], a); b += fabs(x[i]); }
   block_reduce2(a, b, s);
   if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
+}
+
+
+// ---- gradient of the Laplace approximation (likelihoods.h:6521-6700; oracle/gpb_oracle.c: orc_vecchia_laplace_grad) ---------------
+// third derivative of the log-likelihood = d information / d location parameter (CalcFirstDerivInformationLocPar, likelihoods.h:13772-13800)
+template <int LINK>
+__device__ __forceinline__ double lik_third(int y, double x) {
+  if constexpr (LINK == 0) { const double p = sigmoid_stable(x); return -p * (1.0 - p) * (2.0 * p - 1.0); }
+  else if constexpr (LINK == 2) return exp(x);
+  else {
+    const double x2 = x * x;
+    if (y == 0) { const double q = inv_mills_phi(-x); return -q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)); }
+    const double r = inv_mills_phi(x);
+    return -r * (x2 - 1.0 + r * (3.0 * x + 2.0 * r));
+  }
+}
+template <int LINK>
+__global__ void lik_third_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, int n, double* __restrict__ dW3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dW3[i] = lik_third<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i]);
+}
+
+// dA_i / d log(a) and dD_i / d log(a) of the Vecchia factor WITHOUT nugget (Vecchia_utils.cpp:1640-1652; the range parameter is the only
+// one whose derivative of A is not zero): one wavefront per point, C_nn in LDS, lane = row.
+//   t = dc - dC A_i,  dA_i = C^-1 t (Cholesky of the jittered C_nn),  dD_i = -(dA_i . c + A_i . dc)
+// Covariance and its range derivative on the transformed scale: cov_fcts.h:2100-2118, :2535-2554.  Once per gradient evaluation --
+// the block CG around it is what the time goes to -- so this is the plain formulation, not the register-blocked one of vecchia_kernels.hip.
+namespace {
+__device__ __forceinline__ double cov_plain(int cov, double d, double var, double a) {
+  const double r = a * d;
+  if (cov == 0) return var * exp(-r);
+  if (cov == 1) return var * (1.0 + r) * exp(-r);
+  return var * (1.0 + r + r * r / 3.0) * exp(-r);
+}
+__device__ __forceinline__ double dcov_dlog_range_plain(int cov, double d, double var, double a) {
+  if (cov == 0) return -a * d * var * exp(-a * d);
+  const double cm = -var * a * a;
+  if (cov == 1) return cm * d * d * exp(-a * d);
+  const double r = a * d;
+  return cm / 3.0 * d * d * (1.0 + r) * exp(-r);
+}
+}  // namespace
+constexpr int kDerivLd = 63;      // leading dimension of the LDS matrix (odd: rows of one column fall into different banks)
+__global__ __launch_bounds__(64) void lap_range_deriv_kernel(const double4* __restrict__ pts, const int* __restrict__ nn, const double* __restrict__ A, int n, int m,
+                                                             int cov, int d3, double var, double a, double* __restrict__ dA, double* __restrict__ dD) {
+  __shared__ double C[62 * kDerivLd];
+  __shared__ double px[64], py[64], pz[64], Ai[64], tv[64], cv[64], dcv[64];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int idx = lane < m ? nn[(size_t)i * m + lane] : -1;
+  const int k = __popcll(__ballot(idx >= 0));                 // the valid neighbours are a prefix of the row
+  const double4 ctr = pts[i];
+  double ox = 0.0, oy = 0.0, oz = 0.0, ai = 0.0;
+  if (lane < k) {
+    const double4 q = pts[idx];
+    ox = q.x - ctr.x; oy = q.y - ctr.y; oz = d3 ? q.z - ctr.z : 0.0;
+    ai = A[(size_t)i * m + lane];
+  }
+  px[lane] = ox; py[lane] = oy; pz[lane] = oz; Ai[lane] = ai;
+  __syncthreads();
+  if (k == 0) {
+    if (lane < m) dA[(size_t)i * m + lane] = 0.0;
+    if (lane == 0) dD[i] = 0.0;
+    return;
+  }
+  if (lane < k) {
+    const int r = lane;
+    const double di = sqrt(ox * ox + oy * oy + oz * oz);
+    const double dcr = dcov_dlog_range_plain(cov, di, var, a);
+    double tr = dcr;
+    for (int q = 0; q < k; ++q) {
+      if (q == r) continue;
+      const double ex = ox - px[q], ey = oy - py[q], ez = oz - pz[q];
+      const double dq = sqrt(ex * ex + ey * ey + ez * ez);
+      tr -= dcov_dlog_range_plain(cov, dq, var, a) * Ai[q];
+      if (q < r) C[r * kDerivLd + q] = cov_plain(cov, dq, var, a);
+    }
+    C[r * kDerivLd + r] = var * (1.0 + 1e-10);                 // Vecchia_utils.cpp:1608
+    tv[r] = tr; cv[r] = cov_plain(cov, di, var, a); dcv[r] = dcr;
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {                                // right-looking Cholesky, lower, in place
+    if (lane == j) C[j * kDerivLd + j] = sqrt(C[j * kDerivLd + j]);
+    __syncthreads();
+    if (lane > j && lane < k) C[lane * kDerivLd + j] /= C[j * kDerivLd + j];
+    __syncthreads();
+    if (lane > j && lane < k) {
+      const double lj = C[lane * kDerivLd + j];
+      for (int c = j + 1; c <= lane; ++c) C[lane * kDerivLd + c] -= lj * C[c * kDerivLd + j];
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < k; ++j) {                                // L z = t (in tv)
+    if (lane == j) tv[j] /= C[j * kDerivLd + j];
+    __syncthreads();
+    if (lane > j && lane < k) tv[lane] -= C[lane * kDerivLd + j] * tv[j];
+    __syncthreads();
+  }
+  for (int j = k - 1; j >= 0; --j) {                           // L^T x = z
+    if (lane == j) tv[j] /= C[j * kDerivLd + j];
+    __syncthreads();
+    if (lane < j) tv[lane] -= C[j * kDerivLd + lane] * tv[j];
+    __syncthreads();
+  }
+  const double xr = lane < k ? tv[lane] : 0.0;
+  if (lane < m) dA[(size_t)i * m + lane] = xr;
+  double part = lane < k ? xr * cv[lane] + Ai[lane] * dcv[lane] : 0.0;
+  __syncthreads();
+  tv[lane] = part;
+  __syncthreads();
+  if (lane == 0) {
+    double sacc = 0.0;
+    for (int r = 0; r < k; ++r) sacc += tv[r];
+    dD[i] = -sacc;
+  }
+}
+
+// d log|Sigma W + I| / d mode_i with the per-row control variate of the vadu preconditioner (CalcLogDetStochDerivModeVecchia,
+// likelihoods.h:16660-16688; CalcOptimalCVectorized, CG_utils.cpp:1070-1090).  Block vectors in the chunk layout [chunk][row][nc].
+__global__ void lap_row_stats_kernel(const double* __restrict__ U, const double* __restrict__ PIZ, const double* __restrict__ BPIZ, const double* __restrict__ dW3,
+                                     const double* __restrict__ rdw, int n, int t, int nc, double* __restrict__ dld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d3 = dW3[i];
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < t; ++c) {
+    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
+    s1 += U[o] * d3 * PIZ[o];
+    s2 += BPIZ[o] * d3 * BPIZ[o];
+  }
+  const double tr1 = s1 / t, trP = s2 / t;
+  double cv = 0.0, vr = 0.0;
+  for (int c = 0; c < t; ++c) {
+    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
+    const double a1 = U[o] * d3 * PIZ[o] - tr1;
+    const double b1 = BPIZ[o] * d3 * BPIZ[o] - trP;
+    cv += a1 * b1; vr += b1 * b1;
+  }
+  cv /= t; vr /= t;
+  const double copt = (vr == 0.0) ? 1.0 : cv / vr;
+  dld[i] = tr1 + copt * (rdw[i] * d3) - copt * trP;
+}
+
+// per column c of a block: out[c] = X(:, c) . T(:, c), out[ncols + c] = Y(:, c) . T(:, c); one workgroup per chunk, fixed order
+template <int NC>
+__global__ __launch_bounds__(1024) void lap_coldots_kernel(const double* __restrict__ X, const double* __restrict__ Y, const double* __restrict__ T, int n,
+                                                           int ncols, double* __restrict__ out) {
+  __shared__ double s[2048];
+  const size_t off = (size_t)blockIdx.x * n * NC;
+  double ax[NC], ay[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { ax[c] = 0.0; ay[c] = 0.0; }
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const VecN<NC> x = ldvec<NC>(X + off, i), y = ldvec<NC>(Y + off, i), tt = ldvec<NC>(T + off, i);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ax[c] = __builtin_fma(x.v[c], tt.v[c], ax[c]); ay[c] = __builtin_fma(y.v[c], tt.v[c], ay[c]); }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    block_reduce2(ax[c], ay[c], s);
+    if (threadIdx.x == 0) { out[blockIdx.x * NC + c] = ax[c]; out[ncols + blockIdx.x * NC + c] = ay[c]; }
+  }
+}
+
+// the diagonal scalings between the products of SigmaI_deriv / P_deriv (likelihoods.h:6613-6640, :16760-16775), R = B v, Z = (dA) v:
+//   sel 0: H = -R / D                                     (variance: SigmaI_deriv = -Sigma^-1)
+//   sel 1: H = -Z / D - R dD / D^2,  V = R / D            (range:  B^T H - (dA)^T V = SigmaI_deriv v)
+//   sel 2: H = -W Z,                 V = W R              (range:  B^T H - (dA)^T V = the extra part of P_deriv v)
+__global__ void lap_deriv_mid_kernel(const double* __restrict__ R, const double* __restrict__ Z, const double* __restrict__ D, const double* __restrict__ dD,
+                                     const double* __restrict__ W, int n, int nc, int sel, double* __restrict__ H, double* __restrict__ V) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const size_t o = (size_t)blockIdx.y * n * nc + g;
+  const int i = (int)(g / nc);
+  if (sel == 0) H[o] = -R[o] / D[i];
+  else if (sel == 1) { H[o] = -Z[o] / D[i] - R[o] * dD[i] / (D[i] * D[i]); V[o] = R[o] / D[i]; }
+  else { H[o] = -W[i] * Z[o]; V[o] = W[i] * R[o]; }
+}
+// out3 = { sum rdw / D, sum rdw dD / D^2, sum dD / D }  (the deterministic traces of the control variates and of d log|Sigma|)
+__global__ __launch_bounds__(1024) void lap_sums3_kernel(const double* __restrict__ rdw, const double* __restrict__ D, const double* __restrict__ dD, int n, double* __restrict__ out3) {
+  __shared__ double s[2048];
+  double a = 0.0, b = 0.0, c = 0.0, z = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { a += rdw[i] / D[i]; b += rdw[i] * dD[i] / (D[i] * D[i]); c += dD[i] / D[i]; }
+  block_reduce2(a, b, s);
+  block_reduce2(c, z, s);
+  if (threadIdx.x == 0) { out3[0] = a; out3[1] = b; out3[2] = c; }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
@@ -704,6 +883,38 @@ hipError_t lap_logsums(const double* D, const double* dw, int n, double* out2, h
 }
 hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStream_t st) {
   hipLaunchKernelGGL(lap_dot_kernel, dim3(1), dim3(1024), 0, st, x, y, n, out2);
+  return hipGetLastError();
+}
+
+hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_third_kernel<0>, GRID1(n), 0, st, mode, y, fe, n, dW3);
+  else if (link == 1) hipLaunchKernelGGL(lik_third_kernel<1>, GRID1(n), 0, st, mode, y, fe, n, dW3);
+  else hipLaunchKernelGGL(lik_third_kernel<2>, GRID1(n), 0, st, mode, y, fe, n, dW3);
+  return hipGetLastError();
+}
+hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st) {
+  hipLaunchKernelGGL(lap_range_deriv_kernel, dim3(n), dim3(64), 0, st, pts, nn, A, n, m, cov, d3, var, a, dA, dD);
+  return hipGetLastError();
+}
+hipError_t lap_mul(const LapTri& T, int n, const double* x, double* out, int ncol, int nc, hipStream_t st) {
+  LAP_SPMV(3, T, x, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, out);
+  return hipGetLastError();
+}
+hipError_t lap_row_stats(const double* U, const double* PIZ, const double* BPIZ, const double* dW3, const double* rdw, int n, int t, int nc, double* dld, hipStream_t st) {
+  hipLaunchKernelGGL(lap_row_stats_kernel, GRID1(n), 0, st, U, PIZ, BPIZ, dW3, rdw, n, t, nc, dld);
+  return hipGetLastError();
+}
+hipError_t lap_coldots(const double* X, const double* Y, const double* T, int n, int ncol, int nc, double* out, hipStream_t st) {
+  if (nc == 4) hipLaunchKernelGGL(lap_coldots_kernel<4>, dim3(ncol), dim3(1024), 0, st, X, Y, T, n, ncol * nc, out);
+  else hipLaunchKernelGGL(lap_coldots_kernel<1>, dim3(ncol), dim3(1024), 0, st, X, Y, T, n, ncol * nc, out);
+  return hipGetLastError();
+}
+hipError_t lap_deriv_mid(const double* R, const double* Z, const double* D, const double* dD, const double* W, int n, int ncol, int nc, int sel, double* H, double* V, hipStream_t st) {
+  hipLaunchKernelGGL(lap_deriv_mid_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, R, Z, D, dD, W, n, nc, sel, H, V);
+  return hipGetLastError();
+}
+hipError_t lap_sums3(const double* rdw, const double* D, const double* dD, int n, double* out3, hipStream_t st) {
+  hipLaunchKernelGGL(lap_sums3_kernel, dim3(1), dim3(1024), 0, st, rdw, D, dD, n, out3);
   return hipGetLastError();
 }
 

@@ -193,6 +193,32 @@ class VecchiaState(object):
         return -o[0], dict(newton_it=int(o[1]), cg_it=int(o[2]), log_det=o[3], lanczos_it=int(o[4]), mll_no_det=o[5],
                            ms_factor=o[6], ms_mode=o[7], ms_logdet=o[8], mode=mode)
 
+    def laplace_eval_grad(self, cov_type, var, a, num_rand_vec=50, seed_rand_vec=1, cg_max_num_it=1000, cg_max_num_it_tridiag=1000,
+                          cg_delta_conv=1e-2, delta_conv_mode_finding=1e-8, reset_mode=True, want_parts=False):
+        """-> (negll, grad wrt (log var, log a)[, parts]): Vecchia-Laplace approximation and its gradient on the device
+        (gpb_hip_vecchia_laplace_eval + gpb_hip_vecchia_laplace_grad_current)."""
+        o = np.empty(9)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_eval(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), C.c_int(num_rand_vec),
+                                                       C.c_int(seed_rand_vec), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
+                                                       C.c_double(cg_delta_conv), C.c_double(delta_conv_mode_finding),
+                                                       C.c_int(1 if reset_mode else 0), C.c_int(1), _p(o), None))
+        g = np.empty(2)
+        parts = np.empty(8) if want_parts else None
+        vecs = np.empty(2 * self.n) if want_parts else None
+        _shim_call(_lib().gpb_hip_vecchia_laplace_grad_current(self.h, C.c_int(cg_max_num_it), C.c_double(cg_delta_conv), _p(g), _p(parts), _p(vecs)))
+        if want_parts:
+            return -o[0], g, dict(per_par=parts.reshape(2, 4), dlogdet_dmode=vecs[:self.n], implicit_solve=vecs[self.n:])
+        return -o[0], g
+
+    def laplace_reset_mode_to_previous(self):
+        _shim_call(_lib().gpb_hip_vecchia_laplace_reset_mode_to_previous(self.h))
+
+    def laplace_range_deriv(self, cov_type, var, a):
+        """-> (dA / d log a [n, m], dD / d log a [n]) of the factor without nugget (test seam, gpb_hip_vecchia_laplace_range_deriv)."""
+        dA = np.empty((self.n, self.m)); dD = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_range_deriv(self.h, C.c_int(cov_type), C.c_double(var), C.c_double(a), _p(dA), _p(dD)))
+        return dA, dD
+
     def yaux_partial_dev(self, w_dev_ptr):
         """This shard's contribution to y_aux as a full n-vector on the device (sum over ranks = y_aux)."""
         _shim_call(_lib().gpb_hip_vecchia_yaux_partial_dev(self.h, C.c_void_p(int(w_dev_ptr))))

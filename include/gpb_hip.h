@@ -216,6 +216,29 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov_t
                                                  double cg_delta_conv, double delta_conv_mode_finding, int reset_mode,
                                                  double* out9_host, double* mode_host);
 
+/* Gradient of the NEGATIVE approximate marginal log-likelihood wrt (log sigma_1^2, log a) -- what the covariance-parameter optimiser
+ * needs for non-Gaussian data.  Replaces
+ *   Likelihood::CalcGradNegMargLikelihoodLaplaceApproxVecchia   include/GPBoost/likelihoods.h:6521-6700 (iterative methods, "vadu")
+ *   CalcLogDetStochDerivModeVecchia / CalcLogDetStochDerivCovParVecchia   :16636-16690, :16706-16790
+ *   CalcOptimalC / CalcOptimalCVectorized                       src/GPBoost/CG_utils.cpp:1053-1090
+ *   eval          = gpb_hip_vecchia_laplace_logit plus keep_grad_state: the log-determinant's block CG also accumulates
+ *                   U = (Sigma^-1 + W)^-1 Z (CG_utils.cpp:173) and P^-1 Z is kept, so that the gradient can follow
+ *   grad_current  gradient at the state the last eval(keep_grad_state = 1) left; cg_* as in GPB_SetOptimConfig (one more preconditioned CG
+ *                 solve for the implicit derivative).  parts8_host (optional): per parameter { mode' SigmaI_deriv mode, d logdet / d theta,
+ *                 optimal c, implicit part }; vecs2n_host (optional, Vecchia order): d logdet / d mode, (Sigma^-1 + W)^-1 d_mll_d_mode
+ *   reset_mode_to_previous   Likelihood::ResetModeToPreviousValue (likelihoods.h:997-1004): the mode goes back to its value before the
+ *                 last mode finding (rejected optimiser steps)
+ *   range_deriv   test seam: dA / d log a (n x m) and dD / d log a (n) of the factor without nugget (Vecchia_utils.cpp:1640-1652) */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_eval(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int num_rand_vec,
+                                                int seed_rand_vec, int cg_max_num_it, int cg_max_num_it_tridiag, double cg_delta_conv,
+                                                double delta_conv_mode_finding, int reset_mode, int keep_grad_state,
+                                                double* out9_host, double* mode_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_current(gpb_hip_vecchia_t* h, int cg_max_num_it, double cg_delta_conv,
+                                                        double* grad2_host, double* parts8_host, double* vecs2n_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_range_deriv(gpb_hip_vecchia_t* h, int cov_type, double var, double a, double* dA_host,
+                                                       double* dD_host);
+
 /* ------------------------------------------------------------------------------------
  * Exact (dense) GP, Gaussian likelihood -- BASELINE config 1: replaces CalcSigmaComps / CalcZSigmaZt / CalcChol /
  * chol.solve(y) / log-det (include/GPBoost/re_model_template.h:8151, :9273-9287, :6491-6494, :9894, :3127).
