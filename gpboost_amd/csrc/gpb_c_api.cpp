@@ -640,8 +640,9 @@ int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_evals, int* num_grad_
   C_API_END();
 }
 
-/* Test seam (and the host half of the round-2 device path): the optimiser for non-Gaussian likelihoods -- theta = (sigma1_2, a), the
-   Laplace approximation evaluated by a stateful callback (ops documented at gpb_laplace_fn in gpb_optim.h). */
+/* Test seam: the host optimiser for non-Gaussian likelihoods -- theta = (sigma1_2, a) -- with a caller-supplied stateful evaluator of the
+   Laplace approximation (ops documented at gpb_laplace_fn in gpb_optim.h).  GPB_OptimCovPar drives the same optimiser with the device
+   evaluator (device_laplace); the CPU tests drive it with the oracle. */
 int GPB_HIP_OptimizeLaplaceWithCallback(const double* init_theta2, const char* optimizer, double lr_cov, double acc_rate_cov, int max_iter,
                                         double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version, int momentum_offset,
                                         const char* convergence_criterion, int m_lbfgs, int (*eval)(void*, int, double, double, double*),
