@@ -285,7 +285,7 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
                          cg_delta_conv=1e-2, delta_conv_mode=1e-8, likelihood="bernoulli_logit", fixed_effects=None, mode_init=None,
                          want_mode=False, want_parts=False):
     """(negll, gradient of negll wrt (log sigma1^2, log a)) of the Vecchia-Laplace approximation, iterative methods, 'vadu'
-    (orc_vecchia_laplace_grad: the checker of the device gradient, tests/test_laplace_grad_gpu.py).  mode_init: start Newton's method there (the
+    (orc_vecchia_laplace_grad: the checker of the device gradient, tests/test_z_laplace_grad_gpu.py).  mode_init: start Newton's method there (the
     warm start of the reference's optimiser); want_mode: also return the mode found."""
     link = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
     A, D, Ag, Dg, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False, grad=True)

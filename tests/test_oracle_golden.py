@@ -169,7 +169,7 @@ def test_oracle_laplace_poisson_matches_reference_fixture(orc, name):
 def test_oracle_laplace_gradient_matches_reference(orc, name, lik):
     """orc_vecchia_laplace_grad (stochastic trace estimators with the vadu control variates, implicit derivative through the mode)
     against the gradient the reference's own optimiser used for one plain gradient-descent step (tests/golden/laplace_grad_ref.npz,
-    oracle/refdrv.py: ref_laplace_gradient).  The device path is checked against the same fixture (tests/test_laplace_grad_gpu.py).  The extraction is exact up to log / exp
+    oracle/refdrv.py: ref_laplace_gradient).  The device path is checked against the same fixture (tests/test_z_laplace_grad_gpu.py).  The extraction is exact up to log / exp
     rounding over a step of 5e-4 (~1e-8); the gradient itself contains a CG solve that stops at |r| < 1e-2, whose iteration count can
     shift with rounding (seen: 2e-6 relative on one case), hence 1e-5."""
     c = cases.LAPLACE_CASES[name]

@@ -4,7 +4,8 @@
   * gradients read off the reference optimiser's own step (tests/golden/laplace_grad_ref.npz),
   * the reference's own fits (tests/golden/optim_laplace_ref.npz).
 Tolerances as for the oracle against the same fixtures (tests/test_oracle_golden.py, tests/test_optim.py): the gradient contains a CG
-solve that stops at |r| < 1e-2, whose iteration count can move with rounding -> 1e-5."""
+solve that stops at |r| < 1e-2, whose iteration count can move with rounding -> 1e-5.
+(File name: sorts after the other GPU files, so that the established paths report first under `pytest -x`.)"""
 import os
 
 import numpy as np
