@@ -258,7 +258,11 @@ int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, co
     std::copy(mdl->init_cov_pars_tr, mdl->init_cov_pars_tr + 3, mdl->cov_pars_tr);
   } else {
     if (!y_data) return set_error("y_data is NULL: initial covariance parameters cannot be determined");
-    if (find_init_cov_par(mdl, y_data, fixed_effects, mdl->cov_pars_tr)) return -1;
+    if (mdl->likelihood != "gaussian") {     // (sigma1_2, a): marginal variance 1 (re_model_template.h:4865, :4904-4913), the same range heuristic
+      double th3[3];
+      if (find_init_cov_par(mdl, y_data, fixed_effects, th3)) return -1;
+      mdl->cov_pars_tr[0] = 1.; mdl->cov_pars_tr[1] = th3[2]; mdl->cov_pars_tr[2] = 0.;
+    } else if (find_init_cov_par(mdl, y_data, fixed_effects, mdl->cov_pars_tr)) return -1;
     std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, mdl->init_cov_pars_tr);
   }
   mdl->cov_pars_initialized = true;
@@ -503,9 +507,14 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
-  if (!cov_pars && mdl->likelihood != "gaussian") return set_error("GPB_EvalNegLogLikelihood: cov_pars is NULL (no initial-value heuristics for likelihood '%s' on the MI355X path)", mdl->likelihood.c_str());
   if (mdl->likelihood != "gaussian") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
     if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
+    double stored[2] = {0., 0.};
+    if (!cov_pars) {                        // re_model.cpp:759-766: the stored (initial or estimated) parameters
+      if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+      stored[0] = mdl->cov_pars_tr[0]; stored[1] = range_const(mdl) / mdl->cov_pars_tr[1];
+      cov_pars = stored;
+    }
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
     if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
@@ -548,9 +557,9 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
   const char* scope = "is not on the MI355X path of this library yet (parameter estimation: Gaussian likelihood, gp_approx 'vecchia')";
   if (mdl->likelihood != "gaussian") {     // theta = (sigma1_2, a), Laplace approximation + its gradient on the device (gpb_optim.h: gpb_laplace_fn)
     if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
-    if (!mdl->init_cov_pars_provided) return set_error("GPB_OptimCovPar: likelihood '%s' needs init_cov_pars (the initial-value heuristics for non-Gaussian likelihoods are not on the MI355X path of this library yet)", mdl->likelihood.c_str());
+    if (!y_data) return set_error("GPB_OptimCovPar: y_data is NULL");
+    if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;                  // re_model.cpp:487-491
     if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
-    std::copy(mdl->init_cov_pars_tr, mdl->init_cov_pars_tr + 3, mdl->cov_pars_tr);
     mdl->lap_fit_first_eval = true;
     GpbOptimConfig cfg = mdl->optim;
     cfg.range_const = range_const(mdl);
@@ -610,7 +619,7 @@ int GPB_GetInitCovPar(REModelHandle handle, double* init_cov_pars) {
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !init_cov_pars) return set_error("GPB_GetInitCovPar: null argument");
   if (mdl->likelihood != "gaussian") {
-    if (!mdl->init_cov_pars_provided) { init_cov_pars[0] = -1.; init_cov_pars[1] = -1.; return 0; }
+    if (!(mdl->cov_pars_initialized || mdl->init_cov_pars_provided)) { init_cov_pars[0] = -1.; init_cov_pars[1] = -1.; return 0; }
     init_cov_pars[0] = mdl->init_cov_pars_tr[0]; init_cov_pars[1] = range_const(mdl) / mdl->init_cov_pars_tr[1];
     return 0;
   }

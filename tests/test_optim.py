@@ -80,11 +80,36 @@ def test_initial_values_match_the_reference(lib_built, name):
     np.testing.assert_allclose([th[0], th[1] * th[0], rc_ / th[2]], g[name + "_init_cov_pars"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("name", ["logit_n1500_lbfgs", "poisson_n1500_lbfgs", "logit_u3d_n1200_lbfgs"])
+def test_find_init_cov_par_for_non_gaussian_likelihoods(lib_built, name):
+    """Non-Gaussian models start from marginal variance 1 (re_model_template.h:4865, :4904-4913) and the same range heuristic with the same
+    generator state; reference: GPB_GetInitCovPar after its own fit (tests/golden/optim_laplace_ref.npz)."""
+    from oracle import orc
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "optim_laplace_ref.npz"))
+    oc = cases.OPTIM_LAPLACE_CASES[name]
+    c = cases.LAPLACE_CASES[oc["model"]]
+    coords, y = cases.make_count_data(c) if oc["lik"] == "poisson" else cases.make_binary_data(c)
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    cm = np.asfortranarray(co)
+    th = np.empty(3)
+    lib = C.CDLL(lib_built)
+    n = len(y)
+    rc = lib.GPB_HIP_FindInitCovParHost(C.c_int(n), y.ctypes.data_as(C.c_void_p), None, C.c_int(n), C.c_int(coords.shape[1]),
+                                        cm.ctypes.data_as(C.c_void_p), C.c_int(ct), C.c_int(c["seed"]),
+                                        C.c_int(n if c["ordering"] == "random" else 0), th.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    rc_ = [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct]
+    ref = g[name + "_init_cov_pars"]
+    assert ref[0] == 1.0
+    np.testing.assert_allclose(rc_ / th[2], ref[1], rtol=1e-7)
+
+
 @pytest.mark.parametrize("name", list(cases.OPTIM_LAPLACE_CASES))
 def test_host_optimiser_for_non_gaussian_likelihoods_follows_the_reference(lib_built, name):
     """The non-Gaussian branch of the product's host optimiser (lbfgs / gradient descent on (sigma1_2, a), warm-started mode finding,
     mode reset on rejected steps) driven by the oracle's Laplace approximation and gradient, against the reference's own fits of the
-    Vecchia-Laplace model (iterative methods, vadu).  The device half (gradient kernels) is the next step; this pins the host half."""
+    Vecchia-Laplace model (iterative methods, vadu).  The device half is tests/test_z_laplace_grad_gpu.py; this pins the host half."""
     from oracle import orc
     from tests import optim_harness as oh
     g = np.load(os.path.join(os.path.dirname(GOLDEN), "optim_laplace_ref.npz"))

@@ -121,12 +121,27 @@ def test_fit_for_non_gaussian_likelihoods_follows_the_reference(gpb, name):
     np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-14)
 
 
+def test_fit_from_the_reference_initial_values(gpb):
+    """No init_cov_pars: marginal variance 1 and the range heuristic with the model's generator state (FindInitCovPar; the host part is
+    pinned on the CPU by tests/test_optim.py::test_find_init_cov_par_for_non_gaussian_likelihoods) -- the reference's own starting point,
+    hence the reference's fit."""
+    name = "logit_n1500_lbfgs"
+    g = np.load(os.path.join(GOLD, "optim_laplace_ref.npz"))
+    oc = cases.OPTIM_LAPLACE_CASES[name]
+    c = cases.LAPLACE_CASES[oc["model"]]
+    coords, y = cases.make_binary_data(c)
+    mdl = gpb.GPModel(likelihood=oc["lik"], gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    mdl.fit(y)
+    np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-7)
+    assert abs(mdl.get_num_optim_iter() - int(g[name + "_num_it"])) <= 1
+    np.testing.assert_allclose(mdl.get_cov_pars(), g[name + "_cov_pars"], rtol=1e-3)
+
+
 def test_fit_errors_and_iteration_cap(gpb):
     coords, y = cases.synthetic_binary(400, 2, seed=5)
     mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10,
                       vecchia_ordering="none")
-    with pytest.raises(gpb.GPBoostError, match="needs init_cov_pars"):
-        mdl.fit(y)
     with pytest.raises(gpb.GPBoostError, match="positive"):
         mdl.fit(y, params={"init_cov_pars": [1.0, -0.1]})
     with pytest.raises(gpb.GPBoostError, match="needs to be 0 or 1"):
@@ -135,6 +150,5 @@ def test_fit_errors_and_iteration_cap(gpb):
     assert mdl.get_num_optim_iter() <= 2
     cp = mdl.get_cov_pars()
     assert cp.shape == (2,) and np.all(np.isfinite(cp)) and np.all(cp > 0)
-    # the stored likelihood value is the one at the estimated parameters: a fresh evaluation there (mode from 0) agrees to the Newton tolerance
     v = mdl.neg_log_likelihood(cp, y)
     assert np.isfinite(v)
