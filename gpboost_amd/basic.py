@@ -152,7 +152,7 @@ class GPModel(object):
     _OPTIM_DEFAULTS = {   # basic.py:4528-4570 (self.params) -> GPB_SetOptimConfig; -999 / "" / "default" = the library's default
         "init_cov_pars": None, "lr_cov": -999., "acc_rate_cov": -999., "maxit": -999, "delta_rel_conv": -999.,
         "use_nesterov_acc": True, "nesterov_schedule_version": -999, "trace": False, "optimizer_cov": "", "momentum_offset": -999,
-        "convergence_criterion": "default", "m_lbfgs": -999,
+        "convergence_criterion": "default", "m_lbfgs": -999, "estimate_cov_par_index": None,
         "cg_max_num_it": -999, "cg_max_num_it_tridiag": -999, "cg_delta_conv": -999., "num_rand_vec_trace": -999,
         "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999., "cg_preconditioner_type": ""}
 
@@ -160,7 +160,7 @@ class GPModel(object):
         """Optimiser and iterative-method settings (reference: GPModel.set_optim_params, basic.py:5238-5420 -> GPB_SetOptimConfig).
         Estimation: 'optimizer_cov' ("lbfgs" | "gradient_descent"), 'init_cov_pars', 'lr_cov', 'acc_rate_cov', 'maxit',
         'delta_rel_conv', 'use_nesterov_acc', 'nesterov_schedule_version', 'momentum_offset', 'convergence_criterion', 'm_lbfgs',
-        'trace'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
+        'estimate_cov_par_index' (Gaussian models: 0 = hold (error variance, GP variance, range)[i] at its initial value), 'trace'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
         'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'.  Anything else raises: no silent ignore."""
         if not hasattr(self, "_optim_params"):
             self._optim_params = dict(self._OPTIM_DEFAULTS)
@@ -176,6 +176,10 @@ class GPModel(object):
                 raise ValueError("'init_cov_pars' does not contain the correct number of parameters")
             init_c = _dptr(init)
         est = np.array([-1], dtype=np.int32)
+        if o["estimate_cov_par_index"] is not None:
+            est = np.ascontiguousarray(o["estimate_cov_par_index"], dtype=np.int32).reshape(-1)
+            if est.shape[0] != self.num_cov_pars or np.any(est < 0):
+                raise ValueError("'estimate_cov_par_index' needs one entry (1 = estimate, 0 = hold fixed) per covariance parameter")
         _safe_call(_lib().GPB_SetOptimConfig(
             self.handle, init_c, ctypes.c_double(float(o["lr_cov"])), ctypes.c_double(float(o["acc_rate_cov"])), ctypes.c_int(int(o["maxit"])),
             ctypes.c_double(float(o["delta_rel_conv"])), ctypes.c_bool(bool(o["use_nesterov_acc"])),

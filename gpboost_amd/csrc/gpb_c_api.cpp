@@ -431,9 +431,12 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   if (!handle) return set_error("GPB_SetOptimConfig: null handle");
   if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
   if (estimate_aux_pars) return set_error("GPB_SetOptimConfig: estimate_aux_pars is not on the MI355X hot path of this library");
-  if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0)
-    return set_error("GPB_SetOptimConfig: holding covariance parameters fixed (estimate_cov_par_index) is not on the MI355X hot path of this library");
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) {          // re_model_template.h:930-936
+    if (mdl->likelihood != "gaussian")
+      return set_error("GPB_SetOptimConfig: holding covariance parameters fixed (estimate_cov_par_index) for likelihood '%s' is not on the MI355X hot path of this library", mdl->likelihood.c_str());
+    std::copy(estimate_cov_par_index, estimate_cov_par_index + 3, mdl->optim.estimate_cov_par_index);
+  }
   mdl->trace = trace;
   // REModel::SetOptimConfig (re_model.cpp:301-318): initial values are kept on the transformed scale
   if (init_cov_pars) {
@@ -701,10 +704,11 @@ int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_th
                                          int max_iter, double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version,
                                          int momentum_offset, const char* convergence_criterion, int m_lbfgs, double range_const_,
                                          int (*terms)(void*, double, double, int, double*), void* ctx, double* theta_out, int* num_it,
-                                         double* negll, int* num_evals2) {
+                                         double* negll, int* num_evals2, const int* estimate_cov_par_index) {
   C_API_BEGIN();
   if (!init_theta || !terms || !theta_out) return set_error("GPB_HIP_OptimizeGaussianWithCallback: null argument");
   GpbOptimConfig cfg;
+  if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) std::copy(estimate_cov_par_index, estimate_cov_par_index + 3, cfg.estimate_cov_par_index);
   if (optimizer && optimizer[0]) cfg.optimizer = optimizer;
   if (lr_cov > 0.) cfg.lr_cov_init = lr_cov;
   if (acc_rate_cov > 0.) cfg.acc_rate_cov = acc_rate_cov;

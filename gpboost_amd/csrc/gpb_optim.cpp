@@ -35,6 +35,13 @@ struct State {
   double sigma2 = 0., sigma2_lag1 = 0.;
   double negll = 0.;                 // neg_log_likelihood_
   int n_ll = 0, n_grad = 0;
+  double th_first[3] = {0., 0., 0.}; // cov_pars_set_first_time_ (:1201)
+
+  // MaybeKeepVarianceConstant (:7881-7904): the nugget is estimated, the marginal variance is not -> the RATIO follows the nugget so
+  // that sigma1_2 = ratio * sigma2 stays at its initial value
+  void keep_variance_constant(double th[3]) const {
+    if (cfg.estimate_cov_par_index[0] > 0 && cfg.estimate_cov_par_index[1] <= 0) th[1] = th_first[1] * th_first[0] / th[0];
+  }
 
   // ApplyGaussianNuggetLowerBound on the transformed scale (:7849-7874): TransformBack, bound, Transform again
   void nugget_bound(double th[3]) const {
@@ -53,6 +60,7 @@ struct State {
   // CalcCovFactorOrModeAndNegLL (:2832-2852).  with_grad: also fetch the gradient sums in the same launch.
   int calc(const double th_in[3], bool with_grad) {
     double th[3] = {th_in[0], th_in[1], th_in[2]};
+    keep_variance_constant(th);
     nugget_bound(th);
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
     if (fn(ctx, th[1], th[2], with_grad ? 1 : 0, t)) return -1;
@@ -74,12 +82,12 @@ struct State {
       g[0] = t[3]; g[1] = t[4]; g[2] = t[5]; g[3] = t[6];
       have_grad = true;
     }
-    out[0] = g[0] / s2 + g[1];
-    out[1] = g[2] / s2 + g[3];
+    out[0] = cfg.estimate_cov_par_index[1] > 0 ? g[0] / s2 + g[1] : 0.;     // parameters that are not estimated: no gradient entry (:2004)
+    out[1] = cfg.estimate_cov_par_index[2] > 0 ? g[2] / s2 + g[3] : 0.;
     return 0;
   }
   void profile_out_sigma2(double th[3]) {   // :2640-2650
-    sigma2 = yPy / n;
+    if (cfg.estimate_cov_par_index[0] > 0) sigma2 = yPy / n;
     th[0] = sigma2;
     nugget_bound(th);
     sigma2 = th[0];
@@ -486,6 +494,8 @@ int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_
                 theta_init[2]);
   State st{cfg, num_data, fn, ctx};
   double th[3] = {theta_init[0], theta_init[1], theta_init[2]};
+  std::copy(th, th + 3, st.th_first);
+  st.sigma2 = th[0];
   *out = GpbOptimResult();
   int rc = 0;
   if (cfg.max_iter > 0) {
@@ -498,6 +508,7 @@ int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_
       return -1;
     }
   }
+  if (cfg.max_iter > 0) st.keep_variance_constant(th);                   // :1750-1755
   std::copy(th, th + 3, out->theta);
   out->negll = st.negll;
   out->num_ll_evals = st.n_ll;

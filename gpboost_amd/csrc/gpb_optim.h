@@ -38,6 +38,9 @@ struct GpbOptimConfig {                      // defaults: re_model_template.h:56
   std::string convergence_criterion = "relative_change_in_log_likelihood";
   int m_lbfgs = 6;
   double range_const = 1.;                   // sqrt(2 nu): only used by the nugget-bound round trip (TransformBack -> Transform)
+  int estimate_cov_par_index[3] = {1, 1, 1}; // <= 0: (error variance, GP variance, range) held at the initial value (Gaussian models;
+                                             // re_model_template.h:930-936, ProfileOutSigma2 :2640-2650, MaybeKeepVarianceConstant :7881-7904,
+                                             // zero gradient entries :1993-2011)
   bool trace = false;
 };
 

@@ -225,9 +225,10 @@ GPBOOST_C_EXPORT int GPB_HIP_FindInitCovParHost(int32_t num_data, const double* 
 GPBOOST_C_EXPORT int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_theta, const char* optimizer,
     double lr_cov, double acc_rate_cov, int max_iter, double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version,
     int momentum_offset, const char* convergence_criterion, int m_lbfgs, double range_const,
-    int (*terms)(void*, double, double, int, double*), void* ctx, double* theta_out, int* num_it, double* negll, int* num_evals2);
-/* Test seam and host half of parameter estimation for non-Gaussian likelihoods (the device gradient of the Laplace approximation is
- * the next step): the reference's lbfgs / gradient descent on theta = (sigma1_2, a) with a stateful evaluation
+    int (*terms)(void*, double, double, int, double*), void* ctx, double* theta_out, int* num_it, double* negll, int* num_evals2,
+    const int* estimate_cov_par_index /* NULL or [0] < 0: all three estimated (c_api.h:1437-1467) */);
+/* Test seam and host half of parameter estimation for non-Gaussian likelihoods (GPB_OptimCovPar drives it with the device gradient of
+ * the Laplace approximation): the reference's lbfgs / gradient descent on theta = (sigma1_2, a) with a stateful evaluation
  * callback eval(ctx, op, sigma1_2, a, out3): op 0 / 1 = find the mode (warm start) and return the negative approximate marginal
  * log-likelihood (op 1: + its gradient wrt (log sigma1_2, log a) in out3[1..2]); op 2 = gradient of the current state only; op 3 =
  * reset the mode to its previous value (Likelihood::ResetModeToPreviousValue); + 16 = first gradient-descent update (CG caps / 3). */

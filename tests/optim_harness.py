@@ -30,17 +30,18 @@ def oracle_terms(orc, coords_ord, nn, cov_type, y_ord):
 
 def optimize(lib, n, init_theta, terms_cb, optimizer="lbfgs", lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
              use_nesterov_acc=True, nesterov_schedule_version=-999, momentum_offset=-999, convergence_criterion="default", m_lbfgs=-999,
-             range_const=1.0):
+             range_const=1.0, estimate_cov_par_index=None):
     th0 = np.ascontiguousarray(init_theta, dtype=np.float64)
     out = np.empty(3); nit = C.c_int(0); nll = C.c_double(0); ne = np.zeros(2, dtype=np.int32)
     lib.GPB_HIP_OptimizeGaussianWithCallback.argtypes = [
         C.c_int32, C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_bool, C.c_int, C.c_int, C.c_char_p, C.c_int,
-        C.c_double, TERMS_FN, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
+        C.c_double, TERMS_FN, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    est = None if estimate_cov_par_index is None else np.ascontiguousarray(estimate_cov_par_index, dtype=np.int32)
     lib.LGBM_GetLastError.restype = C.c_char_p
     rc = lib.GPB_HIP_OptimizeGaussianWithCallback(
         n, th0.ctypes.data, optimizer.encode(), lr_cov, acc_rate_cov, max_iter, delta_rel_conv, use_nesterov_acc, nesterov_schedule_version,
         momentum_offset, convergence_criterion.encode(), m_lbfgs, range_const, terms_cb, None, out.ctypes.data, C.byref(nit),
-        C.byref(nll), ne.ctypes.data)
+        C.byref(nll), ne.ctypes.data, None if est is None else est.ctypes.data)
     if rc != 0:
         raise RuntimeError(lib.LGBM_GetLastError().decode())
     return out, nit.value, nll.value, ne

@@ -58,6 +58,35 @@ def test_host_optimiser_follows_the_reference_trajectory(lib_built, name):
     assert ne[0] + ne[1] == len(calls)
 
 
+# test_GPModel_gaussian_process.R:1364-1398 ("Holding some parameters fix"): lbfgs from init_cov_pars with estimate_cov_par_index
+R_FIXED_PAR_GOLDENS = {
+    (1, 0, 0): ([0.4585860589, 0.5170731356, 0.1786480774], 127.8100465),
+    (1, 1, 0): ([0.10238832994, 1.23364920496, 0.17864807736], 123.4597106),
+    (0, 1, 0): ([0.5170731356, 0.6109062004, 0.1786480774], 128.005439),
+}
+R_FIXED_PAR_CFG = dict(optimizer="lbfgs", lr_cov=0.1, acc_rate_cov=0.5, delta_rel_conv=1e-6)     # params_vecchia with optimizer_cov = "lbfgs"
+
+
+@pytest.mark.parametrize("est", sorted(R_FIXED_PAR_GOLDENS))
+def test_holding_parameters_fixed_reproduces_the_r_suite_goldens(lib_built, est):
+    """estimate_cov_par_index in the host optimiser (zero gradient entries, ProfileOutSigma2 only when the nugget is estimated,
+    MaybeKeepVarianceConstant when the nugget is estimated but the GP variance is not) against the R suite's golden estimates and
+    likelihood values (TOLERANCE_STRICT = 1e-6 there)."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    coords, y, ids, mc, init, cfg = cases.optim_case("r_gd_nesterov_parcrit")
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    cb, calls = oh.oracle_terms(orc, co, nn, 0, y[perm])
+    th, nit, nll, ne = oh.optimize(C.CDLL(lib_built), len(y), orc.transform_cov_pars(0, init), cb, estimate_cov_par_index=est, **R_FIXED_PAR_CFG)
+    cp, nll_ref = R_FIXED_PAR_GOLDENS[est]
+    out = np.array([th[0], th[1] * th[0], 1.0 / th[2]])
+    assert np.abs(out - cp).sum() < 1e-8
+    assert abs(nll - nll_ref) < 1e-6
+    for i, e in enumerate(est):                       # held parameters come back as they went in (original scale)
+        if not e:
+            assert abs(out[i] - init[i]) < 1e-12
+
+
 @pytest.mark.parametrize("name", [k for k, c in cases.OPTIM_CASES.items() if c["init"] is None and c["model"] != "clusters"])
 def test_initial_values_match_the_reference(lib_built, name):
     """FindInitCovPar (var(y)/2, ratio 1, range from the median pairwise distance; 1000 points drawn from the model's generator AFTER

@@ -152,3 +152,17 @@ def test_fit_errors_and_iteration_cap(gpb):
     assert cp.shape == (2,) and np.all(np.isfinite(cp)) and np.all(cp > 0)
     v = mdl.neg_log_likelihood(cp, y)
     assert np.isfinite(v)
+
+
+@pytest.mark.parametrize("est", [(1, 0, 0), (1, 1, 0), (0, 1, 0)])
+def test_fit_with_parameters_held_fixed_r_goldens(gpb, est):
+    """GPModel.fit(params = {estimate_cov_par_index}) on the device against test_GPModel_gaussian_process.R:1364-1398 (the host logic is
+    pinned on the CPU by tests/test_optim.py::test_holding_parameters_fixed_reproduces_the_r_suite_goldens)."""
+    from tests.test_optim import R_FIXED_PAR_GOLDENS
+    coords, y, ids, mc, init, cfg = cases.optim_case("r_gd_nesterov_parcrit")
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none")
+    mdl.fit(y, params=dict(optimizer_cov="lbfgs", lr_cov=0.1, acc_rate_cov=0.5, delta_rel_conv=1e-6, init_cov_pars=init,
+                           estimate_cov_par_index=list(est)))
+    cp, nll_ref = R_FIXED_PAR_GOLDENS[est]
+    assert np.abs(mdl.get_cov_pars() - cp).sum() < 1e-6
+    assert abs(mdl.get_current_neg_log_likelihood() - nll_ref) < 1e-6
