@@ -357,6 +357,20 @@ def r_fixture():
     return coords, y
 
 
+def r_fixture_multiple():
+    """R-package/tests/testthat/test_GPModel_gaussian_process.R:72-78, :1678-1679: 25 locations, each observed four times
+    (coords_multiple, eps_multiple + xi) and the suite's initial values c(var(y)/2, var(y)/2, mean(dist(unique(coords)))/3)."""
+    from scipy.spatial.distance import cdist, pdist
+    from scipy.stats import norm
+    n, d = 100, 2
+    cu = sim_rand_unif(n * d // 4, 0.1).reshape((n // 4, d), order="F")
+    coords = np.vstack([cu, cu, cu, cu])
+    Sigma = np.exp(-cdist(coords, coords) / 0.1) + 1e-10 * np.eye(n)
+    y = np.linalg.cholesky(Sigma) @ norm.ppf(sim_rand_unif(n, 0.8)) + norm.ppf(sim_rand_unif(n, 0.1)) / 5
+    init = np.array([np.var(y, ddof=1) / 2, np.var(y, ddof=1) / 2, pdist(cu).mean() / 3])
+    return coords, y, init
+
+
 def r_fixture_logit():
     """Binary fixture of R-package/tests/testthat/test_GPModel_non_Gaussian_data.R:52-62, 2510-2513 (same coords / L / b_1
     as above; y = 1{u < sigmoid(L b_1)} with u from the LCG started at 0.2341)."""

@@ -87,6 +87,36 @@ def test_holding_parameters_fixed_reproduces_the_r_suite_goldens(lib_built, est)
             assert abs(out[i] - init[i]) < 1e-12
 
 
+@pytest.mark.parametrize("ordering", ["none", "random"])
+def test_r_suite_fit_with_the_maximal_number_of_neighbours(lib_built, ordering):
+    """test_GPModel_gaussian_process.R:1175-1192, :1231-1239 (random ordering: the same numbers): Vecchia on ALL predecessors (m = n - 1 = 99: exact GP), gradient descent + Nesterov,
+    parameter criterion: 382 iterations, estimates (0.03276547, 1.07617676, 0.11352557), nll 122.7752664.  Host optimiser + oracle
+    (m = 99 is beyond the device kernels' 62 neighbours; the m = 30 sibling, 378 iterations, runs on the device)."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    coords, y, ids, mc, init, cfg = cases.optim_case("r_gd_nesterov_parcrit")
+    perm, co, nn = orc.vecchia_setup(coords, len(y) - 1, ordering, 0)
+    cb, calls = oh.oracle_terms(orc, co, nn, 0, y[perm])
+    th, nit, nll, ne = oh.optimize(C.CDLL(lib_built), len(y), orc.transform_cov_pars(0, init), cb, **_cfg_kwargs(cfg))
+    assert nit == 382
+    assert np.abs(np.array([th[0], th[1] * th[0], 1.0 / th[2]]) - [0.03276547, 1.07617676, 0.11352557]).sum() < 1e-6      # TOLERANCE_STRICT
+    assert abs(nll - 122.7752664) < 1e-6
+
+
+def test_r_suite_fit_with_multiple_observations_per_location(lib_built):
+    """test_GPModel_gaussian_process.R:1676-1687: Vecchia on all predecessors, every location observed four times, lbfgs from the suite's
+    initial values: estimates (0.03713823078, 1.15342626349, 0.19206772520), nll 33.43573582 (the suite allows 1e-2; 1e-7 here).  Host
+    optimiser + oracle: m = n - 1 = 99 is beyond the device kernels' 62 neighbours."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    coords, y, init = orc.r_fixture_multiple()
+    perm, co, nn = orc.vecchia_setup(coords, len(y) - 1, "none", 0)
+    cb, calls = oh.oracle_terms(orc, co, nn, 0, y[perm])
+    th, nit, nll, ne = oh.optimize(C.CDLL(lib_built), len(y), orc.transform_cov_pars(0, init), cb, optimizer="lbfgs", max_iter=1000)
+    np.testing.assert_allclose([th[0], th[1] * th[0], 1.0 / th[2]], [0.03713823078, 1.15342626349, 0.19206772520], rtol=0, atol=1e-7)
+    assert abs(nll - 33.43573582) < 1e-7
+
+
 @pytest.mark.parametrize("name", [k for k, c in cases.OPTIM_CASES.items() if c["init"] is None and c["model"] != "clusters"])
 def test_initial_values_match_the_reference(lib_built, name):
     """FindInitCovPar (var(y)/2, ratio 1, range from the median pairwise distance; 1000 points drawn from the model's generator AFTER
