@@ -294,6 +294,21 @@ def test_r_golden_vecchia_prediction(orc):
     np.testing.assert_allclose(var - var_latent, R_PRED_COV_PARS[0], rtol=1e-12)
 
 
+def test_r_golden_prediction_conditioning_on_all_observations(orc):
+    """test_GPModel_gaussian_process.R:1241-1268: num_neighbors = n - 1, num_neighbors_pred = n + 2 -- every prediction point conditions on
+    every observation, so means and variances are the exact GP's whichever prediction type is used (the suite uses
+    'order_obs_first_cond_all'; its off-diagonal covariances, ~1e-5, are what 'cond_obs_only' does not model)."""
+    coords, y = orc.r_fixture()
+    cov_pars = np.array([0.02, 1.2, 0.9])
+    pt = orc.transform_cov_pars(0, cov_pars)
+    ct = np.array([[0.1, 0.9], [0.2, 0.4], [0.7, 0.55]])
+    mu, var = orc.predict_obs_only(coords, y, ct, 0, pt, len(y) + 2, predict_response=True)
+    assert np.abs(mu - [0.08704577, 1.63875604, 0.48513581]).sum() < R_TOL
+    assert np.abs(var - [1.189093e-01, 7.427727e-02, 8.107455e-02]).sum() < R_TOL
+    mu2, var_latent = orc.predict_obs_only(coords, y, ct, 0, pt, len(y) + 2, predict_response=False)
+    assert np.abs(var_latent - (np.array([1.189093e-01, 7.427727e-02, 8.107455e-02]) - cov_pars[0])).sum() < R_TOL
+
+
 # ---- several clusters (independent realisations of the GP) ---------------------------------------------------------------------
 def test_r_golden_vecchia_cluster_ids(orc):
     """test_GPModel_gaussian_process.R:1638-1648: cluster_ids = 40 x 1, 60 x 2; nll 129.3761486 at the fitted parameters
