@@ -54,9 +54,10 @@ class OracleLaplaceEvaluator(object):
     """Stateful evaluator of the Laplace approximation for GPB_HIP_OptimizeLaplaceWithCallback with the oracle behind it: keeps the
     mode (warm start), its previous value (op 3) and the gradient of the current state (op 2)."""
 
-    def __init__(self, orc, coords_ord, nn, cov_type, y_ord, likelihood, cg_max_num_it=1000, cg_max_num_it_tridiag=1000):
+    def __init__(self, orc, coords_ord, nn, cov_type, y_ord, likelihood, cg_max_num_it=1000, cg_max_num_it_tridiag=1000, num_rand_vec=50,
+                 cg_delta_conv=1e-2):
         self.orc, self.co, self.nn, self.ct, self.y, self.lik = orc, coords_ord, nn, cov_type, y_ord, likelihood
-        self.cg, self.cgt = cg_max_num_it, cg_max_num_it_tridiag
+        self.cg, self.cgt, self.nrv, self.cgd = cg_max_num_it, cg_max_num_it_tridiag, num_rand_vec, cg_delta_conv
         self.mode = None; self.mode_prev = None; self.grad = None
         self.calls = []
         self.cb = LAPLACE_FN(self._fn)
@@ -74,7 +75,8 @@ class OracleLaplaceEvaluator(object):
         self.mode_prev = None if self.mode is None else self.mode.copy()
         nll, g, mode = self.orc.vecchia_laplace_grad(self.co, self.nn, self.ct, var, a, self.y, likelihood=self.lik, mode_init=self.mode,
                                                      want_mode=True, cg_max_num_it=int(round(self.cg / div)),
-                                                     cg_max_num_it_tridiag=int(round(self.cgt / div)))
+                                                     cg_max_num_it_tridiag=int(round(self.cgt / div)), num_rand_vec=self.nrv,
+                                                     cg_delta_conv=self.cgd)
         if self.mode_prev is None:
             self.mode_prev = np.zeros_like(mode)            # InitializeModeAvec: mode and its previous value start at 0
         self.mode, self.grad = mode, (g[0], g[1])
