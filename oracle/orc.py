@@ -116,6 +116,34 @@ def predict_obs_only(coords_obs, y_obs, coords_pred, cov_type, pars_trans, m_pre
     return mean, var
 
 
+def predict_cond_all(coords_obs, y_obs, coords_pred, cov_type, pars_trans, m_pred, predict_response=False):
+    """Vecchia prediction 'order_obs_first_cond_all', Gaussian likelihood (CalcPredVecchiaObservedFirstOrder with CondObsOnly = false,
+    src/GPBoost/Vecchia_utils.cpp:1701-2093): a prediction point conditions on its m_pred nearest points among the observed AND the
+    preceding prediction points (neighbour search with end_search_at = -1, :1806-1822); mean = Bp^-1 (-Bpo y) (:2061-2064), covariance =
+    Bp^-1 Dp Bp^-T (:2077-2090), nugget removed from its diagonal unless predict_response.  Dense algebra in the number of prediction
+    points: a checker for small cases (the device path for this prediction type does not exist yet).  Returns (mean, cov)."""
+    co = np.asarray(coords_obs, dtype=np.float64); cp = np.asarray(coords_pred, dtype=np.float64)
+    n_obs, n_pred = co.shape[0], cp.shape[0]
+    call = np.vstack([co, cp])
+    nn = neighbors_range(call, m_pred, n_obs, -1)
+    A, D, bad = vecchia_factor(call, nn, cov_type, pars_trans[1], pars_trans[2], gauss=True)
+    Bpo = np.zeros((n_pred, n_obs)); Bp = np.eye(n_pred)
+    for i in range(n_pred):
+        for j, c in enumerate(nn[n_obs + i]):
+            if c < 0:
+                continue
+            if c < n_obs:
+                Bpo[i, c] -= A[n_obs + i, j]
+            else:
+                Bp[i, c - n_obs] -= A[n_obs + i, j]
+    mean = np.linalg.solve(Bp, -Bpo @ np.asarray(y_obs, dtype=np.float64))
+    Bpi = np.linalg.inv(Bp)
+    cov = pars_trans[0] * (Bpi @ np.diag(D[n_obs:]) @ Bpi.T)
+    if not predict_response:
+        cov = cov - pars_trans[0] * np.eye(n_pred)
+    return mean, cov
+
+
 def vecchia_factor(coords, nn, cov_type, var, a, gauss=True, grad=False):
     cm = np.asfortranarray(coords, dtype=np.float64)
     n, d = cm.shape

@@ -309,6 +309,34 @@ def test_r_golden_prediction_conditioning_on_all_observations(orc):
     assert np.abs(var_latent - (np.array([1.189093e-01, 7.427727e-02, 8.107455e-02]) - cov_pars[0])).sum() < R_TOL
 
 
+def test_r_golden_predictions_at_given_parameters(orc):
+    """test_GPModel_gaussian_process.R:1459-1495 (30 neighbours, ordering none, cov_pars (0.02, 1.2, 0.9), two of the three prediction
+    points 1.4e-5 apart): 'order_obs_first_cond_obs_only' and 'order_obs_first_cond_all' (the latter correlates the two close points:
+    covariance 0.09889262, and moves the second mean)."""
+    coords, y = orc.r_fixture()
+    pt = orc.transform_cov_pars(0, np.array([0.02, 1.2, 0.9]))
+    mu, var = orc.predict_obs_only(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=True)
+    assert np.abs(mu - [0.08665472, 0.08664854, 0.49011216]).sum() < R_TOL
+    assert np.abs(var - [0.11891, 0.1189129, 0.08108126]).sum() < R_TOL
+    mu, cov = orc.predict_cond_all(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=True)
+    assert np.abs(mu - [0.08665472, 0.08661259, 0.49011216]).sum() < R_TOL
+    assert np.abs(cov.ravel() - [0.11891004, 0.09889262, 0., 0.09889262, 0.11891291, 0., 0., 0., 0.08108126]).sum() < R_TOL
+    mu2, cov_latent = orc.predict_cond_all(coords, y, R_PRED_COORDS, 0, pt, 30, predict_response=False)
+    np.testing.assert_allclose(np.diag(cov) - np.diag(cov_latent), 0.02, rtol=1e-10)
+
+
+def test_r_golden_cond_all_prediction_on_all_observations(orc):
+    """test_GPModel_gaussian_process.R:1241-1258: num_neighbors_pred = n + 2 with 'order_obs_first_cond_all' = the exact GP's joint
+    predictive distribution, off-diagonal covariances (1e-5 .. 1e-7) included."""
+    coords, y = orc.r_fixture()
+    pt = orc.transform_cov_pars(0, np.array([0.02, 1.2, 0.9]))
+    ct = np.array([[0.1, 0.9], [0.2, 0.4], [0.7, 0.55]])
+    mu, cov = orc.predict_cond_all(coords, y, ct, 0, pt, len(y) + 2, predict_response=True)
+    assert np.abs(mu - [0.08704577, 1.63875604, 0.48513581]).sum() < R_TOL
+    assert np.abs(cov.ravel() - [1.189093e-01, 1.171632e-05, -4.172444e-07, 1.171632e-05, 7.427727e-02, 1.492859e-06, -4.172444e-07,
+                                 1.492859e-06, 8.107455e-02]).sum() < R_TOL
+
+
 # ---- several clusters (independent realisations of the GP) ---------------------------------------------------------------------
 def test_r_golden_vecchia_cluster_ids(orc):
     """test_GPModel_gaussian_process.R:1638-1648: cluster_ids = 40 x 1, 60 x 2; nll 129.3761486 at the fitted parameters
