@@ -178,6 +178,26 @@ def optim_laplace_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "optim_laplace_ref.npz"), **res)
 
 
+def fisher_fixture(out_dir):
+    """Standard errors of the covariance parameters (GPB_GetCovPar(calc_std_dev = true) after the reference's own fit; stochastic Fisher
+    information with the default 50 probe vectors, seed 1, first model of the process = run id 0).  One process per case."""
+    import ctypes as C
+    res = {}
+    for name in ("r_gd_nesterov_parcrit", "r_mat15_lbfgs", "u1d_n1000_mat15_lbfgs"):
+        code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); from oracle import refdrv; from tests import cases\n"
+                "coords, y, ids, mc, init, cfg = cases.optim_case(%r)\n"
+                "mdl = refdrv.RefCAPIModel(coords, mc['cov_function'], mc['shape'], mc['m'], mc['ordering'], mc['seed'], threads=1)\n"
+                "mdl.set_optim_config(init_cov_pars=init, **cfg); mdl.optim_cov_par(y)\n"
+                "out = np.empty(6); rc = mdl.L.GPB_GetCovPar(mdl.h, out.ctypes.data_as(C.c_void_p), C.c_bool(True)); assert rc == 0\n"
+                "print(' '.join('%%.17g' %% v for v in out))\n") % (ROOT, name)
+        import subprocess
+        line = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+        v = np.array([float(t) for t in line.split()])
+        res[name + "_cov_pars"] = v[:3]; res[name + "_std"] = v[3:]
+        print("fisher", name, v, flush=True)
+    np.savez_compressed(os.path.join(out_dir, "fisher_ref.npz"), **res)
+
+
 def cluster_fixture(out_dir):
     """Reference nll of a model with several clusters (independent GP realisations), random Vecchia ordering: pins the cluster
     order (first appearance) and the ONE shared std::mt19937 that shuffles cluster after cluster."""
@@ -208,6 +228,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "fisher":
+        fisher_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_laplace":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":

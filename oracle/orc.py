@@ -144,6 +144,38 @@ def predict_cond_all(coords_obs, y_obs, coords_pred, cov_type, pars_trans, m_pre
     return mean, cov
 
 
+def fisher_std_errors(coords, nn, cov_type, cov_pars, num_rand_vec=50, seed_rand=1, run_id=0):
+    """Standard errors of (sigma2, sigma1_2, rho) of a Gaussian Vecchia model from the stochastic Fisher information on the ORIGINAL scale:
+    REModelTemplate::CalcFisherInformation_Vecchia, Hutchinson branch (include/GPBoost/re_model_template.h:10137-10230; default since
+    use_stochastic_trace_for_Fisher_information_Vecchia_ = true, :6033), include_error_var, !transf_scale:
+        v_0 = Psi^-1 z,  v_k = B' D^-1 (-dB_k Psi z + dD_k B^-T z) - dB_k' B^-T z,  FI_kl = mean_z (v_k . v_l) / 2,  se = sqrt(diag(FI^-1)).
+    Probes as GenRandVecNormalParallel(seed_rand_vec_trace, run id).  coords / nn in Vecchia order.  Dense algebra: a checker for small n
+    (no device path computes standard errors yet).  Derivatives on the original scale by the chain rule from the transformed ones."""
+    co = np.asarray(coords, dtype=np.float64)
+    n = co.shape[0]
+    s2, s1, rho = [float(v) for v in cov_pars]
+    pt = transform_cov_pars(cov_type, cov_pars)
+    A, Dt, Ag, Dg, bad = vecchia_factor(co, nn, cov_type, pt[1], pt[2], gauss=True, grad=True)
+    B = np.eye(n); dBt = [np.zeros((n, n)), np.zeros((n, n))]
+    for i in range(n):
+        for j, c in enumerate(nn[i]):
+            if c >= 0:
+                B[i, c] = -A[i, j]
+                dBt[0][i, c] = -Ag[0][i, j]; dBt[1][i, c] = -Ag[1][i, j]
+    D = s2 * Dt
+    dB = [dBt[0] / s1, dBt[1] * (-1.0 / rho)]                  # d / d sigma1_2 = (d / d log ratio) / sigma1_2;  d / d rho = (d / d log a) (-1 / rho)
+    dD = [s2 * Dg[0] / s1, s2 * Dg[1] * (-1.0 / rho)]
+    Z = np.asarray(gen_rand_normal(n, num_rand_vec, seed=seed_rand, run_id=run_id))
+    Bi = np.linalg.inv(B)
+    BTiZ = Bi.T @ Z
+    PsiZ = Bi @ (D[:, None] * BTiZ)
+    V = [B.T @ ((B @ Z) / D[:, None])]
+    for k in range(2):
+        V.append(B.T @ ((-dB[k] @ PsiZ + dD[k][:, None] * BTiZ) / D[:, None]) - dB[k].T @ BTiZ)
+    FI = np.array([[(V[k] * V[l]).sum(axis=0).mean() / 2 for l in range(3)] for k in range(3)])
+    return np.sqrt(np.diag(np.linalg.inv(FI)))
+
+
 def vecchia_factor(coords, nn, cov_type, var, a, gauss=True, grad=False):
     cm = np.asfortranarray(coords, dtype=np.float64)
     n, d = cm.shape
