@@ -437,3 +437,24 @@ def test_oracle_standard_errors_match_the_reference(orc, name):
     np.testing.assert_allclose(se, g[name + "_std"], rtol=1e-7)
     if name == "r_gd_nesterov_parcrit":
         assert np.abs(se - [0.07545639, 0.24785457, 0.03493878]).sum() < 1e-2        # the R suite's tolerance for these
+
+
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "poisson"])
+@pytest.mark.parametrize("n,d,m,ct", [(3000, 2, 30, 0), (2000, 2, 10, 1)])
+def test_stage_tolerances_admit_one_block_cg_iteration(orc, n, d, m, ct, lik):
+    """The stage-by-stage GPU test (tests/test_z_laplace_grad_gpu.py) compares device and oracle with tolerances that must admit a block CG
+    that stops one iteration earlier (the stopping test is a rounded norm against 1e-2): here the oracle with its iteration count capped at
+    k - 1 plays the other implementation."""
+    from tests.laplace_grad_harness import check_stages
+    coords, y = cases.synthetic_binary(n, d, seed=600 + n)
+    if lik == "poisson":
+        y = np.random.default_rng(7).poisson(1.0 + y).astype(np.float64)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 4)
+    var, a = 0.9, {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / 0.15
+    ref, gref, oparts = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=lik, want_parts=True)
+    _, info = orc.vecchia_laplace_logit(co, nn, ct, var, a, y[perm], likelihood=lik)
+    k = info["lanczos_it"]
+    assert k > 2
+    _, g2, parts2 = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=lik, want_parts=True, cg_max_num_it_tridiag=k - 1)
+    assert not np.array_equal(g2, gref)
+    check_stages(g2, parts2, gref, oparts)
