@@ -731,6 +731,55 @@ int GPB_HIP_OptimizeGaussianWithCallback(int32_t num_data, const double* init_th
   C_API_END();
 }
 
+/* Host half of the Vecchia prediction 'order_obs_first_cond_all' (CalcPredVecchiaObservedFirstOrder with CondObsOnly = false,
+   src/GPBoost/Vecchia_utils.cpp:2061-2090), and test seam for it: given the factor rows of the APPENDED prediction points -- neighbour
+   indices into (observed, prediction) points, nn < n_obs + i for row i, -1 padded; A_i = C_nn^-1 c; D_i with the nugget, transformed scale
+   (what vecchia_point_kernel<MODE_FACTOR> leaves for them, neighbours searched with end_search_at = -1) --
+     mean = Bp^-1 (-Bpo y)          forward substitution: Bp = I - A_pp is unit lower triangular (:2061-2064)
+     cov  = sigma2 Bp^-1 Dp Bp^-T   rows of Bp^-1 by the same recursion (:2077-2090); nugget removed from the diagonal unless predict_response
+   var_out (n_pred) and cov_out (n_pred x n_pred, row-major) may each be NULL.  Dense in the number of prediction points (the reference keeps
+   Bp^-1 sparse): refused above 20000 points.  The device wiring into GPB_PredictREModel is not done yet. */
+int GPB_HIP_PredictCondAllHost(int32_t n_obs, int32_t n_pred, int32_t m, const int32_t* nn_pred, const double* A_pred, const double* D_pred,
+                               const double* y_obs, double sigma2, bool predict_response, double* mean_out, double* var_out, double* cov_out) {
+  C_API_BEGIN();
+  if (!nn_pred || !A_pred || !D_pred || !y_obs || !mean_out || n_obs < 1 || n_pred < 1 || m < 1)
+    return set_error("GPB_HIP_PredictCondAllHost: invalid argument");
+  const bool need_rows = var_out || cov_out;
+  if (need_rows && n_pred > 20000) return set_error("GPB_HIP_PredictCondAllHost: predictive (co)variances for %d points (dense limit: 20000)", n_pred);
+  std::vector<double> L;                       // row i of Bp^-1, columns 0..i (lower triangular, row-major full storage)
+  if (need_rows) L.assign((size_t)n_pred * n_pred, 0.);
+  for (int i = 0; i < n_pred; ++i) {
+    double mu = 0.;
+    if (need_rows) L[(size_t)i * n_pred + i] = 1.;
+    for (int j = 0; j < m; ++j) {
+      const int c = nn_pred[(size_t)i * m + j];
+      if (c < 0) continue;
+      if (c >= n_obs + i) return set_error("GPB_HIP_PredictCondAllHost: row %d has neighbour %d that does not precede it", i, c);
+      const double a = A_pred[(size_t)i * m + j];
+      if (c < n_obs) mu += a * y_obs[c];
+      else {
+        const int q = c - n_obs;
+        mu += a * mean_out[q];
+        if (need_rows) for (int k = 0; k <= q; ++k) L[(size_t)i * n_pred + k] += a * L[(size_t)q * n_pred + k];
+      }
+    }
+    mean_out[i] = mu;
+  }
+  if (need_rows) {
+    for (int i = 0; i < n_pred; ++i) {
+      for (int k = cov_out ? 0 : i; k <= i; ++k) {
+        double sacc = 0.;
+        for (int j = 0; j <= k; ++j) sacc += L[(size_t)i * n_pred + j] * D_pred[j] * L[(size_t)k * n_pred + j];
+        double v = sigma2 * sacc;
+        if (i == k && !predict_response) v -= sigma2;
+        if (cov_out) { cov_out[(size_t)i * n_pred + k] = v; cov_out[(size_t)k * n_pred + i] = v; }
+        if (var_out && i == k) var_out[i] = v;
+      }
+    }
+  }
+  C_API_END();
+}
+
 /* c_api.h:1588-1610 -- only what the obs-only Vecchia prediction needs is kept: coordinates, prediction type, #neighbours */
 int GPB_SetPredictionData(REModelHandle handle, int32_t num_data_pred, const int32_t* cluster_ids_data_pred, const char* re_group_data_pred,
                           const double* re_group_rand_coef_data_pred, double* gp_coords_data_pred, const double* gp_rand_coef_data_pred,
@@ -826,7 +875,7 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll || !grad3 || !cov_pars) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: null argument");
-  if (mdl->likelihood != "gaussian") return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the Laplace approximation are not on the MI355X hot path of this library yet");
+  if (mdl->likelihood != "gaussian") return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: Gaussian likelihood only (the gradient of the Laplace approximation is behind GPB_OptimCovPar and gpb_hip_vecchia_laplace_grad_current)");
   if (mdl->eh) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the exact (dense) GP are not on the MI355X hot path of this library yet");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;

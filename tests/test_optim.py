@@ -211,6 +211,50 @@ def test_r_suite_probit_fit_within_the_iterative_tolerance(lib_built):
     assert np.abs(np.array([th[0], 1.0 / th[1]]) - [0.6875476, 0.1062862]).sum() < 0.02       # seen: 0.007
 
 
+def test_cond_all_prediction_host_half_reproduces_the_r_goldens(lib_built):
+    """GPB_HIP_PredictCondAllHost (forward substitution with Bp, rows of Bp^-1) fed with the oracle's factor rows of the appended prediction
+    points: test_GPModel_gaussian_process.R:1478-1485 (30 neighbours: the two points 1.4e-5 apart get covariance 0.09889262) and
+    :1241-1258 (all observations: the exact GP's joint predictive distribution)."""
+    from oracle import orc
+    lib = C.CDLL(lib_built)
+    coords, y = orc.r_fixture()
+    pt = orc.transform_cov_pars(0, np.array([0.02, 1.2, 0.9]))
+    cases_ = [(np.array([[0.1, 0.9], [0.10001, 0.90001], [0.7, 0.55]]), 30, [0.08665472, 0.08661259, 0.49011216],
+               [0.11891004, 0.09889262, 0., 0.09889262, 0.11891291, 0., 0., 0., 0.08108126]),
+              (np.array([[0.1, 0.9], [0.2, 0.4], [0.7, 0.55]]), len(y) + 2, [0.08704577, 1.63875604, 0.48513581],
+               [1.189093e-01, 1.171632e-05, -4.172444e-07, 1.171632e-05, 7.427727e-02, 1.492859e-06, -4.172444e-07, 1.492859e-06, 8.107455e-02])]
+    for ct_, m_pred, mu_ref, cov_ref in cases_:
+        n_obs, n_pred = len(y), len(ct_)
+        call = np.vstack([coords, ct_])
+        nn = orc.neighbors_range(call, m_pred, n_obs, -1)
+        A, D, bad = orc.vecchia_factor(call, nn, 0, pt[1], pt[2], gauss=True)
+        nnp = np.ascontiguousarray(nn[n_obs:], dtype=np.int32); Ap = np.ascontiguousarray(A[n_obs:]); Dp = np.ascontiguousarray(D[n_obs:])
+        mu = np.empty(n_pred); var = np.empty(n_pred); cov = np.empty((n_pred, n_pred))
+        for resp in (True, False):
+            rc = lib.GPB_HIP_PredictCondAllHost(C.c_int(n_obs), C.c_int(n_pred), C.c_int(nnp.shape[1]), nnp.ctypes.data_as(C.c_void_p),
+                                                Ap.ctypes.data_as(C.c_void_p), Dp.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                                C.c_double(pt[0]), C.c_bool(resp), mu.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p),
+                                                cov.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            assert np.abs(mu - mu_ref).sum() < 1e-6
+            expect = np.array(cov_ref).reshape(n_pred, n_pred) - (0. if resp else 0.02) * np.eye(n_pred)
+            assert np.abs(cov - expect).sum() < 1e-6
+            np.testing.assert_allclose(var, np.diag(cov), rtol=0, atol=0)
+        om, oc = orc.predict_cond_all(coords, y, ct_, 0, pt, m_pred, predict_response=False)
+        np.testing.assert_allclose(mu, om, rtol=1e-12); np.testing.assert_allclose(cov, oc, rtol=1e-10, atol=1e-14)
+    # variances only; a neighbour that does not precede its row is refused
+    rc = lib.GPB_HIP_PredictCondAllHost(C.c_int(n_obs), C.c_int(n_pred), C.c_int(nnp.shape[1]), nnp.ctypes.data_as(C.c_void_p),
+                                        Ap.ctypes.data_as(C.c_void_p), Dp.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                        C.c_double(pt[0]), C.c_bool(False), mu.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), None)
+    assert rc == 0
+    np.testing.assert_allclose(var, np.diag(cov), rtol=1e-14)
+    bad_nn = nnp.copy(); bad_nn[0, 0] = n_obs + 1
+    rc = lib.GPB_HIP_PredictCondAllHost(C.c_int(n_obs), C.c_int(n_pred), C.c_int(nnp.shape[1]), bad_nn.ctypes.data_as(C.c_void_p),
+                                        Ap.ctypes.data_as(C.c_void_p), Dp.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                        C.c_double(pt[0]), C.c_bool(False), mu.ctypes.data_as(C.c_void_p), None, None)
+    assert rc == -1
+
+
 def test_host_optimiser_errors(lib_built):
     from tests import optim_harness as oh
     lib = C.CDLL(lib_built)
