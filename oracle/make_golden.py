@@ -169,7 +169,7 @@ def optim_laplace_fixture(out_dir):
         mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=oc["lik"])
         if oc["cfg"]:
             mdl.set_optim_config(**oc["cfg"])
-        mdl.optim_cov_par(y)
+        mdl.optim_cov_par(y, cases.laplace_fixed_effects(coords) if oc.get("fe") else None)
         res[name + "_cov_pars"] = mdl.get_cov_par(2)
         res[name + "_init_cov_pars"] = mdl.get_init_cov_par()[:2].copy()
         res[name + "_num_it"] = np.int32(mdl.get_num_it())

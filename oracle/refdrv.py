@@ -134,9 +134,10 @@ class RefCAPIModel(object):
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 
-    def optim_cov_par(self, y):
+    def optim_cov_par(self, y, fixed_effects=None):
         y = np.ascontiguousarray(y, dtype=np.float64)
-        rc = self.L.GPB_OptimCovPar(self.h, _P(y), C.c_void_p())
+        fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+        rc = self.L.GPB_OptimCovPar(self.h, _P(y), C.c_void_p() if fe is None else _P(fe))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 

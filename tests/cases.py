@@ -215,6 +215,9 @@ OPTIM_LAPLACE_CASES = {
     "poisson_n1500_lbfgs": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(), exact_it=True),
     "poisson_n1500_gd_nesterov": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(optimizer_cov="gradient_descent"), exact_it=False),
     "logit_u3d_n1200_lbfgs": dict(model="lap_u3d_n1200_mat25_m15", lik="bernoulli_logit", cfg=dict(), exact_it=True),
+    # with fixed effects (offset of the location parameter: how the boosting loop passes the ensemble's scores)
+    "logit_n1500_lbfgs_fe": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", cfg=dict(), exact_it=True, fe=True),
+    "poisson_n1500_lbfgs_fe": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(), exact_it=True, fe=True),
 }
 
 

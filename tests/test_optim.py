@@ -179,7 +179,8 @@ def test_host_optimiser_for_non_gaussian_likelihoods_follows_the_reference(lib_b
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     rc_ = [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct]
     init = g[name + "_init_cov_pars"]
-    ev = oh.OracleLaplaceEvaluator(orc, co, nn, ct, y[perm], oc["lik"])
+    fe = cases.laplace_fixed_effects(coords)[perm] if oc.get("fe") else None
+    ev = oh.OracleLaplaceEvaluator(orc, co, nn, ct, y[perm], oc["lik"], fixed_effects_ord=fe)
     th, nit, nll, ne = oh.optimize_laplace(C.CDLL(lib_built), [init[0], rc_ / init[1]], ev, **_cfg_kwargs(oc["cfg"]))
     ref_it = int(g[name + "_num_it"])
     if oc["exact_it"]:

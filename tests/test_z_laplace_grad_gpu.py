@@ -98,7 +98,7 @@ def test_fit_for_non_gaussian_likelihoods_follows_the_reference(gpb, name):
                       num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
     params = dict(oc["cfg"])
     params["init_cov_pars"] = g[name + "_init_cov_pars"]
-    mdl.fit(y, params=params)
+    mdl.fit(y, params=params, fixed_effects=cases.laplace_fixed_effects(coords) if oc.get("fe") else None)
     ref_it = int(g[name + "_num_it"])
     cp = mdl.get_cov_pars()
     nll = mdl.get_current_neg_log_likelihood()
