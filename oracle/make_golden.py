@@ -178,6 +178,20 @@ def optim_laplace_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "optim_laplace_ref.npz"), **res)
 
 
+def laplace_grad_F_fixture(out_dir):
+    """The reference's boosting gradient for non-Gaussian data (REModel::CalcGradient, data order) at the first parameters of the three
+    Laplace cases, with the fixed effects of the other fixtures, for logit / probit / Poisson."""
+    res = {}
+    for name, c in cases.LAPLACE_CASES.items():
+        for lik in ("bernoulli_logit", "bernoulli_probit", "poisson"):
+            coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+            g = refdrv.ref_laplace_grad_F(coords, y, c["cov_pars"][0], lik, cases.laplace_fixed_effects(coords), c["cov_function"], c["shape"],
+                                          c["m"], c["ordering"], c["seed"])
+            res["%s_%s_gradF" % (name, lik)] = g
+            print("laplace grad F", name, lik, np.abs(g).max(), flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_gradF_ref.npz"), **res)
+
+
 def fisher_fixture(out_dir):
     """Standard errors of the covariance parameters (GPB_GetCovPar(calc_std_dev = true) after the reference's own fit; stochastic Fisher
     information with the default 50 probe vectors, seed 1, first model of the process = run id 0).  One process per case."""
@@ -228,6 +242,8 @@ def hist_fixture(out_dir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad_F":
+        laplace_grad_F_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "fisher":
         fisher_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_laplace":

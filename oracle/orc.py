@@ -373,6 +373,29 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
 # ---------------------------------------------------------------------------
 # High-level mirror of GPModel(gp_approx="vecchia").neg_log_likelihood for tests
 # ---------------------------------------------------------------------------
+def vecchia_laplace_grad_F(coords, nn, cov_type, var, a, y01, likelihood="bernoulli_logit", fixed_effects=None, **kw):
+    """Boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF, Vecchia order
+    (Likelihood::CalcGradNegMargLikelihoodLaplaceApproxVecchia with calc_F_grad, include/GPBoost/likelihoods.h:6996-7001):
+        -d log p / d loc  +  d_mll_d_mode  -  W .* (Sigma^-1 + W)^-1 d_mll_d_mode,     d_mll_d_mode = 0.5 d logdet / d mode,
+    from the by-products of vecchia_laplace_grad.  Checker only (no device path yet)."""
+    from scipy.stats import norm
+    negll, g, parts = vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, likelihood=likelihood, fixed_effects=fixed_effects,
+                                           want_parts=True, **kw)
+    y = np.asarray(y01, dtype=np.float64)
+    loc = parts["mode"] + (0.0 if fixed_effects is None else np.asarray(fixed_effects, dtype=np.float64))
+    if likelihood == "bernoulli_logit":
+        p = 1.0 / (1.0 + np.exp(-loc)); first = y - p; W = p * (1.0 - p)
+    elif likelihood == "poisson":
+        e = np.exp(loc); first = y - e; W = e
+    elif likelihood == "bernoulli_probit":
+        z = np.where(y > 0, loc, -loc)
+        r = np.exp(norm.logpdf(z) - norm.logcdf(z)); first = np.where(y > 0, r, -r); W = r * (z + r)
+    else:
+        raise ValueError(likelihood)
+    d_mll_d_mode = 0.5 * parts["dlogdet_dmode"]
+    return -first + d_mll_d_mode - W * parts["implicit_solve"]
+
+
 def vecchia_setup(coords, m, ordering="random", seed=0):
     """Ordering + neighbour search (src/GPBoost/Vecchia_utils.cpp:1095-1221).
     Returns (perm, coords_ordered, nn)."""

@@ -300,4 +300,20 @@ int refdrv_train_tree(int n, int F, const double* X_rowmajor, const char* params
   }
 }
 
+/* Boosting gradient for non-Gaussian data: d(-approximate marginal log-likelihood) / dF at the fixed effects F (REModel::CalcGradient ->
+ * CalcGradientF -> CalcGradFLaplace, re_model_template.h:3298-3321), data order.  h is a handle of the reference's own C API
+ * (GPB_CreateREModel of lib_gpboost_ref.so = REModel*) whose covariance parameters have been set (GPB_SetOptimConfig(init_cov_pars)). */
+__attribute__((visibility("default")))
+int refdrv_laplace_grad_F(void* h, const double* y, const double* fixed_effects, double* grad_out) {
+  try {
+    auto* m = reinterpret_cast<REModel*>(h);
+    m->SetY(y);
+    m->CalcGradient(grad_out, fixed_effects, true);
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_laplace_grad_F: %s\n", e.what());
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -190,6 +190,23 @@ def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponent
     return res[1]
 
 
+def ref_laplace_grad_F(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
+                       threads=8):
+    """The reference's boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF in data order, at cov_pars =
+    (sigma1^2, rho) and the fixed effects F (zero if None): REModel::CalcGradient on a model of the reference's own C API (ref_driver.cpp:
+    refdrv_laplace_grad_F)."""
+    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
+    mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64))
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    fe = np.zeros_like(y) if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+    out = np.empty_like(y)
+    fn = _lib().refdrv_laplace_grad_F
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if fn(mdl.h, y.ctypes.data, fe.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("refdrv_laplace_grad_F failed")
+    return out
+
+
 def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False, extra_params="", split_cfg=None,
                   partitions=None):
     """The reference's own binning + Dataset::ConstructHistograms for one leaf.

@@ -458,3 +458,24 @@ def test_stage_tolerances_admit_one_block_cg_iteration(orc, n, d, m, ct, lik):
     _, g2, parts2 = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=lik, want_parts=True, cg_max_num_it_tridiag=k - 1)
     assert not np.array_equal(g2, gref)
     check_stages(g2, parts2, gref, oparts)
+
+
+# ---- boosting gradient for non-Gaussian data (d(-mll)/dF) -- checker only, no device path yet ----------------------------------
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_oracle_boosting_gradient_matches_the_reference(orc, name, lik):
+    """orc.vecchia_laplace_grad_F against REModel::CalcGradient of the reference (tests/golden/laplace_gradF_ref.npz,
+    oracle/make_golden.py laplace_grad_F): -d log p / d loc + 0.5 d logdet / d mode - W .* (implicit solve), with fixed effects.  The
+    implicit solve is a CG that stops at |r| < 1e-2 (seen: 3e-7 of the gradient's scale)."""
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_gradF_ref.npz"))
+    coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+    fe = cases.laplace_fixed_effects(coords)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    gF = orc.vecchia_laplace_grad_F(co, nn, ct, cp[0], a, y[perm], likelihood=lik, fixed_effects=fe[perm])
+    out = np.empty_like(gF); out[perm] = gF
+    ref = g["%s_%s_gradF" % (name, lik)]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
