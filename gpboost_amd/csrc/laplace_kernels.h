@@ -45,6 +45,7 @@ hipError_t lap_logsums(const double* D, const double* dw, int n, double* out2, h
 hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStream_t st);
 // ---- gradient of the approximate marginal likelihood (block vectors: ncol chunks of nc columns, as above) ----
 hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st);
+hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st);
 hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st);
 hipError_t lap_mul(const LapTri& T, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);       // plain product with T's entries
 hipError_t lap_row_stats(const double* U, const double* PIZ, const double* BPIZ, const double* dW3, const double* rdw, int n, int t, int nc, double* dld, hipStream_t st);

@@ -618,6 +618,18 @@ __global__ void lik_third_kernel(const double* __restrict__ mode, const int* __r
   if (i < n) dW3[i] = lik_third<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i]);
 }
 
+// boosting gradient for non-Gaussian data, d(-mll) / dF = -d log p / d loc + 0.5 d logdet / d mode - W .* (Sigma^-1 + W)^-1 d_mll_d_mode
+// (likelihoods.h:6996-7001), from the vectors the covariance-parameter gradient leaves behind
+template <int LINK>
+__global__ void lik_grad_F_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ dld,
+                                  const double* __restrict__ sv, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double gr, w;
+  lik_grad_info<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i], gr, w);
+  out[i] = -gr + 0.5 * dld[i] - w * sv[i];
+}
+
 // dA_i / d log(a) and dD_i / d log(a) of the Vecchia factor WITHOUT nugget (Vecchia_utils.cpp:1640-1652; the range parameter is the only
 // one whose derivative of A is not zero): one wavefront per point, C_nn in LDS, lane = row.
 //   t = dc - dC A_i,  dA_i = C^-1 t (Cholesky of the jittered C_nn),  dD_i = -(dA_i . c + A_i . dc)
@@ -890,6 +902,12 @@ hipError_t lap_third_deriv(int link, const double* mode, const int* y, const dou
   if (link == 0) hipLaunchKernelGGL(lik_third_kernel<0>, GRID1(n), 0, st, mode, y, fe, n, dW3);
   else if (link == 1) hipLaunchKernelGGL(lik_third_kernel<1>, GRID1(n), 0, st, mode, y, fe, n, dW3);
   else hipLaunchKernelGGL(lik_third_kernel<2>, GRID1(n), 0, st, mode, y, fe, n, dW3);
+  return hipGetLastError();
+}
+hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st) {
+  if (link == 0) hipLaunchKernelGGL(lik_grad_F_kernel<0>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
+  else if (link == 1) hipLaunchKernelGGL(lik_grad_F_kernel<1>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
+  else hipLaunchKernelGGL(lik_grad_F_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
   return hipGetLastError();
 }
 hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st) {

@@ -177,6 +177,11 @@ class VecchiaState(object):
         lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
 
+    def laplace_set_fixed_effects(self, fixed_effects):
+        """Offset of the location parameter, Vecchia order (None removes it)."""
+        fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_fixed_effects(self.h, _p(fe)))
+
     def laplace_set_labels(self, y01):
         y01 = np.ascontiguousarray(y01, dtype=np.int32)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_labels(self.h, _p(y01, C.c_int)))
@@ -209,6 +214,12 @@ class VecchiaState(object):
         if want_parts:
             return -o[0], g, dict(per_par=parts.reshape(2, 4), dlogdet_dmode=vecs[:self.n], implicit_solve=vecs[self.n:])
         return -o[0], g
+
+    def laplace_grad_F(self):
+        """Boosting gradient d(-mll)/dF (Vecchia order) at the state of the last laplace_eval_grad (gpb_hip_vecchia_laplace_grad_F_current)."""
+        out = np.empty(self.n)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_grad_F_current(self.h, _p(out)))
+        return out
 
     def laplace_reset_mode_to_previous(self):
         _shim_call(_lib().gpb_hip_vecchia_laplace_reset_mode_to_previous(self.h))

@@ -236,6 +236,11 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_eval(gpb_hip_vecchia_t* h, int cov_ty
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_current(gpb_hip_vecchia_t* h, int cg_max_num_it, double cg_delta_conv,
                                                         double* grad2_host, double* parts8_host, double* vecs2n_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h);
+/* Boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF in Vecchia order, at the state of the last
+ * grad_current: -d log p / d loc + 0.5 d logdet / d mode - W .* (Sigma^-1 + W)^-1 (0.5 d logdet / d mode)
+ * (CalcGradNegMargLikelihoodLaplaceApproxVecchia with calc_F_grad, likelihoods.h:6996-7001; what REModel::CalcGradient hands to the
+ * boosting objective for non-Gaussian likelihoods, re_model_template.h:3298-3321). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* gradF_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_range_deriv(gpb_hip_vecchia_t* h, int cov_type, double var, double a, double* dA_host,
                                                        double* dD_host);
 

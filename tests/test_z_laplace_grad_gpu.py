@@ -158,3 +158,30 @@ def test_fit_with_parameters_held_fixed_r_goldens(gpb, est):
     cp, nll_ref = R_FIXED_PAR_GOLDENS[est]
     assert np.abs(mdl.get_cov_pars() - cp).sum() < 1e-6
     assert abs(mdl.get_current_neg_log_likelihood() - nll_ref) < 1e-6
+
+
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
+def test_boosting_gradient_matches_the_reference(gpb, orc, name, lik):
+    """d(-mll)/dF on the device (gpb_hip_vecchia_laplace_grad_F_current) against the reference's REModel::CalcGradient with fixed effects
+    (tests/golden/laplace_gradF_ref.npz; the oracle agrees with it to 3e-7 of the scale, tests/test_oracle_golden.py).  The implicit solve
+    is a CG that stops at |r| < 1e-2: 1e-4 of the scale."""
+    from gpboost_amd import shim
+    c = cases.LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_gradF_ref.npz"))
+    coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+    fe = cases.laplace_fixed_effects(coords)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood(lik)
+    st.laplace_set_labels(y[perm].astype(np.int32))
+    st.laplace_set_fixed_effects(fe[perm])
+    st.laplace_eval_grad(ct, cp[0], RC[ct] / cp[1])
+    gF = st.laplace_grad_F()
+    out = np.empty_like(gF); out[perm] = gF
+    ref = g["%s_%s_gradF" % (name, lik)]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4 * np.abs(ref).max())
+    st.close()
