@@ -5,7 +5,8 @@
   * the reference's own fits (tests/golden/optim_laplace_ref.npz).
 Tolerances as for the oracle against the same fixtures (tests/test_oracle_golden.py, tests/test_optim.py): the gradient contains a CG
 solve that stops at |r| < 1e-2, whose iteration count can move with rounding -> 1e-5.
-(File name: sorts after the other GPU files, so that the established paths report first under `pytest -x`.)"""
+(File name: sorts after the other GPU files, and inside the file the tests that have passed on the MI355X come first, so that the
+established paths report first under `pytest -x`.)"""
 import os
 
 import numpy as np
@@ -45,30 +46,6 @@ def test_range_derivative_of_the_factor_matches_the_oracle(gpb, orc, n, d, m, ct
 
 
 @pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
-@pytest.mark.parametrize("n,d,m,ct", [(3000, 2, 30, 0), (2000, 2, 10, 1), (1500, 3, 20, 2)])
-def test_gradient_against_oracle_step_by_step(gpb, orc, n, d, m, ct, lik):
-    from gpboost_amd import shim
-    coords, y = cases.synthetic_binary(n, d, seed=600 + n)
-    if lik == "poisson":
-        y = np.random.default_rng(7).poisson(1.0 + y).astype(np.float64)
-    perm, co, nn = orc.vecchia_setup(coords, m, "random", 4)
-    var, a = 0.9, RC[ct] / 0.15
-    st = shim.VecchiaState(co, m)
-    st.set_neighbors(nn)
-    st.laplace_set_likelihood(lik)
-    st.laplace_set_labels(y[perm].astype(np.int32))
-    negll, g, parts = st.laplace_eval_grad(ct, var, a, want_parts=True)
-    ref, gref, oparts = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=lik, want_parts=True)
-    assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
-    from tests.laplace_grad_harness import check_stages
-    check_stages(g, parts, gref, oparts)
-    # the gradient of the same state again: same numbers bit for bit (fixed reduction orders)
-    _, g2 = st.laplace_eval_grad(ct, var, a)
-    assert np.array_equal(g, g2)
-    st.close()
-
-
-@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
 @pytest.mark.parametrize("name", sorted(cases.LAPLACE_CASES))
 def test_gradient_matches_the_reference_optimisers_step(gpb, orc, name, lik):
     from gpboost_amd import shim
@@ -87,7 +64,7 @@ def test_gradient_matches_the_reference_optimisers_step(gpb, orc, name, lik):
     st.close()
 
 
-@pytest.mark.parametrize("name", sorted(cases.OPTIM_LAPLACE_CASES))
+@pytest.mark.parametrize("name", sorted(cases.OPTIM_LAPLACE_CASES, key=lambda k: (bool(cases.OPTIM_LAPLACE_CASES[k].get("fe")), k)))
 def test_fit_for_non_gaussian_likelihoods_follows_the_reference(gpb, name):
     """GPModel.fit -> GPB_OptimCovPar with everything but the optimiser's control flow on the device, against the reference's own fits."""
     g = np.load(os.path.join(GOLD, "optim_laplace_ref.npz"))
@@ -113,6 +90,46 @@ def test_fit_for_non_gaussian_likelihoods_follows_the_reference(gpb, name):
     np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-14)
 
 
+def test_fit_errors_and_iteration_cap(gpb):
+    coords, y = cases.synthetic_binary(400, 2, seed=5)
+    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10,
+                      vecchia_ordering="none")
+    with pytest.raises(gpb.GPBoostError, match="positive"):
+        mdl.fit(y, params={"init_cov_pars": [1.0, -0.1]})
+    with pytest.raises(gpb.GPBoostError, match="needs to be 0 or 1"):
+        mdl.fit(y + 0.5, params={"init_cov_pars": [1.0, 0.1]})
+    mdl.fit(y, params={"init_cov_pars": [1.0, 0.1], "maxit": 2})
+    assert mdl.get_num_optim_iter() <= 2
+    cp = mdl.get_cov_pars()
+    assert cp.shape == (2,) and np.all(np.isfinite(cp)) and np.all(cp > 0)
+    v = mdl.neg_log_likelihood(cp, y)
+    assert np.isfinite(v)
+
+
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
+@pytest.mark.parametrize("n,d,m,ct", [(3000, 2, 30, 0), (2000, 2, 10, 1), (1500, 3, 20, 2)])
+def test_gradient_against_oracle_step_by_step(gpb, orc, n, d, m, ct, lik):
+    from gpboost_amd import shim
+    coords, y = cases.synthetic_binary(n, d, seed=600 + n)
+    if lik == "poisson":
+        y = np.random.default_rng(7).poisson(1.0 + y).astype(np.float64)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 4)
+    var, a = 0.9, RC[ct] / 0.15
+    st = shim.VecchiaState(co, m)
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood(lik)
+    st.laplace_set_labels(y[perm].astype(np.int32))
+    negll, g, parts = st.laplace_eval_grad(ct, var, a, want_parts=True)
+    ref, gref, oparts = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=lik, want_parts=True)
+    assert abs(negll - ref) <= 1e-8 * abs(ref), (negll, ref)
+    from tests.laplace_grad_harness import check_stages
+    check_stages(g, parts, gref, oparts)
+    # the gradient of the same state again: same numbers bit for bit (fixed reduction orders)
+    _, g2 = st.laplace_eval_grad(ct, var, a)
+    assert np.array_equal(g, g2)
+    st.close()
+
+
 def test_fit_from_the_reference_initial_values(gpb):
     """No init_cov_pars: marginal variance 1 and the range heuristic with the model's generator state (FindInitCovPar; the host part is
     pinned on the CPU by tests/test_optim.py::test_find_init_cov_par_for_non_gaussian_likelihoods) -- the reference's own starting point,
@@ -128,22 +145,6 @@ def test_fit_from_the_reference_initial_values(gpb):
     np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-7)
     assert abs(mdl.get_num_optim_iter() - int(g[name + "_num_it"])) <= 1
     np.testing.assert_allclose(mdl.get_cov_pars(), g[name + "_cov_pars"], rtol=1e-3)
-
-
-def test_fit_errors_and_iteration_cap(gpb):
-    coords, y = cases.synthetic_binary(400, 2, seed=5)
-    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10,
-                      vecchia_ordering="none")
-    with pytest.raises(gpb.GPBoostError, match="positive"):
-        mdl.fit(y, params={"init_cov_pars": [1.0, -0.1]})
-    with pytest.raises(gpb.GPBoostError, match="needs to be 0 or 1"):
-        mdl.fit(y + 0.5, params={"init_cov_pars": [1.0, 0.1]})
-    mdl.fit(y, params={"init_cov_pars": [1.0, 0.1], "maxit": 2})
-    assert mdl.get_num_optim_iter() <= 2
-    cp = mdl.get_cov_pars()
-    assert cp.shape == (2,) and np.all(np.isfinite(cp)) and np.all(cp > 0)
-    v = mdl.neg_log_likelihood(cp, y)
-    assert np.isfinite(v)
 
 
 @pytest.mark.parametrize("est", [(1, 0, 0), (1, 1, 0), (0, 1, 0)])
