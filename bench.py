@@ -26,14 +26,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-# (r01_b_kernel_v2_rocprofv3_summary.txt: FETCH_SIZE 1.24776e6 KB + WRITE_SIZE 5.86e3 KB per dispatch, separate --pmc passes,
-# n = 1e6, m = 30, d = 2, one GPU; gathers are 32-byte records, so the guide's 2x correction for wide coalesced streams is
-# not applied).  Reported only for exactly that configuration; otherwise null.
-PROFILED_TRAFFIC_BYTES = {(1000000, 30, 2, 1): (1.24776e6 + 5.86e3) * 1024}
-# hist_build_kernel<const hessian, all rows> at n = 1e7, F = 50 (profiles/r01_i_hist_pmc_summary.txt: FETCH_SIZE 631486 KB + WRITE_SIZE
-# 110592 KB per dispatch, separate --pmc passes; before the XCD-aware workgroup order FETCH_SIZE was 1.41e6 KB)
-PROFILED_HIST_TRAFFIC_BYTES = {(10000000, 50): (631486 + 110592) * 1024}
+# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in KB, separate --pmc
+# passes, collected by scripts/profile_r02.sh on scripts/gpu_pmc_target.py = exactly these configurations).  The point kernel's
+# gathers are 32-byte records, the histogram's row reads 16 B per lane: the guide's x2 correction (FETCH_SIZE halves wide coalesced
+# 16 B/lane streams on gfx950) is applied to the histogram's bin stream only -- see DESIGN.md section 6.  None when no summary is there.
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def profiled_traffic_bytes(kernel_substr):
+    try:
+        with open(PMC_JSON) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    for name, c in pmc.items():
+        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
 
@@ -49,30 +60,44 @@ def algorithmic_flops_per_point(m, d, cov_type):
     return m ** 3 / 3.0 + 2 * m * m + (m * (m + 1) / 2.0) * (3 * d + ck) + 4 * m
 
 
+def _omp_set_num_threads(k):
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(k))
+    except OSError:
+        pass
+
+
 def cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n_full):
-    """Reference CPU path on a bounded sample (first n_s points), scaled linearly in n to the metric's unit."""
-    n_s = min(len(y), 100000)
-    cores = os.cpu_count() or 1
+    """The reference's CPU path (oracle/_ref: the unmodified reference's GPB_EvalNegLogLikelihood, kind "reference"; the C restatement,
+    kind "port", when oracle/_ref is absent) timed DIRECTLY at the metric's n (no scaling) at several OpenMP thread counts; the best is
+    reported with its count.  Bounded: one model creation + one evaluation per thread count (about 20-40 s of wall time in total)."""
+    n_s = len(y)
+    hw = os.cpu_count() or 1
+    counts = sorted({c for c in (8, 32, 64, hw) if c <= hw})
     from oracle import refdrv
     if refdrv.available():
-        mdl = refdrv.RefCAPIModel(coords[:n_s], cov_function, shape, m, "random", 1, threads=-1)
-        f = lambda cp: mdl.neg_log_likelihood(cp, y[:n_s])
+        mdl = refdrv.RefCAPIModel(coords, cov_function, shape, m, "random", 1, threads=hw)
+        f = lambda cp: mdl.neg_log_likelihood(cp, y)
         kind = "reference"
     else:
         from oracle import orc
-        ct = orc.cov_type_id(cov_function, shape)
-        setup = orc.vecchia_setup(coords[:n_s], m, "random", 1)
-        f = lambda cp: orc.gp_nll(coords[:n_s], y[:n_s], cp, cov_function, shape, m, setup=setup)
+        _omp_set_num_threads(hw)
+        setup = orc.vecchia_setup(coords, m, "random", 1)
+        f = lambda cp: orc.gp_nll(coords, y, cp, cov_function, shape, m, setup=setup)
         kind = "port"
-    f(cov_pars)   # warm-up
-    ts = []
-    for k in range(3):
+    times = {}
+    budget_t0 = time.perf_counter()
+    for k, c in enumerate(reversed(counts)):     # most threads first (doubles as the warm-up of the pages)
+        if time.perf_counter() - budget_t0 > 60.0 and times:
+            break
+        _omp_set_num_threads(c)
         cp = cov_pars * (1.0 + 0.01 * (k + 1))
-        t0 = time.perf_counter(); f(cp); ts.append(time.perf_counter() - t0)
-    s_per_eval = float(np.median(ts))
-    return {"value": (1.0 / s_per_eval) * (n_s / float(n_full)), "unit": "evals/s", "cores": cores, "kind": kind,
-            "sample": "n=%d subset of the same synthetic data (m=%d, same kernel), median of 3 evals = %.3f s, "
-                      "scaled by %d/%d to n=%d (cost is linear in n)" % (n_s, m, s_per_eval, n_s, n_full, n_full)}
+        t0 = time.perf_counter(); f(cp); times[c] = time.perf_counter() - t0
+    best = min(times, key=times.get)
+    return {"value": 1.0 / times[best], "unit": "evals/s", "cores": best, "kind": kind,
+            "sample": "n=%d (the metric's size, no scaling), m=%d, one evaluation per OpenMP thread count; seconds per evaluation: %s; "
+                      "best at %d threads of %d hardware threads" % (n_s, m, ", ".join("%d thr %.2f s" % (c, times[c]) for c in sorted(times)), best, hw)}
 
 
 def main():
@@ -124,7 +149,9 @@ def main():
     t_setup = time.perf_counter() - t0
     perm, _ = mdl.vecchia_structure()
     st = shim.VecchiaState.from_handle(mdl.vecchia_handle(), n, d, m)
-    st.set_y(y[perm])                                  # resident in HBM before the timed region
+    # y is uploaded ONCE (this call; GPB_EvalNegLogLikelihood with a host pointer permutes it to the Vecchia order and copies it to
+    # HBM) and stays resident: every timed evaluation passes y_data = NULL (re_model_template.h:2905-2921)
+    mdl.neg_log_likelihood(cov_pars, y)
     i0, i1 = parallel.shard_range(n, rank, world)
     st.set_shard(i0, i1)
 
@@ -151,19 +178,20 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         native_rccl = bool(okt.item() == 1)
 
-    def one_eval(k):
+    def cov_pars_of(k):
         # covariance parameters change every evaluation (perturbed by <= 1 %): nothing is reusable between steps
-        var = var0 * (1.0 + 0.002 * ((k % 11) - 5))
-        a = a0 * (1.0 + 0.002 * ((k % 7) - 3))
-        if native_rccl:
-            t = st.nll_terms_allreduce(ct, var, a)
-        elif distributed:
-            st.nll_terms_dev(ct, var, a, tdev.data_ptr())
+        return np.array([sigma2, cov_pars[1] * (1.0 + 0.002 * ((k % 11) - 5)), cov_pars[2] / (1.0 + 0.002 * ((k % 7) - 3))])
+
+    def one_eval(k):
+        if distributed and not native_rccl:      # fallback only: shard terms on the device + torch.distributed all-reduce
+            cpk = cov_pars_of(k)
+            st.nll_terms_dev(ct, cpk[1] / cpk[0], a0 * cov_pars[2] / cpk[2], tdev.data_ptr())
             dist.all_reduce(tdev)
             t = tdev.cpu().numpy()
-        else:
-            t = st.nll_terms(ct, var, a)
-        return parallel.nll_from_terms(n, t[0], t[1], sigma2)
+            return parallel.nll_from_terms(n, t[0], t[1], sigma2)
+        # THE metric: wall time of GPB_EvalNegLogLikelihood(handle, y_data = NULL, cov_pars, NULL, &negll) -- on a sharded
+        # handle the library all-reduces the 3 shard sums over RCCL inside the call, every rank gets the job's value
+        return mdl.neg_log_likelihood(cov_pars_of(k))
 
     def sync():
         if distributed:
@@ -173,9 +201,10 @@ def main():
         else:
             st.sync()
 
-    # untimed pre-warm (set-up, not part of W): the first few hundred milliseconds after the neighbour search run at a
-    # lower clock / colder caches; the W warm-up steps the contract asks for follow it
-    for _ in range(200):     # fixed count: every rank must issue the same number of collectives
+    # untimed pre-warm (set-up, not part of W, stated in config.prewarm_evals): the first few hundred milliseconds after the
+    # neighbour search run at a lower clock / colder caches; the W warm-up steps the contract asks for follow it
+    PREWARM = 200            # fixed count: every rank must issue the same number of collectives
+    for _ in range(PREWARM):
         one_eval(0)
     for k in range(args.warmup):
         one_eval(k)
@@ -200,6 +229,8 @@ def main():
     achieved_gbs = bytes_launch / (ms_kernel * 1e-3) / 1e9
     achieved_tflops = flops_launch / (ms_kernel * 1e-3) / 1e12
 
+    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0>" % (m, ct, "true" if d == 3 else "false")) if (n, world) == (1000000, 1) else None
+    rccl_ranks = st.comm_info()[1] if native_rccl else 0
     if rank == 0:
         out = {
             "metric": "neg-log-lik evals/sec, n=%d Vecchia(m=%d) fp64" % (n, m),
@@ -215,21 +246,25 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "Vecchia GP Gaussian nll, n=%d, d=%d, %s, m=%d, vecchia_ordering=random" % (n, d, args.cov, m),
-                       "shard_points_per_gpu": npts, "parallelism": "points sharded x%d, all-reduce of 3 fp64 (%s)" % (world, "in-library RCCL" if native_rccl else ("torch.distributed nccl" if distributed else "single GPU")),
+                       "timed_call": ("GPB_EvalNegLogLikelihood(handle, y_data=NULL, cov_pars, fixed_effects=NULL, &negll) through ctypes: y resident in HBM, "
+                                      "parameters in, value out" if (not distributed or native_rccl) else "shard terms + torch.distributed all_reduce (fallback path)"),
+                       "shard_points_per_gpu": npts, "parallelism": "points sharded x%d, all-reduce of 3 fp64 (%s)" % (world, "in-library RCCL, %d ranks" % rccl_ranks if native_rccl else ("torch.distributed nccl" if distributed else "single GPU")),
+                       "rccl_ranks": rccl_ranks, "prewarm_evals": PREWARM,
                        "setup_s_model_creation_incl_device_neighbor_search": round(t_setup, 3),
                        "last_negll": last,
-                       "grad_eval_ms_kernel": round(ms_gkernel, 4)},
-            # The binding resource of the dominant kernel is the fp64 pipe (96 % VALU-busy), so the
-            # primary roofline is the compute one; fp64 vector and fp64 MFMA have the same 78.6 TFLOP/s peak on this part (the schema's
-            # label for the compute bound is "mfma"; the kernel issues v_fma_f64 / v_fmac_f64_dpp, not MFMA).  The HBM view that
-            # BASELINE.json's metric also asks for is `roofline_hbm`; `traffic` = FETCH_SIZE + WRITE_SIZE of the same launch (PMC).
-            "roofline": {"bound": "mfma", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": PROFILED_TRAFFIC_BYTES.get((n, m, d, world)),
-                         "kernel_ms": ms_kernel, "algorithmic_flops_per_launch": flops_launch,
-                         "note": "fp64-VALU bound (vector fp64 peak = fp64 MFMA peak = 78.6 TFLOP/s); exp / sqrt / division counted as ONE flop each: in issued fp64 instructions the pipe runs at ~73 % (DESIGN.md 4.1)"},
-            "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                             "traffic": PROFILED_TRAFFIC_BYTES.get((n, m, d, world)), "algorithmic_bytes_per_launch": bytes_launch,
-                             "note": "not the binding roofline: 0.864 GB of gathers per launch, coordinates live in L2 / Infinity Cache"},
+                       "grad_eval_ms_kernel": round(ms_gkernel, 4), "grad_over_nll_kernel_time": round(ms_gkernel / ms_kernel, 3)},
+            # BASELINE.json's metric asks for "% HBM roofline": the primary object is the HBM view of the dominant kernel (algorithmic gather
+            # bytes of SURVEY.md 8d / HIP-event kernel time / 8 TB/s).  The kernel is NOT HBM-bound -- it is bound by fp64 VALU issue
+            # (DESIGN.md 4.1); that view is `roofline_fp64_valu` (no MFMA is issued; vector fp64 peak 78.6 TFLOP/s).
+            # `traffic` = FETCH_SIZE + WRITE_SIZE of the same kernel from the PMC passes committed under profiles/ (read at run time).
+            "roofline": {"bound": "hbm", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch,
+                         "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                         "note": "binding resource is fp64 VALU issue, not HBM: see roofline_fp64_valu; 0.864 GB of gathers per launch, the 32 MB record array lives in L2 / Infinity Cache"},
+            "roofline_fp64_valu": {"bound": "fp64 vector ALU issue (no MFMA in this kernel)", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_tflops,
+                                   "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS, "kernel_ms": ms_kernel,
+                                   "algorithmic_flops_per_launch": flops_launch,
+                                   "note": "exp / sqrt / division counted as ONE flop each (SURVEY.md 8d); instruction mix: profiles/r02_*_instruction_mix.txt"},
         }
         if world == 1:
             # the one HBM-bound kernel of the path: dense covariance assembly (exact GP), measured live
@@ -267,7 +302,7 @@ def main():
                 out["roofline_histogram"] = {
                     "bound": "hbm", "kernel": "hist_build_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
-                    "algorithmic_bytes_per_launch": hbytes, "traffic": PROFILED_HIST_TRAFFIC_BYTES.get((nh, Fh)),
+                    "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_kernel<false, false>"),
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
                     "note": "bounded by LDS fp64 atomics (2 per row and feature), not by HBM: see DESIGN.md 4.4"}
                 hb.close()
@@ -290,7 +325,7 @@ def main():
                     "workload": "Bernoulli-logit Vecchia-Laplace nll (Newton + vadu-CG + SLQ, 50 probes), n=%d, m=30, exponential" % n4,
                     "s_per_eval": s4, "negll": v4, "newton_it": i4["newton_it"], "cg_it": i4["cg_it"], "lanczos_it": i4["lanczos_it"],
                     "ms_mode_finding": i4["ms_mode"], "ms_logdet": i4["ms_logdet"],
-                    "reference_s_per_eval": {"value": 26.3, "cores": 8, "where": "same inputs, unmodified reference in this repo's build container (DESIGN.md 4.6)"}}
+                    "reference_timing": "not timed here: tests/golden/config4_ref.npz holds the unmodified reference's value and its wall time for the same-size fixture (seconds_0; 8 cores of the build container)"}
                 del m4
             except Exception as e:
                 out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -349,7 +384,7 @@ def main():
                 t3["total_ms"] = sum(t3.values())
                 out["config3_boosting_iteration"] = dict(
                     workload="one GPBoost iteration, n=%d, F=%d, %d bins, %d leaves, Vecchia m=30 (5th iteration; synthetic bins in the reference's layout)" % (n3, F3, nb3, L3),
-                    reference_s_per_iteration={"value": 21.0, "cores": 8, "where": "SURVEY.md section 0 (survey box)"}, **{k: round(v, 3) for k, v in t3.items()})
+                    reference_timing="not timed here (SURVEY.md section 0 quotes ~21 s per iteration on the survey box's 8 cores)", **{k: round(v, 3) for k, v in t3.items()})
                 hb3.close(); del m3
             except Exception as e:
                 out["config3_boosting_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}

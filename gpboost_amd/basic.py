@@ -128,11 +128,12 @@ class GPModel(object):
     # --- reference surface -------------------------------------------------------------------
     def neg_log_likelihood(self, cov_pars=None, y=None, fixed_effects=None, aux_pars=None):
         """Evaluate the negative log-likelihood (reference: basic.py:5640-5700)."""
-        if y is None:
-            raise ValueError("'y' is required: the likelihood is evaluated at the response passed in")
-        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
-        if y.shape[0] != self.num_data:
-            raise ValueError("Incorrect number of data points in 'y'")
+        y_c = ctypes.c_void_p()        # None -> NULL: the response already resident on the device is used (C-level semantics of
+        if y is not None:              # GPB_EvalNegLogLikelihood, re_model_template.h:2905-2921: SetY only for a non-NULL y_data)
+            y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+            if y.shape[0] != self.num_data:
+                raise ValueError("Incorrect number of data points in 'y'")
+            y_c = _dptr(y)
         cp_c = ctypes.c_void_p()       # None: the stored (initial or estimated) parameters, as in the reference
         if cov_pars is not None:
             cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
@@ -146,7 +147,7 @@ class GPModel(object):
                 raise ValueError("Length of 'fixed_effects' is not correct ")
             fe_c = _dptr(fixed_effects)
         negll = ctypes.c_double(0)
-        _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, _dptr(y), cp_c, fe_c, ctypes.byref(negll)))
+        _safe_call(_lib().GPB_EvalNegLogLikelihood(self.handle, y_c, cp_c, fe_c, ctypes.byref(negll)))
         return negll.value
 
     _OPTIM_DEFAULTS = {   # basic.py:4528-4570 (self.params) -> GPB_SetOptimConfig; -999 / "" / "default" = the library's default

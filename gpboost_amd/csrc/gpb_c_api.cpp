@@ -120,6 +120,16 @@ int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr
   return 0;
 }
 
+// location parameter = mode + fixed effects (likelihoods.h:3861-3870), Vecchia order; NULL clears the offset
+int laplace_upload_fixed_effects(REModelHip* mdl, const double* fixed_effects) {
+  if (fixed_effects) {
+    std::vector<double> fe(mdl->n);
+    for (int k = 0; k < mdl->n; ++k) fe[k] = fixed_effects[mdl->perm[k]];
+    if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, fe.data())) return shim_error();
+  } else if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, nullptr)) return shim_error();
+  return 0;
+}
+
 // response (validated against the likelihood) and fixed effects of the Vecchia-Laplace path, Vecchia order
 int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
@@ -141,12 +151,8 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
   }
   if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : (poisson ? 2 : 0))) return shim_error();
   if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
-  if (fixed_effects) {                                  // location parameter = mode + fixed effects, Vecchia order
-    std::vector<double> fe(mdl->n);
-    for (int k = 0; k < mdl->n; ++k) fe[k] = fixed_effects[mdl->perm[k]];
-    if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, fe.data())) return shim_error();
-  } else if (gpb_hip_vecchia_laplace_set_fixed_effects(mdl->vh, nullptr)) return shim_error();
-  return 0;
+  mdl->y_set = true;
+  return laplace_upload_fixed_effects(mdl, fixed_effects);
 }
 
 // gpb_laplace_fn (gpb_optim.h) on the device: the stateful evaluator behind GPB_OptimCovPar for non-Gaussian likelihoods.  The mode stays
@@ -511,16 +517,19 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll) return set_error("GPB_EvalNegLogLikelihood: null argument");
   if (mdl->likelihood != "gaussian") {   // cov_pars = (sigma1_2, rho): no error variance (re_model_template.h:3191-3212)
-    if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
+    // y_data == NULL: the response of the last call that passed one (CHECK(y_has_been_set_), re_model_template.h:3183-3190)
+    if (!y_data && !mdl->y_set) return set_error("Check failed: y_has_been_set_ (GPB_EvalNegLogLikelihood: y_data is NULL and no response has been set)");
     double stored[2] = {0., 0.};
     if (!cov_pars) {                        // re_model.cpp:759-766: the stored (initial or estimated) parameters
-      if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+      if (y_data && initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+      if (!mdl->cov_pars_initialized) return set_error("Check failed: cov_pars_initialized_ (GPB_EvalNegLogLikelihood: cov_pars is NULL and no parameters are stored)");
       stored[0] = mdl->cov_pars_tr[0]; stored[1] = range_const(mdl) / mdl->cov_pars_tr[1];
       cov_pars = stored;
     }
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
-    if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
+    if (y_data) { if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1; }
+    else if (laplace_upload_fixed_effects(mdl, fixed_effects)) return -1;   // labels stay resident; the offset is this call's
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
                                       mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,
@@ -533,18 +542,26 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
   double tr[3];
   if (cov_pars) { if (transform_cov_pars(mdl, cov_pars, tr)) return -1; }
   else {                                            // re_model.cpp:759-766: the stored (initial or estimated) parameters
-    if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+    if (y_data && initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;
+    if (!mdl->cov_pars_initialized) return set_error("Check failed: cov_pars_initialized_ (GPB_EvalNegLogLikelihood: cov_pars is NULL and no parameters are stored)");
     std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, tr);
   }
-  if (upload_y(mdl, y_data, fixed_effects)) return -1;
+  if (y_data) { if (upload_y(mdl, y_data, fixed_effects)) return -1; }
+  else {
+    // y_data == NULL: the response already resident in HBM is used -- nothing crosses PCIe but the parameters and the value
+    // (EvalNegLogLikelihoodGauss calls SetY only for a non-NULL y_data, re_model_template.h:2905-2921; this is what the
+    //  reference's own optimiser and BASELINE.json's metric do between SetY calls)
+    if (fixed_effects) return set_error("EvalNegLogLikelihoodGauss: 'y_data' cannot nullptr when 'fixed_effects' is provided ");   // :2907-2909
+    if (!mdl->y_set) return set_error("GPB_EvalNegLogLikelihood: y_data is NULL and no response has been set (pass y_data once, or call GPB_OptimCovPar / GPB_SetY first)");
+  }
   double t3[3] = {0., 0., 0.};
   if (mdl->eh) { if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, tr[1], tr[2], t3, nullptr, nullptr)) return shim_error(); }
   else {
-    for (auto* v : mdl->vhs) {      // block-diagonal Psi: the quadratic forms and log-determinants of the clusters add up
-      double t[3];
-      if (gpb_hip_vecchia_nll_terms(v, mdl->cov_type, tr[1], tr[2], 1, t)) return shim_error();
-      t3[0] += t[0]; t3[1] += t[1]; t3[2] += t[2];
-    }
+    // block-diagonal Psi: the quadratic forms and log-determinants of the clusters add up; a sharded handle (one process per GPU,
+    // gpb_hip_vecchia_comm_init) returns the job-wide sums on every rank (one ncclAllReduce of 3 doubles per evaluation)
+    double t7[7];
+    if (device_terms(mdl, tr[1], tr[2], 0, t7)) return -1;
+    t3[0] = t7[0]; t3[1] = t7[1]; t3[2] = t7[2];
   }
   mdl->cur_negll = negll_from_terms(mdl->n, t3[0], t3[1], tr[0]);
   mdl->negll_valid = true;

@@ -510,8 +510,15 @@ int gpb_hip_vecchia_comm_init(gpb_hip_vecchia_t* h, const unsigned char* id128, 
 int gpb_hip_vecchia_comm_info(gpb_hip_vecchia_t* h, int* rank, int* world) {
   API_BEGIN();
   if (!h) return fail("null argument");
-  if (rank) *rank = h->comm ? h->comm_rank : 0;
-  if (world) *world = h->comm ? h->comm_world : 0;
+  if (rank) *rank = 0;
+  if (world) *world = 0;
+  if (h->comm) {     // what RCCL itself says about the communicator, not what was passed to comm_init
+    int r = 0, w = 0;
+    NCCL_OK(ncclCommUserRank(h->comm, &r));
+    NCCL_OK(ncclCommCount(h->comm, &w));
+    if (rank) *rank = r;
+    if (world) *world = w;
+  }
   API_END();
 }
 

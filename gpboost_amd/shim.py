@@ -108,6 +108,12 @@ class VecchiaState(object):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
         _shim_call(_lib().gpb_hip_vecchia_comm_init(self.h, buf, C.c_int(int(rank)), C.c_int(int(world))))
 
+    def comm_info(self):
+        """(rank, number of ranks) as RCCL reports them for the handle's communicator (ncclCommUserRank / ncclCommCount); (0, 0) without one."""
+        r, w = C.c_int(0), C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def find_neighbors_part(self, part, nparts):
         dup = C.c_int(0)
         _shim_call(_lib().gpb_hip_vecchia_find_neighbors_part(self.h, C.c_int(int(part)), C.c_int(int(nparts)), C.byref(dup)))

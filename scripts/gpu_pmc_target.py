@@ -1,0 +1,36 @@
+"""Workload profiled by scripts/profile_r02.sh under rocprofv3 --pmc: the metric configuration's point kernel (likelihood and gradient
+launches through GPB_EvalNegLogLikelihood / the gradient entry point, y resident) and the root histogram pass at n = 1e7."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpboost_amd          # noqa: E402
+from gpboost_amd import shim   # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+gpboost_amd.set_device(0)
+if what in ("all", "vecchia"):
+    n, m, d = 1000000, 30, 2
+    rng = np.random.default_rng(1)
+    coords = rng.uniform(size=(n, d)); y = rng.standard_normal(n)
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=m, vecchia_ordering="random", seed=1)
+    cp = np.array([0.1, 1.0, 0.1])
+    print("nll", mdl.neg_log_likelihood(cp, y))
+    for k in range(12):
+        mdl.neg_log_likelihood(cp * (1 + 0.001 * k))           # y_data = NULL: resident response
+    for k in range(6):
+        mdl.neg_log_likelihood_and_gradient(cp * (1 + 0.001 * k), y)
+    del mdl
+if what in ("all", "hist"):
+    n, F, nb = 10000000, 50, 255
+    rng = np.random.default_rng(2)
+    bins = rng.integers(0, nb, size=(F, n), dtype=np.uint8)
+    bo = (np.arange(F + 1) * nb).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    g = rng.standard_normal(n)
+    hb.set_gradients(g, None)
+    print("hist root ms", hb.bench(None, 1.0, 6))
+    hb.set_gradients(g, np.abs(g) + 0.1)
+    print("hist root (hessians) ms", hb.bench(None, 1.0, 6))

@@ -1,25 +1,76 @@
-"""Condenses rocprofv3 output (rocpd sqlite: kernel trace + PMC passes) into a small text summary for profiles/."""
-import glob, os, sqlite3, sys
-out = sys.argv[1]
+#!/usr/bin/env python
+"""Summarise rocprofv3 output directories (csv or rocpd sqlite) into the small text / json files kept under profiles/.
+
+    python scripts/summarize_prof.py trace <dir>            per-kernel calls / total ms / mean us / min / max / vgpr / lds
+    python scripts/summarize_prof.py pmc <dir> [<dir> ...]  per-kernel mean of every counter found (one --pmc pass per dir)
+    python scripts/summarize_prof.py pmc-json <out.json> <dir> [<dir> ...]   the same as json {kernel: {counter: mean, "n": dispatches}}
+"""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import sys
+from collections import defaultdict
 
 
-def q(db, sql):
-    try:
-        return sqlite3.connect(db).execute(sql).fetchall()
-    except Exception as e:
-        return [("ERR", str(e))]
+def _csvs(d, suffix):
+    return sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
 
 
-tr = glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True)
-print("== kernel stats (rocprofv3 --kernel-trace --stats; view top_kernels) ==")
-for db in tr:
-    for r in q(db, "select name,total_calls,total_duration,average,percentage from top_kernels"):
-        print("%-100s calls=%s total_ns=%s avg_ns=%.1f pct=%.2f" % (str(r[0])[:100], r[1], r[2], r[3], r[4]))
-    print("== per-kernel resources ==")
-    for r in q(db, "select name,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,scratch_size,grid_x,workgroup_x,count(*),avg(duration),min(duration),max(duration) from kernels group by name"):
-        print("%-100s VGPR=%s AGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s n=%s avg_ns=%.1f min=%s max=%s" % ((str(r[0])[:100],) + tuple(r[1:])))
-print("== PMC: mean per dispatch, by kernel ==")
-for db in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True)):
-    for r in q(db, "select kernel_name,counter_name,avg(value),count(*) from counters_collection group by kernel_name,counter_name"):
-        if "vecchia_point" in str(r[0]) or "hist" in str(r[0]) or "nn_kernel" in str(r[0]):
-            print("%-60s %-24s mean=%.6g n=%s" % (str(r[0])[:60], r[1], r[2], r[3]))
+def trace(d):
+    rows = defaultdict(list)
+    meta = {}
+    for f in _csvs(d, "kernel_trace.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                name = r.get("Kernel_Name", "?")
+                rows[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                meta[name] = (r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")), r.get("Accum_VGPR_Count", ""), r.get("LDS_Block_Size", ""))
+    if not rows:
+        for db in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+            c = sqlite3.connect(db)
+            try:
+                for r in c.execute("select name, duration/1e3, vgpr_count, lds_size from kernels"):
+                    rows[str(r[0])].append(float(r[1])); meta[str(r[0])] = (r[2], "", r[3])
+            except sqlite3.Error as e:   # schema differs between ROCm versions
+                print("# %s: %s" % (db, e))
+    out = ["== rocprofv3 --kernel-trace: per-kernel calls, total ms, mean us, min us, max us; VGPR, AGPR, LDS =="]
+    for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        m = meta.get(name, ("", "", ""))
+        out.append("%-120s calls=%7d total_ms=%10.3f mean_us=%10.2f min_us=%9.2f max_us=%10.2f vgpr=%s agpr=%s lds=%s" %
+                   (name[:120], len(v), sum(v) / 1e3, sum(v) / len(v), min(v), max(v), m[0], m[1], m[2]))
+    return "\n".join(out)
+
+
+def pmc(dirs):
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for f in _csvs(d, "counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    if len(sys.argv) < 3:
+        raise SystemExit(__doc__)
+    if sys.argv[1] == "trace":
+        print(trace(sys.argv[2]))
+    elif sys.argv[1] == "pmc":
+        acc = pmc(sys.argv[2:])
+        for k in sorted(acc):
+            for c in sorted(acc[k]):
+                v = acc[k][c]
+                print("%-100s %-28s mean=%.6g n=%d" % (k[:100], c, sum(v) / len(v), len(v)))
+    elif sys.argv[1] == "pmc-json":
+        acc = pmc(sys.argv[3:])
+        out = {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, n=max(len(v) for v in cs.values())) for k, cs in acc.items()}
+        with open(sys.argv[2], "w") as fh:
+            json.dump(out, fh, indent=1, sort_keys=True)
+        print("wrote", sys.argv[2], len(out), "kernels")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""GPU (MI355X): VALUE parity at BASELINE.json's own sizes.
+
+Three Gaussian configurations -- config 2 (n = 1e5, d = 2, exponential, m = 30), the metric configuration (n = 1e6, d = 2,
+exponential, m = 30) and config 5 (n = 1e6, d = 3, Matern-2.5, m = 40) -- are compared
+  (i)  with the UNMODIFIED REFERENCE: tests/golden/atsize_ref.npz holds its nll, its gradient, SHA-256 digests of its Vecchia
+       ordering and of its WHOLE n x m neighbour table, and 1000 sampled rows of D / y_aux / the table
+       (oracle/make_golden.py atsize; src/GPBoost/Vecchia_utils.cpp:733-985, 1367-1699, re_model_template.h:1988-2011);
+  (ii) with the CPU oracle on the same inputs in the same run (whole table array_equal, nll and gradient),
+both at north_star's tolerances: indices bit-exact, nll and gradient 1e-8 relative.
+Config 4 (Bernoulli-logit Vecchia-Laplace, n = 1e5) is compared with ONE evaluation of the reference at that size
+(tests/golden/config4_ref.npz; likelihoods.h:3773-4059, CG_utils.cpp:21-229)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-8      # north_star tolerance on nll / gradients
+
+ATSIZE = {
+    "config2_n1e5_exp_m30": (100000, 2, 30, "exponential", 0.5, (0.1, 1.0, 0.1)),
+    "metric_n1e6_exp_m30": (1000000, 2, 30, "exponential", 0.5, (0.1, 1.0, 0.1)),
+    "config5_n1e6_d3_mat25_m40": (1000000, 3, 40, "matern", 2.5, (0.1, 1.0, 0.1)),
+}
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+@pytest.mark.parametrize("name", sorted(ATSIZE))
+def test_gaussian_configs_at_baseline_size(gpb, orc, name):
+    n, d, m, cf, sh, cp = ATSIZE[name]
+    cp = np.asarray(cp, dtype=np.float64)
+    g = np.load(os.path.join(GOLD, "atsize_ref.npz"))
+    coords, y = cases.synthetic(n, d, seed=1)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m,
+                      vecchia_ordering="random", seed=1)
+    perm, nn = mdl.vecchia_structure()
+    # (i) the reference itself
+    assert _sha(perm.astype(np.int32)) == str(g[name + "_perm_sha256"]), "Vecchia ordering differs from the reference"
+    assert _sha(nn.astype(np.int32)) == str(g[name + "_nn_sha256"]), "the n x m neighbour table is not bit-identical to the reference's"
+    rows = g[name + "_rows"]
+    assert np.array_equal(nn[rows], g[name + "_nn_rows"])
+    nll, grad = mdl.neg_log_likelihood_and_gradient(cp, y)
+    ref_nll, ref_grad = float(g[name + "_nll"]), g[name + "_grad"]
+    assert abs(nll - ref_nll) <= RTOL * abs(ref_nll), (nll, ref_nll)
+    np.testing.assert_allclose(grad, ref_grad, rtol=RTOL, atol=RTOL * np.abs(ref_grad).max())
+    nll0 = mdl.neg_log_likelihood(cp, y)                  # the likelihood-only launch (MODE_NLL) as well
+    assert abs(nll0 - ref_nll) <= RTOL * abs(ref_nll), (nll0, ref_nll)
+    ya = mdl.y_aux(cp, y)
+    np.testing.assert_allclose(ya[perm][rows], g[name + "_yaux_rows"], rtol=1e-7, atol=1e-9)
+    # (ii) the oracle, same inputs, same run: WHOLE table, nll, gradient
+    perm_o, co, nn_o = orc.vecchia_setup(coords, m, "random", 1)
+    assert np.array_equal(perm, perm_o)
+    assert np.array_equal(nn, nn_o), "neighbour indices must be bit-exact (whole table)"
+    ct = orc.cov_type_id(cf, sh)
+    out, grad_o = orc.vecchia_nll_grad(co, nn_o, ct, orc.transform_cov_pars(ct, cp), y[perm])
+    assert abs(nll - out[2]) <= RTOL * abs(out[2]), (nll, out[2])
+    np.testing.assert_allclose(grad, grad_o, rtol=RTOL, atol=RTOL * np.abs(grad_o).max())
+
+
+def test_config4_n1e5_against_the_reference(gpb):
+    """BASELINE config 4 at its full size against ONE evaluation of the unmodified reference (26 s on 8 cores).
+
+    What is admitted and why: the value is defined up to the reference's own stopping rules -- every Newton system is solved by
+    preconditioned CG until the residual norm falls below cg_delta_conv = 1e-2 (CG_utils.cpp:74-82), and the log-determinant's
+    block CG stops on the MEAN residual norm of the 50 probes (:196-204).  Two correct implementations whose rounded norms straddle
+    the threshold in one iteration differ by one CG iteration; at this size that moves the value by <= 5e-9 relative (measured:
+    reference vs this path 3e-9).  North_star's 1e-8 therefore still holds and is what is asserted."""
+    g = np.load(os.path.join(GOLD, "config4_ref.npz"))
+    n, m = 100000, 30
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
+                      num_neighbors=m, vecchia_ordering="random", seed=1)
+    v = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    ref = float(g["negll_0"])
+    assert abs(v - ref) <= RTOL * abs(ref), (v, ref, mdl.laplace_info())
