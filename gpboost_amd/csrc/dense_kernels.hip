@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
   while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while ((long long)ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - (int)((long long)ti * (ti + 1) / 2);
-  const double sc = a * k64OverLn2;
+  const double sc = a * kCoordScale;   // half-scaled coordinates: d2 below is (rho/2)^2, see exp_of_scaled
   if (tid < CT) {
     const int r = ti * CT + tid;
     const double4 p = r < n ? pts[r] : make_double4(0, 0, 0, 0);

@@ -65,6 +65,25 @@ __device__ __forceinline__ void row_fnma(double& acc, double b, double own) {
 // Explicit hazard fence: makes the listed values opaque (they must exist before this point) and supplies the two
 // wait states, so that DPP reads of them further down are safe whatever the compiler scheduled just before.
 __device__ __forceinline__ void dpp_fence(double& a) { asm volatile("s_nop 1" : "+v"(a)); }
+// ---- compile-time lane sets ------------------------------------------------------------------------------------------
+// A workgroup's thread t is lane t % 64 of its wavefront and lane l = t % 16 of its point's DPP row, so "l in S" for a compile-time set
+// S is a compile-time 64-bit mask (S replicated in the four rows).  Selecting with it needs no v_cmp: the mask goes to an SGPR pair.
+__host__ __device__ constexpr unsigned long long row_lanes_le(int j) {   // lanes l <= j of every row
+  return j < 0 ? 0ull : (j >= 15 ? ~0ull : ((1ull << (j + 1)) - 1ull) * 0x0001000100010001ull);
+}
+__host__ __device__ constexpr unsigned long long row_lane_eq(int j) { return (1ull << j) * 0x0001000100010001ull; }
+// lanes in MASK get a, the others b
+template <unsigned long long MASK>
+__device__ __forceinline__ int sel_lanes(int a, int b) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(MASK));
+  return r;
+}
+// lanes in MASK := v (one v_mov_b64 under a constant exec mask).  Only for code every lane of the wavefront executes (exec = all ones).
+template <unsigned long long MASK>
+__device__ __forceinline__ void set_lanes(double& dst, double v) {
+  asm volatile("s_mov_b64 exec, %2\n\tv_mov_b64 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(v), "s"(MASK));
+}
 // Portable-in-HIP variant of the same two primitives (two 32-bit DPP movs that the
 // compiler schedules and pads itself).  Used by the self-test kernel to validate the
 // asm forms on the device, and selectable with -DGPB_DPP_VIA_BUILTIN for debugging.
@@ -94,37 +113,40 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return __builtin_fma(y0, e, y0);
 }
 
-#define GPB_EXP_TAB_SIZE 64   // 2^(j/64), j = 0..63 (filled on the host, pre-multiplied by the variance in the kernels)
+#ifndef GPB_EXP_TAB_SIZE
+#define GPB_EXP_TAB_SIZE 256   // 2^(j/256), j = 0..255 (filled on the host, pre-multiplied by the variance in the kernels)
+#endif
+static_assert(GPB_EXP_TAB_SIZE == 256, "exp_of_scaled is written for a 256-entry table");
 
 // ---- isotropic Matern kernels on the transformed scale --------------------
 // reference: include/GPBoost/cov_fcts.h:2100-2118 (CovarianceMaternShape0_5/1_5/2_5)
 enum CovType : int { kMatern05 = 0, kMatern15 = 1, kMatern25 = 2 };
 
 // ---- scaled-distance form used by the hot kernels -------------------------------------------
-// Coordinates are pre-multiplied by a * 64/ln2, so that exp(-a d) = 2^(-r'/64) with r' the scaled distance:
-// no multiply by the range, no Cody-Waite reduction, the polynomial absorbs ln2/64, the table absorbs the variance.
-constexpr double kLn2Over64 = 0.010830424696249145;   // ln2 / 64
-constexpr double k64OverLn2 = 92.332482616893657;     // 64 / ln2
+// exp(-a d) = 2^(-rho/256) with rho = a d 256/ln2: no multiply by the range, no Cody-Waite reduction, the polynomial absorbs ln2/256,
+// the table absorbs the variance.  Coordinates are pre-multiplied by HALF of that (a * kCoordScale), so the squared distance the
+// kernels form is d2q = rho^2 / 4: with h = rsq(d2q) = 2/rho the square root needs 3 fp64 ops instead of 4 (below).
+constexpr double kLn2OverT = 0.0027076061740622863;   // ln2 / 256
+constexpr double kCoordScale = 184.6649652337873;     // (256 / ln2) / 2
 
-// Everything a kernel evaluation needs, from the scaled squared distance d2s = (a d 64/ln2)^2:
-//   ev = var * exp(-a d)   (tabv already carries var),   rp = a d 64/ln2
+// Everything a kernel evaluation needs, from d2q = (rho / 2)^2:
+//   ev = var * exp(-a d)   (tabv already carries var),   rp = rho = a d 256/ln2
 struct KernEval { double ev, rp; };
-__device__ __forceinline__ KernEval exp_of_scaled(double d2s, const double* __restrict__ tabv) {
-  const double rs = __builtin_amdgcn_rsq(d2s);
-  const double g = d2s * rs, h = 0.5 * rs;
-  const double e = __builtin_fma(-h, g, 0.5);
-  const double rp = __builtin_fma(g, e, g);                 // sqrt(d2s), one Newton step on v_rsq_f64
+__device__ __forceinline__ KernEval exp_of_scaled(double d2q, const double* __restrict__ tabv) {
+  const double h = __builtin_amdgcn_rsq(d2q);               // 2/rho (1 + delta)
+  const double g = d2q * h;                                 // rho/2 (1 + delta)
+  const double e = __builtin_fma(-h, g, 3.0);               // 3 - (1 + delta)^2 = 2 - 2 delta - delta^2
+  const double rp = g * e;                                  // rho (1 - 1.5 delta^2): one Newton step on v_rsq_f64, folded
   const double kf = __builtin_rint(-rp);
-  const double rr = -rp - kf;                               // exact; |rr| <= 1/2, in units of ln2/64
+  const double rr = -rp - kf;                               // exact; |rr| <= 1/2, in units of ln2/256
   const int k = (int)kf;                                    // saturates for the dummy rows
-  // exp(rr ln2/64) = sum_j (ln2/64)^j rr^j / j!, j <= 5  (remainder < 2e-17)
-  double p = __builtin_fma(rr, 1.2417843701716925e-12, 5.732851688640402e-10);
-  p = __builtin_fma(p, rr, 2.1173137155464776e-07);
-  p = __builtin_fma(p, rr, 5.86490495505617e-05);
-  p = __builtin_fma(p, rr, kLn2Over64);
+  // exp(rr ln2/256) = sum_j (ln2/256)^j rr^j / j!, j <= 4  (remainder < 4e-17)
+  double p = __builtin_fma(rr, 2.239395190875157e-12, 3.3083026805413713e-09);
+  p = __builtin_fma(p, rr, 3.6655655969101062e-06);
+  p = __builtin_fma(p, rr, kLn2OverT);
   p = __builtin_fma(p, rr, 1.0);
   KernEval o;
-  o.ev = __builtin_ldexp(tabv[k & 63] * p, k >> 6);
+  o.ev = __builtin_ldexp(tabv[k & (GPB_EXP_TAB_SIZE - 1)] * p, k >> 8);
   o.rp = rp;
   return o;
 }
@@ -133,14 +155,23 @@ template <int COV>
 __device__ __forceinline__ double matern_cov_s(double d2s, const double* __restrict__ tabv) {
   const KernEval k = exp_of_scaled(d2s, tabv);
   if constexpr (COV == kMatern05) return k.ev;
-  else if constexpr (COV == kMatern15) return k.ev * __builtin_fma(k.rp, kLn2Over64, 1.0);
-  else { const double r = k.rp * kLn2Over64; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
+  else if constexpr (COV == kMatern15) return k.ev * __builtin_fma(k.rp, kLn2OverT, 1.0);
+  else { const double r = k.rp * kLn2OverT; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
+}
+// kernel value and d/d log(a) from ONE exp evaluation (MODE_GRAD keeps the derivative in LDS)
+template <int COV>
+__device__ __forceinline__ double matern_cov_dlog_s(double d2s, const double* __restrict__ tabv, double& dk) {
+  const KernEval k = exp_of_scaled(d2s, tabv);
+  const double r = k.rp * kLn2OverT;
+  if constexpr (COV == kMatern05) { dk = -r * k.ev; return k.ev; }
+  else if constexpr (COV == kMatern15) { dk = -(r * r) * k.ev; return k.ev * (1.0 + r); }
+  else { dk = -(1.0 / 3.0) * (r * r) * (1.0 + r) * k.ev; return k.ev * __builtin_fma(r, __builtin_fma(r, 1.0 / 3.0, 1.0), 1.0); }
 }
 // d/d log(a) of the kernel (transf_scale == true): include/GPBoost/cov_fcts.h:2182-2193 (cm), :2535-2554
 template <int COV>
 __device__ __forceinline__ double matern_dlog_range_s(double d2s, const double* __restrict__ tabv) {
   const KernEval k = exp_of_scaled(d2s, tabv);
-  const double r = k.rp * kLn2Over64;
+  const double r = k.rp * kLn2OverT;
   if constexpr (COV == kMatern05) return -r * k.ev;                                 // cm d sigma, cm = -a
   else if constexpr (COV == kMatern15) return -(r * r) * k.ev;                      // cm d^2 e^{-ad}, cm = -var a^2
   else return -(1.0 / 3.0) * (r * r) * __builtin_fma(1.0, r, 1.0) * k.ev;           // cm/3 d^2 (1+ad) e^{-ad}

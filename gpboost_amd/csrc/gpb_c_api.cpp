@@ -35,6 +35,17 @@ namespace {
 
 thread_local char g_last_error[512] = "Everything is fine";   // c_api.h:1837-1849
 
+thread_local void (*g_log_callback)(const char*) = nullptr;   // Log::ResetCallBack (log.h:260-264): thread-local like the reference's
+void log_info(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (g_log_callback) g_log_callback(buf);
+  else { std::fputs(buf, stdout); std::fflush(stdout); }
+}
+
 int set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -85,6 +96,10 @@ struct REModelHip {
   int num_neighbors_pred = 0;   // 0 = default (2 * num_neighbors_, :299)
   int num_it = 0;
   GpbOptimResult last_fit;
+  std::string cg_preconditioner_type = "vadu";   // ParsePreconditionerAlias default for a non-Gaussian Vecchia model (re_model_template.h:7137)
+  std::vector<double> offset;                     // GPB_SetOffsetData (fixed_effects_, has_fixed_effects_; re_model_template.h:6318-6321)
+  bool has_offset = false;
+  bool model_has_been_estimated = false;
   ~REModelHip() { for (auto* v : vhs) gpb_hip_vecchia_free(v); if (eh) gpb_hip_exact_free(eh); if (ybuf) gpb_hip_pinned_free(ybuf); }
 };
 
@@ -300,6 +315,12 @@ void transform_back(const REModelHip* mdl, const double* tr, double* orig) {   /
   orig[2] = range_const(mdl) / tr[2];
 }
 
+const char* kDuplicatesNonGaussianMessage =
+    "Duplicates found in the coordinates for the Gaussian process. This is currently not supported for the Vecchia approximation for non-Gaussian likelihoods ";   // Vecchia_utils.cpp:1211-1214
+
+// CanCalculateStandardErrorsCovPars (re_model_template.h:1804-1807) restricted to what GPB_GetCovPar(calc_std_dev = true) does on the device
+bool can_calc_std_dev(const REModelHip* mdl) { return mdl->likelihood == "gaussian" && !mdl->eh && mdl->vhs.size() == 1 && false; }
+
 double negll_from_terms(int n, double yPy, double logdet, double sigma2) {
   return yPy / 2. / sigma2 + logdet / 2. + n / 2. * (std::log(sigma2) + std::log(2 * M_PI));   // :3132
 }
@@ -316,6 +337,12 @@ double negll_from_terms(int n, double yPy, double logdet, double sigma2) {
 extern "C" {
 
 const char* LGBM_GetLastError() { return g_last_error; }
+
+/* c_api.cpp:1005-1009: the reference's Python package registers its logger at import (basic.py:117-129) */
+int LGBM_RegisterLogCallback(void (*callback)(const char*)) {
+  g_log_callback = callback;
+  return 0;
+}
 
 int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const char* /*re_group_data*/,
                       int32_t num_re_group, const double* /*re_group_rand_coef_data*/,
@@ -415,6 +442,9 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     mdl->cl_off.push_back((int)mdl->perm.size());
   }
   mdl->vh = mdl->vhs[0];
+  // the reference maps repeated locations to unique random effects for one non-Gaussian GP and stops if duplicates remain
+  // (Vecchia_utils.cpp:1156-1158, 1208-1214); the unique-location mapping is not on this path, so duplicates are an error here
+  if (lik_name != "gaussian" && mdl->has_duplicates) return set_error("%s", kDuplicatesNonGaussianMessage);
   *out = mdl.release();
   C_API_END();
 }
@@ -436,7 +466,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   C_API_BEGIN();
   if (!handle) return set_error("GPB_SetOptimConfig: null handle");
   if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
-  if (estimate_aux_pars) return set_error("GPB_SetOptimConfig: estimate_aux_pars is not on the MI355X hot path of this library");
+  (void)estimate_aux_pars;   // the reference's packages pass true by default; none of the supported likelihoods has auxiliary parameters (NumAuxPars = 0), so there is nothing to estimate
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) {          // re_model_template.h:930-936
     if (mdl->likelihood != "gaussian")
@@ -507,6 +537,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     const std::string pc = cg_preconditioner_type;
     if (pc != "" && pc != "vadu" && pc != "Sigma_inv_plus_BtWB" && pc != "vecchia_approximation_with_replicates")   // ParsePreconditionerAlias
       return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library (only 'vadu')", pc.c_str());
+    mdl->cg_preconditioner_type = "vadu";
   }
   C_API_END();
 }
@@ -594,6 +625,7 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
     }
     mdl->num_it = res.num_it;
     mdl->last_fit_lap = res;
+    mdl->model_has_been_estimated = true;
     return 0;
   }
   if (mdl->eh) return set_error("GPB_OptimCovPar: gp_approx 'none' %s", scope);
@@ -616,6 +648,7 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
   }
   mdl->num_it = res.num_it;
   mdl->last_fit = res;
+  mdl->model_has_been_estimated = true;
   C_API_END();
 }
 
@@ -832,8 +865,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
                        bool predict_var, bool predict_response, bool sample_posterior, bool sample_prior, int /*num_post_samples*/,
                        int /*num_prior_samples*/, const int32_t* cluster_ids_data_pred, const char* re_group_data_pred,
                        const double* re_group_rand_coef_data_pred, double* gp_coords_data_pred, const double* gp_rand_coef_data_pred,
-                       const double* cov_pars, const double* covariate_data_pred, bool use_saved_data, const double* /*fixed_effects*/,
-                       const double* /*fixed_effects_pred*/) {
+                       const double* cov_pars, const double* covariate_data_pred, bool use_saved_data, const double* fixed_effects,
+                       const double* fixed_effects_pred) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !out_predict) return set_error("GPB_PredictREModel: null argument");
@@ -843,7 +876,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   if (predict_cov_mat && predict_var) return set_error("Calculation of both the predictive covariance matrix and variances is not supported. Choose one option (predict_cov_mat or predict_var)");   // re_model.cpp Predict
   if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred)
     return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients / covariates for prediction %s", scope);
-  if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only") return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", mdl->vecchia_pred_type.c_str(), scope);
+  const bool cond_all = mdl->vecchia_pred_type == "order_obs_first_cond_all";
+  if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only" && !cond_all) return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", mdl->vecchia_pred_type.c_str(), scope);
   const double* cp = gp_coords_data_pred;
   int np = num_data_pred;
   if (use_saved_data) { cp = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); np = mdl->num_data_pred; }
@@ -854,12 +888,42 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (!mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or are not given.");   // re_model.cpp:1119-1121
     std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, tr);
   }
-  if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
-  else if (!mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
+  // response and offset (SetYCalcCovCalcYAuxForPred, re_model_template.h:11141-11166): with an offset -- the argument, else the one saved by
+  // GPB_SetOffsetData (:3601-3607) -- the residual (y_obs or the stored response) minus the offset becomes the response
+  if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
+  const double* fe = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
+  if (fe) {
+    std::vector<double> resid(mdl->n);
+    if (y_data) std::copy(y_data, y_data + mdl->n, resid.begin());
+    else for (int k = 0; k < mdl->n; ++k) resid[mdl->perm[k]] = mdl->ybuf[k];
+    if (upload_y(mdl, resid.data(), fe)) return -1;
+  } else if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
   mdl->yaux_valid = false;
+  // num_neighbors_pred: default 2 * num_neighbors (:299), at most the number of observed points (Vecchia_utils.cpp:755-758) and the
+  // device kernels' GPB_MAX_NEIGHBORS
   int nnp = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;
+  if (nnp > mdl->n) nnp = mdl->n;
+  if (nnp > 62) {
+    log_info("[GPBoost-AMD] [Warning] num_neighbors_pred = %d exceeds the %d neighbours the MI355X kernels support; %d are used\n", nnp, 62, 62);
+    nnp = 62;
+  }
+  if (cond_all) {
+    // 'order_obs_first_cond_all': search + factor of the appended rows on the device, then the forward substitution with Bp and the rows
+    // of Bp^-1 on the host (Vecchia_utils.cpp:2061-2090); y of the observed points in Vecchia order is the resident response
+    if (nnp > mdl->n + np - 1) nnp = mdl->n + np - 1;
+    if (nnp > 62) nnp = 62;
+    int mu = 0;
+    std::vector<int32_t> nnp_rows((size_t)np * nnp);
+    std::vector<double> Ap((size_t)np * nnp), Dp(np);
+    if (gpb_hip_vecchia_predict_cond_all(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], &mu, nnp_rows.data(), Ap.data(), Dp.data(), nullptr)) return shim_error();
+    if (GPB_HIP_PredictCondAllHost(mdl->n, np, mu, nnp_rows.data(), Ap.data(), Dp.data(), mdl->ybuf, tr[0], predict_response, out_predict,
+                                   predict_var ? out_predict + np : nullptr, predict_cov_mat ? out_predict + np : nullptr)) return -1;
+    if (fixed_effects_pred) for (int k = 0; k < np; ++k) out_predict[k] += fixed_effects_pred[k];   // :3862-3867
+    return 0;
+  }
   std::vector<double> D(np);
   if (gpb_hip_vecchia_predict_obs_only(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], out_predict, D.data(), nullptr)) return shim_error();
+  if (fixed_effects_pred) for (int k = 0; k < np; ++k) out_predict[k] += fixed_effects_pred[k];   // :3862-3867
   if (predict_var)
     for (int k = 0; k < np; ++k) out_predict[np + k] = tr[0] * (predict_response ? D[k] : D[k] - 1.);
   if (predict_cov_mat) {                       // neighbours are observed points only: Bp = I, the predictive covariance is diag(Dp)
@@ -884,6 +948,193 @@ int GPB_GetLikelihoodName(REModelHandle handle, char* out_str, int* num_char) {
   if (!mdl || !out_str || !num_char) return set_error("GPB_GetLikelihoodName: null argument");
   *num_char = (int)mdl->likelihood.size() + 1;   // c_api.cpp: size + 1, then memcpy incl. terminator
   std::memcpy(out_str, mdl->likelihood.c_str(), mdl->likelihood.size() + 1);
+  C_API_END();
+}
+
+/* ---- the rest of the GPB_* surface the reference's GPModel binds (python-package/gpboost/basic.py:5206-7118): state getters / setters
+   are answered from the model's host state; estimation with covariates and auxiliary parameters are off the hot path -> -1 + message ---- */
+
+static int copy_string_out(const std::string& v, char* out_str, int* num_char, const char* who) {
+  if (!out_str || !num_char) return set_error("%s: null argument", who);
+  *num_char = (int)v.size() + 1;                     // c_api.cpp:3025-3034: size + 1, memcpy incl. the terminator
+  std::memcpy(out_str, v.c_str(), v.size() + 1);
+  return 0;
+}
+
+int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const double* covariate_data, int num_covariates,
+                               const double* fixed_effects) {
+  if (num_covariates > 0 || covariate_data)
+    return set_error("GPB_OptimLinRegrCoefCovPar: linear regression covariates are not on the MI355X hot path of this library "
+                     "(pass the linear predictor as 'fixed_effects' / offset, or use the reference's host code for the coefficients)");
+  return GPB_OptimCovPar(handle, y_data, fixed_effects);
+}
+
+int GPB_CanCalculateStandardErrorsCovPars(REModelHandle handle, int* out) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !out) return set_error("GPB_CanCalculateStandardErrorsCovPars: null argument");
+  out[0] = can_calc_std_dev(mdl) ? 1 : 0;
+  C_API_END();
+}
+
+int GPB_CanCalculateStandardErrorsAuxPars(REModelHandle handle, int* out) {
+  C_API_BEGIN();
+  if (!handle || !out) return set_error("GPB_CanCalculateStandardErrorsAuxPars: null argument");
+  out[0] = 0;                                        // none of the supported likelihoods has auxiliary parameters
+  C_API_END();
+}
+
+int GPB_GetCoef(REModelHandle handle, double* /*optim_coef*/, bool /*calc_std_dev*/) {
+  if (!handle) return set_error("GPB_GetCoef: null handle");
+  return set_error("GPB_GetCoef: the model has no linear regression covariates (not on the MI355X hot path of this library)");
+}
+
+int GPB_HasStdCylBesselK(int* has_bessel) {
+  if (!has_bessel) return set_error("GPB_HasStdCylBesselK: null argument");
+  has_bessel[0] = 0;                                 // general-shape Matern (Bessel K) is not on the hot path: shapes 0.5 / 1.5 / 2.5 only
+  return 0;
+}
+
+int GPB_GetOptimizerCovPars(REModelHandle handle, char* out_str, int* num_char) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_GetOptimizerCovPars: null handle");
+  return copy_string_out(mdl->optim.optimizer.empty() ? std::string("lbfgs") : mdl->optim.optimizer, out_str, num_char, "GPB_GetOptimizerCovPars");   // re_model_template.h:8277-8280
+  C_API_END();
+}
+
+int GPB_GetOptimizerCoef(REModelHandle handle, char* out_str, int* num_char) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_GetOptimizerCoef: null handle");
+  return copy_string_out(mdl->likelihood == "gaussian" ? "wls" : "lbfgs", out_str, num_char, "GPB_GetOptimizerCoef");   // defaults, :8281-8288
+  C_API_END();
+}
+
+int GPB_GetCGPreconditionerType(REModelHandle handle, char* out_str, int* num_char) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_GetCGPreconditionerType: null handle");
+  return copy_string_out(mdl->cg_preconditioner_type, out_str, num_char, "GPB_GetCGPreconditionerType");
+  C_API_END();
+}
+
+int GPB_GetNumCGSteps(REModelHandle handle, int* num_cg_steps) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !num_cg_steps) return set_error("GPB_GetNumCGSteps: null argument");
+  num_cg_steps[0] = mdl->likelihood == "gaussian" ? 0 : (int)mdl->lap_info[2];
+  C_API_END();
+}
+
+int GPB_GetNumCGStepsTridiag(REModelHandle handle, int* num_cg_steps) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !num_cg_steps) return set_error("GPB_GetNumCGStepsTridiag: null argument");
+  num_cg_steps[0] = mdl->likelihood == "gaussian" ? 0 : (int)mdl->lap_info[4];
+  C_API_END();
+}
+
+int GPB_GetNumModeFindingSteps(REModelHandle handle, int* num_steps) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !num_steps) return set_error("GPB_GetNumModeFindingSteps: null argument");
+  num_steps[0] = mdl->likelihood == "gaussian" ? 0 : (int)mdl->lap_info[1];
+  C_API_END();
+}
+
+int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !likelihood) return set_error("GPB_SetLikelihood: null argument");
+  std::string lik = likelihood;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
+  if (lik == "binary_probit") lik = "bernoulli_probit";
+  if (lik == "binary" || lik == "binary_logit") lik = "bernoulli_logit";
+  if (mdl->model_has_been_estimated && lik != mdl->likelihood) return set_error("Cannot change likelihood after a model has been estimated ");   // re_model.cpp:154-160
+  if (lik == mdl->likelihood) return 0;
+  if (lik != "gaussian" && lik != "bernoulli_logit" && lik != "bernoulli_probit" && lik != "poisson")
+    return set_error("GPB_SetLikelihood: likelihood '%s' is not on the MI355X hot path of this library", likelihood);
+  if (lik != "gaussian" && (mdl->eh || mdl->vhs.size() != 1)) return set_error("GPB_SetLikelihood: likelihood '%s' needs gp_approx 'vecchia' and one cluster on this path", likelihood);
+  if (lik != "gaussian" && mdl->has_duplicates) return set_error(kDuplicatesNonGaussianMessage);
+  mdl->likelihood = lik;
+  mdl->cov_pars_initialized = false; mdl->init_cov_pars_provided = false; mdl->negll_valid = false; mdl->y_set = false; mdl->yaux_valid = false;
+  C_API_END();
+}
+
+int GPB_GetResponseData(REModelHandle handle, double* response_data) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !response_data) return set_error("GPB_GetResponseData: null argument");
+  if (!mdl->y_set) return set_error("Respone variable data has not been set");      // re_model_template.h:6258-6261 (sic)
+  if (mdl->likelihood == "gaussian") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->ybuf[k]; }   // y_vec_ (what SetY stored: y - fixed effects)
+  else { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = (double)mdl->labels[k]; }
+  C_API_END();
+}
+
+int GPB_GetCovariateData(REModelHandle handle, double* /*covariate_data*/) {
+  if (!handle) return set_error("GPB_GetCovariateData: null handle");
+  return set_error("Model does not have covariates for a linear predictor");          // re_model_template.h GetCovariateData
+}
+
+int GPB_GetOffsetData(REModelHandle handle, double* fixed_effects) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !fixed_effects) return set_error("GPB_GetOffsetData: null argument");
+  if (!mdl->has_offset) return set_error("Model does not have an offset term ");     // :6304-6307
+  std::copy(mdl->offset.begin(), mdl->offset.end(), fixed_effects);
+  C_API_END();
+}
+
+int GPB_SetOffsetData(REModelHandle handle, const double* fixed_effects) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !fixed_effects) return set_error("GPB_SetOffsetData: null argument");
+  mdl->offset.assign(fixed_effects, fixed_effects + mdl->n);                          // :6318-6321
+  mdl->has_offset = true;
+  C_API_END();
+}
+
+int GPB_GetAuxPars(REModelHandle handle, double* /*aux_pars*/, char* out_str, bool /*calc_std_dev*/) {
+  if (!handle) return set_error("GPB_GetAuxPars: null handle");
+  if (out_str) out_str[0] = 0;                        // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
+  return 0;
+}
+
+int GPB_GetNumAuxPars(REModelHandle handle, int* num_aux_pars) {
+  if (!handle || !num_aux_pars) return set_error("GPB_GetNumAuxPars: null argument");
+  num_aux_pars[0] = 0;                                // gaussian / bernoulli_logit / bernoulli_probit / poisson have none (likelihoods.h: num_aux_pars_)
+  return 0;
+}
+
+int GPB_GetInitAuxPars(REModelHandle handle, double* /*aux_pars*/) {
+  if (!handle) return set_error("GPB_GetInitAuxPars: null handle");
+  return 0;
+}
+
+/* PredictTrainingDataRandomEffects (re_model.cpp:1217-1275, re_model_template.h:4455-4514): posterior mean of the latent GP at the
+   training locations, Gaussian Vecchia model: b^ = (y - F) - y_aux with y_aux = Psi^-1 (y - F) (:4502-4505). */
+int GPB_PredictREModelTrainingDataRandomEffects(REModelHandle handle, const double* cov_pars_pred, const double* y_obs, double* out_predict,
+                                                const double* fixed_effects, bool calc_var) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !out_predict) return set_error("GPB_PredictREModelTrainingDataRandomEffects: null argument");
+  if (mdl->likelihood != "gaussian" || mdl->eh) return set_error("GPB_PredictREModelTrainingDataRandomEffects: only the Gaussian Vecchia model is on the MI355X path of this library");
+  if (calc_var) return set_error("GPB_PredictREModelTrainingDataRandomEffects: predictive variances of the training-data random effects are not on the MI355X path of this library yet");
+  double cp[3];
+  if (cov_pars_pred) std::copy(cov_pars_pred, cov_pars_pred + 3, cp);
+  else {
+    if (!mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or are not given.");   // re_model.cpp:1238-1240
+    transform_back(mdl, mdl->cov_pars_tr, cp);
+  }
+  const double* fe = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);   // :4486-4492
+  std::vector<double> yc(mdl->n), ya(mdl->n);
+  if (y_obs) { for (int i = 0; i < mdl->n; ++i) yc[i] = y_obs[i] - (fe ? fe[i] : 0.); }
+  else {
+    if (!mdl->y_set) return set_error("Response variable data is not provided and has not been set before");   // :4473-4477
+    for (int k = 0; k < mdl->n; ++k) yc[mdl->perm[k]] = mdl->ybuf[k];
+  }
+  if (GPB_HIP_CalcYAux(handle, yc.data(), cp, ya.data())) return -1;
+  for (int i = 0; i < mdl->n; ++i) out_predict[i] = yc[i] - ya[i];
   C_API_END();
 }
 

@@ -63,8 +63,8 @@ int check_device() {
 }
 
 std::vector<double> exp_table() {
-  std::vector<double> t(64);
-  for (int j = 0; j < 64; ++j) t[j] = std::exp2((double)j / 64.0);
+  std::vector<double> t(GPB_EXP_TAB_SIZE);
+  for (int j = 0; j < GPB_EXP_TAB_SIZE; ++j) t[j] = std::exp2((double)j / (double)GPB_EXP_TAB_SIZE);
   return t;
 }
 
@@ -242,8 +242,8 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   HIP_OK(hipMemcpy(h->d_pts, pts.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&h->d_nn, sizeof(int) * (size_t)n * h->m));
   const std::vector<double> tab = exp_table();
-  HIP_OK(hipMalloc(&h->d_exp_tab, 64 * sizeof(double)));
-  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_exp_tab, GPB_EXP_TAB_SIZE * sizeof(double)));
+  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), GPB_EXP_TAB_SIZE * sizeof(double), hipMemcpyHostToDevice));
   const int nblocks = (n + 15) / 16;
   HIP_OK(hipMalloc(&h->d_partials, sizeof(double) * (size_t)nblocks * GPB_NUM_PARTIALS));
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 8));
@@ -710,17 +710,20 @@ int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev) {
 // end_search_at = n_obs - 1 (:1792-1799), and runs the same per-point local factorisation as the likelihood (:1883-1975):
 // pred_mean = A_p y_nn, Dp = 1 + sigma1^2/sigma^2 - A_p c.  Here that is one launch of the neighbour-search kernel and one of
 // vecchia_point_kernel<MODE_FACTOR> over the appended rows (their own response slot is 0, so u = -A_p y_nn).
-int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
-                                     int cov_type, double var, double a, double* pred_mean, double* pred_D, int* has_duplicates) {
-  API_BEGIN();
-  if (!h || !coords_pred_colmajor || !pred_mean || !pred_D) return fail("null argument");
-  if (n_pred < 1) return fail("gpb_hip_vecchia_predict_obs_only: n_pred = %d", n_pred);
+// Shared by the two prediction types: temporary state [observed (Vecchia order); prediction], neighbour search for the appended rows
+// only (find_nearest_neighbors_Vecchia_fast with start_at = n_obs and end_search_at = n_obs - 1 [cond_obs_only] or -1 [cond_all],
+// Vecchia_utils.cpp:1792-1822), MODE_FACTOR over the appended rows.  *out_t owns the state (caller frees), *out_m = neighbours used.
+static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                   bool cond_all, int cov_type, double var, double a, gpb_hip_vecchia_t** out_t, int* out_m, int* has_duplicates) {
+  *out_t = nullptr;
+  if (!h || !coords_pred_colmajor) return fail("null argument");
+  if (n_pred < 1) return fail("Vecchia prediction: n_pred = %d", n_pred);
   if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
   const int n_obs = h->n, d = h->d, n_all = n_obs + n_pred;
   int m = num_neighbors_pred;
-  if (m > n_obs) m = n_obs;                                   // :755-758 with end_search_at = n_obs - 1
-  if (m < 1 || m > GPB_MAX_NEIGHBORS) return fail("gpb_hip_vecchia_predict_obs_only: num_neighbors_pred = %d (1..%d supported)", num_neighbors_pred, GPB_MAX_NEIGHBORS);
-  if (n_obs <= m) return fail("gpb_hip_vecchia_predict_obs_only: needs more observed points (%d) than neighbours (%d)", n_obs, m);
+  const int m_cap = cond_all ? n_all - 1 : n_obs;               // :755-758 with end_search_at = num_data - 2 / n_obs - 1
+  if (m > m_cap) m = m_cap;
+  if (m < 1 || m > GPB_MAX_NEIGHBORS) return fail("Vecchia prediction: num_neighbors_pred = %d (1..%d supported)", num_neighbors_pred, GPB_MAX_NEIGHBORS);
   HIP_OK(hipSetDevice(h->device));
   // [observed (Vecchia order); prediction] as one temporary state; the observed records (coordinates + y) are copied on the device
   std::vector<double> call((size_t)n_all * d);
@@ -730,7 +733,7 @@ int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const
   }
   gpb_hip_vecchia_t* t = nullptr;
   if (gpb_hip_vecchia_create(n_all, d, m, call.data(), &t)) return -1;
-  struct Guard { gpb_hip_vecchia_t* p; ~Guard() { gpb_hip_vecchia_free(p); } } guard{t};
+  *out_t = t;
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipMemcpy(t->d_pts, h->d_pts, sizeof(double4) * (size_t)n_obs, hipMemcpyDeviceToDevice));   // pred rows keep y = 0
   t->has_y = true;
@@ -756,7 +759,7 @@ int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const
     HIP_OK(hipMemsetAsync(t->d_nn, 0xff, sizeof(int) * (size_t)n_all * t->m, t->stream));
     gpb::NNKernelArgs na;
     na.sorted_rec = d_rec; na.sorted_idx = d_idx; na.pts = t->d_pts; na.nn = t->d_nn; na.has_duplicates = t->d_flag; na.n = n_all; na.m = t->m;
-    na.start_at = n_obs; na.end_search_at = n_obs - 1; na.pos0 = 0; na.pos1 = n_all;
+    na.start_at = n_obs; na.end_search_at = cond_all ? n_all - 2 : n_obs - 1; na.pos0 = 0; na.pos1 = n_all;
     HIP_OK(gpb::launch_vecchia_nn(d, na, t->stream));
     int flag = 0;
     HIP_OK(hipMemcpyAsync(&flag, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
@@ -767,10 +770,46 @@ int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const
   }
   t->i_begin = n_obs; t->i_end = n_all;
   if (gpb_hip_vecchia_factor(t, cov_type, var, a, 1)) return -1;
-  std::vector<double> u(n_all);
-  HIP_OK(hipMemcpy(u.data(), t->d_u, sizeof(double) * (size_t)n_all, hipMemcpyDeviceToHost));
-  for (int k = 0; k < n_pred; ++k) pred_mean[k] = -u[n_obs + k];
+  *out_m = m;
+  return 0;
+}
+
+int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                     int cov_type, double var, double a, double* pred_mean, double* pred_D, int* has_duplicates) {
+  API_BEGIN();
+  if (!pred_mean || !pred_D) return fail("null argument");
+  gpb_hip_vecchia_t* t = nullptr;
+  int m = 0;
+  const int rc = predict_factor_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, false, cov_type, var, a, &t, &m, has_duplicates);
+  struct Guard { gpb_hip_vecchia_t* p; ~Guard() { if (p) gpb_hip_vecchia_free(p); } } guard{t};
+  if (rc) return -1;
+  const int n_obs = h->n;
+  std::vector<double> u(n_pred);
+  HIP_OK(hipMemcpy(u.data(), t->d_u + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n_pred; ++k) pred_mean[k] = -u[k];
   HIP_OK(hipMemcpy(pred_D, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
+  API_END();
+}
+
+// 'order_obs_first_cond_all' (CondObsOnly = false, Vecchia_utils.cpp:1806-1822, 1883-1975): the factor rows of the appended prediction
+// points, which condition on observed AND preceding prediction points.  Outputs, row-major [n_pred][*m_used]: neighbour indices into
+// (observed, prediction) (-1 padded), A_p = C_nn^-1 c, and D_p (nugget included, transformed scale).  The forward substitution with
+// Bp = I - A_pp and the rows of Bp^-1 are the host half (GPB_HIP_PredictCondAllHost).
+int gpb_hip_vecchia_predict_cond_all(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                     int cov_type, double var, double a, int32_t* m_used, int32_t* nn_pred, double* A_pred, double* D_pred,
+                                     int* has_duplicates) {
+  API_BEGIN();
+  if (!m_used || !nn_pred || !A_pred || !D_pred) return fail("null argument");
+  gpb_hip_vecchia_t* t = nullptr;
+  int m = 0;
+  const int rc = predict_factor_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, true, cov_type, var, a, &t, &m, has_duplicates);
+  struct Guard { gpb_hip_vecchia_t* p; ~Guard() { if (p) gpb_hip_vecchia_free(p); } } guard{t};
+  if (rc) return -1;
+  const int n_obs = h->n;
+  *m_used = m;
+  HIP_OK(hipMemcpy(nn_pred, t->d_nn + (size_t)n_obs * m, sizeof(int) * (size_t)n_pred * m, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(A_pred, t->d_A + (size_t)n_obs * m, sizeof(double) * (size_t)n_pred * m, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(D_pred, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
   API_END();
 }
 
@@ -843,8 +882,8 @@ int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gp
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 2));
   HIP_OK(hipMalloc(&h->d_info, sizeof(int)));
   const std::vector<double> tab = exp_table();
-  HIP_OK(hipMalloc(&h->d_exp_tab, 64 * sizeof(double)));
-  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_exp_tab, GPB_EXP_TAB_SIZE * sizeof(double)));
+  HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), GPB_EXP_TAB_SIZE * sizeof(double), hipMemcpyHostToDevice));
   *out = h;
   API_END();
 }

@@ -24,11 +24,14 @@ enum : int {
 #define GPB_MT_CASES GPB_CASE(10) GPB_CASE(20) GPB_CASE(30) GPB_CASE(40) GPB_CASE(50) GPB_CASE(62)
 #endif
 #define GPB_MAX_NEIGHBORS 62
+#ifndef GPB_EXP_TAB_SIZE
+#define GPB_EXP_TAB_SIZE 256   // entries of the 2^(j/256) table (dev_common.h: exp_of_scaled)
+#endif
 
 struct VecchiaKernelArgs {
   const double4* pts;      // [n] {x0, x1, x2, y} in Vecchia order
   const int* nn;           // [n][m] neighbour indices, -1 padded
-  const double* exp_tab;   // [64] 2^(j/64)
+  const double* exp_tab;   // [GPB_EXP_TAB_SIZE] 2^(j/GPB_EXP_TAB_SIZE)
   double* partials;        // [GPB_NUM_PARTIALS][nblocks]  (term-major)
   double* A;               // MODE_FACTOR: [n][m]
   double* D;               // MODE_FACTOR: [n]

@@ -57,11 +57,15 @@ struct Layout {
   static constexpr int PS = MT / 16, PL = lane_of_row(MT);            // slot / lane of the point's own row
   static constexpr int YS = (MT + 1) / 16, YL = lane_of_row(MT + 1);  // slot / lane of the response row
   static constexpr int NCOL = MT + 1;              // columns 0..MT
-  static constexpr int PTS_STRIDE = NS * 16 + 1;   // LDS records per point group (+1: bank spread)
+  static constexpr int PTS_STRIDE = NS * 16 + 1;   // LDS records per point group with 32-byte records (+1: bank spread)
+  static constexpr int PTS_STRIDE24 = NS * 16 + 2; // ... with 24-byte records (d <= 2): keeps every point's block 16-byte aligned
   __host__ __device__ static constexpr int cmax(int s) { return (16 * s + 15 < MT) ? 16 * s + 15 : MT; }
 };
 
-struct Rec { double x, y, z, w; };   // scaled, centred coordinates + response (w)
+// scaled, centred coordinates + response (w); 24 bytes when the third coordinate does not exist (d <= 2)
+template <bool D3> struct RecT;
+template <> struct RecT<true> { double x, y, z, w; __device__ __forceinline__ double zz() const { return z; } };
+template <> struct RecT<false> { double x, y, w; __device__ __forceinline__ double zz() const { return 0.0; } };
 
 // scaled squared distance + 1e-300 (keeps rsq finite for duplicates)
 template <bool D3>
@@ -81,12 +85,21 @@ __device__ __forceinline__ double sq_dist_s(double px, double py, double pz, dou
 //   rect(s, c)                : all 16 lanes of slot s, column c < 16 s
 //   pair(sA, cA, sB, cB, J)   : lanes l <= J take entry (slot sA, column cA), lanes l > J take (slot sB, column cB)
 //   solo(s, c)                : slot s, column c inside the slot's own triangle (only lanes whose row > c are meaningful)
+// Every callback also receives the step's index E (0 .. num_lower_steps<MT>() - 1) as its last argument.
+template <int MT>
+__host__ __device__ constexpr int num_lower_steps() {
+  using L = Layout<MT>;
+  int n = 8 * L::NS * (L::NS - 1) + 15 * (L::NS / 2);
+  if (L::NS & 1) { const int s = L::NS - 1; const int chi = (16 * s + 14 < MT - 1) ? 16 * s + 14 : MT - 1; n += chi - 16 * s + 1; }
+  return n;
+}
 template <int MT, class FR, class FP, class FS>
 __device__ __forceinline__ void for_each_lower_step(FR&& rect, FP&& pair, FS&& solo) {
   using L = Layout<MT>;
+  constexpr int RECT_TOTAL = 8 * L::NS * (L::NS - 1);
   static_for<1, L::NS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
-    static_for<0, 16 * s>([&](auto c_) { rect(s_, c_); });
+    static_for<0, 16 * s>([&](auto c_) { rect(s_, c_, std::integral_constant<int, 8 * s * (s - 1) + decltype(c_)::value>{}); });
   });
   static_for<0, L::NS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
@@ -94,13 +107,14 @@ __device__ __forceinline__ void for_each_lower_step(FR&& rect, FP&& pair, FS&& s
       static_for<0, 15>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         constexpr int cA = 16 * s + j, cB = 16 * (s - 1) + 14 - j;
+        using E = std::integral_constant<int, RECT_TOTAL + 15 * (s / 2) + j>;
         if constexpr (cA <= MT - 1) pair(s_, std::integral_constant<int, cA>{}, std::integral_constant<int, s - 1>{},
-                                         std::integral_constant<int, cB>{}, std::integral_constant<int, 14 - j>{});
-        else solo(std::integral_constant<int, s - 1>{}, std::integral_constant<int, cB>{});
+                                         std::integral_constant<int, cB>{}, std::integral_constant<int, 14 - j>{}, E{});
+        else solo(std::integral_constant<int, s - 1>{}, std::integral_constant<int, cB>{}, E{});
       });
     } else if constexpr (s == L::NS - 1) {   // unpaired last (even) slot
       constexpr int chi = (16 * s + 14 < MT - 1) ? 16 * s + 14 : MT - 1;
-      static_for<16 * s, chi + 1>([&](auto c_) { solo(s_, c_); });
+      static_for<16 * s, chi + 1>([&](auto c_) { solo(s_, c_, std::integral_constant<int, RECT_TOTAL + 15 * (L::NS / 2) + decltype(c_)::value - 16 * s>{}); });
     }
   });
 }
@@ -117,22 +131,35 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   constexpr bool kNeedSolve = (MODE != MODE_NLL);
   constexpr int NP = (MODE == MODE_GRAD) ? GPB_NUM_PARTIALS : 3;
 
+  using Rec = RecT<D3>;
+  // MODE_GRAD with MT <= 30: d/dlog(a) of every kernel entry is kept in LDS from the assembly pass ([step][thread]: conflict-free,
+  // 31 x 256 x 8 B = 62 KB for MT = 30, two workgroups per CU) so that the contraction pass evaluates no exp; larger MT re-evaluate.
+  constexpr bool kStoreDK = (MODE == MODE_GRAD) && (MT <= 30);
+  constexpr int NSTEP = num_lower_steps<MT>();
+  constexpr bool kLastDkInReg = kStoreDK && D3;      // d = 3: 32-byte records; the last step's value stays in a register so that two workgroups fit a CU's 160 KB
+  constexpr int NSTORE = kStoreDK ? (kLastDkInReg ? NSTEP - 1 : NSTEP) : 1;
+  constexpr int PSTRIDE = D3 ? L::PTS_STRIDE : L::PTS_STRIDE24;
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
-  __shared__ Rec s_pts[16][L::PTS_STRIDE];
+  __shared__ __attribute__((aligned(16))) Rec s_pts[16][PSTRIDE];
   __shared__ double s_red[GPB_NUM_PARTIALS][16];
-  __shared__ double s_A[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? NS * 16 + 1 : 1];
-  __shared__ double s_b[(MODE == MODE_GRAD) ? 16 : 1][(MODE == MODE_GRAD) ? NS * 16 + 1 : 1];
+  __shared__ double s_dk[NSTORE][kStoreDK ? 256 : 1];
+  // (A~_r, b~_r) pairs of the contraction pass: with kStoreDK they live in the point's record block, which is dead by then (the same 16
+  // lanes of one wavefront write and read it); the re-evaluating variant still needs the records and gets its own array
+  static_assert((sizeof(Rec) * PSTRIDE) % 16 == 0 && sizeof(Rec) * PSTRIDE >= 16 * (NS * 16), "record block: 16-byte aligned, room for the (A, b) pairs");
+  __shared__ double2 s_ab[(MODE == MODE_GRAD && !kStoreDK) ? 16 : 1][(MODE == MODE_GRAD && !kStoreDK) ? NS * 16 : 1];
+  double dk_last = 0.0;
 
   const int tid = threadIdx.x;
   const int g = tid >> 4;   // point within the workgroup
   const int l = tid & 15;   // lane within the point's DPP row
-  if (tid < GPB_EXP_TAB_SIZE) s_tab[tid] = args.exp_tab[tid] * args.var;   // var * 2^(j/64)
+  static_assert(GPB_EXP_TAB_SIZE == 256, "one table entry per thread");
+  s_tab[tid] = args.exp_tab[tid] * args.var;            // var * 2^(j/256)
 
   const long long i_raw = (long long)args.i_begin + (long long)blockIdx.x * 16 + g;
   const bool active = i_raw < (long long)args.i_end;
   const int i = active ? (int)i_raw : args.i_end - 1;   // inactive groups redo the last point, contribute 0
   const int m = args.m;
-  const double sc = args.a * k64OverLn2;                // coordinates are scaled so that exp(-a d) = 2^(-r'/64)
+  const double sc = args.a * kCoordScale;               // half-scaled coordinates: squared distances are (rho/2)^2, exp(-a d) = 2^(-rho/256)
 
   // ---- gather the rows' records: centred on the point (differences of nearby points stay accurate for
   //      coordinates with a large offset), scaled, staged in LDS for the column operands ------------------
@@ -147,9 +174,11 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
     Rec p;
     if (idx >= 0) {
       const double4 q = args.pts[idx];
-      p.x = (q.x - ctr.x) * sc; p.y = (q.y - ctr.y) * sc; p.z = D3 ? (q.z - ctr.z) * sc : 0.0; p.w = q.w;
+      p.x = (q.x - ctr.x) * sc; p.y = (q.y - ctr.y) * sc; p.w = q.w;
+      if constexpr (D3) p.z = (q.z - ctr.z) * sc;
     } else {
-      p.x = kDummyCoord * (double)(r + 1); p.y = 0.0; p.z = 0.0; p.w = 0.0;
+      p.x = kDummyCoord * (double)(r + 1); p.y = 0.0; p.w = 0.0;
+      if constexpr (D3) p.z = 0.0;
     }
     own[s] = p;
     s_pts[g][r] = p;
@@ -157,40 +186,58 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   __syncthreads();
   const double* tabv = s_tab;
   const Rec* gp = s_pts[g];
+  int row_off[NS];      // byte offset of this lane's row of slot s inside the point's record block
+#pragma unroll
+  for (int s = 0; s < NS; ++s) row_off[s] = (16 * s + ((s & 1) ? 15 - l : l)) * (int)sizeof(Rec);
 
   // ---- assemble the augmented matrix, row-per-lane, in registers ----------------
   // include/GPBoost/cov_fcts.h:634-755 (CalculateCovMat) + Vecchia_utils.cpp:1599-1609
   double M[NS][L::NCOL];
+  // one kernel evaluation; MODE_GRAD with kStoreDK also leaves d/dlog(a) of the entry in LDS (cov_fcts.h:2535-2554)
+  auto eval_entry = [&](const Rec& o, const Rec& q, auto e_) -> double {
+    const double d2 = sq_dist_s<D3>(o.x, o.y, o.zz(), q.x, q.y, q.zz());
+    if constexpr (kStoreDK) {
+      double dk;
+      const double v = matern_cov_dlog_s<COV>(d2, tabv, dk);
+      if constexpr (kLastDkInReg && decltype(e_)::value == NSTEP - 1) dk_last = dk;
+      else s_dk[decltype(e_)::value][tid] = dk;
+      return v;
+    } else {
+      return matern_cov_s<COV>(d2, tabv);
+    }
+  };
   for_each_lower_step<MT>(
-      [&](auto s_, auto c_) {                                     // rect
+      [&](auto s_, auto c_, auto e_) {                            // rect
         constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
-        const Rec q = gp[c];
-        M[s][c] = matern_cov_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+        M[s][c] = eval_entry(own[s], gp[c], e_);
       },
-      [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_) {      // pair
+      [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_, auto e_) {   // pair
         constexpr int sA = decltype(sA_)::value, cA = decltype(cA_)::value, sB = decltype(sB_)::value,
                       cB = decltype(cB_)::value, J = decltype(J_)::value;
-        const bool selA = l <= J;
-        const Rec q = gp[selA ? cA : cB];
-        const double ox = selA ? own[sA].x : own[sB].x, oy = selA ? own[sA].y : own[sB].y;
-        const double oz = D3 ? (selA ? own[sA].z : own[sB].z) : 0.0;
-        const double v = matern_cov_s<COV>(sq_dist_s<D3>(ox, oy, oz, q.x, q.y, q.z), tabv);
+        // lanes l <= J: entry (slot sA, column cA); lanes l > J: entry (slot sB, column cB).  Both records come from LDS through
+        // per-lane addresses picked with a constant lane mask (2 selects instead of 1 compare + 5 selects per step).
+        constexpr unsigned long long MA = row_lanes_le(J);
+        const int ro = sel_lanes<MA>(row_off[sA], row_off[sB]);
+        const int co = sel_lanes<MA>(cA, cB) * (int)sizeof(Rec);
+        const Rec o = *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + ro);
+        const Rec q = *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + co);
+        const double v = eval_entry(o, q, e_);
         M[sA][cA] = v;    // lanes of the other half hold entries above the diagonal there: never read
         M[sB][cB] = v;
       },
-      [&](auto s_, auto c_) {                                     // solo
+      [&](auto s_, auto c_, auto e_) {                            // solo
         constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
-        const Rec q = gp[c];
-        M[s][c] = matern_cov_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
+        M[s][c] = eval_entry(own[s], gp[c], e_);
       });
-  // diagonal: nugget / jitter (Vecchia_utils.cpp:1599-1609) and the first summand of D_i (:1555-1563)
+  // diagonal: nugget / jitter (Vecchia_utils.cpp:1599-1609) and the first summand of D_i (:1555-1563): one v_mov_b64 under a constant
+  // exec mask per diagonal entry (the lane that owns row c)
   static_for<0, NS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     static_for<16 * s, L::cmax(s) + 1>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
       const double dg = (c == MT) ? args.diag_i : args.diag_nn;
       if constexpr (c == 16 * s + 15 || c == MT) M[s][c] = dg;     // column never evaluated: plain init
-      else M[s][c] = (l == lane_of_row(c)) ? dg : M[s][c];
+      else set_lanes<row_lane_eq(lane_of_row(c))>(M[s][c], dg);
     });
   });
   // response row: entries are the gathered y's (only lane YL of slot YS; exec-masked, no DPP inside)
@@ -221,6 +268,8 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
     });
     if constexpr (kNeedSolve) static_for<sk, NS>([&](auto s_) { M[decltype(s_)::value][k] = T[decltype(s_)::value]; });
   });
+  // (a software-pipelined variant -- pivot k+1 started right after column k+1 of sweep k -- was measured at n = 1e6: no gain in any mode,
+  //  and its extra live registers pushed MT >= 40 into AGPR spills next to DPP reads; not kept)
 
   const double Dv = GPB_ROW_BCAST(L::PL, M[L::PS][MT]);   // D_i  (Vecchia_utils.cpp:1623; the reference stores 1/D_i, :1682)
   const double uv = GPB_ROW_BCAST(L::YL, M[L::YS][MT]);   // u_i = (B y)_i
@@ -229,7 +278,7 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   double red[GPB_NUM_PARTIALS];
 #pragma unroll
   for (int t = 0; t < GPB_NUM_PARTIALS; ++t) red[t] = 0.0;
-  red[GPB_P_LOGDET] = log(Dv);
+  red[GPB_P_LOGDET] = Dv;                      // the logarithm is taken once per workgroup (16 values, wave 0) below
   red[GPB_P_QUAD] = uv * uv * Dinv;
   red[GPB_P_BAD] = (Dv > 0.0) ? 0.0 : 1.0;
 
@@ -243,7 +292,7 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
     static_for_down<0, MT>([&](auto j_) {
       constexpr int j = decltype(j_)::value;
       constexpr int sj = j / 16, lj = lane_of_row(j);
-      static_for<0, j>([&](auto k_) {
+      static_for_down<0, j>([&](auto k_) {      // k = j-1 first: X[j-1], the next sweep's multiplier, is final early
         constexpr int k = decltype(k_)::value;
         GPB_ROW_FNMA(lj, X[k], M[sj][k], X[j]);
       });
@@ -260,57 +309,65 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
       if (active && l == 0) { args.D[i] = Dv; args.u[i] = uv; }
     }
     if constexpr (MODE == MODE_GRAD) {
-      // extended vectors over rows 0..MT+1: At = (A, -1, 0), bt = (b, 0, 0)
-      if (l == L::PL) { static_for<0, MT>([&](auto k_) { s_A[g][decltype(k_)::value] = X[decltype(k_)::value]; }); s_A[g][MT] = -1.0; s_A[g][MT + 1] = 0.0; }
-      if (l == L::YL) { static_for<0, MT>([&](auto k_) { s_b[g][decltype(k_)::value] = X[decltype(k_)::value]; }); s_b[g][MT] = 0.0; s_b[g][MT + 1] = 0.0; }
-      if (l == 0) { for (int r = MT + 2; r < NS * 16; ++r) { s_A[g][r] = 0.0; s_b[g][r] = 0.0; } }
+      // extended vectors over rows 0..MT+1 as pairs: (A~_r, b~_r) with A~ = (A, -1, 0), b~ = (b, 0, 0)
+      asm volatile("" ::: "memory");      // every read of the records precedes the pairs that overwrite them (kStoreDK)
+      double2* gab = kStoreDK ? reinterpret_cast<double2*>(&s_pts[g][0]) : &s_ab[g][0];
+      if (l == L::PL) { static_for<0, MT>([&](auto k_) { gab[decltype(k_)::value].x = X[decltype(k_)::value]; }); gab[MT].x = -1.0; gab[MT + 1].x = 0.0; }
+      if (l == L::YL) { static_for<0, MT>([&](auto k_) { gab[decltype(k_)::value].y = X[decltype(k_)::value]; }); gab[MT].y = 0.0; gab[MT + 1].y = 0.0; }
+      if (l == 0) { for (int r = MT + 2; r < NS * 16; ++r) gab[r] = make_double2(0.0, 0.0); }
       __syncthreads();
-      // range parameter: accD = sum_{c<r<=MT} dK_rc At_r At_c ; accU = sum dK_rc (bt_r At_c + bt_c At_r)
+      // range parameter: accD = sum_{c<r<=MT} dK_rc A~_r A~_c ; accU = sum dK_rc (b~_r A~_c + b~_c A~_r)
       // (dD_range = 2 accD, (dB_range y)_i = accU; derivation in DESIGN.md, restating
       //  Vecchia_utils.cpp:1640-1652 without forming dA_i)
-      double Ar[NS], br[NS];
+      double2 abr[NS];
+      int ab_off[NS];
       double sAA = 0.0, sbA = 0.0;
       static_for<0, NS>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
         const int r = 16 * s + ((s & 1) ? 15 - l : l);
-        Ar[s] = s_A[g][r]; br[s] = s_b[g][r];
-        if (r < MT) { sAA = __builtin_fma(Ar[s], Ar[s], sAA); sbA = __builtin_fma(br[s], Ar[s], sbA); }
+        abr[s] = gab[r]; ab_off[s] = r * (int)sizeof(double2);
+        if (r < MT) { sAA = __builtin_fma(abr[s].x, abr[s].x, sAA); sbA = __builtin_fma(abr[s].y, abr[s].x, sbA); }
       });
       double accD = 0.0, accU = 0.0;
-      const double* gA = s_A[g];
-      const double* gb = s_b[g];
+      auto accumulate = [&](double dk, const double2& r_, const double2& c_) {
+        accD = __builtin_fma(dk * r_.x, c_.x, accD);
+        accU = __builtin_fma(dk, __builtin_fma(r_.y, c_.x, c_.y * r_.x), accU);
+      };
+      // d/dlog(a) of the entry of step e: from LDS (kStoreDK) or evaluated again
+      auto dk_of = [&](auto e_, const Rec& o, const Rec& q) -> double {
+        if constexpr (kStoreDK) {
+          if constexpr (kLastDkInReg && decltype(e_)::value == NSTEP - 1) return dk_last;
+          else return s_dk[decltype(e_)::value][tid];
+        } else {
+          return matern_dlog_range_s<COV>(sq_dist_s<D3>(o.x, o.y, o.zz(), q.x, q.y, q.zz()), tabv);
+        }
+      };
       for_each_lower_step<MT>(
-          [&](auto s_, auto c_) {
+          [&](auto s_, auto c_, auto e_) {
             constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
-            const Rec q = gp[c];
-            const double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
-            const double Ac = gA[c], bc = gb[c];
-            accD = __builtin_fma(dk * Ar[s], Ac, accD);
-            accU = __builtin_fma(dk, __builtin_fma(br[s], Ac, bc * Ar[s]), accU);
+            accumulate(dk_of(e_, own[s], gp[c]), abr[s], gab[c]);
           },
-          [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_) {
+          [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_, auto e_) {
             constexpr int sA = decltype(sA_)::value, cA = decltype(cA_)::value, sB = decltype(sB_)::value,
                           cB = decltype(cB_)::value, J = decltype(J_)::value;
-            const bool selA = l <= J;
-            const int c = selA ? cA : cB;
-            const Rec q = gp[c];
-            const double ox = selA ? own[sA].x : own[sB].x, oy = selA ? own[sA].y : own[sB].y;
-            const double oz = D3 ? (selA ? own[sA].z : own[sB].z) : 0.0;
-            const double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(ox, oy, oz, q.x, q.y, q.z), tabv);
-            const double Arr = selA ? Ar[sA] : Ar[sB], brr = selA ? br[sA] : br[sB];
-            const double Ac = gA[c], bc = gb[c];
-            accD = __builtin_fma(dk * Arr, Ac, accD);
-            accU = __builtin_fma(dk, __builtin_fma(brr, Ac, bc * Arr), accU);
+            constexpr unsigned long long MA = row_lanes_le(J);
+            const int ci = sel_lanes<MA>(cA, cB);
+            double dk;
+            if constexpr (kStoreDK) dk = dk_of(e_, own[0], own[0]);
+            else {
+              const int ro = sel_lanes<MA>(row_off[sA], row_off[sB]);
+              dk = dk_of(e_, *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + ro),
+                         *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + ci * (int)sizeof(Rec)));
+            }
+            const int ao = sel_lanes<MA>(ab_off[sA], ab_off[sB]);
+            accumulate(dk, *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gab) + ao), gab[ci]);
           },
-          [&](auto s_, auto c_) {
+          [&](auto s_, auto c_, auto e_) {
             constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
-            const Rec q = gp[c];
-            double dk = matern_dlog_range_s<COV>(sq_dist_s<D3>(own[s].x, own[s].y, own[s].z, q.x, q.y, q.z), tabv);
-            const int r = 16 * s + ((s & 1) ? 15 - l : l);
-            dk = (r > c) ? dk : 0.0;                                 // entries on/above the diagonal do not exist
-            const double Ac = gA[c], bc = gb[c];
-            accD = __builtin_fma(dk * Ar[s], Ac, accD);
-            accU = __builtin_fma(dk, __builtin_fma(br[s], Ac, bc * Ar[s]), accU);
+            static_assert((s & 1) == 0, "solo steps only occur in even slots");
+            double dk = dk_of(e_, own[s], gp[c]);
+            set_lanes<row_lanes_le(c - 16 * s)>(dk, 0.0);              // rows <= c: entries on / above the diagonal do not exist
+            accumulate(dk, abr[s], gab[c]);
           });
       // reduce the four accumulators over the 16 lanes of the row (xor butterflies stay inside the row)
 #pragma unroll
@@ -336,8 +393,10 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   // ---- workgroup partial sums, fixed order; layout [term][workgroup] ---------------
   if (l == 0) {
 #pragma unroll
-    for (int t = 0; t < NP; ++t) s_red[t][g] = active ? red[t] : 0.0;
+    for (int t = 0; t < NP; ++t) s_red[t][g] = active ? red[t] : (t == GPB_P_LOGDET ? 1.0 : 0.0);
   }
+  __syncthreads();
+  if (tid < 16) s_red[GPB_P_LOGDET][tid] = log(s_red[GPB_P_LOGDET][tid]);   // sum log D_i (re_model_template.h:2946-2948); NaN for D_i <= 0 as before
   __syncthreads();
   if (tid < NP) {
     double acc = 0.0;

@@ -173,6 +173,16 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_
                                                     int32_t num_neighbors_pred, int cov_type, double var, double a, double* pred_mean,
                                                     double* pred_D, int* has_duplicates);
 
+/* Vecchia prediction 'order_obs_first_cond_all' (CalcPredVecchiaObservedFirstOrder with CondObsOnly = false,
+ * src/GPBoost/Vecchia_utils.cpp:1701-2093): the prediction points condition on their num_neighbors_pred nearest points among the observed AND
+ * the preceding prediction points (neighbour search with end_search_at = -1, :1806-1822).  The device does the search and the per-point
+ * factor of the appended rows; outputs (row-major [n_pred][*m_used], caller allocates for num_neighbors_pred columns): neighbour indices
+ * into (observed, prediction) (-1 padded), A_p, D_p (nugget included).  mean = Bp^-1 (-Bpo y) and the rows of Bp^-1 (:2061-2090) are
+ * host work: GPB_HIP_PredictCondAllHost / GPB_PredictREModel. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_predict_cond_all(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor,
+                                                    int32_t num_neighbors_pred, int cov_type, double var, double a, int32_t* m_used,
+                                                    int32_t* nn_pred, double* A_pred, double* D_pred, int* has_duplicates);
+
 /* Newton update of the tree leaf values in the GPBoost algorithm: replaces
  * REModelTemplate::NewtonUpdateLeafValues, Vecchia branch (include/GPBoost/re_model_template.h:4982-5063; B H and
  * (B H)^T D^-1 (B H) at :5005-5008, the L x L solve at :5056-5062).

@@ -184,6 +184,77 @@ GPBOOST_C_EXPORT int GPB_PredictREModel(REModelHandle handle,
 /* c_api.h:1686-1688 */
 GPBOOST_C_EXPORT int GPB_GetLikelihoodName(REModelHandle handle, char* out_str, int* num_char);
 
+/* ---- the rest of the reference's GPB_* surface (all 32 functions of c_api.h:1359-1824 are exported) and the log hook its Python
+ *      package registers at import (python-package/gpboost/basic.py:117-129).  Getters / setters answer from the model's state;
+ *      what is off the hot path (linear-regression covariates, auxiliary parameters, predictive variances of the training-data
+ *      random effects) returns -1 with a message. ---- */
+typedef void* BoosterHandle; /* c_api.h:31; the reference declares four REModel getters with this handle type */
+
+/* c_api.h:61 */
+GPBOOST_C_EXPORT int LGBM_RegisterLogCallback(void (*callback)(const char*));
+/* c_api.h:1490-1494 -- num_covariates = 0 / covariate_data = NULL: GPB_OptimCovPar; covariates: -1 */
+GPBOOST_C_EXPORT int GPB_OptimLinRegrCoefCovPar(REModelHandle handle,
+    const double* y_data,
+    const double* covariate_data,
+    int num_covariates,
+    const double* fixed_effects);
+/* c_api.h:1520-1521, 1526-1527 */
+GPBOOST_C_EXPORT int GPB_CanCalculateStandardErrorsCovPars(REModelHandle handle,
+    int* out);
+GPBOOST_C_EXPORT int GPB_CanCalculateStandardErrorsAuxPars(REModelHandle handle,
+    int* out);
+/* c_api.h:1556-1558 */
+GPBOOST_C_EXPORT int GPB_GetCoef(REModelHandle handle,
+    double* optim_coef,
+    bool calc_std_dev);
+/* c_api.h:1579 */
+GPBOOST_C_EXPORT int GPB_HasStdCylBesselK(int* has_bessel);
+/* c_api.h:1672-1677 -- posterior mean of the latent GP at the training locations (Gaussian Vecchia model): (y - F) - Psi^-1 (y - F) */
+GPBOOST_C_EXPORT int GPB_PredictREModelTrainingDataRandomEffects(REModelHandle handle,
+    const double* cov_pars_pred,
+    const double* y_obs,
+    double* out_predict,
+    const double* fixed_effects,
+    bool calc_var);
+/* c_api.h:1697-1699, 1708-1710, 1719-1721 */
+GPBOOST_C_EXPORT int GPB_GetOptimizerCovPars(REModelHandle handle,
+    char* out_str,
+    int* num_char);
+GPBOOST_C_EXPORT int GPB_GetOptimizerCoef(REModelHandle handle,
+    char* out_str,
+    int* num_char);
+GPBOOST_C_EXPORT int GPB_GetCGPreconditionerType(REModelHandle handle,
+    char* out_str,
+    int* num_char);
+/* c_api.h:1729-1730, 1738-1739, 1747-1748 */
+GPBOOST_C_EXPORT int GPB_GetNumCGSteps(BoosterHandle handle,
+    int* num_cg_steps);
+GPBOOST_C_EXPORT int GPB_GetNumCGStepsTridiag(BoosterHandle handle,
+    int* num_cg_steps);
+GPBOOST_C_EXPORT int GPB_GetNumModeFindingSteps(BoosterHandle handle,
+    int* num_cg_steps);
+/* c_api.h:1756-1757 */
+GPBOOST_C_EXPORT int GPB_SetLikelihood(REModelHandle handle,
+    const char* likelihood);
+/* c_api.h:1765-1766, 1774-1775, 1783-1784, 1792-1793 */
+GPBOOST_C_EXPORT int GPB_GetResponseData(REModelHandle handle,
+    double* response_data);
+GPBOOST_C_EXPORT int GPB_GetCovariateData(REModelHandle handle,
+    double* covariate_data);
+GPBOOST_C_EXPORT int GPB_GetOffsetData(REModelHandle handle,
+    double* fixed_effects);
+GPBOOST_C_EXPORT int GPB_SetOffsetData(REModelHandle handle,
+    const double* fixed_effects);
+/* c_api.h:1804-1807, 1815-1816, 1824-1825 */
+GPBOOST_C_EXPORT int GPB_GetAuxPars(REModelHandle handle,
+    double* aux_pars,
+    char* out_str,
+    bool calc_std_dev);
+GPBOOST_C_EXPORT int GPB_GetNumAuxPars(BoosterHandle handle,
+    int* num_aux_pars);
+GPBOOST_C_EXPORT int GPB_GetInitAuxPars(REModelHandle handle,
+    double* aux_pars);
+
 /* ---- additions (not in the reference ABI; used by the host mirror, tests and bench) ---- */
 
 /* Gradient of the nll wrt log(sigma2), log(sigma1_2/sigma2), log(a) -- the vector CalcGradPars hands

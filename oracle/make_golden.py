@@ -99,6 +99,10 @@ def laplace_grad_fixture(out_dir):
             g = refdrv.ref_laplace_gradient(coords, y, cp, lik, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
             res["%s_%s_grad" % (name, lik)] = g
             print("laplace grad", name, lik, g, flush=True)
+            # the same with the CG threshold tightened from 1e-2 to 1e-6: no dependence on which iteration crosses the threshold
+            gt = refdrv.ref_laplace_gradient(coords, y, cp, lik, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], cg_delta_conv=1e-6)
+            res["%s_%s_grad_tight" % (name, lik)] = gt
+            print("laplace grad (cg_delta_conv = 1e-6)", name, lik, gt, flush=True)
     np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
 
 
@@ -290,6 +294,13 @@ def config4_fixture(out_dir):
         res["negll_%d" % k] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
         res["seconds_%d" % k] = np.float64(time.time() - t0)
         print("config4", cp, "negll = %.12f" % res["negll_%d" % k], "%.1f s" % res["seconds_%d" % k], flush=True)
+    # the same evaluation with the CG stopping threshold tightened from the default 1e-2 to 1e-6: the value no longer hinges on which
+    # iteration a rounded residual norm crosses the threshold, so two correct implementations agree far below 1e-8
+    mdl.set_optim_config(cg_delta_conv=1e-6)
+    t0 = time.time()
+    res["negll_tight_0"] = np.float64(mdl.neg_log_likelihood(np.asarray((1.0, 0.1), dtype=np.float64), y))
+    res["seconds_tight_0"] = np.float64(time.time() - t0)
+    print("config4 cg_delta_conv=1e-6 negll = %.12f" % res["negll_tight_0"], "%.1f s" % res["seconds_tight_0"], flush=True)
     np.savez_compressed(os.path.join(out_dir, "config4_ref.npz"), **res)
 
 

@@ -91,8 +91,9 @@ class RefModel(object):
 # ---------------------------------------------------------------------------------------------
 class RefCAPIModel(object):
     def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1,
-                 likelihood="gaussian", cluster_ids=None):
-        self.L = C.CDLL(os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
+                 likelihood="gaussian", cluster_ids=None, lib_path=None, gpu_use=False):
+        # lib_path / gpu_use: the route-B build (oracle/Makefile.routeB -> oracle/_ref/lib_gpboost_hip.so), the same C API with GPU_use = true
+        self.L = C.CDLL(lib_path or os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
         self.L.LGBM_GetLastError.restype = C.c_char_p
         cm = np.asfortranarray(coords, dtype=np.float64)
         self.n, self.d = cm.shape
@@ -103,7 +104,7 @@ class RefCAPIModel(object):
             C.c_int(self.n), C.c_void_p() if cid is None else _P(cid), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
             C.c_int(1), _P(cm), C.c_int(self.d), C.c_void_p(), C.c_int(0), s(cov_function), C.c_double(shape), s("vecchia"),
             C.c_double(1.), C.c_double(0.), C.c_int(m), s(ordering), C.c_int(500), C.c_double(1.), s("kmeans++"),
-            s(likelihood), C.c_double(-999.), s("default"), C.c_int(seed), C.c_int(threads), C.c_bool(False),
+            s(likelihood), C.c_double(-999.), s("default"), C.c_int(seed), C.c_int(threads), C.c_bool(bool(gpu_use)),
             C.c_bool(False), C.c_void_p(), C.c_double(1.), C.byref(self.h))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
@@ -120,7 +121,7 @@ class RefCAPIModel(object):
 
     def set_optim_config(self, init_cov_pars=None, lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
                          use_nesterov_acc=True, nesterov_schedule_version=-999, trace=False, optimizer_cov="", momentum_offset=-999,
-                         convergence_criterion="default", m_lbfgs=-999):
+                         convergence_criterion="default", m_lbfgs=-999, cg_delta_conv=-999.):
         """GPB_SetOptimConfig with the argument order of include/LightGBM/c_api.h:1437-1467 (basic.py:5460-5496 binds it the same way)."""
         s = lambda x: C.c_char_p(x.encode())
         ic = None if init_cov_pars is None else np.ascontiguousarray(init_cov_pars, dtype=np.float64)
@@ -129,7 +130,7 @@ class RefCAPIModel(object):
             self.h, C.c_void_p() if ic is None else _P(ic), C.c_double(lr_cov), C.c_double(acc_rate_cov), C.c_int(max_iter),
             C.c_double(delta_rel_conv), C.c_bool(use_nesterov_acc), C.c_int(nesterov_schedule_version), C.c_bool(trace), s(optimizer_cov),
             C.c_int(momentum_offset), s(convergence_criterion), C.c_int(0), C.c_void_p(), C.c_double(-999.), C.c_double(-999.), s(""),
-            C.c_int(-999), C.c_int(-999), C.c_double(-999.), C.c_int(-999), C.c_bool(True), s("vadu"), C.c_int(1), C.c_int(-999),
+            C.c_int(-999), C.c_int(-999), C.c_double(cg_delta_conv), C.c_int(-999), C.c_bool(True), s("vadu"), C.c_int(1), C.c_int(-999),
             C.c_void_p(), C.c_bool(False), C.c_bool(False), _P(est), C.c_int(m_lbfgs), C.c_double(-999.))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
@@ -173,7 +174,7 @@ class RefCAPIModel(object):
 
 
 def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, lr=1e-3,
-                         threads=8):
+                         threads=8, cg_delta_conv=-999.):
     """Gradient of the reference's approximate negative marginal log-likelihood wrt (log sigma1^2, log a) at cov_pars = (sigma1^2, rho),
     read off ONE plain gradient-descent step of its own optimiser: theta_1 = exp(log theta_0 - lr * grad) (re_model_template.h:8737-8742),
     so grad = -(log theta_1 - log theta_0) / lr exactly, provided the step was not halved -- checked by repeating with lr / 2."""
@@ -181,7 +182,7 @@ def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponent
     for step in (lr, lr / 2):
         mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
         mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), lr_cov=step, max_iter=1, use_nesterov_acc=False,
-                             optimizer_cov="gradient_descent")
+                             optimizer_cov="gradient_descent", cg_delta_conv=cg_delta_conv)
         mdl.optim_cov_par(y)
         th1 = mdl.get_cov_par(2)
         res.append(np.array([-(np.log(th1[0]) - np.log(cov_pars[0])) / step, (np.log(th1[1]) - np.log(cov_pars[1])) / step]))

@@ -1,0 +1,56 @@
+"""Evidence run (GPU box, via scripts/run_reference_package_on_gpu.sh): the reference's unmodified Python package -- a scratch copy under
+oracle/_ref/refpkg, git-ignored, never committed -- drives lib_gpboost_amd.so on the MI355X and reproduces the R suite's goldens
+(R-package/tests/testthat/test_GPModel_gaussian_process.R:1144-1148, 1316-1334; test_GPModel_non_Gaussian_data.R) with ITS OWN
+GPModel class: creation, likelihood evaluation, fit (GPB_OptimCovPar through the package's fit()), summary getters, prediction."""
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpboost_amd.libpath import find_lib_path   # noqa: E402
+sys.modules.setdefault("optuna", types.ModuleType("optuna"))
+fake = types.ModuleType("gpboost.libpath")
+fake.find_lib_path = lambda: [find_lib_path()]
+sys.modules["gpboost.libpath"] = fake
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref", "refpkg"))
+import numpy as np            # noqa: E402
+import gpboost as gpb         # noqa: E402   (the reference's package)
+from oracle import orc        # noqa: E402   (only for the R fixture's inputs)
+
+print("package:", gpb.__file__, "| library:", find_lib_path(), flush=True)
+coords, y = orc.r_fixture()
+m = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none", likelihood="gaussian")
+nll = m.neg_log_likelihood(cov_pars=np.array([0.1, 1.6, 0.2]), y=y)
+print("neg_log_likelihood = %.7f (R golden 124.2252524)" % nll, flush=True)
+assert abs(nll - 124.2252524) < 1e-6
+params = {"optimizer_cov": "gradient_descent", "lr_cov": 0.1, "use_nesterov_acc": True, "acc_rate_cov": 0.5, "delta_rel_conv": 1e-6,
+          "maxit": 1000, "convergence_criterion": "relative_change_in_parameters",
+          "init_cov_pars": np.array([np.var(y, ddof=1) / 2, np.var(y, ddof=1) / 2, 0.0])}
+from scipy.spatial.distance import pdist   # noqa: E402
+params["init_cov_pars"][2] = pdist(coords).mean() / 3
+m = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none", likelihood="gaussian")
+m.fit(y=y, params=params)
+cp = m.get_cov_pars(format_pandas=False)
+print("fit: cov pars", np.asarray(cp).ravel(), "iterations", m._get_num_optim_iter(), "nll %.7f" % m.get_current_neg_log_likelihood(), flush=True)
+assert m._get_num_optim_iter() == 378
+assert np.abs(np.asarray(cp).ravel()[:3] - np.array([0.03297349, 1.07691542, 0.11378505])).sum() < 1e-6
+assert abs(m.get_current_neg_log_likelihood() - 122.7680889) < 1e-6
+coord_test = np.array([[0.1, 0.9], [0.10001, 0.90001], [0.7, 0.55]])
+m.set_prediction_data(vecchia_pred_type="order_obs_first_cond_obs_only", num_neighbors_pred=30)
+pred = m.predict(y=y, gp_coords_pred=coord_test, predict_cov_mat=True, predict_response=True)
+print("predict: mu", pred["mu"], "cov diag", np.diag(pred["cov"]), flush=True)
+assert np.abs(pred["mu"] - np.array([0.06968068, 0.06967750, 0.44208925])).sum() < 1e-6
+assert np.abs(np.diag(pred["cov"]) - np.array([0.6214955, 0.6215069, 0.4199531])).sum() < 1e-6
+print(m.summary() if hasattr(m, "summary") else "", flush=True)
+# non-Gaussian: the package's GPModel with likelihood = "bernoulli_logit" (Vecchia-Laplace, iterative methods) on seeded data
+rng = np.random.default_rng(21)
+c2 = rng.uniform(size=(2000, 2))
+lat = 1.5 * np.sin(5 * c2[:, 0]) * np.cos(3 * c2[:, -1]) + 0.3
+y2 = (rng.uniform(size=2000) < 1.0 / (1.0 + np.exp(-lat))).astype(np.float64)
+mb = gpb.GPModel(gp_coords=c2, cov_function="exponential", gp_approx="vecchia", num_neighbors=20, vecchia_ordering="random", likelihood="bernoulli_logit", seed=1)
+g = np.load(os.path.join(ROOT, "tests", "golden", "laplace_ref.npz"))
+v = mb.neg_log_likelihood(cov_pars=np.array([1.0, 0.1]), y=y2)
+print("bernoulli_logit neg_log_likelihood = %.9f (reference library %.9f)" % (v, float(g["lap_u2d_n2000_exp_m20_negll_0"])), flush=True)
+assert abs(v - float(g["lap_u2d_n2000_exp_m20_negll_0"])) <= 1e-8 * abs(v)
+print("REFERENCE PACKAGE ON MI355X: OK", flush=True)

@@ -1,0 +1,88 @@
+"""Evidence run on the MI355X for INTEGRATION.md route B (scripts run by gpurun; needs oracle/_ref/lib_gpboost_hip.so built by
+`make -f oracle/Makefile.routeB`): the reference's OWN host code -- REModel, its optimiser, Booster / GBDT / SerialTreeLearner, reached
+through its unchanged C API -- with the patched seams calling lib_gpboost_amd.so.
+
+ (1) Gaussian Vecchia model: GPB_EvalNegLogLikelihood and GPB_OptimCovPar with GPU_use = true against GPU_use = false of the same library
+     (same process, same inputs): likelihood to 1e-8 relative, same number of optimiser iterations, estimates to 1e-6.
+ (2) GPBoost-free LightGBM boosting: LGBM_BoosterUpdateOneIter with device_type = gpu (-> HIPTreeLearner, histograms on the device)
+     against device_type = cpu: predictions after 5 iterations agree to 1e-9."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refdrv   # noqa: E402
+from tests import cases     # noqa: E402
+
+LIBP = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
+print("library:", LIBP, flush=True)
+
+# ---- (1) GP ---------------------------------------------------------------------------------------------------------------------
+for n, m in ((20000, 30), (100000, 30)):
+    coords, _ = cases.synthetic(n, 2, seed=3)
+    rng = np.random.default_rng(5)
+    y = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
+    cp = np.array([0.2, 0.8, 0.15])
+    res = {}
+    for gpu in (False, True):
+        t0 = time.perf_counter()
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
+        t_create = time.perf_counter() - t0
+        mdl.neg_log_likelihood(cp, y)
+        t0 = time.perf_counter()
+        nll = mdl.neg_log_likelihood(cp * 1.01, y)
+        t_eval = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mdl.optim_cov_par(y)
+        t_fit = time.perf_counter() - t0
+        res[gpu] = dict(nll=nll, cov=mdl.get_cov_par(3), it=mdl.get_num_it(), t_create=t_create, t_eval=t_eval, t_fit=t_fit)
+        print("n=%d GPU_use=%s: nll %.10f | fit: %d iterations, cov pars %s | create %.2f s, eval %.3f s, fit %.2f s" %
+              (n, gpu, nll, res[gpu]["it"], res[gpu]["cov"], t_create, t_eval, t_fit), flush=True)
+    a, b = res[False], res[True]
+    assert abs(a["nll"] - b["nll"]) <= 1e-8 * abs(a["nll"]), (a["nll"], b["nll"])
+    assert a["it"] == b["it"], (a["it"], b["it"])
+    np.testing.assert_allclose(a["cov"], b["cov"], rtol=1e-6)
+    print("n=%d: GPU_use=true reproduces the CPU path of the same build; likelihood evaluation %.1fx, fit %.1fx faster" % (n, a["t_eval"] / b["t_eval"], a["t_fit"] / b["t_fit"]), flush=True)
+
+# ---- (2) trees ------------------------------------------------------------------------------------------------------------------
+L = C.CDLL(LIBP)
+L.LGBM_GetLastError.restype = C.c_char_p
+
+
+def ok(rc):
+    if rc != 0:
+        raise RuntimeError(L.LGBM_GetLastError().decode())
+
+
+n, F = 100000, 50
+rng = np.random.default_rng(1)
+X = np.ascontiguousarray(rng.uniform(size=(n, F)))
+yb = (np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + 0.5 * rng.standard_normal(n)).astype(np.float32)
+pred = {}
+for dev in ("cpu", "gpu"):
+    ds = C.c_void_p()
+    ok(L.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
+                                   C.c_char_p(("max_bin=255 verbosity=-1 device_type=%s" % dev).encode()), C.c_void_p(), C.byref(ds)))
+    ok(L.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yb.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
+    bst = C.c_void_p()
+    params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16" % dev
+    ok(L.LGBM_BoosterCreate(ds, C.c_char_p(params.encode()), C.byref(bst)))
+    fin = C.c_int(0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+    dt = time.perf_counter() - t0
+    out = np.empty(n)
+    olen = C.c_int64(0)
+    ok(L.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(0), C.c_int(0),
+                                   C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
+    pred[dev] = out
+    print("device_type=%s: 5 boosting iterations in %.3f s; prediction[:3] = %s" % (dev, dt, out[:3]), flush=True)
+    ok(L.LGBM_BoosterFree(bst)); ok(L.LGBM_DatasetFree(ds))
+np.testing.assert_allclose(pred["gpu"], pred["cpu"], rtol=0, atol=1e-9)
+print("trees: device_type=gpu (HIPTreeLearner) reproduces device_type=cpu, max |diff| = %.2e" % np.abs(pred["gpu"] - pred["cpu"]).max(), flush=True)
+print("ROUTE B ON MI355X: OK", flush=True)

@@ -73,13 +73,16 @@ def test_gaussian_configs_at_baseline_size(gpb, orc, name):
 
 
 def test_config4_n1e5_against_the_reference(gpb):
-    """BASELINE config 4 at its full size against ONE evaluation of the unmodified reference (26 s on 8 cores).
+    """BASELINE config 4 at its full size against the unmodified reference (tests/golden/config4_ref.npz, oracle/make_golden.py config4).
 
-    What is admitted and why: the value is defined up to the reference's own stopping rules -- every Newton system is solved by
-    preconditioned CG until the residual norm falls below cg_delta_conv = 1e-2 (CG_utils.cpp:74-82), and the log-determinant's
-    block CG stops on the MEAN residual norm of the 50 probes (:196-204).  Two correct implementations whose rounded norms straddle
-    the threshold in one iteration differ by one CG iteration; at this size that moves the value by <= 5e-9 relative (measured:
-    reference vs this path 3e-9).  North_star's 1e-8 therefore still holds and is what is asserted."""
+    Two evaluations of the reference are pinned:
+    * cg_delta_conv = 1e-6 (negll_tight_0, 57 s on 8 cores): with the CG residual threshold four orders below the default, the value no
+      longer depends on WHICH iteration a rounded residual norm crosses the threshold -- this is the comparison of the arithmetic
+      (factor, Newton, CG, Lanczos quadrature with the reference's probe vectors) and it is held to north_star's 1e-8.
+    * the defaults (cg_delta_conv = 1e-2, negll_0, 22 s): every Newton system is solved until ||r|| < 1e-2 (CG_utils.cpp:74-82) and the
+      log-determinant's block CG stops on the MEAN residual norm of the 50 probes (:196-204), so the value is only defined up to one CG /
+      Lanczos iteration: the reference, the C oracle and three versions of this path have given 62930.4025 / .4010 / .4023 / .4016
+      (spread 2.4e-8 relative) on these inputs, each moved by kernel values that differ in the last bit.  Admitted here: 5e-8."""
     g = np.load(os.path.join(GOLD, "config4_ref.npz"))
     n, m = 100000, 30
     coords, y = cases.synthetic_binary(n, 2, seed=1)
@@ -87,4 +90,8 @@ def test_config4_n1e5_against_the_reference(gpb):
                       num_neighbors=m, vecchia_ordering="random", seed=1)
     v = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
     ref = float(g["negll_0"])
-    assert abs(v - ref) <= RTOL * abs(ref), (v, ref, mdl.laplace_info())
+    assert abs(v - ref) <= 5e-8 * abs(ref), (v, ref, mdl.laplace_info())
+    mdl.set_optim_params({"cg_delta_conv": 1e-6})
+    vt = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    reft = float(g["negll_tight_0"])
+    assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())

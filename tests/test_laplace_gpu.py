@@ -94,9 +94,16 @@ def test_probit_against_oracle_with_details(gpb, orc, n, d, m, ct):
     st.set_neighbors(nn)
     st.laplace_set_likelihood("bernoulli_probit")
     st.laplace_set_labels(y[perm].astype(np.int32))
+    # (i) the arithmetic: CG threshold 1e-6 on both sides, so that no iteration count hinges on a rounded residual norm -> 1e-8
+    negll_t, info_t = st.laplace_logit(ct, var, a, cg_delta_conv=1e-6, want_mode=True)
+    ref_t, oinfo_t = orc.vecchia_laplace_logit(co, nn, ct, var, a, y[perm], likelihood="bernoulli_probit", cg_delta_conv=1e-6)
+    assert abs(negll_t - ref_t) <= RTOL * abs(ref_t), (negll_t, ref_t)
+    np.testing.assert_allclose(info_t["mode"], oinfo_t["mode"], rtol=0, atol=1e-7)
+    # (ii) the reference's default threshold 1e-2: two correct implementations may stop one CG / Lanczos iteration apart, which moves the
+    #      value by up to ~1e-6 relative at these sizes (measured 2e-7) -- admitted: 2e-6
     negll, info = st.laplace_logit(ct, var, a, want_mode=True)
     ref, oinfo = orc.vecchia_laplace_logit(co, nn, ct, var, a, y[perm], likelihood="bernoulli_probit")
-    assert abs(negll - ref) <= RTOL * abs(ref), (negll, ref)
+    assert abs(negll - ref) <= 2e-6 * abs(ref), (negll, ref)
     assert info["newton_it"] == oinfo["newton_it"]
     np.testing.assert_allclose(info["mode"], oinfo["mode"], rtol=0, atol=1e-4)   # CG stops at |r| < 1e-2: the mode is only that sharp
     st.close()

@@ -323,7 +323,7 @@ def test_r_suite_fit_then_predict_end_to_end(lib_built):
     again = mdl.predict(gp_coords_pred=coord_test, predict_var=True)          # y of the fit is still resident
     np.testing.assert_allclose(again["var"], np.diag(pred["cov"]), rtol=1e-12)
     with pytest.raises(gpboost_amd.GPBoostError, match="not on the MI355X path"):
-        mdl.predict(gp_coords_pred=coord_test, vecchia_pred_type="order_obs_first_cond_all")
+        mdl.predict(gp_coords_pred=coord_test, vecchia_pred_type="latent_order_obs_first_cond_all")
     with pytest.raises(gpboost_amd.GPBoostError, match="not supported for the Veccia"):
         mdl.set_prediction_data(vecchia_pred_type="nonsense")
 
@@ -387,3 +387,39 @@ def test_fit_errors_on_device(lib_built):
     ex = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="none")
     with pytest.raises(gpboost_amd.GPBoostError, match="gp_approx 'none'"):
         ex.fit(y)
+
+
+@pytest.mark.gpu
+def test_cond_all_prediction_on_device_reproduces_the_r_goldens_and_the_oracle(lib_built):
+    """vecchia_pred_type = 'order_obs_first_cond_all' through the reference's entry points (GPB_SetPredictionData + GPB_PredictREModel):
+    neighbour search among observed AND preceding prediction points + factor of the appended rows on the device, forward substitution with
+    Bp on the host (CalcPredVecchiaObservedFirstOrder, CondObsOnly = false, Vecchia_utils.cpp:1701-2093).  R goldens
+    test_GPModel_gaussian_process.R:1478-1485 (30 neighbours; the two points 1.4e-5 apart get covariance 0.09889262), and the oracle on a
+    seeded larger case (means / covariance matrix / variances, response and latent)."""
+    import gpboost_amd
+    from oracle import orc
+    coords, y = orc.r_fixture()
+    cp = np.array([0.02, 1.2, 0.9])
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none")
+    ct = np.array([[0.1, 0.9], [0.10001, 0.90001], [0.7, 0.55]])
+    mdl.set_prediction_data(vecchia_pred_type="order_obs_first_cond_all", num_neighbors_pred=30)
+    pred = mdl.predict(y=y, gp_coords_pred=ct, cov_pars=cp, predict_cov_mat=True, predict_response=True)
+    assert np.abs(pred["mu"] - [0.08665472, 0.08661259, 0.49011216]).sum() < 1e-6
+    assert np.abs(pred["cov"].ravel() - [0.11891004, 0.09889262, 0., 0.09889262, 0.11891291, 0., 0., 0., 0.08108126]).sum() < 1e-6
+    lat = mdl.predict(y=y, gp_coords_pred=ct, cov_pars=cp, predict_var=True, predict_response=False)
+    np.testing.assert_allclose(np.diag(pred["cov"]) - lat["var"], 0.02, rtol=1e-9)
+    # seeded larger case against the oracle: random ordering, Matern-1.5, d = 3, prediction points that neighbour each other
+    cases_ = [(4000, 3, 20, "matern", 1.5, 300, 25), (3000, 2, 30, "exponential", 0.5, 500, 40)]
+    for n, d, m, cf, sh, npred, mpred in cases_:
+        c2, y2 = cases.synthetic(n, d, seed=n + 1)
+        rng = np.random.default_rng(3)
+        cpred = rng.uniform(0.3, 0.5, size=(npred, d))
+        cp2 = np.array([0.1, 1.0, 0.15])
+        md = gpboost_amd.GPModel(gp_coords=c2, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m, vecchia_ordering="random", seed=2)
+        md.set_prediction_data(vecchia_pred_type="order_obs_first_cond_all", num_neighbors_pred=mpred)
+        pr = md.predict(y=y2, gp_coords_pred=cpred, cov_pars=cp2, predict_cov_mat=True, predict_response=False)
+        perm, _ = md.vecchia_structure()
+        ctid = orc.cov_type_id(cf, sh)
+        om, oc = orc.predict_cond_all(c2[perm], y2[perm], cpred, ctid, orc.transform_cov_pars(ctid, cp2), mpred, predict_response=False)
+        np.testing.assert_allclose(pr["mu"], om, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(pr["cov"], oc, rtol=1e-7, atol=1e-10)

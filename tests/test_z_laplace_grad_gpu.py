@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RC = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}
+# gradient of the Laplace approximation against the reference optimiser's own gradient with the CG threshold at 1e-6 on both sides.  The
+# reference's gradient is read off a gradient-descent step of size 5e-4 (oracle/refdrv.py: ref_laplace_gradient), i.e. it is itself only
+# known to ~1e-7 relative (rounding of log(theta_1 / theta_0) / lr); the residual CG error at 1e-6 is of the same order.
+GRAD_RTOL_TIGHT = 2e-6
 
 
 @pytest.fixture(scope="module")
@@ -59,8 +63,14 @@ def test_gradient_matches_the_reference_optimisers_step(gpb, orc, name, lik):
     st.set_neighbors(nn)
     st.laplace_set_likelihood(lik)
     st.laplace_set_labels(y[perm].astype(np.int32))
+    # (i) CG threshold 1e-6 on both sides (fixture key *_grad_tight): the comparison of the arithmetic, no stopping-rule noise
+    negll_t, grad_t = st.laplace_eval_grad(ct, cp[0], RC[ct] / cp[1], cg_delta_conv=1e-6)
+    ref_t = g["%s_%s_grad_tight" % (name, lik)]
+    np.testing.assert_allclose(grad_t, ref_t, rtol=GRAD_RTOL_TIGHT, atol=GRAD_RTOL_TIGHT * np.abs(ref_t).max())
+    # (ii) the reference's default threshold 1e-2: the three CG solves inside the gradient may each stop one iteration apart in two correct
+    #      implementations, which moves the gradient by up to ~4e-5 relative at these sizes (measured 1.2e-5) -- admitted: 5e-5
     negll, grad = st.laplace_eval_grad(ct, cp[0], RC[ct] / cp[1])
-    np.testing.assert_allclose(grad, g["%s_%s_grad" % (name, lik)], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(grad, g["%s_%s_grad" % (name, lik)], rtol=5e-5, atol=5e-5)
     st.close()
 
 
