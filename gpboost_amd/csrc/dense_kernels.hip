@@ -36,7 +36,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // store instruction covers 512 contiguous bytes of a row with its 16 lanes (write-combining friendly).
 constexpr int CT = 128;
 template <int COV, bool D3>
-__global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __restrict__ pts, int n, int np, double var,
+__global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __restrict__ pts, int n, int np, int ld, double var,
                                                               double a, double nugget, const double* __restrict__ gtab,
                                                               double* __restrict__ P) {
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void dense_cov_lower_kernel(const double4* __r
       if (r >= n || c >= n) val = (r == c) ? 1.0 : 0.0;     // identity padding
       v[cc] = val;
     }
-    double* rowp = P + (size_t)r * np + (size_t)tj * CT + tx * 4;
+    double* rowp = P + (size_t)r * ld + (size_t)tj * CT + tx * 4;   // ld > np: Psi is the top-left block of the augmented matrix (dense_grad)
     if (tj * CT + tx * 4 < np) *reinterpret_cast<double4*>(rowp) = make_double4(v[0], v[1], v[2], v[3]);
     if (tj * CT + 64 + tx * 4 < np) *reinterpret_cast<double4*>(rowp + 64) = make_double4(v[4], v[5], v[6], v[7]);
   }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, 
 
 // ---- triangular solves + reductions, one workgroup ----------------------------------------------
 // z = L^-1 y; out[0] = z^T z (= y^T Psi^-1 y), out[1] = 2 sum log L_ii; if x_out: x = L^-T z (= Psi^-1 y)
-__global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restrict__ P, int n, int np,
+__global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restrict__ P, int n, int np, int ld,
                                                           const double* __restrict__ y, double* __restrict__ z,
                                                           double* __restrict__ out, double* __restrict__ x_out) {
   __shared__ double sz[TB];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
   for (int i = tid; i < np; i += 1024) z[i] = i < n ? y[i] : 0.0;
   __syncthreads();
   for (int b0 = 0; b0 < np; b0 += TB) {
-    for (int e = tid; e < TB * TB; e += 1024) sD[e >> 6][e & 63] = P[(size_t)(b0 + (e >> 6)) * np + b0 + (e & 63)];
+    for (int e = tid; e < TB * TB; e += 1024) sD[e >> 6][e & 63] = P[(size_t)(b0 + (e >> 6)) * ld + b0 + (e & 63)];
     __syncthreads();
     // diagonal block: 64 sequential steps by the first wavefront
     if (tid < TB) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
     // rows below: z[i] -= L[i][b0:b0+64] . z_block   (4 threads per row, 16 columns each)
     const int sub = tid & 3;
     for (int i = b0 + TB + (tid >> 2); i < np; i += 256) {
-      const double* row = P + (size_t)i * np + b0 + sub * 16;
+      const double* row = P + (size_t)i * ld + b0 + sub * 16;
       double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc = __builtin_fma(row[k], sz[sub * 16 + k], acc);
@@ -269,20 +269,20 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
     }
     __syncthreads();
   }
-  double q = 0.0, ld = 0.0;
-  for (int i = tid; i < n; i += 1024) { q = __builtin_fma(z[i], z[i], q); ld += log(P[(size_t)i * np + i]); }
+  double q = 0.0, lgd = 0.0;
+  for (int i = tid; i < n; i += 1024) { q = __builtin_fma(z[i], z[i], q); lgd += log(P[(size_t)i * ld + i]); }
   sred[tid] = q; __syncthreads();
   for (int w = 512; w >= 1; w >>= 1) { if (tid < w) sred[tid] += sred[tid + w]; __syncthreads(); }
   if (tid == 0) out[0] = sred[0];
   __syncthreads();
-  sred[tid] = ld; __syncthreads();
+  sred[tid] = lgd; __syncthreads();
   for (int w = 512; w >= 1; w >>= 1) { if (tid < w) sred[tid] += sred[tid + w]; __syncthreads(); }
   if (tid == 0) out[1] = 2.0 * sred[0];
   if (x_out == nullptr) return;
   __syncthreads();
   // backward: L^T x = z, blocks from the bottom; x overwrites z
   for (int b0 = np - TB; b0 >= 0; b0 -= TB) {
-    for (int e = tid; e < TB * TB; e += 1024) sD[e >> 6][e & 63] = P[(size_t)(b0 + (e >> 6)) * np + b0 + (e & 63)];
+    for (int e = tid; e < TB * TB; e += 1024) sD[e >> 6][e & 63] = P[(size_t)(b0 + (e >> 6)) * ld + b0 + (e & 63)];
     __syncthreads();
     if (tid < TB) {
       double xi = z[b0 + tid];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
     for (int i = tid; i < b0; i += 1024) {
       double acc = 0.0;
 #pragma unroll 8
-      for (int k = 0; k < TB; ++k) acc = __builtin_fma(P[(size_t)(b0 + k) * np + i], sz[k], acc);
+      for (int k = 0; k < TB; ++k) acc = __builtin_fma(P[(size_t)(b0 + k) * ld + i], sz[k], acc);
       z[i] -= acc;
     }
     __syncthreads();
@@ -307,22 +307,97 @@ __global__ __launch_bounds__(1024) void trsv_lower_kernel(const double* __restri
   for (int i = tid; i < n; i += 1024) x_out[i] = z[i];
 }
 
+// ---- exact-GP gradient: the trace and the quadratic forms of CalcGradPars (re_model_template.h:2016-2040) in one pass --------
+// For the lower 128x128 tiles of the n x n problem: Sigma_ij = var k(d_ij) (no nugget) and dSigma_ij = d/dlog(a) of it are evaluated
+// again from the coordinates (never stored), W_ij = -(Psi^-1)_ij is read from the Schur-complement block of the augmented matrix
+// (rows / columns np.. of P2, leading dimension ld), ya = Psi^-1 y.  Per tile, with weight 2 off the diagonal:
+//   part[0] = sum Sigma_ij ya_i ya_j      part[1] = sum Sigma_ij W_ij      part[2] = sum dSigma_ij ya_i ya_j      part[3] = sum dSigma_ij W_ij
+// which give  g_k = -1/2 ya' dPsi_k ya / sigma2 + 1/2 tr(Psi^-1 dPsi_k)  for k = variance, range  (:2031-2034).
+template <int COV, bool D3>
+__global__ __launch_bounds__(256) void dense_grad_kernel(const double4* __restrict__ pts, int n, int np, int ld, double var, double a,
+                                                         const double* __restrict__ gtab, const double* __restrict__ P2,
+                                                         const double* __restrict__ ya, double* __restrict__ part, int ntiles) {
+  __shared__ double s_tab[GPB_EXP_TAB_SIZE];
+  __shared__ double s_rx[CT], s_ry[CT], s_rz[CT], s_ra[CT], s_cx[CT], s_cy[CT], s_cz[CT], s_ca[CT];
+  __shared__ double s_red[4][256];
+  const int tid = threadIdx.x;
+  s_tab[tid] = gtab[tid] * var;
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > t) --ti;
+  const int tj = t - (int)((long long)ti * (ti + 1) / 2);
+  const double sc = a * kCoordScale;
+  if (tid < CT) {
+    const int r = ti * CT + tid;
+    const double4 p = r < n ? pts[r] : make_double4(0, 0, 0, 0);
+    s_rx[tid] = p.x * sc; s_ry[tid] = p.y * sc; s_rz[tid] = p.z * sc; s_ra[tid] = r < n ? ya[r] : 0.0;
+  } else {
+    const int c = tj * CT + tid - CT;
+    const double4 p = c < n ? pts[c] : make_double4(0, 0, 0, 0);
+    s_cx[tid - CT] = p.x * sc; s_cy[tid - CT] = p.y * sc; s_cz[tid - CT] = p.z * sc; s_ca[tid - CT] = c < n ? ya[c] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int rr = 0; rr < 8; ++rr) {
+    const int lr = ty * 8 + rr, r = ti * CT + lr;
+    if (r >= n) break;
+    const double px = s_rx[lr], py = s_ry[lr], pz = D3 ? s_rz[lr] : 0.0, yr = s_ra[lr];
+    const double* wrow = P2 + (size_t)(np + r) * ld + np;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int lc = (cc < 4) ? tx * 4 + cc : 64 + tx * 4 + (cc - 4);
+      const int c = tj * CT + lc;
+      if (c > r || c >= n) continue;
+      const double dx = px - s_cx[lc], dy = py - s_cy[lc];
+      double d2 = __builtin_fma(dx, dx, 1e-300);
+      d2 = __builtin_fma(dy, dy, d2);
+      if (D3) { const double dz = pz - s_cz[lc]; d2 = __builtin_fma(dz, dz, d2); }
+      double dk;
+      double k = matern_cov_dlog_s<COV>(d2, s_tab, dk);
+      if (r == c) { k = var; dk = 0.0; }
+      const double w = (r == c) ? 1.0 : 2.0;
+      const double yy = w * yr * s_ca[lc], ww = w * wrow[c];
+      acc[0] = __builtin_fma(k, yy, acc[0]); acc[1] = __builtin_fma(k, ww, acc[1]);
+      acc[2] = __builtin_fma(dk, yy, acc[2]); acc[3] = __builtin_fma(dk, ww, acc[3]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s_red[q][tid] = acc[q];
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s_red[q][tid] += s_red[q][tid + w];
+    }
+    __syncthreads();
+  }
+  if (tid < 4) part[(size_t)tid * ntiles + t] = s_red[tid][0];
+}
+
+// bottom-left block of the augmented matrix := identity (the rest was zeroed by a memset)
+__global__ void dense_aug_identity_kernel(double* __restrict__ P2, int np, int ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) P2[(size_t)(np + i) * ld + i] = 1.0;
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 template <int COV>
-static void launch_cov(bool d3, const double4* pts, int n, int np, double var, double a, double nugget, const double* gtab,
+static void launch_cov(bool d3, const double4* pts, int n, int np, int ld, double var, double a, double nugget, const double* gtab,
                        double* P, hipStream_t st) {
   const int nt = (np + CT - 1) / CT;
   const int ntiles = nt * (nt + 1) / 2;
-  if (d3) hipLaunchKernelGGL((dense_cov_lower_kernel<COV, true>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);
-  else hipLaunchKernelGGL((dense_cov_lower_kernel<COV, false>), dim3(ntiles), dim3(256), 0, st, pts, n, np, var, a, nugget, gtab, P);
+  if (d3) hipLaunchKernelGGL((dense_cov_lower_kernel<COV, true>), dim3(ntiles), dim3(256), 0, st, pts, n, np, ld, var, a, nugget, gtab, P);
+  else hipLaunchKernelGGL((dense_cov_lower_kernel<COV, false>), dim3(ntiles), dim3(256), 0, st, pts, n, np, ld, var, a, nugget, gtab, P);
 }
 
-hipError_t launch_dense_cov(int cov, bool d3, const double4* pts, int n, int np, double var, double a, double nugget,
+hipError_t launch_dense_cov(int cov, bool d3, const double4* pts, int n, int np, int ld, double var, double a, double nugget,
                             const double* gtab, double* P, hipStream_t st) {
   switch (cov) {
-    case kMatern05: launch_cov<kMatern05>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
-    case kMatern15: launch_cov<kMatern15>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
-    case kMatern25: launch_cov<kMatern25>(d3, pts, n, np, var, a, nugget, gtab, P, st); break;
+    case kMatern05: launch_cov<kMatern05>(d3, pts, n, np, ld, var, a, nugget, gtab, P, st); break;
+    case kMatern15: launch_cov<kMatern15>(d3, pts, n, np, ld, var, a, nugget, gtab, P, st); break;
+    case kMatern25: launch_cov<kMatern25>(d3, pts, n, np, ld, var, a, nugget, gtab, P, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -343,12 +418,16 @@ static void launch_update(double* P, int np, int kp0, int K, int r_base, int c_b
 //   STRIP_J touches columns REST_{J-1} also updates             -> waits for REST_{J-1}     (event ev_rest)
 //   panels of J + 1 touch only columns [J1, J1 + 512)           -> disjoint from REST_J, ordered after STRIP_J on st
 //   REST_J and REST_{J-1} overlap                               -> same stream st2, in order
-hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st, hipStream_t st2, hipEvent_t ev_panels, hipEvent_t ev_rest) {
+// ncols < np (default: all): only the first ncols columns are factorised; the rest of the matrix then holds the Schur complement
+// C22 - L21 L21^T of the trailing block (lower triangle) -- the exact-GP gradient uses it on [[Psi, .], [I, 0]] to get -Psi^-1.
+hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st, hipStream_t st2, hipEvent_t ev_panels, hipEvent_t ev_rest,
+                                 int ncols) {
   constexpr int OB = 512;
+  if (ncols <= 0 || ncols > np) ncols = np;
   const bool lookahead = st2 != nullptr && ev_panels != nullptr && ev_rest != nullptr && np > 2 * OB;
   bool rest_pending = false;
-  for (int J0 = 0; J0 < np; J0 += OB) {
-    const int Jend = (J0 + OB < np) ? J0 + OB : np;
+  for (int J0 = 0; J0 < ncols; J0 += OB) {
+    const int Jend = (J0 + OB < ncols) ? J0 + OB : ncols;
     for (int k0 = J0; k0 < Jend; k0 += TB) {
       hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
       const int rows_below = np - k0 - TB;
@@ -376,9 +455,33 @@ hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st, h
   return hipGetLastError();
 }
 
-hipError_t launch_dense_solve(const double* P, int n, int np, const double* y, double* z, double* out, double* x_out,
+hipError_t launch_dense_aug_identity(double* P2, int np, int ld, hipStream_t st) {
+  hipLaunchKernelGGL(dense_aug_identity_kernel, dim3((np + 255) / 256), dim3(256), 0, st, P2, np, ld);
+  return hipGetLastError();
+}
+
+template <int COV>
+static void launch_grad(bool d3, const double4* pts, int n, int np, int ld, double var, double a, const double* gtab, const double* P2,
+                        const double* ya, double* part, int ntiles, hipStream_t st) {
+  if (d3) hipLaunchKernelGGL((dense_grad_kernel<COV, true>), dim3(ntiles), dim3(256), 0, st, pts, n, np, ld, var, a, gtab, P2, ya, part, ntiles);
+  else hipLaunchKernelGGL((dense_grad_kernel<COV, false>), dim3(ntiles), dim3(256), 0, st, pts, n, np, ld, var, a, gtab, P2, ya, part, ntiles);
+}
+int dense_grad_num_tiles(int np) { const int nt = (np + CT - 1) / CT; return nt * (nt + 1) / 2; }
+hipError_t launch_dense_grad(int cov, bool d3, const double4* pts, int n, int np, int ld, double var, double a, const double* gtab,
+                             const double* P2, const double* ya, double* part, hipStream_t st) {
+  const int ntiles = dense_grad_num_tiles(np);
+  switch (cov) {
+    case kMatern05: launch_grad<kMatern05>(d3, pts, n, np, ld, var, a, gtab, P2, ya, part, ntiles, st); break;
+    case kMatern15: launch_grad<kMatern15>(d3, pts, n, np, ld, var, a, gtab, P2, ya, part, ntiles, st); break;
+    case kMatern25: launch_grad<kMatern25>(d3, pts, n, np, ld, var, a, gtab, P2, ya, part, ntiles, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_solve(const double* P, int n, int np, int ld, const double* y, double* z, double* out, double* x_out,
                               hipStream_t st) {
-  hipLaunchKernelGGL(trsv_lower_kernel, dim3(1), dim3(1024), 0, st, P, n, np, y, z, out, x_out);
+  hipLaunchKernelGGL(trsv_lower_kernel, dim3(1), dim3(1024), 0, st, P, n, np, ld, y, z, out, x_out);
   return hipGetLastError();
 }
 

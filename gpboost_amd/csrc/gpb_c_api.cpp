@@ -294,6 +294,11 @@ int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, co
 int device_terms(void* ctx, double ratio, double a, int with_grad, double* t7) {
   auto* mdl = reinterpret_cast<REModelHip*>(ctx);
   for (int q = 0; q < 7; ++q) t7[q] = 0.;
+  if (mdl->eh) {      // exact GP (gp_approx "none"): dense Cholesky; the gradient through one partial factorisation of [[Psi, .], [I, 0]]
+    if (with_grad) { if (gpb_hip_exact_grad_terms(mdl->eh, mdl->cov_type, ratio, a, t7)) return shim_error(); }
+    else if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, ratio, a, t7, nullptr, nullptr)) return shim_error();
+    return 0;
+  }
   for (auto* v : mdl->vhs) {
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
     int world = 0;
@@ -401,6 +406,9 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
         if (cluster_ids_data[i] != cluster_ids_data[0]) return set_error("GPB_CreateREModel: more than one cluster with gp_approx 'none' %s", scope);
     if (gpb_hip_exact_create(num_data, dim_gp_coords, gp_coords_data, &mdl->eh)) return shim_error();
     mdl->m = 0;
+    mdl->rng = std::mt19937(seed);                                   // rng_ (re_model_template.h:161): FindInitCovPar draws its sub-sample from it
+    mdl->coords0.assign(gp_coords_data, gp_coords_data + (size_t)num_data * dim_gp_coords); mdl->n0 = num_data;
+    mdl->cl_off = {0, num_data};
     *out = mdl.release();
     return 0;
   }
@@ -628,7 +636,6 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
     mdl->model_has_been_estimated = true;
     return 0;
   }
-  if (mdl->eh) return set_error("GPB_OptimCovPar: gp_approx 'none' %s", scope);
   if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
   if (!y_data) return set_error("GPB_OptimCovPar: y_data is NULL");
   for (int i = 0; i < mdl->n; ++i)
@@ -1144,16 +1151,11 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !negll || !grad3 || !cov_pars) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: null argument");
   if (mdl->likelihood != "gaussian") return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: Gaussian likelihood only (the gradient of the Laplace approximation is behind GPB_OptimCovPar and gpb_hip_vecchia_laplace_grad_current)");
-  if (mdl->eh) return set_error("GPB_HIP_EvalNegLogLikelihoodAndGrad: gradients of the exact (dense) GP are not on the MI355X hot path of this library yet");
   double tr[3];
   if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
   if (upload_y(mdl, y_data, fixed_effects)) return -1;
   double t7[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (auto* v : mdl->vhs) {
-    double t[7];
-    if (gpb_hip_vecchia_grad_terms(v, mdl->cov_type, tr[1], tr[2], t)) return shim_error();
-    for (int q = 0; q < 7; ++q) t7[q] += t[q];
-  }
+  if (device_terms(mdl, tr[1], tr[2], 1, t7)) return -1;      // Vecchia: fused point kernel; exact GP: dense path (gpb_hip_exact_grad_terms)
   mdl->cur_negll = negll_from_terms(mdl->n, t7[0], t7[1], tr[0]);
   mdl->negll_valid = true;
   *negll = mdl->cur_negll;

@@ -110,6 +110,9 @@ struct gpb_hip_exact {
   int* d_info = nullptr;
   bool has_y = false;
   hipStream_t stream2 = nullptr; hipEvent_t ev_panels = nullptr, ev_rest = nullptr;   // look-ahead of the blocked Cholesky
+  double* d_P2 = nullptr;       // gradient: augmented matrix [[Psi, .], [I, 0]], (2 np)^2, allocated on first use
+  double* d_gpart = nullptr;    // gradient: [4][tiles] partial sums
+  double* d_g4 = nullptr;       // gradient: the four sums
 };
 
 struct gpb_hip_hist {
@@ -897,7 +900,7 @@ int gpb_hip_exact_free(gpb_hip_exact_t* h) {
   if (h->ev_panels) (void)hipEventDestroy(h->ev_panels);
   if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
   dev_free(h->d_pts); dev_free(h->d_P); dev_free(h->d_y); dev_free(h->d_z); dev_free(h->d_x); dev_free(h->d_out);
-  dev_free(h->d_exp_tab); dev_free(h->d_info);
+  dev_free(h->d_exp_tab); dev_free(h->d_info); dev_free(h->d_P2); dev_free(h->d_gpart); dev_free(h->d_g4);
   delete h;
   API_END();
 }
@@ -924,7 +927,7 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   for (auto& ev : e) HIP_OK(hipEventCreate(&ev));
   HIP_OK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
   HIP_OK(hipEventRecord(e[0], h->stream));
-  HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, h->np, var, a, 1.0, h->d_exp_tab, h->d_P, h->stream));   // Psi = Sigma + I (:9273-9287)
+  HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, h->np, h->np, var, a, 1.0, h->d_exp_tab, h->d_P, h->stream));   // Psi = Sigma + I (:9273-9287)
   HIP_OK(hipEventRecord(e[1], h->stream));
   if (!h->stream2) {
     HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -933,7 +936,7 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   }
   HIP_OK(gpb::launch_dense_cholesky(h->d_P, h->np, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest));
   HIP_OK(hipEventRecord(e[2], h->stream));
-  HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream));
+  HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream));
   HIP_OK(hipEventRecord(e[3], h->stream));
   int info = 0;
   HIP_OK(hipMemcpyAsync(out2_host, h->d_out, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
@@ -943,6 +946,52 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   if (ms3) for (int t = 0; t < 3; ++t) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e[t], e[t + 1])); ms3[t] = ms; }
   for (auto& ev : e) (void)hipEventDestroy(ev);
   if (info != 0) return fail("the covariance matrix is not positive definite (dense Cholesky failed)");
+  API_END();
+}
+
+/* Likelihood terms AND the covariance-parameter gradient sums of the exact (dense) GP: CalcGradPars, dense branch
+   (re_model_template.h:2016-2040) with CalcPsiInv (:6586-6614).  Psi^-1 comes out of ONE partial factorisation: the blocked Cholesky run
+   on the first np columns of [[Psi, .], [I, 0]] leaves L in the top-left block, L^-T below it and -L^-T L^-1 = -Psi^-1 as the Schur
+   complement in the bottom-right block (the same MFMA trailing updates as the factorisation itself).  out7 has the layout of
+   gpb_hip_vecchia_grad_terms: {y' Psi^-1 y, log|Psi|, 0, g1_var, g2_var, g1_range, g2_range}, gradient_k = g1_k / sigma2 + g2_k. */
+int gpb_hip_exact_grad_terms(gpb_hip_exact_t* h, int cov_type, double var, double a, double* out7_host) {
+  API_BEGIN();
+  if (!h || !out7_host) return fail("null argument");
+  if (!h->has_y) return fail("response data has not been set (call gpb_hip_exact_set_y)");
+  if (cov_type < 0 || cov_type > 2) return fail("covariance type %d is not on the HIP hot path (Matern 0.5/1.5/2.5 only)", cov_type);
+  if (!(var > 0.) || !(a > 0.)) return fail("covariance parameters must be positive (var = %g, range = %g)", var, a);
+  if (h->n > 24000) return fail("gpb_hip_exact_grad_terms: n = %d is too large for the dense gradient (the augmented matrix has (2 n)^2 entries); use gp_approx = 'vecchia'", h->n);
+  HIP_OK(hipSetDevice(h->device));
+  const int np = h->np, ld = 2 * np, ntiles = gpb::dense_grad_num_tiles(np);
+  if (!h->d_P2) {
+    HIP_OK(hipMalloc(&h->d_P2, sizeof(double) * (size_t)ld * ld));
+    HIP_OK(hipMalloc(&h->d_gpart, sizeof(double) * 4 * (size_t)ntiles));
+    HIP_OK(hipMalloc(&h->d_g4, sizeof(double) * 8));
+  }
+  if (!h->stream2) {
+    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
+  }
+  HIP_OK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  HIP_OK(hipMemsetAsync(h->d_P2, 0, sizeof(double) * (size_t)ld * ld, h->stream));
+  HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, np, ld, var, a, 1.0, h->d_exp_tab, h->d_P2, h->stream));
+  HIP_OK(gpb::launch_dense_aug_identity(h->d_P2, np, ld, h->stream));
+  HIP_OK(gpb::launch_dense_cholesky(h->d_P2, ld, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest, np));
+  HIP_OK(gpb::launch_dense_solve(h->d_P2, h->n, np, ld, h->d_y, h->d_z, h->d_out, h->d_x, h->stream));           // y' Psi^-1 y, log|Psi|, ya = Psi^-1 y
+  HIP_OK(gpb::launch_dense_grad(cov_type, h->d == 3, h->d_pts, h->n, np, ld, var, a, h->d_exp_tab, h->d_P2, h->d_x, h->d_gpart, h->stream));
+  HIP_OK(gpb::launch_reduce_partials(h->d_gpart, ntiles, 4, h->d_g4, nullptr, h->stream));
+  double o2[2], g4[4];
+  int info = 0;
+  HIP_OK(hipMemcpyAsync(o2, h->d_out, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(g4, h->d_g4, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (info != 0) return fail("the covariance matrix is not positive definite (dense Cholesky failed)");
+  // g4 = {S.yy, S.W, dS.yy, dS.W} with W = -Psi^-1:  -1/2 ya' dPsi ya  and  1/2 tr(Psi^-1 dPsi) = -1/2 sum dPsi o W
+  out7_host[0] = o2[0]; out7_host[1] = o2[1]; out7_host[2] = 0.;
+  out7_host[3] = -0.5 * g4[0]; out7_host[4] = -0.5 * g4[1];
+  out7_host[5] = -0.5 * g4[2]; out7_host[6] = -0.5 * g4[3];
   API_END();
 }
 

@@ -267,6 +267,10 @@ GPB_HIP_EXPORT int gpb_hip_exact_free(gpb_hip_exact_t* h);
 GPB_HIP_EXPORT int gpb_hip_exact_set_y(gpb_hip_exact_t* h, const double* y_host);
 GPB_HIP_EXPORT int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double a, double* out2_host,
                                            double* yaux_host, double* ms3);
+/* Likelihood terms and covariance-parameter gradient sums of the exact GP: replaces CalcPsiInv + the trace / quadratic forms of
+ * CalcGradPars' dense branch (include/GPBoost/re_model_template.h:6586-6614, 2016-2040).  out7 as gpb_hip_vecchia_grad_terms:
+ * {y' Psi^-1 y, log|Psi|, 0, g1_var, g2_var, g1_range, g2_range}; d nll / d log(theta_k) = g1_k / sigma2 + g2_k (transformed scale). */
+GPB_HIP_EXPORT int gpb_hip_exact_grad_terms(gpb_hip_exact_t* h, int cov_type, double var, double a, double* out7_host);
 
 /* ------------------------------------------------------------------------------------
  * LightGBM feature histograms: replaces Dataset::ConstructHistogramsInner for dense uint8

@@ -423,3 +423,56 @@ def test_cond_all_prediction_on_device_reproduces_the_r_goldens_and_the_oracle(l
         om, oc = orc.predict_cond_all(c2[perm], y2[perm], cpred, ctid, orc.transform_cov_pars(ctid, cp2), mpred, predict_response=False)
         np.testing.assert_allclose(pr["mu"], om, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(pr["cov"], oc, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_exact_gp_gradient_and_fit_reproduce_the_r_goldens(lib_built):
+    """gp_approx = "none" (SURVEY.md 8 row a10): the gradient of the exact GP -- CalcPsiInv + trace + quadratic forms
+    (re_model_template.h:6586-6614, 2016-2040), here one partial factorisation of [[Psi, .], [I, 0]] on the device -- and GPB_OptimCovPar on
+    top of it.  Pins: central differences of the oracle's exact likelihood (1e-6), and the R suite's own exact-GP fits
+    (test_GPModel_gaussian_process.R:130-182): gradient descent + Nesterov 59 iterations, without Nesterov 97, lr_cov = 1 -> 49,
+    relative_change_in_parameters 382, lbfgs to the suite's own tolerance."""
+    import gpboost_amd
+    from oracle import orc
+    from scipy.spatial.distance import pdist
+    coords, y = orc.r_fixture()
+    init = np.array([np.var(y, ddof=1) / 2, np.var(y, ddof=1) / 2, pdist(coords).mean() / 3])
+    # gradient against central differences of the oracle's exact likelihood, on the optimiser's scale (log sigma2, log ratio, log a)
+    for (n, d, cf, sh, cp) in [(100, 2, "exponential", 0.5, np.array([0.1, 1.6, 0.2])), (700, 3, "matern", 2.5, np.array([0.2, 0.9, 0.3])),
+                               (1300, 2, "matern", 1.5, np.array([0.05, 1.2, 0.15]))]:
+        c2, y2 = (coords, y) if n == 100 else cases.synthetic(n, d, seed=n)
+        mdl = gpboost_amd.GPModel(gp_coords=c2, cov_function=cf, cov_fct_shape=sh)
+        nll, grad = mdl.neg_log_likelihood_and_gradient(cp, y2)
+        ct = orc.cov_type_id(cf, sh)
+        pt = orc.transform_cov_pars(ct, cp)
+        assert abs(nll - orc.exact_nll(c2, ct, pt, y2)[2]) <= 1e-8 * abs(nll)
+        fd = np.empty(3)
+        for k in range(3):
+            h = 1e-5
+            pp, pm = pt.copy(), pt.copy()
+            pp[k] *= np.exp(h); pm[k] *= np.exp(-h)
+            fd[k] = (orc.exact_nll(c2, ct, pp, y2)[2] - orc.exact_nll(c2, ct, pm, y2)[2]) / (2 * h)
+        np.testing.assert_allclose(grad, fd, rtol=2e-6, atol=2e-6 * np.abs(fd).max())
+    gd = dict(optimizer_cov="gradient_descent", lr_cov=0.1, acc_rate_cov=0.5, delta_rel_conv=1e-6, use_nesterov_acc=True, init_cov_pars=init)
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential")
+    mdl.fit(y, params=gd)
+    assert mdl.get_num_optim_iter() == 59
+    assert np.abs(mdl.get_cov_pars() - np.array([0.03784221, 1.07390943, 0.11451432])).sum() < 1e-6
+    assert abs(mdl.get_current_neg_log_likelihood() - 122.7771373) < 1e-6
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential")
+    mdl.fit(y, params=dict(gd, use_nesterov_acc=False))
+    assert mdl.get_num_optim_iter() == 97
+    assert np.abs(mdl.get_cov_pars() - np.array([0.04040441, 1.06926607, 0.11502362])).sum() < 5e-6
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential")
+    mdl.fit(y, params=dict(gd, lr_cov=1.0))
+    assert mdl.get_num_optim_iter() == 49
+    assert np.abs(mdl.get_cov_pars() - np.array([0.03738147, 1.07520000, 0.11441031])).sum() < 1e-6
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential")
+    mdl.fit(y, params=dict(gd, convergence_criterion="relative_change_in_parameters"))
+    assert mdl.get_num_optim_iter() == 382
+    assert np.abs(mdl.get_cov_pars() - np.array([0.03276547, 1.07617676, 0.11352557])).sum() < 1e-6
+    assert abs(mdl.neg_log_likelihood(mdl.get_cov_pars(), y) - 122.7752664) < 1e-6
+    mdl = gpboost_amd.GPModel(gp_coords=coords, cov_function="exponential")
+    mdl.fit(y, params=dict(optimizer_cov="lbfgs", init_cov_pars=init))
+    assert np.abs(mdl.get_cov_pars() - np.array([0.03784221, 1.07390943, 0.11451432])).sum() < 0.02
+    assert abs(mdl.get_current_neg_log_likelihood() - 122.7771373) < 1e-2
