@@ -324,7 +324,7 @@ const char* kDuplicatesNonGaussianMessage =
     "Duplicates found in the coordinates for the Gaussian process. This is currently not supported for the Vecchia approximation for non-Gaussian likelihoods ";   // Vecchia_utils.cpp:1211-1214
 
 // CanCalculateStandardErrorsCovPars (re_model_template.h:1804-1807) restricted to what GPB_GetCovPar(calc_std_dev = true) does on the device
-bool can_calc_std_dev(const REModelHip* mdl) { return mdl->likelihood == "gaussian" && !mdl->eh && mdl->vhs.size() == 1 && false; }
+bool can_calc_std_dev(const REModelHip* mdl) { return mdl->likelihood == "gaussian" && !mdl->eh && mdl->vhs.size() == 1; }
 
 double negll_from_terms(int n, double yPy, double logdet, double sigma2) {
   return yPy / 2. / sigma2 + logdet / 2. + n / 2. * (std::log(sigma2) + std::log(2 * M_PI));   // :3132
@@ -669,8 +669,15 @@ int GPB_GetCovPar(REModelHandle handle, double* optim_cov_pars, bool calc_std_de
     optim_cov_pars[0] = mdl->cov_pars_tr[0]; optim_cov_pars[1] = range_const(mdl) / mdl->cov_pars_tr[1];
     return 0;
   }
-  if (calc_std_dev) return set_error("GPB_GetCovPar: standard deviations (Fisher information, re_model_template.h:10137) are not on the MI355X path of this library yet");
   transform_back(mdl, mdl->cov_pars_tr, optim_cov_pars);
+  if (calc_std_dev) {      // CalculateStandardErrorsCovPars -> CalcFisherInformation_Vecchia (stochastic trace, re_model_template.h:10137-10230)
+    if (!can_calc_std_dev(mdl)) return set_error("GPB_GetCovPar: standard deviations are on the MI355X path of this library for a one-cluster Gaussian Vecchia model only");
+    double se[3];
+    if (gpb_hip_vecchia_fisher_std_errors(mdl->vh, mdl->cov_type, optim_cov_pars[0], optim_cov_pars[1], optim_cov_pars[2], mdl->cov_pars_tr[1], mdl->cov_pars_tr[2],
+                                          mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, se)) return shim_error();
+    for (int j = 0; j < 3; ++j) optim_cov_pars[3 + j] = se[j];     // re_model.cpp:961-963
+    mdl->yaux_valid = false;                                        // the factor on the device was recomputed
+  }
   C_API_END();
 }
 

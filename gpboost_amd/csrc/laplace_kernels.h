@@ -47,6 +47,9 @@ hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStr
 hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st);
 hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st);
 hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st);
+hipError_t lap_factor_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double diag_nn, double nug,
+                            int which, double* dA, double* dD, hipStream_t st);   // which: 0 = d/dlog(range), 1 = d/dlog(variance ratio) with a nugget
+hipError_t lap_fisher_mid(const double* P, const double* T, const double* D, const double* dD, int n, int ncol, int nc, double* H, hipStream_t st);
 hipError_t lap_mul(const LapTri& T, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);       // plain product with T's entries
 hipError_t lap_row_stats(const double* U, const double* PIZ, const double* BPIZ, const double* dW3, const double* rdw, int n, int t, int nc, double* dld, hipStream_t st);
 hipError_t lap_coldots(const double* X, const double* Y, const double* T, int n, int ncol, int nc, double* out, hipStream_t st);

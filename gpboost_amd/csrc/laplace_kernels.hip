@@ -651,8 +651,12 @@ __device__ __forceinline__ double dcov_dlog_range_plain(int cov, double d, doubl
 }
 }  // namespace
 constexpr int kDerivLd = 63;      // leading dimension of the LDS matrix (odd: rows of one column fall into different banks)
+// which = 0: d/dlog(range) (the Laplace gradient and the Fisher information); which = 1: d/dlog(variance ratio) of a model WITH a nugget
+// (Fisher information of the Gaussian model: dC = C - nug I, dc = c  =>  dA = nug C^-1 A exactly, dD = var - dA'c - A'c).
+// diag_nn = diagonal of C_nn (Gaussian: var + 1; otherwise var (1 + 1e-10), Vecchia_utils.cpp:1599-1609); nug = its nugget part.
 __global__ __launch_bounds__(64) void lap_range_deriv_kernel(const double4* __restrict__ pts, const int* __restrict__ nn, const double* __restrict__ A, int n, int m,
-                                                             int cov, int d3, double var, double a, double* __restrict__ dA, double* __restrict__ dD) {
+                                                             int cov, int d3, double var, double a, double diag_nn, double nug, int which,
+                                                             double* __restrict__ dA, double* __restrict__ dD) {
   __shared__ double C[62 * kDerivLd];
   __shared__ double px[64], py[64], pz[64], Ai[64], tv[64], cv[64], dcv[64];
   const int i = blockIdx.x, lane = threadIdx.x;
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(64) void lap_range_deriv_kernel(const double4* __re
   __syncthreads();
   if (k == 0) {
     if (lane < m) dA[(size_t)i * m + lane] = 0.0;
-    if (lane == 0) dD[i] = 0.0;
+    if (lane == 0) dD[i] = which == 1 ? var : 0.0;
     return;
   }
   if (lane < k) {
@@ -684,8 +688,10 @@ __global__ __launch_bounds__(64) void lap_range_deriv_kernel(const double4* __re
       tr -= dcov_dlog_range_plain(cov, dq, var, a) * Ai[q];
       if (q < r) C[r * kDerivLd + q] = cov_plain(cov, dq, var, a);
     }
-    C[r * kDerivLd + r] = var * (1.0 + 1e-10);                 // Vecchia_utils.cpp:1608
-    tv[r] = tr; cv[r] = cov_plain(cov, di, var, a); dcv[r] = dcr;
+    C[r * kDerivLd + r] = diag_nn;                             // Vecchia_utils.cpp:1599-1609
+    cv[r] = cov_plain(cov, di, var, a);
+    if (which == 1) { tv[r] = nug * Ai[r]; dcv[r] = cv[r]; }   // dc - dC A = c - (C - nug I) A = nug A;  dc = c
+    else { tv[r] = tr; dcv[r] = dcr; }
   }
   __syncthreads();
   for (int j = 0; j < k; ++j) {                                // right-looking Cholesky, lower, in place
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(64) void lap_range_deriv_kernel(const double4* __re
   if (lane == 0) {
     double sacc = 0.0;
     for (int r = 0; r < k; ++r) sacc += tv[r];
-    dD[i] = -sacc;
+    dD[i] = (which == 1 ? var : 0.0) - sacc;
   }
 }
 
@@ -911,7 +917,25 @@ hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* 
   return hipGetLastError();
 }
 hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st) {
-  hipLaunchKernelGGL(lap_range_deriv_kernel, dim3(n), dim3(64), 0, st, pts, nn, A, n, m, cov, d3, var, a, dA, dD);
+  hipLaunchKernelGGL(lap_range_deriv_kernel, dim3(n), dim3(64), 0, st, pts, nn, A, n, m, cov, d3, var, a, var * (1.0 + 1e-10), 0.0, 0, dA, dD);
+  return hipGetLastError();
+}
+hipError_t lap_factor_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double diag_nn, double nug,
+                            int which, double* dA, double* dD, hipStream_t st) {
+  hipLaunchKernelGGL(lap_range_deriv_kernel, dim3(n), dim3(64), 0, st, pts, nn, A, n, m, cov, d3, var, a, diag_nn, nug, which, dA, dD);
+  return hipGetLastError();
+}
+// Fisher information (CalcFisherInformation_Vecchia, re_model_template.h:10137-10230): H = (P + dD o T) / D on a block
+__global__ void lap_fisher_mid_kernel(const double* __restrict__ P, const double* __restrict__ T, const double* __restrict__ D, const double* __restrict__ dD,
+                                      int n, int nc, double* __restrict__ H) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const size_t o = (size_t)blockIdx.y * n * nc + g;
+  const int i = (int)(g / nc);
+  H[o] = (P[o] + dD[i] * T[o]) / D[i];
+}
+hipError_t lap_fisher_mid(const double* P, const double* T, const double* D, const double* dD, int n, int ncol, int nc, double* H, hipStream_t st) {
+  hipLaunchKernelGGL(lap_fisher_mid_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, P, T, D, dD, n, nc, H);
   return hipGetLastError();
 }
 hipError_t lap_mul(const LapTri& T, int n, const double* x, double* out, int ncol, int nc, hipStream_t st) {

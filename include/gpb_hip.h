@@ -183,6 +183,13 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_predict_cond_all(gpb_hip_vecchia_t* h, int32_
                                                     int32_t num_neighbors_pred, int cov_type, double var, double a, int32_t* m_used,
                                                     int32_t* nn_pred, double* A_pred, double* D_pred, int* has_duplicates);
 
+/* Standard errors of (sigma2, sigma1_2, rho) of a Gaussian Vecchia model: stochastic (Hutchinson) Fisher information on the original scale,
+ * REModelTemplate::CalcFisherInformation_Vecchia (include/GPBoost/re_model_template.h:10137-10230) behind CalculateStandardErrorsCovPars /
+ * GPB_GetCovPar(calc_std_dev = true), with the reference's probe vectors (num_rand_vec, seed_rand_vec as in GPB_SetOptimConfig).
+ * (ratio, a) = the transformed parameters (sigma1_2 / sigma2, transformed range) belonging to (sigma2, sigma1_2, rho). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_fisher_std_errors(gpb_hip_vecchia_t* h, int cov_type, double sigma2, double sigma1_2, double rho, double ratio,
+                                                     double a, int num_rand_vec, int seed_rand_vec, double* se3_host);
+
 /* Newton update of the tree leaf values in the GPBoost algorithm: replaces
  * REModelTemplate::NewtonUpdateLeafValues, Vecchia branch (include/GPBoost/re_model_template.h:4982-5063; B H and
  * (B H)^T D^-1 (B H) at :5005-5008, the L x L solve at :5056-5062).
