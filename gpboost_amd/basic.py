@@ -255,6 +255,14 @@ class GPModel(object):
         return buf.value.decode("utf-8")
 
     # --- additions used by tests / bench (no reference C entry point exists for these) --------
+    def neg_log_likelihood_batch(self, cov_pars_K3):
+        """K likelihood evaluations at K parameter sets (K x 3) on the resident response with one synchronisation (GPB_HIP_EvalNegLogLikelihoodBatch)."""
+        cp = np.ascontiguousarray(cov_pars_K3, dtype=np.float64).reshape(-1, 3)
+        out = np.empty(cp.shape[0])
+        _safe_call(_lib().GPB_HIP_EvalNegLogLikelihoodBatch(self.handle, ctypes.c_int32(cp.shape[0]), _dptr(cp), _dptr(out)))
+        return out
+
+
     def neg_log_likelihood_and_gradient(self, cov_pars, y, fixed_effects=None):
         """(nll, gradient wrt log(sigma2), log(sigma1_2/sigma2), log(transformed range)): what
         ``CalcGradPars`` hands to the reference's optimisers (re_model_template.h:1988-2011)."""

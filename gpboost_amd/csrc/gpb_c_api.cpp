@@ -1172,6 +1172,26 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   C_API_END();
 }
 
+/* K evaluations of the Gaussian Vecchia likelihood at K parameter sets (row-major K x 3, original scale) on the response already resident
+   (GPB_EvalNegLogLikelihood with y_data once, or a fit): one synchronisation and, on a sharded handle, one all-reduce for the whole batch. */
+int GPB_HIP_EvalNegLogLikelihoodBatch(REModelHandle handle, int32_t K, const double* cov_pars_K3, double* negll_K) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !cov_pars_K3 || !negll_K || K < 1) return set_error("GPB_HIP_EvalNegLogLikelihoodBatch: invalid argument");
+  if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_HIP_EvalNegLogLikelihoodBatch: one-cluster Gaussian Vecchia model only");
+  if (!mdl->y_set) return set_error("GPB_HIP_EvalNegLogLikelihoodBatch: no response has been set (call GPB_EvalNegLogLikelihood with y_data once)");
+  std::vector<double> var(K), a(K), s2(K), t3((size_t)3 * K);
+  for (int k = 0; k < K; ++k) {
+    double tr[3];
+    if (transform_cov_pars(mdl, cov_pars_K3 + (size_t)3 * k, tr)) return -1;
+    s2[k] = tr[0]; var[k] = tr[1]; a[k] = tr[2];
+  }
+  if (gpb_hip_vecchia_nll_terms_batch(mdl->vh, mdl->cov_type, K, var.data(), a.data(), 1, t3.data())) return shim_error();
+  for (int k = 0; k < K; ++k) negll_K[k] = negll_from_terms(mdl->n, t3[(size_t)3 * k], t3[(size_t)3 * k + 1], s2[k]);
+  mdl->cur_negll = negll_K[K - 1]; mdl->negll_valid = true;
+  C_API_END();
+}
+
 int GPB_HIP_CalcYAux(REModelHandle handle, const double* y_data, double* cov_pars, double* y_aux) {
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);

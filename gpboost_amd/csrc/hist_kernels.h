@@ -17,6 +17,7 @@ struct HistKernelArgs {
   double* part_hess;        // [nchunks][fpad][256]   (non-constant hessian)
   uint32_t* part_cnt;       // [nchunks][fpad][256]
   int fpad, num_data, rows_per_chunk, nchunks;
+  int num_features;         // real features (<= fpad): the padding features of the last group are not accumulated
 };
 
 struct HistReduceArgs {

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
     if constexpr (HAS_HESS) (&s_hess[0][0])[t] = 0.0;
   }
   __syncthreads();
+  const int nf = min(GPB_HIST_FG, a.num_features - fg * GPB_HIST_FG);   // real features of this group (the last group may be partial)
   const int r0 = chunk * a.rows_per_chunk;
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
   const uint8_t* base = a.bins_rm + (size_t)fg * GPB_HIST_FG;
@@ -55,6 +56,19 @@ __global__ __launch_bounds__(256) void hist_build_kernel(HistKernelArgs a) {
     double h = 0.0;
     if constexpr (HAS_HESS) h = a.hess[row];
     const unsigned long long lo = ((unsigned long long)bv.y << 32) | bv.x, hi = ((unsigned long long)bv.w << 32) | bv.z;
+    if (nf < GPB_HIST_FG) {
+      // last, partial feature group: only its nf real features are accumulated (the padding features all sit in bin 0: 4 lanes of every
+      // step would hit ONE address, the slowest case of the LDS atomic unit, for entries nobody reads -- 22 % of the atomics at F = 50)
+      int f = tid % nf;
+      for (int s = 0; s < nf; ++s) {
+        const int b = (int)(((f & 8) ? hi : lo) >> (8 * (f & 7))) & 0xff;
+        atomicAdd(&s_grad[f][b], g);
+        if constexpr (HAS_HESS) atomicAdd(&s_hess[f][b], h);
+        atomicAdd(&s_cnt[f][b], 1u);
+        f = (f + 1 == nf) ? 0 : f + 1;
+      }
+      continue;
+    }
 #pragma unroll
     for (int s = 0; s < GPB_HIST_FG; ++s) {
       // lane l handles feature (s + l) % 16 at step s: the 64 lanes of a wavefront spread over all 16 sub-histograms

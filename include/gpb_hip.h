@@ -102,6 +102,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double*
 GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
                                              int gauss_likelihood, double* out3_host);
 /* Enqueue only; out3_dev is a device pointer (3 doubles). */
+/* K evaluations with one synchronisation (and, on a sharded handle, ONE ncclAllReduce of 3 K doubles): the trial points of a line search
+ * or any batch of parameter sets.  var[k], a[k]: transformed parameters of evaluation k; out: K x {y' Psi^-1 y, log|Psi|, #(D <= 0)} job-wide. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_batch(gpb_hip_vecchia_t* h, int cov_type, int32_t K, const double* var, const double* a,
+                                                   int gauss_likelihood, double* out3K_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_dev(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
                                                  int gauss_likelihood, double* out3_dev);
 

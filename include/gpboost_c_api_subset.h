@@ -257,6 +257,10 @@ GPBOOST_C_EXPORT int GPB_GetInitAuxPars(REModelHandle handle,
 
 /* ---- additions (not in the reference ABI; used by the host mirror, tests and bench) ---- */
 
+/* K likelihood evaluations at K parameter sets (row-major K x 3: sigma2, sigma1_2, rho) on the resident response: one synchronisation and
+ * -- on a sharded handle -- ONE RCCL all-reduce for the whole batch (gpb_hip_vecchia_nll_terms_batch).  Not in the reference ABI. */
+GPBOOST_C_EXPORT int GPB_HIP_EvalNegLogLikelihoodBatch(REModelHandle handle, int32_t K, const double* cov_pars_K3, double* negll_K);
+
 /* Gradient of the nll wrt log(sigma2), log(sigma1_2/sigma2), log(a) -- the vector CalcGradPars hands
  * to the reference's optimisers (include/GPBoost/re_model_template.h:1988-2011,
  * include/GPBoost/optim_utils.h:322-338); the reference has no C entry point for it. */

@@ -506,3 +506,19 @@ def test_cluster_ids_r_golden_and_reference_fixture(gpb, orc):
         assert abs((f(lp + e) - f(lp - e)) / (2 * eps) - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
     with pytest.raises(gpb.GPBoostError):
         mdl.vecchia_structure()
+
+
+def test_batched_evaluations_equal_single_evaluations(gpb):
+    """GPB_HIP_EvalNegLogLikelihoodBatch (K parameter sets, one synchronisation) against K calls of GPB_EvalNegLogLikelihood on the resident
+    response (y_data = NULL): bitwise equal -- same kernels, same fixed-order reductions."""
+    coords, y = cases.synthetic(30000, 2, seed=77)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=25, vecchia_ordering="random", seed=3)
+    base = np.array([0.2, 0.9, 0.12])
+    first = mdl.neg_log_likelihood(base, y)                 # uploads y once
+    cps = np.stack([base * (1 + 0.01 * k) for k in range(9)])
+    single = np.array([mdl.neg_log_likelihood(cp) for cp in cps])
+    assert single[0] == first
+    batch = mdl.neg_log_likelihood_batch(cps)
+    assert np.array_equal(batch, single)
+    with pytest.raises(gpb.GPBoostError):
+        gpb.GPModel(gp_coords=coords[:100], cov_function="exponential", gp_approx="vecchia", num_neighbors=5).neg_log_likelihood_batch(cps)   # no response set
