@@ -917,15 +917,15 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   // device kernels' GPB_MAX_NEIGHBORS
   int nnp = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;
   if (nnp > mdl->n) nnp = mdl->n;
-  if (nnp > 62) {
-    log_info("[GPBoost-AMD] [Warning] num_neighbors_pred = %d exceeds the %d neighbours the MI355X kernels support; %d are used\n", nnp, 62, 62);
-    nnp = 62;
+  if (nnp > 126) {
+    log_info("[GPBoost-AMD] [Warning] num_neighbors_pred = %d exceeds the %d neighbours the MI355X kernels support; %d are used\n", nnp, 126, 126);
+    nnp = 126;
   }
   if (cond_all) {
     // 'order_obs_first_cond_all': search + factor of the appended rows on the device, then the forward substitution with Bp and the rows
     // of Bp^-1 on the host (Vecchia_utils.cpp:2061-2090); y of the observed points in Vecchia order is the resident response
     if (nnp > mdl->n + np - 1) nnp = mdl->n + np - 1;
-    if (nnp > 62) nnp = 62;
+    if (nnp > 126) nnp = 126;
     int mu = 0;
     std::vector<int32_t> nnp_rows((size_t)np * nnp);
     std::vector<double> Ap((size_t)np * nnp), Dp(np);

@@ -228,7 +228,7 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   if (m > n - 1) m = n - 1;   // Vecchia_utils.cpp:755-758
   if (m < 0) m = 0;
   if (num_neighbors < 1 && n > 1) return fail("gpb_hip_vecchia_create: num_neighbors = %d", num_neighbors);
-  if (m > GPB_MAX_NEIGHBORS) return fail("gpb_hip_vecchia_create: num_neighbors = %d exceeds the supported maximum %d", m, GPB_MAX_NEIGHBORS);
+  if (m > GPB_MAX_NEIGHBORS_BIG) return fail("gpb_hip_vecchia_create: num_neighbors = %d exceeds the supported maximum %d", m, GPB_MAX_NEIGHBORS_BIG);
   auto* h = new gpb_hip_vecchia();
   h->n = n; h->d = d; h->m = m < 1 ? 1 : m;   // n == 1: one (empty, -1) column keeps indexing uniform
   h->i_begin = 0; h->i_end = n;
@@ -248,7 +248,7 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   const std::vector<double> tab = exp_table();
   HIP_OK(hipMalloc(&h->d_exp_tab, GPB_EXP_TAB_SIZE * sizeof(double)));
   HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), GPB_EXP_TAB_SIZE * sizeof(double), hipMemcpyHostToDevice));
-  const int nblocks = (n + 15) / 16;
+  const int nblocks = h->m > GPB_MAX_NEIGHBORS ? n : (n + 15) / 16;      // m > 62: the LDS-resident kernel, one workgroup per point
   HIP_OK(hipMalloc(&h->d_partials, sizeof(double) * (size_t)nblocks * GPB_NUM_PARTIALS));
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 8));
   HIP_OK(hipHostMalloc(&h->h_out, sizeof(double) * 8));
@@ -445,9 +445,11 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   k.diag_i = gauss ? var + 1.0 : var;                    // :1410-1417 + :1555-1563
   k.nugget = gauss ? 1.0 : 0.0;
   if (ev0) HIP_OK(hipEventRecord(ev0, h->stream));
-  HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
+  const bool big = h->m > GPB_MAX_NEIGHBORS;       // 62 < m <= 126: LDS-resident generality kernel (vecchia_big_kernels.hip)
+  if (big) HIP_OK(gpb::launch_vecchia_point_big(mode, cov_type, h->d == 3, k, h->stream));
+  else HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
   if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
-  const int nblocks = (h->i_end - h->i_begin + 15) / 16;
+  const int nblocks = big ? (h->i_end - h->i_begin) : (h->i_end - h->i_begin + 15) / 16;
   // the final reduction also writes the caller's device buffer (documented order), no extra copies on the stream
   (void)nout;
   HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream));
@@ -750,7 +752,7 @@ static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const d
   int m = num_neighbors_pred;
   const int m_cap = cond_all ? n_all - 1 : n_obs;               // :755-758 with end_search_at = num_data - 2 / n_obs - 1
   if (m > m_cap) m = m_cap;
-  if (m < 1 || m > GPB_MAX_NEIGHBORS) return fail("Vecchia prediction: num_neighbors_pred = %d (1..%d supported)", num_neighbors_pred, GPB_MAX_NEIGHBORS);
+  if (m < 1 || m > GPB_MAX_NEIGHBORS_BIG) return fail("Vecchia prediction: num_neighbors_pred = %d (1..%d supported)", num_neighbors_pred, GPB_MAX_NEIGHBORS_BIG);
   HIP_OK(hipSetDevice(h->device));
   // [observed (Vecchia order); prediction] as one temporary state; the observed records (coordinates + y) are copied on the device
   std::vector<double> call((size_t)n_all * d);

@@ -115,6 +115,12 @@ hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st) {
   const size_t shmem = (size_t)m * 64 * 12;
   const int nblocks = (a.pos1 - a.pos0 + 63) / 64;
   if (nblocks <= 0) return hipGetLastError();
+  if (shmem > 64 * 1024) {      // m > 85: the per-lane top-m lists need more than the default 64 KB of dynamic LDS
+    const void* kf = d == 1 ? reinterpret_cast<const void*>(vecchia_nn_kernel<1>) : (d == 2 ? reinterpret_cast<const void*>(vecchia_nn_kernel<2>)
+                                                                                            : reinterpret_cast<const void*>(vecchia_nn_kernel<3>));
+    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+  }
   switch (d) {
     case 1: hipLaunchKernelGGL(vecchia_nn_kernel<1>, dim3(nblocks), dim3(64), shmem, st, a); break;
     case 2: hipLaunchKernelGGL(vecchia_nn_kernel<2>, dim3(nblocks), dim3(64), shmem, st, a); break;

@@ -1,0 +1,193 @@
+// gpboost_amd/csrc/vecchia_big_kernels.hip
+//
+// The per-point Vecchia computation (src/GPBoost/Vecchia_utils.cpp:1461-1683, re_model_template.h:1988-2011, 9960-9968, 2946-2948) for
+// neighbour counts beyond what the register-resident kernel of vecchia_kernels.hip is instantiated for (62 < m <= 126; the R suite's
+// own Vecchia goldens use m = n - 1 = 99).  Same inputs, outputs and partial-sum layout as vecchia_point_kernel; different mapping:
+//   * one workgroup of 128 lanes per point, lane r owns row r of C_nn, which lives in LDS (lower triangle, odd leading dimension);
+//   * right-looking Cholesky in LDS, two forward substitutions (c -> D_i, y_nn -> u_i) and, for MODE_FACTOR / MODE_GRAD, two backward
+//     substitutions (A_i = C^-1 c, b_i = C^-1 y_nn); MODE_GRAD evaluates d/dlog(a) of every entry again for the contraction
+//     sum dK_rc A~_r A~_c (the derivation is the one of vecchia_kernels.hip).
+// It is the generality path (barrier-bound, one workgroup per CU at m = 126), not the fast one: the metric configurations (m = 30, 40)
+// never reach it.
+#include "dev_common.h"
+#include "vecchia_kernels.h"
+
+namespace gpb {
+
+namespace {
+constexpr int kBigThreads = 128;
+
+__device__ __forceinline__ double block_sum128(double v, double* s_red, int tid) {
+  s_red[tid] = v;
+  __syncthreads();
+  for (int w = 64; w >= 1; w >>= 1) {
+    if (tid < w) s_red[tid] += s_red[tid + w];
+    __syncthreads();
+  }
+  const double r = s_red[0];
+  __syncthreads();
+  return r;
+}
+}  // namespace
+
+template <int COV, bool D3, int MODE>
+__global__ __launch_bounds__(kBigThreads) void vecchia_point_big_kernel(VecchiaKernelArgs args, int ld) {
+  extern __shared__ double s_C[];                       // [m][ld] lower triangle of C_nn, then its Cholesky factor
+  __shared__ double s_tab[GPB_EXP_TAB_SIZE];
+  __shared__ double s_x[kBigThreads], s_y[kBigThreads], s_z[kBigThreads], s_w[kBigThreads];   // scaled, centred coordinates + response of row r
+  __shared__ double s_c[kBigThreads], s_z1[kBigThreads], s_z2[kBigThreads], s_red[kBigThreads];
+  constexpr int NP = (MODE == MODE_GRAD) ? GPB_NUM_PARTIALS : 3;
+  const int tid = threadIdx.x;
+  const int m = args.m;
+  const int i = args.i_begin + blockIdx.x;
+  for (int t = tid; t < GPB_EXP_TAB_SIZE; t += kBigThreads) s_tab[t] = args.exp_tab[t] * args.var;
+  const int idx = tid < m ? args.nn[(size_t)i * m + tid] : -1;
+  const int k = __syncthreads_count(idx >= 0);          // the valid neighbours are a prefix of the row (short rows: i < m)
+  const double sc = args.a * kCoordScale;
+  const double4 ctr = args.pts[i];
+  double ox = 0.0, oy = 0.0, oz = 0.0, ow = 0.0;
+  if (tid < k) {
+    const double4 q = args.pts[idx];
+    ox = (q.x - ctr.x) * sc; oy = (q.y - ctr.y) * sc; oz = D3 ? (q.z - ctr.z) * sc : 0.0; ow = q.w;
+  }
+  s_x[tid] = ox; s_y[tid] = oy; s_z[tid] = oz; s_w[tid] = ow;
+  __syncthreads();
+  auto d2 = [&](double ax, double ay, double az, double bx, double by, double bz) {
+    const double dx = ax - bx, dy = ay - by;
+    double v = __builtin_fma(dx, dx, 1e-300);
+    v = __builtin_fma(dy, dy, v);
+    if constexpr (D3) { const double dz = az - bz; v = __builtin_fma(dz, dz, v); }
+    return v;
+  };
+  // ---- C_nn (lower), c ------------------------------------------------------------------------------------------
+  if (tid < k) {
+    for (int q = 0; q < tid; ++q) s_C[tid * ld + q] = matern_cov_s<COV>(d2(ox, oy, oz, s_x[q], s_y[q], s_z[q]), s_tab);
+    s_C[tid * ld + tid] = args.diag_nn;
+    s_c[tid] = matern_cov_s<COV>(d2(ox, oy, oz, 0.0, 0.0, 0.0), s_tab);
+  }
+  s_z1[tid] = tid < k ? s_c[tid] : 0.0;
+  s_z2[tid] = tid < k ? ow : 0.0;
+  __syncthreads();
+  // ---- Cholesky, right-looking, in place (stands in for Eigen LLT, Vecchia_utils.cpp:1617) ------------------------
+  for (int j = 0; j < k; ++j) {
+    if (tid == j) s_C[j * ld + j] = sqrt(s_C[j * ld + j]);
+    __syncthreads();
+    if (tid > j && tid < k) s_C[tid * ld + j] /= s_C[j * ld + j];
+    __syncthreads();
+    if (tid > j && tid < k) {
+      const double lj = s_C[tid * ld + j];
+      for (int c = j + 1; c <= tid; ++c) s_C[tid * ld + c] = __builtin_fma(-lj, s_C[c * ld + j], s_C[tid * ld + c]);
+    }
+    __syncthreads();
+  }
+  // ---- L z1 = c, L z2 = y_nn ---------------------------------------------------------------------------------------
+  for (int j = 0; j < k; ++j) {
+    if (tid == j) { const double inv = 1.0 / s_C[j * ld + j]; s_z1[j] *= inv; s_z2[j] *= inv; }
+    __syncthreads();
+    if (tid > j && tid < k) {
+      const double l = s_C[tid * ld + j];
+      s_z1[tid] = __builtin_fma(-l, s_z1[j], s_z1[tid]);
+      s_z2[tid] = __builtin_fma(-l, s_z2[j], s_z2[tid]);
+    }
+    __syncthreads();
+  }
+  const double z1 = tid < k ? s_z1[tid] : 0.0, z2 = tid < k ? s_z2[tid] : 0.0;
+  const double s11 = block_sum128(z1 * z1, s_red, tid);
+  const double s12 = block_sum128(z1 * z2, s_red, tid);
+  const double Dv = args.diag_i - s11;                  // D_i  (Vecchia_utils.cpp:1555-1563, :1623)
+  const double uv = ctr.w - s12;                        // u_i = (B y)_i
+  const double Dinv = 1.0 / Dv;
+  double red[GPB_NUM_PARTIALS];
+#pragma unroll
+  for (int t = 0; t < GPB_NUM_PARTIALS; ++t) red[t] = 0.0;
+  red[GPB_P_LOGDET] = log(Dv);
+  red[GPB_P_QUAD] = uv * uv * Dinv;
+  red[GPB_P_BAD] = (Dv > 0.0) ? 0.0 : 1.0;
+  if constexpr (MODE != MODE_NLL) {
+    // ---- L^T A = z1, L^T b = z2 -----------------------------------------------------------------------------------
+    for (int j = k - 1; j >= 0; --j) {
+      if (tid == j) { const double inv = 1.0 / s_C[j * ld + j]; s_z1[j] *= inv; s_z2[j] *= inv; }
+      __syncthreads();
+      if (tid < j) {
+        const double l = s_C[j * ld + tid];
+        s_z1[tid] = __builtin_fma(-l, s_z1[j], s_z1[tid]);
+        s_z2[tid] = __builtin_fma(-l, s_z2[j], s_z2[tid]);
+      }
+      __syncthreads();
+    }
+    if constexpr (MODE == MODE_FACTOR) {
+      if (tid < m) args.A[(size_t)i * m + tid] = tid < k ? s_z1[tid] : 0.0;
+      if (tid == 0) { args.D[i] = Dv; args.u[i] = uv; }
+    }
+    if constexpr (MODE == MODE_GRAD) {
+      // range: accD = sum_{c<r} dK_rc A_r A_c - sum_r dK_pr A_r ; accU = sum_{c<r} dK_rc (b_r A_c + b_c A_r) - sum_r dK_pr b_r
+      // (A~ = (A, -1), b~ = (b, 0) over the extended rows: the point itself is the last row)
+      double accD = 0.0, accU = 0.0, aa = 0.0, ba = 0.0;
+      if (tid < k) {
+        const double Ar = s_z1[tid], br = s_z2[tid];
+        aa = Ar * Ar; ba = br * Ar;
+        for (int q = 0; q < tid; ++q) {
+          const double dk = matern_dlog_range_s<COV>(d2(ox, oy, oz, s_x[q], s_y[q], s_z[q]), s_tab);
+          const double Ac = s_z1[q], bc = s_z2[q];
+          accD = __builtin_fma(dk * Ar, Ac, accD);
+          accU = __builtin_fma(dk, __builtin_fma(br, Ac, bc * Ar), accU);
+        }
+        const double dkp = matern_dlog_range_s<COV>(d2(ox, oy, oz, 0.0, 0.0, 0.0), s_tab);
+        accD = __builtin_fma(-dkp, Ar, accD);
+        accU = __builtin_fma(-dkp, br, accU);
+      }
+      accD = block_sum128(accD, s_red, tid);
+      accU = block_sum128(accU, s_red, tid);
+      const double sAA = block_sum128(aa, s_red, tid);
+      const double sbA = block_sum128(ba, s_red, tid);
+      const double up = uv * Dinv;                       // u' = D^-1 B y  (re_model_template.h:1999)
+      const double dD_var = Dv - args.nugget - sAA;
+      const double uk_var = -sbA;
+      const double dD_rng = 2.0 * accD;
+      const double uk_rng = accU;
+      red[GPB_P_G1_VAR] = uk_var * up - 0.5 * up * up * dD_var;
+      red[GPB_P_G2_VAR] = 0.5 * Dinv * dD_var;
+      red[GPB_P_G1_RNG] = uk_rng * up - 0.5 * up * up * dD_rng;
+      red[GPB_P_G2_RNG] = 0.5 * Dinv * dD_rng;
+    }
+  }
+  if (tid < NP) {
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) if (t == tid) v = red[t];
+    args.partials[(size_t)tid * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+template <int COV, bool D3>
+static hipError_t launch_big_mode(int mode, const VecchiaKernelArgs& args, int npts, int ld, size_t lds, hipStream_t st) {
+#define GPB_BIG_LAUNCH(MODE_)                                                                                                     \
+  do {                                                                                                                              \
+    auto kern = vecchia_point_big_kernel<COV, D3, MODE_>;                                                                         \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e_ != hipSuccess) return e_;                                                                                                \
+    hipLaunchKernelGGL(kern, dim3(npts), dim3(kBigThreads), lds, st, args, ld);                                                   \
+  } while (0)
+  if (mode == MODE_NLL) GPB_BIG_LAUNCH(MODE_NLL);
+  else if (mode == MODE_FACTOR) GPB_BIG_LAUNCH(MODE_FACTOR);
+  else if (mode == MODE_GRAD) GPB_BIG_LAUNCH(MODE_GRAD);
+  else return hipErrorInvalidValue;
+#undef GPB_BIG_LAUNCH
+  return hipGetLastError();
+}
+
+// one workgroup (and one row of partial sums) per point: the caller sizes `partials` for (i_end - i_begin) blocks
+hipError_t launch_vecchia_point_big(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st) {
+  const int npts = args.i_end - args.i_begin;
+  if (npts <= 0 || args.m < 1 || args.m > GPB_MAX_NEIGHBORS_BIG) return hipErrorInvalidValue;
+  const int ld = args.m | 1;
+  const size_t lds = sizeof(double) * (size_t)args.m * ld;
+  switch (cov) {
+    case kMatern05: return d3 ? launch_big_mode<kMatern05, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern05, false>(mode, args, npts, ld, lds, st);
+    case kMatern15: return d3 ? launch_big_mode<kMatern15, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern15, false>(mode, args, npts, ld, lds, st);
+    case kMatern25: return d3 ? launch_big_mode<kMatern25, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern25, false>(mode, args, npts, ld, lds, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace gpb

@@ -23,7 +23,8 @@ enum : int {
 #define GPB_MT_LIST 10, 20, 30, 40, 50, 62
 #define GPB_MT_CASES GPB_CASE(10) GPB_CASE(20) GPB_CASE(30) GPB_CASE(40) GPB_CASE(50) GPB_CASE(62)
 #endif
-#define GPB_MAX_NEIGHBORS 62
+#define GPB_MAX_NEIGHBORS 62        // the register-resident point kernel (vecchia_kernels.hip)
+#define GPB_MAX_NEIGHBORS_BIG 126   // the LDS-resident generality kernel (vecchia_big_kernels.hip): 62 < m <= 126
 #ifndef GPB_EXP_TAB_SIZE
 #define GPB_EXP_TAB_SIZE 256   // entries of the 2^(j/256) table (dev_common.h: exp_of_scaled)
 #endif
@@ -47,6 +48,8 @@ struct VecchiaKernelArgs {
 
 int vecchia_padded_m(int m);
 hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
+// m > GPB_MAX_NEIGHBORS: one workgroup and one row of `partials` per point (vecchia_big_kernels.hip)
+hipError_t launch_vecchia_point_big(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
                                   hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);

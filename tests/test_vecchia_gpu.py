@@ -31,7 +31,7 @@ def test_device_is_gfx950_and_dpp_selftest(gpb):
 
 
 # ---- golden fixtures (reference outputs) ---------------------------------------------------------------
-GPU_GOLDEN = [n for n, c in sorted(cases.GOLDEN_CASES.items()) if c["m"] <= 62]
+GPU_GOLDEN = [n for n, c in sorted(cases.GOLDEN_CASES.items()) if c["m"] <= 126]
 
 
 @pytest.mark.parametrize("name", GPU_GOLDEN)
@@ -78,6 +78,10 @@ ORACLE_CASES = [
     (4000, 3, 10, "matern", 1.5, "random"),
     (2000, 2, 50, "exponential", 0.5, "random"),
     (2000, 2, 62, "matern", 2.5, "random"),
+    (1500, 2, 63, "exponential", 0.5, "random"),  # first size of the LDS-resident generality kernel (vecchia_big_kernels.hip)
+    (1200, 3, 100, "matern", 1.5, "random"),
+    (900, 2, 126, "matern", 2.5, "random"),       # its maximum
+    (100, 2, 99, "exponential", 0.5, "none"),     # m = n - 1: the Vecchia approximation is exact (R suite, test_GPModel_gaussian_process.R:1104-1111)
     (1500, 2, 1, "exponential", 0.5, "random"),
     (777, 2, 33, "matern", 1.5, "random"),      # m not an instantiated size: padded to 40
     (40, 2, 30, "exponential", 0.5, "random"),   # mostly short rows
@@ -222,7 +226,7 @@ def test_errors_are_loud(gpb):
     from gpboost_amd import shim
     coords, y = cases.synthetic(300, 2, seed=2)
     with pytest.raises(gpb.GPBoostError):
-        gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=80)   # > 62
+        gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=200)   # > 126
     with pytest.raises(gpb.GPBoostError):
         gpb.GPModel(gp_coords=np.random.default_rng(0).uniform(size=(100, 4)), cov_function="exponential",
                     gp_approx="vecchia", num_neighbors=10)                                            # d > 3
