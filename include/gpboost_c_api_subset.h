@@ -13,8 +13,8 @@
  *   one GP (any number of clusters = independent realisations through cluster_ids_data, Gaussian likelihood), no grouped effects /
  *   random coefficients / weights, d <= 3,
  *   cov_fct "exponential" or "matern" with shape 0.5 / 1.5 / 2.5, likelihood "gaussian", and either
- *   gp_approx "vecchia" (num_neighbors <= 62, vecchia_ordering "none" | "random") or gp_approx "none"
- *   (exact GP, dense Cholesky; likelihood and y_aux only); parameter estimation (GPB_OptimCovPar) and prediction
+ *   gp_approx "vecchia" (num_neighbors <= 126, vecchia_ordering "none" | "random") or gp_approx "none"
+ *   (exact GP, dense Cholesky; likelihood, y_aux, gradient and GPB_OptimCovPar); parameter estimation (GPB_OptimCovPar) and prediction
  *   (GPB_PredictREModel, "order_obs_first_cond_obs_only") for the Gaussian Vecchia model;
  *   likelihood "bernoulli_logit", "bernoulli_probit" (aliases "binary", "binary_logit", "binary_probit") or "poisson" with gp_approx "vecchia" and matrix_inversion_method "default" | "iterative"
  *   (Vecchia-Laplace approximation, "vadu"-preconditioned CG + stochastic Lanczos quadrature: the reference's
