@@ -198,8 +198,6 @@ class GPModel(object):
     def fit(self, y, X=None, params=None, fixed_effects=None):
         """Maximum-likelihood estimation of the covariance parameters (reference: GPModel.fit, basic.py:5422-5560 ->
         GPB_OptimCovPar).  y is uploaded once; every likelihood / gradient evaluation of the fit runs on the device."""
-        if X is not None:
-            raise GPBoostError("linear regression covariates are not on the MI355X hot path of this library")
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         if y.shape[0] != self.num_data:
             raise ValueError("Incorrect number of data points in 'y'")
@@ -211,8 +209,26 @@ class GPModel(object):
             if fixed_effects.shape[0] != self.num_data:
                 raise ValueError("Length of 'fixed_effects' is not correct ")
             fe_c = _dptr(fixed_effects)
+        if X is not None:
+            # linear regression term X beta: GPB_OptimLinRegrCoefCovPar (basic.py:5519-5540); beta is profiled out by GLS on the device
+            X = np.asarray(X, dtype=np.float64)
+            if X.ndim == 1:
+                X = X.reshape(-1, 1)
+            if X.shape[0] != self.num_data:
+                raise ValueError("Incorrect number of data points in 'X'")
+            Xf = np.asfortranarray(X)
+            self.num_coef = X.shape[1]
+            _safe_call(_lib().GPB_OptimLinRegrCoefCovPar(self.handle, _dptr(y), _dptr(Xf), ctypes.c_int(self.num_coef), fe_c))
+            return self
         _safe_call(_lib().GPB_OptimCovPar(self.handle, _dptr(y), fe_c))
         return self
+
+    def get_coef(self, std_err=False):
+        """Estimated linear regression coefficients (reference: GPModel.get_coef, basic.py:6332-6370 -> GPB_GetCoef)."""
+        p = int(getattr(self, "num_coef", 0))
+        out = np.empty(max(p, 1) * (2 if std_err else 1))
+        _safe_call(_lib().GPB_GetCoef(self.handle, _dptr(out), ctypes.c_bool(bool(std_err))))
+        return out[:p * (2 if std_err else 1)]
 
     def get_cov_pars(self, std_err=False):
         """(error variance, GP variance, range) on the original scale (reference: GPModel.get_cov_pars, basic.py:6290-6330)."""
@@ -323,7 +339,7 @@ class GPModel(object):
         return self
 
     def predict(self, y=None, gp_coords_pred=None, cov_pars=None, predict_var=False, predict_cov_mat=False, predict_response=True,
-                num_neighbors_pred=None, vecchia_pred_type=None, use_saved_data=False):
+                num_neighbors_pred=None, vecchia_pred_type=None, use_saved_data=False, X_pred=None):
         """Predictive mean / variances / covariance matrix at new locations (reference: GPModel.predict, basic.py:5702-6050 ->
         GPB_PredictREModel -> CalcPredVecchiaObservedFirstOrder); vecchia_pred_type "order_obs_first_cond_obs_only".  cov_pars=None
         uses the estimated parameters, y=None the response of the last fit / evaluation.  Returns {'mu', 'var', 'cov'}."""
@@ -353,12 +369,20 @@ class GPModel(object):
             cpc = np.asfortranarray(cp); crd_c = _dptr(cpc); npred = cp.shape[0]
         else:
             npred = int(getattr(self, "_num_data_pred_saved", 0))
+        xp_c = ctypes.c_void_p()
+        if X_pred is not None:
+            X_pred = np.asarray(X_pred, dtype=np.float64)
+            if X_pred.ndim == 1:
+                X_pred = X_pred.reshape(-1, 1)
+            if X_pred.shape[0] != npred or X_pred.shape[1] != int(getattr(self, "num_coef", 0)):
+                raise ValueError("Incorrect dimensions of 'X_pred'")
+            Xpf = np.asfortranarray(X_pred); xp_c = _dptr(Xpf)
         n_out = npred * (1 + npred) if predict_cov_mat else (2 * npred if predict_var else npred)
         out = np.empty(max(n_out, 1))
         _safe_call(_lib().GPB_PredictREModel(
             self.handle, y_c, ctypes.c_int(npred), _dptr(out), ctypes.c_bool(bool(predict_cov_mat)), ctypes.c_bool(bool(predict_var)),
             ctypes.c_bool(bool(predict_response)), ctypes.c_bool(False), ctypes.c_bool(False), ctypes.c_int(0), ctypes.c_int(0),
-            ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), crd_c, ctypes.c_void_p(), cp_c, ctypes.c_void_p(),
+            ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), crd_c, ctypes.c_void_p(), cp_c, xp_c,
             ctypes.c_bool(bool(use_saved_data)), ctypes.c_void_p(), ctypes.c_void_p()))
         res = {"mu": out[:npred].copy(), "var": None, "cov": None}
         if predict_var:

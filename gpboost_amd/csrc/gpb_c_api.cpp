@@ -29,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -96,6 +97,13 @@ struct REModelHip {
   int num_neighbors_pred = 0;   // 0 = default (2 * num_neighbors_, :299)
   int num_it = 0;
   GpbOptimResult last_fit;
+  // linear-regression covariates (GPB_OptimLinRegrCoefCovPar; Gaussian likelihood, coefficients profiled out by GLS = the reference's default "wls")
+  int p_cov = 0;
+  std::vector<double> X;        // data order, column-major n x p (X_)
+  std::vector<double> beta;     // beta_
+  std::vector<double> chol_XtPsiInvX;   // lower Cholesky factor (p x p, row-major) of X' Psi^-1 X (Psi on the error-variance-free scale) at the last GLS step
+  bool coef_estimated = false;
+  std::string optimizer_coef = "";   // as given to GPB_SetOptimConfig ("" = default: "wls" for the Gaussian likelihood)
   std::string cg_preconditioner_type = "vadu";   // ParsePreconditionerAlias default for a non-Gaussian Vecchia model (re_model_template.h:7137)
   std::vector<double> offset;                     // GPB_SetOffsetData (fixed_effects_, has_fixed_effects_; re_model_template.h:6318-6321)
   bool has_offset = false;
@@ -290,10 +298,41 @@ int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, co
   return 0;
 }
 
+// ProfileOutCoef (re_model_template.h:2665-2683) with UpdateCoefGLS (:10012-10019): beta = (X' Psi^-1 X)^-1 X' Psi^-1 y0 at the covariance
+// parameters of this evaluation -- the Gram matrix of B [X, y0] with weights 1 / D comes from the device in one pass -- then the response on the
+// device becomes the residual y0 - X beta (UpdateFixedEffects, :2859-2871).
+int profile_out_coef(REModelHip* mdl, double ratio, double a) {
+  const int p = mdl->p_cov, q = p + 1;
+  if (gpb_hip_vecchia_factor(mdl->vh, mdl->cov_type, ratio, a, 1)) return shim_error();
+  std::vector<double> G((size_t)q * q);
+  if (gpb_hip_vecchia_gram(mdl->vh, G.data())) return shim_error();
+  // Cholesky of X' Psi^-1 X (Eigen's llt().solve)
+  std::vector<double> L((size_t)p * p, 0.), rhs(p);
+  for (int i = 0; i < p; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      double sacc = G[(size_t)i * q + j];
+      for (int k = 0; k < j; ++k) sacc -= L[(size_t)i * p + k] * L[(size_t)j * p + k];
+      if (i == j) {
+        if (!(sacc > 0.)) return set_error("The matrix X' Psi^-1 X of the linear regression covariates is not positive definite (collinear covariates?)");
+        L[(size_t)i * p + i] = std::sqrt(sacc);
+      } else L[(size_t)i * p + j] = sacc / L[(size_t)j * p + j];
+    }
+    rhs[i] = G[(size_t)i * q + p];
+  }
+  for (int i = 0; i < p; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v -= L[(size_t)i * p + k] * rhs[k]; rhs[i] = v / L[(size_t)i * p + i]; }
+  for (int i = p - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < p; ++k) v -= L[(size_t)k * p + i] * rhs[k]; rhs[i] = v / L[(size_t)i * p + i]; }
+  mdl->beta = rhs;
+  mdl->chol_XtPsiInvX = L;
+  if (gpb_hip_vecchia_set_resid(mdl->vh, mdl->beta.data())) return shim_error();
+  mdl->yaux_valid = false;
+  return 0;
+}
+
 // the optimiser's window on the device: the shard sums of all clusters at (ratio, a); y is already resident
 int device_terms(void* ctx, double ratio, double a, int with_grad, double* t7) {
   auto* mdl = reinterpret_cast<REModelHip*>(ctx);
   for (int q = 0; q < 7; ++q) t7[q] = 0.;
+  if (mdl->p_cov > 0 && profile_out_coef(mdl, ratio, a)) return -1;      // response := y0 - X beta_GLS(ratio, a) before the terms are evaluated
   if (mdl->eh) {      // exact GP (gp_approx "none"): dense Cholesky; the gradient through one partial factorisation of [[Psi, .], [I, 0]]
     if (with_grad) { if (gpb_hip_exact_grad_terms(mdl->eh, mdl->cov_type, ratio, a, t7)) return shim_error(); }
     else if (gpb_hip_exact_nll_terms(mdl->eh, mdl->cov_type, ratio, a, t7, nullptr, nullptr)) return shim_error();
@@ -466,14 +505,14 @@ int GPB_REModelFree(REModelHandle handle) {
 int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, double acc_rate_cov, int max_iter, double delta_rel_conv,
                        bool use_nesterov_acc, int nesterov_schedule_version, bool trace, const char* optimizer, int momentum_offset,
                        const char* convergence_criterion, int num_covariates, double* /*init_coef*/, double /*lr_coef*/,
-                       double /*acc_rate_coef*/, const char* /*optimizer_coef*/, int cg_max_num_it, int cg_max_num_it_tridiag,
+                       double /*acc_rate_coef*/, const char* optimizer_coef, int cg_max_num_it, int cg_max_num_it_tridiag,
                        double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/, const char* cg_preconditioner_type,
                        int seed_rand_vec_trace, int /*piv_chol_rank*/, double* /*init_aux_pars*/, bool estimate_aux_pars,
                        bool /*init_coef_aux_pars_from_iid_model*/, const int* estimate_cov_par_index, int m_lbfgs,
                        double delta_conv_mode_finding) {
   C_API_BEGIN();
   if (!handle) return set_error("GPB_SetOptimConfig: null handle");
-  if (num_covariates > 0) return set_error("GPB_SetOptimConfig: linear regression covariates are not on the MI355X hot path of this library");
+  (void)num_covariates;      // covariates arrive with GPB_OptimLinRegrCoefCovPar; init_coef is irrelevant when the coefficients are profiled out ("wls")
   (void)estimate_aux_pars;   // the reference's packages pass true by default; none of the supported likelihoods has auxiliary parameters (NumAuxPars = 0), so there is nothing to estimate
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) {          // re_model_template.h:930-936
@@ -482,6 +521,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     std::copy(estimate_cov_par_index, estimate_cov_par_index + 3, mdl->optim.estimate_cov_par_index);
   }
   mdl->trace = trace;
+  if (optimizer_coef && optimizer_coef[0]) mdl->optimizer_coef = optimizer_coef;
   // REModel::SetOptimConfig (re_model.cpp:301-318): initial values are kept on the transformed scale
   if (init_cov_pars) {
     if (mdl->likelihood != "gaussian") {        // (sigma1_2, rho) -> (sigma1_2, a): no error variance (re_model.cpp:301-318 with gauss_likelihood_ = false)
@@ -888,8 +928,12 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_PredictREModel: this model %s", scope);
   if (sample_posterior || sample_prior) return set_error("GPB_PredictREModel: posterior / prior samples %s", scope);
   if (predict_cov_mat && predict_var) return set_error("Calculation of both the predictive covariance matrix and variances is not supported. Choose one option (predict_cov_mat or predict_var)");   // re_model.cpp Predict
-  if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred)
-    return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients / covariates for prediction %s", scope);
+  if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred)
+    return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients for prediction %s", scope);
+  if (mdl->p_cov > 0 && !mdl->coef_estimated) return set_error("GPB_PredictREModel: the model has covariates but no estimated coefficients");
+  if (mdl->p_cov > 0 && !covariate_data_pred && !use_saved_data) return set_error("No covariate data is provided in 'covariate_data_pred' but the model has linear regression covariates");   // re_model.cpp Predict
+  if (mdl->p_cov == 0 && covariate_data_pred) return set_error("Covariate data is provided in 'covariate_data_pred' but the model has no linear regression covariates");
+  if (mdl->p_cov > 0 && use_saved_data) return set_error("GPB_PredictREModel: saved prediction data together with covariates %s", scope);
   const bool cond_all = mdl->vecchia_pred_type == "order_obs_first_cond_all";
   if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only" && !cond_all) return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", mdl->vecchia_pred_type.c_str(), scope);
   const double* cp = gp_coords_data_pred;
@@ -912,6 +956,18 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     else for (int k = 0; k < mdl->n; ++k) resid[mdl->perm[k]] = mdl->ybuf[k];
     if (upload_y(mdl, resid.data(), fe)) return -1;
   } else if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
+  if (mdl->p_cov > 0 && gpb_hip_vecchia_set_resid(mdl->vh, mdl->beta.data())) return shim_error();   // resid -= X beta (:11150-11152); the host copy for 'cond_all' below
+  std::vector<double> resid_v;                          // response the prediction conditions on, Vecchia order
+  const double* yv = mdl->ybuf;
+  if (mdl->p_cov > 0) {
+    resid_v.assign(mdl->ybuf, mdl->ybuf + mdl->n);
+    for (int j = 0; j < mdl->p_cov; ++j) for (int k = 0; k < mdl->n; ++k) resid_v[k] -= mdl->X[(size_t)j * mdl->n + mdl->perm[k]] * mdl->beta[j];
+    yv = resid_v.data();
+  }
+  auto add_linear_predictor = [&](double* mean) {       // mu += X_pred beta (:3868-3880) and the external fixed effects (:3862-3867)
+    if (mdl->p_cov > 0) for (int j = 0; j < mdl->p_cov; ++j) for (int k = 0; k < np; ++k) mean[k] += covariate_data_pred[(size_t)j * np + k] * mdl->beta[j];
+    if (fixed_effects_pred) for (int k = 0; k < np; ++k) mean[k] += fixed_effects_pred[k];
+  };
   mdl->yaux_valid = false;
   // num_neighbors_pred: default 2 * num_neighbors (:299), at most the number of observed points (Vecchia_utils.cpp:755-758) and the
   // device kernels' GPB_MAX_NEIGHBORS
@@ -930,14 +986,14 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     std::vector<int32_t> nnp_rows((size_t)np * nnp);
     std::vector<double> Ap((size_t)np * nnp), Dp(np);
     if (gpb_hip_vecchia_predict_cond_all(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], &mu, nnp_rows.data(), Ap.data(), Dp.data(), nullptr)) return shim_error();
-    if (GPB_HIP_PredictCondAllHost(mdl->n, np, mu, nnp_rows.data(), Ap.data(), Dp.data(), mdl->ybuf, tr[0], predict_response, out_predict,
+    if (GPB_HIP_PredictCondAllHost(mdl->n, np, mu, nnp_rows.data(), Ap.data(), Dp.data(), yv, tr[0], predict_response, out_predict,
                                    predict_var ? out_predict + np : nullptr, predict_cov_mat ? out_predict + np : nullptr)) return -1;
-    if (fixed_effects_pred) for (int k = 0; k < np; ++k) out_predict[k] += fixed_effects_pred[k];   // :3862-3867
+    add_linear_predictor(out_predict);
     return 0;
   }
   std::vector<double> D(np);
   if (gpb_hip_vecchia_predict_obs_only(mdl->vh, np, cp, nnp, mdl->cov_type, tr[1], tr[2], out_predict, D.data(), nullptr)) return shim_error();
-  if (fixed_effects_pred) for (int k = 0; k < np; ++k) out_predict[k] += fixed_effects_pred[k];   // :3862-3867
+  add_linear_predictor(out_predict);
   if (predict_var)
     for (int k = 0; k < np; ++k) out_predict[np + k] = tr[0] * (predict_response ? D[k] : D[k] - 1.);
   if (predict_cov_mat) {                       // neighbours are observed points only: Bp = I, the predictive covariance is diag(Dp)
@@ -977,10 +1033,29 @@ static int copy_string_out(const std::string& v, char* out_str, int* num_char, c
 
 int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const double* covariate_data, int num_covariates,
                                const double* fixed_effects) {
-  if (num_covariates > 0 || covariate_data)
-    return set_error("GPB_OptimLinRegrCoefCovPar: linear regression covariates are not on the MI355X hot path of this library "
-                     "(pass the linear predictor as 'fixed_effects' / offset, or use the reference's host code for the coefficients)");
-  return GPB_OptimCovPar(handle, y_data, fixed_effects);
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_OptimLinRegrCoefCovPar: null handle");
+  if (num_covariates <= 0 || !covariate_data) return GPB_OptimCovPar(handle, y_data, fixed_effects);
+  C_API_BEGIN();
+  const char* scope = "is not on the MI355X path of this library (covariates: one-cluster Gaussian Vecchia model, optimizer_cov 'lbfgs', coefficients by 'wls')";
+  if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_OptimLinRegrCoefCovPar: this model %s", scope);
+  if (mdl->optim.optimizer != "" && mdl->optim.optimizer != "lbfgs") return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_cov '%s' with covariates %s", mdl->optim.optimizer.c_str(), scope);
+  if (mdl->optimizer_coef != "" && mdl->optimizer_coef != "wls") return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_coef '%s' %s", mdl->optimizer_coef.c_str(), scope);
+  if (num_covariates > 256) return set_error("GPB_OptimLinRegrCoefCovPar: %d covariates %s", num_covariates, scope);
+  if (!y_data) return set_error("GPB_OptimLinRegrCoefCovPar: y_data is NULL");
+  const int n = mdl->n, p = num_covariates;
+  mdl->p_cov = p;
+  mdl->X.assign(covariate_data, covariate_data + (size_t)n * p);             // column-major n x p, data order (X_)
+  std::vector<double> Xv((size_t)n * p);                                      // Vecchia order for the device
+  for (int j = 0; j < p; ++j) for (int k = 0; k < n; ++k) Xv[(size_t)j * n + k] = covariate_data[(size_t)j * n + mdl->perm[k]];
+  if (gpb_hip_vecchia_set_covariates(mdl->vh, p, Xv.data())) return shim_error();
+  mdl->beta.assign(p, 0.);
+  const int rc = GPB_OptimCovPar(handle, y_data, fixed_effects);             // y0 = y - fixed_effects is uploaded there; every evaluation profiles beta out (device_terms)
+  if (rc != 0) { mdl->p_cov = 0; (void)gpb_hip_vecchia_set_covariates(mdl->vh, 0, nullptr); return rc; }
+  // the coefficients that belong to the final covariance parameters (and the residual response for prediction)
+  if (profile_out_coef(mdl, mdl->cov_pars_tr[1], mdl->cov_pars_tr[2])) return -1;
+  mdl->coef_estimated = true;
+  C_API_END();
 }
 
 int GPB_CanCalculateStandardErrorsCovPars(REModelHandle handle, int* out) {
@@ -998,9 +1073,29 @@ int GPB_CanCalculateStandardErrorsAuxPars(REModelHandle handle, int* out) {
   C_API_END();
 }
 
-int GPB_GetCoef(REModelHandle handle, double* /*optim_coef*/, bool /*calc_std_dev*/) {
-  if (!handle) return set_error("GPB_GetCoef: null handle");
-  return set_error("GPB_GetCoef: the model has no linear regression covariates (not on the MI355X hot path of this library)");
+int GPB_GetCoef(REModelHandle handle, double* optim_coef, bool calc_std_dev) {
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !optim_coef) return set_error("GPB_GetCoef: null argument");
+  if (mdl->p_cov < 1 || !mdl->coef_estimated) return set_error("Linear regression coefficients have not been estimated (the model has no covariates or has not been fitted with them)");
+  std::copy(mdl->beta.begin(), mdl->beta.end(), optim_coef);
+  if (calc_std_dev) {
+    // CalcStdDevCoef (re_model_template.h:10823-10841): sqrt(diag((X' Psi^-1 X / sigma2)^-1)); the factor is that of the final GLS step
+    const int p = mdl->p_cov;
+    if (p >= mdl->n) { for (int j = 0; j < p; ++j) optim_coef[p + j] = std::numeric_limits<double>::quiet_NaN(); return 0; }
+    const std::vector<double>& L = mdl->chol_XtPsiInvX;
+    std::vector<double> col(p);
+    for (int j = 0; j < p; ++j) {          // (L L')^-1_jj = || L^-1 e_j ||^2
+      double ss = 0.;
+      for (int i = j; i < p; ++i) {
+        double v = (i == j) ? 1. : 0.;
+        for (int k = j; k < i; ++k) v -= L[(size_t)i * p + k] * col[k];
+        col[i] = v / L[(size_t)i * p + i];
+        ss += col[i] * col[i];
+      }
+      optim_coef[p + j] = std::sqrt(mdl->cov_pars_tr[0] * ss);
+    }
+  }
+  return 0;
 }
 
 int GPB_HasStdCylBesselK(int* has_bessel) {
@@ -1085,9 +1180,12 @@ int GPB_GetResponseData(REModelHandle handle, double* response_data) {
   C_API_END();
 }
 
-int GPB_GetCovariateData(REModelHandle handle, double* /*covariate_data*/) {
-  if (!handle) return set_error("GPB_GetCovariateData: null handle");
-  return set_error("Model does not have covariates for a linear predictor");          // re_model_template.h GetCovariateData
+int GPB_GetCovariateData(REModelHandle handle, double* covariate_data) {
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !covariate_data) return set_error("GPB_GetCovariateData: null argument");
+  if (mdl->p_cov < 1) return set_error("Model does not have covariates for a linear predictor");          // re_model_template.h GetCovariateData
+  std::copy(mdl->X.begin(), mdl->X.end(), covariate_data);
+  return 0;
 }
 
 int GPB_GetOffsetData(REModelHandle handle, double* fixed_effects) {

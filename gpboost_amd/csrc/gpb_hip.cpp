@@ -89,6 +89,7 @@ struct gpb_hip_vecchia {
   double* h_out = nullptr;   // pinned
   double* d_A = nullptr; double* d_D = nullptr; double* d_u = nullptr; double* d_v = nullptr; double* d_w = nullptr;
   double* d_ystage = nullptr;
+  double* d_X = nullptr; double* d_U = nullptr; double* d_G = nullptr; double* d_beta = nullptr; int p_cov = 0;   // linear-regression covariates (Vecchia order)
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false, nn_partial = false;
@@ -263,7 +264,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream || !h->owns_stream) { (void)hipStreamSynchronize(h->stream); if (h->owns_stream) (void)hipStreamDestroy(h->stream); }
   dev_free(h->d_pts); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out); dev_free(h->d_batch);
-  dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage);
+  dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage); dev_free(h->d_X); dev_free(h->d_U); dev_free(h->d_G); dev_free(h->d_beta);
   dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
   dev_free(h->d_leaf); dev_free(h->d_leaf_part); dev_free(h->d_leaf_out);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
@@ -651,6 +652,61 @@ int gpb_hip_vecchia_bench(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   for (int s = 0; s < steps; ++s) { (void)hipEventDestroy(e0[s]); (void)hipEventDestroy(e1[s]); }
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
   if (out7_host && vecchia_fetch(h, out7_host, 7)) return -1;
+  API_END();
+}
+
+/* ---- linear-regression covariates (Gaussian likelihood; GPB_OptimLinRegrCoefCovPar with optimizer_coef "wls": the coefficients are profiled out
+   by generalised least squares at every evaluation, optim_utils.h:296-302 -> ProfileOutCoef, re_model_template.h:2665-2683) ----
+   X: p columns of n values in Vecchia order (column-major [p][n]); the response last uploaded with gpb_hip_vecchia_set_y is y0. */
+int gpb_hip_vecchia_set_covariates(gpb_hip_vecchia_t* h, int32_t p, const double* X_colmajor) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (p < 0 || p > 256 || (p > 0 && !X_colmajor)) return fail("gpb_hip_vecchia_set_covariates: p = %d", p);
+  HIP_OK(hipSetDevice(h->device));
+  dev_free(h->d_X); dev_free(h->d_U); dev_free(h->d_G); dev_free(h->d_beta);
+  h->p_cov = p;
+  if (p == 0) return 0;
+  HIP_OK(hipMalloc(&h->d_X, sizeof(double) * (size_t)p * h->n));
+  HIP_OK(hipMalloc(&h->d_U, sizeof(double) * (size_t)(p + 1) * h->n));
+  HIP_OK(hipMalloc(&h->d_G, sizeof(double) * (size_t)(p + 1) * (p + 1)));
+  HIP_OK(hipMalloc(&h->d_beta, sizeof(double) * (size_t)p));
+  HIP_OK(hipMemcpy(h->d_X, X_colmajor, sizeof(double) * (size_t)p * h->n, hipMemcpyHostToDevice));
+  API_END();
+}
+
+/* Gram matrix of [X, y0] in the Psi^-1 inner product from the factor on the device (gpb_hip_vecchia_factor must have run at the parameters
+   of interest): G = (B [X, y0])' D^-1 (B [X, y0]), (p+1) x (p+1) row-major -- X' Psi^-1 X (CalcXTPsiInvX, re_model_template.h:6624-6628),
+   X' Psi^-1 y0 and y0' Psi^-1 y0 in one pass. */
+int gpb_hip_vecchia_gram(gpb_hip_vecchia_t* h, double* G_host) {
+  API_BEGIN();
+  if (!h || !G_host) return fail("null argument");
+  if (h->p_cov < 1) return fail("gpb_hip_vecchia_gram: no covariates have been set");
+  if (!h->has_factor) return fail("gpb_hip_vecchia_gram needs the factor (call gpb_hip_vecchia_factor first)");
+  if (!h->d_ystage || !h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
+  if (h->i_begin != 0 || h->i_end != h->n) return fail("gpb_hip_vecchia_gram needs the whole factor on this device");
+  HIP_OK(hipSetDevice(h->device));
+  const int n = h->n, q = h->p_cov + 1;
+  for (int j = 0; j < h->p_cov; ++j) HIP_OK(gpb::launch_By(h->d_A, h->d_nn, n, h->m, h->d_X + (size_t)j * n, h->d_U + (size_t)j * n, h->stream));
+  HIP_OK(gpb::launch_By(h->d_A, h->d_nn, n, h->m, h->d_ystage, h->d_U + (size_t)h->p_cov * n, h->stream));
+  HIP_OK(gpb::launch_gram(h->d_U, h->d_D, n, q, h->d_G, h->stream));
+  HIP_OK(hipMemcpyAsync(G_host, h->d_G, sizeof(double) * (size_t)q * q, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+/* response := y0 - X beta (UpdateFixedEffects, re_model_template.h:2859-2871); beta = NULL restores y0 */
+int gpb_hip_vecchia_set_resid(gpb_hip_vecchia_t* h, const double* beta_host) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  if (!h->d_ystage || !h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
+  HIP_OK(hipSetDevice(h->device));
+  if (!beta_host || h->p_cov < 1) { HIP_OK(gpb::launch_pack_y(h->d_pts, h->d_ystage, h->n, h->stream)); }
+  else {
+    HIP_OK(hipMemcpyAsync(h->d_beta, beta_host, sizeof(double) * (size_t)h->p_cov, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(gpb::launch_resid(h->d_pts, h->d_ystage, h->d_X, h->d_beta, h->n, h->p_cov, h->stream));
+  }
+  HIP_OK(hipStreamSynchronize(h->stream));     // beta_host is borrowed for the call only
+  h->has_yaux = false; h->has_factor = false;
   API_END();
 }
 

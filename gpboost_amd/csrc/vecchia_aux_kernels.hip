@@ -92,6 +92,49 @@ __global__ void dpp_selftest_kernel(const double* __restrict__ in, double* __res
 }
 
 
+// ---- linear-regression covariates, Gaussian likelihood (GPB_OptimLinRegrCoefCovPar: UpdateCoefGLS / CalcXTPsiInvX, re_model_template.h:10012-10019,
+//      6624-6628): Gram matrix of U = B [x_1 .. x_p, y0] with weights 1/D, and the residual response y0 - X beta -----------------------------
+// G[a][b] = sum_i U[a][i] U[b][i] / D[i], a >= b (lower triangle); one workgroup per pair, fixed order -> bit-reproducible
+__global__ __launch_bounds__(1024) void gram_kernel(const double* __restrict__ U, const double* __restrict__ D, int n, int q, double* __restrict__ G) {
+  __shared__ double s[1024];
+  int t = blockIdx.x, a = 0;
+  while (t >= a + 1) { t -= a + 1; ++a; }            // pair index -> (a, b = t), b <= a
+  const int b = t;
+  const double* ua = U + (size_t)a * n;
+  const double* ub = U + (size_t)b * n;
+  double acc = 0.0, comp = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double v = ua[i] * ub[i] / D[i] - comp;
+    const double tmp = acc + v;
+    comp = (tmp - acc) - v;
+    acc = tmp;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { G[(size_t)a * q + b] = s[0]; G[(size_t)b * q + a] = s[0]; }
+}
+// pts[i].w = y0[i] - sum_j X[j][i] beta[j]   (response := residual; UpdateFixedEffects, re_model_template.h:2859-2871)
+__global__ void resid_kernel(double4* __restrict__ pts, const double* __restrict__ y0, const double* __restrict__ X, const double* __restrict__ beta,
+                             int n, int p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = y0[i];
+  for (int j = 0; j < p; ++j) r -= X[(size_t)j * n + i] * beta[j];    // left-to-right like Eigen's X * beta row
+  pts[i].w = r;
+}
+hipError_t launch_gram(const double* U, const double* D, int n, int q, double* G, hipStream_t st) {
+  hipLaunchKernelGGL(gram_kernel, dim3(q * (q + 1) / 2), dim3(1024), 0, st, U, D, n, q, G);
+  return hipGetLastError();
+}
+hipError_t launch_resid(double4* pts, const double* y0, const double* X, const double* beta, int n, int p, hipStream_t st) {
+  hipLaunchKernelGGL(resid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, y0, X, beta, n, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
                                   hipStream_t st) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user);

@@ -102,6 +102,16 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double*
 GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov_type, double var, double a,
                                              int gauss_likelihood, double* out3_host);
 /* Enqueue only; out3_dev is a device pointer (3 doubles). */
+/* Linear-regression covariates, Gaussian likelihood (GPB_OptimLinRegrCoefCovPar with the default optimizer_coef "wls": the coefficients are profiled
+ * out by generalised least squares at every evaluation, optim_utils.h:296-302 -> ProfileOutCoef / UpdateCoefGLS, re_model_template.h:2665-2683, 10012-10019).
+ *   set_covariates  X: p columns of n values in VECCHIA order, column-major [p][n]; resident until replaced (p = 0 removes them)
+ *   gram            after gpb_hip_vecchia_factor: G = (B [X, y0])' D^-1 (B [X, y0]), (p+1) x (p+1) row-major, y0 = the response last uploaded with
+ *                   gpb_hip_vecchia_set_y: X' Psi^-1 X (CalcXTPsiInvX, :6624-6628), X' Psi^-1 y0 and y0' Psi^-1 y0 in one pass
+ *   set_resid       response := y0 - X beta (UpdateFixedEffects, :2859-2871); beta = NULL restores y0 */
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_covariates(gpb_hip_vecchia_t* h, int32_t p, const double* X_colmajor);
+GPB_HIP_EXPORT int gpb_hip_vecchia_gram(gpb_hip_vecchia_t* h, double* G_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_set_resid(gpb_hip_vecchia_t* h, const double* beta_host);
+
 /* K evaluations with one synchronisation (and, on a sharded handle, ONE ncclAllReduce of 3 K doubles): the trial points of a line search
  * or any batch of parameter sets.  var[k], a[k]: transformed parameters of evaluation k; out: K x {y' Psi^-1 y, log|Psi|, #(D <= 0)} job-wide. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_nll_terms_batch(gpb_hip_vecchia_t* h, int cov_type, int32_t K, const double* var, const double* a,

@@ -164,6 +164,29 @@ def optim_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "optim_ref.npz"), **res)
 
 
+def optim_coef_fixture(out_dir):
+    """The reference's own GPB_OptimLinRegrCoefCovPar + GPB_GetCoef + GPB_PredictREModel with covariates (one OpenMP thread) for
+    tests/cases.py:COEF_CASES (optimizer_coef left at the reference's default for Gaussian data, "wls")."""
+    res = {}
+    for name in cases.COEF_CASES:
+        coords, y, X, mc, init, cfg, Xp = cases.coef_case(name)
+        mdl = refdrv.RefCAPIModel(coords, mc["cov_function"], mc["shape"], mc["m"], mc["ordering"], mc["seed"], threads=1)
+        if init is not None or cfg:
+            mdl.set_optim_config(init_cov_pars=init, **cfg)
+        mdl.optim_lin_regr_coef_cov_par(y, X)
+        res[name + "_cov_pars"] = mdl.get_cov_par()
+        res[name + "_coef"] = mdl.get_coef()
+        res[name + "_coef_sd"] = mdl.get_coef(std_dev=True)[mdl.p:]
+        res[name + "_num_it"] = np.int32(mdl.get_num_it())
+        res[name + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        mu, var = mdl.predict(cases.COEF_PRED_COORDS, Xp)
+        res[name + "_pred_mu"], res[name + "_pred_var"] = mu, var
+        mu, var = mdl.predict(cases.COEF_PRED_COORDS, Xp, vecchia_pred_type="order_obs_first_cond_all")
+        res[name + "_pred_all_mu"], res[name + "_pred_all_var"] = mu, var
+        print("optim coef", name, res[name + "_cov_pars"], res[name + "_coef"], res[name + "_num_it"], res[name + "_negll"], mu, flush=True)
+    np.savez_compressed(os.path.join(out_dir, "optim_coef_ref.npz"), **res)
+
+
 def optim_laplace_fixture(out_dir):
     """The reference's own GPB_OptimCovPar for non-Gaussian Vecchia models (iterative methods, vadu): tests/cases.py:OPTIM_LAPLACE_CASES."""
     res = {}
@@ -319,6 +342,8 @@ if __name__ == "__main__":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":
         laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "optim_coef":
+        optim_coef_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim":
         optim_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "tree":

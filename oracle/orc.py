@@ -223,6 +223,23 @@ def vecchia_yaux(A, D, nn, y):
     return out
 
 
+def gls_coef(A, D, nn, X, y):
+    """Generalised-least-squares coefficients beta = (X' Psi^-1 X)^-1 X' Psi^-1 y with Psi^-1 = B' D^-1 B of the Vecchia factor (Vecchia
+    order): ProfileOutCoef / UpdateCoefGLS / CalcXTPsiInvX (re_model_template.h:2665-2683, :10012-10019, :6622-6628), solved by
+    Cholesky as Eigen's llt() there.  Returns (beta, residual y - X beta)."""
+    nn = np.asarray(nn)
+    X = np.asarray(X, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    U = np.column_stack([X, y])
+    valid = nn >= 0
+    idx = np.where(valid, nn, 0)
+    BU = U - np.einsum("ij,ijk->ik", np.where(valid, A, 0.0), U[idx])
+    G = BU.T @ (BU / np.asarray(D)[:, None])
+    p = X.shape[1]
+    L = np.linalg.cholesky(G[:p, :p])
+    beta = np.linalg.solve(L.T, np.linalg.solve(L, G[:p, p]))
+    return beta, y - X @ beta
+
+
 def exact_nll(coords, cov_type, pars_trans, y, want_yaux=False):
     cm = np.asfortranarray(coords, dtype=np.float64)
     n, d = cm.shape

@@ -142,6 +142,44 @@ class RefCAPIModel(object):
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 
+    def optim_lin_regr_coef_cov_par(self, y, X, fixed_effects=None):
+        """GPB_OptimLinRegrCoefCovPar (c_api.h:1490-1494); X: n x p."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
+        self.p = Xf.shape[1]
+        rc = self.L.GPB_OptimLinRegrCoefCovPar(self.h, _P(y), _P(Xf), C.c_int(self.p), C.c_void_p() if fe is None else _P(fe))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+
+    def get_coef(self, std_dev=False):
+        out = np.empty(self.p * (2 if std_dev else 1))
+        rc = self.L.GPB_GetCoef(self.h, _P(out), C.c_bool(bool(std_dev)))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out
+
+    def predict(self, coords_pred, X_pred=None, predict_var=True, predict_response=True, vecchia_pred_type=None, num_neighbors_pred=-1):
+        """GPB_SetPredictionData + GPB_PredictREModel (c_api.h:1594-1660) with the response / parameters of the last fit."""
+        s = lambda x: C.c_char_p(x.encode())
+        cp = np.asfortranarray(coords_pred, dtype=np.float64)
+        npred = cp.shape[0]
+        if vecchia_pred_type is not None or num_neighbors_pred > 0:
+            rc = self.L.GPB_SetPredictionData(self.h, C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(),
+                                              C.c_void_p() if vecchia_pred_type is None else s(vecchia_pred_type), C.c_int(num_neighbors_pred),
+                                              C.c_double(-1.), C.c_int(-1), C.c_int(-1))
+            if rc != 0:
+                raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        Xp = None if X_pred is None else np.asfortranarray(X_pred, dtype=np.float64)
+        out = np.empty(npred * (2 if predict_var else 1))
+        rc = self.L.GPB_PredictREModel(self.h, C.c_void_p(), C.c_int(npred), _P(out), C.c_bool(False), C.c_bool(bool(predict_var)),
+                                       C.c_bool(bool(predict_response)), C.c_bool(False), C.c_bool(False), C.c_int(0), C.c_int(0), C.c_void_p(), C.c_void_p(),
+                                       C.c_void_p(), _P(cp), C.c_void_p(), C.c_void_p(), C.c_void_p() if Xp is None else _P(Xp), C.c_bool(False),
+                                       C.c_void_p(), C.c_void_p())
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out[:npred].copy(), (out[npred:].copy() if predict_var else None)
+
     def get_cov_par(self, num_cov_pars=3):
         out = np.empty(num_cov_pars)
         rc = self.L.GPB_GetCovPar(self.h, _P(out), C.c_bool(False))

@@ -43,6 +43,22 @@ print("predict: mu", pred["mu"], "cov diag", np.diag(pred["cov"]), flush=True)
 assert np.abs(pred["mu"] - np.array([0.06968068, 0.06967750, 0.44208925])).sum() < 1e-6
 assert np.abs(np.diag(pred["cov"]) - np.array([0.6214955, 0.6215069, 0.4199531])).sum() < 1e-6
 print(m.summary() if hasattr(m, "summary") else "", flush=True)
+# linear regression term: the package's fit(y, X) -> GPB_OptimLinRegrCoefCovPar, get_coef -> GPB_GetCoef, predict(X_pred) (tests/cases.py:COEF_CASES,
+# tests/golden/optim_coef_ref.npz = the reference LIBRARY on the same inputs)
+from tests import cases       # noqa: E402
+gc = np.load(os.path.join(ROOT, "tests", "golden", "optim_coef_ref.npz"))
+cx, yx, X, mc, init, cfg, Xp = cases.coef_case("r_m30_none_wls_default")
+mx = gpb.GPModel(gp_coords=cx, cov_function="exponential", gp_approx="vecchia", num_neighbors=30, vecchia_ordering="none", likelihood="gaussian")
+mx.fit(y=yx, X=X)
+coef = np.asarray(mx.get_coef(std_err=True, format_pandas=False))
+print("fit with X: cov pars", np.asarray(mx.get_cov_pars(format_pandas=False)).ravel(), "coef", coef.ravel(), "iterations", mx._get_num_optim_iter(), flush=True)
+assert mx._get_num_optim_iter() == int(gc["r_m30_none_wls_default_num_it"])
+assert np.allclose(coef[0].ravel() if coef.ndim > 1 else coef[:2], gc["r_m30_none_wls_default_coef"], rtol=1e-6)
+assert np.allclose(coef[1].ravel() if coef.ndim > 1 else coef[2:], gc["r_m30_none_wls_default_coef_sd"], rtol=1e-6)
+px = mx.predict(gp_coords_pred=cases.COEF_PRED_COORDS, X_pred=Xp, predict_var=True, predict_response=True)
+print("predict with X_pred: mu", px["mu"], "var", px["var"], flush=True)
+assert np.allclose(px["mu"], gc["r_m30_none_wls_default_pred_mu"], rtol=1e-6) and np.allclose(px["var"], gc["r_m30_none_wls_default_pred_var"], rtol=1e-6)
+print(mx.summary() if hasattr(mx, "summary") else "", flush=True)
 # non-Gaussian: the package's GPModel with likelihood = "bernoulli_logit" (Vecchia-Laplace, iterative methods) on seeded data
 rng = np.random.default_rng(21)
 c2 = rng.uniform(size=(2000, 2))

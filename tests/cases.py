@@ -238,6 +238,47 @@ def optim_case(name):
     return coords, y, ids, mc, init, c["cfg"]
 
 
+# Linear regression term X beta + GP (GPB_OptimLinRegrCoefCovPar): GOLDEN_CASES model, how X is made, optimiser settings.  The coefficients
+# are profiled out by GLS (the reference's default optimizer_coef = "wls" for Gaussian data).  Outputs of the reference: tests/golden/optim_coef_ref.npz.
+COEF_CASES = {
+    # data of the R suite's "Vecchia approximation for Gaussian process model with linear regression term"
+    # (test_GPModel_gaussian_process.R:1556-1583: X = cbind(1, sin((1:n - n/2)^2 * 2 pi / n)), beta = (2, 2), num_neighbors = n + 2)
+    "r_m99_none_wls": dict(model="r_mat25_m99_none", cov_function="exponential", shape=0.5, X="r", init="r", cfg=dict(optimizer_cov="lbfgs")),
+    "r_m30_none_wls_default": dict(model="r_exp_m30_none", X="r", init=None, cfg=dict()),
+    "u2d_n3000_p4_wls": dict(model="u2d_n3000_exp_m30", X="random4", init=None, cfg=dict()),
+}
+COEF_PRED_COORDS = np.array([[0.1, 0.9], [0.2, 0.4], [0.7, 0.55]])      # coord_test / X_test of the R suite (:1575-1576)
+COEF_PRED_X_R = np.array([[1., -0.5], [1., 0.2], [1., 0.4]])
+
+
+def coef_case(name):
+    """-> (coords, y, X, model dict, init_cov_pars | None, cfg dict, X_pred)"""
+    c = COEF_CASES[name]
+    mc = dict(GOLDEN_CASES[c["model"]])
+    for k in ("cov_function", "shape"):
+        if k in c:
+            mc[k] = c[k]
+    coords, y0 = make_data(mc)
+    n = coords.shape[0]
+    if c["X"] == "r":
+        i = np.arange(1, n + 1)
+        X = np.column_stack([np.ones(n), np.sin((i - n / 2) ** 2 * 2 * np.pi / n)])
+        beta = np.array([2., 2.])
+        Xp = COEF_PRED_X_R
+    else:
+        rng = np.random.default_rng(77)
+        X = np.column_stack([np.ones(n), rng.standard_normal((n, 3))])
+        X[:, 3] = 0.5 * X[:, 2] + X[:, 3]                               # correlated columns
+        beta = np.array([1.5, -0.7, 0.3, 2.0])
+        Xp = np.column_stack([np.ones(3), rng.standard_normal((3, 3))])
+    y = y0 + X @ beta
+    init = None
+    if c["init"] == "r":
+        from scipy.spatial.distance import pdist
+        init = np.array([np.var(y, ddof=1) / 2, np.var(y, ddof=1) / 2, pdist(coords).mean() / 3])
+    return coords, y, X, mc, init, c["cfg"], Xp
+
+
 def synthetic(n, d, seed=1):
     """BASELINE.md's synthetic inputs: coords U[0,1]^d, y ~ N(0,1), default_rng(seed)."""
     rng = np.random.default_rng(seed)

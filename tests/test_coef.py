@@ -1,0 +1,93 @@
+"""Linear regression term X beta + Vecchia GP, coefficients profiled out by GLS (GPB_OptimLinRegrCoefCovPar with the reference's default
+optimizer_coef = "wls" for Gaussian data; optim_utils.h:296-302, re_model_template.h:2665-2683, :10012-10019).
+
+Pins: tests/golden/optim_coef_ref.npz = the UNMODIFIED reference's GPB_OptimLinRegrCoefCovPar / GPB_GetCoef / GPB_PredictREModel on
+tests/cases.py:COEF_CASES (oracle/make_golden.py optim_coef).  The CPU tests hold the oracle's restatement of the GLS step to those
+outputs; the GPU tests hold the device path (Gram matrix of B [X, y] weighted by 1 / D, residual update, fit, prediction) to them."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "optim_coef_ref.npz")
+
+
+@pytest.mark.parametrize("name", sorted(cases.COEF_CASES))
+def test_oracle_gls_step_reproduces_the_reference(orc, name):
+    g = np.load(GOLDEN)
+    coords, y, X, mc, init, cfg, Xp = cases.coef_case(name)
+    cp = g[name + "_cov_pars"]
+    ct = orc.cov_type_id(mc["cov_function"], mc["shape"])
+    pt = orc.transform_cov_pars(ct, cp)
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    A, D, bad = orc.vecchia_factor(co, nn, ct, pt[1], pt[2], gauss=True)
+    assert bad == 0
+    beta, resid = orc.gls_coef(A, D, nn, X[perm], y[perm])
+    np.testing.assert_allclose(beta, g[name + "_coef"], rtol=1e-7, atol=1e-9)
+    nll = orc.vecchia_nll(co, nn, ct, pt, resid)[2]
+    assert abs(nll - float(g[name + "_negll"])) <= 1e-8 * abs(nll)
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+def _model(gpb, coords, mc):
+    return gpb.GPModel(gp_coords=coords, cov_function=mc["cov_function"], cov_fct_shape=mc["shape"], gp_approx="vecchia",
+                       num_neighbors=mc["m"], vecchia_ordering=mc["ordering"], seed=mc["seed"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.COEF_CASES))
+def test_fit_with_covariates_against_the_reference(gpb, name):
+    g = np.load(GOLDEN)
+    coords, y, X, mc, init, cfg, Xp = cases.coef_case(name)
+    mdl = _model(gpb, coords, mc)
+    params = dict(cfg)
+    if "max_iter" in params:
+        params["maxit"] = params.pop("max_iter")
+    if init is not None:
+        params["init_cov_pars"] = init
+    mdl.fit(y, X=X, params=params or None)
+    assert mdl.get_num_optim_iter() == int(g[name + "_num_it"])
+    np.testing.assert_allclose(mdl.get_cov_pars(), g[name + "_cov_pars"], rtol=1e-6)
+    np.testing.assert_allclose(mdl.get_coef(), g[name + "_coef"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(mdl.get_coef(std_err=True)[X.shape[1]:], g[name + "_coef_sd"], rtol=1e-6)     # CalcStdDevCoef (:10823-10841)
+    ref = float(g[name + "_negll"])
+    assert abs(mdl.get_current_neg_log_likelihood() - ref) <= 1e-8 * abs(ref)
+    # prediction with X_pred at the fitted parameters, both conditioning types (re_model_template.h:3868-3880)
+    pr = mdl.predict(gp_coords_pred=cases.COEF_PRED_COORDS, X_pred=Xp, predict_var=True, predict_response=True)
+    np.testing.assert_allclose(pr["mu"], g[name + "_pred_mu"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pr["var"], g[name + "_pred_var"], rtol=1e-6, atol=1e-8)
+    pr = mdl.predict(gp_coords_pred=cases.COEF_PRED_COORDS, X_pred=Xp, predict_var=True, predict_response=True,
+                     vecchia_pred_type="order_obs_first_cond_all")
+    np.testing.assert_allclose(pr["mu"], g[name + "_pred_all_mu"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pr["var"], g[name + "_pred_all_var"], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_covariate_api_surface(gpb):
+    """GPB_GetCovariateData / GPB_GetCoef error behaviour, the missing-X_pred error of the reference, and the R suite's own fitted values
+    (test_GPModel_gaussian_process.R:1567-1572: joint lbfgs there, the profiled fit reaches the same optimum to the optimiser's tolerance)."""
+    coords, y, X, mc, init, cfg, Xp = cases.coef_case("r_m99_none_wls")
+    mdl = _model(gpb, coords, mc)
+    with pytest.raises(gpb.GPBoostError, match="have not been estimated"):
+        mdl.num_coef = 2
+        mdl.get_coef()
+    mdl.fit(y, X=X, params=dict(init_cov_pars=init, optimizer_cov="lbfgs"))
+    np.testing.assert_allclose(mdl.get_cov_pars(), [0.008993586382, 1.000518636089, 0.094683724304], rtol=2e-2)
+    np.testing.assert_allclose(mdl.get_coef(), [2.309738418, 1.899886232], rtol=2e-3)
+    assert abs(mdl.get_current_neg_log_likelihood() - 121.4824924) < 1e-3
+    with pytest.raises(gpb.GPBoostError, match="No covariate data is provided"):
+        mdl.predict(gp_coords_pred=cases.COEF_PRED_COORDS)
+    # the design matrix comes back as it went in
+    import ctypes
+    out = np.empty(X.size)
+    from gpboost_amd.basic import _lib, _safe_call, _dptr
+    _safe_call(_lib().GPB_GetCovariateData(mdl.handle, _dptr(out)))
+    np.testing.assert_array_equal(out.reshape(X.shape, order="F"), X)
