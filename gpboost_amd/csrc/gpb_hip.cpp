@@ -138,6 +138,7 @@ struct gpb_hip_hist {
   int* d_part = nullptr; int part_cap = 0;                 // partition workspace: block counts / offsets, lte, gt
   double* d_split = nullptr; int* d_split_i = nullptr; signed char* d_used = nullptr;   // split search outputs: F x 10, F + 1 ints
   // gpb_hip_hist_grow_tree: resident row lists of the leaves, two sets of search outputs (device + pinned host)
+  int* d_rows2 = nullptr; int* d_counts = nullptr; int* h_counts = nullptr;     // second (ping-pong) row buffer; {left rows of this rank, of all ranks} of the current split
   int* d_rows = nullptr; double* d_split2 = nullptr; int* d_split2_i = nullptr; signed char* d_used2 = nullptr;
   double* h_split2 = nullptr; int* h_split2_i = nullptr;
   double* d_tree_red = nullptr;                            // 4 doubles: root sums / left count of the data-parallel tree grower
@@ -1120,7 +1121,8 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt); dev_free(h->d_absmax);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
-  dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
+  dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_rows2); dev_free(h->d_counts);
+  if (h->h_counts) (void)hipHostFree(h->h_counts); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
   if (h->h_split2) (void)hipHostFree(h->h_split2);
   if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
@@ -1216,6 +1218,39 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   HIP_OK(hipStreamSynchronize(h->stream));
   if (ms_avg) { float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); *ms_avg = ms / reps; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   }
+  return 0;
+}
+
+// Tree grower: histogram of the SMALLER child of the split whose left counts the partition kernels have left in h->d_counts -- enqueued
+// without a host round trip; ub_rows = upper bound of the child's rows on this rank (sizes the launch), result in d_target.
+static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_begin, int seg_cnt, int seg_gcnt, int min_data_in_leaf, int ub_rows,
+                              double const_hess, double* d_target) {
+  const int groups = h->fpad / GPB_HIST_FG;
+  if (h->num_cu <= 0) { HIP_OK(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, h->device)); if (h->num_cu <= 0) h->num_cu = 256; }
+  const int chunk_mult = h->has_hess ? 2 : 4;
+  int nchunks = std::max(1, std::min((ub_rows + 1023) / 1024, std::max(1, chunk_mult * h->num_cu / groups)));
+  if (nchunks >= 16) nchunks &= ~7;
+  if (h->part_chunks < nchunks) {
+    dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt);
+    const size_t cnt = (size_t)nchunks * h->fpad * GPB_HIST_MAX_BIN;
+    HIP_OK(hipMalloc(&h->d_part_grad, sizeof(long long) * cnt));
+    HIP_OK(hipMalloc(&h->d_part_hess, sizeof(long long) * cnt));
+    HIP_OK(hipMalloc(&h->d_part_cnt, sizeof(uint32_t) * cnt));
+    h->part_chunks = nchunks;
+  }
+  gpb::HistKernelArgs a;
+  a.bins_rm = h->d_bins_rm; a.data_indices = rows_base; a.grad = h->d_grad; a.hess = h->has_hess ? h->d_hess : nullptr;
+  a.part_grad = h->d_part_grad; a.part_hess = h->d_part_hess; a.part_cnt = h->d_part_cnt;
+  a.grad_max_bits = h->d_absmax; a.hess_max_bits = h->d_absmax + 1;
+  a.fpad = h->fpad; a.num_data = 0; a.rows_per_chunk = 1; a.nchunks = nchunks; a.num_features = h->F;
+  a.seg_counts = h->d_counts; a.seg_begin = seg_begin; a.seg_cnt = seg_cnt; a.seg_gcnt = seg_gcnt; a.seg_min_data_in_leaf = min_data_in_leaf;
+  gpb::HistReduceArgs r;
+  r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
+  r.grad_max_bits = h->d_absmax; r.hess_max_bits = h->d_absmax + 1;
+  r.hist_out = d_target; r.cnt_out = nullptr; r.fpad = h->fpad; r.nchunks = nchunks; r.num_features = h->F;
+  r.const_hess = const_hess; r.has_hess = h->has_hess ? 1 : 0;
+  HIP_OK(gpb::launch_hist_build(a, h->stream));
+  HIP_OK(gpb::launch_hist_reduce(r, h->stream));
   return 0;
 }
 

@@ -20,6 +20,22 @@ struct HistKernelArgs {
   const unsigned long long* hess_max_bits;   // they fix the power-of-two scale q of the fixed-point sums (launch_hist_absmax)
   int fpad, num_data, rows_per_chunk, nchunks;
   int num_features;         // real features (<= fpad): the padding features of the last group are not accumulated
+  // tree grower: when seg_counts != nullptr the rows are the SMALLER child of the split of the segment (seg_begin, seg_cnt) of
+  // data_indices whose left counts {this rank, all ranks} sit in seg_counts (device memory); num_data / rows_per_chunk are ignored
+  const int* seg_counts = nullptr;
+  int seg_begin = 0, seg_cnt = 0, seg_gcnt = 0, seg_min_data_in_leaf = 0;
+};
+
+struct ChildrenSearchArgs {
+  double* smaller;          // slot of the smaller child's histogram (fresh from the build, not yet fixed)
+  double* parent;           // slot of the parent's histogram: becomes the larger child's
+  const int* counts;        // {left rows of this rank, left rows of all ranks} of the split (device)
+  const int* bin_offsets; const int* view_offset; const int* num_bin; const int* most_freq_bin; const int* meta3;
+  int num_features, gcnt, min_data_in_leaf;
+  double left_sum_gradient, left_sum_hessian, right_sum_gradient, right_sum_hessian;     // of the parent's split
+  double lambda_l2, min_sum_hessian, min_gain_to_split;
+  double* out10;            // [2][F][10]: candidates of the smaller, then of the larger child
+  int* out_flags;           // [2][F + 1]
 };
 
 struct HistReduceArgs {
@@ -44,7 +60,12 @@ hipError_t launch_hist_best_split(const double* hist, int num_features, const in
 hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                  int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
                                  int* blk_off, int* lte, int* gt, hipStream_t st);
-hipError_t launch_hist_label_rows(const int* rows, int n, const int* seg_begin, const int* seg_leaf, int nseg, int* out, hipStream_t st);
+hipError_t launch_hist_partition_segment(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
+                                         int missing_type, int default_left, unsigned threshold, const int* src, int cnt, int* blk_cnt,
+                                         int* blk_off, int* dst, int* counts, int* host_counts, hipStream_t st);
+hipError_t launch_hist_children_search(const ChildrenSearchArgs& a, hipStream_t st);
+hipError_t launch_hist_label_rows(const int* rows0, const int* rows1, int n, const int* seg_begin, const int* seg_leaf, const int* seg_buf, int nseg,
+                                  int* out, hipStream_t st);
 hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st);
 hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
 

@@ -53,6 +53,22 @@ __device__ inline unsigned long long fixed_point_bits(double v, double inv_q) { 
   return (unsigned long long)__double_as_longlong(v * inv_q + kMagic) - kMagicBits;
 }
 
+// The two children of a split as the tree grower's kernels see them: counts[0] = rows of THIS rank that went left, counts[1] = of all
+// ranks; (begin, cnt) = the parent's segment of the row list, gcnt = its rows over all ranks.  BeforeFindBestSplit
+// (serial_tree_learner.cpp:283-323): no search when both children hold fewer than 2 min_data_in_leaf rows; the smaller child is the left
+// one iff left_cnt < right_cnt (global counts).
+struct ChildSegment { int nl, gnl, smaller_is_left, smaller_begin, smaller_cnt, skip; };
+__device__ inline ChildSegment child_segment(const int* counts, int begin, int cnt, int gcnt, int min_data_in_leaf) {
+  ChildSegment c;
+  c.nl = counts[0]; c.gnl = counts[1];
+  const int gl = c.gnl, gr = gcnt - c.gnl;
+  c.skip = (gr < 2 * min_data_in_leaf && gl < 2 * min_data_in_leaf) ? 1 : 0;
+  c.smaller_is_left = gl < gr ? 1 : 0;
+  c.smaller_begin = begin + (c.smaller_is_left ? 0 : c.nl);
+  c.smaller_cnt = c.smaller_is_left ? c.nl : cnt - c.nl;
+  return c;
+}
+
 // LDS layout: BIN-major, word(bin, f) = bin * 16 + f.  A 64-bit word covers one pair of the 64 banks, pair(bin, f) = (16 bin + f) mod 32
 // = f + 16 (bin & 1): sixteen lanes that update sixteen DIFFERENT features can never meet in a bank pair, whatever their bins are --
 // and the LDS works through a wavefront's 64-bit accesses 16 lanes at a time.  With lane l on feature (s + l) mod 16 at step s every
@@ -103,8 +119,19 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 #pragma unroll
   for (int s = 0; s < GPB_HIST_FG; ++s) fcol[s] = s_acc + ((s + tid) & 15);
   const int nf = min(GPB_HIST_FG, a.num_features - fg * GPB_HIST_FG);   // real features of this group (the last group may be partial)
-  const int r0 = chunk * a.rows_per_chunk;
-  const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
+  // the rows: [0, num_data) of data_indices as given by the host, or -- tree grower -- the SMALLER child of the split whose left counts
+  // the partition kernels have just left in device memory (no host round trip between the partition and this build)
+  int num_data = a.num_data, rows_per_chunk = a.rows_per_chunk;
+  if constexpr (HAS_IDX) {
+    if (a.seg_counts) {
+      const ChildSegment cs = child_segment(a.seg_counts, a.seg_begin, a.seg_cnt, a.seg_gcnt, a.seg_min_data_in_leaf);
+      a.data_indices += cs.smaller_begin;
+      num_data = cs.skip ? 0 : cs.smaller_cnt;
+      rows_per_chunk = (num_data + a.nchunks - 1) / a.nchunks;
+    }
+  }
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(r0 + rows_per_chunk, num_data);
   const uint8_t* base = a.bins_rm + (size_t)fg * GPB_HIST_FG;
   // one lane = one row: a 16-byte load brings the row's 16 bins of this feature group, the gradient load is coalesced across the
   // wavefront (or gathered through data_indices for a leaf); the lane then issues one 64-bit LDS atomic per feature.
@@ -281,17 +308,20 @@ __global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* _
   }
 }
 
-// leaf id of every row from the resident row lists: position p of `rows` belongs to the segment with the largest begin <= p
-__global__ void hist_label_rows_kernel(const int* __restrict__ rows, int n, const int* __restrict__ seg_begin, const int* __restrict__ seg_leaf,
-                                       int nseg, int* __restrict__ out) {
+// leaf id of every row from the resident row lists: position p belongs to the segment with the largest begin <= p; the segment's rows
+// live in one of the two ping-pong buffers of the tree grower (seg_buf)
+__global__ void hist_label_rows_kernel(const int* __restrict__ rows0, const int* __restrict__ rows1, int n, const int* __restrict__ seg_begin,
+                                       const int* __restrict__ seg_leaf, const int* __restrict__ seg_buf, int nseg, int* __restrict__ out) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   int lo = 0, hi = nseg - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_begin[mid] <= p) lo = mid; else hi = mid - 1; }
+  const int* rows = (seg_buf && seg_buf[lo]) ? rows1 : rows0;
   out[rows[p]] = seg_leaf[lo];
 }
-hipError_t launch_hist_label_rows(const int* rows, int n, const int* seg_begin, const int* seg_leaf, int nseg, int* out, hipStream_t st) {
-  hipLaunchKernelGGL(hist_label_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, seg_begin, seg_leaf, nseg, out);
+hipError_t launch_hist_label_rows(const int* rows0, const int* rows1, int n, const int* seg_begin, const int* seg_leaf, const int* seg_buf, int nseg,
+                                  int* out, hipStream_t st) {
+  hipLaunchKernelGGL(hist_label_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rows0, rows1, n, seg_begin, seg_leaf, seg_buf, nseg, out);
   return hipGetLastError();
 }
 
@@ -372,22 +402,20 @@ constexpr int kSplitSteps = GPB_HIST_MAX_BIN + 2;      // step index t + 1 (the 
 }  // namespace
 
 #pragma clang fp contract(off)
-__global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
-                                       const int* __restrict__ num_bin, const int* __restrict__ meta3 /* offset, default_bin, missing */,
-                                       double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2, int min_data_in_leaf,
-                                       double min_sum_hessian, double min_gain_to_split, double* __restrict__ out10,
-                                       int* __restrict__ out_default_left) {
+// the search for feature f by the 256 threads of a workgroup (all of them must call it; it ends with a barrier, so it can be called again)
+__device__ void best_split_feature(const double* hist, int f, const int* __restrict__ view_offset,
+                                   const int* __restrict__ num_bin, const int* __restrict__ meta3 /* offset, default_bin, missing */,
+                                   double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2, int min_data_in_leaf,
+                                   double min_sum_hessian, double min_gain_to_split, double* __restrict__ out10,
+                                   int* __restrict__ out_default_left) {
 #pragma clang fp contract(off)
-  __shared__ double s_d[2 * (GPB_HIST_MAX_BIN + 1)];
-  __shared__ double s_ag[2][kSplitSteps], s_ah[2][kSplitSteps];
-  __shared__ int s_ac[2][kSplitSteps];
+  __shared__ double s_x[GPB_HIST_MAX_BIN + 1][4];           // per entry: gradient sum, hessian sum, rounded count (as a double), pad
+  __shared__ double s_o[2][kSplitSteps][4];                 // per direction and step: the three running sums
   __shared__ signed char s_eval[2][kSplitSteps];
   __shared__ double s_rg[256];
   __shared__ int s_rt[256], s_rs[256];
-  __shared__ int s_cnt[GPB_HIST_MAX_BIN + 1];
   __shared__ int s_brk[2];                                 // first break of the reverse (max t) / forward (min t) scan
-  const int f = blockIdx.x, tid = threadIdx.x;
-  if (f >= num_features) return;
+  const int tid = threadIdx.x;
   const double kEps = (double)1e-15f;                      // include/LightGBM/meta.h:54
   const double* data = hist + (size_t)view_offset[f] * 2;
   const int nb = num_bin[f], offset = meta3[3 * f], default_bin = meta3[3 * f + 1], missing = meta3[3 * f + 2];
@@ -398,48 +426,41 @@ __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __re
   const bool skip_default = two_scans && missing == 1;
   const int na_as_missing = (two_scans && missing != 1) ? 1 : 0;
   const int nent = nb - offset;                            // entries of the feature's view
-  for (int i = tid; i < 2 * nent; i += 256) s_d[i] = data[i];
   for (int i = tid; i < 2 * kSplitSteps; i += 256) (&s_eval[0][0])[i] = 0;
-  __syncthreads();
   const double cnt_factor = num_data / sum_hessian;
-  for (int i = tid; i < nent; i += 256) s_cnt[i] = (int)(s_d[2 * i + 1] * cnt_factor + 0.5f);      // Common::RoundInt, utils/common.h:920-922
+  for (int i = tid; i < nent; i += 256) {
+    // an entry the scans `continue` over before anything is accumulated (the default bin, zero-as-missing) contributes exact zeros
+    const bool skipped = skip_default && (i + offset) == default_bin;
+    const double g = data[2 * i], hh = data[2 * i + 1];
+    s_x[i][0] = skipped ? 0.0 : g;
+    s_x[i][1] = skipped ? 0.0 : hh;
+    s_x[i][2] = skipped ? 0.0 : (double)(int)(hh * cnt_factor + 0.5f);      // Common::RoundInt, utils/common.h:920-922
+  }
   if (tid < 2) s_brk[tid] = tid == 0 ? -2147483647 : 2147483647;
   __syncthreads();
-  // (2) the running sums, one lane per direction, branch-free so that the LDS reads run ahead of the two add chains
+  // (2) the running sums in the reference's order.  Lanes 0 / 1 / 2 of a wavefront carry the gradient sum, the hessian sum and the
+  // count (integers below 2^31 are exact in fp64) of ONE scan direction: a step is one LDS read, one v_add_f64 and one LDS write for
+  // all three (the first form -- one lane, three scalars, selects for the skipped bin -- spent ~150 cycles per step waiting for its
+  // own LDS reads: 16 of the kernel's 23 us at 255 bins).  Reverse scan on wavefront 0, forward scan on wavefront 1, concurrently.
   const int r_hi = nb - 1 - offset - na_as_missing, r_lo = 1 - offset;        // reverse scan: t = r_hi .. r_lo  (:880-960)
   const int f_hi = nb - 2 - offset;                                           // forward scan: t = f_lo .. f_hi  (:962-1050)
   const bool fwd_pre = na_as_missing && offset == 1;
   const int f_lo = fwd_pre ? -1 : 0;
-  if (tid == 0) {
-    double srg = 0.0, srh = kEps;
-    int rc = 0;
-#pragma unroll 4
-    for (int t = r_hi; t >= r_lo; --t) {
-      const bool skip = skip_default && (t + offset) == default_bin;
-      const double g = s_d[2 * t], hh = s_d[2 * t + 1];
-      const int c = s_cnt[t];
-      const double srg2 = srg + g, srh2 = srh + hh;
-      srg = skip ? srg : srg2; srh = skip ? srh : srh2; rc = skip ? rc : rc + c;
-      s_ag[0][t + 1] = srg; s_ah[0][t + 1] = srh; s_ac[0][t + 1] = rc;
+  const int q = tid & 63;
+  if (tid < 3) {
+    double acc = q == 1 ? kEps : 0.0;
+#pragma unroll 8
+    for (int t = r_hi; t >= r_lo; --t) { acc += s_x[t][q]; s_o[0][t + 1][q] = acc; }
+  } else if (tid >= 64 && tid < 67 && two_scans) {
+    double acc = q == 1 ? kEps : 0.0;
+    if (fwd_pre) {                              // NaN-as-missing with the first bin outside the view: start from the leaf's totals (:985-1001)
+      acc = q == 0 ? sum_gradient : (q == 1 ? sum_hessian - kEps : (double)num_data);
+#pragma unroll 8
+      for (int i = 0; i < nent; ++i) acc -= s_x[i][q];
+      s_o[1][0][q] = acc;                       // step t = -1: nothing accumulated
     }
-  } else if (tid == 64 && two_scans) {
-    double slg = 0.0, slh = kEps;
-    int lc = 0;
-    if (fwd_pre) {
-      slg = sum_gradient; slh = sum_hessian - kEps; lc = num_data;
-#pragma unroll 4
-      for (int i = 0; i < nent; ++i) { slg -= s_d[2 * i]; slh -= s_d[2 * i + 1]; lc -= s_cnt[i]; }
-    }
-#pragma unroll 4
-    for (int t = f_lo; t <= f_hi; ++t) {
-      const bool skip = (skip_default && (t + offset) == default_bin) || t < 0;
-      const int tt = t < 0 ? 0 : t;
-      const double g = s_d[2 * tt], hh = s_d[2 * tt + 1];
-      const int c = s_cnt[tt];
-      const double slg2 = slg + g, slh2 = slh + hh;
-      slg = skip ? slg : slg2; slh = skip ? slh : slh2; lc = skip ? lc : lc + c;
-      s_ag[1][t + 1] = slg; s_ah[1][t + 1] = slh; s_ac[1][t + 1] = lc;
-    }
+#pragma unroll 8
+    for (int t = 0; t <= f_hi; ++t) { acc += s_x[t][q]; s_o[1][t + 1][q] = acc; }
   }
   __syncthreads();
   // (3) the reference's continue / break conditions of every step, in parallel; the scan stops at the FIRST break in scan order
@@ -449,8 +470,8 @@ __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __re
       const bool in_range = dir == 0 ? (t >= r_lo && t <= r_hi) : (t >= f_lo && t <= f_hi);
       if (!in_range) continue;
       if (skip_default && (t + offset) == default_bin) continue;            // `continue` before anything is accumulated
-      const double ah = s_ah[dir][k];
-      const int ac = s_ac[dir][k];
+      const double ah = s_o[dir][k][1];
+      const int ac = (int)s_o[dir][k][2];
       if (ac < min_data_in_leaf || ah < min_sum_hessian) continue;
       const int other_count = num_data - ac;
       const double other_h = sum_hessian - ah;
@@ -475,8 +496,8 @@ __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __re
     for (int k = tid; k < kSplitSteps; k += 256) {
       if (!s_eval[dir][k]) continue;
       double slg, slh, srg, srh;
-      if (dir == 0) { srg = s_ag[0][k]; srh = s_ah[0][k]; slh = sum_hessian - srh; slg = sum_gradient - srg; }
-      else { slg = s_ag[1][k]; slh = s_ah[1][k]; srh = sum_hessian - slh; srg = sum_gradient - slg; }
+      if (dir == 0) { srg = s_o[0][k][0]; srh = s_o[0][k][1]; slh = sum_hessian - srh; slg = sum_gradient - srg; }
+      else { slg = s_o[1][k][0]; slh = s_o[1][k][1]; srh = sum_hessian - slh; srg = sum_gradient - slg; }
       const double current_gain = (slg * slg) / (slh + l2) + (srg * srg) / (srh + l2);
       if (current_gain <= min_gain_shift) continue;
       any = 1;
@@ -504,8 +525,8 @@ __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __re
       if (splittable && k >= 0 && best_gain > o.gain + min_gain_shift) {
         const int t = k - 1;
         double best_slg, best_slh; int best_left_count;
-        if (dir == 0) { best_left_count = num_data - s_ac[0][k]; best_slg = sum_gradient - s_ag[0][k]; best_slh = sum_hessian - s_ah[0][k]; o.threshold = (unsigned)(t - 1 + offset); }
-        else { best_left_count = s_ac[1][k]; best_slg = s_ag[1][k]; best_slh = s_ah[1][k]; o.threshold = (unsigned)(t + offset); }
+        if (dir == 0) { best_left_count = num_data - (int)s_o[0][k][2]; best_slg = sum_gradient - s_o[0][k][0]; best_slh = sum_hessian - s_o[0][k][1]; o.threshold = (unsigned)(t - 1 + offset); }
+        else { best_left_count = (int)s_o[1][k][2]; best_slg = s_o[1][k][0]; best_slh = s_o[1][k][1]; o.threshold = (unsigned)(t + offset); }
         o.left_output = -best_slg / (best_slh + l2);
         o.left_count = best_left_count;
         o.lsg = best_slg; o.lsh = best_slh - kEps;
@@ -518,12 +539,72 @@ __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __re
     }
     __syncthreads();
   }
-  if (tid != 0) return;
-  if (!two_scans && missing == 2) o.default_left = 0;
-  double* r = out10 + (size_t)f * 10;
-  r[0] = o.gain; r[1] = (double)o.threshold; r[2] = o.left_count; r[3] = o.right_count; r[4] = o.left_output; r[5] = o.right_output;
-  r[6] = o.lsg; r[7] = o.lsh; r[8] = o.rsg; r[9] = o.rsh;
-  out_default_left[f] = o.default_left | (splittable ? 2 : 0);      // bit 1: FeatureHistogram::is_splittable() after the search
+  if (tid == 0) {
+    if (!two_scans && missing == 2) o.default_left = 0;
+    double* r = out10 + (size_t)f * 10;
+    r[0] = o.gain; r[1] = (double)o.threshold; r[2] = o.left_count; r[3] = o.right_count; r[4] = o.left_output; r[5] = o.right_output;
+    r[6] = o.lsg; r[7] = o.lsh; r[8] = o.rsg; r[9] = o.rsh;
+    out_default_left[f] = o.default_left | (splittable ? 2 : 0);      // bit 1: FeatureHistogram::is_splittable() after the search
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
+                                       const int* __restrict__ num_bin, const int* __restrict__ meta3, double sum_gradient, double sum_hessian_leaf,
+                                       int num_data, double lambda_l2, int min_data_in_leaf, double min_sum_hessian, double min_gain_to_split,
+                                       double* __restrict__ out10, int* __restrict__ out_default_left) {
+  if ((int)blockIdx.x >= num_features) return;
+  best_split_feature(hist, blockIdx.x, view_offset, num_bin, meta3, sum_gradient, sum_hessian_leaf, num_data, lambda_l2, min_data_in_leaf,
+                     min_sum_hessian, min_gain_to_split, out10, out_default_left);
+}
+
+// Both children of a split in ONE launch (tree grower): workgroup (f, child) handles feature f of the smaller (child = 0) or the larger
+// (child = 1) leaf, for the feature's own histogram entries only:
+//   child 0: FixHistogram of the freshly built smaller child (dataset.cpp:1272-1290), written to its slot; threshold search -> result set 0
+//   child 1: larger = parent - fixed smaller in the parent's slot (serial_tree_learner.cpp:419-421); threshold search -> result set 1.
+//            It derives the fixed most-frequent-bin entry of the smaller child itself (same loop, same order) instead of waiting for
+//            workgroup (f, 0) to store it.
+// Which child is the smaller one -- and whether the pair is searched at all -- is read from the partition's device-resident counts.
+__global__ __launch_bounds__(256) void hist_children_search_kernel(ChildrenSearchArgs a) {
+#pragma clang fp contract(off)
+  const int f = blockIdx.x, child = blockIdx.y, tid = threadIdx.x;
+  if (f >= a.num_features) return;
+  const ChildSegment cs = child_segment(a.counts, 0, 0, a.gcnt, a.min_data_in_leaf);
+  if (cs.skip) return;
+  const double sg_s = cs.smaller_is_left ? a.left_sum_gradient : a.right_sum_gradient, sh_s = cs.smaller_is_left ? a.left_sum_hessian : a.right_sum_hessian;
+  const double sg_l = cs.smaller_is_left ? a.right_sum_gradient : a.left_sum_gradient, sh_l = cs.smaller_is_left ? a.right_sum_hessian : a.left_sum_hessian;
+  const int n_s = cs.smaller_is_left ? cs.gnl : a.gcnt - cs.gnl, n_l = a.gcnt - n_s;
+  const int mfb = a.most_freq_bin[f];
+  __shared__ double s_fix[2];
+  if (tid == 0 && mfb > 0) {                    // the same subtraction order as the reference's loop
+    const double* v = a.smaller + (size_t)a.view_offset[f] * 2;
+    double g = sg_s, hh = sh_s;
+    const int nb = a.num_bin[f];
+    for (int i = 0; i < nb; ++i) if (i != mfb) { g -= v[2 * i]; hh -= v[2 * i + 1]; }
+    s_fix[0] = g; s_fix[1] = hh;
+  }
+  __syncthreads();
+  const size_t fix_at = mfb > 0 ? 2 * ((size_t)a.view_offset[f] + mfb) : (size_t)-1;     // index of the fixed entry in the flat histogram
+  if (child == 0) {
+    if (tid == 0 && mfb > 0) { a.smaller[fix_at] = s_fix[0]; a.smaller[fix_at + 1] = s_fix[1]; }
+    __threadfence_block();
+    __syncthreads();
+    best_split_feature(a.smaller, f, a.view_offset, a.num_bin, a.meta3, sg_s, sh_s, n_s, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
+                       a.min_gain_to_split, a.out10, a.out_flags);
+  } else {
+    for (size_t i = 2 * (size_t)a.bin_offsets[f] + tid; i < 2 * (size_t)a.bin_offsets[f + 1]; i += 256) {
+      const double sm = (i == fix_at || i == fix_at + 1) ? s_fix[i - fix_at] : a.smaller[i];
+      a.parent[i] = a.parent[i] - sm;
+    }
+    __threadfence_block();
+    __syncthreads();
+    best_split_feature(a.parent, f, a.view_offset, a.num_bin, a.meta3, sg_l, sh_l, n_l, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
+                       a.min_gain_to_split, a.out10 + (size_t)a.num_features * 10, a.out_flags + (a.num_features + 1));
+  }
+}
+hipError_t launch_hist_children_search(const ChildrenSearchArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(hist_children_search_kernel, dim3(a.num_features, 2), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 // the winner: larger gain, equal gains -> smaller feature index; features masked out by is_feature_used never win
@@ -610,23 +691,41 @@ __global__ __launch_bounds__(256) void hist_partition_kernel(const uint8_t* __re
   }
   int l = blk_off[blockIdx.x] + s_scan[tid] - nl;                      // rows going left before this lane's first row
   int g = (blockIdx.x * 1024 + tid * 4) - l;                           // rows going right before it = position - lefts
+  if (gt == nullptr) gt = lte + blk_off[gridDim.x];                    // one output segment: [left rows | right rows], the total from the scan
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (base + k < cnt) { if (left[k]) lte[l++] = idx[k]; else gt[g++] = idx[k]; }
   }
 }
 
-// exclusive scan of the block counts (one block; nblk is small: cnt / 1024), total written to off[nblk]
-__global__ void hist_partition_scan_kernel(const int* __restrict__ blk_cnt, int nblk, int* __restrict__ off) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int run = 0;
-  for (int b = 0; b < nblk; ++b) { off[b] = run; run += blk_cnt[b]; }
-  off[nblk] = run;
+// exclusive scan of the block counts by one workgroup (lane = a contiguous run of blocks), total written to off[nblk] and, for the tree
+// grower, to counts[0] (rows of this rank going left) and counts[1] (the same until an all-reduce over the ranks replaces it)
+__global__ __launch_bounds__(256) void hist_partition_scan_kernel(const int* __restrict__ blk_cnt, int nblk, int* __restrict__ off, int* __restrict__ counts,
+                                                                  int* __restrict__ host_counts) {
+  // (counts: device memory, read by the kernels that follow in the stream; host_counts: pinned host memory the host reads after the
+  // split's synchronisation -- written from here, no copy launch)
+  __shared__ int s_run[256];
+  const int tid = threadIdx.x, per = (nblk + 255) / 256, b0 = tid * per, b1 = min(b0 + per, nblk);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += blk_cnt[b];
+  s_run[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = tid >= o ? s_run[tid - o] : 0;
+    __syncthreads();
+    s_run[tid] += v;
+    __syncthreads();
+  }
+  int run = s_run[tid] - sum;
+  for (int b = b0; b < b1; ++b) { off[b] = run; run += blk_cnt[b]; }
+  if (tid == 255) {
+    off[nblk] = s_run[255];
+    if (counts) { counts[0] = s_run[255]; counts[1] = s_run[255]; }
+    if (host_counts) { host_counts[0] = s_run[255]; host_counts[1] = s_run[255]; }
+  }
 }
 
-hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
-                                 int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
-                                 int* blk_off, int* lte, int* gt, hipStream_t st) {
+static SplitRule make_split_rule(int max_bin, int default_bin, int most_freq_bin, int missing_type, int default_left, unsigned threshold) {
   SplitRule r;
   r.max_bin = max_bin;
   r.miss_zero = missing_type == 1; r.miss_na = missing_type == 2;
@@ -637,13 +736,36 @@ hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, 
   r.th = th; r.t_zero_bin = tz;
   r.default_goes_left = (unsigned)most_freq_bin <= threshold;                        // :196-199
   r.missing_goes_left = (r.miss_zero || r.miss_na) && default_left;                  // :200-205
+  return r;
+}
+
+hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
+                                 int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
+                                 int* blk_off, int* lte, int* gt, hipStream_t st) {
+  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold);
   const int nblk = (cnt + 1023) / 1024;
   if (nblk == 0) return hipSuccess;
   hipLaunchKernelGGL(hist_partition_kernel<false>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, data_indices, cnt, blk_cnt,
                      (const int*)nullptr, (int*)nullptr, (int*)nullptr);
-  hipLaunchKernelGGL(hist_partition_scan_kernel, dim3(1), dim3(64), 0, st, (const int*)blk_cnt, nblk, blk_off);
+  hipLaunchKernelGGL(hist_partition_scan_kernel, dim3(1), dim3(256), 0, st, (const int*)blk_cnt, nblk, blk_off, (int*)nullptr, (int*)nullptr);
   hipLaunchKernelGGL(hist_partition_kernel<true>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, data_indices, cnt, blk_cnt,
                      (const int*)blk_off, lte, gt);
+  return hipGetLastError();
+}
+
+// the tree grower's form: the segment's rows (src, or the identity when src == nullptr) are written as [left rows | right rows] to dst
+// (the other one of its two row buffers); counts[0] = counts[1] = rows going left stay on the device for the kernels that follow
+hipError_t launch_hist_partition_segment(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
+                                         int missing_type, int default_left, unsigned threshold, const int* src, int cnt, int* blk_cnt,
+                                         int* blk_off, int* dst, int* counts, int* host_counts, hipStream_t st) {
+  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold);
+  const int nblk = (cnt + 1023) / 1024;
+  if (nblk == 0) { if (host_counts) { host_counts[0] = 0; host_counts[1] = 0; } return hipMemsetAsync(counts, 0, 2 * sizeof(int), st); }
+  hipLaunchKernelGGL(hist_partition_kernel<false>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, src, cnt, blk_cnt,
+                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(hist_partition_scan_kernel, dim3(1), dim3(256), 0, st, (const int*)blk_cnt, nblk, blk_off, counts, host_counts);
+  hipLaunchKernelGGL(hist_partition_kernel<true>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, src, cnt, blk_cnt,
+                     (const int*)blk_off, dst, (int*)nullptr);
   return hipGetLastError();
 }
 

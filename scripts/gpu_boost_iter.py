@@ -57,7 +57,9 @@ def main():
             hb.pool_resize(L + 1); hb.set_fix_info(voff, num_bin, mfb); hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
         hb.set_gradients(grad, None)
         sg = float(np.cumsum(grad)[-1])
+        t1 = time.perf_counter()
         tree = hb.grow_tree(L, sg, float(n), *cfg)
+        t["2a_grow_tree_call_only_ms"] = (time.perf_counter() - t1) * 1e3
         t["2_tree_growth_ms"] = (time.perf_counter() - t0) * 1e3
         leaf_of, nleaves = tree["data_leaf_index"], tree["num_leaves"]
         if it == niter - 1:                          # the same tree through the single-step entry points driven from Python (harness)
