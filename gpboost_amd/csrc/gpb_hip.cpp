@@ -455,13 +455,13 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   const int nblocks = big ? (h->i_end - h->i_begin) : (h->i_end - h->i_begin + 15) / 16;
   // the final reduction also writes the caller's device buffer (documented order), no extra copies on the stream
   (void)nout;
-  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream));
+  // (the sums also go straight to the pinned host buffer: vecchia_fetch needs no copy on the stream)
+  HIP_OK(gpb::launch_reduce_partials(h->d_partials, nblocks, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream, h->h_out));
   return 0;
 }
 
 static int vecchia_fetch(gpb_hip_vecchia_t* h, double* out_host, int nout) {
-  HIP_OK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * GPB_NUM_PARTIALS, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));          // reduce_partials_kernel has written h_out itself
   out_host[0] = h->h_out[gpb::GPB_P_QUAD];
   out_host[1] = h->h_out[gpb::GPB_P_LOGDET];
   for (int t = 2; t < nout; ++t) out_host[t] = h->h_out[t];

@@ -11,7 +11,8 @@ namespace gpb {
 // Deterministic final reduction: one workgroup per term; each thread sums a strided subset of the block partials
 // (layout [term][nblocks], contiguous per term) in a fixed order, then a fixed-shape tree.  out[t] = sum_b partials[t][b].
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
-                                                               double* __restrict__ out, double* __restrict__ out2) {
+                                                               double* __restrict__ out, double* __restrict__ out2,
+                                                               double* __restrict__ out_host) {
   __shared__ double s[1024];
   const int t = blockIdx.x;
   const double* p = partials + (size_t)t * nblocks;
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __r
   }
   if (threadIdx.x == 0) {
     out[t] = s[0];
+    if (out_host) out_host[t] = s[0];      // pinned host memory: the host reads it after the stream's synchronisation, no copy on the stream
     // caller-facing layout {quad, logdet, bad, g1v, g2v, g1r, g2r}: terms 0 and 1 swapped w.r.t. GPB_P_*
     if (out2) out2[t == GPB_P_LOGDET ? 1 : (t == GPB_P_QUAD ? 0 : t)] = s[0];
   }
@@ -136,8 +138,8 @@ hipError_t launch_resid(double4* pts, const double* y0, const double* X, const d
 }
 
 hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
-                                  hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user);
+                                  hipStream_t st, double* out_host) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user, out_host);
   return hipGetLastError();
 }
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
