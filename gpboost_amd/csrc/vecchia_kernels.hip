@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   // 31 x 256 x 8 B = 62 KB for MT = 30, two workgroups per CU) so that the contraction pass evaluates no exp; larger MT re-evaluate.
   constexpr bool kStoreDK = (MODE == MODE_GRAD) && (MT <= 30);
   constexpr int NSTEP = num_lower_steps<MT>();
+  // (Tried in round 2: the last 13 steps' values in registers + __launch_bounds__(256, 3), so that three workgroups -- 12 wavefronts instead of
+  // 8 -- share a CU: the compiler needs 241 VGPRs for that form, capped at 168 it spills 12 doubles to scratch, and the kernel got 13 % SLOWER.)
   constexpr bool kLastDkInReg = kStoreDK && D3;      // d = 3: 32-byte records; the last step's value stays in a register so that two workgroups fit a CU's 160 KB
   constexpr int NSTORE = kStoreDK ? (kLastDkInReg ? NSTEP - 1 : NSTEP) : 1;
   constexpr int PSTRIDE = D3 ? L::PTS_STRIDE : L::PTS_STRIDE24;
