@@ -89,6 +89,7 @@ struct gpb_hip_vecchia {
   double* d_partials = nullptr;
   double* d_out = nullptr;   // GPB_NUM_PARTIALS + 1
   double* h_out = nullptr;   // pinned, coherent: written by reduce_partials_kernel, polled by vecchia_fetch
+  double* h_red = nullptr;   // pinned, coherent: the all-reduced terms, published by a one-wavefront kernel after ncclAllReduce and polled by the host
   int launches_unfetched = 0; // reductions enqueued since the last vecchia_fetch (polling is only unambiguous for exactly one)
   double* d_A = nullptr; double* d_D = nullptr; double* d_u = nullptr; double* d_v = nullptr; double* d_w = nullptr;
   double* d_ystage = nullptr;
@@ -260,6 +261,7 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   HIP_OK(hipMalloc(&h->d_partials, sizeof(double) * (size_t)nblocks * GPB_NUM_PARTIALS));
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 8));
   HIP_OK(hipHostMalloc(&h->h_out, sizeof(double) * 8, hipHostMallocCoherent));
+  HIP_OK(hipHostMalloc(&h->h_red, sizeof(double) * 8, hipHostMallocCoherent));
   HIP_OK(hipMalloc(&h->d_flag, sizeof(int)));
   *out = h;
   API_END();
@@ -277,6 +279,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
   laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->h_red) (void)hipHostFree(h->h_red);
   delete h;
   API_END();
 }
@@ -562,9 +565,23 @@ static int vecchia_allreduce_terms(gpb_hip_vecchia_t* h, int mode, int cov_type,
   if (!h->comm) return fail("no communicator: call gpb_hip_vecchia_comm_init first");
   if (vecchia_launch(h, mode, cov_type, var, a, gauss, h->d_red, nout)) return -1;
   NCCL_OK(ncclAllReduce(h->d_red, h->d_red, (size_t)nout, ncclDouble, ncclSum, h->comm, h->stream));
-  HIP_OK(hipMemcpyAsync(h->h_out, h->d_red, sizeof(double) * nout, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  for (int t = 0; t < nout; ++t) out_host[t] = h->h_out[t];
+  // the job's sums reach the host without a copy engine and without the wake-up of a stream synchronisation: a one-wavefront kernel
+  // stores them into pinned memory behind the all-reduce, the host polls (as vecchia_fetch does for the single-GPU evaluation)
+  volatile unsigned long long* v = reinterpret_cast<volatile unsigned long long*>(h->h_red);
+  for (int t = 0; t < nout; ++t) v[t] = kFetchSentinel;
+  HIP_OK(gpb::launch_publish(h->d_red, h->h_red, nout, h->stream));
+  h->launches_unfetched = 0;
+  bool polled = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    bool all = true;
+    for (int t = 0; t < nout; ++t) all = all && v[t] != kFetchSentinel;
+    if (all) { polled = true; break; }
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (!polled) HIP_OK(hipStreamSynchronize(h->stream));
+  for (int t = 0; t < nout; ++t) out_host[t] = h->h_red[t];
   return 0;
 }
 

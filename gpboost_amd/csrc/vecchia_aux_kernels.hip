@@ -142,6 +142,14 @@ hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterm
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(nterms), dim3(1024), 0, st, partials, nblocks, out, out_user, out_host);
   return hipGetLastError();
 }
+// dst (pinned host memory) <- src (device), a handful of doubles: see vecchia_allreduce_terms
+__global__ void publish_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_t st) {
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, src, dst_host, n);
+  return hipGetLastError();
+}
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
   hipLaunchKernelGGL(pack_y_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, y, n);
   return hipGetLastError();

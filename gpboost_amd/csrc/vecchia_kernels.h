@@ -52,6 +52,7 @@ hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const Vecchia
 hipError_t launch_vecchia_point_big(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
                                   hipStream_t st, double* out_host = nullptr);
+hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,
