@@ -112,6 +112,7 @@ struct gpb_hip_exact {
   int n = 0, d = 0, np = 0;
   double4* d_pts = nullptr;
   double* d_P = nullptr; double* d_y = nullptr; double* d_z = nullptr; double* d_x = nullptr; double* d_out = nullptr;
+  double* d_work = nullptr;        // np doubles: the running right-hand side of the blocked triangular solves
   double* d_exp_tab = nullptr;
   int* d_info = nullptr;
   bool has_y = false;
@@ -1007,6 +1008,7 @@ int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gp
   HIP_OK(hipMalloc(&h->d_y, sizeof(double) * (size_t)h->np));
   HIP_OK(hipMalloc(&h->d_z, sizeof(double) * (size_t)h->np));
   HIP_OK(hipMalloc(&h->d_x, sizeof(double) * (size_t)h->np));
+  HIP_OK(hipMalloc(&h->d_work, sizeof(double) * (size_t)h->np));
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 2));
   HIP_OK(hipMalloc(&h->d_info, sizeof(int)));
   const std::vector<double> tab = exp_table();
@@ -1024,7 +1026,7 @@ int gpb_hip_exact_free(gpb_hip_exact_t* h) {
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->ev_panels) (void)hipEventDestroy(h->ev_panels);
   if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
-  dev_free(h->d_pts); dev_free(h->d_P); dev_free(h->d_y); dev_free(h->d_z); dev_free(h->d_x); dev_free(h->d_out);
+  dev_free(h->d_pts); dev_free(h->d_P); dev_free(h->d_y); dev_free(h->d_z); dev_free(h->d_x); dev_free(h->d_out); dev_free(h->d_work);
   dev_free(h->d_exp_tab); dev_free(h->d_info); dev_free(h->d_P2); dev_free(h->d_gpart); dev_free(h->d_g4);
   delete h;
   API_END();
@@ -1061,7 +1063,7 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   }
   HIP_OK(gpb::launch_dense_cholesky(h->d_P, h->np, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest));
   HIP_OK(hipEventRecord(e[2], h->stream));
-  HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream));
+  HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream, h->d_work));
   HIP_OK(hipEventRecord(e[3], h->stream));
   int info = 0;
   HIP_OK(hipMemcpyAsync(out2_host, h->d_out, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
@@ -1103,7 +1105,7 @@ int gpb_hip_exact_grad_terms(gpb_hip_exact_t* h, int cov_type, double var, doubl
   HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, np, ld, var, a, 1.0, h->d_exp_tab, h->d_P2, h->stream));
   HIP_OK(gpb::launch_dense_aug_identity(h->d_P2, np, ld, h->stream));
   HIP_OK(gpb::launch_dense_cholesky(h->d_P2, ld, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest, np));
-  HIP_OK(gpb::launch_dense_solve(h->d_P2, h->n, np, ld, h->d_y, h->d_z, h->d_out, h->d_x, h->stream));           // y' Psi^-1 y, log|Psi|, ya = Psi^-1 y
+  HIP_OK(gpb::launch_dense_solve(h->d_P2, h->n, np, ld, h->d_y, h->d_z, h->d_out, h->d_x, h->stream, h->d_work));           // y' Psi^-1 y, log|Psi|, ya = Psi^-1 y
   HIP_OK(gpb::launch_dense_grad(cov_type, h->d == 3, h->d_pts, h->n, np, ld, var, a, h->d_exp_tab, h->d_P2, h->d_x, h->d_gpart, h->stream));
   HIP_OK(gpb::launch_reduce_partials(h->d_gpart, ntiles, 4, h->d_g4, nullptr, h->stream));
   double o2[2], g4[4];
