@@ -58,19 +58,26 @@ __global__ void vecchia_By_kernel(const double* __restrict__ A, const int* __res
 
 // w = B^T v via the transposed index (CSR over columns): w_j = v_j - sum_{e in T[j]} A_flat[e] v[e / m]
 // With a shard [i0, i1) only the rows of B owned by this device contribute (the caller all-reduces the n-vector).
-__global__ void vecchia_Bt_kernel(const double* __restrict__ A, const int* __restrict__ t_ptr,
+// 16 lanes per column: the first points of the ordering are neighbours of thousands of rows (at n = 1e5 the longest column has > 3000
+// entries against a mean of 30), and with one lane per column that one lane set the kernel's time (243 us at n = 1e5; now the entries of
+// a column are strided over its 16 lanes and summed by a fixed-shape butterfly -- a fixed order, so the result stays reproducible).
+__global__ __launch_bounds__(256) void vecchia_Bt_kernel(const double* __restrict__ A, const int* __restrict__ t_ptr,
                                   const int* __restrict__ t_pos, int n, int m, int i0, int i1,
                                   const double* __restrict__ v, double* __restrict__ w) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double s = (j >= i0 && j < i1) ? v[j] : 0.0;
-  const int e0 = t_ptr[j], e1 = t_ptr[j + 1];
-  for (int e = e0; e < e1; ++e) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, lane = threadIdx.x & 15;
+  const int jj = j < n ? j : n - 1;                  // whole groups stay active for the shuffles
+  const int e0 = t_ptr[jj], e1 = t_ptr[jj + 1];
+  double s = 0.0;
+  for (int e = e0 + lane; e < e1; e += 16) {
     const int pos = t_pos[e];
     const int row = pos / m;
     if (row >= i0 && row < i1) s = __builtin_fma(-A[pos], v[row], s);
   }
-  w[j] = s;
+  s += __shfl_xor(s, 8, 16);
+  s += __shfl_xor(s, 4, 16);
+  s += __shfl_xor(s, 2, 16);
+  s += __shfl_xor(s, 1, 16);
+  if (lane == 0 && j < n) w[j] = ((j >= i0 && j < i1) ? v[j] : 0.0) + s;
 }
 
 // v = u / D elementwise
@@ -160,7 +167,7 @@ hipError_t launch_By(const double* A, const int* nn, int n, int m, const double*
 }
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,
                      double* w, hipStream_t st) {
-  hipLaunchKernelGGL(vecchia_Bt_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, t_ptr, t_pos, n, m, i0, i1, v, w);
+  hipLaunchKernelGGL(vecchia_Bt_kernel, dim3((n + 15) / 16), dim3(256), 0, st, A, t_ptr, t_pos, n, m, i0, i1, v, w);
   return hipGetLastError();
 }
 hipError_t launch_scale_by_Dinv(const double* u, const double* D, int n, int i0, int i1, double* v, hipStream_t st) {
