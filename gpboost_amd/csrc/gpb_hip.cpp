@@ -338,6 +338,14 @@ static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* 
   // positions are balanced (SURVEY.md 8e suggested cyclic assignment for index-ordered blocks; not needed here)
   a.start_at = 0; a.end_search_at = n - 2;
   a.pos0 = (int)((long long)n * part / nparts); a.pos1 = (int)((long long)n * (part + 1) / nparts);
+  // the order in which the lanes take this block's queries: grouped by index octave quarter (nn_kernels.h)
+  std::vector<int> qorder((size_t)std::max(a.pos1 - a.pos0, 1));
+  int nq = 0;
+  gpb::nn_query_order(sort_sum.data(), a.pos0, a.pos1, m, 0, qorder.data(), &nq);
+  int* d_qorder = nullptr;
+  HIP_OK(hipMalloc(&d_qorder, sizeof(int) * qorder.size()));
+  HIP_OK(hipMemcpyAsync(d_qorder, qorder.data(), sizeof(int) * (size_t)std::max(nq, 1), hipMemcpyHostToDevice, h->stream));
+  a.qorder = d_qorder; a.nq = nq;
   if (nparts > 1) HIP_OK(hipMemsetAsync(h->d_nn, 0x80, sizeof(int) * (size_t)n * m, h->stream));     // 0x80808080 < -1: "not mine"
   if (n == 1) {
     HIP_OK(hipMemsetAsync(h->d_nn, 0xff, sizeof(int) * (size_t)n * m, h->stream));
@@ -347,7 +355,7 @@ static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* 
   int flag = 0;
   HIP_OK(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_rec); (void)hipFree(d_idx);
+  (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder);
   if (has_duplicates) *has_duplicates = flag;
   h->has_nn = nparts == 1; h->nn_partial = nparts > 1;
   h->has_transpose = false; h->has_levels = false; h->has_factor = false; h->nn_host.clear();
@@ -889,11 +897,19 @@ static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const d
     gpb::NNKernelArgs na;
     na.sorted_rec = d_rec; na.sorted_idx = d_idx; na.pts = t->d_pts; na.nn = t->d_nn; na.has_duplicates = t->d_flag; na.n = n_all; na.m = t->m;
     na.start_at = n_obs; na.end_search_at = cond_all ? n_all - 2 : n_obs - 1; na.pos0 = 0; na.pos1 = n_all;
+    // only the appended rows are searched: their positions, grouped like the training-time search
+    std::vector<int> qorder((size_t)std::max(n_pred, 1));
+    int nq = 0;
+    gpb::nn_query_order(sort_sum.data(), 0, n_all, t->m, n_obs, qorder.data(), &nq);
+    int* d_qorder = nullptr;
+    HIP_OK(hipMalloc(&d_qorder, sizeof(int) * qorder.size()));
+    HIP_OK(hipMemcpyAsync(d_qorder, qorder.data(), sizeof(int) * (size_t)std::max(nq, 1), hipMemcpyHostToDevice, t->stream));
+    na.qorder = d_qorder; na.nq = nq;
     HIP_OK(gpb::launch_vecchia_nn(d, na, t->stream));
     int flag = 0;
     HIP_OK(hipMemcpyAsync(&flag, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
     HIP_OK(hipStreamSynchronize(t->stream));
-    (void)hipFree(d_rec); (void)hipFree(d_idx);
+    (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder);
     if (has_duplicates) *has_duplicates = flag;
     t->has_nn = true;
   }

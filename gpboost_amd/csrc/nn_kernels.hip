@@ -39,8 +39,9 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
   double* s_sq = reinterpret_cast<double*>(smem);              // [m][64]
   int* s_id = reinterpret_cast<int*>(smem + (size_t)m * 64 * 8);  // [m][64]
   const int lane = threadIdx.x;
-  const int pos = a.pos0 + blockIdx.x * 64 + lane;             // position in coordinate-sum order
-  if (pos >= a.pos1) return;
+  const int qid = blockIdx.x * 64 + lane;
+  if (qid >= a.nq) return;
+  const int pos = a.qorder ? a.qorder[qid] : a.pos0 + qid;     // position in coordinate-sum order
   const int i = a.sorted_idx[pos];                             // original (Vecchia-order) index of the query
   if (i <= m || i < a.start_at) return;                        // first m+1 points: all predecessors (:788-813); rows below start_at: not asked for
   const double4 q = a.sorted_rec[pos];
@@ -51,10 +52,9 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
   double worst = INFINITY;
   bool down = true, up = true;
   int up_i = pos, down_i = pos;
-  auto visit = [&](int p, bool& dir) {
-    const int c = a.sorted_idx[p];
-    if (c < i && c <= end_search_at) {
-      const double4 r = a.sorted_rec[p];
+  // one candidate, exactly the reference's step: c = its index, r = its record (loaded only when c is eligible)
+  auto visit = [&](int c, bool eligible, const double4& r, bool& dir) {
+    if (eligible) {
       const double ds = r.w - q.w;                             // coords_sum[c] - coords_sum[i]
       const double smd = ds * ds;                              // std::pow(.,2)
       if (smd > dd * worst) {
@@ -75,11 +75,36 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
       }
     }
   };
-  while (up || down) {                                         // :1049-1092
-    if (down_i == 0) down = false;
-    if (up_i == n - 1) up = false;
-    if (down) { --down_i; visit(down_i, down); }
-    if (up) { ++up_i; visit(up_i, up); }
+  // The visiting ORDER is the reference's (down, up, down, up ...; :1049-1092), but the loads run ahead of it: the indices of the next
+  // kAhead candidates of both directions are fetched together, then the records of the eligible ones together, and only then are the
+  // candidates taken one by one.  (One candidate at a time meant two dependent L2 round trips per visit with 1.5 wavefronts per SIMD to
+  // hide them: the kernel was latency-bound, SQ_WAIT_ANY >> busy cycles.)  Candidates fetched past the point where a direction stops
+  // are simply not used.
+  constexpr int kAhead = 4;
+  while (up || down) {
+    int cD[kAhead], cU[kAhead];
+    bool eD[kAhead], eU[kAhead];
+    double4 rD[kAhead], rU[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      cD[k] = a.sorted_idx[max(down_i - 1 - k, 0)];
+      cU[k] = a.sorted_idx[min(up_i + 1 + k, n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      eD[k] = cD[k] < i && cD[k] <= end_search_at;
+      eU[k] = cU[k] < i && cU[k] <= end_search_at;
+      rD[k] = q; rU[k] = q;
+      if (eD[k]) rD[k] = a.sorted_rec[max(down_i - 1 - k, 0)];
+      if (eU[k]) rU[k] = a.sorted_rec[min(up_i + 1 + k, n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      if (down_i == 0) down = false;
+      if (up_i == n - 1) up = false;
+      if (down) { --down_i; visit(cD[k], eD[k], rD[k], down); }
+      if (up) { ++up_i; visit(cU[k], eU[k], rU[k], up); }
+    }
   }
   int* out = a.nn + (size_t)i * m;
   bool dup = false;
@@ -108,12 +133,24 @@ __global__ void vecchia_nn_head_kernel(NNKernelArgs a, int d) {
   }
 }
 
-hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st) {
+void nn_query_order(const int* sorted_idx, int pos0, int pos1, int m, int start_at, int* out, int* nq) {
+  constexpr int NB = 4 * 32;
+  int cnt[NB + 1] = {0};
+  auto key = [](int i) -> int { int k = (int)(4.0 * log2((double)i)); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
+  for (int p = pos0; p < pos1; ++p) { const int i = sorted_idx[p]; if (i > m && i >= start_at) ++cnt[key(i) + 1]; }
+  for (int k = 0; k < NB; ++k) cnt[k + 1] += cnt[k];
+  *nq = cnt[NB];
+  for (int p = pos0; p < pos1; ++p) { const int i = sorted_idx[p]; if (i > m && i >= start_at) out[cnt[key(i)]++] = p; }
+}
+
+hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a_in, hipStream_t st) {
+  NNKernelArgs a = a_in;
+  if (!a.qorder) a.nq = a.pos1 - a.pos0;
   const int m = a.m;
   hipLaunchKernelGGL(vecchia_nn_head_kernel, dim3(((m + 1) * m + 255) / 256), dim3(256), 0, st, a, d);
   if (a.n <= m + 1) return hipGetLastError();
   const size_t shmem = (size_t)m * 64 * 12;
-  const int nblocks = (a.pos1 - a.pos0 + 63) / 64;
+  const int nblocks = ((a.qorder ? a.nq : a.pos1 - a.pos0) + 63) / 64;
   if (nblocks <= 0) return hipGetLastError();
   if (shmem > 64 * 1024) {      // m > 85: the per-lane top-m lists need more than the default 64 KB of dynamic LDS
     const void* kf = d == 1 ? reinterpret_cast<const void*>(vecchia_nn_kernel<1>) : (d == 2 ? reinterpret_cast<const void*>(vecchia_nn_kernel<2>)
