@@ -346,6 +346,15 @@ def main():
                     "workload": "Bernoulli-logit Vecchia-Laplace nll (Newton + vadu-CG + SLQ, 50 probes), n=%d, m=30, exponential" % n4,
                     "s_per_eval": s4, "negll": v4, "newton_it": i4["newton_it"], "cg_it": i4["cg_it"], "lanczos_it": i4["lanczos_it"],
                     "ms_mode_finding": i4["ms_mode"], "ms_logdet": i4["ms_logdet"],
+                    # one preconditioned-CG iteration of the mode finding streams the factor four times (B and B' products of Sigma^-1 + W,
+                    # B' and B triangular solves of the preconditioner: 16-byte {coefficient, source} entries + one 16-byte slot record per row
+                    # and pass) and ~10 n-vectors: what it would cost at the HBM rate against what the level-scheduled solves take
+                    "roofline_cg_iteration": (lambda byt, ms: {
+                        "bound": "hbm", "kernel": "lap_tri_spmv_kernel x2 + lap_sptrsv_kernel (389 dependency levels each way) + cg_* vector kernels",
+                        "algorithmic_bytes_per_iteration": byt, "ms_per_iteration": ms, "achieved": byt / (ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "latency-bound, not bandwidth-bound: ~140 dependent launches per iteration (DESIGN.md 4.6)"})(
+                        4 * n4 * (30 * 16 + 16) + 10 * n4 * 8, i4["ms_mode"] / max(i4["cg_it"], 1)),
                     "reference_timing": "not timed here: tests/golden/config4_ref.npz holds the unmodified reference's value and its wall time for the same-size fixture (seconds_0; 8 cores of the build container)"}
                 del m4
             except Exception as e:

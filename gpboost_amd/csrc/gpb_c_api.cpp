@@ -664,8 +664,11 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
     cfg.range_const = range_const(mdl);
     char err[512] = "";
     GpbLaplaceOptimResult res;
-    if (gpb_optimize_laplace_cov_pars(cfg, device_laplace, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err)))
+    if (gpb_optimize_laplace_cov_pars(cfg, device_laplace, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err))) {
+      const char* why = gpb_hip_get_last_error();           // what the device path said, not only "evaluation failed"
+      if (err[0] && why && why[0]) return set_error("%s: %s", err, why);
       return err[0] ? set_error("%s", err) : shim_error();
+    }
     if (cfg.max_iter > 0) {
       mdl->cov_pars_tr[0] = res.theta[0]; mdl->cov_pars_tr[1] = res.theta[1];
       mdl->cur_negll = res.negll;
@@ -686,8 +689,11 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
   cfg.range_const = range_const(mdl);
   char err[512] = "";
   GpbOptimResult res;
-  if (gpb_optimize_gaussian_cov_pars(cfg, mdl->n, device_terms, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err)))
+  if (gpb_optimize_gaussian_cov_pars(cfg, mdl->n, device_terms, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err))) {
+    const char* why = gpb_hip_get_last_error();
+    if (err[0] && why && why[0] && !std::strstr(err, why)) return set_error("%s: %s", err, why);
     return err[0] ? set_error("%s", err) : -1;
+  }
   if (cfg.max_iter > 0) {
     std::copy(res.theta, res.theta + 3, mdl->cov_pars_tr);
     mdl->cur_negll = res.negll;

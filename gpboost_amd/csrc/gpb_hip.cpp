@@ -84,6 +84,7 @@ struct gpb_hip_vecchia {
   int n = 0, d = 0, m = 0;
   int i_begin = 0, i_end = 0;
   double4* d_pts = nullptr;
+  double* d_coords_nd = nullptr;   // d > 3: [n][d] coordinates (Vecchia order); the records then only carry the response
   int* d_nn = nullptr;
   double* d_exp_tab = nullptr;
   double* d_partials = nullptr;
@@ -232,7 +233,7 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   *out = nullptr;
   if (check_device()) return -1;
   if (n < 1) return fail("gpb_hip_vecchia_create: n = %d", n);
-  if (d < 1 || d > 3) return fail("gpb_hip_vecchia_create: coordinate dimension %d not supported by the HIP hot path (1..3)", d);
+  if (d < 1 || d > GPB_MAX_DIM) return fail("gpb_hip_vecchia_create: coordinate dimension %d not supported by the HIP hot path (1..%d)", d, GPB_MAX_DIM);
   if (!coords_colmajor) return fail("gpb_hip_vecchia_create: coords is NULL");
   int m = num_neighbors;
   if (m > n - 1) m = n - 1;   // Vecchia_utils.cpp:755-758
@@ -254,11 +255,17 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   }
   HIP_OK(hipMalloc(&h->d_pts, sizeof(double4) * (size_t)n));
   HIP_OK(hipMemcpy(h->d_pts, pts.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice));
+  if (d > 3) {       // generality path: row-major coordinates for the LDS-resident point kernel and the d-dimensional neighbour search
+    std::vector<double> rm((size_t)n * d);
+    for (int i = 0; i < n; ++i) for (int c = 0; c < d; ++c) rm[(size_t)i * d + c] = coords_colmajor[(size_t)c * n + i];
+    HIP_OK(hipMalloc(&h->d_coords_nd, sizeof(double) * rm.size()));
+    HIP_OK(hipMemcpy(h->d_coords_nd, rm.data(), sizeof(double) * rm.size(), hipMemcpyHostToDevice));
+  }
   HIP_OK(hipMalloc(&h->d_nn, sizeof(int) * (size_t)n * h->m));
   const std::vector<double> tab = exp_table();
   HIP_OK(hipMalloc(&h->d_exp_tab, GPB_EXP_TAB_SIZE * sizeof(double)));
   HIP_OK(hipMemcpy(h->d_exp_tab, tab.data(), GPB_EXP_TAB_SIZE * sizeof(double), hipMemcpyHostToDevice));
-  const int nblocks = h->m > GPB_MAX_NEIGHBORS ? n : (n + 15) / 16;      // m > 62: the LDS-resident kernel, one workgroup per point
+  const int nblocks = (h->m > GPB_MAX_NEIGHBORS || d > 3) ? n : (n + 15) / 16;      // m > 62 or d > 3: the LDS-resident kernel, one workgroup per point
   HIP_OK(hipMalloc(&h->d_partials, sizeof(double) * (size_t)nblocks * GPB_NUM_PARTIALS));
   HIP_OK(hipMalloc(&h->d_out, sizeof(double) * 8));
   HIP_OK(hipHostMalloc(&h->h_out, sizeof(double) * 8, hipHostMallocCoherent));
@@ -273,7 +280,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->stream || !h->owns_stream) { (void)hipStreamSynchronize(h->stream); if (h->owns_stream) (void)hipStreamDestroy(h->stream); }
-  dev_free(h->d_pts); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out); dev_free(h->d_batch);
+  dev_free(h->d_pts); dev_free(h->d_coords_nd); dev_free(h->d_nn); dev_free(h->d_exp_tab); dev_free(h->d_partials); dev_free(h->d_out); dev_free(h->d_batch);
   dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage); dev_free(h->d_X); dev_free(h->d_U); dev_free(h->d_G); dev_free(h->d_beta);
   dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
   dev_free(h->d_leaf); dev_free(h->d_leaf_part); dev_free(h->d_leaf_out);
@@ -326,14 +333,26 @@ static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* 
     rec[k].z = d > 2 ? h->coords[(size_t)2 * n + i] : 0.0;
     rec[k].w = csum[i];
   }
-  double4* d_rec = nullptr; int* d_idx = nullptr;
+  double4* d_rec = nullptr; int* d_idx = nullptr; double* d_rec_nd = nullptr;
   HIP_OK(hipMalloc(&d_rec, sizeof(double4) * (size_t)n));
   HIP_OK(hipMalloc(&d_idx, sizeof(int) * (size_t)n));
   HIP_OK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  std::vector<double> rec_nd;
+  if (d > 3) {
+    rec_nd.resize((size_t)n * (d + 1));
+    for (int k = 0; k < n; ++k) {
+      const int i = sort_sum[k];
+      for (int c = 0; c < d; ++c) rec_nd[(size_t)k * (d + 1) + c] = h->coords[(size_t)c * n + i];
+      rec_nd[(size_t)k * (d + 1) + d] = csum[i];
+    }
+    HIP_OK(hipMalloc(&d_rec_nd, sizeof(double) * rec_nd.size()));
+    HIP_OK(hipMemcpyAsync(d_rec_nd, rec_nd.data(), sizeof(double) * rec_nd.size(), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_OK(hipMemcpyAsync(d_idx, sort_sum.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
   gpb::NNKernelArgs a;
   a.sorted_rec = d_rec; a.sorted_idx = d_idx; a.pts = h->d_pts; a.nn = h->d_nn; a.has_duplicates = h->d_flag; a.n = n; a.m = m;
+  a.sorted_nd = d_rec_nd; a.coords_nd = h->d_coords_nd;
   // positions are in coordinate-sum order, i.e. random with respect to the index that decides a query's cost: equal blocks of
   // positions are balanced (SURVEY.md 8e suggested cyclic assignment for index-ordered blocks; not needed here)
   a.start_at = 0; a.end_search_at = n - 2;
@@ -355,7 +374,7 @@ static int find_neighbors_impl(gpb_hip_vecchia_t* h, int part, int nparts, int* 
   int flag = 0;
   HIP_OK(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder);
+  (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder); if (d_rec_nd) (void)hipFree(d_rec_nd);
   if (has_duplicates) *has_duplicates = flag;
   h->has_nn = nparts == 1; h->nn_partial = nparts > 1;
   h->has_transpose = false; h->has_levels = false; h->has_factor = false; h->nn_host.clear();
@@ -465,8 +484,9 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   k.diag_i = gauss ? var + 1.0 : var;                    // :1410-1417 + :1555-1563
   k.nugget = gauss ? 1.0 : 0.0;
   if (ev0) HIP_OK(hipEventRecord(ev0, h->stream));
-  const bool big = h->m > GPB_MAX_NEIGHBORS;       // 62 < m <= 126: LDS-resident generality kernel (vecchia_big_kernels.hip)
-  if (big) HIP_OK(gpb::launch_vecchia_point_big(mode, cov_type, h->d == 3, k, h->stream));
+  const bool big = h->m > GPB_MAX_NEIGHBORS || h->d > 3;       // 62 < m <= 126 or 3 < d <= 10: LDS-resident generality kernel (vecchia_big_kernels.hip)
+  k.coords_nd = h->d_coords_nd; k.dim = h->d;
+  if (big) HIP_OK(gpb::launch_vecchia_point_big(mode, cov_type, h->d > 3 ? 0 : (h->d == 3 ? 3 : 2), k, h->stream));
   else HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
   if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
   const int nblocks = big ? (h->i_end - h->i_begin) : (h->i_end - h->i_begin + 15) / 16;
@@ -887,15 +907,27 @@ static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const d
       const int i = sort_sum[k];
       rec[k].x = call[i]; rec[k].y = d > 1 ? call[(size_t)n_all + i] : 0.0; rec[k].z = d > 2 ? call[(size_t)2 * n_all + i] : 0.0; rec[k].w = csum[i];
     }
-    double4* d_rec = nullptr; int* d_idx = nullptr;
+    double4* d_rec = nullptr; int* d_idx = nullptr; double* d_rec_nd = nullptr;
     HIP_OK(hipMalloc(&d_rec, sizeof(double4) * (size_t)n_all));
     HIP_OK(hipMalloc(&d_idx, sizeof(int) * (size_t)n_all));
     HIP_OK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double4) * (size_t)n_all, hipMemcpyHostToDevice, t->stream));
+    std::vector<double> rec_nd;
+    if (d > 3) {
+      rec_nd.resize((size_t)n_all * (d + 1));
+      for (int k = 0; k < n_all; ++k) {
+        const int i = sort_sum[k];
+        for (int c = 0; c < d; ++c) rec_nd[(size_t)k * (d + 1) + c] = call[(size_t)c * n_all + i];
+        rec_nd[(size_t)k * (d + 1) + d] = csum[i];
+      }
+      HIP_OK(hipMalloc(&d_rec_nd, sizeof(double) * rec_nd.size()));
+      HIP_OK(hipMemcpyAsync(d_rec_nd, rec_nd.data(), sizeof(double) * rec_nd.size(), hipMemcpyHostToDevice, t->stream));
+    }
     HIP_OK(hipMemcpyAsync(d_idx, sort_sum.data(), sizeof(int) * (size_t)n_all, hipMemcpyHostToDevice, t->stream));
     HIP_OK(hipMemsetAsync(t->d_flag, 0, sizeof(int), t->stream));
     HIP_OK(hipMemsetAsync(t->d_nn, 0xff, sizeof(int) * (size_t)n_all * t->m, t->stream));
     gpb::NNKernelArgs na;
     na.sorted_rec = d_rec; na.sorted_idx = d_idx; na.pts = t->d_pts; na.nn = t->d_nn; na.has_duplicates = t->d_flag; na.n = n_all; na.m = t->m;
+    na.sorted_nd = d_rec_nd; na.coords_nd = t->d_coords_nd;
     na.start_at = n_obs; na.end_search_at = cond_all ? n_all - 2 : n_obs - 1; na.pos0 = 0; na.pos1 = n_all;
     // only the appended rows are searched: their positions, grouped like the training-time search
     std::vector<int> qorder((size_t)std::max(n_pred, 1));
@@ -909,7 +941,7 @@ static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const d
     int flag = 0;
     HIP_OK(hipMemcpyAsync(&flag, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, t->stream));
     HIP_OK(hipStreamSynchronize(t->stream));
-    (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder);
+    (void)hipFree(d_rec); (void)hipFree(d_idx); (void)hipFree(d_qorder); if (d_rec_nd) (void)hipFree(d_rec_nd);
     if (has_duplicates) *has_duplicates = flag;
     t->has_nn = true;
   }

@@ -13,6 +13,8 @@ struct NNKernelArgs {
   int n, m;
   int start_at, end_search_at; // rows [start_at, n) are searched; candidates have index < i and <= end_search_at (Vecchia_utils.cpp:739-754)
   int pos0, pos1;             // positions (coordinate-sum order) this launch searches for: [pos0, pos1) -- multi-GPU: a block per rank
+  const double* sorted_nd = nullptr;   // d > 3: [n][d + 1] {x_0 .. x_{d-1}, coords_sum} in coordinate-sum order (sorted_rec unused)
+  const double* coords_nd = nullptr;   // d > 3: [n][d] coordinates in Vecchia order (head rows' duplicate check)
   const int* qorder;          // [nq] positions of the queries in the order the lanes take them (nn_query_order), or nullptr: pos0 + lane id
   int nq;
 };

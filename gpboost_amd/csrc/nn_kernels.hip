@@ -117,6 +117,72 @@ __global__ __launch_bounds__(64) void vecchia_nn_kernel(NNKernelArgs a) {
   if (dup) atomicOr(a.has_duplicates, 1);
 }
 
+// ---- coordinate dimensions 4 .. 10 (generality path): the same search with records {x_0 .. x_{D-1}, sum} of D + 1 doubles ----------
+template <int D>
+__global__ __launch_bounds__(64) void vecchia_nn_nd_kernel(NNKernelArgs a) {
+  extern __shared__ unsigned char smem[];
+  const int m = a.m;
+  double* s_sq = reinterpret_cast<double*>(smem);              // [m][64]
+  int* s_id = reinterpret_cast<int*>(smem + (size_t)m * 64 * 8);  // [m][64]
+  const int lane = threadIdx.x;
+  const int qid = blockIdx.x * 64 + lane;
+  if (qid >= a.nq) return;
+  const int pos = a.qorder ? a.qorder[qid] : a.pos0 + qid;
+  const int i = a.sorted_idx[pos];
+  if (i <= m || i < a.start_at) return;
+  constexpr int RS = D + 1;
+  double q[RS];
+#pragma unroll
+  for (int c = 0; c < RS; ++c) q[c] = a.sorted_nd[(size_t)pos * RS + c];
+  const int n = a.n;
+  const int end_search_at = a.end_search_at;
+  const double dd = (double)D;
+  for (int j = 0; j < m; ++j) s_sq[j * 64 + lane] = INFINITY;
+  double worst = INFINITY;
+  bool down = true, up = true;
+  int up_i = pos, down_i = pos;
+  auto visit = [&](int p, bool& dir) {
+    const int c = a.sorted_idx[p];
+    if (c < i && c <= end_search_at) {
+      const double* r = a.sorted_nd + (size_t)p * RS;
+      const double ds = r[D] - q[D];
+      const double smd = ds * ds;
+      if (smd > dd * worst) {
+        dir = false;
+      } else {
+        const double d0 = r[0] - q[0];
+        double sed = d0 * d0;                                   // sequential left-to-right sum (Vecchia_utils.cpp:1064)
+#pragma unroll
+        for (int t = 1; t < D; ++t) { const double dt = r[t] - q[t]; sed = sed + dt * dt; }
+        if (sed < worst) {
+          int k = m - 1;
+          while (k > 0 && sed < s_sq[(k - 1) * 64 + lane]) {
+            s_sq[k * 64 + lane] = s_sq[(k - 1) * 64 + lane];
+            s_id[k * 64 + lane] = s_id[(k - 1) * 64 + lane];
+            --k;
+          }
+          s_sq[k * 64 + lane] = sed;
+          s_id[k * 64 + lane] = c;
+          worst = s_sq[(m - 1) * 64 + lane];
+        }
+      }
+    }
+  };
+  while (up || down) {
+    if (down_i == 0) down = false;
+    if (up_i == n - 1) up = false;
+    if (down) { --down_i; visit(down_i, down); }
+    if (up) { ++up_i; visit(up_i, up); }
+  }
+  int* out = a.nn + (size_t)i * m;
+  bool dup = false;
+  for (int j = 0; j < m; ++j) {
+    out[j] = s_id[j * 64 + lane];
+    if (sqrt(s_sq[j * 64 + lane]) < 1e-10) dup = true;
+  }
+  if (dup) atomicOr(a.has_duplicates, 1);
+}
+
 // rows 0..m: neighbours are all predecessors in index order, -1 padded (:788-813)
 __global__ void vecchia_nn_head_kernel(NNKernelArgs a, int d) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,10 +193,16 @@ __global__ void vecchia_nn_head_kernel(NNKernelArgs a, int d) {
   if (i < a.start_at) return;
   a.nn[(size_t)i * m + j] = (j < i) ? j : -1;
   if (j < i) {                                                  // duplicate check of :799-811
-    const double4 p = a.pts[j], q = a.pts[i];
-    double s = (p.x - q.x) * (p.x - q.x);
-    if (d >= 2) s = s + (p.y - q.y) * (p.y - q.y);
-    if (d >= 3) s = s + (p.z - q.z) * (p.z - q.z);
+    double s;
+    if (d > 3) {
+      s = 0.0;
+      for (int c = 0; c < d; ++c) { const double t = a.coords_nd[(size_t)j * d + c] - a.coords_nd[(size_t)i * d + c]; s = s + t * t; }
+    } else {
+      const double4 p = a.pts[j], q = a.pts[i];
+      s = (p.x - q.x) * (p.x - q.x);
+      if (d >= 2) s = s + (p.y - q.y) * (p.y - q.y);
+      if (d >= 3) s = s + (p.z - q.z) * (p.z - q.z);
+    }
     if (sqrt(s) < 1e-10) atomicOr(a.has_duplicates, 1);
   }
 }
@@ -154,18 +226,29 @@ hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a_in, hipStream_t st) {
   const size_t shmem = (size_t)m * 64 * 12;
   const int nblocks = ((a.qorder ? a.nq : a.pos1 - a.pos0) + 63) / 64;
   if (nblocks <= 0) return hipGetLastError();
-  if (shmem > 64 * 1024) {      // m > 85: the per-lane top-m lists need more than the default 64 KB of dynamic LDS
+  if (shmem > 64 * 1024 && d <= 3) {      // m > 85: the per-lane top-m lists need more than the default 64 KB of dynamic LDS
     const void* kf = d == 1 ? reinterpret_cast<const void*>(vecchia_nn_kernel<1>) : (d == 2 ? reinterpret_cast<const void*>(vecchia_nn_kernel<2>)
                                                                                             : reinterpret_cast<const void*>(vecchia_nn_kernel<3>));
     const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
   }
+#define GPB_NN_ND(D_)                                                                                                   \
+  case D_: {                                                                                                          \
+    if (a.sorted_nd == nullptr || a.coords_nd == nullptr) return hipErrorInvalidValue;                               \
+    if (shmem > 64 * 1024) {                                                                                          \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vecchia_nn_nd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return e;                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(vecchia_nn_nd_kernel<D_>, dim3(nblocks), dim3(64), shmem, st, a);                             \
+  } break
   switch (d) {
     case 1: hipLaunchKernelGGL(vecchia_nn_kernel<1>, dim3(nblocks), dim3(64), shmem, st, a); break;
     case 2: hipLaunchKernelGGL(vecchia_nn_kernel<2>, dim3(nblocks), dim3(64), shmem, st, a); break;
     case 3: hipLaunchKernelGGL(vecchia_nn_kernel<3>, dim3(nblocks), dim3(64), shmem, st, a); break;
+    GPB_NN_ND(4); GPB_NN_ND(5); GPB_NN_ND(6); GPB_NN_ND(7); GPB_NN_ND(8); GPB_NN_ND(9); GPB_NN_ND(10);
     default: return hipErrorInvalidValue;
   }
+#undef GPB_NN_ND
   return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
 //     substitutions (A_i = C^-1 c, b_i = C^-1 y_nn); MODE_GRAD evaluates d/dlog(a) of every entry again for the contraction
 //     sum dK_rc A~_r A~_c (the derivation is the one of vecchia_kernels.hip).
 // It is the generality path (barrier-bound, one workgroup per CU at m = 126), not the fast one: the metric configurations (m = 30, 40)
-// never reach it.
+// never reach it.  It also serves coordinate dimensions 4 .. GPB_MAX_DIM (DK = 0: coordinates from a separate [n][dim] array).
 #include "dev_common.h"
 #include "vecchia_kernels.h"
 
@@ -30,11 +30,12 @@ __device__ __forceinline__ double block_sum128(double v, double* s_red, int tid)
 }
 }  // namespace
 
-template <int COV, bool D3, int MODE>
+template <int COV, int DK, int MODE>
 __global__ __launch_bounds__(kBigThreads) void vecchia_point_big_kernel(VecchiaKernelArgs args, int ld) {
+  constexpr int NC = DK == 0 ? GPB_MAX_DIM : DK;         // coordinates kept per row
   extern __shared__ double s_C[];                       // [m][ld] lower triangle of C_nn, then its Cholesky factor
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
-  __shared__ double s_x[kBigThreads], s_y[kBigThreads], s_z[kBigThreads], s_w[kBigThreads];   // scaled, centred coordinates + response of row r
+  __shared__ double s_co[NC][kBigThreads], s_w[kBigThreads];   // scaled, centred coordinates + response of row r
   __shared__ double s_c[kBigThreads], s_z1[kBigThreads], s_z2[kBigThreads], s_red[kBigThreads];
   constexpr int NP = (MODE == MODE_GRAD) ? GPB_NUM_PARTIALS : 3;
   const int tid = threadIdx.x;
@@ -45,25 +46,40 @@ __global__ __launch_bounds__(kBigThreads) void vecchia_point_big_kernel(VecchiaK
   const int k = __syncthreads_count(idx >= 0);          // the valid neighbours are a prefix of the row (short rows: i < m)
   const double sc = args.a * kCoordScale;
   const double4 ctr = args.pts[i];
-  double ox = 0.0, oy = 0.0, oz = 0.0, ow = 0.0;
+  const int dim = DK == 0 ? args.dim : DK;
+  double oc[NC], ow = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) oc[c] = 0.0;
   if (tid < k) {
     const double4 q = args.pts[idx];
-    ox = (q.x - ctr.x) * sc; oy = (q.y - ctr.y) * sc; oz = D3 ? (q.z - ctr.z) * sc : 0.0; ow = q.w;
+    ow = q.w;
+    if constexpr (DK == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (c < dim) oc[c] = (args.coords_nd[(size_t)idx * dim + c] - args.coords_nd[(size_t)i * dim + c]) * sc;
+    } else {
+      oc[0] = (q.x - ctr.x) * sc; oc[1] = (q.y - ctr.y) * sc;
+      if constexpr (DK == 3) oc[2] = (q.z - ctr.z) * sc;
+    }
   }
-  s_x[tid] = ox; s_y[tid] = oy; s_z[tid] = oz; s_w[tid] = ow;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s_co[c][tid] = oc[c];
+  s_w[tid] = ow;
   __syncthreads();
-  auto d2 = [&](double ax, double ay, double az, double bx, double by, double bz) {
-    const double dx = ax - bx, dy = ay - by;
-    double v = __builtin_fma(dx, dx, 1e-300);
-    v = __builtin_fma(dy, dy, v);
-    if constexpr (D3) { const double dz = az - bz; v = __builtin_fma(dz, dz, v); }
+  // squared scaled distance of this lane's row to row q (q < 0: to the point itself, the origin of the centred coordinates)
+  auto d2 = [&](int q) {
+    double v = 1e-300;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double dx = oc[c] - (q >= 0 ? s_co[c][q] : 0.0);
+      v = __builtin_fma(dx, dx, v);             // (unused coordinates are zero on both sides)
+    }
     return v;
   };
   // ---- C_nn (lower), c ------------------------------------------------------------------------------------------
   if (tid < k) {
-    for (int q = 0; q < tid; ++q) s_C[tid * ld + q] = matern_cov_s<COV>(d2(ox, oy, oz, s_x[q], s_y[q], s_z[q]), s_tab);
+    for (int q = 0; q < tid; ++q) s_C[tid * ld + q] = matern_cov_s<COV>(d2(q), s_tab);
     s_C[tid * ld + tid] = args.diag_nn;
-    s_c[tid] = matern_cov_s<COV>(d2(ox, oy, oz, 0.0, 0.0, 0.0), s_tab);
+    s_c[tid] = matern_cov_s<COV>(d2(-1), s_tab);
   }
   s_z1[tid] = tid < k ? s_c[tid] : 0.0;
   s_z2[tid] = tid < k ? ow : 0.0;
@@ -127,12 +143,12 @@ __global__ __launch_bounds__(kBigThreads) void vecchia_point_big_kernel(VecchiaK
         const double Ar = s_z1[tid], br = s_z2[tid];
         aa = Ar * Ar; ba = br * Ar;
         for (int q = 0; q < tid; ++q) {
-          const double dk = matern_dlog_range_s<COV>(d2(ox, oy, oz, s_x[q], s_y[q], s_z[q]), s_tab);
+          const double dk = matern_dlog_range_s<COV>(d2(q), s_tab);
           const double Ac = s_z1[q], bc = s_z2[q];
           accD = __builtin_fma(dk * Ar, Ac, accD);
           accU = __builtin_fma(dk, __builtin_fma(br, Ac, bc * Ar), accU);
         }
-        const double dkp = matern_dlog_range_s<COV>(d2(ox, oy, oz, 0.0, 0.0, 0.0), s_tab);
+        const double dkp = matern_dlog_range_s<COV>(d2(-1), s_tab);
         accD = __builtin_fma(-dkp, Ar, accD);
         accU = __builtin_fma(-dkp, br, accU);
       }
@@ -159,11 +175,11 @@ __global__ __launch_bounds__(kBigThreads) void vecchia_point_big_kernel(VecchiaK
   }
 }
 
-template <int COV, bool D3>
+template <int COV, int DK>
 static hipError_t launch_big_mode(int mode, const VecchiaKernelArgs& args, int npts, int ld, size_t lds, hipStream_t st) {
 #define GPB_BIG_LAUNCH(MODE_)                                                                                                     \
   do {                                                                                                                              \
-    auto kern = vecchia_point_big_kernel<COV, D3, MODE_>;                                                                         \
+    auto kern = vecchia_point_big_kernel<COV, DK, MODE_>;                                                                         \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e_ != hipSuccess) return e_;                                                                                                \
     hipLaunchKernelGGL(kern, dim3(npts), dim3(kBigThreads), lds, st, args, ld);                                                   \
@@ -177,17 +193,22 @@ static hipError_t launch_big_mode(int mode, const VecchiaKernelArgs& args, int n
 }
 
 // one workgroup (and one row of partial sums) per point: the caller sizes `partials` for (i_end - i_begin) blocks
-hipError_t launch_vecchia_point_big(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st) {
+hipError_t launch_vecchia_point_big(int mode, int cov, int dk, const VecchiaKernelArgs& args, hipStream_t st) {
   const int npts = args.i_end - args.i_begin;
   if (npts <= 0 || args.m < 1 || args.m > GPB_MAX_NEIGHBORS_BIG) return hipErrorInvalidValue;
+  if (dk == 0 && (args.coords_nd == nullptr || args.dim < 1 || args.dim > GPB_MAX_DIM)) return hipErrorInvalidValue;
   const int ld = args.m | 1;
   const size_t lds = sizeof(double) * (size_t)args.m * ld;
+#define GPB_BIG_COV(COV_)                                                                  \
+  (dk == 3 ? launch_big_mode<COV_, 3>(mode, args, npts, ld, lds, st)                      \
+           : (dk == 0 ? launch_big_mode<COV_, 0>(mode, args, npts, ld, lds, st) : launch_big_mode<COV_, 2>(mode, args, npts, ld, lds, st)))
   switch (cov) {
-    case kMatern05: return d3 ? launch_big_mode<kMatern05, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern05, false>(mode, args, npts, ld, lds, st);
-    case kMatern15: return d3 ? launch_big_mode<kMatern15, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern15, false>(mode, args, npts, ld, lds, st);
-    case kMatern25: return d3 ? launch_big_mode<kMatern25, true>(mode, args, npts, ld, lds, st) : launch_big_mode<kMatern25, false>(mode, args, npts, ld, lds, st);
+    case kMatern05: return GPB_BIG_COV(kMatern05);
+    case kMatern15: return GPB_BIG_COV(kMatern15);
+    case kMatern25: return GPB_BIG_COV(kMatern25);
     default: return hipErrorInvalidValue;
   }
+#undef GPB_BIG_COV
 }
 
 }  // namespace gpb

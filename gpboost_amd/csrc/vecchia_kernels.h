@@ -44,12 +44,16 @@ struct VecchiaKernelArgs {
   double diag_nn;          // diagonal of C_nn:   Gaussian var + 1;          else var * (1 + 1e-10)
   double diag_i;           // first summand of D: Gaussian var + 1;          else var
   double nugget;           // Gaussian 1, else 0
+  const double* coords_nd = nullptr;   // d > 3 (generality path): [n][dim] coordinates in Vecchia order; pts then only carries the response (w)
+  int dim = 0;
 };
+#define GPB_MAX_DIM 10
 
 int vecchia_padded_m(int m);
 hipError_t launch_vecchia_point_kernel(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
 // m > GPB_MAX_NEIGHBORS: one workgroup and one row of `partials` per point (vecchia_big_kernels.hip)
-hipError_t launch_vecchia_point_big(int mode, int cov, bool d3, const VecchiaKernelArgs& args, hipStream_t st);
+// (dk = 2: d <= 2, 3: d = 3 -- coordinates from the point records; 0: 3 < d <= GPB_MAX_DIM -- coordinates from args.coords_nd)
+hipError_t launch_vecchia_point_big(int mode, int cov, int dk, const VecchiaKernelArgs& args, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterms, double* out, double* out_user,
                                   hipStream_t st, double* out_host = nullptr);
 hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_t st);

@@ -23,7 +23,10 @@ def main():
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = [a for a in sys.argv[2:]] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None      # `cases <name> ...`: only these fixtures
     for name, c in cases.GOLDEN_CASES.items():
+        if only is not None and name not in only:
+            continue
         coords, y = cases.make_data(c)
         mdl = refdrv.RefModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
         perm = mdl.perm()
@@ -47,6 +50,8 @@ def main():
                 res["A_%d" % k] = A[res["A_rows_%d" % k]]
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
         print("wrote", name, "n=%d m=%d" % (mdl.n, mdl.m), "nll0=%.10f" % res["nll_0"])
+    if only is not None:
+        return
     hist_fixture(out_dir)
     laplace_fixture(out_dir)
     cluster_fixture(out_dir)

@@ -29,6 +29,13 @@ GOLDEN_CASES = {
                                ordering="random", seed=5, cov_pars=[(0.3, 1.0, 0.2)]),
     "tiny_n8_m30": dict(data="uniform", n=8, d=2, seed_data=16, cov_function="exponential", shape=0.5, m=30,
                         ordering="none", seed=0, cov_pars=[(0.1, 1.0, 0.3)]),
+    # coordinate dimensions beyond 3 (the generality path: d-dimensional neighbour search + the LDS-resident point kernel)
+    "u5d_n700_mat15_m20": dict(data="uniform", n=700, d=5, seed_data=31, cov_function="matern", shape=1.5, m=20,
+                               ordering="random", seed=4, cov_pars=[(0.2, 1.1, 0.4)]),
+    "u4d_n1500_exp_m30": dict(data="uniform", n=1500, d=4, seed_data=32, cov_function="exponential", shape=0.5, m=30,
+                              ordering="random", seed=2, cov_pars=[(0.1, 1.0, 0.3)]),
+    "u10d_n400_mat25_m70": dict(data="uniform", n=400, d=10, seed_data=33, cov_function="matern", shape=2.5, m=70,
+                                ordering="none", seed=0, cov_pars=[(0.3, 0.8, 1.5)]),
 }
 
 
@@ -200,6 +207,7 @@ OPTIM_CASES = {
     "u2d_n3000_lbfgs": dict(model="u2d_n3000_exp_m30", init=None, cpu=True, cfg=dict()),          # n > 1000: sub-sampled FindInitCovPar
     "u3d_n3000_mat25_gd": dict(model="u3d_n3000_mat25_m40", init=None, cpu=False, cfg=dict(R_GD)),
     "clusters_lbfgs": dict(model="clusters", init=None, cpu=False, cfg=dict()),
+    "u5d_n700_mat15_lbfgs": dict(model="u5d_n700_mat15_m20", init=None, cpu=True, cfg=dict()),       # d = 5: the generality path end to end
 }
 
 

@@ -228,8 +228,8 @@ def test_errors_are_loud(gpb):
     with pytest.raises(gpb.GPBoostError):
         gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=200)   # > 126
     with pytest.raises(gpb.GPBoostError):
-        gpb.GPModel(gp_coords=np.random.default_rng(0).uniform(size=(100, 4)), cov_function="exponential",
-                    gp_approx="vecchia", num_neighbors=10)                                            # d > 3
+        gpb.GPModel(gp_coords=np.random.default_rng(0).uniform(size=(100, 11)), cov_function="exponential",
+                    gp_approx="vecchia", num_neighbors=10)                                            # d > 10
     st = shim.VecchiaState(coords, 10)
     with pytest.raises(gpb.GPBoostError):
         st.nll_terms(0, 1.0, 1.0)        # neighbours not set
@@ -457,7 +457,8 @@ def test_prediction_r_suite_golden_values(gpb):
     np.testing.assert_allclose(pred["var"] - lat["var"], R_PRED_COV_PARS[0], rtol=1e-10)
 
 
-@pytest.mark.parametrize("n,npred,d,m,ct,ordering", [(20000, 5000, 2, 30, 0, "random"), (3000, 700, 3, 15, 2, "random"), (500, 33, 1, 10, 1, "none")])
+@pytest.mark.parametrize("n,npred,d,m,ct,ordering", [(20000, 5000, 2, 30, 0, "random"), (3000, 700, 3, 15, 2, "random"), (500, 33, 1, 10, 1, "none"),
+                                                     (1200, 150, 5, 20, 1, "random"), (300, 40, 10, 70, 0, "none")])      # d > 3: the generality path
 def test_prediction_against_oracle(gpb, orc, n, npred, d, m, ct, ordering):
     cf, sh = {0: ("exponential", 0.5), 1: ("matern", 1.5), 2: ("matern", 2.5)}[ct]
     coords, y = cases.synthetic(n, d, seed=31 + n)
@@ -478,6 +479,22 @@ def test_prediction_against_oracle(gpb, orc, n, npred, d, m, ct, ordering):
     mu2, Dp, dup = st.predict_obs_only(cpred, m, ct, cp[1] / cp[0], {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[2])
     assert dup                                               # the three coinciding points
     np.testing.assert_allclose(mu2, mu, rtol=1e-8, atol=1e-10)
+
+
+def test_dimension_limits_fail_loudly(gpb):
+    """d = 4 .. 10 runs (Gaussian Vecchia: search, likelihood, gradient, fit, prediction -- the fixtures above); what does not is rejected by name."""
+    rng = np.random.default_rng(5)
+    with pytest.raises(gpb.GPBoostError, match="coordinate dimension 11"):
+        gpb.GPModel(gp_coords=rng.uniform(size=(50, 11)), cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
+    c5 = rng.uniform(size=(400, 5)); yb = (rng.uniform(size=400) < 0.5).astype(np.float64)
+    mb = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=c5, cov_function="exponential", gp_approx="vecchia", num_neighbors=15, seed=1)
+    assert np.isfinite(mb.neg_log_likelihood(np.array([1.0, 0.5]), yb))       # the Laplace value needs only the factor: any d
+    with pytest.raises(gpb.GPBoostError, match="coordinate dimensions 1..3"):
+        mb.fit(yb)                                                             # its gradient uses the per-point derivative kernel
+    mg = gpb.GPModel(gp_coords=c5, cov_function="exponential", gp_approx="vecchia", num_neighbors=15, seed=1)
+    mg.fit(rng.standard_normal(400))
+    with pytest.raises(gpb.GPBoostError, match="coordinate dimensions 1..3"):
+        mg.get_cov_pars(std_err=True)
 
 
 # ---- several clusters (independent realisations of the GP, cluster_ids) -------------------------------------------------------
