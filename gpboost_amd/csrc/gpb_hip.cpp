@@ -1275,6 +1275,11 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   const int chunk_mult = h->has_hess ? 2 : 4;          // with hessians the workgroup holds two 32 KB arrays: two per CU
   int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, chunk_mult * h->num_cu / groups)));
   if (nchunks >= 16) nchunks &= ~7;                 // multiples of 8: the XCD-aware workgroup order of hist_build_kernel
+  // whole rows per lane (hist_build_rows_kernel: 128 KB of LDS, one workgroup of 512 lanes per CU and quad of feature groups) when the
+  // hessian is constant, there are at least four feature groups and every CU gets a workgroup with >= 4096 rows
+  const int quads = (groups + 3) / 4;
+  const bool rows_kernel = !h->has_hess && groups >= 4 && (long long)num_data * quads >= 4096LL * h->num_cu;
+  if (rows_kernel) nchunks = std::max(1, h->num_cu / quads);
   const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
   if (nchunks < 16 && rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
   if (nchunks < 1) nchunks = 1;
@@ -1292,6 +1297,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   a.part_grad = h->d_part_grad; a.part_hess = h->d_part_hess; a.part_cnt = h->d_part_cnt;
   a.grad_max_bits = h->d_absmax; a.hess_max_bits = h->d_absmax + 1;
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks; a.num_features = h->F;
+  a.use_rows_kernel = rows_kernel ? 1 : 0;
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
   r.grad_max_bits = h->d_absmax; r.hess_max_bits = h->d_absmax + 1;

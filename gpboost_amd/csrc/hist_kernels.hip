@@ -207,6 +207,91 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
   }
 }
 
+// ---- whole rows per lane (constant hessian, four feature groups = 64 features per workgroup) -----------------------------------
+// hist_build_kernel keeps three units near 35 % each at n = 1e7 (VALU issue, LDS atomics, L1 tag lookups: profiles/r02_i_hist_*), because
+// every workgroup repeats the per-row work -- row index, gradient load and conversion, one 64-byte-line request per 16 features -- for
+// its 16 features only.  Here a lane takes a row's whole 64 bytes (four feature groups) and issues its 64 atomics into four 32 KB
+// sub-histogram blocks (128 KB of LDS: one workgroup of 512 lanes per CU): the per-row work is paid once per 64 features, what remains
+// is the LDS atomic rate.  Same words, same drains (every 3 iterations = 1536 rows <= 1792), same partial layout as hist_build_kernel.
+template <bool HAS_IDX>
+__global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
+  constexpr int THREADS = 512, NB = 4,      // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower) kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
+  extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features]
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, quad = blockIdx.y, groups = a.fpad / GPB_HIST_FG;
+  for (int t = tid; t < NB * kWords; t += THREADS) s_rows[t] = 0ull;
+  const double inv_q = fixed_point_inv_q<false>(a.grad_max_bits);
+  long long rk[kOwn];
+  unsigned rc[kOwn];
+#pragma unroll
+  for (int i = 0; i < kOwn; ++i) { rk[i] = 0; rc[i] = 0u; }
+  auto flush = [&]() {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+      const unsigned long long v = __hip_atomic_exchange(&s_rows[i * THREADS + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const long long sum = (long long)(v << (64 - kSumBits)) >> (64 - kSumBits);
+      rk[i] += sum;
+      rc[i] += (unsigned)((v - (unsigned long long)sum) >> kSumBits);
+    }
+    __syncthreads();
+  };
+  __syncthreads();
+  const int r0 = chunk * a.rows_per_chunk;
+  const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
+  const uint8_t* base = a.bins_rm + (size_t)quad * NB * GPB_HIST_FG;
+  struct RowData { uint4 bv[NB]; double g; };
+  auto fetch = [&](int r) -> RowData {
+    RowData d;
+    const int row = HAS_IDX ? a.data_indices[r] : r;
+    const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)row * a.fpad);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) d.bv[b] = p[b];
+    d.g = a.grad[row];
+    return d;
+  };
+  const unsigned wr = (unsigned)(tid >> 2) & 3u, sh = (unsigned)(tid & 3), l15 = (unsigned)tid & 15u;
+  auto accumulate = [&](const RowData& cur) {
+    const unsigned long long add_g = fixed_point_bits(cur.g, inv_q) + (1ull << kSumBits);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      unsigned w0 = cur.bv[b].x, w1 = cur.bv[b].y, w2 = cur.bv[b].z, w3 = cur.bv[b].w, t0, t1, t2, t3;
+      t0 = (wr & 1u) ? w1 : w0; t1 = (wr & 1u) ? w2 : w1; t2 = (wr & 1u) ? w3 : w2; t3 = (wr & 1u) ? w0 : w3;
+      w0 = (wr & 2u) ? t2 : t0; w1 = (wr & 2u) ? t3 : t1; w2 = (wr & 2u) ? t0 : t2; w3 = (wr & 2u) ? t1 : t3;
+      const unsigned rw[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                              __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w0, w3, sh)};
+#pragma unroll
+      for (int s = 0; s < GPB_HIST_FG; ++s) {
+        const unsigned bin = (rw[s >> 2] >> (8 * (s & 3))) & 0xffu;
+        atomicAdd(&s_rows[b * kWords + bin * GPB_HIST_FG + ((s + l15) & 15u)], add_g);
+      }
+    }
+  };
+  const int nrows = max(r1 - r0, 0), nfull = nrows / THREADS;
+  if (nrows > 0) {
+    int since_flush = 0;
+    RowData cur = fetch(min(r0 + tid, r1 - 1));
+    for (int it = 0; it < nfull; ++it) {
+      const RowData nxt = fetch(min(r0 + (it + 1) * THREADS + tid, r1 - 1));
+      accumulate(cur);
+      cur = nxt;
+      if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
+    }
+    if (r0 + nfull * THREADS + tid < r1) accumulate(cur);
+  }
+  flush();
+  // word w of block b -> partial (chunk, group 4 quad + b, word w): the layout of hist_build_kernel's partials
+#pragma unroll
+  for (int i = 0; i < kOwn; ++i) {
+    const int w = i * THREADS + tid, b = w / kWords, ww = w - b * kWords;
+    if (quad * NB + b < groups) {
+      const size_t o = ((size_t)chunk * groups + quad * NB + b) * kWords + ww;
+      a.part_grad[o] = rk[i];
+      a.part_cnt[o] = rc[i];
+    }
+  }
+}
+
 // Sum of the chunk partials -- integers, so the total is exact and independent of the chunking.  A workgroup owns 64 consecutive words
 // (4 bins x 16 features) of one feature group; its 16 slices of 64 lanes take the chunks ch = slice, slice + 16, ... (coalesced 512-byte
 // segments, 4 loads in flight per lane).  A 64-bit partial is at most 2^41 * rows-per-chunk; the total over all chunks may pass 2^63,
@@ -335,6 +420,21 @@ static void launch_hist_build_t(const HistKernelArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((hist_build_kernel<false, false, THREADS>), grid, block, 0, st, a);
 }
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
+  // constant hessian, at least four feature groups, enough rows to fill the CUs one workgroup each: whole rows per lane
+  if (a.use_rows_kernel) {
+    constexpr int lds = 4 * GPB_HIST_MAX_BIN * GPB_HIST_FG * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_build_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_build_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    const dim3 grid(a.nchunks, (a.fpad / GPB_HIST_FG + 3) / 4);
+    if (a.data_indices) hipLaunchKernelGGL(hist_build_rows_kernel<true>, grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(hist_build_rows_kernel<false>, grid, dim3(512), lds, st, a);
+    return hipGetLastError();
+  }
   // 256 threads: 512 and 1024 (twice / four times the wavefronts on the same 32 KB of LDS) time the same within 2 % at n = 1e7
   launch_hist_build_t<256>(a, st);
   return hipGetLastError();
