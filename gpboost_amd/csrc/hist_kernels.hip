@@ -215,7 +215,8 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // is the LDS atomic rate.  Same words, same drains (every 3 iterations = 1536 rows <= 1792), same partial layout as hist_build_kernel.
 template <bool HAS_IDX>
 __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
-  constexpr int THREADS = 512, NB = 4,      // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower) kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
+  // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
+  constexpr int THREADS = 512, NB = 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
   extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features]
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, quad = blockIdx.y, groups = a.fpad / GPB_HIST_FG;
