@@ -320,12 +320,12 @@ def main():
                 ms_h = hb.bench(None, 1.0, 10)
                 hbytes = nh * (Fh + 8 + 4) + Fh * nbh * 16
                 out["roofline_histogram"] = {
-                    "bound": "hbm", "kernel": "hist_build_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
+                    "bound": "hbm", "kernel": "hist_build_rows_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
-                    "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_kernel<false, false"),
+                    "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_rows_kernel<false>"),
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
-                    "note": "fixed-point sums (one 64-bit LDS atomic per row and feature, count packed in, bank-conflict-free layout): "
-                            "bit-reproducible, counts exact; see DESIGN.md 4.4"}
+                    "note": "fixed-point sums (one 64-bit LDS atomic per row and feature, count packed in, bank-conflict-free layout, a whole "
+                            "64-byte row per lane): bit-reproducible, counts exact; see DESIGN.md 4.4"}
                 hb.close()
             except Exception as e:
                 out["roofline_histogram"] = {"error": "%s: %s" % (type(e).__name__, e)}
