@@ -150,6 +150,7 @@ struct gpb_hip_hist {
   int* d_rows = nullptr; double* d_split2 = nullptr; int* d_split2_i = nullptr; signed char* d_used2 = nullptr;
   double* h_split2 = nullptr; int* h_split2_i = nullptr;
   double* d_tree_red = nullptr;                            // 4 doubles: root sums / left count of the data-parallel tree grower
+  std::vector<double> tree_node_info;                      // last tree of gpb_hip_hist_grow_tree: per node {left / right output, count, sum of hessians}
 };
 
 extern "C" {

@@ -365,6 +365,10 @@ GPB_HIP_EXPORT int gpb_hip_hist_grow_tree(gpb_hip_hist_t* h, int32_t num_leaves,
                                           uint32_t* threshold_in_bin, int32_t* default_left, int32_t* left_child, int32_t* right_child,
                                           double* split_gain, int32_t* internal_count, double* leaf_value, int32_t* leaf_count,
                                           int32_t* data_leaf_index);
+/* Per node of the LAST tree grown on the handle: {left output, right output, left count, right count, left sum of hessians, right sum of
+ * hessians} -- what Tree::Split (include/LightGBM/tree.h:63-66) takes next to the arrays above (integration/hip_tree_learner.h builds the
+ * reference's own Tree object from them).  out6: 6 x num_nodes doubles. */
+GPB_HIP_EXPORT int gpb_hip_hist_last_tree_node_info(gpb_hip_hist_t* h, int32_t num_nodes, double* out6);
 GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out);
 
 /* Split search on a device-resident (fixed) leaf histogram -- SURVEY.md 8f rank 2: FeatureHistogram::FindBestThreshold for every

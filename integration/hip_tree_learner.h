@@ -9,6 +9,12 @@
  * reference is built with -DUSE_HIP_GP; Config::CheckParamConflict already forces col-wise (dense) bins for that device type
  * (config.cpp:349-355).  Feature groups are dense uint8 columns here (one feature or an EFB bundle, <= 256 bins); a data set with a
  * multi-value / sparse group keeps the reference's CPU histograms (never a silent wrong answer).
+ *
+ * Whole trees: when the configuration is the one gpb_hip_hist_grow_tree restates (numerical features in single-feature groups, default
+ * regularisation path, no depth limit / bagging / column sampling / forced splits / constraints), Train() hands the whole leaf-wise
+ * growth to the device (row lists resident, one synchronisation per split) and rebuilds the reference's own Tree object and
+ * DataPartition from the returned arrays -- GBDT (shrinkage, score update, the GPBoost leaf update) carries on unchanged.  Anything
+ * else: SerialTreeLearner::Train with the device histograms above.
  */
 #ifndef LIGHTGBM_TREELEARNER_HIP_TREE_LEARNER_H_
 #define LIGHTGBM_TREELEARNER_HIP_TREE_LEARNER_H_
@@ -20,6 +26,7 @@
 
 #include <gpb_hip.h>
 
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -40,6 +47,45 @@ class HIPTreeLearner : public SerialTreeLearner {
   void ResetTrainingDataInner(const Dataset* train_data, bool is_constant_hessian, bool reset_multi_val_bin) override {
     SerialTreeLearner::ResetTrainingDataInner(train_data, is_constant_hessian, reset_multi_val_bin);
     CreateDeviceBins();
+  }
+
+  void SetBaggingData(const Dataset* subset, const data_size_t* used_indices, data_size_t num_data) override {
+    SerialTreeLearner::SetBaggingData(subset, used_indices, num_data);
+    bagging_ = used_indices != nullptr && num_data != train_data_->num_data();
+  }
+
+  Tree* Train(const score_t* gradients, const score_t* hessians, bool is_first_tree) override {
+    if (!hist_ || !whole_tree_ok_ || bagging_ || !WholeTreeConfig()) return SerialTreeLearner::Train(gradients, hessians, is_first_tree);
+    if (!announced_) { Log::Info("HIPTreeLearner: whole trees are grown on the GPU (gpb_hip_hist_grow_tree)"); announced_ = true; }
+    gradients_ = gradients;
+    hessians_ = hessians;
+    BeforeTrain();                                   // root sums (LeafSplits::Init), data partition reset, gradient upload (override below)
+    const int L = config_->num_leaves;
+    const bool const_hess = share_state_->is_constant_hessian;
+    int32_t nl = 0;
+    std::vector<int32_t> sf(L), dl(L), lc(L), rc(L), icnt(L), lcnt(L), leaf_of_row(num_data_);
+    std::vector<uint32_t> thr(L);
+    std::vector<double> gain(L), lval(L);
+    if (gpb_hip_hist_grow_tree(hist_, L, smaller_leaf_splits_->sum_gradients(), smaller_leaf_splits_->sum_hessians(), config_->lambda_l2,
+                               config_->min_data_in_leaf, config_->min_sum_hessian_in_leaf, config_->min_gain_to_split,
+                               const_hess ? static_cast<double>(hessians_[0]) : 1.0, &nl, sf.data(), thr.data(), dl.data(), lc.data(), rc.data(),
+                               gain.data(), icnt.data(), lval.data(), lcnt.data(), leaf_of_row.data())) {
+      Log::Fatal("%s", gpb_hip_get_last_error());
+    }
+    std::vector<double> info(static_cast<size_t>(std::max(nl - 1, 1)) * 6);
+    if (nl > 1 && gpb_hip_hist_last_tree_node_info(hist_, nl - 1, info.data())) Log::Fatal("%s", gpb_hip_get_last_error());
+    auto tree = std::unique_ptr<Tree>(new Tree(L, false, false));
+    for (int k = 0; k + 1 < nl; ++k) {
+      int leaf = lc[k];                              // the split leaf kept its id on the left: the leftmost leaf below node k
+      while (leaf >= 0) leaf = lc[leaf];
+      leaf = ~leaf;
+      const int inner = sf[k];
+      tree->Split(leaf, inner, train_data_->RealFeatureIndex(inner), thr[k], train_data_->RealThreshold(inner, thr[k]), info[6 * k], info[6 * k + 1],
+                  static_cast<int>(info[6 * k + 2]), static_cast<int>(info[6 * k + 3]), info[6 * k + 4], info[6 * k + 5], static_cast<float>(gain[k]),
+                  train_data_->FeatureBinMapper(inner)->missing_type(), dl[k] != 0);
+    }
+    data_partition_->ResetByLeafPred(std::vector<int>(leaf_of_row.begin(), leaf_of_row.end()), nl);
+    return tree.release();
   }
 
  protected:
@@ -95,10 +141,36 @@ class HIPTreeLearner : public SerialTreeLearner {
     if (gpb_hip_hist_create(num_data_, num_groups, bins.data(), offsets.data(), &hist_)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
+    // whole-tree growth on the device: numerical features, one per group; their histogram views and FeatureMetainfo
+    // (HistogramPool::SetFeatureInfo, feature_histogram.hpp:1146-1182; view = one bin past the start of the group, train_share_states.cpp:296-300)
+    whole_tree_ok_ = num_groups == train_data_->num_features();
+    const int F = train_data_->num_features();
+    std::vector<int32_t> voff(F), nbin(F), mfb(F), off(F), dbin(F), miss(F);
+    for (int f = 0; f < F && whole_tree_ok_; ++f) {
+      const BinMapper* bm = train_data_->FeatureBinMapper(f);
+      if (bm->bin_type() != BinType::NumericalBin || train_data_->Feature2Group(f) != f) { whole_tree_ok_ = false; break; }
+      voff[f] = static_cast<int32_t>(train_data_->GroupBinBoundary(f)) + 1;
+      nbin[f] = bm->num_bin(); mfb[f] = static_cast<int32_t>(bm->GetMostFreqBin());
+      off[f] = mfb[f] == 0 ? 1 : 0; dbin[f] = static_cast<int32_t>(bm->GetDefaultBin()); miss[f] = static_cast<int32_t>(bm->missing_type());
+    }
+    if (whole_tree_ok_ && (gpb_hip_hist_set_fix_info(hist_, voff.data(), nbin.data(), mfb.data()) ||
+                           gpb_hip_hist_set_split_info(hist_, off.data(), dbin.data(), miss.data()) ||
+                           gpb_hip_hist_pool_resize(hist_, config_->num_leaves + 1))) {
+      Log::Fatal("%s", gpb_hip_get_last_error());
+    }
     Log::Info("HIPTreeLearner: %d feature groups x %d rows resident on the GPU (%d bins in total)", num_groups, num_data_, offsets[num_groups]);
   }
 
+  // the configuration gpb_hip_hist_grow_tree restates: default regularisation path, nothing that changes the candidate set per node
+  bool WholeTreeConfig() const {
+    return config_->num_leaves >= 2 && config_->max_depth <= 0 && config_->lambda_l1 == 0.0 && config_->max_delta_step <= 0.0 &&
+           config_->path_smooth <= 0.0 && !config_->extra_trees && !config_->linear_tree && config_->feature_fraction >= 1.0 &&
+           config_->feature_fraction_bynode >= 1.0 && config_->monotone_constraints.empty() && config_->interaction_constraints_vector.empty() &&
+           (forced_split_json_ == nullptr || forced_split_json_->is_null()) && cegb_ == nullptr && num_data_ == train_data_->num_data();
+  }
+
   gpb_hip_hist_t* hist_ = nullptr;
+  bool whole_tree_ok_ = false, bagging_ = false, announced_ = false;
 };
 
 }  // namespace LightGBM
