@@ -424,13 +424,10 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
   // constant hessian, at least four feature groups, enough rows to fill the CUs one workgroup each: whole rows per lane
   if (a.use_rows_kernel) {
     constexpr int lds = 4 * GPB_HIST_MAX_BIN * GPB_HIST_FG * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_build_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_build_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    // (per launch, not once per process: the attribute belongs to the current device)
+    const void* kf = a.data_indices ? reinterpret_cast<const void*>(hist_build_rows_kernel<true>) : reinterpret_cast<const void*>(hist_build_rows_kernel<false>);
+    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
     const dim3 grid(a.nchunks, (a.fpad / GPB_HIST_FG + 3) / 4);
     if (a.data_indices) hipLaunchKernelGGL(hist_build_rows_kernel<true>, grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL(hist_build_rows_kernel<false>, grid, dim3(512), lds, st, a);
