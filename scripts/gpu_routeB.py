@@ -3,7 +3,8 @@
 through its unchanged C API -- with the patched seams calling lib_gpboost_amd.so.
 
  (1) Gaussian Vecchia model: GPB_EvalNegLogLikelihood and GPB_OptimCovPar with GPU_use = true against GPU_use = false of the same library
-     (same process, same inputs): likelihood to 1e-8 relative, same number of optimiser iterations, estimates to 1e-6.
+     (same process, same inputs): likelihood to 1e-8 relative, same number of optimiser iterations, estimates to 1e-6, and predictions
+     after the fit (the optimiser's evaluations run fused on the device; the host factor is built once at the final parameters).
  (2) GPBoost-free LightGBM boosting: LGBM_BoosterUpdateOneIter with device_type = gpu (-> HIPTreeLearner, histograms on the device)
      against device_type = cpu: predictions after 20 iterations agree to 1e-9 -- once with whole trees grown on the device
      (HIPTreeLearner::Train -> gpb_hip_hist_grow_tree) and once with max_depth set (not restated: SerialTreeLearner::Train + device histograms)."""
@@ -40,13 +41,19 @@ for n, m in ((20000, 30), (100000, 30)):
         t0 = time.perf_counter()
         mdl.optim_cov_par(y)
         t_fit = time.perf_counter() - t0
-        res[gpu] = dict(nll=nll, cov=mdl.get_cov_par(3), it=mdl.get_num_it(), t_create=t_create, t_eval=t_eval, t_fit=t_fit)
+        # prediction after the fit: the factor / y_aux at the final parameters must be there (the optimiser's evaluations used the fused kernel)
+        mu, var = mdl.predict(np.random.default_rng(9).uniform(size=(50, 2)))
+        res[gpu] = dict(nll=nll, cov=mdl.get_cov_par(3), it=mdl.get_num_it(), t_create=t_create, t_eval=t_eval, t_fit=t_fit, mu=mu, var=var,
+                        negll_fit=mdl.current_neg_log_likelihood())
         print("n=%d GPU_use=%s: nll %.10f | fit: %d iterations, cov pars %s | create %.2f s, eval %.3f s, fit %.2f s" %
               (n, gpu, nll, res[gpu]["it"], res[gpu]["cov"], t_create, t_eval, t_fit), flush=True)
     a, b = res[False], res[True]
     assert abs(a["nll"] - b["nll"]) <= 1e-8 * abs(a["nll"]), (a["nll"], b["nll"])
     assert a["it"] == b["it"], (a["it"], b["it"])
     np.testing.assert_allclose(a["cov"], b["cov"], rtol=1e-6)
+    assert abs(a["negll_fit"] - b["negll_fit"]) <= 1e-8 * abs(a["negll_fit"])
+    np.testing.assert_allclose(b["mu"], a["mu"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(b["var"], a["var"], rtol=1e-6, atol=1e-8)
     print("n=%d: GPU_use=true reproduces the CPU path of the same build; likelihood evaluation %.1fx, fit %.1fx faster" % (n, a["t_eval"] / b["t_eval"], a["t_fit"] / b["t_fit"]), flush=True)
 
 # ---- (2) trees ------------------------------------------------------------------------------------------------------------------
