@@ -24,8 +24,8 @@ LIBP = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
 print("library:", LIBP, flush=True)
 
 # ---- (1) GP ---------------------------------------------------------------------------------------------------------------------
-for n, m in ((20000, 30), (100000, 30)):
-    coords, _ = cases.synthetic(n, 2, seed=3)
+for n, m, d in ((20000, 30, 2), (100000, 30, 2), (5000, 70, 5)):          # the last one: d = 5, m = 70 -> the library's generality kernels
+    coords, _ = cases.synthetic(n, d, seed=3)
     rng = np.random.default_rng(5)
     y = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
     cp = np.array([0.2, 0.8, 0.15])
@@ -42,7 +42,7 @@ for n, m in ((20000, 30), (100000, 30)):
         mdl.optim_cov_par(y)
         t_fit = time.perf_counter() - t0
         # prediction after the fit: the factor / y_aux at the final parameters must be there (the optimiser's evaluations used the fused kernel)
-        mu, var = mdl.predict(np.random.default_rng(9).uniform(size=(50, 2)))
+        mu, var = mdl.predict(np.random.default_rng(9).uniform(size=(50, d)))
         res[gpu] = dict(nll=nll, cov=mdl.get_cov_par(3), it=mdl.get_num_it(), t_create=t_create, t_eval=t_eval, t_fit=t_fit, mu=mu, var=var,
                         negll_fit=mdl.current_neg_log_likelihood())
         print("n=%d GPU_use=%s: nll %.10f | fit: %d iterations, cov pars %s | create %.2f s, eval %.3f s, fit %.2f s" %
