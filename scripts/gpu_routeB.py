@@ -66,36 +66,38 @@ def ok(rc):
         raise RuntimeError(L.LGBM_GetLastError().decode())
 
 
-n, F = 100000, 50
-rng = np.random.default_rng(1)
-X = np.ascontiguousarray(rng.uniform(size=(n, F)))
-yb = (np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + 0.5 * rng.standard_normal(n)).astype(np.float32)
-pred = {}
 NIT = 20
-for tag, dev, extra in (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8")):
-    ds = C.c_void_p()
-    ok(L.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
-                                   C.c_char_p(("max_bin=255 verbosity=-1 device_type=%s" % dev).encode()), C.c_void_p(), C.byref(ds)))
-    ok(L.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yb.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
-    bst = C.c_void_p()
-    params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16%s" % (dev, extra)
-    ok(L.LGBM_BoosterCreate(ds, C.c_char_p(params.encode()), C.byref(bst)))
-    fin = C.c_int(0)
-    ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))          # first iteration: allocations, uploads
-    t0 = time.perf_counter()
-    for _ in range(NIT - 1):
-        ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
-    dt = time.perf_counter() - t0
-    out = np.empty(n)
-    olen = C.c_int64(0)
-    ok(L.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(0), C.c_int(0),
-                                   C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
-    pred[tag] = out
-    print("%s (device_type=%s%s): %.2f ms per LGBM_BoosterUpdateOneIter over %d iterations; prediction[:3] = %s" % (tag, dev, extra, dt / (NIT - 1) * 1e3, NIT - 1, out[:3]), flush=True)
-    ok(L.LGBM_BoosterFree(bst)); ok(L.LGBM_DatasetFree(ds))
-# whole trees on the device (num_leaves only) and the fallback with device histograms (max_depth set) against the CPU learner of the same build
-np.testing.assert_allclose(pred["gpu"], pred["cpu"], rtol=0, atol=1e-9)
-np.testing.assert_allclose(pred["gpu_maxdepth"], pred["cpu_maxdepth"], rtol=0, atol=1e-9)
-print("trees: device_type=gpu (HIPTreeLearner: whole trees / histograms only) reproduces device_type=cpu, max |diff| = %.2e / %.2e" %
-      (np.abs(pred["gpu"] - pred["cpu"]).max(), np.abs(pred["gpu_maxdepth"] - pred["cpu_maxdepth"]).max()), flush=True)
+for n, F, variants in ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8"))),
+                       (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", "")))):
+  rng = np.random.default_rng(1)
+  X = np.ascontiguousarray(rng.uniform(size=(n, F)))
+  yb = (np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + 0.5 * rng.standard_normal(n)).astype(np.float32)
+  pred = {}
+  print("---- trees, n = %d, F = %d ----" % (n, F), flush=True)
+  for tag, dev, extra in variants:
+      ds = C.c_void_p()
+      ok(L.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
+                                     C.c_char_p(("max_bin=255 verbosity=-1 device_type=%s" % dev).encode()), C.c_void_p(), C.byref(ds)))
+      ok(L.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yb.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
+      bst = C.c_void_p()
+      params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16%s" % (dev, extra)
+      ok(L.LGBM_BoosterCreate(ds, C.c_char_p(params.encode()), C.byref(bst)))
+      fin = C.c_int(0)
+      ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))          # first iteration: allocations, uploads
+      t0 = time.perf_counter()
+      for _ in range(NIT - 1):
+          ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+      dt = time.perf_counter() - t0
+      out = np.empty(n)
+      olen = C.c_int64(0)
+      ok(L.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(0), C.c_int(0),
+                                     C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
+      pred[tag] = out
+      print("%s (device_type=%s%s): %.2f ms per LGBM_BoosterUpdateOneIter over %d iterations; prediction[:3] = %s" % (tag, dev, extra, dt / (NIT - 1) * 1e3, NIT - 1, out[:3]), flush=True)
+      ok(L.LGBM_BoosterFree(bst)); ok(L.LGBM_DatasetFree(ds))
+  # whole trees on the device (num_leaves only) and the fallback with device histograms (max_depth set) against the CPU learner of the same build
+  np.testing.assert_allclose(pred["gpu"], pred["cpu"], rtol=0, atol=1e-9)
+  if "gpu_maxdepth" in pred:
+    np.testing.assert_allclose(pred["gpu_maxdepth"], pred["cpu_maxdepth"], rtol=0, atol=1e-9)
+  print("trees (n = %d): device_type=gpu (HIPTreeLearner, whole trees) reproduces device_type=cpu, max |diff| = %.2e" % (n, np.abs(pred["gpu"] - pred["cpu"]).max()), flush=True)
 print("ROUTE B ON MI355X: OK", flush=True)
