@@ -931,6 +931,44 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !out_predict) return set_error("GPB_PredictREModel: null argument");
   const char* scope = "is not on the MI355X path of this library (prediction: one-cluster Gaussian Vecchia model, 'order_obs_first_cond_obs_only')";
+  if (mdl->likelihood != "gaussian" && !mdl->eh && mdl->vhs.size() == 1) {
+    // non-Gaussian (Vecchia-Laplace) models: the LATENT predictive mean -Bpo mode (PredictLaplaceApproxVecchia, likelihoods.h:8600-8602) with the
+    // reference's default prediction type for them, 'latent_order_obs_first_cond_obs_only'; variances (stochastic, nsim_var_pred probes) and the
+    // response mean, which needs them, are not on the path
+    const char* lscope = "is not on the MI355X path of this library (non-Gaussian likelihoods: the latent predictive mean, predict_response = false, no variances)";
+    if (predict_var || predict_cov_mat || predict_response || sample_posterior || sample_prior) return set_error("GPB_PredictREModel: variances / response predictions / samples %s", lscope);
+    if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred)
+      return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients / covariates for prediction %s", lscope);
+    const std::string& pt = mdl->vecchia_pred_type;
+    if (!pt.empty() && pt != "order_obs_first_cond_obs_only" && pt != "latent_order_obs_first_cond_obs_only")
+      return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", pt.c_str(), lscope);
+    const double* cpl = gp_coords_data_pred;
+    int npl = num_data_pred;
+    if (use_saved_data) { cpl = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npl = mdl->num_data_pred; }
+    if (!cpl || npl <= 0) return set_error("GPB_PredictREModel: no coordinates for prediction (gp_coords_data_pred / GPB_SetPredictionData)");
+    if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
+    double s12, rho;
+    if (cov_pars) { s12 = cov_pars[0]; rho = cov_pars[1]; }
+    else {
+      if (!mdl->cov_pars_initialized) return set_error("Covariance parameters have not been estimated or are not given.");
+      s12 = mdl->cov_pars_tr[0]; rho = range_const(mdl) / mdl->cov_pars_tr[1];
+    }
+    if (!(s12 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", s12, rho);
+    const double* fel = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
+    if (y_data) { if (laplace_upload_data(mdl, y_data, fel)) return -1; }
+    else if (laplace_upload_fixed_effects(mdl, fel)) return -1;
+    const double a_tr = range_const(mdl) / rho;
+    std::vector<double> mode(mdl->n);
+    if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, s12, a_tr, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, mdl->cg_max_num_it,
+                                      mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding, 1, mdl->lap_info, mode.data()))
+      return shim_error();
+    if (gpb_hip_vecchia_set_y(mdl->vh, mode.data())) return shim_error();          // the "response" of the prediction is the mode (Vecchia order)
+    const int nnpl = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;     // re_model_template.h:299
+    if (gpb_hip_vecchia_predict_latent_obs_only(mdl->vh, npl, cpl, std::min(nnpl, 126), mdl->cov_type, s12, a_tr, out_predict, nullptr))
+      return shim_error();
+    if (fixed_effects_pred) for (int k = 0; k < npl; ++k) out_predict[k] += fixed_effects_pred[k];
+    return 0;
+  }
   if (mdl->likelihood != "gaussian" || mdl->eh || mdl->vhs.size() != 1) return set_error("GPB_PredictREModel: this model %s", scope);
   if (sample_posterior || sample_prior) return set_error("GPB_PredictREModel: posterior / prior samples %s", scope);
   if (predict_cov_mat && predict_var) return set_error("Calculation of both the predictive covariance matrix and variances is not supported. Choose one option (predict_cov_mat or predict_var)");   // re_model.cpp Predict

@@ -872,7 +872,8 @@ int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double* w_dev) {
 // only (find_nearest_neighbors_Vecchia_fast with start_at = n_obs and end_search_at = n_obs - 1 [cond_obs_only] or -1 [cond_all],
 // Vecchia_utils.cpp:1792-1822), MODE_FACTOR over the appended rows.  *out_t owns the state (caller frees), *out_m = neighbours used.
 static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
-                                   bool cond_all, int cov_type, double var, double a, gpb_hip_vecchia_t** out_t, int* out_m, int* has_duplicates) {
+                                   bool cond_all, int cov_type, double var, double a, gpb_hip_vecchia_t** out_t, int* out_m, int* has_duplicates,
+                                   int gauss_likelihood = 1) {
   *out_t = nullptr;
   if (!h || !coords_pred_colmajor) return fail("null argument");
   if (n_pred < 1) return fail("Vecchia prediction: n_pred = %d", n_pred);
@@ -947,7 +948,7 @@ static int predict_factor_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const d
     t->has_nn = true;
   }
   t->i_begin = n_obs; t->i_end = n_all;
-  if (gpb_hip_vecchia_factor(t, cov_type, var, a, 1)) return -1;
+  if (gpb_hip_vecchia_factor(t, cov_type, var, a, gauss_likelihood)) return -1;     // non-Gaussian: no nugget, diagonal x (1 + 1e-10) (Vecchia_utils.cpp:1963-1965)
   *out_m = m;
   return 0;
 }
@@ -966,6 +967,24 @@ int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const
   HIP_OK(hipMemcpy(u.data(), t->d_u + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
   for (int k = 0; k < n_pred; ++k) pred_mean[k] = -u[k];
   HIP_OK(hipMemcpy(pred_D, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
+  API_END();
+}
+
+// Latent predictive mean of a non-Gaussian (Vecchia-Laplace) model, 'latent_order_obs_first_cond_obs_only': pred_mean = -Bpo mode
+// (PredictLaplaceApproxVecchia, likelihoods.h:8600-8602) with the factor rows of the prediction points computed without a nugget.
+// The "response" on the handle must be the mode (gpb_hip_vecchia_set_y(mode), Vecchia order).
+int gpb_hip_vecchia_predict_latent_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                            int cov_type, double var, double a, double* pred_mean, int* has_duplicates) {
+  API_BEGIN();
+  if (!pred_mean) return fail("null argument");
+  gpb_hip_vecchia_t* t = nullptr;
+  int m = 0;
+  const int rc = predict_factor_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, false, cov_type, var, a, &t, &m, has_duplicates, 0);
+  struct Guard { gpb_hip_vecchia_t* p; ~Guard() { if (p) gpb_hip_vecchia_free(p); } } guard{t};
+  if (rc) return -1;
+  std::vector<double> u(n_pred);
+  HIP_OK(hipMemcpy(u.data(), t->d_u + h->n, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n_pred; ++k) pred_mean[k] = -u[k];
   API_END();
 }
 

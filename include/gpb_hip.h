@@ -186,6 +186,13 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_yaux_partial_dev(gpb_hip_vecchia_t* h, double
 GPB_HIP_EXPORT int gpb_hip_vecchia_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor,
                                                     int32_t num_neighbors_pred, int cov_type, double var, double a, double* pred_mean,
                                                     double* pred_D, int* has_duplicates);
+/* Latent predictive mean of a non-Gaussian (Vecchia-Laplace) model at new locations, every prediction point conditioning on its nearest
+ * OBSERVED points: pred_mean = -Bpo mode (PredictLaplaceApproxVecchia with CondObsOnly, include/GPBoost/likelihoods.h:8600-8602), the rows
+ * of Bpo from the latent covariance (no nugget, diagonal x (1 + 1e-10): Vecchia_utils.cpp:1963-1965).  The response on the handle must be
+ * the mode in Vecchia order (gpb_hip_vecchia_set_y). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_predict_latent_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor,
+                                                           int32_t num_neighbors_pred, int cov_type, double var, double a, double* pred_mean,
+                                                           int* has_duplicates);
 
 /* Vecchia prediction 'order_obs_first_cond_all' (CalcPredVecchiaObservedFirstOrder with CondObsOnly = false,
  * src/GPBoost/Vecchia_utils.cpp:1701-2093): the prediction points condition on their num_neighbors_pred nearest points among the observed AND

@@ -210,6 +210,25 @@ def optim_laplace_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "optim_laplace_ref.npz"), **res)
 
 
+def laplace_pred_fixture(out_dir):
+    """Latent predictive mean of the reference for non-Gaussian Vecchia models after its own fit (GPB_PredictREModel, predict_response = false,
+    no variances; PredictLaplaceApproxVecchia, likelihoods.h:8600-8602) -- tests/cases.py:LAPLACE_CASES lap_u2d_n1500_mat15_m30."""
+    res = {}
+    c = cases.LAPLACE_CASES["lap_u2d_n1500_mat15_m30"]
+    cpred = np.random.default_rng(77).uniform(size=(40, 2))
+    res["coords_pred"] = cpred
+    for lik in ("bernoulli_logit", "bernoulli_probit", "poisson"):
+        coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=lik)
+        mdl.set_optim_config(cg_delta_conv=1e-8, delta_conv_mode_finding=1e-13)     # the mode to ~1e-7: the comparison is of the prediction, not of Newton's stopping rule
+        mdl.optim_cov_par(y)
+        mu, _ = mdl.predict(cpred, predict_var=False, predict_response=False)
+        res[lik + "_cov_pars"] = mdl.get_cov_par(2)
+        res[lik + "_pred_latent_mu"] = mu
+        print("laplace pred", lik, res[lik + "_cov_pars"], mu[:4], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_pred_ref.npz"), **res)
+
+
 def laplace_grad_F_fixture(out_dir):
     """The reference's boosting gradient for non-Gaussian data (REModel::CalcGradient, data order) at the first parameters of the three
     Laplace cases, with the fixed effects of the other fixtures, for logit / probit / Poisson."""
@@ -339,6 +358,8 @@ if __name__ == "__main__":
         config4_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace":     # only (re)generate the Laplace fixture
         laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pred":
+        laplace_pred_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad_F":
         laplace_grad_F_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "fisher":

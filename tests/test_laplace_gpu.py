@@ -191,3 +191,24 @@ def test_config4_size_n1e5(gpb, orc):
     grad = y[perm] - 1.0 / (1.0 + np.exp(-mode))
     # Newton's method stops on the objective (1e-8 relative), so the gradient is small but not zero
     assert np.linalg.norm(lhs - grad) <= 1e-2 * np.linalg.norm(grad)
+
+
+@pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
+def test_latent_prediction_against_the_reference(gpb, lik):
+    """Latent predictive mean of a non-Gaussian Vecchia model, -Bpo mode (PredictLaplaceApproxVecchia, likelihoods.h:8600-8602;
+    'latent_order_obs_first_cond_obs_only'), at the reference's own fitted parameters against its own GPB_PredictREModel
+    (tests/golden/laplace_pred_ref.npz, oracle/make_golden.py laplace_pred; both sides with cg_delta_conv = 1e-8 and delta_conv_mode_finding =
+    1e-13: with the defaults -- Newton stops at a 1e-8 relative change of its objective -- the mode, and so the prediction, is only defined to ~1e-4).  Variances and response-scale predictions are not on the path and say so."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "laplace_pred_ref.npz"))
+    c = cases.LAPLACE_CASES["lap_u2d_n1500_mat15_m30"]
+    coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
+    mdl = gpb.GPModel(likelihood=lik, gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+                      num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    mdl.set_optim_params({"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13})
+    pr = mdl.predict(y=y, gp_coords_pred=g["coords_pred"], cov_pars=g[lik + "_cov_pars"], predict_var=False, predict_response=False)
+    np.testing.assert_allclose(pr["mu"], g[lik + "_pred_latent_mu"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(gpb.GPBoostError, match="latent predictive mean"):
+        mdl.predict(y=y, gp_coords_pred=g["coords_pred"], cov_pars=g[lik + "_cov_pars"], predict_var=True, predict_response=False)
+    with pytest.raises(gpb.GPBoostError, match="latent predictive mean"):
+        mdl.predict(y=y, gp_coords_pred=g["coords_pred"], cov_pars=g[lik + "_cov_pars"], predict_response=True)
