@@ -1296,10 +1296,9 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   int nchunks = std::max(1, std::min((num_data + 1023) / 1024, std::max(1, chunk_mult * h->num_cu / groups)));
   if (nchunks >= 16) nchunks &= ~7;                 // multiples of 8: the XCD-aware workgroup order of hist_build_kernel
   // whole rows per lane (hist_build_rows_kernel: 128 KB of LDS, one workgroup of 512 lanes per CU and quad of feature groups) when the
-  // hessian is constant, there are at least four feature groups and every CU gets a workgroup with >= 4096 rows
-  const int quads = (groups + 3) / 4;
-  const bool rows_kernel = !h->has_hess && groups >= 4 && (long long)num_data * quads >= 4096LL * h->num_cu;
-  if (rows_kernel) nchunks = std::max(1, h->num_cu / quads);
+  // hessian is constant, there are at least four feature groups and every CU gets a workgroup with >= 2048 rows
+  const bool rows_kernel = !h->has_hess && groups >= 4 && (long long)num_data >= 2048LL * h->num_cu;
+  if (rows_kernel) nchunks = std::max(1, h->num_cu);      // one workgroup per CU and quad of feature groups (launches of whole quads, then the partial one)
   const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
   if (nchunks < 16 && rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;
   if (nchunks < 1) nchunks = 1;

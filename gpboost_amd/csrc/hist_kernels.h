@@ -22,6 +22,7 @@ struct HistKernelArgs {
   int num_features;         // real features (<= fpad): the padding features of the last group are not accumulated
   // tree grower: when seg_counts != nullptr the rows are the SMALLER child of the split of the segment (seg_begin, seg_cnt) of
   // data_indices whose left counts {this rank, all ranks} sit in seg_counts (device memory); num_data / rows_per_chunk are ignored
+  int quad0 = 0;            // hist_build_rows_kernel: first quad of feature groups of this launch
   int use_rows_kernel = 0;  // hist_build_rows_kernel (constant hessian, >= 4 feature groups): set by the host with a chunking of one workgroup per CU
   const int* seg_counts = nullptr;
   int seg_begin = 0, seg_cnt = 0, seg_gcnt = 0, seg_min_data_in_leaf = 0;

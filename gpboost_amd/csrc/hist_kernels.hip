@@ -213,13 +213,13 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // its 16 features only.  Here a lane takes a row's whole 64 bytes (four feature groups) and issues its 64 atomics into four 32 KB
 // sub-histogram blocks (128 KB of LDS: one workgroup of 512 lanes per CU): the per-row work is paid once per 64 features, what remains
 // is the LDS atomic rate.  Same words, same drains (every 3 iterations = 1536 rows <= 1792), same partial layout as hist_build_kernel.
-template <bool HAS_IDX>
+template <bool HAS_IDX, int NBK>          // NBK = feature groups of this launch's quads that exist: 4, or 1..3 for the data set's last, partial quad
 __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
   // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
   constexpr int THREADS = 512, NB = 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
   extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features]
   const int tid = threadIdx.x;
-  const int chunk = blockIdx.x, quad = blockIdx.y, groups = a.fpad / GPB_HIST_FG;
+  const int chunk = blockIdx.x, quad = blockIdx.y + a.quad0, groups = a.fpad / GPB_HIST_FG;
   for (int t = tid; t < NB * kWords; t += THREADS) s_rows[t] = 0ull;
   const double inv_q = fixed_point_inv_q<false>(a.grad_max_bits);
   long long rk[kOwn];
@@ -241,13 +241,14 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
   const int r0 = chunk * a.rows_per_chunk;
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
   const uint8_t* base = a.bins_rm + (size_t)quad * NB * GPB_HIST_FG;
+  constexpr int nblk = NBK;                           // (compile-time: a run-time bound in the unrolled block loop cost 25 %)
   struct RowData { uint4 bv[NB]; double g; };
   auto fetch = [&](int r) -> RowData {
     RowData d;
     const int row = HAS_IDX ? a.data_indices[r] : r;
     const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)row * a.fpad);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) d.bv[b] = p[b];
+    for (int b = 0; b < NB; ++b) d.bv[b] = b < nblk ? p[b] : make_uint4(0u, 0u, 0u, 0u);      // never read past the row's fpad bytes
     d.g = a.grad[row];
     return d;
   };
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
     const unsigned long long add_g = fixed_point_bits(cur.g, inv_q) + (1ull << kSumBits);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      if (b >= nblk) break;
       unsigned w0 = cur.bv[b].x, w1 = cur.bv[b].y, w2 = cur.bv[b].z, w3 = cur.bv[b].w, t0, t1, t2, t3;
       t0 = (wr & 1u) ? w1 : w0; t1 = (wr & 1u) ? w2 : w1; t2 = (wr & 1u) ? w3 : w2; t3 = (wr & 1u) ? w0 : w3;
       w0 = (wr & 2u) ? t2 : t0; w1 = (wr & 2u) ? t3 : t1; w2 = (wr & 2u) ? t0 : t2; w3 = (wr & 2u) ? t1 : t3;
@@ -424,14 +426,23 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
   // constant hessian, at least four feature groups, enough rows to fill the CUs one workgroup each: whole rows per lane
   if (a.use_rows_kernel) {
     constexpr int lds = 4 * GPB_HIST_MAX_BIN * GPB_HIST_FG * 8;
-    // (per launch, not once per process: the attribute belongs to the current device)
-    const void* kf = a.data_indices ? reinterpret_cast<const void*>(hist_build_rows_kernel<true>) : reinterpret_cast<const void*>(hist_build_rows_kernel<false>);
-    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    const dim3 grid(a.nchunks, (a.fpad / GPB_HIST_FG + 3) / 4);
-    if (a.data_indices) hipLaunchKernelGGL(hist_build_rows_kernel<true>, grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(hist_build_rows_kernel<false>, grid, dim3(512), lds, st, a);
-    return hipGetLastError();
+    // full quads in one launch, the last partial quad (1..3 feature groups) in a second one; the dynamic-LDS attribute is set per launch
+    // (it belongs to the current device)
+    const int groups = a.fpad / GPB_HIST_FG, full = groups / 4, rest = groups % 4;
+    auto go = [&](auto kern, int nquads, int quad0) -> hipError_t {
+      HistKernelArgs b = a;
+      b.quad0 = quad0;
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(a.nchunks, nquads), dim3(512), lds, st, b);
+      return hipGetLastError();
+    };
+    hipError_t e = hipSuccess;
+    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0);
+    if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1>, 1, full) : go(hist_build_rows_kernel<false, 1>, 1, full);
+    if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2>, 1, full) : go(hist_build_rows_kernel<false, 2>, 1, full);
+    if (e == hipSuccess && rest == 3) e = a.data_indices ? go(hist_build_rows_kernel<true, 3>, 1, full) : go(hist_build_rows_kernel<false, 3>, 1, full);
+    return e;
   }
   // 256 threads: 512 and 1024 (twice / four times the wavefronts on the same 32 KB of LDS) time the same within 2 % at n = 1e7
   launch_hist_build_t<256>(a, st);

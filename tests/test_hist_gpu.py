@@ -16,7 +16,7 @@ def _case(n, F, seed, max_bin=255):
     return bins, bo, rng.standard_normal(n), rng.uniform(0.5, 2.0, size=n), rng
 
 
-@pytest.mark.parametrize("n,F", [(100000, 50), (4097, 3), (1000, 17), (50, 64)])
+@pytest.mark.parametrize("n,F", [(100000, 50), (4097, 3), (1000, 17), (50, 64), (1200000, 50), (600000, 70)])   # the last two: the whole-row kernel (one full quad of feature groups; a full and a partial one)
 def test_histogram_counts_exact_and_sums_close(lib_built, orc, n, F):
     from gpboost_amd import shim
     bins, bo, grad, hess, rng = _case(n, F, seed=n + F)
