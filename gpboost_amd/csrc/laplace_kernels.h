@@ -17,10 +17,28 @@ struct LapTri {            // one level-scheduled triangular solve; matrix store
 constexpr int kTriThreads = 512;        // workgroup of the level-scheduled solves
 constexpr int kTriRowsPerRound = 64;    // rows it handles per round (32 groups of 16 lanes x 2)
 struct LapSeg { int L0, L1, nsplit, nrounds; };   // levels [L0, L1) in one launch, nrounds rounds per workgroup; nsplit > 1: one wide level, one round per workgroup
+// Dense block of a solve: the rows of a contiguous range of NARROW levels (the head of the forward solve -- the first points of the
+// ordering, which all depend on each other -- and the tail of the backward solve).  A run of such levels costs one dependent L2 round
+// trip per level (~3 us, ~270 levels at n = 1e5); instead the inverse of the block's unit lower-triangular matrix I - A_blk is formed
+// once per evaluation (row k = e_k + sum_j A_kj row j: 30 row updates, level by level) and a solve applies it as one dense product:
+//     x_blk = inv * (rhs_blk [.* rdw] + A_(blk, outside) x_outside).
+struct LapDense {
+  int K, ld;                   // rows of the block (0: no block), leading dimension of inv
+  const int* rows;             // [K] storage index of block row k (level order)
+  const int* iptr; const int* icol; const int* ipos;   // entries inside the block: column = block-local index (< k), position in A
+  const int* optr; const int* osrc; const int* opos;   // entries whose source row lies outside the block: storage index, position in A
+  double* inv;                 // [K * ld] lower triangle of (I - A_blk)^-1 (the rest is never read), refreshed per evaluation
+  double* tbuf;                // [K * kDenseCols] right-hand sides of the block, [k][column]; then kDenseSplit partial products of the same size
+  const int* blev; int nblev;  // HOST array [nblev + 1]: block-local level boundaries (the order inv is built in)
+};
+constexpr int kDenseCols = 64;            // columns the dense block handles per pass
+constexpr int kDenseSplit = 8;            // parts the column range of the block product is cut into (probe block)
 struct LapLevels {                        // fwd: (D^-1 + W) B z = t;  bwd: B^T t = r;  launch segments of each (host arrays)
   LapTri fwd, bwd;
   const LapSeg* fseg; int n_fseg;
   const LapSeg* bseg; int n_bseg;
+  LapDense fdense, bdense;                // head block of the forward solve (before fseg), tail block of the backward solve (after bseg)
+  const double* A;                        // this evaluation's coefficients, Vecchia order [n][m] (the blocks' entries point into it)
 };
 struct CgScalars {         // per-column CG scalars on the device; part / part2: lap_cg_parts(n) partial dot products per column
   double* a; double* a_old; double* b; double* rz_old; double* rnorm; double* Td; double* Ts; double* part; double* part2;
@@ -35,6 +53,7 @@ hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int 
 hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st);
 hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st);
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st);
+hipError_t lap_dense_build(const LapDense& d, const double* A, hipStream_t st);    // inv of the block from this evaluation's A (Vecchia order [n][m])
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st);
 hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st);
 hipError_t lap_cg_update(double* u, double* r, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st);

@@ -556,6 +556,155 @@ __global__ __launch_bounds__(256) void lap_tri_spmv_kernel(LapTri T, int n, cons
 }
 
 // once per evaluation: the factor's A into the level-ordered entry records of a solve
+// ---- dense blocks of the solves (laplace_kernels.h: LapDense) -------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ double wave_sum(double v) {          // sum over the 64 lanes, result in every lane
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+}  // namespace
+// One level of the block: row k of inv = e_k + sum_e A[ipos[e]] * (row icol[e] of inv); the rows it reads belong to earlier levels
+// (earlier launches).  Thread = one column c <= k; entries of inv right of the diagonal are never read (c <= j guards them).
+__global__ __launch_bounds__(256) void lap_dense_inv_kernel(LapDense d, const double* __restrict__ A, int k0) {
+  const int k = k0 + (int)blockIdx.y;
+  const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (c > k) return;
+  double acc = (c == k) ? 1.0 : 0.0;
+  const int e1 = d.iptr[k + 1];
+  for (int e = d.iptr[k]; e < e1; ++e) {
+    const int j = d.icol[e];
+    if (c <= j) acc = __builtin_fma(A[d.ipos[e]], d.inv[(size_t)j * d.ld + c], acc);
+  }
+  d.inv[(size_t)k * d.ld + c] = acc;
+}
+// Right-hand side of the block, one wavefront per block row and chunk: t = rhs [* rdw] + sum over the row's entries with a source
+// OUTSIDE the block (already solved: earlier levels) of A * x[source].   tbuf[k][(chunk - c0) * NC + c], cn chunks per pass.
+template <int NC, bool SCALE>
+__global__ __launch_bounds__(256) void lap_dense_rhs_kernel(LapDense d, const double* __restrict__ A, int n, int c0, int cn, const double* __restrict__ rhs,
+                                                            const double* __restrict__ rdw, const double* __restrict__ x) {
+  const int k = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (k >= d.K) return;
+  const int lane = threadIdx.x & 63, chunk = c0 + (int)blockIdx.y;
+  const size_t off = (size_t)chunk * n * NC;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  const int e1 = d.optr[k + 1];
+  for (int e = d.optr[k] + lane; e < e1; e += 64) {
+    const double a = A[d.opos[e]];
+    const VecN<NC> v = ldvec<NC>(x + off, (unsigned)d.osrc[e]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(a, v.v[c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+  if (lane == 0) {
+    const unsigned row = (unsigned)d.rows[k];
+    const VecN<NC> num = ldvec<NC>(rhs + off, row);
+    const double den = SCALE ? rdw[row] : 1.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) d.tbuf[(size_t)k * (cn * NC) + (size_t)(chunk - c0) * NC + c] = SCALE ? __builtin_fma(num.v[c], den, acc[c]) : num.v[c] + acc[c];
+  }
+}
+// x_blk = inv * t for plain columns (NC = 1): one wavefront per block row (long rows first) and column, four independent partial sums
+__global__ __launch_bounds__(256) void lap_dense_matvec_kernel(LapDense d, int n, int c0, int cn, double* __restrict__ x) {
+  const int w = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (w >= d.K) return;
+  const int k = d.K - 1 - w, lane = threadIdx.x & 63, col = (int)blockIdx.y;
+  const double* __restrict__ row = d.inv + (size_t)k * d.ld;
+  const double* __restrict__ t = d.tbuf + col;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int j = lane;
+  for (; j + 192 <= k; j += 256) {
+    a0 = __builtin_fma(row[j], t[(size_t)j * cn], a0);
+    a1 = __builtin_fma(row[j + 64], t[(size_t)(j + 64) * cn], a1);
+    a2 = __builtin_fma(row[j + 128], t[(size_t)(j + 128) * cn], a2);
+    a3 = __builtin_fma(row[j + 192], t[(size_t)(j + 192) * cn], a3);
+  }
+  for (; j <= k; j += 64) a0 = __builtin_fma(row[j], t[(size_t)j * cn], a0);
+  const double sum = wave_sum((a0 + a1) + (a2 + a3));
+  if (lane == 0) x[(size_t)(c0 + col) * n + (unsigned)d.rows[k]] = sum;
+}
+// x_blk = inv * t for the probe block (chunks of 4 columns; cn <= 16 chunks per pass): a workgroup takes 32 block rows (long tiles
+// first) and walks the columns of inv 64 at a time: the 32 x 64 tile of inv and the 64 x (4 cn) tile of tbuf go through LDS (coalesced
+// loads, fetched into registers one tile ahead); thread (r, cg) keeps the 4 columns of chunk cg for rows r and r + 16.
+// The column range of a row tile is cut into kDenseSplit equal parts (blockIdx.y) whose partial products go to `part`
+// ([split][k][4 cn]) and are added in a fixed order by lap_dense_gemm4_sum_kernel: the longest row tile alone would otherwise take
+// K / 64 column tiles in sequence.
+__global__ __launch_bounds__(256) void lap_dense_gemm4_kernel(LapDense d, int cn, double* __restrict__ part) {
+  __shared__ double s_inv[32][65];
+  __shared__ alignas(32) double s_t[64 * 64];
+  const int tile = (int)(gridDim.x - 1 - blockIdx.x);
+  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15;
+  const int k0 = tile * 32;
+  const int kmax = (k0 + 31 < d.K ? k0 + 31 : d.K - 1);
+  const int nt_all = kmax / 64 + 1, per = (nt_all + kDenseSplit - 1) / kDenseSplit;
+  const int jt0 = (int)blockIdx.y * per, ntiles = (jt0 + per < nt_all ? jt0 + per : nt_all);      // column tiles [jt0, ntiles)
+  const int ts = cn * 4;
+  const size_t tend = (size_t)d.K * ts;
+  double pinv[8], pt[16];
+  auto fetch = [&](int jt) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = q * 256 + tid, rr = idx >> 6, j = jt * 64 + (idx & 63), kk = k0 + rr;
+      pinv[q] = (kk < d.K && j <= kk) ? d.inv[(size_t)kk * d.ld + j] : 0.0;        // zero right of the diagonal: the products below run unmasked
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const size_t g = (size_t)jt * 64 * ts + (size_t)(q * 256 + tid);
+      pt[q] = (q < cn && g < tend) ? d.tbuf[g] : 0.0;
+    }
+  };
+  double acc0[4] = { 0.0, 0.0, 0.0, 0.0 }, acc1[4] = { 0.0, 0.0, 0.0, 0.0 };
+  if (jt0 < ntiles) fetch(jt0);
+  for (int jt = jt0; jt < ntiles; ++jt) {
+    __syncthreads();                      // the previous tile has been consumed
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int idx = q * 256 + tid; s_inv[idx >> 6][idx & 63] = pinv[q]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < cn) s_t[q * 256 + tid] = pt[q];
+    __syncthreads();
+    if (jt + 1 < ntiles) fetch(jt + 1);
+    if (cg < cn) {
+#pragma unroll 8
+      for (int jj = 0; jj < 64; ++jj) {
+        const double a0 = s_inv[r][jj], a1 = s_inv[r + 16][jj];
+        const VecN<4> v = *reinterpret_cast<const VecN<4>*>(&s_t[jj * ts + cg * 4]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { acc0[c] = __builtin_fma(a0, v.v[c], acc0[c]); acc1[c] = __builtin_fma(a1, v.v[c], acc1[c]); }
+      }
+    }
+  }
+  if (cg < cn) {
+    double* pc = part + (size_t)blockIdx.y * d.K * ts + (size_t)cg * 4;
+    VecN<4> o;
+    if (k0 + r < d.K) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o.v[c] = acc0[c];
+      *reinterpret_cast<VecN<4>*>(pc + (size_t)(k0 + r) * ts) = o;
+    }
+    if (k0 + r + 16 < d.K) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o.v[c] = acc1[c];
+      *reinterpret_cast<VecN<4>*>(pc + (size_t)(k0 + r + 16) * ts) = o;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lap_dense_gemm4_sum_kernel(LapDense d, int n, int c0, int cn, const double* __restrict__ part, double* __restrict__ x) {
+  const int g = (int)(blockIdx.x * 256 + threadIdx.x);          // (block row, chunk)
+  if (g >= d.K * cn) return;
+  const int k = g / cn, cg = g - k * cn;
+  const size_t ts = (size_t)cn * 4;
+  VecN<4> o = *reinterpret_cast<const VecN<4>*>(part + (size_t)k * ts + (size_t)cg * 4);
+  for (int sp = 1; sp < kDenseSplit; ++sp) {
+    const VecN<4> v = *reinterpret_cast<const VecN<4>*>(part + ((size_t)sp * d.K + k) * ts + (size_t)cg * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o.v[c] += v.v[c];
+  }
+  *reinterpret_cast<VecN<4>*>(x + (size_t)(c0 + cg) * n * 4 + (size_t)(unsigned)d.rows[k] * 4) = o;
+}
+
 __global__ void lap_permute_factor_kernel(const double* __restrict__ A, const int* __restrict__ hpos, const int* __restrict__ opos, size_t nh,
                                           size_t novf, LapEnt* __restrict__ hent, LapEnt* __restrict__ oent) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -852,9 +1001,37 @@ hipError_t lap_objective(int link, const double* x, const int* y, const double* 
   } while (0)
 #define LAP_TRSV(SCALE, T_, SEG, RHS, RDW, X)                                                                                         \
   do { if ((T_).has_ovf) LAP_TRSV_O(SCALE, true, T_, SEG, RHS, RDW, X); else LAP_TRSV_O(SCALE, false, T_, SEG, RHS, RDW, X); } while (0)
+hipError_t lap_dense_build(const LapDense& d, const double* A, hipStream_t st) {
+  for (int l = 0; l < d.nblev; ++l) {
+    const int k0 = d.blev[l], k1 = d.blev[l + 1];
+    if (k1 > k0) hipLaunchKernelGGL(lap_dense_inv_kernel, dim3((k1 + 255) / 256, k1 - k0), dim3(256), 0, st, d, A, k0);
+  }
+  return hipGetLastError();
+}
+// the block of a solve: right-hand sides (with the part of the product that comes from outside the block), then the dense product;
+// kDenseCols columns per pass
+template <bool SCALE>
+static void lap_dense_solve(const LapDense& d, const double* A, int n, const double* rhs, const double* rdw, double* x, int ncol, int nc, hipStream_t st) {
+  if (d.K <= 0) return;
+  const int per = nc == 4 ? 16 : kDenseCols;                     // chunks per pass (16 x 4 columns, or 64 plain columns)
+  for (int c0 = 0; c0 < ncol; c0 += per) {
+    const int cn = ncol - c0 < per ? ncol - c0 : per;
+    if (nc == 4) {
+      hipLaunchKernelGGL((lap_dense_rhs_kernel<4, SCALE>), dim3((d.K + 3) / 4, cn), dim3(256), 0, st, d, A, n, c0, cn, rhs, rdw, (const double*)x);
+      double* part = d.tbuf + (size_t)d.K * kDenseCols;
+      hipLaunchKernelGGL(lap_dense_gemm4_kernel, dim3((d.K + 31) / 32, kDenseSplit), dim3(256), 0, st, d, cn, part);
+      hipLaunchKernelGGL(lap_dense_gemm4_sum_kernel, dim3((d.K * cn + 255) / 256), dim3(256), 0, st, d, n, c0, cn, (const double*)part, x);
+    } else {
+      hipLaunchKernelGGL((lap_dense_rhs_kernel<1, SCALE>), dim3((d.K + 3) / 4, cn), dim3(256), 0, st, d, A, n, c0, cn, rhs, rdw, (const double*)x);
+      hipLaunchKernelGGL(lap_dense_matvec_kernel, dim3((d.K + 3) / 4, cn), dim3(256), 0, st, d, n, c0, cn, x);
+    }
+  }
+}
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
   for (int k = 0; k < lv.n_bseg; ++k) LAP_TRSV(false, lv.bwd, lv.bseg[k], r, (const double*)nullptr, t);     // B^T t = r
-  for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], (const double*)t, rdw, z);            // (D^-1 + W) B z = t
+  lap_dense_solve<false>(lv.bdense, lv.A, n, r, nullptr, t, ncol, nc, st);                                    //   ... its last (narrow) levels as one dense block
+  lap_dense_solve<true>(lv.fdense, lv.A, n, t, rdw, z, ncol, nc, st);                                         // (D^-1 + W) B z = t: the first (narrow) levels
+  for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], (const double*)t, rdw, z);
   return hipGetLastError();
 }
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st) {
