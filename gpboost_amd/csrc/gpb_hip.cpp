@@ -130,6 +130,8 @@ struct gpb_hip_hist {
   hipStream_t stream = nullptr;
   int n = 0, F = 0, fpad = 0, total_bins = 0;
   int num_cu = 0;                                          // compute units of the device (chunking of the build kernel)
+  // regularisation of the split search beyond lambda_l2 (gpb_hip_hist_set_regularisation); parent_output: of the next single-leaf searches
+  double reg_l1 = 0., reg_max_delta_step = 0., reg_path_smooth = 0., reg_parent_output = 0.;
   uint8_t* d_bins_rm = nullptr;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
@@ -1483,6 +1485,15 @@ int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const 
   API_END();
 }
 
+int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lambda_l1, double max_delta_step, double path_smooth, double parent_output) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  if (!(lambda_l1 >= 0.0) || !(path_smooth >= 0.0) || !std::isfinite(max_delta_step) || !std::isfinite(parent_output))
+    return fail("gpb_hip_hist_set_regularisation: lambda_l1 and path_smooth must be >= 0 (got %g, %g), max_delta_step and parent_output finite", lambda_l1, path_smooth);
+  h->reg_l1 = lambda_l1; h->reg_max_delta_step = max_delta_step; h->reg_path_smooth = path_smooth; h->reg_parent_output = parent_output;
+  API_END();
+}
+
 int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data, double lambda_l2,
                                  int32_t min_data_in_leaf, double min_sum_hessian_in_leaf, double min_gain_to_split,
                                  const int8_t* is_feature_used, int32_t* best_feature, double* per_feature_out10,
@@ -1501,7 +1512,9 @@ int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gra
   }
   if (is_feature_used) HIP_OK(hipMemcpyAsync(h->d_used, is_feature_used, (size_t)F, hipMemcpyHostToDevice, h->stream));
   HIP_OK(gpb::launch_hist_best_split(src, F, h->d_fix, h->d_fix + F, h->d_meta3, sum_gradient, sum_hessian, num_data, lambda_l2,
-                                     min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split, is_feature_used ? h->d_used : nullptr,
+                                     min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split,
+                                     gpb::SplitReg{ h->reg_l1, h->reg_max_delta_step, h->reg_path_smooth, h->reg_parent_output },
+                                     is_feature_used ? h->d_used : nullptr,
                                      h->d_split, h->d_split_i, h->d_split_i + F, h->stream));
   std::vector<int> ints(F + 1);
   HIP_OK(hipMemcpyAsync(ints.data(), h->d_split_i, sizeof(int) * (size_t)(F + 1), hipMemcpyDeviceToHost, h->stream));

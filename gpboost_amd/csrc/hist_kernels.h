@@ -28,6 +28,9 @@ struct HistKernelArgs {
   int seg_begin = 0, seg_cnt = 0, seg_gcnt = 0, seg_min_data_in_leaf = 0;
 };
 
+// regularisation of the split search beyond lambda_l2 (feature_histogram.hpp:137-161) + the parent_output argument of FindBestThreshold
+struct SplitReg { double lambda_l1 = 0.0, max_delta_step = 0.0, path_smooth = 0.0, parent_output = 0.0; };
+
 struct ChildrenSearchArgs {
   double* smaller;          // slot of the smaller child's histogram (fresh from the build, not yet fixed)
   double* parent;           // slot of the parent's histogram: becomes the larger child's
@@ -36,6 +39,8 @@ struct ChildrenSearchArgs {
   int num_features, gcnt, min_data_in_leaf;
   double left_sum_gradient, left_sum_hessian, right_sum_gradient, right_sum_hessian;     // of the parent's split
   double lambda_l2, min_sum_hessian, min_gain_to_split;
+  double lambda_l1 = 0.0, max_delta_step = 0.0, path_smooth = 0.0;
+  double left_output = 0.0, right_output = 0.0;                                          // outputs of the parent's split = parent_output of the children
   double* out10;            // [2][F][10]: candidates of the smaller, then of the larger child
   int* out_flags;           // [2][F + 1]
 };
@@ -57,7 +62,7 @@ hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offse
                            double sum_gradient, double sum_hessian, hipStream_t st);
 hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
                                   double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
-                                  double min_sum_hessian, double min_gain_to_split, const signed char* is_feature_used, double* out10,
+                                  double min_sum_hessian, double min_gain_to_split, SplitReg reg, const signed char* is_feature_used, double* out10,
                                   int* out_default_left, int* best_feature, hipStream_t st);
 hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                  int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,

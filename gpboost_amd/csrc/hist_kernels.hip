@@ -510,12 +510,50 @@ struct SplitOut { double gain, left_output, right_output, lsg, lsh, rsg, rsh; un
 constexpr int kSplitSteps = GPB_HIST_MAX_BIN + 2;      // step index t + 1 (the forward scan may start at t = -1)
 }  // namespace
 
+// The regularisation paths of the search (feature_histogram.hpp:137-161 picks the template instance; here run-time flags with the same
+// expressions, so that with all three off the default path is reproduced bit for bit): lambda_l1 > 0 (USE_L1), max_delta_step > 0
+// (USE_MAX_OUTPUT), path_smooth > kEpsilon (USE_SMOOTHING, parent_output = the leaf's own output).  :737-741 ThresholdL1,
+// :743-765 CalculateSplittedLeafOutput, :826-857 GetLeafGain / GetLeafGainGivenOutput.
+#pragma clang fp contract(off)
+namespace {
+struct RegPath { double l1, l2, mds, smooth, parent; bool use_l1, use_mds, use_smooth; };
+__device__ __forceinline__ double reg_sign(double x) { return (double)((x > 0.0) - (x < 0.0)); }
+__device__ __forceinline__ double reg_threshold_l1(double s, double l1) {
+#pragma clang fp contract(off)
+  const double reg_s = fmax(0.0, fabs(s) - l1);
+  return reg_sign(s) * reg_s;
+}
+__device__ __forceinline__ double reg_leaf_output(double sg, double sh, const RegPath& r, int num_data) {
+#pragma clang fp contract(off)
+  double ret = r.use_l1 ? -reg_threshold_l1(sg, r.l1) / (sh + r.l2) : -sg / (sh + r.l2);
+  if (r.use_mds && fabs(ret) > r.mds) ret = reg_sign(ret) * r.mds;
+  if (r.use_smooth) {
+    const double w = num_data / r.smooth;
+    ret = ret * w / (w + 1) + r.parent / (w + 1);
+  }
+  return ret;
+}
+__device__ __forceinline__ double reg_gain_given_output(double sg, double sh, const RegPath& r, double output) {
+#pragma clang fp contract(off)
+  const double sg_l1 = r.use_l1 ? reg_threshold_l1(sg, r.l1) : sg;
+  return -(2.0 * sg_l1 * output + (sh + r.l2) * output * output);
+}
+__device__ __forceinline__ double reg_leaf_gain(double sg, double sh, const RegPath& r, int num_data) {
+#pragma clang fp contract(off)
+  if (!r.use_mds && !r.use_smooth) {
+    if (r.use_l1) { const double sg_l1 = reg_threshold_l1(sg, r.l1); return (sg_l1 * sg_l1) / (sh + r.l2); }
+    return (sg * sg) / (sh + r.l2);
+  }
+  return reg_gain_given_output(sg, sh, r, reg_leaf_output(sg, sh, r, num_data));
+}
+}  // namespace
+
 #pragma clang fp contract(off)
 // the search for feature f by the 256 threads of a workgroup (all of them must call it; it ends with a barrier, so it can be called again)
 __device__ void best_split_feature(const double* hist, int f, const int* __restrict__ view_offset,
                                    const int* __restrict__ num_bin, const int* __restrict__ meta3 /* offset, default_bin, missing */,
                                    double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2, int min_data_in_leaf,
-                                   double min_sum_hessian, double min_gain_to_split, double* __restrict__ out10,
+                                   double min_sum_hessian, double min_gain_to_split, SplitReg reg, double* __restrict__ out10,
                                    int* __restrict__ out_default_left) {
 #pragma clang fp contract(off)
   __shared__ double s_x[GPB_HIST_MAX_BIN + 1][4];           // per entry: gradient sum, hessian sum, rounded count (as a double), pad
@@ -529,8 +567,9 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
   const double* data = hist + (size_t)view_offset[f] * 2;
   const int nb = num_bin[f], offset = meta3[3 * f], default_bin = meta3[3 * f + 1], missing = meta3[3 * f + 2];
   const double sum_hessian = sum_hessian_leaf + 2 * kEps;
-  const double min_gain_shift = (sum_gradient * sum_gradient) / (sum_hessian + lambda_l2) + min_gain_to_split;
-  const double l2 = lambda_l2;
+  const RegPath rp{ reg.lambda_l1, lambda_l2, reg.max_delta_step, reg.path_smooth, reg.parent_output, reg.lambda_l1 > 0.0, reg.max_delta_step > 0.0,
+                    reg.path_smooth > kEps };
+  const double min_gain_shift = reg_leaf_gain(sum_gradient, sum_hessian, rp, num_data) + min_gain_to_split;      // BeforeNumercal :103-113
   const bool two_scans = nb > 2 && missing != 0;
   const bool skip_default = two_scans && missing == 1;
   const int na_as_missing = (two_scans && missing != 1) ? 1 : 0;
@@ -607,7 +646,9 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
       double slg, slh, srg, srh;
       if (dir == 0) { srg = s_o[0][k][0]; srh = s_o[0][k][1]; slh = sum_hessian - srh; slg = sum_gradient - srg; }
       else { slg = s_o[1][k][0]; slh = s_o[1][k][1]; srh = sum_hessian - slh; srg = sum_gradient - slg; }
-      const double current_gain = (slg * slg) / (slh + l2) + (srg * srg) / (srh + l2);
+      const int ac = (int)s_o[dir][k][2];                  // rows on the accumulated side (right in the reverse scan, left in the forward one)
+      const int lcnt = dir == 0 ? num_data - ac : ac;
+      const double current_gain = reg_leaf_gain(slg, slh, rp, lcnt) + reg_leaf_gain(srg, srh, rp, num_data - lcnt);      // GetSplitGains :797-804
       if (current_gain <= min_gain_shift) continue;
       any = 1;
       const bool earlier = tbest < 0 || (dir == 0 ? k > tbest : k < tbest);
@@ -636,10 +677,10 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
         double best_slg, best_slh; int best_left_count;
         if (dir == 0) { best_left_count = num_data - (int)s_o[0][k][2]; best_slg = sum_gradient - s_o[0][k][0]; best_slh = sum_hessian - s_o[0][k][1]; o.threshold = (unsigned)(t - 1 + offset); }
         else { best_left_count = (int)s_o[1][k][2]; best_slg = s_o[1][k][0]; best_slh = s_o[1][k][1]; o.threshold = (unsigned)(t + offset); }
-        o.left_output = -best_slg / (best_slh + l2);
+        o.left_output = reg_leaf_output(best_slg, best_slh, rp, best_left_count);
         o.left_count = best_left_count;
         o.lsg = best_slg; o.lsh = best_slh - kEps;
-        o.right_output = -(sum_gradient - best_slg) / (sum_hessian - best_slh + l2);
+        o.right_output = reg_leaf_output(sum_gradient - best_slg, sum_hessian - best_slh, rp, num_data - best_left_count);
         o.right_count = num_data - best_left_count;
         o.rsg = sum_gradient - best_slg; o.rsh = sum_hessian - best_slh - kEps;
         o.gain = best_gain - min_gain_shift;
@@ -661,10 +702,10 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
 __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
                                        const int* __restrict__ num_bin, const int* __restrict__ meta3, double sum_gradient, double sum_hessian_leaf,
                                        int num_data, double lambda_l2, int min_data_in_leaf, double min_sum_hessian, double min_gain_to_split,
-                                       double* __restrict__ out10, int* __restrict__ out_default_left) {
+                                       SplitReg reg, double* __restrict__ out10, int* __restrict__ out_default_left) {
   if ((int)blockIdx.x >= num_features) return;
   best_split_feature(hist, blockIdx.x, view_offset, num_bin, meta3, sum_gradient, sum_hessian_leaf, num_data, lambda_l2, min_data_in_leaf,
-                     min_sum_hessian, min_gain_to_split, out10, out_default_left);
+                     min_sum_hessian, min_gain_to_split, reg, out10, out_default_left);
 }
 
 // Both children of a split in ONE launch (tree grower): workgroup (f, child) handles feature f of the smaller (child = 0) or the larger
@@ -683,6 +724,9 @@ __global__ __launch_bounds__(256) void hist_children_search_kernel(ChildrenSearc
   const double sg_s = cs.smaller_is_left ? a.left_sum_gradient : a.right_sum_gradient, sh_s = cs.smaller_is_left ? a.left_sum_hessian : a.right_sum_hessian;
   const double sg_l = cs.smaller_is_left ? a.right_sum_gradient : a.left_sum_gradient, sh_l = cs.smaller_is_left ? a.right_sum_hessian : a.left_sum_hessian;
   const int n_s = cs.smaller_is_left ? cs.gnl : a.gcnt - cs.gnl, n_l = a.gcnt - n_s;
+  // parent_output of a child's search = the child's own output (LeafSplits::weight, serial_tree_learner.cpp:766-768)
+  const SplitReg reg_s{ a.lambda_l1, a.max_delta_step, a.path_smooth, cs.smaller_is_left ? a.left_output : a.right_output };
+  const SplitReg reg_l{ a.lambda_l1, a.max_delta_step, a.path_smooth, cs.smaller_is_left ? a.right_output : a.left_output };
   const int mfb = a.most_freq_bin[f];
   __shared__ double s_fix[2];
   if (tid == 0 && mfb > 0) {                    // the same subtraction order as the reference's loop
@@ -699,7 +743,7 @@ __global__ __launch_bounds__(256) void hist_children_search_kernel(ChildrenSearc
     __threadfence_block();
     __syncthreads();
     best_split_feature(a.smaller, f, a.view_offset, a.num_bin, a.meta3, sg_s, sh_s, n_s, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
-                       a.min_gain_to_split, a.out10, a.out_flags);
+                       a.min_gain_to_split, reg_s, a.out10, a.out_flags);
   } else {
     for (size_t i = 2 * (size_t)a.bin_offsets[f] + tid; i < 2 * (size_t)a.bin_offsets[f + 1]; i += 256) {
       const double sm = (i == fix_at || i == fix_at + 1) ? s_fix[i - fix_at] : a.smaller[i];
@@ -708,7 +752,7 @@ __global__ __launch_bounds__(256) void hist_children_search_kernel(ChildrenSearc
     __threadfence_block();
     __syncthreads();
     best_split_feature(a.parent, f, a.view_offset, a.num_bin, a.meta3, sg_l, sh_l, n_l, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
-                       a.min_gain_to_split, a.out10 + (size_t)a.num_features * 10, a.out_flags + (a.num_features + 1));
+                       a.min_gain_to_split, reg_l, a.out10 + (size_t)a.num_features * 10, a.out_flags + (a.num_features + 1));
   }
 }
 hipError_t launch_hist_children_search(const ChildrenSearchArgs& a, hipStream_t st) {
@@ -738,10 +782,10 @@ __global__ void hist_pick_split_kernel(const double* __restrict__ out10, int num
 
 hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
                                   double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
-                                  double min_sum_hessian, double min_gain_to_split, const signed char* is_feature_used, double* out10,
+                                  double min_sum_hessian, double min_gain_to_split, SplitReg reg, const signed char* is_feature_used, double* out10,
                                   int* out_default_left, int* best_feature, hipStream_t st) {
   hipLaunchKernelGGL(hist_best_split_kernel, dim3(num_features), dim3(256), 0, st, hist, num_features, view_offset, num_bin, meta3,
-                     sum_gradient, sum_hessian, num_data, lambda_l2, min_data_in_leaf, min_sum_hessian, min_gain_to_split, out10,
+                     sum_gradient, sum_hessian, num_data, lambda_l2, min_data_in_leaf, min_sum_hessian, min_gain_to_split, reg, out10,
                      out_default_left);
   if (best_feature)      // the tree grower picks on the host from the per-feature candidates it needs anyway
     hipLaunchKernelGGL(hist_pick_split_kernel, dim3(1), dim3(64), 0, st, (const double*)out10, num_features, is_feature_used, best_feature);

@@ -395,6 +395,12 @@ class HistBuilder(object):
         a = [np.ascontiguousarray(x, dtype=np.int32) for x in (offset, default_bin, missing_type)]
         _shim_call(_lib().gpb_hip_hist_set_split_info(self.h, *[_p(x, C.c_int) for x in a]))
 
+    def set_regularisation(self, lambda_l1=0.0, max_delta_step=0.0, path_smooth=0.0, parent_output=0.0):
+        """lambda_l1 / max_delta_step / path_smooth of the split search (they stay set for find_best_split and grow_tree); parent_output: the
+        leaf's own output, for the following find_best_split calls (path smoothing; grow_tree tracks it itself)."""
+        _shim_call(_lib().gpb_hip_hist_set_regularisation(self.h, C.c_double(lambda_l1), C.c_double(max_delta_step), C.c_double(path_smooth),
+                                                          C.c_double(parent_output)))
+
     def find_best_split(self, slot, sum_gradient, sum_hessian, num_data, lambda_l2=0.0, min_data_in_leaf=20,
                         min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, is_feature_used=None):
         """-> (best_feature, out (F, 10), default_left (F,)): FeatureHistogram::FindBestThreshold per feature + the winner;

@@ -399,6 +399,14 @@ GPB_HIP_EXPORT int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* dat
                                            uint32_t threshold, int default_left, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count);
 GPB_HIP_EXPORT int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const int32_t* default_bin,
                                                const int32_t* missing_type);
+/* The other regularisation paths of the search (config lambda_l1, max_delta_step, path_smooth: feature_histogram.hpp:137-161 picks the template
+ * instance of FindBestThresholdSequentially; ThresholdL1 :737-741, CalculateSplittedLeafOutput :743-765, GetLeafGain :826-857).  They stay set on
+ * the handle for gpb_hip_hist_find_best_split and gpb_hip_hist_grow_tree; all zero (the default) is the plain lambda_l2 path.  parent_output is
+ * the `parent_output` argument of FindBestThreshold (:85-95) for the following gpb_hip_hist_find_best_split calls -- the leaf's own output,
+ * used by path smoothing only; gpb_hip_hist_grow_tree keeps track of it itself (SerialTreeLearner::GetParentOutput,
+ * serial_tree_learner.cpp:758-770). */
+GPB_HIP_EXPORT int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lambda_l1, double max_delta_step, double path_smooth,
+                                                   double parent_output);
 GPB_HIP_EXPORT int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data,
                                                 double lambda_l2, int32_t min_data_in_leaf, double min_sum_hessian_in_leaf,
                                                 double min_gain_to_split, const int8_t* is_feature_used, int32_t* best_feature,

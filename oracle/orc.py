@@ -287,8 +287,16 @@ def hist_subtract(parent, smaller):
     return out
 
 
+def root_parent_output(sum_gradient, sum_hessian, lambda_l1=0.0, lambda_l2=0.0, max_delta_step=0.0):
+    """SerialTreeLearner::GetParentOutput for the root: its own output without smoothing (serial_tree_learner.cpp:758-770)."""
+    lib().orc_root_parent_output.restype = C.c_double
+    return float(lib().orc_root_parent_output(C.c_double(sum_gradient), C.c_double(sum_hessian), C.c_double(lambda_l1), C.c_double(lambda_l2),
+                                              C.c_double(max_delta_step)))
+
+
 def find_best_split(hist, view_offset, num_bin, offset, default_bin, missing, sum_gradient, sum_hessian, num_data, lambda_l2=0.0,
-                    min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0):
+                    min_data_in_leaf=20, min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, lambda_l1=0.0, max_delta_step=0.0,
+                    path_smooth=0.0, parent_output=0.0):
     """FeatureHistogram::FindBestThreshold for every (numerical) feature + the choice among features.
     -> (best_feature, out (F, 10), default_left (F,)); columns of out: gain, threshold, left_count, right_count, left_output,
     right_output, left_sum_gradient, left_sum_hessian, right_sum_gradient, right_sum_hessian."""
@@ -296,10 +304,12 @@ def find_best_split(hist, view_offset, num_bin, offset, default_bin, missing, su
     arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (view_offset, num_bin, offset, default_bin, missing)]
     F = arrs[0].size
     out = np.zeros((F, 10)); dl = np.zeros(F, dtype=np.int32)
-    lib().orc_find_best_split.restype = C.c_int
-    best = lib().orc_find_best_split(_p(h, C.c_double), C.c_int(F), *[_p(a, C.c_int) for a in arrs], C.c_double(sum_gradient),
-                                     C.c_double(sum_hessian), C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
-                                     C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), _p(out, C.c_double), _p(dl, C.c_int))
+    lib().orc_find_best_split_reg.restype = C.c_int
+    best = lib().orc_find_best_split_reg(_p(h, C.c_double), C.c_int(F), *[_p(a, C.c_int) for a in arrs], C.c_double(sum_gradient),
+                                         C.c_double(sum_hessian), C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
+                                         C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), C.c_double(lambda_l1),
+                                         C.c_double(max_delta_step), C.c_double(path_smooth), C.c_double(parent_output),
+                                         _p(out, C.c_double), _p(dl, C.c_int))
     find_best_split.last_splittable = (dl >> 1) & 1
     return best, out, dl & 1
 

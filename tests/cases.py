@@ -147,6 +147,13 @@ TREE_CASES = {
     "plain_l15_reg": ("plain", "max_bin=63 num_leaves=15 min_data_in_leaf=40 lambda_l2=2.5 min_gain_to_split=0.05"),
     "nan_l20": ("nan", "max_bin=63 num_leaves=20 min_data_in_leaf=10 lambda_l2=0.1"),
     "zero_missing_l12": ("zero_missing", "max_bin=63 num_leaves=12 min_data_in_leaf=25 lambda_l2=0 zero_as_missing=true"),
+    # the other regularisation paths of FindBestThreshold (feature_histogram.hpp:137-161): L1, max_delta_step, path smoothing
+    "plain_l1": ("plain", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.5 lambda_l1=3.0"),
+    # (max_delta_step clips both children of many candidates to the same output: their gain is exactly 0 up to rounding noise, and a tree
+    #  that may split on a gain of 1e-13 depends on the last bits of the histogram sums -- min_gain_to_split keeps the case well-posed)
+    "plain_mds": ("plain", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0 max_delta_step=0.2 min_gain_to_split=0.05"),
+    "nan_smooth": ("nan", "max_bin=63 num_leaves=16 min_data_in_leaf=10 lambda_l2=0.1 path_smooth=25"),
+    "plain_all_reg": ("plain", "max_bin=255 num_leaves=20 min_data_in_leaf=20 lambda_l2=1.0 lambda_l1=1.5 max_delta_step=0.3 path_smooth=10 min_gain_to_split=0.01"),
 }
 TREE_COMMON = " min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=1 min_sum_hessian_in_leaf=0.001"
 
@@ -155,6 +162,9 @@ def tree_params(name):
     data, p = TREE_CASES[name]
     kv = dict(t.split("=") for t in p.split())
     cfg = (float(kv.get("lambda_l2", 0.0)), int(kv.get("min_data_in_leaf", 20)), 1e-3, float(kv.get("min_gain_to_split", 0.0)))
+    reg = (float(kv.get("lambda_l1", 0.0)), float(kv.get("max_delta_step", 0.0)), float(kv.get("path_smooth", 0.0)))
+    if any(v != 0.0 for v in reg):
+        cfg = cfg + reg
     return data, p + TREE_COMMON, int(kv["num_leaves"]), cfg
 
 

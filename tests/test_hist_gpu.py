@@ -251,7 +251,7 @@ def test_leaf_partition_against_reference_fixture(lib_built, name):
     hb.close()
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12"])
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     """The five device primitives (leaf histogram, FixHistogram, parent - smaller, split search, leaf partition), driven by the control
@@ -292,7 +292,7 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
         assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1]), nd
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12"])
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     """gpb_hip_hist_grow_tree (row lists of the leaves resident on the device, control flow in C++) against the reference's own
@@ -315,7 +315,9 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
     hb.set_gradients(grad, hs)
     sg = float(np.cumsum(grad)[-1]); sh = float(np.cumsum(np.ones(n) if hs is None else hs)[-1])
-    t = hb.grow_tree(L, sg, sh, *cfg)
+    if len(cfg) > 4:                      # lambda_l1, max_delta_step, path_smooth (the grower tracks parent_output itself)
+        hb.set_regularisation(cfg[4], cfg[5], cfg[6])
+    t = hb.grow_tree(L, sg, sh, *cfg[:4])
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):
         assert np.array_equal(t[key], g[k + key]), key
@@ -342,11 +344,11 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
         nleaves += 1
     assert np.array_equal(lab, dli)
     # a second tree on the same handle (workspaces are reused) gives the same result
-    t2 = hb.grow_tree(L, sg, sh, *cfg)
+    t2 = hb.grow_tree(L, sg, sh, *cfg[:4])
     assert np.array_equal(t2["data_leaf_index"], dli) and np.array_equal(t2["threshold_in_bin"], t["threshold_in_bin"])
     # data-parallel form with a 1-rank communicator: root sums, every new histogram and every left count go through ncclAllReduce
     hb.comm_init(shim.comm_unique_id(), 0, 1)
-    t3 = hb.grow_tree(L, sg, sh, *cfg)
+    t3 = hb.grow_tree(L, sg, sh, *cfg[:4])
     for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "data_leaf_index"):
         assert np.array_equal(t3[key], t[key]), key                     # (default_left: void ties, see the harness test above)
     np.testing.assert_allclose(t3["leaf_value"], t["leaf_value"], rtol=1e-10, atol=1e-13)

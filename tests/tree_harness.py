@@ -27,9 +27,9 @@ class OracleBackend(object):
     def subtract(self, parent, smaller, out):
         self.slots[out] = self.orc.hist_subtract(self.slots[parent], self.slots[smaller])
 
-    def search(self, slot, sg, sh, cnt, cfg, used):
+    def search(self, slot, sg, sh, cnt, cfg, used, parent_output=0.0):
         best, out, dl = self.orc.find_best_split(self.slots[slot], self.vo, self.nb, self.meta3[:, 0], self.meta3[:, 1], self.meta3[:, 2],
-                                                 sg, sh, cnt, *cfg)
+                                                 sg, sh, cnt, *cfg, parent_output=parent_output)
         return out, dl, self.orc.find_best_split.last_splittable.copy()
 
     def partition(self, idx, f, thr, dl):
@@ -53,8 +53,10 @@ class GpuBackend(object):
     def subtract(self, parent, smaller, out):
         self.hb.subtract_slots(parent, smaller, out)
 
-    def search(self, slot, sg, sh, cnt, cfg, used):
-        best, out, dl = self.hb.find_best_split(slot, sg, sh, cnt, *cfg)
+    def search(self, slot, sg, sh, cnt, cfg, used, parent_output=0.0):
+        if len(cfg) > 4:
+            self.hb.set_regularisation(cfg[4], cfg[5], cfg[6], parent_output)
+        best, out, dl = self.hb.find_best_split(slot, sg, sh, cnt, *cfg[:4])
         return out, dl, self.hb.last_splittable.copy()
 
     def partition(self, idx, f, thr, dl):
@@ -71,9 +73,23 @@ def _better(a, b):
     return a[0] > b[0] if a[0] != b[0] else fa < fb
 
 
+def root_parent_output(sg, sh, l1, l2, max_delta_step):
+    """SerialTreeLearner::GetParentOutput for the root (serial_tree_learner.cpp:758-770): its own output, L1 and max_delta_step applied,
+    no smoothing (feature_histogram.hpp:743-765)."""
+    if l1 > 0:
+        ret = -float(np.sign(sg)) * max(0.0, abs(sg) - l1) / (sh + l2)
+    else:
+        ret = -sg / (sh + l2)
+    if max_delta_step > 0 and abs(ret) > max_delta_step:
+        ret = float(np.sign(ret)) * max_delta_step
+    return ret
+
+
 def grow_tree(be, grad, hess, n, num_leaves, cfg):
-    """cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split).  Returns the same arrays ref_train_tree does."""
-    l2, min_data, min_hess, min_gain = cfg
+    """cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth]).
+    Returns the same arrays ref_train_tree does."""
+    l2, min_data, min_hess, min_gain = cfg[:4]
+    l1, mds, smooth = (cfg[4:7] if len(cfg) > 4 else (0.0, 0.0, 0.0))
     F = be.F
     hs = np.ones(n) if hess is None else hess
     # root sums: left-to-right summation (leaf_splits.hpp:73-86 with one thread)
@@ -85,10 +101,14 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg):
     splittable = {}
     slot_of = {0: 0}                             # leaf -> histogram slot; every split takes one new slot for the smaller child
     next_free = [1]
+    leaf_value = {0: 0.0}
+    nleaves = 1
 
     def search_leaf(leaf, used):
         g_, h_ = sums[leaf]
-        out, dl, spl = be.search(slot_of[leaf], g_, h_, cnt[leaf], cfg, used)
+        # parent_output of FindBestThreshold: the leaf's own output (LeafSplits::weight), the root's unsmoothed output for the root
+        po = root_parent_output(g_, h_, l1, l2, mds) if nleaves == 1 else leaf_value[leaf]
+        out, dl, spl = be.search(slot_of[leaf], g_, h_, cnt[leaf], cfg, used, po)
         spl = np.where(used > 0, spl, 0)
         top = (-np.inf, -1); row = None
         for f in range(F):
@@ -104,10 +124,8 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg):
     search_leaf(0, np.ones(F, dtype=np.int8))
     nodes = dict(split_feature_inner=[], threshold_in_bin=[], default_left=[], left_child=[], right_child=[], split_gain=[], internal_count=[])
     node_rows = []                               # rows of the leaf each node split (for the tests' tie analysis)
-    leaf_value = {0: 0.0}
     leaf_parent_node = {0: -1}
     leaf_is_left = {0: True}
-    nleaves = 1
     left = right = None
     for split in range(num_leaves - 1):
         if split > 0:
