@@ -24,7 +24,8 @@ LIBP = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
 print("library:", LIBP, flush=True)
 
 # ---- (1) GP ---------------------------------------------------------------------------------------------------------------------
-for n, m, d in ((20000, 30, 2), (100000, 30, 2), (5000, 70, 5)):          # the last one: d = 5, m = 70 -> the library's generality kernels
+GP_CASES = () if "--trees-only" in sys.argv else ((20000, 30, 2), (100000, 30, 2), (5000, 70, 5))   # the last one: d = 5, m = 70 -> the library's generality kernels
+for n, m, d in GP_CASES:
     coords, _ = cases.synthetic(n, d, seed=3)
     rng = np.random.default_rng(5)
     y = np.sin(4 * coords[:, 0]) + 0.5 * rng.standard_normal(n)
@@ -67,8 +68,13 @@ def ok(rc):
 
 
 NIT = 20
-for n, F, variants in ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8"))),
-                       (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", "")))):
+REG = " lambda_l1=2 lambda_l2=1 max_delta_step=0.5 path_smooth=20 min_gain_to_split=0.01"      # the other regularisation paths of the split search
+SIZES = ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8"),
+                       ("cpu_reg", "cpu", REG), ("gpu_reg", "gpu", REG))),
+         (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""))))
+if "--trees-only" in sys.argv:
+    SIZES = SIZES[:1]
+for n, F, variants in SIZES:
   rng = np.random.default_rng(1)
   X = np.ascontiguousarray(rng.uniform(size=(n, F)))
   yb = (np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + 0.5 * rng.standard_normal(n)).astype(np.float32)
@@ -99,5 +105,8 @@ for n, F, variants in ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("g
   np.testing.assert_allclose(pred["gpu"], pred["cpu"], rtol=0, atol=1e-9)
   if "gpu_maxdepth" in pred:
     np.testing.assert_allclose(pred["gpu_maxdepth"], pred["cpu_maxdepth"], rtol=0, atol=1e-9)
+  if "gpu_reg" in pred:
+    np.testing.assert_allclose(pred["gpu_reg"], pred["cpu_reg"], rtol=0, atol=1e-9)
+    print("trees with lambda_l1 / max_delta_step / path_smooth: whole trees on the device reproduce device_type=cpu, max |diff| = %.2e" % np.abs(pred["gpu_reg"] - pred["cpu_reg"]).max(), flush=True)
   print("trees (n = %d): device_type=gpu (HIPTreeLearner, whole trees) reproduces device_type=cpu, max |diff| = %.2e" % (n, np.abs(pred["gpu"] - pred["cpu"]).max()), flush=True)
 print("ROUTE B ON MI355X: OK", flush=True)
