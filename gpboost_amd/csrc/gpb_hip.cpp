@@ -132,6 +132,7 @@ struct gpb_hip_hist {
   int num_cu = 0;                                          // compute units of the device (chunking of the build kernel)
   // regularisation of the split search beyond lambda_l2 (gpb_hip_hist_set_regularisation); parent_output: of the next single-leaf searches
   double reg_l1 = 0., reg_max_delta_step = 0., reg_path_smooth = 0., reg_parent_output = 0.;
+  int max_depth = 0;                                       // depth limit of gpb_hip_hist_grow_tree (<= 0: none)
   uint8_t* d_bins_rm = nullptr;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
@@ -1491,6 +1492,13 @@ int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lambda_l1, double 
   if (!(lambda_l1 >= 0.0) || !(path_smooth >= 0.0) || !std::isfinite(max_delta_step) || !std::isfinite(parent_output))
     return fail("gpb_hip_hist_set_regularisation: lambda_l1 and path_smooth must be >= 0 (got %g, %g), max_delta_step and parent_output finite", lambda_l1, path_smooth);
   h->reg_l1 = lambda_l1; h->reg_max_delta_step = max_delta_step; h->reg_path_smooth = path_smooth; h->reg_parent_output = parent_output;
+  API_END();
+}
+
+int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  h->max_depth = max_depth;
   API_END();
 }
 

@@ -401,6 +401,10 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_set_regularisation(self.h, C.c_double(lambda_l1), C.c_double(max_delta_step), C.c_double(path_smooth),
                                                           C.c_double(parent_output)))
 
+    def set_max_depth(self, max_depth):
+        """config max_depth of grow_tree (<= 0: no limit)."""
+        _shim_call(_lib().gpb_hip_hist_set_max_depth(self.h, C.c_int(int(max_depth))))
+
     def find_best_split(self, slot, sum_gradient, sum_hessian, num_data, lambda_l2=0.0, min_data_in_leaf=20,
                         min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, is_feature_used=None):
         """-> (best_feature, out (F, 10), default_left (F,)): FeatureHistogram::FindBestThreshold per feature + the winner;

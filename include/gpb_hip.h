@@ -407,6 +407,9 @@ GPB_HIP_EXPORT int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t*
  * serial_tree_learner.cpp:758-770). */
 GPB_HIP_EXPORT int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lambda_l1, double max_delta_step, double path_smooth,
                                                    double parent_output);
+/* config max_depth for gpb_hip_hist_grow_tree (<= 0: no limit): the children of a split at depth max_depth - 1 are not searched
+ * (SerialTreeLearner::BeforeFindBestSplit, serial_tree_learner.cpp:286-295). */
+GPB_HIP_EXPORT int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth);
 GPB_HIP_EXPORT int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data,
                                                 double lambda_l2, int32_t min_data_in_leaf, double min_sum_hessian_in_leaf,
                                                 double min_gain_to_split, const int8_t* is_feature_used, int32_t* best_feature,

@@ -153,6 +153,7 @@ TREE_CASES = {
     #  that may split on a gain of 1e-13 depends on the last bits of the histogram sums -- min_gain_to_split keeps the case well-posed)
     "plain_mds": ("plain", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0 max_delta_step=0.2 min_gain_to_split=0.05"),
     "nan_smooth": ("nan", "max_bin=63 num_leaves=16 min_data_in_leaf=10 lambda_l2=0.1 path_smooth=25"),
+    "plain_depth4": ("plain", "max_bin=63 num_leaves=31 min_data_in_leaf=20 lambda_l2=0 max_depth=4"),
     "plain_all_reg": ("plain", "max_bin=255 num_leaves=20 min_data_in_leaf=20 lambda_l2=1.0 lambda_l1=1.5 max_delta_step=0.3 path_smooth=10 min_gain_to_split=0.01"),
 }
 TREE_COMMON = " min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=1 min_sum_hessian_in_leaf=0.001"
@@ -166,6 +167,11 @@ def tree_params(name):
     if any(v != 0.0 for v in reg):
         cfg = cfg + reg
     return data, p + TREE_COMMON, int(kv["num_leaves"]), cfg
+
+
+def tree_max_depth(name):
+    kv = dict(t.split("=") for t in TREE_CASES[name][1].split())
+    return int(kv.get("max_depth", 0))
 
 
 # Newton leaf update (row a9): leaf assignment per DATA point for the golden cases that carry a "leaf_values_*" entry

@@ -251,7 +251,7 @@ def test_leaf_partition_against_reference_fixture(lib_built, name):
     hb.close()
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg"])
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     """The five device primitives (leaf histogram, FixHistogram, parent - smaller, split search, leaf partition), driven by the control
@@ -269,7 +269,7 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     hs = hess if hi else None
     be = th.GpuBackend(shim, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
                        g[k + "meta3"], grad, hs, L)
-    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg)
+    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg, max_depth=cases.tree_max_depth(name))
     be.close()
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):
@@ -292,7 +292,7 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
         assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1]), nd
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg"])
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     """gpb_hip_hist_grow_tree (row lists of the leaves resident on the device, control flow in C++) against the reference's own
@@ -317,6 +317,7 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     sg = float(np.cumsum(grad)[-1]); sh = float(np.cumsum(np.ones(n) if hs is None else hs)[-1])
     if len(cfg) > 4:                      # lambda_l1, max_delta_step, path_smooth (the grower tracks parent_output itself)
         hb.set_regularisation(cfg[4], cfg[5], cfg[6])
+    hb.set_max_depth(cases.tree_max_depth(name))
     t = hb.grow_tree(L, sg, sh, *cfg[:4])
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):

@@ -415,7 +415,7 @@ def test_oracle_primitives_grow_the_reference_tree(orc, name, hi):
     hs = hess if hi else None
     be = th.OracleBackend(orc, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
                           g[k + "meta3"], grad, hs)
-    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg)
+    t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg, max_depth=cases.tree_max_depth(name))
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count", "leaf_count"):
         assert np.array_equal(t[key], g[k + key]), key

@@ -85,7 +85,7 @@ def root_parent_output(sg, sh, l1, l2, max_delta_step):
     return ret
 
 
-def grow_tree(be, grad, hess, n, num_leaves, cfg):
+def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0):
     """cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth]).
     Returns the same arrays ref_train_tree does."""
     l2, min_data, min_hess, min_gain = cfg[:4]
@@ -127,10 +127,14 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg):
     leaf_parent_node = {0: -1}
     leaf_is_left = {0: True}
     left = right = None
+    leaf_depth = {0: 0}
     for split in range(num_leaves - 1):
         if split > 0:
             nl_, nr_ = cnt[left], cnt[right]
-            if nr_ < 2 * min_data and nl_ < 2 * min_data:                      # BeforeFindBestSplit :296-306
+            if max_depth > 0 and leaf_depth[left] >= max_depth:                # BeforeFindBestSplit :286-295
+                best[left] = dict(gain=-np.inf, feature=best.get(left, {}).get("feature", -1), row=None)
+                best[right] = dict(gain=-np.inf, feature=-1, row=None)
+            elif nr_ < 2 * min_data and nl_ < 2 * min_data:                    # BeforeFindBestSplit :296-306
                 best[left] = dict(gain=-np.inf, feature=best.get(left, {}).get("feature", -1), row=None)
                 best[right] = dict(gain=-np.inf, feature=-1, row=None)
             else:
@@ -176,6 +180,7 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg):
         cnt[left], cnt[right] = len(lte), len(gt)                                # update_cnt (:591-595)
         sums[left], sums[right] = (row[6], row[7]), (row[8], row[9])
         leaf_value[left], leaf_value[right] = row[4], row[5]
+        leaf_depth[left] = leaf_depth[right] = leaf_depth[top_leaf] + 1
         nleaves += 1
     out = {k: np.asarray(v) for k, v in nodes.items()}
     out["num_leaves"] = nleaves
