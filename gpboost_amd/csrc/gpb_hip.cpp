@@ -133,6 +133,7 @@ struct gpb_hip_hist {
   // regularisation of the split search beyond lambda_l2 (gpb_hip_hist_set_regularisation); parent_output: of the next single-leaf searches
   double reg_l1 = 0., reg_max_delta_step = 0., reg_path_smooth = 0., reg_parent_output = 0.;
   int max_depth = 0;                                       // depth limit of gpb_hip_hist_grow_tree (<= 0: none)
+  std::vector<signed char> feature_mask;                   // columns the next trees may split on (empty: all)
   uint8_t* d_bins_rm = nullptr;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
@@ -1499,6 +1500,14 @@ int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth) {
   API_BEGIN();
   if (!h) return fail("null argument");
   h->max_depth = max_depth;
+  API_END();
+}
+
+int gpb_hip_hist_set_feature_mask(gpb_hip_hist_t* h, const int8_t* is_feature_used) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  if (!is_feature_used) h->feature_mask.clear();
+  else h->feature_mask.assign(is_feature_used, is_feature_used + h->F);
   API_END();
 }
 

@@ -401,6 +401,13 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_set_regularisation(self.h, C.c_double(lambda_l1), C.c_double(max_delta_step), C.c_double(path_smooth),
                                                           C.c_double(parent_output)))
 
+    def set_feature_mask(self, is_feature_used=None):
+        """The columns grow_tree may split on (feature_fraction's per-tree sample); None = all."""
+        m = None if is_feature_used is None else np.ascontiguousarray(is_feature_used, dtype=np.int8)
+        if m is not None and m.size != self.F:
+            raise ValueError("is_feature_used must have one flag per feature")
+        _shim_call(_lib().gpb_hip_hist_set_feature_mask(self.h, _p(m, C.c_int8)))
+
     def set_max_depth(self, max_depth):
         """config max_depth of grow_tree (<= 0: no limit)."""
         _shim_call(_lib().gpb_hip_hist_set_max_depth(self.h, C.c_int(int(max_depth))))

@@ -410,6 +410,9 @@ GPB_HIP_EXPORT int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lam
 /* config max_depth for gpb_hip_hist_grow_tree (<= 0: no limit): the children of a split at depth max_depth - 1 are not searched
  * (SerialTreeLearner::BeforeFindBestSplit, serial_tree_learner.cpp:286-295). */
 GPB_HIP_EXPORT int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth);
+/* The columns gpb_hip_hist_grow_tree may split on (config feature_fraction: ColSampler::is_feature_used_bytree(), col_sampler.hpp:181; the
+ * caller samples, as the reference's learner does in BeforeTrain, serial_tree_learner.cpp:258): F flags by inner feature index, NULL = all. */
+GPB_HIP_EXPORT int gpb_hip_hist_set_feature_mask(gpb_hip_hist_t* h, const int8_t* is_feature_used);
 GPB_HIP_EXPORT int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gradient, double sum_hessian, int32_t num_data,
                                                 double lambda_l2, int32_t min_data_in_leaf, double min_sum_hessian_in_leaf,
                                                 double min_gain_to_split, const int8_t* is_feature_used, int32_t* best_feature,

@@ -71,6 +71,10 @@ class HIPTreeLearner : public SerialTreeLearner {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
     if (gpb_hip_hist_set_max_depth(hist_, config_->max_depth)) Log::Fatal("%s", gpb_hip_get_last_error());
+    // feature_fraction: the columns col_sampler_ drew for this tree in BeforeTrain (serial_tree_learner.cpp:258)
+    if (gpb_hip_hist_set_feature_mask(hist_, config_->feature_fraction < 1.0 ? col_sampler_.is_feature_used_bytree().data() : nullptr)) {
+      Log::Fatal("%s", gpb_hip_get_last_error());
+    }
     if (gpb_hip_hist_grow_tree(hist_, L, smaller_leaf_splits_->sum_gradients(), smaller_leaf_splits_->sum_hessians(), config_->lambda_l2,
                                config_->min_data_in_leaf, config_->min_sum_hessian_in_leaf, config_->min_gain_to_split,
                                const_hess ? static_cast<double>(hessians_[0]) : 1.0, &nl, sf.data(), thr.data(), dl.data(), lc.data(), rc.data(),
@@ -167,10 +171,10 @@ class HIPTreeLearner : public SerialTreeLearner {
   }
 
   // the configuration gpb_hip_hist_grow_tree restates: every regularisation path of the numerical threshold search (lambda_l1, lambda_l2,
-  // max_delta_step, path_smooth) and max_depth, nothing that changes the candidate set per node
+  // max_delta_step, path_smooth), max_depth and the per-tree column sample; nothing that changes the candidate set per node
   bool WholeTreeConfig() const {
     return config_->num_leaves >= 2 && config_->lambda_l1 >= 0.0 &&
-           !config_->extra_trees && !config_->linear_tree && config_->feature_fraction >= 1.0 &&
+           !config_->extra_trees && !config_->linear_tree &&
            config_->feature_fraction_bynode >= 1.0 && config_->monotone_constraints.empty() && config_->interaction_constraints_vector.empty() &&
            (forced_split_json_ == nullptr || forced_split_json_->is_null()) && cegb_ == nullptr && num_data_ == train_data_->num_data();
   }

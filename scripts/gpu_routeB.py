@@ -7,8 +7,8 @@ through its unchanged C API -- with the patched seams calling lib_gpboost_amd.so
      after the fit (the optimiser's evaluations run fused on the device; the host factor is built once at the final parameters).
  (2) GPBoost-free LightGBM boosting: LGBM_BoosterUpdateOneIter with device_type = gpu (-> HIPTreeLearner, histograms on the device)
      against device_type = cpu: predictions after 20 iterations agree to 1e-9 -- once with whole trees grown on the device
-     (HIPTreeLearner::Train -> gpb_hip_hist_grow_tree; also with max_depth and with lambda_l1 / max_delta_step / path_smooth) and once with
-     feature_fraction < 1 (not restated: SerialTreeLearner::Train + device histograms)."""
+     (HIPTreeLearner::Train -> gpb_hip_hist_grow_tree; also with max_depth, feature_fraction and lambda_l1 / max_delta_step / path_smooth) and once
+     with feature_fraction_bynode < 1 (not restated: SerialTreeLearner::Train + device histograms)."""
 import ctypes as C
 import os
 import sys
@@ -72,7 +72,8 @@ NIT = 20
 REG = " lambda_l1=2 lambda_l2=1 max_delta_step=0.5 path_smooth=20 min_gain_to_split=0.01"      # the other regularisation paths of the split search
 SIZES = ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8"),
                        ("cpu_reg", "cpu", REG), ("gpu_reg", "gpu", REG),
-                       ("cpu_colsample", "cpu", " feature_fraction=0.8"), ("gpu_colsample", "gpu", " feature_fraction=0.8"))),
+                       ("cpu_colsample", "cpu", " feature_fraction=0.8"), ("gpu_colsample", "gpu", " feature_fraction=0.8"),
+                       ("cpu_bynode", "cpu", " feature_fraction_bynode=0.8"), ("gpu_bynode", "gpu", " feature_fraction_bynode=0.8"))),
          (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""))))
 if "--trees-only" in sys.argv:
     SIZES = SIZES[:1]
@@ -107,8 +108,10 @@ for n, F, variants in SIZES:
   np.testing.assert_allclose(pred["gpu"], pred["cpu"], rtol=0, atol=1e-9)
   if "gpu_maxdepth" in pred:
     np.testing.assert_allclose(pred["gpu_maxdepth"], pred["cpu_maxdepth"], rtol=0, atol=1e-9)
-  if "gpu_colsample" in pred:      # column sampling is not restated by the device grower: SerialTreeLearner::Train + device histograms
+  if "gpu_colsample" in pred:      # the per-tree column sample of the reference's ColSampler is handed to the device grower
     np.testing.assert_allclose(pred["gpu_colsample"], pred["cpu_colsample"], rtol=0, atol=1e-9)
+  if "gpu_bynode" in pred:         # per-node column sampling is not restated by the device grower: SerialTreeLearner::Train + device histograms
+    np.testing.assert_allclose(pred["gpu_bynode"], pred["cpu_bynode"], rtol=0, atol=1e-9)
   if "gpu_reg" in pred:
     np.testing.assert_allclose(pred["gpu_reg"], pred["cpu_reg"], rtol=0, atol=1e-9)
     print("trees with lambda_l1 / max_delta_step / path_smooth: whole trees on the device reproduce device_type=cpu, max |diff| = %.2e" % np.abs(pred["gpu_reg"] - pred["cpu_reg"]).max(), flush=True)

@@ -354,3 +354,46 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
         assert np.array_equal(t3[key], t[key]), key                     # (default_left: void ties, see the harness test above)
     np.testing.assert_allclose(t3["leaf_value"], t["leaf_value"], rtol=1e-10, atol=1e-13)
     hb.close()
+
+
+def test_tree_grower_with_a_column_sample_and_a_depth_limit(lib_built):
+    """feature_fraction's per-tree column sample (gpb_hip_hist_set_feature_mask) and max_depth in the resident grower against the control flow of
+    SerialTreeLearner::Train over the ORACLE's primitives (tests/tree_harness.py) with the same mask: masked columns never split, the rest of the
+    tree is the reference's choice among the remaining ones."""
+    import os
+    from gpboost_amd import shim
+    from oracle import orc
+    from tests import cases
+    from tests import tree_harness as th
+    name, hi = "plain_l31", 0
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    n = X.shape[0]
+    k = "%s_hess%d_" % (name, hi)
+    bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+    F = bins.shape[0]
+    mask = np.ones(F, dtype=np.int8)
+    mask[int(g[k + "split_feature_inner"][0])] = 0              # the root's own choice is not available
+    mask[F - 1] = 0
+    ob = th.OracleBackend(orc, bins, gnb, g[k + "view_offset"], g[k + "num_bin"], mfb, meta3, grad, None)
+    ref = th.grow_tree(ob, grad, None, n, L, cfg, max_depth=5, feature_mask=mask)
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(L + 1)
+    hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    hb.set_gradients(grad, None)
+    hb.set_feature_mask(mask)
+    hb.set_max_depth(5)
+    sg = float(np.cumsum(grad)[-1]); sh = float(n)
+    t = hb.grow_tree(L, sg, sh, *cfg[:4])
+    assert t["num_leaves"] == ref["num_leaves"] and t["num_leaves"] > 8
+    assert not np.any(mask[t["split_feature_inner"]] == 0)
+    for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "default_left"):
+        assert np.array_equal(t[key], ref[key]), key
+    np.testing.assert_allclose(t["leaf_value"], ref["leaf_value"], rtol=1e-9, atol=1e-12)
+    hb.set_feature_mask(None); hb.set_max_depth(0)              # back to the unrestricted tree of the fixture
+    t0 = hb.grow_tree(L, sg, sh, *cfg[:4])
+    assert np.array_equal(t0["split_feature_inner"], g[k + "split_feature_inner"])
+    hb.close()

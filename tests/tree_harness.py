@@ -85,7 +85,7 @@ def root_parent_output(sg, sh, l1, l2, max_delta_step):
     return ret
 
 
-def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0):
+def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None):
     """cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth]).
     Returns the same arrays ref_train_tree does."""
     l2, min_data, min_hess, min_gain = cfg[:4]
@@ -121,7 +121,9 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0):
         splittable[leaf] = spl
 
     be.build_fix(0, None, sg, sh)
-    search_leaf(0, np.ones(F, dtype=np.int8))
+    # feature_fraction: the tree's sampled columns (ColSampler::is_feature_used_bytree, serial_tree_learner.cpp:329); children inherit the mask
+    # through the parent's is_splittable flags
+    search_leaf(0, np.ones(F, dtype=np.int8) if feature_mask is None else np.asarray(feature_mask, dtype=np.int8))
     nodes = dict(split_feature_inner=[], threshold_in_bin=[], default_left=[], left_child=[], right_child=[], split_gain=[], internal_count=[])
     node_rows = []                               # rows of the leaf each node split (for the tests' tie analysis)
     leaf_parent_node = {0: -1}
