@@ -350,10 +350,10 @@ def main():
                     # B' and B triangular solves of the preconditioner: 16-byte {coefficient, source} entries + one 16-byte slot record per row
                     # and pass) and ~10 n-vectors: what it would cost at the HBM rate against what the level-scheduled solves take
                     "roofline_cg_iteration": (lambda byt, ms: {
-                        "bound": "hbm", "kernel": "lap_tri_spmv_kernel x2 + lap_sptrsv_kernel (389 dependency levels each way) + cg_* vector kernels",
+                        "bound": "hbm", "kernel": "lap_tri_spmv_kernel x2 + triangular solves (dense block of the ~270 narrow levels: lap_dense_matvec_kernel, 268 MB at ~5.6 TB/s; lap_sptrsv_kernel for the ~118 wide levels each way) + cg_* vector kernels",
                         "algorithmic_bytes_per_iteration": byt, "ms_per_iteration": ms, "achieved": byt / (ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "note": "latency-bound, not bandwidth-bound: ~140 dependent launches per iteration (DESIGN.md 4.6)"})(
+                        "note": "latency-bound, not bandwidth-bound: ~240 dependent launches of 5-8 us per iteration for the wide levels (DESIGN.md 4.6); algorithmic bytes do not count the dense inverse blocks (2 x 268 MB per iteration), which replace ~540 dependent level steps"})(
                         4 * n4 * (30 * 16 + 16) + 10 * n4 * 8, i4["ms_mode"] / max(i4["cg_it"], 1)),
                     "reference_timing": "not timed here: tests/golden/config4_ref.npz holds the unmodified reference's value and its wall time for the same-size fixture (seconds_0; 8 cores of the build container)"}
                 del m4
