@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void vecchia_point_kernel(VecchiaKernelArgs ar
   constexpr int NSTEP = num_lower_steps<MT>();
   // (Tried in round 2: the last 13 steps' values in registers + __launch_bounds__(256, 3), so that three workgroups -- 12 wavefronts instead of
   // 8 -- share a CU: the compiler needs 241 VGPRs for that form, capped at 168 it spills 12 doubles to scratch, and the kernel got 13 % SLOWER.)
+  // (Also tried: amdgpu_waves_per_eu(5, 5) on the likelihood kernel -- 102 -> 96 VGPRs, five wavefronts per SIMD instead of four, 84 bytes of
+  // scratch per lane: 0.89 -> 1.10 ms.  Any spill to scratch costs more than the extra wavefront hides.)
   constexpr bool kLastDkInReg = kStoreDK && D3;      // d = 3: 32-byte records; the last step's value stays in a register so that two workgroups fit a CU's 160 KB
   constexpr int NSTORE = kStoreDK ? (kLastDkInReg ? NSTEP - 1 : NSTEP) : 1;
   constexpr int PSTRIDE = D3 ? L::PTS_STRIDE : L::PTS_STRIDE24;
