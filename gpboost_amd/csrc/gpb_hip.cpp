@@ -134,6 +134,7 @@ struct gpb_hip_hist {
   double reg_l1 = 0., reg_max_delta_step = 0., reg_path_smooth = 0., reg_parent_output = 0.;
   int max_depth = 0;                                       // depth limit of gpb_hip_hist_grow_tree (<= 0: none)
   std::vector<signed char> feature_mask;                   // columns the next trees may split on (empty: all)
+  int* d_root_rows = nullptr; int root_cnt = 0;            // bagging: the rows of the root of the next trees (root_cnt = 0: all rows)
   uint8_t* d_bins_rm = nullptr;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
@@ -1236,7 +1237,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt); dev_free(h->d_absmax);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
-  dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_rows2); dev_free(h->d_counts);
+  dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_rows2); dev_free(h->d_counts); dev_free(h->d_root_rows);
   if (h->h_counts) (void)hipHostFree(h->h_counts); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
   if (h->h_split2) (void)hipHostFree(h->h_split2);
   if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
@@ -1500,6 +1501,21 @@ int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth) {
   API_BEGIN();
   if (!h) return fail("null argument");
   h->max_depth = max_depth;
+  API_END();
+}
+
+int gpb_hip_hist_set_root_rows(gpb_hip_hist_t* h, const int32_t* rows, int32_t cnt) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  if (!rows || cnt <= 0) { h->root_cnt = 0; return 0; }
+  if (cnt > h->n) return fail("gpb_hip_hist_set_root_rows: %d rows, the handle holds %d", cnt, h->n);
+  for (int i = 0; i < cnt; ++i)
+    if (rows[i] < 0 || rows[i] >= h->n || (i > 0 && rows[i] <= rows[i - 1])) return fail("gpb_hip_hist_set_root_rows: rows must be ascending row indices in [0, %d)", h->n);
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->d_root_rows) HIP_OK(hipMalloc(&h->d_root_rows, sizeof(int) * (size_t)h->n));
+  HIP_OK(hipMemcpyAsync(h->d_root_rows, rows, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->root_cnt = cnt;
   API_END();
 }
 

@@ -401,6 +401,11 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_set_regularisation(self.h, C.c_double(lambda_l1), C.c_double(max_delta_step), C.c_double(path_smooth),
                                                           C.c_double(parent_output)))
 
+    def set_root_rows(self, rows=None):
+        """Bagging: the (ascending) rows the root of the following trees holds; None = all rows."""
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+        _shim_call(_lib().gpb_hip_hist_set_root_rows(self.h, _p(r, C.c_int), C.c_int(0 if r is None else r.size)))
+
     def set_feature_mask(self, is_feature_used=None):
         """The columns grow_tree may split on (feature_fraction's per-tree sample); None = all."""
         m = None if is_feature_used is None else np.ascontiguousarray(is_feature_used, dtype=np.int8)

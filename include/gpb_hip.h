@@ -410,6 +410,10 @@ GPB_HIP_EXPORT int gpb_hip_hist_set_regularisation(gpb_hip_hist_t* h, double lam
 /* config max_depth for gpb_hip_hist_grow_tree (<= 0: no limit): the children of a split at depth max_depth - 1 are not searched
  * (SerialTreeLearner::BeforeFindBestSplit, serial_tree_learner.cpp:286-295). */
 GPB_HIP_EXPORT int gpb_hip_hist_set_max_depth(gpb_hip_hist_t* h, int32_t max_depth);
+/* Bagging: the rows the root of the following trees holds (ascending row indices; NULL or cnt <= 0: all rows) -- what
+ * DataPartition::SetUsedDataIndices / Init do for the reference's learner (data_partition.hpp:57-63, serial_tree_learner.cpp SetBaggingData).
+ * The caller passes the bag's own sum_gradient / sum_hessian to gpb_hip_hist_grow_tree; data_leaf_index is -1 for rows outside the bag. */
+GPB_HIP_EXPORT int gpb_hip_hist_set_root_rows(gpb_hip_hist_t* h, const int32_t* rows, int32_t cnt);
 /* The columns gpb_hip_hist_grow_tree may split on (config feature_fraction: ColSampler::is_feature_used_bytree(), col_sampler.hpp:181; the
  * caller samples, as the reference's learner does in BeforeTrain, serial_tree_learner.cpp:258): F flags by inner feature index, NULL = all. */
 GPB_HIP_EXPORT int gpb_hip_hist_set_feature_mask(gpb_hip_hist_t* h, const int8_t* is_feature_used);

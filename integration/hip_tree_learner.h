@@ -46,24 +46,49 @@ class HIPTreeLearner : public SerialTreeLearner {
 
   void ResetTrainingDataInner(const Dataset* train_data, bool is_constant_hessian, bool reset_multi_val_bin) override {
     SerialTreeLearner::ResetTrainingDataInner(train_data, is_constant_hessian, reset_multi_val_bin);
-    CreateDeviceBins();
+    if (!keep_device_bins_) { CreateDeviceBins(); subset_bins_ = false; bag_is_subset_ = false; bag_rows_ = nullptr; bag_cnt_ = 0; }
   }
 
   void SetBaggingData(const Dataset* subset, const data_size_t* used_indices, data_size_t num_data) override {
+    // Two forms of bagging (gbdt.cpp:925-945): on the full Dataset (subset == nullptr; bags above half of the rows per iteration) and on a copied
+    // subset Dataset (small bags), whose rows are renumbered 0 .. num_data - 1 and whose gradients arrive compacted.  The device keeps the bins
+    // of the FULL data in both: the grower starts from the bag's rows (gpb_hip_hist_set_root_rows); for a subset the compact gradients are
+    // spread to full row positions (BeforeTrain) and the returned row labels are read at the bag's rows.  If whole trees cannot be grown on
+    // the device for this configuration, a subset gets its own device bins as before (the reference's Train over device histograms).
+    const bool unified = subset != nullptr && hist_ != nullptr && whole_tree_ok_ && !subset_bins_ && WholeTreeConfigOnly() && used_indices != nullptr &&
+                         Ascending(used_indices, num_data) && used_indices[num_data - 1] < hist_rows_;
+    keep_device_bins_ = unified;
     SerialTreeLearner::SetBaggingData(subset, used_indices, num_data);
-    bagging_ = used_indices != nullptr && num_data != train_data_->num_data();
+    keep_device_bins_ = false;
+    bag_rows_ = nullptr; bag_cnt_ = 0; bag_is_subset_ = false;
+    bagging_ = false;
+    if (subset != nullptr) {
+      if (unified) { bag_rows_ = used_indices; bag_cnt_ = num_data; bag_is_subset_ = true; }
+      else { bagging_ = true; subset_bins_ = true; }
+    } else if (used_indices != nullptr && hist_ != nullptr && num_data < hist_rows_) {
+      if (Ascending(used_indices, num_data)) { bag_rows_ = used_indices; bag_cnt_ = num_data; } else { bagging_ = true; }
+    }
+    bag_dirty_ = true;
   }
 
   Tree* Train(const score_t* gradients, const score_t* hessians, bool is_first_tree) override {
+    if (bag_is_subset_ && !WholeTreeConfig()) {      // (the configuration changed under a subset bag: give the subset its own device bins)
+      bag_is_subset_ = false; bag_rows_ = nullptr; bag_cnt_ = 0; bagging_ = true; subset_bins_ = true;
+      CreateDeviceBins();
+    }
     if (!hist_ || !whole_tree_ok_ || bagging_ || !WholeTreeConfig()) return SerialTreeLearner::Train(gradients, hessians, is_first_tree);
     if (!announced_) { Log::Info("HIPTreeLearner: whole trees are grown on the GPU (gpb_hip_hist_grow_tree)"); announced_ = true; }
     gradients_ = gradients;
     hessians_ = hessians;
     BeforeTrain();                                   // root sums (LeafSplits::Init), data partition reset, gradient upload (override below)
+    if (bag_dirty_) {                                // the bag changes every bagging_freq iterations: one upload then
+      if (gpb_hip_hist_set_root_rows(hist_, bag_rows_, bag_cnt_)) Log::Fatal("%s", gpb_hip_get_last_error());
+      bag_dirty_ = false;
+    }
     const int L = config_->num_leaves;
     const bool const_hess = share_state_->is_constant_hessian;
     int32_t nl = 0;
-    std::vector<int32_t> sf(L), dl(L), lc(L), rc(L), icnt(L), lcnt(L), leaf_of_row(num_data_);
+    std::vector<int32_t> sf(L), dl(L), lc(L), rc(L), icnt(L), lcnt(L), leaf_of_row(hist_rows_);
     std::vector<uint32_t> thr(L);
     std::vector<double> gain(L), lval(L);
     if (gpb_hip_hist_set_regularisation(hist_, config_->lambda_l1, config_->max_delta_step > 0.0 ? config_->max_delta_step : 0.0,
@@ -93,7 +118,21 @@ class HIPTreeLearner : public SerialTreeLearner {
                   static_cast<int>(info[6 * k + 2]), static_cast<int>(info[6 * k + 3]), info[6 * k + 4], info[6 * k + 5], static_cast<float>(gain[k]),
                   train_data_->FeatureBinMapper(inner)->missing_type(), dl[k] != 0);
     }
-    data_partition_->ResetByLeafPred(std::vector<int>(leaf_of_row.begin(), leaf_of_row.end()), nl);
+    if (bag_rows_ == nullptr) {
+      data_partition_->ResetByLeafPred(std::vector<int>(leaf_of_row.begin(), leaf_of_row.end()), nl);
+    } else if (bag_is_subset_) {                     // the subset Dataset numbers its rows by position in the bag
+      std::vector<int> pred(bag_cnt_);
+      for (data_size_t k = 0; k < bag_cnt_; ++k) pred[k] = leaf_of_row[bag_rows_[k]];
+      data_partition_->ResetByLeafPred(pred, nl);
+    } else {
+      // the partition of the BAG (what AddPredictionToScore and the leaf refits walk): ResetByLeafPred numbers positions, here positions in
+      // the bag -> mapped to row indices in place
+      std::vector<int> pred(bag_cnt_);
+      for (data_size_t k = 0; k < bag_cnt_; ++k) pred[k] = leaf_of_row[bag_rows_[k]];
+      data_partition_->ResetByLeafPred(pred, nl);
+      data_size_t* idx = const_cast<data_size_t*>(data_partition_->indices());
+      for (data_size_t k = 0; k < bag_cnt_; ++k) idx[k] = bag_rows_[idx[k]];
+    }
     return tree.release();
   }
 
@@ -101,7 +140,19 @@ class HIPTreeLearner : public SerialTreeLearner {
   void BeforeTrain() override {
     SerialTreeLearner::BeforeTrain();
     // one upload per tree: gradients (and hessians unless constant) in data order, as CUDATreeLearner::BeforeTrain does
-    if (hist_ && gpb_hip_hist_set_gradients(hist_, gradients_, share_state_->is_constant_hessian ? nullptr : hessians_)) {
+    const score_t* g = gradients_;
+    const score_t* hs = share_state_->is_constant_hessian ? nullptr : hessians_;
+    if (hist_ && bag_is_subset_) {                   // compact gradients of a subset bag -> the rows of the full data the device bins belong to
+      full_grad_.assign(hist_rows_, 0.0f);
+      for (data_size_t k = 0; k < bag_cnt_; ++k) full_grad_[bag_rows_[k]] = gradients_[k];
+      g = full_grad_.data();
+      if (hs != nullptr) {
+        full_hess_.assign(hist_rows_, 0.0f);
+        for (data_size_t k = 0; k < bag_cnt_; ++k) full_hess_[bag_rows_[k]] = hessians_[k];
+        hs = full_hess_.data();
+      }
+    }
+    if (hist_ && gpb_hip_hist_set_gradients(hist_, g, hs)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
   }
@@ -150,6 +201,8 @@ class HIPTreeLearner : public SerialTreeLearner {
     if (gpb_hip_hist_create(num_data_, num_groups, bins.data(), offsets.data(), &hist_)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
+    hist_rows_ = num_data_;
+    bag_dirty_ = true;
     // whole-tree growth on the device: numerical features, one per group; their histogram views and FeatureMetainfo
     // (HistogramPool::SetFeatureInfo, feature_histogram.hpp:1146-1182; view = one bin past the start of the group, train_share_states.cpp:296-300)
     whole_tree_ok_ = num_groups == train_data_->num_features();
@@ -172,15 +225,27 @@ class HIPTreeLearner : public SerialTreeLearner {
 
   // the configuration gpb_hip_hist_grow_tree restates: every regularisation path of the numerical threshold search (lambda_l1, lambda_l2,
   // max_delta_step, path_smooth), max_depth and the per-tree column sample; nothing that changes the candidate set per node
-  bool WholeTreeConfig() const {
+  static bool Ascending(const data_size_t* v, data_size_t cnt) {
+    for (data_size_t i = 1; i < cnt; ++i) if (v[i] <= v[i - 1]) return false;
+    return cnt > 0;
+  }
+  bool WholeTreeConfig() const { return WholeTreeConfigOnly() && num_data_ == train_data_->num_data(); }
+  bool WholeTreeConfigOnly() const {
     return config_->num_leaves >= 2 && config_->lambda_l1 >= 0.0 &&
            !config_->extra_trees && !config_->linear_tree &&
            config_->feature_fraction_bynode >= 1.0 && config_->monotone_constraints.empty() && config_->interaction_constraints_vector.empty() &&
-           (forced_split_json_ == nullptr || forced_split_json_->is_null()) && cegb_ == nullptr && num_data_ == train_data_->num_data();
+           (forced_split_json_ == nullptr || forced_split_json_->is_null()) && cegb_ == nullptr;
   }
 
   gpb_hip_hist_t* hist_ = nullptr;
-  bool whole_tree_ok_ = false, bagging_ = false, announced_ = false;
+  bool whole_tree_ok_ = false, bagging_ = false, announced_ = false, bag_dirty_ = false;
+  bool keep_device_bins_ = false;                      // inside SetBaggingData: the base class switches to the subset Dataset, the device bins stay
+  bool bag_is_subset_ = false;                         // the bag is a copied subset Dataset (rows renumbered) over full-data device bins
+  bool subset_bins_ = false;                           // the device bins were built from a subset Dataset (older path)
+  data_size_t hist_rows_ = 0;                          // rows of the Dataset the device bins were built from
+  std::vector<score_t> full_grad_, full_hess_;
+  const data_size_t* bag_rows_ = nullptr;              // the current bag (GBDT's bag_data_indices_, alive until the next SetBaggingData)
+  data_size_t bag_cnt_ = 0;
 };
 
 }  // namespace LightGBM

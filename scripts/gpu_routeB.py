@@ -73,7 +73,9 @@ REG = " lambda_l1=2 lambda_l2=1 max_delta_step=0.5 path_smooth=20 min_gain_to_sp
 SIZES = ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", "gpu", " max_depth=8"), ("cpu_maxdepth", "cpu", " max_depth=8"),
                        ("cpu_reg", "cpu", REG), ("gpu_reg", "gpu", REG),
                        ("cpu_colsample", "cpu", " feature_fraction=0.8"), ("gpu_colsample", "gpu", " feature_fraction=0.8"),
-                       ("cpu_bynode", "cpu", " feature_fraction_bynode=0.8"), ("gpu_bynode", "gpu", " feature_fraction_bynode=0.8"))),
+                       ("cpu_bynode", "cpu", " feature_fraction_bynode=0.8"), ("gpu_bynode", "gpu", " feature_fraction_bynode=0.8"),
+                       ("cpu_bag", "cpu", " bagging_fraction=0.7 bagging_freq=1 bagging_seed=3"), ("gpu_bag", "gpu", " bagging_fraction=0.7 bagging_freq=1 bagging_seed=3"),
+                       ("cpu_bagsub", "cpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"), ("gpu_bagsub", "gpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"))),
          (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""))))
 if "--trees-only" in sys.argv:
     SIZES = SIZES[:1]
@@ -110,6 +112,10 @@ for n, F, variants in SIZES:
     np.testing.assert_allclose(pred["gpu_maxdepth"], pred["cpu_maxdepth"], rtol=0, atol=1e-9)
   if "gpu_colsample" in pred:      # the per-tree column sample of the reference's ColSampler is handed to the device grower
     np.testing.assert_allclose(pred["gpu_colsample"], pred["cpu_colsample"], rtol=0, atol=1e-9)
+  if "gpu_bag" in pred:            # bagging on the full Dataset: the device grower starts from the bag's rows
+    np.testing.assert_allclose(pred["gpu_bag"], pred["cpu_bag"], rtol=0, atol=1e-9)
+  if "gpu_bagsub" in pred:         # small bags: the reference copies a subset Dataset; the device keeps the full data's bins and starts from the bag's rows
+    np.testing.assert_allclose(pred["gpu_bagsub"], pred["cpu_bagsub"], rtol=0, atol=1e-9)
   if "gpu_bynode" in pred:         # per-node column sampling is not restated by the device grower: SerialTreeLearner::Train + device histograms
     np.testing.assert_allclose(pred["gpu_bynode"], pred["cpu_bynode"], rtol=0, atol=1e-9)
   if "gpu_reg" in pred:

@@ -397,3 +397,46 @@ def test_tree_grower_with_a_column_sample_and_a_depth_limit(lib_built):
     t0 = hb.grow_tree(L, sg, sh, *cfg[:4])
     assert np.array_equal(t0["split_feature_inner"], g[k + "split_feature_inner"])
     hb.close()
+
+
+def test_tree_grower_on_a_bag_of_rows(lib_built):
+    """Bagging: the root of the tree holds a subset of the rows (gpb_hip_hist_set_root_rows) -- against SerialTreeLearner::Train's control flow over
+    the ORACLE's primitives started from the same subset; rows outside the bag are labelled -1."""
+    import os
+    from gpboost_amd import shim
+    from oracle import orc
+    from tests import cases
+    from tests import tree_harness as th
+    name = "plain_l15_reg"
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    n = X.shape[0]
+    for hi in (0, 1):
+        k = "%s_hess%d_" % (name, hi)
+        hs = hess if hi else None
+        bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+        bag = np.sort(np.random.default_rng(77).choice(n, size=int(0.7 * n), replace=False)).astype(np.int32)
+        ob = th.OracleBackend(orc, bins, gnb, g[k + "view_offset"], g[k + "num_bin"], mfb, meta3, grad, hs)
+        ref = th.grow_tree(ob, grad, hs, n, L, cfg, root_rows=bag)
+        bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+        hb = shim.HistBuilder(bins, bo)
+        hb.pool_resize(L + 1)
+        hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
+        hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+        hb.set_gradients(grad, hs)
+        hb.set_root_rows(bag)
+        sg = float(np.cumsum(grad[bag])[-1]); sh = float(np.cumsum((np.ones(n) if hs is None else hs)[bag])[-1])
+        t = hb.grow_tree(L, sg, sh, *cfg[:4])
+        assert t["num_leaves"] == ref["num_leaves"] and t["num_leaves"] > 4
+        for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "default_left"):
+            assert np.array_equal(t[key], ref[key]), key
+        np.testing.assert_allclose(t["leaf_value"], ref["leaf_value"], rtol=1e-9, atol=1e-12)
+        dli = t["data_leaf_index"]
+        out = np.ones(n, dtype=bool); out[bag] = False
+        assert np.all(dli[out] == -1) and np.all(dli[bag] >= 0)
+        assert np.array_equal(np.bincount(dli[bag], minlength=t["num_leaves"]), t["leaf_count"])
+        hb.set_root_rows(None)                                       # back to all rows: the fixture's tree
+        t0 = hb.grow_tree(L, float(np.cumsum(grad)[-1]), float(np.cumsum(np.ones(n) if hs is None else hs)[-1]), *cfg[:4])
+        assert np.array_equal(t0["split_feature_inner"], g[k + "split_feature_inner"])
+        hb.close()

@@ -85,7 +85,7 @@ def root_parent_output(sg, sh, l1, l2, max_delta_step):
     return ret
 
 
-def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None):
+def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None, root_rows=None):
     """cfg = (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth]).
     Returns the same arrays ref_train_tree does."""
     l2, min_data, min_hess, min_gain = cfg[:4]
@@ -96,6 +96,10 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
     sg = float(np.cumsum(grad)[-1]); sh = float(np.cumsum(hs)[-1])
     idx = {0: None}
     cnt = {0: n}
+    if root_rows is not None:                    # bagging: the root holds these rows (DataPartition::Init with used_data_indices_); sums over them
+        rr = np.ascontiguousarray(root_rows, dtype=np.int32)
+        sg = float(np.cumsum(grad[rr])[-1]); sh = float(np.cumsum(hs[rr])[-1])
+        idx = {0: rr}; cnt = {0: rr.size}
     sums = {0: (sg, sh)}
     best = {}                                    # leaf -> dict(gain, feature, row) of its best split
     splittable = {}
@@ -120,7 +124,7 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
         best[leaf] = dict(gain=top[0], feature=top[1], row=row)
         splittable[leaf] = spl
 
-    be.build_fix(0, None, sg, sh)
+    be.build_fix(0, idx[0], sg, sh)
     # feature_fraction: the tree's sampled columns (ColSampler::is_feature_used_bytree, serial_tree_learner.cpp:329); children inherit the mask
     # through the parent's is_splittable flags
     search_leaf(0, np.ones(F, dtype=np.int8) if feature_mask is None else np.asarray(feature_mask, dtype=np.int8))
