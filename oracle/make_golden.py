@@ -116,12 +116,12 @@ def split_fixture(out_dir):
     res = {}
     for name in cases.SPLIT_DATA:
         X, g, h, leaf = cases.make_split_data(name)
-        for ci, cfg in enumerate(cases.SPLIT_CFGS):
+        for ci, cfg in [(str(i), c) for i, c in enumerate(cases.SPLIT_CFGS)] + [("r%d" % i, c) for i, c in enumerate(cases.SPLIT_CFGS_REG)]:
             for li, di in enumerate((None, leaf)):
                 for hi, hs in enumerate((None, h)):
                     bins, gnb, hist, fx = refdrv.ref_histogram(X, 63, di, g, hs, 1.0, with_fix=True,
                                                                extra_params=cases.SPLIT_DATA[name]["params"], split_cfg=cfg)
-                    key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                    key = "%s_cfg%s_leaf%d_hess%d" % (name, ci, li, hi)
                     res[name + "_bins"] = bins; res[name + "_group_num_bin"] = gnb
                     res[name + "_view_offset"] = fx["view_offset"]; res[name + "_num_bin"] = fx["num_bin"]
                     res[name + "_most_freq_bin"] = fx["most_freq_bin"]; res[name + "_meta3"] = fx["meta3"]

@@ -194,15 +194,20 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
       /* FeatureHistogram::FindBestThreshold of every feature on the fixed histogram, exactly as
        * SerialTreeLearner::ComputeBestSplitForFeature calls it (serial_tree_learner.cpp:736-740); feature metas from the
        * reference's own HistogramPool::SetFeatureInfo (feature_histogram.hpp:1146-1182).
-       * split_cfg4 = { lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split } */
+       * split_cfg4 = { lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split, lambda_l1, max_delta_step, path_smooth,
+       *                parent_output } (8 doubles; parent_output NaN: the root's, as GetParentOutput computes it) */
       if (split_out10) {
         Config config;
         config.lambda_l2 = split_cfg4[0]; config.min_data_in_leaf = (int)split_cfg4[1];
         config.min_sum_hessian_in_leaf = split_cfg4[2]; config.min_gain_to_split = split_cfg4[3];
+        config.lambda_l1 = split_cfg4[4]; config.max_delta_step = split_cfg4[5]; config.path_smooth = split_cfg4[6];
         std::vector<FeatureMetainfo> metas;
         HistogramPool::SetFeatureInfo<true, true>(ds, &config, &metas);
-        /* root leaf: parent_output as GetParentOutput computes it (serial_tree_learner.cpp:758-770); unused without smoothing */
-        const double parent_output = -sg / (sh + config.lambda_l2);
+        /* root leaf: parent_output as GetParentOutput computes it (serial_tree_learner.cpp:758-770); used by path smoothing only */
+        const double parent_output = std::isnan(split_cfg4[7])
+            ? FeatureHistogram::CalculateSplittedLeafOutput<true, true, true, false>(sg, sh, config.lambda_l1, config.lambda_l2, config.max_delta_step,
+                                                                                     BasicConstraint(), config.path_smooth, (data_size_t)num_data, 0)
+            : split_cfg4[7];
         for (int f = 0; f < ds->num_features(); ++f) {
           feat_meta3[3 * f] = metas[f].offset; feat_meta3[3 * f + 1] = (int)metas[f].default_bin; feat_meta3[3 * f + 2] = (int)metas[f].missing_type;
           FeatureHistogram fh;

@@ -266,7 +266,10 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
     hist = np.zeros((F * (max_bin + 3), 2))
     voff = np.zeros(F, dtype=np.int32); nbin = np.zeros(F, dtype=np.int32); mfb = np.zeros(F, dtype=np.int32)
     sums = np.zeros(2); hfix = np.zeros((F * (max_bin + 3), 2))
-    cfg = None if split_cfg is None else np.ascontiguousarray(split_cfg, dtype=np.float64)
+    cfg = None
+    if split_cfg is not None:      # (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth[, parent_output]])
+        cfg = np.zeros(8); cfg[7] = np.nan
+        cfg[:len(split_cfg)] = split_cfg
     meta3 = np.zeros((F, 3), dtype=np.int32); sp = np.zeros((F, 10)); sdl = np.zeros(F, dtype=np.int32)
     npart = 0 if partitions is None else len(partitions)
     ftd = np.ascontiguousarray(partitions if npart else np.zeros((1, 3)), dtype=np.int32)

@@ -110,6 +110,10 @@ SPLIT_DATA = {"plain": dict(seed=51, params=""),                       # no miss
               "zero_missing": dict(seed=52, params="zero_as_missing=true"),   # MissingType::Zero, both scans, default bin skipped
               "nan": dict(seed=53, params="")}                           # NaNs in two features: MissingType::NaN, both scans
 SPLIT_CFGS = [(0.0, 20, 1e-3, 0.0), (1.5, 5, 1e-3, 0.1)]              # lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split
+# the other regularisation paths: ... + lambda_l1, max_delta_step, path_smooth, parent_output (min_gain_to_split > 0 wherever max_delta_step clips:
+# candidates whose children are clipped to the same output have gain 0 up to rounding noise)
+SPLIT_CFGS_REG = [(0.5, 20, 1e-3, 0.0, 3.0, 0.0, 0.0, 0.0), (0.0, 20, 1e-3, 0.05, 0.0, 0.2, 0.0, 0.0), (0.1, 10, 1e-3, 0.0, 0.0, 0.0, 25.0, 0.07),
+                  (1.0, 20, 1e-3, 0.01, 1.5, 0.3, 10.0, -0.11)]
 
 
 def split_partition_requests(num_bin):

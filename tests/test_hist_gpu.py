@@ -440,3 +440,42 @@ def test_tree_grower_on_a_bag_of_rows(lib_built):
         t0 = hb.grow_tree(L, float(np.cumsum(grad)[-1]), float(np.cumsum(np.ones(n) if hs is None else hs)[-1]), *cfg[:4])
         assert np.array_equal(t0["split_feature_inner"], g[k + "split_feature_inner"])
         hb.close()
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_missing", "nan"])
+def test_split_search_regularisation_paths_against_reference_fixture(lib_built, name):
+    """lambda_l1 / max_delta_step / path_smooth with a given parent_output (gpb_hip_hist_set_regularisation): the device search is bit-identical
+    to the oracle's on the device-built histogram, and agrees with the reference's own FindBestThreshold (tests/golden/split_ref.npz, the
+    USE_L1 / USE_MAX_OUTPUT / USE_SMOOTHING instances) in feature, threshold and -- to the summation order of the histogram -- values."""
+    import os
+    from gpboost_amd import shim
+    from oracle import orc
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_ref.npz"))
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3 = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(2)
+    hb.set_fix_info(g[name + "_view_offset"], g[name + "_num_bin"], g[name + "_most_freq_bin"])
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    for ci, cfg in enumerate(cases.SPLIT_CFGS_REG):
+        hb.set_regularisation(cfg[4], cfg[5], cfg[6], cfg[7])
+        for li, di in enumerate((None, leaf)):
+            for hi, hs in enumerate((None, hess)):
+                key = "%s_cfgr%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums, ref, ref_dl = g[key + "_sums"], g[key + "_split"], g[key + "_default_left"]
+                nd = bins.shape[1] if di is None else di.size
+                hb.set_gradients(grad, hs)
+                hb.build_slot(0, di)
+                hb.fix_slot(0, sums[0], sums[1])
+                best, out, dl = hb.find_best_split(0, sums[0], sums[1], nd, *cfg[:4])
+                raw = hb.get_slot(0)
+                obest, oout, odl = orc.find_best_split(raw, g[name + "_view_offset"], g[name + "_num_bin"], meta3[:, 0], meta3[:, 1],
+                                                       meta3[:, 2], sums[0], sums[1], nd, *cfg)
+                assert best == obest and np.array_equal(out, oout) and np.array_equal(dl, odl), key      # bit-identical given the histogram
+                assert best == int(np.argmax(ref[:, 0])), key
+                assert out[best, 1] == ref[best, 1], key
+                np.testing.assert_allclose(out[best, [0, 4, 5, 6, 7, 8, 9]], ref[best, [0, 4, 5, 6, 7, 8, 9]], rtol=1e-9, atol=1e-9)
+    hb.set_regularisation(0.0, 0.0, 0.0, 0.0)
+    hb.close()

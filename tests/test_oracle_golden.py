@@ -354,6 +354,29 @@ def test_r_golden_vecchia_cluster_ids(orc):
     assert abs(nll - 129.3761486) < R_TOL
 
 
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+def test_oracle_split_search_regularisation_paths_match_reference_fixture(orc, name):
+    """The same with lambda_l1 / max_delta_step / path_smooth (and a given parent_output): the reference's USE_L1 / USE_MAX_OUTPUT /
+    USE_SMOOTHING instances of FindBestThresholdSequentially (feature_histogram.hpp:137-161), every field of SplitInfo bit-identical."""
+    g = np.load(os.path.join(GOLD, "split_ref.npz"))
+    meta3 = g[name + "_meta3"]
+    n_all = g[name + "_bins"].shape[1]
+    checked = 0
+    for ci, cfg in enumerate(cases.SPLIT_CFGS_REG):
+        for li in (0, 1):
+            for hi in (0, 1):
+                key = "%s_cfgr%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums = g[key + "_sums"]
+                num_data = n_all if li == 0 else 2500
+                best, out, dl = orc.find_best_split(g[key + "_hist_fixed"], g[name + "_view_offset"], g[name + "_num_bin"], meta3[:, 0],
+                                                    meta3[:, 1], meta3[:, 2], sums[0], sums[1], num_data, *cfg)
+                ref = g[key + "_split"]
+                assert np.array_equal(out, ref), (key, np.abs(out - ref).max())
+                assert np.array_equal(dl, g[key + "_default_left"])
+                checked += int(np.isfinite(ref[:, 0]).sum())
+    assert checked >= 40
+
+
 # ---- split search on a leaf histogram (SURVEY.md 8f rank 2) ----------------------------------------------------------------------
 @pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
 def test_oracle_split_search_matches_reference_fixture(orc, name):
