@@ -75,7 +75,11 @@ SIZES = ((100000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("gpu_maxdepth", 
                        ("cpu_colsample", "cpu", " feature_fraction=0.8"), ("gpu_colsample", "gpu", " feature_fraction=0.8"),
                        ("cpu_bynode", "cpu", " feature_fraction_bynode=0.8"), ("gpu_bynode", "gpu", " feature_fraction_bynode=0.8"),
                        ("cpu_bag", "cpu", " bagging_fraction=0.7 bagging_freq=1 bagging_seed=3"), ("gpu_bag", "gpu", " bagging_fraction=0.7 bagging_freq=1 bagging_seed=3"),
-                       ("cpu_bagsub", "cpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"), ("gpu_bagsub", "gpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"))),
+                       ("cpu_bagsub", "cpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"), ("gpu_bagsub", "gpu", " bagging_fraction=0.6 bagging_freq=3 bagging_seed=3"),
+                       # the reference's other bin storages: row-wise multi-value bins for the histograms, 4-bit dense bins --
+                       # CreateDeviceBins reads the bins through the Dataset's own group iterators, whatever the storage
+                       ("cpu_rowwise", "cpu", " force_row_wise=true"), ("gpu_rowwise", "gpu", " force_row_wise=true"),
+                       ("cpu_4bit", "cpu", "", " max_bin=15"), ("gpu_4bit", "gpu", "", " max_bin=15"))),
          (1000000, 50, (("cpu", "cpu", ""), ("gpu", "gpu", ""))))
 if "--trees-only" in sys.argv:
     SIZES = SIZES[:1]
@@ -85,13 +89,15 @@ for n, F, variants in SIZES:
   yb = (np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + 0.5 * rng.standard_normal(n)).astype(np.float32)
   pred = {}
   print("---- trees, n = %d, F = %d ----" % (n, F), flush=True)
-  for tag, dev, extra in variants:
+  for var in variants:
+      tag, dev, extra = var[:3]
+      dsp = var[3] if len(var) > 3 else " max_bin=255"
       ds = C.c_void_p()
       ok(L.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
-                                     C.c_char_p(("max_bin=255 verbosity=-1 device_type=%s" % dev).encode()), C.c_void_p(), C.byref(ds)))
+                                     C.c_char_p(("verbosity=-1 device_type=%s%s%s" % (dev, dsp, extra)).encode()), C.c_void_p(), C.byref(ds)))
       ok(L.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yb.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
       bst = C.c_void_p()
-      params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16%s" % (dev, extra)
+      params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16%s%s" % (dev, extra, dsp)
       ok(L.LGBM_BoosterCreate(ds, C.c_char_p(params.encode()), C.byref(bst)))
       fin = C.c_int(0)
       ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))          # first iteration: allocations, uploads
@@ -114,6 +120,9 @@ for n, F, variants in SIZES:
     np.testing.assert_allclose(pred["gpu_colsample"], pred["cpu_colsample"], rtol=0, atol=1e-9)
   if "gpu_bag" in pred:            # bagging on the full Dataset: the device grower starts from the bag's rows
     np.testing.assert_allclose(pred["gpu_bag"], pred["cpu_bag"], rtol=0, atol=1e-9)
+  for t in ("rowwise", "4bit"):
+    if "gpu_" + t in pred:
+      np.testing.assert_allclose(pred["gpu_" + t], pred["cpu_" + t], rtol=0, atol=1e-9)
   if "gpu_bagsub" in pred:         # small bags: the reference copies a subset Dataset; the device keeps the full data's bins and starts from the bag's rows
     np.testing.assert_allclose(pred["gpu_bagsub"], pred["cpu_bagsub"], rtol=0, atol=1e-9)
   if "gpu_bynode" in pred:         # per-node column sampling is not restated by the device grower: SerialTreeLearner::Train + device histograms
