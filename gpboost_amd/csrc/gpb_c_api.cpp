@@ -185,6 +185,7 @@ int device_laplace(void* ctx, int op_in, double var, double a, double* out3) {
   const bool first_update = (op_in & 16) != 0;
   const int op = op_in & 15;
   if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
+  if (op == 4) { mdl->lap_fit_first_eval = true; return 0; }      // the next evaluation starts its mode finding from zero
   // first gradient-descent update: cg_max_num_it(_tridiag) / 3 (likelihoods.h:3833-3836)
   const int cg = first_update ? (int)std::round(mdl->cg_max_num_it / 3.) : mdl->cg_max_num_it;
   const int cgt = first_update ? (int)std::round(mdl->cg_max_num_it_tridiag / 3.) : mdl->cg_max_num_it_tridiag;
@@ -290,7 +291,8 @@ int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, co
     if (mdl->likelihood != "gaussian") {     // (sigma1_2, a): marginal variance 1 (re_model_template.h:4865, :4904-4913), the same range heuristic
       double th3[3];
       if (find_init_cov_par(mdl, y_data, fixed_effects, th3)) return -1;
-      mdl->cov_pars_tr[0] = 1.; mdl->cov_pars_tr[1] = th3[2]; mdl->cov_pars_tr[2] = 0.;
+      mdl->cov_pars_tr[0] = mdl->optim.optimizer == "nelder_mead" ? 0.1 : 1.;       // init_marg_var (re_model_template.h:4904-4909)
+      mdl->cov_pars_tr[1] = th3[2]; mdl->cov_pars_tr[2] = 0.;
     } else if (find_init_cov_par(mdl, y_data, fixed_effects, mdl->cov_pars_tr)) return -1;
     std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, mdl->init_cov_pars_tr);
   }

@@ -9,6 +9,7 @@
 #include <vector>
 
 namespace {
+constexpr int kNaOrInf = 2;      // return code of the gradient-based optimisers: NaN / Inf in the parameters or the objective
 
 constexpr double kMinNuggetVarRatio = 1e-10;          // re_model_template.h:5668
 constexpr double kLrShrinkageFactor = 0.5;            // :5750
@@ -169,8 +170,7 @@ int run_gradient_descent(State& st, const GpbOptimConfig& cfg, double th[3], Gpb
       fprintf(stderr, "[gpboost_amd] it %d: cov pars (transformed) %.10g %.10g %.10g negll %.10g lr %g\n", it + 1, th[0], th[1], th[2],
               st.negll, lr_cov);
     if (!std::isfinite(st.negll) || !finite3(th))
-      return fail("NaN or Inf occurred in covariance parameter optimization using 'gradient_descent' (the reference restarts with "
-                  "'nelder_mead' here, which is not on the MI355X path); try a smaller learning rate or other initial values");
+      return kNaOrInf;                                             // the caller starts again with 'nelder_mead' (:1706-1731)
     // CheckOptimizerHasConverged
     bool terminate = false;
     if (cfg.convergence_criterion == "relative_change_in_parameters") {
@@ -305,12 +305,120 @@ int run_lbfgs(State& st, const GpbOptimConfig& cfg, double th[3], GpbOptimResult
     }
   }
   if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
-    return fail("NaN or Inf occurred in covariance parameter optimization using 'lbfgs' (the reference restarts with 'nelder_mead' here, "
-                "which is not on the MI355X path); try other initial values");
+    return kNaOrInf;                                               // the caller starts again with 'nelder_mead' (:1706-1731)
   th[0] = st.sigma2; th[1] = std::exp(x[0]); th[2] = std::exp(x[1]);   // OptimExternal :690-693
   st.negll = fx;
   out->num_it = k;
   out->lr_cov_final = initial_step_factor;
+  return 0;
+}
+
+// "nelder_mead": OptimLib's simplex search as GPBoost ships it (external_libs/OptimLib/unconstrained/nm.hpp:95-372, settings of
+// OptimExternal, optim_utils.h:624-645, :677-684) for two parameters x = log(theta[1:]); the objective is EvalLLforOptimLib
+// (optim_utils.h:61-213) -- likelihood evaluations only, which makes this optimiser a pure consumer of the hot path.  f(x, &fx) returns
+// non-zero on an evaluator error.  adaptive_pars (the default) gives the classic coefficients for n = 2: reflection 1, contraction
+// 0.75 - 1 / (2 n) = 0.5, expansion 1 + 2 / n = 2, shrinkage 1 - 1 / n = 0.5.  The vertex order after std::sort, the centroid of the n best
+// vertices and the two relative-change measures (largest change of the SORTED value / point arrays against the arrays of the previous
+// iteration) are the reference's.  Returns the iteration count in *num_it and the best vertex in x (its value in *fbest, re-evaluated as
+// error_reporting does, error_reporting.ipp:25-75).
+template <class F>
+int nelder_mead_2d(F&& f, double x[2], const GpbOptimConfig& cfg, double delta, int* num_it, double* fbest) {
+  constexpr int n = 2;
+  const double par_alpha = 1.0, par_beta = 0.75 - 1.0 / (2.0 * n), par_gamma = 1.0 + 2.0 / n, par_delta = 1.0 - 1.0 / n;
+  double tol_f, tol_x;
+  if (cfg.convergence_criterion == "relative_change_in_parameters") { tol_x = delta; tol_f = 1e-20; }
+  else { tol_f = delta; tol_x = 1e-20; }
+  const size_t iter_max = (size_t)cfg.max_iter;
+  double fv[n + 1], fv_old[n + 1], pt[n + 1][n], pt_old[n + 1][n];
+  if (f(x, &fv[0])) return -1;
+  pt[0][0] = x[0]; pt[0][1] = x[1];
+  for (int i = 1; i < n + 1; ++i) {
+    for (int c = 0; c < n; ++c) pt[i][c] = x[c] + (x[i - 1] != 0.0 ? 0.05 * x[i - 1] : 0.00025) * (c == i - 1 ? 1.0 : 0.0);
+    if (f(pt[i], &fv[i])) return -1;
+  }
+  size_t iter = 0;
+  double rel_f = 2 * std::fabs(tol_f), rel_x = 2 * std::fabs(tol_x);
+  std::copy(fv, fv + n + 1, fv_old);
+  std::copy(&pt[0][0], &pt[0][0] + (n + 1) * n, &pt_old[0][0]);
+  bool has_converged = false;
+  while (!has_converged) {
+    ++iter;
+    bool next_iter = false;
+    size_t idx[n + 1] = {0, 1, 2};
+    std::sort(idx, idx + n + 1, [&](size_t a, size_t b) { return fv[a] < fv[b]; });
+    {
+      double fs[n + 1], ps[n + 1][n];
+      for (int i = 0; i < n + 1; ++i) { fs[i] = fv[idx[i]]; ps[i][0] = pt[idx[i]][0]; ps[i][1] = pt[idx[i]][1]; }
+      std::copy(fs, fs + n + 1, fv);
+      std::copy(&ps[0][0], &ps[0][0] + (n + 1) * n, &pt[0][0]);
+    }
+    double cen[n], xr[n], xt[n], ft;
+    for (int c = 0; c < n; ++c) cen[c] = (pt[0][c] + pt[1][c]) / (double)n;
+    for (int c = 0; c < n; ++c) xr[c] = cen[c] + par_alpha * (cen[c] - pt[n][c]);
+    double fr;
+    if (f(xr, &fr)) return -1;
+    if (fr >= fv[0] && fr < fv[n - 1]) { pt[n][0] = xr[0]; pt[n][1] = xr[1]; fv[n] = fr; next_iter = true; }
+    if (!next_iter && fr < fv[0]) {                                   // expansion
+      for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_gamma * (xr[c] - cen[c]);
+      if (f(xt, &ft)) return -1;
+      if (ft < fr) { pt[n][0] = xt[0]; pt[n][1] = xt[1]; fv[n] = ft; } else { pt[n][0] = xr[0]; pt[n][1] = xr[1]; fv[n] = fr; }
+      next_iter = true;
+    }
+    if (!next_iter && fr >= fv[n - 1]) {
+      if (fr < fv[n]) {                                               // outside contraction
+        for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_beta * (xr[c] - cen[c]);
+        if (f(xt, &ft)) return -1;
+        if (ft <= fr) { pt[n][0] = xt[0]; pt[n][1] = xt[1]; fv[n] = ft; next_iter = true; }
+      } else {                                                        // inside contraction
+        for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_beta * (pt[n][c] - cen[c]);
+        if (f(xt, &ft)) return -1;
+        if (ft < fv[n]) { pt[n][0] = xt[0]; pt[n][1] = xt[1]; fv[n] = ft; next_iter = true; }
+      }
+    }
+    if (!next_iter) {                                                 // shrink towards the best vertex
+      for (int i = 1; i < n + 1; ++i) for (int c = 0; c < n; ++c) pt[i][c] = pt[0][c] + par_delta * (pt[i][c] - pt[0][c]);
+      for (int i = 1; i < n + 1; ++i) if (f(pt[i], &fv[i])) return -1;
+    }
+    double num = 0., den = 0.;
+    for (int i = 0; i < n + 1; ++i) { num = std::max(num, std::fabs(fv[i] - fv_old[i])); den = std::max(den, std::fabs(fv_old[i])); }
+    rel_f = num / (1.0e-08 + den);
+    std::copy(fv, fv + n + 1, fv_old);
+    if (tol_x >= 0.0) {
+      num = 0.; den = 0.;
+      for (int i = 0; i < n + 1; ++i) for (int c = 0; c < n; ++c) { num = std::max(num, std::fabs(pt[i][c] - pt_old[i][c])); den = std::max(den, std::fabs(pt_old[i][c])); }
+      rel_x = num / (1.0e-08 + den);
+      std::copy(&pt[0][0], &pt[0][0] + (n + 1) * n, &pt_old[0][0]);
+    }
+    has_converged = !(rel_f > tol_f && rel_x > tol_x && iter < iter_max);
+  }
+  int best = 0;
+  for (int i = 1; i < n + 1; ++i) if (fv[i] < fv[best]) best = i;
+  x[0] = pt[best][0]; x[1] = pt[best][1];
+  if (f(x, fbest)) return -1;                                         // settings->opt_fn_value = opt_objfn(x_p) (error_reporting)
+  *num_it = (int)iter;
+  return 0;
+}
+
+int run_nelder_mead(State& st, const GpbOptimConfig& cfg, double th[3], GpbOptimResult* out, const Fail& fail) {
+  for (int k = 0; k < 3; ++k)
+    if (cfg.estimate_cov_par_index[k] <= 0)
+      return fail("Holding fix some covariance parameters (via 'estimate_cov_par_index') when using optimizer_cov = 'nelder_mead' as optimizer is currently not supported ");   // :1075-1080
+  const double delta = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-8;      // SetInitialValueDeltaRelConv :8338-8347
+  st.sigma2 = th[0];
+  double x[2] = {std::log(th[1]), std::log(th[2])}, fx = 1e99, g[2];
+  auto f = [&](const double* xv, double* fv) -> int {
+    const double xx[2] = {xv[0], xv[1]};
+    return lbfgs_objective(st, xx, true, false, false, fv, g);
+  };
+  int num_it = 0;
+  if (nelder_mead_2d(f, x, cfg, delta, &num_it, &fx)) return -1;
+  if (f(x, &fx)) return -1;                                           // OptimExternal re-evaluates at the solution (optim_utils.h:677-684)
+  if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
+    return fail("NaN or Inf occurred in covariance parameter optimization using 'nelder_mead'; try other initial values");
+  th[0] = st.sigma2; th[1] = std::exp(x[0]); th[2] = std::exp(x[1]);
+  st.negll = fx;
+  out->num_it = num_it;
+  out->lr_cov_final = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 1.;
   return 0;
 }
 
@@ -393,8 +501,7 @@ int run_gradient_descent_laplace(LapState& st, const GpbOptimConfig& cfg, double
     if (cfg.trace)
       fprintf(stderr, "[gpboost_amd] it %d: cov pars (transformed) %.10g %.10g negll %.10g lr %g\n", it + 1, th[0], th[1], st.negll, lr_cov);
     if (!std::isfinite(st.negll) || !std::isfinite(th[0]) || !std::isfinite(th[1]))
-      return fail("NaN or Inf occurred in covariance parameter optimization using 'gradient_descent' (the reference restarts with "
-                  "'nelder_mead' here, which is not on the MI355X path); try a smaller learning rate or other initial values");
+      return kNaOrInf;                                             // the caller starts again with 'nelder_mead' (:1706-1731)
     bool terminate = false;
     if (cfg.convergence_criterion == "relative_change_in_parameters") {
       const double d = std::sqrt((th[0] - th_lag1[0]) * (th[0] - th_lag1[0]) + (th[1] - th_lag1[1]) * (th[1] - th_lag1[1]));
@@ -474,11 +581,32 @@ int run_lbfgs_laplace(LapState& st, const GpbOptimConfig& cfg, double th[2], Gpb
     }
   }
   if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
-    return fail("NaN or Inf occurred in covariance parameter optimization using 'lbfgs' (the reference restarts with 'nelder_mead' here, "
-                "which is not on the MI355X path); try other initial values");
+    return kNaOrInf;                                               // the caller starts again with 'nelder_mead' (:1706-1731)
   th[0] = std::exp(x[0]); th[1] = std::exp(x[1]);
   st.negll = fx;
   out->num_it = k;
+  return 0;
+}
+
+// the same simplex search on theta = (sigma1_2, a) of a non-Gaussian model: the objective is the Laplace approximation with its warm-started
+// mode; a NaN / Inf value resets the mode to the one before the evaluation (EvalLLforOptimLib, optim_utils.h:196-200)
+int run_nelder_mead_laplace(LapState& st, const GpbOptimConfig& cfg, double th[2], GpbLaplaceOptimResult* out, const Fail& fail) {
+  const double delta = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-8;
+  double x[2] = {std::log(th[0]), std::log(th[1])}, fx = 1e99;
+  auto f = [&](const double* xv, double* fv) -> int {
+    const double thx[2] = {std::exp(xv[0]), std::exp(xv[1])};
+    if (st.eval(thx, false, false, nullptr)) return -1;
+    *fv = st.negll;
+    if (!std::isfinite(*fv) && st.reset_mode()) return -1;
+    return 0;
+  };
+  int num_it = 0;
+  if (nelder_mead_2d(f, x, cfg, delta, &num_it, &fx)) return -1;
+  if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(fx))
+    return fail("NaN or Inf occurred in covariance parameter optimization using 'nelder_mead'; try other initial values");
+  th[0] = std::exp(x[0]); th[1] = std::exp(x[1]);
+  st.negll = fx;
+  out->num_it = num_it;
   return 0;
 }
 
@@ -501,8 +629,22 @@ int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_
   if (cfg.max_iter > 0) {
     if (cfg.optimizer == "gradient_descent") rc = run_gradient_descent(st, cfg, th, out, fail);
     else if (cfg.optimizer == "lbfgs") rc = run_lbfgs(st, cfg, th, out, fail);
+    else if (cfg.optimizer == "nelder_mead") rc = run_nelder_mead(st, cfg, th, out, fail);
     else
-      return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent')", cfg.optimizer.c_str());
+      return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent', 'nelder_mead')", cfg.optimizer.c_str());
+    if (rc == kNaOrInf) {
+      // "redo optimization with nelder_mead in case NA or Inf occurred" (re_model_template.h:1706-1731): from the initial values, with the
+      // convergence tolerance the first optimiser had (delta_rel_conv_init_: 1e-6 unless given)
+      fprintf(stderr, "[gpboost_amd] Warning: NaN or Inf occurred in covariance parameter optimization using '%s'. The optimization will be started a "
+                      "second time using 'nelder_mead'. If you want to avoid this, try directly using a different optimizer. If you have used "
+                      "'gradient_descent', you can also consider using a smaller learning rate \n", cfg.optimizer.c_str());
+      GpbOptimConfig c2 = cfg;
+      c2.optimizer = "nelder_mead";
+      if (!(cfg.delta_rel_conv_init > 0.)) c2.delta_rel_conv_init = 1e-6;
+      std::copy(theta_init, theta_init + 3, th);
+      st.sigma2 = th[0];
+      rc = run_nelder_mead(st, c2, th, out, fail);
+    }
     if (rc) {
       if (!err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation");
       return -1;
@@ -530,7 +672,19 @@ int gpb_optimize_laplace_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fn fn, 
     int rc;
     if (cfg.optimizer == "gradient_descent") rc = run_gradient_descent_laplace(st, cfg, th, out, fail);
     else if (cfg.optimizer == "lbfgs") rc = run_lbfgs_laplace(st, cfg, th, out, fail);
-    else return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent')", cfg.optimizer.c_str());
+    else if (cfg.optimizer == "nelder_mead") rc = run_nelder_mead_laplace(st, cfg, th, out, fail);
+    else return fail("optimizer_cov = '%s' is not on the MI355X path of this library (supported: 'lbfgs', 'gradient_descent', 'nelder_mead')", cfg.optimizer.c_str());
+    if (rc == kNaOrInf) {                    // as above; the mode starts from zero again (InitializeModeAvec, :1722-1726)
+      fprintf(stderr, "[gpboost_amd] Warning: NaN or Inf occurred in covariance parameter optimization using '%s'. The optimization will be started a "
+                      "second time using 'nelder_mead'. \n", cfg.optimizer.c_str());
+      GpbOptimConfig c2 = cfg;
+      c2.optimizer = "nelder_mead";
+      if (!(cfg.delta_rel_conv_init > 0.)) c2.delta_rel_conv_init = 1e-6;
+      th[0] = theta_init[0]; th[1] = theta_init[1];
+      double o3[3];
+      if (fn(ctx, 4, 0., 0., o3)) return fail("the evaluator could not reset the mode");
+      rc = run_nelder_mead_laplace(st, c2, th, out, fail);
+    }
     if (rc) { if (!err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation"); return -1; }
   }
   out->theta[0] = th[0]; out->theta[1] = th[1];

@@ -64,6 +64,8 @@ int gpb_optimize_gaussian_cov_pars(const GpbOptimConfig& cfg, int num_data, gpb_
 //             out3[0]; op 1 also returns its gradient wrt (log var, log a) in out3[1..2]
 //   op 2      gradient of the CURRENT state only (parameters and mode of the last op 0 / 1; no new mode finding)
 //   op 3      reset the mode to its value before the last mode finding (Likelihood::ResetModeToPreviousValue, likelihoods.h:997-1004)
+//   op 4      forget the mode: the next mode finding starts from zero (InitializeModeAvec; the restart with 'nelder_mead' after NaN / Inf,
+//             re_model_template.h:1722-1726)
 //   + 16      first_update: the reference divides cg_max_num_it(_tridiag) by 3 in the first gradient-descent update (likelihoods.h:3833-3836)
 typedef int (*gpb_laplace_fn)(void* ctx, int op, double var, double a, double* out3);
 

@@ -155,7 +155,13 @@ def tree_fixture(out_dir):
 def optim_fixture(out_dir):
     """The reference's own GPB_SetOptimConfig + GPB_OptimCovPar (one OpenMP thread) for tests/cases.py:OPTIM_CASES."""
     res = {}
+    path = os.path.join(out_dir, "optim_ref.npz")
+    only = sys.argv[2:]                       # `optim <name> ...`: (re)generate only these cases, keep the others as they are
+    if only and os.path.exists(path):
+        res = dict(np.load(path))
     for name in cases.OPTIM_CASES:
+        if only and name not in only:
+            continue
         coords, y, ids, mc, init, cfg = cases.optim_case(name)
         mdl = refdrv.RefCAPIModel(coords, mc["cov_function"], mc["shape"], mc["m"], mc["ordering"], mc["seed"], threads=1, cluster_ids=ids)
         if init is not None or cfg:
@@ -166,7 +172,7 @@ def optim_fixture(out_dir):
         res[name + "_num_it"] = np.int32(mdl.get_num_it())
         res[name + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
         print("optim", name, res[name + "_init_cov_pars"], "->", res[name + "_cov_pars"], res[name + "_num_it"], res[name + "_negll"], flush=True)
-    np.savez_compressed(os.path.join(out_dir, "optim_ref.npz"), **res)
+    np.savez_compressed(path, **res)
 
 
 def optim_coef_fixture(out_dir):
@@ -195,7 +201,13 @@ def optim_coef_fixture(out_dir):
 def optim_laplace_fixture(out_dir):
     """The reference's own GPB_OptimCovPar for non-Gaussian Vecchia models (iterative methods, vadu): tests/cases.py:OPTIM_LAPLACE_CASES."""
     res = {}
+    path = os.path.join(out_dir, "optim_laplace_ref.npz")
+    only = sys.argv[2:]                       # `optim_laplace <name> ...`: (re)generate only these cases, keep the others as they are
+    if only and os.path.exists(path):
+        res = dict(np.load(path))
     for name, oc in cases.OPTIM_LAPLACE_CASES.items():
+        if only and name not in only:
+            continue
         c = cases.LAPLACE_CASES[oc["model"]]
         coords, y = cases.make_count_data(c) if oc["lik"] == "poisson" else cases.make_binary_data(c)
         mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=oc["lik"])
@@ -207,7 +219,7 @@ def optim_laplace_fixture(out_dir):
         res[name + "_num_it"] = np.int32(mdl.get_num_it())
         res[name + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
         print("optim laplace", name, res[name + "_init_cov_pars"], "->", res[name + "_cov_pars"], res[name + "_num_it"], res[name + "_negll"], flush=True)
-    np.savez_compressed(os.path.join(out_dir, "optim_laplace_ref.npz"), **res)
+    np.savez_compressed(path, **res)
 
 
 def laplace_pred_fixture(out_dir):

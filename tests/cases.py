@@ -228,6 +228,11 @@ OPTIM_CASES = {
     "u3d_n3000_mat25_gd": dict(model="u3d_n3000_mat25_m40", init=None, cpu=False, cfg=dict(R_GD)),
     "clusters_lbfgs": dict(model="clusters", init=None, cpu=False, cfg=dict()),
     "u5d_n700_mat15_lbfgs": dict(model="u5d_n700_mat15_m20", init=None, cpu=True, cfg=dict()),       # d = 5: the generality path end to end
+    # derivative-free simplex search (OptimLib's nm as GPBoost ships it): likelihood evaluations only
+    "r_nelder_mead": dict(model="r_exp_m30_none", init=None, cpu=True, cfg=dict(optimizer_cov="nelder_mead")),
+    "r_nelder_mead_init_parcrit": dict(model="r_exp_m30_none", init="r", cpu=True,
+                                       cfg=dict(optimizer_cov="nelder_mead", convergence_criterion="relative_change_in_parameters", delta_rel_conv=1e-6)),
+    "u1d_n1000_mat15_nelder_mead_maxit25": dict(model="u1d_n1000_mat15_m10", init=None, cpu=True, cfg=dict(optimizer_cov="nelder_mead", max_iter=25)),
 }
 
 
@@ -246,6 +251,9 @@ OPTIM_LAPLACE_CASES = {
     # with fixed effects (offset of the location parameter: how the boosting loop passes the ensemble's scores)
     "logit_n1500_lbfgs_fe": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", cfg=dict(), exact_it=True, fe=True),
     "poisson_n1500_lbfgs_fe": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", cfg=dict(), exact_it=True, fe=True),
+    # simplex search (likelihood evaluations only; starts from marginal variance 0.1, re_model_template.h:4904-4909); 12 iterations keep the CPU test short
+    "logit_n1500_nelder_mead_maxit12": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", cfg=dict(optimizer_cov="nelder_mead", max_iter=12),
+                                            exact_it=True),
 }
 
 

@@ -69,6 +69,9 @@ class OracleLaplaceEvaluator(object):
         if op == 3:
             self.mode = None if self.mode_prev is None else self.mode_prev.copy()
             return 0
+        if op == 4:
+            self.mode = None; self.mode_prev = None
+            return 0
         if op == 2:
             out3[1], out3[2] = self.grad
             return 0

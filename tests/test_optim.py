@@ -261,7 +261,11 @@ def test_host_optimiser_errors(lib_built):
     lib = C.CDLL(lib_built)
     cb = oh.TERMS_FN(lambda ctx, r, a, wg, t7: -1)
     with pytest.raises(RuntimeError, match="not on the MI355X path"):
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="fisher_scoring")
+    with pytest.raises(RuntimeError):                      # failing evaluation callback under the simplex search too
         oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="nelder_mead")
+    with pytest.raises(RuntimeError, match="estimate_cov_par_index"):
+        oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="nelder_mead", estimate_cov_par_index=[1, 0, 1])
     with pytest.raises(RuntimeError, match="nesterov_schedule_version = 1"):
         oh.optimize(lib, 10, [1.0, 1.0, 1.0], cb, optimizer="gradient_descent", nesterov_schedule_version=1)
     with pytest.raises(RuntimeError, match="positive"):
@@ -275,6 +279,38 @@ def test_host_optimiser_errors(lib_built):
         return 0
     with pytest.raises(RuntimeError, match="NaN occurred in initial"):
         oh.optimize(lib, 10, [1.0, 1.0, 1.0], oh.TERMS_FN(nan_terms), optimizer="gradient_descent")
+
+
+def test_nan_in_a_gradient_based_fit_restarts_with_the_simplex_search(lib_built, capfd):
+    """re_model_template.h:1706-1731: when NaN / Inf occurs with a gradient-based optimiser the reference starts the optimisation a second time
+    from the initial values with 'nelder_mead' (tolerance of the first optimiser).  Here the oracle's gradient terms turn into NaN after a few
+    gradient evaluations; the result must be that of a direct 'nelder_mead' run with delta_rel_conv = 1e-6 from the same initial values."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    g = np.load(GOLDEN)
+    name = "r_lbfgs_default"
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    ct = orc.cov_type_id(mc["cov_function"], mc["shape"])
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    th0 = orc.transform_cov_pars(ct, g[name + "_init_cov_pars"])
+    good, _ = oh.oracle_terms(orc, co, nn, ct, y[perm])
+    lib = C.CDLL(lib_built)
+    for optimizer in ("gradient_descent",):      # (lbfgs backtracks out of a NaN step and stops at the last finite point, as the reference's copy does)
+        ngrad = [0]
+
+        def poisoned(ctx, ratio, a, with_grad, t7):
+            rc = good(ctx, ratio, a, with_grad, t7)
+            if with_grad:
+                ngrad[0] += 1
+                if ngrad[0] > 2:
+                    for q in range(3, 7):
+                        t7[q] = float("nan")
+            return rc
+        th, nit, nll, ne = oh.optimize(lib, coords.shape[0], th0, oh.TERMS_FN(poisoned), optimizer=optimizer)
+        assert "started a second time using 'nelder_mead'" in capfd.readouterr().err
+        th2, nit2, nll2, ne2 = oh.optimize(lib, coords.shape[0], th0, good, optimizer="nelder_mead", delta_rel_conv=1e-6)
+        assert nit == nit2 and np.array_equal(th, th2) and nll == nll2
+        assert np.all(np.isfinite(th)) and nit > 10
 
 
 @pytest.mark.gpu
@@ -293,7 +329,10 @@ def test_fit_on_device_matches_the_reference(lib_built, name):
     np.testing.assert_allclose(mdl._get_init_cov_pars(), g[name + "_init_cov_pars"], rtol=1e-10)    # FindInitCovPar (or the given values)
     _check(name, g, mdl.get_cov_pars(), mdl.get_num_optim_iter(), mdl.get_current_neg_log_likelihood())
     info = mdl.optim_info()
-    assert info["num_grad_evals"] >= mdl.get_num_optim_iter()
+    if cfg.get("optimizer_cov") == "nelder_mead":       # derivative-free: likelihood evaluations only (at least one per iteration + the initial simplex)
+        assert info["num_grad_evals"] == 0 and info["num_ll_evals"] >= mdl.get_num_optim_iter() + 3
+    else:
+        assert info["num_grad_evals"] >= mdl.get_num_optim_iter()
     # the stored parameters are the estimates: evaluating the likelihood there reproduces the optimum
     nll = mdl.neg_log_likelihood(cov_pars=mdl.get_cov_pars(), y=y)
     assert abs(nll - mdl.get_current_neg_log_likelihood()) <= 1e-9 * abs(nll)

@@ -83,7 +83,7 @@ def test_fit_for_non_gaussian_likelihoods_follows_the_reference(gpb, name):
     coords, y = cases.make_count_data(c) if oc["lik"] == "poisson" else cases.make_binary_data(c)
     mdl = gpb.GPModel(likelihood=oc["lik"], gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
                       num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
-    params = dict(oc["cfg"])
+    params = {("maxit" if k == "max_iter" else k): v for k, v in oc["cfg"].items()}
     params["init_cov_pars"] = g[name + "_init_cov_pars"]
     mdl.fit(y, params=params, fixed_effects=cases.laplace_fixed_effects(coords) if oc.get("fe") else None)
     ref_it = int(g[name + "_num_it"])
