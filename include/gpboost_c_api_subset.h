@@ -76,7 +76,7 @@ GPBOOST_C_EXPORT int GPB_CreateREModel(int32_t num_data,
 GPBOOST_C_EXPORT int GPB_REModelFree(REModelHandle handle);
 
 /* c_api.h:1437-1467 -- used: init_cov_pars, lr, acc_rate_cov, max_iter, delta_rel_conv, use_nesterov_acc,
- * nesterov_schedule_version, trace, optimizer ("lbfgs" = default | "gradient_descent"), momentum_offset, convergence_criterion,
+ * nesterov_schedule_version, trace, optimizer ("lbfgs" = default | "gradient_descent" | "nelder_mead"), momentum_offset, convergence_criterion,
  * m_lbfgs (GPB_OptimCovPar below); for the Laplace path cg_max_num_it, cg_max_num_it_tridiag, cg_delta_conv, num_rand_vec_trace,
  * seed_rand_vec_trace, delta_conv_mode_finding and cg_preconditioner_type (only "vadu").  -999 / "" / "default" keep the
  * reference's defaults.  num_covariates > 0, estimate_aux_pars and estimate_cov_par_index[0] >= 0 return -1. */
@@ -128,7 +128,8 @@ GPBOOST_C_EXPORT int GPB_GetCurrentNegLogLikelihood(REModelHandle handle, double
 /* c_api.h:1476-1478 -- maximum-likelihood estimation of (sigma2, sigma1_2, rho): the direct caller of the hot path
  * (REModel::OptimCovPar, re_model.cpp:483-546 -> REModelTemplate::OptimLinRegrCoefCovPar, re_model_template.h:972-1802).
  * Gaussian likelihood + gp_approx "vecchia"; optimizer_cov "lbfgs" (default; LBFGSpp with the backtracking Armijo line search,
- * nugget profiled out) or "gradient_descent" (Nesterov acceleration, Armijo step halving, nugget profiled out).  y is uploaded
+ * nugget profiled out) or "gradient_descent" (Nesterov acceleration, Armijo step halving, nugget profiled out) or "nelder_mead" (the reference's OptimLib
+ * simplex search: likelihood evaluations only).  y is uploaded
  * ONCE; every likelihood / gradient evaluation of the fit returns 3 or 7 doubles from the device.  Without init_cov_pars the
  * initial values are the reference's (FindInitCovPar, re_model_template.h:4849-4968, cov_fcts.h:1422-1683). */
 GPBOOST_C_EXPORT int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fixed_effects);
