@@ -281,6 +281,25 @@ def test_host_optimiser_errors(lib_built):
         oh.optimize(lib, 10, [1.0, 1.0, 1.0], oh.TERMS_FN(nan_terms), optimizer="gradient_descent")
 
 
+def test_nelder_mead_default_tolerance_is_1e_8(lib_built):
+    """R-package/tests/testthat/test_GPModel_gaussian_process.R:200-208: without delta_rel_conv the simplex search stops at 1e-8 (the other
+    optimisers at 1e-6, SetInitialValueDeltaRelConv re_model_template.h:8338-8347): the default fit equals the 1e-8 fit and differs from 1e-6."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    g = np.load(GOLDEN)
+    name = "r_nelder_mead"
+    coords, y, ids, mc, init, cfg = cases.optim_case(name)
+    perm, co, nn = orc.vecchia_setup(coords, mc["m"], mc["ordering"], mc["seed"])
+    th0 = orc.transform_cov_pars(0, g[name + "_init_cov_pars"])
+    cb, _ = oh.oracle_terms(orc, co, nn, 0, y[perm])
+    lib = C.CDLL(lib_built)
+    d = oh.optimize(lib, len(y), th0, cb, optimizer="nelder_mead")
+    d8 = oh.optimize(lib, len(y), th0, cb, optimizer="nelder_mead", delta_rel_conv=1e-8)
+    d6 = oh.optimize(lib, len(y), th0, cb, optimizer="nelder_mead", delta_rel_conv=1e-6)
+    assert np.array_equal(d[0], d8[0]) and d[1] == d8[1] and d[2] == d8[2]
+    assert d6[1] < d[1] and not np.array_equal(d6[0], d[0])
+
+
 def test_nan_in_a_gradient_based_fit_restarts_with_the_simplex_search(lib_built, capfd):
     """re_model_template.h:1706-1731: when NaN / Inf occurs with a gradient-based optimiser the reference starts the optimisation a second time
     from the initial values with 'nelder_mead' (tolerance of the first optimiser).  Here the oracle's gradient terms turn into NaN after a few
