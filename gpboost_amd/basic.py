@@ -439,5 +439,15 @@ class GPModel(object):
         _safe_call(_lib().GPB_HIP_GetVecchiaStructure(self.handle, None, nn.ctypes.data_as(ctypes.c_void_p), None))
         return perm, nn
 
+    def vif_grad_factor(self, cov_pars, p):
+        """Full-scale Vecchia (VIF) models, test seam: (dA, dD) of parameter p (0: variance, 1: range; log of the transformed parameter) of the
+        residual-process factor on the resident response -- the reference's -B_grad / D_grad (src/GPBoost/Vecchia_utils.cpp:1640-1656)."""
+        cov_pars = np.ascontiguousarray(cov_pars, dtype=np.float64).reshape(-1)
+        m = ctypes.c_int(0)
+        _safe_call(_lib().GPB_HIP_GetVecchiaStructure(self.handle, None, None, ctypes.byref(m)))
+        dA = np.empty((self.num_data, max(m.value, 1))); dD = np.empty(self.num_data)
+        _safe_call(_lib().GPB_HIP_VifGradFactor(self.handle, _dptr(cov_pars), ctypes.c_int(int(p)), _dptr(dA), _dptr(dD)))
+        return dA, dD
+
     def vecchia_handle(self):
         return ctypes.c_void_p(_lib().GPB_HIP_GetVecchiaHandle(self.handle))

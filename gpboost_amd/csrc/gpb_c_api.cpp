@@ -445,38 +445,79 @@ bool cholesky_lower(std::vector<double>& M, int k) {
 
 // Full-scale Vecchia, Gaussian likelihood: y' Psi^-1 y and log|Psi| at (ratio, a) by the Woodbury identity with the residual-process
 // Vecchia factor on the device (CalcSigmaComps re_model_template.h:8151-8200, CalcCovFactorFITC_FSA :9646-9745, CalcYAux :9785-9806,
-// the log-determinant :2950-2966).  The k x k work -- Sigma_m, its Cholesky factor and inverse, the Woodbury matrix -- is host work (k <= 256).
+// the log-determinant :2950-2966) and -- with_grad -- their derivatives wrt (log ratio, log a): the analytic gradient of
+// CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i (:2205-2330, 2447-2452) in the form of DESIGN.md 4.12.  The k x k work -- Sigma_m, its Cholesky
+// factor and inverse, the Woodbury matrix and its inverse, the traces with dSigma_m -- is host work (k <= 256); everything with an n in it is the
+// device's: `factor` = gpb_hip_vecchia_vif_factor, `gsums` = gpb_hip_vecchia_vif_grad_sums (function pointers so that the CPU suite can drive this
+// routine with a numpy restatement of the two, GPB_HIP_VifTermsWithCallback).
 struct VifSolve { std::vector<double> Linv, Lw, v; };      // for the prediction: L_m^-1, the Cholesky factor of the Woodbury matrix, W^-1 (B C)' D^-1 B y
-int vif_terms(REModelHip* mdl, double ratio, double a, double* t3, VifSolve* keep = nullptr) {
-  const int k = mdl->num_ind_points, d = mdl->d;
-  std::vector<double> Sm((size_t)k * k);
-  auto kern = [&](double dist) {
-    const double r = a * dist, e = ratio * std::exp(-r);
-    return mdl->cov_type == 0 ? e : (mdl->cov_type == 1 ? e * (1. + r) : e * (1. + r + r * r / 3.));
-  };
+typedef int (*vif_factor_fn)(void* ctx, const double* Linv, int with_grad, double* out3, double* G);
+typedef int (*vif_gsums_fn)(void* ctx, const double* Winv, const double* Si, const double* N0, const double* negMp1, const double* w, double* sums12);
+
+// C = A B for k x k row-major matrices
+void matmul_kk(const std::vector<double>& A, const std::vector<double>& B, int k, std::vector<double>* C) {
+  C->assign((size_t)k * k, 0.);
+  parallel_for(k, [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i)
+      for (int q = 0; q < k; ++q) {
+        const double aiq = A[(size_t)i * k + q];
+        if (aiq == 0.) continue;
+        for (int j = 0; j < k; ++j) (*C)[(size_t)i * k + j] += aiq * B[(size_t)q * k + j];
+      }
+  });
+}
+// inverse of a lower-triangular k x k row-major matrix (row-major lower-triangular result), column by column
+void tri_inverse_lower(const std::vector<double>& L, int k, std::vector<double>* Linv) {
+  Linv->assign((size_t)k * k, 0.);
+  for (int c = 0; c < k; ++c) {
+    (*Linv)[(size_t)c * k + c] = 1. / L[(size_t)c * k + c];
+    for (int i = c + 1; i < k; ++i) {
+      double sacc = 0.;
+      for (int q = c; q < i; ++q) sacc -= L[(size_t)i * k + q] * (*Linv)[(size_t)q * k + c];
+      (*Linv)[(size_t)i * k + c] = sacc / L[(size_t)i * k + i];
+    }
+  }
+}
+// (L L')^-1 = Linv' Linv from the lower-triangular inverse
+void spd_inverse_from_tri(const std::vector<double>& Linv, int k, std::vector<double>* inv) {
+  inv->assign((size_t)k * k, 0.);
+  parallel_for(k, [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double sacc = 0.;
+        for (int q = i; q < k; ++q) sacc += Linv[(size_t)q * k + i] * Linv[(size_t)q * k + j];      // rows q >= max(i, j) = i
+        (*inv)[(size_t)i * k + j] = sacc;
+      }
+  });
+  for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j) (*inv)[(size_t)i * k + j] = (*inv)[(size_t)j * k + i];
+}
+
+int vif_terms_core(int k, int d, const double* ip_colmajor, int cov_type, double ratio, double a, int with_grad, vif_factor_fn factor, vif_gsums_fn gsums,
+                   void* ctx, double* t7, VifSolve* keep) {
+  std::vector<double> Sm0((size_t)k * k), dSm1;
+  if (with_grad) dSm1.assign((size_t)k * k, 0.);
   for (int i = 0; i < k; ++i)
     for (int j = 0; j <= i; ++j) {
       double s2 = 0.;
-      for (int c = 0; c < d; ++c) { const double t = mdl->ip[(size_t)c * k + i] - mdl->ip[(size_t)c * k + j]; s2 += t * t; }
-      Sm[(size_t)i * k + j] = Sm[(size_t)j * k + i] = kern(std::sqrt(s2));
+      for (int c = 0; c < d; ++c) { const double t = ip_colmajor[(size_t)c * k + i] - ip_colmajor[(size_t)c * k + j]; s2 += t * t; }
+      const double r = a * std::sqrt(s2), e = ratio * std::exp(-r);
+      const double kv = cov_type == 0 ? e : (cov_type == 1 ? e * (1. + r) : e * (1. + r + r * r / 3.));
+      Sm0[(size_t)i * k + j] = Sm0[(size_t)j * k + i] = kv;
+      if (with_grad) {      // d/d log a (GradientRangeMaternShape0_5 / 1_5 / 2_5 with transf_scale, cov_fcts.h:2535-2554)
+        const double dk = cov_type == 0 ? -r * e : (cov_type == 1 ? -r * r * e : -r * r * (1. + r) * e / 3.);
+        dSm1[(size_t)i * k + j] = dSm1[(size_t)j * k + i] = dk;
+      }
     }
-  for (int i = 0; i < k; ++i) Sm[(size_t)i * k + i] *= 1. + 1e-6;                   // JITTER_MULT_IP_FITC_FSA (utils.h:41)
+  std::vector<double> Sm = Sm0;
+  for (int i = 0; i < k; ++i) Sm[(size_t)i * k + i] *= 1. + 1e-6;                   // JITTER_MULT_IP_FITC_FSA (utils.h:41): only what is FACTORISED carries it
   std::vector<double> L = Sm;
   if (!cholesky_lower(L, k)) return set_error("The covariance matrix of the inducing points is not positive definite");
-  std::vector<double> Linv((size_t)k * k, 0.);                                     // row-major lower-triangular inverse, column by column
-  for (int c = 0; c < k; ++c) {
-    Linv[(size_t)c * k + c] = 1. / L[(size_t)c * k + c];
-    for (int i = c + 1; i < k; ++i) {
-      double sacc = 0.;
-      for (int q = c; q < i; ++q) sacc -= L[(size_t)i * k + q] * Linv[(size_t)q * k + c];
-      Linv[(size_t)i * k + c] = sacc / L[(size_t)i * k + i];
-    }
-  }
+  std::vector<double> Linv;
+  tri_inverse_lower(L, k, &Linv);
   double o3[3];
-  if (gpb_hip_vecchia_vif_factor(mdl->vh, mdl->cov_type, ratio, a, Linv.data(), o3)) return shim_error();
   const int q = k + 1;
   std::vector<double> G((size_t)q * q);
-  if (gpb_hip_vecchia_gram(mdl->vh, G.data())) return shim_error();                // (B [C_nm, y])' D^-1 (B [C_nm, y])
+  if (factor(ctx, Linv.data(), with_grad, o3, G.data())) return -1;                // device: (B [C_nm, y])' D^-1 (B [C_nm, y]) and the factor's sums
   std::vector<double> W((size_t)k * k), r(k);
   for (int i = 0; i < k; ++i) { for (int j = 0; j < k; ++j) W[(size_t)i * k + j] = Sm[(size_t)i * k + j] + G[(size_t)i * q + j]; r[i] = G[(size_t)i * q + k]; }
   if (!cholesky_lower(W, k)) return set_error("The Woodbury matrix of the full-scale Vecchia approximation is not positive definite");
@@ -484,13 +525,55 @@ int vif_terms(REModelHip* mdl, double ratio, double a, double* t3, VifSolve* kee
   for (int i = 0; i < k; ++i) { ldm += std::log(L[(size_t)i * k + i]); ldw += std::log(W[(size_t)i * k + i]); }
   for (int i = 0; i < k; ++i) { double v = r[i]; for (int j = 0; j < i; ++j) v -= W[(size_t)i * k + j] * r[j]; r[i] = v / W[(size_t)i * k + i]; }   // L_W^-1 r
   double rr = 0.; for (int i = 0; i < k; ++i) rr += r[i] * r[i];
-  if (keep) {
-    keep->Linv = Linv; keep->Lw = W; keep->v = r;            // v = L_W^-T (L_W^-1 r)
-    for (int i = k - 1; i >= 0; --i) { double v = keep->v[i]; for (int j = i + 1; j < k; ++j) v -= W[(size_t)j * k + i] * keep->v[j]; keep->v[i] = v / W[(size_t)i * k + i]; }
+  std::vector<double> w = r;                                                       // w = L_W^-T (L_W^-1 r) = W^-1 (B C)' D^-1 B y
+  for (int i = k - 1; i >= 0; --i) { double v = w[i]; for (int j = i + 1; j < k; ++j) v -= W[(size_t)j * k + i] * w[j]; w[i] = v / W[(size_t)i * k + i]; }
+  if (keep) { keep->Linv = Linv; keep->Lw = W; keep->v = w; }
+  t7[0] = o3[0] - rr;
+  t7[1] = o3[1] - 2. * ldm + 2. * ldw;
+  t7[2] = o3[2];
+  if (!with_grad) return 0;
+  // ---- gradient -------------------------------------------------------------------------------------------------------------------------
+  std::vector<double> LwInv, Winv, Si, T, Mp0, Mp1;
+  tri_inverse_lower(W, k, &LwInv);
+  spd_inverse_from_tri(LwInv, k, &Winv);
+  spd_inverse_from_tri(Linv, k, &Si);
+  matmul_kk(Si, Sm0, k, &T); matmul_kk(T, Si, k, &Mp0);                            // Si dSm^var Si   (dSm^var = the UN-jittered Sigma_m, as the reference's GetZSigmaZtGrad)
+  matmul_kk(Si, dSm1, k, &T); matmul_kk(T, Si, k, &Mp1);                           // Si dSm^range Si
+  std::vector<double> N0((size_t)k * k), negMp1((size_t)k * k);
+  for (size_t e = 0; e < N0.size(); ++e) { N0[e] = 2. * Si[e] - Mp0[e]; negMp1[e] = -Mp1[e]; }
+  double S[12];
+  if (gsums(ctx, Winv.data(), Si.data(), N0.data(), negMp1.data(), w.data(), S)) return -1;
+  for (int p = 0; p < 2; ++p) {
+    const std::vector<double>& dSm = p == 0 ? Sm0 : dSm1;
+    double wdw = 0., trSi = 0., trW = 0.;
+    for (int i = 0; i < k; ++i) {
+      double acc = 0.;
+      for (int j = 0; j < k; ++j) { const double v = dSm[(size_t)i * k + j]; acc += v * w[j]; trSi += Si[(size_t)i * k + j] * v; trW += Winv[(size_t)i * k + j] * v; }
+      wdw += w[i] * acc;
+    }
+    const double S1 = S[0 + p], S2 = S[2 + p], S3 = S[4 + p], S4 = S[6 + p], S5 = S[8 + p], S6 = S[10 + p];
+    const double dquad = S2 - 2. * S6 + wdw;                                        // d(y' Psi^-1 y) / d log theta_p
+    const double dlogdet = S1 - trSi + trW + 2. * S5 + 2. * S3 - S4;                // d log|Psi| / d log theta_p
+    t7[3 + 2 * p] = 0.5 * dquad;
+    t7[4 + 2 * p] = 0.5 * dlogdet;
   }
-  t3[0] = o3[0] - rr;
-  t3[1] = o3[1] - 2. * ldm + 2. * ldw;
-  t3[2] = o3[2];
+  return 0;
+}
+
+int vif_terms(REModelHip* mdl, double ratio, double a, double* t7, VifSolve* keep = nullptr, int with_grad = 0, int keep_grad_factor = 0) {
+  struct Ctx { REModelHip* mdl; double ratio, a; int keep; } c{mdl, ratio, a, keep_grad_factor};
+  const vif_factor_fn factor = [](void* ctx, const double* Linv, int wg, double* out3, double* G) -> int {
+    auto* x = reinterpret_cast<Ctx*>(ctx);
+    return gpb_hip_vecchia_vif_factor(x->mdl->vh, x->mdl->cov_type, x->ratio, x->a, Linv, wg, out3, G) ? shim_error() : 0;
+  };
+  const vif_gsums_fn gsums = [](void* ctx, const double* Winv, const double* Si, const double* N0, const double* negMp1, const double* w, double* sums12) -> int {
+    auto* x = reinterpret_cast<Ctx*>(ctx);
+    return gpb_hip_vecchia_vif_grad_sums(x->mdl->vh, x->mdl->cov_type, x->ratio, x->a, Winv, Si, N0, negMp1, w, x->keep, sums12) ? shim_error() : 0;
+  };
+  double t[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int rc = vif_terms_core(mdl->num_ind_points, mdl->d, mdl->ip.data(), mdl->cov_type, ratio, a, with_grad, factor, gsums, &c, t, keep);
+  if (rc) return -1;
+  for (int q = 0; q < (with_grad ? 7 : 3); ++q) t7[q] = t[q];
   mdl->yaux_valid = false;
   return 0;
 }
@@ -500,26 +583,7 @@ int device_terms(void* ctx, double ratio, double a, int with_grad, double* t7) {
   auto* mdl = reinterpret_cast<REModelHip*>(ctx);
   for (int q = 0; q < 7; ++q) t7[q] = 0.;
   if (mdl->vif) {
-    if (vif_terms(mdl, ratio, a, t7)) return -1;
-    if (!with_grad) return 0;
-    // Gradient of the full-scale Vecchia likelihood wrt (log ratio, log a): NOT the reference's analytic expressions
-    // (CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i, re_model_template.h:2205-2330 -- the derivative mode of the residual-process kernel and four
-    // dense n x k products) but FOURTH-ORDER central differences of the two device sums, step h = 1e-3 on the log scale:
-    //   f'(x) = [8 (f(x + h) - f(x - h)) - (f(x + 2h) - f(x - 2h))] / (12 h) + O(h^4 f^(5) / 30)
-    // truncation ~1e-12 relative, rounding ~eps |f| / h ~ 1e-10 of the gradient's magnitude: inside the 1e-8 the path is held to, at the price
-    // of EIGHT more likelihood evaluations per gradient.  The sums are deterministic (fixed-order reductions), so the differences are smooth.
-    const double h = 1e-3;
-    for (int k = 0; k < 2; ++k) {
-      double f[4][3];
-      const double s[4] = {-2., -1., 1., 2.};
-      for (int q = 0; q < 4; ++q) {
-        const double r2 = k == 0 ? ratio * std::exp(s[q] * h) : ratio, a2 = k == 1 ? a * std::exp(s[q] * h) : a;
-        if (vif_terms(mdl, r2, a2, f[q])) return -1;
-      }
-      for (int w = 0; w < 2; ++w)       // w = 0: y' Psi^-1 y -> g1_k = d(y' Psi^-1 y / 2) / d log theta_k;  w = 1: log|Psi| -> g2_k
-        t7[3 + 2 * k + w] = 0.5 * (8. * (f[2][w] - f[1][w]) - (f[3][w] - f[0][w])) / (12. * h);
-    }
-    return 0;
+    return vif_terms(mdl, ratio, a, t7, nullptr, with_grad);      // with_grad: the analytic gradient, two more passes over the n x k matrices
   }
   // covariate fit: response := y0 - X beta_GLS(ratio, a) before the terms are evaluated.  Only there -- GPB_EvalNegLogLikelihood and a later
   // GPB_OptimCovPar stay plain evaluations of y - fixed_effects (re_model.cpp:755-790), whatever was fitted before
@@ -1500,6 +1564,20 @@ int GPB_HIP_FindInitCovParHost(int32_t num_data, const double* y_data, const dou
   std::mt19937 rng(seed);
   if (shuffle_len > 0) { std::vector<int> idx(shuffle_len); std::iota(idx.begin(), idx.end(), 0); std::shuffle(idx.begin(), idx.end(), rng); }
   if (find_init_cov_par_core(num_data, y_data, fixed_effects, n0, dim, coords0_colmajor, cov_type, rng, theta3)) return -1;
+  C_API_END();
+}
+
+/* Test seam: the host half of the full-scale Vecchia (VIF) likelihood and its analytic gradient (vif_terms_core: Sigma_m and its factor, the Woodbury
+   matrix, the k x k inverses and traces) with the two device passes supplied by the caller -- the CPU suite hands it a numpy restatement of
+   gpb_hip_vecchia_vif_factor / gpb_hip_vecchia_vif_grad_sums (tests/test_vif.py).  t7 = {y' Psi^-1 y, log|Psi|, #(D <= 0), g1_var, g2_var, g1_range, g2_range}. */
+int GPB_HIP_VifTermsWithCallback(int32_t k, int32_t d, const double* ip_colmajor, int cov_type, double ratio, double a, int with_grad,
+                                 int (*factor)(void*, const double*, int, double*, double*),
+                                 int (*gsums)(void*, const double*, const double*, const double*, const double*, const double*, double*), void* ctx, double* t7) {
+  C_API_BEGIN();
+  if (k < 1 || d < 1 || !ip_colmajor || !factor || (with_grad && !gsums) || !t7) return set_error("GPB_HIP_VifTermsWithCallback: invalid argument");
+  double t[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (vif_terms_core(k, d, ip_colmajor, cov_type, ratio, a, with_grad, factor, gsums, ctx, t, nullptr)) return -1;
+  std::copy(t, t + 7, t7);
   C_API_END();
 }
 
@@ -2550,6 +2628,23 @@ int GPB_HIP_EvalNegLogLikelihoodAndGrad(REModelHandle handle, const double* y_da
   grad3[0] = -1. * t7[0] / tr[0] / 2. + mdl->n / 2.;   // re_model_template.h:1994
   grad3[1] = t7[3] / tr[0] + t7[4];                    // :2004
   grad3[2] = t7[5] / tr[0] + t7[6];
+  C_API_END();
+}
+
+/* Test seam, full-scale Vecchia (VIF) models: the derivative factors of the residual process at cov_pars (original scale) on the resident response --
+   dA (n x m, Vecchia order, aligned with the neighbour table) and dD (n) of parameter p (0: variance, 1: range; wrt the log of the transformed
+   parameter): the reference's -B_grad / D_grad (src/GPBoost/Vecchia_utils.cpp:1640-1656). */
+int GPB_HIP_VifGradFactor(REModelHandle handle, double* cov_pars, int p, double* dA, double* dD) {
+  C_API_BEGIN();
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !cov_pars || !dA || !dD) return set_error("GPB_HIP_VifGradFactor: null argument");
+  if (!mdl->vif) return set_error("GPB_HIP_VifGradFactor: gp_approx 'full_scale_vecchia' models only");
+  if (!mdl->y_set) return set_error("GPB_HIP_VifGradFactor: no response has been set (call GPB_EvalNegLogLikelihood with y_data once)");
+  double tr[3];
+  if (transform_cov_pars(mdl, cov_pars, tr)) return -1;
+  double t7[7];
+  if (vif_terms(mdl, tr[1], tr[2], t7, nullptr, 1, 1)) return -1;
+  if (gpb_hip_vecchia_vif_get_grad_factor(mdl->vh, p, dA, dD)) return shim_error();
   C_API_END();
 }
 

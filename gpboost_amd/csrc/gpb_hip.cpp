@@ -229,8 +229,14 @@ struct gpb_hip_vecchia {
   int rounds = 0;                 // measurement knob (GPB_POINT_ROUNDS): resident rounds of persistent workers of the point kernel; 0 = default
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false, nn_partial = false;
   double* d_nug = nullptr;        // sample weights (Gaussian likelihood): observation-specific nugget 1 / w_i, Vecchia order (gpb_hip_vecchia_set_nugget_diag)
-  // full-scale Vecchia (VIF): k inducing points [k][3], whitened cross-covariances V [n][kp], Linv, per-point partial sums; C lives in d_X
-  int vif_k = 0, vif_kp = 0; double* d_ip = nullptr; double* d_V = nullptr; double* d_Linv = nullptr; double* d_vif_part = nullptr;
+  // full-scale Vecchia (VIF): k inducing points [k][3]; row-major [n][kq] matrices (vif_kernels.hip): cross-covariances C (column k: the response),
+  // whitened V, Q = B C; k x k matrices of the products [6][kq][kq]; Gram tiles; per-point partial sums [12][n]; the gradient's matrices are
+  // allocated at its first use
+  int vif_k = 0, vif_kp = 0, vif_kq = 0; double* d_ip = nullptr; double* d_V = nullptr; double* d_vif_part = nullptr;
+  double* d_vC = nullptr; double* d_vQ = nullptr; double* d_vM = nullptr; double* d_vG = nullptr; double* d_vgpart = nullptr; double* d_vout = nullptr;
+  double* d_vdC = nullptr; double* d_vQdC = nullptr; double* d_vX1 = nullptr; double* d_vV1 = nullptr; double* d_vX2 = nullptr; double* d_vHm = nullptr;
+  double* d_vw = nullptr; double* d_vv = nullptr; double* d_vz = nullptr; double* d_vdA = nullptr; double* d_vdD = nullptr;
+  bool vif_has_grad_inputs = false, vif_has_grad_factor = false;
   int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   GpbComm comm;                   // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init / _comm_init_local)
@@ -238,6 +244,13 @@ struct gpb_hip_vecchia {
   std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
   std::vector<int> nn_host;
 };
+
+static void vif_free(gpb_hip_vecchia* h) {
+  dev_free(h->d_ip); dev_free(h->d_V); dev_free(h->d_vif_part); dev_free(h->d_vC); dev_free(h->d_vQ); dev_free(h->d_vM); dev_free(h->d_vG); dev_free(h->d_vgpart);
+  dev_free(h->d_vout); dev_free(h->d_vdC); dev_free(h->d_vQdC); dev_free(h->d_vX1); dev_free(h->d_vV1); dev_free(h->d_vX2); dev_free(h->d_vHm); dev_free(h->d_vw);
+  dev_free(h->d_vv); dev_free(h->d_vz); dev_free(h->d_vdA); dev_free(h->d_vdD);
+  h->vif_has_grad_inputs = h->vif_has_grad_factor = false;
+}
 
 struct gpb_hip_exact {
   int device = 0;
@@ -434,7 +447,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   dev_free(h->d_A); dev_free(h->d_D); dev_free(h->d_u); dev_free(h->d_v); dev_free(h->d_w); dev_free(h->d_ystage); dev_free(h->d_X); dev_free(h->d_U); dev_free(h->d_G); dev_free(h->d_beta);
   dev_free(h->d_tptr); dev_free(h->d_tpos); dev_free(h->d_flag); dev_free(h->d_red);
   dev_free(h->d_leaf); dev_free(h->d_leaf_part); dev_free(h->d_leaf_out);
-  dev_free(h->d_ip); dev_free(h->d_V); dev_free(h->d_Linv); dev_free(h->d_vif_part); dev_free(h->d_nug);
+  vif_free(h); dev_free(h->d_nug);
   h->comm.release();
   laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
@@ -983,39 +996,49 @@ int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, doubl
 }
 
 /* ---- full-scale Vecchia ("VIF") approximation, Gaussian likelihood (vif_kernels.hip) ----
-   set_inducing_points: k <= 256 inducing points (column-major k x d, from the host's kmeans++); allocates C (= the handle's covariate block,
-   so that gpb_hip_vecchia_gram returns (B [C_nm, y])' D^-1 (B [C_nm, y])) and V.
-   vif_factor: C_nm, V = L_m^-1 C_mn (Linv: k x k row-major inverse of the host's chol(Sigma_m)), the residual-process factor A, D, u;
-   out3 = {sum u_i^2 / D_i, sum log D_i, #(D_i <= 0)}. */
+   set_inducing_points: k <= 256 inducing points (column-major k x d, from the host's kmeans++); allocates the row-major n x kq matrices.
+   vif_factor: C_nm (+ its range derivative), V = C L_m^-T (Linv: k x k row-major inverse of the host's chol(Sigma_m)), the residual-process factor
+   A, D, u, Q = B [C, y] and the Gram matrix Q' D^-1 Q; out3 = {sum u_i^2 / D_i, sum log D_i, #(D_i <= 0)}, G: (k + 1) x (k + 1).
+   vif_grad_sums: the four n x k x k products, the derivative factor kernel and its twelve sums. */
 int gpb_hip_vecchia_vif_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip_colmajor) {
   API_BEGIN();
   if (!h || !ip_colmajor) return fail("null argument");
   if (k < 1 || k > 256 || k >= h->n) return fail("gpb_hip_vecchia_vif_set_inducing_points: %d inducing points (1..256, fewer than data points) are supported", k);
   if (h->d > 3) return fail("full-scale Vecchia: coordinate dimensions 1..3 are on the HIP hot path (got %d)", h->d);
   HIP_OK(hipSetDevice(h->device));
-  const int kp = (k | 1);
+  const int kp = (k | 1), kq = gpb::vif_kq(k);
   if (gpb::vif_resid_lds_bytes(h->m, kp) > 150 * 1024) return fail("full-scale Vecchia: %d neighbours x %d inducing points exceed the LDS of a CU", h->m, k);
-  dev_free(h->d_ip); dev_free(h->d_V); dev_free(h->d_Linv); dev_free(h->d_vif_part);
-  dev_free(h->d_X); dev_free(h->d_U); dev_free(h->d_G); dev_free(h->d_beta);
+  HIP_OK(hipStreamSynchronize(h->stream));
+  vif_free(h);
   std::vector<double> ip3((size_t)k * 3, 0.0);
   for (int j = 0; j < k; ++j) for (int c = 0; c < h->d; ++c) ip3[(size_t)j * 3 + c] = ip_colmajor[(size_t)c * k + j];
+  const size_t nk = sizeof(double) * (size_t)h->n * kq;
   HIP_OK(hipMalloc(&h->d_ip, sizeof(double) * ip3.size()));
   HIP_OK(hipMemcpy(h->d_ip, ip3.data(), sizeof(double) * ip3.size(), hipMemcpyHostToDevice));
-  HIP_OK(hipMalloc(&h->d_V, sizeof(double) * (size_t)h->n * kp));
-  HIP_OK(hipMemset(h->d_V, 0, sizeof(double) * (size_t)h->n * kp));
-  HIP_OK(hipMalloc(&h->d_Linv, sizeof(double) * (size_t)k * k));
-  HIP_OK(hipMalloc(&h->d_vif_part, sizeof(double) * 3 * (size_t)h->n));
-  HIP_OK(hipMalloc(&h->d_X, sizeof(double) * (size_t)k * h->n));
-  HIP_OK(hipMalloc(&h->d_U, sizeof(double) * (size_t)(k + 1) * h->n));
-  HIP_OK(hipMalloc(&h->d_G, sizeof(double) * (size_t)(k + 1) * (k + 1)));
-  HIP_OK(hipMalloc(&h->d_beta, sizeof(double) * (size_t)k));
-  h->p_cov = k; h->vif_k = k; h->vif_kp = kp;
+  HIP_OK(hipMalloc(&h->d_vC, nk)); HIP_OK(hipMalloc(&h->d_V, nk)); HIP_OK(hipMalloc(&h->d_vQ, nk));
+  HIP_OK(hipMalloc(&h->d_vM, sizeof(double) * 6 * (size_t)kq * kq));
+  HIP_OK(hipMalloc(&h->d_vG, sizeof(double) * (size_t)kq * kq));
+  HIP_OK(hipMalloc(&h->d_vgpart, sizeof(double) * gpb::vif_gram_part_doubles(h->n, kq)));
+  HIP_OK(hipMalloc(&h->d_vif_part, sizeof(double) * GPB_VIF_GRAD_TERMS * (size_t)h->n));
+  HIP_OK(hipMalloc(&h->d_vout, sizeof(double) * 16));
+  h->vif_k = k; h->vif_kp = kp; h->vif_kq = kq;
   API_END();
 }
 
-int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Linv_rowmajor, double* out3_host) {
+// M [kq][kq] row-major (zero outside the k x k block) <- src (k x k row-major), optionally transposed, into slot `slot` of d_vM
+static int vif_upload_matrix(gpb_hip_vecchia_t* h, int slot, const double* src, bool transpose) {
+  const int k = h->vif_k, kq = h->vif_kq;
+  std::vector<double> M((size_t)kq * kq, 0.0);
+  for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) M[(size_t)i * kq + j] = transpose ? src[(size_t)j * k + i] : src[(size_t)i * k + j];
+  HIP_OK(hipMemcpyAsync(h->d_vM + (size_t)slot * kq * kq, M.data(), sizeof(double) * M.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));     // (M is a local buffer)
+  return 0;
+}
+
+int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Linv_rowmajor, int with_grad, double* out3_host,
+                               double* G_host) {
   API_BEGIN();
-  if (!h || !Linv_rowmajor || !out3_host) return fail("null argument");
+  if (!h || !Linv_rowmajor || !out3_host || !G_host) return fail("null argument");
   if (h->vif_k < 1) return fail("no inducing points have been set (call gpb_hip_vecchia_vif_set_inducing_points)");
   if (!h->has_nn) return fail("neighbours have not been determined (call gpb_hip_vecchia_find_neighbors / _set_neighbors)");
   if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
@@ -1023,28 +1046,95 @@ int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, d
   if (!(var > 0.) || !(a > 0.)) return fail("covariance parameters must be positive (var = %g, range = %g)", var, a);
   if (h->i_begin != 0 || h->i_end != h->n) return fail("full-scale Vecchia needs the whole factor on this device");
   HIP_OK(hipSetDevice(h->device));
-  const int n = h->n, k = h->vif_k, kp = h->vif_kp;
+  const int n = h->n, k = h->vif_k, kp = h->vif_kp, kq = h->vif_kq;
   if (!h->d_A) {
     HIP_OK(hipMalloc(&h->d_A, sizeof(double) * (size_t)n * h->m));
     HIP_OK(hipMalloc(&h->d_D, sizeof(double) * (size_t)n));
     HIP_OK(hipMalloc(&h->d_u, sizeof(double) * (size_t)n));
   }
-  h->has_yaux = false;
-  HIP_OK(hipMemcpyAsync(h->d_Linv, Linv_rowmajor, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, h->stream));
-  HIP_OK(gpb::launch_vif_crosscov(cov_type, h->d_pts, h->d_ip, n, k, h->d, var, a, h->d_X, h->stream));
-  HIP_OK(gpb::launch_vif_whiten(h->d_X, h->d_Linv, n, k, kp, h->d_V, h->stream));
+  const size_t nk = sizeof(double) * (size_t)n * kq;
+  if (with_grad && !h->d_vdC) { HIP_OK(hipMalloc(&h->d_vdC, nk)); HIP_OK(hipMalloc(&h->d_vQdC, nk)); }
+  h->has_yaux = false; h->vif_has_grad_inputs = false; h->vif_has_grad_factor = false;
+  if (vif_upload_matrix(h, 0, Linv_rowmajor, true)) return -1;                   // V = C Linv'
+  HIP_OK(gpb::launch_vif_crosscov(cov_type, h->d_pts, h->d_ip, 0, n, k, kq, h->d, var, a, h->d_vC, with_grad ? h->d_vdC : nullptr, h->stream));
+  HIP_OK(gpb::launch_vif_gemm(h->d_vC, h->d_vM, n, kq, h->d_V, false, h->stream));
   gpb::VecchiaKernelArgs ka;
   ka.pts = h->d_pts; ka.nn = h->d_nn; ka.exp_tab = h->d_exp_tab; ka.partials = h->d_vif_part;
   ka.A = h->d_A; ka.D = h->d_D; ka.u = h->d_u;
   ka.m = h->m; ka.i_begin = 0; ka.i_end = n;
   ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
-  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, h->d_V, k, kp, h->stream));
-  HIP_OK(gpb::launch_reduce_partials(h->d_vif_part, n, 3, h->d_out, h->d_red ? h->d_red : nullptr, h->stream, nullptr));
+  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, h->d_V, k, kq, kp, h->stream));
+  HIP_OK(gpb::launch_reduce_partials(h->d_vif_part, n, 3, h->d_vout, nullptr, h->stream, nullptr));
+  HIP_OK(gpb::launch_vif_spmm(h->d_A, h->d_nn, 0, n, h->m, kq, h->d_vC, h->d_vQ, with_grad ? h->d_vdC : nullptr, with_grad ? h->d_vQdC : nullptr, h->stream));
+  HIP_OK(gpb::launch_vif_gram(h->d_vQ, h->d_D, n, kq, h->d_vgpart, h->d_vG, h->stream));
   double o[3];
-  HIP_OK(hipMemcpyAsync(o, h->d_out, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(o, h->d_vout, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpy2DAsync(G_host, sizeof(double) * (size_t)(k + 1), h->d_vG, sizeof(double) * (size_t)kq, sizeof(double) * (size_t)(k + 1), (size_t)(k + 1),
+                          hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   out3_host[0] = o[gpb::GPB_P_QUAD]; out3_host[1] = o[gpb::GPB_P_LOGDET]; out3_host[2] = o[gpb::GPB_P_BAD];
-  h->has_factor = true;
+  h->has_factor = true; h->vif_has_grad_inputs = with_grad != 0;
+  API_END();
+}
+
+/* Gradient sums of the full-scale Vecchia likelihood (after gpb_hip_vecchia_vif_factor(with_grad = 1) at the same parameters).
+   Winv = W^-1 (Woodbury matrix), Si = Sigma_m^-1 (jittered), N0 = 2 Si - Si dSigma_m^var Si, negMp1 = -Si dSigma_m^range Si: k x k row-major (symmetric);
+   w = W^-1 (B C)' D^-1 B y.  sums12 = {S1, S2, S3, S4, S5, S6} x {variance, range} in the order [2 * S + p] (vif_kernels.hip).  keep_factor: also keep
+   dA / dD on the device for gpb_hip_vecchia_vif_get_grad_factor (tests). */
+int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si, const double* N0,
+                                  const double* negMp1, const double* w_host, int keep_factor, double* sums12_host) {
+  API_BEGIN();
+  if (!h || !Winv || !Si || !N0 || !negMp1 || !w_host || !sums12_host) return fail("null argument");
+  if (h->vif_k < 1 || !h->has_factor || !h->vif_has_grad_inputs) return fail("gpb_hip_vecchia_vif_grad_sums needs gpb_hip_vecchia_vif_factor(with_grad = 1) first");
+  if (cov_type < 0 || cov_type > 2) return fail("covariance type %d is not on the HIP hot path (Matern 0.5/1.5/2.5 only)", cov_type);
+  HIP_OK(hipSetDevice(h->device));
+  const int n = h->n, k = h->vif_k, kp = h->vif_kp, kq = h->vif_kq;
+  const size_t nk = sizeof(double) * (size_t)n * kq;
+  if (!h->d_vX1) {
+    HIP_OK(hipMalloc(&h->d_vX1, nk)); HIP_OK(hipMalloc(&h->d_vV1, nk)); HIP_OK(hipMalloc(&h->d_vX2, nk)); HIP_OK(hipMalloc(&h->d_vHm, nk));
+    HIP_OK(hipMalloc(&h->d_vw, sizeof(double) * (size_t)kq)); HIP_OK(hipMalloc(&h->d_vv, sizeof(double) * (size_t)n)); HIP_OK(hipMalloc(&h->d_vz, sizeof(double) * (size_t)n));
+  }
+  if (keep_factor && !h->d_vdA) {
+    HIP_OK(hipMalloc(&h->d_vdA, sizeof(double) * 2 * (size_t)n * h->m)); HIP_OK(hipMalloc(&h->d_vdD, sizeof(double) * 2 * (size_t)n));
+  }
+  if (vif_upload_matrix(h, 1, Winv, false) || vif_upload_matrix(h, 2, Si, false) || vif_upload_matrix(h, 3, N0, false) || vif_upload_matrix(h, 4, negMp1, false)) return -1;
+  std::vector<double> wq((size_t)kq, 0.0);
+  for (int j = 0; j < k; ++j) wq[j] = w_host[j];
+  HIP_OK(hipMemcpyAsync(h->d_vw, wq.data(), sizeof(double) * (size_t)kq, hipMemcpyHostToDevice, h->stream));
+  const size_t mm = (size_t)kq * kq;
+  HIP_OK(gpb::launch_vif_gemm(h->d_vQ, h->d_vM + 1 * mm, n, kq, h->d_vHm, false, h->stream));      // Hm  = Q W^-1
+  HIP_OK(gpb::launch_vif_gemm(h->d_vQ, h->d_vM + 2 * mm, n, kq, h->d_vX1, false, h->stream));      // X1  = Q Si
+  HIP_OK(gpb::launch_vif_gemm(h->d_vQ, h->d_vM + 3 * mm, n, kq, h->d_vV1, false, h->stream));      // V1  = Q (2 Si - Si dSm0 Si) = X1 + X2^0
+  HIP_OK(gpb::launch_vif_gemm(h->d_vQdC, h->d_vM + 2 * mm, n, kq, h->d_vX2, false, h->stream));    // X2r = (B dC) Si ...
+  HIP_OK(gpb::launch_vif_gemm(h->d_vQ, h->d_vM + 4 * mm, n, kq, h->d_vX2, true, h->stream));       //       ... - Q Si dSm1 Si
+  HIP_OK(gpb::launch_vif_vec(h->d_vQ, h->d_vC, h->d_D, h->d_vw, n, k, kq, h->d_vv, h->d_vz, h->stream));
+  gpb::VecchiaKernelArgs ka;
+  ka.pts = h->d_pts; ka.nn = h->d_nn; ka.exp_tab = h->d_exp_tab; ka.partials = nullptr;
+  ka.A = h->d_A; ka.D = h->d_D; ka.u = h->d_u;
+  ka.m = h->m; ka.i_begin = 0; ka.i_end = n;
+  ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
+  gpb::VifGradLaunch L;
+  L.V = h->d_V; L.C = h->d_vC; L.dC = h->d_vdC; L.Q = h->d_vQ; L.QdC = h->d_vQdC; L.X1 = h->d_vX1; L.V1 = h->d_vV1; L.X2r = h->d_vX2; L.Hm = h->d_vHm;
+  L.w = h->d_vw; L.v = h->d_vv; L.z = h->d_vz;
+  L.dA0 = keep_factor ? h->d_vdA : nullptr; L.dA1 = keep_factor ? h->d_vdA + (size_t)n * h->m : nullptr;
+  L.dD0 = keep_factor ? h->d_vdD : nullptr; L.dD1 = keep_factor ? h->d_vdD + n : nullptr;
+  L.partials = h->d_vif_part;
+  HIP_OK(gpb::launch_vif_resid_grad(cov_type, ka, L, k, kq, kp, h->stream));
+  HIP_OK(gpb::launch_reduce_partials(h->d_vif_part, n, GPB_VIF_GRAD_TERMS, h->d_vout, nullptr, h->stream, nullptr));
+  HIP_OK(hipMemcpyAsync(sums12_host, h->d_vout, sizeof(double) * GPB_VIF_GRAD_TERMS, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->vif_has_grad_factor = keep_factor != 0;
+  API_END();
+}
+
+/* dA (n x m) and dD (n) of parameter p (0: variance, 1: range; log scale) of the last gpb_hip_vecchia_vif_grad_sums(keep_factor = 1), Vecchia order */
+int gpb_hip_vecchia_vif_get_grad_factor(gpb_hip_vecchia_t* h, int p, double* dA_host, double* dD_host) {
+  API_BEGIN();
+  if (!h || !dA_host || !dD_host || p < 0 || p > 1) return fail("bad argument");
+  if (!h->vif_has_grad_factor) return fail("gpb_hip_vecchia_vif_get_grad_factor needs gpb_hip_vecchia_vif_grad_sums(keep_factor = 1) first");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpy(dA_host, h->d_vdA + (size_t)p * h->n * h->m, sizeof(double) * (size_t)h->n * h->m, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(dD_host, h->d_vdD + (size_t)p * h->n, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost));
   API_END();
 }
 
@@ -1346,30 +1436,28 @@ int gpb_hip_vecchia_vif_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, c
   if (rc) return -1;
   const int n_obs = h->n, n_all = n_obs + n_pred, k = h->vif_k;
   if (gpb_hip_vecchia_vif_set_inducing_points(t, k, ip_colmajor)) return -1;
-  const int kp = t->vif_kp;
+  const int kp = t->vif_kp, kq = t->vif_kq;
   if (!t->d_A) {
     HIP_OK(hipMalloc(&t->d_A, sizeof(double) * (size_t)n_all * t->m));
     HIP_OK(hipMalloc(&t->d_D, sizeof(double) * (size_t)n_all));
     HIP_OK(hipMalloc(&t->d_u, sizeof(double) * (size_t)n_all));
   }
-  HIP_OK(hipMemcpyAsync(t->d_Linv, Linv_rowmajor, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, t->stream));
-  HIP_OK(gpb::launch_vif_crosscov(cov_type, t->d_pts, t->d_ip, n_all, k, t->d, var, a, t->d_X, t->stream));
-  HIP_OK(gpb::launch_vif_whiten(t->d_X, t->d_Linv, n_all, k, kp, t->d_V, t->stream));
+  if (vif_upload_matrix(t, 0, Linv_rowmajor, true)) return -1;
+  HIP_OK(gpb::launch_vif_crosscov(cov_type, t->d_pts, t->d_ip, 0, n_all, k, kq, t->d, var, a, t->d_vC, nullptr, t->stream));
+  HIP_OK(gpb::launch_vif_gemm(t->d_vC, t->d_vM, n_all, kq, t->d_V, false, t->stream));
   gpb::VecchiaKernelArgs ka;
   ka.pts = t->d_pts; ka.nn = t->d_nn; ka.exp_tab = t->d_exp_tab; ka.partials = t->d_vif_part;
   ka.A = t->d_A; ka.D = t->d_D; ka.u = t->d_u;
   ka.m = t->m; ka.i_begin = n_obs; ka.i_end = n_all;
   ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
-  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, t->d_V, k, kp, t->stream));
-  // (B C) of the appended rows, column by column (the observed rows of the temporary state have no neighbours: B = I there, A is not read)
-  for (int j = 0; j < k; ++j) HIP_OK(gpb::launch_By(t->d_A, t->d_nn, n_all, t->m, t->d_X + (size_t)j * n_all, t->d_U + (size_t)j * n_all, t->stream));
+  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, t->d_V, k, kq, kp, t->stream));
+  // (B C) of the appended rows
+  HIP_OK(gpb::launch_vif_spmm(t->d_A, t->d_nn, n_obs, n_all, t->m, kq, t->d_vC, t->d_vQ, nullptr, nullptr, t->stream));
   HIP_OK(hipMemcpyAsync(u_pred, t->d_u + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost, t->stream));
   HIP_OK(hipMemcpyAsync(D_pred, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost, t->stream));
-  std::vector<double> cols((size_t)n_pred * k);
-  HIP_OK(hipMemcpy2DAsync(cols.data(), sizeof(double) * (size_t)n_pred, t->d_U + n_obs, sizeof(double) * (size_t)n_all, sizeof(double) * (size_t)n_pred, (size_t)k,
+  HIP_OK(hipMemcpy2DAsync(BC_pred, sizeof(double) * (size_t)k, t->d_vQ + (size_t)n_obs * kq, sizeof(double) * (size_t)kq, sizeof(double) * (size_t)k, (size_t)n_pred,
                           hipMemcpyDeviceToHost, t->stream));
   HIP_OK(hipStreamSynchronize(t->stream));
-  for (int i = 0; i < n_pred; ++i) for (int j = 0; j < k; ++j) BC_pred[(size_t)i * k + j] = cols[(size_t)j * n_pred + i];
   API_END();
 }
 

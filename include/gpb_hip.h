@@ -138,16 +138,30 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_set_nugget_diag(gpb_hip_vecchia_t* h, const d
 
 /* Full-scale Vecchia ("VIF": Vecchia-inducing-points full-scale) approximation, Gaussian likelihood, Euclidean neighbours -- the
  * device part of CalcSigmaComps (include/GPBoost/re_model_template.h:8151-8200: cross-covariances, V = L_m^-1 C_mn), of the
- * full_scale_vecchia branches of CalcCovFactorGradientVecchia (src/GPBoost/Vecchia_utils.cpp:1463-1500, 1599-1623: the Vecchia factor
- * of the residual process) and of CalcCovFactorFITC_FSA (re_model_template.h:9646-9745: (B C_nm)' D^-1 (B C_nm) through
- * gpb_hip_vecchia_gram, whose "covariates" are C_nm after these calls).  The k x k matrices (Sigma_m, its Cholesky factor, the
- * Woodbury matrix) stay on the host, k <= 256.
+ * full_scale_vecchia branches of CalcCovFactorGradientVecchia (src/GPBoost/Vecchia_utils.cpp:1463-1524, 1599-1656: the Vecchia factor
+ * of the residual process and its derivatives), of CalcCovFactorFITC_FSA (re_model_template.h:9646-9745: B C_nm and (B C_nm)' D^-1 (B C_nm))
+ * and of CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i (:2205-2330, 2447-2452).  The k x k matrices (Sigma_m, its Cholesky factor, the
+ * Woodbury matrix, their inverses) stay on the host, k <= 256.
  *   set_inducing_points   ip: column-major k x d (the host's kmeans++, GP_utils.cpp:208-308)
- *   vif_factor            Linv: k x k row-major inverse of chol(Sigma_m with its diagonal x (1 + 1e-6));
- *                         out3 = { sum u_i^2 / D_i, sum log D_i, #(D_i <= 0) } of the residual factor; A / D / u stay on the device */
+ *   vif_factor            Linv: k x k row-major inverse of chol(Sigma_m with its diagonal x (1 + 1e-6)); with_grad: also the range derivative of
+ *                         C_nm and B dC_nm (inputs of vif_grad_sums);
+ *                         out3 = { sum u_i^2 / D_i, sum log D_i, #(D_i <= 0) } of the residual factor;
+ *                         G = (B [C_nm, y])' D^-1 (B [C_nm, y]), (k + 1) x (k + 1) row-major; A / D / u / B C_nm stay on the device
+ *   vif_grad_sums         after vif_factor(with_grad = 1) at the same parameters.  Winv = W^-1 (W = Sigma_m + (B C)' D^-1 (B C)), Si = Sigma_m^-1,
+ *                         N0 = 2 Si - Si dSigma_m/dlog(var) Si, negMp1 = -Si dSigma_m/dlog(a) Si (derivatives of the UN-jittered Sigma_m as in the
+ *                         reference), all k x k row-major; w = W^-1 (B C)' D^-1 B y.  sums12[2 s + p], p = 0 variance / 1 range, over the points i:
+ *                           s = 0: dD_i / D_i                         s = 1: 2 (dB z)_i v_i - v_i^2 dD_i     (z = y - C w, v = D^-1 B z)
+ *                           s = 2: (dB C)_i . Hm_i / D_i  (Hm = B C W^-1)   s = 3: dD_i (B C)_i . Hm_i / D_i^2
+ *                           s = 4: (B dC)_i . Hm_i / D_i               s = 5: v_i (B dC)_i . w
+ *                         from which  d(y' Psi^-1 y) = S2 - 2 S6 + w' dSigma_m w  and
+ *                         d log|Psi| = S1 - tr(Si dSigma_m) + tr(Winv dSigma_m) + 2 S5 + 2 S3 - S4   (DESIGN.md 4.12).
+ *   vif_get_grad_factor   dA_i (n x m) and dD_i (n) of parameter p of the last vif_grad_sums(keep_factor = 1): the reference's -B_grad / D_grad */
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip_colmajor);
-GPB_HIP_EXPORT int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Linv_rowmajor,
-                                              double* out3_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Linv_rowmajor, int with_grad,
+                                              double* out3_host, double* G_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si,
+                                                 const double* N0, const double* negMp1, const double* w_host, int keep_factor, double* sums12_host);
+GPB_HIP_EXPORT int gpb_hip_vecchia_vif_get_grad_factor(gpb_hip_vecchia_t* h, int p, double* dA_host, double* dD_host);
 
 /* In-library RCCL reduction over the ranks of a node (one process per GPU; xGMI): the communicator is bootstrapped from a
  * 128-byte ncclUniqueId made on rank 0 and handed to every rank by the host (e.g. a torch.distributed broadcast).

@@ -300,6 +300,16 @@ GPBOOST_C_EXPORT int GPB_HIP_GetOptimInfo(REModelHandle handle, int* num_ll_eval
  * one-cluster model with vecchia_ordering = "random").  theta3 = (sigma2, sigma1_2 / sigma2, a), transformed scale. */
 GPBOOST_C_EXPORT int GPB_HIP_FindInitCovParHost(int32_t num_data, const double* y_data, const double* fixed_effects, int32_t n0, int32_t dim,
     const double* coords0_colmajor, int cov_type, int seed, int32_t shuffle_len, double* theta3);
+/* Test seam: derivative factors dA (n x m) / dD (n) of the residual process of a full-scale Vecchia (VIF) model at cov_pars, parameter p (0 variance, 1 range) */
+GPBOOST_C_EXPORT int GPB_HIP_VifGradFactor(REModelHandle handle, double* cov_pars, int p, double* dA, double* dD);
+
+/* Test seam: host half of the full-scale Vecchia (VIF) likelihood + analytic gradient (gpb_c_api.cpp: vif_terms_core) with the two device passes
+ * (gpb_hip_vecchia_vif_factor, gpb_hip_vecchia_vif_grad_sums) supplied by the caller.  t7 = {quad, logdet, bad, g1_var, g2_var, g1_range, g2_range}. */
+GPBOOST_C_EXPORT int GPB_HIP_VifTermsWithCallback(int32_t k, int32_t d, const double* ip_colmajor, int cov_type, double ratio, double a, int with_grad,
+                                                  int (*factor)(void*, const double*, int, double*, double*),
+                                                  int (*gsums)(void*, const double*, const double*, const double*, const double*, const double*, double*),
+                                                  void* ctx, double* t7);
+
 /* Test seam: the host optimiser of GPB_OptimCovPar with a caller-supplied evaluation callback
  * terms(ctx, sigma1_2 / sigma2, a, with_grad, t7) -> 0 | -1 that fills the seven shard sums of gpb_hip_vecchia_grad_terms
  * (t7[0..1] only when with_grad == 0).  init_theta / theta_out = (sigma2, sigma1_2 / sigma2, a): the reference's transformed

@@ -647,6 +647,41 @@ def vif_fit_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "vif_fit_ref.npz"), **res)
 
 
+VIF_GRAD_CASES = ["vif_u2d_n1500_exp_m15_k40_none", "vif_u2d_n1500_exp_m15_k40_random", "vif_u2d_n3000_mat15_m30_k100_random",
+                  "vif_u3d_n2000_mat25_m20_k64_random", "vif_u2d_n20000_exp_m30_k200_random", "vif_u2d_n100000_exp_m30_k200_random"]
+VIF_GRAD_PARS = [(0.1, 1.0, 0.1), (0.3, 0.6, 0.25)]
+
+
+def vif_grad_fixture(out_dir, only=None):
+    """Gradient of the full-scale Vecchia (VIF) likelihood by the unmodified reference (REModelTemplate::CalcGradPars ->
+    CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i through oracle/ref_driver.cpp:refdrv_nll_grad -- the sequence of the L-BFGS functor) at
+    VIF_GRAD_PARS for every case of VIF_GRAD_CASES: negll, the three gradient entries wrt the log of the transformed parameters
+    (sigma2, sigma1_2 / sigma2, a) and, for n <= 3000, 200 sampled rows of the derivative factors dA / dD of both parameters
+    (tests/golden/vif_grad_ref.npz)."""
+    import time
+    path = os.path.join(out_dir, "vif_grad_ref.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in VIF_GRAD_CASES:
+        if only and name not in only:
+            continue
+        n, d, cf, sh, m, k, ordering, seed, cps = cases.VIF_CASES[name]
+        coords, y = cases.vif_data(name)
+        mdl = refdrv.RefVifModel(coords, cf, sh, m, ordering, seed, num_ind_points=k, threads=8)
+        for j, cp in enumerate(VIF_GRAD_PARS):
+            t0 = time.time()
+            nll, g, pt = mdl.nll_grad(y, np.asarray(cp, dtype=np.float64))
+            res["%s_negll_%d" % (name, j)] = np.float64(nll); res["%s_grad_%d" % (name, j)] = g; res["%s_pars_trans_%d" % (name, j)] = pt
+            if n <= 3000:
+                rows = np.sort(np.random.default_rng(5).choice(n, size=200, replace=False))
+                res["%s_rows" % name] = rows
+                for p in range(2):
+                    dA, dD = mdl.grad_factor(p)
+                    res["%s_dA%d_%d" % (name, p, j)] = dA[rows]; res["%s_dD%d_%d" % (name, p, j)] = dD[rows]
+            print("vif grad", name, cp, "negll = %.12f" % nll, g, "%.1f s" % (time.time() - t0), flush=True)
+        del mdl
+        np.savez_compressed(path, **res)
+
+
 def weights_fixture(out_dir, only=None):
     """Sample weights (Gaussian Vecchia model): the unmodified reference's likelihood values, lbfgs fit and predictions after the fit on
     tests/cases.py:WEIGHT_CASES (tests/golden/weights_ref.npz)."""
@@ -817,6 +852,8 @@ if __name__ == "__main__":
         exact_fisher_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "predtypes":
         predtypes_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_grad":
+        vif_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif":
         vif_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "config4":

@@ -321,4 +321,59 @@ int refdrv_laplace_grad_F(void* h, const double* y, const double* fixed_effects,
   }
 }
 
+/* ---- full-scale Vecchia ("VIF"), Gaussian likelihood: the reference's own REModel with gp_approx = "full_scale_vecchia" ----
+ * refdrv_nll_grad works on such a handle unchanged (CalcGradPars dispatches to CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i,
+ * include/GPBoost/re_model_template.h:2205-2330); the two functions below expose what its public API does not: the inducing points
+ * and the derivative factors B_grad = -dA / D_grad of the residual process (src/GPBoost/Vecchia_utils.cpp:1503-1524, 1640-1656). */
+__attribute__((visibility("default")))
+void* refdrv_create_vif(int n, const double* coords_colmajor, int d, const char* cov_fct, double shape, int m,
+                        const char* ordering, int seed, int num_ind_points, int num_threads) {
+  try {
+    return new REModel(n, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, coords_colmajor, d, nullptr, 0,
+                       cov_fct, shape, "full_scale_vecchia", 1., 0., m, ordering, num_ind_points, 1., "kmeans++",
+                       "gaussian", 1., "cholesky", seed, num_threads, false, false, nullptr, 1.);
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_create_vif: %s\n", e.what());
+    return nullptr;
+  }
+}
+
+/* after refdrv_nll_grad on a VIF handle: dA (n x m, aligned with the neighbour table) and dD of parameter ipar (0: variance, 1: range),
+ * derivatives wrt the log of the transformed parameters; optionally the factor itself and y_aux (Vecchia order) */
+__attribute__((visibility("default")))
+int refdrv_get_grad_factor(void* h, int m, int ipar, double* dA, double* dD) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    const int c0 = t->unique_clusters_[0];
+    const sp_mat_t& Bg = t->B_grad_[c0][0][ipar];
+    const sp_mat_t& Dg = t->D_grad_[c0][0][ipar];
+    const auto& nn = t->nearest_neighbors_[c0][0];
+    const int n = (int)nn.size();
+    for (int i = 0; i < n; ++i) {
+      dD[i] = Dg.coeff(i, i);
+      for (int j = 0; j < m; ++j) dA[(size_t)i * m + j] = (j < (int)nn[i].size()) ? -Bg.coeff(i, nn[i][j]) : 0.;
+    }
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_get_grad_factor: %s\n", e.what());
+    return -1;
+  }
+}
+
+/* y_aux = Psi^-1 y of the last evaluation (Vecchia order), any approximation */
+__attribute__((visibility("default")))
+int refdrv_get_yaux(void* h, double* yaux) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    const int c0 = t->unique_clusters_[0];
+    t->CalcYAux(1., false);
+    const vec_t& ya = t->y_aux_[c0];
+    for (int i = 0; i < (int)ya.size(); ++i) yaux[i] = ya[i];
+    return (int)ya.size();
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_get_yaux: %s\n", e.what());
+    return -1;
+  }
+}
+
 }  // extern "C"

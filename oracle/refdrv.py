@@ -85,6 +85,37 @@ class RefModel(object):
         return out
 
 
+class RefVifModel(RefModel):
+    """One Gaussian full-scale Vecchia (VIF) model built by the reference's own REModel constructor (gp_approx = "full_scale_vecchia"):
+    nll_grad / perm / neighbors as RefModel; grad_factor() = the derivative factors of the residual process of the last nll_grad call."""
+
+    def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=0, num_ind_points=200, threads=8):
+        cm = np.asfortranarray(coords, dtype=np.float64)
+        self.n, self.d = cm.shape
+        self.m = min(m, self.n - 1)
+        L = _lib()
+        L.refdrv_create_vif.restype = C.c_void_p
+        L.refdrv_create_vif.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_double, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        h = L.refdrv_create_vif(self.n, _P(cm), self.d, cov_function.encode(), float(shape), int(m), ordering.encode(), int(seed),
+                                int(num_ind_points), int(threads))
+        if not h:
+            raise RuntimeError("reference VIF model creation failed")
+        self.h = C.c_void_p(h)
+
+    def grad_factor(self, ipar):
+        """(dA, dD) of parameter ipar (0: variance, 1: range) wrt the log of the transformed parameter, aligned with neighbors()."""
+        dA = np.empty((self.n, self.m)); dD = np.empty(self.n)
+        if _lib().refdrv_get_grad_factor(self.h, C.c_int(self.m), C.c_int(ipar), _P(dA), _P(dD)) != 0:
+            raise RuntimeError("refdrv_get_grad_factor failed")
+        return dA, dD
+
+    def yaux(self):
+        ya = np.empty(self.n)
+        if _lib().refdrv_get_yaux(self.h, _P(ya)) < 0:
+            raise RuntimeError("refdrv_get_yaux failed")
+        return ya
+
+
 # ---------------------------------------------------------------------------------------------
 # The reference's own public C API (lib_gpboost_ref.so), bound the way python-package/gpboost/basic.py:5206-5240
 # binds it: used as the "reference" CPU baseline of bench.py (BASELINE.md section 3).

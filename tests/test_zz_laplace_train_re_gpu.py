@@ -4,7 +4,7 @@ values, tests/golden/laplace_train_re_ref.npz (oracle/make_golden.py laplace_tra
 tests/test_laplace_predvar.py.
 
 This file sorts last on purpose: its device half (gpb_hip_vecchia_laplace_mode_var = the block solves of the predictive variances on unit vectors,
-which ARE validated on the MI355X, profiles/r03_zzz_predvar_quick.log) was added after the GPU budget of round 3 was spent and has not run on a device yet."""
+which ARE validated on the MI355X, profiles/r03_zzz_predvar_quick.log) was added after the GPU budget of round 3 was spent; its first device run was the driver's at the end of round 3 (all passed), since round 4 these are hard tests."""
 import os
 
 import numpy as np
@@ -13,9 +13,7 @@ import pytest
 from tests import cases
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "laplace_train_re_ref.npz")
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="device half written after the GPU budget of round 3 was spent: not yet run on an MI355X "
-                                                     "(expected to pass; remove this marker after the first run)")]
+pytestmark = [pytest.mark.gpu]
 
 
 @pytest.mark.parametrize("lik", ["bernoulli_logit", "bernoulli_probit", "poisson"])
