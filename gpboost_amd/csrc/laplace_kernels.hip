@@ -1228,6 +1228,128 @@ __global__ __launch_bounds__(kSfThreads) void lap_sptrsv_sf_kernel(LapTri T, int
   }
 }
 
+// ---- barrier-free solve of the PROBE BLOCK (round 4): one WAVEFRONT per row, all column chunks -------------------------------------------
+// lap_sptrsv_sf_kernel gives every (row, chunk of 4 columns) pair its own 16-lane group: at n = 1e5 the 13 chunks of the 50 probe vectors are
+// ~9600 groups per dependency level, each polling its 32 sources with 128 8-byte loads per pass -- measured SLOWER than one launch per level
+// (profiles/r03_c_*: 442 vs 362 ms per log-determinant), the pollers crowd out the stores they wait for.  Here a row is owned by ONE wavefront
+// for all its chunks: lane = (cg, e), e = lane % 16 the entry slot (entries e and e + 16 of the slot's 32-wide head, as in every other solve
+// kernel), cg = lane / 16 takes the chunks cg, cg + 4, cg + 8, cg + 12.  The slot descriptor and the matrix entries are loaded ONCE per row
+// (not once per chunk: 13x less index / coefficient traffic), the readiness of a source row is discovered once for all its chunks, and a
+// level has ~740 pollers, not 9600.  Same arithmetic per (row, column) as lap_sptrsv_kernel / lap_sptrsv_sf_kernel -- per slot the fma chain over
+// the lane's entries in the same order, the same 16-lane butterfly, split rows added slot by slot: results are bit-identical to the
+// level-scheduled solve.  Forward progress as in lap_sptrsv_sf_kernel: the grid is resident (host: occupancy x CUs), a wavefront takes its slots
+// in increasing (= level) order, a wavefront handles ONE row at a time (no lane ever waits for another lane of its own wavefront); spins are
+// bounded (kLapSpinLimit) and a give-up sets the error word instead of hanging the device.
+constexpr int kSfwThreads = 256;
+constexpr int kSfwMaxChunkPerLaneGroup = 4;             // chunks per 16-lane group: up to 16 chunks = 64 columns per block
+
+__device__ __forceinline__ void lap_sfw_peek4(const double* xchunk, unsigned src, double (&g)[4], bool& ok) {
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(xchunk) + src * 32u);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long raw = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = ok && raw != kLapEmpty;
+    g[c] = __longlong_as_double((long long)raw);
+  }
+}
+
+template <bool SCALE, bool OVF>
+__global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, int n, int qa, int qb, int ncol, const double* __restrict__ rhs,
+                                                                   const double* __restrict__ rdw, double* x, int* err) {
+  const int lane = threadIdx.x & 63, e = lane & 15, cg = lane >> 4;
+  const int NW = gridDim.x * (kSfwThreads / 64);
+  const size_t cstride = (size_t)n * 4;                  // doubles per chunk of the [chunk][row][4] layout
+  int q = qa + blockIdx.x * (kSfwThreads / 64) + (threadIdx.x >> 6);
+  int4 m_nx = T.meta[q < qb ? q : qa];
+  LapEnt h_nx[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) h_nx[k] = T.hent[(size_t)(q < qb ? q : qa) * 32 + e + 16 * k];
+  for (; q < qb; q += NW) {
+    const int4 m0 = m_nx;
+    LapEnt h0[2] = {h_nx[0], h_nx[1]};
+    {
+      const int qn = q + NW < qb ? q + NW : q;
+      m_nx = T.meta[qn];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) h_nx[k] = T.hent[(size_t)qn * 32 + e + 16 * k];
+    }
+    if (m0.y <= 0) continue;                             // continuation / padding slot (uniform over the wavefront)
+    const unsigned row = (unsigned)m0.x;
+    double v[kSfwMaxChunkPerLaneGroup][4];
+    int passes = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = 0.0;
+      for (int sl = 0; sl < m0.y; ++sl) {
+        const int qq = q + sl;
+        int ob = m0.z, oe = m0.w;
+        if (sl > 0) { const int4 ms = T.meta[qq]; ob = ms.z; oe = ms.w; }
+        double sum[kSfwMaxChunkPerLaneGroup][4];
+#pragma unroll
+        for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sum[j][c] = 0.0;
+        auto take = [&](const LapEnt& en) {
+          if (en.val != 0.0) {                           // (padding: coefficient 0 -- not a dependency)
+#pragma unroll
+            for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
+              const int ch = cg + 4 * j;
+              if (ch < ncol) {
+                double g[4];
+                lap_sfw_peek4(x + (size_t)ch * cstride, (unsigned)en.src, g, ok);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum[j][c] = __builtin_fma(en.val, g[c], sum[j][c]);
+              }
+            }
+          }
+        };
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const LapEnt h = sl == 0 ? h0[k] : T.hent[(size_t)qq * 32 + e + 16 * k];
+          take(h);
+          if (OVF) {
+            const int eo = ob + e + 16 * k;
+            if (eo < oe) take(T.oent[eo]);
+          }
+        }
+        if (OVF) for (int e0 = ob + 32 + e; e0 - e < oe; e0 += 64) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int eo = e0 + 16 * k;
+            if (eo < oe) take(T.oent[eo]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[j][c] += row16_sum(sum[j][c]);       // (first slot: 0 + its sum, exact)
+      }
+      if (__all(ok)) break;                              // every source of every chunk of this row has arrived
+      if (++passes > kLapSpinLimit) { if (lane == 0) *err = 1; break; }       // give the row up: never hang the device
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (e == 0) {
+      const double den = SCALE ? rdw[row] : 1.0;
+#pragma unroll
+      for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
+        const int ch = cg + 4 * j;
+        if (ch < ncol) {
+          const VecN<4> num = ldvec<4, 4>(rhs + (size_t)ch * cstride, row);
+          unsigned long long* xr = reinterpret_cast<unsigned long long*>(x + (size_t)ch * cstride + (size_t)row * 4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double out = SCALE ? __builtin_fma(num.v[c], den, v[j][c]) : num.v[c] + v[j][c];
+            __hip_atomic_store(xr + c, (unsigned long long)__double_as_longlong(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+  }
+}
+
 // OVF = false: no slot has more than 32 entries (B with m <= 32 neighbours): the overflow loads and gathers are compiled out
 #define LAP_TRSV_NC(SCALE, OVF_, NC_, LS_, T_, SEG, RHS, RDW, X)                                                                     \
   hipLaunchKernelGGL((lap_sptrsv_kernel<SCALE, OVF_, NC_, LS_>), dim3(ncol * (LS_ / NC_) * (SEG).nsplit), dim3(kTriThreads), 0, st, T_, \
@@ -1301,8 +1423,45 @@ static hipError_t lap_trsv_syncfree(const LapTri& T, const int* host_ptr, const 
   }
   return hipGetLastError();
 }
+// probe block (nc == 4), one wavefront per row over all chunks: one launch (+ the sentinel prefill) per triangular solve
+template <bool SCALE>
+static hipError_t lap_trsv_syncfree_block(const LapTri& T, const int* host_ptr, const LapSeg* seg, int nseg, int n, const double* rhs, const double* rdw, double* x,
+                                          int ncol, int* err, hipStream_t st) {
+  if (nseg <= 0) return hipSuccess;
+  const int qa = host_ptr[seg[0].L0], qb = host_ptr[seg[nseg - 1].L1];
+  if (qb <= qa) return hipSuccess;
+  static int resident = 0, wanted = 0;     // workgroups the device holds at once; workgroups to launch (GPB_LAP_SFW_WGS, default 3 per CU)
+  if (resident == 0) {
+    int occ = 0, cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lap_sptrsv_sfw_kernel<true, true>, kSfwThreads, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
+    resident = std::max(1, occ * cus / 2);               // conservative: half of what the occupancy calculator admits
+    wanted = std::min(resident, 3 * cus);
+    if (const char* ev = std::getenv("GPB_LAP_SFW_WGS")) { const int w = std::atoi(ev); if (w > 0) wanted = std::min(resident, w); }
+    (void)hipGetLastError();
+  }
+  const int nslot = qb - qa;
+  const int wgs = std::max(1, std::min(wanted, (nslot + kSfwThreads / 64 - 1) / (kSfwThreads / 64)));
+  for (int c0 = 0; c0 < ncol; c0 += 4 * kSfwMaxChunkPerLaneGroup) {       // at most 16 chunks per pass
+    const int cn = std::min(ncol - c0, 4 * kSfwMaxChunkPerLaneGroup);
+    const size_t coff = (size_t)c0 * 4 * n;
+    const dim3 pg((nslot + 255) / 256, cn);
+    hipLaunchKernelGGL((lap_sf_prefill_kernel<4, 4>), pg, dim3(256), 0, st, T, qa, qb, n, x + coff);
+    if (T.has_ovf) hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, true>), dim3(wgs), dim3(kSfwThreads), 0, st, T, n, qa, qb, cn, rhs + coff, rdw, x + coff, err);
+    else hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, false>), dim3(wgs), dim3(kSfwThreads), 0, st, T, n, qa, qb, cn, rhs + coff, rdw, x + coff, err);
+  }
+  return hipGetLastError();
+}
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
-  if (nc == 4 ? (lv.syncfree & 2) : (lv.syncfree & 1)) {      // bit 0: single vectors (mode finding), bit 1: the probe block
+  if (nc == 4 && (lv.syncfree & 4)) {                          // bit 2: the probe block, one wavefront per row over all chunks (round 4)
+    (void)lap_trsv_syncfree_block<false>(lv.bwd, lv.bwd_ptr_host, lv.bseg, lv.n_bseg, n, r, nullptr, t, ncol, lv.err, st);        // B^T t = r
+    lap_dense_solve<false>(lv.bdense, lv.A, n, r, nullptr, t, ncol, nc, st);
+    lap_dense_solve<true>(lv.fdense, lv.A, n, t, rdw, z, ncol, nc, st);
+    (void)lap_trsv_syncfree_block<true>(lv.fwd, lv.fwd_ptr_host, lv.fseg, lv.n_fseg, n, t, rdw, z, ncol, lv.err, st);             // (D^-1 + W) B z = t
+    return hipGetLastError();
+  }
+  if (nc == 4 ? (lv.syncfree & 2) : (lv.syncfree & 1)) {      // bit 0: single vectors (mode finding), bit 1: the probe block, one 16-lane group per (row, chunk)
     (void)lap_trsv_syncfree<false>(lv.bwd, lv.bwd_ptr_host, lv.bseg, lv.n_bseg, n, r, nullptr, t, ncol, nc, lv.err, st); // B^T t = r
     lap_dense_solve<false>(lv.bdense, lv.A, n, r, nullptr, t, ncol, nc, st);
     lap_dense_solve<true>(lv.fdense, lv.A, n, t, rdw, z, ncol, nc, st);
