@@ -21,6 +21,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <cerrno>
 #include <vector>
 
 #include "dense_kernels.h"
@@ -29,6 +31,10 @@
 #include "nn_kernels.h"
 #include "vecchia_kernels.h"
 #include "vif_kernels.h"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -202,6 +208,38 @@ static int comm_allreduce(GpbComm& c, void* buf, size_t count, GpbType type, Gpb
 }
 
 // ------------------------------------------------------------------------------------------
+// Node-local MAILBOX for the 3 / 7 sums of a sharded likelihood evaluation (round 4).  ncclAllReduce of 24 / 56 bytes
+// costs ~24 us with ONE rank in the loop (launch of the collective kernel + the publish kernel behind it) -- the largest term outside the shard
+// kernel at N = 8.  The sums do not need a device collective at all: every rank's finisher workgroup already stores them
+// straight into pinned host memory with system-scope stores ("the data is the flag", vecchia_kernels.hip: vecchia_finish) and its host polls
+// for them.  The mailbox makes that pinned buffer a POSIX shared-memory segment mapped by every rank of the node: rank r's GPU writes slot r,
+// every host polls all `world` slots and adds them IN RANK ORDER -- the same bits on every rank, no collective launch, no second kernel, no
+// peer access; the cross-rank step is the hosts' cache coherence.  Layout: header {magic, world, ready[world]}, then [3 generations][world][8]
+// doubles.  Generation g = evaluation count % 3; at the start of evaluation e a rank re-arms ITS OWN slot of generation (e + 1) % 3 with the
+// sentinel: no rank can still be reading that generation (it was read in evaluation e - 2, and a rank only starts evaluation e after every
+// rank's result of e - 1 has arrived, i.e. after every rank finished e - 2).  RCCL stays for the big messages (y_aux, histograms, tables).
+struct GpbMailbox {
+  int world = 0, rank = -1;
+  void* base = nullptr; size_t bytes = 0;
+  double* dev_base = nullptr;                 // device address of the mapping (hipHostGetDevicePointer)
+  unsigned long long evals = 0;
+  char name[64] = "";
+  static constexpr unsigned long long kMagic = 0x4750424d41494c42ull;   // "GPBMAILB"
+  static size_t header_bytes(int w) { return ((16 + 8 * (size_t)w) + 63) / 64 * 64; }
+  static size_t total_bytes(int w) { return header_bytes(w) + sizeof(double) * 3 * (size_t)w * 8; }
+  bool active() const { return base != nullptr; }
+  volatile unsigned long long* slot(int gen, int r) const {
+    return reinterpret_cast<volatile unsigned long long*>(static_cast<char*>(base) + header_bytes(world)) + ((size_t)gen * world + r) * 8;
+  }
+  double* dev_slot(int gen, int r) const {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(dev_base) + header_bytes(world)) + ((size_t)gen * world + r) * 8;
+  }
+  void release() {
+    if (base) { (void)hipHostUnregister(base); (void)munmap(base, bytes); }
+    base = nullptr; dev_base = nullptr; world = 0; rank = -1; bytes = 0; evals = 0;
+  }
+};
+
 struct LaplaceState;                                   // gpb_laplace.inc (Vecchia-Laplace workspace, row a13)
 static void laplace_state_free(LaplaceState* s);
 
@@ -240,6 +278,7 @@ struct gpb_hip_vecchia {
   int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   GpbComm comm;                   // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init / _comm_init_local)
+  GpbMailbox mbox;                // optional: node-local shared-memory mailbox for the 3 / 7 sums of a sharded evaluation (gpb_hip_vecchia_mailbox_attach)
   double* d_red = nullptr;        // 8 doubles: all-reduce buffer in the caller-facing term order
   std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
   std::vector<int> nn_host;
@@ -449,6 +488,7 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   dev_free(h->d_leaf); dev_free(h->d_leaf_part); dev_free(h->d_leaf_out);
   vif_free(h); dev_free(h->d_nug);
   h->comm.release();
+  h->mbox.release();
   laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->h_red) (void)hipHostFree(h->h_red);
@@ -630,7 +670,7 @@ int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) {
 }
 
 static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss, double* out_dev,
-                          int nout, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+                          int nout, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, double* host_slot_dev = nullptr) {
   if (!h) return fail("null handle");
   if (!h->has_nn) return fail("neighbours have not been determined (call gpb_hip_vecchia_find_neighbors / _set_neighbors)");
   if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
@@ -661,11 +701,12 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   if (big) {
     HIP_OK(gpb::launch_vecchia_point_big(mode, cov_type, h->d > 3 ? 0 : (h->d == 3 ? 3 : 2), k, h->stream));
     if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
-    HIP_OK(gpb::launch_reduce_partials(h->d_partials, h->i_end - h->i_begin, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream, h->h_out));
+    HIP_OK(gpb::launch_reduce_partials(h->d_partials, h->i_end - h->i_begin, mode == gpb::MODE_GRAD ? GPB_NUM_PARTIALS : 3, h->d_out, out_dev, h->stream,
+                                       host_slot_dev ? host_slot_dev : h->h_out));
   } else {
     // ONE launch per evaluation: persistent worker workgroups + a finisher workgroup that adds up their sums (vecchia_kernels.hip)
     k.ngroups = (h->i_end - h->i_begin + 15) / 16; k.rounds = h->rounds;
-    k.out = h->d_out; k.out_user = out_dev; k.out_host = h->h_out;
+    k.out = h->d_out; k.out_user = out_dev; k.out_host = host_slot_dev ? host_slot_dev : h->h_out;
     HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
     if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
   }
@@ -780,15 +821,138 @@ int gpb_hip_vecchia_comm_info(gpb_hip_vecchia_t* h, int* rank, int* world) {
   } else if (h->comm.lg) {
     if (rank) *rank = h->comm.rank;
     if (world) *world = h->comm.world;
+  } else if (h->mbox.active()) {     // a handle whose only transport is the node-local mailbox (the 3 / 7 sums of a sharded evaluation)
+    if (rank) *rank = h->mbox.rank;
+    if (world) *world = h->mbox.world;
   }
   API_END();
+}
+
+// ---- node-local mailbox (GpbMailbox above) ----------------------------------------------------------------------------------------
+// rank 0: create the segment for `world` ranks; name_out: 64 bytes, the name every rank attaches to (hand it over like the ncclUniqueId)
+int gpb_hip_mailbox_create(int world, char* name_out64) {
+  API_BEGIN();
+  if (!name_out64 || world < 1 || world > 64) return fail("gpb_hip_mailbox_create: invalid argument");
+  char name[64];
+  std::snprintf(name, sizeof(name), "/gpb_mbox_%d_%llx", (int)getpid(),
+                (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return fail("gpb_hip_mailbox_create: shm_open(%s) failed: %s", name, std::strerror(errno));
+  const size_t bytes = GpbMailbox::total_bytes(world);
+  if (ftruncate(fd, (off_t)bytes) != 0) { (void)close(fd); (void)shm_unlink(name); return fail("gpb_hip_mailbox_create: ftruncate failed: %s", std::strerror(errno)); }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  (void)close(fd);
+  if (p == MAP_FAILED) { (void)shm_unlink(name); return fail("gpb_hip_mailbox_create: mmap failed: %s", std::strerror(errno)); }
+  auto* hdr = static_cast<volatile unsigned long long*>(p);      // fresh segments are zero-filled: ready[] = 0
+  hdr[1] = (unsigned long long)world;
+  std::atomic_thread_fence(std::memory_order_release);
+  hdr[0] = GpbMailbox::kMagic;
+  (void)munmap(p, bytes);
+  std::memset(name_out64, 0, 64);
+  std::strncpy(name_out64, name, 63);
+  API_END();
+}
+// every rank (rank 0 included): map the segment, page-lock it for this rank's device, arm the own slots, wait until all ranks have done so;
+// the name is unlinked once everybody is attached (the mappings keep the segment alive)
+int gpb_hip_vecchia_mailbox_attach(gpb_hip_vecchia_t* h, const char* name, int rank, int world) {
+  API_BEGIN();
+  if (!h || !name || !name[0]) return fail("null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("gpb_hip_vecchia_mailbox_attach: rank %d / world %d", rank, world);
+  HIP_OK(hipSetDevice(h->device));
+  h->mbox.release();
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return fail("gpb_hip_vecchia_mailbox_attach: shm_open(%s) failed: %s", name, std::strerror(errno));
+  const size_t bytes = GpbMailbox::total_bytes(world);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { (void)close(fd); return fail("gpb_hip_vecchia_mailbox_attach: segment %s is smaller than %zu bytes (world mismatch?)", name, bytes); }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  (void)close(fd);
+  if (p == MAP_FAILED) return fail("gpb_hip_vecchia_mailbox_attach: mmap failed: %s", std::strerror(errno));
+  auto* hdr = static_cast<volatile unsigned long long*>(p);
+  if (hdr[0] != GpbMailbox::kMagic || hdr[1] != (unsigned long long)world) { (void)munmap(p, bytes); return fail("gpb_hip_vecchia_mailbox_attach: %s is not a mailbox for %d ranks", name, world); }
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped);
+  if (e != hipSuccess) { (void)munmap(p, bytes); return fail("hipHostRegister of the mailbox failed: %s", hipGetErrorString(e)); }
+  void* dp = nullptr;
+  e = hipHostGetDevicePointer(&dp, p, 0);
+  if (e != hipSuccess) { (void)hipHostUnregister(p); (void)munmap(p, bytes); return fail("hipHostGetDevicePointer of the mailbox failed: %s", hipGetErrorString(e)); }
+  GpbMailbox& mb = h->mbox;
+  mb.base = p; mb.bytes = bytes; mb.dev_base = static_cast<double*>(dp); mb.world = world; mb.rank = rank; mb.evals = 0;
+  std::strncpy(mb.name, name, sizeof(mb.name) - 1);
+  for (int g = 0; g < 3; ++g) for (int t = 0; t < 8; ++t) mb.slot(g, rank)[t] = kFetchSentinel;
+  std::atomic_thread_fence(std::memory_order_release);
+  hdr[2 + rank] = 1ull;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    bool all = true;
+    for (int r = 0; r < world; ++r) all = all && hdr[2 + r] != 0ull;
+    if (all) break;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { mb.release(); return fail("gpb_hip_vecchia_mailbox_attach: not all %d ranks attached within 120 s", world); }
+    std::this_thread::yield();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (rank == 0) (void)shm_unlink(name);
+  API_END();
+}
+int gpb_hip_vecchia_mailbox_info(gpb_hip_vecchia_t* h, int* rank, int* world) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  if (rank) *rank = h->mbox.active() ? h->mbox.rank : 0;
+  if (world) *world = h->mbox.active() ? h->mbox.world : 0;
+  API_END();
+}
+int gpb_hip_vecchia_mailbox_detach(gpb_hip_vecchia_t* h) {
+  API_BEGIN();
+  if (!h) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->mbox.release();
+  API_END();
+}
+
+// one sharded evaluation through the mailbox: ONE launch (the point kernel, whose finisher writes this rank's slot), then the host polls all slots
+static int vecchia_mailbox_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss, double* out_host, int nout) {
+  GpbMailbox& mb = h->mbox;
+  const unsigned long long e = ++mb.evals;
+  const int gen = (int)(e % 3), next = (int)((e + 1) % 3);
+  for (int t = 0; t < 8; ++t) mb.slot(next, mb.rank)[t] = kFetchSentinel;       // re-arm the own slot of the generation after this one (see GpbMailbox)
+  std::atomic_thread_fence(std::memory_order_release);
+  if (vecchia_launch(h, mode, cov_type, var, a, gauss, nullptr, nout, nullptr, nullptr, mb.dev_slot(gen, mb.rank))) return -1;
+  h->launches_unfetched = 0;
+  const int nterms = nout > 3 ? GPB_NUM_PARTIALS : 3;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool own_synced = false;
+  for (unsigned spin = 0;; ++spin) {
+    bool all = true;
+    for (int r = 0; r < mb.world && all; ++r) {
+      const volatile unsigned long long* v = mb.slot(gen, r);
+      for (int t = 0; t < nterms; ++t) all = all && v[t] != kFetchSentinel;
+    }
+    if (all) break;
+    if ((spin & 1023u) == 1023u) {
+      const auto dt = std::chrono::steady_clock::now() - t0;
+      if (!own_synced && dt > std::chrono::milliseconds(50)) { HIP_OK(hipStreamSynchronize(h->stream)); own_synced = true; }   // (surfaces a launch error of this rank)
+      if (dt > std::chrono::seconds(120)) return fail("mailbox: the sums of all %d ranks did not arrive within 120 s (evaluation %llu)", mb.world, e);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  double acc[GPB_NUM_PARTIALS];
+  for (int t = 0; t < nterms; ++t) acc[t] = 0.0;
+  for (int r = 0; r < mb.world; ++r) {                                             // rank order: the same bits on every rank
+    const volatile unsigned long long* v = mb.slot(gen, r);
+    for (int t = 0; t < nterms; ++t) { const unsigned long long raw = v[t]; double d; std::memcpy(&d, &raw, 8); acc[t] += d; }
+  }
+  out_host[0] = acc[gpb::GPB_P_QUAD];
+  out_host[1] = acc[gpb::GPB_P_LOGDET];
+  for (int t = 2; t < nout; ++t) out_host[t] = acc[t];
+  return 0;
 }
 
 // point kernel + fixed-order reduction + ncclAllReduce(sum) of the 3 / 7 terms on the handle's stream, result to the host
 static int vecchia_allreduce_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss,
                                    double* out_host, int nout) {
   if (!h || !out_host) return fail("null argument");
-  if (!h->comm.active()) return fail("no communicator: call gpb_hip_vecchia_comm_init first");
+  if (h->mbox.active()) return vecchia_mailbox_terms(h, mode, cov_type, var, a, gauss, out_host, nout);
+  if (!h->comm.active()) return fail("no communicator: call gpb_hip_vecchia_comm_init (or gpb_hip_vecchia_mailbox_attach) first");
   if (vecchia_launch(h, mode, cov_type, var, a, gauss, h->d_red, nout)) return -1;
   if (comm_allreduce(h->comm, h->d_red, (size_t)nout, GPB_T_F64, GPB_OP_SUM, h->stream)) return -1;
   // the job's sums reach the host without a copy engine and without the wake-up of a stream synchronisation: a one-wavefront kernel

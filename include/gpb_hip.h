@@ -163,6 +163,18 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_t
                                                  const double* N0, const double* negMp1, const double* w_host, int keep_factor, double* sums12_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_get_grad_factor(gpb_hip_vecchia_t* h, int p, double* dA_host, double* dD_host);
 
+/* Node-local MAILBOX for the 3 / 7 sums of a sharded likelihood / gradient evaluation: a POSIX
+ * shared-memory segment mapped and page-locked by every rank of the node.  Each rank's finisher workgroup stores its shard sums straight into its
+ * slot (system-scope stores, no collective kernel, no copy), every host polls all slots and adds them in rank order: identical bits on all ranks.
+ * With a mailbox attached, gpb_hip_vecchia_{nll,grad}_terms_allreduce use it instead of ncclAllReduce; RCCL stays for y_aux, histograms and the
+ * neighbour table.  Every rank must make the same sequence of evaluations (SPMD), as with any collective.
+ *   gpb_hip_mailbox_create          rank 0: creates the segment for `world` ranks, returns its name (64 bytes; hand it to the other ranks)
+ *   gpb_hip_vecchia_mailbox_attach  every rank: maps it, waits for all ranks (120 s), rank 0 unlinks the name */
+GPB_HIP_EXPORT int gpb_hip_mailbox_create(int world, char* name_out64);
+GPB_HIP_EXPORT int gpb_hip_vecchia_mailbox_attach(gpb_hip_vecchia_t* h, const char* name, int rank, int world);
+GPB_HIP_EXPORT int gpb_hip_vecchia_mailbox_info(gpb_hip_vecchia_t* h, int* rank, int* world);
+GPB_HIP_EXPORT int gpb_hip_vecchia_mailbox_detach(gpb_hip_vecchia_t* h);
+
 /* In-library RCCL reduction over the ranks of a node (one process per GPU; xGMI): the communicator is bootstrapped from a
  * 128-byte ncclUniqueId made on rank 0 and handed to every rank by the host (e.g. a torch.distributed broadcast).
  * The *_allreduce calls run point kernel -> fixed-order reduction -> ncclAllReduce(sum) of the 3 / 7 terms on the handle's
