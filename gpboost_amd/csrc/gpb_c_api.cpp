@@ -396,7 +396,7 @@ int profile_out_coef(REModelHip* mdl, double ratio, double a) {
 // :208-235 -- every new mean is a draw from std::discrete_distribution weighted by the PLAIN distance to the closest mean chosen so far --,
 // calculate_means :237-280, kmeans_plusplus :282-308: Lloyd iterations until the means repeat, at most max_it) on the model's ONE
 // generator, which has already shuffled the ordering (re_model_template.h:351-355).  x: column-major n x d (Vecchia order); means: column-major k x d.
-void kmeans_plusplus(const std::vector<double>& x, int n, int d, int k, std::mt19937& gen, int max_it, std::vector<double>* means_out) {
+int kmeans_plusplus(const std::vector<double>& x, int n, int d, int k, std::mt19937& gen, int max_it, std::vector<double>* means_out) {
   auto dist = [&](int r, const double* mean) { double s2 = 0.; for (int c = 0; c < d; ++c) { const double t = x[(size_t)c * n + r] - mean[c]; s2 += t * t; } return std::sqrt(s2); };
   std::vector<double> means((size_t)k * d, 0.), w(n, 1.0);           // means row-major here
   for (int i = 0; i < k; ++i) {
@@ -408,25 +408,13 @@ void kmeans_plusplus(const std::vector<double>& x, int n, int d, int k, std::mt1
     else v = std::uniform_int_distribution<>(0, n - 1)(gen);
     for (int c = 0; c < d; ++c) means[(size_t)i * d + c] = x[(size_t)c * n + v];
   }
-  std::vector<double> old(means.size(), 0.), oldold(means.size(), 0.), mnew(means.size());
-  std::vector<int> cl(n), cnt(k);
-  int count = 0;
-  do {
-    oldold = old; old = means;
-    parallel_for(n, [&](int lo, int hi) {
-      for (int r = lo; r < hi; ++r) {
-        int best = 0; double bd = dist(r, &means[0]);
-        for (int j = 1; j < k; ++j) { const double dd = dist(r, &means[(size_t)j * d]); if (dd < bd) { bd = dd; best = j; } }
-        cl[r] = best;
-      }
-    });
-    std::fill(mnew.begin(), mnew.end(), 0.); std::fill(cnt.begin(), cnt.end(), 0);
-    for (int r = 0; r < n; ++r) { for (int c = 0; c < d; ++c) mnew[(size_t)cl[r] * d + c] += x[(size_t)c * n + r]; cnt[cl[r]]++; }   // per mean: its rows in ascending order
-    for (int j = 0; j < k; ++j) if (cnt[j] > 0) for (int c = 0; c < d; ++c) means[(size_t)j * d + c] = mnew[(size_t)j * d + c] / cnt[j];
-    ++count;
-  } while (means != old && means != oldold && count != max_it);
+  // Lloyd iterations (calculate_means, :237-280): the n x k distances of the assignment step on the device, the ordered mean update on the host
+  // (gpb_hip_kmeans_lloyd) -- 10 s of model creation at n = 1e5, k = 200 were this loop on the host's cores
+  int its = 0;
+  if (gpb_hip_kmeans_lloyd(n, d, x.data(), k, means.data(), max_it, &its)) return shim_error();
   means_out->assign((size_t)k * d, 0.);
   for (int j = 0; j < k; ++j) for (int c = 0; c < d; ++c) (*means_out)[(size_t)c * k + j] = means[(size_t)j * d + c];
+  return 0;
 }
 
 // lower Cholesky factor of the k x k row-major matrix M (in place, upper part zeroed); false if not positive definite
@@ -1088,7 +1076,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
       for (int k = 0; k < nc; ++k) coords[(size_t)j * nc + k] = gp_coords_data[(size_t)j * num_data + idx[k]];
     if (vif) {     // CreateREComponentsFITC_FSA (re_model_template.h:7639-7720) runs between the shuffle and the neighbour search, on the same generator
       if (nc <= num_ind_points) return set_error("Need to have less inducing points (currently num_ind_points = %d) than data points (%d) if gp_approx = 'full_scale_vecchia' ", num_ind_points, nc);
-      kmeans_plusplus(coords, nc, dim_gp_coords, num_ind_points, rng, 1000, &mdl->ip);
+      if (kmeans_plusplus(coords, nc, dim_gp_coords, num_ind_points, rng, 1000, &mdl->ip)) return -1;
     }
     gpb_hip_vecchia_t* vh = nullptr;
     int n_pts = nc;                                                    // points of the Vecchia approximation

@@ -278,6 +278,9 @@ struct gpb_hip_vecchia {
   int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   GpbComm comm;                   // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init / _comm_init_local)
+  // optional in-loop timing of the dominant kernel (gpb_hip_vecchia_timing): a ring of HIP event pairs recorded around every point-kernel launch on
+  // the handle's stream, so that the kernel time reported next to a timed loop is measured INSIDE that loop
+  bool timing_on = false; unsigned long long timing_count = 0; std::vector<hipEvent_t> timing_ev;
   GpbMailbox mbox;                // optional: node-local shared-memory mailbox for the 3 / 7 sums of a sharded evaluation (gpb_hip_vecchia_mailbox_attach)
   double* d_red = nullptr;        // 8 doubles: all-reduce buffer in the caller-facing term order
   std::vector<double> coords;   // host copy, column-major n x d (for the neighbour search set-up)
@@ -489,6 +492,8 @@ int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) {
   vif_free(h); dev_free(h->d_nug);
   h->comm.release();
   h->mbox.release();
+  for (hipEvent_t ev : h->timing_ev) (void)hipEventDestroy(ev);
+  h->timing_ev.clear();
   laplace_state_free(h->lap); h->lap = nullptr;
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->h_red) (void)hipHostFree(h->h_red);
@@ -697,6 +702,10 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   (void)nout;
   for (int t = 0; t < GPB_NUM_PARTIALS; ++t) reinterpret_cast<volatile unsigned long long*>(h->h_out)[t] = kFetchSentinel;
   ++h->launches_unfetched;
+  if (!ev0 && h->timing_on) {
+    const size_t slot = (size_t)(h->timing_count++ % (h->timing_ev.size() / 2));
+    ev0 = h->timing_ev[2 * slot]; ev1 = h->timing_ev[2 * slot + 1];
+  }
   if (ev0) HIP_OK(hipEventRecord(ev0, h->stream));
   if (big) {
     HIP_OK(gpb::launch_vecchia_point_big(mode, cov_type, h->d > 3 ? 0 : (h->d == 3 ? 3 : 2), k, h->stream));
@@ -1088,6 +1097,36 @@ int gpb_hip_vecchia_bench(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   API_END();
 }
 
+/* In-loop kernel timing: enable = 1 starts recording an event pair around every point-kernel launch of this handle (ring of 256 pairs, count reset);
+   enable = 0 stops, synchronises and returns the number of launches seen and the mean kernel time of the last min(count, 256) of them. */
+int gpb_hip_vecchia_timing(gpb_hip_vecchia_t* h, int enable, int64_t* launches, double* mean_kernel_ms) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipSetDevice(h->device));
+  constexpr int kPairs = 256;
+  if (enable) {
+    if (h->timing_ev.empty()) {
+      h->timing_ev.resize(2 * kPairs);
+      for (auto& ev : h->timing_ev) HIP_OK(hipEventCreate(&ev));
+    }
+    h->timing_count = 0; h->timing_on = true;
+    return 0;
+  }
+  h->timing_on = false;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const unsigned long long cnt = h->timing_count;
+  double acc = 0.;
+  const int used = (int)std::min<unsigned long long>(cnt, kPairs);
+  for (int q = 0; q < used; ++q) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, h->timing_ev[2 * q], h->timing_ev[2 * q + 1]));
+    acc += ms;
+  }
+  if (launches) *launches = (int64_t)cnt;
+  if (mean_kernel_ms) *mean_kernel_ms = used ? acc / used : 0.;
+  API_END();
+}
+
 /* ---- linear-regression covariates (Gaussian likelihood; GPB_OptimLinRegrCoefCovPar with optimizer_coef "wls": the coefficients are profiled out
    by generalised least squares at every evaluation, optim_utils.h:296-302 -> ProfileOutCoef, re_model_template.h:2665-2683) ----
    X: p columns of n values in Vecchia order (column-major [p][n]); the response last uploaded with gpb_hip_vecchia_set_y is y0. */
@@ -1156,6 +1195,39 @@ int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, doubl
   if (vecchia_launch(h, gpb::MODE_FACTOR, cov_type, var, a, gauss_likelihood, nullptr, 0)) return -1;
   HIP_OK(hipStreamSynchronize(h->stream));
   h->has_factor = true;
+  API_END();
+}
+
+/* Lloyd iterations of the inducing-point selection (kmeans_plusplus, src/GPBoost/GP_utils.cpp:282-308, after its random_plusplus start on the host):
+   the assignment step -- n x k distances per iteration, all of the 10 s the host spent at n = 1e5, k = 200 -- runs on the device with the reference's
+   arithmetic (nn_kernels.hip: kmeans_assign_kernel); the mean update stays on the host in the reference's order (per mean: its rows ascending, then one
+   division), so the means are the reference's bit for bit; iterations until the means repeat (the previous or the one before) or max_it.
+   x: column-major n x d (host); means: ROW-major k x d, in: the start, out: the result. */
+int gpb_hip_kmeans_lloyd(int32_t n, int32_t d, const double* x_colmajor, int32_t k, double* means_rowmajor, int32_t max_it, int32_t* iterations) {
+  API_BEGIN();
+  if (!x_colmajor || !means_rowmajor || n < 1 || d < 1 || d > 3 || k < 1 || k > 256) return fail("gpb_hip_kmeans_lloyd: invalid argument (d <= 3, k <= 256)");
+  if (check_device()) return -1;                        // (the current device, as gpb_hip_vecchia_create)
+  double* d_x = nullptr; double* d_m = nullptr; int* d_cl = nullptr;
+  auto guard = scope_exit([&] { dev_free(d_x); dev_free(d_m); dev_free(d_cl); });
+  HIP_OK(hipMalloc(&d_x, sizeof(double) * (size_t)n * d));
+  HIP_OK(hipMalloc(&d_m, sizeof(double) * (size_t)k * d));
+  HIP_OK(hipMalloc(&d_cl, sizeof(int) * (size_t)n));
+  HIP_OK(hipMemcpy(d_x, x_colmajor, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice));
+  std::vector<double> means(means_rowmajor, means_rowmajor + (size_t)k * d), old(means.size(), 0.), oldold(means.size(), 0.), mnew(means.size());
+  std::vector<int> cl(n), cnt(k);
+  int count = 0;
+  do {
+    oldold = old; old = means;
+    HIP_OK(hipMemcpy(d_m, means.data(), sizeof(double) * means.size(), hipMemcpyHostToDevice));
+    HIP_OK(gpb::launch_kmeans_assign(d_x, d_m, n, d, k, d_cl, nullptr));
+    HIP_OK(hipMemcpy(cl.data(), d_cl, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    std::fill(mnew.begin(), mnew.end(), 0.); std::fill(cnt.begin(), cnt.end(), 0);
+    for (int r = 0; r < n; ++r) { for (int c = 0; c < d; ++c) mnew[(size_t)cl[r] * d + c] += x_colmajor[(size_t)c * n + r]; cnt[cl[r]]++; }   // per mean: its rows in ascending order
+    for (int j = 0; j < k; ++j) if (cnt[j] > 0) for (int c = 0; c < d; ++c) means[(size_t)j * d + c] = mnew[(size_t)j * d + c] / cnt[j];
+    ++count;
+  } while (means != old && means != oldold && count != max_it);
+  std::copy(means.begin(), means.end(), means_rowmajor);
+  if (iterations) *iterations = count;
   API_END();
 }
 

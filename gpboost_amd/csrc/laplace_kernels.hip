@@ -1243,15 +1243,43 @@ __global__ __launch_bounds__(kSfThreads) void lap_sptrsv_sf_kernel(LapTri T, int
 constexpr int kSfwThreads = 256;
 constexpr int kSfwMaxChunkPerLaneGroup = 4;             // chunks per 16-lane group: up to 16 chunks = 64 columns per block
 
-__device__ __forceinline__ void lap_sfw_peek4(const double* xchunk, unsigned src, double (&g)[4], bool& ok) {
-  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(xchunk) + src * 32u);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const unsigned long long raw = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = ok && raw != kLapEmpty;
-    g[c] = __longlong_as_double((long long)raw);
-  }
+// v1 of this kernel gathered with 8-byte agent-scope atomic loads (as lap_sptrsv_sf_kernel does): four instructions and four 32-byte sector
+// requests per 32-byte row of a chunk -- 1.8e8 sector requests per solve at n = 1e5, request-rate bound (profiles/r04_a_*: 3.3 / 2.0 ms per solve
+// against 1.1 / 0.9 ms of level launches).  v2: a row of a chunk is gathered as TWO L1-bypassing 16-byte loads (global_load_dwordx4 sc1) and
+// published as two 16-byte write-through stores; the sentinel is still checked per 8-byte value (16-byte sc1 halves are observed untorn on
+// gfx950, MI355X_MICROARCH.md -- and a torn half would only be seen as "not there yet").  The loads of a batch (two entries x four chunks of a
+// lane) and their s_waitcnt are ONE asm block: the compiler never sees a register that a load in flight is still going to write.
+typedef double lap_v2d __attribute__((ext_vector_type(2)));
+struct SfwBatch { lap_v2d d[16]; };     // [entry 0/1][chunk slot j][half]
+__device__ __forceinline__ void lap_sfw_gather(const void* p00, const void* p01, const void* p02, const void* p03,
+                                               const void* p10, const void* p11, const void* p12, const void* p13, SfwBatch& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off sc1\n\t"
+      "global_load_dwordx4 %1, %16, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %17, off sc1\n\t"
+      "global_load_dwordx4 %3, %17, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %4, %18, off sc1\n\t"
+      "global_load_dwordx4 %5, %18, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %6, %19, off sc1\n\t"
+      "global_load_dwordx4 %7, %19, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %8, %20, off sc1\n\t"
+      "global_load_dwordx4 %9, %20, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %10, %21, off sc1\n\t"
+      "global_load_dwordx4 %11, %21, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %12, %22, off sc1\n\t"
+      "global_load_dwordx4 %13, %22, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %14, %23, off sc1\n\t"
+      "global_load_dwordx4 %15, %23, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3]), "=&v"(b.d[4]), "=&v"(b.d[5]), "=&v"(b.d[6]), "=&v"(b.d[7]),
+        "=&v"(b.d[8]), "=&v"(b.d[9]), "=&v"(b.d[10]), "=&v"(b.d[11]), "=&v"(b.d[12]), "=&v"(b.d[13]), "=&v"(b.d[14]), "=&v"(b.d[15])
+      : "v"(p00), "v"(p01), "v"(p02), "v"(p03), "v"(p10), "v"(p11), "v"(p12), "v"(p13)
+      : "memory");
 }
+__device__ __forceinline__ void lap_sfw_store32(void* p, lap_v2d lo, lap_v2d hi) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ bool lap_sfw_present(double v) { return (unsigned long long)__double_as_longlong(v) != kLapEmpty; }
 
 template <bool SCALE, bool OVF>
 __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, int n, int qa, int qb, int ncol, const double* __restrict__ rhs,
@@ -1259,6 +1287,15 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
   const int lane = threadIdx.x & 63, e = lane & 15, cg = lane >> 4;
   const int NW = gridDim.x * (kSfwThreads / 64);
   const size_t cstride = (size_t)n * 4;                  // doubles per chunk of the [chunk][row][4] layout
+  // byte address of row `src` of this lane's j-th chunk (a chunk beyond ncol: chunk cg, never consumed)
+  const char* xb[kSfwMaxChunkPerLaneGroup];
+  bool chunk_on[kSfwMaxChunkPerLaneGroup];
+#pragma unroll
+  for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
+    const int ch = cg + 4 * j;
+    chunk_on[j] = ch < ncol;
+    xb[j] = reinterpret_cast<const char*>(x + (size_t)(chunk_on[j] ? ch : (cg < ncol ? cg : 0)) * cstride);
+  }
   int q = qa + blockIdx.x * (kSfwThreads / 64) + (threadIdx.x >> 6);
   int4 m_nx = T.meta[q < qb ? q : qa];
   LapEnt h_nx[2];
@@ -1292,35 +1329,50 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
         for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
 #pragma unroll
           for (int c = 0; c < 4; ++c) sum[j][c] = 0.0;
-        auto take = [&](const LapEnt& en) {
-          if (en.val != 0.0) {                           // (padding: coefficient 0 -- not a dependency)
+        // two entries of this lane in ONE round trip; an entry with coefficient 0 is padding (not a dependency): its gather goes to row 0 and is ignored.
+        // Accumulation order per (chunk, column): entry A, then entry B -- callers pass them in the order of lap_sptrsv_kernel's fma chain.
+        auto take2 = [&](const LapEnt& ea, const LapEnt& eb) {
+          const bool ua = ea.val != 0.0, ub = eb.val != 0.0;
+          if (!__any(ua || ub)) return;                  // (uniform) nothing to gather for the whole wavefront
+          const unsigned oa = ua ? (unsigned)ea.src * 32u : 0u, obt = ub ? (unsigned)eb.src * 32u : 0u;
+          SfwBatch b;
+          lap_sfw_gather(xb[0] + oa, xb[1] + oa, xb[2] + oa, xb[3] + oa, xb[0] + obt, xb[1] + obt, xb[2] + obt, xb[3] + obt, b);
 #pragma unroll
-            for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
-              const int ch = cg + 4 * j;
-              if (ch < ncol) {
-                double g[4];
-                lap_sfw_peek4(x + (size_t)ch * cstride, (unsigned)en.src, g, ok);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sum[j][c] = __builtin_fma(en.val, g[c], sum[j][c]);
+          for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
+            if (chunk_on[j]) {
+              if (ua) {
+                const double g0 = b.d[2 * j][0], g1 = b.d[2 * j][1], g2 = b.d[2 * j + 1][0], g3 = b.d[2 * j + 1][1];
+                ok = ok && lap_sfw_present(g0) && lap_sfw_present(g1) && lap_sfw_present(g2) && lap_sfw_present(g3);
+                sum[j][0] = __builtin_fma(ea.val, g0, sum[j][0]); sum[j][1] = __builtin_fma(ea.val, g1, sum[j][1]);
+                sum[j][2] = __builtin_fma(ea.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(ea.val, g3, sum[j][3]);
+              }
+              if (ub) {
+                const double g0 = b.d[8 + 2 * j][0], g1 = b.d[8 + 2 * j][1], g2 = b.d[8 + 2 * j + 1][0], g3 = b.d[8 + 2 * j + 1][1];
+                ok = ok && lap_sfw_present(g0) && lap_sfw_present(g1) && lap_sfw_present(g2) && lap_sfw_present(g3);
+                sum[j][0] = __builtin_fma(eb.val, g0, sum[j][0]); sum[j][1] = __builtin_fma(eb.val, g1, sum[j][1]);
+                sum[j][2] = __builtin_fma(eb.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(eb.val, g3, sum[j][3]);
               }
             }
           }
         };
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const LapEnt h = sl == 0 ? h0[k] : T.hent[(size_t)qq * 32 + e + 16 * k];
-          take(h);
-          if (OVF) {
-            const int eo = ob + e + 16 * k;
-            if (eo < oe) take(T.oent[eo]);
+        const LapEnt none = {0.0, 0, 0};
+        // fma chain of lap_sptrsv_kernel / lap_sptrsv_sf_kernel per lane: head k = 0, overflow k = 0, head k = 1, overflow k = 1, then the rest of the overflow
+        const LapEnt hA = sl == 0 ? h0[0] : T.hent[(size_t)qq * 32 + e];
+        const LapEnt hB = sl == 0 ? h0[1] : T.hent[(size_t)qq * 32 + e + 16];
+        if (OVF) {
+          const int eo0 = ob + e, eo1 = ob + e + 16;
+          const LapEnt oA = eo0 < oe ? T.oent[eo0] : none;
+          const LapEnt oB = eo1 < oe ? T.oent[eo1] : none;
+          take2(hA, oA);
+          take2(hB, oB);
+          for (int e0 = ob + 32 + e; e0 - e < oe; e0 += 64) {
+            const LapEnt o0 = e0 < oe ? T.oent[e0] : none, o1 = e0 + 16 < oe ? T.oent[e0 + 16] : none;
+            const LapEnt o2 = e0 + 32 < oe ? T.oent[e0 + 32] : none, o3 = e0 + 48 < oe ? T.oent[e0 + 48] : none;
+            take2(o0, o1);
+            take2(o2, o3);
           }
-        }
-        if (OVF) for (int e0 = ob + 32 + e; e0 - e < oe; e0 += 64) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int eo = e0 + 16 * k;
-            if (eo < oe) take(T.oent[eo]);
-          }
+        } else {
+          take2(hA, hB);
         }
 #pragma unroll
         for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
@@ -1329,7 +1381,7 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
       }
       if (__all(ok)) break;                              // every source of every chunk of this row has arrived
       if (++passes > kLapSpinLimit) { if (lane == 0) *err = 1; break; }       // give the row up: never hang the device
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(4);
     }
     if (e == 0) {
       const double den = SCALE ? rdw[row] : 1.0;
@@ -1338,12 +1390,11 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
         const int ch = cg + 4 * j;
         if (ch < ncol) {
           const VecN<4> num = ldvec<4, 4>(rhs + (size_t)ch * cstride, row);
-          unsigned long long* xr = reinterpret_cast<unsigned long long*>(x + (size_t)ch * cstride + (size_t)row * 4);
+          double o[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const double out = SCALE ? __builtin_fma(num.v[c], den, v[j][c]) : num.v[c] + v[j][c];
-            __hip_atomic_store(xr + c, (unsigned long long)__double_as_longlong(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          for (int c = 0; c < 4; ++c) o[c] = SCALE ? __builtin_fma(num.v[c], den, v[j][c]) : num.v[c] + v[j][c];
+          const lap_v2d lo = {o[0], o[1]}, hi = {o[2], o[3]};
+          lap_sfw_store32(x + (size_t)ch * cstride + (size_t)row * 4, lo, hi);
         }
       }
     }

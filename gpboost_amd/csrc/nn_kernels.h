@@ -27,5 +27,7 @@ struct NNKernelArgs {
 void nn_query_order(const int* sorted_idx, int pos0, int pos1, int m, int start_at, int* out, int* nq);
 
 hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a, hipStream_t st);
+// k-means assignment step (GP_utils.cpp:237-280): x column-major [d][n], means row-major [k][d] (k <= 256, d <= 3) -> cl[n]
+hipError_t launch_kmeans_assign(const double* x, const double* means, int n, int d, int k, int* cl, hipStream_t st);
 
 }  // namespace gpb

@@ -252,4 +252,34 @@ hipError_t launch_vecchia_nn(int d, const NNKernelArgs& a_in, hipStream_t st) {
   return hipGetLastError();
 }
 
+
+// ---- k-means assignment step of the inducing-point selection (full-scale Vecchia: kmeans_plusplus -> calculate_means,
+// src/GPBoost/GP_utils.cpp:237-280): cluster[r] = the FIRST mean at the smallest Euclidean distance sqrt(sum_c (x[c][r] - mean[j][c])^2),
+// evaluated in the reference's operation order (this translation unit is compiled with fp contraction off, like the reference's baseline
+// x86-64 build), so the assignments -- and with the host's ordered mean update the inducing points -- equal the reference's.
+// x: column-major [d][n]; means: row-major [k][d]; one thread per point, the means (k <= 256, d <= 3) through LDS.
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(const double* __restrict__ x, const double* __restrict__ means, int n, int d, int k, int* __restrict__ cl) {
+  __shared__ double s_m[256 * 3];
+  for (int e = threadIdx.x; e < k * d; e += 256) s_m[e] = means[e];
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  double xr[3] = {0.0, 0.0, 0.0};
+  for (int c = 0; c < d; ++c) xr[c] = x[(size_t)c * n + r];
+  int best = 0;
+  double bd = 0.0;
+  for (int j = 0; j < k; ++j) {
+    double s2 = 0.0;
+    for (int c = 0; c < d; ++c) { const double t = xr[c] - s_m[j * d + c]; s2 += t * t; }
+    const double dd = sqrt(s2);
+    if (j == 0 || dd < bd) { bd = dd; best = j; }
+  }
+  cl[r] = best;
+}
+hipError_t launch_kmeans_assign(const double* x, const double* means, int n, int d, int k, int* cl, hipStream_t st) {
+  if (k > 256 || d > 3 || d < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kmeans_assign_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, means, n, d, k, cl);
+  return hipGetLastError();
+}
+
 }  // namespace gpb

@@ -108,6 +108,25 @@ class VecchiaState(object):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
         _shim_call(_lib().gpb_hip_vecchia_comm_init(self.h, buf, C.c_int(int(rank)), C.c_int(int(world))))
 
+    def mailbox_attach(self, name, rank, world):
+        """Collective: attach to the node-local shared-memory mailbox `name` (mailbox_create() on rank 0); the 3 / 7 sums of the sharded
+        evaluations then travel through it instead of ncclAllReduce."""
+        _shim_call(_lib().gpb_hip_vecchia_mailbox_attach(self.h, C.c_char_p(name if isinstance(name, bytes) else name.encode()), C.c_int(int(rank)), C.c_int(int(world))))
+
+    def mailbox_info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        _shim_call(_lib().gpb_hip_vecchia_mailbox_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def mailbox_detach(self):
+        _shim_call(_lib().gpb_hip_vecchia_mailbox_detach(self.h))
+
+    def timing(self, enable):
+        """enable=True: record HIP events around every point-kernel launch; enable=False: -> (launches, mean kernel ms of the last <= 256)"""
+        cnt = C.c_int64(0); ms = C.c_double(0.0)
+        _shim_call(_lib().gpb_hip_vecchia_timing(self.h, C.c_int(1 if enable else 0), C.byref(cnt), C.byref(ms)))
+        return cnt.value, ms.value
+
     def comm_init_local(self, group, rank):
         """Collective over the threads of an in-process group (LocalGroup) instead of RCCL."""
         _shim_call(_lib().gpb_hip_vecchia_comm_init_local(self.h, group.g, C.c_int(int(rank))))
@@ -359,6 +378,13 @@ class LocalGroup(object):
             if e is not None:
                 raise e
         return res
+
+
+def mailbox_create(world):
+    """rank 0: create the node-local mailbox segment for `world` ranks -> its name (bytes; hand it to every rank's mailbox_attach)"""
+    buf = C.create_string_buffer(64)
+    _shim_call(_lib().gpb_hip_mailbox_create(C.c_int(int(world)), buf))
+    return buf.value
 
 
 def comm_unique_id():

@@ -156,12 +156,20 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_set_nugget_diag(gpb_hip_vecchia_t* h, const d
  *                         from which  d(y' Psi^-1 y) = S2 - 2 S6 + w' dSigma_m w  and
  *                         d log|Psi| = S1 - tr(Si dSigma_m) + tr(Winv dSigma_m) + 2 S5 + 2 S3 - S4   (DESIGN.md 4.12).
  *   vif_get_grad_factor   dA_i (n x m) and dD_i (n) of parameter p of the last vif_grad_sums(keep_factor = 1): the reference's -B_grad / D_grad */
+/* Lloyd iterations of kmeans_plusplus (src/GPBoost/GP_utils.cpp:237-308) after the host's random_plusplus start: assignment step on the device with the
+ * reference's arithmetic, ordered mean update on the host -- the reference's means bit for bit.  x: column-major n x d; means: row-major k x d in / out. */
+GPB_HIP_EXPORT int gpb_hip_kmeans_lloyd(int32_t n, int32_t d, const double* x_colmajor, int32_t k, double* means_rowmajor, int32_t max_it,
+                                        int32_t* iterations);
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip_colmajor);
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Linv_rowmajor, int with_grad,
                                               double* out3_host, double* G_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si,
                                                  const double* N0, const double* negMp1, const double* w_host, int keep_factor, double* sums12_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_get_grad_factor(gpb_hip_vecchia_t* h, int p, double* dA_host, double* dD_host);
+
+/* In-loop timing of the dominant kernel: enable = 1 records a HIP event pair around every point-kernel launch of the handle (ring of 256 pairs);
+ * enable = 0 stops, synchronises the stream and returns the launches seen and the mean kernel time (ms) of the last min(count, 256) launches. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_timing(gpb_hip_vecchia_t* h, int enable, int64_t* launches, double* mean_kernel_ms);
 
 /* Node-local MAILBOX for the 3 / 7 sums of a sharded likelihood / gradient evaluation: a POSIX
  * shared-memory segment mapped and page-locked by every rank of the node.  Each rank's finisher workgroup stores its shard sums straight into its

@@ -161,3 +161,49 @@ def test_sharded_vecchia_evaluation_neighbours_yaux_with_three_ranks(lib_built, 
         np.testing.assert_allclose(o7, t7, rtol=1e-10, atol=1e-8)
         np.testing.assert_allclose(ya_r, ya, rtol=1e-10, atol=1e-12)
     grp.close()
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_mailbox_sums_of_a_sharded_evaluation(lib_built, W):
+    """SURVEY.md 8e row 1 through the node-local shared-memory MAILBOX (round 4): W ranks (threads, one device) attach to one
+    segment, every rank's finisher workgroup stores its shard sums into its slot, every host polls all slots and adds them in rank order -- no
+    collective launch.  Likelihood and gradient terms equal the unsharded handle's (1e-12), are bit-identical on all ranks, over many evaluations
+    (the three slot generations are re-used), and alternate between 3 and 7 terms."""
+    from gpboost_amd import parallel, shim
+    n, m = 24013, 30
+    rng = np.random.default_rng(7)
+    coords = rng.uniform(size=(n, 2)); y = rng.standard_normal(n)
+    pars = [(10.0 * (1 + 0.01 * k), 1.0 / (0.1 * (1 + 0.005 * k))) for k in range(9)]
+    full = shim.VecchiaState(coords, m); full.find_neighbors(); full.set_y(y)
+    nn = full.get_neighbors()
+    ref3 = [full.nll_terms(0, v, a) for v, a in pars]
+    ref7 = [full.grad_terms(0, v, a) for v, a in pars]
+    full.close()
+    name = shim.mailbox_create(W)
+    grp = shim.LocalGroup(W)                 # (only to run the rank functions as threads; the sums do not use its all-reduce)
+
+    def rank(r):
+        st = shim.VecchiaState(coords, m)
+        st.set_neighbors(nn)
+        st.set_y(y)
+        st.set_shard(*parallel.shard_range(n, r, W))
+        st.mailbox_attach(name, r, W)
+        assert st.mailbox_info() == (r, W) and st.comm_info() == (r, W)
+        out = []
+        for k, (v, a) in enumerate(pars):
+            out.append(st.nll_terms_allreduce(0, v, a))
+            if k % 2 == 0:
+                out.append(st.grad_terms_allreduce(0, v, a))
+        st.mailbox_detach()
+        st.close()
+        return out
+    res = grp.run(rank)
+    for r in range(1, W):
+        for a_, b_ in zip(res[0], res[r]):
+            assert np.array_equal(a_, b_), "every rank adds the slots in rank order: identical bits"
+    q = 0
+    for k in range(len(pars)):
+        np.testing.assert_allclose(res[0][q], ref3[k], rtol=1e-12); q += 1
+        if k % 2 == 0:
+            np.testing.assert_allclose(res[0][q], ref7[k], rtol=1e-10, atol=1e-8); q += 1
+    grp.close()
