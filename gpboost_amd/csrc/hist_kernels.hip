@@ -262,6 +262,8 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
     return d;
   };
   const unsigned wr = (unsigned)(tid >> 2) & 3u, sh = (unsigned)(tid & 3), l15 = (unsigned)tid & 15u;
+  // real features of the LAST block of this launch's workgroups (16 unless it is the data set's last, partial feature group)
+  const int nf_last = min(GPB_HIST_FG, a.num_features - (quad * NB + nblk - 1) * GPB_HIST_FG);
   auto accumulate = [&](const RowData& cur) {
     const unsigned long long add_g = fixed_point_bits(cur.g, inv_q) + (1ull << kSumBits);
     unsigned long long add_h = 0ull;
@@ -269,6 +271,21 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= nblk) break;
+      if (b == nblk - 1 && nf_last < GPB_HIST_FG) {
+        // the data set's last, PARTIAL feature group (round 4): only its nf_last real features are accumulated -- the padding features all sit
+        // in bin 0 and nobody reads them (hist_reduce_kernel stops at num_features); at F = 50 that is 2 atomics per row instead of 16 in this
+        // block, 50 instead of 64 per row in all.  Lanes of a 16-lane group share features here, so some of these atomics meet in a bank pair.
+        const unsigned wsel[4] = {cur.bv[b].x, cur.bv[b].y, cur.bv[b].z, cur.bv[b].w};
+        int f = tid % nf_last;
+        for (int s = 0; s < nf_last; ++s) {
+          const unsigned wv = (f & 8) ? ((f & 4) ? wsel[3] : wsel[2]) : ((f & 4) ? wsel[1] : wsel[0]);
+          const unsigned bin = (wv >> (8 * (f & 3))) & 0xffu;
+          atomicAdd(&s_rows[b * kWords + bin * GPB_HIST_FG + f], add_g);
+          if constexpr (HAS_HESS) atomicAdd(&s_hrows[b * kWords + bin * GPB_HIST_FG + f], add_h);
+          f = (f + 1 == nf_last) ? 0 : f + 1;
+        }
+        continue;
+      }
       unsigned w0 = cur.bv[b].x, w1 = cur.bv[b].y, w2 = cur.bv[b].z, w3 = cur.bv[b].w, t0, t1, t2, t3;
       t0 = (wr & 1u) ? w1 : w0; t1 = (wr & 1u) ? w2 : w1; t2 = (wr & 1u) ? w3 : w2; t3 = (wr & 1u) ? w0 : w3;
       w0 = (wr & 2u) ? t2 : t0; w1 = (wr & 2u) ? t3 : t1; w2 = (wr & 2u) ? t0 : t2; w3 = (wr & 2u) ? t1 : t3;
