@@ -1241,18 +1241,46 @@ __global__ __launch_bounds__(kSfThreads) void lap_sptrsv_sf_kernel(LapTri T, int
 // in increasing (= level) order, a wavefront handles ONE row at a time (no lane ever waits for another lane of its own wavefront); spins are
 // bounded (kLapSpinLimit) and a give-up sets the error word instead of hanging the device.
 constexpr int kSfwThreads = 256;
-constexpr int kSfwMaxChunkPerLaneGroup = 4;             // chunks per 16-lane group: up to 16 chunks = 64 columns per block
 
 // v1 of this kernel gathered with 8-byte agent-scope atomic loads (as lap_sptrsv_sf_kernel does): four instructions and four 32-byte sector
 // requests per 32-byte row of a chunk -- 1.8e8 sector requests per solve at n = 1e5, request-rate bound (profiles/r04_a_*: 3.3 / 2.0 ms per solve
 // against 1.1 / 0.9 ms of level launches).  v2: a row of a chunk is gathered as TWO L1-bypassing 16-byte loads (global_load_dwordx4 sc1) and
 // published as two 16-byte write-through stores; the sentinel is still checked per 8-byte value (16-byte sc1 halves are observed untorn on
-// gfx950, MI355X_MICROARCH.md -- and a torn half would only be seen as "not there yet").  The loads of a batch (two entries x four chunks of a
+// gfx950, MI355X_MICROARCH.md -- and a torn half would only be seen as "not there yet").  The loads of a batch (two entries x J chunks of a
 // lane) and their s_waitcnt are ONE asm block: the compiler never sees a register that a load in flight is still going to write.
+// v3: J = chunks per 16-lane group is a template parameter.  With J = 4 one wavefront owns all (<= 16) chunks of a row and the per-level
+// chain is gather (16 loads per lane) -> 16 butterflies -> 16 stores: ~7 us per dependency level measured (profiles/r04_b_*), 118 levels deep.
+// With J = 1 a wavefront owns 4 chunks of a row, the block is solved as ceil(chunks / 4) independent column units (blockIdx.y) whose chains
+// are as short as a single vector's; J = 2 in between.
 typedef double lap_v2d __attribute__((ext_vector_type(2)));
-struct SfwBatch { lap_v2d d[16]; };     // [entry 0/1][chunk slot j][half]
-__device__ __forceinline__ void lap_sfw_gather(const void* p00, const void* p01, const void* p02, const void* p03,
-                                               const void* p10, const void* p11, const void* p12, const void* p13, SfwBatch& b) {
+template <int J> struct SfwBatch { lap_v2d d[4 * J]; };     // [entry 0/1][chunk slot j][half]
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[1], const void* const (&pb)[1], SfwBatch<1>& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %5, off sc1\n\t"
+      "global_load_dwordx4 %3, %5, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3])
+      : "v"(pa[0]), "v"(pb[0])
+      : "memory");
+}
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[2], const void* const (&pb)[2], SfwBatch<2>& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %9, off sc1\n\t"
+      "global_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %4, %10, off sc1\n\t"
+      "global_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %6, %11, off sc1\n\t"
+      "global_load_dwordx4 %7, %11, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3]), "=&v"(b.d[4]), "=&v"(b.d[5]), "=&v"(b.d[6]), "=&v"(b.d[7])
+      : "v"(pa[0]), "v"(pa[1]), "v"(pb[0]), "v"(pb[1])
+      : "memory");
+}
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[4], const void* const (&pb)[4], SfwBatch<4>& b) {
   asm volatile(
       "global_load_dwordx4 %0, %16, off sc1\n\t"
       "global_load_dwordx4 %1, %16, off offset:16 sc1\n\t"
@@ -1273,7 +1301,7 @@ __device__ __forceinline__ void lap_sfw_gather(const void* p00, const void* p01,
       "s_waitcnt vmcnt(0)"
       : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3]), "=&v"(b.d[4]), "=&v"(b.d[5]), "=&v"(b.d[6]), "=&v"(b.d[7]),
         "=&v"(b.d[8]), "=&v"(b.d[9]), "=&v"(b.d[10]), "=&v"(b.d[11]), "=&v"(b.d[12]), "=&v"(b.d[13]), "=&v"(b.d[14]), "=&v"(b.d[15])
-      : "v"(p00), "v"(p01), "v"(p02), "v"(p03), "v"(p10), "v"(p11), "v"(p12), "v"(p13)
+      : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3])
       : "memory");
 }
 __device__ __forceinline__ void lap_sfw_store32(void* p, lap_v2d lo, lap_v2d hi) {
@@ -1281,20 +1309,23 @@ __device__ __forceinline__ void lap_sfw_store32(void* p, lap_v2d lo, lap_v2d hi)
 }
 __device__ __forceinline__ bool lap_sfw_present(double v) { return (unsigned long long)__double_as_longlong(v) != kLapEmpty; }
 
-template <bool SCALE, bool OVF>
+// one wavefront per (row, column unit): the unit (blockIdx.y) covers the chunks [4 J unit, 4 J (unit + 1)) of the block; lane = (cg, e) takes
+// the entries e, e + 16 of the slot for the unit's chunks cg, cg + 4, .., cg + 4 (J - 1)
+template <bool SCALE, bool OVF, int J>
 __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, int n, int qa, int qb, int ncol, const double* __restrict__ rhs,
                                                                    const double* __restrict__ rdw, double* x, int* err) {
   const int lane = threadIdx.x & 63, e = lane & 15, cg = lane >> 4;
   const int NW = gridDim.x * (kSfwThreads / 64);
   const size_t cstride = (size_t)n * 4;                  // doubles per chunk of the [chunk][row][4] layout
-  // byte address of row `src` of this lane's j-th chunk (a chunk beyond ncol: chunk cg, never consumed)
-  const char* xb[kSfwMaxChunkPerLaneGroup];
-  bool chunk_on[kSfwMaxChunkPerLaneGroup];
+  const int ch0 = (int)blockIdx.y * 4 * J;               // first chunk of this column unit
+  // byte address of row 0 of this lane's j-th chunk (a chunk beyond ncol: the unit's first chunk, never consumed)
+  const char* xb[J];
+  bool chunk_on[J];
 #pragma unroll
-  for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
-    const int ch = cg + 4 * j;
+  for (int j = 0; j < J; ++j) {
+    const int ch = ch0 + cg + 4 * j;
     chunk_on[j] = ch < ncol;
-    xb[j] = reinterpret_cast<const char*>(x + (size_t)(chunk_on[j] ? ch : (cg < ncol ? cg : 0)) * cstride);
+    xb[j] = reinterpret_cast<const char*>(x + (size_t)(chunk_on[j] ? ch : ch0) * cstride);
   }
   int q = qa + blockIdx.x * (kSfwThreads / 64) + (threadIdx.x >> 6);
   int4 m_nx = T.meta[q < qb ? q : qa];
@@ -1312,21 +1343,26 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
     }
     if (m0.y <= 0) continue;                             // continuation / padding slot (uniform over the wavefront)
     const unsigned row = (unsigned)m0.x;
-    double v[kSfwMaxChunkPerLaneGroup][4];
+    // the row's right-hand side (and scale) travel with the first gathers instead of after the last one: one dependent round trip less per row
+    VecN<4> num[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) num[j] = ldvec<4, 4>(rhs + (size_t)(chunk_on[j] ? ch0 + cg + 4 * j : ch0) * cstride, row);
+    const double den = SCALE ? rdw[row] : 1.0;
+    double v[J][4];
     int passes = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+      for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[j][c] = 0.0;
       for (int sl = 0; sl < m0.y; ++sl) {
         const int qq = q + sl;
         int ob = m0.z, oe = m0.w;
         if (sl > 0) { const int4 ms = T.meta[qq]; ob = ms.z; oe = ms.w; }
-        double sum[kSfwMaxChunkPerLaneGroup][4];
+        double sum[J][4];
 #pragma unroll
-        for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
           for (int c = 0; c < 4; ++c) sum[j][c] = 0.0;
         // two entries of this lane in ONE round trip; an entry with coefficient 0 is padding (not a dependency): its gather goes to row 0 and is ignored.
@@ -1335,10 +1371,13 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
           const bool ua = ea.val != 0.0, ub = eb.val != 0.0;
           if (!__any(ua || ub)) return;                  // (uniform) nothing to gather for the whole wavefront
           const unsigned oa = ua ? (unsigned)ea.src * 32u : 0u, obt = ub ? (unsigned)eb.src * 32u : 0u;
-          SfwBatch b;
-          lap_sfw_gather(xb[0] + oa, xb[1] + oa, xb[2] + oa, xb[3] + oa, xb[0] + obt, xb[1] + obt, xb[2] + obt, xb[3] + obt, b);
+          const void* pa[J]; const void* pb[J];
 #pragma unroll
-          for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
+          for (int j = 0; j < J; ++j) { pa[j] = xb[j] + oa; pb[j] = xb[j] + obt; }
+          SfwBatch<J> b;
+          lap_sfw_gather(pa, pb, b);
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
             if (chunk_on[j]) {
               if (ua) {
                 const double g0 = b.d[2 * j][0], g1 = b.d[2 * j][1], g2 = b.d[2 * j + 1][0], g3 = b.d[2 * j + 1][1];
@@ -1347,7 +1386,7 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
                 sum[j][2] = __builtin_fma(ea.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(ea.val, g3, sum[j][3]);
               }
               if (ub) {
-                const double g0 = b.d[8 + 2 * j][0], g1 = b.d[8 + 2 * j][1], g2 = b.d[8 + 2 * j + 1][0], g3 = b.d[8 + 2 * j + 1][1];
+                const double g0 = b.d[2 * J + 2 * j][0], g1 = b.d[2 * J + 2 * j][1], g2 = b.d[2 * J + 2 * j + 1][0], g3 = b.d[2 * J + 2 * j + 1][1];
                 ok = ok && lap_sfw_present(g0) && lap_sfw_present(g1) && lap_sfw_present(g2) && lap_sfw_present(g3);
                 sum[j][0] = __builtin_fma(eb.val, g0, sum[j][0]); sum[j][1] = __builtin_fma(eb.val, g1, sum[j][1]);
                 sum[j][2] = __builtin_fma(eb.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(eb.val, g3, sum[j][3]);
@@ -1375,24 +1414,22 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
           take2(hA, hB);
         }
 #pragma unroll
-        for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[j][c] += row16_sum(sum[j][c]);       // (first slot: 0 + its sum, exact)
       }
       if (__all(ok)) break;                              // every source of every chunk of this row has arrived
       if (++passes > kLapSpinLimit) { if (lane == 0) *err = 1; break; }       // give the row up: never hang the device
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(2);
     }
     if (e == 0) {
-      const double den = SCALE ? rdw[row] : 1.0;
 #pragma unroll
-      for (int j = 0; j < kSfwMaxChunkPerLaneGroup; ++j) {
-        const int ch = cg + 4 * j;
+      for (int j = 0; j < J; ++j) {
+        const int ch = ch0 + cg + 4 * j;
         if (ch < ncol) {
-          const VecN<4> num = ldvec<4, 4>(rhs + (size_t)ch * cstride, row);
           double o[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = SCALE ? __builtin_fma(num.v[c], den, v[j][c]) : num.v[c] + v[j][c];
+          for (int c = 0; c < 4; ++c) o[c] = SCALE ? __builtin_fma(num[j].v[c], den, v[j][c]) : num[j].v[c] + v[j][c];
           const lap_v2d lo = {o[0], o[1]}, hi = {o[2], o[3]};
           lap_sfw_store32(x + (size_t)ch * cstride + (size_t)row * 4, lo, hi);
         }
@@ -1474,35 +1511,43 @@ static hipError_t lap_trsv_syncfree(const LapTri& T, const int* host_ptr, const 
   }
   return hipGetLastError();
 }
-// probe block (nc == 4), one wavefront per row over all chunks: one launch (+ the sentinel prefill) per triangular solve
+// probe block (nc == 4), barrier-free, one wavefront per (row, column unit of 4 J chunks): one launch (+ the sentinel prefill) per triangular solve.
+// GPB_LAP_SFW_J = chunks per 16-lane group (1, 2 or 4), GPB_LAP_SFW_WGS = workgroups per column unit (measurement knobs).
+template <bool SCALE, int J>
+static hipError_t lap_trsv_syncfree_block_j(const LapTri& T, int n, int qa, int qb, const double* rhs, const double* rdw, double* x, int ncol, int* err,
+                                            int wanted_total, hipStream_t st) {
+  const int nslot = qb - qa;
+  const int units = (ncol + 4 * J - 1) / (4 * J);
+  int occ = 0, cus = 0, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lap_sptrsv_sfw_kernel<true, true, J>, kSfwThreads, 0) != hipSuccess || occ < 1) occ = 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
+  (void)hipGetLastError();
+  const int resident = std::max(1, occ * cus * 3 / 4);   // every workgroup of the launch must be resident (forward progress): stay below what the calculator admits
+  int total = wanted_total > 0 ? wanted_total : 2 * cus;
+  total = std::min(total, resident);
+  const int per_unit = std::max(1, std::min(total / units, (nslot + kSfwThreads / 64 - 1) / (kSfwThreads / 64)));
+  hipLaunchKernelGGL((lap_sf_prefill_kernel<4, 4>), dim3((nslot + 255) / 256, ncol), dim3(256), 0, st, T, qa, qb, n, x);
+  if (T.has_ovf) hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, true, J>), dim3(per_unit, units), dim3(kSfwThreads), 0, st, T, n, qa, qb, ncol, rhs, rdw, x, err);
+  else hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, false, J>), dim3(per_unit, units), dim3(kSfwThreads), 0, st, T, n, qa, qb, ncol, rhs, rdw, x, err);
+  return hipGetLastError();
+}
 template <bool SCALE>
 static hipError_t lap_trsv_syncfree_block(const LapTri& T, const int* host_ptr, const LapSeg* seg, int nseg, int n, const double* rhs, const double* rdw, double* x,
                                           int ncol, int* err, hipStream_t st) {
   if (nseg <= 0) return hipSuccess;
   const int qa = host_ptr[seg[0].L0], qb = host_ptr[seg[nseg - 1].L1];
   if (qb <= qa) return hipSuccess;
-  static int resident = 0, wanted = 0;     // workgroups the device holds at once; workgroups to launch (GPB_LAP_SFW_WGS, default 3 per CU)
-  if (resident == 0) {
-    int occ = 0, cus = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lap_sptrsv_sfw_kernel<true, true>, kSfwThreads, 0) != hipSuccess || occ < 1) occ = 1;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
-    resident = std::max(1, occ * cus / 2);               // conservative: half of what the occupancy calculator admits
-    wanted = std::min(resident, 3 * cus);
-    if (const char* ev = std::getenv("GPB_LAP_SFW_WGS")) { const int w = std::atoi(ev); if (w > 0) wanted = std::min(resident, w); }
-    (void)hipGetLastError();
+  static int jsel = 0, wanted = 0;
+  if (jsel == 0) {
+    jsel = 1;
+    if (const char* ev = std::getenv("GPB_LAP_SFW_J")) { const int j = std::atoi(ev); if (j == 1 || j == 2 || j == 4) jsel = j; }
+    if (const char* ev = std::getenv("GPB_LAP_SFW_WGS")) wanted = std::max(0, std::atoi(ev));
   }
-  const int nslot = qb - qa;
-  const int wgs = std::max(1, std::min(wanted, (nslot + kSfwThreads / 64 - 1) / (kSfwThreads / 64)));
-  for (int c0 = 0; c0 < ncol; c0 += 4 * kSfwMaxChunkPerLaneGroup) {       // at most 16 chunks per pass
-    const int cn = std::min(ncol - c0, 4 * kSfwMaxChunkPerLaneGroup);
-    const size_t coff = (size_t)c0 * 4 * n;
-    const dim3 pg((nslot + 255) / 256, cn);
-    hipLaunchKernelGGL((lap_sf_prefill_kernel<4, 4>), pg, dim3(256), 0, st, T, qa, qb, n, x + coff);
-    if (T.has_ovf) hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, true>), dim3(wgs), dim3(kSfwThreads), 0, st, T, n, qa, qb, cn, rhs + coff, rdw, x + coff, err);
-    else hipLaunchKernelGGL((lap_sptrsv_sfw_kernel<SCALE, false>), dim3(wgs), dim3(kSfwThreads), 0, st, T, n, qa, qb, cn, rhs + coff, rdw, x + coff, err);
-  }
-  return hipGetLastError();
+  if (ncol > 16 && jsel == 4) return hipErrorInvalidValue;     // (one column unit of J = 4 covers 16 chunks; larger blocks take J <= 2 with more units)
+  if (jsel == 4) return lap_trsv_syncfree_block_j<SCALE, 4>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
+  if (jsel == 2) return lap_trsv_syncfree_block_j<SCALE, 2>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
+  return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
 }
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
   if (nc == 4 && (lv.syncfree & 4)) {                          // bit 2: the probe block, one wavefront per row over all chunks (round 4)
