@@ -95,9 +95,9 @@ class GPModel(object):
         self.likelihood = likelihood
         # Gaussian: error variance, GP variance, range; non-Gaussian: GP variance, range (basic.py:4618-4624)
         self.num_cov_pars = 3 if likelihood == "gaussian" else 2
-        if num_neighbors is None or num_neighbors <= 0:
-            num_neighbors = 20   # the library default for gp_approx="vecchia" (re_model_template.h:288-294)
-        self.num_neighbors = int(num_neighbors)
+        # None / <= 0: the LIBRARY resolves the default as the reference's does (20 for "vecchia", 30 for "full_scale_vecchia",
+        # re_model_template.h:287-298; the reference's package passes -1, basic.py:4590-4600)
+        self.num_neighbors = -1 if (num_neighbors is None or num_neighbors <= 0) else int(num_neighbors)
         coords_c = np.asfortranarray(gp_coords)   # column-major, basic.py:5075-5081
         cluster_c = ctypes.c_void_p()
         if cluster_ids is not None:
@@ -121,6 +121,12 @@ class GPModel(object):
             ctypes.c_int(self.seed), ctypes.c_int(-1 if num_parallel_threads is None else int(num_parallel_threads)),
             ctypes.c_bool(bool(GPU_use)), ctypes.c_bool(weights is not None), weights_c,
             ctypes.c_double(likelihood_learning_rate), ctypes.byref(self.handle)))
+        if self.num_neighbors <= 0 and gp_approx != "none":      # the default the library resolved
+            m = ctypes.c_int(0)
+            if _lib().GPB_HIP_GetVecchiaStructure(self.handle, None, None, ctypes.byref(m)) == 0:
+                self.num_neighbors = int(m.value)
+            else:      # several clusters: one table per cluster, the defaults are the library's (re_model_template.h:287-298)
+                self.num_neighbors = 30 if gp_approx in ("full_scale_vecchia", "vif", "VIF") else 20
 
     def __del__(self):
         try:

@@ -371,6 +371,12 @@ int gpb_hip_set_device(int device) {
   API_END();
 }
 
+/* Route B seam switch: while set, the reference's find_nearest_neighbors_Vecchia_fast (src/GPBoost/Vecchia_utils.cpp, patched)
+   hands the ordered neighbour search to the device.  Thread-local: REModelTemplate's constructor sets it around CreateREComponentsVecchia. */
+static thread_local int g_route_b_device_search = 0;
+int gpb_hip_route_b_set_device_search(int on) { g_route_b_device_search = on ? 1 : 0; return 0; }
+int gpb_hip_route_b_get_device_search(void) { return g_route_b_device_search; }
+
 int gpb_hip_device_is_gfx950(int* yes) {
   API_BEGIN();
   if (check_device()) return -1;
@@ -2168,15 +2174,35 @@ int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins, co
   API_END();
 }
 
-// page-lock a caller buffer the first time it is seen (slot: 0 gradients, 1 hessians, 2 leaf index); failures are harmless (the copy
-// then takes the pageable path)
+// Page-locking of caller buffers is OPT-IN (gpb_hip_hist_register_host_buffers; ADVICE r03: the library used to register whatever pointer
+// set_gradients / grow_tree saw and keep the registration after the call returned -- undefined once the caller frees a temporary).  A caller
+// that hands over the SAME arrays every iteration (the reference's Booster through route B) registers them once and owns the lifetime contract:
+// the arrays stay allocated until gpb_hip_hist_unregister_host_buffers / gpb_hip_hist_free.  slot: 0 gradients, 1 hessians, 2 leaf index.
 static void hist_pin(gpb_hip_hist_t* h, int slot, const void* p, size_t bytes) {
-  if (!p || bytes < (1u << 20)) return;                    // small arrays: not worth a registration
   gpb_hip_hist::Pinned& q = h->pin[slot];
   if (q.p == p && q.bytes >= bytes) return;
   if (q.p) { (void)hipHostUnregister(const_cast<void*>(q.p)); q.p = nullptr; q.bytes = 0; }
+  if (!p || bytes < (1u << 20)) return;                    // small arrays: not worth a registration
   if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) { q.p = p; q.bytes = bytes; }
-  else (void)hipGetLastError();
+  else (void)hipGetLastError();                            // harmless: the copies then take the pageable path
+}
+int gpb_hip_hist_register_host_buffers(gpb_hip_hist_t* h, const double* grad, const double* hess, const int32_t* data_leaf_index) {
+  API_BEGIN();
+  if (!h) return fail("null handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  hist_pin(h, 0, grad, sizeof(double) * (size_t)h->n);
+  hist_pin(h, 1, hess, sizeof(double) * (size_t)h->n);
+  hist_pin(h, 2, data_leaf_index, sizeof(int) * (size_t)h->n);
+  API_END();
+}
+int gpb_hip_hist_unregister_host_buffers(gpb_hip_hist_t* h) {
+  API_BEGIN();
+  if (!h) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  for (auto& q : h->pin) if (q.p) { (void)hipHostUnregister(const_cast<void*>(q.p)); q.p = nullptr; q.bytes = 0; }
+  API_END();
 }
 
 int gpb_hip_hist_free(gpb_hip_hist_t* h) {
@@ -2201,8 +2227,6 @@ int gpb_hip_hist_set_gradients(gpb_hip_hist_t* h, const double* grad, const doub
   API_BEGIN();
   if (!h || !grad) return fail("null argument");
   HIP_OK(hipSetDevice(h->device));
-  hist_pin(h, 0, grad, sizeof(double) * (size_t)h->n);
-  hist_pin(h, 1, hess, sizeof(double) * (size_t)h->n);
   HIP_OK(hipMemcpyAsync(h->d_grad, grad, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   if (hess) HIP_OK(hipMemcpyAsync(h->d_hess, hess, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   if (!h->d_absmax) HIP_OK(hipMalloc(&h->d_absmax, 2 * sizeof(unsigned long long)));

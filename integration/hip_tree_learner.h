@@ -161,6 +161,25 @@ class HIPTreeLearner : public SerialTreeLearner {
         hs = full_hess_.data();
       }
     }
+    else if (hist_ && hist_rows_ >= (1 << 17)) {
+      // staging buffers OWNED by this learner, page-locked once (gpb_hip_hist_register_host_buffers): the Booster's gradient vectors are destroyed
+      // BEFORE its tree learner (gbdt.h member order), so they must not stay registered; a parallel copy into the staging buffer + an upload at the
+      // PCIe rate beats the pageable copy of the Booster's own buffer (8 MB at n = 1e6: ~0.6 ms against ~2.5 ms)
+      full_grad_.resize(hist_rows_);
+#pragma omp parallel for schedule(static)
+      for (data_size_t k = 0; k < hist_rows_; ++k) full_grad_[k] = gradients_[k];
+      g = full_grad_.data();
+      if (hs != nullptr) {
+        full_hess_.resize(hist_rows_);
+#pragma omp parallel for schedule(static)
+        for (data_size_t k = 0; k < hist_rows_; ++k) full_hess_[k] = hessians_[k];
+        hs = full_hess_.data();
+      }
+    }
+    if (hist_ && (g == full_grad_.data()) && (g != registered_grad_ || hs != registered_hess_)) {
+      if (gpb_hip_hist_register_host_buffers(hist_, g, hs, nullptr)) Log::Fatal("%s", gpb_hip_get_last_error());
+      registered_grad_ = g; registered_hess_ = hs;
+    }
     if (hist_ && gpb_hip_hist_set_gradients(hist_, g, hs)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
@@ -188,7 +207,7 @@ class HIPTreeLearner : public SerialTreeLearner {
   }
 
   void CreateDeviceBins() {
-    if (hist_) { gpb_hip_hist_free(hist_); hist_ = nullptr; }
+    if (hist_) { gpb_hip_hist_free(hist_); hist_ = nullptr; registered_grad_ = registered_hess_ = nullptr; }   // (the free unregisters the staging buffers)
     const int num_groups = train_data_->num_feature_groups();
     std::vector<int32_t> offsets(num_groups + 1);
     for (int g = 0; g < num_groups; ++g) {
@@ -253,8 +272,9 @@ class HIPTreeLearner : public SerialTreeLearner {
   bool bag_is_subset_ = false;                         // the bag is a copied subset Dataset (rows renumbered) over full-data device bins
   bool subset_bins_ = false;                           // the device bins were built from a subset Dataset (older path)
   data_size_t hist_rows_ = 0;                          // rows of the Dataset the device bins were built from
-  std::vector<score_t> full_grad_, full_hess_;
-  std::vector<int32_t> leaf_of_row_;                   // row -> leaf of the last device-grown tree (kept: page-locked by the library)
+  std::vector<score_t> full_grad_, full_hess_;         // learner-owned staging buffers (page-locked once: gpb_hip_hist_register_host_buffers)
+  const score_t* registered_grad_ = nullptr; const score_t* registered_hess_ = nullptr;
+  std::vector<int32_t> leaf_of_row_;                   // row -> leaf of the last device-grown tree
   const data_size_t* bag_rows_ = nullptr;              // the current bag (GBDT's bag_data_indices_, alive until the next SetBaggingData)
   data_size_t bag_cnt_ = 0;
 };

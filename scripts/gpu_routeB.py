@@ -64,6 +64,58 @@ for n, m, d in GP_CASES:
     np.testing.assert_allclose(b["var"], a["var"], rtol=1e-6, atol=1e-8)
     print("n=%d: GPU_use=true reproduces the CPU path of the same build; likelihood evaluation %.1fx, fit %.1fx faster" % (n, a["t_eval"] / b["t_eval"], a["t_fit"] / b["t_fit"]), flush=True)
 
+# ---- (1b) GPBoost iterations through the round-4 seams: device neighbour search at model creation, y_aux = Psi^-1 (F - y) from the resident
+#      factor (CalcYAux), Newton leaf values (NewtonUpdateLeafValues) -- GPU_use = true against GPU_use = false of the same build -------------
+GPB_CASES = ((20000, 20, 3),) if TEST else ((100000, 50, 5), (1000000, 50, 2))
+if "--trees-only" in sys.argv:
+    GPB_CASES = ()
+LB = C.CDLL(LIBP)
+LB.LGBM_GetLastError.restype = C.c_char_p
+
+
+def okb(rc):
+    if rc != 0:
+        raise RuntimeError(LB.LGBM_GetLastError().decode())
+
+
+for n, F, nit in GPB_CASES:
+    rng = np.random.default_rng(11)
+    coords = rng.uniform(size=(n, 2))
+    X = np.ascontiguousarray(rng.uniform(size=(n, F)))
+    yb = np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + np.sin(5 * coords[:, 0]) * np.cos(4 * coords[:, 1]) + 0.3 * rng.standard_normal(n)
+    yf = yb.astype(np.float32)
+    res = {}
+    for gpu in (False, True):
+        t0 = time.perf_counter()
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
+        t_create = time.perf_counter() - t0
+        ds = C.c_void_p()
+        okb(LB.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
+                                         C.c_char_p(b"verbosity=-1 max_bin=255"), C.c_void_p(), C.byref(ds)))
+        okb(LB.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yf.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
+        bst = C.c_void_p()
+        params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=-1 num_threads=16 max_bin=255 leaves_newton_update=true train_gp_model_cov_pars=true"
+        okb(LB.LGBM_GPBoosterCreate(ds, C.c_char_p(params.encode()), mdl.h, C.byref(bst)))
+        fin = C.c_int(0)
+        ts = []
+        for _ in range(nit):
+            t0 = time.perf_counter()
+            okb(LB.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+            ts.append(time.perf_counter() - t0)
+        out = np.empty(n); olen = C.c_int64(0)
+        okb(LB.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(1), C.c_int(0),
+                                         C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
+        res[gpu] = dict(pred=out, cov=mdl.get_cov_par(3), t_create=t_create, t_iter=float(np.median(ts)))
+        print("GPBoost n=%d GPU_use=%s: model creation %.2f s, median %.1f ms per boosting iteration (gradient Psi^-1(F-y), tree, Newton leaf values, one "
+              "covariance-parameter step); cov pars %s; tree ensemble[:3] = %s" % (n, gpu, t_create, 1e3 * res[gpu]["t_iter"], res[gpu]["cov"], out[:3]), flush=True)
+        okb(LB.LGBM_BoosterFree(bst)); okb(LB.LGBM_DatasetFree(ds))
+        del mdl
+    a, b = res[False], res[True]
+    np.testing.assert_allclose(b["pred"], a["pred"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(b["cov"], a["cov"], rtol=1e-6)
+    print("GPBoost n=%d: GPU_use=true (device neighbour search, y_aux and Newton leaf values from the resident factor) reproduces the CPU path; "
+          "model creation %.1fx, boosting iteration %.1fx faster" % (n, a["t_create"] / b["t_create"], a["t_iter"] / b["t_iter"]), flush=True)
+
 # ---- (2) trees ------------------------------------------------------------------------------------------------------------------
 L = C.CDLL(LIBP)
 L.LGBM_GetLastError.restype = C.c_char_p
