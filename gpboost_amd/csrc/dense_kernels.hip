@@ -11,9 +11,9 @@
 // rows/columns are the identity so they change neither the log-determinant nor the solves):
 //   dense_cov_lower_kernel   covariance assembly, one 128x128 tile per workgroup, 8x8 entries per lane, 32-byte
 //                            stores: the HBM-write-bound kernel of the path (8 B written per Matern evaluation)
-//   potrf_diag_kernel        64x64 diagonal block, one wavefront, row-per-lane in registers, v_readlane broadcasts
-//   trsm_panel_kernel        L21 = A21 L11^-T, one lane per row, L11 staged in LDS (wave-uniform reads)
-//   syrk_mfma_kernel         C -= L L^T on lower 128x128 tiles with v_mfma_f64_16x16x4_f64 (one wavefront per 64x64
+//   potrf_diag_v2_kernel     64x64 diagonal block, one wavefront, row-per-lane in registers, v_readlane broadcasts
+//   trsm_panel_v2_kernel     L21 = A21 L11^-T, one lane per row, L11 staged in LDS (wave-uniform reads)
+//   syrk_mfma_db_kernel      C -= L L^T on lower 128x128 tiles with v_mfma_f64_16x16x4_f64 (one wavefront per 64x64
 //                            quadrant = 16 accumulator tiles kept across the K loop, K staged through LDS in chunks of
 //                            64); used "narrow" (K = 64, inside a 512-wide block column) and "wide" (K = 512)
 //   trsv_lower_kernel        forward (and optionally backward) substitution + y^T Psi^-1 y + log-det
@@ -102,133 +102,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned int)lo);
 }
 
-// (A four-wavefront variant -- 16 columns of every row per wavefront, column k published through LDS, one barrier per step -- did
-// not measure faster (3.3 vs 2.95 ms for the whole factorisation at n = 2000, on different boxes of a pool with ~20 % box-to-box
-// spread): not kept.)
-__global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ P, int np, int k0, int* __restrict__ info) {
-  const int r = threadIdx.x;
-  double* row = P + (size_t)(k0 + r) * np + k0;
-  double M[TB];
-#pragma unroll
-  for (int c = 0; c < TB; ++c) M[c] = row[c];        // entries c > r are never used meaningfully
-  bool bad = false;
-  static_for<0, TB>([&](auto k_) {
-    constexpr int k = decltype(k_)::value;
-    const double piv = readlane_f64(M[k], k);
-    if (!(piv > 0.0)) bad = true;
-    const double inv = 1.0 / sqrt(piv);                // wave-uniform
-    M[k] = (r == k) ? piv * inv : M[k] * inv;           // L[r][k] (L[k][k] = sqrt(piv))
-    static_for<k + 1, TB>([&](auto c_) {
-      constexpr int c = decltype(c_)::value;
-      const double lck = readlane_f64(M[k], c);         // L[c][k], wave-uniform
-      M[c] = __builtin_fma(-M[k], lck, M[c]);           // rows r >= c are the meaningful ones
-    });
-  });
-#pragma unroll
-  for (int c = 0; c < TB; ++c) if (c <= r) row[c] = M[c];
-  if (bad && r == 0) atomicOr(info, 1);
-}
-
-// ---- panel solve: rows below the diagonal block ------------------------------------------------
-// One lane per row, the row's 64 entries in registers; L11 (32 KB) is staged in LDS with coalesced loads and read back as
-// wave-uniform (broadcast) ds_reads that the compiler can issue far ahead of the dependent FMA chain.  (The first version read
-// L11 through scalar loads: ~55 cycles per FMA, 50 us per panel -- a third of the panel chain.)
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ P, int np, int k0) {
-  __shared__ double sL[TB][TB + 1];
-  const int tid = threadIdx.x;
-  const double* __restrict__ L11 = P + (size_t)k0 * np + k0;
-#pragma unroll 8
-  for (int r = 0; r < TB; ++r) sL[r][tid] = L11[(size_t)r * np + tid];
-  __syncthreads();
-  const int i = k0 + TB + blockIdx.x * 64 + tid;
-  const bool live = i < np;
-  double* row = P + (size_t)(live ? i : k0 + TB) * np + k0;
-  double x[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) x[j] = row[j];
-  static_for<0, TB>([&](auto j_) {
-    constexpr int j = decltype(j_)::value;
-    double t = x[j];
-    static_for<0, j>([&](auto p_) {
-      constexpr int p = decltype(p_)::value;
-      t = __builtin_fma(-x[p], sL[j][p], t);
-    });
-    x[j] = t / sL[j][j];
-  });
-  if (live) {
-#pragma unroll
-    for (int j = 0; j < TB; ++j) row[j] = x[j];
-  }
-}
-
-// ---- trailing update with fp64 MFMA -------------------------------------------------------------
-// C[r][c] -= sum_{k in [kp0, kp0+K)} L[r][k] L[c][k]   for r in [r_base, np), c in [c_base, c_lim), c <= r.
-// One workgroup (4 wavefronts, one per SIMD) per 128x128 tile; each wavefront owns a 64x64 quadrant = 4x4 MFMA
-// tiles of v_mfma_f64_16x16x4_f64 whose accumulators stay in registers across the whole K loop; K is consumed in
-// chunks of 64 columns staged through LDS (2 x 128 x 66 doubles = 135 KB).  The factorisation calls it twice per
-// step: "narrow" (K = 64, only the columns of the current 512-wide block column) and "wide" (K = 512, the whole
-// trailing matrix, once per block column) -- the wide call reads and writes every C tile once per 512 columns
-// instead of once per 64, which is what lifts the arithmetic intensity from ~5 to ~40 flop/B.
-__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ P, int np, int kp0, int K, int r_base,
-                                                        int c_base, int c_lim, int ntj) {
-  __shared__ double sA[128 * LDSS], sB[128 * LDSS];   // 135,168 B static LDS: one workgroup per CU
-  const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
-  const int r0 = r_base + ti * 128, c0 = c_base + tj * 128;
-  if (c0 > r0 + 127) return;                            // tile strictly above the diagonal
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wi = wave >> 1, wj = wave & 1;
-  const int gr0 = r0 + 64 * wi, gc0 = c0 + 64 * wj;
-  // quadrant-level skips (wave-uniform); the wavefront still takes part in the staging and the barriers
-  const bool quad_live = (gc0 <= gr0 + 63) && gr0 < np && gc0 < c_lim;
-  const double* qA = sA + (64 * wi) * LDSS;
-  const double* qB = sB + (64 * wj) * LDSS;
-  double4v acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (double4v){0.0, 0.0, 0.0, 0.0};
-  const int fr = lane & 15, fk = lane >> 4;   // fragment row / k within the 16x4 (A) and 4x16 (B) operands
-  for (int kc = 0; kc < K; kc += TB) {
-    __syncthreads();                                    // previous chunk fully consumed
-    for (int e = tid; e < 128 * (TB / 2); e += 256) {   // stage 128 rows x 64 doubles per panel, 16-byte loads
-      const int i = e / (TB / 2), j2 = (e % (TB / 2)) * 2;
-      double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
-      if (r0 + i < np) va = *reinterpret_cast<const double2*>(P + (size_t)(r0 + i) * np + kp0 + kc + j2);
-      if (c0 + i < np) vb = *reinterpret_cast<const double2*>(P + (size_t)(c0 + i) * np + kp0 + kc + j2);
-      sA[i * LDSS + j2] = va.x; sA[i * LDSS + j2 + 1] = va.y;
-      sB[i * LDSS + j2] = vb.x; sB[i * LDSS + j2 + 1] = vb.y;
-    }
-    __syncthreads();
-    if (quad_live) {
-#pragma unroll 4
-      for (int kk = 0; kk < TB / 4; ++kk) {
-        double af[4], bf[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          af[q] = qA[(16 * q + fr) * LDSS + 4 * kk + fk];   // A[i][k]
-          bf[q] = qB[(16 * q + fr) * LDSS + 4 * kk + fk];   // B^T[k][j] = L[j][k]
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int nj = 0; nj < 4; ++nj)
-            acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
-      }
-    }
-  }
-  if (!quad_live) return;
-  // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = gr0 + 16 * mi + fk + 4 * r, gj = gc0 + 16 * nj + fr;
-        if (gj <= gi && gi < np && gj < c_lim) P[(size_t)gi * np + gj] -= acc[mi][nj][r];
-      }
-}
+// ---- trailing update with fp64 MFMA: C[r][c] -= sum_{k in [kp0, kp0 + K)} L[r][k] L[c][k] for r in [r_base, np), c in [c_base, c_lim), c <= r ----
+// (syrk_mfma_db_kernel / syrk_mfma_small_kernel below.  The factorisation calls the update twice per step: "narrow" (K = 64, only the columns of the
+// current 512-wide block column) and "wide" (K = 512, the whole trailing matrix, once per block column) -- the wide call reads and writes every C tile
+// once per 512 columns instead of once per 64, which lifts the arithmetic intensity from ~5 to ~40 flop/B.  Round 4 removed the superseded generations:
+// the single-buffered 128 x 128 update of round 2 and the first forms of the two panel kernels; their measurements are in DESIGN.md section 4.5.)
 
 // ---- round 3: the panel chain and the update, second forms --------------------------------------------------------------------
 // (2) syrk_mfma_db_kernel: the same tiles and MFMA schedule as syrk_mfma_kernel with the K loop double-buffered -- the next 32-column
@@ -243,7 +121,7 @@ __device__ __forceinline__ double inv_sqrt_newton(double x) {
   const double e = __builtin_fma(-0.5 * x * y0, y0, 0.5);
   return __builtin_fma(y0, e, y0);
 }
-// Second forms of the two panel kernels (GPB_DENSE_FORM bit 1).  potrf: the pivot's inverse square root by inv_sqrt_newton (27.7 -> 21.3 us
+// Second forms of the two panel kernels.  potrf: the pivot's inverse square root by inv_sqrt_newton (27.7 -> 21.3 us
 // per block under the kernel trace).  trsm: the reciprocals of L11's diagonal once per workgroup (one division per lane, in parallel)
 // instead of 64 divisions in every lane's chain, and four running sums per entry instead of one dependent chain of fmas.
 // (Tried: the COLUMN-oriented recurrence -- once x_j is final the other 63 - j entries take x_j L[q][j] as independent fmas, L11 staged
@@ -309,7 +187,7 @@ __global__ __launch_bounds__(64) void trsm_panel_v2_kernel(double* __restrict__ 
   }
 }
 
-//     KCT = 16 (GPB_DENSE_FORM bit 3; used when an update has more than 256 tiles): 16-column chunks, 74 KB of LDS and -- with
+//     KCT = 16 (used when an update has more than 256 tiles): 16-column chunks, 74 KB of LDS and -- with
 //     __launch_bounds__(256, 2) -- 224 VGPRs without spills, so that TWO workgroups share a CU: two wavefronts per SIMD, one issuing MFMAs
 //     while the other waits at its barrier or for its operands, and room for the panel kernels of the next block column (trsm 33 KB, 64 x 64
 //     update 68 KB of LDS) beside a workgroup of the look-ahead update instead of queueing behind it.  Measured at n = 16 384
@@ -777,12 +655,6 @@ hipError_t launch_dense_cov(int cov, bool d3, const double4* pts, int n, int np,
   return hipGetLastError();
 }
 
-// GPB_DENSE_FORM (bit 0: double-buffered update, bit 1: second forms of the panel kernels, bit 2: 64 x 64 tiles for the narrow
-// updates, bit 3: 16-column chunks = half the LDS for the double-buffered update; bit 4: 64 x 64 tiles also for wide updates of at most 256 big tiles; default 31) keeps the round-2 kernels reachable for A/B measurements (scripts/gpu_dense_ab.py)
-static int dense_form() {
-  static const int f = [] { const char* e = getenv("GPB_DENSE_FORM"); return e ? atoi(e) : 31; }();
-  return f;
-}
 static void launch_update_narrow(double* P, int np, int kp0, int K, int r_base, int c_base, int c_lim, hipStream_t st) {
   if (r_base >= np || c_base >= c_lim) return;
   const int nti = (np - r_base + 63) / 64, ntj = (c_lim - c_base + 63) / 64;
@@ -793,11 +665,10 @@ static void launch_update(double* P, int np, int kp0, int K, int r_base, int c_b
   const int nti = (np - r_base + 127) / 128, ntj = (c_lim - c_base + 127) / 128;
   // a trailing matrix of at most 256 tiles of 128 x 128 does not fill the CUs with one workgroup each: 64 x 64 tiles (two workgroups per CU, a
   // quarter of the K loop per workgroup) shorten the update that sits on the critical path of small factorisations (n = 2000: three wide updates
-  // of ~95 us each) and of the last block columns of large ones.  GPB_DENSE_FORM bit 4.
-  if ((dense_form() & 20) == 20 && nti * ntj <= 256) { launch_update_narrow(P, np, kp0, K, r_base, c_base, c_lim, st); return; }
-  if ((dense_form() & 9) == 9 && nti * ntj > 256) hipLaunchKernelGGL(syrk_mfma_db_kernel<16>, dim3(nti * ntj), dim3(256), 0, st, P, np, kp0, K, r_base, c_base, c_lim, ntj);
-  else if (dense_form() & 1) hipLaunchKernelGGL(syrk_mfma_db_kernel<32>, dim3(nti * ntj), dim3(256), 0, st, P, np, kp0, K, r_base, c_base, c_lim, ntj);
-  else hipLaunchKernelGGL(syrk_mfma_kernel, dim3(nti * ntj), dim3(256), 0, st, P, np, kp0, K, r_base, c_base, c_lim, ntj);
+  // of ~95 us each) and of the last block columns of large ones.
+  if (nti * ntj <= 256) { launch_update_narrow(P, np, kp0, K, r_base, c_base, c_lim, st); return; }
+  // more than 256 tiles: 16-column chunks and two workgroups per CU (74 KB of LDS each: one issues MFMAs while the other waits at its barrier)
+  hipLaunchKernelGGL(syrk_mfma_db_kernel<16>, dim3(nti * ntj), dim3(256), 0, st, P, np, kp0, K, r_base, c_base, c_lim, ntj);
 }
 
 // Blocked right-looking Cholesky with two levels: 64-column panels (potrf + trsm + narrow update inside the current
@@ -821,17 +692,10 @@ hipError_t launch_dense_cholesky(double* P, int np, int* info, hipStream_t st, h
     const int Jend = (J0 + OB < ncols) ? J0 + OB : ncols;
     for (int k0 = J0; k0 < Jend; k0 += TB) {
       const int rows_below = np - k0 - TB;
-      if (dense_form() & 2) {
-        hipLaunchKernelGGL(potrf_diag_v2_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
-        if (rows_below <= 0) break;
-        hipLaunchKernelGGL(trsm_panel_v2_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
-      } else {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
-        if (rows_below <= 0) break;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
-      }
-      if (dense_form() & 4) launch_update_narrow(P, np, k0, TB, k0 + TB, k0 + TB, Jend, st);
-      else launch_update(P, np, k0, TB, k0 + TB, k0 + TB, Jend, st);       // narrow: columns of this block column only
+      hipLaunchKernelGGL(potrf_diag_v2_kernel, dim3(1), dim3(64), 0, st, P, np, k0, info);
+      if (rows_below <= 0) break;
+      hipLaunchKernelGGL(trsm_panel_v2_kernel, dim3((rows_below + 63) / 64), dim3(64), 0, st, P, np, k0);
+      launch_update_narrow(P, np, k0, TB, k0 + TB, k0 + TB, Jend, st);     // narrow (K = 64): columns of this block column only, 64 x 64 tiles
     }
     if (Jend >= np) break;
     if (!lookahead) {

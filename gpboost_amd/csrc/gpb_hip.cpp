@@ -1903,12 +1903,11 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   HIP_OK(hipEventRecord(e[0], h->stream));
   // Two forms.  yrow (default): y rides along as row np of the (np + 64)-row matrix -- the panel solves of the factorisation leave
   // z = L^-1 y in that row and the trailing update leaves -z'z at [np][np]: no forward substitution (np / 64 launches less; the backward
-  // one only when y_aux is asked for).  GPB_EXACT_YROW=0: the factorisation of the np x np matrix and both substitutions (round 2).
-  static const bool yrow = [] { const char* v = getenv("GPB_EXACT_YROW"); return !v || atoi(v) != 0; }();
-  const int ld = yrow ? h->np + 64 : h->np;
-  if (yrow) HIP_OK(hipMemsetAsync(h->d_P + (size_t)h->np * ld, 0, sizeof(double) * (size_t)64 * ld, h->stream));
+  // one only when y_aux is asked for).  (Round 2's form -- the np x np matrix and both substitutions -- was removed in round 4.)
+  const int ld = h->np + 64;
+  HIP_OK(hipMemsetAsync(h->d_P + (size_t)h->np * ld, 0, sizeof(double) * (size_t)64 * ld, h->stream));
   HIP_OK(gpb::launch_dense_cov(cov_type, h->d == 3, h->d_pts, h->n, h->np, ld, var, a, 1.0, h->d_exp_tab, h->d_P, h->stream));   // Psi = Sigma + I (:9273-9287)
-  if (yrow) HIP_OK(gpb::launch_dense_set_yrow(h->d_P, h->n, h->np, ld, h->d_y, h->stream));
+  HIP_OK(gpb::launch_dense_set_yrow(h->d_P, h->n, h->np, ld, h->d_y, h->stream));
   HIP_OK(hipEventRecord(e[1], h->stream));
   if (!h->stream2) {
     HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -1917,14 +1916,10 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   }
   HIP_OK(gpb::launch_dense_cholesky(h->d_P, ld, h->d_info, h->stream, h->stream2, h->ev_panels, h->ev_rest, h->np));
   HIP_OK(hipEventRecord(e[2], h->stream));
-  if (yrow) {
-    HIP_OK(gpb::launch_dense_yrow_sums(h->d_P, h->n, h->np, ld, h->d_out, h->stream));
-    if (yaux_host) {
-      HIP_OK(hipMemcpyAsync(h->d_work, h->d_P + (size_t)h->np * ld, sizeof(double) * (size_t)h->np, hipMemcpyDeviceToDevice, h->stream));
-      HIP_OK(gpb::launch_dense_solve_backward(h->d_P, h->np, ld, h->d_work, h->d_x, h->stream));
-    }
-  } else {
-    HIP_OK(gpb::launch_dense_solve(h->d_P, h->n, h->np, h->np, h->d_y, h->d_z, h->d_out, yaux_host ? h->d_x : nullptr, h->stream, h->d_work));
+  HIP_OK(gpb::launch_dense_yrow_sums(h->d_P, h->n, h->np, ld, h->d_out, h->stream));
+  if (yaux_host) {
+    HIP_OK(hipMemcpyAsync(h->d_work, h->d_P + (size_t)h->np * ld, sizeof(double) * (size_t)h->np, hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(gpb::launch_dense_solve_backward(h->d_P, h->np, ld, h->d_work, h->d_x, h->stream));
   }
   HIP_OK(hipEventRecord(e[3], h->stream));
   int info = 0;

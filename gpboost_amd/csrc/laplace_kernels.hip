@@ -1253,8 +1253,9 @@ constexpr int kSfwThreads = 256;
 // With J = 1 a wavefront owns 4 chunks of a row, the block is solved as ceil(chunks / 4) independent column units (blockIdx.y) whose chains
 // are as short as a single vector's; J = 2 in between.
 typedef double lap_v2d __attribute__((ext_vector_type(2)));
-template <int J> struct SfwBatch { lap_v2d d[4 * J]; };     // [entry 0/1][chunk slot j][half]
-__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[1], const void* const (&pb)[1], SfwBatch<1>& b) {
+// NL rows of 32 bytes (one row of one chunk each) -> d[2 r], d[2 r + 1] = the two halves of row r; loads + wait in one asm block
+template <int NL> struct SfwRows { lap_v2d d[2 * NL]; };
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&p)[2], SfwRows<2>& b) {
   asm volatile(
       "global_load_dwordx4 %0, %4, off sc1\n\t"
       "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
@@ -1262,10 +1263,10 @@ __device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[1], const
       "global_load_dwordx4 %3, %5, off offset:16 sc1\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3])
-      : "v"(pa[0]), "v"(pb[0])
+      : "v"(p[0]), "v"(p[1])
       : "memory");
 }
-__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[2], const void* const (&pb)[2], SfwBatch<2>& b) {
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&p)[4], SfwRows<4>& b) {
   asm volatile(
       "global_load_dwordx4 %0, %8, off sc1\n\t"
       "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
@@ -1277,10 +1278,10 @@ __device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[2], const
       "global_load_dwordx4 %7, %11, off offset:16 sc1\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3]), "=&v"(b.d[4]), "=&v"(b.d[5]), "=&v"(b.d[6]), "=&v"(b.d[7])
-      : "v"(pa[0]), "v"(pa[1]), "v"(pb[0]), "v"(pb[1])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
       : "memory");
 }
-__device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[4], const void* const (&pb)[4], SfwBatch<4>& b) {
+__device__ __forceinline__ void lap_sfw_gather(const void* const (&p)[8], SfwRows<8>& b) {
   asm volatile(
       "global_load_dwordx4 %0, %16, off sc1\n\t"
       "global_load_dwordx4 %1, %16, off offset:16 sc1\n\t"
@@ -1301,7 +1302,7 @@ __device__ __forceinline__ void lap_sfw_gather(const void* const (&pa)[4], const
       "s_waitcnt vmcnt(0)"
       : "=&v"(b.d[0]), "=&v"(b.d[1]), "=&v"(b.d[2]), "=&v"(b.d[3]), "=&v"(b.d[4]), "=&v"(b.d[5]), "=&v"(b.d[6]), "=&v"(b.d[7]),
         "=&v"(b.d[8]), "=&v"(b.d[9]), "=&v"(b.d[10]), "=&v"(b.d[11]), "=&v"(b.d[12]), "=&v"(b.d[13]), "=&v"(b.d[14]), "=&v"(b.d[15])
-      : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
       : "memory");
 }
 __device__ __forceinline__ void lap_sfw_store32(void* p, lap_v2d lo, lap_v2d hi) {
@@ -1365,31 +1366,34 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
         for (int j = 0; j < J; ++j)
 #pragma unroll
           for (int c = 0; c < 4; ++c) sum[j][c] = 0.0;
-        // two entries of this lane in ONE round trip; an entry with coefficient 0 is padding (not a dependency): its gather goes to row 0 and is ignored.
-        // Accumulation order per (chunk, column): entry A, then entry B -- callers pass them in the order of lap_sptrsv_kernel's fma chain.
-        auto take2 = [&](const LapEnt& ea, const LapEnt& eb) {
-          const bool ua = ea.val != 0.0, ub = eb.val != 0.0;
-          if (!__any(ua || ub)) return;                  // (uniform) nothing to gather for the whole wavefront
-          const unsigned oa = ua ? (unsigned)ea.src * 32u : 0u, obt = ub ? (unsigned)eb.src * 32u : 0u;
-          const void* pa[J]; const void* pb[J];
+        // NE entries of this lane in ONE round trip (NE x J rows of 32 bytes); an entry with coefficient 0 is padding (not a dependency): its gather
+        // goes to row 0 and is ignored.  Accumulation order per (chunk, column): the entries in the order given -- callers pass them in the order
+        // of lap_sptrsv_kernel's fma chain.
+        auto take = [&](auto ne_, const LapEnt* en) {
+          constexpr int NE = decltype(ne_)::value;
+          bool used[NE], any = false;
 #pragma unroll
-          for (int j = 0; j < J; ++j) { pa[j] = xb[j] + oa; pb[j] = xb[j] + obt; }
-          SfwBatch<J> b;
-          lap_sfw_gather(pa, pb, b);
+          for (int q = 0; q < NE; ++q) { used[q] = en[q].val != 0.0; any = any || used[q]; }
+          if (!__any(any)) return;                       // (uniform) nothing to gather for the whole wavefront
+          const void* p[NE * J];
 #pragma unroll
-          for (int j = 0; j < J; ++j) {
-            if (chunk_on[j]) {
-              if (ua) {
-                const double g0 = b.d[2 * j][0], g1 = b.d[2 * j][1], g2 = b.d[2 * j + 1][0], g3 = b.d[2 * j + 1][1];
+          for (int q = 0; q < NE; ++q) {
+            const unsigned off = used[q] ? (unsigned)en[q].src * 32u : 0u;
+#pragma unroll
+            for (int j = 0; j < J; ++j) p[q * J + j] = xb[j] + off;
+          }
+          SfwRows<NE * J> b;
+          lap_sfw_gather(p, b);
+#pragma unroll
+          for (int q = 0; q < NE; ++q) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+              if (chunk_on[j] && used[q]) {
+                const int r = q * J + j;
+                const double g0 = b.d[2 * r][0], g1 = b.d[2 * r][1], g2 = b.d[2 * r + 1][0], g3 = b.d[2 * r + 1][1];
                 ok = ok && lap_sfw_present(g0) && lap_sfw_present(g1) && lap_sfw_present(g2) && lap_sfw_present(g3);
-                sum[j][0] = __builtin_fma(ea.val, g0, sum[j][0]); sum[j][1] = __builtin_fma(ea.val, g1, sum[j][1]);
-                sum[j][2] = __builtin_fma(ea.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(ea.val, g3, sum[j][3]);
-              }
-              if (ub) {
-                const double g0 = b.d[2 * J + 2 * j][0], g1 = b.d[2 * J + 2 * j][1], g2 = b.d[2 * J + 2 * j + 1][0], g3 = b.d[2 * J + 2 * j + 1][1];
-                ok = ok && lap_sfw_present(g0) && lap_sfw_present(g1) && lap_sfw_present(g2) && lap_sfw_present(g3);
-                sum[j][0] = __builtin_fma(eb.val, g0, sum[j][0]); sum[j][1] = __builtin_fma(eb.val, g1, sum[j][1]);
-                sum[j][2] = __builtin_fma(eb.val, g2, sum[j][2]); sum[j][3] = __builtin_fma(eb.val, g3, sum[j][3]);
+                sum[j][0] = __builtin_fma(en[q].val, g0, sum[j][0]); sum[j][1] = __builtin_fma(en[q].val, g1, sum[j][1]);
+                sum[j][2] = __builtin_fma(en[q].val, g2, sum[j][2]); sum[j][3] = __builtin_fma(en[q].val, g3, sum[j][3]);
               }
             }
           }
@@ -1400,18 +1404,16 @@ __global__ __launch_bounds__(kSfwThreads) void lap_sptrsv_sfw_kernel(LapTri T, i
         const LapEnt hB = sl == 0 ? h0[1] : T.hent[(size_t)qq * 32 + e + 16];
         if (OVF) {
           const int eo0 = ob + e, eo1 = ob + e + 16;
-          const LapEnt oA = eo0 < oe ? T.oent[eo0] : none;
-          const LapEnt oB = eo1 < oe ? T.oent[eo1] : none;
-          take2(hA, oA);
-          take2(hB, oB);
+          const LapEnt first[4] = {hA, eo0 < oe ? T.oent[eo0] : none, hB, eo1 < oe ? T.oent[eo1] : none};
+          take(IntC<4>{}, first);                          // the head and the first 32 overflow entries of the slot: one round trip (v3: two)
           for (int e0 = ob + 32 + e; e0 - e < oe; e0 += 64) {
-            const LapEnt o0 = e0 < oe ? T.oent[e0] : none, o1 = e0 + 16 < oe ? T.oent[e0 + 16] : none;
-            const LapEnt o2 = e0 + 32 < oe ? T.oent[e0 + 32] : none, o3 = e0 + 48 < oe ? T.oent[e0 + 48] : none;
-            take2(o0, o1);
-            take2(o2, o3);
+            const LapEnt more[4] = {e0 < oe ? T.oent[e0] : none, e0 + 16 < oe ? T.oent[e0 + 16] : none,
+                                    e0 + 32 < oe ? T.oent[e0 + 32] : none, e0 + 48 < oe ? T.oent[e0 + 48] : none};
+            take(IntC<4>{}, more);
           }
         } else {
-          take2(hA, hB);
+          const LapEnt two[2] = {hA, hB};
+          take(IntC<2>{}, two);
         }
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -1524,7 +1526,7 @@ static hipError_t lap_trsv_syncfree_block_j(const LapTri& T, int n, int qa, int 
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
   (void)hipGetLastError();
   const int resident = std::max(1, occ * cus * 3 / 4);   // every workgroup of the launch must be resident (forward progress): stay below what the calculator admits
-  int total = wanted_total > 0 ? wanted_total : 2 * cus;
+  int total = wanted_total > 0 ? wanted_total : 2 * cus;      // (measured at config 4, profiles/r04_c_*: J = 1 with 512 workgroups 279 ms, 256: 295, 768 / 1024: 300)
   total = std::min(total, resident);
   const int per_unit = std::max(1, std::min(total / units, (nslot + kSfwThreads / 64 - 1) / (kSfwThreads / 64)));
   hipLaunchKernelGGL((lap_sf_prefill_kernel<4, 4>), dim3((nslot + 255) / 256, ncol), dim3(256), 0, st, T, qa, qb, n, x);
@@ -1541,11 +1543,9 @@ static hipError_t lap_trsv_syncfree_block(const LapTri& T, const int* host_ptr, 
   static int jsel = 0, wanted = 0;
   if (jsel == 0) {
     jsel = 1;
-    if (const char* ev = std::getenv("GPB_LAP_SFW_J")) { const int j = std::atoi(ev); if (j == 1 || j == 2 || j == 4) jsel = j; }
+    if (const char* ev = std::getenv("GPB_LAP_SFW_J")) { const int j = std::atoi(ev); if (j == 1 || j == 2) jsel = j; }
     if (const char* ev = std::getenv("GPB_LAP_SFW_WGS")) wanted = std::max(0, std::atoi(ev));
   }
-  if (ncol > 16 && jsel == 4) return hipErrorInvalidValue;     // (one column unit of J = 4 covers 16 chunks; larger blocks take J <= 2 with more units)
-  if (jsel == 4) return lap_trsv_syncfree_block_j<SCALE, 4>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
   if (jsel == 2) return lap_trsv_syncfree_block_j<SCALE, 2>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
   return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
 }
