@@ -2287,12 +2287,10 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   if (nchunks >= 16) nchunks &= ~7;                 // multiples of 8: the XCD-aware workgroup order of hist_build_kernel
   // whole rows per lane (hist_build_rows_kernel: 128 KB of LDS, one workgroup of 512 lanes per CU and quad of feature groups) when the
   // hessian is constant, there are at least four feature groups and every CU gets a workgroup with >= 2048 rows
-  // Per-row hessians: hist_build_kernel (a workgroup per 16 features, four workgroups per CU).  The whole-row form with two words per
-  // (bin, feature) -- hist_build_rows_kernel<.., HAS_HESS = true>, two feature groups per lane -- is correct (same bits) but SLOWER:
-  // 0.395 vs 0.335 ms at n = 1e7, F = 50 (profiles/r03_f_hist_per_row_hessians.log): 64 LDS atomics per row and lane on ONE workgroup
-  // per CU lose more to the atomic rate than the shared row prologue saves.  GPB_HIST_ROWS_HESS=1 selects it for measurements.
-  static const bool rows_hess = [] { const char* v = getenv("GPB_HIST_ROWS_HESS"); return v && atoi(v) != 0; }();
-  const bool rows_kernel = (h->has_hess ? (rows_hess && groups >= 2) : groups >= 4) && (long long)num_data >= 2048LL * h->num_cu;
+  // Per-row hessians: hist_build_kernel (a workgroup per 16 features, four workgroups per CU).  (A whole-row form with two words per (bin, feature)
+  // was measured in round 3 -- same bits, 0.395 vs 0.335 ms at n = 1e7, F = 50, profiles/r03_f_hist_per_row_hessians.log: 64 LDS atomics per row
+  // and lane on ONE workgroup per CU lose more to the atomic rate than the shared row prologue saves -- and removed in round 4.)
+  const bool rows_kernel = !h->has_hess && groups >= 4 && (long long)num_data >= 2048LL * h->num_cu;
   if (rows_kernel) nchunks = std::max(1, h->num_cu);      // one workgroup per CU and quad of feature groups (launches of whole quads, then the partial one)
   const int rows_per_chunk = (num_data + nchunks - 1) / std::max(nchunks, 1);
   if (nchunks < 16 && rows_per_chunk > 0) nchunks = (num_data + rows_per_chunk - 1) / rows_per_chunk;

@@ -213,25 +213,20 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // its 16 features only.  Here a lane takes a row's whole 64 bytes (four feature groups) and issues its 64 atomics into four 32 KB
 // sub-histogram blocks (128 KB of LDS: one workgroup of 512 lanes per CU): the per-row work is paid once per 64 features, what remains
 // is the LDS atomic rate.  Same words, same drains (every 3 iterations = 1536 rows <= 1792), same partial layout as hist_build_kernel.
-// HAS_HESS (per-row hessians: every likelihood but the Gaussian one): a second 64-bit word per (bin, feature) carries the hessian sum, so
-// the same 128 KB of LDS hold TWO feature groups -- a lane takes 32 bytes of its row and issues 32 + 32 atomics; the per-row work (row
-// index, gradient / hessian load and conversion) is paid once per 32 features instead of once per 16 in hist_build_kernel.
-template <bool HAS_IDX, int NBK, bool HAS_HESS>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block
+// Constant hessian only: per-row hessians stay on hist_build_kernel (the two-word whole-row form was slower).
+template <bool HAS_IDX, int NBK>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block
 __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
   // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
-  constexpr int THREADS = 512, NB = HAS_HESS ? 2 : 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
+  constexpr int THREADS = 512, NB = 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
   extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features] (+ the same again for the hessian sums)
-  unsigned long long* const s_hrows = s_rows + NB * kWords;
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, quad = blockIdx.y + a.quad0, groups = a.fpad / GPB_HIST_FG;
-  for (int t = tid; t < (HAS_HESS ? 2 : 1) * NB * kWords; t += THREADS) s_rows[t] = 0ull;
+  for (int t = tid; t < NB * kWords; t += THREADS) s_rows[t] = 0ull;
   const double inv_q = fixed_point_inv_q<false>(a.grad_max_bits);
-  double inv_qh = 1.0;
-  if constexpr (HAS_HESS) inv_qh = fixed_point_inv_q<true>(a.hess_max_bits);
-  long long rk[kOwn], rh[HAS_HESS ? kOwn : 1];
+  long long rk[kOwn];
   unsigned rc[kOwn];
 #pragma unroll
-  for (int i = 0; i < kOwn; ++i) { rk[i] = 0; rc[i] = 0u; if constexpr (HAS_HESS) rh[i] = 0; }
+  for (int i = 0; i < kOwn; ++i) { rk[i] = 0; rc[i] = 0u; }
   auto flush = [&]() {
     __syncthreads();
 #pragma unroll
@@ -240,7 +235,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
       const long long sum = (long long)(v << (64 - kSumBits)) >> (64 - kSumBits);
       rk[i] += sum;
       rc[i] += (unsigned)((v - (unsigned long long)sum) >> kSumBits);
-      if constexpr (HAS_HESS) rh[i] += (long long)__hip_atomic_exchange(&s_hrows[i * THREADS + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
   };
@@ -249,7 +243,7 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
   const uint8_t* base = a.bins_rm + (size_t)quad * NB * GPB_HIST_FG;
   constexpr int nblk = NBK;                           // (compile-time: a run-time bound in the unrolled block loop cost 25 %)
-  struct RowData { uint4 bv[NB]; double g, h; };
+  struct RowData { uint4 bv[NB]; double g; };
   auto fetch = [&](int r) -> RowData {
     RowData d;
     const int row = HAS_IDX ? a.data_indices[r] : r;
@@ -257,8 +251,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
 #pragma unroll
     for (int b = 0; b < NB; ++b) d.bv[b] = b < nblk ? p[b] : make_uint4(0u, 0u, 0u, 0u);      // never read past the row's fpad bytes
     d.g = a.grad[row];
-    d.h = 0.0;
-    if constexpr (HAS_HESS) d.h = a.hess[row];
     return d;
   };
   const unsigned wr = (unsigned)(tid >> 2) & 3u, sh = (unsigned)(tid & 3), l15 = (unsigned)tid & 15u;
@@ -266,8 +258,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
   const int nf_last = min(GPB_HIST_FG, a.num_features - (quad * NB + nblk - 1) * GPB_HIST_FG);
   auto accumulate = [&](const RowData& cur) {
     const unsigned long long add_g = fixed_point_bits(cur.g, inv_q) + (1ull << kSumBits);
-    unsigned long long add_h = 0ull;
-    if constexpr (HAS_HESS) add_h = fixed_point_bits(cur.h, inv_qh);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= nblk) break;
@@ -281,7 +271,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
           const unsigned wv = (f & 8) ? ((f & 4) ? wsel[3] : wsel[2]) : ((f & 4) ? wsel[1] : wsel[0]);
           const unsigned bin = (wv >> (8 * (f & 3))) & 0xffu;
           atomicAdd(&s_rows[b * kWords + bin * GPB_HIST_FG + f], add_g);
-          if constexpr (HAS_HESS) atomicAdd(&s_hrows[b * kWords + bin * GPB_HIST_FG + f], add_h);
           f = (f + 1 == nf_last) ? 0 : f + 1;
         }
         continue;
@@ -295,7 +284,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
       for (int s = 0; s < GPB_HIST_FG; ++s) {
         const unsigned bin = (rw[s >> 2] >> (8 * (s & 3))) & 0xffu;
         atomicAdd(&s_rows[b * kWords + bin * GPB_HIST_FG + ((s + l15) & 15u)], add_g);
-        if constexpr (HAS_HESS) atomicAdd(&s_hrows[b * kWords + bin * GPB_HIST_FG + ((s + l15) & 15u)], add_h);
       }
     }
   };
@@ -320,7 +308,6 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
       const size_t o = ((size_t)chunk * groups + quad * NB + b) * kWords + ww;
       a.part_grad[o] = rk[i];
       a.part_cnt[o] = rc[i];
-      if constexpr (HAS_HESS) a.part_hess[o] = rh[i];
     }
   }
 }
@@ -522,19 +509,12 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(kern, dim3(a.nchunks, nquads), dim3(512), lds, st, b);
       return hipGetLastError();
     };
-    if (a.hess) {
-      const int groups = a.fpad / GPB_HIST_FG, full = groups / 2, rest = groups % 2;
-      hipError_t e = hipSuccess;
-      if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 2, true>, full, 0) : go(hist_build_rows_kernel<false, 2, true>, full, 0);
-      if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1, true>, 1, full) : go(hist_build_rows_kernel<false, 1, true>, 1, full);
-      return e;
-    }
     const int groups = a.fpad / GPB_HIST_FG, full = groups / 4, rest = groups % 4;
     hipError_t e = hipSuccess;
-    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4, false>, full, 0) : go(hist_build_rows_kernel<false, 4, false>, full, 0);
-    if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1, false>, 1, full) : go(hist_build_rows_kernel<false, 1, false>, 1, full);
-    if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2, false>, 1, full) : go(hist_build_rows_kernel<false, 2, false>, 1, full);
-    if (e == hipSuccess && rest == 3) e = a.data_indices ? go(hist_build_rows_kernel<true, 3, false>, 1, full) : go(hist_build_rows_kernel<false, 3, false>, 1, full);
+    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0);
+    if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1>, 1, full) : go(hist_build_rows_kernel<false, 1>, 1, full);
+    if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2>, 1, full) : go(hist_build_rows_kernel<false, 2>, 1, full);
+    if (e == hipSuccess && rest == 3) e = a.data_indices ? go(hist_build_rows_kernel<true, 3>, 1, full) : go(hist_build_rows_kernel<false, 3>, 1, full);
     return e;
   }
   // 256 threads: 512 and 1024 (twice / four times the wavefronts on the same 32 KB of LDS) time the same within 2 % at n = 1e7
