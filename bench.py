@@ -31,7 +31,10 @@ if ROOT not in sys.path:
 # (HBM): on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (>= 16 B per lane) -- "double it
 # before comparing with a byte count"; other access widths are uncalibrated.  So: the histogram's row stream (64 B per lane) gets the
 # x2 (`fetch_factor` 2), the point kernel's 32-byte gathers are reported as counted (factor 1, stated).  None when no summary is there.
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+# counters of the newest committed PMC evidence set (scripts/profile_r04.sh -> profiles/r04_pmc.json; the round-3 set as the fallback)
+PMC_JSON = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json")) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r04_pmc.json"))
+PMC_NAME = "profiles/" + os.path.basename(PMC_JSON)
 
 
 def _pmc():
@@ -368,7 +371,7 @@ def main():
             # `traffic` = FETCH_SIZE + WRITE_SIZE of the same kernel from the PMC passes committed under profiles/ (read at run time).
             "roofline": {"bound": "hbm", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch,
-                         "traffic_source": "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at HEAD, separate passes; 32-byte gathers: counted as reported, no x2)" if traffic else None,
+                         "traffic_source": PMC_NAME + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 32-byte gathers: counted as reported, no x2)" if traffic else None,
                          "note": "binding resource is fp64 VALU issue, not HBM: see roofline_fp64_valu; 0.864 GB of gathers per launch, the 32 MB record array lives in L2 / Infinity Cache"},
             "roofline_fp64_valu": {"bound": "fp64 vector ALU issue (no MFMA in this kernel)", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_tflops,
                                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS, "kernel_ms": ms_kernel,
@@ -399,7 +402,7 @@ def main():
                 if mb:
                     out["roofline_cov_assembly"]["mfma_busy_cycles_per_factorisation"] = mb[0] / 3.0
                     out["roofline_cov_assembly"]["mfma_utilisation_pmc"] = mb[0] / 3.0 / (ms3[1] * 1e-3 * 2.4e9 * 1024)
-                    out["roofline_cov_assembly"]["mfma_utilisation_source"] = "profiles/r03_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES (64 cycles per v_mfma_f64_16x16x4) of the syrk_mfma_* kernels, %d dispatches = 3 factorisations" % mb[1]
+                    out["roofline_cov_assembly"]["mfma_utilisation_source"] = PMC_NAME + ": SQ_VALU_MFMA_BUSY_CYCLES (64 cycles per v_mfma_f64_16x16x4) of the syrk_mfma_* kernels, %d dispatches = 3 factorisations" % mb[1]
                 ex.close()
             except Exception as e:
                 out["roofline_cov_assembly"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -435,7 +438,7 @@ def main():
                     "bound": "hbm", "kernel": "hist_build_rows_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
                     "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_rows_kernel<false", fetch_factor=2.0),
-                    "traffic_source": "profiles/r03_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced streams); rows are padded to 64 bytes for F = 50 (28 % more bin bytes than the algorithmic count)",
+                    "traffic_source": PMC_NAME + ": 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced streams); rows are padded to 64 bytes for F = 50 (28 % more bin bytes than the algorithmic count)",
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
                     "note": "fixed-point sums (one 64-bit LDS atomic per row and feature, count packed in, bank-conflict-free layout, a whole "
                             "64-byte row per lane): bit-reproducible, counts exact; see DESIGN.md 4.4"}
@@ -554,36 +557,23 @@ def main():
             except Exception as e:
                 out["config3_boosting_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
-            # While the reference's CPU path is timed on the host cores (20 - 40 s), the GPU keeps evaluating the same likelihood through the
-            # batched entry point on one more host thread: a SUSTAINED rate over tens of seconds (clocks / thermals at steady state), reported
-            # next to the 20-step `value`, never instead of it.
-            import threading
-            stop = threading.Event()
-            sus = {"evals": 0, "s": 0.0}
-
-            def sustain():
-                cps32 = np.stack([cov_pars_of(k) for k in range(32)])
-                t0s = time.perf_counter()
-                try:
-                    while not stop.is_set():
-                        mdl.neg_log_likelihood_batch(cps32)
-                        sus["evals"] += 32
-                except Exception as e:   # noqa: BLE001
-                    sus["error"] = "%s: %s" % (type(e).__name__, e)
-                sus["s"] = time.perf_counter() - t0s
-            th = threading.Thread(target=sustain)
-            th.start()
+            # (1) the reference's CPU path on the host cores with the GPU IDLE (round 3 timed it beside a loop that drove the GPU flat out)
             try:
                 out["cpu_baseline"] = cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n)
             except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
-            stop.set(); th.join()
-            if sus["s"] > 0 and sus["evals"] > 0:
-                out["config"]["sustained"] = {"evals_per_s": sus["evals"] / sus["s"], "seconds": round(sus["s"], 1), "evals": sus["evals"],
-                                              "call": "GPB_HIP_EvalNegLogLikelihoodBatch (K = 32) in a loop beside the CPU baseline leg",
-                                              "note": "a LOWER bound on the sustained rate: the reference's OpenMP threads (up to one per hardware thread) occupy every host core while this loop's one thread launches and polls (r03_z: 550 evaluations/s here against 1159 in the timed region and 1150 - 1270 batched with an idle host)"}
-            if "error" in sus:
-                out["config"]["sustained"] = {"error": sus["error"]}
+            # (2) a SUSTAINED rate over ~10 s with an idle host (clocks / thermals at steady state): the batched entry point in a loop; reported
+            # next to the `steps`-step `value`, never instead of it
+            try:
+                cps32 = np.stack([cov_pars_of(k) for k in range(32)])
+                t0s = time.perf_counter(); nev = 0
+                while time.perf_counter() - t0s < 10.0:
+                    mdl.neg_log_likelihood_batch(cps32); nev += 32
+                dts = time.perf_counter() - t0s
+                out["config"]["sustained"] = {"evals_per_s": nev / dts, "seconds": round(dts, 1), "evals": nev,
+                                              "call": "GPB_HIP_EvalNegLogLikelihoodBatch (K = 32) in a loop for 10 s, host otherwise idle (after the CPU baseline leg)"}
+            except Exception as e:   # noqa: BLE001
+                out["config"]["sustained"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

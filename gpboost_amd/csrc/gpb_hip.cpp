@@ -264,7 +264,6 @@ struct gpb_hip_vecchia {
   double* d_X = nullptr; double* d_U = nullptr; double* d_G = nullptr; double* d_beta = nullptr; int p_cov = 0;   // linear-regression covariates (Vecchia order)
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
-  int rounds = 0;                 // measurement knob (GPB_POINT_ROUNDS): resident rounds of persistent workers of the point kernel; 0 = default
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false, nn_partial = false;
   double* d_nug = nullptr;        // sample weights (Gaussian likelihood): observation-specific nugget 1 / w_i, Vecchia order (gpb_hip_vecchia_set_nugget_diag)
   // full-scale Vecchia (VIF): k inducing points [k][3]; row-major [n][kq] matrices (vif_kernels.hip): cross-covariances C (column k: the response),
@@ -480,7 +479,6 @@ int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, const do
   HIP_OK(hipHostMalloc(&h->h_out, sizeof(double) * 8, hipHostMallocCoherent));
   HIP_OK(hipHostMalloc(&h->h_red, sizeof(double) * 8, hipHostMallocCoherent));
   HIP_OK(hipMalloc(&h->d_flag, sizeof(int)));
-  if (const char* e = std::getenv("GPB_POINT_ROUNDS")) h->rounds = std::atoi(e);
   built = true;
   *out = h;
   API_END();
@@ -720,7 +718,7 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
                                        host_slot_dev ? host_slot_dev : h->h_out));
   } else {
     // ONE launch per evaluation: persistent worker workgroups + a finisher workgroup that adds up their sums (vecchia_kernels.hip)
-    k.ngroups = (h->i_end - h->i_begin + 15) / 16; k.rounds = h->rounds;
+    k.ngroups = (h->i_end - h->i_begin + 15) / 16;
     k.out = h->d_out; k.out_user = out_dev; k.out_host = host_slot_dev ? host_slot_dev : h->h_out;
     HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
     if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
@@ -1249,7 +1247,7 @@ int gpb_hip_vecchia_vif_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, con
   if (h->d > 3) return fail("full-scale Vecchia: coordinate dimensions 1..3 are on the HIP hot path (got %d)", h->d);
   HIP_OK(hipSetDevice(h->device));
   const int kp = (k | 1), kq = gpb::vif_kq(k);
-  if (gpb::vif_resid_lds_bytes(h->m, kp) > 150 * 1024) return fail("full-scale Vecchia: %d neighbours x %d inducing points exceed the LDS of a CU", h->m, k);
+  if (gpb::vif_resid_lds_bytes(h->m, kq) > 150 * 1024) return fail("full-scale Vecchia: %d neighbours x %d inducing points exceed the LDS of a CU", h->m, k);
   HIP_OK(hipStreamSynchronize(h->stream));
   vif_free(h);
   std::vector<double> ip3((size_t)k * 3, 0.0);
@@ -1305,7 +1303,7 @@ int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, d
   ka.A = h->d_A; ka.D = h->d_D; ka.u = h->d_u;
   ka.m = h->m; ka.i_begin = 0; ka.i_end = n;
   ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
-  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, h->d_V, k, kq, kp, h->stream));
+  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, h->d_V, k, kq, h->stream));
   HIP_OK(gpb::launch_reduce_partials(h->d_vif_part, n, 3, h->d_vout, nullptr, h->stream, nullptr));
   HIP_OK(gpb::launch_vif_spmm(h->d_A, h->d_nn, 0, n, h->m, kq, h->d_vC, h->d_vQ, with_grad ? h->d_vdC : nullptr, with_grad ? h->d_vQdC : nullptr, h->stream));
   HIP_OK(gpb::launch_vif_gram(h->d_vQ, h->d_D, n, kq, h->d_vgpart, h->d_vG, h->stream));
@@ -1361,7 +1359,7 @@ int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var
   L.dA0 = keep_factor ? h->d_vdA : nullptr; L.dA1 = keep_factor ? h->d_vdA + (size_t)n * h->m : nullptr;
   L.dD0 = keep_factor ? h->d_vdD : nullptr; L.dD1 = keep_factor ? h->d_vdD + n : nullptr;
   L.partials = h->d_vif_part;
-  HIP_OK(gpb::launch_vif_resid_grad(cov_type, ka, L, k, kq, kp, h->stream));
+  HIP_OK(gpb::launch_vif_resid_grad(cov_type, ka, L, k, kq, h->stream));
   HIP_OK(gpb::launch_reduce_partials(h->d_vif_part, n, GPB_VIF_GRAD_TERMS, h->d_vout, nullptr, h->stream, nullptr));
   HIP_OK(hipMemcpyAsync(sums12_host, h->d_vout, sizeof(double) * GPB_VIF_GRAD_TERMS, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1692,7 +1690,7 @@ int gpb_hip_vecchia_vif_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, c
   ka.A = t->d_A; ka.D = t->d_D; ka.u = t->d_u;
   ka.m = t->m; ka.i_begin = n_obs; ka.i_end = n_all;
   ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
-  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, t->d_V, k, kq, kp, t->stream));
+  HIP_OK(gpb::launch_vif_resid_factor(cov_type, ka, t->d_V, k, kq, t->stream));
   // (B C) of the appended rows
   HIP_OK(gpb::launch_vif_spmm(t->d_A, t->d_nn, n_obs, n_all, t->m, kq, t->d_vC, t->d_vQ, nullptr, nullptr, t->stream));
   HIP_OK(hipMemcpyAsync(u_pred, t->d_u + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost, t->stream));

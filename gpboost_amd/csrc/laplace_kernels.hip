@@ -1490,7 +1490,7 @@ static hipError_t lap_trsv_syncfree(const LapTri& T, const int* host_ptr, const 
   if (resident == 0) {
     int occ = 0, cus = 0, dev = 0;
     (void)hipGetDevice(&dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lap_sptrsv_sf_kernel<true, true, 4, 4>, kSfThreads, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lap_sptrsv_sf_kernel<true, true, 1, 1>, kSfThreads, 0) != hipSuccess || occ < 1) occ = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
     resident = std::max(1, occ * cus / 2);
     (void)hipGetLastError();
@@ -1506,18 +1506,17 @@ static hipError_t lap_trsv_syncfree(const LapTri& T, const int* host_ptr, const 
       hipLaunchKernelGGL((lap_sf_prefill_kernel<NC_, LS_>), pg, dim3(256), 0, st, T, qa, qb, n, x + coff);                              \
       hipLaunchKernelGGL((lap_sptrsv_sf_kernel<SCALE, OVF_, NC_, LS_>), grid, dim3(kSfThreads), 0, st, T, n, qa, qb, rhs + coff, rdw, x + coff, err); \
     } while (0)
-    if (nc == 4) { if (T.has_ovf) LAP_SF(true, 4, 4); else LAP_SF(false, 4, 4); }
-    else { if (T.has_ovf) LAP_SF(true, 1, 1); else LAP_SF(false, 1, 1); }
+    if (T.has_ovf) LAP_SF(true, 1, 1); else LAP_SF(false, 1, 1);
 #undef LAP_SF
     c0 += cn;
   }
   return hipGetLastError();
 }
 // probe block (nc == 4), barrier-free, one wavefront per (row, column unit of 4 J chunks): one launch (+ the sentinel prefill) per triangular solve.
-// GPB_LAP_SFW_J = chunks per 16-lane group (1, 2 or 4), GPB_LAP_SFW_WGS = workgroups per column unit (measurement knobs).
+// J = chunks per 16-lane group: 1 (J = 2 measured 5 % slower, J = 4 cannot keep its grid resident; profiles/r04_c_laplace_block_sweep.txt).
 template <bool SCALE, int J>
 static hipError_t lap_trsv_syncfree_block_j(const LapTri& T, int n, int qa, int qb, const double* rhs, const double* rdw, double* x, int ncol, int* err,
-                                            int wanted_total, hipStream_t st) {
+                                            hipStream_t st) {
   const int nslot = qb - qa;
   const int units = (ncol + 4 * J - 1) / (4 * J);
   int occ = 0, cus = 0, dev = 0;
@@ -1526,7 +1525,7 @@ static hipError_t lap_trsv_syncfree_block_j(const LapTri& T, int n, int qa, int 
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
   (void)hipGetLastError();
   const int resident = std::max(1, occ * cus * 3 / 4);   // every workgroup of the launch must be resident (forward progress): stay below what the calculator admits
-  int total = wanted_total > 0 ? wanted_total : 2 * cus;      // (measured at config 4, profiles/r04_c_*: J = 1 with 512 workgroups 279 ms, 256: 295, 768 / 1024: 300)
+  int total = 2 * cus;                                   // (measured at config 4, profiles/r04_c_*: J = 1 with 512 workgroups 279 ms, 256: 295, 768 / 1024: 300)
   total = std::min(total, resident);
   const int per_unit = std::max(1, std::min(total / units, (nslot + kSfwThreads / 64 - 1) / (kSfwThreads / 64)));
   hipLaunchKernelGGL((lap_sf_prefill_kernel<4, 4>), dim3((nslot + 255) / 256, ncol), dim3(256), 0, st, T, qa, qb, n, x);
@@ -1540,14 +1539,7 @@ static hipError_t lap_trsv_syncfree_block(const LapTri& T, const int* host_ptr, 
   if (nseg <= 0) return hipSuccess;
   const int qa = host_ptr[seg[0].L0], qb = host_ptr[seg[nseg - 1].L1];
   if (qb <= qa) return hipSuccess;
-  static int jsel = 0, wanted = 0;
-  if (jsel == 0) {
-    jsel = 1;
-    if (const char* ev = std::getenv("GPB_LAP_SFW_J")) { const int j = std::atoi(ev); if (j == 1 || j == 2) jsel = j; }
-    if (const char* ev = std::getenv("GPB_LAP_SFW_WGS")) wanted = std::max(0, std::atoi(ev));
-  }
-  if (jsel == 2) return lap_trsv_syncfree_block_j<SCALE, 2>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
-  return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, wanted, st);
+  return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, st);   // J = 1: measured best (profiles/r04_c_laplace_block_sweep.txt)
 }
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
   if (nc == 4 && (lv.syncfree & 4)) {                          // bit 2: the probe block, one wavefront per row over all chunks (round 4)
@@ -1557,7 +1549,7 @@ hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double*
     (void)lap_trsv_syncfree_block<true>(lv.fwd, lv.fwd_ptr_host, lv.fseg, lv.n_fseg, n, t, rdw, z, ncol, lv.err, st);             // (D^-1 + W) B z = t
     return hipGetLastError();
   }
-  if (nc == 4 ? (lv.syncfree & 2) : (lv.syncfree & 1)) {      // bit 0: single vectors (mode finding), bit 1: the probe block, one 16-lane group per (row, chunk)
+  if (nc == 1 && (lv.syncfree & 1)) {                          // bit 0: single vectors (mode finding), one 16-lane group per row
     (void)lap_trsv_syncfree<false>(lv.bwd, lv.bwd_ptr_host, lv.bseg, lv.n_bseg, n, r, nullptr, t, ncol, nc, lv.err, st); // B^T t = r
     lap_dense_solve<false>(lv.bdense, lv.A, n, r, nullptr, t, ncol, nc, st);
     lap_dense_solve<true>(lv.fdense, lv.A, n, t, rdw, z, ncol, nc, st);

@@ -52,7 +52,6 @@ struct VecchiaKernelArgs {
   // used by the generality kernel).  `partials` then holds [GPB_NUM_PARTIALS][workers] 8-byte slots that are all-ones ("empty") between
   // launches: the host fills the buffer with 0xFF once, the finisher restores what it consumed.
   int ngroups = 0;                     // groups of 16 points of this launch = ceil((i_end - i_begin) / 16)
-  int rounds = 0;                      // 0: four resident rounds of workers; > 0: that many; < 0: one worker per group
   double* out = nullptr;               // [GPB_NUM_PARTIALS] the launch's sums in GPB_P_* order
   double* out_user = nullptr;          // optional: the same in the caller-facing order {quad, logdet, bad, g1v, g2v, g1r, g2r}
   double* out_host = nullptr;          // optional: pinned + coherent host copy (GPB_P_* order), polled by the host

@@ -676,8 +676,7 @@ __device__ __forceinline__ void vecchia_finish(const VecchiaKernelArgs& args, in
 // x CUs x rounds, trimmed to ceil(ngroups / trips) so that all workers make the same number of trips (+- 1).  With ONE round every
 // worker runs start to end on "its" CU and the slowest CU sets the time (measured at n = 1e6, m = 30: 0.93 ms); a few rounds let the
 // dispatcher balance (2 rounds 0.893 ms, 4 rounds 0.885 ms, 8 rounds 0.874 ms; profiles/r03_a_*) while the table set-up, the argument
-// loads and the launch of a workgroup are still paid once per ~8 groups.  The occupancy and the CU count are asked once per instantiation and device.  args.rounds > 0
-// overrides the default of 4 (measurement knob: GPB_POINT_ROUNDS); < 0: one group per worker.
+// loads and the launch of a workgroup are still paid once per ~8 groups.  The occupancy and the CU count are asked once per instantiation and device.
 template <int MT, int COV, bool D3>
 static int persistent_grid(const VecchiaKernelArgs& args) {
   auto kern = vecchia_point_kernel<MT, COV, D3, GPB_INSTANTIATE_MODE>;
@@ -691,10 +690,9 @@ static int persistent_grid(const VecchiaKernelArgs& args) {
     per_dev = occ * cus; cached_dev = dev;
     (void)hipGetLastError();
   }
-  if (args.rounds < 0) return args.ngroups;
   // default: about four trips per worker, at most eight rounds (n = 1e6: 8 rounds, 0.874 ms; an 8-GPU shard of 125 000 points: 2 rounds, 0.123 ms)
   const int auto_rounds = (int)std::max(1LL, std::min(8LL, ((long long)args.ngroups + 2LL * per_dev) / (4LL * per_dev)));
-  const long long slots = (long long)per_dev * (args.rounds > 0 ? args.rounds : auto_rounds);
+  const long long slots = (long long)per_dev * auto_rounds;
   if (args.ngroups <= slots) return args.ngroups;
   const int trips = (int)((args.ngroups + slots - 1) / slots);
   return (args.ngroups + trips - 1) / trips;

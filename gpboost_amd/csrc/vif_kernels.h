@@ -21,8 +21,8 @@ hipError_t launch_vif_gram(const double* Q, const double* D, int n, int kq, doub
 // v = D^-1 (u - Q w), z = y - C w   (u, y: column k of Q, C; w: kq doubles, zero from k on)
 hipError_t launch_vif_vec(const double* Q, const double* C, const double* D, const double* w, int n, int k, int kq, double* v, double* z, hipStream_t st);
 // residual-process Vecchia factor: A, D, u (MODE_FACTOR outputs) + partials [GPB_P_*][npts] (one row of three sums per point)
-hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const double* V, int kip, int kq, int kp, hipStream_t st);
-size_t vif_resid_lds_bytes(int m, int kp);
+hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const double* V, int kip, int kq, hipStream_t st);
+size_t vif_resid_lds_bytes(int m, int kq_grad);      // dynamic LDS of the per-point kernels (kq_grad > 0: the derivative kernel)
 // derivative of the residual-process factor + the per-point sums of the gradient: partials [12][npts] = {S1..S6} x {variance, range}
 struct VifGradLaunch {
   const double* V; const double* C; const double* dC; const double* Q; const double* QdC;
@@ -32,6 +32,6 @@ struct VifGradLaunch {
   double* partials;
 };
 #define GPB_VIF_GRAD_TERMS 12
-hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const VifGradLaunch& L, int kip, int kq, int kp, hipStream_t st);
+hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const VifGradLaunch& L, int kip, int kq, hipStream_t st);
 
 }  // namespace gpb

@@ -28,7 +28,6 @@
 namespace gpb {
 
 namespace {
-constexpr int kVifThreads = 128;
 
 // Matern 0.5 / 1.5 / 2.5 on the transformed scale (include/GPBoost/cov_fcts.h:2100-2118): var * f(a * dist)
 template <int COV>
@@ -141,41 +140,55 @@ __global__ __launch_bounds__(256) void vif_gemm_kernel(const double* __restrict_
   }
 }
 
-// Common prefix of the factor and the derivative kernel of the residual process: one workgroup of 128 lanes per point stages the whitened
-// cross-covariances of the point and its neighbours in LDS, deals the (k + 1)(k + 2) / 2 inner products V_a . V_b to the lanes, forms
+// Common prefix of the factor and the derivative kernel of the residual process: one workgroup of T lanes per point -- T = 64, ONE wavefront, for
+// m <= 62 (every __syncthreads of the Cholesky / substitution chains is then a barrier of a single wavefront: the 128-lane form spent most of its
+// 16 ms at n = 1e5 in ~210 two-wavefront barriers per point), T = 128 beyond.  The whitened cross-covariances of the point and its neighbours pass
+// through LDS in chunks of kVifKC columns (round 4: 16 KB instead of 50 KB per workgroup at m = 30, k = 200 -> six workgroups per CU instead of two);
+// the (k + 1)(k + 2) / 2 inner products V_a . V_b are dealt to the lanes pair by pair and accumulate in s_C across the chunks in ascending column
+// order (the same fma chain as one pass over the whole rows).  Then
 //   C_nn = var k(.) - G + nugget I,   c = var k(.) - G[., i]                      (Vecchia_utils.cpp:1489-1500, 1601)
-// and factorises C_nn in place (right-looking Cholesky in LDS, stands in for Eigen's LLT, :1617).  Returns k = number of neighbours and
+// and C_nn is factorised in place (right-looking Cholesky in LDS, stands in for Eigen's LLT, :1617).  Returns k = number of neighbours and
 // G[i][i]; s_c = c; s_C rows 0..k-1 = the lower factor; s_idx = the staged points (row k: the point itself).
-template <int COV>
-__device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, const double* __restrict__ V, int kip, int kq, int kp, int ld, int i,
+constexpr int kVifKC = 64;            // columns of V per staged chunk
+constexpr int kVifKCP = kVifKC + 1;   // LDS row stride of a chunk (odd: the rows start on different banks)
+template <int COV, int T>
+__device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, const double* __restrict__ V, int kip, int kq, int ld, int i,
                                                double* s_C, double* s_V, double* s_c, int* s_idx, double4& ctr, double4& own, double& gii) {
   const int m = args.m, tid = threadIdx.x;
   const int idx = tid < m ? args.nn[(size_t)i * m + tid] : -1;
   const int k = __syncthreads_count(idx >= 0);           // the valid neighbours are a prefix of the row (short rows: i < m)
   s_idx[tid] = tid < k ? idx : (tid == k ? i : -1);      // row k of the staged block is the point itself
+  const int npair = (k + 1) * (k + 2) / 2;
+  for (int p = tid; p < npair; p += T) {                 // zero the Gram accumulators (pair p -> (r, c <= r))
+    int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);   // p < 2^13: exact up to the two corrections below
+    while (r * (r + 1) / 2 > p) --r;
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    s_C[r * ld + (p - r * (r + 1) / 2)] = 0.0;
+  }
   __syncthreads();
   ctr = args.pts[i];
   own = ctr;
   if (tid < k) own = args.pts[idx];
-  for (int e = tid; e < (k + 1) * kip; e += kVifThreads) {
-    const int r = e / kip, c = e - r * kip;
-    s_V[(size_t)r * kp + c] = V[(size_t)s_idx[r] * kq + c];
+  for (int c0 = 0; c0 < kip; c0 += kVifKC) {
+    const int cw = min(kVifKC, kip - c0);
+    for (int e = tid; e < (k + 1) * cw; e += T) {
+      const int r = e / cw, c = e - r * cw;
+      s_V[r * kVifKCP + c] = V[(size_t)s_idx[r] * kq + c0 + c];
+    }
+    __syncthreads();
+    for (int p = tid; p < npair; p += T) {
+      int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);   // p < 2^13: exact up to the two corrections below
+      while (r * (r + 1) / 2 > p) --r;
+      while ((r + 1) * (r + 2) / 2 <= p) ++r;
+      const int c = p - r * (r + 1) / 2;
+      const double* vr = s_V + r * kVifKCP;
+      const double* vc = s_V + c * kVifKCP;
+      double acc = s_C[r * ld + c];
+      for (int j = 0; j < cw; ++j) acc = __builtin_fma(vr[j], vc[j], acc);
+      s_C[r * ld + c] = acc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // Gram matrix, lower triangle incl. the diagonal, rows 0..k: pair p -> (r, c <= r)
-  const int npair = (k + 1) * (k + 2) / 2;
-  for (int p = tid; p < npair; p += kVifThreads) {
-    int r = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-    while (r * (r + 1) / 2 > p) --r;
-    while ((r + 1) * (r + 2) / 2 <= p) ++r;
-    const int c = p - r * (r + 1) / 2;
-    const double* vr = s_V + (size_t)r * kp;
-    const double* vc = s_V + (size_t)c * kp;
-    double acc = 0.0;
-    for (int j = 0; j < kip; ++j) acc = __builtin_fma(vr[j], vc[j], acc);
-    s_C[r * ld + c] = acc;
-  }
-  __syncthreads();
   gii = s_C[k * ld + k];
   if (tid < k) {
     for (int q = 0; q < tid; ++q) s_C[tid * ld + q] = matern_plain<COV>(dist4(own, args.pts[s_idx[q]]), args.var, args.a) - s_C[tid * ld + q];
@@ -225,18 +238,18 @@ __device__ __forceinline__ void vif_chol_solve2(const double* s_C, int ld, int k
 
 // Residual-process factor: D_i = var + nugget - G[i][i] - A_i . c,  A_i = C_nn^-1 c,  u_i = y_i - A_i . y_nn.  Outputs as MODE_FACTOR:
 // A [n][m], D [n], u [n], and the three partial sums {log D_i, u_i^2 / D_i, D_i <= 0} per point.
-template <int COV>
-__global__ __launch_bounds__(kVifThreads) void vif_resid_factor_kernel(VecchiaKernelArgs args, const double* __restrict__ V, int kip, int kq, int kp, int ld) {
+template <int COV, int T>
+__global__ __launch_bounds__(T) void vif_resid_factor_kernel(VecchiaKernelArgs args, const double* __restrict__ V, int kip, int kq, int ld) {
   extern __shared__ double s_dyn[];
   const int m = args.m;
   double* s_C = s_dyn;                                   // [m + 1][ld]: Gram matrix of the staged rows, then C_nn and its factor (row m: the point)
-  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kp]
-  __shared__ double s_c[kVifThreads], s_z1[kVifThreads], s_z2[kVifThreads], s_red[kVifThreads];
-  __shared__ int s_idx[kVifThreads];
+  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kVifKCP]: one chunk of the whitened rows
+  __shared__ double s_c[T], s_z1[T], s_z2[T], s_red[T];
+  __shared__ int s_idx[T];
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
   double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV>(args, V, kip, kq, kp, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  const int k = vif_point_setup<COV, T>(args, V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
   s_z1[tid] = tid < k ? s_c[tid] : 0.0;
   s_z2[tid] = tid < k ? own.w : 0.0;
   __syncthreads();
@@ -253,8 +266,12 @@ __global__ __launch_bounds__(kVifThreads) void vif_resid_factor_kernel(VecchiaKe
   const double z1 = tid < k ? s_z1[tid] : 0.0, z2 = tid < k ? s_z2[tid] : 0.0;
   s_red[tid] = z1 * z1; s_c[tid] = z1 * z2;
   __syncthreads();
+  // fixed tree over 128 slots whatever T (T = 64: the upper half is zero): the same additions in the same order as the 128-lane form
   for (int w = 64; w >= 1; w >>= 1) {
-    if (tid < w) { s_red[tid] += s_red[tid + w]; s_c[tid] += s_c[tid + w]; }
+    if (tid < w) {
+      const double a2 = (tid + w < T) ? s_red[tid + w] : 0.0, b2 = (tid + w < T) ? s_c[tid + w] : 0.0;
+      s_red[tid] += a2; s_c[tid] += b2;
+    }
     __syncthreads();
   }
   const double Dv = args.diag_i - gii - s_red[0];        // D_i (Vecchia_utils.cpp:1463-1465, :1623)
@@ -415,40 +432,40 @@ struct VifGradArgs {
 };
 enum : int { VIF_S1 = 0, VIF_S2 = 1, VIF_S3 = 2, VIF_S4 = 3, VIF_S5 = 4, VIF_S6 = 5 };
 
-template <int COV>
-__global__ __launch_bounds__(kVifThreads) void vif_resid_grad_kernel(VecchiaKernelArgs args, VifGradArgs g) {
+template <int COV, int T>
+__global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs args, VifGradArgs g) {
   extern __shared__ double s_dyn[];
   const int m = args.m, ld = g.ld, kq = g.kq, kip = g.kip;
   double* s_C = s_dyn;
-  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kp] during the set-up; afterwards the five k-vectors of the point
-  __shared__ double s_c[kVifThreads], s_h0[kVifThreads], s_h1[kVifThreads], s_at[kVifThreads], s_g[kVifThreads], s_red[kVifThreads];
-  __shared__ double s_pk[4][kVifThreads];                // partial sums of the kernel-derivative contraction: [sub][row] for K and dK
-  __shared__ double s_pk2[4][kVifThreads];
+  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kVifKCP] chunks of V during the set-up; afterwards the five k-vectors of the point
+  __shared__ double s_c[T], s_h0[T], s_h1[T], s_at[T], s_g[T], s_red[T];
+  __shared__ double s_pk[4][T];                          // partial sums of the kernel-derivative contraction: [sub][row] for K and dK
+  __shared__ double s_pk2[4][T];
   __shared__ double s_self[4];
-  __shared__ int s_idx[kVifThreads];
+  __shared__ int s_idx[T];
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
   double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV>(args, g.V, kip, kq, g.kp, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  const int k = vif_point_setup<COV, T>(args, g.V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
   // Atilde = (A_i, -1)
   s_at[tid] = tid < k ? args.A[(size_t)i * m + tid] : (tid == k ? -1.0 : 0.0);
   // the point's k-vectors (after the set-up the staged rows of V are dead): X1_i, V1_i, X2r_i, Hm_i, w
   double* s_x1 = s_V; double* s_v1 = s_V + kq; double* s_x2 = s_V + 2 * kq; double* s_hm = s_V + 3 * kq; double* s_w = s_V + 4 * kq;
-  for (int c = tid; c < kq; c += kVifThreads) {
+  for (int c = tid; c < kq; c += T) {
     s_x1[c] = g.X1[(size_t)i * kq + c]; s_v1[c] = g.V1[(size_t)i * kq + c]; s_x2[c] = g.X2r[(size_t)i * kq + c];
     s_hm[c] = g.Hm[(size_t)i * kq + c]; s_w[c] = g.w[c];
   }
   __syncthreads();
   // ---- sum_b K_ab Atilde_b and sum_b dK_ab Atilde_b, rows a = 0..k: LPR lanes per row, each a strided part of the columns ----------
   const int rows = k + 1;
-  const int lpr = rows <= 32 ? 4 : (rows <= 64 ? 2 : 1);
+  const int lpr = rows <= T / 4 ? 4 : (rows <= T / 2 ? 2 : 1);
   {
     const int a = tid / lpr, sub = tid - a * lpr;
     double sk = 0.0, sd = 0.0;
     if (a < rows) {
-      const double4 pa = a < k ? args.pts[s_idx[a]] : ctr;
+      const double4 pa = args.pts[s_idx[a]];              // s_idx[k] = i: row k is the point itself
       for (int b = sub; b < rows; b += lpr) {
-        const double4 pb = b < k ? args.pts[s_idx[b]] : ctr;
+        const double4 pb = args.pts[s_idx[b]];
         double kv, dk;
         matern_with_grad<COV>(dist4(pa, pb), args.var, args.a, kv, dk);
         const double at = s_at[b];
@@ -459,7 +476,7 @@ __global__ __launch_bounds__(kVifThreads) void vif_resid_grad_kernel(VecchiaKern
     __syncthreads();
   }
   // ---- low-rank parts: 16 lanes per staged row (8 rows per pass), row a <= k: c_a . V1_i, dc_a . X1_i + c_a . X2r_i, c_a . Hm_i ---------
-  for (int a0 = 0; a0 < rows; a0 += kVifThreads / 16) {
+  for (int a0 = 0; a0 < rows; a0 += T / 16) {
     const int a = a0 + (tid >> 4), lane = tid & 15;
     const bool live = a < rows;
     const size_t src = (size_t)s_idx[live ? a : 0] * kq;
@@ -501,30 +518,30 @@ __global__ __launch_bounds__(kVifThreads) void vif_resid_grad_kernel(VecchiaKern
   vif_chol_solve2(s_C, ld, k, s_h0, s_h1);               // x^p = C_nn^-1 h^p[nn]
   const double x0 = tid < k ? s_h0[tid] : 0.0, x1 = tid < k ? s_h1[tid] : 0.0;
   if (g.dA0 && tid < m) { g.dA0[(size_t)i * m + tid] = -x0; g.dA1[(size_t)i * m + tid] = -x1; }
-  // six 128-lane sums: A . h^p, x^p . z_nn, x^p . g
-  double red[6] = {a_own * h0_own, a_own * h1_own, x0 * z_own, x1 * z_own, x0 * g_own, x1 * g_own};
-  double tot[6];
+  // six sums over the neighbours in one tree: A . h^p, x^p . z_nn, x^p . g   (s_pk / s_pk2 are dead by now)
+  __syncthreads();
+  s_pk[0][tid] = a_own * h0_own; s_pk[1][tid] = a_own * h1_own; s_pk[2][tid] = x0 * z_own; s_pk[3][tid] = x1 * z_own;
+  s_pk2[0][tid] = x0 * g_own; s_pk2[1][tid] = x1 * g_own;
+  __syncthreads();
+  for (int w = 64; w >= 1; w >>= 1) {                   // fixed tree over 128 slots whatever T (T = 64: the upper half is zero)
+    if (tid < w && tid + w < T) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    s_red[tid] = red[q];
-    __syncthreads();
-    for (int w = 64; w >= 1; w >>= 1) {
-      if (tid < w) s_red[tid] += s_red[tid + w];
-      __syncthreads();
+      for (int q = 0; q < 4; ++q) s_pk[q][tid] += s_pk[q][tid + w];
+      s_pk2[0][tid] += s_pk2[0][tid + w]; s_pk2[1][tid] += s_pk2[1][tid + w];
     }
-    tot[q] = s_red[0];
     __syncthreads();
   }
+  const double tot0 = s_pk[0][0], tot1 = s_pk[1][0], tot2 = s_pk[2][0], tot3 = s_pk[3][0], tot4 = s_pk2[0][0], tot5 = s_pk2[1][0];
   if (tid == 0) {
     const double Di = args.D[i], di = 1.0 / Di, vi = g.v[i];
-    const double dD0 = tot[0] - h0_self, dD1 = tot[1] - h1_self;
+    const double dD0 = tot0 - h0_self, dD1 = tot1 - h1_self;
     if (g.dD0) { g.dD0[i] = dD0; g.dD1[i] = dD1; }
     const double kappa = s_self[0];
     const size_t nb = gridDim.x, b = blockIdx.x;
     double* P = g.partials;
     P[(size_t)(2 * VIF_S1 + 0) * nb + b] = dD0 * di;                       P[(size_t)(2 * VIF_S1 + 1) * nb + b] = dD1 * di;
-    P[(size_t)(2 * VIF_S2 + 0) * nb + b] = 2.0 * tot[2] * vi - vi * vi * dD0; P[(size_t)(2 * VIF_S2 + 1) * nb + b] = 2.0 * tot[3] * vi - vi * vi * dD1;
-    P[(size_t)(2 * VIF_S3 + 0) * nb + b] = tot[4] * di;                    P[(size_t)(2 * VIF_S3 + 1) * nb + b] = tot[5] * di;
+    P[(size_t)(2 * VIF_S2 + 0) * nb + b] = 2.0 * tot2 * vi - vi * vi * dD0; P[(size_t)(2 * VIF_S2 + 1) * nb + b] = 2.0 * tot3 * vi - vi * vi * dD1;
+    P[(size_t)(2 * VIF_S3 + 0) * nb + b] = tot4 * di;                    P[(size_t)(2 * VIF_S3 + 1) * nb + b] = tot5 * di;
     P[(size_t)(2 * VIF_S4 + 0) * nb + b] = dD0 * di * di * kappa;          P[(size_t)(2 * VIF_S4 + 1) * nb + b] = dD1 * di * di * kappa;
     P[(size_t)(2 * VIF_S5 + 0) * nb + b] = kappa * di;                     P[(size_t)(2 * VIF_S5 + 1) * nb + b] = s_self[1] * di;
     P[(size_t)(2 * VIF_S6 + 0) * nb + b] = vi * s_self[2];                 P[(size_t)(2 * VIF_S6 + 1) * nb + b] = vi * s_self[3];
@@ -586,20 +603,24 @@ hipError_t launch_vif_vec(const double* Q, const double* C, const double* D, con
   hipLaunchKernelGGL(vif_vec_kernel, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, Q, C, D, w, n, k, kq, v, z);
   return hipGetLastError();
 }
-size_t vif_resid_lds_bytes(int m, int kp) { return sizeof(double) * ((size_t)(m + 1) * ((m + 1) | 1) + (size_t)(m + 1) * kp); }
-hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const double* V, int kip, int kq, int kp, hipStream_t st) {
+size_t vif_resid_lds_bytes(int m, int kq_grad) {      // kq_grad > 0: the derivative kernel (its five k-vectors alias the chunk buffer)
+  const size_t chunk = (size_t)(m + 1) * kVifKCP, vecs = 5 * (size_t)kq_grad;
+  return sizeof(double) * ((size_t)(m + 1) * ((m + 1) | 1) + (chunk > vecs ? chunk : vecs));
+}
+hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const double* V, int kip, int kq, hipStream_t st) {
   const int npts = args.i_end - args.i_begin;
   if (npts <= 0 || args.m < 1 || args.m > GPB_MAX_NEIGHBORS_BIG) return hipErrorInvalidValue;
   const int ld = (args.m + 1) | 1;
-  const size_t lds = vif_resid_lds_bytes(args.m, kp);
+  const size_t lds = vif_resid_lds_bytes(args.m, 0);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define GPB_VIF_LAUNCH(C_)                                                                                                          \
+#define GPB_VIF_LAUNCH_T(C_, T_)                                                                                                    \
   do {                                                                                                                              \
-    auto kern = vif_resid_factor_kernel<C_>;                                                                                        \
+    auto kern = vif_resid_factor_kernel<C_, T_>;                                                                                    \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e_ != hipSuccess) return e_;                                                                                                \
-    hipLaunchKernelGGL(kern, dim3(npts), dim3(kVifThreads), lds, st, args, V, kip, kq, kp, ld);                                     \
+    hipLaunchKernelGGL(kern, dim3(npts), dim3(T_), lds, st, args, V, kip, kq, ld);                                                  \
   } while (0)
+#define GPB_VIF_LAUNCH(C_) do { if (args.m <= 62) GPB_VIF_LAUNCH_T(C_, 64); else GPB_VIF_LAUNCH_T(C_, 128); } while (0)
   switch (cov) {
     case kMatern05: GPB_VIF_LAUNCH(kMatern05); break;
     case kMatern15: GPB_VIF_LAUNCH(kMatern15); break;
@@ -607,26 +628,26 @@ hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const
     default: return hipErrorInvalidValue;
   }
 #undef GPB_VIF_LAUNCH
+#undef GPB_VIF_LAUNCH_T
   return hipGetLastError();
 }
-hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const VifGradLaunch& L, int kip, int kq, int kp, hipStream_t st) {
+hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const VifGradLaunch& L, int kip, int kq, hipStream_t st) {
   const int npts = args.i_end - args.i_begin;
   if (npts <= 0 || args.m < 1 || args.m > GPB_MAX_NEIGHBORS_BIG) return hipErrorInvalidValue;
   const int ld = (args.m + 1) | 1;
-  size_t lds = vif_resid_lds_bytes(args.m, kp);
-  const size_t need = sizeof(double) * ((size_t)(args.m + 1) * ld + 5 * (size_t)kq);        // the five k-vectors alias the staged rows
-  if (need > lds) lds = need;
+  const size_t lds = vif_resid_lds_bytes(args.m, kq);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   VifGradArgs g;
   g.V = L.V; g.C = L.C; g.dC = L.dC; g.Q = L.Q; g.QdC = L.QdC; g.X1 = L.X1; g.V1 = L.V1; g.X2r = L.X2r; g.Hm = L.Hm; g.w = L.w; g.v = L.v; g.z = L.z;
-  g.dA0 = L.dA0; g.dA1 = L.dA1; g.dD0 = L.dD0; g.dD1 = L.dD1; g.partials = L.partials; g.kip = kip; g.kq = kq; g.kp = kp; g.ld = ld;
-#define GPB_VIF_LAUNCH(C_)                                                                                                          \
+  g.dA0 = L.dA0; g.dA1 = L.dA1; g.dD0 = L.dD0; g.dD1 = L.dD1; g.partials = L.partials; g.kip = kip; g.kq = kq; g.kp = 0; g.ld = ld;
+#define GPB_VIF_LAUNCH_T(C_, T_)                                                                                                    \
   do {                                                                                                                              \
-    auto kern = vif_resid_grad_kernel<C_>;                                                                                          \
+    auto kern = vif_resid_grad_kernel<C_, T_>;                                                                                      \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e_ != hipSuccess) return e_;                                                                                                \
-    hipLaunchKernelGGL(kern, dim3(npts), dim3(kVifThreads), lds, st, args, g);                                                      \
+    hipLaunchKernelGGL(kern, dim3(npts), dim3(T_), lds, st, args, g);                                                               \
   } while (0)
+#define GPB_VIF_LAUNCH(C_) do { if (args.m <= 62) GPB_VIF_LAUNCH_T(C_, 64); else GPB_VIF_LAUNCH_T(C_, 128); } while (0)
   switch (cov) {
     case kMatern05: GPB_VIF_LAUNCH(kMatern05); break;
     case kMatern15: GPB_VIF_LAUNCH(kMatern15); break;
@@ -634,6 +655,7 @@ hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const V
     default: return hipErrorInvalidValue;
   }
 #undef GPB_VIF_LAUNCH
+#undef GPB_VIF_LAUNCH_T
   return hipGetLastError();
 }
 

@@ -35,10 +35,10 @@ def _run_gpu_tests_on_the_mock(mock_lib, files, extra=()):
 
 def test_device_tests_written_without_a_gpu_pass_on_the_cpu_restatement_of_the_shim(mock_lib):
     """The tests that sort last (tests/test_zz_*): prediction with cluster ids (the R golden), training-data random effects / standard errors / fits
-    with covariates of the non-Gaussian models, the R suite's logit / probit prediction goldens through the C API.  On the device they are marked as
-    not yet run; here every one of them must pass (XPASS) against the oracle-backed shim."""
+    with covariates of the non-Gaussian models, the R suite's logit / probit prediction goldens through the C API.  They pass on the MI355X since
+    round 4 (profiles/r04_*); here every one of them must pass against the oracle-backed shim as well."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_cluster_prediction_gpu.py", "test_zz_laplace_train_re_gpu.py"])
-    assert "27 xpassed" in tail, tail
+    assert "27 passed" in tail, tail
 
 
 def test_validated_device_tests_still_pass_on_the_cpu_restatement_of_the_shim(mock_lib):
