@@ -265,6 +265,7 @@ struct gpb_hip_vecchia {
   int* d_tptr = nullptr; int* d_tpos = nullptr;
   int* d_flag = nullptr;
   bool has_nn = false, has_y = false, has_factor = false, has_transpose = false, has_levels = false, has_yaux = false, nn_partial = false;
+  bool u_stale = false;           // A, D belong to the current parameters but u = B y to an earlier response (a new y arrived: refresh_u renews it, no refactorisation)
   double* d_nug = nullptr;        // sample weights (Gaussian likelihood): observation-specific nugget 1 / w_i, Vecchia order (gpb_hip_vecchia_set_nugget_diag)
   // full-scale Vecchia (VIF): k inducing points [k][3]; row-major [n][kq] matrices (vif_kernels.hip): cross-covariances C (column k: the response),
   // whitened V, Q = B C; k x k matrices of the products [6][kq][kq]; Gram tiles; per-point partial sums [12][n]; the gradient's matrices are
@@ -643,12 +644,27 @@ int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_begin, int32_t i_e
   API_END();
 }
 
+// A new response: the Vecchia factor (A_i, D_i) does not depend on it, only u = B y does -- the factor stays, u is renewed at its next use
+// (refresh_u: one pass over A, no Cholesky).  The GPBoost algorithm sets a new response (F - y) every boosting iteration at unchanged
+// parameters (CalcGradientF, re_model_template.h:3313-3316).  The full-scale factor carries the response inside Q, v, z: that one goes.
+static void response_changed(gpb_hip_vecchia_t* h) {
+  h->has_yaux = false;
+  if (h->vif_k > 0) h->has_factor = false;
+  else if (h->has_factor) h->u_stale = true;
+}
+static int refresh_u(gpb_hip_vecchia_t* h) {
+  if (!h->u_stale) return 0;
+  HIP_OK(gpb::launch_By_pts(h->d_A, h->d_nn, h->d_pts, h->m, h->i_begin, h->i_end, h->d_u, h->stream));
+  h->u_stale = false;
+  return 0;
+}
+
 int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev) {
   API_BEGIN();
   if (!h || !y_dev) return fail("null argument");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(gpb::launch_pack_y(h->d_pts, y_dev, h->n, h->stream));
-  h->has_y = true; h->has_yaux = false; h->has_factor = false;
+  h->has_y = true; response_changed(h);
   API_END();
 }
 
@@ -674,7 +690,7 @@ int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) {
   HIP_OK(hipMemcpyAsync(h->d_ystage, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   HIP_OK(gpb::launch_pack_y(h->d_pts, h->d_ystage, h->n, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));   // y_host is borrowed for the call only
-  h->has_y = true; h->has_yaux = false; h->has_factor = false;
+  h->has_y = true; response_changed(h);
   API_END();
 }
 
@@ -1182,7 +1198,7 @@ int gpb_hip_vecchia_set_resid(gpb_hip_vecchia_t* h, const double* beta_host) {
     HIP_OK(gpb::launch_resid(h->d_pts, h->d_ystage, h->d_X, h->d_beta, h->n, h->p_cov, h->stream));
   }
   HIP_OK(hipStreamSynchronize(h->stream));     // beta_host is borrowed for the call only
-  h->has_yaux = false; h->has_factor = false;
+  response_changed(h);
   API_END();
 }
 
@@ -1198,7 +1214,7 @@ int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, double var, doubl
   h->has_yaux = false;
   if (vecchia_launch(h, gpb::MODE_FACTOR, cov_type, var, a, gauss_likelihood, nullptr, 0)) return -1;
   HIP_OK(hipStreamSynchronize(h->stream));
-  h->has_factor = true;
+  h->has_factor = true; h->u_stale = false;
   API_END();
 }
 
@@ -1404,6 +1420,7 @@ int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_host, double* D_h
   HIP_OK(hipSetDevice(h->device));
   if (A_host) HIP_OK(hipMemcpyAsync(A_host, h->d_A, sizeof(double) * (size_t)h->n * h->m, hipMemcpyDeviceToHost, h->stream));
   if (D_host) HIP_OK(hipMemcpyAsync(D_host, h->d_D, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  if (u_host && refresh_u(h)) return -1;
   if (u_host) HIP_OK(hipMemcpyAsync(u_host, h->d_u, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   API_END();
@@ -1436,6 +1453,7 @@ static int yaux_enqueue(gpb_hip_vecchia_t* h) {
   HIP_OK(hipSetDevice(h->device));
   if (!h->has_transpose && build_transpose(h)) return -1;
   if (!h->d_v) { HIP_OK(hipMalloc(&h->d_v, sizeof(double) * (size_t)h->n)); HIP_OK(hipMalloc(&h->d_w, sizeof(double) * (size_t)h->n)); }
+  if (refresh_u(h)) return -1;
   HIP_OK(gpb::launch_scale_by_Dinv(h->d_u, h->d_D, h->n, h->i_begin, h->i_end, h->d_v, h->stream));
   HIP_OK(gpb::launch_Bt(h->d_A, h->d_tptr, h->d_tpos, h->n, h->m, h->i_begin, h->i_end, h->d_v, h->d_w, h->stream));
   h->has_yaux = true;

@@ -56,6 +56,19 @@ __global__ void vecchia_By_kernel(const double* __restrict__ A, const int* __res
   u[i] = s;
 }
 
+// the same with the response read from the packed points (pts[i].w), rows [i0, i1): renews u after a new response arrived while A, D stay valid
+__global__ void vecchia_By_pts_kernel(const double* __restrict__ A, const int* __restrict__ nn, const double4* __restrict__ pts, int m, int i0, int i1,
+                                      double* __restrict__ u) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i1) return;
+  double s = pts[i].w;
+  for (int j = 0; j < m; ++j) {
+    const int c = nn[(size_t)i * m + j];
+    if (c >= 0) s = __builtin_fma(-A[(size_t)i * m + j], pts[c].w, s);
+  }
+  u[i] = s;
+}
+
 // w = B^T v via the transposed index (CSR over columns): w_j = v_j - sum_{e in T[j]} A_flat[e] v[e / m]
 // With a shard [i0, i1) only the rows of B owned by this device contribute (the caller all-reduces the n-vector).
 // 16 lanes per column: the first points of the ordering are neighbours of thousands of rows (at n = 1e5 the longest column has > 3000
@@ -184,6 +197,11 @@ hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
 }
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st) {
   hipLaunchKernelGGL(vecchia_By_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, nn, n, m, y, u);
+  return hipGetLastError();
+}
+hipError_t launch_By_pts(const double* A, const int* nn, const double4* pts, int m, int i0, int i1, double* u, hipStream_t st) {
+  if (i1 <= i0) return hipSuccess;
+  hipLaunchKernelGGL(vecchia_By_pts_kernel, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, A, nn, pts, m, i0, i1, u);
   return hipGetLastError();
 }
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,

@@ -68,6 +68,7 @@ hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterm
 hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
+hipError_t launch_By_pts(const double* A, const int* nn, const double4* pts, int m, int i0, int i1, double* u, hipStream_t st);   // u = B y, y = pts[.].w
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,
                      double* w, hipStream_t st);
 hipError_t launch_scale_by_Dinv(const double* u, const double* D, int n, int i0, int i1, double* v, hipStream_t st);

@@ -26,11 +26,15 @@ print("library:", LIBP, flush=True)
 
 # ---- (1) GP ---------------------------------------------------------------------------------------------------------------------
 # --test (tests/test_routes_gpu.py): the reduced sizes of the -m gpu test; --gp-only / --trees-only: one half
+# --cpu-mock (tests/test_routeB_seams_cpu.py, no GPU): the same seams with tests/mock_shim's CPU restatement of gpb_hip_* preloaded -- small sizes, no trees
 TEST = "--test" in sys.argv
+MOCK = "--cpu-mock" in sys.argv
 GP_CASES = ((20000, 30, 2), (100000, 30, 2), (5000, 70, 5))   # the last one: d = 5, m = 70 -> the library's generality kernels
 if TEST:
     GP_CASES = ((20000, 30, 2), (5000, 70, 5))
-if "--trees-only" in sys.argv:
+if MOCK:
+    GP_CASES = ((1500, 12, 2),)
+if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
     GP_CASES = ()
 for n, m, d in GP_CASES:
     coords, _ = cases.synthetic(n, d, seed=3)
@@ -67,6 +71,8 @@ for n, m, d in GP_CASES:
 # ---- (1b) GPBoost iterations through the round-4 seams: device neighbour search at model creation, y_aux = Psi^-1 (F - y) from the resident
 #      factor (CalcYAux), Newton leaf values (NewtonUpdateLeafValues) -- GPU_use = true against GPU_use = false of the same build -------------
 GPB_CASES = ((20000, 20, 3),) if TEST else ((100000, 50, 5), (1000000, 50, 2))
+if MOCK:
+    GPB_CASES = ((int(os.environ.get("GPB_ROUTEB_MOCK_N", "2500")), 6, 4),)
 if "--trees-only" in sys.argv:
     GPB_CASES = ()
 LB = C.CDLL(LIBP)
@@ -85,9 +91,12 @@ for n, F, nit in GPB_CASES:
     yb = np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + np.sin(5 * coords[:, 0]) * np.cos(4 * coords[:, 1]) + 0.3 * rng.standard_normal(n)
     yf = yb.astype(np.float32)
     res = {}
-    for gpu in (False, True):
+    # --skip-cpu-1e6: the CPU leg at n = 1e6 takes 236 s per boosting iteration (profiles/r04_d_routeB.log: measured once); the GPU leg is then checked
+    # against the values that run printed
+    skip_cpu = n == 1000000 and "--skip-cpu-1e6" in sys.argv
+    for gpu in ((True,) if skip_cpu else (False, True)):
         t0 = time.perf_counter()
-        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 12 if MOCK else 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
         t_create = time.perf_counter() - t0
         ds = C.c_void_p()
         okb(LB.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
@@ -110,11 +119,24 @@ for n, F, nit in GPB_CASES:
               "covariance-parameter step); cov pars %s; tree ensemble[:3] = %s" % (n, gpu, t_create, 1e3 * res[gpu]["t_iter"], res[gpu]["cov"], out[:3]), flush=True)
         okb(LB.LGBM_BoosterFree(bst)); okb(LB.LGBM_DatasetFree(ds))
         del mdl
+    if skip_cpu:
+        np.testing.assert_allclose(res[True]["cov"], [0.32799919, 0.29574258, 1.36517975], rtol=1e-6)
+        np.testing.assert_allclose(res[True]["pred"][:3], [0.71453864, 0.51212445, 0.9169032], rtol=1e-6)
+        print("GPBoost n=%d: GPU_use=true reproduces the CPU values of profiles/r04_d_routeB.log (model creation 14.92 s, 236254.6 ms per iteration there): "
+              "model creation %.1fx, boosting iteration %.1fx faster" % (n, 14.92 / res[True]["t_create"], 236.2546 / res[True]["t_iter"]), flush=True)
+        continue
     a, b = res[False], res[True]
     np.testing.assert_allclose(b["pred"], a["pred"], rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(b["cov"], a["cov"], rtol=1e-6)
     print("GPBoost n=%d: GPU_use=true (device neighbour search, y_aux and Newton leaf values from the resident factor) reproduces the CPU path; "
           "model creation %.1fx, boosting iteration %.1fx faster" % (n, a["t_create"] / b["t_create"], a["t_iter"] / b["t_iter"]), flush=True)
+
+if MOCK:
+    print("ROUTE B SEAMS ON THE CPU RESTATEMENT: OK")
+    sys.exit(0)
+if "--gpboost-only" in sys.argv:
+    print("ROUTE B (GPBoost iterations) ON MI355X: OK")
+    sys.exit(0)
 
 # ---- (2) trees ------------------------------------------------------------------------------------------------------------------
 L = C.CDLL(LIBP)

@@ -25,6 +25,7 @@ int orc_vecchia_factor(const double* coords, int n, int d, const int* nn, int m,
                        double* A_grad, double* D_grad);
 void orc_vecchia_By(const double* A, const int* nn, int n, int m, const double* y, double* u);
 void orc_vecchia_yaux(const double* A, const double* D, const int* nn, int n, int m, const double* y, double* y_aux);
+int orc_newton_leaf_values(const double* A, const double* D, const int* nn, int n, int m, const double* yaux, const int* leaf, int L, double* leaf_values);
 void orc_gen_rand_normal(int seed, unsigned long long run_id, int n, int t, double* out);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
@@ -60,6 +61,17 @@ void lik_terms(int link, int y, double x, double* first, double* info, double* d
 }
 }  // namespace
 
+// GPB_MOCK_TIMING=1: seconds spent inside the restated calls, printed at exit (to separate the host code under test from the oracle's arithmetic)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+namespace {
+struct MockTimes { double t[8] = {0}; long c[8] = {0}; const char* name[8] = {"factor", "nll_terms", "grad_terms", "yaux", "newton_leaf_values", "get_factor", "set_y", "other"};
+  ~MockTimes() { if (std::getenv("GPB_MOCK_TIMING")) for (int i = 0; i < 8; ++i) if (c[i]) std::fprintf(stderr, "mock timing: %-20s %6ld calls %9.3f s\n", name[i], c[i], t[i]); } };
+MockTimes g_times;
+struct MockTimer { int k; std::chrono::steady_clock::time_point t0; explicit MockTimer(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+  ~MockTimer() { g_times.t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_times.c[k]++; } };
+}  // namespace
 struct gpb_hip_vecchia {
   int n = 0, d = 0, m = 0;
   std::vector<double> coords;                  // column-major n x d
@@ -229,7 +241,7 @@ EXPORT int gpb_hip_vecchia_get_neighbors(gpb_hip_vecchia_t* h, int32_t* nn) {
   std::copy(h->nn.begin(), h->nn.end(), nn);
   return 0;
 }
-EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) { h->y.assign(y_host, y_host + h->n); h->y0 = h->y; h->has_y = true; return 0; }
+EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host) { MockTimer mock_timer_(6); h->y.assign(y_host, y_host + h->n); h->y0 = h->y; h->has_y = true; return 0; }
 EXPORT int gpb_hip_vecchia_set_covariates(gpb_hip_vecchia_t* h, int32_t p, const double* X) {
   if (p < 0 || (p > 0 && !X)) return fail("mock: set_covariates: bad arguments");
   h->p = p; h->X.assign(X, X + (size_t)p * h->n);
@@ -255,14 +267,14 @@ EXPORT int gpb_hip_vecchia_gram(gpb_hip_vecchia_t* h, double* G) {
   }
   return 0;
 }
-EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss) {
+EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss) { MockTimer mock_timer_(0);
   if (!h->has_nn) return fail("neighbours have not been determined");
   h->A.assign((size_t)h->n * h->m, 0.); h->D.assign(h->n, 0.);
   orc_vecchia_factor(h->coords.data(), h->n, h->d, h->nn.data(), h->m, cov, var, a, gauss, h->A.data(), h->D.data(), nullptr, nullptr);
   h->has_factor = true; h->f_gauss = gauss;
   return 0;
 }
-EXPORT int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss, double* out3) {
+EXPORT int gpb_hip_vecchia_nll_terms(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss, double* out3) { MockTimer mock_timer_(1);
   if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
   if (gpb_hip_vecchia_factor(h, cov, var, a, gauss)) return -1;
   std::vector<double> u(h->n);
@@ -276,7 +288,7 @@ EXPORT int gpb_hip_vecchia_nll_terms_batch(gpb_hip_vecchia_t* h, int cov, int32_
   for (int k = 0; k < K; ++k) if (gpb_hip_vecchia_nll_terms(h, cov, var[k], a[k], gauss, out3K + 3 * (size_t)k)) return -1;
   return 0;
 }
-EXPORT int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov, double var, double a, double* t7) {
+EXPORT int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov, double var, double a, double* t7) { MockTimer mock_timer_(2);
   if (!h->has_y) return fail("response data has not been set (call gpb_hip_vecchia_set_y)");
   if (!h->has_nn) return fail("neighbours have not been determined");
   const int n = h->n, m = h->m;
@@ -302,7 +314,7 @@ EXPORT int gpb_hip_vecchia_grad_terms(gpb_hip_vecchia_t* h, int cov, double var,
   }
   return 0;
 }
-EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) {
+EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host) { MockTimer mock_timer_(3);
   if (!h->has_factor || !h->has_y) return fail("mock: factor / response missing");
   orc_vecchia_yaux(h->A.data(), h->D.data(), h->nn.data(), h->n, h->m, h->y.data(), yaux_host);
   return 0;
@@ -513,11 +525,29 @@ EXPORT int gpb_hip_vecchia_laplace_quad_forms(gpb_hip_vecchia_t* h, int32_t n_ro
 }
 
 // ---- what this restatement leaves out ----
+// route B on the CPU (tests/test_routeB_seams_cpu.py preloads this library under the route-B build of the reference): the neighbour search stays on
+// the host (get = 0), the Newton leaf values come from the oracle
+EXPORT int gpb_hip_route_b_set_device_search(int) { return 0; }
+EXPORT int gpb_hip_route_b_get_device_search(void) { return 0; }
+EXPORT int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_host, double* D_host, double* u_host) { MockTimer mock_timer_(5);
+  if (!h->has_factor) return fail("mock: factor missing");
+  if (A_host) std::copy(h->A.begin(), h->A.end(), A_host);
+  if (D_host) std::copy(h->D.begin(), h->D.end(), D_host);
+  if (u_host) { if (!h->has_y) return fail("mock: response missing"); orc_vecchia_By(h->A.data(), h->nn.data(), h->n, h->m, h->y.data(), u_host); }
+  return 0;
+}
+EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, const int32_t* leaf_index, int32_t num_leaves, double* leaf_values) { MockTimer mock_timer_(4);
+  if (!h->has_factor || !h->has_y) return fail("mock: factor / response missing");
+  std::vector<double> yaux(h->n);
+  orc_vecchia_yaux(h->A.data(), h->D.data(), h->nn.data(), h->n, h->m, h->y.data(), yaux.data());
+  if (orc_newton_leaf_values(h->A.data(), h->D.data(), h->nn.data(), h->n, h->m, yaux.data(), leaf_index, num_leaves, leaf_values)) return fail("mock: H' Psi^-1 H is not positive definite");
+  return 0;
+}
 #define NOT_IN_MOCK(name) EXPORT int name() { return fail("mock shim (tests/mock_shim): " #name " is not restated on the CPU"); }
 NOT_IN_MOCK(gpb_hip_exact_create) NOT_IN_MOCK(gpb_hip_exact_fisher_std_errors) NOT_IN_MOCK(gpb_hip_exact_free) NOT_IN_MOCK(gpb_hip_exact_grad_terms)
 NOT_IN_MOCK(gpb_hip_exact_nll_terms) NOT_IN_MOCK(gpb_hip_exact_predict) NOT_IN_MOCK(gpb_hip_exact_psi_inv_diag) NOT_IN_MOCK(gpb_hip_exact_set_y)
 NOT_IN_MOCK(gpb_hip_vecchia_fisher_std_errors) NOT_IN_MOCK(gpb_hip_vecchia_grad_terms_allreduce)
-NOT_IN_MOCK(gpb_hip_vecchia_newton_leaf_values) NOT_IN_MOCK(gpb_hip_vecchia_nll_terms_allreduce)
-NOT_IN_MOCK(gpb_hip_vecchia_set_nugget_diag) NOT_IN_MOCK(gpb_hip_route_b_set_device_search) NOT_IN_MOCK(gpb_hip_route_b_get_device_search) NOT_IN_MOCK(gpb_hip_hist_register_host_buffers) NOT_IN_MOCK(gpb_hip_hist_unregister_host_buffers) NOT_IN_MOCK(gpb_hip_kmeans_lloyd) NOT_IN_MOCK(gpb_hip_vecchia_timing) NOT_IN_MOCK(gpb_hip_mailbox_create) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_attach) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_info) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_detach)
+NOT_IN_MOCK(gpb_hip_vecchia_nll_terms_allreduce)
+NOT_IN_MOCK(gpb_hip_vecchia_set_nugget_diag) NOT_IN_MOCK(gpb_hip_hist_register_host_buffers) NOT_IN_MOCK(gpb_hip_hist_unregister_host_buffers) NOT_IN_MOCK(gpb_hip_kmeans_lloyd) NOT_IN_MOCK(gpb_hip_vecchia_timing) NOT_IN_MOCK(gpb_hip_mailbox_create) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_attach) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_info) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_detach)
 NOT_IN_MOCK(gpb_hip_vecchia_vif_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_grad_sums) NOT_IN_MOCK(gpb_hip_vecchia_vif_get_grad_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_obs_only) NOT_IN_MOCK(gpb_hip_vecchia_vif_set_inducing_points)
 }  // extern "C"

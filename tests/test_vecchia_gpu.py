@@ -135,6 +135,30 @@ def test_factor_A_D_u_and_yaux_against_oracle(gpb, orc):
         assert t[2] == 0
 
 
+def test_new_response_keeps_the_factor_and_renews_u(gpb, orc):
+    """The GPBoost algorithm hands over a new response (F - y) every boosting iteration at unchanged covariance parameters (CalcGradientF,
+    re_model_template.h:3313-3316: SetY, CalcYAux): A, D stay on the device, u = B y is renewed by one pass over A -- no refactorisation."""
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(5000, 2, seed=4)
+    perm, co, nn = orc.vecchia_setup(coords, 20, "random", 2)
+    st = shim.VecchiaState(co, 20)
+    st.set_neighbors(nn)
+    st.set_y(y[perm])
+    st.factor(2, 3.0, 9.0)
+    A0, D0, _ = st.get_factor()
+    Ao, Do, _ = orc.vecchia_factor(co, nn, 2, 3.0, 9.0)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        y2 = rng.standard_normal(len(y))
+        st.set_y(y2)
+        yo = orc.vecchia_yaux(Ao, Do, nn, y2)
+        np.testing.assert_allclose(st.yaux(), yo, rtol=1e-9, atol=1e-10 * np.abs(yo).max())
+        A, D, u = st.get_factor()
+        assert np.array_equal(A, A0) and np.array_equal(D, D0)
+        uo = y2 - np.einsum("ij,ij->i", Ao, np.where(nn >= 0, y2[np.maximum(nn, 0)], 0.))
+        np.testing.assert_allclose(u, uo, rtol=0, atol=1e-10)
+
+
 def test_device_neighbor_search_equals_host_table(gpb, orc):
     """find_neighbors (device) == set_neighbors(oracle table): both routes give identical likelihood terms."""
     from gpboost_amd import shim
