@@ -107,6 +107,7 @@ struct REModelHip {
   bool cov_pars_initialized = false, init_cov_pars_provided = false;
   bool yaux_valid = false;      // y_aux_has_been_calculated_: factor + y_aux of the last GPB_HIP_CalcYAux are still on the device
   bool y_set = false;           // y_has_been_set_: ybuf / the device copy hold the response of the last call that passed one
+  bool dev_y_is_host = false;   // the device response is exactly y_host (no offset subtracted, not a boosting seam's working response): see prediction_response
   // GPB_SetPredictionData (re_model_template.h:3337-3400)
   std::vector<double> coords_pred; int num_data_pred = 0;
   std::string vecchia_pred_type = "order_obs_first_cond_obs_only";   // default for the Gaussian likelihood (:7112-7115)
@@ -279,11 +280,22 @@ int upload_y(REModelHip* mdl, const double* y_data, const double* fixed_effects,
     parallel_for(n, [&](int k0, int k1) { for (int k = k0; k < k1; ++k) mdl->ybuf[k] = y_data[mdl->perm[k]]; });
   }
   mdl->yaux_valid = false;
+  mdl->dev_y_is_host = remember && !fixed_effects;
   if (remember && y_data != mdl->y_host.data()) mdl->y_host.assign(y_data, y_data + n);   // later calls with an offset but without y start from THIS, not from y - offset
   if (mdl->eh) { if (gpb_hip_exact_set_y(mdl->eh, mdl->ybuf)) return shim_error(); mdl->y_set = true; return 0; }
   for (size_t k = 0; k < mdl->vhs.size(); ++k)
     if (gpb_hip_vecchia_set_y(mdl->vhs[k], mdl->ybuf + mdl->cl_off[k])) return shim_error();
   mdl->y_set = true;
+  return 0;
+}
+
+// The response a prediction conditions on (SetYCalcCovCalcYAuxForPred, re_model_template.h:11141-11166): y_obs if given, else y_vec_, minus this call's
+// offset.  Without y_data and offset the device must hold y_vec_ itself: an earlier call may have left y - F there (an evaluation or prediction with
+// fixed_effects) or a boosting seam's working response -- then y_host goes up again.
+int prediction_response(REModelHip* mdl, const double* y_data, const double* fe) {
+  if (fe) return upload_y(mdl, y_data ? y_data : mdl->y_host.data(), fe);
+  if (y_data) return upload_y(mdl, y_data, nullptr);
+  if (!mdl->dev_y_is_host && !mdl->y_host.empty()) return upload_y(mdl, mdl->y_host.data(), nullptr);
   return 0;
 }
 
@@ -1747,8 +1759,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     }
     if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
     const double* fev = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
-    if (y_data) { if (upload_y(mdl, y_data, fev)) return -1; }
-    else if (fev) { if (upload_y(mdl, mdl->y_host.data(), fev)) return -1; }   // y_vec_ minus this call's offset
+    if (prediction_response(mdl, y_data, fev)) return -1;
     VifSolve vs;
     double t3[3];
     if (vif_terms(mdl, trv[1], trv[2], t3, &vs)) return -1;
@@ -1946,8 +1957,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     }
     if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
     const double* fee = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
-    if (y_data) { if (upload_y(mdl, y_data, fee)) return -1; }
-    else if (fee) { if (upload_y(mdl, mdl->y_host.data(), fee)) return -1; }   // the stored response (y_vec_) minus this call's offset
+    if (prediction_response(mdl, y_data, fee)) return -1;
     const bool need_cov = predict_var || predict_cov_mat;
     std::vector<double> q;
     if (need_cov) q.resize((size_t)npe * npe);
@@ -1994,8 +2004,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (transform_cov_pars(mdl, c3, tr)) return -1;
     if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
     const double* fe = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
-    if (fe) { if (upload_y(mdl, y_data ? y_data : mdl->y_host.data(), fe)) return -1; }   // as in the one-cluster path: the residual becomes the response
-    else if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
+    if (prediction_response(mdl, y_data, fe)) return -1;   // as in the one-cluster path: the residual becomes the response
     mdl->yaux_valid = false;
     // prediction points by cluster, clusters in the order of their first appearance
     std::vector<int32_t> pid; std::vector<std::vector<int>> pidx;
@@ -2084,8 +2093,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   // GPB_SetOffsetData (:3601-3607) -- the residual (y_obs or the stored response) minus the offset becomes the response
   if (!y_data && !mdl->y_set) return set_error("GPB_PredictREModel: y_data is NULL and no response has been set by an earlier call");
   const double* fe = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
-  if (fe) { if (upload_y(mdl, y_data ? y_data : mdl->y_host.data(), fe)) return -1; }   // y_obs, else y_vec_ = the response as it was passed in (NOT y - offset of the fit)
-  else if (y_data) { if (upload_y(mdl, y_data, nullptr)) return -1; }
+  if (prediction_response(mdl, y_data, fe)) return -1;   // y_obs, else y_vec_ = the response as it was passed in (NOT y - offset of the fit)
   if (mdl->p_cov > 0 && gpb_hip_vecchia_set_resid(mdl->vh, mdl->beta.data())) return shim_error();   // resid -= X beta (:11150-11152); the host copy for 'cond_all' below
   std::vector<double> resid_v;                          // response the prediction conditions on, Vecchia order
   const double* yv = mdl->ybuf;
@@ -2247,7 +2255,7 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
     }
     LaplaceCoefSetup su;
     if (laplace_coef_setup(mdl->likelihood, n, p, covariate_data, y_data, fixed_effects, mdl->cov_pars_tr[0], init_coef.empty() ? nullptr : init_coef.data(), &su)) return -1;
-    const double* offs = fixed_effects ? fixed_effects : (mdl->has_offset ? mdl->offset.data() : nullptr);
+    const double* offs = fixed_effects;      // the fit sees the argument only (re_model_template.h:1184, fixed_effects_ptr = fixed_effects); a stored offset serves prediction
     if (laplace_upload_data(mdl, y_data, offs)) return -1;
     mdl->lap_fit_first_eval = true;
     GpbOptimConfig cfg = mdl->optim;

@@ -468,7 +468,10 @@ struct LapState {
   int eval(const double th[2], bool with_grad, bool first_update, double* grad) {
     double o[3] = {0, 0, 0};
     if (th[0] <= 0. || th[1] <= 0.)      // CovFunction::CheckPars (cov_fcts.h:426-429), as for the Gaussian models above
-      return fail_ ? (*fail_)("Check failed: pars[i] > 0. (a covariance parameter has reached zero during the optimisation: %g, %g) ", th[0], th[1]) : -1;
+    {                                    // ends the fit (kCheckFailed), also inside a simplex search that would survive an evaluator error
+      if (fail_) (*fail_)("Check failed: pars[i] > 0. (a covariance parameter has reached zero during the optimisation: %g, %g) ", th[0], th[1]);
+      return kCheckFailed;
+    }
     if (fn(ctx, (with_grad ? 1 : 0) | (first_update ? 16 : 0), th[0], th[1], o)) return -1;
     ++n_evals;
     negll = o[0];
@@ -637,8 +640,8 @@ int run_nelder_mead_laplace(LapState& st, const GpbOptimConfig& cfg, double th[2
   int n_ok = 0;
   auto f = [&](const double* xv, double* fv) -> int {
     const double thx[2] = {std::exp(xv[0]), std::exp(xv[1])};
-    if (st.eval(thx, false, false, nullptr)) {       // evaluator error at a trial vertex: +Inf there, the mode goes back (see run_nelder_mead)
-      if (n_ok == 0) return -1;
+    if (const int rc = st.eval(thx, false, false, nullptr)) {       // evaluator error at a trial vertex: +Inf there, the mode goes back (see run_nelder_mead)
+      if (n_ok == 0 || rc == kCheckFailed) return rc;
       *fv = INFINITY;
       return st.reset_mode() ? -1 : 0;
     }

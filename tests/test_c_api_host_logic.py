@@ -43,9 +43,9 @@ def test_device_tests_written_without_a_gpu_pass_on_the_cpu_restatement_of_the_s
 
 def test_validated_device_tests_still_pass_on_the_cpu_restatement_of_the_shim(mock_lib):
     """A regression net for the C API's host code under the tests that HAVE run on the MI355X: non-Gaussian predictive variances / response predictions
-    and repeated locations, the five Gaussian prediction types incl. the R goldens, Gaussian fits with covariates (32 tests)."""
+    and repeated locations, the five Gaussian prediction types incl. the R goldens, Gaussian fits with covariates (33 tests)."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_laplace_predvar.py", "test_laplace_dup.py", "test_predtypes.py", "test_coef.py"])
-    assert "32 passed" in tail, tail
+    assert "33 passed" in tail, tail
 
 
 ROUTE_A_DRIVER = r'''

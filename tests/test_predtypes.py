@@ -163,3 +163,20 @@ def test_device_pred_first_on_scattered_points_is_in_the_callers_order(orc, lib_
     mu, cov = orc.predict_pred_first(coords, y, cpred, 0, orc.transform_cov_pars(0, cp), 15, True)
     np.testing.assert_allclose(pr["mu"], mu, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(pr["cov"], cov, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_prediction_without_y_conditions_on_the_stored_response_not_on_a_leftover_residual(orc, lib_built):
+    """An evaluation with fixed_effects leaves y - F on the device; a later prediction without y_data and without an offset conditions on y_vec_
+    (SetYCalcCovCalcYAuxForPred, re_model_template.h:11141-11166), so the stored response goes up again (gpb_c_api.cpp: prediction_response)."""
+    import gpboost_amd
+    coords, y, cpred, cp = _perm_case()
+    kw = dict(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none")
+    fresh = gpboost_amd.GPModel(**kw)
+    want = fresh.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_var=True)
+    mdl = gpboost_amd.GPModel(**kw)
+    mdl.neg_log_likelihood(cp, y)                                                    # y_vec_ = y
+    mdl.neg_log_likelihood(cp, y, fixed_effects=np.linspace(-1., 1., len(y)))        # the device now holds y - F
+    got = mdl.predict(gp_coords_pred=cpred, cov_pars=cp, predict_var=True)
+    np.testing.assert_allclose(got["mu"], want["mu"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["var"], want["var"], rtol=1e-12, atol=1e-14)
