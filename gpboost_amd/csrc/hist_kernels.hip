@@ -36,6 +36,11 @@ namespace gpb {
 // registers; those are written per chunk and summed over chunks -- exactly -- by hist_reduce_kernel.
 // Hessians (non-constant case) go to a second word without a count: |k_h| <= 2^51.
 constexpr int kSumBits = 53;                                   // low bits of the packed word: the two's-complement sum
+// drain of one LDS word between the two barriers of a flush: one returning atomic (a plain read + write of the word was measured equal within the
+// run-to-run noise, 0.187 - 0.197 against 0.190 - 0.191 ms for the root pass at n = 1e7: profiles/r04_f_hist_flush_ab.txt)
+__device__ __forceinline__ unsigned long long hist_drain_word(unsigned long long* w) {
+  return __hip_atomic_exchange(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // rows between two flushes: at most 1792 <= 2^11 - 1 (count field), 1792 * 2^41 < 2^52 (sum field)
 constexpr double kMagic = 6755399441055744.0;                  // 1.5 * 2^52: x + kMagic holds rint(x) in its mantissa for |x| < 2^51
 constexpr unsigned long long kMagicBits = 0x4338000000000000ull;
@@ -106,11 +111,11 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
-      const unsigned long long v = __hip_atomic_exchange(&s_acc[i * THREADS + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long v = hist_drain_word(&s_acc[i * THREADS + tid]);
       const long long sum = (long long)(v << (64 - kSumBits)) >> (64 - kSumBits);
       rk[i] += sum;
       rc[i] += (unsigned)((v - (unsigned long long)sum) >> kSumBits);
-      if constexpr (HAS_HESS) rh[i] += (long long)__hip_atomic_exchange(&s_hacc[i * THREADS + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if constexpr (HAS_HESS) rh[i] += (long long)hist_drain_word(&s_hacc[i * THREADS + tid]);
     }
     __syncthreads();
   };
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
-      const unsigned long long v = __hip_atomic_exchange(&s_rows[i * THREADS + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long v = hist_drain_word(&s_rows[i * THREADS + tid]);
       const long long sum = (long long)(v << (64 - kSumBits)) >> (64 - kSumBits);
       rk[i] += sum;
       rc[i] += (unsigned)((v - (unsigned long long)sum) >> kSumBits);

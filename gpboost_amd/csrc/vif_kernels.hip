@@ -143,50 +143,105 @@ __global__ __launch_bounds__(256) void vif_gemm_kernel(const double* __restrict_
 // Common prefix of the factor and the derivative kernel of the residual process: one workgroup of T lanes per point -- T = 64, ONE wavefront, for
 // m <= 62 (every __syncthreads of the Cholesky / substitution chains is then a barrier of a single wavefront: the 128-lane form spent most of its
 // 16 ms at n = 1e5 in ~210 two-wavefront barriers per point), T = 128 beyond.  The whitened cross-covariances of the point and its neighbours pass
-// through LDS in chunks of kVifKC columns (round 4: 16 KB instead of 50 KB per workgroup at m = 30, k = 200 -> six workgroups per CU instead of two);
-// the (k + 1)(k + 2) / 2 inner products V_a . V_b are dealt to the lanes pair by pair and accumulate in s_C across the chunks in ascending column
-// order (the same fma chain as one pass over the whole rows).  Then
+// through LDS in chunks of kVifKC = 64 columns (round 4: 16 KB instead of 50 KB per workgroup at m = 30, k = 200 -> six workgroups per CU instead of
+// two); a chunk is staged with one lane per column and eight rows' loads in flight (the first form's element loop issued one dependent
+// load -> store pair at a time: ~30 exposed memory latencies per chunk).  The Gram matrix G = V_S V_S' of the staged rows S accumulates across the
+// chunks
+//   NT > 0 (T = 64, NT = ceil((m + 1) / 16) <= 4): on the matrix cores -- 16 x 16 tiles (I >= J) of v_mfma_f64_16x16x4_f64, the A operand of tile
+//           row I doubling as the B operand of tile column I (lane (fr, fk) holds V[16 I + fr][4 kk + fk] for both), NT (NT + 1) / 2 accumulator
+//           tiles in registers over all chunks; rows beyond the point's k + 1 are zero;
+//   NT = 0 (T = 128, m > 62): pair (r, c <= r) by pair on the lanes, one fma chain per pair in ascending column order, accumulated in s_C.
+// Then
 //   C_nn = var k(.) - G + nugget I,   c = var k(.) - G[., i]                      (Vecchia_utils.cpp:1489-1500, 1601)
 // and C_nn is factorised in place (right-looking Cholesky in LDS, stands in for Eigen's LLT, :1617).  Returns k = number of neighbours and
 // G[i][i]; s_c = c; s_C rows 0..k-1 = the lower factor; s_idx = the staged points (row k: the point itself).
 constexpr int kVifKC = 64;            // columns of V per staged chunk
 constexpr int kVifKCP = kVifKC + 1;   // LDS row stride of a chunk (odd: the rows start on different banks)
-template <int COV, int T>
+typedef double vif_double4v __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int vif_staged_rows(int m, int nt) { return nt > 0 ? 16 * nt : m + 1; }
+template <int COV, int T, int NT>
 __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, const double* __restrict__ V, int kip, int kq, int ld, int i,
                                                double* s_C, double* s_V, double* s_c, int* s_idx, double4& ctr, double4& own, double& gii) {
+  static_assert(NT == 0 || T == 64, "the MFMA Gram path is the one-wavefront form");
   const int m = args.m, tid = threadIdx.x;
   const int idx = tid < m ? args.nn[(size_t)i * m + tid] : -1;
   const int k = __syncthreads_count(idx >= 0);           // the valid neighbours are a prefix of the row (short rows: i < m)
   s_idx[tid] = tid < k ? idx : (tid == k ? i : -1);      // row k of the staged block is the point itself
   const int npair = (k + 1) * (k + 2) / 2;
-  for (int p = tid; p < npair; p += T) {                 // zero the Gram accumulators (pair p -> (r, c <= r))
-    int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);   // p < 2^13: exact up to the two corrections below
-    while (r * (r + 1) / 2 > p) --r;
-    while ((r + 1) * (r + 2) / 2 <= p) ++r;
-    s_C[r * ld + (p - r * (r + 1) / 2)] = 0.0;
+  if constexpr (NT == 0) {
+    for (int p = tid; p < npair; p += T) {               // zero the Gram accumulators (pair p -> (r, c <= r))
+      int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);   // p < 2^13: exact up to the two corrections below
+      while (r * (r + 1) / 2 > p) --r;
+      while ((r + 1) * (r + 2) / 2 <= p) ++r;
+      s_C[r * ld + (p - r * (r + 1) / 2)] = 0.0;
+    }
   }
   __syncthreads();
   ctr = args.pts[i];
   own = ctr;
   if (tid < k) own = args.pts[idx];
+  constexpr int kAcc = NT > 0 ? NT * (NT + 1) / 2 : 1;
+  vif_double4v acc[kAcc];
+#pragma unroll
+  for (int q = 0; q < kAcc; ++q) acc[q] = (vif_double4v){0.0, 0.0, 0.0, 0.0};
+  const int cl = tid & 63, rp = tid >> 6;               // staging: lane = column of the chunk; T = 128: two rows per pass
+  constexpr int RP = T / 64;
+  const int rows_staged = NT > 0 ? 16 * NT : k + 1;      // NT > 0: the tiles' rows beyond k are written as zeros
   for (int c0 = 0; c0 < kip; c0 += kVifKC) {
     const int cw = min(kVifKC, kip - c0);
-    for (int e = tid; e < (k + 1) * cw; e += T) {
-      const int r = e / cw, c = e - r * cw;
-      s_V[r * kVifKCP + c] = V[(size_t)s_idx[r] * kq + c0 + c];
+    for (int r0 = 0; r0 * RP < rows_staged; r0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (r0 + j) * RP + rp;
+        v[j] = (r <= k && cl < cw) ? V[(size_t)s_idx[r] * kq + c0 + cl] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (r0 + j) * RP + rp;
+        if (r < rows_staged) s_V[r * kVifKCP + cl] = v[j];
+      }
     }
     __syncthreads();
-    for (int p = tid; p < npair; p += T) {
-      int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);   // p < 2^13: exact up to the two corrections below
-      while (r * (r + 1) / 2 > p) --r;
-      while ((r + 1) * (r + 2) / 2 <= p) ++r;
-      const int c = p - r * (r + 1) / 2;
-      const double* vr = s_V + r * kVifKCP;
-      const double* vc = s_V + c * kVifKCP;
-      double acc = s_C[r * ld + c];
-      for (int j = 0; j < cw; ++j) acc = __builtin_fma(vr[j], vc[j], acc);
-      s_C[r * ld + c] = acc;
+    if constexpr (NT > 0) {
+      const int fr = tid & 15, fk = tid >> 4;
+      const int ksteps = (cw + 3) >> 2;                  // columns cw .. 63 of the chunk hold zeros
+      for (int kk = 0; kk < ksteps; ++kk) {
+        double a[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) a[q] = s_V[(16 * q + fr) * kVifKCP + 4 * kk + fk];
+#pragma unroll
+        for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+          for (int nj = 0; nj <= mi; ++nj)
+            acc[mi * (mi + 1) / 2 + nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], a[nj], acc[mi * (mi + 1) / 2 + nj], 0, 0, 0);
+      }
+    } else {
+      for (int p = tid; p < npair; p += T) {
+        int r = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > p) --r;
+        while ((r + 1) * (r + 2) / 2 <= p) ++r;
+        const int c = p - r * (r + 1) / 2;
+        const double* vr = s_V + r * kVifKCP;
+        const double* vc = s_V + c * kVifKCP;
+        double sum = s_C[r * ld + c];
+        for (int j = 0; j < cw; ++j) sum = __builtin_fma(vr[j], vc[j], sum);
+        s_C[r * ld + c] = sum;
+      }
     }
+    __syncthreads();
+  }
+  if constexpr (NT > 0) {                                // accumulator entry r of lane (fr, fk) of tile (mi, nj): G[16 mi + fk + 4 r][16 nj + fr]
+    const int fr = tid & 15, fk = tid >> 4;
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+      for (int nj = 0; nj <= mi; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = 16 * mi + fk + 4 * r, gj = 16 * nj + fr;
+          if (gj <= gi && gi <= k) s_C[gi * ld + gj] = acc[mi * (mi + 1) / 2 + nj][r];
+        }
     __syncthreads();
   }
   gii = s_C[k * ld + k];
@@ -238,18 +293,18 @@ __device__ __forceinline__ void vif_chol_solve2(const double* s_C, int ld, int k
 
 // Residual-process factor: D_i = var + nugget - G[i][i] - A_i . c,  A_i = C_nn^-1 c,  u_i = y_i - A_i . y_nn.  Outputs as MODE_FACTOR:
 // A [n][m], D [n], u [n], and the three partial sums {log D_i, u_i^2 / D_i, D_i <= 0} per point.
-template <int COV, int T>
+template <int COV, int T, int NT>
 __global__ __launch_bounds__(T) void vif_resid_factor_kernel(VecchiaKernelArgs args, const double* __restrict__ V, int kip, int kq, int ld) {
   extern __shared__ double s_dyn[];
   const int m = args.m;
   double* s_C = s_dyn;                                   // [m + 1][ld]: Gram matrix of the staged rows, then C_nn and its factor (row m: the point)
-  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kVifKCP]: one chunk of the whitened rows
+  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [vif_staged_rows(m, NT)][kVifKCP]: one chunk of the whitened rows
   __shared__ double s_c[T], s_z1[T], s_z2[T], s_red[T];
   __shared__ int s_idx[T];
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
   double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV, T>(args, V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  const int k = vif_point_setup<COV, T, NT>(args, V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
   s_z1[tid] = tid < k ? s_c[tid] : 0.0;
   s_z2[tid] = tid < k ? own.w : 0.0;
   __syncthreads();
@@ -432,12 +487,12 @@ struct VifGradArgs {
 };
 enum : int { VIF_S1 = 0, VIF_S2 = 1, VIF_S3 = 2, VIF_S4 = 3, VIF_S5 = 4, VIF_S6 = 5 };
 
-template <int COV, int T>
+template <int COV, int T, int NT>
 __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs args, VifGradArgs g) {
   extern __shared__ double s_dyn[];
   const int m = args.m, ld = g.ld, kq = g.kq, kip = g.kip;
   double* s_C = s_dyn;
-  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [m + 1][kVifKCP] chunks of V during the set-up; afterwards the five k-vectors of the point
+  double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [vif_staged_rows(m, NT)][kVifKCP] chunks of V during the set-up; afterwards the five k-vectors of the point
   __shared__ double s_c[T], s_h0[T], s_h1[T], s_at[T], s_g[T], s_red[T];
   __shared__ double s_pk[4][T];                          // partial sums of the kernel-derivative contraction: [sub][row] for K and dK
   __shared__ double s_pk2[4][T];
@@ -446,7 +501,7 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
   double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV, T>(args, g.V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  const int k = vif_point_setup<COV, T, NT>(args, g.V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
   // Atilde = (A_i, -1)
   s_at[tid] = tid < k ? args.A[(size_t)i * m + tid] : (tid == k ? -1.0 : 0.0);
   // the point's k-vectors (after the set-up the staged rows of V are dead): X1_i, V1_i, X2r_i, Hm_i, w
@@ -603,8 +658,9 @@ hipError_t launch_vif_vec(const double* Q, const double* C, const double* D, con
   hipLaunchKernelGGL(vif_vec_kernel, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, Q, C, D, w, n, k, kq, v, z);
   return hipGetLastError();
 }
+static int vif_tiles(int m) { return m <= 62 ? (m + 1 + 15) / 16 : 0; }      // NT of the per-point kernels: 1..4 (one wavefront, MFMA Gram) or 0
 size_t vif_resid_lds_bytes(int m, int kq_grad) {      // kq_grad > 0: the derivative kernel (its five k-vectors alias the chunk buffer)
-  const size_t chunk = (size_t)(m + 1) * kVifKCP, vecs = 5 * (size_t)kq_grad;
+  const size_t chunk = (size_t)vif_staged_rows(m, vif_tiles(m)) * kVifKCP, vecs = 5 * (size_t)kq_grad;
   return sizeof(double) * ((size_t)(m + 1) * ((m + 1) | 1) + (chunk > vecs ? chunk : vecs));
 }
 hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const double* V, int kip, int kq, hipStream_t st) {
@@ -613,14 +669,23 @@ hipError_t launch_vif_resid_factor(int cov, const VecchiaKernelArgs& args, const
   const int ld = (args.m + 1) | 1;
   const size_t lds = vif_resid_lds_bytes(args.m, 0);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define GPB_VIF_LAUNCH_T(C_, T_)                                                                                                    \
+#define GPB_VIF_LAUNCH_T(C_, T_, NT_)                                                                                                   \
   do {                                                                                                                              \
-    auto kern = vif_resid_factor_kernel<C_, T_>;                                                                                    \
+    auto kern = vif_resid_factor_kernel<C_, T_, NT_>;                                                                                   \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e_ != hipSuccess) return e_;                                                                                                \
     hipLaunchKernelGGL(kern, dim3(npts), dim3(T_), lds, st, args, V, kip, kq, ld);                                                  \
   } while (0)
-#define GPB_VIF_LAUNCH(C_) do { if (args.m <= 62) GPB_VIF_LAUNCH_T(C_, 64); else GPB_VIF_LAUNCH_T(C_, 128); } while (0)
+#define GPB_VIF_LAUNCH(C_)                                                                                                           \
+  do {                                                                                                                              \
+    switch (vif_tiles(args.m)) {                                                                                                    \
+      case 1: GPB_VIF_LAUNCH_T(C_, 64, 1); break;                                                                                   \
+      case 2: GPB_VIF_LAUNCH_T(C_, 64, 2); break;                                                                                   \
+      case 3: GPB_VIF_LAUNCH_T(C_, 64, 3); break;                                                                                   \
+      case 4: GPB_VIF_LAUNCH_T(C_, 64, 4); break;                                                                                   \
+      default: GPB_VIF_LAUNCH_T(C_, 128, 0); break;                                                                                 \
+    }                                                                                                                               \
+  } while (0)
   switch (cov) {
     case kMatern05: GPB_VIF_LAUNCH(kMatern05); break;
     case kMatern15: GPB_VIF_LAUNCH(kMatern15); break;
@@ -640,14 +705,23 @@ hipError_t launch_vif_resid_grad(int cov, const VecchiaKernelArgs& args, const V
   VifGradArgs g;
   g.V = L.V; g.C = L.C; g.dC = L.dC; g.Q = L.Q; g.QdC = L.QdC; g.X1 = L.X1; g.V1 = L.V1; g.X2r = L.X2r; g.Hm = L.Hm; g.w = L.w; g.v = L.v; g.z = L.z;
   g.dA0 = L.dA0; g.dA1 = L.dA1; g.dD0 = L.dD0; g.dD1 = L.dD1; g.partials = L.partials; g.kip = kip; g.kq = kq; g.kp = 0; g.ld = ld;
-#define GPB_VIF_LAUNCH_T(C_, T_)                                                                                                    \
+#define GPB_VIF_LAUNCH_T(C_, T_, NT_)                                                                                                   \
   do {                                                                                                                              \
-    auto kern = vif_resid_grad_kernel<C_, T_>;                                                                                      \
+    auto kern = vif_resid_grad_kernel<C_, T_, NT_>;                                                                                   \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e_ != hipSuccess) return e_;                                                                                                \
     hipLaunchKernelGGL(kern, dim3(npts), dim3(T_), lds, st, args, g);                                                               \
   } while (0)
-#define GPB_VIF_LAUNCH(C_) do { if (args.m <= 62) GPB_VIF_LAUNCH_T(C_, 64); else GPB_VIF_LAUNCH_T(C_, 128); } while (0)
+#define GPB_VIF_LAUNCH(C_)                                                                                                           \
+  do {                                                                                                                              \
+    switch (vif_tiles(args.m)) {                                                                                                    \
+      case 1: GPB_VIF_LAUNCH_T(C_, 64, 1); break;                                                                                   \
+      case 2: GPB_VIF_LAUNCH_T(C_, 64, 2); break;                                                                                   \
+      case 3: GPB_VIF_LAUNCH_T(C_, 64, 3); break;                                                                                   \
+      case 4: GPB_VIF_LAUNCH_T(C_, 64, 4); break;                                                                                   \
+      default: GPB_VIF_LAUNCH_T(C_, 128, 0); break;                                                                                 \
+    }                                                                                                                               \
+  } while (0)
   switch (cov) {
     case kMatern05: GPB_VIF_LAUNCH(kMatern05); break;
     case kMatern15: GPB_VIF_LAUNCH(kMatern15); break;

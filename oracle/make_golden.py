@@ -648,7 +648,8 @@ def vif_fit_fixture(out_dir):
 
 
 VIF_GRAD_CASES = ["vif_u2d_n1500_exp_m15_k40_none", "vif_u2d_n1500_exp_m15_k40_random", "vif_u2d_n3000_mat15_m30_k100_random",
-                  "vif_u3d_n2000_mat25_m20_k64_random", "vif_u2d_n20000_exp_m30_k200_random", "vif_u2d_n100000_exp_m30_k200_random"]
+                  "vif_u3d_n2000_mat25_m20_k64_random", "vif_u2d_n20000_exp_m30_k200_random", "vif_u2d_n100000_exp_m30_k200_random",
+                  "vif_u2d_n1500_exp_m40_k50_random", "vif_u2d_n1500_mat15_m55_k60_random", "vif_u2d_n1200_exp_m70_k40_random"]
 VIF_GRAD_PARS = [(0.1, 1.0, 0.1), (0.3, 0.6, 0.25)]
 
 

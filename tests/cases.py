@@ -351,6 +351,10 @@ VIF_CASES = {
     "vif_u3d_n2000_mat25_m20_k64_random": (2000, 3, "matern", 2.5, 20, 64, "random", 2, [(0.1, 1.0, 0.2)]),
     "vif_u2d_n20000_exp_m30_k200_random": (20000, 2, "exponential", 0.5, 30, 200, "random", 1, [(0.1, 1.0, 0.1)]),
     "vif_u2d_n100000_exp_m30_k200_random": (100000, 2, "exponential", 0.5, 30, 200, "random", 1, [(0.1, 1.0, 0.1)]),
+    # round 4: the per-point kernels' other tile counts -- 32 <= m <= 47 (three 16 x 16 MFMA tile rows), 48 <= m <= 62 (four), m > 62 (two wavefronts, scalar Gram)
+    "vif_u2d_n1500_exp_m40_k50_random": (1500, 2, "exponential", 0.5, 40, 50, "random", 2, [(0.2, 0.8, 0.15)]),
+    "vif_u2d_n1500_mat15_m55_k60_random": (1500, 2, "matern", 1.5, 55, 60, "random", 3, [(0.1, 1.0, 0.2)]),
+    "vif_u2d_n1200_exp_m70_k40_random": (1200, 2, "exponential", 0.5, 70, 40, "random", 1, [(0.2, 0.8, 0.15)]),
 }
 
 
