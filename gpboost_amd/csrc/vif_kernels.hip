@@ -140,11 +140,104 @@ __global__ __launch_bounds__(256) void vif_gemm_kernel(const double* __restrict_
   }
 }
 
+// ---- the point's k x k system in REGISTERS (one-wavefront kernels, NT > 0) -----------------------------------------------------------
+// Lane r holds row r of C_nn / of its lower factor L in R = 16 NT registers (static indices: every loop below is unrolled over R and guarded by the
+// uniform j < k); a pivot or a multiplier travels by v_readlane (SGPR pair -> operand of the fma), so a column step of the right-looking Cholesky is
+// 2 readlanes + 1 fma per trailing column instead of a read-modify-write chain through LDS with three barriers (the LDS form cost ~3500 cycles per
+// column: 44 of the ~98 us a point took).  Entries above the diagonal are never read (lane c's row[j], j < c, is the multiplier l_cj), so the
+// updates run unpredicated and leave garbage there.  Lanes >= k carry identity rows: their multipliers are zero.
+__device__ __forceinline__ double vif_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+template <int I> struct VifIC { static constexpr int value = I; };
+template <int B, int E, class F> __device__ __forceinline__ void vif_sfor(F&& f) {
+  if constexpr (B < E) { f(VifIC<B>{}); vif_sfor<B + 1, E>(f); }
+}
+template <int B, int E, class F> __device__ __forceinline__ void vif_sfor_down(F&& f) {      // E - 1, E - 2, ..., B
+  if constexpr (B < E) { f(VifIC<E - 1>{}); vif_sfor_down<B, E - 1>(f); }
+}
+// in: rows of the SPD matrix (lower triangle); out: rows of L (diagonal included), dinv = 1 / L_rr of this lane's row (1 for lanes >= k)
+template <int R>
+__device__ __forceinline__ void vif_reg_cholesky(double (&row)[R], int k, int lane, double& dinv) {
+  dinv = 1.0;
+  vif_sfor<0, R>([&](auto j_) {
+    constexpr int j = decltype(j_)::value;
+    if (j < k) {
+      const double d = vif_readlane(row[j], j);
+      const double sd = sqrt(d), inv = 1.0 / sd;
+      const double t = row[j] * inv;
+      row[j] = lane == j ? sd : t;
+      if (lane == j) dinv = inv;
+      vif_sfor<j + 1, R>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        const double lc = vif_readlane(row[j], c);
+        row[c] = __builtin_fma(-row[j], lc, row[c]);
+      });
+    }
+  });
+}
+// L z = b for two right-hand sides held one entry per lane (b -> z in place); row = rows of L
+template <int R>
+__device__ __forceinline__ void vif_reg_forward2(const double (&row)[R], int k, int lane, double dinv, double& b1, double& b2) {
+  vif_sfor<0, R>([&](auto j_) {
+    constexpr int j = decltype(j_)::value;
+    if (j < k) {
+      const double t1 = b1 * dinv, t2 = b2 * dinv;
+      const double z1 = vif_readlane(t1, j), z2 = vif_readlane(t2, j);
+      b1 = lane > j ? __builtin_fma(-row[j], z1, b1) : (lane == j ? t1 : b1);
+      b2 = lane > j ? __builtin_fma(-row[j], z2, b2) : (lane == j ? t2 : b2);
+    }
+  });
+}
+// L' x = z (z -> x in place); col = COLUMNS of L: col[r] of lane c is L[r][c]
+template <int R, bool TWO>
+__device__ __forceinline__ void vif_reg_backward(const double (&col)[R], int k, int lane, double dinv, double& z1, double& z2) {
+  vif_sfor_down<0, R>([&](auto j_) {
+    constexpr int j = decltype(j_)::value;
+    if (j < k) {
+      const double t1 = z1 * dinv;
+      const double x1 = vif_readlane(t1, j);
+      z1 = lane < j ? __builtin_fma(-col[j], x1, z1) : (lane == j ? t1 : z1);
+      if constexpr (TWO) {
+        const double t2 = z2 * dinv;
+        const double x2 = vif_readlane(t2, j);
+        z2 = lane < j ? __builtin_fma(-col[j], x2, z2) : (lane == j ? t2 : z2);
+      }
+    }
+  });
+}
+// rows / columns of the factor kept in s_C (lower triangle) -> registers; lanes >= k: identity
+template <int R>
+__device__ __forceinline__ void vif_load_rows(const double* s_C, int ld, int k, int lane, double (&row)[R]) {
+  const int rl = min(lane, k);                                   // (keeps the address inside s_C for the idle lanes)
+  vif_sfor<0, R>([&](auto c_) {
+    constexpr int c = decltype(c_)::value;
+    const double v = (c < k) ? s_C[rl * ld + c] : 0.0;
+    row[c] = lane < k ? v : (c == lane ? 1.0 : 0.0);
+  });
+}
+template <int R>
+__device__ __forceinline__ void vif_load_cols(const double* s_C, int ld, int k, int lane, double (&col)[R]) {
+  const int cl = min(lane, k);
+  vif_sfor<0, R>([&](auto r_) {
+    constexpr int r = decltype(r_)::value;
+    const double v = (r < k) ? s_C[r * ld + cl] : 0.0;           // r < lane: above the diagonal, never used
+    col[r] = lane < k ? v : (r == lane ? 1.0 : 0.0);
+  });
+}
+// sum over the wavefront (fixed butterfly: every lane ends with the same total)
+__device__ __forceinline__ double vif_wave_sum(double v) {
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) v += __shfl_xor(v, w, 64);
+  return v;
+}
+
 // Common prefix of the factor and the derivative kernel of the residual process: one workgroup of T lanes per point -- T = 64, ONE wavefront, for
 // m <= 62 (every __syncthreads of the Cholesky / substitution chains is then a barrier of a single wavefront: the 128-lane form spent most of its
 // 16 ms at n = 1e5 in ~210 two-wavefront barriers per point), T = 128 beyond.  The whitened cross-covariances of the point and its neighbours pass
 // through LDS in chunks of kVifKC = 64 columns (round 4: 16 KB instead of 50 KB per workgroup at m = 30, k = 200 -> six workgroups per CU instead of
-// two); a chunk is staged with one lane per column and eight rows' loads in flight (the first form's element loop issued one dependent
+// two); a chunk is staged with one lane per column and sixteen rows' loads in flight (the first form's element loop issued one dependent
 // load -> store pair at a time: ~30 exposed memory latencies per chunk).  The Gram matrix G = V_S V_S' of the staged rows S accumulates across the
 // chunks
 //   NT > 0 (T = 64, NT = ceil((m + 1) / 16) <= 4): on the matrix cores -- 16 x 16 tiles (I >= J) of v_mfma_f64_16x16x4_f64, the A operand of tile
@@ -157,16 +250,19 @@ __global__ __launch_bounds__(256) void vif_gemm_kernel(const double* __restrict_
 // G[i][i]; s_c = c; s_C rows 0..k-1 = the lower factor; s_idx = the staged points (row k: the point itself).
 constexpr int kVifKC = 64;            // columns of V per staged chunk
 constexpr int kVifKCP = kVifKC + 1;   // LDS row stride of a chunk (odd: the rows start on different banks)
+constexpr int kVifStageRows = 16;     // rows of a chunk whose loads a lane keeps in flight
 typedef double vif_double4v __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int vif_staged_rows(int m, int nt) { return nt > 0 ? 16 * nt : m + 1; }
 template <int COV, int T, int NT>
 __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, const double* __restrict__ V, int kip, int kq, int ld, int i,
-                                               double* s_C, double* s_V, double* s_c, int* s_idx, double4& ctr, double4& own, double& gii) {
+                                               double* s_C, double* s_V, double* s_c, int* s_idx, double4* s_pts, double4& ctr, double4& own, double& gii,
+                                               double& dinv) {
   static_assert(NT == 0 || T == 64, "the MFMA Gram path is the one-wavefront form");
   const int m = args.m, tid = threadIdx.x;
   const int idx = tid < m ? args.nn[(size_t)i * m + tid] : -1;
-  const int k = __syncthreads_count(idx >= 0);           // the valid neighbours are a prefix of the row (short rows: i < m)
+  const int k = __builtin_amdgcn_readfirstlane(__syncthreads_count(idx >= 0));   // the valid neighbours are a prefix of the row (short rows: i < m)
   s_idx[tid] = tid < k ? idx : (tid == k ? i : -1);      // row k of the staged block is the point itself
+  dinv = 1.0;
   const int npair = (k + 1) * (k + 2) / 2;
   if constexpr (NT == 0) {
     for (int p = tid; p < npair; p += T) {               // zero the Gram accumulators (pair p -> (r, c <= r))
@@ -178,8 +274,7 @@ __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, co
   }
   __syncthreads();
   ctr = args.pts[i];
-  own = ctr;
-  if (tid < k) own = args.pts[idx];
+  own = args.pts[tid < k ? idx : i];                       // (an index select: a select between two double4 objects goes through the stack)
   constexpr int kAcc = NT > 0 ? NT * (NT + 1) / 2 : 1;
   vif_double4v acc[kAcc];
 #pragma unroll
@@ -189,15 +284,15 @@ __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, co
   const int rows_staged = NT > 0 ? 16 * NT : k + 1;      // NT > 0: the tiles' rows beyond k are written as zeros
   for (int c0 = 0; c0 < kip; c0 += kVifKC) {
     const int cw = min(kVifKC, kip - c0);
-    for (int r0 = 0; r0 * RP < rows_staged; r0 += 8) {
-      double v[8];
+    for (int r0 = 0; r0 * RP < rows_staged; r0 += kVifStageRows) {
+      double v[kVifStageRows];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kVifStageRows; ++j) {
         const int r = (r0 + j) * RP + rp;
         v[j] = (r <= k && cl < cw) ? V[(size_t)s_idx[r] * kq + c0 + cl] : 0.0;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kVifStageRows; ++j) {
         const int r = (r0 + j) * RP + rp;
         if (r < rows_staged) s_V[r * kVifKCP + cl] = v[j];
       }
@@ -245,6 +340,35 @@ __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, co
     __syncthreads();
   }
   gii = s_C[k * ld + k];
+  if constexpr (NT > 0) {
+    // C_nn row by row in registers (lane r = row r; the staged points come from LDS), factorised there, then the factor goes to s_C for the
+    // solves that need its columns (vif_load_cols) and for the derivative kernel
+    constexpr int R = 16 * NT;
+    s_pts[tid] = own;                                          // lanes >= k hold the point itself (row k of the staged block)
+    __syncthreads();
+    double row[R];
+    const int rl = min(tid, k);
+    vif_sfor<0, R>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      double v = 0.0;
+      if (c < k) {
+        const double g = s_C[rl * ld + c];
+        const double kv = matern_plain<COV>(dist4(own, s_pts[c]), args.var, args.a);
+        v = (c == tid ? args.diag_nn : kv) - g;               // diagonal: var + nugget - |V_a|^2
+      }
+      row[c] = tid < k ? v : (c == tid ? 1.0 : 0.0);
+    });
+    const double cv = tid < k ? matern_plain<COV>(dist4(own, ctr), args.var, args.a) - s_C[k * ld + rl] : 0.0;
+    s_c[tid] = cv;
+    vif_reg_cholesky<R>(row, k, tid, dinv);
+    __syncthreads();                                           // (every lane has read its Gram row)
+    vif_sfor<0, R>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      if (c < k && c <= tid && tid < k) s_C[tid * ld + c] = row[c];
+    });
+    __syncthreads();
+    return k;
+  }
   if (tid < k) {
     for (int q = 0; q < tid; ++q) s_C[tid * ld + q] = matern_plain<COV>(dist4(own, args.pts[s_idx[q]]), args.var, args.a) - s_C[tid * ld + q];
     s_c[tid] = matern_plain<COV>(dist4(own, ctr), args.var, args.a) - s_C[k * ld + tid];
@@ -301,10 +425,33 @@ __global__ __launch_bounds__(T) void vif_resid_factor_kernel(VecchiaKernelArgs a
   double* s_V = s_dyn + (size_t)(m + 1) * ld;            // [vif_staged_rows(m, NT)][kVifKCP]: one chunk of the whitened rows
   __shared__ double s_c[T], s_z1[T], s_z2[T], s_red[T];
   __shared__ int s_idx[T];
+  __shared__ double4 s_pts[NT > 0 ? T : 1];
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
-  double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV, T, NT>(args, V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  double4 ctr, own; double gii, dinv;
+  const int k = vif_point_setup<COV, T, NT>(args, V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, s_pts, ctr, own, gii, dinv);
+  if constexpr (NT > 0) {                                // the solves in registers (see vif_reg_cholesky)
+    constexpr int R = 16 * NT;
+    double reg[R];
+    vif_load_rows<R>(s_C, ld, k, tid, reg);
+    double z1 = tid < k ? s_c[tid] : 0.0, z2 = tid < k ? own.w : 0.0;
+    vif_reg_forward2<R>(reg, k, tid, dinv, z1, z2);      // L z1 = c, L z2 = y_nn
+    if (tid >= k) { z1 = 0.0; z2 = 0.0; }
+    const double Dv = args.diag_i - gii - vif_wave_sum(z1 * z1);      // D_i (Vecchia_utils.cpp:1463-1465, :1623)
+    const double uv = ctr.w - vif_wave_sum(z1 * z2);                  // u_i = (B y)_i
+    vif_load_cols<R>(s_C, ld, k, tid, reg);
+    double unused = 0.0;
+    vif_reg_backward<R, false>(reg, k, tid, dinv, z1, unused);        // L' A = z1
+    if (tid < m) args.A[(size_t)i * m + tid] = tid < k ? z1 : 0.0;
+    if (tid == 0) {
+      args.D[i] = Dv; args.u[i] = uv;
+      const size_t nb = gridDim.x;
+      args.partials[(size_t)GPB_P_LOGDET * nb + blockIdx.x] = log(Dv);
+      args.partials[(size_t)GPB_P_QUAD * nb + blockIdx.x] = uv * uv / Dv;
+      args.partials[(size_t)GPB_P_BAD * nb + blockIdx.x] = (Dv > 0.0) ? 0.0 : 1.0;
+    }
+    return;
+  }
   s_z1[tid] = tid < k ? s_c[tid] : 0.0;
   s_z2[tid] = tid < k ? own.w : 0.0;
   __syncthreads();
@@ -498,10 +645,11 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
   __shared__ double s_pk2[4][T];
   __shared__ double s_self[4];
   __shared__ int s_idx[T];
+  __shared__ double4 s_pts[NT > 0 ? T : 1];
   const int tid = threadIdx.x;
   const int i = args.i_begin + blockIdx.x;
-  double4 ctr, own; double gii;
-  const int k = vif_point_setup<COV, T, NT>(args, g.V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, ctr, own, gii);
+  double4 ctr, own; double gii, dinv;
+  const int k = vif_point_setup<COV, T, NT>(args, g.V, kip, kq, ld, i, s_C, s_V, s_c, s_idx, s_pts, ctr, own, gii, dinv);
   // Atilde = (A_i, -1)
   s_at[tid] = tid < k ? args.A[(size_t)i * m + tid] : (tid == k ? -1.0 : 0.0);
   // the point's k-vectors (after the set-up the staged rows of V are dead): X1_i, V1_i, X2r_i, Hm_i, w
@@ -518,9 +666,9 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
     const int a = tid / lpr, sub = tid - a * lpr;
     double sk = 0.0, sd = 0.0;
     if (a < rows) {
-      const double4 pa = args.pts[s_idx[a]];              // s_idx[k] = i: row k is the point itself
+      const double4 pa = NT > 0 ? s_pts[a] : args.pts[s_idx[a]];      // row k is the point itself (s_idx[k] = i, s_pts[k] = the point)
       for (int b = sub; b < rows; b += lpr) {
-        const double4 pb = args.pts[s_idx[b]];
+        const double4 pb = NT > 0 ? s_pts[b] : args.pts[s_idx[b]];
         double kv, dk;
         matern_with_grad<COV>(dist4(pa, pb), args.var, args.a, kv, dk);
         const double at = s_at[b];
@@ -536,13 +684,24 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
     const bool live = a < rows;
     const size_t src = (size_t)s_idx[live ? a : 0] * kq;
     double t0 = 0.0, t1 = 0.0, tg = 0.0;
-    if (live)
-      for (int c = lane; c < kip; c += 16) {
-        const double cv = g.C[src + c], dv = g.dC[src + c];
-        t0 = __builtin_fma(cv, s_v1[c], t0);
-        t1 = __builtin_fma(dv, s_x1[c], __builtin_fma(cv, s_x2[c], t1));
-        tg = __builtin_fma(cv, s_hm[c], tg);
+    for (int c0 = lane; c0 < kip; c0 += 64) {            // four columns per lane with their eight loads in flight (same order of the fma chains)
+      double cv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        const bool ok = live && c < kip;
+        cv[u] = ok ? g.C[src + c] : 0.0; dv[u] = ok ? g.dC[src + c] : 0.0;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        if (c < kip) {
+          t0 = __builtin_fma(cv[u], s_v1[c], t0);
+          t1 = __builtin_fma(dv[u], s_x1[c], __builtin_fma(cv[u], s_x2[c], t1));
+          tg = __builtin_fma(cv[u], s_hm[c], tg);
+        }
+      }
+    }
     t0 = sum16(t0); t1 = sum16(t1); tg = sum16(tg);
     if (live && lane == 0) {
       double k0 = 0.0, k1 = 0.0;
@@ -553,10 +712,21 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
   // the point's own row-wise dot products: kappa = Q_i . Hm_i, (B dC)_i . Hm_i, Q_i . w, (B dC)_i . w   (first 16 lanes)
   if (tid < 16) {
     double q_hm = 0.0, d_hm = 0.0, q_w = 0.0, d_w = 0.0;
-    for (int c = tid; c < kip; c += 16) {
-      const double qv = g.Q[(size_t)i * kq + c], dv = g.QdC[(size_t)i * kq + c];
-      q_hm = __builtin_fma(qv, s_hm[c], q_hm); d_hm = __builtin_fma(dv, s_hm[c], d_hm);
-      q_w = __builtin_fma(qv, s_w[c], q_w); d_w = __builtin_fma(dv, s_w[c], d_w);
+    for (int c0 = tid; c0 < kip; c0 += 64) {
+      double qv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        qv[u] = c < kip ? g.Q[(size_t)i * kq + c] : 0.0; dv[u] = c < kip ? g.QdC[(size_t)i * kq + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        if (c < kip) {
+          q_hm = __builtin_fma(qv[u], s_hm[c], q_hm); d_hm = __builtin_fma(dv[u], s_hm[c], d_hm);
+          q_w = __builtin_fma(qv[u], s_w[c], q_w); d_w = __builtin_fma(dv[u], s_w[c], d_w);
+        }
+      }
     }
     q_hm = sum16(q_hm); d_hm = sum16(d_hm); q_w = sum16(q_w); d_w = sum16(d_w);
     if (tid == 0) { s_self[0] = q_hm; s_self[1] = d_hm; s_self[2] = q_w; s_self[3] = d_w; }
@@ -567,11 +737,23 @@ __global__ __launch_bounds__(T) void vif_resid_grad_kernel(VecchiaKernelArgs arg
   const double h0_own = tid < k ? s_h0[tid] : 0.0, h1_own = tid < k ? s_h1[tid] : 0.0;
   const double g_own = tid < k ? s_g[tid] : 0.0;
   const double z_own = tid < k ? g.z[s_idx[tid]] : 0.0;
-  __syncthreads();
-  if (tid >= k) { s_h0[tid] = 0.0; s_h1[tid] = 0.0; }
-  __syncthreads();
-  vif_chol_solve2(s_C, ld, k, s_h0, s_h1);               // x^p = C_nn^-1 h^p[nn]
-  const double x0 = tid < k ? s_h0[tid] : 0.0, x1 = tid < k ? s_h1[tid] : 0.0;
+  double x0, x1;                                          // x^p = C_nn^-1 h^p[nn]
+  if constexpr (NT > 0) {
+    constexpr int R = 16 * NT;
+    double reg[R];
+    vif_load_rows<R>(s_C, ld, k, tid, reg);
+    x0 = h0_own; x1 = h1_own;
+    vif_reg_forward2<R>(reg, k, tid, dinv, x0, x1);
+    vif_load_cols<R>(s_C, ld, k, tid, reg);
+    vif_reg_backward<R, true>(reg, k, tid, dinv, x0, x1);
+    if (tid >= k) { x0 = 0.0; x1 = 0.0; }
+  } else {
+    __syncthreads();
+    if (tid >= k) { s_h0[tid] = 0.0; s_h1[tid] = 0.0; }
+    __syncthreads();
+    vif_chol_solve2(s_C, ld, k, s_h0, s_h1);
+    x0 = tid < k ? s_h0[tid] : 0.0; x1 = tid < k ? s_h1[tid] : 0.0;
+  }
   if (g.dA0 && tid < m) { g.dA0[(size_t)i * m + tid] = -x0; g.dA1[(size_t)i * m + tid] = -x1; }
   // six sums over the neighbours in one tree: A . h^p, x^p . z_nn, x^p . g   (s_pk / s_pk2 are dead by now)
   __syncthreads();
