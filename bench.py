@@ -376,7 +376,7 @@ def main():
             "roofline_fp64_valu": {"bound": "fp64 vector ALU issue (no MFMA in this kernel)", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_tflops,
                                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS, "kernel_ms": ms_kernel,
                                    "algorithmic_flops_per_launch": flops_launch,
-                                   "note": "exp / sqrt / division counted as ONE flop each (SURVEY.md 8d); instruction mix: profiles/r02_*_instruction_mix.txt"},
+                                   "note": "exp / sqrt / division counted as ONE flop each (SURVEY.md 8d); instruction mix: profiles/r04_point_kernel_instruction_mix.txt"},
         }
         if world == 1:
             # the one HBM-bound kernel of the path: dense covariance assembly (exact GP), measured live
@@ -469,8 +469,15 @@ def main():
                         "bound": "hbm", "kernel": "lap_tri_spmv_kernel x2 + triangular solves (dense block of the ~270 narrow levels: lap_dense_matvec_kernel, 268 MB at ~5.6 TB/s; lap_sptrsv_sf_kernel: ONE barrier-free launch per solve for the ~118 wide levels each way) + cg_* vector kernels",
                         "algorithmic_bytes_per_iteration": byt, "ms_per_iteration": ms, "achieved": byt / (ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "note": "latency-bound, not bandwidth-bound: the two triangular solves are dependency chains of ~118 levels; round 3 replaced ~240 launches of 5-8 us per iteration by two barrier-free launches (0.28 + 0.42 ms: one visibility round trip per level, DESIGN.md 4.6); algorithmic bytes do not count the dense inverse blocks (2 x 268 MB per iteration), which replace ~540 dependent level steps"})(
+                        "note": "latency-bound, not bandwidth-bound: the two triangular solves are dependency chains of ~118 levels, one visibility round trip (~2.4 us) per level whatever the level's size (DESIGN.md 4.6: the floor of this formulation is ~0.33 s per evaluation); algorithmic bytes do not count the dense inverse blocks (2 x 268 MB per iteration), which replace ~540 dependent level steps"})(
                         4 * n4 * (30 * 16 + 16) + 10 * n4 * 8, i4["ms_mode"] / max(i4["cg_it"], 1)),
+                    # one Lanczos / block-CG iteration of the log-determinant: the factor streamed four times for ALL 50 probe vectors (13 chunks of four
+                    # columns share every entry load) + ~10 n-vectors per probe
+                    "roofline_logdet_iteration": (lambda byt, ms: {
+                        "bound": "hbm", "kernel": "lap_sptrsv_sfw_kernel x2 (round 4: the 50-probe block barrier-free, one launch per solve, one wavefront per (row, unit of four chunks)) + lap_dense_gemm4_kernel x2 + lap_tri_spmv_kernel<.,4> x2 + cg_* block kernels",
+                        "algorithmic_bytes_per_iteration": byt, "ms_per_iteration": ms, "achieved": byt / (ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})(
+                        4 * n4 * (30 * 16 + 16) + 10 * n4 * 8 * 52, i4["ms_logdet"] / max(i4["lanczos_it"], 1)),
                     "reference_timing": "not timed here: tests/golden/config4_ref.npz holds the unmodified reference's value and its wall time for the same-size fixture (seconds_0; 8 cores of the build container)"}
                 del m4
             except Exception as e:
@@ -490,9 +497,14 @@ def main():
                 for kv in range(3):
                     vv = mv.neg_log_likelihood(np.array([0.1, 1.0 + 0.01 * (kv + 1), 0.1]))
                 sv = (time.perf_counter() - tv1) / 3
+                mv.neg_log_likelihood_and_gradient(np.array([0.1, 1.0, 0.1]), yv)
+                tv2 = time.perf_counter()
+                for kv in range(3):
+                    mv.neg_log_likelihood_and_gradient(np.array([0.1, 1.0 + 0.01 * (kv + 1), 0.1]), yv)
+                sgv = (time.perf_counter() - tv2) / 3
                 out["vif_full_scale_vecchia"] = {
-                    "workload": "Gaussian nll, gp_approx=full_scale_vecchia, n=%d, d=2, exponential, m=30, 200 inducing points (kmeans++ on the host)" % nv,
-                    "s_per_eval": sv, "negll": vv, "setup_s_incl_host_kmeans_and_device_neighbor_search": round(tv_setup, 3),
+                    "workload": "Gaussian nll, gp_approx=full_scale_vecchia, n=%d, d=2, exponential, m=30, 200 inducing points (kmeans++ start on the host, Lloyd iterations on the device)" % nv,
+                    "s_per_eval": sv, "s_per_eval_with_analytic_gradient": sgv, "negll": vv, "setup_s_incl_kmeans_and_device_neighbor_search": round(tv_setup, 3),
                     "reference_timing": "tests/golden/vif_ref.npz was generated by the unmodified reference at this size: 1.8 s per evaluation on 8 threads of the build container (oracle/make_golden.py vif)"}
                 del mv
             except Exception as e:

@@ -2355,7 +2355,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
 // Tree grower: histogram of the SMALLER child of the split whose left counts the partition kernels have left in h->d_counts -- enqueued
 // without a host round trip; ub_rows = upper bound of the child's rows on this rank (sizes the launch), result in d_target.
 static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_begin, int seg_cnt, int seg_gcnt, int min_data_in_leaf, int ub_rows,
-                              double const_hess, double* d_target) {
+                              double const_hess, double* d_target, int* nchunks_without_reduce = nullptr) {
   const int groups = h->fpad / GPB_HIST_FG;
   if (h->num_cu <= 0) { HIP_OK(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, h->device)); if (h->num_cu <= 0) h->num_cu = 256; }
   const int chunk_mult = h->has_hess ? 2 : 4;
@@ -2385,6 +2385,9 @@ static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_b
     r.limbs_out = h->d_limbs;
   }
   HIP_OK(gpb::launch_hist_build(a, h->stream));
+  // few chunks (leaves below ~8000 rows: most splits of a tree): the children's search sums them itself, one launch and one kernel boundary less per
+  // split; with many chunks the dedicated reduction (16 slices per word) is faster than the search workgroups' serial sums (measured: 36 us for 49 chunks)
+  if (nchunks_without_reduce && !h->comm.active() && nchunks <= 8) { *nchunks_without_reduce = nchunks; return 0; }
   HIP_OK(gpb::launch_hist_reduce(r, h->stream));
   if (h->comm.active() && hist_finish_sharded(h, const_hess, d_target, nullptr)) return -1;
   return 0;

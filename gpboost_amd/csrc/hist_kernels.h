@@ -43,6 +43,12 @@ struct ChildrenSearchArgs {
   double left_output = 0.0, right_output = 0.0;                                          // outputs of the parent's split = parent_output of the children
   double* out10;            // [2][F][10]: candidates of the smaller, then of the larger child
   int* out_flags;           // [2][F + 1]
+  // chunk partials of the smaller child's build (hist_build_kernel's layout): when part_grad != nullptr the workgroups sum the chunks of THEIR feature
+  // themselves (integer totals, converted as hist_reduce_kernel does: the same bits) and workgroup (f, 0) writes the entries to `smaller` -- no
+  // reduce launch between build and search (round 4)
+  const long long* part_grad = nullptr; const long long* part_hess = nullptr; const uint32_t* part_cnt = nullptr;
+  const unsigned long long* grad_max_bits = nullptr; const unsigned long long* hess_max_bits = nullptr;
+  int fpad = 0, nchunks = 0, has_hess = 0; double const_hess = 1.0;
   unsigned* ticket = nullptr;   // device word, zero between launches: workgroups that have finished
   int* host_seq = nullptr;      // pinned host word: receives seq from the last workgroup (nullptr: the host synchronises the stream instead)
   int seq = 0;

@@ -632,7 +632,7 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
                                    const int* __restrict__ num_bin, const int* __restrict__ meta3 /* offset, default_bin, missing */,
                                    double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2, int min_data_in_leaf,
                                    double min_sum_hessian, double min_gain_to_split, SplitReg reg, double* __restrict__ out10,
-                                   int* __restrict__ out_default_left) {
+                                   int* __restrict__ out_default_left, const double* data_in = nullptr /* the feature's view, if not hist + view_offset */) {
 #pragma clang fp contract(off)
   __shared__ double s_x[GPB_HIST_MAX_BIN + 1][4];           // per entry: gradient sum, hessian sum, rounded count (as a double), pad
   __shared__ double s_o[2][kSplitSteps][4];                 // per direction and step: the three running sums
@@ -642,7 +642,7 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
   __shared__ int s_brk[2];                                 // first break of the reverse (max t) / forward (min t) scan
   const int tid = threadIdx.x;
   const double kEps = (double)1e-15f;                      // include/LightGBM/meta.h:54
-  const double* data = hist + (size_t)view_offset[f] * 2;
+  const double* data = data_in ? data_in : hist + (size_t)view_offset[f] * 2;
   const int nb = num_bin[f], offset = meta3[3 * f], default_bin = meta3[3 * f + 1], missing = meta3[3 * f + 2];
   const double sum_hessian = sum_hessian_leaf + 2 * kEps;
   const RegPath rp{ reg.lambda_l1, lambda_l2, reg.max_delta_step, reg.path_smooth, reg.parent_output, reg.lambda_l1 > 0.0, reg.max_delta_step > 0.0,
@@ -807,8 +807,35 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
   const SplitReg reg_l{ a.lambda_l1, a.max_delta_step, a.path_smooth, cs.smaller_is_left ? a.right_output : a.left_output };
   const int mfb = a.most_freq_bin[f];
   __shared__ double s_fix[2];
+  // the smaller child's entries of THIS feature, local: from the build's chunk partials (summed here, see ChildrenSearchArgs) or from its slot
+  __shared__ double s_sm[2 * (GPB_HIST_MAX_BIN + 1)];
+  const int bo = a.bin_offsets[f], nbin_f = a.bin_offsets[f + 1] - bo;
+  if (a.part_grad) {
+    constexpr int kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG;
+    const size_t stride = (size_t)(a.fpad / GPB_HIST_FG) * kWords;
+    for (int b = tid; b < nbin_f; b += 256) {
+      Limbs g, h;
+      unsigned long long c = 0;
+      size_t p = (size_t)(f / GPB_HIST_FG) * kWords + (size_t)b * GPB_HIST_FG + (f % GPB_HIST_FG);
+      for (int ch = 0; ch < a.nchunks; ++ch, p += stride) {
+        g.add(a.part_grad[p]); c += a.part_cnt[p];
+        if (a.has_hess) h.add(a.part_hess[p]);
+      }
+      if (a.has_hess) hist_convert_entry<true>(g, h, c, a.grad_max_bits, a.hess_max_bits, a.const_hess, s_sm + 2 * b, nullptr);
+      else hist_convert_entry<false>(g, h, c, a.grad_max_bits, a.hess_max_bits, a.const_hess, s_sm + 2 * b, nullptr);
+      if (child == 0) { a.smaller[2 * ((size_t)bo + b)] = s_sm[2 * b]; a.smaller[2 * ((size_t)bo + b) + 1] = s_sm[2 * b + 1]; }
+    }
+  } else {
+    for (int e = tid; e < 2 * nbin_f; e += 256) s_sm[e] = a.smaller[2 * (size_t)bo + e];
+  }
+  __syncthreads();
+  // the feature's view (FeatureHistogram::data_) inside its own entries: num_bin entries from view_offset when most_freq_bin > 0, one fewer
+  // otherwise (offset = 1).  The tree grower hands over chunk partials only when this holds for every feature; a view that reaches outside is read
+  // from the slot as before
+  const int vrel = 2 * (a.view_offset[f] - bo);
+  const bool local_view = a.part_grad != nullptr || (vrel >= 0 && vrel / 2 + a.num_bin[f] - (mfb == 0 ? 1 : 0) <= nbin_f);
   if (tid == 0 && mfb > 0) {                    // the same subtraction order as the reference's loop
-    const double* v = a.smaller + (size_t)a.view_offset[f] * 2;
+    const double* v = local_view ? s_sm + vrel : a.smaller + (size_t)a.view_offset[f] * 2;
     double g = sg_s, hh = sh_s;
     const int nb = a.num_bin[f];
     for (int i = 0; i < nb; ++i) if (i != mfb) { g -= v[2 * i]; hh -= v[2 * i + 1]; }
@@ -817,14 +844,17 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
   __syncthreads();
   const size_t fix_at = mfb > 0 ? 2 * ((size_t)a.view_offset[f] + mfb) : (size_t)-1;     // index of the fixed entry in the flat histogram
   if (child == 0) {
-    if (tid == 0 && mfb > 0) { a.smaller[fix_at] = s_fix[0]; a.smaller[fix_at + 1] = s_fix[1]; }
+    if (tid == 0 && mfb > 0) {
+      a.smaller[fix_at] = s_fix[0]; a.smaller[fix_at + 1] = s_fix[1];
+      if (local_view) { s_sm[vrel + 2 * mfb] = s_fix[0]; s_sm[vrel + 2 * mfb + 1] = s_fix[1]; }
+    }
     __threadfence_block();
     __syncthreads();
     best_split_feature(a.smaller, f, a.view_offset, a.num_bin, a.meta3, sg_s, sh_s, n_s, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
-                       a.min_gain_to_split, reg_s, a.out10, a.out_flags);
+                       a.min_gain_to_split, reg_s, a.out10, a.out_flags, local_view ? s_sm + vrel : nullptr);
   } else {
-    for (size_t i = 2 * (size_t)a.bin_offsets[f] + tid; i < 2 * (size_t)a.bin_offsets[f + 1]; i += 256) {
-      const double sm = (i == fix_at || i == fix_at + 1) ? s_fix[i - fix_at] : a.smaller[i];
+    for (size_t i = 2 * (size_t)bo + tid; i < 2 * (size_t)a.bin_offsets[f + 1]; i += 256) {
+      const double sm = (i == fix_at || i == fix_at + 1) ? s_fix[i - fix_at] : s_sm[i - 2 * (size_t)bo];
       a.parent[i] = a.parent[i] - sm;
     }
     __threadfence_block();

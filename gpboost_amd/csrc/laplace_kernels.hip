@@ -1513,7 +1513,7 @@ static hipError_t lap_trsv_syncfree(const LapTri& T, const int* host_ptr, const 
   return hipGetLastError();
 }
 // probe block (nc == 4), barrier-free, one wavefront per (row, column unit of 4 J chunks): one launch (+ the sentinel prefill) per triangular solve.
-// J = chunks per 16-lane group: 1 (J = 2 measured 5 % slower, J = 4 cannot keep its grid resident; profiles/r04_c_laplace_block_sweep.txt).
+// J = chunks per 16-lane group: 1 (J = 2 measured 5 % slower, J = 4 cannot keep its grid resident; profiles/r04_c_laplace_block_solve_v3_sweep.log).
 template <bool SCALE, int J>
 static hipError_t lap_trsv_syncfree_block_j(const LapTri& T, int n, int qa, int qb, const double* rhs, const double* rdw, double* x, int ncol, int* err,
                                             hipStream_t st) {
@@ -1539,7 +1539,7 @@ static hipError_t lap_trsv_syncfree_block(const LapTri& T, const int* host_ptr, 
   if (nseg <= 0) return hipSuccess;
   const int qa = host_ptr[seg[0].L0], qb = host_ptr[seg[nseg - 1].L1];
   if (qb <= qa) return hipSuccess;
-  return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, st);   // J = 1: measured best (profiles/r04_c_laplace_block_sweep.txt)
+  return lap_trsv_syncfree_block_j<SCALE, 1>(T, n, qa, qb, rhs, rdw, x, ncol, err, st);   // J = 1: measured best (profiles/r04_c_laplace_block_solve_v3_sweep.log)
 }
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st) {
   if (nc == 4 && (lv.syncfree & 4)) {                          // bit 2: the probe block, one wavefront per row over all chunks (round 4)
