@@ -551,7 +551,11 @@ __global__ void hist_fix_kernel(double* __restrict__ hist, int num_features, con
   double* v = hist + (size_t)view_offset[f] * 2;
   double g = sum_gradient, h = sum_hessian;
   const int nb = num_bin[f];
-  for (int i = 0; i < nb; ++i) if (i != mfb) { g -= v[2 * i]; h -= v[2 * i + 1]; }
+#pragma unroll 8
+  for (int i = 0; i < nb; ++i) {                      // branch-free (x - 0.0 == x): eight steps' loads in flight
+    const double vg = v[2 * i], vh = v[2 * i + 1];
+    g -= (i != mfb) ? vg : 0.0; h -= (i != mfb) ? vh : 0.0;
+  }
   v[2 * mfb] = g; v[2 * mfb + 1] = h;
 }
 __global__ void hist_subtract_kernel(const double* __restrict__ parent, const double* __restrict__ smaller, double* __restrict__ out, int len) {
@@ -838,7 +842,12 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
     const double* v = local_view ? s_sm + vrel : a.smaller + (size_t)a.view_offset[f] * 2;
     double g = sg_s, hh = sh_s;
     const int nb = a.num_bin[f];
-    for (int i = 0; i < nb; ++i) if (i != mfb) { g -= v[2 * i]; hh -= v[2 * i + 1]; }
+    // branch-free so that the reads of eight steps are in flight while the two subtraction chains run: x - 0.0 == x, the skipped entry changes nothing
+#pragma unroll 8
+    for (int i = 0; i < nb; ++i) {
+      const double vg = v[2 * i], vh = v[2 * i + 1];
+      g -= (i != mfb) ? vg : 0.0; hh -= (i != mfb) ? vh : 0.0;
+    }
     s_fix[0] = g; s_fix[1] = hh;
   }
   __syncthreads();

@@ -90,7 +90,9 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_beg
  * 8 MB upload from pinned memory takes about half the time of one from pageable memory). */
 GPB_HIP_EXPORT int gpb_hip_pinned_alloc(size_t bytes, void** out);
 GPB_HIP_EXPORT int gpb_hip_pinned_free(void* p);
-/* y in Vecchia order (REModelTemplate::SetY, include/GPBoost/re_model_template.h:6185-6222). */
+/* y in Vecchia order (REModelTemplate::SetY, include/GPBoost/re_model_template.h:6185-6222).  A factor computed by gpb_hip_vecchia_factor stays
+ * valid (A, D do not depend on y); u = B y is renewed for the new response at its next use (y_aux, get_factor) -- the GPBoost algorithm sets a new
+ * response every boosting iteration at unchanged parameters (CalcGradientF, :3313-3316).  The full-scale (VIF) factor carries the response: it goes. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev);
 
@@ -237,7 +239,7 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov_type, do
 GPB_HIP_EXPORT int gpb_hip_vecchia_get_factor(gpb_hip_vecchia_t* h, double* A_host, double* D_host, double* u_host);
 
 /* y_aux = B^T D^-1 B y (CalcYAux, include/GPBoost/re_model_template.h:9771-9773), Vecchia order.
- * Requires gpb_hip_vecchia_factor() with the current y. */
+ * Requires gpb_hip_vecchia_factor() at the current parameters; the response may have been replaced since (see gpb_hip_vecchia_set_y). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_yaux(gpb_hip_vecchia_t* h, double* yaux_host);
 /* diag(Psi^-1) = diag(B^T D^-1 B) (transformed scale, Vecchia order) from the stored factor: the predictive variances of the training-data
  * random effects are sigma2 (1 - diag) (PredictTrainingDataRandomEffects with calc_var, include/GPBoost/re_model_template.h:4508-4514). */
