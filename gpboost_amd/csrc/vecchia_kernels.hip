@@ -129,6 +129,9 @@ __device__ __forceinline__ void vecchia_finish(const VecchiaKernelArgs& args, in
 // MODE_NLL    : partial sums {sum log D, sum u^2/D, #(D<=0)} only
 // MODE_FACTOR : additionally A[n][m], D[n], u[n] to HBM
 // MODE_GRAD   : partial sums for the nll terms and the two parameter gradients
+// 30 < MT <= 40, solving modes: TWO workgroups per CU, i.e. a 256-VGPR cap with 60 - 89 values in scratch.  Round 4 measured the alternative the
+// spills suggest -- one workgroup per CU, 316 registers (60 of them AGPRs), no scratch, no DPP hazards: 6.30 ms against 5.40 ms per gradient launch at
+// n = 1e6, d = 3, Matern-2.5, m = 40 (profiles/r04_j_grad_m40_one_workgroup_per_cu_ab.txt): the second wavefront per SIMD hides more than the spills cost.
 template <int MT, int COV, bool D3, int MODE>
 __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 : 1) void vecchia_point_kernel(VecchiaKernelArgs args) {
   using L = Layout<MT>;
