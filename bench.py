@@ -221,6 +221,28 @@ def main():
                 if mok:
                     st.mailbox_detach()
                 mok = 0
+            if mok:
+                # one evaluation through the mailbox, checked before anything is timed: the job's sums must equal the ranks' shard sums added in rank
+                # order (all-gathered over torch) bit for bit -- the mailbox adds them in exactly that order.  Any rank that fails (a time-out of the
+                # bounded poll included) sends every rank back to ncclAllReduce for the sums.
+                try:
+                    got = np.asarray(st.nll_terms_allreduce(ct, var0, a0))[:3]
+                    loc = torch.tensor(np.asarray(st.nll_terms(ct, var0, a0))[:3], dtype=torch.float64, device="cuda")
+                    parts = [torch.zeros(3, dtype=torch.float64, device="cuda") for _ in range(world)]
+                    dist.all_gather(parts, loc)
+                    want = np.zeros(3)
+                    for pr in parts:
+                        want = want + pr.cpu().numpy()
+                    if not np.array_equal(got, want):
+                        raise RuntimeError("mailbox sums %r differ from the rank-ordered sums %r" % (got.tolist(), want.tolist()))
+                except Exception as e:   # noqa: BLE001
+                    print("rank %d: mailbox check failed (%s); the sums go through ncclAllReduce" % (rank, e), file=sys.stderr)
+                    mok = 0
+                mkt = torch.tensor([mok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(mkt, op=dist.ReduceOp.MIN)
+                if mkt.item() != 1:
+                    st.mailbox_detach()
+                    mok = 0
         use_mailbox = bool(mok)
         # Under a multi-rank launch a silent fallback would report a number for a path that is not the product's: fail loudly instead
         # (GPB_BENCH_TORCH_ALLREDUCE=1 asks for the torch fallback explicitly).

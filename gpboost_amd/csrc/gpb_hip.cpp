@@ -960,7 +960,7 @@ static int vecchia_mailbox_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, d
     if ((spin & 1023u) == 1023u) {
       const auto dt = std::chrono::steady_clock::now() - t0;
       if (!own_synced && dt > std::chrono::milliseconds(50)) { HIP_OK(hipStreamSynchronize(h->stream)); own_synced = true; }   // (surfaces a launch error of this rank)
-      if (dt > std::chrono::seconds(120)) return fail("mailbox: the sums of all %d ranks did not arrive within 120 s (evaluation %llu)", mb.world, e);
+      if (dt > std::chrono::seconds(30)) return fail("mailbox: the sums of all %d ranks did not arrive within 30 s (evaluation %llu)", mb.world, e);
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
