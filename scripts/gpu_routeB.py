@@ -34,7 +34,7 @@ if TEST:
     GP_CASES = ((20000, 30, 2), (5000, 70, 5))
 if MOCK:
     GP_CASES = ((1500, 12, 2),)
-if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
+if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv or "--laplace-only" in sys.argv:
     GP_CASES = ()
 for n, m, d in GP_CASES:
     coords, _ = cases.synthetic(n, d, seed=3)
@@ -68,9 +68,77 @@ for n, m, d in GP_CASES:
     np.testing.assert_allclose(b["var"], a["var"], rtol=1e-6, atol=1e-8)
     print("n=%d: GPU_use=true reproduces the CPU path of the same build; likelihood evaluation %.1fx, fit %.1fx faster" % (n, a["t_eval"] / b["t_eval"], a["t_fit"] / b["t_fit"]), flush=True)
 
+# ---- (1c) non-Gaussian likelihoods through the Laplace seams (round 4): Likelihood::FindModePostRandEffCalcMLLVecchia, its gradient and
+#      ResetModeToPreviousValue call gpb_hip_vecchia_laplace_eval / _grad_current / _reset_mode_to_previous when the model is one Vecchia GP with
+#      matrix_inversion_method = "iterative" and the "vadu" preconditioner -- GPU_use = true against GPU_use = false of the same build -------------
+# The reference's own iterative CPU path is slow (n = 20000: 112 s per evaluation, 1063 s per fit on the GPU box's 256 threads, profiles/r04_l_*): its values
+# are computed ONCE (--make-laplace-ref, CPU only, GPU_use = false of the same build) and kept in tests/golden/routeB_laplace_ref.json; the GPU run compares
+# GPU_use = true against them.  The CPU-mock test runs both legs at n = 800.
+import json  # noqa: E402
+LAP_REF_PATH = os.path.join(ROOT, "tests", "golden", "routeB_laplace_ref.json")
+LAP_REF = json.load(open(LAP_REF_PATH)) if os.path.exists(LAP_REF_PATH) else {}
+MAKE_LAP_REF = "--make-laplace-ref" in sys.argv
+LAP_CASES = ((800, 10, ("bernoulli_logit",)),) if MOCK else (((5000, 20, ("bernoulli_logit", "poisson")),) if (TEST or MAKE_LAP_REF) else ((5000, 20, ("bernoulli_logit", "poisson")), (20000, 30, ("bernoulli_logit",)), (100000, 30, ("bernoulli_logit",))))
+if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
+    LAP_CASES = ()
+for n, m, liks in LAP_CASES:
+    rng = np.random.default_rng(21)
+    coords = rng.uniform(size=(n, 2))
+    eta = np.sin(4 * coords[:, 0]) + np.cos(3 * coords[:, 1])
+    for lik in liks:
+        if lik == "poisson":
+            yl = rng.poisson(np.exp(0.5 * eta)).astype(np.float64)
+        else:
+            yl = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-1.5 * eta))).astype(np.float64)
+        cp = np.array([1.0, 0.1])
+        key = "%s_n%d_m%d" % (lik, n, m)
+        res = {}
+        legs = (False,) if MAKE_LAP_REF else ((False, True) if MOCK else (True,))
+        for gpu in legs:
+            mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, likelihood=lik, lib_path=LIBP, gpu_use=gpu,
+                                      matrix_inversion_method="iterative")
+            mdl.set_optim_config(init_cov_pars=cp, optimizer_cov="lbfgs", cg_delta_conv=1e-6)
+            t0 = time.perf_counter()
+            nll0 = mdl.neg_log_likelihood(cp, yl)
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nll1 = mdl.neg_log_likelihood(cp * np.array([1.1, 0.9]), yl)
+            t_eval = time.perf_counter() - t0
+            out = dict(nll0=nll0, nll1=nll1, t_first=t_first, t_eval=t_eval)
+            if n <= 20000:
+                t0 = time.perf_counter()
+                mdl.optim_cov_par(yl)
+                out.update(t_fit=time.perf_counter() - t0, cov=[float(v) for v in mdl.get_cov_par(2)], it=int(mdl.get_num_it()), negll_fit=mdl.current_neg_log_likelihood())
+            res[gpu] = out
+            print("Laplace %s n=%d GPU_use=%s: nll %.10f / %.10f, evaluation %.3f s%s" % (
+                lik, n, gpu, nll0, nll1, t_eval, "" if "cov" not in out else "; fit: %d iterations, cov pars %s, negll %.8f, %.2f s" % (out["it"], out["cov"], out["negll_fit"], out["t_fit"])), flush=True)
+            del mdl
+        if MAKE_LAP_REF:
+            LAP_REF[key] = res[False]
+            json.dump(LAP_REF, open(LAP_REF_PATH, "w"), indent=1, sort_keys=True)
+            continue
+        a = res[False] if False in res else LAP_REF.get(key)
+        b = res[True]
+        if a is None:
+            print("Laplace %s n=%d: GPU_use=true evaluation %.3f s (no stored CPU values at this size: the reference's CPU path takes minutes per evaluation)" % (lik, n, b["t_eval"]), flush=True)
+            continue
+        assert abs(a["nll0"] - b["nll0"]) <= 1e-7 * abs(a["nll0"]), (a["nll0"], b["nll0"])
+        assert abs(a["nll1"] - b["nll1"]) <= 1e-7 * abs(a["nll1"]), (a["nll1"], b["nll1"])
+        msg = "evaluation %.1fx" % (a["t_eval"] / b["t_eval"])
+        if "cov" in a and "cov" in b:
+            np.testing.assert_allclose(b["cov"], a["cov"], rtol=1e-3)
+            assert abs(a["negll_fit"] - b["negll_fit"]) <= 1e-6 * abs(a["negll_fit"]), (a["negll_fit"], b["negll_fit"])
+            msg += ", fit %.1fx (%d / %d iterations)" % (a["t_fit"] / b["t_fit"], a["it"], b["it"])
+        print("Laplace %s n=%d: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build%s; %s faster" % (
+            lik, n, "" if False in res else " (its values: tests/golden/routeB_laplace_ref.json)", msg), flush=True)
+if MAKE_LAP_REF:
+    sys.exit(0)
+
 # ---- (1b) GPBoost iterations through the round-4 seams: device neighbour search at model creation, y_aux = Psi^-1 (F - y) from the resident
 #      factor (CalcYAux), Newton leaf values (NewtonUpdateLeafValues) -- GPU_use = true against GPU_use = false of the same build -------------
 GPB_CASES = ((20000, 20, 3),) if TEST else ((100000, 50, 5), (1000000, 50, 2))
+if "--laplace-only" in sys.argv:
+    GPB_CASES = ()
 if MOCK:
     GPB_CASES = ((int(os.environ.get("GPB_ROUTEB_MOCK_N", "2500")), 6, 4),)
 if "--trees-only" in sys.argv:
@@ -134,8 +202,8 @@ for n, F, nit in GPB_CASES:
 if MOCK:
     print("ROUTE B SEAMS ON THE CPU RESTATEMENT: OK")
     sys.exit(0)
-if "--gpboost-only" in sys.argv:
-    print("ROUTE B (GPBoost iterations) ON MI355X: OK")
+if "--gpboost-only" in sys.argv or "--laplace-only" in sys.argv:
+    print("ROUTE B (%s) ON MI355X: OK" % ("GPBoost iterations" if "--gpboost-only" in sys.argv else "Laplace seams"))
     sys.exit(0)
 
 # ---- (2) trees ------------------------------------------------------------------------------------------------------------------

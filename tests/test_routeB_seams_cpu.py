@@ -1,8 +1,9 @@
 """INTEGRATION.md route B without a GPU: the route-B build of the reference (oracle/_ref/lib_gpboost_hip.so = the reference's own host code with
 integration/reference_hip_seams.patch) with tests/mock_shim's CPU restatement of gpb_hip_* PRELOADED in place of lib_gpboost_amd.so.  What runs is
 the patched host code -- HipCreateVecchiaStates, HipCalcCovFactorVecchia (B refilled through the cached pattern), the fused evaluations inside the
-optimiser, CalcYAux after a new response at unchanged parameters, NewtonUpdateLeafValues -- and GPU_use = true must reproduce GPU_use = false of
-the same build.  The MI355X run of the same script is scripts/gpu_routeB.py (profiles/r04_*_routeB.log)."""
+optimiser, CalcYAux after a new response at unchanged parameters, NewtonUpdateLeafValues, and the Laplace seams of a Bernoulli-logit model
+(Likelihood::FindModePostRandEffCalcMLLVecchia, its gradient, ResetModeToPreviousValue; evaluations and an lbfgs fit) -- and GPU_use = true must
+reproduce GPU_use = false of the same build.  The MI355X run of the same script is scripts/gpu_routeB.py (profiles/r04_*_routeB.log)."""
 import os
 import subprocess
 import sys
@@ -22,3 +23,4 @@ def test_patched_reference_host_code_on_the_cpu_restatement_of_the_shim():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "ROUTE B SEAMS ON THE CPU RESTATEMENT: OK" in out.stdout
     assert "HIP device detected" in out.stdout + out.stderr      # the seams were active (the mock reports one device)
+    assert "Laplace bernoulli_logit" in out.stdout and "reproduces the CPU path of the same build" in out.stdout

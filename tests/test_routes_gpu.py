@@ -44,6 +44,9 @@ def test_route_a_reference_python_package_reproduces_the_r_goldens_on_the_device
 def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_built):
     out = _run(["scripts/gpu_routeB.py", "--test", "--gp-only"], "ROUTE B ON MI355X: OK", 1500)
     assert out.count("GPU_use=true reproduces the CPU path of the same build") == 2
+    # round 4: the Laplace seams (Bernoulli-logit and Poisson, n = 5000: evaluations and lbfgs fits) against the CPU path's stored values, and the GPBoost loop
+    assert out.count("(mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build") == 2
+    assert "y_aux and Newton leaf values from the resident factor) reproduces the CPU path" in out
 
 
 @pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="oracle/_ref/lib_gpboost_hip.so (route-B build of the reference) not built")
