@@ -207,3 +207,16 @@ def test_mailbox_sums_of_a_sharded_evaluation(lib_built, W):
         if k % 2 == 0:
             np.testing.assert_allclose(res[0][q], ref7[k], rtol=1e-10, atol=1e-8); q += 1
     grp.close()
+
+
+@pytest.mark.gpu
+def test_mailbox_across_processes(lib_built):
+    """The form bench.py --gpus N uses: separate PROCESSES (own HIP context each; all on device 0 here, no RCCL) shard one evaluation and exchange their sums
+    through the shared-memory mailbox -- identical bits on every rank, equal to the rank-ordered sum of the shard sums and to the unsharded evaluation
+    (scripts/gpu_mailbox_multiprocess.py; profiles/r04_n_mailbox_multiprocess.log)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_mailbox_multiprocess.py"), "2", "3"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MAILBOX ACROSS PROCESSES: OK" in r.stdout
