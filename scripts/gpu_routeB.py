@@ -131,6 +131,64 @@ for n, m, liks in LAP_CASES:
             msg += ", fit %.1fx (%d / %d iterations)" % (a["t_fit"] / b["t_fit"], a["it"], b["it"])
         print("Laplace %s n=%d: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build%s; %s faster" % (
             lik, n, "" if False in res else " (its values: tests/golden/routeB_laplace_ref.json)", msg), flush=True)
+# ---- (1d) the GPBoost algorithm for binary classification: every boosting iteration finds the mode at the current scores (fixed effects of the
+#      Laplace state), takes one covariance-parameter step (device mode finding + device gradient) and hands d(-mll)/dF to the tree as the gradient
+#      (CalcGradNegMargLikelihoodLaplaceApproxVecchia with calc_F_grad -> gpb_hip_vecchia_laplace_grad_F_current) -- GPU_use = true against false ----
+CLS_CASES = ((1200, 6, 3, 10),) if MOCK else ((5000, 10, 4, 20),)
+if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
+    CLS_CASES = ()
+LC = C.CDLL(LIBP)
+LC.LGBM_GetLastError.restype = C.c_char_p
+for n, F, nit, m in CLS_CASES:
+    rng = np.random.default_rng(31)
+    coords = rng.uniform(size=(n, 2))
+    X = np.ascontiguousarray(rng.uniform(size=(n, F)))
+    eta = 2.0 * np.sin(4 * X[:, 0]) + X[:, 1] - 0.5 + np.sin(5 * coords[:, 0]) * np.cos(4 * coords[:, 1])
+    yc = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
+    key = "gpboost_binary_n%d_F%d_m%d_it%d" % (n, F, m, nit)
+    res = {}
+    legs = (False,) if MAKE_LAP_REF else ((False, True) if MOCK else (True,))
+    for gpu in legs:
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, likelihood="bernoulli_logit", lib_path=LIBP, gpu_use=gpu,
+                                  matrix_inversion_method="iterative")
+        mdl.set_optim_config(init_cov_pars=np.array([1.0, 0.1]), optimizer_cov="gradient_descent", cg_delta_conv=1e-6)
+        ds = C.c_void_p()
+        rc = LC.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
+                                          C.c_char_p(b"verbosity=-1 max_bin=63"), C.c_void_p(), C.byref(ds))
+        assert rc == 0, LC.LGBM_GetLastError().decode()
+        assert LC.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yc.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)) == 0
+        bst = C.c_void_p()
+        params = "objective=binary num_leaves=15 learning_rate=0.1 min_data_in_leaf=20 verbosity=-1 num_threads=8 max_bin=63 train_gp_model_cov_pars=true"
+        rc = LC.LGBM_GPBoosterCreate(ds, C.c_char_p(params.encode()), mdl.h, C.byref(bst))
+        assert rc == 0, LC.LGBM_GetLastError().decode()
+        fin = C.c_int(0)
+        ts = []
+        for _ in range(nit):
+            t0 = time.perf_counter()
+            rc = LC.LGBM_BoosterUpdateOneIter(bst, C.byref(fin))
+            assert rc == 0, LC.LGBM_GetLastError().decode()
+            ts.append(time.perf_counter() - t0)
+        out = np.empty(n); olen = C.c_int64(0)
+        rc = LC.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(1), C.c_int(0),
+                                          C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0, LC.LGBM_GetLastError().decode()
+        res[gpu] = dict(pred=[float(v) for v in out[:200]], cov=[float(v) for v in mdl.get_cov_par(2)], t_iter=float(np.median(ts)))
+        print("GPBoost binary n=%d GPU_use=%s: median %.1f ms per boosting iteration; cov pars %s; tree ensemble[:3] = %s" % (n, gpu, 1e3 * res[gpu]["t_iter"], res[gpu]["cov"], out[:3]), flush=True)
+        LC.LGBM_BoosterFree(bst); LC.LGBM_DatasetFree(ds)
+        del mdl
+    if MAKE_LAP_REF:
+        LAP_REF[key] = res[False]
+        json.dump(LAP_REF, open(LAP_REF_PATH, "w"), indent=1, sort_keys=True)
+        continue
+    a = res[False] if False in res else LAP_REF.get(key)
+    b = res[True]
+    if a is None:
+        print("GPBoost binary n=%d: no stored CPU values" % n, flush=True)
+        continue
+    np.testing.assert_allclose(b["pred"], a["pred"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b["cov"], a["cov"], rtol=1e-5)
+    print("GPBoost binary n=%d: GPU_use=true (mode finding at the scores, covariance step and the boosting gradient d(-mll)/dF on the device) reproduces the CPU path%s; "
+          "boosting iteration %.1fx faster" % (n, "" if False in res else " (its values: tests/golden/routeB_laplace_ref.json)", a["t_iter"] / b["t_iter"]), flush=True)
 if MAKE_LAP_REF:
     sys.exit(0)
 

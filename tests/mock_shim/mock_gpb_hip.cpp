@@ -69,6 +69,8 @@ namespace {
 struct MockTimes { double t[8] = {0}; long c[8] = {0}; const char* name[8] = {"factor", "nll_terms", "grad_terms", "yaux", "newton_leaf_values", "get_factor", "set_y", "laplace_eval / grad_current"};
   ~MockTimes() { if (std::getenv("GPB_MOCK_TIMING")) for (int i = 0; i < 8; ++i) if (c[i]) std::fprintf(stderr, "mock timing: %-20s %6ld calls %9.3f s\n", name[i], c[i], t[i]); } };
 MockTimes g_times;
+static const bool g_mock_trace = std::getenv("GPB_MOCK_TRACE") != nullptr;
+#define MOCK_TRACE(name) do { if (g_mock_trace) std::fprintf(stderr, "mock call: %s\n", name); } while (0)
 struct MockTimer { int k; std::chrono::steady_clock::time_point t0; explicit MockTimer(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
   ~MockTimer() { g_times.t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_times.c[k]++; } };
 }  // namespace
@@ -267,7 +269,7 @@ EXPORT int gpb_hip_vecchia_gram(gpb_hip_vecchia_t* h, double* G) {
   }
   return 0;
 }
-EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss) { MockTimer mock_timer_(0);
+EXPORT int gpb_hip_vecchia_factor(gpb_hip_vecchia_t* h, int cov, double var, double a, int gauss) { MOCK_TRACE("gpb_hip_vecchia_factor"); MockTimer mock_timer_(0);
   if (!h->has_nn) return fail("neighbours have not been determined");
   h->A.assign((size_t)h->n * h->m, 0.); h->D.assign(h->n, 0.);
   orc_vecchia_factor(h->coords.data(), h->n, h->d, h->nn.data(), h->m, cov, var, a, gauss, h->A.data(), h->D.data(), nullptr, nullptr);
@@ -404,32 +406,32 @@ EXPORT int gpb_hip_vecchia_laplace_set_data_map(gpb_hip_vecchia_t* h, const int3
   h->labels.clear(); h->fe.clear(); h->has_fe = false; h->has_mode = false; h->grad_state = false;
   return 0;
 }
-EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y) {
+EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_labels");
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   h->labels.assign(y, y + nd); h->grad_state = false; return 0;
 }
-EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fe) {
+EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fe) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_fixed_effects");
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   if (fe) { h->fe.assign(fe, fe + nd); h->has_fe = true; } else { h->fe.clear(); h->has_fe = false; }
   h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_eval(gpb_hip_vecchia_t* h, int cov, double var, double a, int nrv, int seed, int cg, int cgt, double cgd, double dcm, int reset,
-                                        int /*keep*/, double* out9, double* mode_host) { MockTimer mock_timer_(7);
+                                        int /*keep*/, double* out9, double* mode_host) { MOCK_TRACE("gpb_hip_vecchia_laplace_eval"); MockTimer mock_timer_(7);
   return laplace_run(h, cov, var, a, nrv, seed, cg, cgt, cgd, dcm, reset, out9, mode_host);
 }
 EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov, double var, double a, int nrv, int seed, int cg, int cgt, double cgd, double dcm, int reset,
                                          double* out9, double* mode_host) {
   return laplace_run(h, cov, var, a, nrv, seed, cg, cgt, cgd, dcm, reset, out9, mode_host);
 }
-EXPORT int gpb_hip_vecchia_laplace_grad_current(gpb_hip_vecchia_t* h, int, double, double* grad2, double*, double*) { MockTimer mock_timer_(7);
+EXPORT int gpb_hip_vecchia_laplace_grad_current(gpb_hip_vecchia_t* h, int, double, double* grad2, double*, double*) { MOCK_TRACE("gpb_hip_vecchia_laplace_grad_current"); MockTimer mock_timer_(7);
   if (!h->grad_state) return fail("the gradient needs the state of an evaluation that kept it");
   grad2[0] = h->grad2[0]; grad2[1] = h->grad2[1]; return 0;
 }
-EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h) {
+EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h) { MOCK_TRACE("gpb_hip_vecchia_laplace_reset_mode_to_previous");
   if (h->mode_prev.empty()) return fail("no mode has been found yet");
   h->mode = h->mode_prev; h->has_mode = true; h->grad_state = false; return 0;
 }
-EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* gF) {
+EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* gF) { MOCK_TRACE("gpb_hip_vecchia_laplace_grad_F_current");
   if (!h->grad_state) return fail("the gradient wrt the fixed effects needs the state of gpb_hip_vecchia_laplace_grad_current");
   const int n = h->n;
   const bool mapped = !h->re_ptr.empty();
