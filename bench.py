@@ -109,18 +109,30 @@ def cpu_baseline(coords, y, cov_function, shape, m, cov_pars, n_full):
         setup = orc.vecchia_setup(coords, m, "random", 1)
         f = lambda cp: orc.gp_nll(coords, y, cp, cov_function, shape, m, setup=setup)
         kind = "port"
-    times = {}
+    # warm-up, then >= 3 timed evaluations with perturbed parameters, median.  Leg 1 (doubles as the warm-up of the
+    # pages and of the OpenMP pools): ONE evaluation per thread count picks the best count; leg 2: three more timed evaluations at that count.
+    scan = {}
     budget_t0 = time.perf_counter()
-    for k, c in enumerate(reversed(counts)):     # most threads first (doubles as the warm-up of the pages)
-        if time.perf_counter() - budget_t0 > 60.0 and times:
+    for k, c in enumerate(reversed(counts)):     # most threads first
+        if time.perf_counter() - budget_t0 > 60.0 and scan:
             break
         _omp_set_num_threads(c)
         cp = cov_pars * (1.0 + 0.01 * (k + 1))
-        t0 = time.perf_counter(); f(cp); times[c] = time.perf_counter() - t0
-    best = min(times, key=times.get)
-    return {"value": 1.0 / times[best], "unit": "evals/s", "cores": best, "kind": kind,
-            "sample": "n=%d (the metric's size, no scaling), m=%d, one evaluation per OpenMP thread count; seconds per evaluation: %s; "
-                      "best at %d threads of %d hardware threads" % (n_s, m, ", ".join("%d thr %.2f s" % (c, times[c]) for c in sorted(times)), best, hw)}
+        t0 = time.perf_counter(); f(cp); scan[c] = time.perf_counter() - t0
+    best = min(scan, key=scan.get)
+    _omp_set_num_threads(best)
+    timed = []
+    for k in range(3):
+        cp = cov_pars * (1.0 + 0.003 * (k + 1))
+        t0 = time.perf_counter(); f(cp); timed.append(time.perf_counter() - t0)
+        if time.perf_counter() - budget_t0 > 120.0:
+            break
+    med = float(np.median(timed))
+    return {"value": 1.0 / med, "unit": "evals/s", "cores": best, "kind": kind, "seconds_per_eval_median": med, "timed_evals": len(timed),
+            "sample": "n=%d (the metric's size, no scaling), m=%d; thread-count scan, one evaluation each (also the warm-up): %s; then %d timed "
+                      "evaluations with perturbed parameters at the best count (%d of %d hardware threads): %s s, median %.3f s"
+                      % (n_s, m, ", ".join("%d thr %.2f s" % (c, scan[c]) for c in sorted(scan)), len(timed), best, hw,
+                         " / ".join("%.3f" % t for t in timed), med)}
 
 
 def main():
@@ -133,24 +145,59 @@ def main():
     ap.add_argument("--d", type=int, default=2)
     ap.add_argument("--cov", default="exponential", choices=["exponential", "matern_1.5", "matern_2.5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the metric's line: skip the other configurations' measurements reported next to it")
     args = ap.parse_args()
+
+    # --gpus N without a launcher (WORLD_SIZE unset): this process becomes the launcher of its own N ranks -- the same command line the driver
+    # uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...), so that
+    # `python bench.py --gpus N` and the torchrun form walk the same code.  A line is only ever printed with n_gpus == --gpus (checked below).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GPB_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL init, shared stream, all-reduce) with one rank
     distributed = world > 1 or os.environ.get("GPB_BENCH_FORCE_DIST", "0") == "1"
-    if args.gpus != world and rank == 0 and distributed:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: no line is printed whose n_gpus differs from --gpus "
+                         "(run `python bench.py --gpus %d`, which starts its own ranks)" % (args.gpus, world, world))
 
+    import gpboost_amd
+    from gpboost_amd import parallel, shim
     torch = dist = None
+    rehearsal = False
+    cdev = "cpu"                 # where the bootstrap's small tensors live: the GPU under RCCL, the host under gloo (rehearsal)
     if distributed:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    import gpboost_amd
-    from gpboost_amd import parallel, shim
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise RuntimeError("bench.py: no GPU visible")
+        # REHEARSAL (one-GPU lease): fewer devices than ranks -> every rank uses device 0, the process group is gloo, RCCL (one device per
+        # rank) stays down and the shard sums travel through the node-local mailbox -- after the bootstrap exactly the code of a real
+        # N-device launch.  The line says so ("rehearsal": true, the metric's name too): its value is NOT a scaling number, the N shard
+        # kernels time-share one device.  GPB_BENCH_REHEARSAL=1 forces it, =0 forbids it.
+        want = os.environ.get("GPB_BENCH_REHEARSAL", "")
+        rehearsal = (want == "1") or (ndev < world and want != "0")
+        if ndev < world and not rehearsal:
+            raise RuntimeError("bench.py --gpus %d: only %d device(s) visible and GPB_BENCH_REHEARSAL=0" % (world, ndev))
+        if rehearsal:
+            torch.cuda.set_device(0)
+            gpboost_amd.set_device(0)
+            dist.init_process_group("gloo")
+            if rank == 0:
+                print("bench.py: REHEARSAL -- %d ranks share device 0 (%d device(s) visible); gloo bootstrap, mailbox for the sums" % (world, ndev), file=sys.stderr)
+        else:
+            torch.cuda.set_device(local_rank)
+            gpboost_amd.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            cdev = "cuda"
     if not distributed:
         gpboost_amd.set_device(0)
 
@@ -183,41 +230,43 @@ def main():
     if distributed:
         st.set_stream(torch.cuda.current_stream().cuda_stream)
         tdev = torch.zeros(3, dtype=torch.float64, device="cuda")
+
+        def all_min(flag):          # every rank learns whether EVERY rank succeeded
+            t = torch.tensor([int(flag)], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        def bcast_bytes(payload, nbytes):     # rank 0's bytes to every rank
+            t = torch.zeros(nbytes, dtype=torch.uint8, device=cdev)
+            if rank == 0:
+                t.copy_(torch.tensor(list(payload.ljust(nbytes, b"\0")), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().tolist())
+
         # In-library RCCL reduction (point kernel -> reduction -> ncclAllReduce -> host on ONE stream, one sync per
         # evaluation) unless GPB_BENCH_TORCH_ALLREDUCE=1; the unique id travels over the torch process group.  Every rank
         # reports whether its communicator came up; if any did not, all ranks use torch.distributed.all_reduce instead.
+        # (Rehearsal: RCCL refuses two ranks on one device -- it stays down, rccl_ranks = 0, and the mailbox below is the only transport.)
         ok = 0
-        if os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
+        if not rehearsal and os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
             try:
-                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    idt.copy_(torch.tensor(list(shim.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                st.comm_init(bytes(idt.cpu().tolist()), rank, world)
+                st.comm_init(bcast_bytes(bytes(shim.comm_unique_id()) if rank == 0 else b"", 128), rank, world)
                 ok = 1
             except Exception as e:   # noqa: BLE001
                 print("rank %d: native RCCL communicator failed (%s); falling back to torch all_reduce" % (rank, e), file=sys.stderr)
-        okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        native_rccl = bool(okt.item() == 1)
+        native_rccl = (not rehearsal) and all_min(ok) == 1
         # The 3 shard sums of an evaluation travel through the node-local shared-memory MAILBOX: every rank's finisher
         # workgroup stores its sums into its slot, every host polls all slots -- no collective launch per evaluation.  RCCL stays up for the big
         # messages.  GPB_BENCH_NO_MAILBOX=1 keeps ncclAllReduce for the sums (A/B).
         mok = 0
-        if native_rccl and os.environ.get("GPB_BENCH_NO_MAILBOX", "0") != "1":
+        if os.environ.get("GPB_BENCH_NO_MAILBOX", "0") != "1":      # (the mailbox does not need RCCL: a job whose communicator failed still runs the product's sums)
             try:
-                nmt = torch.zeros(64, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    nm = shim.mailbox_create(world)
-                    nmt.copy_(torch.tensor(list(nm.ljust(64, b"\0")), dtype=torch.uint8))
-                dist.broadcast(nmt, src=0)
-                st.mailbox_attach(bytes(nmt.cpu().tolist()).rstrip(b"\0"), rank, world)
+                nm = bcast_bytes(shim.mailbox_create(world) if rank == 0 else b"", 64)
+                st.mailbox_attach(nm.rstrip(b"\0"), rank, world)
                 mok = 1
             except Exception as e:   # noqa: BLE001
                 print("rank %d: mailbox failed (%s)" % (rank, e), file=sys.stderr)
-            mkt = torch.tensor([mok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(mkt, op=dist.ReduceOp.MIN)
-            if mkt.item() != 1:
+            if all_min(mok) != 1:
                 if mok:
                     st.mailbox_detach()
                 mok = 0
@@ -227,8 +276,8 @@ def main():
                 # bounded poll included) sends every rank back to ncclAllReduce for the sums.
                 try:
                     got = np.asarray(st.nll_terms_allreduce(ct, var0, a0))[:3]
-                    loc = torch.tensor(np.asarray(st.nll_terms(ct, var0, a0))[:3], dtype=torch.float64, device="cuda")
-                    parts = [torch.zeros(3, dtype=torch.float64, device="cuda") for _ in range(world)]
+                    loc = torch.tensor(np.asarray(st.nll_terms(ct, var0, a0))[:3], dtype=torch.float64, device=cdev)
+                    parts = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
                     dist.all_gather(parts, loc)
                     want = np.zeros(3)
                     for pr in parts:
@@ -238,19 +287,23 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     print("rank %d: mailbox check failed (%s); the sums go through ncclAllReduce" % (rank, e), file=sys.stderr)
                     mok = 0
-                mkt = torch.tensor([mok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(mkt, op=dist.ReduceOp.MIN)
-                if mkt.item() != 1:
+                if all_min(mok) != 1:
                     st.mailbox_detach()
                     mok = 0
         use_mailbox = bool(mok)
         # Under a multi-rank launch a silent fallback would report a number for a path that is not the product's: fail loudly instead
         # (GPB_BENCH_TORCH_ALLREDUCE=1 asks for the torch fallback explicitly).
-        if world > 1 and not native_rccl and os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
-            raise RuntimeError("bench.py --gpus %d: the in-library RCCL communicator did not come up on every rank (see stderr); "
+        if world > 1 and not native_rccl and not use_mailbox and os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
+            raise RuntimeError("bench.py --gpus %d: neither the in-library RCCL communicator nor the mailbox came up on every rank (see stderr); "
                                "GPB_BENCH_TORCH_ALLREDUCE=1 selects the torch.distributed fallback explicitly" % world)
+        if world > 1 and not native_rccl and not rehearsal and rank == 0:
+            print("bench.py --gpus %d: WARNING -- the in-library RCCL communicator did not come up (rccl_ranks = 0 in the line); the shard sums travel "
+                  "through the mailbox, which does not need it" % world, file=sys.stderr)
+        if rehearsal and not use_mailbox:
+            raise RuntimeError("bench.py --gpus %d (rehearsal): the mailbox did not come up on every rank (see stderr)" % world)
     else:
         use_mailbox = False
+    native = native_rccl or use_mailbox      # the library reduces the shard sums inside GPB_EvalNegLogLikelihood (RCCL or the mailbox)
 
     def cov_pars_of(k):
         # covariance parameters change every evaluation (perturbed by <= 1 %): nothing is reusable between steps
@@ -273,7 +326,7 @@ def main():
     cp_ptrs = [cp.ctypes.data for cp in cp_sets]
 
     def one_eval(k):
-        if distributed and not native_rccl:      # fallback only: shard terms on the device + torch.distributed all-reduce
+        if distributed and not native:      # fallback only: shard terms on the device + torch.distributed all-reduce
             cpk = cov_pars_of(k)
             st.nll_terms_dev(ct, cpk[1] / cpk[0], a0 * cov_pars[2] / cpk[2], tdev.data_ptr())
             dist.all_reduce(tdev)
@@ -311,13 +364,13 @@ def main():
     dt = time.perf_counter() - t0
     timed_launches, ms_kernel_inloop = st.timing(False)
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # the same call through the package-style wrapper (GPModel.neg_log_likelihood: argument checks + numpy marshalling per call), untimed
     # steps first so that both loops run at the same clocks; reported in config, never as `value`
     wrapper_ms = None
-    if not distributed or native_rccl:
+    if not distributed or native:
         for k in range(5):
             mdl.neg_log_likelihood(cov_pars_of(k))
         sync()
@@ -327,10 +380,36 @@ def main():
         sync()
         wrapper_ms = (time.perf_counter() - tw0) / args.steps * 1e3
 
+    # A/B inside the same run (real multi-device launches only): the same timed call with the sums through ncclAllReduce (+ publish kernel) instead of
+    # the mailbox -- north_star names "RCCL all-reduce of log-likelihood scalars"; both rates are in the line, `value` is the mailbox's (the default)
+    ab_rccl = None
+    if distributed and native_rccl and use_mailbox and os.environ.get("GPB_BENCH_NO_AB", "0") != "1":
+        mbox_name_ranks = st.mailbox_info()[1]
+        st.mailbox_detach()
+        try:
+            for k in range(max(args.warmup, 3)):
+                one_eval(k)
+            sync()
+            ta0 = time.perf_counter()
+            for k in range(args.steps):
+                one_eval(args.warmup + k)
+            sync()
+            dta = time.perf_counter() - ta0
+            tta = torch.tensor([dta], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tta, op=dist.ReduceOp.MAX)
+            dta = float(tta.item())
+            ab_rccl = {"ms_per_step": dta / args.steps * 1e3, "evals_per_s": args.steps / dta, "rccl_ranks": st.comm_info()[1],
+                       "call": "the same GPB_EvalNegLogLikelihood loop with the mailbox detached: point kernel -> ncclAllReduce(3 fp64) -> publish kernel -> host poll"}
+        finally:
+            # back to the mailbox for everything measured after this (a fresh segment: the old one's generations ended with the detach)
+            nm = bcast_bytes(shim.mailbox_create(world) if rank == 0 else b"", 64)
+            st.mailbox_attach(nm.rstrip(b"\0"), rank, world)
+        assert st.mailbox_info()[1] == mbox_name_ranks
+
     # batched entry point (GPB_HIP_EvalNegLogLikelihoodBatch): K parameter sets per call, ONE synchronisation and ONE all-reduce of 3 K
     # doubles -- what an optimiser's line search / a grid of trial points would use; reported next to the metric, never as `value`
     batched = None
-    if not distributed or native_rccl:
+    if not distributed or native:
         Kb = 32
         cps = np.stack([cov_pars_of(k) for k in range(Kb)])
         mdl.neg_log_likelihood_batch(cps)
@@ -341,7 +420,7 @@ def main():
         sync()
         dtb = time.perf_counter() - tb0
         if distributed:
-            ttb = torch.tensor([dtb], dtype=torch.float64, device="cuda")
+            ttb = torch.tensor([dtb], dtype=torch.float64, device=cdev)
             dist.all_reduce(ttb, op=dist.ReduceOp.MAX)
             dtb = float(ttb.item())
         batched = {"K": Kb, "evals_per_s": 4 * Kb / dtb, "ms_per_eval": dtb / (4 * Kb) * 1e3,
@@ -360,9 +439,25 @@ def main():
     traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0>" % (m, ct, "true" if d == 3 else "false")) if (n, world) == (1000000, 1) else None
     rccl_ranks = st.comm_info()[1] if native_rccl else 0
     mailbox_ranks = st.mailbox_info()[1] if use_mailbox else 0
+    # per-rank view (N > 1): every rank's in-loop kernel time and shard size -- min / max over the ranks is the skew the N = 8 budget of DESIGN.md
+    # section 5 leaves open; and what every rank's transport says about itself (the line is refused if they disagree with the launch)
+    per_rank = None
+    if distributed:
+        mine = torch.tensor([ms_kernel, float(npts), float(rccl_ranks), float(mailbox_ranks)], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros(4, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = np.stack([t.cpu().numpy() for t in allr])
+        per_rank = {"kernel_ms": [round(float(v), 5) for v in allr[:, 0]], "kernel_ms_min": float(allr[:, 0].min()), "kernel_ms_max": float(allr[:, 0].max()),
+                    "shard_points": [int(v) for v in allr[:, 1]], "rccl_ranks_seen": [int(v) for v in allr[:, 2]], "mailbox_ranks_seen": [int(v) for v in allr[:, 3]]}
+        if world > 1:
+            seen = allr[:, 3] if use_mailbox else allr[:, 2]
+            if native and not np.all(seen == world):
+                raise RuntimeError("bench.py --gpus %d: the ranks' transport reports %r ranks -- no line is printed for a job that is not the one asked for" % (world, seen.tolist()))
+            if int(allr[:, 1].sum()) != n:
+                raise RuntimeError("bench.py --gpus %d: the shards cover %d of %d points" % (world, int(allr[:, 1].sum()), n))
     if rank == 0:
         out = {
-            "metric": "neg-log-lik evals/sec, n=%d Vecchia(m=%d) fp64" % (n, m),
+            "metric": "neg-log-lik evals/sec, n=%d Vecchia(m=%d) fp64" % (n, m) + (" [REHEARSAL: %d ranks time-share ONE device -- not a scaling number]" % world if rehearsal else ""),
             "value": args.steps / dt,
             "unit": "evals/s",
             "n_gpus": world,
@@ -376,9 +471,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Vecchia GP Gaussian nll, n=%d, d=%d, %s, m=%d, vecchia_ordering=random" % (n, d, args.cov, m),
                        "timed_call": ("GPB_EvalNegLogLikelihood(handle, y_data=NULL, cov_pars, fixed_effects=NULL, &negll) through ctypes: y resident in HBM, "
-                                      "parameters in, value out" if (not distributed or native_rccl) else "shard terms + torch.distributed all_reduce (fallback path)"),
-                       "shard_points_per_gpu": npts, "parallelism": "points sharded x%d, sum of 3 fp64 over the ranks (%s)" % (world, ("node-local shared-memory mailbox, %d ranks (RCCL up with %d ranks for the big messages)" % (mailbox_ranks, rccl_ranks)) if use_mailbox else ("in-library RCCL, %d ranks" % rccl_ranks if native_rccl else ("torch.distributed nccl" if distributed else "single GPU"))),
-                       "rccl_ranks": rccl_ranks, "mailbox_ranks": mailbox_ranks, "prewarm_evals": PREWARM,
+                                      "parameters in, value out" if (not distributed or native) else "shard terms + torch.distributed all_reduce (fallback path)"),
+                       "shard_points_per_gpu": npts, "parallelism": "points sharded x%d, sum of 3 fp64 over the ranks (%s)" % (world, ("node-local shared-memory mailbox, %d ranks (RCCL up with %d ranks for the big messages)" % (mailbox_ranks, rccl_ranks)) if use_mailbox else ("in-library RCCL, %d ranks" % rccl_ranks if native_rccl else ("torch.distributed nccl" if distributed else "single GPU"))) + (" -- REHEARSAL on one device" if rehearsal else ""),
+                       "rccl_ranks": rccl_ranks, "mailbox_ranks": mailbox_ranks, "prewarm_evals": PREWARM, "rehearsal": rehearsal, "per_rank": per_rank, "ab_sums_through_ncclAllReduce": ab_rccl,
+                       "process_group": ("gloo (rehearsal bootstrap)" if rehearsal else "nccl (RCCL)") if distributed else None,
                        "kernel_ms_source": "HIP events around every point-kernel launch INSIDE the timed loop (%d launches); separate loop of launches: %.4f ms" % (timed_launches, ms_kernel_sep),
                        "setup_s_model_creation_incl_device_neighbor_search": round(t_setup, 3),
                        "last_negll": last, "batched": batched,
@@ -400,7 +496,7 @@ def main():
                                    "algorithmic_flops_per_launch": flops_launch,
                                    "note": "exp / sqrt / division counted as ONE flop each (SURVEY.md 8d); instruction mix: profiles/r04_point_kernel_instruction_mix.txt"},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the one HBM-bound kernel of the path: dense covariance assembly (exact GP), measured live
             try:
                 ne = 16384
@@ -442,7 +538,7 @@ def main():
                 ex1.close()
             except Exception as e:
                 out["config1_exact_gp_n2000"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # LightGBM feature-histogram build at a size where GB/s means something (8d: n = 1e7 rows, F = 50,
             # 255 bins, constant hessian): algorithmic bytes = rows * (F + 8 + 4) in + F * bins * 16 out
             try:
@@ -504,7 +600,7 @@ def main():
                 del m4
             except Exception as e:
                 out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # full-scale Vecchia / VIF: one likelihood evaluation at n = 1e5, m = 30, 200 inducing points
             try:
                 nv = 100000
@@ -531,7 +627,7 @@ def main():
                 del mv
             except Exception as e:
                 out["vif_full_scale_vecchia"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the direct caller of the hot path: a complete maximum-likelihood fit of (sigma2, sigma1_2, rho) on the
             # bench model -- y uploaded once, 3 / 7 doubles back per evaluation.  y = smooth signal + noise so that the optimum is interior.
             try:
@@ -549,7 +645,7 @@ def main():
                     "reference": "DESIGN.md 4.10: unmodified reference, same data recipe at n=1e5, this repo's build container"}
             except Exception as e:
                 out["fit_covariance_parameters"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # BASELINE config 3: the device work of one GPBoost iteration (Gaussian likelihood, Vecchia m = 30, n = 1e5; tree of 31 leaves
             # on F = 50 features x 255 bins), every step through the C ABI with host arrays in and out (scripts/gpu_boost_iter.py)
             try:

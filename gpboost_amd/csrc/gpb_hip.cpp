@@ -223,7 +223,15 @@ struct GpbMailbox {
   void* base = nullptr; size_t bytes = 0;
   double* dev_base = nullptr;                 // device address of the mapping (hipHostGetDevicePointer)
   unsigned long long evals = 0;
+  bool dead = false;                          // an evaluation failed or timed out on this rank: the generation counters of the ranks may be out of step, nothing more goes through it
   char name[64] = "";
+  // poll limits (seconds): GPB_MAILBOX_TIMEOUT_S for an evaluation's sums (default 30), GPB_MAILBOX_ATTACH_TIMEOUT_S for the attach rendezvous (default 120)
+  static double env_seconds(const char* var, double dflt) {
+    const char* v = std::getenv(var);
+    if (!v || !v[0]) return dflt;
+    const double x = std::atof(v);
+    return x > 0.0 ? x : dflt;
+  }
   static constexpr unsigned long long kMagic = 0x4750424d41494c42ull;   // "GPBMAILB"
   static size_t header_bytes(int w) { return ((16 + 8 * (size_t)w) + 63) / 64 * 64; }
   static size_t total_bytes(int w) { return header_bytes(w) + sizeof(double) * 3 * (size_t)w * 8; }
@@ -236,7 +244,7 @@ struct GpbMailbox {
   }
   void release() {
     if (base) { (void)hipHostUnregister(base); (void)munmap(base, bytes); }
-    base = nullptr; dev_base = nullptr; world = 0; rank = -1; bytes = 0; evals = 0;
+    base = nullptr; dev_base = nullptr; world = 0; rank = -1; bytes = 0; evals = 0; dead = false;
   }
 };
 
@@ -640,7 +648,7 @@ int gpb_hip_vecchia_set_shard(gpb_hip_vecchia_t* h, int32_t i_begin, int32_t i_e
   if (!h) return fail("null handle");
   if (i_begin < 0 || i_end > h->n || i_begin >= i_end) return fail("gpb_hip_vecchia_set_shard: invalid range [%d, %d) for n = %d", i_begin, i_end, h->n);
   h->i_begin = i_begin; h->i_end = i_end;
-  h->has_factor = false;
+  h->has_factor = false; h->u_stale = false;
   API_END();
 }
 
@@ -739,6 +747,10 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
     HIP_OK(gpb::launch_vecchia_point_kernel(mode, cov_type, h->d == 3, k, h->stream));
     if (ev1) HIP_OK(hipEventRecord(ev1, h->stream));
   }
+  // every MODE_FACTOR launch rewrites u = B y from the response resident NOW (Gaussian factor, the Laplace seams' factor launches alike): the one
+  // place where "u belongs to an earlier response" ends.  (refresh_u's u is the fma chain of vecchia_By_pts_kernel over the stored A -- equal to the
+  // factor kernel's u to rounding, ~1e-16 relative, not bit for bit: stated in include/gpb_hip.h at gpb_hip_vecchia_set_y.)
+  if (mode == gpb::MODE_FACTOR) h->u_stale = false;
   return 0;
 }
 
@@ -893,29 +905,35 @@ int gpb_hip_vecchia_mailbox_attach(gpb_hip_vecchia_t* h, const char* name, int r
   if (fd < 0) return fail("gpb_hip_vecchia_mailbox_attach: shm_open(%s) failed: %s", name, std::strerror(errno));
   const size_t bytes = GpbMailbox::total_bytes(world);
   struct stat st;
-  if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { (void)close(fd); return fail("gpb_hip_vecchia_mailbox_attach: segment %s is smaller than %zu bytes (world mismatch?)", name, bytes); }
+  // a failed attach ends the mailbox for every rank (the callers agree on that by an all-reduce of a success flag): whoever fails removes the name,
+  // so that no /dev/shm/gpb_mbox_* outlives the job (the mappings of ranks already attached keep the memory alive until they release it)
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { (void)close(fd); (void)shm_unlink(name); return fail("gpb_hip_vecchia_mailbox_attach: segment %s is smaller than %zu bytes (world mismatch?)", name, bytes); }
   void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   (void)close(fd);
-  if (p == MAP_FAILED) return fail("gpb_hip_vecchia_mailbox_attach: mmap failed: %s", std::strerror(errno));
+  if (p == MAP_FAILED) { (void)shm_unlink(name); return fail("gpb_hip_vecchia_mailbox_attach: mmap failed: %s", std::strerror(errno)); }
   auto* hdr = static_cast<volatile unsigned long long*>(p);
-  if (hdr[0] != GpbMailbox::kMagic || hdr[1] != (unsigned long long)world) { (void)munmap(p, bytes); return fail("gpb_hip_vecchia_mailbox_attach: %s is not a mailbox for %d ranks", name, world); }
+  if (hdr[0] != GpbMailbox::kMagic || hdr[1] != (unsigned long long)world) { (void)munmap(p, bytes); (void)shm_unlink(name); return fail("gpb_hip_vecchia_mailbox_attach: %s is not a mailbox for %d ranks", name, world); }
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped);
-  if (e != hipSuccess) { (void)munmap(p, bytes); return fail("hipHostRegister of the mailbox failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)munmap(p, bytes); (void)shm_unlink(name); return fail("hipHostRegister of the mailbox failed: %s", hipGetErrorString(e)); }
   void* dp = nullptr;
   e = hipHostGetDevicePointer(&dp, p, 0);
-  if (e != hipSuccess) { (void)hipHostUnregister(p); (void)munmap(p, bytes); return fail("hipHostGetDevicePointer of the mailbox failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipHostUnregister(p); (void)munmap(p, bytes); (void)shm_unlink(name); return fail("hipHostGetDevicePointer of the mailbox failed: %s", hipGetErrorString(e)); }
   GpbMailbox& mb = h->mbox;
   mb.base = p; mb.bytes = bytes; mb.dev_base = static_cast<double*>(dp); mb.world = world; mb.rank = rank; mb.evals = 0;
   std::strncpy(mb.name, name, sizeof(mb.name) - 1);
   for (int g = 0; g < 3; ++g) for (int t = 0; t < 8; ++t) mb.slot(g, rank)[t] = kFetchSentinel;
   std::atomic_thread_fence(std::memory_order_release);
   hdr[2 + rank] = 1ull;
+  const double attach_limit_s = GpbMailbox::env_seconds("GPB_MAILBOX_ATTACH_TIMEOUT_S", 120.0);
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     bool all = true;
     for (int r = 0; r < world; ++r) all = all && hdr[2 + r] != 0ull;
     if (all) break;
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { mb.release(); return fail("gpb_hip_vecchia_mailbox_attach: not all %d ranks attached within 120 s", world); }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > attach_limit_s) {
+      mb.release(); (void)shm_unlink(name);
+      return fail("gpb_hip_vecchia_mailbox_attach: not all %d ranks attached within %.0f s (GPB_MAILBOX_ATTACH_TIMEOUT_S)", world, attach_limit_s);
+    }
     std::this_thread::yield();
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -941,13 +959,18 @@ int gpb_hip_vecchia_mailbox_detach(gpb_hip_vecchia_t* h) {
 // one sharded evaluation through the mailbox: ONE launch (the point kernel, whose finisher writes this rank's slot), then the host polls all slots
 static int vecchia_mailbox_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, double var, double a, int gauss, double* out_host, int nout) {
   GpbMailbox& mb = h->mbox;
-  const unsigned long long e = ++mb.evals;
+  if (mb.dead) return fail("mailbox: an earlier evaluation failed or timed out on this rank; the ranks' slot generations may be out of step -- detach and attach a new mailbox");
+  // the evaluation counter advances only once this rank's launch is enqueued: a launch that fails leaves the rank in step with nothing written, and the
+  // mailbox is marked dead (the peers run into their poll limit for this evaluation and mark theirs dead too -- no later evaluation reads stale slots)
+  const unsigned long long e = mb.evals + 1;
   const int gen = (int)(e % 3), next = (int)((e + 1) % 3);
   for (int t = 0; t < 8; ++t) mb.slot(next, mb.rank)[t] = kFetchSentinel;       // re-arm the own slot of the generation after this one (see GpbMailbox)
   std::atomic_thread_fence(std::memory_order_release);
-  if (vecchia_launch(h, mode, cov_type, var, a, gauss, nullptr, nout, nullptr, nullptr, mb.dev_slot(gen, mb.rank))) return -1;
+  if (vecchia_launch(h, mode, cov_type, var, a, gauss, nullptr, nout, nullptr, nullptr, mb.dev_slot(gen, mb.rank))) { mb.dead = true; return -1; }
+  mb.evals = e;
   h->launches_unfetched = 0;
   const int nterms = nout > 3 ? GPB_NUM_PARTIALS : 3;
+  const double limit_s = GpbMailbox::env_seconds("GPB_MAILBOX_TIMEOUT_S", 30.0);
   const auto t0 = std::chrono::steady_clock::now();
   bool own_synced = false;
   for (unsigned spin = 0;; ++spin) {
@@ -959,8 +982,15 @@ static int vecchia_mailbox_terms(gpb_hip_vecchia_t* h, int mode, int cov_type, d
     if (all) break;
     if ((spin & 1023u) == 1023u) {
       const auto dt = std::chrono::steady_clock::now() - t0;
-      if (!own_synced && dt > std::chrono::milliseconds(50)) { HIP_OK(hipStreamSynchronize(h->stream)); own_synced = true; }   // (surfaces a launch error of this rank)
-      if (dt > std::chrono::seconds(30)) return fail("mailbox: the sums of all %d ranks did not arrive within 30 s (evaluation %llu)", mb.world, e);
+      if (!own_synced && dt > std::chrono::milliseconds(50)) {      // (surfaces a launch error of this rank)
+        const hipError_t se = hipStreamSynchronize(h->stream);
+        if (se != hipSuccess) { mb.dead = true; return fail("mailbox: this rank's evaluation failed on the device: %s", hipGetErrorString(se)); }
+        own_synced = true;
+      }
+      if (std::chrono::duration<double>(dt).count() > limit_s) {
+        mb.dead = true;
+        return fail("mailbox: the sums of all %d ranks did not arrive within %.0f s (evaluation %llu; GPB_MAILBOX_TIMEOUT_S)", mb.world, limit_s, e);
+      }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -1058,6 +1088,11 @@ int gpb_hip_vecchia_nll_terms_batch(gpb_hip_vecchia_t* h, int cov_type, int32_t 
   if (!h || !var || !a || !out3K_host) return fail("null argument");
   if (K < 1 || K > 4096) return fail("gpb_hip_vecchia_nll_terms_batch: K = %d (1..4096)", K);
   HIP_OK(hipSetDevice(h->device));
+  if (h->mbox.active() && !h->comm.active()) {      // the mailbox is the handle's only transport (no RCCL: e.g. several ranks on one device): K evaluations through it
+    for (int k = 0; k < K; ++k)
+      if (vecchia_mailbox_terms(h, gpb::MODE_NLL, cov_type, var[k], a[k], gauss_likelihood, out3K_host + (size_t)3 * k, 3)) return -1;
+    return 0;
+  }
   if (h->batch_cap < (size_t)3 * K) {
     dev_free(h->d_batch);
     HIP_OK(hipMalloc(&h->d_batch, sizeof(double) * 3 * (size_t)K));
@@ -1409,7 +1444,7 @@ int gpb_hip_vecchia_set_nugget_diag(gpb_hip_vecchia_t* h, const double* nug_host
     if (!h->d_nug) HIP_OK(hipMalloc(&h->d_nug, sizeof(double) * (size_t)h->n));
     HIP_OK(hipMemcpy(h->d_nug, nug_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
   }
-  h->has_factor = false; h->has_yaux = false;
+  h->has_factor = false; h->u_stale = false; h->has_yaux = false;
   API_END();
 }
 
@@ -2220,8 +2255,11 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   API_BEGIN();
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  // copies from the caller-registered staging buffers may still be in flight: drain the stream BEFORE they lose their registration (same order as
+  // gpb_hip_hist_unregister_host_buffers; the caller may destroy the buffers right after this call)
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& q : h->pin) if (q.p) { (void)hipHostUnregister(const_cast<void*>(q.p)); q.p = nullptr; }
-  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt); dev_free(h->d_absmax);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);

@@ -92,7 +92,9 @@ GPB_HIP_EXPORT int gpb_hip_pinned_alloc(size_t bytes, void** out);
 GPB_HIP_EXPORT int gpb_hip_pinned_free(void* p);
 /* y in Vecchia order (REModelTemplate::SetY, include/GPBoost/re_model_template.h:6185-6222).  A factor computed by gpb_hip_vecchia_factor stays
  * valid (A, D do not depend on y); u = B y is renewed for the new response at its next use (y_aux, get_factor) -- the GPBoost algorithm sets a new
- * response every boosting iteration at unchanged parameters (CalcGradientF, :3313-3316).  The full-scale (VIF) factor carries the response: it goes. */
+ * response every boosting iteration at unchanged parameters (CalcGradientF, :3313-3316).  The full-scale (VIF) factor carries the response: it goes.
+ * Rounding: the renewed u is y_i - sum_j A_ij y_nn(i,j) accumulated by fma over the STORED A (vecchia_By_pts_kernel), the factor kernel's u comes out of
+ * its elimination: equal to ~1e-16 relative, not bit for bit -- y_aux after set_y is not bit-identical to factor-then-y_aux at the same response. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y(gpb_hip_vecchia_t* h, const double* y_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_set_y_dev(gpb_hip_vecchia_t* h, const double* y_dev);
 

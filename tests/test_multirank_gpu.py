@@ -220,3 +220,40 @@ def test_mailbox_across_processes(lib_built):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_mailbox_multiprocess.py"), "2", "3"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "MAILBOX ACROSS PROCESSES: OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 4])
+def test_bench_starts_its_own_ranks_and_rehearses_on_one_device(lib_built, N):
+    """`python bench.py --gpus N` with NO launcher around it (the way the driver started N = 1): the script starts its own N ranks through
+    torch.distributed.run; on a box with fewer devices than ranks they rehearse on device 0 (gloo bootstrap, mailbox for the shard sums, RCCL down) and
+    walk the code of a real N-device launch after the bootstrap.  The line must say n_gpus = N, name the rehearsal, report N mailbox ranks, shards that
+    cover n, and the job's value must equal the one-process value of the same evaluation (the mailbox adds the shard sums in rank order: 1e-12)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    n = 200000
+
+    def run(gpus):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "4", "--warmup", "1", "--n", str(n),
+                            "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-3000:]
+        return json.loads(lines[0])
+
+    one = run(1)
+    out = run(N)
+    assert one["n_gpus"] == 1 and out["n_gpus"] == N
+    cfg = out["config"]
+    assert cfg["mailbox_ranks"] == N and cfg["per_rank"]["mailbox_ranks_seen"] == [N] * N
+    assert sum(cfg["per_rank"]["shard_points"]) == n and len(cfg["per_rank"]["kernel_ms"]) == N
+    import gpboost_amd
+    if gpboost_amd.device_count() < N:
+        assert cfg["rehearsal"] is True and cfg["rccl_ranks"] == 0 and "REHEARSAL" in out["metric"]
+    else:
+        assert cfg["rehearsal"] is False and cfg["rccl_ranks"] == N
+    assert abs(cfg["last_negll"] - one["config"]["last_negll"]) <= 1e-12 * abs(one["config"]["last_negll"])
+    assert out["roofline"]["kernel_ms"] <= out["ms_per_step"] and cfg["overhead_us"] >= 0.0
