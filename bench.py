@@ -146,7 +146,10 @@ def main():
     ap.add_argument("--cov", default="exponential", choices=["exponential", "matern_1.5", "matern_2.5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the metric's line: skip the other configurations' measurements reported next to it")
-    args = ap.parse_args()
+    # (the self-launcher below hands the ranks their arguments through GPB_BENCH_ARGV: torch.distributed.run's own parser would reject an
+    #  abbreviation-ambiguous script option such as --n before it ever reaches the script)
+    argv = json.loads(os.environ["GPB_BENCH_ARGV"]) if (len(sys.argv) == 1 and "GPB_BENCH_ARGV" in os.environ) else sys.argv[1:]
+    args = ap.parse_args(argv)
 
     # --gpus N without a launcher (WORLD_SIZE unset): this process becomes the launcher of its own N ranks -- the same command line the driver
     # uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...), so that
@@ -156,7 +159,8 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-port", str(port), os.path.abspath(__file__)]
+        os.environ["GPB_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,7 +194,17 @@ def main():
         if rehearsal:
             torch.cuda.set_device(0)
             gpboost_amd.set_device(0)
-            dist.init_process_group("gloo")
+            # (gloo announces its connections on STDOUT: keep the one JSON line alone there)
+            sys.stdout.flush()
+            saved_out = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_out, 1)
+                os.close(saved_out)
             if rank == 0:
                 print("bench.py: REHEARSAL -- %d ranks share device 0 (%d device(s) visible); gloo bootstrap, mailbox for the sums" % (world, ndev), file=sys.stderr)
         else:

@@ -94,20 +94,35 @@ def laplace_fixture(out_dir):
 
 
 def laplace_grad_fixture(out_dir):
-    """Gradients of the reference's approximate negative marginal log-likelihood wrt (log sigma1^2, log a), read off one plain
-    gradient-descent step of its optimiser (oracle/refdrv.py: ref_laplace_gradient) -- the pin of orc_vecchia_laplace_grad."""
+    """Gradients of the reference's approximate negative marginal log-likelihood wrt (log sigma1^2, log a) -- the pin of orc_vecchia_laplace_grad and of
+    the device gradient.  Three sets per case and likelihood:
+      *_grad_direct / *_negll_direct   the reference's OWN gradient routine (CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia,
+                                       likelihoods.h:6521-6700) called through oracle/ref_driver.cpp: refdrv_laplace_nll_grad with cg_delta_conv = 1e-8 and
+                                       delta_conv_mode_finding = 1e-13: no stopping-rule noise left (1e-10 thresholds move it by < 1.1e-9) -> the 1e-8 pin;
+      *_grad_tight                     read off one gradient-descent step of the reference's optimiser, cg_delta_conv = 1e-6 (round 3's pin; kept);
+      *_grad                           the same at the reference's DEFAULT thresholds (1e-2 / 1e-8): the looser, second assertion."""
     res = {}
     for name, c in cases.LAPLACE_CASES.items():
         for lik in ("bernoulli_logit", "bernoulli_probit", "poisson"):
             coords, y = cases.make_count_data(c) if lik == "poisson" else cases.make_binary_data(c)
             cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+            nll, gd, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, None, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"],
+                                                     cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode_finding=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+            res["%s_%s_grad_direct" % (name, lik)] = gd
+            res["%s_%s_negll_direct" % (name, lik)] = np.float64(nll)
+            print("laplace grad (CalcGradPars, cg 1e-8 / mode 1e-13)", name, lik, gd, "%.12f" % nll, flush=True)
+            # the same with fixed effects (the offset of the GPBoost algorithm)
+            fe = cases.laplace_fixed_effects(coords)
+            nllf, gf, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, fe, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"],
+                                                      cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode_finding=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+            res["%s_%s_fe_grad_direct" % (name, lik)] = gf
+            res["%s_%s_fe_negll_direct" % (name, lik)] = np.float64(nllf)
             g = refdrv.ref_laplace_gradient(coords, y, cp, lik, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
             res["%s_%s_grad" % (name, lik)] = g
-            print("laplace grad", name, lik, g, flush=True)
-            # the same with the CG threshold tightened from 1e-2 to 1e-6: no dependence on which iteration crosses the threshold
+            print("laplace grad (optimiser step, default thresholds)", name, lik, g, flush=True)
             gt = refdrv.ref_laplace_gradient(coords, y, cp, lik, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], cg_delta_conv=1e-6)
             res["%s_%s_grad_tight" % (name, lik)] = gt
-            print("laplace grad (cg_delta_conv = 1e-6)", name, lik, gt, flush=True)
+            print("laplace grad (optimiser step, cg_delta_conv = 1e-6)", name, lik, gt, flush=True)
     np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
 
 
@@ -496,6 +511,11 @@ def laplace_grad_F_fixture(out_dir):
                                           c["m"], c["ordering"], c["seed"])
             res["%s_%s_gradF" % (name, lik)] = g
             print("laplace grad F", name, lik, np.abs(g).max(), flush=True)
+            # the pin (round 5): the same at cases.LAPLACE_TIGHT (cg_delta_conv 1e-8, delta_conv_mode_finding 1e-13) -- no stopping-rule noise
+            gt = refdrv.ref_laplace_grad_F(coords, y, c["cov_pars"][0], lik, cases.laplace_fixed_effects(coords), c["cov_function"], c["shape"],
+                                           c["m"], c["ordering"], c["seed"], **cases.LAPLACE_TIGHT)
+            res["%s_%s_gradF_tight" % (name, lik)] = gt
+            print("laplace grad F (tight)", name, lik, np.abs(gt).max(), np.abs(gt - g).max(), flush=True)
     np.savez_compressed(os.path.join(out_dir, "laplace_gradF_ref.npz"), **res)
 
 

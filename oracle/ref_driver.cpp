@@ -321,6 +321,42 @@ int refdrv_laplace_grad_F(void* h, const double* y, const double* fixed_effects,
   }
 }
 
+/* Covariance-parameter gradient of the Laplace-approximated negative marginal log-likelihood, read off the reference's OWN gradient routine
+ * (REModelTemplate::CalcGradPars -> Likelihood::CalcGradNegMargLikelihoodLaplaceApproxVecchia, include/GPBoost/re_model_template.h:2050-2098,
+ * include/GPBoost/likelihoods.h:6521-6700) -- not off an optimiser step.  Sequence = the L-BFGS functor's (include/GPBoost/optim_utils.h:299-338):
+ * the public evaluation first (sets y, initialises the mode: what GPB_EvalNegLogLikelihood does, c_api.cpp:2849-2858), then
+ * CalcCovFactorOrModeAndNegLL at the transformed parameters (the mode finding restarts from the mode just found) and CalcGradPars.
+ * h: handle of the reference's own C API (REModel*); solver thresholds (cg_delta_conv, delta_conv_mode_finding) as set by GPB_SetOptimConfig before.
+ * cov_pars_orig = (sigma1^2, rho) [+ nothing: no auxiliary parameters here]; grad_out[k] = d(-mll) / d log(transformed parameter k) = wrt (log sigma1^2, log a).
+ * naux > 0 (likelihoods with auxiliary parameters, estimate_aux_pars): grad_out holds num_cov_par + naux entries, the last naux wrt log(aux). */
+__attribute__((visibility("default")))
+int refdrv_laplace_nll_grad(void* h, const double* y, const double* cov_pars_orig, const double* fixed_effects, int estimate_aux,
+                            double* nll_public, double* nll_functor, double* grad_out, int* ngrad_out) {
+  try {
+    auto* m = reinterpret_cast<REModel*>(h);
+    std::vector<double> cp(cov_pars_orig, cov_pars_orig + m->num_cov_pars_);
+    double negll = 0.;
+    m->EvalNegLogLikelihood(y, cp.data(), negll, fixed_effects, true, false);
+    *nll_public = negll;
+    if (m->matrix_format_ != "den_mat_t") { fprintf(stderr, "refdrv_laplace_nll_grad: matrix format %s\n", m->matrix_format_.c_str()); return -1; }
+    auto* t = m->re_model_den_.get();
+    vec_t orig = Eigen::Map<const vec_t>(cov_pars_orig, m->num_cov_pars_), trafo(m->num_cov_pars_);
+    t->TransformCovPars(orig, trafo);
+    if ((int)t->estimate_cov_par_index_.size() != m->num_cov_pars_) t->estimate_cov_par_index_ = std::vector<int>(m->num_cov_pars_, 1);
+    t->estimate_aux_pars_ = estimate_aux != 0 && t->NumAuxPars() > 0;
+    t->CalcCovFactorOrModeAndNegLL(trafo, fixed_effects);
+    *nll_functor = t->GetNegLogLikelihood();
+    vec_t grad_cov, grad_beta;
+    t->CalcGradPars(trafo, 1., true, false, grad_cov, grad_beta, false, false, fixed_effects, false);
+    for (int k = 0; k < (int)grad_cov.size(); ++k) grad_out[k] = grad_cov[k];
+    *ngrad_out = (int)grad_cov.size();
+    return 0;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_laplace_nll_grad: %s\n", e.what());
+    return -1;
+  }
+}
+
 /* ---- full-scale Vecchia ("VIF"), Gaussian likelihood: the reference's own REModel with gp_approx = "full_scale_vecchia" ----
  * refdrv_nll_grad works on such a handle unchanged (CalcGradPars dispatches to CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i,
  * include/GPBoost/re_model_template.h:2205-2330); the two functions below expose what its public API does not: the inducing points

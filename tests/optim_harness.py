@@ -55,9 +55,10 @@ class OracleLaplaceEvaluator(object):
     mode (warm start), its previous value (op 3) and the gradient of the current state (op 2)."""
 
     def __init__(self, orc, coords_ord, nn, cov_type, y_ord, likelihood, cg_max_num_it=1000, cg_max_num_it_tridiag=1000, num_rand_vec=50,
-                 cg_delta_conv=1e-2, fixed_effects_ord=None):
+                 cg_delta_conv=1e-2, fixed_effects_ord=None, delta_conv_mode=1e-8):
         self.orc, self.co, self.nn, self.ct, self.y, self.lik = orc, coords_ord, nn, cov_type, y_ord, likelihood
         self.cg, self.cgt, self.nrv, self.cgd = cg_max_num_it, cg_max_num_it_tridiag, num_rand_vec, cg_delta_conv
+        self.dcm = delta_conv_mode
         self.fe = fixed_effects_ord
         self.mode = None; self.mode_prev = None; self.grad = None
         self.calls = []
@@ -80,7 +81,7 @@ class OracleLaplaceEvaluator(object):
         nll, g, mode = self.orc.vecchia_laplace_grad(self.co, self.nn, self.ct, var, a, self.y, likelihood=self.lik, mode_init=self.mode,
                                                      want_mode=True, cg_max_num_it=int(round(self.cg / div)),
                                                      cg_max_num_it_tridiag=int(round(self.cgt / div)), num_rand_vec=self.nrv,
-                                                     cg_delta_conv=self.cgd, fixed_effects=self.fe)
+                                                     cg_delta_conv=self.cgd, fixed_effects=self.fe, delta_conv_mode=self.dcm)
         if self.mode_prev is None:
             self.mode_prev = np.zeros_like(mode)            # InitializeModeAvec: mode and its previous value start at 0
         self.mode, self.grad = mode, (g[0], g[1])

@@ -180,10 +180,17 @@ def test_host_optimiser_for_non_gaussian_likelihoods_follows_the_reference(lib_b
     rc_ = [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct]
     init = g[name + "_init_cov_pars"]
     fe = cases.laplace_fixed_effects(coords)[perm] if oc.get("fe") else None
-    ev = oh.OracleLaplaceEvaluator(orc, co, nn, ct, y[perm], oc["lik"], fixed_effects_ord=fe)
-    th, nit, nll, ne = oh.optimize_laplace(C.CDLL(lib_built), [init[0], rc_ / init[1]], ev, **_cfg_kwargs(oc["cfg"]))
+    solver = {k: oc["cfg"][k] for k in ("cg_delta_conv", "delta_conv_mode_finding") if k in oc["cfg"]}      # thresholds of the evaluator, not of the optimiser
+    ev = oh.OracleLaplaceEvaluator(orc, co, nn, ct, y[perm], oc["lik"], fixed_effects_ord=fe, cg_delta_conv=solver.get("cg_delta_conv", 1e-2),
+                                   delta_conv_mode=solver.get("delta_conv_mode_finding", 1e-8))
+    th, nit, nll, ne = oh.optimize_laplace(C.CDLL(lib_built), [init[0], rc_ / init[1]], ev,
+                                           **_cfg_kwargs({k: v for k, v in oc["cfg"].items() if k not in solver}))
     ref_it = int(g[name + "_num_it"])
-    if oc["exact_it"]:
+    if oc.get("tight"):      # tight solver thresholds (cases.LAPLACE_TIGHT): the fit is reproducible to the accuracy of its evaluations
+        assert nit == ref_it, (nit, ref_it)
+        np.testing.assert_allclose([th[0], rc_ / th[1]], g[name + "_cov_pars"], rtol=1e-6)
+        assert abs(nll - float(g[name + "_negll"])) <= 1e-8 * abs(nll)
+    elif oc["exact_it"]:
         assert nit == ref_it, (nit, ref_it)
         np.testing.assert_allclose([th[0], rc_ / th[1]], g[name + "_cov_pars"], rtol=1e-4)     # flat optimum: 2e-5 seen at nll agreement 1e-8
         assert abs(nll - float(g[name + "_negll"])) <= 1e-7 * abs(nll)

@@ -181,6 +181,16 @@ def test_oracle_laplace_gradient_matches_reference(orc, name, lik):
     a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
     negll, grad = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik)
     np.testing.assert_allclose(grad, g["%s_%s_grad" % (name, lik)], rtol=1e-5, atol=1e-5)
+    # THE PIN (round 5): the reference's own CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia (likelihoods.h:6521-6700) through
+    # oracle/ref_driver.cpp: refdrv_laplace_nll_grad at cg_delta_conv 1e-8 / delta_conv_mode_finding 1e-13 (cases.LAPLACE_TIGHT), where no stopping rule
+    # is left in the comparison: north_star's 1e-8 relative (observed <= 1e-9), value and gradient, without and with fixed effects
+    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+        negll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik, fixed_effects=fe,
+                                                   cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+        ref = g["%s_%s%s_grad_direct" % (name, lik, fe_key)]
+        np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+        ref_v = float(g["%s_%s%s_negll_direct" % (name, lik, fe_key)])
+        assert abs(negll_t - ref_v) <= 1e-10 * abs(ref_v), (negll_t, ref_v)
 
 
 def test_r_probit_fixture_oracle_vs_reference(orc):
@@ -526,3 +536,9 @@ def test_oracle_boosting_gradient_matches_the_reference(orc, name, lik):
     out = np.empty_like(gF); out[perm] = gF
     ref = g["%s_%s_gradF" % (name, lik)]
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+    # the pin (round 5): both sides at cases.LAPLACE_TIGHT -> 1e-8 of the gradient's scale
+    gFt = orc.vecchia_laplace_grad_F(co, nn, ct, cp[0], a, y[perm], likelihood=lik, fixed_effects=fe[perm],
+                                     cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    out_t = np.empty_like(gFt); out_t[perm] = gFt
+    ref_t = g["%s_%s_gradF_tight" % (name, lik)]
+    np.testing.assert_allclose(out_t, ref_t, rtol=0, atol=1e-8 * np.abs(ref_t).max())
