@@ -143,8 +143,15 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
   // MODE_NLL with MT > 30: left-looking Cholesky with lazily evaluated columns (see below).  Measured at n = 1e6 (profiles/r03_b_*):
   // MT = 40 (d = 3, Matern-2.5) 288 -> 166 VGPRs, one -> three wavefronts per SIMD, 3.3 -> 2.19 ms per launch; MT = 30 gains no
   // occupancy from it (118 -> 124 VGPRs, four wavefronts either way) and loses 4 % to the extra rsq / fences: it keeps the right-looking form.
-  constexpr bool kLeftLooking = !kNeedSolve && MT > 30;
+  // Round 5: the SOLVING modes with 30 < MT <= 46 (three register slots: config 5's m = 40) are left-looking too (kLeftSolve).  Right-looking they need
+  // the whole triangle, 89 doubles, live from the first sweep on: 256 VGPRs + 60 - 89 values in scratch (8.3 GB of scratch traffic per gradient launch
+  // at n = 1e6, profiles/r04_pmc.json).  Left-looking, what is live at column c is the columns < c of the slots that still have rows >= c, PLUS -- for
+  // the back-substitution -- the finished pieces above them: slot 0's 16 columns are parked in LDS ([column][thread], 32 KB per workgroup: two
+  // workgroups still fit a CU) once column 15 is done, slots 1 and 2 stay in registers (32 + 41 doubles): no scratch.  The factor is S = L sqrt(D)
+  // (Cholesky) with 1 / S_kk parked in the diagonal lane of column k's own slot; the back-substitution below solves S^T x = (row MT / MT + 1 of S).
+  constexpr bool kLeftLooking = MT > 30 && (!kNeedSolve || NS == 3);
 #endif
+  constexpr bool kLeftSolve = kLeftLooking && kNeedSolve;
   constexpr int NP = (MODE == MODE_GRAD) ? GPB_NUM_PARTIALS : 3;
 
   using Rec = RecT<D3>;
@@ -162,6 +169,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
   __shared__ double s_tab[GPB_EXP_TAB_SIZE];
   __shared__ __attribute__((aligned(16))) Rec s_pts[16][PSTRIDE];
   __shared__ double s_red[GPB_NUM_PARTIALS][16];
+  __shared__ double s_f0[kLeftSolve ? 16 : 1][kLeftSolve ? 256 : 1];   // kLeftSolve: slot 0's pieces of the factor's columns 0..15, [column][thread]
+  constexpr bool kDgInLds = (MODE == MODE_NLL) && kLeftLooking;      // (MT <= 30 keeps them in registers: four wavefronts per SIMD either way)
+  __shared__ double s_dg[kDgInLds ? 16 : 1][kDgInLds ? NS * 16 : 1];   // sample weights, MODE_NLL with MT > 30: diagonal entry (var + nugget_r) of every row of the point's system
   __shared__ double s_dk[NSTORE][kStoreDK ? 256 : 1];
   // (A~_r, b~_r) pairs of the contraction pass: with kStoreDK they live in the point's record block, which is dead by then (the same 16
   // lanes of one wavefront write and read it); the re-evaluating variant still needs the records and gets its own array
@@ -233,15 +243,21 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
   Rec own[NS];
   // sample weights (Gaussian likelihood: observation-specific nugget 1 / w on the transformed scale, GetGaussianNuggetDiagFromWeights,
   // re_model_template.h:6393-6417; Vecchia_utils.cpp:1418-1422, 1610-1614): own_dg[s] = diagonal entry of this lane's row of slot s
+  // MODE_NLL with MT > 30 (round 5): the entries wait in LDS, s_dg[point][row], not in NS doubles per lane that are live across the whole factorisation -- those had
+  // pushed the d = 3, MT = 40 likelihood instance from 166 to 174 VGPRs, i.e. from three wavefronts per SIMD to two: the 2.20 -> 2.42 ms regression of round 3.
+  // The solving modes are not register-limited at that point and MODE_GRAD with stored derivatives has no LDS to spare (two workgroups per CU): registers there.
   const bool weighted = args.nug != nullptr;           // (uniform)
-  double own_dg[NS];
+  double own_dg[kDgInLds ? 1 : NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) own_dg[s] = 0.0;
+  for (int s = 0; s < (kDgInLds ? 1 : NS); ++s) own_dg[s] = 0.0;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int r = 16 * s + ((s & 1) ? 15 - l : l);
     const int idx = cidx[s];
-    if (weighted) own_dg[s] = args.var + (idx >= 0 ? args.nug[idx] : 1.0);
+    if (weighted) {
+      const double dgv = args.var + (idx >= 0 ? args.nug[idx] : 1.0);
+      if constexpr (kDgInLds) s_dg[g][r] = dgv; else own_dg[s] = dgv;
+    }
     Rec p;
     if (idx >= 0) {
       const double4 q = args.pts[idx];
@@ -313,7 +329,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
       }
       // (2) diagonal (nugget / jitter, Vecchia_utils.cpp:1599-1609; first summand of D_i, :1555-1563) and the response row's entry
       {
-        const double dg = weighted ? own_dg[sc_] : ((c == MT) ? args.diag_i : args.diag_nn);   // (weighted: every lane offers its own row's entry, the mask picks the owner's)
+        double dg;      // (weighted: row c's entry by a broadcast read [MODE_NLL] / every lane offers its own row's entry [solving modes]; the mask picks the owner)
+        if constexpr (kDgInLds) dg = weighted ? s_dg[g][c] : ((c == MT) ? args.diag_i : args.diag_nn);
+        else dg = weighted ? own_dg[sc_] : ((c == MT) ? args.diag_i : args.diag_nn);
         if constexpr (c == 16 * sc_ + 15 || c == MT) M[sc_][c] = dg;     // own-slot piece never evaluated: plain init
         else set_lanes<row_lane_eq(lc)>(M[sc_][c], dg);
         set_lanes<row_lane_eq(L::YL)>(M[L::YS][c], gp[c].w);
@@ -333,12 +351,16 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
         const double e = __builtin_fma(-0.5 * piv * y0, y0, 0.5);
         const double rs = __builtin_fma(y0, e, y0);
         static_for<sc_, NS>([&](auto s_) { constexpr int s = decltype(s_)::value; M[s][c] *= rs; });
+        // kLeftSolve: the diagonal lane keeps 1 / S_cc (no update ever reads lane lc of column c's own slot: rows r > c only)
+        if constexpr (kLeftSolve) set_lanes<row_lane_eq(lc)>(M[sc_][c], rs);
         // the scaled column was written by plain multiplies (compiler-scheduled) and is a DPP source from the next column on: ONE fence
         static_assert(NS <= 4, "dpp_fence overloads cover four slots");
         if constexpr (NS - sc_ == 1) dpp_fence(M[sc_][c]);
         else if constexpr (NS - sc_ == 2) dpp_fence(M[sc_][c], M[sc_ + 1][c]);
         else if constexpr (NS - sc_ == 3) dpp_fence(M[sc_][c], M[sc_ + 1][c], M[sc_ + 2][c]);
         else dpp_fence(M[sc_][c], M[sc_ + 1][c], M[sc_ + 2][c], M[sc_ + 3][c]);
+        // kLeftSolve: slot 0's pieces are dead for the elimination once its last column is done -- parked in LDS for the back-substitution
+        if constexpr (kLeftSolve && c == 15) static_for<0, 16>([&](auto q_) { s_f0[decltype(q_)::value][tid] = M[0][decltype(q_)::value]; });
       }
     });
   } else {
@@ -371,7 +393,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
     constexpr int s = decltype(s_)::value;
     static_for<16 * s, L::cmax(s) + 1>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
-      const double dg = weighted ? own_dg[s] : ((c == MT) ? args.diag_i : args.diag_nn);
+      double dg;       // (weighted: every lane offers its own row's entry / row c's entry by a broadcast read, the mask picks the owner's)
+      if constexpr (kDgInLds) dg = weighted ? s_dg[g][c] : ((c == MT) ? args.diag_i : args.diag_nn);
+      else dg = weighted ? own_dg[s] : ((c == MT) ? args.diag_i : args.diag_nn);
       if constexpr (c == 16 * s + 15 || c == MT) M[s][c] = dg;     // column never evaluated: plain init
       else set_lanes<row_lane_eq(lane_of_row(c))>(M[s][c], dg);
     });
@@ -430,7 +454,34 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
     constexpr bool kLaneX = MT > 30;
     double X[kLaneX ? 1 : MT];
     double xa[NS], xb[NS];                          // kLaneX: A_r, b_r of this lane's rows
-    if constexpr (kLaneX) {
+    if constexpr (kLeftSolve) {
+      // S^T x = s (s = row MT / MT + 1 of S = S^-1 c / S^-1 y_nn): x_k = (s_k - sum_{r > k} S[r][k] x_r) / S_kk, lane r holds x_r of its own rows; the
+      // column's 16-lane sums as in the LDL^T form below, 1 / S_kk from the diagonal lane, slot 0's pieces from LDS
+      static_assert(NS == 3 && L::PS == 2 && L::YS == 2, "kLeftSolve: three slots, the point's and the response row in the last one");
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { xa[s] = 0.0; xb[s] = 0.0; }
+      static_for_down<0, MT>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        constexpr int sk = k / 16, lk = lane_of_row(k);
+        constexpr unsigned long long kKeep = (sk & 1) ? row_lanes_le(14 - (k % 16)) : ~row_lanes_le(k % 16);
+        double own_col;                       // column k's piece in its own slot
+        if constexpr (sk == 0) own_col = s_f0[k][tid]; else own_col = M[sk][k];
+        double ta = own_col * xa[sk], tb = own_col * xb[sk];
+        set_lanes<~kKeep>(ta, 0.0);
+        set_lanes<~kKeep>(tb, 0.0);
+        static_for<sk + 1, NS>([&](auto s_) {       // rows of later slots: MT, MT + 1 and the padding rows carry x = 0
+          constexpr int s = decltype(s_)::value;
+          ta = __builtin_fma(M[s][k], xa[s], ta);
+          tb = __builtin_fma(M[s][k], xb[s], tb);
+        });
+        ta = row_sum16(ta); tb = row_sum16(tb);
+        const double rk = GPB_ROW_BCAST(lk, own_col);               // 1 / S_kk  (row_bcast carries its own wait states)
+        const double la = GPB_ROW_BCAST(L::PL, M[L::PS][k]);        // S[MT][k]
+        const double lb = GPB_ROW_BCAST(L::YL, M[L::YS][k]);        // S[MT + 1][k]
+        set_lanes<row_lane_eq(lk)>(xa[sk], (la - ta) * rk);
+        set_lanes<row_lane_eq(lk)>(xb[sk], (lb - tb) * rk);
+      });
+    } else if constexpr (kLaneX) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) { xa[s] = 0.0; xb[s] = 0.0; }
       static_for_down<0, MT>([&](auto k_) {
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
         const int r = 16 * s + ((s & 1) ? 15 - l : l);
         abr[s] = gab[r]; ab_off[s] = r * (int)sizeof(double2);
         // variance parameter: dD = D - nug_i - sum_r nug_r A_r^2, (dB y)_i = -sum_r nug_r b_r A_r (uniform nugget 1 without weights)
-        const double nr = weighted ? own_dg[s] - args.var : 1.0;
+        const double nr = weighted ? own_dg[s] - args.var : 1.0;      // (MODE_GRAD: !kDgInLds)
         if (r < MT) { sAA = __builtin_fma(nr * abr[s].x, abr[s].x, sAA); sbA = __builtin_fma(nr * abr[s].y, abr[s].x, sbA); }
       });
       double accD = 0.0, accU = 0.0;
@@ -531,7 +582,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
       for_each_lower_step<MT>(
           [&](auto s_, auto c_, auto e_) {
             constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
-            accumulate(dk_of(e_, own[s], gp[c]), abr[s], gab[c]);
+            // (re-evaluating variant: the lane's own record is read back from LDS here -- as a register it would be live across the whole back-substitution)
+            if constexpr (kStoreDK) accumulate(dk_of(e_, own[s], gp[c]), abr[s], gab[c]);
+            else accumulate(dk_of(e_, *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + row_off[s]), gp[c]), abr[s], gab[c]);
           },
           [&](auto sA_, auto cA_, auto sB_, auto cB_, auto J_, auto e_) {
             constexpr int sA = decltype(sA_)::value, cA = decltype(cA_)::value, sB = decltype(sB_)::value,
@@ -551,7 +604,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
           [&](auto s_, auto c_, auto e_) {
             constexpr int s = decltype(s_)::value, c = decltype(c_)::value;
             static_assert((s & 1) == 0, "solo steps only occur in even slots");
-            double dk = dk_of(e_, own[s], gp[c]);
+            double dk;
+            if constexpr (kStoreDK) dk = dk_of(e_, own[s], gp[c]);
+            else dk = dk_of(e_, *reinterpret_cast<const Rec*>(reinterpret_cast<const char*>(gp) + row_off[s]), gp[c]);
             set_lanes<row_lanes_le(c - 16 * s)>(dk, 0.0);              // rows <= c: entries on / above the diagonal do not exist
             accumulate(dk, abr[s], gab[c]);
           });
