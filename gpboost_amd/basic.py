@@ -138,7 +138,10 @@ class GPModel(object):
 
     # --- reference surface -------------------------------------------------------------------
     def neg_log_likelihood(self, cov_pars=None, y=None, fixed_effects=None, aux_pars=None):
-        """Evaluate the negative log-likelihood (reference: basic.py:5640-5700)."""
+        """Evaluate the negative log-likelihood (reference: basic.py:5640-5700); aux_pars: the likelihood's auxiliary parameters ("gamma" /
+        "negative_binomial": the shape), set as the reference's package does it -- set_optim_params({"init_aux_pars": aux_pars}) (basic.py:5688-5690)."""
+        if aux_pars is not None:
+            self.set_optim_params({"init_aux_pars": aux_pars})
         y_c = ctypes.c_void_p()        # None -> NULL: the response already resident on the device is used (C-level semantics of
         if y is not None:              # GPB_EvalNegLogLikelihood, re_model_template.h:2905-2921: SetY only for a non-NULL y_data)
             y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
@@ -169,14 +172,17 @@ class GPModel(object):
         "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999., "cg_preconditioner_type": "",
         # non-Gaussian models with covariates: start of the coefficients in the lbfgs vector; default as in the reference's packages: the fit of the
         # same likelihood without the Gaussian process (init_coef_aux_pars_from_iid_model, re_model.cpp:380-470)
-        "init_coef": None, "init_coef_aux_pars_from_iid_model": True}
+        "init_coef": None, "init_coef_aux_pars_from_iid_model": True,
+        # likelihoods with auxiliary parameters (gamma / negative_binomial: the shape): initial values and whether they are estimated (basic.py:5420-5440)
+        "init_aux_pars": None, "estimate_aux_pars": True}
 
     def set_optim_params(self, params):
         """Optimiser and iterative-method settings (reference: GPModel.set_optim_params, basic.py:5238-5420 -> GPB_SetOptimConfig).
         Estimation: 'optimizer_cov' ("lbfgs" | "gradient_descent" | "nelder_mead"), 'init_cov_pars', 'lr_cov', 'acc_rate_cov', 'maxit',
         'delta_rel_conv', 'use_nesterov_acc', 'nesterov_schedule_version', 'momentum_offset', 'convergence_criterion', 'm_lbfgs',
         'estimate_cov_par_index' (0 = hold a covariance parameter at its initial value: (error variance, GP variance, range) for Gaussian models, (GP variance, range) for non-Gaussian ones with 'lbfgs'), 'trace', 'init_coef', 'init_coef_aux_pars_from_iid_model'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
-        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'.  Anything else raises: no silent ignore."""
+        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'; likelihoods with auxiliary parameters ("gamma", "negative_binomial"):
+        'init_aux_pars', 'estimate_aux_pars'.  Anything else raises: no silent ignore."""
         if not hasattr(self, "_optim_params"):
             self._optim_params = dict(self._OPTIM_DEFAULTS)
         for k in params:
@@ -199,6 +205,12 @@ class GPModel(object):
         if o["init_coef"] is not None:
             icoef = np.ascontiguousarray(o["init_coef"], dtype=np.float64).reshape(-1)
             ncov_c, icoef_c = icoef.shape[0], _dptr(icoef)
+        iaux_c = ctypes.c_void_p()
+        if o["init_aux_pars"] is not None:
+            iaux = np.ascontiguousarray(np.atleast_1d(o["init_aux_pars"]), dtype=np.float64).reshape(-1)
+            if iaux.shape[0] != self.get_num_aux_pars():
+                raise ValueError("params['init_aux_pars'] does not contain the correct number of parameters")
+            iaux_c = _dptr(iaux)
         _safe_call(_lib().GPB_SetOptimConfig(
             self.handle, init_c, ctypes.c_double(float(o["lr_cov"])), ctypes.c_double(float(o["acc_rate_cov"])), ctypes.c_int(int(o["maxit"])),
             ctypes.c_double(float(o["delta_rel_conv"])), ctypes.c_bool(bool(o["use_nesterov_acc"])),
@@ -208,7 +220,7 @@ class GPModel(object):
             ctypes.c_int(int(o["cg_max_num_it"])), ctypes.c_int(int(o["cg_max_num_it_tridiag"])),
             ctypes.c_double(float(o["cg_delta_conv"])), ctypes.c_int(int(o["num_rand_vec_trace"])), ctypes.c_bool(True),
             c_str(o["cg_preconditioner_type"]), ctypes.c_int(int(o["seed_rand_vec_trace"])), ctypes.c_int(-999),
-            ctypes.c_void_p(), ctypes.c_bool(False), ctypes.c_bool(bool(o["init_coef_aux_pars_from_iid_model"])), est.ctypes.data_as(ctypes.c_void_p),
+            iaux_c, ctypes.c_bool(bool(o["estimate_aux_pars"])), ctypes.c_bool(bool(o["init_coef_aux_pars_from_iid_model"])), est.ctypes.data_as(ctypes.c_void_p),
             ctypes.c_int(int(o["m_lbfgs"])),
             ctypes.c_double(float(o["delta_conv_mode_finding"]))))
         self._optim_params = o          # only settings the library accepted are remembered
@@ -244,6 +256,22 @@ class GPModel(object):
             return self
         _safe_call(_lib().GPB_OptimCovPar(self.handle, _dptr(y), fe_c))
         return self
+
+    def get_num_aux_pars(self):
+        """Number of auxiliary parameters of the likelihood (GPB_GetNumAuxPars): 1 (the shape) for "gamma" / "negative_binomial", else 0."""
+        k = ctypes.c_int(0)
+        _safe_call(_lib().GPB_GetNumAuxPars(self.handle, ctypes.byref(k)))
+        return k.value
+
+    def get_aux_pars(self):
+        """Auxiliary parameters of the likelihood on the original scale (reference: GPModel.get_aux_pars, basic.py:6372-6400 -> GPB_GetAuxPars);
+        None for likelihoods without any."""
+        k = self.get_num_aux_pars()
+        if k == 0:
+            return None
+        out = np.empty(k); name = ctypes.create_string_buffer(256)
+        _safe_call(_lib().GPB_GetAuxPars(self.handle, _dptr(out), name, ctypes.c_bool(False)))
+        return out
 
     def get_coef(self, std_err=False):
         """Estimated linear regression coefficients (reference: GPModel.get_coef, basic.py:6332-6370 -> GPB_GetCoef)."""

@@ -90,6 +90,10 @@ struct REModelHip {
   int cg_max_num_it = 1000, cg_max_num_it_tridiag = 1000, num_rand_vec_trace = 50, seed_rand_vec_trace = 1;
   double cg_delta_conv = 1e-2, delta_conv_mode_finding = 1e-8;
   std::vector<int> labels;      // y in {0,1}, Vecchia order
+  // likelihoods with an auxiliary parameter (round 5: gamma, negative_binomial -- the shape; likelihoods.h:298-322): num_aux_pars_, aux_pars_ (original
+  // scale), AuxParsHaveBeenSet(), init_aux_pars_ / init_aux_pars_given_ (re_model.cpp:327-344), estimate_aux_pars_ (re_model_template.h:909-912)
+  int num_aux = 0; double aux_pars[1] = {1.}; bool aux_set = false; double init_aux[1] = {-1.}; bool init_aux_given = false; bool estimate_aux_pars = true;
+  std::vector<double> resp_real;   // gamma: the real-valued response, Vecchia order
   // repeated locations of a non-Gaussian model (the reference's unique-location mapping, Vecchia_utils.cpp:1156-1168, re_comp.h:863-885): the
   // Vecchia handle lives on the n_re unique locations; datum at shuffled position k belongs to random effect re_of[k]; dorder lists the
   // shuffled positions grouped by random effect (stable), re_ptr is the CSR of that grouping.  n_re == 0: no repeated locations.
@@ -166,6 +170,47 @@ int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr
   return 0;
 }
 
+int laplace_link_id(const std::string& lik) {
+  return lik == "bernoulli_probit" ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : 0)));
+}
+bool supported_non_gaussian(const std::string& lik) {
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial";
+}
+int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial") ? 1 : 0; }
+// the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
+int laplace_push_aux(REModelHip* mdl) {
+  if (mdl->num_aux < 1) return 0;
+  if (gpb_hip_vecchia_laplace_set_aux_pars(mdl->vh, mdl->aux_pars, mdl->num_aux)) return shim_error();
+  return 0;
+}
+// Likelihood::FindInitialAuxPars (likelihoods.h:1851-1947) for gamma (approximate MLE of the shape ignoring the effects) and negative_binomial
+// (method of moments); y, fixed_effects in data order
+double initial_aux_par(const std::string& lik, int n, const double* y, const double* fe) {
+  if (lik == "gamma") {
+    double log_avg = 0., avg_log = 0.;
+    for (int i = 0; i < n; ++i) {
+      if (fe) { log_avg += y[i] / std::exp(fe[i]); avg_log += std::log(y[i]) - fe[i]; }
+      else { log_avg += y[i]; avg_log += std::log(y[i]); }
+    }
+    log_avg = std::log(log_avg / n); avg_log /= n;
+    const double s = std::max(log_avg - avg_log, 1e-8);
+    return (3. - s + std::sqrt((s - 3.) * (s - 3.) + 24. * s)) / (12. * s);
+  }
+  if (lik == "negative_binomial") {
+    double avg = 0., sum_sq = 0.;
+    for (int i = 0; i < n; ++i) { const double v = fe ? y[i] / std::exp(fe[i]) : y[i]; avg += v; sum_sq += v * v; }
+    avg /= n;
+    const double avg_sq = avg * avg;
+    const double sample_var = std::max((sum_sq - n * avg_sq) / (n - 1), 1e-6);
+    return sample_var <= avg ? 100 * avg_sq : avg_sq / (sample_var - avg);
+  }
+  return 1.;
+}
+void find_initial_aux_pars(REModelHip* mdl, const double* y, const double* fe) {
+  mdl->aux_pars[0] = initial_aux_par(mdl->likelihood, mdl->n, y, fe);
+  mdl->aux_set = true;
+}
+
 // location parameter = mode + fixed effects (likelihoods.h:3861-3870), Vecchia order; NULL clears the offset
 int laplace_upload_fixed_effects(REModelHip* mdl, const double* fixed_effects) {
   if (fixed_effects) {
@@ -181,7 +226,24 @@ int laplace_upload_fixed_effects(REModelHip* mdl, const double* fixed_effects) {
 int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fixed_effects) {
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   mdl->labels.resize(mdl->n);
-  const bool poisson = mdl->likelihood == "poisson";
+  const bool poisson = mdl->likelihood == "poisson" || mdl->likelihood == "negative_binomial";     // integer-valued responses >= 0
+  if (mdl->likelihood == "gamma") {                       // likelihoods.h:1365-1373: strictly positive, real-valued
+    mdl->resp_real.resize(mdl->n);
+    for (int k = 0; k < mdl->n; ++k) {
+      const double yk = y_data[mdl->perm[k]];
+      if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
+      mdl->resp_real[k] = yk; mdl->labels[k] = 0;
+    }
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, 3)) return shim_error();
+    if (mdl->n_re > 0) {
+      std::vector<double> grouped(mdl->n);
+      for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
+      if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, grouped.data())) return shim_error();
+    } else if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, mdl->resp_real.data())) return shim_error();
+    if (laplace_push_aux(mdl)) return -1;
+    mdl->y_set = true;
+    return laplace_upload_fixed_effects(mdl, fixed_effects);
+  }
   for (int k = 0; k < mdl->n; ++k) {
     const double yk = y_data[mdl->perm[k]];
     if (poisson) {                                        // likelihoods.h:1338-1350
@@ -196,12 +258,13 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
       return set_error("The response variable ('y') needs to be 0 or 1 for likelihood = '%s' ", mdl->likelihood.c_str());
     mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
   }
-  if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, mdl->likelihood == "bernoulli_probit" ? 1 : (poisson ? 2 : 0))) return shim_error();
+  if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, laplace_link_id(mdl->likelihood))) return shim_error();
   if (mdl->n_re > 0) {
     std::vector<int> grouped(mdl->n);
     for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->labels[mdl->dorder[g]];
     if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, grouped.data())) return shim_error();
   } else if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
+  if (laplace_push_aux(mdl)) return -1;
   mdl->y_set = true;
   return laplace_upload_fixed_effects(mdl, fixed_effects);
 }
@@ -228,6 +291,29 @@ int device_laplace(void* ctx, int op_in, double var, double a, double* out3) {
   double g2[2];
   if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(cg, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
   out3[1] = g2[0]; out3[2] = g2[1];
+  return 0;
+}
+
+// gpb_laplace_aux_fn (gpb_optim.h) on the device: likelihoods whose auxiliary parameters are estimated with the covariance parameters
+int device_laplace_aux(void* ctx, int op, double var, double a, const double* aux, int naux, double* out) {
+  auto* mdl = static_cast<REModelHip*>(ctx);
+  if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
+  if (op == 4) { mdl->lap_fit_first_eval = true; return 0; }
+  if (op == 0 || op == 1) {
+    for (int j = 0; j < naux && j < 1; ++j) mdl->aux_pars[j] = aux[j];      // SetAuxPars at every evaluation (optim_utils.h:279-282)
+    mdl->aux_set = true;
+    if (laplace_push_aux(mdl)) return -1;
+    const int reset = mdl->lap_fit_first_eval ? 1 : 0;
+    if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(mdl->cg_max_num_it, 1),
+                                     std::max(mdl->cg_max_num_it_tridiag, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
+    mdl->lap_fit_first_eval = false;
+    out[0] = -mdl->lap_info[0];
+    if (op == 0) return 0;
+  }
+  double g2[2], g4[4];
+  if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(mdl->cg_max_num_it, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
+  if (gpb_hip_vecchia_laplace_grad_aux_current(mdl->vh, g4)) return -1;
+  out[1] = g2[0]; out[2] = g2[1]; out[3] = g4[0];
   return 0;
 }
 
@@ -715,7 +801,23 @@ double resp_mean_logit(double latent_mean, double latent_var, double delta, cons
 }
 
 // in place: latent (mean, var) -> response (mean, var if predict_var); false = likelihood not on the path
-bool predict_response_host(const std::string& lik, int n, double* mean, double* var, bool predict_var, double delta) {
+bool predict_response_host(const std::string& lik, int n, double* mean, double* var, bool predict_var, double delta, double aux = 1.0) {
+  if (lik == "gamma") {                     // likelihoods.h:9715-9728
+    for (int i = 0; i < n; ++i) {
+      const double pm = std::exp(mean[i] + 0.5 * var[i]);
+      if (predict_var) var[i] = (std::exp(var[i]) - 1.) * pm * pm + std::exp(2 * mean[i] + 2 * var[i]) / aux;
+      mean[i] = pm;
+    }
+    return true;
+  }
+  if (lik == "negative_binomial") {         // likelihoods.h:9783-9793
+    for (int i = 0; i < n; ++i) {
+      const double pm = std::exp(mean[i] + 0.5 * var[i]);
+      if (predict_var) var[i] = std::exp(2 * (mean[i] + var[i])) * (1 + 1 / aux) + pm * (1 - pm);
+      mean[i] = pm;
+    }
+    return true;
+  }
   if (lik == "bernoulli_probit") {
     for (int i = 0; i < n; ++i) { mean[i] = normal_cdf(mean[i] / std::sqrt(1.0 + var[i])); if (predict_var) var[i] = mean[i] * (1.0 - mean[i]); }
     return true;
@@ -1022,7 +1124,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   std::string lik_name = lik;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
   if (lik == "binary_probit") lik_name = "bernoulli_probit";
   if (lik == "binary" || lik == "binary_logit") lik_name = "bernoulli_logit";
-  if (lik_name != "gaussian" && lik_name != "bernoulli_logit" && lik_name != "bernoulli_probit" && lik_name != "poisson") return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  if (lik_name != "gaussian" && !supported_non_gaussian(lik_name)) return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
   if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
     if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
@@ -1042,7 +1144,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
-  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_neighbors = num_neighbors;
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); mdl->num_neighbors = num_neighbors;
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
@@ -1154,7 +1256,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
                        const char* convergence_criterion, int num_covariates, double* init_coef, double /*lr_coef*/,
                        double /*acc_rate_coef*/, const char* optimizer_coef, int cg_max_num_it, int cg_max_num_it_tridiag,
                        double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/, const char* cg_preconditioner_type,
-                       int seed_rand_vec_trace, int /*piv_chol_rank*/, double* /*init_aux_pars*/, bool estimate_aux_pars,
+                       int seed_rand_vec_trace, int /*piv_chol_rank*/, double* init_aux_pars, bool estimate_aux_pars,
                        bool init_coef_aux_pars_from_iid_model, const int* estimate_cov_par_index, int m_lbfgs,
                        double delta_conv_mode_finding) {
   C_API_BEGIN();
@@ -1164,8 +1266,14 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   auto* mdl0 = reinterpret_cast<REModelHip*>(handle);
   if (init_coef && num_covariates > 0) mdl0->init_coef.assign(init_coef, init_coef + num_covariates); else mdl0->init_coef.clear();
   mdl0->init_coef_from_iid_model = init_coef_aux_pars_from_iid_model;
-  (void)estimate_aux_pars;   // the reference's packages pass true by default; none of the supported likelihoods has auxiliary parameters (NumAuxPars = 0), so there is nothing to estimate
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  // auxiliary parameters (gamma / negative_binomial; re_model.cpp:327-344, re_model_template.h:909-912): initial values are applied at once (SetAuxPars)
+  mdl->estimate_aux_pars = estimate_aux_pars;
+  if (init_aux_pars && mdl->num_aux > 0) {
+    if (!(init_aux_pars[0] > 0.)) return set_error("The shape parameter is not > 0 (found %g)", init_aux_pars[0]);
+    mdl->init_aux[0] = init_aux_pars[0]; mdl->aux_pars[0] = init_aux_pars[0];
+    mdl->init_aux_given = true; mdl->aux_set = true;
+  } else mdl->init_aux_given = false;
   if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) {          // re_model_template.h:930-936
     if (mdl->likelihood != "gaussian") {      // two covariance parameters (sigma1_2, rho): lbfgs leaves the ones marked 0 at their initial values
       mdl->optim.estimate_cov_par_index[0] = estimate_cov_par_index[0]; mdl->optim.estimate_cov_par_index[1] = estimate_cov_par_index[1];
@@ -1261,7 +1369,7 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     const double sigma1_2 = cov_pars[0], rho = cov_pars[1];
     if (!(sigma1_2 > 0.) || !(rho > 0.)) return set_error("Covariance parameters need to be positive (found %g, %g)", sigma1_2, rho);
     if (y_data) { if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1; }
-    else if (laplace_upload_fixed_effects(mdl, fixed_effects)) return -1;   // labels stay resident; the offset is this call's
+    else { if (laplace_upload_fixed_effects(mdl, fixed_effects)) return -1; if (laplace_push_aux(mdl)) return -1; }   // labels stay resident; the offset and the auxiliary parameters are this call's
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
                                       mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,
@@ -1320,12 +1428,35 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
     if (mdl->optimizer_unsupported_alias) return set_error("GPB_OptimCovPar: this variant of optimizer_cov %s", scope);
     if (!y_data) return set_error("GPB_OptimCovPar: y_data is NULL");
     if (initialize_cov_pars_if_not_defined(mdl, y_data, fixed_effects)) return -1;                  // re_model.cpp:487-491
+    // initial values of the auxiliary parameters if none were given (re_model_template.h:1332-1349)
+    if (mdl->num_aux > 0 && mdl->estimate_aux_pars && !mdl->aux_set) find_initial_aux_pars(mdl, y_data, fixed_effects);
     if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1;
     mdl->lap_fit_first_eval = true;
     GpbOptimConfig cfg = mdl->optim;
     cfg.range_const = range_const(mdl);
     char err[512] = "";
     GpbLaplaceOptimResult res;
+    if (mdl->num_aux > 0 && mdl->estimate_aux_pars) {      // the shape is part of the lbfgs vector (optim_utils.h:256-283)
+      GpbLaplaceAuxResult ra;
+      double aux[1] = {mdl->aux_pars[0]};
+      if (gpb_optimize_laplace_cov_aux_pars(cfg, device_laplace_aux, mdl, mdl->num_aux, mdl->cov_pars_tr, aux, &ra, err, (int)sizeof(err))) {
+        const char* why = gpb_hip_get_last_error();
+        if (err[0] && why && why[0]) return set_error("%s: %s", err, why);
+        return err[0] ? set_error("%s", err) : shim_error();
+      }
+      if (cfg.max_iter > 0) {
+        mdl->cov_pars_tr[0] = ra.theta[0]; mdl->cov_pars_tr[1] = ra.theta[1];
+        mdl->aux_pars[0] = aux[0];
+        if (laplace_push_aux(mdl)) return -1;
+        mdl->cur_negll = ra.negll;
+        mdl->negll_valid = true;
+      }
+      mdl->num_it = ra.num_it;
+      res.theta[0] = ra.theta[0]; res.theta[1] = ra.theta[1]; res.num_it = ra.num_it; res.negll = ra.negll; res.num_evals = ra.num_evals;
+      mdl->last_fit_lap = res;
+      mdl->model_has_been_estimated = true;
+      return 0;
+    }
     if (gpb_optimize_laplace_cov_pars(cfg, device_laplace, mdl, mdl->cov_pars_tr, &res, err, (int)sizeof(err))) {
       const char* why = gpb_hip_get_last_error();           // what the device path said, not only "evaluation failed"
       if (err[0] && why && why[0]) return set_error("%s: %s", err, why);
@@ -1490,6 +1621,39 @@ int GPB_HIP_OptimizeLaplaceWithCallback(const double* init_theta2, const char* o
   if (num_it) *num_it = res.num_it;
   if (negll) *negll = res.negll;
   if (num_evals) *num_evals = res.num_evals;
+  C_API_END();
+}
+
+/* Test seam and host half of GPB_OptimCovPar for likelihoods whose auxiliary parameters are estimated with the covariance parameters (gamma,
+   negative_binomial): lbfgs on (log sigma1_2, log a, log aux) with the evaluation callback of gpb_laplace_aux_fn (gpb_optim.h). */
+int GPB_HIP_OptimizeLaplaceAuxWithCallback(const double* init_theta2, const double* init_aux, int naux, double lr_cov, int max_iter, double delta_rel_conv,
+                                           int m_lbfgs, int (*eval)(void*, int, double, double, const double*, int, double*), void* ctx,
+                                           double* theta_out2, double* aux_out, int* num_it, double* negll, int* num_evals) {
+  C_API_BEGIN();
+  if (!init_theta2 || !init_aux || !eval || !theta_out2 || !aux_out || naux < 1 || naux > 8) return set_error("GPB_HIP_OptimizeLaplaceAuxWithCallback: invalid argument");
+  GpbOptimConfig cfg;
+  if (lr_cov > 0.) cfg.lr_cov_init = lr_cov;
+  if (max_iter >= 0) cfg.max_iter = max_iter;
+  if (delta_rel_conv > 0.) cfg.delta_rel_conv_init = delta_rel_conv;
+  if (m_lbfgs > 0) cfg.m_lbfgs = m_lbfgs;
+  char err[512] = "";
+  GpbLaplaceAuxResult res;
+  std::vector<double> aux(init_aux, init_aux + naux);
+  if (gpb_optimize_laplace_cov_aux_pars(cfg, eval, ctx, naux, init_theta2, aux.data(), &res, err, (int)sizeof(err)))
+    return set_error("%s", err[0] ? err : "evaluation callback failed");
+  theta_out2[0] = res.theta[0]; theta_out2[1] = res.theta[1];
+  std::copy(aux.begin(), aux.end(), aux_out);
+  if (num_it) *num_it = res.num_it;
+  if (negll) *negll = res.negll;
+  if (num_evals) *num_evals = res.num_evals;
+  C_API_END();
+}
+
+int GPB_HIP_FindInitialAuxParsHost(const char* likelihood, int32_t n, const double* y, const double* fixed_effects, double* aux_out) {
+  C_API_BEGIN();
+  if (!likelihood || !y || !aux_out || n < 2) return set_error("GPB_HIP_FindInitialAuxParsHost: invalid argument");
+  if (num_aux_of(likelihood) < 1) return set_error("GPB_HIP_FindInitialAuxParsHost: likelihood '%s' has no auxiliary parameters on this path", likelihood);
+  aux_out[0] = initial_aux_par(likelihood, n, y, fixed_effects);
   C_API_END();
 }
 
@@ -1928,7 +2092,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (fixed_effects_pred) for (int k = 0; k < npl; ++k) mu[k] += fixed_effects_pred[k];
     if (mdl->p_cov > 0) for (int j = 0; j < mdl->p_cov; ++j) for (int k = 0; k < npl; ++k) mu[k] += covariate_data_pred[(size_t)j * npl + k] * mdl->beta[j];   // + X_pred beta (:3868-3880)
     if (predict_response) {
-      if (!predict_response_host(mdl->likelihood, npl, mu.data(), var.data(), predict_var, mdl->delta_conv_mode_finding))
+      if (!predict_response_host(mdl->likelihood, npl, mu.data(), var.data(), predict_var, mdl->delta_conv_mode_finding, mdl->aux_pars[0]))
         return set_error("GPB_PredictREModel: response predictions for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
     }
     std::copy(mu.begin(), mu.end(), out_predict);
@@ -2460,13 +2624,14 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   if (lik == "binary" || lik == "binary_logit") lik = "bernoulli_logit";
   if (mdl->model_has_been_estimated && lik != mdl->likelihood) return set_error("Cannot change likelihood after a model has been estimated ");   // re_model.cpp:154-160
   if (lik == mdl->likelihood) return 0;
-  if (lik != "gaussian" && lik != "bernoulli_logit" && lik != "bernoulli_probit" && lik != "poisson")
+  if (lik != "gaussian" && !supported_non_gaussian(lik))
     return set_error("GPB_SetLikelihood: likelihood '%s' is not on the MI355X hot path of this library", likelihood);
   if (lik != "gaussian" && (mdl->eh || mdl->vhs.size() != 1)) return set_error("GPB_SetLikelihood: likelihood '%s' needs gp_approx 'vecchia' and one cluster on this path", likelihood);
   if (lik != "gaussian" && mdl->has_duplicates) return set_error(kDuplicatesNonGaussianMessage);
   if (lik == "gaussian" && mdl->n_re > 0)
     return set_error("GPB_SetLikelihood: this model was created with repeated locations under a non-Gaussian likelihood -- its Vecchia approximation lives on the %d unique locations (Vecchia_utils.cpp:1156-1168); create a new model for the Gaussian likelihood", mdl->n_re);
   mdl->likelihood = lik;
+  mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = 1.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
   mdl->cov_pars_initialized = false; mdl->init_cov_pars_provided = false; mdl->negll_valid = false; mdl->y_set = false; mdl->yaux_valid = false;
   C_API_END();
 }
@@ -2477,6 +2642,7 @@ int GPB_GetResponseData(REModelHandle handle, double* response_data) {
   if (!mdl || !response_data) return set_error("GPB_GetResponseData: null argument");
   if (!mdl->y_set) return set_error("Respone variable data has not been set");      // re_model_template.h:6258-6261 (sic)
   if (mdl->likelihood == "gaussian") { std::copy(mdl->y_host.begin(), mdl->y_host.end(), response_data); }   // y_vec_: the response as passed in
+  else if (mdl->likelihood == "gamma") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
   else { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = (double)mdl->labels[k]; }
   C_API_END();
 }
@@ -2507,20 +2673,27 @@ int GPB_SetOffsetData(REModelHandle handle, const double* fixed_effects) {
   C_API_END();
 }
 
-int GPB_GetAuxPars(REModelHandle handle, double* /*aux_pars*/, char* out_str, bool /*calc_std_dev*/) {
-  if (!handle) return set_error("GPB_GetAuxPars: null handle");
-  if (out_str) out_str[0] = 0;                        // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
+int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool calc_std_dev) {
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_GetAuxPars: null handle");
+  if (mdl->num_aux < 1) { if (out_str) out_str[0] = 0; return 0; }      // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
+  if (calc_std_dev) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters are not on the MI355X path of this library");
+  if (aux_pars) aux_pars[0] = mdl->aux_pars[0];       // REModel::GetAuxPars (re_model.cpp:1408-1421), original scale
+  if (out_str) std::strcpy(out_str, "shape");         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319)
   return 0;
 }
 
 int GPB_GetNumAuxPars(REModelHandle handle, int* num_aux_pars) {
-  if (!handle || !num_aux_pars) return set_error("GPB_GetNumAuxPars: null argument");
-  num_aux_pars[0] = 0;                                // gaussian / bernoulli_logit / bernoulli_probit / poisson have none (likelihoods.h: num_aux_pars_)
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl || !num_aux_pars) return set_error("GPB_GetNumAuxPars: null argument");
+  num_aux_pars[0] = mdl->num_aux;                     // gaussian / bernoulli_logit / bernoulli_probit / poisson have none (likelihoods.h: num_aux_pars_)
   return 0;
 }
 
-int GPB_GetInitAuxPars(REModelHandle handle, double* /*aux_pars*/) {
-  if (!handle) return set_error("GPB_GetInitAuxPars: null handle");
+int GPB_GetInitAuxPars(REModelHandle handle, double* aux_pars) {
+  auto* mdl = reinterpret_cast<REModelHip*>(handle);
+  if (!mdl) return set_error("GPB_GetInitAuxPars: null handle");
+  if (mdl->num_aux > 0 && aux_pars) aux_pars[0] = mdl->init_aux_given ? mdl->init_aux[0] : -1.;      // re_model.cpp:1423-1434: -1 = found internally
   return 0;
 }
 

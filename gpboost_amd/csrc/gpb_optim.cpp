@@ -834,6 +834,16 @@ struct LapCoefState {
   double negll = 0.;
   int nc = 2;                       // covariance entries at the head of the lbfgs vector: 2 = (log var, log a), 0 = held at th_fixed
   double th_fixed[2] = {1., 1.};
+  // likelihoods with auxiliary parameters (no covariates: p = 0): naux entries log(aux) at the TAIL of the vector (optim_utils.h:256-283), evaluator afn
+  gpb_laplace_aux_fn afn = nullptr; int naux = 0;
+  int eval_aux(const double* x, int op, double* grad) {
+    double auxv[8], o[3 + 8] = {0};
+    for (int j = 0; j < naux; ++j) auxv[j] = std::exp(x[nc + p + j]);
+    if (afn(ctx, op, var_of(x), a_of(x), auxv, naux, o)) return -1;
+    if (op != 2) { ++n_evals; negll = o[0]; }
+    if (op >= 1 && grad) { if (nc) { grad[0] = o[1]; grad[1] = o[2]; } for (int j = 0; j < naux; ++j) grad[nc + p + j] = o[3 + j]; }
+    return 0;
+  }
   double var_of(const double* x) const { return nc ? std::exp(x[0]) : th_fixed[0]; }
   double a_of(const double* x) const { return nc ? std::exp(x[1]) : th_fixed[1]; }
   void linear_predictor(const double* beta) {                        // UpdateFixedEffects: fixed_effects + X beta (non-Gaussian)
@@ -845,6 +855,7 @@ struct LapCoefState {
   }
   // x = (log var, log a, beta) [nc = 2] or (beta) [nc = 0]; grad (nc + p) filled if with_grad
   int eval(const double* x, bool with_grad, double* grad) {
+    if (afn) return eval_aux(x, with_grad ? 1 : 0, grad);
     linear_predictor(x + nc);
     double o[3] = {0, 0, 0};
     if (fn(ctx, with_grad ? 1 : 0, var_of(x), a_of(x), fe.data(), o, gF.data())) return -1;
@@ -854,16 +865,18 @@ struct LapCoefState {
     return 0;
   }
   int grad_current(const double* x, double* grad) {
+    if (afn) return eval_aux(x, 2, grad);
     double o[3] = {0, 0, 0};
     if (fn(ctx, 2, var_of(x), a_of(x), fe.data(), o, gF.data())) return -1;
     if (nc) { grad[0] = o[1]; grad[1] = o[2]; }
     grad_beta(grad + nc);
     return 0;
   }
-  int reset_mode() { double o[3]; return fn(ctx, 3, 0., 0., nullptr, o, nullptr); }
+  int reset_mode() { double o[3 + 8]; if (afn) return afn(ctx, 3, 0., 0., nullptr, naux, o); return fn(ctx, 3, 0., 0., nullptr, o, nullptr); }
   // MaximalLearningRateCoef (re_model_template.h:5428-5464): the step along neg_step_dir may move the mean of the linear predictor by at most
   // C_mu C_MAX_CHANGE_COEF and its variance by at most C_sigma2 C_MAX_CHANGE_COEF
   double max_lr_coef(const double* beta, const double* dir) const {
+    if (p == 0) return 1e99;                                         // no coefficients in the vector
     const double C_MAX_CHANGE_COEF = 10.;                            // :5795
     double m_ch = 0., m_l1 = 0., v_ch = 0., c_ch = 0.;
     for (int i = 0; i < n; ++i) {
@@ -909,7 +922,13 @@ int run_lbfgs_laplace_coef(LapCoefState& st, const GpbOptimConfig& cfg, std::vec
       xp = x; gradp = grad;
       // GetMaximalLearningRate (optim_utils.h:498-535)
       const int nc = st.nc;
-      double max_lr = nc ? kMaxGradientUpdateLogScale / std::max(std::fabs(drt[0]), std::fabs(drt[1])) : 1e99;
+      double max_lr = 1e99;
+      {       // MaximalLearningRateCovAuxPars over the covariance AND the auxiliary entries (optim_utils.h:515-523)
+        double mx = 0.;
+        if (nc) mx = std::max(std::fabs(drt[0]), std::fabs(drt[1]));
+        for (int j = 0; j < st.naux; ++j) mx = std::max(mx, std::fabs(drt[nc + st.p + j]));
+        if (nc || st.naux) max_lr = kMaxGradientUpdateLogScale / mx;
+      }
       for (int i = 0; i < N; ++i) ndir[i] = -drt[i];
       const double max_lr_beta = st.max_lr_coef(x.data() + nc, ndir.data() + nc);
       if (max_lr_beta < max_lr) max_lr = max_lr_beta;
@@ -933,7 +952,7 @@ int run_lbfgs_laplace_coef(LapCoefState& st, const GpbOptimConfig& cfg, std::vec
             break;
           }
         }
-        if (iter >= max_linesearch) { x = xp; fx = fx_init; step = 0.; st.linear_predictor(x.data() + st.nc); }
+        if (iter >= max_linesearch) { x = xp; fx = fx_init; step = 0.; if (!st.afn) st.linear_predictor(x.data() + st.nc); }
       }
       if (!grad_is_current && st.grad_current(x.data(), grad.data())) return -1;
       mask(grad);
@@ -988,6 +1007,34 @@ int gpb_optimize_laplace_coef_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fe
   }
   out->theta[0] = st.var_of(x.data()); out->theta[1] = st.a_of(x.data());
   for (int j = 0; j < p; ++j) beta[j] = x[nc + j];
+  out->negll = st.negll;
+  out->num_evals = st.n_evals;
+  return 0;
+}
+
+int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux_fn fn, void* ctx, int naux, const double theta_init[2], double* aux,
+                                      GpbLaplaceAuxResult* out, char* err, int errlen) {
+  const Fail fail{err, errlen};
+  if (err && errlen > 0) err[0] = 0;
+  if (!fn || !out || !theta_init || !aux || naux < 1 || naux > 8) return fail("gpb_optimize_laplace_cov_aux_pars: invalid argument");
+  if (!(theta_init[0] > 0.) || !(theta_init[1] > 0.))
+    return fail("Initial covariance parameters need to be positive (found %g, %g on the transformed scale)", theta_init[0], theta_init[1]);
+  for (int j = 0; j < naux; ++j) if (!(aux[j] > 0.)) return fail("Initial auxiliary parameters need to be positive (found %g)", aux[j]);
+  if (cfg.optimizer != "lbfgs")
+    return fail("optimizer_cov = '%s' for a likelihood with estimated auxiliary parameters is not on the MI355X path of this library (supported: 'lbfgs', the reference's default)", cfg.optimizer.c_str());
+  LapCoefState st{nullptr, ctx, 0, 0, nullptr, nullptr, 1., 1., std::vector<double>(), std::vector<double>()};
+  st.afn = fn; st.naux = naux; st.nc = 2;
+  std::vector<double> x(2 + naux);
+  x[0] = std::log(theta_init[0]); x[1] = std::log(theta_init[1]);
+  for (int j = 0; j < naux; ++j) x[2 + j] = std::log(aux[j]);
+  *out = GpbLaplaceAuxResult();
+  if (cfg.max_iter > 0) {
+    const int rc = run_lbfgs_laplace_coef(st, cfg, x, &out->num_it, fail);
+    if (rc == kNaOrInf) return fail("NaN or Inf occurred in the parameter optimisation of a likelihood with auxiliary parameters (the reference restarts with 'nelder_mead', which is not on this path for such models)");
+    if (rc) { if (err && !err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation"); return -1; }
+  }
+  out->theta[0] = std::exp(x[0]); out->theta[1] = std::exp(x[1]);
+  for (int j = 0; j < naux; ++j) aux[j] = std::exp(x[2 + j]);
   out->negll = st.negll;
   out->num_evals = st.n_evals;
   return 0;

@@ -123,6 +123,26 @@ int gpb_optimize_laplace_coef_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fe
                                        const double* offset, double C_mu, double C_sigma2, const double theta_init[2], double* beta,
                                        GpbLaplaceCoefResult* out, char* err, int errlen, bool learn_cov = true);
 
+// ---- non-Gaussian likelihoods WITH auxiliary parameters (gamma / negative_binomial: the shape), estimated jointly with the covariance parameters ----
+// (EvalLLforLBFGSpp with EstimateAuxPars(), optim_utils.h:256-283, 345-348: the lbfgs vector is (log sigma1_2, log a, log aux_1 .. log aux_naux);
+// GetMaximalLearningRate -> MaximalLearningRateCovAuxPars over covariance AND auxiliary entries, :498-535.)  The evaluator is gpb_laplace_fn with
+// the auxiliary parameters in and their gradient out:
+//   op 0 / 1  mode finding at (var, a, aux), warm-started; out[0] = negative approximate marginal log-likelihood; op 1 also out[1..2] = gradient wrt
+//             (log var, log a) and out[3 .. 3 + naux) = gradient wrt log aux
+//   op 2      gradient of the CURRENT state; op 3 reset the mode to its previous value; op 4 forget the mode
+typedef int (*gpb_laplace_aux_fn)(void* ctx, int op, double var, double a, const double* aux, int naux, double* out);
+
+struct GpbLaplaceAuxResult {
+  double theta[2];
+  int num_it = 0;
+  double negll = 0.;
+  int num_evals = 0;
+};
+
+// aux: in = initial values, out = estimates (original scale).  Only optimizer_cov = "lbfgs" (the reference's default).
+int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux_fn fn, void* ctx, int naux, const double theta_init[2], double* aux,
+                                      GpbLaplaceAuxResult* out, char* err, int errlen);
+
 // Standard errors of the regression coefficients of a non-Gaussian model: CalcStdDevCoefNonGaussian (include/GPBoost/re_model_template.h:10851-10897) --
 // Hessian wrt beta as the numerical Jacobian of X' grad_F (central differences, step beta_i eps^(1/3), at least eps^(1/3)), symmetrised, Cholesky
 // inverse, sqrt of its diagonal ("(very) approximate", as the reference says).  X: ORIGINAL covariates (column-major n x p), beta on that scale.

@@ -50,14 +50,17 @@ struct CgScalars {         // per-column CG scalars on the device; part / part2:
 };
 int lap_cg_parts(int n);
 
-hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st,
+// the response as the likelihood kernels see it: int labels / counts (yi) or -- gamma -- real values (yd), and the likelihood's auxiliary parameter
+// (shape of gamma / negative_binomial; unused by the others)
+struct LikResp { const int* yi; const double* yd; double aux; };
+hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st,
                             const int* dptr = nullptr);   // dptr (n + 1): repeated locations -- row i sums over the data y[dptr[i] .. dptr[i + 1]) (also below)
 // ncol = number of column chunks, nc = columns per chunk (1: plain columns; 4: block vectors stored [chunk][row][4])
 hipError_t lap_apply(const LapLevels& lv, int n, const double* D, const double* W, const double* h, double* v, double* tmp, int ncol, int nc, hipStream_t st);
 hipError_t lap_B(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);
 hipError_t lap_Bt(const LapLevels& lv, int n, const double* x, double* out, int ncol, int nc, hipStream_t st);
 hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, hipStream_t st);
-hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st,
+hipError_t lap_objective(int link, const double* x, const LikResp& y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st,
                          const int* dptr = nullptr);
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st);
 hipError_t lap_dense_build(const LapDense& d, const double* A, hipStream_t st);    // inv of the block from this evaluation's A (Vecchia order [n][m])
@@ -70,10 +73,13 @@ hipError_t lap_scale_probes(const double* rv, const double* dw, int n, int ncol,
 hipError_t lap_logsums(const double* D, const double* dw, int n, double* out2, hipStream_t st);
 hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStream_t st);
 // ---- gradient of the approximate marginal likelihood (block vectors: ncol chunks of nc columns, as above) ----
-hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st, const int* dptr = nullptr);
-hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st);
-hipError_t lap_grad_F_map(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
+hipError_t lap_third_deriv(int link, const double* mode, const LikResp& y, const double* fe, int n, double* dW3, hipStream_t st, const int* dptr = nullptr);
+hipError_t lap_grad_F(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st);
+hipError_t lap_grad_F_map(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
                           const int* dptr, double* out, hipStream_t st);      // repeated locations: per datum, storage order of the data
+// link 3 / 4: the three data sums of the gradient wrt log(aux) (laplace_kernels.hip: lik_aux_grad_kernel); dptr may be NULL (one datum per row)
+hipError_t lap_aux_grad(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
+                        const int* dptr, double* out3, hipStream_t st);
 hipError_t lap_range_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double* dA, double* dD, hipStream_t st);
 hipError_t lap_factor_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double diag_nn, double nug,
                             int which, double* dA, double* dD, hipStream_t st);   // which: 0 = d/dlog(range), 1 = d/dlog(variance ratio) with a nugget

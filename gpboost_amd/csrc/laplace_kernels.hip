@@ -64,29 +64,56 @@ __device__ __forceinline__ double inv_mills_phi(double z) {
 }
 // per-observation pieces of the supported likelihoods: LINK 0 = Bernoulli-logit, 1 = Bernoulli-probit, 2 = Poisson (log link:
 // LogLikPoisson without the normalising constant, FirstDerivLogLikPoisson, SecondDerivNegLogLikPoisson; likelihoods.h:11407-11415,
-// :12481-12483, :13315-13317)
+// :12481-12483, :13315-13317); round 5, likelihoods with an auxiliary parameter `aux` (shape): 3 = gamma (log link, real-valued response:
+// LogLikGamma :11872-11880, FirstDerivLogLikGamma :12485-12487, SecondDerivNegLogLikGamma :13319-13321), 4 = negative_binomial (LogLikNegBin
+// :11882-11890, FirstDerivLogLikNegBin :12489-12492, SecondDerivNegLogLikNegBin :13323-13327).  The response reaches them as a double
+// (LikResp::at: the int label, or gamma's real value).
 template <int LINK>
-__device__ __forceinline__ void lik_grad_info(int y, double x, double& grad, double& w) {
+__device__ __forceinline__ double resp_at(const LikResp& r, int d) {
+  if constexpr (LINK == 3) return r.yd[d]; else return (double)r.yi[d];
+}
+template <int LINK>
+__device__ __forceinline__ void lik_grad_info(double y, double x, double aux, double& grad, double& w) {
   if constexpr (LINK == 0) {
     const double p = sigmoid_stable(x);
-    grad = (double)y - p;                 // likelihoods.h:12477
+    grad = y - p;                         // likelihoods.h:12477
     w = p * (1.0 - p);                    // :13307
   } else if constexpr (LINK == 1) {
-    const double z = y ? x : -x;
+    const double z = y != 0.0 ? x : -x;
     const double r = inv_mills_phi(z);
-    grad = y ? r : -r;
+    grad = y != 0.0 ? r : -r;
     w = r * (z + r);
+  } else if constexpr (LINK == 3) {
+    const double q = y * exp(-x);
+    grad = aux * (q - 1.0);
+    w = aux * q;
+  } else if constexpr (LINK == 4) {
+    const double mu = exp(x), mr = mu + aux;
+    grad = y - (y + aux) / mr * mu;
+    w = (y + aux) * mu * aux / (mr * mr);
   } else {
     const double e = exp(x);
-    grad = (double)y - e;
+    grad = y - e;
     w = e;
   }
 }
 template <int LINK>
-__device__ __forceinline__ double lik_loglik(int y, double x) {
-  if constexpr (LINK == 0) return (double)y * x - softplus(x);      // likelihoods.h:11401-11403
-  else if constexpr (LINK == 1) return normal_log_cdf(y ? x : -x);
-  else return (double)y * x - exp(x);
+__device__ __forceinline__ double lik_loglik(double y, double x, double aux) {
+  if constexpr (LINK == 0) return y * x - softplus(x);      // likelihoods.h:11401-11403
+  else if constexpr (LINK == 1) return normal_log_cdf(y != 0.0 ? x : -x);
+  else if constexpr (LINK == 3) return -aux * (x + y * exp(-x));
+  else if constexpr (LINK == 4) return y * x - (y + aux) * log(exp(x) + aux);
+  else return y * x - exp(x);
+}
+// digamma as GPBoost::digamma (src/GPBoost/DF_utils.cpp:82-125): small-argument approximation, recurrence up to x >= 8.5, de Moivre's expansion
+__device__ __forceinline__ double digamma_dev(double x) {
+  if (x <= 0.000001) return -0.57721566490153286060 - 1.0 / x + 1.6449340668482264365 * x;
+  double v = 0.0;
+  while (x < 8.5) { v -= 1.0 / x; x += 1.0; }
+  double r = 1.0 / x;
+  v += log(x) - 0.5 * r;
+  r = r * r;
+  return v - r * (1.0 / 12.0 - r * (1.0 / 120.0 - r * (1.0 / 252.0 - r * (1.0 / 240.0 - r * (1.0 / 132.0)))));
 }
 // fixed-order block reduction of two values; result valid in thread 0
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
@@ -107,7 +134,7 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s) {
 // is a RANDOM EFFECT whose data are y[dptr[i] .. dptr[i + 1]) (grouped by random effect in the storage order of the rows), and every
 // likelihood term of the row is the sum over its data (first_deriv_ll_ / information_ll_ on the random-effect scale, CalcZtVGivenIndices).
 template <int LINK>
-__global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ D,
+__global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const LikResp y, const double* __restrict__ fe, const double* __restrict__ D,
                                           int n, double* __restrict__ W, double* __restrict__ rhs, double* __restrict__ dw, double* __restrict__ rdw,
                                           const int* __restrict__ dptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,9 +142,9 @@ __global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const i
   double gr, w;
   if (dptr) {
     gr = 0.0; w = 0.0;
-    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(y[d], fe ? mode[i] + fe[d] : mode[i], g1, w1); gr += g1; w += w1; }
+    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, g1, w1); gr += g1; w += w1; }
   } else
-  lik_grad_info<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i], gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
+  lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
   W[i] = w;
   if (rhs) rhs[i] = w * mode[i] + gr;
   const double v = 1.0 / D[i] + w;
@@ -127,13 +154,13 @@ __global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const i
 
 // one workgroup: out2 = { sum_i log p(y_i | x_i),  sum_i Bx_i^2 / D_i }   (likelihoods.h:3808-3812, :3955-3959)
 template <int LINK>
-__global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __restrict__ x, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ Bx,
+__global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __restrict__ x, const LikResp y, const double* __restrict__ fe, const double* __restrict__ Bx,
                                                                const double* __restrict__ D, int n, double* __restrict__ out2, const int* __restrict__ dptr) {
   __shared__ double s[2048];
   double ll = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += lik_loglik<LINK>(y[d], fe ? x[i] + fe[d] : x[i]); }
-    else ll += lik_loglik<LINK>(y[i], fe ? x[i] + fe[i] : x[i]);
+    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += lik_loglik<LINK>(resp_at<LINK>(y, d), fe ? x[i] + fe[d] : x[i], y.aux); }
+    else ll += lik_loglik<LINK>(resp_at<LINK>(y, i), fe ? x[i] + fe[i] : x[i], y.aux);
     if (Bx) q = __builtin_fma(Bx[i] * (1.0 / D[i]), Bx[i], q);
   }
   block_reduce2(ll, q, s);
@@ -794,34 +821,36 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 // ---- gradient of the Laplace approximation (likelihoods.h:6521-6700; oracle/gpb_oracle.c: orc_vecchia_laplace_grad) ---------------
 // third derivative of the log-likelihood = d information / d location parameter (CalcFirstDerivInformationLocPar, likelihoods.h:13772-13800)
 template <int LINK>
-__device__ __forceinline__ double lik_third(int y, double x) {
+__device__ __forceinline__ double lik_third(double y, double x, double aux) {
   if constexpr (LINK == 0) { const double p = sigmoid_stable(x); return -p * (1.0 - p) * (2.0 * p - 1.0); }
   else if constexpr (LINK == 2) return exp(x);
+  else if constexpr (LINK == 3) return -aux * y * exp(-x);                                            // likelihoods.h:13843-13849
+  else if constexpr (LINK == 4) { const double mu = exp(x), mr = mu + aux; return -(y + aux) * mu * aux * (mu - aux) / (mr * mr * mr); }   // :13870-13878
   else {
     const double x2 = x * x;
-    if (y == 0) { const double q = inv_mills_phi(-x); return -q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)); }
+    if (y == 0.0) { const double q = inv_mills_phi(-x); return -q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)); }
     const double r = inv_mills_phi(x);
     return -r * (x2 - 1.0 + r * (3.0 * x + 2.0 * r));
   }
 }
 template <int LINK>
-__global__ void lik_third_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, int n, double* __restrict__ dW3,
+__global__ void lik_third_kernel(const double* __restrict__ mode, const LikResp y, const double* __restrict__ fe, int n, double* __restrict__ dW3,
                                  const int* __restrict__ dptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += lik_third<LINK>(y[d], fe ? mode[i] + fe[d] : mode[i]); dW3[i] = t3; }
-  else dW3[i] = lik_third<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i]);
+  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += lik_third<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux); dW3[i] = t3; }
+  else dW3[i] = lik_third<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux);
 }
 
 // boosting gradient for non-Gaussian data, d(-mll) / dF = -d log p / d loc + 0.5 d logdet / d mode - W .* (Sigma^-1 + W)^-1 d_mll_d_mode
 // (likelihoods.h:6996-7001), from the vectors the covariance-parameter gradient leaves behind
 template <int LINK>
-__global__ void lik_grad_F_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ dld,
+__global__ void lik_grad_F_kernel(const double* __restrict__ mode, const LikResp y, const double* __restrict__ fe, const double* __restrict__ dld,
                                   const double* __restrict__ sv, int n, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double gr, w;
-  lik_grad_info<LINK>(y[i], fe ? mode[i] + fe[i] : mode[i], gr, w);
+  lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);
   out[i] = -gr + 0.5 * dld[i] - w * sv[i];
 }
 
@@ -830,7 +859,7 @@ __global__ void lik_grad_F_kernel(const double* __restrict__ mode, const int* __
 //   out_d = -d log p_d / d loc + 0.5 (d information_d / d loc) diag_r - information_d [(Sigma^-1 + W)^-1 d_mll_d_mode]_r,   r = random effect of d
 // one thread per random effect (storage order), a handful of data each; out per datum in the storage order of the data
 template <int LINK>
-__global__ void lik_grad_F_map_kernel(const double* __restrict__ mode, const int* __restrict__ y, const double* __restrict__ fe, const double* __restrict__ dld,
+__global__ void lik_grad_F_map_kernel(const double* __restrict__ mode, const LikResp y, const double* __restrict__ fe, const double* __restrict__ dld,
                                       const double* __restrict__ dW3, const double* __restrict__ sv, int n, const int* __restrict__ dptr,
                                       double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -841,9 +870,51 @@ __global__ void lik_grad_F_map_kernel(const double* __restrict__ mode, const int
   for (int d = dptr[i]; d < dptr[i + 1]; ++d) {
     const double loc = fe ? mi + fe[d] : mi;
     double gr, w;
-    lik_grad_info<LINK>(y[d], loc, gr, w);
-    out[d] = -gr + 0.5 * lik_third<LINK>(y[d], loc) * diag - w * svi;
+    const double yd = resp_at<LINK>(y, d);
+    lik_grad_info<LINK>(yd, loc, y.aux, gr, w);
+    out[d] = -gr + 0.5 * lik_third<LINK>(yd, loc, y.aux) * diag - w * svi;
   }
+}
+
+// Gradient wrt log(auxiliary parameter) of the likelihoods that have one (CalcGradNegMargLikelihoodLaplaceApproxVecchia, iterative branch,
+// likelihoods.h:6743-6808): three sums over the data, from the vectors the covariance-parameter gradient leaves behind --
+//   out3[0] = the data-dependent part of CalcGradNegLogLikAuxPars (:14185-14215; the host adds the terms that depend on aux and n only),
+//   out3[1] = sum_d (d information_d / d log aux) diag_r(d),   diag_r = (d logdet / d mode)_r / (d information / d loc)_r  (:6700-6703),
+//   out3[2] = sum_d (d^2 log p_d / d loc d log aux) s_r(d),    s = (Sigma^-1 + W)^-1 d_mll_d_mode  (CalcSecondDerivLogLikFirstDerivInformationAuxPar, :14777-14799).
+// One workgroup, fixed reduction order: bit-reproducible.
+template <int LINK>
+__global__ __launch_bounds__(1024) void lik_aux_grad_kernel(const double* __restrict__ mode, const LikResp y, const double* __restrict__ fe,
+                                                              const double* __restrict__ dld, const double* __restrict__ dW3, const double* __restrict__ sv,
+                                                              int n, const int* __restrict__ dptr, double* __restrict__ out3) {
+  __shared__ double s[2048];
+  double e = 0.0, dsum = 0.0, isum = 0.0;
+  const double r = y.aux;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int d0 = dptr ? dptr[i] : i, d1 = dptr ? dptr[i + 1] : i + 1;
+    const double t3 = dW3[i];
+    const double diag = t3 == 0.0 ? 0.0 : dld[i] / t3;
+    const double mi = mode[i], svi = sv[i];
+    for (int d = d0; d < d1; ++d) {
+      const double x = fe ? mi + fe[d] : mi, yv = resp_at<LINK>(y, d);
+      if constexpr (LINK == 3) {
+        const double q = yv * exp(-x);
+        e += x + q;
+        const double s2 = r * (q - 1.0);
+        dsum = __builtin_fma(s2 + r, diag, dsum);
+        isum = __builtin_fma(s2, svi, isum);
+      } else {
+        const double mu = exp(x), mr = mu + r, yr = yv + r;
+        e += r * (-digamma_dev(yr) + log(mr) + yr / mr);
+        const double q = mu * r / (mr * mr);
+        dsum = __builtin_fma(-q * (yv * (r - mu) - 2.0 * r * mu) / mr, diag, dsum);
+        isum = __builtin_fma(q * (yv - mu), svi, isum);
+      }
+    }
+  }
+  double z = 0.0;
+  block_reduce2(e, dsum, s);
+  block_reduce2(isum, z, s);
+  if (threadIdx.x == 0) { out3[0] = e; out3[1] = dsum; out3[2] = isum; }
 }
 
 // dA_i / d log(a) and dD_i / d log(a) of the Vecchia factor WITHOUT nugget (Vecchia_utils.cpp:1640-1652; the range parameter is the only
@@ -1028,11 +1099,16 @@ __global__ __launch_bounds__(1024) void lap_sums3_kernel(const double* __restric
 
 // ---- launchers --------------------------------------------------------------------------------------------
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256)
-hipError_t lap_newton_setup(int link, const double* mode, const int* y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st,
+hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st,
                             const int* dptr) {
-  if (link == 0) hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr);
-  else if (link == 1) hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr);
-  else hipLaunchKernelGGL(lik_newton_setup_kernel<2>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr);
+  switch (link) {
+    case 0: hipLaunchKernelGGL(lik_newton_setup_kernel<0>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 1: hipLaunchKernelGGL(lik_newton_setup_kernel<1>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 2: hipLaunchKernelGGL(lik_newton_setup_kernel<2>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 3: hipLaunchKernelGGL(lik_newton_setup_kernel<3>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 4: hipLaunchKernelGGL(lik_newton_setup_kernel<4>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 // nc = columns per chunk of the block layout (1: plain column-major; 4: the probe block), ncol = number of chunks
@@ -1069,11 +1145,16 @@ hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, h
   hipLaunchKernelGGL(lap_scatter_kernel, GRID1(n), 0, st, in, sigma, n, out);
   return hipGetLastError();
 }
-hipError_t lap_objective(int link, const double* x, const int* y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st,
+hipError_t lap_objective(int link, const double* x, const LikResp& y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st,
                          const int* dptr) {
-  if (link == 0) hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr);
-  else if (link == 1) hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr);
-  else hipLaunchKernelGGL(lik_objective_kernel<2>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr);
+  switch (link) {
+    case 0: hipLaunchKernelGGL(lik_objective_kernel<0>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 1: hipLaunchKernelGGL(lik_objective_kernel<1>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 2: hipLaunchKernelGGL(lik_objective_kernel<2>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 3: hipLaunchKernelGGL(lik_objective_kernel<3>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 4: hipLaunchKernelGGL(lik_objective_kernel<4>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 // ---- the same solve WITHOUT level barriers: one launch for all levels [L0, L1) -------------------------------------------------------
@@ -1609,23 +1690,45 @@ hipError_t lap_dot(const double* x, const double* y, int n, double* out2, hipStr
   return hipGetLastError();
 }
 
-hipError_t lap_third_deriv(int link, const double* mode, const int* y, const double* fe, int n, double* dW3, hipStream_t st, const int* dptr) {
-  if (link == 0) hipLaunchKernelGGL(lik_third_kernel<0>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr);
-  else if (link == 1) hipLaunchKernelGGL(lik_third_kernel<1>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr);
-  else hipLaunchKernelGGL(lik_third_kernel<2>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr);
+hipError_t lap_third_deriv(int link, const double* mode, const LikResp& y, const double* fe, int n, double* dW3, hipStream_t st, const int* dptr) {
+  switch (link) {
+    case 0: hipLaunchKernelGGL(lik_third_kernel<0>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 1: hipLaunchKernelGGL(lik_third_kernel<1>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 2: hipLaunchKernelGGL(lik_third_kernel<2>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 3: hipLaunchKernelGGL(lik_third_kernel<3>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 4: hipLaunchKernelGGL(lik_third_kernel<4>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
-hipError_t lap_grad_F(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st) {
-  if (link == 0) hipLaunchKernelGGL(lik_grad_F_kernel<0>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
-  else if (link == 1) hipLaunchKernelGGL(lik_grad_F_kernel<1>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
-  else hipLaunchKernelGGL(lik_grad_F_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out);
+hipError_t lap_grad_F(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* sv, int n, double* out, hipStream_t st) {
+  switch (link) {
+    case 0: hipLaunchKernelGGL(lik_grad_F_kernel<0>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 1: hipLaunchKernelGGL(lik_grad_F_kernel<1>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 2: hipLaunchKernelGGL(lik_grad_F_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 3: hipLaunchKernelGGL(lik_grad_F_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 4: hipLaunchKernelGGL(lik_grad_F_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
-hipError_t lap_grad_F_map(int link, const double* mode, const int* y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
+hipError_t lap_grad_F_map(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
                           const int* dptr, double* out, hipStream_t st) {
-  if (link == 0) hipLaunchKernelGGL(lik_grad_F_map_kernel<0>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out);
-  else if (link == 1) hipLaunchKernelGGL(lik_grad_F_map_kernel<1>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out);
-  else hipLaunchKernelGGL(lik_grad_F_map_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out);
+  switch (link) {
+    case 0: hipLaunchKernelGGL(lik_grad_F_map_kernel<0>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 1: hipLaunchKernelGGL(lik_grad_F_map_kernel<1>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 2: hipLaunchKernelGGL(lik_grad_F_map_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 3: hipLaunchKernelGGL(lik_grad_F_map_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 4: hipLaunchKernelGGL(lik_grad_F_map_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t lap_aux_grad(int link, const double* mode, const LikResp& y, const double* fe, const double* dld, const double* dW3, const double* sv, int n,
+                        const int* dptr, double* out3, hipStream_t st) {
+  if (link == 3) hipLaunchKernelGGL(lik_aux_grad_kernel<3>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
+  else if (link == 4) hipLaunchKernelGGL(lik_aux_grad_kernel<4>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t lap_factor_deriv(const double4* pts, const int* nn, const double* A, int n, int m, int cov, int d3, double var, double a, double diag_nn, double nug,

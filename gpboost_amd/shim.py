@@ -203,8 +203,25 @@ class VecchiaState(object):
         return out
 
     def laplace_set_likelihood(self, likelihood):
-        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
+        self._lap_link = lid
+
+    def laplace_set_response_real(self, y):
+        """gamma: the real-valued response (> 0), in the order laplace_set_labels takes its labels."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_response_real(self.h, _p(y)))
+
+    def laplace_set_aux(self, aux):
+        """gamma / negative_binomial: the shape parameter (gpb_hip_vecchia_laplace_set_aux_pars)."""
+        a = np.ascontiguousarray(np.atleast_1d(aux), dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_aux_pars(self.h, _p(a), C.c_int(a.size)))
+
+    def laplace_grad_aux(self):
+        """-> {gradient wrt log(shape), CalcGradNegLogLikAuxPars part, log-determinant part, implicit part} at the state of the last laplace_eval_grad."""
+        o = np.empty(4)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_grad_aux_current(self.h, _p(o)))
+        return o
 
     def laplace_set_fixed_effects(self, fixed_effects):
         """Offset of the location parameter, Vecchia order (None removes it)."""
@@ -240,6 +257,8 @@ class VecchiaState(object):
         parts = np.empty(8) if want_parts else None
         vecs = np.empty(2 * self.n) if want_parts else None
         _shim_call(_lib().gpb_hip_vecchia_laplace_grad_current(self.h, C.c_int(cg_max_num_it), C.c_double(cg_delta_conv), _p(g), _p(parts), _p(vecs)))
+        if getattr(self, "_lap_link", 0) >= 3:      # likelihoods with an auxiliary parameter: third entry = d / d log(aux)
+            g = np.array([g[0], g[1], self.laplace_grad_aux()[0]])
         if want_parts:
             return -o[0], g, dict(per_par=parts.reshape(2, 4), dlogdet_dmode=vecs[:self.n], implicit_solve=vecs[self.n:])
         return -o[0], g

@@ -395,6 +395,20 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_data_map(gpb_hip_vecchia_t* h, co
  * (likelihoods.h:3861-3870), which is how the GPBoost algorithm passes the tree ensemble's scores for non-Gaussian data. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fixed_effects);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y01);
+/* Likelihoods with an auxiliary parameter (round 5): likelihood ids 3 = "gamma" (shape; log link, response > 0, real-valued:
+ * LogLikGamma / FirstDerivLogLikGamma / SecondDerivNegLogLikGamma, likelihoods.h:11872-11880, :12485-12487, :13319-13321; normalising constant
+ * :10998-11007) and 4 = "negative_binomial" (shape; counts >= 0 through gpb_hip_vecchia_laplace_set_labels: LogLikNegBin / FirstDerivLogLikNegBin /
+ * SecondDerivNegLogLikNegBin, :11882-11890, :12489-12492, :13323-13327; normalising constant :11019-11030).
+ *   set_response_real  gamma's response, in the order set_labels takes its labels (Vecchia order / grouped by random effect)
+ *   set_aux_pars       the shape (> 0; default 1): Likelihood::SetAuxPars; every later evaluation uses it
+ *   grad_aux_current   d(-approximate marginal log-likelihood) / d log(shape) at the state of the last gpb_hip_vecchia_laplace_grad_current:
+ *                      CalcGradNegLogLikAuxPars (:14185-14215) + 0.5 sum_d (d information_d / d log aux) diag_r(d) + sum_d (d^2 log p_d / d loc d log aux)
+ *                      [(Sigma^-1 + W)^-1 d_mll_d_mode]_r(d)  (:6743-6808, CalcSecondDerivLogLikFirstDerivInformationAuxPar :14777-14799);
+ *                      out4 = { the gradient, its three parts } */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov_type, double var, double a, int num_rand_vec,
                                                  int seed_rand_vec, int cg_max_num_it, int cg_max_num_it_tridiag,
                                                  double cg_delta_conv, double delta_conv_mode_finding, int reset_mode,

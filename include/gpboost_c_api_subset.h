@@ -346,6 +346,17 @@ GPBOOST_C_EXPORT int GPB_HIP_OptimizeLaplaceWithCallback(const double* init_thet
     double acc_rate_cov, int max_iter, double delta_rel_conv, bool use_nesterov_acc, int nesterov_schedule_version, int momentum_offset,
     const char* convergence_criterion, int m_lbfgs, int (*eval)(void*, int, double, double, double*), void* ctx, double* theta_out2,
     int* num_it, double* negll, int* num_evals);
+/* Test seam and host half of GPB_OptimCovPar for likelihoods with auxiliary parameters estimated jointly with the covariance parameters (round 5: gamma,
+ * negative_binomial -- the shape): lbfgs on (log sigma1_2, log a, log aux_1 .. log aux_naux) as EvalLLforLBFGSpp lays the vector out with EstimateAuxPars()
+ * (include/GPBoost/optim_utils.h:256-283, 345-348, 498-535).  eval(ctx, op, sigma1_2, a, aux, naux, out): op 0 / 1 = find the mode (warm start) at the
+ * given parameters, out[0] = negative approximate marginal log-likelihood (op 1: + gradient wrt (log sigma1_2, log a) in out[1..2] and wrt log aux in
+ * out[3 ..]); op 2 = gradient of the current state; op 3 = reset the mode to its previous value; op 4 = forget the mode. */
+GPBOOST_C_EXPORT int GPB_HIP_OptimizeLaplaceAuxWithCallback(const double* init_theta2, const double* init_aux, int naux, double lr_cov, int max_iter,
+    double delta_rel_conv, int m_lbfgs, int (*eval)(void*, int, double, double, const double*, int, double*), void* ctx, double* theta_out2,
+    double* aux_out, int* num_it, double* negll, int* num_evals);
+/* Host half of the same fit: Likelihood::FindInitialAuxPars (include/GPBoost/likelihoods.h:1851-1947) -- the shape's start value when none is given:
+ * gamma: approximate MLE ignoring the effects; negative_binomial: method of moments (fixed_effects may be NULL; data order). */
+GPBOOST_C_EXPORT int GPB_HIP_FindInitialAuxParsHost(const char* likelihood, int32_t n, const double* y, const double* fixed_effects, double* aux_out);
 /* Test seam and host half of GPB_GetCovPar(calc_std_dev = true) for non-Gaussian models: CalcStdDevCovParAuxParsNonGaussian
  * (include/GPBoost/re_model_template.h:11029-11117) -- Hessian of the negative approximate marginal log-likelihood as the numerical Jacobian (central
  * differences on the log scale, step 1e-4 max(|log theta_i|, 1)) of its analytic gradient, Cholesky inverse, delta method -- on theta = (sigma1_2, a)

@@ -126,6 +126,62 @@ def laplace_grad_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
 
 
+def laplace_aux_fixture(out_dir):
+    """gamma and negative_binomial Vecchia-Laplace models (auxiliary shape parameter estimated with the covariance parameters): the reference's own
+      *_negll_0                      GPB_EvalNegLogLikelihood at (cov_pars, aux) with the default thresholds
+      *_negll_direct, *_grad_direct  value and gradient wrt (log sigma1^2, log a, log aux) from the reference's CalcGradPars (refdrv_laplace_nll_grad) at
+                                     cases.LAPLACE_TIGHT; *_fe_*: with fixed effects
+      *_fit_*                        GPB_OptimCovPar (lbfgs, estimate_aux_pars = true, aux initialised by FindInitialAuxPars): cov_pars, aux, init aux,
+                                     iterations, negll -- at the default thresholds and (*_fit_tight_*) at cases.LAPLACE_TIGHT
+      *_fitfix_*                     the same with the auxiliary parameter held at cases' aux (estimate_aux_pars = false)"""
+    res = {}
+    for name, ac in cases.LAPLACE_AUX_CASES.items():
+        c = cases.LAPLACE_CASES[ac["model"]]
+        coords, y = cases.make_aux_data(ac)
+        lik, aux = ac["lik"], ac["aux"]
+        cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+        args = (c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
+        mdl.set_optim_config(init_aux_pars=aux)
+        res[name + "_negll_0"] = np.float64(mdl.neg_log_likelihood(cp, y))
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
+            nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, fe, *args, aux_pars=aux, estimate_aux=True, **cases.LAPLACE_TIGHT)
+            res[name + fe_key + "_negll_direct"] = np.float64(nll)
+            res[name + fe_key + "_grad_direct"] = g
+            print("laplace aux", name, fe_key, "negll %.10f" % nll, "grad", g, flush=True)
+        for key, cfg in (("_fit", {}), ("_fit_tight", dict(cases.LAPLACE_TIGHT))):
+            m2 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
+            m2.set_optim_config(estimate_aux_pars=True, **cfg)
+            m2.optim_cov_par(y)
+            res[name + key + "_cov_pars"] = m2.get_cov_par(2)
+            res[name + key + "_aux"] = m2.get_aux_pars(1)
+            res[name + key + "_init_cov_pars"] = m2.get_init_cov_par()[:2].copy()
+            res[name + key + "_init_aux"] = m2.get_init_aux_pars(1)
+            res[name + key + "_num_it"] = np.int32(m2.get_num_it())
+            res[name + key + "_negll"] = np.float64(m2.current_neg_log_likelihood())
+            print("laplace aux fit", name, key, res[name + key + "_init_cov_pars"], res[name + key + "_init_aux"], "->", res[name + key + "_cov_pars"],
+                  res[name + key + "_aux"], res[name + key + "_num_it"], res[name + key + "_negll"], flush=True)
+        m3 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
+        m3.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False)
+        m3.optim_cov_par(y)
+        res[name + "_fitfix_cov_pars"] = m3.get_cov_par(2)
+        res[name + "_fitfix_aux"] = m3.get_aux_pars(1)
+        res[name + "_fitfix_num_it"] = np.int32(m3.get_num_it())
+        res[name + "_fitfix_negll"] = np.float64(m3.current_neg_log_likelihood())
+        print("laplace aux fit (aux fixed)", name, res[name + "_fitfix_cov_pars"], res[name + "_fitfix_aux"], res[name + "_fitfix_num_it"], res[name + "_fitfix_negll"], flush=True)
+        # predictions at (cov_pars, aux): latent mean / variance and the response's (PredictResponse, likelihoods.h:9715-9728, :9783-9793); Cholesky-based =
+        # the exact values the iterative methods estimate (as tests/golden/laplace_predvar_ref.npz)
+        cpred = np.random.default_rng(79).uniform(size=(40, c["d"]))
+        res[name + "_coords_pred"] = cpred
+        m4 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik, matrix_inversion_method="cholesky")
+        m4.set_optim_config(init_aux_pars=aux, **cases.LAPLACE_TIGHT)
+        mu, var = m4.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp)
+        rmu, rvar = m4.predict(cpred, predict_var=True, predict_response=True, y=y, cov_pars=cp)
+        res[name + "_latent_mu"] = mu; res[name + "_latent_var"] = var; res[name + "_resp_mu"] = rmu; res[name + "_resp_var"] = rvar
+        print("laplace aux predictions", name, mu[:2], var[:2], rmu[:2], rvar[:2], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_aux_ref.npz"), **res)
+
+
 def split_fixture(out_dir):
     """The reference's FeatureHistogram::FindBestThreshold on its own (fixed) histograms: all inputs of the call + its outputs."""
     res = {}
@@ -889,6 +945,8 @@ if __name__ == "__main__":
         fisher_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_laplace":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":
+        laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":
         laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_coef":

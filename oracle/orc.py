@@ -467,19 +467,53 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
     return out
 
 
+LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4}
+
+
+def _responses(likelihood, y):
+    """-> (int32 responses, float64 responses | None): gamma's response is real-valued (handed to the C side through orc_set_aux)."""
+    if likelihood == "gamma":
+        yd = np.ascontiguousarray(y, dtype=np.float64)
+        return np.zeros(yd.shape[0], dtype=np.int32), yd
+    return np.ascontiguousarray(y, dtype=np.int32), None
+
+
+class _aux_context(object):
+    """orc_set_aux / orc_clear_aux around a call for the likelihoods with an auxiliary parameter (link >= 3); a no-op otherwise."""
+
+    def __init__(self, link, aux, yd, aux_grad4):
+        self.on = link >= 3
+        self.args = (float(1.0 if aux is None else aux), yd, aux_grad4)
+
+    def __enter__(self):
+        if self.on:
+            aux, yd, g4 = self.args
+            fn = lib().orc_set_aux
+            fn.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+            fn(aux, None if yd is None else yd.ctypes.data, None if g4 is None else g4.ctypes.data)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib().orc_clear_aux()
+        return False
+
+
 def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
-                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit", fixed_effects=None):
+                          cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit", fixed_effects=None,
+                          aux=None):
     """Approximate negative log marginal likelihood of a Bernoulli-logit (or, likelihood="bernoulli_probit", -probit) Vecchia GP
     (Laplace, iterative, 'vadu').  Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
-    link = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
+    link = LINK_ID[likelihood]
     A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
-    yi = np.ascontiguousarray(y01, dtype=np.int32)
+    yi, yd = _responses(likelihood, y01)
     rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0) if rand_vec is None else np.asfortranarray(rand_vec)
     out = np.empty(6); mode = np.empty(n)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
-    rc = lib().orc_vecchia_laplace_binary_fe(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
+    with _aux_context(link, aux, yd, None):
+      rc = lib().orc_vecchia_laplace_binary_fe(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(nn, C.c_int), C.c_int(n), C.c_int(m),
                                           _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double), _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it),
                                           C.c_int(cg_max_num_it_tridiag), C.c_double(cg_delta_conv), C.c_double(delta_conv_mode),
                                           _p(out, C.c_double), _p(mode, C.c_double))
@@ -559,27 +593,31 @@ def vecchia_laplace_dup(coords_u, nn, cov_type, var, a, unique_idx, y, num_rand_
 
 def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000, cg_max_num_it_tridiag=1000,
                          cg_delta_conv=1e-2, delta_conv_mode=1e-8, likelihood="bernoulli_logit", fixed_effects=None, mode_init=None,
-                         want_mode=False, want_parts=False):
+                         want_mode=False, want_parts=False, aux=None):
     """(negll, gradient of negll wrt (log sigma1^2, log a)) of the Vecchia-Laplace approximation, iterative methods, 'vadu'
     (orc_vecchia_laplace_grad: the checker of the device gradient, tests/test_z_laplace_grad_gpu.py).  mode_init: start Newton's method there (the
     warm start of the reference's optimiser); want_mode: also return the mode found."""
-    link = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2}[likelihood]
+    link = LINK_ID[likelihood]
     A, D, Ag, Dg, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False, grad=True)
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
-    yi = np.ascontiguousarray(y01, dtype=np.int32)
+    yi, yd = _responses(likelihood, y01)
+    aux_g4 = np.zeros(4) if link >= 3 else None
     rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     out = np.empty(6); g = np.empty(2)
     mode = np.zeros(n) if mode_init is None else np.ascontiguousarray(mode_init, dtype=np.float64).copy()
     dbg = np.zeros(2 * n + 8) if want_parts else None
-    rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double),
-                                        _p(nn, C.c_int), C.c_int(n), C.c_int(m), _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double),
-                                        _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
-                                        C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double),
-                                        _p(mode, C.c_double), C.c_int(0 if mode_init is None else 1), None if dbg is None else _p(dbg, C.c_double))
+    with _aux_context(link, aux, yd, aux_g4):
+        rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double),
+                                            _p(nn, C.c_int), C.c_int(n), C.c_int(m), _p(yi, C.c_int), None if fe is None else _p(fe, C.c_double),
+                                            _p(rv, C.c_double), C.c_int(rv.shape[1]), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
+                                            C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double),
+                                            _p(mode, C.c_double), C.c_int(0 if mode_init is None else 1), None if dbg is None else _p(dbg, C.c_double))
     if rc != 0:
         raise RuntimeError("orc_vecchia_laplace_grad failed")
+    if link >= 3:      # likelihoods with an auxiliary parameter: the gradient's third entry is d(-mll) / d log(aux)
+        g = np.array([g[0], g[1], aux_g4[0]])
     if want_parts:      # intermediate values for device parity tests
         parts = dict(dlogdet_dmode=dbg[:n].copy(), implicit_solve=dbg[n:2 * n].copy(), per_par=dbg[2 * n:].reshape(2, 4).copy(), mode=mode)
         return -out[0], g, parts

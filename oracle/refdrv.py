@@ -158,19 +158,37 @@ class RefCAPIModel(object):
     def set_optim_config(self, init_cov_pars=None, lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
                          use_nesterov_acc=True, nesterov_schedule_version=-999, trace=False, optimizer_cov="", momentum_offset=-999,
                          convergence_criterion="default", m_lbfgs=-999, cg_delta_conv=-999., delta_conv_mode_finding=-999.,
-                         init_coef_aux_pars_from_iid_model=False, estimate_cov_par_index=None):
+                         init_coef_aux_pars_from_iid_model=False, estimate_cov_par_index=None, init_aux_pars=None, estimate_aux_pars=False):
         """GPB_SetOptimConfig with the argument order of include/LightGBM/c_api.h:1437-1467 (basic.py:5460-5496 binds it the same way)."""
         s = lambda x: C.c_char_p(x.encode())
         ic = None if init_cov_pars is None else np.ascontiguousarray(init_cov_pars, dtype=np.float64)
         est = np.array([-1], dtype=np.int32) if estimate_cov_par_index is None else np.ascontiguousarray(estimate_cov_par_index, dtype=np.int32)
+        ia = None if init_aux_pars is None else np.ascontiguousarray(np.atleast_1d(init_aux_pars), dtype=np.float64)
         rc = self.L.GPB_SetOptimConfig(
             self.h, C.c_void_p() if ic is None else _P(ic), C.c_double(lr_cov), C.c_double(acc_rate_cov), C.c_int(max_iter),
             C.c_double(delta_rel_conv), C.c_bool(use_nesterov_acc), C.c_int(nesterov_schedule_version), C.c_bool(trace), s(optimizer_cov),
             C.c_int(momentum_offset), s(convergence_criterion), C.c_int(0), C.c_void_p(), C.c_double(-999.), C.c_double(-999.), s(""),
             C.c_int(-999), C.c_int(-999), C.c_double(cg_delta_conv), C.c_int(-999), C.c_bool(True), s("vadu"), C.c_int(1), C.c_int(-999),
-            C.c_void_p(), C.c_bool(False), C.c_bool(bool(init_coef_aux_pars_from_iid_model)), _P(est), C.c_int(m_lbfgs), C.c_double(delta_conv_mode_finding))
+            C.c_void_p() if ia is None else _P(ia), C.c_bool(bool(estimate_aux_pars)), C.c_bool(bool(init_coef_aux_pars_from_iid_model)), _P(est), C.c_int(m_lbfgs),
+            C.c_double(delta_conv_mode_finding))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
+
+    def get_aux_pars(self, num=1):
+        """GPB_GetAuxPars (c_api.h:1804-1807) -> the first `num` auxiliary parameters (original scale)."""
+        out = np.zeros(max(num, 1)); name = C.create_string_buffer(256)
+        rc = self.L.GPB_GetAuxPars(self.h, _P(out), name, C.c_bool(False))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out[:num].copy()
+
+    def get_init_aux_pars(self, num=1):
+        """GPB_GetInitAuxPars (c_api.h:1824-1825)."""
+        out = np.zeros(max(num, 1))
+        rc = self.L.GPB_GetInitAuxPars(self.h, _P(out))
+        if rc != 0:
+            raise RuntimeError(self.L.LGBM_GetLastError().decode())
+        return out[:num].copy()
 
     def optim_cov_par(self, y, fixed_effects=None):
         y = np.ascontiguousarray(y, dtype=np.float64)
@@ -290,9 +308,7 @@ def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, co
     cov_pars = (sigma1^2, rho), from the reference's OWN CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia
     (ref_driver.cpp: refdrv_laplace_nll_grad) with the solver thresholds given -- the pin of orc_vecchia_laplace_grad and of the device gradient."""
     mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
-    mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding)
-    if aux_pars is not None:
-        mdl.set_aux_pars(aux_pars)
+    mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding, init_aux_pars=aux_pars, estimate_aux_pars=estimate_aux)
     y = np.ascontiguousarray(y, dtype=np.float64)
     cp = np.ascontiguousarray(cov_pars, dtype=np.float64)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)

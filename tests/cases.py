@@ -101,6 +101,37 @@ def make_count_data(c):
     return coords, y
 
 
+# Likelihoods with an auxiliary parameter (first slice of round 5): gamma (shape) and negative_binomial (shape), estimated
+# jointly with the covariance parameters (likelihoods.h:298-322, CalcGradNegLogLikAuxPars :14185-14215).  model: a LAPLACE_CASES entry (coordinates,
+# covariance function, neighbours, ordering); aux: the parameter the likelihood / gradient fixtures are evaluated at; true_aux: what the data were drawn with.
+LAPLACE_AUX_CASES = {
+    "gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", aux=2.0, true_aux=2.5),
+    "gamma_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="gamma", aux=0.8, true_aux=1.2),
+    "negbin_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="negative_binomial", aux=1.5, true_aux=1.7),
+    # (its fit ends in a line search whose second trial point the reference accepts by 2e-8 of the likelihood: at the DEFAULT solver thresholds two correct
+    #  implementations part there -- estimates 1.2e-2 apart at likelihoods 2e-8 apart; at cases.LAPLACE_TIGHT they agree to 1e-6.  flat_default marks it.)
+    "negbin_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", aux=3.0, true_aux=4.0, flat_default=True),
+}
+
+
+def make_aux_data(ac):
+    """-> (coords, y) in DATA order for a LAPLACE_AUX_CASES entry: the coordinates of its model (as make_binary_data draws them), responses with
+    log-mean = a smooth surface: gamma(shape true_aux, mean mu) / negative binomial(size true_aux, mean mu)."""
+    c = LAPLACE_CASES[ac["model"]]
+    rng = np.random.default_rng(c["seed_data"])
+    n, d = c["n"], c["d"]
+    coords = rng.uniform(size=(n, d))
+    latent = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.3
+    mu = np.exp(latent)
+    r = ac["true_aux"]
+    rng2 = np.random.default_rng(c["seed_data"] + 1000)
+    if ac["lik"] == "gamma":
+        y = rng2.gamma(r, mu / r)
+    else:
+        y = rng2.negative_binomial(r, r / (r + mu)).astype(np.float64)
+    return coords, y
+
+
 def laplace_fixed_effects(coords):
     """Offset of the location parameter used by the fixed-effects Laplace fixtures (data order)."""
     return 0.8 * np.cos(6 * coords[:, -1]) - 0.3

@@ -27,6 +27,8 @@ void orc_vecchia_By(const double* A, const int* nn, int n, int m, const double* 
 void orc_vecchia_yaux(const double* A, const double* D, const int* nn, int n, int m, const double* y, double* y_aux);
 int orc_newton_leaf_values(const double* A, const double* D, const int* nn, int n, int m, const double* yaux, const int* leaf, int L, double* leaf_values);
 void orc_gen_rand_normal(int seed, unsigned long long run_id, int n, int t, double* out);
+void orc_set_aux(double aux, const double* y_real, double* aux_grad4);
+void orc_clear_aux(void);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
                                      int cg_max_num_it_tridiag, double cg_delta_conv, double delta_conv_mode_finding, double* out6, double* grad2,
@@ -49,7 +51,13 @@ double normal_log_cdf(double x) {
   return Q == 0.0 ? 0.0 : std::log1p(-Q);
 }
 // d log p / d loc, information, d information / d loc
-void lik_terms(int link, int y, double x, double* first, double* info, double* dinfo) {
+double g_mock_aux = 1.0;        // auxiliary parameter seen by lik_terms (links 3 / 4; set by the entry points from the handle)
+void lik_terms(int link, double y, double x, double* first, double* info, double* dinfo) {
+  if (link == 3) { const double r = g_mock_aux, q = y * std::exp(-x); *first = r * (q - 1.); *info = r * q; *dinfo = -r * q; return; }
+  if (link == 4) {
+    const double r = g_mock_aux, mu = std::exp(x), mr = mu + r;
+    *first = y - (y + r) / mr * mu; *info = (y + r) * mu * r / (mr * mr); *dinfo = -(y + r) * mu * r * (mu - r) / (mr * mr * mr); return;
+  }
   if (link == 0) { const double p = sigmoid(x); *first = y - p; *info = p * (1. - p); *dinfo = p * (1. - p) * (1. - 2. * p); return; }
   if (link == 2) { const double e = std::exp(x); *first = y - e; *info = e; *dinfo = e; return; }
   const double z = y > 0 ? x : -x;
@@ -85,6 +93,8 @@ struct gpb_hip_vecchia {
   // Laplace state
   int link = 0;
   std::vector<int> labels; std::vector<double> fe; bool has_fe = false;
+  std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
+  double yv(int k) const { return link == 3 ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
   bool has_mode = false, grad_state = false;
@@ -152,10 +162,11 @@ int dense_M_chol(const gpb_hip_vecchia* h, std::vector<double>* Mout) {
     for (size_t a1 = 0; a1 < ec.size(); ++a1) for (size_t b1 = 0; b1 < ec.size(); ++b1) M[(size_t)ec[a1] * n + ec[b1]] += ev[a1] * di * ev[b1];
   }
   const bool mapped = !h->re_ptr.empty();
+  g_mock_aux = h->aux;
   for (int i = 0; i < n; ++i) {
     const int d0 = mapped ? h->re_ptr[i] : i, d1 = mapped ? h->re_ptr[i + 1] : i + 1;
     double w = 0.;
-    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->labels[k], h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); w += inf; }
+    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); w += inf; }
     M[(size_t)i * n + i] += w;
   }
   for (int i = 0; i < n; ++i)
@@ -190,9 +201,11 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   h->mode_prev = warm ? h->mode : std::vector<double>(n, 0.);
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
+  if (h->link >= 3) orc_set_aux(h->aux, h->link == 3 ? h->resp_real.data() : nullptr, h->aux_grad4);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
                                                   h->has_fe ? h->fe.data() : nullptr, rv.data(), nrv, cg, cgt, cgd, dcm, out6, h->grad2, mode.data(), warm ? 1 : 0,
                                                   dbg.data());
+  if (h->link >= 3) orc_clear_aux();
   if (rc) return fail("NaN or Inf occurred in the mode finding algorithm for the Laplace approximation");
   h->mode = mode; h->has_mode = true; h->grad_state = true;
   h->dld.assign(dbg.begin(), dbg.begin() + n); h->sv.assign(dbg.begin() + n, dbg.begin() + 2 * n);
@@ -397,7 +410,7 @@ EXPORT int gpb_hip_dense_spd_solve(int32_t n, const double* M_host, const double
 
 // ---- Laplace path ----
 EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int id) {
-  if (id < 0 || id > 2) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
+  if (id < 0 || id > 4) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
   if (h->link != id) { h->labels.clear(); h->grad_state = false; }
   h->link = id; return 0;
 }
@@ -409,6 +422,29 @@ EXPORT int gpb_hip_vecchia_laplace_set_data_map(gpb_hip_vecchia_t* h, const int3
 EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_labels");
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   h->labels.assign(y, y + nd); h->grad_state = false; return 0;
+}
+EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
+  if (h->link != 3) return fail("gpb_hip_vecchia_laplace_set_response_real: only the gamma likelihood has a real-valued response on this path (likelihood id %d)", h->link);
+  const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
+  for (int i = 0; i < nd; ++i) if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i);
+  h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->grad_state = false; return 0;
+}
+EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux) {
+  if (h->link < 3) return fail("gpb_hip_vecchia_laplace_set_aux_pars: likelihood id %d has no auxiliary parameters", h->link);
+  if (num_aux != 1 || !(aux[0] > 0.)) return fail("The shape parameter is not > 0 (found %g)", aux[0]);
+  if (aux[0] != h->aux) { h->aux = aux[0]; h->grad_state = false; }
+  return 0;
+}
+EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux) {
+  *num_aux = h->link >= 3 ? 1 : 0;
+  if (aux_out && *num_aux) aux_out[0] = h->aux;
+  return 0;
+}
+EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4) {
+  if (h->link < 3) return fail("gpb_hip_vecchia_laplace_grad_aux_current: the likelihood has no auxiliary parameter");
+  if (!h->grad_state) return fail("the gradient wrt the auxiliary parameter needs the state of gpb_hip_vecchia_laplace_grad_current");
+  for (int k = 0; k < 4; ++k) out4[k] = h->aux_grad4[k];
+  return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fe) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_fixed_effects");
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
@@ -433,15 +469,16 @@ EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h) 
 }
 EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* gF) { MOCK_TRACE("gpb_hip_vecchia_laplace_grad_F_current");
   if (!h->grad_state) return fail("the gradient wrt the fixed effects needs the state of gpb_hip_vecchia_laplace_grad_current");
+  g_mock_aux = h->aux;
   const int n = h->n;
   const bool mapped = !h->re_ptr.empty();
   for (int i = 0; i < n; ++i) {
     const int d0 = mapped ? h->re_ptr[i] : i, d1 = mapped ? h->re_ptr[i + 1] : i + 1;
     double t3 = 0.;
-    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->labels[k], h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); t3 += di; }
+    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); t3 += di; }
     const double diag = t3 == 0. ? 0. : h->dld[i] / t3;
     for (int k = d0; k < d1; ++k) {
-      double f, inf, di; lik_terms(h->link, h->labels[k], h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di);
+      double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di);
       gF[k] = -f + 0.5 * di * diag - inf * h->sv[i];
     }
   }

@@ -174,3 +174,55 @@ def optimize_laplace_coef(lib, likelihood, X, y, init_theta2, evaluator, fixed_e
     if want_init_coef:
         return out, coef, nit.value, nll.value, ic_out
     return out, coef, nit.value, nll.value
+
+
+LAPLACE_AUX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+
+
+class OracleLaplaceAuxEvaluator(object):
+    """gpb_laplace_aux_fn (gpboost_amd/csrc/gpb_optim.h) with the oracle behind it: likelihoods whose auxiliary parameter (gamma / negative_binomial: the
+    shape) is estimated with the covariance parameters.  Keeps the mode (warm start), its previous value (op 3) and the gradient of the current state."""
+
+    def __init__(self, orc, coords_ord, nn, cov_type, y_ord, likelihood, cg_delta_conv=1e-2, delta_conv_mode=1e-8, fixed_effects_ord=None):
+        self.orc, self.co, self.nn, self.ct, self.y, self.lik = orc, coords_ord, nn, cov_type, y_ord, likelihood
+        self.cgd, self.dcm, self.fe = cg_delta_conv, delta_conv_mode, fixed_effects_ord
+        self.mode = None; self.mode_prev = None; self.grad = None
+        self.calls = []
+        self.cb = LAPLACE_AUX_FN(self._fn)
+
+    def _fn(self, ctx, op, var, a, aux, naux, out):
+        self.calls.append((op, var, a, aux[0] if (naux and aux) else None))
+        if op == 3:
+            self.mode = None if self.mode_prev is None else self.mode_prev.copy()
+            return 0
+        if op == 4:
+            self.mode = None; self.mode_prev = None
+            return 0
+        if op == 2:
+            out[1], out[2], out[3] = self.grad
+            return 0
+        self.mode_prev = None if self.mode is None else self.mode.copy()
+        nll, g, mode = self.orc.vecchia_laplace_grad(self.co, self.nn, self.ct, var, a, self.y, likelihood=self.lik, mode_init=self.mode, want_mode=True,
+                                                     cg_delta_conv=self.cgd, delta_conv_mode=self.dcm, fixed_effects=self.fe, aux=aux[0])
+        if self.mode_prev is None:
+            self.mode_prev = np.zeros_like(mode)
+        self.mode, self.grad = mode, (g[0], g[1], g[2])
+        out[0] = nll
+        if op == 1:
+            out[1], out[2], out[3] = self.grad
+        return 0
+
+
+def optimize_laplace_aux(lib, init_theta2, init_aux, evaluator, lr_cov=-999., max_iter=-999, delta_rel_conv=-999., m_lbfgs=-999):
+    """GPB_HIP_OptimizeLaplaceAuxWithCallback -> ((sigma1_2, a), aux, iterations, negll, evaluations)."""
+    th0 = np.ascontiguousarray(init_theta2, dtype=np.float64)
+    a0 = np.ascontiguousarray(np.atleast_1d(init_aux), dtype=np.float64)
+    out = np.empty(2); aout = np.empty(a0.size); nit = C.c_int(0); nll = C.c_double(0); ne = C.c_int(0)
+    lib.GPB_HIP_OptimizeLaplaceAuxWithCallback.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, LAPLACE_AUX_FN,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.LGBM_GetLastError.restype = C.c_char_p
+    rc = lib.GPB_HIP_OptimizeLaplaceAuxWithCallback(th0.ctypes.data, a0.ctypes.data, a0.size, lr_cov, max_iter, delta_rel_conv, m_lbfgs, evaluator.cb, None,
+                                                    out.ctypes.data, aout.ctypes.data, C.byref(nit), C.byref(nll), C.byref(ne))
+    if rc != 0:
+        raise RuntimeError(lib.LGBM_GetLastError().decode())
+    return out, aout, nit.value, nll.value, ne.value

@@ -48,6 +48,14 @@ def test_validated_device_tests_still_pass_on_the_cpu_restatement_of_the_shim(mo
     assert "33 passed" in tail, tail
 
 
+def test_auxiliary_parameter_likelihoods_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):
+    """Round 5: gamma / negative_binomial through the model surface (GPB_SetOptimConfig(init_aux_pars, estimate_aux_pars), GPB_EvalNegLogLikelihood,
+    GPB_OptimCovPar with the shape in the lbfgs vector and FindInitialAuxPars' start, GPB_GetAuxPars, response predictions): the host code under
+    tests/test_zz_laplace_aux_gpu.py's model-API tests, against the reference's fixtures, with the oracle-backed shim."""
+    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_aux_gpu.py"], extra=["-k", "model_api"])
+    assert "5 passed" in tail, tail
+
+
 ROUTE_A_DRIVER = r'''
 import json, sys, types
 sys.modules.setdefault("optuna", types.ModuleType("optuna"))       # optional dependency of the reference's package, absent here

@@ -588,3 +588,35 @@ def test_standard_errors_with_more_than_62_neighbours(lib_built):
     o2 = md.get_cov_pars(std_err=True)
     perm, co, nn = orc.vecchia_setup(c2, 70, "random", 2)
     np.testing.assert_allclose(o2[3:], orc.fisher_std_errors(co, nn, 1, o2[:3]), rtol=1e-7)
+
+
+@pytest.mark.parametrize("tight", [False, True])
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_AUX_CASES))
+def test_host_optimiser_with_an_estimated_shape_parameter_follows_the_reference(lib_built, name, tight):
+    """gamma / negative_binomial: the shape is the third entry of the lbfgs vector (log scale; optim_utils.h:256-283), started at
+    Likelihood::FindInitialAuxPars (GPB_HIP_FindInitialAuxParsHost) -- the product's host optimiser driven by the oracle against the reference's own
+    GPB_OptimCovPar with estimate_aux_pars = true (tests/golden/laplace_aux_ref.npz): same iteration count, estimates 1e-4 (default thresholds) /
+    1e-6 (cases.LAPLACE_TIGHT)."""
+    from oracle import orc
+    from tests import optim_harness as oh
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "laplace_aux_ref.npz"))
+    ac = cases.LAPLACE_AUX_CASES[name]
+    c = cases.LAPLACE_CASES[ac["model"]]
+    coords, y = cases.make_aux_data(ac)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    rc_ = [1.0, np.sqrt(3.0), np.sqrt(5.0)][ct]
+    key = name + ("_fit_tight" if tight else "_fit")
+    init = g[key + "_init_cov_pars"]
+    lib = C.CDLL(lib_built)
+    aux0 = np.empty(1)
+    yc = np.ascontiguousarray(y)
+    assert lib.GPB_HIP_FindInitialAuxParsHost(ac["lik"].encode(), C.c_int(len(y)), yc.ctypes.data_as(C.c_void_p), None, aux0.ctypes.data_as(C.c_void_p)) == 0
+    thr = cases.LAPLACE_TIGHT if tight else dict(cg_delta_conv=1e-2, delta_conv_mode_finding=1e-8)
+    ev = oh.OracleLaplaceAuxEvaluator(orc, co, nn, ct, y[perm], ac["lik"], cg_delta_conv=thr["cg_delta_conv"], delta_conv_mode=thr["delta_conv_mode_finding"])
+    th, aux, nit, nll, ne = oh.optimize_laplace_aux(lib, [init[0], rc_ / init[1]], aux0, ev)
+    assert nit == int(g[key + "_num_it"]), (nit, int(g[key + "_num_it"]))
+    rtol = 1e-6 if tight else (2e-2 if ac.get("flat_default") else 1e-4)
+    np.testing.assert_allclose([th[0], rc_ / th[1]], g[key + "_cov_pars"], rtol=rtol)
+    np.testing.assert_allclose(aux, g[key + "_aux"], rtol=rtol)
+    assert abs(nll - float(g[key + "_negll"])) <= (1e-8 if tight else 1e-7) * abs(nll)

@@ -542,3 +542,31 @@ def test_oracle_boosting_gradient_matches_the_reference(orc, name, lik):
     out_t = np.empty_like(gFt); out_t[perm] = gFt
     ref_t = g["%s_%s_gradF_tight" % (name, lik)]
     np.testing.assert_allclose(out_t, ref_t, rtol=0, atol=1e-8 * np.abs(ref_t).max())
+
+
+# ---- likelihoods with an auxiliary parameter: gamma, negative_binomial -----------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_AUX_CASES))
+def test_oracle_gamma_negbin_value_and_gradient_match_the_reference(orc, name):
+    """orc_vecchia_laplace_grad with link 3 (gamma) / 4 (negative_binomial): value and gradient wrt (log sigma1^2, log a, log shape) against the reference's
+    own CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia incl. its auxiliary-parameter branch (likelihoods.h:6743-6808; fixture
+    tests/golden/laplace_aux_ref.npz from oracle/make_golden.py laplace_aux) at cases.LAPLACE_TIGHT: 1e-8 relative, without and with fixed effects; and the
+    reference's GPB_EvalNegLogLikelihood at its default thresholds."""
+    ac = cases.LAPLACE_AUX_CASES[name]
+    c = cases.LAPLACE_CASES[ac["model"]]
+    g = np.load(os.path.join(GOLD, "laplace_aux_ref.npz"))
+    coords, y = cases.make_aux_data(ac)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    negll, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=ac["lik"], aux=ac["aux"])
+    ref0 = float(g[name + "_negll_0"])
+    assert abs(negll - ref0) <= 1e-8 * abs(ref0), (negll, ref0)
+    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+        nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=ac["lik"], fixed_effects=fe, aux=ac["aux"],
+                                                 cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+        ref = g[name + fe_key + "_grad_direct"]
+        assert grad_t.shape == (3,)
+        np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+        ref_v = float(g[name + fe_key + "_negll_direct"])
+        assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
