@@ -32,8 +32,8 @@ if ROOT not in sys.path:
 # before comparing with a byte count"; other access widths are uncalibrated.  So: the histogram's row stream (64 B per lane) gets the
 # x2 (`fetch_factor` 2), the point kernel's 32-byte gathers are reported as counted (factor 1, stated).  None when no summary is there.
 # counters of the newest committed PMC evidence set (scripts/profile_r04.sh -> profiles/r04_pmc.json; the round-3 set as the fallback)
-PMC_JSON = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json")) if os.path.exists(q)),
-                os.path.join(ROOT, "profiles", "r04_pmc.json"))
+PMC_JSON = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json")) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r05_pmc.json"))
 PMC_NAME = "profiles/" + os.path.basename(PMC_JSON)
 
 
@@ -45,9 +45,26 @@ def _pmc():
         return None
 
 
-def profiled_traffic_bytes(kernel_substr, fetch_factor=1.0):
+def pmc_is_current(source_file):
+    """True while the kernel source the counters were collected on (sha256 recorded by scripts/summarize_prof.py pmc-json, `_meta`) is the one in this tree:
+    a counter json that belongs to an older kernel is not reported as this run's traffic."""
+    import hashlib
+    pmc = _pmc()
+    want = ((pmc or {}).get("_meta") or {}).get("kernel_sources_sha256", {}).get(source_file)
+    if not want:
+        return False
+    try:
+        with open(os.path.join(ROOT, "gpboost_amd", "csrc", source_file), "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest() == want
+    except OSError:
+        return False
+
+
+def profiled_traffic_bytes(kernel_substr, fetch_factor=1.0, source_file=None):
     pmc = _pmc()
     if not pmc:
+        return None
+    if source_file is not None and not pmc_is_current(source_file):
         return None
     for name, c in pmc.items():
         if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -450,7 +467,7 @@ def main():
     achieved_gbs = bytes_launch / (ms_kernel * 1e-3) / 1e9
     achieved_tflops = flops_launch / (ms_kernel * 1e-3) / 1e12
 
-    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0>" % (m, ct, "true" if d == 3 else "false")) if (n, world) == (1000000, 1) else None
+    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0>" % (m, ct, "true" if d == 3 else "false"), source_file="vecchia_kernels.hip") if (n, world) == (1000000, 1) else None
     rccl_ranks = st.comm_info()[1] if native_rccl else 0
     mailbox_ranks = st.mailbox_info()[1] if use_mailbox else 0
     # per-rank view (N > 1): every rank's in-loop kernel time and shard size -- min / max over the ranks is the skew the N = 8 budget of DESIGN.md
@@ -503,7 +520,8 @@ def main():
             # `traffic` = FETCH_SIZE + WRITE_SIZE of the same kernel from the PMC passes committed under profiles/ (read at run time).
             "roofline": {"bound": "hbm", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch,
-                         "traffic_source": PMC_NAME + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 32-byte gathers: counted as reported, no x2)" if traffic else None,
+                         "traffic_source": (PMC_NAME + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 32-byte gathers: counted as reported, no x2; the json's recorded sha256 of vecchia_kernels.hip equals this tree's)") if traffic else
+                                           ("null: " + PMC_NAME + " was collected on another version of vecchia_kernels.hip (sha256 mismatch) -- rerun scripts/gpu_run.sh <tag> pmc" if (n, world) == (1000000, 1) else None),
                          "note": "binding resource is fp64 VALU issue, not HBM: see roofline_fp64_valu; 0.864 GB of gathers per launch, the 32 MB record array lives in L2 / Infinity Cache"},
             "roofline_fp64_valu": {"bound": "fp64 vector ALU issue (no MFMA in this kernel)", "kernel": "vecchia_point_kernel<MODE_NLL>", "achieved": achieved_tflops,
                                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS, "kernel_ms": ms_kernel,
@@ -569,7 +587,7 @@ def main():
                 out["roofline_histogram"] = {
                     "bound": "hbm", "kernel": "hist_build_rows_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
-                    "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_rows_kernel<false", fetch_factor=2.0),
+                    "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_rows_kernel<false", fetch_factor=2.0, source_file="hist_kernels.hip"),
                     "traffic_source": PMC_NAME + ": 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced streams); rows are padded to 64 bytes for F = 50 (28 % more bin bytes than the algorithmic count)",
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
                     "note": "fixed-point sums (one 64-bit LDS atomic per row and feature, count packed in, bank-conflict-free layout, a whole "

@@ -339,7 +339,7 @@ struct gpb_hip_hist {
   unsigned long long* d_absmax = nullptr;                  // bits of max |grad|, max |hess|: the scale of the fixed-point histogram sums
   double* d_hist = nullptr; unsigned long long* d_cnt = nullptr;
   GpbComm comm;                                            // optional: data-parallel histogram all-reduce (rows sharded per rank)
-  long long* d_limbs = nullptr;                            // sharded handles: integer totals [total_bins][5] {grad hi, lo, hess hi, lo, count} between reduce, all-reduce and conversion
+  long long* d_limbs = nullptr;                            // sharded handles: integer totals [5][total_bins] {grad hi, grad lo, count, hess hi, hess lo} between reduce, all-reduce and conversion
   double* d_pool = nullptr; int nslots = 0;                 // resident leaf histograms (HistogramPool), 2 * total_bins doubles each
   int* d_fix = nullptr; bool has_fix = false;              // view_offset[F], num_bin[F], most_freq_bin[F]
   int* d_meta3 = nullptr; bool has_split_info = false;     // per feature: FeatureMetainfo::offset, default_bin, missing_type
@@ -2295,10 +2295,13 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
                            const int* dev_indices = nullptr, bool dev_all_rows = false);
 
 // Sharded handle (DataParallelTreeLearner's scheme, data_parallel_tree_learner.cpp:155-173, with integers on the wire): the reduce kernel has
-// left this rank's INTEGER totals in d_limbs; one all-reduce(sum, int64) of 5 words per bin, then the same conversion as on one GPU.
+// left this rank's INTEGER totals in d_limbs (word-major); one all-reduce(sum, int64) of 3 words per bin -- {grad hi, grad lo, count}: 24 bytes, the
+// constant-hessian case of the GPBoost algorithm with a Gaussian likelihood -- or 5 with per-row hessians, then the same conversion as on one GPU.
+// (Round 4 sent 5 words per bin in every case: 510 KB per leaf at config 3; now 306 KB.  The reference's reduce-scatter moves 16 bytes per bin of
+// DOUBLES, data_parallel_tree_learner.cpp:155-173 -- its sums then depend on the rank layout, these do not.)
 // Counts are exact, and so are the sums of the once-rounded gradients: the job's histogram is bit-identical for every rank layout.
 static int hist_finish_sharded(gpb_hip_hist_t* h, double const_hess, double* d_hist_out, unsigned long long* d_cnt_out) {
-  if (comm_allreduce(h->comm, h->d_limbs, 5 * (size_t)h->total_bins, GPB_T_I64, GPB_OP_SUM, h->stream)) return -1;
+  if (comm_allreduce(h->comm, h->d_limbs, (h->has_hess ? 5 : 3) * (size_t)h->total_bins, GPB_T_I64, GPB_OP_SUM, h->stream)) return -1;
   HIP_OK(gpb::launch_hist_convert(h->d_limbs, h->total_bins, h->d_absmax, h->d_absmax + 1, const_hess, h->has_hess ? 1 : 0, d_hist_out, d_cnt_out, h->stream));
   return 0;
 }
@@ -2372,7 +2375,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   const bool sharded = h->comm.active() && !ms_avg;          // (gpb_hip_hist_bench times the local build)
   if (sharded) {
     if (!h->d_limbs) HIP_OK(hipMalloc(&h->d_limbs, sizeof(long long) * 5 * (size_t)h->total_bins));
-    r.limbs_out = h->d_limbs;
+    r.limbs_out = h->d_limbs; r.limb_stride = h->total_bins;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ms_avg) { HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventRecord(e0, h->stream)); }
@@ -2420,7 +2423,7 @@ static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_b
   r.const_hess = const_hess; r.has_hess = h->has_hess ? 1 : 0;
   if (h->comm.active()) {
     if (!h->d_limbs) HIP_OK(hipMalloc(&h->d_limbs, sizeof(long long) * 5 * (size_t)h->total_bins));
-    r.limbs_out = h->d_limbs;
+    r.limbs_out = h->d_limbs; r.limb_stride = h->total_bins;
   }
   HIP_OK(gpb::launch_hist_build(a, h->stream));
   // few chunks (leaves below ~8000 rows: most splits of a tree): the children's search sums them itself, one launch and one kernel boundary less per

@@ -62,14 +62,15 @@ struct HistReduceArgs {
   unsigned long long* cnt_out;  // [total_bins]
   int fpad, nchunks, num_features;
   double const_hess; int has_hess;
-  long long* limbs_out = nullptr;  // sharded handles: [total_bins][5] integer totals {grad hi, lo, hess hi, lo, count} INSTEAD of hist_out / cnt_out
+  long long* limbs_out = nullptr;  // sharded handles: [5][limb_stride] integer totals {grad hi, grad lo, count, hess hi, hess lo} (word-major) INSTEAD of hist_out / cnt_out
+  int limb_stride = 0;             // = total bins
 };
 
 hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
 hipError_t launch_hist_convert(const long long* limbs, int total_bins, const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
                                double const_hess, int has_hess, double* hist_out, unsigned long long* cnt_out, hipStream_t st);
-hipError_t launch_hist_root_sums(const long long* limbs, const int* bin_offsets, const unsigned long long* grad_max_bits,
+hipError_t launch_hist_root_sums(const long long* limbs, int total_bins, const int* bin_offsets, const unsigned long long* grad_max_bits,
                                  const unsigned long long* hess_max_bits, double const_hess, int has_hess, double* out3, hipStream_t st);
 hipError_t launch_hist_absmax(const double* v, int n, unsigned long long* out_bits, hipStream_t st);
 hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offset, const int* num_bin, const int* most_freq_bin,

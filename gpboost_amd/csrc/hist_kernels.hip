@@ -381,14 +381,18 @@ __global__ __launch_bounds__(1024) void hist_reduce_kernel(HistReduceArgs a) {
   }
   const size_t o = (size_t)a.bin_offsets[f] + b;
   if (a.limbs_out) {        // sharded handle: the integer totals leave as they are -- summed over the ranks as INTEGERS, converted once afterwards
-    long long* L = a.limbs_out + 5 * o;
-    L[0] = g.hi; L[1] = (long long)g.lo; L[2] = h.hi; L[3] = (long long)h.lo; L[4] = (long long)c;
+    // word-major [5][limb_stride]: {grad hi, grad lo, count, hess hi, hess lo} -- the constant-hessian case (GPBoost's Gaussian likelihood) puts
+    // only the first THREE words of every bin on the wire (hist_finish_sharded)
+    long long* L = a.limbs_out + o;
+    const size_t S = (size_t)a.limb_stride;
+    L[0] = g.hi; L[S] = (long long)g.lo; L[2 * S] = (long long)c;
+    if constexpr (HAS_HESS) { L[3 * S] = h.hi; L[4 * S] = (long long)h.lo; }
     return;
   }
   hist_convert_entry<HAS_HESS>(g, h, c, a.grad_max_bits, a.hess_max_bits, a.const_hess, a.hist_out + 2 * o, a.cnt_out ? a.cnt_out + o : nullptr);
 }
 
-// Sharded handles: limbs[total_bins][5] = {grad hi, grad lo, hess hi, hess lo, count} summed over the ranks -> the histogram entries.  The
+// Sharded handles: limbs[5][total_bins] = {grad hi, grad lo, count, hess hi, hess lo} (word-major) summed over the ranks -> the histogram entries.  The
 // integer total does not depend on how the rows were dealt to ranks, chunks or lanes, and it is converted by the same expression as on
 // one GPU: the histogram of a sharded job is bit-identical to the one-GPU histogram of the same rows (given the same scale: the
 // all-reduced max |g|, gpb_hip_hist_set_gradients).
@@ -397,10 +401,12 @@ __global__ __launch_bounds__(256) void hist_convert_kernel(const long long* __re
                                                           double* __restrict__ hist_out, unsigned long long* __restrict__ cnt_out) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= total_bins) return;
-  const long long* L = limbs + 5 * (size_t)o;
+  const long long* L = limbs + o;
+  const size_t S = (size_t)total_bins;
   Limbs g, h;
-  g.hi = L[0]; g.lo = (unsigned long long)L[1]; h.hi = L[2]; h.lo = (unsigned long long)L[3];
-  const unsigned long long c = (unsigned long long)L[4];
+  g.hi = L[0]; g.lo = (unsigned long long)L[S];
+  if (has_hess) { h.hi = L[3 * S]; h.lo = (unsigned long long)L[4 * S]; }
+  const unsigned long long c = (unsigned long long)L[2 * S];
   if (has_hess) hist_convert_entry<true>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * (size_t)o, cnt_out ? cnt_out + o : nullptr);
   else hist_convert_entry<false>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * (size_t)o, cnt_out ? cnt_out + o : nullptr);
 }
@@ -413,23 +419,25 @@ hipError_t launch_hist_convert(const long long* limbs, int total_bins, const uns
 
 // Root of a sharded tree: (sum of gradients, sum of hessians, rows) of ALL ranks from the all-reduced integer totals of feature 0's bins
 // (every row has exactly one bin there): layout-independent like the histogram itself.  out3 = {sum_gradient, sum_hessian, rows}.
-__global__ __launch_bounds__(64) void hist_root_sums_kernel(const long long* __restrict__ limbs, const int* __restrict__ bin_offsets,
+__global__ __launch_bounds__(64) void hist_root_sums_kernel(const long long* __restrict__ limbs, int total_bins, const int* __restrict__ bin_offsets,
                                                            const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
                                                            double const_hess, int has_hess, double* __restrict__ out3) {
   if (threadIdx.x != 0) return;
   Limbs g, h; unsigned long long c = 0;
+  const size_t S = (size_t)total_bins;
   for (int o = bin_offsets[0]; o < bin_offsets[1]; ++o) {
-    const long long* L = limbs + 5 * (size_t)o;
-    g.hi += L[0]; g.lo += (unsigned long long)L[1]; h.hi += L[2]; h.lo += (unsigned long long)L[3]; c += (unsigned long long)L[4];
+    const long long* L = limbs + o;
+    g.hi += L[0]; g.lo += (unsigned long long)L[S]; c += (unsigned long long)L[2 * S];
+    if (has_hess) { h.hi += L[3 * S]; h.lo += (unsigned long long)L[4 * S]; }
   }
   double e[2];
   if (has_hess) hist_convert_entry<true>(g, h, c, grad_max_bits, hess_max_bits, const_hess, e, nullptr);
   else hist_convert_entry<false>(g, h, c, grad_max_bits, hess_max_bits, const_hess, e, nullptr);
   out3[0] = e[0]; out3[1] = e[1]; out3[2] = (double)c;
 }
-hipError_t launch_hist_root_sums(const long long* limbs, const int* bin_offsets, const unsigned long long* grad_max_bits,
+hipError_t launch_hist_root_sums(const long long* limbs, int total_bins, const int* bin_offsets, const unsigned long long* grad_max_bits,
                                  const unsigned long long* hess_max_bits, double const_hess, int has_hess, double* out3, hipStream_t st) {
-  hipLaunchKernelGGL(hist_root_sums_kernel, dim3(1), dim3(64), 0, st, limbs, bin_offsets, grad_max_bits, hess_max_bits, const_hess, has_hess, out3);
+  hipLaunchKernelGGL(hist_root_sums_kernel, dim3(1), dim3(64), 0, st, limbs, total_bins, bin_offsets, grad_max_bits, hess_max_bits, const_hess, has_hess, out3);
   return hipGetLastError();
 }
 

@@ -124,7 +124,7 @@ class RefCAPIModel(object):
     def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1,
                  likelihood="gaussian", cluster_ids=None, lib_path=None, gpu_use=False, gp_approx="vecchia", num_ind_points=500, weights=None,
                  matrix_inversion_method="default"):
-        # lib_path / gpu_use: the route-B build (oracle/Makefile.routeB -> oracle/_ref/lib_gpboost_hip.so), the same C API with GPU_use = true
+        # lib_path / gpu_use: the route-B build (integration/Makefile.routeB -> integration/_build/lib_gpboost_hip.so), the same C API with GPU_use = true
         self.L = C.CDLL(lib_path or os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
         self.L.LGBM_GetLastError.restype = C.c_char_p
         cm = np.asfortranarray(coords, dtype=np.float64)

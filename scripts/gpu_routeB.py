@@ -1,5 +1,5 @@
-"""Evidence run on the MI355X for INTEGRATION.md route B (scripts run by gpurun; needs oracle/_ref/lib_gpboost_hip.so built by
-`make -f oracle/Makefile.routeB`): the reference's OWN host code -- REModel, its optimiser, Booster / GBDT / SerialTreeLearner, reached
+"""Evidence run on the MI355X for INTEGRATION.md route B (scripts run by gpurun; needs integration/_build/lib_gpboost_hip.so built by
+`make -f integration/Makefile.routeB`): the reference's OWN host code -- REModel, its optimiser, Booster / GBDT / SerialTreeLearner, reached
 through its unchanged C API -- with the patched seams calling lib_gpboost_amd.so.
 
  (1) Gaussian Vecchia model: GPB_EvalNegLogLikelihood and GPB_OptimCovPar with GPU_use = true against GPU_use = false of the same library
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from oracle import refdrv   # noqa: E402
 from tests import cases     # noqa: E402
 
-LIBP = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
+LIBP = os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so")
 print("library:", LIBP, flush=True)
 
 # ---- (1) GP ---------------------------------------------------------------------------------------------------------------------

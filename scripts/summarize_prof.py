@@ -53,6 +53,23 @@ def pmc(dirs):
     return acc
 
 
+KERNEL_SOURCES = ("vecchia_kernels.hip", "dev_common.h", "hist_kernels.hip", "dense_kernels.hip")
+
+
+def kernel_source_hashes(root=None):
+    """sha256 of the kernel sources whose counters the PMC json holds (relative to gpboost_amd/csrc)."""
+    import hashlib
+    root = root or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpboost_amd", "csrc")
+    out = {}
+    for f in KERNEL_SOURCES:
+        try:
+            with open(os.path.join(root, f), "rb") as fh:
+                out[f] = hashlib.sha256(fh.read()).hexdigest()
+        except OSError:
+            out[f] = None
+    return out
+
+
 def main():
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
@@ -67,6 +84,8 @@ def main():
     elif sys.argv[1] == "pmc-json":
         acc = pmc(sys.argv[3:])
         out = {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, n=max(len(v) for v in cs.values())) for k, cs in acc.items()}
+        # which kernel sources the counters belong to: bench.py reports `traffic` only while these hashes match the tree it runs in
+        out["_meta"] = {"kernel_sources_sha256": kernel_source_hashes()}
         with open(sys.argv[2], "w") as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
         print("wrote", sys.argv[2], len(out), "kernels")

@@ -1,5 +1,5 @@
 """integration/reference_hip_seams.patch (INTEGRATION.md route B) applies cleanly (no fuzz) to the reference tree it was made against and touches only the
-files INTEGRATION.md names; the seams carry the USE_HIP_GP build flag (oracle/Makefile.routeB compiles the patched translation units, tests/test_routeB_seams_cpu.py
+files INTEGRATION.md names; the seams carry the USE_HIP_GP build flag (integration/Makefile.routeB compiles the patched translation units, tests/test_routeB_seams_cpu.py
 and tests/test_routes_gpu.py run them)."""
 import os
 import shutil

@@ -1,4 +1,4 @@
-"""INTEGRATION.md route B without a GPU: the route-B build of the reference (oracle/_ref/lib_gpboost_hip.so = the reference's own host code with
+"""INTEGRATION.md route B without a GPU: the route-B build of the reference (integration/_build/lib_gpboost_hip.so = the reference's own host code with
 integration/reference_hip_seams.patch) with tests/mock_shim's CPU restatement of gpb_hip_* PRELOADED in place of lib_gpboost_amd.so.  What runs is
 the patched host code -- HipCreateVecchiaStates, HipCalcCovFactorVecchia (B refilled through the cached pattern), the fused evaluations inside the
 optimiser, CalcYAux after a new response at unchanged parameters, NewtonUpdateLeafValues, and the Laplace seams of a Bernoulli-logit model
@@ -11,11 +11,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIPLIB = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
+HIPLIB = os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so")
 MOCK = os.path.join(ROOT, "tests", "mock_shim", "libgpb_c_api_on_oracle_TEST_ONLY.so")
 
 
-@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="oracle/_ref/lib_gpboost_hip.so (route-B build of the reference) not built")
+@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="integration/_build/lib_gpboost_hip.so (route-B build of the reference) not built")
 def test_patched_reference_host_code_on_the_cpu_restatement_of_the_shim():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "mock_shim")], check=True)
     env = dict(os.environ, LD_PRELOAD=MOCK, OMP_NUM_THREADS="4")

@@ -7,8 +7,8 @@ gpboost_amd/lib_gpboost_amd.so: its GPModel creates, evaluates, fits, predicts t
 Binding: python-package/gpboost/basic.py:117-129, 5206-7118.
 
 Route B -- the reference's own HOST code (REModel, its optimiser, Booster / GBDT / SerialTreeLearner) compiled with
-integration/reference_hip_seams.patch + integration/hip_tree_learner.h against this library (oracle/Makefile.routeB ->
-oracle/_ref/lib_gpboost_hip.so): GPU_use = true reproduces GPU_use = false (likelihood 1e-8, same optimiser iterations, predictions),
+integration/reference_hip_seams.patch + integration/hip_tree_learner.h against this library (integration/Makefile.routeB ->
+integration/_build/lib_gpboost_hip.so): GPU_use = true reproduces GPU_use = false (likelihood 1e-8, same optimiser iterations, predictions),
 device_type = gpu reproduces device_type = cpu after 20 boosting iterations in 9 configurations (seam: tree_learner.cpp:15-52).
 
 Both run as subprocesses of scripts/ (they replace modules / load a second library); skipped only where the prebuilt files are absent.
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFPKG = os.path.join(ROOT, "oracle", "_ref", "refpkg", "gpboost", "basic.py")
-HIPLIB = os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_hip.so")
+HIPLIB = os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so")
 
 
 def _run(args, ok_line, timeout):
@@ -40,7 +40,7 @@ def test_route_a_reference_python_package_reproduces_the_r_goldens_on_the_device
     assert "iterations 378" in out and "124.2252524" in out
 
 
-@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="oracle/_ref/lib_gpboost_hip.so (route-B build of the reference) not built")
+@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="integration/_build/lib_gpboost_hip.so (route-B build of the reference) not built")
 def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_built):
     out = _run(["scripts/gpu_routeB.py", "--test", "--gp-only"], "ROUTE B ON MI355X: OK", 1500)
     assert out.count("GPU_use=true reproduces the CPU path of the same build") == 2
@@ -49,7 +49,7 @@ def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_buil
     assert "y_aux and Newton leaf values from the resident factor) reproduces the CPU path" in out
 
 
-@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="oracle/_ref/lib_gpboost_hip.so (route-B build of the reference) not built")
+@pytest.mark.skipif(not os.path.isfile(HIPLIB), reason="integration/_build/lib_gpboost_hip.so (route-B build of the reference) not built")
 def test_route_b_reference_booster_with_device_type_gpu_reproduces_device_type_cpu(lib_built):
     out = _run(["scripts/gpu_routeB.py", "--test", "--trees-only"], "ROUTE B ON MI355X: OK", 1500)
     assert "device_type=gpu (HIPTreeLearner, whole trees) reproduces device_type=cpu" in out
