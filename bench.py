@@ -696,7 +696,9 @@ def main():
                 hb3.set_fix_info((bo3[:-1] + 1).astype(np.int32), np.full(F3, nb3, dtype=np.int32), np.zeros(F3, dtype=np.int32))
                 hb3.set_split_info(np.ones(F3, dtype=np.int32), np.zeros(F3, dtype=np.int32), np.zeros(F3, dtype=np.int32))
                 score = np.zeros(n3); t3 = {}
-                for it3 in range(5):
+                R3 = 100                                  # BASELINE config 3 as written: 100 trees, timed as a whole
+                t_all0 = time.perf_counter()
+                for it3 in range(R3):
                     ta = time.perf_counter()
                     grad3 = m3.y_aux(m3.get_cov_pars() if it3 else cp3, score - y3)
                     tb = time.perf_counter()
@@ -712,10 +714,16 @@ def main():
                     tf3 = time.perf_counter()
                     t3 = {"gradient_yaux_ms": (tb - ta) * 1e3, "set_gradients_ms": (tb2 - tb) * 1e3, "tree_31_leaves_ms": (tc - tb2) * 1e3,
                           "newton_leaf_values_ms": (td - tc) * 1e3, "cov_par_step_ms": (tf3 - te) * 1e3}
+                t_all = time.perf_counter() - t_all0
                 t3["total_ms"] = sum(t3.values())
                 out["config3_boosting_iteration"] = dict(
-                    workload="one GPBoost iteration, n=%d, F=%d, %d bins, %d leaves, Vecchia m=30 (5th iteration; synthetic bins in the reference's layout)" % (n3, F3, nb3, L3),
-                    reference_timing="not timed here (SURVEY.md section 0 quotes ~21 s per iteration on the survey box's 8 cores)", **{k: round(v, 3) for k, v in t3.items()})
+                    workload="GPBoost boosting loop as BASELINE config 3 writes it: %d trees, n=%d, F=%d, %d bins, %d leaves, Vecchia m=30 -- natively through this library's C ABI "
+                             "(synthetic equal-width bins in the reference's layout); the *_ms entries are the LAST iteration's" % (R3, n3, F3, nb3, L3),
+                    config3_100_trees_s=round(t_all, 4), ms_per_iteration_mean=round(t_all / R3 * 1e3, 3),
+                    route_b="the same loop through the reference's own Booster / REModel host code (GPU_use = true): profiles/r05_e_config3_100_trees_routeB_and_native.log "
+                            "(scripts/gpu_config3.py: 1.27 s for the 100 iterations, ensemble predictions of the first 4 trees equal to GPU_use = false to 4e-14; "
+                            "the reference's CPU path: 9.3 s per iteration on that box)",
+                    reference_timing="CPU path of the reference on the bench box: scripts/gpu_config3.py times 4 iterations of it (GPU_use = false)", **{k: round(v, 3) for k, v in t3.items()})
                 hb3.close(); del m3
             except Exception as e:
                 out["config3_boosting_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -1234,6 +1234,14 @@ __global__ __launch_bounds__(kSfThreads) void lap_sptrsv_sf_kernel(LapTri T, int
     // The four groups of a wavefront run in lockstep: a group must never WAIT inside a loop the others cannot leave (one of them may
     // own a source of this row -- the last slot of a level and the first of the next sit side by side).  So a pass only PEEKS at the
     // sources; the groups whose sources are all there finish and publish in that pass, the others take another pass.
+    // (round 5) the row's right-hand side and scale are fetched BEFORE the wait for the sources, not after it: one dependent memory round trip
+    // less on the critical path of every dependency level (the probe-block kernel below has done so since round 4)
+    VecN<NC> num_pre;
+    double den_pre = 1.0;
+    if (lane == 0) {
+      num_pre = ldvec<NC, LS>(rc, row);
+      if (SCALE) den_pre = rdw[row];
+    }
     bool done = false;
     int passes = 0;
     while (!done) {
@@ -1289,8 +1297,8 @@ __global__ __launch_bounds__(kSfThreads) void lap_sptrsv_sf_kernel(LapTri T, int
       const bool ready = ((bal >> gsh) & 0xFFFFull) == 0xFFFFull;        // all 16 lanes of this group saw all their sources
       if (ready) {
         if (lane == 0) {
-          const VecN<NC> num = ldvec<NC, LS>(rc, row);
-          const double den = SCALE ? rdw[row] : 1.0;
+          const VecN<NC>& num = num_pre;
+          const double den = den_pre;
           unsigned long long* xr = reinterpret_cast<unsigned long long*>(xc + (size_t)row * LS);
 #pragma unroll
           for (int c = 0; c < NC; ++c) {

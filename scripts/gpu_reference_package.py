@@ -69,4 +69,28 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "laplace_ref.npz"))
 v = mb.neg_log_likelihood(cov_pars=np.array([1.0, 0.1]), y=y2)
 print("bernoulli_logit neg_log_likelihood = %.9f (reference library %.9f)" % (v, float(g["lap_u2d_n2000_exp_m20_negll_0"])), flush=True)
 assert abs(v - float(g["lap_u2d_n2000_exp_m20_negll_0"])) <= 1e-8 * abs(v)
+# likelihoods with an auxiliary parameter (round 5): the package's GPModel(likelihood = "gamma") -- evaluation at a given shape (aux_pars -> GPB_SetOptimConfig(init_aux_pars)),
+# the fit with the shape estimated (the package's default estimate_aux_pars = True) and get_aux_pars (GPB_GetAuxPars) against the reference LIBRARY's values
+# (tests/golden/laplace_aux_ref.npz)
+ga = np.load(os.path.join(ROOT, "tests", "golden", "laplace_aux_ref.npz"))
+for name in ("gamma_n1500", "negbin_n1500"):
+    ac = cases.LAPLACE_AUX_CASES[name]
+    c = cases.LAPLACE_CASES[ac["model"]]
+    ca, ya = cases.make_aux_data(ac)
+    kw = dict(gp_coords=ca, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"], vecchia_ordering=c["ordering"],
+              likelihood=ac["lik"], seed=c["seed"])
+    mg = gpb.GPModel(**kw)
+    v = mg.neg_log_likelihood(cov_pars=np.asarray(c["cov_pars"][0], dtype=np.float64), y=ya, aux_pars=np.array([ac["aux"]]))
+    print("%s neg_log_likelihood(aux_pars = %g) = %.9f (reference library %.9f)" % (ac["lik"], ac["aux"], v, float(ga[name + "_negll_0"])), flush=True)
+    assert abs(v - float(ga[name + "_negll_0"])) <= 1e-8 * abs(v)
+    mg = gpb.GPModel(**kw)
+    mg.fit(y=ya)
+    cpg = np.asarray(mg.get_cov_pars(format_pandas=False)).ravel()
+    aux = np.asarray(mg.get_aux_pars(format_pandas=False)).ravel()
+    print("%s fit: cov pars %s, shape %s, %d iterations, nll %.7f (reference library: %s, %s, %d, %.7f)" %
+          (ac["lik"], cpg, aux, mg._get_num_optim_iter(), mg.get_current_neg_log_likelihood(), ga[name + "_fit_cov_pars"], ga[name + "_fit_aux"],
+           int(ga[name + "_fit_num_it"]), float(ga[name + "_fit_negll"])), flush=True)
+    assert mg._get_num_optim_iter() == int(ga[name + "_fit_num_it"])
+    assert np.allclose(cpg[:2], ga[name + "_fit_cov_pars"], rtol=1e-4) and np.allclose(aux[:1], ga[name + "_fit_aux"], rtol=1e-4)
+    assert abs(mg.get_current_neg_log_likelihood() - float(ga[name + "_fit_negll"])) <= 1e-7 * abs(float(ga[name + "_fit_negll"]))
 print("REFERENCE PACKAGE ON MI355X: OK", flush=True)
