@@ -7,6 +7,7 @@
 #   smoke                        __graft_entry__.smoke()                        -> smoke.log
 #   bench:<name>:<bench args>    python bench.py <args>                         -> bench_<name>.json (+ .err)
 #   rehearsal:<N>[,<N>...]       python bench.py --gpus N (self-launching; rehearses on one device)  -> bench_rehearsal_N<N>.json
+#   dist1                        bench.py under torch.distributed.run with ONE rank and GPB_BENCH_FORCE_DIST=1 (RCCL + mailbox + A/B in the loop) -> bench_forced_dist_1rank.json
 #   config5                      bench.py at config 5's shape (n=1e6, d=3, Matern-2.5, m=40), metric line only -> bench_config5.json
 #   ubench:<name>                scripts/ubench/<name> (prebuilt binary)        -> ubench_<name>.log
 #   py:<name>:<script + args>    python scripts/<script> <args>                 -> <name>.log
@@ -33,6 +34,9 @@ for STEP in "$@"; do
                  timeout 900 python bench.py --gpus $N --steps 20 --warmup 5 > $O/bench_rehearsal_N$N.json 2> $O/bench_rehearsal_N$N.err; echo "N=$N rc=$?"
                  cut -c1-900 $O/bench_rehearsal_N$N.json; grep -v "^$" $O/bench_rehearsal_N$N.err | grep -iv "warn\|OMP_NUM\|\*\*\*" | tail -4 | cut -c1-300
                done ;;
+    dist1)     # the multi-GPU code path with ONE rank under the driver's launcher: nccl process group, in-library RCCL communicator, mailbox, the A/B of the sums through ncclAllReduce
+               GPB_BENCH_FORCE_DIST=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_forced_dist_1rank.json 2> $O/bench_forced_dist_1rank.err
+               echo "rc=$?"; cut -c1-1500 $O/bench_forced_dist_1rank.json; grep -v "^$" $O/bench_forced_dist_1rank.err | grep -iv "warn\|OMP_NUM\|\*\*\*" | tail -4 | cut -c1-300 ;;
     config5)   timeout 900 python bench.py --n 1000000 --m 40 --d 3 --cov matern_2.5 --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $O/bench_config5.json 2> $O/bench_config5.err
                echo "rc=$?"; cut -c1-1800 $O/bench_config5.json; show $O/bench_config5.err 4 ;;
     ubench)    timeout 300 scripts/ubench/$REST > $O/ubench_$REST.log 2>&1; echo "rc=$?"; show $O/ubench_$REST.log 60 ;;
