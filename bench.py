@@ -189,6 +189,12 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: no line is printed whose n_gpus differs from --gpus "
                          "(run `python bench.py --gpus %d`, which starts its own ranks)" % (args.gpus, world, world))
 
+    # STDOUT carries the one JSON line and nothing else: libraries announce themselves there (RCCL prints its version banner on the first
+    # communicator, gloo its connections), so the descriptor is parked and fd 1 points at stderr until rank 0 writes the line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import gpboost_amd
     from gpboost_amd import parallel, shim
     torch = dist = None
@@ -211,17 +217,8 @@ def main():
         if rehearsal:
             torch.cuda.set_device(0)
             gpboost_amd.set_device(0)
-            # (gloo announces its connections on STDOUT: keep the one JSON line alone there)
-            sys.stdout.flush()
-            saved_out = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group("gloo")
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved_out, 1)
-                os.close(saved_out)
+            dist.init_process_group("gloo")
+            dist.barrier()
             if rank == 0:
                 print("bench.py: REHEARSAL -- %d ranks share device 0 (%d device(s) visible); gloo bootstrap, mailbox for the sums" % (world, ndev), file=sys.stderr)
         else:
@@ -745,7 +742,8 @@ def main():
                                               "call": "GPB_HIP_EvalNegLogLikelihoodBatch (K = 32) in a loop for 10 s, host otherwise idle (after the CPU baseline leg)"}
             except Exception as e:   # noqa: BLE001
                 out["config"]["sustained"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

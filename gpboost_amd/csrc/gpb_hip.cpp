@@ -54,7 +54,40 @@ int fail(const char* fmt, ...) {
     if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-#define API_BEGIN() try {
+// GPB_HIP_API_TIMING=1: every entry point of this ABI accumulates its wall time and call count (inclusive: an entry point that calls another one
+// counts both); the table goes to stderr at process exit and on gpb_hip_api_timing_report.  The integration's counterpart of the reference's TIMETAG
+// build (include/LightGBM/utils/common.h:989-1068): it separates the time the reference's host code spends INSIDE this library from the time it spends
+// in its own code around the seams.  Off (the default): one predictable branch per call.
+struct ApiTiming {
+  struct Row { const char* name; double seconds; long calls; };
+  std::mutex mu;
+  std::vector<Row> rows;
+  bool on;
+  ApiTiming() { const char* e = std::getenv("GPB_HIP_API_TIMING"); on = e && e[0] && e[0] != '0'; }
+  ~ApiTiming() { if (on) report(stderr, true); }
+  void add(const char* name, double s) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& r : rows) if (r.name == name || std::strcmp(r.name, name) == 0) { r.seconds += s; ++r.calls; return; }
+    rows.push_back(Row{ name, s, 1 });
+  }
+  void report(FILE* f, bool reset) {
+    std::lock_guard<std::mutex> lk(mu);
+    std::vector<Row> v = rows;
+    std::sort(v.begin(), v.end(), [](const Row& a, const Row& b) { return a.seconds > b.seconds; });
+    std::fprintf(f, "[gpb_hip api timing] %-52s %10s %12s %12s\n", "entry point (inclusive)", "calls", "total ms", "ms / call");
+    for (const auto& r : v) std::fprintf(f, "[gpb_hip api timing] %-52s %10ld %12.3f %12.4f\n", r.name, r.calls, 1e3 * r.seconds, 1e3 * r.seconds / r.calls);
+    if (reset) rows.clear();
+  }
+};
+ApiTiming g_api_timing;
+struct ApiTimer {
+  const char* name;
+  std::chrono::steady_clock::time_point t0;
+  explicit ApiTimer(const char* n) : name(g_api_timing.on ? n : nullptr) { if (name) t0 = std::chrono::steady_clock::now(); }
+  ~ApiTimer() { if (name) g_api_timing.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
+#define API_BEGIN() ApiTimer api_timer_(__func__); try {
 #define API_END()                                                        \
   }                                                                      \
   catch (const std::exception& ex) { return fail("%s", ex.what()); }     \
@@ -363,6 +396,12 @@ struct gpb_hip_hist {
 extern "C" {
 
 const char* gpb_hip_get_last_error(void) { return g_err; }
+
+int gpb_hip_api_timing_report(int reset) {
+  if (!g_api_timing.on) return fail("gpb_hip_api_timing_report: GPB_HIP_API_TIMING is not set");
+  g_api_timing.report(stderr, reset != 0);
+  return 0;
+}
 
 int gpb_hip_device_count(int* count) {
   int cnt = 0;

@@ -44,6 +44,12 @@ typedef struct gpb_hip_exact gpb_hip_exact_t;
 typedef struct gpb_hip_local_group gpb_hip_local_group_t;   /* in-process group of ranks (threads), see gpb_hip_local_group_create */
 
 GPB_HIP_EXPORT const char* gpb_hip_get_last_error(void);
+
+/* Diagnostics.  With GPB_HIP_API_TIMING=1 in the environment every entry point of this header accumulates its wall time and call count (inclusive);
+ * the table is written to stderr at process exit and by this call (reset != 0 clears it).  It plays the part of the reference's TIMETAG build
+ * (include/LightGBM/utils/common.h:989-1068) for an integration: time inside this library against time in the caller's host code.  -1 if the
+ * variable is not set. */
+GPB_HIP_EXPORT int gpb_hip_api_timing_report(int reset);
 GPB_HIP_EXPORT int gpb_hip_device_count(int* count);
 /* Make `device` current for the calling thread (handles bind to the device current at their creation). */
 GPB_HIP_EXPORT int gpb_hip_set_device(int device);

@@ -40,7 +40,7 @@ if os.path.isfile(LIBP) and "--native-only" not in sys.argv:
     params = ("objective=regression num_leaves=%d learning_rate=0.1 min_data_in_leaf=20 verbosity=-1 num_threads=16 max_bin=%d leaves_newton_update=true "
               "train_gp_model_cov_pars=true" % (LEAVES, NB))
 
-    def run(gpu, rounds):
+    def run(gpu, rounds, device_trees=False):
         t0 = time.perf_counter()
         mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
         ds = C.c_void_p()
@@ -48,7 +48,7 @@ if os.path.isfile(LIBP) and "--native-only" not in sys.argv:
                                          C.c_char_p(("verbosity=-1 max_bin=%d" % NB).encode()), C.c_void_p(), C.byref(ds)))
         okb(LB.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yf.ctypes.data_as(C.c_void_p), C.c_int(N), C.c_int(0)))
         bst = C.c_void_p()
-        okb(LB.LGBM_GPBoosterCreate(ds, C.c_char_p(params.encode()), mdl.h, C.byref(bst)))
+        okb(LB.LGBM_GPBoosterCreate(ds, C.c_char_p((params + (" device_type=gpu" if device_trees else "")).encode()), mdl.h, C.byref(bst)))
         t_setup = time.perf_counter() - t0
         fin = C.c_int(0)
         ts = []
@@ -73,6 +73,15 @@ if os.path.isfile(LIBP) and "--native-only" not in sys.argv:
           (a["t_setup"], ROUNDS, a["t_loop"], 1e3 * float(np.median(a["ts"])), 1e3 * a["ts"][0], a["cov"]), file=sys.stderr, flush=True)
     out.update(config3_100_trees_route_b_s=a["t_loop"], route_b_setup_s=a["t_setup"], route_b_ms_per_iteration_median=1e3 * float(np.median(a["ts"])),
                route_b_cov_pars_after_100=[float(v) for v in a["cov"]])
+    # the whole MI355X configuration of route B: GPU_use = true for the GP AND device_type = gpu for the trees (HIPTreeLearner: whole trees grown by
+    # gpb_hip_hist_grow_tree) -- the reference's Booster / REModel host code around both
+    a2 = run(True, ROUNDS, device_trees=True)
+    err2 = float(np.abs(a2["pred_all"] - a["pred_all"]).max())
+    print("route B, GPU_use=true + device_type=gpu: setup %.2f s, %d iterations %.3f s (median %.2f ms, first %.1f ms), cov pars %s; ensemble of all %d trees: "
+          "max |device trees - host trees| = %.2e" % (a2["t_setup"], ROUNDS, a2["t_loop"], 1e3 * float(np.median(a2["ts"])), 1e3 * a2["ts"][0], a2["cov"], ROUNDS, err2),
+          file=sys.stderr, flush=True)
+    out.update(config3_100_trees_route_b_device_trees_s=a2["t_loop"], route_b_device_trees_ms_per_iteration_median=1e3 * float(np.median(a2["ts"])),
+               route_b_device_trees_vs_host_trees_max_abs_diff=err2)
     if K_CPU > 0:
         b = run(False, K_CPU)
         err = float(np.abs(a["pred_k"] - b["pred_all"]).max())

@@ -203,6 +203,9 @@ if "--trees-only" in sys.argv:
     GPB_CASES = ()
 LB = C.CDLL(LIBP)
 LB.LGBM_GetLastError.restype = C.c_char_p
+EXTRA_IT = 0 if (MOCK or TEST) else int(os.environ.get("GPB_ROUTEB_EXTRA_IT", "8"))
+API_TIMING = os.environ.get("GPB_HIP_API_TIMING", "") not in ("", "0")
+AMD = C.CDLL(os.path.join(ROOT, "gpboost_amd", "lib_gpboost_amd.so")) if API_TIMING else None
 
 
 def okb(rc):
@@ -220,9 +223,11 @@ for n, F, nit in GPB_CASES:
     # --skip-cpu-1e6: the CPU leg at n = 1e6 takes 236 s per boosting iteration (profiles/r04_d_routeB.log: measured once); the GPU leg is then checked
     # against the values that run printed
     skip_cpu = n == 1000000 and "--skip-cpu-1e6" in sys.argv
-    for gpu in ((True,) if skip_cpu else (False, True)):
+    # legs: False = the reference's CPU path; True = GPU_use = true (GP on the device, the reference's CPU tree learner); "trees" = GPU_use = true AND
+    # device_type = gpu (HIPTreeLearner: whole trees on the device too)
+    for gpu in ((True, "trees") if skip_cpu else (False, True) if (MOCK or TEST) else (False, True, "trees")):
         t0 = time.perf_counter()
-        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 12 if MOCK else 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=gpu)
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, 12 if MOCK else 30, "random", 1, threads=-1, lib_path=LIBP, gpu_use=bool(gpu))
         t_create = time.perf_counter() - t0
         ds = C.c_void_p()
         okb(LB.LGBM_DatasetCreateFromMat(X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1),
@@ -230,7 +235,7 @@ for n, F, nit in GPB_CASES:
         okb(LB.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yf.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
         bst = C.c_void_p()
         params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=-1 num_threads=16 max_bin=255 leaves_newton_update=true train_gp_model_cov_pars=true"
-        okb(LB.LGBM_GPBoosterCreate(ds, C.c_char_p(params.encode()), mdl.h, C.byref(bst)))
+        okb(LB.LGBM_GPBoosterCreate(ds, C.c_char_p((params + (" device_type=gpu" if gpu == "trees" else "")).encode()), mdl.h, C.byref(bst)))
         fin = C.c_int(0)
         ts = []
         for _ in range(nit):
@@ -240,11 +245,31 @@ for n, F, nit in GPB_CASES:
         out = np.empty(n); olen = C.c_int64(0)
         okb(LB.LGBM_BoosterPredictForMat(bst, X.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(F), C.c_int(1), C.c_int(1), C.c_int(0),
                                          C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
-        res[gpu] = dict(pred=out, cov=mdl.get_cov_par(3), t_create=t_create, t_iter=float(np.median(ts)))
+        cov_checked = mdl.get_cov_par(3)
+        if gpu and EXTRA_IT > 0:
+            # (the values above are those the CPU leg is compared on; the iterations below only add timing samples: the first iteration of a Booster
+            #  carries BoostFromAverage and the learner's one-time set-up, so a median over 2 is not a per-iteration cost)
+            if API_TIMING:
+                AMD.gpb_hip_api_timing_report(1)
+            for _ in range(EXTRA_IT):
+                t0 = time.perf_counter()
+                okb(LB.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+                ts.append(time.perf_counter() - t0)
+            print("GPBoost n=%d GPU_use=%s: per-iteration wall ms %s" % (n, gpu, " ".join("%.1f" % (1e3 * t) for t in ts)), flush=True)
+            if API_TIMING:
+                print("time inside lib_gpboost_amd.so over the last %d iterations (%.1f ms wall):" % (EXTRA_IT, 1e3 * sum(ts[-EXTRA_IT:])), file=sys.stderr, flush=True)
+                AMD.gpb_hip_api_timing_report(1)
+            ts = ts[nit:]
+        res[gpu] = dict(pred=out, cov=cov_checked, t_create=t_create, t_iter=float(np.median(ts)))
         print("GPBoost n=%d GPU_use=%s: model creation %.2f s, median %.1f ms per boosting iteration (gradient Psi^-1(F-y), tree, Newton leaf values, one "
               "covariance-parameter step); cov pars %s; tree ensemble[:3] = %s" % (n, gpu, t_create, 1e3 * res[gpu]["t_iter"], res[gpu]["cov"], out[:3]), flush=True)
         okb(LB.LGBM_BoosterFree(bst)); okb(LB.LGBM_DatasetFree(ds))
         del mdl
+    if "trees" in res:
+        np.testing.assert_allclose(res["trees"]["pred"], res[True]["pred"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(res["trees"]["cov"], res[True]["cov"], rtol=1e-6)
+        print("GPBoost n=%d: device_type=gpu trees under GPU_use=true give the ensemble and covariance parameters of the host trees; %.1f ms against %.1f ms per iteration"
+              % (n, 1e3 * res["trees"]["t_iter"], 1e3 * res[True]["t_iter"]), flush=True)
     if skip_cpu:
         np.testing.assert_allclose(res[True]["cov"], [0.32799919, 0.29574258, 1.36517975], rtol=1e-6)
         np.testing.assert_allclose(res[True]["pred"][:3], [0.71453864, 0.51212445, 0.9169032], rtol=1e-6)
