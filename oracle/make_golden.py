@@ -185,7 +185,7 @@ def laplace_aux_fixture(out_dir):
 def split_fixture(out_dir):
     """The reference's FeatureHistogram::FindBestThreshold on its own (fixed) histograms: all inputs of the call + its outputs."""
     res = {}
-    for name in cases.SPLIT_DATA:
+    for name in cases.SPLIT_DATA_UNIT:
         X, g, h, leaf = cases.make_split_data(name)
         for ci, cfg in [(str(i), c) for i, c in enumerate(cases.SPLIT_CFGS)] + [("r%d" % i, c) for i, c in enumerate(cases.SPLIT_CFGS_REG)]:
             for li, di in enumerate((None, leaf)):
@@ -209,18 +209,60 @@ def split_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "split_ref.npz"), **res)
 
 
-def tree_fixture(out_dir):
-    """Whole trees grown by the reference's SerialTreeLearner (constant and per-row hessians)."""
+def split_cat_fixture(out_dir):
+    """Round 5: the reference's FeatureHistogram::FindBestThreshold for CATEGORICAL features (FindBestThresholdCategoricalInner) on its own fixed
+    histograms, and Dataset::Split with a bitset over bins (SplitCategorical): tests/golden/split_cat_ref.npz."""
     res = {}
-    for name in cases.TREE_CASES:
+    name = "cat"
+    X, g, h, leaf = cases.make_split_data(name)
+    extra = cases.SPLIT_DATA[name]["params"]
+    for ci, (cfg, cc) in enumerate(cases.SPLIT_CAT_CFGS):
+        for li, di in enumerate((None, leaf)):
+            for hi, hs in enumerate((None, h)):
+                bins, gnb, hist, fx = refdrv.ref_histogram(X, 63, di, g, hs, 1.0, with_fix=True, extra_params=extra, split_cfg=cfg, cat_cfg=cc)
+                key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                res[name + "_bins"] = bins; res[name + "_group_num_bin"] = gnb
+                res[name + "_view_offset"] = fx["view_offset"]; res[name + "_num_bin"] = fx["num_bin"]
+                res[name + "_most_freq_bin"] = fx["most_freq_bin"]; res[name + "_meta3"] = fx["meta3"]; res[name + "_is_categorical"] = fx["is_categorical"]
+                res[key + "_hist_fixed"] = fx["hist_fixed"]; res[key + "_sums"] = fx["sums"]
+                res[key + "_split"] = fx["split"]; res[key + "_default_left"] = fx["split_default_left"]; res[key + "_cat_bits"] = fx["split_cat_bits"]
+                print("split cat", key, "gains", fx["split"][:, 0], "ncat", fx["split"][fx["is_categorical"] > 0, 1])
+    # Dataset::Split of the leaf's rows by bitsets over the bins of the categorical features: the root's winning sets of configuration 0 and fixed patterns
+    cats = np.flatnonzero(res[name + "_is_categorical"])
+    req, bits = [], []
+    for f in cats:
+        nb = int(res[name + "_num_bin"][f])
+        pats = [res["%s_cfg0_leaf0_hess0_cat_bits" % name][f].copy()]
+        for pat in (lambda b: b % 2 == 1, lambda b: b < 3, lambda b: b >= nb - 2, lambda b: True):
+            w = np.zeros(8, dtype=np.uint32)
+            for b in range(nb):
+                if pat(b):
+                    w[b >> 5] |= np.uint32(1) << np.uint32(b & 31)
+            pats.append(w)
+        for w in pats:
+            req.append((int(f), 0, 0)); bits.append(w)
+    _, _, _, fx = refdrv.ref_histogram(X, 63, leaf, g, None, 1.0, with_fix=True, extra_params=extra, partitions=req, partition_cat_bits=np.asarray(bits))
+    res[name + "_part_req"] = np.asarray(req, dtype=np.int32); res[name + "_part_bits"] = np.asarray(bits, dtype=np.uint32)
+    res[name + "_part_lte_count"] = np.asarray([len(a) for a in fx["part_lte"]], dtype=np.int32)
+    res[name + "_part_lte"] = np.concatenate(fx["part_lte"]).astype(np.int32)
+    print("split cat partitions", res[name + "_part_lte_count"])
+    np.savez_compressed(os.path.join(out_dir, "split_cat_ref.npz"), **res)
+
+
+def tree_fixture(out_dir):
+    """Whole trees grown by the reference's SerialTreeLearner (constant and per-row hessians).  `tree r5` regenerates only the round-5 cases
+    (categorical columns, bundled groups) into tree_ref_r5.npz: their bins are the UNBUNDLED per-feature columns."""
+    res = {}
+    r5 = "r5" in sys.argv[2:]
+    for name in (cases.TREE_CASES_R5 if r5 else [k for k in cases.TREE_CASES if k not in cases.TREE_CASES_R5]):
         data, params, L, cfg = cases.tree_params(name)
         X, g, h, leaf = cases.make_split_data(data)
         for hi, hs in enumerate((None, h)):
-            t = refdrv.ref_train_tree(X, params, g, hs, max_leaves=L)
+            t = refdrv.ref_train_tree(X, params, g, hs, max_leaves=L, unbundle=r5)
             for k, v in t.items():
                 res["%s_hess%d_%s" % (name, hi, k)] = np.asarray(v)
             print("tree", name, "hess%d" % hi, "leaves", t["num_leaves"], "root split feature", t["split_feature_inner"][0], "thr", t["threshold_in_bin"][0])
-    np.savez_compressed(os.path.join(out_dir, "tree_ref.npz"), **res)
+    np.savez_compressed(os.path.join(out_dir, "tree_ref_r5.npz" if r5 else "tree_ref.npz"), **res)
 
 
 def optim_fixture(out_dir):
@@ -957,6 +999,8 @@ if __name__ == "__main__":
         tree_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "split":
         split_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "split_cat":
+        split_cat_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "clusters":
         cluster_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "hist":

@@ -433,6 +433,43 @@ def find_best_split(hist, view_offset, num_bin, offset, default_bin, missing, su
     return best, out, dl & 1
 
 
+CAT_DEFAULTS = (4, 32, 10.0, 10.0, 100)     # max_cat_to_onehot, max_cat_threshold, cat_smooth, cat_l2, min_data_per_group (include/LightGBM/config.h)
+
+
+def find_best_split_cat(hist, view_offset_f, num_bin_f, offset_f, sum_gradient, sum_hessian, num_data, lambda_l2=0.0, min_data_in_leaf=20,
+                        min_sum_hessian_in_leaf=1e-3, min_gain_to_split=0.0, lambda_l1=0.0, max_delta_step=0.0, path_smooth=0.0, parent_output=0.0,
+                        cat_cfg=CAT_DEFAULTS):
+    """FeatureHistogram::FindBestThresholdCategoricalInner for ONE categorical feature on the fixed leaf histogram hist (total_bins, 2).
+    -> (row (10,), flags (bit 0 default_left, bit 1 splittable), cat_bits (8,) uint32: bitset over the feature's bins of the categories going left);
+    row[1] = the number of those categories."""
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    row = np.zeros(10); fl = C.c_int(0); bits = np.zeros(8, dtype=np.uint32)
+    data = h[int(view_offset_f):].reshape(-1)
+    lib().orc_find_best_split_cat(_p(np.ascontiguousarray(data), C.c_double), C.c_int(int(num_bin_f)), C.c_int(int(offset_f)), C.c_double(sum_gradient),
+                                  C.c_double(sum_hessian), C.c_int(int(num_data)), C.c_double(lambda_l2), C.c_int(int(min_data_in_leaf)),
+                                  C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split), C.c_double(lambda_l1), C.c_double(max_delta_step),
+                                  C.c_double(path_smooth), C.c_double(parent_output), C.c_int(int(cat_cfg[0])), C.c_int(int(cat_cfg[1])),
+                                  C.c_double(cat_cfg[2]), C.c_double(cat_cfg[3]), C.c_int(int(cat_cfg[4])), _p(row, C.c_double), C.byref(fl),
+                                  _p(bits, C.c_uint32))
+    return row, fl.value, bits
+
+
+def split_leaf_layout(bins_col, min_bin, max_bin, use_min_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, is_categorical,
+                      cat_bits, data_indices):
+    """FeatureGroup::Split for a feature inside a column that may hold several features (numerical: DenseBin::SplitInner<.., USE_MIN_BIN>,
+    categorical: SplitCategoricalInner): (lte_indices, gt_indices) in the order of data_indices."""
+    b = np.ascontiguousarray(bins_col, dtype=np.uint8)
+    di = np.ascontiguousarray(data_indices, dtype=np.int32)
+    bits = np.zeros(8, dtype=np.uint32) if cat_bits is None else np.ascontiguousarray(cat_bits, dtype=np.uint32)
+    lte = np.empty(di.size, dtype=np.int32); gt = np.empty(di.size, dtype=np.int32)
+    lib().orc_split_leaf_layout.restype = C.c_int
+    nl = lib().orc_split_leaf_layout(_p(b, C.c_ubyte), C.c_int(int(min_bin)), C.c_int(int(max_bin)), C.c_int(int(bool(use_min_bin))), C.c_int(int(default_bin)),
+                                     C.c_int(int(most_freq_bin)), C.c_int(int(missing_type)), C.c_int(int(bool(default_left))), C.c_uint(int(threshold)),
+                                     C.c_int(int(bool(is_categorical))), _p(bits, C.c_uint32), _p(di, C.c_int), C.c_int(di.size), _p(lte, C.c_int),
+                                     _p(gt, C.c_int))
+    return lte[:nl].copy(), gt[:di.size - nl].copy()
+
+
 def split_leaf(bins_f, max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, data_indices):
     """DenseBin::Split for a single-feature group: (lte_indices, gt_indices), both in the order of data_indices."""
     b = np.ascontiguousarray(bins_f, dtype=np.uint8)

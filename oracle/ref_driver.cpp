@@ -148,7 +148,7 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
                 unsigned char* bins_out, double* hist_out, int* feat_view_offset, int* feat_num_bin, int* feat_most_freq_bin,
                 double* sums2, double* hist_fixed_out, const char* extra_params, const double* split_cfg4, int* feat_meta3,
                 double* split_out10, int* split_default_left, int num_part, const int* part_ftd3, int* part_lte_out,
-                int* part_lte_count) {
+                int* part_lte_count, int* feat_is_cat, unsigned* split_cat_bits8, const unsigned* part_cat_bits8) {
   try {
     using namespace LightGBM;
     char params[256];
@@ -201,6 +201,12 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
         config.lambda_l2 = split_cfg4[0]; config.min_data_in_leaf = (int)split_cfg4[1];
         config.min_sum_hessian_in_leaf = split_cfg4[2]; config.min_gain_to_split = split_cfg4[3];
         config.lambda_l1 = split_cfg4[4]; config.max_delta_step = split_cfg4[5]; config.path_smooth = split_cfg4[6];
+        /* round 5: [8..12] = max_cat_to_onehot, max_cat_threshold, cat_smooth, cat_l2, min_data_per_group (NaN: the reference's defaults) */
+        if (!std::isnan(split_cfg4[8])) config.max_cat_to_onehot = (int)split_cfg4[8];
+        if (!std::isnan(split_cfg4[9])) config.max_cat_threshold = (int)split_cfg4[9];
+        if (!std::isnan(split_cfg4[10])) config.cat_smooth = split_cfg4[10];
+        if (!std::isnan(split_cfg4[11])) config.cat_l2 = split_cfg4[11];
+        if (!std::isnan(split_cfg4[12])) config.min_data_per_group = (int)split_cfg4[12];
         std::vector<FeatureMetainfo> metas;
         HistogramPool::SetFeatureInfo<true, true>(ds, &config, &metas);
         /* root leaf: parent_output as GetParentOutput computes it (serial_tree_learner.cpp:758-770); used by path smoothing only */
@@ -213,11 +219,21 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
           FeatureHistogram fh;
           fh.Init(hist.data() + (size_t)feat_view_offset[f] * 2, &metas[f]);
           SplitInfo si;
-          fh.FindBestThreshold(sg, sh, num_data, nullptr, parent_output, &si);
+          BasicConstraintEntry no_constraint;            /* (the categorical search reads constraints->LeftToBasicConstraint() even without monotone constraints) */
+          fh.FindBestThreshold(sg, sh, num_data, &no_constraint, parent_output, &si);
           double* r = split_out10 + (size_t)f * 10;
           r[0] = si.gain; r[1] = (double)si.threshold; r[2] = si.left_count; r[3] = si.right_count; r[4] = si.left_output;
           r[5] = si.right_output; r[6] = si.left_sum_gradient; r[7] = si.left_sum_hessian; r[8] = si.right_sum_gradient; r[9] = si.right_sum_hessian;
           split_default_left[f] = si.default_left ? 1 : 0;
+          /* categorical feature (round 5): cat_threshold = the BINS going left (feature_histogram.hpp:495-514); threshold column = their number */
+          if (feat_is_cat) {
+            feat_is_cat[f] = ds->FeatureBinMapper(f)->bin_type() == BinType::CategoricalBin ? 1 : 0;
+            for (int w = 0; w < 8; ++w) split_cat_bits8[8 * f + w] = 0u;
+            if (feat_is_cat[f] && si.gain > kMinScore) {
+              r[1] = (double)si.num_cat_threshold;
+              for (int c = 0; c < si.num_cat_threshold; ++c) split_cat_bits8[8 * f + (si.cat_threshold[c] >> 5)] |= 1u << (si.cat_threshold[c] & 31);
+            }
+          }
         }
       }
     }
@@ -228,7 +244,10 @@ int refdrv_hist(int n, int F, const double* X_rowmajor, int max_bin, const int* 
       std::vector<data_size_t> idx(num_data), lte(num_data), gt(num_data);
       for (int k = 0; k < num_data; ++k) idx[k] = data_indices ? data_indices[k] : k;
       const uint32_t th = (uint32_t)part_ftd3[3 * p + 1];
-      const data_size_t nl = ds->Split(part_ftd3[3 * p], &th, 1, part_ftd3[3 * p + 2] != 0, idx.data(), num_data, lte.data(), gt.data());
+      const bool cat = part_cat_bits8 && ds->FeatureBinMapper(part_ftd3[3 * p])->bin_type() == BinType::CategoricalBin;
+      /* categorical request: the bitset over bins (SerialTreeLearner::SplitInner hands Common::ConstructBitset(cat_threshold), serial_tree_learner.cpp:617-640) */
+      const data_size_t nl = cat ? ds->Split(part_ftd3[3 * p], part_cat_bits8 + 8 * (size_t)p, 8, part_ftd3[3 * p + 2] != 0, idx.data(), num_data, lte.data(), gt.data())
+                                 : ds->Split(part_ftd3[3 * p], &th, 1, part_ftd3[3 * p + 2] != 0, idx.data(), num_data, lte.data(), gt.data());
       part_lte_count[p] = nl;
       std::copy(lte.begin(), lte.begin() + nl, part_lte_out + (size_t)p * num_data);
     }
@@ -251,7 +270,7 @@ int refdrv_train_tree(int n, int F, const double* X_rowmajor, const char* params
                       int* num_groups_out, int* group_num_bin, unsigned char* bins_out, int* feat_view_offset, int* feat_num_bin,
                       int* feat_most_freq_bin, int* feat_meta3, int* num_leaves_out, int* split_feature_inner, int* threshold_in_bin,
                       int* default_left, int* left_child, int* right_child, double* split_gain, int* internal_count,
-                      double* leaf_value, int* leaf_count) {
+                      double* leaf_value, int* leaf_count, int* feat_layout4, int* node_is_cat, unsigned* node_cat_bits8, int max_columns) {
   try {
     using namespace LightGBM;
     omp_set_num_threads(1);
@@ -262,22 +281,90 @@ int refdrv_train_tree(int n, int F, const double* X_rowmajor, const char* params
     }
     Dataset* ds = reinterpret_cast<Dataset*>(dh);
     const int ng = ds->num_groups_;
-    *num_groups_out = ng;
-    for (int g = 0; g < ng; ++g) {
-      group_num_bin[g] = ds->feature_groups_[g]->num_total_bin_;
-      std::unique_ptr<BinIterator> it(ds->feature_groups_[g]->bin_data_->GetIterator(0, group_num_bin[g] - 1, 0));
-      it->Reset(0);
-      for (int i = 0; i < n; ++i) bins_out[(size_t)g * n + i] = (unsigned char)it->RawGet(i);
+    /* COLUMNS of stored bins (what a device keeps resident): a group whose features share ONE Bin (single-feature groups, EFB bundles:
+     * feature_group.h:50-76, bin_offsets_) is one column; a multi-value group keeps one Bin per feature (multi_bin_data_, :484-496, stored
+     * like a single-feature group: 0 = most frequent bin, PushData :199-213) and gives one column per feature.
+     * feat_layout4 (round 5) per feature: {column, min_bin, max_bin of the feature inside the column (FeatureGroup::Split :353-354, :382-383),
+     * bin type (0 numerical, 1 categorical)}; feat_view_offset = first histogram entry of FeatureHistogram::data_ in a histogram laid out
+     * column after column (= group_bin_boundaries_ + bin_offsets_[sub] when no group is multi-valued, train_share_states.cpp:296-300). */
+    int ncol = 0;
+    std::vector<int> col_base;               /* first histogram entry of every column */
+    std::vector<std::vector<int>> col_of(ng);
+    int base = 0;
+    /* max_columns < 0: UNBUNDLED columns -- one column per feature in the layout of a single-feature group (0 = most frequent bin, else the bin,
+     * shifted by one when the most frequent bin is not bin 0: PushData :199-213 with bin_offsets_[0] = 1), whatever Bin the reference keeps the
+     * feature in (dense, sparse, a bundle of any width, a multi-value group): BinIterator::Get returns the feature's own bin for all of them. */
+    const bool unbundle = max_columns < 0;
+    if (unbundle) {
+      int nmv = 0, widest = 0;
+      for (int g = 0; g < ng; ++g) { nmv += ds->feature_groups_[g]->is_multi_val_ ? 1 : 0; widest = std::max(widest, ds->feature_groups_[g]->num_total_bin_); }
+      fprintf(stderr, "refdrv_train_tree: %d features in %d feature groups (%d multi-value), widest group %d bins\n", ds->num_features(), ng, nmv, widest);
+      for (int f = 0; f < ds->num_features(); ++f) {
+        const BinMapper* bm = ds->FeatureBinMapper(f);
+        const int mfb = (int)bm->GetMostFreqBin();
+        const int nb = bm->num_bin() + (mfb == 0 ? 0 : 1);
+        if (nb > 256) { fprintf(stderr, "refdrv_train_tree: a feature with %d stored bins\n", nb); return -1; }
+        std::unique_ptr<BinIterator> it(ds->FeatureIterator(f));
+        it->Reset(0);
+        for (int i = 0; i < n; ++i) {
+          const int b = (int)it->Get(i);
+          bins_out[(size_t)f * n + i] = (unsigned char)(b == mfb ? 0 : (mfb == 0 ? b : b + 1));
+        }
+        group_num_bin[f] = nb;
+        col_base.push_back(base);
+        base += nb;
+      }
+      ncol = ds->num_features();
     }
+    for (int g = 0; g < ng && !unbundle; ++g) {
+      FeatureGroup* fg = ds->feature_groups_[g].get();
+      const int nsub = fg->is_multi_val_ ? fg->num_feature_ : 1;
+      for (int sidx = 0; sidx < nsub; ++sidx) {
+        if (max_columns > 0 && ncol >= max_columns) { fprintf(stderr, "refdrv_train_tree: more than %d columns\n", max_columns); return -1; }
+        int nb;
+        std::unique_ptr<BinIterator> it;
+        if (fg->is_multi_val_) {
+          const int addi = fg->bin_mappers_[sidx]->GetMostFreqBin() == 0 ? 0 : 1;
+          nb = fg->bin_mappers_[sidx]->num_bin() + addi;
+          it.reset(fg->multi_bin_data_[sidx]->GetIterator(0, nb - 1, 0));
+        } else {
+          nb = fg->num_total_bin_;
+          it.reset(fg->bin_data_->GetIterator(0, nb - 1, 0));
+        }
+        if (nb > 256) { fprintf(stderr, "refdrv_train_tree: a column with %d bins\n", nb); return -1; }
+        group_num_bin[ncol] = nb;
+        it->Reset(0);
+        for (int i = 0; i < n; ++i) bins_out[(size_t)ncol * n + i] = (unsigned char)it->RawGet(i);
+        col_of[g].push_back(ncol);
+        col_base.push_back(base);
+        base += nb;
+        ++ncol;
+      }
+    }
+    *num_groups_out = ncol;
     Config config;
     config.Set(Config::Str2Map(params));
     std::vector<FeatureMetainfo> metas;
     HistogramPool::SetFeatureInfo<true, true>(ds, &config, &metas);
     for (int f = 0; f < ds->num_features(); ++f) {
       const BinMapper* bm = ds->FeatureBinMapper(f);
-      feat_view_offset[f] = (int)ds->group_bin_boundaries_[ds->feature2group_[f]] + 1;
+      const int g = ds->feature2group_[f], sub = ds->feature2subfeature_[f];
+      FeatureGroup* fg = ds->feature_groups_[g].get();
+      int col, min_bin, max_bin;
+      if (unbundle) {
+        col = f; min_bin = 1; max_bin = group_num_bin[f] - 1;
+      } else if (fg->is_multi_val_) {
+        col = col_of[g][sub]; min_bin = 1; max_bin = group_num_bin[col] - 1;
+      } else {
+        col = col_of[g][0]; min_bin = (int)fg->bin_offsets_[sub]; max_bin = (int)fg->bin_offsets_[sub + 1] - 1;
+      }
+      feat_view_offset[f] = col_base[col] + min_bin;
       feat_num_bin[f] = bm->num_bin(); feat_most_freq_bin[f] = (int)bm->GetMostFreqBin();
       feat_meta3[3 * f] = metas[f].offset; feat_meta3[3 * f + 1] = (int)metas[f].default_bin; feat_meta3[3 * f + 2] = (int)metas[f].missing_type;
+      if (feat_layout4) {
+        feat_layout4[4 * f] = col; feat_layout4[4 * f + 1] = min_bin; feat_layout4[4 * f + 2] = max_bin;
+        feat_layout4[4 * f + 3] = bm->bin_type() == BinType::CategoricalBin ? 1 : 0;
+      }
     }
     std::vector<score_t> g_all(grad, grad + n), h_all(n, 1.0);
     if (hess) std::copy(hess, hess + n, h_all.begin());
@@ -294,6 +381,18 @@ int refdrv_train_tree(int n, int F, const double* X_rowmajor, const char* params
       default_left[k] = Tree::GetDecisionType(tree->decision_type_[k], kDefaultLeftMask) ? 1 : 0;
       left_child[k] = tree->left_child_[k]; right_child[k] = tree->right_child_[k];
       split_gain[k] = tree->split_gain_[k]; internal_count[k] = tree->internal_count_[k];
+      /* categorical node (Tree::SplitCategorical, src/LightGBM/io/tree.cpp:76-108): threshold_in_bin_ indexes cat_boundaries_inner_; the bitset
+       * over the feature's BINS of the categories going left */
+      if (node_is_cat) {
+        const bool is_cat = Tree::GetDecisionType(tree->decision_type_[k], kCategoricalMask);
+        node_is_cat[k] = is_cat ? 1 : 0;
+        for (int w = 0; w < 8; ++w) node_cat_bits8[8 * k + w] = 0u;
+        if (is_cat) {
+          const int ci = (int)tree->threshold_in_bin_[k];
+          const int b0 = tree->cat_boundaries_inner_[ci], b1 = tree->cat_boundaries_inner_[ci + 1];
+          for (int w = b0; w < b1 && w - b0 < 8; ++w) node_cat_bits8[8 * k + (w - b0)] = tree->cat_threshold_inner_[w];
+        }
+      }
     }
     for (int k = 0; k < nl; ++k) { leaf_value[k] = tree->leaf_value_[k]; leaf_count[k] = tree->leaf_count_[k]; }
     tl.reset();

@@ -340,7 +340,7 @@ def ref_laplace_grad_F(coords, y, cov_pars, likelihood, fixed_effects=None, cov_
 
 
 def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, with_fix=False, extra_params="", split_cfg=None,
-                  partitions=None):
+                  partitions=None, cat_cfg=None, partition_cat_bits=None):
     """The reference's own binning + Dataset::ConstructHistograms for one leaf.
     Returns (bins uint8 (G, n) = the reference's stored group bins, group_num_bin (G,), hist (sum bins, 2)); with_fix=True adds
     a dict with the per-feature view offsets / num_bin / most_freq_bin, the leaf sums and the histogram after
@@ -361,8 +361,11 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
     sums = np.zeros(2); hfix = np.zeros((F * (max_bin + 3), 2))
     cfg = None
     if split_cfg is not None:      # (lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split[, lambda_l1, max_delta_step, path_smooth[, parent_output]])
-        cfg = np.zeros(8); cfg[7] = np.nan
+        cfg = np.zeros(13); cfg[7:] = np.nan
         cfg[:len(split_cfg)] = split_cfg
+        if cat_cfg is not None:    # (max_cat_to_onehot, max_cat_threshold, cat_smooth, cat_l2, min_data_per_group); categorical columns: extra_params "categorical_feature=..."
+            cfg[8:13] = cat_cfg
+    is_cat = np.zeros(F, dtype=np.int32); cat_bits = np.zeros((F, 8), dtype=np.uint32)
     meta3 = np.zeros((F, 3), dtype=np.int32); sp = np.zeros((F, 10)); sdl = np.zeros(F, dtype=np.int32)
     npart = 0 if partitions is None else len(partitions)
     ftd = np.ascontiguousarray(partitions if npart else np.zeros((1, 3)), dtype=np.int32)
@@ -371,7 +374,8 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
                             None if h is None else _P(h), C.c_double(const_hess), C.byref(ng), _P(gnb), _P(bins), _P(hist),
                             _P(voff), _P(nbin), _P(mfb), _P(sums), _P(hfix) if (with_fix or cfg is not None) else None,
                             C.c_char_p(extra_params.encode()), None if cfg is None else _P(cfg), _P(meta3),
-                            None if cfg is None else _P(sp), _P(sdl), C.c_int(npart), _P(ftd), _P(plte), _P(pcnt))
+                            None if cfg is None else _P(sp), _P(sdl), C.c_int(npart), _P(ftd), _P(plte), _P(pcnt), _P(is_cat), _P(cat_bits),
+                            None if partition_cat_bits is None else _P(np.ascontiguousarray(partition_cat_bits, dtype=np.uint32)))
     if rc != 0:
         raise RuntimeError("refdrv_hist failed")
     G = ng.value
@@ -379,14 +383,14 @@ def ref_histogram(X, max_bin, data_indices, grad, hess=None, const_hess=1.0, wit
     if with_fix or cfg is not None:
         out = dict(view_offset=voff, num_bin=nbin, most_freq_bin=mfb, sums=sums, hist_fixed=hfix[:tot].copy())
         if cfg is not None:
-            out.update(meta3=meta3, split=sp, split_default_left=sdl)
+            out.update(meta3=meta3, split=sp, split_default_left=sdl, is_categorical=is_cat, split_cat_bits=cat_bits)
         if npart:
             out["part_lte"] = [plte[p, :pcnt[p]].copy() for p in range(npart)]
         return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy(), out
     return bins[:G].copy(), gnb[:G].copy(), hist[:tot].copy()
 
 
-def ref_train_tree(X, params, grad, hess=None, max_leaves=64):
+def ref_train_tree(X, params, grad, hess=None, max_leaves=64, unbundle=False):
     """One tree grown by the reference's own SerialTreeLearner::Train (single OpenMP thread) on its own Dataset.
     Returns a dict: bins (G, n), group_num_bin, view_offset / num_bin / most_freq_bin / meta3 per feature, num_leaves, and the tree
     arrays split_feature_inner, threshold_in_bin, default_left, left_child, right_child, split_gain, internal_count (num_leaves - 1)
@@ -402,10 +406,12 @@ def ref_train_tree(X, params, grad, hess=None, max_leaves=64):
     ia = {k: np.zeros(L, dtype=np.int32) for k in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child",
                                                     "internal_count", "leaf_count")}
     gain = np.zeros(L); lv = np.zeros(L)
+    layout = np.zeros((F, 4), dtype=np.int32); node_cat = np.zeros(L, dtype=np.int32); node_bits = np.zeros((L, 8), dtype=np.uint32)
     rc = _lib().refdrv_train_tree(C.c_int(n), C.c_int(F), _P(X), C.c_char_p(params.encode()), _P(g), None if h is None else _P(h),
                                   C.byref(ng), _P(gnb), _P(bins), _P(voff), _P(nbin), _P(mfb), _P(meta3), C.byref(nl),
                                   _P(ia["split_feature_inner"]), _P(ia["threshold_in_bin"]), _P(ia["default_left"]), _P(ia["left_child"]),
-                                  _P(ia["right_child"]), _P(gain), _P(ia["internal_count"]), _P(lv), _P(ia["leaf_count"]))
+                                  _P(ia["right_child"]), _P(gain), _P(ia["internal_count"]), _P(lv), _P(ia["leaf_count"]), _P(layout), _P(node_cat),
+                                  _P(node_bits), C.c_int(-1 if unbundle else F))
     if rc != 0:
         raise RuntimeError("refdrv_train_tree failed")
     G, nlv = ng.value, nl.value
@@ -413,4 +419,6 @@ def ref_train_tree(X, params, grad, hess=None, max_leaves=64):
                num_leaves=nlv, split_gain=gain[:nlv - 1].copy(), leaf_value=lv[:nlv].copy(), leaf_count=ia["leaf_count"][:nlv].copy())
     for k in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count"):
         out[k] = ia[k][:nlv - 1].copy()
+    # round 5: per feature (column, min_bin, max_bin, bin type) and per node (is categorical, bitset over the feature's bins of the categories going left)
+    out.update(layout=layout, node_is_cat=node_cat[:nlv - 1].copy(), node_cat_bits=node_bits[:nlv - 1].copy())
     return out

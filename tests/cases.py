@@ -145,12 +145,24 @@ def synthetic_binary(n, d, seed=1):
 # Split search (FeatureHistogram::FindBestThreshold) fixtures: three data sets x two configurations, tests/golden/split_ref.npz
 SPLIT_DATA = {"plain": dict(seed=51, params=""),                       # no missing values: MissingType::None, one reverse scan
               "zero_missing": dict(seed=52, params="zero_as_missing=true"),   # MissingType::Zero, both scans, default bin skipped
-              "nan": dict(seed=53, params="")}                           # NaNs in two features: MissingType::NaN, both scans
+              "nan": dict(seed=53, params=""),                           # NaNs in two features: MissingType::NaN, both scans
+              # round 5 (tree cases only): categorical columns; exclusive sparse columns the reference bundles
+              "cat": dict(seed=54, params="categorical_feature=2,5"),
+              "efb": dict(seed=55, params="")}
+SPLIT_DATA_UNIT = ("plain", "zero_missing", "nan")                        # the data sets of the split / partition unit fixtures (split_ref.npz)
 SPLIT_CFGS = [(0.0, 20, 1e-3, 0.0), (1.5, 5, 1e-3, 0.1)]              # lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split
 # the other regularisation paths: ... + lambda_l1, max_delta_step, path_smooth, parent_output (min_gain_to_split > 0 wherever max_delta_step clips:
 # candidates whose children are clipped to the same output have gain 0 up to rounding noise)
 SPLIT_CFGS_REG = [(0.5, 20, 1e-3, 0.0, 3.0, 0.0, 0.0, 0.0), (0.0, 20, 1e-3, 0.05, 0.0, 0.2, 0.0, 0.0), (0.1, 10, 1e-3, 0.0, 0.0, 0.0, 25.0, 0.07),
                   (1.0, 20, 1e-3, 0.01, 1.5, 0.3, 10.0, -0.11)]
+
+
+# round 5, categorical search: (split cfg as SPLIT_CFGS / SPLIT_CFGS_REG, (max_cat_to_onehot, max_cat_threshold, cat_smooth, cat_l2, min_data_per_group))
+SPLIT_CAT_CFGS = [((0.0, 20, 1e-3, 0.0), (4, 32, 10.0, 10.0, 100)),
+                  ((1.5, 5, 1e-3, 0.1), (4, 32, 5.0, 2.0, 30)),
+                  ((0.5, 20, 1e-3, 0.0, 3.0, 0.0, 0.0, 0.0), (64, 32, 10.0, 10.0, 100)),           # every categorical column one-hot, L1
+                  ((0.1, 10, 1e-3, 0.0, 0.0, 0.3, 25.0, 0.07), (4, 6, 1.0, 0.0, 20)),                 # max_delta_step + smoothing, short scans
+                  ((1.0, 20, 1e-3, 0.01, 1.5, 0.3, 10.0, -0.11), (2, 32, 20.0, 10.0, 200))]
 
 
 def split_partition_requests(num_bin):
@@ -168,6 +180,31 @@ def make_split_data(name):
     c = SPLIT_DATA[name]
     rng = np.random.default_rng(c["seed"])
     n, F = 6000, 6
+    if name == "cat":
+        # two categorical columns (round 5): 3 categories (one-hot search, num_bin <= max_cat_to_onehot) and 40 categories with 10 % of the rows in
+        # category 0 on top (sorted many-vs-many search), next to four numerical columns
+        X = rng.uniform(size=(n, F))
+        X[:, 2] = rng.integers(0, 3, size=n)
+        X[:, 5] = rng.integers(0, 40, size=n) * (rng.uniform(size=n) < 0.9)
+        eff = rng.standard_normal(40)
+        g = np.sin(6 * X[:, 0]) + 0.8 * (X[:, 2] == 1) + eff[X[:, 5].astype(int)] + 0.3 * rng.standard_normal(n)
+        h = rng.uniform(0.5, 2.0, size=n)
+        leaf = np.sort(rng.choice(n, size=2500, replace=False)).astype(np.int32)
+        return X, g, h, leaf
+    if name == "efb":
+        # mutually exclusive sparse columns (round 5): the reference bundles columns 2..9 into ONE feature group (exclusive feature bundling,
+        # dataset.cpp FastFeatureBundling) of 376 bins -- wider than a byte
+        X = np.zeros((n, 10))
+        X[:, 0] = rng.uniform(size=n); X[:, 1] = rng.uniform(size=n)
+        c12 = rng.integers(0, 12, size=n)
+        for k in range(6):
+            X[:, 2 + k] = (c12 == k) * rng.uniform(0.5, 2.0, size=n)
+        X[:, 8] = (c12 == 8) * rng.integers(1, 4, size=n)
+        X[:, 9] = (c12 == 9) * rng.uniform(size=n)
+        g = np.sin(6 * X[:, 0]) + X[:, 3] - 0.5 * X[:, 5] + 0.4 * X[:, 8] + 0.3 * rng.standard_normal(n)
+        h = rng.uniform(0.5, 2.0, size=n)
+        leaf = np.sort(rng.choice(n, size=2500, replace=False)).astype(np.int32)
+        return X, g, h, leaf
     X = rng.uniform(size=(n, F))
     X[:, 1] = 2.0 * X[:, 1] - 1.0
     X[:, 2] = np.round(X[:, 2] * 12) / 12
@@ -196,8 +233,27 @@ TREE_CASES = {
     "nan_smooth": ("nan", "max_bin=63 num_leaves=16 min_data_in_leaf=10 lambda_l2=0.1 path_smooth=25"),
     "plain_depth4": ("plain", "max_bin=63 num_leaves=31 min_data_in_leaf=20 lambda_l2=0 max_depth=4"),
     "plain_all_reg": ("plain", "max_bin=255 num_leaves=20 min_data_in_leaf=20 lambda_l2=1.0 lambda_l1=1.5 max_delta_step=0.3 path_smooth=10 min_gain_to_split=0.01"),
+    # round 5 -- categorical features (FindBestThresholdCategoricalInner, feature_histogram.hpp:278-519): the sorted many-vs-many search with
+    # explicit and with default (cat_smooth = 10, cat_l2 = 10, min_data_per_group = 100, max_cat_threshold = 32) settings, the one-hot search for
+    # every categorical column (max_cat_to_onehot = 64) with L1, path smoothing with a small max_cat_threshold
+    "cat_l15": ("cat", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.1 categorical_feature=2,5 min_data_per_group=50 cat_smooth=5"),
+    "cat_defaults": ("cat", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.1 categorical_feature=2,5"),
+    "cat_onehot_l1": ("cat", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.1 categorical_feature=2,5 max_cat_to_onehot=64 lambda_l1=0.5"),
+    "cat_smooth": ("cat", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.1 categorical_feature=2,5 path_smooth=20 max_cat_threshold=4 cat_l2=1"),
+    # round 5 -- exclusive feature bundling left ON (the reference's default): eight sparse columns in one group of 376 bins; the device keeps
+    # one column per FEATURE (the fixture's bins are the unbundled columns, oracle/ref_driver.cpp)
+    "efb_l15": ("efb", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0 enable_bundle=true"),
+    "efb_rowwise_l15": ("efb", "max_bin=63 num_leaves=15 min_data_in_leaf=20 lambda_l2=0.5 enable_bundle=true force_row_wise=true"),
 }
 TREE_COMMON = " min_data_in_bin=1 enable_bundle=false force_col_wise=true verbosity=-1 num_threads=1 min_sum_hessian_in_leaf=0.001"
+TREE_CASES_R5 = ("cat_l15", "cat_defaults", "cat_onehot_l1", "cat_smooth", "efb_l15", "efb_rowwise_l15")
+
+
+def tree_cat_cfg(name):
+    """(max_cat_to_onehot, max_cat_threshold, cat_smooth, cat_l2, min_data_per_group) of a tree case (the reference's defaults where not given)."""
+    kv = dict(t.split("=") for t in TREE_CASES[name][1].split())
+    return (int(kv.get("max_cat_to_onehot", 4)), int(kv.get("max_cat_threshold", 32)), float(kv.get("cat_smooth", 10.0)), float(kv.get("cat_l2", 10.0)),
+            int(kv.get("min_data_per_group", 100)))
 
 
 def tree_params(name):
@@ -207,7 +263,12 @@ def tree_params(name):
     reg = (float(kv.get("lambda_l1", 0.0)), float(kv.get("max_delta_step", 0.0)), float(kv.get("path_smooth", 0.0)))
     if any(v != 0.0 for v in reg):
         cfg = cfg + reg
-    return data, p + TREE_COMMON, int(kv["num_leaves"]), cfg
+    common = TREE_COMMON
+    if "enable_bundle" in kv:              # (Config::Str2Map keeps the first value of a repeated key -- still, say it once)
+        common = common.replace(" enable_bundle=false", "")
+    if "force_row_wise" in kv:
+        common = common.replace(" force_col_wise=true", "")
+    return data, p + common, int(kv["num_leaves"]), cfg
 
 
 def tree_max_depth(name):

@@ -388,7 +388,7 @@ def test_r_golden_vecchia_cluster_ids_prediction(orc):
     assert np.abs(cov.ravel() - [0.7430552, 0.0, 0.6423148, 0.0, 1.1, 0.0, 0.6423148, 0.0, 0.7434589]).sum() < R_TOL
 
 
-@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA_UNIT))
 def test_oracle_split_search_regularisation_paths_match_reference_fixture(orc, name):
     """The same with lambda_l1 / max_delta_step / path_smooth (and a given parent_output): the reference's USE_L1 / USE_MAX_OUTPUT /
     USE_SMOOTHING instances of FindBestThresholdSequentially (feature_histogram.hpp:137-161), every field of SplitInfo bit-identical."""
@@ -412,7 +412,7 @@ def test_oracle_split_search_regularisation_paths_match_reference_fixture(orc, n
 
 
 # ---- split search on a leaf histogram ----------------------------------------------------------------------
-@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA_UNIT))
 def test_oracle_split_search_matches_reference_fixture(orc, name):
     """orc_find_best_split against the reference's own FeatureHistogram::FindBestThreshold (all three missing-value types, two
     regularisation settings, root and leaf, constant and per-row hessians): every field of SplitInfo bit-identical."""
@@ -437,7 +437,7 @@ def test_oracle_split_search_matches_reference_fixture(orc, name):
     assert checked >= 30        # most features are splittable in every setting
 
 
-@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA))
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_DATA_UNIT))
 def test_oracle_leaf_partition_matches_reference_fixture(orc, name):
     """orc_split_leaf against the reference's own Dataset::Split (DenseBin::SplitInner, all missing-value variants): the lists of
     rows going left / right are identical, order included."""
@@ -465,19 +465,81 @@ def test_oracle_primitives_grow_the_reference_tree(orc, name, hi):
     SerialTreeLearner::Train (tests/tree_harness.py), reproduce the tree the reference's own SerialTreeLearner grows on its own Dataset
     (tests/golden/tree_ref.npz): structure, thresholds, default directions, counts exactly; leaf values and gains bit for bit."""
     from tests import tree_harness as th
-    g = np.load(os.path.join(GOLD, "tree_ref.npz"))
+    r5 = name in cases.TREE_CASES_R5       # round 5: categorical columns / bundled groups (bins = the unbundled per-feature columns), tree_ref_r5.npz
+    g = np.load(os.path.join(GOLD, "tree_ref_r5.npz" if r5 else "tree_ref.npz"))
     data, params, L, cfg = cases.tree_params(name)
     X, grad, hess, leaf = cases.make_split_data(data)
     k = "%s_hess%d_" % (name, hi)
     hs = hess if hi else None
     be = th.OracleBackend(orc, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
-                          g[k + "meta3"], grad, hs)
+                          g[k + "meta3"], grad, hs, is_cat=g[k + "layout"][:, 3] if r5 else None, cat_cfg=cases.tree_cat_cfg(name))
     t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg, max_depth=cases.tree_max_depth(name))
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count", "leaf_count"):
         assert np.array_equal(t[key], g[k + key]), key
     assert np.array_equal(t["leaf_value"], g[k + "leaf_value"])
     assert np.array_equal(t["split_gain"], g[k + "split_gain"])
+    if r5:       # categorical nodes: the same nodes, the same sets of bins going left (Tree::SplitCategorical's cat_threshold_inner_)
+        assert np.array_equal(t["node_is_cat"], g[k + "node_is_cat"])
+        assert np.array_equal(np.asarray(t["node_cat_bits"]).reshape(-1, 8), g[k + "node_cat_bits"])
+        if data == "cat":
+            assert int(g[k + "node_is_cat"].sum()) >= 5
+        if data == "efb":
+            assert len(set(t["split_feature_inner"].tolist()) & set(range(2, 10))) >= 2        # splits on bundled columns
+
+
+def test_oracle_categorical_split_search_matches_reference_fixture(orc):
+    """orc_find_best_split_cat against the reference's own FeatureHistogram::FindBestThreshold for categorical features
+    (FindBestThresholdCategoricalInner: one-hot and sorted many-vs-many, L1 / max_delta_step / path smoothing, cat_smooth / cat_l2 /
+    min_data_per_group / max_cat_threshold varied; root and leaf, constant and per-row hessians): every field of SplitInfo and the set of bins going
+    left bit-identical (tests/golden/split_cat_ref.npz, oracle/make_golden.py split_cat)."""
+    g = np.load(os.path.join(GOLD, "split_cat_ref.npz"))
+    name = "cat"
+    meta3, is_cat = g[name + "_meta3"], g[name + "_is_categorical"]
+    assert is_cat.sum() == 2
+    n_all = g[name + "_bins"].shape[1]
+    splittable = onehot = sorted_sets = 0
+    for ci, (cfg, cc) in enumerate(cases.SPLIT_CAT_CFGS):
+        for li in (0, 1):
+            for hi in (0, 1):
+                key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums = g[key + "_sums"]
+                num_data = n_all if li == 0 else 2500
+                for f in np.flatnonzero(is_cat):
+                    row, fl, bits = orc.find_best_split_cat(g[key + "_hist_fixed"], g[name + "_view_offset"][f], g[name + "_num_bin"][f], meta3[f, 0],
+                                                            sums[0], sums[1], num_data, *cfg, cat_cfg=cc)
+                    ref = g[key + "_split"][f]
+                    assert np.array_equal(row, ref), (key, f, row, ref)
+                    assert (fl & 1) == int(g[key + "_default_left"][f])
+                    assert np.array_equal(bits, g[key + "_cat_bits"][f]), (key, f)
+                    if np.isfinite(ref[0]):
+                        splittable += 1
+                        assert int(ref[1]) == sum(bin(int(w)).count("1") for w in bits)
+                        onehot += int(g[name + "_num_bin"][f] <= cc[0]); sorted_sets += int(ref[1] > 1)
+                # the numerical columns of the same histograms through the threshold scans
+                best, out, dl = orc.find_best_split(g[key + "_hist_fixed"], g[name + "_view_offset"], g[name + "_num_bin"], meta3[:, 0], meta3[:, 1],
+                                                    meta3[:, 2], sums[0], sums[1], num_data, *cfg)
+                num = np.flatnonzero(is_cat == 0)
+                assert np.array_equal(out[num], g[key + "_split"][num]) and np.array_equal(dl[num], g[key + "_default_left"][num])
+    assert splittable >= 30 and onehot >= 8 and sorted_sets >= 8
+
+
+def test_oracle_categorical_partition_matches_reference_fixture(orc):
+    """orc_split_leaf_layout (categorical) against the reference's Dataset::Split with a bitset over bins (DenseBin::SplitCategoricalInner): the rows going
+    left, order included."""
+    g = np.load(os.path.join(GOLD, "split_cat_ref.npz"))
+    name = "cat"
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3, mfb = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"], g[name + "_most_freq_bin"]
+    pos = 0
+    two_sided = 0
+    for (f, th, dl), w, nl in zip(g[name + "_part_req"], g[name + "_part_bits"], g[name + "_part_lte_count"]):
+        lte, gt = orc.split_leaf_layout(bins[f], 1, gnb[f] - 1, False, meta3[f, 1], mfb[f], meta3[f, 2], dl, th, True, w, leaf)
+        assert np.array_equal(lte, g[name + "_part_lte"][pos:pos + nl]), (f, w)
+        assert np.array_equal(np.sort(np.concatenate([lte, gt])), leaf)
+        two_sided += int(len(lte) > 0 and len(gt) > 0)
+        pos += nl
+    assert pos == g[name + "_part_lte"].size and two_sided >= 6
 
 
 # ---- standard errors (Fisher information; SURVEY.md 8f rank 3) -- checker only, no device path yet -----------------------------

@@ -11,8 +11,11 @@ K_EPS = float(np.float32(1e-15))
 class OracleBackend(object):
     """bins (G, n) uint8 + metas; histograms live in a dict of numpy arrays."""
 
-    def __init__(self, orc, bins, gnb, view_offset, num_bin, most_freq_bin, meta3, grad, hess):
+    def __init__(self, orc, bins, gnb, view_offset, num_bin, most_freq_bin, meta3, grad, hess, is_cat=None, cat_cfg=None):
         self.orc, self.bins = orc, bins
+        self.is_cat = np.zeros(bins.shape[0], dtype=np.int32) if is_cat is None else np.asarray(is_cat, dtype=np.int32)
+        self.cat_cfg = orc.CAT_DEFAULTS if cat_cfg is None else cat_cfg
+        self.last_cat_bits = np.zeros((bins.shape[0], 8), dtype=np.uint32)
         self.bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
         self.gnb, self.vo, self.nb, self.mfb, self.meta3 = gnb, view_offset, num_bin, most_freq_bin, meta3
         self.grad, self.hess = grad, hess
@@ -30,19 +33,31 @@ class OracleBackend(object):
     def search(self, slot, sg, sh, cnt, cfg, used, parent_output=0.0):
         best, out, dl = self.orc.find_best_split(self.slots[slot], self.vo, self.nb, self.meta3[:, 0], self.meta3[:, 1], self.meta3[:, 2],
                                                  sg, sh, cnt, *cfg, parent_output=parent_output)
-        return out, dl, self.orc.find_best_split.last_splittable.copy()
+        spl = self.orc.find_best_split.last_splittable.copy()
+        self.last_cat_bits = np.zeros((self.F, 8), dtype=np.uint32)
+        for f in np.nonzero(self.is_cat)[0]:          # categorical features: FindBestThresholdCategoricalInner instead of the threshold scans
+            row, fl, bits = self.orc.find_best_split_cat(self.slots[slot], self.vo[f], self.nb[f], self.meta3[f, 0], sg, sh, cnt, *cfg,
+                                                         parent_output=parent_output, cat_cfg=self.cat_cfg)
+            out[f] = row; dl[f] = fl & 1; spl[f] = (fl >> 1) & 1; self.last_cat_bits[f] = bits
+        return out, dl, spl
 
-    def partition(self, idx, f, thr, dl):
+    def partition(self, idx, f, thr, dl, cat_bits=None):
+        if self.is_cat[f]:
+            return self.orc.split_leaf_layout(self.bins[f], 1, self.gnb[f] - 1, False, self.meta3[f, 1], self.mfb[f], self.meta3[f, 2], dl, thr, True, cat_bits, idx)
         return self.orc.split_leaf(self.bins[f], self.gnb[f] - 1, self.meta3[f, 1], self.mfb[f], self.meta3[f, 2], dl, thr, idx)
 
 
 class GpuBackend(object):
-    def __init__(self, shim, bins, gnb, view_offset, num_bin, most_freq_bin, meta3, grad, hess, num_leaves):
+    def __init__(self, shim, bins, gnb, view_offset, num_bin, most_freq_bin, meta3, grad, hess, num_leaves, is_cat=None, cat_cfg=None):
         bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
         self.hb = shim.HistBuilder(bins, bo)
         self.hb.pool_resize(num_leaves + 1)
         self.hb.set_fix_info(view_offset, num_bin, most_freq_bin)
         self.hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+        self.is_cat = np.zeros(bins.shape[0], dtype=np.int32) if is_cat is None else np.asarray(is_cat, dtype=np.int32)
+        if self.is_cat.any():
+            self.hb.set_categorical(self.is_cat, *(cat_cfg if cat_cfg is not None else (4, 32, 10.0, 10.0, 100)))
+        self.last_cat_bits = np.zeros((bins.shape[0], 8), dtype=np.uint32)
         self.hb.set_gradients(grad, hess)
         self.F = bins.shape[0]
 
@@ -57,10 +72,11 @@ class GpuBackend(object):
         if len(cfg) > 4:
             self.hb.set_regularisation(cfg[4], cfg[5], cfg[6], parent_output)
         best, out, dl = self.hb.find_best_split(slot, sg, sh, cnt, *cfg[:4])
+        self.last_cat_bits = self.hb.last_cat_bits.copy()
         return out, dl, self.hb.last_splittable.copy()
 
-    def partition(self, idx, f, thr, dl):
-        return self.hb.split_leaf(idx, f, thr, dl)
+    def partition(self, idx, f, thr, dl, cat_bits=None):
+        return self.hb.split_leaf(idx, f, thr, dl, cat_bits=cat_bits if self.is_cat[f] else None)
 
     def close(self):
         self.hb.close()
@@ -120,7 +136,7 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
                 continue
             cand = (out[f, 0], f)
             if _better(cand, top):
-                top = cand; row = (out[f].copy(), int(dl[f]))
+                top = cand; row = (out[f].copy(), int(dl[f]), be.last_cat_bits[f].copy())
         best[leaf] = dict(gain=top[0], feature=top[1], row=row)
         splittable[leaf] = spl
 
@@ -128,7 +144,10 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
     # feature_fraction: the tree's sampled columns (ColSampler::is_feature_used_bytree, serial_tree_learner.cpp:329); children inherit the mask
     # through the parent's is_splittable flags
     search_leaf(0, np.ones(F, dtype=np.int8) if feature_mask is None else np.asarray(feature_mask, dtype=np.int8))
-    nodes = dict(split_feature_inner=[], threshold_in_bin=[], default_left=[], left_child=[], right_child=[], split_gain=[], internal_count=[])
+    nodes = dict(split_feature_inner=[], threshold_in_bin=[], default_left=[], left_child=[], right_child=[], split_gain=[], internal_count=[],
+                 node_is_cat=[], node_cat_bits=[])
+    is_cat = getattr(be, "is_cat", np.zeros(F, dtype=np.int32))
+    ncat_nodes = 0
     node_rows = []                               # rows of the leaf each node split (for the tests' tie analysis)
     leaf_parent_node = {0: -1}
     leaf_is_left = {0: True}
@@ -163,11 +182,15 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
         b = best[top_leaf]
         if not (b["gain"] > 0.0):
             break
-        row, dl = b["row"]
+        row, dl, cbits = b["row"]
         f, thr = b["feature"], int(row[1])
         rows = idx[top_leaf] if idx[top_leaf] is not None else np.arange(n, dtype=np.int32)
         node_rows.append(rows)
-        lte, gt = be.partition(rows, f, thr, dl)
+        if is_cat[f]:
+            lte, gt = be.partition(rows, f, thr, dl, cat_bits=cbits)
+            thr = ncat_nodes; ncat_nodes += 1          # Tree::SplitCategorical: threshold_in_bin_ = index of the node's bitset (tree.cpp:76-108)
+        else:
+            lte, gt = be.partition(rows, f, thr, dl)
         left, right = top_leaf, nleaves
         node = len(nodes["split_feature_inner"])
         # Tree::Split bookkeeping (include/LightGBM/tree.h): children are ~leaf; the parent's pointer to this leaf becomes the new node
@@ -178,6 +201,7 @@ def grow_tree(be, grad, hess, n, num_leaves, cfg, max_depth=0, feature_mask=None
             else:
                 nodes["right_child"][pn] = node
         nodes["split_feature_inner"].append(f); nodes["threshold_in_bin"].append(thr); nodes["default_left"].append(dl)
+        nodes["node_is_cat"].append(int(is_cat[f])); nodes["node_cat_bits"].append(cbits if is_cat[f] else np.zeros(8, dtype=np.uint32))
         nodes["left_child"].append(~left); nodes["right_child"].append(~right)
         nodes["split_gain"].append(float(np.float32(row[0] + min_gain))); nodes["internal_count"].append(len(lte) + len(gt))
         leaf_parent_node[left] = node; leaf_parent_node[right] = node
