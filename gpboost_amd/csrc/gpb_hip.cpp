@@ -391,6 +391,12 @@ struct gpb_hip_hist {
   struct Pinned { const void* p = nullptr; size_t bytes = 0; };
   Pinned pin[3];
   std::vector<double> tree_node_info;                      // last tree of gpb_hip_hist_grow_tree: per node {left / right output, count, sum of hessians}
+  // categorical features (round 5; gpb_hip_hist_set_categorical): flags per feature, the search's configuration, bitsets over bins of the last searches
+  std::vector<signed char> h_is_cat; signed char* d_is_cat = nullptr; bool any_cat = false;
+  gpb::CatCfg cat;
+  unsigned* d_cat_bits = nullptr;                          // [F][8]: gpb_hip_hist_find_best_split
+  unsigned* d_cat_bits2 = nullptr; unsigned* h_cat_bits2 = nullptr;     // [2][F][8]: the tree grower's two candidate sets (device, pinned host)
+  std::vector<int> tree_node_is_cat; std::vector<unsigned> tree_node_cat_bits;   // last tree: per node, is the split categorical / the 8 words of its set of bins
 };
 
 extern "C" {
@@ -2306,8 +2312,36 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   if (h->h_counts) (void)hipHostFree(h->h_counts); dev_free(h->d_ptags); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
   if (h->h_split2) (void)hipHostFree(h->h_split2);
   if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
+  dev_free(h->d_is_cat); dev_free(h->d_cat_bits); dev_free(h->d_cat_bits2);
+  if (h->h_cat_bits2) (void)hipHostFree(h->h_cat_bits2);
   h->comm.release(); dev_free(h->d_limbs);
   delete h;
+  API_END();
+}
+
+/* Categorical features (round 5): is_categorical[f] != 0 -> feature f is searched by FindBestThresholdCategoricalInner (feature_histogram.hpp:278-519)
+ * instead of the threshold scans, and its splits are sets of bins (DenseBin::SplitCategorical).  NULL flags: every feature numerical again. */
+int gpb_hip_hist_set_categorical(gpb_hip_hist_t* h, const int8_t* is_categorical, int32_t max_cat_to_onehot, int32_t max_cat_threshold, double cat_smooth,
+                                 double cat_l2, int32_t min_data_per_group) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  HIP_OK(hipSetDevice(h->device));
+  h->any_cat = false;
+  h->h_is_cat.assign((size_t)h->F, 0);
+  if (is_categorical) for (int f = 0; f < h->F; ++f) { h->h_is_cat[f] = is_categorical[f] ? 1 : 0; h->any_cat = h->any_cat || is_categorical[f]; }
+  if (!h->any_cat) return 0;
+  if (max_cat_to_onehot < 0 || max_cat_threshold < 1 || !(cat_smooth >= 0.0) || !(cat_l2 >= 0.0) || min_data_per_group < 0)
+    return fail("gpb_hip_hist_set_categorical: max_cat_to_onehot %d, max_cat_threshold %d, cat_smooth %g, cat_l2 %g, min_data_per_group %d", max_cat_to_onehot,
+                max_cat_threshold, cat_smooth, cat_l2, min_data_per_group);
+  h->cat.max_cat_to_onehot = max_cat_to_onehot; h->cat.max_cat_threshold = max_cat_threshold; h->cat.cat_smooth = cat_smooth; h->cat.cat_l2 = cat_l2;
+  h->cat.min_data_per_group = min_data_per_group;
+  if (!h->d_is_cat) HIP_OK(hipMalloc(&h->d_is_cat, (size_t)h->F));
+  HIP_OK(hipMemcpy(h->d_is_cat, h->h_is_cat.data(), (size_t)h->F, hipMemcpyHostToDevice));
+  if (!h->d_cat_bits) {
+    HIP_OK(hipMalloc(&h->d_cat_bits, sizeof(unsigned) * (size_t)h->F * 8)); HIP_OK(hipMemset(h->d_cat_bits, 0, sizeof(unsigned) * (size_t)h->F * 8));
+    HIP_OK(hipMalloc(&h->d_cat_bits2, sizeof(unsigned) * (size_t)h->F * 16)); HIP_OK(hipMemset(h->d_cat_bits2, 0, sizeof(unsigned) * (size_t)h->F * 16));
+    HIP_OK(hipHostMalloc(&h->h_cat_bits2, sizeof(unsigned) * (size_t)h->F * 16)); std::memset(h->h_cat_bits2, 0, sizeof(unsigned) * (size_t)h->F * 16);
+  }
   API_END();
 }
 
@@ -2653,7 +2687,7 @@ int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gra
                                      min_data_in_leaf, min_sum_hessian_in_leaf, min_gain_to_split,
                                      gpb::SplitReg{ h->reg_l1, h->reg_max_delta_step, h->reg_path_smooth, h->reg_parent_output },
                                      is_feature_used ? h->d_used : nullptr,
-                                     h->d_split, h->d_split_i, h->d_split_i + F, h->stream));
+                                     h->d_split, h->d_split_i, h->d_split_i + F, h->stream, h->any_cat ? h->d_is_cat : nullptr, h->cat, h->d_cat_bits));
   std::vector<int> ints(F + 1);
   HIP_OK(hipMemcpyAsync(ints.data(), h->d_split_i, sizeof(int) * (size_t)(F + 1), hipMemcpyDeviceToHost, h->stream));
   if (per_feature_out10) HIP_OK(hipMemcpyAsync(per_feature_out10, h->d_split, sizeof(double) * (size_t)F * 10, hipMemcpyDeviceToHost, h->stream));
@@ -2666,9 +2700,41 @@ int gpb_hip_hist_find_best_split(gpb_hip_hist_t* h, int32_t slot, double sum_gra
   API_END();
 }
 
+/* the sets of bins (8 words per feature) the categorical features' candidates of the LAST gpb_hip_hist_find_best_split send left */
+int gpb_hip_hist_last_split_cat_bits(gpb_hip_hist_t* h, uint32_t* bits_out) {
+  API_BEGIN();
+  if (!h || !bits_out) return fail("null argument");
+  std::fill(bits_out, bits_out + (size_t)h->F * 8, 0u);
+  if (!h->any_cat) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpyAsync(bits_out, h->d_cat_bits, sizeof(unsigned) * (size_t)h->F * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  API_END();
+}
+
+static int hist_split_leaf_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature, uint32_t threshold,
+                                int default_left, const uint32_t* cat_bits8, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count);
+
 int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature, uint32_t threshold,
                             int default_left, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count) {
   API_BEGIN();
+  if (hist_split_leaf_impl(h, data_indices, cnt, feature, threshold, default_left, nullptr, lte_out, gt_out, lte_count)) return -1;
+  API_END();
+}
+
+/* the same for a categorical feature: the rows whose bin is in the set (8 words, bit b = the feature's bin b) go left (Dataset::Split with a bitset,
+ * DenseBin::SplitCategorical, dense_bin.hpp:305-362) */
+int gpb_hip_hist_split_leaf_categorical(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature, const uint32_t* cat_bits8,
+                                        int32_t* lte_out, int32_t* gt_out, int32_t* lte_count) {
+  API_BEGIN();
+  if (!cat_bits8) return fail("null argument");
+  if (hist_split_leaf_impl(h, data_indices, cnt, feature, 0u, 0, cat_bits8, lte_out, gt_out, lte_count)) return -1;
+  API_END();
+}
+
+static int hist_split_leaf_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature, uint32_t threshold,
+                                int default_left, const uint32_t* cat_bits8, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count) {
+  {
   if (!h || !lte_out || !gt_out || !lte_count) return fail("null argument");
   if (!h->has_fix || !h->has_split_info) return fail("gpb_hip_hist_split_leaf: feature metas have not been set (gpb_hip_hist_set_fix_info, gpb_hip_hist_set_split_info)");
   if (feature < 0 || feature >= h->F) return fail("gpb_hip_hist_split_leaf: feature %d of %d", feature, h->F);
@@ -2686,7 +2752,7 @@ int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* data_indices, int3
   const int max_bin = h->h_bin_offsets[feature + 1] - h->h_bin_offsets[feature] - 1;      // stored bins of the (single-feature) group - 1
   HIP_OK(gpb::launch_hist_partition(h->d_bins_rm, h->fpad, feature, max_bin, h->h_meta3[3 * feature + 1], h->h_fix[2 * F + feature],
                                     h->h_meta3[3 * feature + 2], default_left ? 1 : 0, threshold, data_indices ? d_idx : nullptr, cnt,
-                                    blk_cnt, blk_off, d_lte, d_gt, h->stream));
+                                    blk_cnt, blk_off, d_lte, d_gt, h->stream, cat_bits8));
   int nl = 0;
   HIP_OK(hipMemcpyAsync(&nl, blk_off + nblk, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -2694,7 +2760,8 @@ int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* data_indices, int3
   if (cnt - nl > 0) HIP_OK(hipMemcpyAsync(gt_out, d_gt, sizeof(int) * (size_t)(cnt - nl), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   *lte_count = nl;
-  API_END();
+  }
+  return 0;
 }
 
 int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out) {

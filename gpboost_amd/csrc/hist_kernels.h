@@ -31,6 +31,10 @@ struct HistKernelArgs {
 // regularisation of the split search beyond lambda_l2 (feature_histogram.hpp:137-161) + the parent_output argument of FindBestThreshold
 struct SplitReg { double lambda_l1 = 0.0, max_delta_step = 0.0, path_smooth = 0.0, parent_output = 0.0; };
 
+// categorical features (round 5): the configuration of FindBestThresholdCategoricalInner (include/LightGBM/config.h: max_cat_to_onehot 4,
+// max_cat_threshold 32, cat_smooth 10, cat_l2 10, min_data_per_group 100)
+struct CatCfg { int max_cat_to_onehot = 4, max_cat_threshold = 32, min_data_per_group = 100; double cat_smooth = 10.0, cat_l2 = 10.0; };
+
 struct ChildrenSearchArgs {
   double* smaller;          // slot of the smaller child's histogram (fresh from the build, not yet fixed)
   double* parent;           // slot of the parent's histogram: becomes the larger child's
@@ -49,6 +53,7 @@ struct ChildrenSearchArgs {
   const long long* part_grad = nullptr; const long long* part_hess = nullptr; const uint32_t* part_cnt = nullptr;
   const unsigned long long* grad_max_bits = nullptr; const unsigned long long* hess_max_bits = nullptr;
   int fpad = 0, nchunks = 0, has_hess = 0; double const_hess = 1.0;
+  const signed char* is_cat = nullptr; CatCfg cat; unsigned* out_cat = nullptr;   // categorical features: flags [F], configuration, [2][F][8] bitsets over bins
   unsigned* ticket = nullptr;   // device word, zero between launches: workgroups that have finished
   int* host_seq = nullptr;      // pinned host word: receives seq from the last workgroup (nullptr: the host synchronises the stream instead)
   int seq = 0;
@@ -78,15 +83,16 @@ hipError_t launch_hist_fix(double* hist, int num_features, const int* view_offse
 hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
                                   double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
                                   double min_sum_hessian, double min_gain_to_split, SplitReg reg, const signed char* is_feature_used, double* out10,
-                                  int* out_default_left, int* best_feature, hipStream_t st);
+                                  int* out_default_left, int* best_feature, hipStream_t st, const signed char* is_cat = nullptr, CatCfg cat = CatCfg(),
+                                  unsigned* out_cat = nullptr);
 hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                  int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
-                                 int* blk_off, int* lte, int* gt, hipStream_t st);
+                                 int* blk_off, int* lte, int* gt, hipStream_t st, const unsigned* cat_bits8 = nullptr);
 hipError_t launch_hist_partition_segment(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                          int missing_type, int default_left, unsigned threshold, const int* src, int cnt, int* blk_cnt,
                                          int* blk_off, int* dst, int* counts, int* host_counts, hipStream_t st,
                                          unsigned long long* tags = nullptr, unsigned epoch = 0, int host_seq = 0, int* err = nullptr,
-                                         bool* host_seq_written = nullptr);
+                                         bool* host_seq_written = nullptr, const unsigned* cat_bits8 = nullptr);
 // (tags: 256 device granules, zero at allocation, epoch > 0 and different for every launch -> segments of at most 262 144 rows go through
 //  ONE launch, hist_partition_onepass_kernel; host_seq != 0: host_counts[2] receives it after host_counts[0..1], see *host_seq_written)
 hipError_t launch_hist_children_search(const ChildrenSearchArgs& a, hipStream_t st);

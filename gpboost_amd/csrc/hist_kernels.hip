@@ -789,11 +789,184 @@ __device__ void best_split_feature(const double* hist, int f, const int* __restr
   __syncthreads();
 }
 
+// ---- categorical features (round 5) -----------------------------------------------------------------------------------------
+// FeatureHistogram::FindBestThresholdCategoricalInner (feature_histogram.hpp:278-519; no monotone constraints, no extra_trees) for feature f by the
+// 256 threads of a workgroup (all must call it; ends with a barrier).  One-hot (num_bin <= max_cat_to_onehot, :317-370): every bin alone against the
+// rest -- independent candidates, all lanes, first maximal gain in ascending bin order.  Otherwise (:371-470): the bins with at least cat_smooth rows
+// are STABLE-sorted by sum_grad / (sum_hess + cat_smooth) -- a rank sort, every lane counts the keys before its own (equal keys keep their bin order,
+// as std::stable_sort does) --, then one lane per direction walks at most max_cat_threshold of them from its end (the walk carries cnt_cur_group
+// across candidates: sequential by construction, <= 32 steps by default).  l2 is raised by cat_l2 for gains and outputs, not for the gain of the
+// unsplit leaf (:296-303).  Results: out10 as the numerical search (column 1: number of categories going left), flags (bit 1: splittable; bit 0,
+// default_left, is false for categorical features, :284), and the bitset over the feature's BINS of the categories going left (8 words).
+#pragma clang fp contract(off)
+__device__ void best_split_feature_cat(const double* hist, int f, const int* __restrict__ view_offset, const int* __restrict__ num_bin,
+                                       const int* __restrict__ meta3, double sum_gradient, double sum_hessian_leaf, int num_data, double lambda_l2,
+                                       int min_data_in_leaf, double min_sum_hessian, double min_gain_to_split, SplitReg reg, CatCfg cat,
+                                       double* __restrict__ out10, int* __restrict__ out_flags, unsigned* __restrict__ out_cat,
+                                       const double* data_in = nullptr) {
+#pragma clang fp contract(off)
+  __shared__ double s_cg[GPB_HIST_MAX_BIN], s_ch[GPB_HIST_MAX_BIN], s_key[GPB_HIST_MAX_BIN];
+  __shared__ int s_cc[GPB_HIST_MAX_BIN], s_sorted[GPB_HIST_MAX_BIN], s_sel[GPB_HIST_MAX_BIN];
+  __shared__ double s_rgain[256];
+  __shared__ int s_rt2[256], s_any[256];
+  __shared__ double s_dir[2][4];       // per direction: best gain, best left gradient sum, best left hessian sum, (unused)
+  __shared__ int s_diri[2][3];         // per direction: best threshold (index into the walk), best left count, splittable
+  __shared__ int s_used;
+  const int tid = threadIdx.x;
+  const double kEps = (double)1e-15f;
+  const double* data = data_in ? data_in : hist + (size_t)view_offset[f] * 2;
+  const int nb = num_bin[f], offset = meta3[3 * f];
+  const double sum_hessian = sum_hessian_leaf + 2 * kEps;
+  const RegPath rp0{ reg.lambda_l1, lambda_l2, reg.max_delta_step, reg.path_smooth, reg.parent_output, reg.lambda_l1 > 0.0, reg.max_delta_step > 0.0,
+                     reg.path_smooth > kEps };
+  const double gain_shift = rp0.use_smooth ? reg_gain_given_output(sum_gradient, sum_hessian, rp0, reg.parent_output)
+                                           : reg_leaf_gain(sum_gradient, sum_hessian, rp0, num_data);
+  const double min_gain_shift = gain_shift + min_gain_to_split;
+  const int bin_start = 1 - offset, bin_end = nb - offset;
+  const bool use_onehot = nb <= cat.max_cat_to_onehot;
+  const double cnt_factor = num_data / sum_hessian;
+  if (tid == 0) s_used = 0;
+  for (int t = tid; t < GPB_HIST_MAX_BIN; t += 256) {
+    const bool in = t >= bin_start && t < bin_end;
+    const double g = in ? data[2 * t] : 0.0, hh = in ? data[2 * t + 1] : 0.0;
+    s_cg[t] = g; s_ch[t] = hh;
+    s_cc[t] = in ? (int)(hh * cnt_factor + 0.5f) : 0;
+    s_sel[t] = 0;
+  }
+  __syncthreads();
+  RegPath rp = rp0;
+  double best_gain = -INFINITY, best_slg = 0.0, best_slh = 0.0;
+  int best_threshold = -1, best_left_count = 0, best_dir = 1, used_bin = -1;
+  bool splittable = false;
+  if (use_onehot) {
+    double gbest = -INFINITY; int tbest = -1, any = 0;
+    for (int t = bin_start + tid; t < bin_end; t += 256) {
+      const double grad = s_cg[t], hess = s_ch[t];
+      const int cnt = s_cc[t];
+      if (cnt < min_data_in_leaf || hess < min_sum_hessian) continue;
+      const int other_count = num_data - cnt;
+      if (other_count < min_data_in_leaf) continue;
+      const double sum_other_hessian = sum_hessian - hess - kEps;
+      if (sum_other_hessian < min_sum_hessian) continue;
+      const double sum_other_gradient = sum_gradient - grad;
+      const double current_gain = reg_leaf_gain(sum_other_gradient, sum_other_hessian, rp, other_count) + reg_leaf_gain(grad, hess + kEps, rp, cnt);
+      if (current_gain <= min_gain_shift) continue;
+      any = 1;
+      if (current_gain > gbest) { gbest = current_gain; tbest = t; }      // (ascending t within a lane: strict > keeps the first)
+    }
+    s_rgain[tid] = gbest; s_rt2[tid] = tbest; s_any[tid] = any;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+      if (tid < w) {
+        s_any[tid] |= s_any[tid + w];
+        const double g2 = s_rgain[tid + w]; const int t2 = s_rt2[tid + w];
+        if (t2 >= 0) {
+          const int t1 = s_rt2[tid];
+          if (t1 < 0 || g2 > s_rgain[tid] || (g2 == s_rgain[tid] && t2 < t1)) { s_rgain[tid] = g2; s_rt2[tid] = t2; }
+        }
+      }
+      __syncthreads();
+    }
+    splittable = s_any[0] != 0;
+    if (splittable) {
+      best_threshold = s_rt2[0]; best_gain = s_rgain[0];
+      best_slg = s_cg[best_threshold]; best_slh = s_ch[best_threshold] + kEps; best_left_count = s_cc[best_threshold];
+    }
+  } else {
+    // the bins that take part (:372-377) and their keys
+    for (int t = bin_start + tid; t < bin_end; t += 256) {
+      const bool sel = (double)s_cc[t] >= cat.cat_smooth;
+      s_sel[t] = sel ? 1 : 0;
+      s_key[t] = s_cg[t] / (s_ch[t] + cat.cat_smooth);
+      if (sel) atomicAdd(&s_used, 1);
+    }
+    __syncthreads();
+    used_bin = s_used;
+    for (int t = bin_start + tid; t < bin_end; t += 256) {
+      if (!s_sel[t]) continue;
+      const double k = s_key[t];
+      int rank = 0;
+      for (int j = bin_start; j < bin_end; ++j) {
+        if (!s_sel[j]) continue;
+        const double kj = s_key[j];
+        rank += (kj < k || (!(k < kj) && j < t)) ? 1 : 0;       // stable order under the comparator `key_i < key_j`
+      }
+      s_sorted[rank] = t;
+    }
+    __syncthreads();
+    rp.l2 += cat.cat_l2;
+    const int max_num_cat = min(cat.max_cat_threshold, (used_bin + 1) / 2);
+    if (tid == 0 || tid == 64) {
+      const int d = tid == 0 ? 0 : 1, dir = d == 0 ? 1 : -1;
+      int start_pos = d == 0 ? 0 : used_bin - 1;
+      int cnt_cur_group = 0, left_count = 0;
+      double slg = 0.0, slh = kEps;
+      double bg = -INFINITY, bslg = 0.0, bslh = 0.0; int bt = -1, blc = 0, spl = 0;
+      for (int i = 0; i < used_bin && i < max_num_cat; ++i) {
+        const int t = s_sorted[start_pos];
+        start_pos += dir;
+        const double grad = s_cg[t], hess = s_ch[t];
+        const int cnt = s_cc[t];
+        slg += grad; slh += hess; left_count += cnt; cnt_cur_group += cnt;
+        if (left_count < min_data_in_leaf || slh < min_sum_hessian) continue;
+        const int right_count = num_data - left_count;
+        if (right_count < min_data_in_leaf || right_count < cat.min_data_per_group) break;
+        const double srh = sum_hessian - slh;
+        if (srh < min_sum_hessian) break;
+        if (cnt_cur_group < cat.min_data_per_group) continue;
+        cnt_cur_group = 0;
+        const double srg = sum_gradient - slg;
+        const double current_gain = reg_leaf_gain(slg, slh, rp, left_count) + reg_leaf_gain(srg, srh, rp, right_count);
+        if (current_gain <= min_gain_shift) continue;
+        spl = 1;
+        if (current_gain > bg) { blc = left_count; bslg = slg; bslh = slh; bt = i; bg = current_gain; }
+      }
+      s_dir[d][0] = bg; s_dir[d][1] = bslg; s_dir[d][2] = bslh;
+      s_diri[d][0] = bt; s_diri[d][1] = blc; s_diri[d][2] = spl;
+    }
+    __syncthreads();
+    splittable = (s_diri[0][2] | s_diri[1][2]) != 0;
+    // dir = +1 first; dir = -1 replaces it on a strictly larger gain only (the reference's single running best over both walks)
+    if (s_diri[0][0] >= 0) { best_gain = s_dir[0][0]; best_slg = s_dir[0][1]; best_slh = s_dir[0][2]; best_threshold = s_diri[0][0]; best_left_count = s_diri[0][1]; best_dir = 1; }
+    if (s_diri[1][0] >= 0 && s_dir[1][0] > best_gain) { best_gain = s_dir[1][0]; best_slg = s_dir[1][1]; best_slh = s_dir[1][2]; best_threshold = s_diri[1][0]; best_left_count = s_diri[1][1]; best_dir = -1; }
+  }
+  if (tid == 0) {
+    double* r = out10 + (size_t)f * 10;
+    unsigned bits[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (splittable) {
+      r[4] = reg_leaf_output(best_slg, best_slh, rp, best_left_count);
+      r[2] = best_left_count; r[6] = best_slg; r[7] = best_slh - kEps;
+      r[5] = reg_leaf_output(sum_gradient - best_slg, sum_hessian - best_slh, rp, num_data - best_left_count);
+      r[3] = num_data - best_left_count; r[8] = sum_gradient - best_slg; r[9] = sum_hessian - best_slh - kEps;
+      r[0] = best_gain - min_gain_shift;
+      int ncat;
+      if (use_onehot) { ncat = 1; const int b = best_threshold + offset; bits[b >> 5] |= 1u << (b & 31); }
+      else {
+        ncat = best_threshold + 1;
+        for (int i = 0; i < ncat; ++i) { const int b = (best_dir == 1 ? s_sorted[i] : s_sorted[used_bin - 1 - i]) + offset; bits[b >> 5] |= 1u << (b & 31); }
+      }
+      r[1] = (double)ncat;
+    } else {
+      r[0] = -INFINITY;
+      for (int k = 1; k < 10; ++k) r[k] = 0.0;
+    }
+    out_flags[f] = splittable ? 2 : 0;
+    if (out_cat) for (int k = 0; k < 8; ++k) out_cat[(size_t)f * 8 + k] = bits[k];
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void hist_best_split_kernel(const double* __restrict__ hist, int num_features, const int* __restrict__ view_offset,
                                        const int* __restrict__ num_bin, const int* __restrict__ meta3, double sum_gradient, double sum_hessian_leaf,
                                        int num_data, double lambda_l2, int min_data_in_leaf, double min_sum_hessian, double min_gain_to_split,
-                                       SplitReg reg, double* __restrict__ out10, int* __restrict__ out_default_left) {
+                                       SplitReg reg, double* __restrict__ out10, int* __restrict__ out_default_left,
+                                       const signed char* __restrict__ is_cat, CatCfg cat, unsigned* __restrict__ out_cat) {
   if ((int)blockIdx.x >= num_features) return;
+  if (is_cat && is_cat[blockIdx.x]) {
+    best_split_feature_cat(hist, blockIdx.x, view_offset, num_bin, meta3, sum_gradient, sum_hessian_leaf, num_data, lambda_l2, min_data_in_leaf,
+                           min_sum_hessian, min_gain_to_split, reg, cat, out10, out_default_left, out_cat);
+    return;
+  }
   best_split_feature(hist, blockIdx.x, view_offset, num_bin, meta3, sum_gradient, sum_hessian_leaf, num_data, lambda_l2, min_data_in_leaf,
                      min_sum_hessian, min_gain_to_split, reg, out10, out_default_left);
 }
@@ -867,6 +1040,10 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
     }
     __threadfence_block();
     __syncthreads();
+    if (a.is_cat && a.is_cat[f])
+      best_split_feature_cat(a.smaller, f, a.view_offset, a.num_bin, a.meta3, sg_s, sh_s, n_s, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
+                             a.min_gain_to_split, reg_s, a.cat, a.out10, a.out_flags, a.out_cat, local_view ? s_sm + vrel : nullptr);
+    else
     best_split_feature(a.smaller, f, a.view_offset, a.num_bin, a.meta3, sg_s, sh_s, n_s, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
                        a.min_gain_to_split, reg_s, a.out10, a.out_flags, local_view ? s_sm + vrel : nullptr);
   } else {
@@ -876,6 +1053,11 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
     }
     __threadfence_block();
     __syncthreads();
+    if (a.is_cat && a.is_cat[f])
+      best_split_feature_cat(a.parent, f, a.view_offset, a.num_bin, a.meta3, sg_l, sh_l, n_l, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
+                             a.min_gain_to_split, reg_l, a.cat, a.out10 + (size_t)a.num_features * 10, a.out_flags + (a.num_features + 1),
+                             a.out_cat ? a.out_cat + (size_t)a.num_features * 8 : nullptr);
+    else
     best_split_feature(a.parent, f, a.view_offset, a.num_bin, a.meta3, sg_l, sh_l, n_l, a.lambda_l2, a.min_data_in_leaf, a.min_sum_hessian,
                        a.min_gain_to_split, reg_l, a.out10 + (size_t)a.num_features * 10, a.out_flags + (a.num_features + 1));
   }
@@ -924,10 +1106,10 @@ __global__ void hist_pick_split_kernel(const double* __restrict__ out10, int num
 hipError_t launch_hist_best_split(const double* hist, int num_features, const int* view_offset, const int* num_bin, const int* meta3,
                                   double sum_gradient, double sum_hessian, int num_data, double lambda_l2, int min_data_in_leaf,
                                   double min_sum_hessian, double min_gain_to_split, SplitReg reg, const signed char* is_feature_used, double* out10,
-                                  int* out_default_left, int* best_feature, hipStream_t st) {
+                                  int* out_default_left, int* best_feature, hipStream_t st, const signed char* is_cat, CatCfg cat, unsigned* out_cat) {
   hipLaunchKernelGGL(hist_best_split_kernel, dim3(num_features), dim3(256), 0, st, hist, num_features, view_offset, num_bin, meta3,
                      sum_gradient, sum_hessian, num_data, lambda_l2, min_data_in_leaf, min_sum_hessian, min_gain_to_split, reg, out10,
-                     out_default_left);
+                     out_default_left, is_cat, cat, out_cat);
   if (best_feature)      // the tree grower picks on the host from the per-feature candidates it needs anyway
     hipLaunchKernelGGL(hist_pick_split_kernel, dim3(1), dim3(64), 0, st, (const double*)out10, num_features, is_feature_used, best_feature);
   return hipGetLastError();
@@ -939,8 +1121,17 @@ hipError_t launch_hist_best_split(const double* hist, int num_features, const in
 // per-thread blocks do when they are concatenated.  Three small kernels: per-block count of rows going left, exclusive scan of
 // the block counts, classify again + scatter (1024 rows per block, 4 consecutive rows per lane).
 namespace {
-struct SplitRule { int max_bin, t_zero_bin, th, miss_zero, miss_na, mfb_zero, mfb_na, default_goes_left, missing_goes_left; };
+// (categorical, round 5: DenseBin::SplitCategoricalInner<USE_MIN_BIN = false>, dense_bin.hpp:305-342 -- stored bin 0 = the most frequent bin goes
+//  with default_goes_left = its own bit; every other stored bin b stands for the feature's bin b - 1 + cat_offset, looked up in the 256-bit set)
+struct SplitRule { int max_bin, t_zero_bin, th, miss_zero, miss_na, mfb_zero, mfb_na, default_goes_left, missing_goes_left;
+                   int is_cat, cat_offset; unsigned b0, b1, b2, b3, b4, b5, b6, b7; };
 __device__ __forceinline__ bool goes_left(const SplitRule& r, int bin) {
+  if (r.is_cat) {
+    if (bin == 0) return r.default_goes_left != 0;
+    const int b = bin - 1 + r.cat_offset, w = b >> 5;
+    const unsigned word = w == 0 ? r.b0 : w == 1 ? r.b1 : w == 2 ? r.b2 : w == 3 ? r.b3 : w == 4 ? r.b4 : w == 5 ? r.b5 : w == 6 ? r.b6 : w == 7 ? r.b7 : 0u;
+    return ((word >> (b & 31)) & 1u) != 0u;
+  }
   if (1 < r.max_bin) {
     if ((r.miss_zero && !r.mfb_zero && bin == r.t_zero_bin) || (r.miss_na && !r.mfb_na && bin == r.max_bin)) return r.missing_goes_left;
     if (bin == 0) return ((r.miss_na && r.mfb_na) || (r.miss_zero && r.mfb_zero)) ? r.missing_goes_left : r.default_goes_left;
@@ -1091,8 +1282,17 @@ __global__ __launch_bounds__(256) void hist_partition_scan_kernel(const int* __r
   }
 }
 
-static SplitRule make_split_rule(int max_bin, int default_bin, int most_freq_bin, int missing_type, int default_left, unsigned threshold) {
+static SplitRule make_split_rule(int max_bin, int default_bin, int most_freq_bin, int missing_type, int default_left, unsigned threshold,
+                                 const unsigned* cat_bits8 = nullptr) {
   SplitRule r;
+  r.is_cat = cat_bits8 ? 1 : 0; r.cat_offset = most_freq_bin == 0 ? 1 : 0;
+  r.b0 = r.b1 = r.b2 = r.b3 = r.b4 = r.b5 = r.b6 = r.b7 = 0u;
+  if (cat_bits8) {
+    r.b0 = cat_bits8[0]; r.b1 = cat_bits8[1]; r.b2 = cat_bits8[2]; r.b3 = cat_bits8[3]; r.b4 = cat_bits8[4]; r.b5 = cat_bits8[5]; r.b6 = cat_bits8[6]; r.b7 = cat_bits8[7];
+    r.max_bin = max_bin; r.t_zero_bin = 0; r.th = 0; r.miss_zero = r.miss_na = r.mfb_zero = r.mfb_na = 0; r.missing_goes_left = 0;
+    r.default_goes_left = most_freq_bin > 0 && most_freq_bin < 256 && ((cat_bits8[most_freq_bin >> 5] >> (most_freq_bin & 31)) & 1u);      // :316-320
+    return r;
+  }
   r.max_bin = max_bin;
   r.miss_zero = missing_type == 1; r.miss_na = missing_type == 2;
   r.mfb_zero = r.miss_zero && default_bin == most_freq_bin;                          // dense_bin.hpp:268-272
@@ -1107,8 +1307,8 @@ static SplitRule make_split_rule(int max_bin, int default_bin, int most_freq_bin
 
 hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                  int missing_type, int default_left, unsigned threshold, const int* data_indices, int cnt, int* blk_cnt,
-                                 int* blk_off, int* lte, int* gt, hipStream_t st) {
-  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold);
+                                 int* blk_off, int* lte, int* gt, hipStream_t st, const unsigned* cat_bits8) {
+  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, cat_bits8);
   const int nblk = (cnt + 1023) / 1024;
   if (nblk == 0) return hipSuccess;
   hipLaunchKernelGGL(hist_partition_kernel<false>, dim3(nblk), dim3(256), 0, st, bins_rm, fpad, feature, r, data_indices, cnt, blk_cnt,
@@ -1124,8 +1324,8 @@ hipError_t launch_hist_partition(const uint8_t* bins_rm, int fpad, int feature, 
 hipError_t launch_hist_partition_segment(const uint8_t* bins_rm, int fpad, int feature, int max_bin, int default_bin, int most_freq_bin,
                                          int missing_type, int default_left, unsigned threshold, const int* src, int cnt, int* blk_cnt,
                                          int* blk_off, int* dst, int* counts, int* host_counts, hipStream_t st, unsigned long long* tags,
-                                         unsigned epoch, int host_seq, int* err, bool* host_seq_written) {
-  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold);
+                                         unsigned epoch, int host_seq, int* err, bool* host_seq_written, const unsigned* cat_bits8) {
+  const SplitRule r = make_split_rule(max_bin, default_bin, most_freq_bin, missing_type, default_left, threshold, cat_bits8);
   const int nblk = (cnt + 1023) / 1024;
   if (host_seq_written) *host_seq_written = false;
   if (nblk == 0) { if (host_counts) { host_counts[0] = 0; host_counts[1] = 0; } return hipMemsetAsync(counts, 0, 2 * sizeof(int), st); }

@@ -500,6 +500,16 @@ class HistBuilder(object):
         a = [np.ascontiguousarray(x, dtype=np.int32) for x in (offset, default_bin, missing_type)]
         _shim_call(_lib().gpb_hip_hist_set_split_info(self.h, *[_p(x, C.c_int) for x in a]))
 
+    def set_categorical(self, is_categorical, max_cat_to_onehot=4, max_cat_threshold=32, cat_smooth=10.0, cat_l2=10.0, min_data_per_group=100):
+        """Categorical features: flags per feature (None: all numerical) and the reference's Config values of the same names
+        (FindBestThresholdCategoricalInner, feature_histogram.hpp:278-519); they stay set for find_best_split and grow_tree."""
+        m = None if is_categorical is None else np.ascontiguousarray(np.asarray(is_categorical) != 0, dtype=np.int8)
+        if m is not None and m.size != self.F:
+            raise ValueError("is_categorical must have one flag per feature")
+        self.is_categorical = np.zeros(self.F, dtype=np.int8) if m is None else m
+        _shim_call(_lib().gpb_hip_hist_set_categorical(self.h, _p(m, C.c_int8), C.c_int(int(max_cat_to_onehot)), C.c_int(int(max_cat_threshold)),
+                                                       C.c_double(cat_smooth), C.c_double(cat_l2), C.c_int(int(min_data_per_group))))
+
     def set_regularisation(self, lambda_l1=0.0, max_delta_step=0.0, path_smooth=0.0, parent_output=0.0):
         """lambda_l1 / max_delta_step / path_smooth of the split search (they stay set for find_best_split and grow_tree); parent_output: the
         leaf's own output, for the following find_best_split calls (path smoothing; grow_tree tracks it itself)."""
@@ -534,13 +544,22 @@ class HistBuilder(object):
                                                        C.c_double(min_sum_hessian_in_leaf), C.c_double(min_gain_to_split),
                                                        _p(used, C.c_int8), C.byref(best), _p(out), _p(dl, C.c_int),
                                                        _p(self.last_splittable, C.c_int)))
+        # categorical features: the sets of bins going left (8 words per feature; zeros for numerical features)
+        self.last_cat_bits = np.zeros((self.F, 8), dtype=np.uint32)
+        _shim_call(_lib().gpb_hip_hist_last_split_cat_bits(self.h, _p(self.last_cat_bits, C.c_uint32)))
         return best.value, out, dl
 
-    def split_leaf(self, data_indices, feature, threshold, default_left):
-        """-> (lte_indices, gt_indices), both in the order of data_indices (None = all rows)."""
+    def split_leaf(self, data_indices, feature, threshold, default_left, cat_bits=None):
+        """-> (lte_indices, gt_indices), both in the order of data_indices (None = all rows).  cat_bits (8 words): a categorical split, the rows whose
+        bin is in the set go left."""
         idx = None if data_indices is None else np.ascontiguousarray(data_indices, dtype=np.int32)
         cnt = self.n if idx is None else idx.size
         lte = np.empty(cnt, dtype=np.int32); gt = np.empty(cnt, dtype=np.int32); nl = C.c_int(0)
+        if cat_bits is not None:
+            w = np.ascontiguousarray(cat_bits, dtype=np.uint32)
+            _shim_call(_lib().gpb_hip_hist_split_leaf_categorical(self.h, _p(idx, C.c_int), C.c_int(cnt), C.c_int(int(feature)), _p(w, C.c_uint32),
+                                                                  _p(lte, C.c_int), _p(gt, C.c_int), C.byref(nl)))
+            return lte[:nl.value].copy(), gt[:cnt - nl.value].copy()
         _shim_call(_lib().gpb_hip_hist_split_leaf(self.h, _p(idx, C.c_int), C.c_int(cnt), C.c_int(int(feature)), C.c_uint(int(threshold)),
                                                   C.c_int(int(bool(default_left))), _p(lte, C.c_int), _p(gt, C.c_int), C.byref(nl)))
         return lte[:nl.value].copy(), gt[:cnt - nl.value].copy()
@@ -565,6 +584,11 @@ class HistBuilder(object):
                    leaf_count=ia["leaf_count"][:k].copy(), data_leaf_index=dli)
         for key in ("split_feature_inner", "default_left", "left_child", "right_child", "internal_count"):
             out[key] = ia[key][:k - 1].copy()
+        # categorical nodes: flags and the sets of bins going left (threshold_in_bin of such a node = its index among them, as in the reference's Tree)
+        nic = np.zeros(max(k - 1, 1), dtype=np.int32); ncb = np.zeros((max(k - 1, 1), 8), dtype=np.uint32)
+        if k > 1:
+            _shim_call(_lib().gpb_hip_hist_last_tree_cat_nodes(self.h, C.c_int(k - 1), _p(nic, C.c_int), _p(ncb, C.c_uint32)))
+        out["node_is_cat"] = nic[:k - 1].copy(); out["node_cat_bits"] = ncb[:k - 1].copy()
         return out
 
     def get_slot(self, slot):

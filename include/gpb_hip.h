@@ -601,6 +601,24 @@ GPB_HIP_EXPORT int gpb_hip_hist_split_leaf(gpb_hip_hist_t* h, const int32_t* dat
                                            uint32_t threshold, int default_left, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count);
 GPB_HIP_EXPORT int gpb_hip_hist_set_split_info(gpb_hip_hist_t* h, const int32_t* offset, const int32_t* default_bin,
                                                const int32_t* missing_type);
+/* Categorical features (round 5).  is_categorical[f] != 0: feature f is searched by FeatureHistogram::FindBestThresholdCategoricalInner
+ * (src/LightGBM/treelearner/feature_histogram.hpp:278-519: one-hot for num_bin <= max_cat_to_onehot, otherwise the bins with >= cat_smooth rows sorted by
+ * sum_grad / (sum_hess + cat_smooth) and accumulated from both ends, at most max_cat_threshold per side, a candidate every min_data_per_group rows, l2
+ * raised by cat_l2) instead of the threshold scans, in gpb_hip_hist_find_best_split AND gpb_hip_hist_grow_tree; its splits are SETS of bins
+ * (DataPartition::Split -> DenseBin::SplitCategorical, dense_bin.hpp:305-362).  The five configuration values are the reference's Config fields of the
+ * same names (defaults 4, 32, 10, 10, 100).  is_categorical == NULL: every feature numerical.  Columns stay single-feature columns: a feature the
+ * reference keeps inside a bundle (EFB) or a multi-value group is handed over as its own column (0 = most frequent bin; BinIterator::Get gives the bin).
+ *   per_feature_out10 of a categorical feature: column 1 (threshold) holds the NUMBER of bins going left; gpb_hip_hist_last_split_cat_bits returns the sets
+ *   (8 words per feature, bit b = the feature's bin b; zeros for numerical features) of the last gpb_hip_hist_find_best_split
+ *   gpb_hip_hist_split_leaf_categorical: gpb_hip_hist_split_leaf with such a set instead of (threshold, default_left)
+ *   gpb_hip_hist_last_tree_cat_nodes: per node of the last gpb_hip_hist_grow_tree tree, is it categorical and its set (8 words) -- the cat_bitset_inner of
+ *   Tree::SplitCategorical (serial_tree_learner.cpp:617-640); threshold_in_bin of such a node = its running index among the categorical nodes */
+GPB_HIP_EXPORT int gpb_hip_hist_set_categorical(gpb_hip_hist_t* h, const int8_t* is_categorical, int32_t max_cat_to_onehot, int32_t max_cat_threshold,
+                                                double cat_smooth, double cat_l2, int32_t min_data_per_group);
+GPB_HIP_EXPORT int gpb_hip_hist_last_split_cat_bits(gpb_hip_hist_t* h, uint32_t* bits_out);
+GPB_HIP_EXPORT int gpb_hip_hist_split_leaf_categorical(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t cnt, int32_t feature,
+                                                       const uint32_t* cat_bits8, int32_t* lte_out, int32_t* gt_out, int32_t* lte_count);
+GPB_HIP_EXPORT int gpb_hip_hist_last_tree_cat_nodes(gpb_hip_hist_t* h, int32_t num_nodes, int32_t* is_categorical, uint32_t* cat_bits8);
 /* The other regularisation paths of the search (config lambda_l1, max_delta_step, path_smooth: feature_histogram.hpp:137-161 picks the template
  * instance of FindBestThresholdSequentially; ThresholdL1 :737-741, CalculateSplittedLeafOutput :743-765, GetLeafGain :826-857).  They stay set on
  * the handle for gpb_hip_hist_find_best_split and gpb_hip_hist_grow_tree; all zero (the default) is the plain lambda_l2 path.  parent_output is

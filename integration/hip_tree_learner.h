@@ -7,11 +7,12 @@
  * extern "C" shim of lib_gpboost_amd.so (include/gpb_hip.h), the way CUDATreeLearner overrides it for CUDA
  * (cuda_tree_learner.cpp:767).  Registered for device_type = "gpu" in TreeLearner::CreateTreeLearner (tree_learner.cpp:15-52) when the
  * reference is built with -DUSE_HIP_GP; Config::CheckParamConflict already forces col-wise (dense) bins for that device type
- * (config.cpp:349-355).  Feature groups are dense uint8 columns here (one feature or an EFB bundle, <= 256 bins); a data set with a
- * multi-value / sparse group keeps the reference's CPU histograms (never a silent wrong answer).
+ * (config.cpp:349-355).  The resident columns are either the reference's feature groups (dense uint8 columns: one feature or an EFB bundle,
+ * <= 256 bins) or -- round 5, whenever whole trees can be grown -- one column per FEATURE, so that bundles of any width, multi-value groups and
+ * sparse bins are served as well (CreateDeviceBins).  A data set that fits neither keeps the reference's CPU histograms (never a silent wrong answer).
  *
- * Whole trees: when the configuration is the one gpb_hip_hist_grow_tree restates (numerical features in single-feature groups, default
- * regularisation path, no depth limit / bagging / column sampling / forced splits / constraints), Train() hands the whole leaf-wise
+ * Whole trees: when the configuration is the one gpb_hip_hist_grow_tree restates (numerical AND categorical features, every regularisation path of
+ * the two searches, depth limit, column sampling by tree, bagging; no forced splits / constraints / extra_trees), Train() hands the whole leaf-wise
  * growth to the device (row lists resident, one synchronisation per split) and rebuilds the reference's own Tree object and
  * DataPartition from the returned arrays -- GBDT (shrinkage, score update, the GPBoost leaf update) carries on unchanged.  Anything
  * else: SerialTreeLearner::Train with the device histograms above.
@@ -105,6 +106,14 @@ class HIPTreeLearner : public SerialTreeLearner {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
     if (gpb_hip_hist_set_max_depth(hist_, config_->max_depth)) Log::Fatal("%s", gpb_hip_get_last_error());
+    if (has_categorical_) {                          // the Config fields FindBestThresholdCategoricalInner reads (feature_histogram.hpp:278-519)
+      std::vector<int8_t> is_cat(train_data_->num_features());
+      for (int f = 0; f < train_data_->num_features(); ++f) is_cat[f] = train_data_->FeatureBinMapper(f)->bin_type() == BinType::CategoricalBin ? 1 : 0;
+      if (gpb_hip_hist_set_categorical(hist_, is_cat.data(), config_->max_cat_to_onehot, config_->max_cat_threshold, config_->cat_smooth, config_->cat_l2,
+                                       config_->min_data_per_group)) {
+        Log::Fatal("%s", gpb_hip_get_last_error());
+      }
+    }
     // feature_fraction: the columns col_sampler_ drew for this tree in BeforeTrain (serial_tree_learner.cpp:258)
     if (gpb_hip_hist_set_feature_mask(hist_, config_->feature_fraction < 1.0 ? col_sampler_.is_feature_used_bytree().data() : nullptr)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
@@ -117,12 +126,30 @@ class HIPTreeLearner : public SerialTreeLearner {
     }
     std::vector<double> info(static_cast<size_t>(std::max(nl - 1, 1)) * 6);
     if (nl > 1 && gpb_hip_hist_last_tree_node_info(hist_, nl - 1, info.data())) Log::Fatal("%s", gpb_hip_get_last_error());
+    std::vector<int32_t> node_cat(static_cast<size_t>(std::max(nl - 1, 1)), 0);
+    std::vector<uint32_t> node_bits(static_cast<size_t>(std::max(nl - 1, 1)) * 8, 0u);
+    if (nl > 1 && has_categorical_ && gpb_hip_hist_last_tree_cat_nodes(hist_, nl - 1, node_cat.data(), node_bits.data())) Log::Fatal("%s", gpb_hip_get_last_error());
     auto tree = std::unique_ptr<Tree>(new Tree(L, false, false));
     for (int k = 0; k + 1 < nl; ++k) {
       int leaf = lc[k];                              // the split leaf kept its id on the left: the leftmost leaf below node k
       while (leaf >= 0) leaf = lc[leaf];
       leaf = ~leaf;
       const int inner = sf[k];
+      if (node_cat[k]) {
+        // SerialTreeLearner::SplitInner, categorical branch (serial_tree_learner.cpp:612-646): the set over BINS as it came from the search, and the
+        // same set over the real category values (BinMapper::BinToValue through Dataset::RealThreshold)
+        std::vector<uint32_t> cat_bins;
+        for (int b = 0; b < 256; ++b) if ((node_bits[8 * static_cast<size_t>(k) + (b >> 5)] >> (b & 31)) & 1u) cat_bins.push_back(static_cast<uint32_t>(b));
+        std::vector<uint32_t> cat_bitset_inner = Common::ConstructBitset(cat_bins.data(), static_cast<int>(cat_bins.size()));
+        std::vector<int> threshold_int(cat_bins.size());
+        for (size_t c = 0; c < cat_bins.size(); ++c) threshold_int[c] = static_cast<int>(train_data_->RealThreshold(inner, cat_bins[c]));
+        std::vector<uint32_t> cat_bitset = Common::ConstructBitset(threshold_int.data(), static_cast<int>(threshold_int.size()));
+        tree->SplitCategorical(leaf, inner, train_data_->RealFeatureIndex(inner), cat_bitset_inner.data(), static_cast<int>(cat_bitset_inner.size()),
+                               cat_bitset.data(), static_cast<int>(cat_bitset.size()), info[6 * k], info[6 * k + 1], static_cast<int>(info[6 * k + 2]),
+                               static_cast<int>(info[6 * k + 3]), info[6 * k + 4], info[6 * k + 5], static_cast<float>(gain[k]),
+                               train_data_->FeatureBinMapper(inner)->missing_type());
+        continue;
+      }
       tree->Split(leaf, inner, train_data_->RealFeatureIndex(inner), thr[k], train_data_->RealThreshold(inner, thr[k]), info[6 * k], info[6 * k + 1],
                   static_cast<int>(info[6 * k + 2]), static_cast<int>(info[6 * k + 3]), info[6 * k + 4], info[6 * k + 5], static_cast<float>(gain[k]),
                   train_data_->FeatureBinMapper(inner)->missing_type(), dl[k] != 0);
@@ -186,7 +213,7 @@ class HIPTreeLearner : public SerialTreeLearner {
   }
 
   void ConstructHistograms(const std::vector<int8_t>& is_feature_used, bool use_subtract) override {
-    if (!hist_) {
+    if (!hist_ || !host_layout_) {                      // (per-feature columns serve whole trees only: their histogram is not laid out as the host's)
       SerialTreeLearner::ConstructHistograms(is_feature_used, use_subtract);
       return;
     }
@@ -208,47 +235,92 @@ class HIPTreeLearner : public SerialTreeLearner {
 
   void CreateDeviceBins() {
     if (hist_) { gpb_hip_hist_free(hist_); hist_ = nullptr; registered_grad_ = registered_hess_ = nullptr; }   // (the free unregisters the staging buffers)
+    whole_tree_ok_ = false; host_layout_ = false;
     const int num_groups = train_data_->num_feature_groups();
-    std::vector<int32_t> offsets(num_groups + 1);
+    const int F = train_data_->num_features();
+    // Two layouts of the resident columns.
+    //  * GROUP columns (the reference's own: one uint8 column per feature group, its histogram in group_bin_boundaries_ order): possible when no group is
+    //    multi-valued or wider than 256 bins; the per-leaf histograms can then be handed back to the reference's host search (ConstructHistograms below).
+    //  * FEATURE columns (round 5): one column per feature in the layout of a single-feature group (0 = most frequent bin, else the bin, shifted by one
+    //    when the most frequent bin is not bin 0 -- FeatureGroup::PushData, feature_group.h:199-213), whatever the reference keeps the feature in: an EFB
+    //    bundle of any width, a multi-value group, a sparse bin (BinIterator::Get returns the feature's own bin for all of them).  Whole trees are grown
+    //    from these; the histogram never leaves the device, so its layout need not be the host's.
+    bool groups_ok = true, all_single = num_groups == F;
     for (int g = 0; g < num_groups; ++g) {
-      if (train_data_->IsMultiGroup(g) || train_data_->FeatureGroupNumBin(g) > 256) {
-        Log::Warning("HIPTreeLearner: feature group %d is multi-valued or has more than 256 bins; histograms stay on the CPU.", g);
-        return;
+      if (train_data_->IsMultiGroup(g) || train_data_->FeatureGroupNumBin(g) > 256) groups_ok = false;
+    }
+    for (int f = 0; f < F && all_single; ++f) if (train_data_->Feature2Group(f) != f) all_single = false;
+    bool features_ok = true;
+    for (int f = 0; f < F; ++f) {
+      const BinMapper* bm = train_data_->FeatureBinMapper(f);
+      if (bm->num_bin() + (bm->GetMostFreqBin() == 0 ? 0 : 1) > 256) features_ok = false;
+    }
+    const bool feature_columns = features_ok && !(groups_ok && all_single) && WholeTreeConfigOnly();
+    if (!feature_columns && !groups_ok) {
+      Log::Warning("HIPTreeLearner: a feature group is multi-valued or has more than 256 bins and the configuration is not one whole trees are grown for on the "
+                   "GPU%s; histograms stay on the CPU.", features_ok ? "" : " (a feature has more than 255 bins)");
+      return;
+    }
+    const int ncol = feature_columns ? F : num_groups;
+    std::vector<int32_t> offsets(ncol + 1);
+    std::vector<uint8_t> bins(static_cast<size_t>(ncol) * num_data_);   // column-major, the layout of DenseBin storage
+    if (feature_columns) {
+      offsets[0] = 0;
+      for (int f = 0; f < F; ++f) {
+        const BinMapper* bm = train_data_->FeatureBinMapper(f);
+        offsets[f + 1] = offsets[f] + bm->num_bin() + (bm->GetMostFreqBin() == 0 ? 0 : 1);
       }
-      offsets[g] = static_cast<int32_t>(train_data_->GroupBinBoundary(g));
-    }
-    offsets[num_groups] = static_cast<int32_t>(train_data_->NumTotalBin());
-    std::vector<uint8_t> bins(static_cast<size_t>(num_groups) * num_data_);   // feature(-group)-major, the layout of DenseBin storage
 #pragma omp parallel for schedule(static)
-    for (int g = 0; g < num_groups; ++g) {
-      std::unique_ptr<BinIterator> it(train_data_->FeatureGroupIterator(g));
-      it->Reset(0);
-      uint8_t* col = bins.data() + static_cast<size_t>(g) * num_data_;
-      for (data_size_t i = 0; i < num_data_; ++i) col[i] = static_cast<uint8_t>(it->RawGet(i));
+      for (int f = 0; f < F; ++f) {
+        const int mfb = static_cast<int>(train_data_->FeatureBinMapper(f)->GetMostFreqBin());
+        std::unique_ptr<BinIterator> it(train_data_->FeatureIterator(f));
+        it->Reset(0);
+        uint8_t* col = bins.data() + static_cast<size_t>(f) * num_data_;
+        for (data_size_t i = 0; i < num_data_; ++i) {
+          const int b = static_cast<int>(it->Get(i));
+          col[i] = static_cast<uint8_t>(b == mfb ? 0 : (mfb == 0 ? b : b + 1));
+        }
+      }
+    } else {
+      for (int g = 0; g < num_groups; ++g) offsets[g] = static_cast<int32_t>(train_data_->GroupBinBoundary(g));
+      offsets[num_groups] = static_cast<int32_t>(train_data_->NumTotalBin());
+#pragma omp parallel for schedule(static)
+      for (int g = 0; g < num_groups; ++g) {
+        std::unique_ptr<BinIterator> it(train_data_->FeatureGroupIterator(g));
+        it->Reset(0);
+        uint8_t* col = bins.data() + static_cast<size_t>(g) * num_data_;
+        for (data_size_t i = 0; i < num_data_; ++i) col[i] = static_cast<uint8_t>(it->RawGet(i));
+      }
     }
-    if (gpb_hip_hist_create(num_data_, num_groups, bins.data(), offsets.data(), &hist_)) {
+    if (gpb_hip_hist_create(num_data_, ncol, bins.data(), offsets.data(), &hist_)) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
     hist_rows_ = num_data_;
     bag_dirty_ = true;
-    // whole-tree growth on the device: numerical features, one per group; their histogram views and FeatureMetainfo
-    // (HistogramPool::SetFeatureInfo, feature_histogram.hpp:1146-1182; view = one bin past the start of the group, train_share_states.cpp:296-300)
-    whole_tree_ok_ = num_groups == train_data_->num_features();
-    const int F = train_data_->num_features();
+    host_layout_ = !feature_columns;
+    // whole-tree growth on the device: one column per feature (numerical or categorical); the features' histogram views and FeatureMetainfo
+    // (HistogramPool::SetFeatureInfo, feature_histogram.hpp:1146-1182; view = one bin past the start of the column, train_share_states.cpp:296-300)
+    whole_tree_ok_ = ncol == F;
     std::vector<int32_t> voff(F), nbin(F), mfb(F), off(F), dbin(F), miss(F);
+    std::vector<int8_t> is_cat(F, 0);
+    bool any_cat = false;
     for (int f = 0; f < F && whole_tree_ok_; ++f) {
       const BinMapper* bm = train_data_->FeatureBinMapper(f);
-      if (bm->bin_type() != BinType::NumericalBin || train_data_->Feature2Group(f) != f) { whole_tree_ok_ = false; break; }
-      voff[f] = static_cast<int32_t>(train_data_->GroupBinBoundary(f)) + 1;
+      if (!feature_columns && train_data_->Feature2Group(f) != f) { whole_tree_ok_ = false; break; }
+      voff[f] = offsets[f] + 1;
       nbin[f] = bm->num_bin(); mfb[f] = static_cast<int32_t>(bm->GetMostFreqBin());
       off[f] = mfb[f] == 0 ? 1 : 0; dbin[f] = static_cast<int32_t>(bm->GetDefaultBin()); miss[f] = static_cast<int32_t>(bm->missing_type());
+      is_cat[f] = bm->bin_type() == BinType::CategoricalBin ? 1 : 0;
+      any_cat = any_cat || is_cat[f];
     }
     if (whole_tree_ok_ && (gpb_hip_hist_set_fix_info(hist_, voff.data(), nbin.data(), mfb.data()) ||
                            gpb_hip_hist_set_split_info(hist_, off.data(), dbin.data(), miss.data()) ||
                            gpb_hip_hist_pool_resize(hist_, config_->num_leaves + 1))) {
       Log::Fatal("%s", gpb_hip_get_last_error());
     }
-    Log::Info("HIPTreeLearner: %d feature groups x %d rows resident on the GPU (%d bins in total)", num_groups, num_data_, offsets[num_groups]);
+    has_categorical_ = whole_tree_ok_ && any_cat;
+    Log::Info("HIPTreeLearner: %d %s columns x %d rows resident on the GPU (%d bins in total%s)", ncol, feature_columns ? "per-feature (unbundled)" : "feature-group",
+              num_data_, offsets[ncol], has_categorical_ ? "; categorical features searched on the GPU" : "");
   }
 
   // the configuration gpb_hip_hist_grow_tree restates: every regularisation path of the numerical threshold search (lambda_l1, lambda_l2,
@@ -268,6 +340,8 @@ class HIPTreeLearner : public SerialTreeLearner {
 
   gpb_hip_hist_t* hist_ = nullptr;
   bool whole_tree_ok_ = false, bagging_ = false, announced_ = false, bag_dirty_ = false;
+  bool host_layout_ = false;                           // the device columns are the reference's feature groups: per-leaf histograms can go back to the host search
+  bool has_categorical_ = false;                       // some feature is categorical (searched by gpb_hip_hist_set_categorical's configuration)
   bool keep_device_bins_ = false;                      // inside SetBaggingData: the base class switches to the subset Dataset, the device bins stay
   bool bag_is_subset_ = false;                         // the bag is a copied subset Dataset (rows renumbered) over full-data device bins
   bool subset_bins_ = false;                           // the device bins were built from a subset Dataset (older path)

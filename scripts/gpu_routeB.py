@@ -364,4 +364,54 @@ for n, F, variants in SIZES:
     np.testing.assert_allclose(pred["gpu_reg"], pred["cpu_reg"], rtol=0, atol=1e-9)
     print("trees with lambda_l1 / max_delta_step / path_smooth: whole trees on the device reproduce device_type=cpu, max |diff| = %.2e" % np.abs(pred["gpu_reg"] - pred["cpu_reg"]).max(), flush=True)
   print("trees (n = %d): device_type=gpu (HIPTreeLearner, whole trees) reproduces device_type=cpu, max |diff| = %.2e" % (n, np.abs(pred["gpu"] - pred["cpu"]).max()), flush=True)
+
+# ---- (2b) round 5: categorical columns and exclusive sparse columns (the reference bundles them, EFB) -- HIPTreeLearner keeps one column per FEATURE on the
+#      device and grows whole trees with the categorical search (gpb_hip_hist_set_categorical); no CPU-histogram fallback ------------------------------
+if "--gp-only" not in sys.argv:
+    n = 20000 if TEST else 100000
+    rng = np.random.default_rng(5)
+    Xc = np.zeros((n, 14))
+    Xc[:, :4] = rng.uniform(size=(n, 4))
+    Xc[:, 4] = rng.integers(0, 5, size=n)
+    Xc[:, 5] = rng.integers(0, 60, size=n) * (rng.uniform(size=n) < 0.85)
+    c12 = rng.integers(0, 12, size=n)
+    for k in range(8):
+        Xc[:, 6 + k] = (c12 == k) * rng.uniform(0.5, 2.0, size=n)
+    eff = rng.standard_normal(60)
+    yc = (np.sin(4 * Xc[:, 0]) + Xc[:, 1] ** 2 + 0.7 * (Xc[:, 4] == 2) + eff[Xc[:, 5].astype(int)] + Xc[:, 7] - 0.5 * Xc[:, 9] + 0.4 * rng.standard_normal(n)).astype(np.float32)
+    Xc = np.ascontiguousarray(Xc)
+    predc = {}
+    print("---- trees with categorical and bundled columns, n = %d, F = 14 ----" % n, flush=True)
+    for tag, dev, extra in (("cpu", "cpu", ""), ("gpu", "gpu", ""), ("cpu_cfg", "cpu", " max_cat_to_onehot=8 cat_smooth=3 cat_l2=1 min_data_per_group=40 lambda_l1=0.5 path_smooth=5"),
+                            ("gpu_cfg", "gpu", " max_cat_to_onehot=8 cat_smooth=3 cat_l2=1 min_data_per_group=40 lambda_l1=0.5 path_smooth=5")):
+        ds = C.c_void_p()
+        ok(L.LGBM_DatasetCreateFromMat(Xc.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(14), C.c_int(1),
+                                       C.c_char_p(("verbosity=1 device_type=%s max_bin=63 categorical_feature=4,5" % dev).encode()), C.c_void_p(), C.byref(ds)))
+        ok(L.LGBM_DatasetSetField(ds, C.c_char_p(b"label"), yc.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(0)))
+        bst = C.c_void_p()
+        params = "objective=regression num_leaves=31 learning_rate=0.1 min_data_in_leaf=20 verbosity=1 device_type=%s num_threads=16 max_bin=63 categorical_feature=4,5%s" % (dev, extra)
+        ok(L.LGBM_BoosterCreate(ds, C.c_char_p(params.encode()), C.byref(bst)))
+        fin = C.c_int(0)
+        ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+        t0 = time.perf_counter()
+        for _ in range(NIT - 1):
+            ok(L.LGBM_BoosterUpdateOneIter(bst, C.byref(fin)))
+        dt = time.perf_counter() - t0
+        out = np.empty(n); olen = C.c_int64(0)
+        ok(L.LGBM_BoosterPredictForMat(bst, Xc.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int32(n), C.c_int32(14), C.c_int(1), C.c_int(0), C.c_int(0),
+                                       C.c_int(-1), C.c_char_p(b""), C.byref(olen), out.ctypes.data_as(C.POINTER(C.c_double))))
+        # the model text names the categorical nodes (decision_type bit 0, num_cat)
+        blen = C.c_int64(0); buf = C.create_string_buffer(1 << 22)
+        ok(L.LGBM_BoosterSaveModelToString(bst, C.c_int(0), C.c_int(-1), C.c_int(0), C.c_int64(len(buf)), C.byref(blen), buf))
+        ncat = sum(int(ln.split("=")[1]) for ln in buf.value.decode().splitlines() if ln.startswith("num_cat="))
+        predc[tag] = (out, ncat)
+        print("%s (device_type=%s%s): %.2f ms per LGBM_BoosterUpdateOneIter over %d iterations; categorical nodes in the model: %d; prediction[:3] = %s"
+              % (tag, dev, extra, dt / (NIT - 1) * 1e3, NIT - 1, ncat, out[:3]), flush=True)
+        ok(L.LGBM_BoosterFree(bst)); ok(L.LGBM_DatasetFree(ds))
+    for a, b in (("gpu", "cpu"), ("gpu_cfg", "cpu_cfg")):
+        np.testing.assert_allclose(predc[a][0], predc[b][0], rtol=0, atol=1e-9)
+        assert predc[a][1] == predc[b][1] and predc[a][1] > 0
+    print("trees with categorical + bundled columns (n = %d): device_type=gpu (HIPTreeLearner, whole trees, per-feature columns) reproduces device_type=cpu, "
+          "max |diff| = %.2e / %.2e, %d / %d categorical nodes" % (n, np.abs(predc["gpu"][0] - predc["cpu"][0]).max(), np.abs(predc["gpu_cfg"][0] - predc["cpu_cfg"][0]).max(),
+                                                                   predc["gpu"][1], predc["gpu_cfg"][1]), flush=True)
 print("ROUTE B ON MI355X: OK", flush=True)

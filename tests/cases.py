@@ -186,7 +186,13 @@ def make_split_data(name):
         X = rng.uniform(size=(n, F))
         X[:, 2] = rng.integers(0, 3, size=n)
         X[:, 5] = rng.integers(0, 40, size=n) * (rng.uniform(size=n) < 0.9)
-        eff = rng.standard_normal(40)
+        # category effects in three clear groups, the rest zero: the best many-vs-many split takes a few categories from one END of the sorted order.
+        # (With 40 generic effects the best split is the half / half one, which BOTH scan directions reach at their cap max_num_cat = (used + 1) / 2 --
+        #  complementary sets, mathematically equal gains, and the winner is decided by the last bits of the histogram sums: a void tie like the
+        #  default_left of a numerical split without missing rows, not something a fixture can pin.)
+        eff = np.zeros(40)
+        idx = rng.permutation(40)
+        eff[idx[:7]] = 1.5 + 0.2 * rng.standard_normal(7); eff[idx[7:12]] = -1.2 + 0.2 * rng.standard_normal(5); eff[idx[12:16]] = 0.6
         g = np.sin(6 * X[:, 0]) + 0.8 * (X[:, 2] == 1) + eff[X[:, 5].astype(int)] + 0.3 * rng.standard_normal(n)
         h = rng.uniform(0.5, 2.0, size=n)
         leaf = np.sort(rng.choice(n, size=2500, replace=False)).astype(np.int32)

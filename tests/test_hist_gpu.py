@@ -272,7 +272,76 @@ def test_leaf_partition_against_reference_fixture(lib_built, name):
     hb.close()
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4"])
+def test_categorical_split_search_and_partition_against_reference_fixture(lib_built, orc):
+    """Round 5: FindBestThresholdCategoricalInner on device-resident histograms and DenseBin::SplitCategorical on the device, against the reference's
+    own output (tests/golden/split_cat_ref.npz): end to end from the bins (build -> fix -> search) the device's SplitInfo is bit-identical to the
+    oracle's on the device's own histogram, and has the reference's winner sets of bins (its sums to the build's 1e-9); the partitions are identical,
+    order included."""
+    import os
+    from gpboost_amd import shim
+    from tests import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_cat_ref.npz"))
+    name = "cat"
+    X, grad, hess, leaf = cases.make_split_data(name)
+    bins, gnb, meta3, is_cat = g[name + "_bins"], g[name + "_group_num_bin"], g[name + "_meta3"], g[name + "_is_categorical"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(2)
+    hb.set_fix_info(g[name + "_view_offset"], g[name + "_num_bin"], g[name + "_most_freq_bin"])
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    same_sets = total = 0
+    for ci, (cfg, cc) in enumerate(cases.SPLIT_CAT_CFGS):
+        hb.set_categorical(is_cat, *cc)
+        hb.set_regularisation(*(cfg[4:8] if len(cfg) > 4 else (0.0, 0.0, 0.0, 0.0)))
+        for li, di in enumerate((None, leaf)):
+            for hi, hs in enumerate((None, hess)):
+                key = "%s_cfg%d_leaf%d_hess%d" % (name, ci, li, hi)
+                sums, ref = g[key + "_sums"], g[key + "_split"]
+                nd = bins.shape[1] if di is None else di.size
+                hb.set_gradients(grad, hs)
+                hb.build_slot(0, di)
+                hb.fix_slot(0, sums[0], sums[1])
+                best, out, dl = hb.find_best_split(0, sums[0], sums[1], nd, *cfg[:4])
+                raw = hb.get_slot(0)
+                for f in np.flatnonzero(is_cat):
+                    row, fl, bits = orc.find_best_split_cat(raw, g[name + "_view_offset"][f], g[name + "_num_bin"][f], meta3[f, 0], sums[0], sums[1], nd,
+                                                            *cfg, cat_cfg=cc)
+                    assert np.array_equal(out[f], row), (key, f, out[f], row)                 # bit-identical given the histogram
+                    assert dl[f] == (fl & 1) and hb.last_splittable[f] == ((fl >> 1) & 1)
+                    assert np.array_equal(hb.last_cat_bits[f], bits)
+                    if np.isfinite(ref[f, 0]):
+                        total += 1
+                        rb = g[key + "_cat_bits"][f]
+                        if np.array_equal(hb.last_cat_bits[f], rb):
+                            same_sets += 1
+                            np.testing.assert_allclose(out[f, [0, 4, 5, 6, 7, 8, 9]], ref[f, [0, 4, 5, 6, 7, 8, 9]], rtol=1e-9, atol=1e-9)
+                            assert out[f, 1] == ref[f, 1]
+                        else:
+                            # the one void tie of the sorted search: both scan directions end at their cap with COMPLEMENTARY halves of the used bins --
+                            # the same partition with left and right exchanged, mathematically equal gains, the winner decided by the last bits of the
+                            # histogram sums (tests/cases.py, make_split_data("cat")).  Anything else is a defect.
+                            assert not (hb.last_cat_bits[f] & rb).any() and out[f, 1] == ref[f, 1]
+                            np.testing.assert_allclose(out[f, 0], ref[f, 0], rtol=1e-12)
+                            np.testing.assert_allclose(out[f, [2, 3]], ref[f, [3, 2]], atol=4)
+                num = np.flatnonzero(is_cat == 0)
+                assert not hb.last_cat_bits[num].any()
+                assert best == int(np.argmax(ref[:, 0]))
+    # (the sorted search orders bins by sum_grad / (sum_hess + cat_smooth): two bins whose keys differ in the last bits of the histogram sums may
+    #  swap; none does on this fixture)
+    assert total >= 30 and same_sets >= total - 1
+    hb.set_regularisation(0.0, 0.0, 0.0, 0.0)
+    pos = 0
+    for (f, th, dl_), w, nl in zip(g[name + "_part_req"], g[name + "_part_bits"], g[name + "_part_lte_count"]):
+        lte, gt = hb.split_leaf(leaf, f, th, dl_, cat_bits=w)
+        assert np.array_equal(lte, g[name + "_part_lte"][pos:pos + nl]), (f, w)
+        assert np.array_equal(np.sort(np.concatenate([lte, gt])), leaf) and np.all(np.diff(gt) > 0)
+        pos += nl
+    assert pos == g[name + "_part_lte"].size
+    hb.close()
+
+
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4",
+                                  "cat_l15", "cat_defaults", "cat_onehot_l1", "cat_smooth", "efb_l15", "efb_rowwise_l15"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     """The five device primitives (leaf histogram, FixHistogram, parent - smaller, split search, leaf partition), driven by the control
@@ -283,18 +352,22 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     from gpboost_amd import shim
     from tests import cases
     from tests import tree_harness as th
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    r5 = name in cases.TREE_CASES_R5       # round 5: categorical columns / bundled groups (the fixture's bins are the unbundled per-feature columns)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref_r5.npz" if r5 else "tree_ref.npz"))
     data, params, L, cfg = cases.tree_params(name)
     X, grad, hess, leaf = cases.make_split_data(data)
     k = "%s_hess%d_" % (name, hi)
     hs = hess if hi else None
     be = th.GpuBackend(shim, g[k + "bins"], g[k + "group_num_bin"], g[k + "view_offset"], g[k + "num_bin"], g[k + "most_freq_bin"],
-                       g[k + "meta3"], grad, hs, L)
+                       g[k + "meta3"], grad, hs, L, is_cat=g[k + "layout"][:, 3] if r5 else None, cat_cfg=cases.tree_cat_cfg(name))
     t = th.grow_tree(be, grad, hs, X.shape[0], L, cfg, max_depth=cases.tree_max_depth(name))
     be.close()
     assert t["num_leaves"] == int(g[k + "num_leaves"])
     for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count"):
         assert np.array_equal(t[key], g[k + key]), key
+    if r5:
+        assert np.array_equal(t["node_is_cat"], g[k + "node_is_cat"])
+        assert np.array_equal(np.asarray(t["node_cat_bits"]).reshape(-1, 8), g[k + "node_cat_bits"])       # the same sets of bins go left
     np.testing.assert_allclose(t["leaf_value"], g[k + "leaf_value"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(t["split_gain"], g[k + "split_gain"], rtol=1e-6)
     # default_left: for features with a missing-value type the reverse and the forward scan find the SAME split whenever the leaf holds
@@ -303,7 +376,7 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
     # identical partition of the node's rows (checked with the oracle's DenseBin::SplitInner).  Without missing-value types there is
     # one scan and the flag is exact.
     flipped = np.flatnonzero(t["default_left"] != g[k + "default_left"])
-    if data == "plain":
+    if data in ("plain", "cat", "efb"):
         assert flipped.size == 0
     from oracle import orc
     bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
@@ -313,7 +386,8 @@ def test_device_primitives_grow_the_reference_tree(lib_built, name, hi):
         assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1]), nd
 
 
-@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4"])
+@pytest.mark.parametrize("name", ["plain_l31", "plain_l15_reg", "nan_l20", "zero_missing_l12", "plain_l1", "plain_mds", "nan_smooth", "plain_all_reg", "plain_depth4",
+                                  "cat_l15", "cat_defaults", "cat_onehot_l1", "cat_smooth", "efb_l15", "efb_rowwise_l15"])
 @pytest.mark.parametrize("hi", [0, 1])
 def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     """gpb_hip_hist_grow_tree (row lists of the leaves resident on the device, control flow in C++) against the reference's own
@@ -322,18 +396,22 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
     from gpboost_amd import shim
     from oracle import orc
     from tests import cases
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    r5 = name in cases.TREE_CASES_R5
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref_r5.npz" if r5 else "tree_ref.npz"))
     data, params, L, cfg = cases.tree_params(name)
     X, grad, hess, leaf = cases.make_split_data(data)
     n = X.shape[0]
     k = "%s_hess%d_" % (name, hi)
     hs = hess if hi else None
     bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+    is_cat = g[k + "layout"][:, 3] if r5 else np.zeros(bins.shape[0], dtype=np.int32)
     bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
     hb = shim.HistBuilder(bins, bo)
     hb.pool_resize(L + 1)
     hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
     hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    if is_cat.any():
+        hb.set_categorical(is_cat, *cases.tree_cat_cfg(name))
     hb.set_gradients(grad, hs)
     sg = float(np.cumsum(grad)[-1]); sh = float(np.cumsum(np.ones(n) if hs is None else hs)[-1])
     if len(cfg) > 4:                      # lambda_l1, max_delta_step, path_smooth (the grower tracks parent_output itself)
@@ -345,8 +423,11 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
         assert np.array_equal(t[key], g[k + key]), key
     np.testing.assert_allclose(t["leaf_value"], g[k + "leaf_value"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(t["split_gain"], g[k + "split_gain"], rtol=1e-6)
-    if data == "plain":
+    if data in ("plain", "cat", "efb"):
         assert np.array_equal(t["default_left"], g[k + "default_left"])
+    if r5:       # categorical nodes: the reference's nodes and its sets of bins (Tree::SplitCategorical's cat_threshold_inner_)
+        assert np.array_equal(t["node_is_cat"], g[k + "node_is_cat"]) and np.array_equal(t["node_cat_bits"], g[k + "node_cat_bits"])
+        assert (data != "cat") or int(t["node_is_cat"].sum()) >= 5
     # leaf of every row: sizes equal the leaf counts, and replaying the tree's splits on the bins reproduces the labels
     dli = t["data_leaf_index"]
     assert np.array_equal(np.bincount(dli, minlength=t["num_leaves"]), t["leaf_count"])
@@ -357,7 +438,10 @@ def test_resident_tree_grower_grows_the_reference_tree(lib_built, name, hi):
         lf = leaf_of_node[nd]
         rows = np.flatnonzero(lab == lf).astype(np.int32)
         f = int(t["split_feature_inner"][nd])
-        lte, gt = orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], int(t["default_left"][nd]), int(t["threshold_in_bin"][nd]), rows)
+        if is_cat[f]:
+            lte, gt = orc.split_leaf_layout(bins[f], 1, gnb[f] - 1, False, meta3[f, 1], mfb[f], meta3[f, 2], 0, 0, True, t["node_cat_bits"][nd], rows)
+        else:
+            lte, gt = orc.split_leaf(bins[f], gnb[f] - 1, meta3[f, 1], mfb[f], meta3[f, 2], int(t["default_left"][nd]), int(t["threshold_in_bin"][nd]), rows)
         lab[gt] = nleaves
         if t["left_child"][nd] >= 0:
             leaf_of_node[int(t["left_child"][nd])] = lf

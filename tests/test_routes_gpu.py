@@ -26,8 +26,12 @@ REFPKG = os.path.join(ROOT, "oracle", "_ref", "refpkg", "gpboost", "basic.py")
 HIPLIB = os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so")
 
 
+_LAST_STDERR = [""]
+
+
 def _run(args, ok_line, timeout):
     r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    _LAST_STDERR[0] = r.stderr
     tail = (r.stdout[-4000:] + "\n--- stderr ---\n" + r.stderr[-3000:])
     assert r.returncode == 0, tail
     assert ok_line in r.stdout, tail
@@ -53,3 +57,8 @@ def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_buil
 def test_route_b_reference_booster_with_device_type_gpu_reproduces_device_type_cpu(lib_built):
     out = _run(["scripts/gpu_routeB.py", "--test", "--trees-only"], "ROUTE B ON MI355X: OK", 1500)
     assert "device_type=gpu (HIPTreeLearner, whole trees) reproduces device_type=cpu" in out
+    # round 5: categorical columns and columns the reference bundles (EFB): whole trees on the device from per-feature columns, no CPU-histogram fallback
+    assert "device_type=gpu (HIPTreeLearner, whole trees, per-feature columns) reproduces device_type=cpu" in out
+    both = out + "\n" + _LAST_STDERR[0]
+    assert "per-feature (unbundled) columns" in both and "categorical features searched on the GPU" in both
+    assert "histograms stay on the CPU" not in both
