@@ -1905,12 +1905,14 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     // full-scale Vecchia, 'order_obs_first_cond_obs_only' (the reference's default for Gaussian data; CalcPredVecchiaObservedFirstOrder with the
     // full_scale_vecchia arguments, Vecchia_utils.cpp:1701-2060; re_model_template.h:4041-4056): y_p = C_p Sigma_m^-1 eta + e_p with the residual
     // e_p conditioning on the nearest observed points -> mean = A_p y_nn + (B C)_p W^-1 (B C)' D^-1 B y, var = sigma2 (D_p + (B C)_p W^-1 (B C)_p')
-    const char* vscope = "is not on the MI355X path of this library (full-scale Vecchia prediction: 'order_obs_first_cond_obs_only', no covariates / samples)";
+    const char* vscope = "is not on the MI355X path of this library (full-scale Vecchia prediction: 'order_obs_first_cond_obs_only' / 'order_obs_first_cond_all', no covariates / samples)";
     if (sample_posterior || sample_prior) return set_error("GPB_PredictREModel: samples of a full-scale Vecchia model %s", vscope);
     if (predict_cov_mat && predict_var) return set_error("Calculation of both the predictive covariance matrix and variances is not supported. Choose one option (predict_cov_mat or predict_var)");
     if (cluster_ids_data_pred || re_group_data_pred || re_group_rand_coef_data_pred || gp_rand_coef_data_pred || covariate_data_pred || mdl->p_cov > 0)
       return set_error("GPB_PredictREModel: cluster ids / grouped effects / random coefficients / covariates for prediction %s", vscope);
-    if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only") return set_error("GPB_PredictREModel: vecchia_pred_type '%s' of a full-scale Vecchia model %s", mdl->vecchia_pred_type.c_str(), vscope);
+    // (the reference has exactly these two for full-scale Vecchia models: 'order_pred_first' and the latent types are fatal there, re_model_template.h:4072-4110)
+    const bool v_cond_all = mdl->vecchia_pred_type == "order_obs_first_cond_all";
+    if (mdl->vecchia_pred_type != "order_obs_first_cond_obs_only" && !v_cond_all) return set_error("GPB_PredictREModel: vecchia_pred_type '%s' of a full-scale Vecchia model %s", mdl->vecchia_pred_type.c_str(), vscope);
     const double* cpv = gp_coords_data_pred;
     int npv = num_data_pred;
     if (use_saved_data) { cpv = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npv = mdl->num_data_pred; }
@@ -1928,10 +1930,71 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     double t3[3];
     if (vif_terms(mdl, trv[1], trv[2], t3, &vs)) return -1;
     int nnpv = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;
-    if (nnpv > mdl->n) nnpv = mdl->n;
+    if (nnpv > (v_cond_all ? mdl->n + npv - 1 : mdl->n)) nnpv = v_cond_all ? mdl->n + npv - 1 : mdl->n;
     if (nnpv > 126) nnpv = 126;
     const int kv = mdl->num_ind_points;
     std::vector<double> up(npv), Dp(npv), BC((size_t)npv * kv);
+    if (v_cond_all) {
+      // 'order_obs_first_cond_all' (CalcPredVecchiaObservedFirstOrder, CondObsOnly = false, Vecchia_utils.cpp:1975-2046): the device returns the rows of
+      // [Bpo Bp] of the appended points, -(Bpo y) and (B~ C~)_p; here the forward substitutions with Bp = I - A_pp (unit lower triangular: a neighbour
+      // precedes its point) --  mean = Bp^-1 (-Bpo y + (B~ C~)_p v),  T = Bp^-1 (B~ C~)_p,  rows of Bp^-1 --  and
+      // cov = sigma2 (Bp^-1 Dp Bp^-T + T W^-1 T')  [- sigma2 I for the latent process].  The reference's eight-term expression (:2028-2046) is T W^-1 T'
+      // written out with W = Sigma_m + (B C)' D^-1 (B C).  Dense in the number of prediction points, as the 'cond_all' type of the plain Vecchia model here.
+      const bool second2 = predict_var || predict_cov_mat;
+      if (second2 && npv > 20000) return set_error("GPB_PredictREModel: predictive (co)variances of 'order_obs_first_cond_all' for %d points (dense limit: 20000)", npv);
+      int mu_ = 0;
+      std::vector<int32_t> nnr((size_t)npv * nnpv);
+      std::vector<double> Ap((size_t)npv * nnpv);
+      if (gpb_hip_vecchia_vif_predict_cond_all(mdl->vh, npv, cpv, nnpv, mdl->ip.data(), mdl->cov_type, trv[1], trv[2], vs.Linv.data(), &mu_, nnr.data(), Ap.data(),
+                                               up.data(), Dp.data(), BC.data(), nullptr)) return shim_error();
+      std::vector<double> Lr(second2 ? (size_t)npv * npv : 0, 0.);       // rows of Bp^-1
+      std::vector<double> mean(npv);
+      for (int i = 0; i < npv; ++i) {
+        double* bc = BC.data() + (size_t)i * kv;
+        if (second2) Lr[(size_t)i * npv + i] = 1.;
+        double w = -up[i];
+        for (int j = 0; j < kv; ++j) w += bc[j] * vs.v[j];
+        for (int j = 0; j < mu_; ++j) {
+          const int c = nnr[(size_t)i * mu_ + j];
+          if (c < mdl->n) continue;                              // (-1 padding and observed neighbours: already in u and BC)
+          const int q = c - mdl->n;
+          if (q >= i) return set_error("GPB_PredictREModel: prediction point %d has neighbour %d that does not precede it", i, q);
+          const double aij = Ap[(size_t)i * mu_ + j];
+          w += aij * mean[q];
+          if (second2) {
+            const double* bq = BC.data() + (size_t)q * kv;       // (already T_q: rows are finished in order)
+            for (int r = 0; r < kv; ++r) bc[r] += aij * bq[r];
+            for (int r = 0; r <= q; ++r) Lr[(size_t)i * npv + r] += aij * Lr[(size_t)q * npv + r];
+          }
+        }
+        mean[i] = w;
+        out_predict[i] = w + (fixed_effects_pred ? fixed_effects_pred[i] : 0.);
+      }
+      if (second2) {
+        std::vector<double> T((size_t)npv * kv);
+        for (int i = 0; i < npv; ++i) {                          // T_i <- L_W^-1 T_i
+          const double* bc = BC.data() + (size_t)i * kv;
+          double* tmp = T.data() + (size_t)i * kv;
+          for (int r = 0; r < kv; ++r) {
+            double v = bc[r];
+            for (int j = 0; j < r; ++j) v -= vs.Lw[(size_t)r * kv + j] * tmp[j];
+            tmp[r] = v / vs.Lw[(size_t)r * kv + r];
+          }
+        }
+        for (int i = 0; i < npv; ++i) {
+          for (int j = predict_cov_mat ? 0 : i; j <= i; ++j) {
+            double qq = 0.;
+            for (int r = 0; r < kv; ++r) qq += T[(size_t)i * kv + r] * T[(size_t)j * kv + r];
+            for (int r = 0; r <= j; ++r) qq += Lr[(size_t)i * npv + r] * Dp[r] * Lr[(size_t)j * npv + r];
+            const double v = trv[0] * (qq - ((i == j && !predict_response) ? 1. : 0.));
+            if (predict_cov_mat) { out_predict[npv + (size_t)i * npv + j] = v; out_predict[npv + (size_t)j * npv + i] = v; }
+            else out_predict[npv + i] = v;
+          }
+        }
+      }
+      mdl->yaux_valid = false;
+      return 0;
+    }
     if (gpb_hip_vecchia_vif_predict_obs_only(mdl->vh, npv, cpv, nnpv, mdl->ip.data(), mdl->cov_type, trv[1], trv[2], vs.Linv.data(), up.data(), Dp.data(), BC.data(), nullptr))
       return shim_error();
     // T = L_W^-1 (B C)_p' column by column (only when second moments are asked for): var_p = D_p + ||T_p||^2, and -- the residuals of two

@@ -1761,15 +1761,42 @@ int gpb_hip_vecchia_predict_cond_all_latent(gpb_hip_vecchia_t* h, int32_t n_pred
 // Woodbury quantities of the observed points (GPB_PredictREModel): mean = -u_p + (B C)_p W^-1 (B C)' D^-1 B y, var = D_p + (B C)_p W^-1 (B C)_p'.
 // ip_colmajor: k x d inducing points; Linv_rowmajor: inverse Cholesky factor of Sigma_m (as gpb_hip_vecchia_vif_factor takes it).
 // Outputs: u_pred, D_pred (n_pred), BC_pred (n_pred x k, row-major).
+static int vif_predict_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred, bool cond_all,
+                                const double* ip_colmajor, int cov_type, double var, double a, const double* Linv_rowmajor,
+                                double* u_pred, double* D_pred, double* BC_pred, int* has_duplicates, int32_t* m_used, int32_t* nn_pred, double* A_pred);
+
 int gpb_hip_vecchia_vif_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
                                          const double* ip_colmajor, int cov_type, double var, double a, const double* Linv_rowmajor,
                                          double* u_pred, double* D_pred, double* BC_pred, int* has_duplicates) {
   API_BEGIN();
+  if (vif_predict_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, false, ip_colmajor, cov_type, var, a, Linv_rowmajor, u_pred, D_pred, BC_pred,
+                           has_duplicates, nullptr, nullptr, nullptr)) return -1;
+  API_END();
+}
+
+// 'order_obs_first_cond_all' of a full-scale Vecchia model (round 5; CalcPredVecchiaObservedFirstOrder with CondObsOnly = false and the full_scale_vecchia
+// arguments, Vecchia_utils.cpp:1803-1826, 1889-1925): the same device half with the neighbours of the appended points searched among the observed AND the
+// preceding prediction points (the low-rank correction of a residual covariance reads the whitened cross-covariances of prediction points as well);
+// returns in addition the rows of [Bpo Bp]: neighbour indices into (observed, prediction) points (-1 padded) and the coefficients A, m_used per row.
+int gpb_hip_vecchia_vif_predict_cond_all(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                         const double* ip_colmajor, int cov_type, double var, double a, const double* Linv_rowmajor,
+                                         int32_t* m_used, int32_t* nn_pred, double* A_pred, double* u_pred, double* D_pred, double* BC_pred, int* has_duplicates) {
+  API_BEGIN();
+  if (!m_used || !nn_pred || !A_pred) return fail("null argument");
+  if (vif_predict_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, true, ip_colmajor, cov_type, var, a, Linv_rowmajor, u_pred, D_pred, BC_pred,
+                           has_duplicates, m_used, nn_pred, A_pred)) return -1;
+  API_END();
+}
+
+static int vif_predict_appended(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred, bool cond_all,
+                                const double* ip_colmajor, int cov_type, double var, double a, const double* Linv_rowmajor,
+                                double* u_pred, double* D_pred, double* BC_pred, int* has_duplicates, int32_t* m_used, int32_t* nn_pred, double* A_pred) {
+  {
   if (!h || !ip_colmajor || !Linv_rowmajor || !u_pred || !D_pred || !BC_pred) return fail("null argument");
   if (h->vif_k < 1) return fail("no inducing points have been set (call gpb_hip_vecchia_vif_set_inducing_points)");
   gpb_hip_vecchia_t* t = nullptr;
   int m = 0;
-  const int rc = predict_factor_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, false, cov_type, var, a, &t, &m, has_duplicates, 1, false, false, false);
+  const int rc = predict_factor_appended(h, n_pred, coords_pred_colmajor, num_neighbors_pred, cond_all, cov_type, var, a, &t, &m, has_duplicates, 1, false, false, false);
   struct Guard { gpb_hip_vecchia_t* p; ~Guard() { if (p) gpb_hip_vecchia_free(p); } } guard{t};
   if (rc) return -1;
   const int n_obs = h->n, n_all = n_obs + n_pred, k = h->vif_k;
@@ -1795,8 +1822,14 @@ int gpb_hip_vecchia_vif_predict_obs_only(gpb_hip_vecchia_t* h, int32_t n_pred, c
   HIP_OK(hipMemcpyAsync(D_pred, t->d_D + n_obs, sizeof(double) * (size_t)n_pred, hipMemcpyDeviceToHost, t->stream));
   HIP_OK(hipMemcpy2DAsync(BC_pred, sizeof(double) * (size_t)k, t->d_vQ + (size_t)n_obs * kq, sizeof(double) * (size_t)kq, sizeof(double) * (size_t)k, (size_t)n_pred,
                           hipMemcpyDeviceToHost, t->stream));
+  if (nn_pred) {
+    *m_used = m;
+    HIP_OK(hipMemcpyAsync(nn_pred, t->d_nn + (size_t)n_obs * m, sizeof(int) * (size_t)n_pred * m, hipMemcpyDeviceToHost, t->stream));
+    HIP_OK(hipMemcpyAsync(A_pred, t->d_A + (size_t)n_obs * m, sizeof(double) * (size_t)n_pred * m, hipMemcpyDeviceToHost, t->stream));
+  }
   HIP_OK(hipStreamSynchronize(t->stream));
-  API_END();
+  }
+  return 0;
 }
 
 // Factor rows of EVERY point of a joint (observed, prediction) ordering -- the device half of the prediction types that re-factor the

@@ -313,6 +313,15 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_vif_predict_obs_only(gpb_hip_vecchia_t* h, in
                                                         int32_t num_neighbors_pred, const double* ip_colmajor, int cov_type, double var, double a,
                                                         const double* Linv_rowmajor, double* u_pred, double* D_pred, double* BC_pred,
                                                         int* has_duplicates);
+/* The same for 'order_obs_first_cond_all' (round 5; CalcPredVecchiaObservedFirstOrder with CondObsOnly = false, src/GPBoost/Vecchia_utils.cpp:1803-1826,
+ * 1889-1925, 1975-2046; the reference's only other prediction type for full-scale Vecchia models, re_model_template.h:4057-4085): neighbours among the
+ * observed AND the preceding prediction points.  In addition to the outputs above (BC_pred = row of [Bpo Bp] [C; C_p], u_pred = (Bpo y)): the rows of
+ * [Bpo Bp] themselves -- nn_pred (n_pred x *m_used, indices into (observed, prediction) points, -1 padded) and A_pred.  With Bp = I - A_pp (unit lower
+ * triangular):  mean = Bp^-1 (-u_pred + BC_pred W^-1 (B C)' D^-1 B y),  cov = sigma2 (Bp^-1 D_pred Bp^-T + T W^-1 T'),  T = Bp^-1 BC_pred. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_vif_predict_cond_all(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred,
+                                                        const double* ip_colmajor, int cov_type, double var, double a, const double* Linv_rowmajor,
+                                                        int32_t* m_used, int32_t* nn_pred, double* A_pred, double* u_pred, double* D_pred, double* BC_pred,
+                                                        int* has_duplicates);
 
 /* Device half of the Vecchia prediction types that factor EVERY point of a joint (observed, prediction) ordering again:
  *   layout_pred_first = 1  'order_pred_first' (CalcPredVecchiaPredictedFirstOrder, src/GPBoost/Vecchia_utils.cpp:2203-2444): prediction points

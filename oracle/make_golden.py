@@ -749,6 +749,33 @@ def vif_pred_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "vif_pred_ref.npz"), **res)
 
 
+def vif_pred_points(d):
+    """40 prediction points of the VIF 'cond_all' fixture: 25 uniform ones and a tight cluster of 15 (so that prediction points are each other's neighbours)."""
+    rng = np.random.default_rng(52)
+    return np.vstack([rng.uniform(size=(25, d)), 0.37 + 0.02 * rng.uniform(size=(15, d))])
+
+
+def vif_pred_condall_fixture(out_dir):
+    """Round 5: the same for 'order_obs_first_cond_all' (neighbours among observed and preceding prediction points; the only other prediction type the
+    reference has for full-scale Vecchia models, re_model_template.h:4057-4085): tests/golden/vif_pred_condall_ref.npz."""
+    res = {}
+    for name in VIF_FIT_CASES:
+        n, d, cf, sh, m, k, ordering, seed, cps = cases.VIF_CASES[name]
+        coords, y = cases.vif_data(name)
+        cpred = vif_pred_points(d)
+        mdl = refdrv.RefCAPIModel(coords, cf, sh, m, ordering, seed, threads=4, gp_approx="full_scale_vecchia", num_ind_points=k)
+        cp = np.asarray(cps[0], dtype=np.float64)
+        for tag, mp in (("m", m), ("2m", 2 * m)):
+            mu, var = mdl.predict(cpred, predict_var=True, predict_response=True, vecchia_pred_type="order_obs_first_cond_all", num_neighbors_pred=mp, y=y, cov_pars=cp)
+            mu2, lvar = mdl.predict(cpred, predict_var=True, predict_response=False, vecchia_pred_type="order_obs_first_cond_all", num_neighbors_pred=mp, y=y, cov_pars=cp)
+            res["%s_%s_mu" % (name, tag)] = mu; res["%s_%s_var" % (name, tag)] = var; res["%s_%s_latent_var" % (name, tag)] = lvar
+            if tag == "m":
+                _, cov = mdl.predict(cpred, predict_response=True, vecchia_pred_type="order_obs_first_cond_all", num_neighbors_pred=mp, y=y, cov_pars=cp, predict_cov_mat=True)
+                res["%s_%s_cov" % (name, tag)] = cov
+        print("vif pred cond_all", name, mu[:3], var[:3], lvar[:3], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "vif_pred_condall_ref.npz"), **res)
+
+
 def vif_fit_fixture(out_dir):
     """The unmodified reference's own lbfgs fits (its default optimiser, analytic gradient) of full-scale Vecchia models from the first
     parameter set of tests/cases.py:VIF_CASES (tests/golden/vif_fit_ref.npz)."""
@@ -949,6 +976,8 @@ if __name__ == "__main__":
         exact_pred_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_pred":
         vif_pred_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_pred_condall":
+        vif_pred_condall_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_fit":
         vif_fit_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_dup_gradF":

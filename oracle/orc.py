@@ -1087,6 +1087,68 @@ def vif_predict_obs_only(co, nn, ip, cov_type, pars_trans, y, coords_pred, m_pre
     return mean, varp
 
 
+def vif_predict_cond_all(co, nn, ip, cov_type, pars_trans, y, coords_pred, m_pred, predict_response=True, want_cov=False):
+    """Prediction of a full-scale Vecchia (VIF) model, 'order_obs_first_cond_all' (CalcPredVecchiaObservedFirstOrder with CondObsOnly = false and the
+    full_scale_vecchia arguments, src/GPBoost/Vecchia_utils.cpp:1803-1826 neighbours among observed AND preceding prediction points, :1889-1925 the
+    residual covariances of such neighbours, :1975-2046 mean and (co)variances; called from re_model_template.h:4057-4071).  With Bpo / Bp / Dp the
+    factor rows of the appended points in the residual process + nugget (Bp unit lower triangular) and C~ = [C; C_p]:
+        mean = Bp^-1 (-Bpo y + (B~ C~)_p v),   v = W^-1 (B C)' D^-1 B y          (:1976-1981)
+        cov  = sigma2 (Bp^-1 Dp Bp^-T + T W^-1 T'),   T = Bp^-1 (B~ C~)_p = C_p + Bp^-1 Bpo C     [- sigma2 I for the latent process]
+    -- the reference's eight-term expression (:2028-2046) collapses to T W^-1 T' with W = Sigma_m + (B C)' D^-1 (B C).  numpy, small n.
+    -> (mean, var) or (mean, var, cov)."""
+    from scipy.spatial.distance import cdist
+    from scipy.linalg import cholesky, solve_triangular, cho_solve
+    sigma2, var, a = pars_trans
+    co = np.asarray(co, dtype=np.float64); cp = np.asarray(coords_pred, dtype=np.float64)
+    n, npd = co.shape[0], cp.shape[0]
+    Sm = _matern(cov_type, cdist(ip, ip), var, a)
+    Sm[np.diag_indices_from(Sm)] *= 1.0 + 1e-6
+    Lm = cholesky(Sm, lower=True)
+    Cnm = _matern(cov_type, cdist(co, ip), var, a)
+    Cpm = _matern(cov_type, cdist(cp, ip), var, a)
+    call = np.vstack([co, cp]); Call = np.vstack([Cnm, Cpm])
+    Vall = solve_triangular(Lm, Call.T, lower=True)
+    quad, logdet, A, D = vif_terms(co, nn, ip, cov_type, var, a, y)
+    y = np.asarray(y, dtype=np.float64)
+
+    def Bmul(x):
+        out = x.copy()
+        for i in range(n):
+            idx = nn[i][nn[i] >= 0]
+            out[i] -= A[i, :idx.size] @ x[idx]
+        return out
+    u = Bmul(y); U = Bmul(Cnm)
+    W = Sm + U.T @ (U / D[:, None])
+    Lw = cholesky(W, lower=True)
+    v = cho_solve((Lw, True), U.T @ (u / D))
+    nnp = neighbors_range(call, min(m_pred, n + npd - 1), n, -1)[n:]
+    yall = np.concatenate([y, np.zeros(npd)])
+    mean = np.empty(npd); Dp = np.empty(npd)
+    T = np.empty((npd, ip.shape[0])); Linv = np.zeros((npd, npd))
+    for i in range(npd):
+        idx = nnp[i][nnp[i] >= 0]
+        Cnn = _matern(cov_type, cdist(call[idx], call[idx]), var, a) - Vall[:, idx].T @ Vall[:, idx]
+        Cnn[np.diag_indices_from(Cnn)] += 1.0
+        c = _matern(cov_type, cdist(call[idx], cp[i:i + 1]), var, a)[:, 0] - Vall[:, idx].T @ Vall[:, n + i]
+        Ai = cho_solve((cholesky(Cnn, lower=True), True), c)
+        Dp[i] = var + 1.0 - Vall[:, n + i] @ Vall[:, n + i] - Ai @ c
+        bc = Cpm[i] - Ai @ Call[idx]                       # row i of B~ C~
+        w = Ai @ yall[idx] + bc @ v                        # -(Bpo y)_i + (B~ C~)_i v
+        Linv[i, i] = 1.0
+        for aij, c_ in zip(Ai, idx):
+            if c_ >= n:                                    # a preceding prediction point: forward substitution with Bp = I - A_pp
+                q = c_ - n
+                w += aij * mean[q]; bc = bc + aij * T[q]; Linv[i, :q + 1] += aij * Linv[q, :q + 1]
+        mean[i] = w; T[i] = bc
+    Tw = solve_triangular(Lw, T.T, lower=True)             # k x np
+    cov = sigma2 * ((Linv * Dp[None, :]) @ Linv.T + Tw.T @ Tw)
+    if not predict_response:
+        cov[np.diag_indices_from(cov)] -= sigma2
+    if want_cov:
+        return mean, np.diag(cov).copy(), cov
+    return mean, np.diag(cov).copy()
+
+
 def vif_nll(coords, y, cov_pars, cov_function="exponential", shape=0.5, m=30, num_ind_points=200, ordering="random", seed=0, setup=None):
     ct = cov_type_id(cov_function, shape)
     pt = transform_cov_pars(ct, cov_pars)

@@ -588,5 +588,5 @@ NOT_IN_MOCK(gpb_hip_exact_nll_terms) NOT_IN_MOCK(gpb_hip_exact_predict) NOT_IN_M
 NOT_IN_MOCK(gpb_hip_vecchia_fisher_std_errors) NOT_IN_MOCK(gpb_hip_vecchia_grad_terms_allreduce)
 NOT_IN_MOCK(gpb_hip_vecchia_nll_terms_allreduce)
 NOT_IN_MOCK(gpb_hip_vecchia_set_nugget_diag) NOT_IN_MOCK(gpb_hip_hist_register_host_buffers) NOT_IN_MOCK(gpb_hip_hist_unregister_host_buffers) NOT_IN_MOCK(gpb_hip_kmeans_lloyd) NOT_IN_MOCK(gpb_hip_vecchia_timing) NOT_IN_MOCK(gpb_hip_mailbox_create) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_attach) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_info) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_detach)
-NOT_IN_MOCK(gpb_hip_vecchia_vif_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_grad_sums) NOT_IN_MOCK(gpb_hip_vecchia_vif_get_grad_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_obs_only) NOT_IN_MOCK(gpb_hip_vecchia_vif_set_inducing_points)
+NOT_IN_MOCK(gpb_hip_vecchia_vif_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_grad_sums) NOT_IN_MOCK(gpb_hip_vecchia_vif_get_grad_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_obs_only) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_cond_all) NOT_IN_MOCK(gpb_hip_vecchia_vif_set_inducing_points)
 }  // extern "C"

@@ -163,7 +163,7 @@ def test_alias_ordering_structure_and_rejections(gpb, orc):
     g = np.load(GOLDEN)
     assert abs(mdl.neg_log_likelihood(np.asarray(cps[0]), y) - float(g[name + "_negll_0"])) <= 1e-8 * abs(float(g[name + "_negll_0"]))
     with pytest.raises(gpb.GPBoostError, match="full-scale Vecchia"):
-        mdl.predict(y, coords[:5], np.asarray(cps[0]), vecchia_pred_type="order_obs_first_cond_all")       # the default type is on the path, the others are not
+        mdl.predict(y, coords[:5], np.asarray(cps[0]), vecchia_pred_type="order_pred_first")       # (fatal in the reference too for this approximation, re_model_template.h:4072-4075)
     with pytest.raises(gpb.GPBoostError, match="gp_approx"):
         gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="full_scale_vecchia_correlation_based", num_neighbors=m, num_ind_points=k)
     with pytest.raises(gpb.GPBoostError, match="num_ind_points"):
@@ -240,6 +240,58 @@ def test_prediction_oracle_reproduces_the_reference(orc, name):
         np.testing.assert_allclose(var, g["%s_%s_var" % (name, tag)], rtol=1e-8)
         _, lvar = orc.vif_predict_obs_only(co, nn, ip, ct, pt, y[perm], cpred, mp, False)
         np.testing.assert_allclose(lvar, g["%s_%s_latent_var" % (name, tag)], rtol=1e-7)
+
+
+def _condall_points(d):
+    rng = np.random.default_rng(52)          # (oracle/make_golden.py: vif_pred_points)
+    return np.vstack([rng.uniform(size=(25, d)), 0.37 + 0.02 * rng.uniform(size=(15, d))])
+
+
+@pytest.mark.parametrize("name", PRED_CASES)
+def test_prediction_cond_all_oracle_reproduces_the_reference(orc, name):
+    """Round 5 -- VIF prediction 'order_obs_first_cond_all' (the reference's only other prediction type for full-scale Vecchia models): neighbours among
+    the observed AND the preceding prediction points, mean / variances / covariance matrix by forward substitution with Bp and the low-rank part
+    T W^-1 T' (orc.vif_predict_cond_all) against the unmodified reference (tests/golden/vif_pred_condall_ref.npz)."""
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "vif_pred_condall_ref.npz"))
+    n, d, cf, sh, m, k, ordering, seed, cps = cases.VIF_CASES[name]
+    coords, y = cases.vif_data(name)
+    cpred = _condall_points(d)
+    perm, co, nn, ip = orc.vif_setup(coords, m, k, ordering, seed)
+    ct = orc.cov_type_id(cf, sh)
+    pt = orc.transform_cov_pars(ct, np.asarray(cps[0]))
+    for tag, mp in (("m", m), ("2m", 2 * m)):
+        mu, var, cov = orc.vif_predict_cond_all(co, nn, ip, ct, pt, y[perm], cpred, mp, True, want_cov=True)
+        np.testing.assert_allclose(mu, g["%s_%s_mu" % (name, tag)], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(var, g["%s_%s_var" % (name, tag)], rtol=1e-8)
+        _, lvar = orc.vif_predict_cond_all(co, nn, ip, ct, pt, y[perm], cpred, mp, False)
+        np.testing.assert_allclose(lvar, g["%s_%s_latent_var" % (name, tag)], rtol=1e-7)
+        if tag == "m":
+            np.testing.assert_allclose(cov, g["%s_%s_cov" % (name, tag)], rtol=1e-7, atol=1e-11)
+    # the type differs from 'cond_obs_only' on these points (the cluster's points condition on each other)
+    mu_o, var_o = orc.vif_predict_obs_only(co, nn, ip, ct, pt, y[perm], cpred, m, True)
+    assert np.abs(var_o - g["%s_m_var" % name]).max() > 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PRED_CASES)
+def test_device_prediction_cond_all_against_the_reference(gpb, name):
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "vif_pred_condall_ref.npz"))
+    n, d, cf, sh, m, k, ordering, seed, cps = cases.VIF_CASES[name]
+    mdl, coords, y, _ = _model(gpb, name)
+    cpred = _condall_points(d)
+    cp = np.asarray(cps[0])
+    for tag, mp in (("m", m), ("2m", 2 * m)):
+        kw = dict(y=y, gp_coords_pred=cpred, cov_pars=cp, num_neighbors_pred=mp, vecchia_pred_type="order_obs_first_cond_all")
+        pr = mdl.predict(predict_var=True, predict_response=True, **kw)
+        np.testing.assert_allclose(pr["mu"], g["%s_%s_mu" % (name, tag)], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(pr["var"], g["%s_%s_var" % (name, tag)], rtol=1e-8)
+        pl = mdl.predict(predict_var=True, predict_response=False, **kw)
+        np.testing.assert_allclose(pl["var"], g["%s_%s_latent_var" % (name, tag)], rtol=1e-7)
+        pm = mdl.predict(**kw)
+        np.testing.assert_allclose(pm["mu"], g["%s_%s_mu" % (name, tag)], rtol=1e-8, atol=1e-10)
+        if tag == "m":
+            pc = mdl.predict(predict_cov_mat=True, predict_response=True, **kw)
+            np.testing.assert_allclose(pc["cov"], g["%s_%s_cov" % (name, tag)], rtol=1e-7, atol=1e-11)
 
 
 @pytest.mark.gpu
