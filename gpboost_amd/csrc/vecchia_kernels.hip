@@ -137,7 +137,12 @@ __device__ __forceinline__ void vecchia_finish(const VecchiaKernelArgs& args, in
 // 30 < MT <= 40, solving modes: TWO workgroups per CU, i.e. a 256-VGPR cap with 60 - 89 values in scratch.  Round 4 measured the alternative the
 // spills suggest -- one workgroup per CU, 316 registers (60 of them AGPRs), no scratch, no DPP hazards: 6.30 ms against 5.40 ms per gradient launch at
 // n = 1e6, d = 3, Matern-2.5, m = 40 (profiles/r04_j_grad_m40_one_workgroup_per_cu_ab.txt): the second wavefront per SIMD hides more than the spills cost.
-template <int MT, int COV, bool D3, int MODE>
+// WT (round 5): sample weights (args.nug != nullptr) as a template argument -- the instances without weights carry neither the NS diagonal entries per lane nor the
+// selects between them and the uniform diagonal (the d = 3, MT = 40 gradient instance had reached 256 VGPRs and spilled one).
+template <int MT, int MODE>
+constexpr bool kRuntimeWeightedInstance() { return MODE == MODE_GRAD && MT > 30 && MT <= 40; }
+
+template <int MT, int COV, bool D3, int MODE, bool WT>
 __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 : 1) void vecchia_point_kernel(VecchiaKernelArgs args) {
   using L = Layout<MT>;
   constexpr int NS = L::NS;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
   __shared__ __attribute__((aligned(16))) char s_pts_raw[16 * PBYTES];
   __shared__ double s_red[GPB_NUM_PARTIALS][16];
   __shared__ double s_f0[kLeftSolve ? 16 : 1][kLeftSolve ? 256 : 1];   // kLeftSolve: slot 0's pieces of the factor's columns 0..15, [column][thread]
-  constexpr bool kDgInLds = (MODE == MODE_NLL) && kLeftLooking;      // (MT <= 30 keeps them in registers: four wavefronts per SIMD either way)
+  constexpr bool kDgInLds = WT && (MODE == MODE_NLL) && kLeftLooking;      // (MT <= 30 keeps them in registers: four wavefronts per SIMD either way)
   __shared__ double s_dg[kDgInLds ? 16 : 1][kDgInLds ? NS * 16 : 1];   // sample weights, MODE_NLL with MT > 30: diagonal entry (var + nugget_r) of every row of the point's system
   __shared__ double s_dk[NSTORE][kStoreDK ? 256 : 1];
   // (A~_r, b~_r) pairs of the contraction pass: with kStoreDK they live in the point's record block, which is dead by then (the same 16
@@ -251,15 +256,21 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
   // MODE_NLL with MT > 30 (round 5): the entries wait in LDS, s_dg[point][row], not in NS doubles per lane that are live across the whole factorisation -- those had
   // pushed the d = 3, MT = 40 likelihood instance from 166 to 174 VGPRs, i.e. from three wavefronts per SIMD to two: the 2.20 -> 2.42 ms regression of round 3.
   // The solving modes are not register-limited at that point and MODE_GRAD with stored derivatives has no LDS to spare (two workgroups per CU): registers there.
-  const bool weighted = args.nug != nullptr;           // (uniform)
-  double own_dg[kDgInLds ? 1 : NS];
+  // (the launcher picks the instance by args.nug != nullptr -- except for the gradient instance of 30 < MT <= 40: there the WT = true instance serves both cases
+  //  with the run-time test of rounds 3-4.  Measured at config 5's shape, d = 3 Matern-2.5: 4.93 ms that way; the compile-time unweighted instance got 256 VGPRs + 5
+  //  spilled and 5.24 ms, the compile-time weighted one on unit nuggets 247 VGPRs and 5.12 ms -- profiles/r05_l_*, r05_m_*)
+  constexpr bool kRuntimeW = WT && kRuntimeWeightedInstance<MT, MODE>();
+  const bool weighted = kRuntimeW ? (args.nug != nullptr) : WT;
+  constexpr int kOwnDg = (kDgInLds || !WT) ? 1 : NS;
+  double own_dg[kOwnDg];
 #pragma unroll
-  for (int s = 0; s < (kDgInLds ? 1 : NS); ++s) own_dg[s] = 0.0;
+  for (int s = 0; s < kOwnDg; ++s) own_dg[s] = 0.0;
+  auto own_dg_of = [&](int s) -> double { if constexpr (kOwnDg == NS) return own_dg[s]; else { (void)s; return own_dg[0]; } };
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int r = 16 * s + ((s & 1) ? 15 - l : l);
     const int idx = cidx[s];
-    if (weighted) {
+    if (WT && weighted) {
       const double dgv = args.var + (idx >= 0 ? args.nug[idx] : 1.0);
       if constexpr (kDgInLds) s_dg[g][r] = dgv; else own_dg[s] = dgv;
     }
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
       {
         double dg;      // (weighted: row c's entry by a broadcast read [MODE_NLL] / every lane offers its own row's entry [solving modes]; the mask picks the owner)
         if constexpr (kDgInLds) dg = weighted ? s_dg[g][c] : ((c == MT) ? args.diag_i : args.diag_nn);
-        else dg = weighted ? own_dg[sc_] : ((c == MT) ? args.diag_i : args.diag_nn);
+        else dg = weighted ? own_dg_of(sc_) : ((c == MT) ? args.diag_i : args.diag_nn);
         if constexpr (c == 16 * sc_ + 15 || c == MT) M[sc_][c] = dg;     // own-slot piece never evaluated: plain init
         else set_lanes<row_lane_eq(lc)>(M[sc_][c], dg);
         set_lanes<row_lane_eq(L::YL)>(M[L::YS][c], gp[c].w);
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
       constexpr int c = decltype(c_)::value;
       double dg;       // (weighted: every lane offers its own row's entry / row c's entry by a broadcast read, the mask picks the owner's)
       if constexpr (kDgInLds) dg = weighted ? s_dg[g][c] : ((c == MT) ? args.diag_i : args.diag_nn);
-      else dg = weighted ? own_dg[s] : ((c == MT) ? args.diag_i : args.diag_nn);
+      else dg = weighted ? own_dg_of(s) : ((c == MT) ? args.diag_i : args.diag_nn);
       if constexpr (c == 16 * s + 15 || c == MT) M[s][c] = dg;     // column never evaluated: plain init
       else set_lanes<row_lane_eq(lane_of_row(c))>(M[s][c], dg);
     });
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
         const int r = 16 * s + ((s & 1) ? 15 - l : l);
         abr[s] = gab[r]; ab_off[s] = r * (int)sizeof(double2);
         // variance parameter: dD = D - nug_i - sum_r nug_r A_r^2, (dB y)_i = -sum_r nug_r b_r A_r (uniform nugget 1 without weights)
-        const double nr = weighted ? own_dg[s] - args.var : 1.0;      // (MODE_GRAD: !kDgInLds)
+        const double nr = weighted ? own_dg_of(s) - args.var : 1.0;      // (MODE_GRAD: !kDgInLds)
         if (r < MT) { sAA = __builtin_fma(nr * abr[s].x, abr[s].x, sAA); sbA = __builtin_fma(nr * abr[s].y, abr[s].x, sbA); }
       });
       double accD = 0.0, accU = 0.0;
@@ -625,7 +636,9 @@ __global__ __launch_bounds__(256, (MT > 30 && MT <= 40 && MODE != MODE_NLL) ? 2 
       }
       const double up = uv * Dinv;                       // u' = D^-1 B y  (re_model_template.h:1999)
       // variance (ipar 0): dD = D - nugget - sum A^2 (Gaussian: nugget = 1), (dB y)_i = -sum b_r A_r
-      const double dD_var = Dv - (weighted ? args.nug[i] : args.nugget) - sAA;
+      double nug_i = args.nugget;
+      if (WT && weighted) nug_i = args.nug[i];
+      const double dD_var = Dv - nug_i - sAA;
       const double uk_var = -sbA;
       const double dD_rng = 2.0 * accD;
       const double uk_rng = accU;
@@ -740,9 +753,9 @@ __device__ __forceinline__ void vecchia_finish(const VecchiaKernelArgs& args, in
 // worker runs start to end on "its" CU and the slowest CU sets the time (measured at n = 1e6, m = 30: 0.93 ms); a few rounds let the
 // dispatcher balance (2 rounds 0.893 ms, 4 rounds 0.885 ms, 8 rounds 0.874 ms; profiles/r03_a_*) while the table set-up, the argument
 // loads and the launch of a workgroup are still paid once per ~8 groups.  The occupancy and the CU count are asked once per instantiation and device.
-template <int MT, int COV, bool D3>
+template <int MT, int COV, bool D3, bool WT>
 static int persistent_grid(const VecchiaKernelArgs& args) {
-  auto kern = vecchia_point_kernel<MT, COV, D3, GPB_INSTANTIATE_MODE>;
+  auto kern = vecchia_point_kernel<MT, COV, D3, GPB_INSTANTIATE_MODE, WT>;
   static int cached_dev = -1, per_dev = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return args.ngroups;
@@ -764,7 +777,10 @@ template <int MT, bool D3>
 static hipError_t launch_cov(int cov, const VecchiaKernelArgs& args, int nblocks, hipStream_t st) {
   (void)nblocks;
   switch (cov) {
-#define GPB_LAUNCH_COV(C) hipLaunchKernelGGL((vecchia_point_kernel<MT, C, D3, GPB_INSTANTIATE_MODE>), dim3(persistent_grid<MT, C, D3>(args) + 1), dim3(256), 0, st, args); break
+#define GPB_LAUNCH_COV(C) \
+  if (args.nug || kRuntimeWeightedInstance<MT, GPB_INSTANTIATE_MODE>()) hipLaunchKernelGGL((vecchia_point_kernel<MT, C, D3, GPB_INSTANTIATE_MODE, true>), dim3(persistent_grid<MT, C, D3, true>(args) + 1), dim3(256), 0, st, args); \
+  else hipLaunchKernelGGL((vecchia_point_kernel<MT, C, D3, GPB_INSTANTIATE_MODE, false>), dim3(persistent_grid<MT, C, D3, false>(args) + 1), dim3(256), 0, st, args); \
+  break
     case kMatern05: GPB_LAUNCH_COV(kMatern05);
     case kMatern15: GPB_LAUNCH_COV(kMatern15);
     case kMatern25: GPB_LAUNCH_COV(kMatern25);
