@@ -240,6 +240,27 @@ static int comm_allreduce(GpbComm& c, void* buf, size_t count, GpbType type, Gpb
   return 0;
 }
 
+// reduce-scatter(sum, int64): rank r receives the sum over the ranks of send[r * count .. (r + 1) * count) in recv (count values); on `st`
+static int comm_reducescatter_i64(GpbComm& c, const long long* send, long long* recv, size_t count, hipStream_t st) {
+  if (!c.active()) return fail("no communicator on this handle");
+  if (c.nccl) {
+    NCCL_OK(ncclReduceScatter(send, recv, count, ncclInt64, ncclSum, c.nccl, st));
+    return 0;
+  }
+  gpb_hip_local_group* g = c.lg;
+  HIP_OK(hipStreamSynchronize(st));                           // this rank's contribution is complete
+  { std::lock_guard<std::mutex> lk(g->mu); g->bufs[c.rank] = send; }
+  if (!g->barrier()) return fail("in-process group: a peer rank did not arrive at the reduce-scatter");
+  LocalBufs b;
+  { std::lock_guard<std::mutex> lk(g->mu); for (int r = 0; r < g->world; ++r) b.p[r] = static_cast<const long long*>(g->bufs[r]) + (size_t)c.rank * count; }
+  const dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 4096))), block(256);
+  hipLaunchKernelGGL((local_allreduce_kernel<long long, GPB_OP_SUM>), grid, block, 0, st, b, g->world, recv, count);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(st));                           // every peer's buffer has been read by this rank ...
+  if (!g->barrier()) return fail("in-process group: a peer rank did not finish the reduce-scatter");   // ... and this rank's by every peer
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Node-local MAILBOX for the 3 / 7 sums of a sharded likelihood evaluation (round 4).  ncclAllReduce of 24 / 56 bytes
 // costs ~24 us with ONE rank in the loop (launch of the collective kernel + the publish kernel behind it) -- the largest term outside the shard
@@ -396,6 +417,11 @@ struct gpb_hip_hist {
   gpb::CatCfg cat;
   unsigned* d_cat_bits = nullptr;                          // [F][8]: gpb_hip_hist_find_best_split
   unsigned* d_cat_bits2 = nullptr; unsigned* h_cat_bits2 = nullptr;     // [2][F][8]: the tree grower's two candidate sets (device, pinned host)
+  // feature-block exchange of the data-parallel tree grower (round 5): contiguous blocks of features, one per rank; ONE reduce-scatter of the integer totals per
+  // leaf, every rank converts and searches its own block, the ranks' best candidates are exchanged (gpb_tree.inc)
+  int block_exchange = -1;                                 // gpb_hip_hist_set_feature_block_exchange: 1 on, 0 off (every rank all-reduces and searches everything), -1 by message size
+  std::vector<int> blk_f0, blk_bin0, blk_bins; int blk_max = 0;   // per rank: first feature (world + 1 entries), first bin, number of bins; the common padded length
+  long long* d_rs_send = nullptr; long long* d_rs_recv = nullptr; double* d_xchg = nullptr; double* h_xchg = nullptr;
   std::vector<int> tree_node_is_cat; std::vector<unsigned> tree_node_cat_bits;   // last tree: per node, is the split categorical / the 8 words of its set of bins
 };
 
@@ -2345,7 +2371,8 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   if (h->h_counts) (void)hipHostFree(h->h_counts); dev_free(h->d_ptags); dev_free(h->d_split2); dev_free(h->d_split2_i); dev_free(h->d_used2);
   if (h->h_split2) (void)hipHostFree(h->h_split2);
   if (h->h_split2_i) (void)hipHostFree(h->h_split2_i);
-  dev_free(h->d_is_cat); dev_free(h->d_cat_bits); dev_free(h->d_cat_bits2);
+  dev_free(h->d_is_cat); dev_free(h->d_cat_bits); dev_free(h->d_cat_bits2); dev_free(h->d_rs_send); dev_free(h->d_rs_recv); dev_free(h->d_xchg);
+  if (h->h_xchg) (void)hipHostFree(h->h_xchg);
   if (h->h_cat_bits2) (void)hipHostFree(h->h_cat_bits2);
   h->comm.release(); dev_free(h->d_limbs);
   delete h;
@@ -2410,6 +2437,54 @@ static int hist_finish_sharded(gpb_hip_hist_t* h, double const_hess, double* d_h
   if (comm_allreduce(h->comm, h->d_limbs, (h->has_hess ? 5 : 3) * (size_t)h->total_bins, GPB_T_I64, GPB_OP_SUM, h->stream)) return -1;
   HIP_OK(gpb::launch_hist_convert(h->d_limbs, h->total_bins, h->d_absmax, h->d_absmax + 1, const_hess, h->has_hess ? 1 : 0, d_hist_out, d_cnt_out, h->stream));
   return 0;
+}
+
+// Feature-block form (the tree grower's smaller-child builds): d_limbs -> blocks -> ONE reduce-scatter -> this rank's block of the histogram.  The blocks are
+// contiguous runs of features with about total_bins / world bins each (whole features: a feature's bins are searched by one rank).
+static int hist_blocks_setup(gpb_hip_hist_t* h) {
+  const int W = h->comm.world, F = h->F;
+  if ((int)h->blk_f0.size() == W + 1) return 0;
+  if (W > 16) return fail("feature-block exchange: %d ranks (at most 16)", W);
+  h->blk_f0.assign(W + 1, F); h->blk_bin0.assign(W, 0); h->blk_bins.assign(W, 0);
+  int f = 0;
+  for (int r = 0; r < W; ++r) {
+    h->blk_f0[r] = f;
+    if (r == W - 1) { f = F; break; }
+    const long long target = (long long)h->total_bins * (r + 1) / W;          // whole features whose bins end within the rank's share (a block may be empty)
+    while (f < F && h->h_bin_offsets[f + 1] <= target) ++f;
+  }
+  h->blk_f0[W] = F;
+  h->blk_max = 1;
+  for (int r = 0; r < W; ++r) {
+    h->blk_bin0[r] = h->h_bin_offsets[h->blk_f0[r]];
+    h->blk_bins[r] = h->h_bin_offsets[h->blk_f0[r + 1]] - h->blk_bin0[r];
+    h->blk_max = std::max(h->blk_max, h->blk_bins[r]);
+  }
+  dev_free(h->d_rs_send); dev_free(h->d_rs_recv);
+  HIP_OK(hipMalloc(&h->d_rs_send, sizeof(long long) * 5 * (size_t)h->blk_max * W));
+  HIP_OK(hipMalloc(&h->d_rs_recv, sizeof(long long) * 5 * (size_t)h->blk_max));
+  if (!h->d_xchg) { HIP_OK(hipMalloc(&h->d_xchg, sizeof(double) * 2 * 16 * 24)); HIP_OK(hipHostMalloc(&h->h_xchg, sizeof(double) * 2 * 16 * 24)); }
+  return 0;
+}
+static int hist_finish_sharded_block(gpb_hip_hist_t* h, double const_hess, double* d_hist_out) {
+  const int nw = h->has_hess ? 5 : 3, W = h->comm.world, r = h->comm.rank;
+  HIP_OK(gpb::launch_hist_limbs_pack(h->d_limbs, h->total_bins, nw, h->blk_bin0.data(), h->blk_bins.data(), W, h->blk_max, h->d_rs_send, h->stream));
+  if (comm_reducescatter_i64(h->comm, h->d_rs_send, h->d_rs_recv, (size_t)nw * h->blk_max, h->stream)) return -1;
+  HIP_OK(gpb::launch_hist_convert_block(h->d_rs_recv, h->blk_max, h->blk_bins[r], h->blk_bin0[r], h->d_absmax, h->d_absmax + 1, const_hess, h->has_hess ? 1 : 0, d_hist_out,
+                                        h->stream));
+  return 0;
+}
+
+/* Data-parallel tree grower: on = reduce-scatter of the integer totals by feature block + exchange of the ranks' best splits (DataParallelTreeLearner,
+ * data_parallel_tree_learner.cpp:131, :155-173, :244); off = every rank all-reduces every histogram and searches every feature; < 0 (the default) = by the size
+ * of a histogram message: feature blocks from 2 MB on.  Below that a message is latency-bound on any fabric and the feature-block form pays one more collective and
+ * one more synchronisation per split: with 2 / 4 / 8 ranks time-sharing one MI355X, config 3's 306 KB histograms, 5.8 / 7.7 / 13.5 ms per tree against
+ * 3.5 / 5.4 / 10.4 ms for the all-reduce (profiles/r05_p_tree_multirank.log).  The trees are identical either way (tests/test_multirank_gpu.py). */
+int gpb_hip_hist_set_feature_block_exchange(gpb_hip_hist_t* h, int on) {
+  API_BEGIN();
+  if (!h) return fail("null argument");
+  h->block_exchange = on < 0 ? -1 : (on != 0 ? 1 : 0);
+  API_END();
 }
 
 int gpb_hip_hist_build(gpb_hip_hist_t* h, const int32_t* data_indices, int32_t num_data, double const_hess,
@@ -2502,7 +2577,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
 // Tree grower: histogram of the SMALLER child of the split whose left counts the partition kernels have left in h->d_counts -- enqueued
 // without a host round trip; ub_rows = upper bound of the child's rows on this rank (sizes the launch), result in d_target.
 static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_begin, int seg_cnt, int seg_gcnt, int min_data_in_leaf, int ub_rows,
-                              double const_hess, double* d_target, int* nchunks_without_reduce = nullptr) {
+                              double const_hess, double* d_target, int* nchunks_without_reduce = nullptr, bool block_form = false) {
   const int groups = h->fpad / GPB_HIST_FG;
   if (h->num_cu <= 0) { HIP_OK(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, h->device)); if (h->num_cu <= 0) h->num_cu = 256; }
   const int chunk_mult = h->has_hess ? 2 : 4;
@@ -2536,7 +2611,10 @@ static int hist_build_planned(gpb_hip_hist_t* h, const int* rows_base, int seg_b
   // split; with many chunks the dedicated reduction (16 slices per word) is faster than the search workgroups' serial sums (measured: 36 us for 49 chunks)
   if (nchunks_without_reduce && !h->comm.active() && nchunks <= 8) { *nchunks_without_reduce = nchunks; return 0; }
   HIP_OK(gpb::launch_hist_reduce(r, h->stream));
-  if (h->comm.active() && hist_finish_sharded(h, const_hess, d_target, nullptr)) return -1;
+  if (h->comm.active()) {
+    if (block_form) { if (hist_finish_sharded_block(h, const_hess, d_target)) return -1; }
+    else if (hist_finish_sharded(h, const_hess, d_target, nullptr)) return -1;
+  }
   return 0;
 }
 
@@ -2551,6 +2629,7 @@ int gpb_hip_hist_comm_init(gpb_hip_hist_t* h, const unsigned char* id128, int ra
   if (world < 1 || rank < 0 || rank >= world) return fail("gpb_hip_hist_comm_init: rank %d / world %d", rank, world);
   HIP_OK(hipSetDevice(h->device));
   if (comm_init_rccl(h->comm, id128, rank, world)) return -1;
+  h->blk_f0.clear();
   h->has_grad = false;          // the scale of the fixed-point sums must be agreed by all ranks: set the gradients again
   API_END();
 }
@@ -2560,6 +2639,7 @@ int gpb_hip_hist_comm_init_local(gpb_hip_hist_t* h, gpb_hip_local_group_t* g, in
   if (!h) return fail("null argument");
   HIP_OK(hipSetDevice(h->device));
   if (comm_init_local(h->comm, g, rank)) return -1;
+  h->blk_f0.clear();
   h->has_grad = false;
   API_END();
 }

@@ -53,6 +53,7 @@ struct ChildrenSearchArgs {
   const long long* part_grad = nullptr; const long long* part_hess = nullptr; const uint32_t* part_cnt = nullptr;
   const unsigned long long* grad_max_bits = nullptr; const unsigned long long* hess_max_bits = nullptr;
   int fpad = 0, nchunks = 0, has_hess = 0; double const_hess = 1.0;
+  int own_f0 = 0, own_f1 = 2147483647;   // feature-block exchange of the data-parallel grower: the features whose bins this rank holds (default: all)
   const signed char* is_cat = nullptr; CatCfg cat; unsigned* out_cat = nullptr;   // categorical features: flags [F], configuration, [2][F][8] bitsets over bins
   unsigned* ticket = nullptr;   // device word, zero between launches: workgroups that have finished
   int* host_seq = nullptr;      // pinned host word: receives seq from the last workgroup (nullptr: the host synchronises the stream instead)
@@ -75,6 +76,10 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st);
 hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st);
 hipError_t launch_hist_convert(const long long* limbs, int total_bins, const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
                                double const_hess, int has_hess, double* hist_out, unsigned long long* cnt_out, hipStream_t st);
+hipError_t launch_hist_limbs_pack(const long long* limbs, int total_bins, int nwords, const int* blk_bin0, const int* blk_bins, int world, int maxblk, long long* send,
+                                  hipStream_t st);
+hipError_t launch_hist_convert_block(const long long* recv, int maxblk, int nbins, int bin0, const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
+                                     double const_hess, int has_hess, double* hist_out, hipStream_t st);
 hipError_t launch_hist_root_sums(const long long* limbs, int total_bins, const int* bin_offsets, const unsigned long long* grad_max_bits,
                                  const unsigned long long* hess_max_bits, double const_hess, int has_hess, double* out3, hipStream_t st);
 hipError_t launch_hist_absmax(const double* v, int n, unsigned long long* out_bits, hipStream_t st);

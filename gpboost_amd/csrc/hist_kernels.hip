@@ -410,6 +410,49 @@ __global__ __launch_bounds__(256) void hist_convert_kernel(const long long* __re
   if (has_hess) hist_convert_entry<true>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * (size_t)o, cnt_out ? cnt_out + o : nullptr);
   else hist_convert_entry<false>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * (size_t)o, cnt_out ? cnt_out + o : nullptr);
 }
+// Feature-block exchange of the data-parallel tree grower (round 5; DataParallelTreeLearner's reduce-scatter by feature block + best-split sync,
+// data_parallel_tree_learner.cpp:131, :155-173, :244, with the integer totals on the wire): hist_limbs_pack_kernel lays this rank's totals out block after
+// block -- send[r][w][i] = limbs[w][blk_bin0[r] + i] for i < blk_bins[r], zero up to the common block length -- so that ONE reduce-scatter leaves on rank r
+// the job-wide totals of ITS features' bins; hist_convert_block_kernel converts them (the same expression, the same bits as the all-reduce form) into the
+// entries blk_bin0[r] .. of the flat histogram.
+struct HistBlocks { int bin0[16]; int bins[16]; };
+__global__ __launch_bounds__(256) void hist_limbs_pack_kernel(const long long* __restrict__ limbs, int total_bins, int nwords, HistBlocks b, int world, int maxblk,
+                                                             long long* __restrict__ send) {
+  const size_t per_rank = (size_t)nwords * maxblk, total = per_rank * world;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const int r = (int)(o / per_rank), w = (int)((o % per_rank) / maxblk), i = (int)(o % maxblk);
+    send[o] = i < b.bins[r] ? limbs[(size_t)w * total_bins + b.bin0[r] + i] : 0LL;
+  }
+}
+__global__ __launch_bounds__(256) void hist_convert_block_kernel(const long long* __restrict__ recv, int maxblk, int nbins, int bin0, const unsigned long long* grad_max_bits,
+                                                                const unsigned long long* hess_max_bits, double const_hess, int has_hess, double* __restrict__ hist_out) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= nbins) return;
+  const long long* L = recv + o;
+  const size_t S = (size_t)maxblk;
+  Limbs g, h;
+  g.hi = L[0]; g.lo = (unsigned long long)L[S];
+  if (has_hess) { h.hi = L[3 * S]; h.lo = (unsigned long long)L[4 * S]; }
+  const unsigned long long c = (unsigned long long)L[2 * S];
+  if (has_hess) hist_convert_entry<true>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * ((size_t)bin0 + o), nullptr);
+  else hist_convert_entry<false>(g, h, c, grad_max_bits, hess_max_bits, const_hess, hist_out + 2 * ((size_t)bin0 + o), nullptr);
+}
+hipError_t launch_hist_limbs_pack(const long long* limbs, int total_bins, int nwords, const int* blk_bin0, const int* blk_bins, int world, int maxblk, long long* send,
+                                  hipStream_t st) {
+  HistBlocks b;
+  for (int r = 0; r < 16; ++r) { b.bin0[r] = r < world ? blk_bin0[r] : 0; b.bins[r] = r < world ? blk_bins[r] : 0; }
+  const size_t total = (size_t)nwords * maxblk * world;
+  hipLaunchKernelGGL(hist_limbs_pack_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 1024))), dim3(256), 0, st, limbs, total_bins, nwords, b,
+                     world, maxblk, send);
+  return hipGetLastError();
+}
+hipError_t launch_hist_convert_block(const long long* recv, int maxblk, int nbins, int bin0, const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
+                                     double const_hess, int has_hess, double* hist_out, hipStream_t st) {
+  if (nbins <= 0) return hipSuccess;
+  hipLaunchKernelGGL(hist_convert_block_kernel, dim3((nbins + 255) / 256), dim3(256), 0, st, recv, maxblk, nbins, bin0, grad_max_bits, hess_max_bits, const_hess, has_hess, hist_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_hist_convert(const long long* limbs, int total_bins, const unsigned long long* grad_max_bits, const unsigned long long* hess_max_bits,
                                double const_hess, int has_hess, double* hist_out, unsigned long long* cnt_out, hipStream_t st) {
   hipLaunchKernelGGL(hist_convert_kernel, dim3((total_bins + 255) / 256), dim3(256), 0, st, limbs, total_bins, grad_max_bits, hess_max_bits, const_hess,
@@ -982,6 +1025,7 @@ __device__ __forceinline__ void children_search_body(const ChildrenSearchArgs& a
 #pragma clang fp contract(off)
   const int f = blockIdx.x, child = blockIdx.y, tid = threadIdx.x;
   if (f >= a.num_features) return;
+  if (f < a.own_f0 || f >= a.own_f1) return;        // feature-block exchange: another rank owns this feature's bins (and searches it)
   const ChildSegment cs = child_segment(a.counts, 0, 0, a.gcnt, a.min_data_in_leaf);
   if (cs.skip) return;
   const double sg_s = cs.smaller_is_left ? a.left_sum_gradient : a.right_sum_gradient, sh_s = cs.smaller_is_left ? a.left_sum_hessian : a.right_sum_hessian;

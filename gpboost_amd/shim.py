@@ -510,6 +510,10 @@ class HistBuilder(object):
         _shim_call(_lib().gpb_hip_hist_set_categorical(self.h, _p(m, C.c_int8), C.c_int(int(max_cat_to_onehot)), C.c_int(int(max_cat_threshold)),
                                                        C.c_double(cat_smooth), C.c_double(cat_l2), C.c_int(int(min_data_per_group))))
 
+    def set_feature_block_exchange(self, on=True):
+        """Data-parallel tree grower: reduce-scatter by feature block + exchange of the ranks' best splits (default) or all-reduce of every histogram."""
+        _shim_call(_lib().gpb_hip_hist_set_feature_block_exchange(self.h, C.c_int(-1 if on is None else int(bool(on)))))
+
     def set_regularisation(self, lambda_l1=0.0, max_delta_step=0.0, path_smooth=0.0, parent_output=0.0):
         """lambda_l1 / max_delta_step / path_smooth of the split search (they stay set for find_best_split and grow_tree); parent_output: the
         leaf's own output, for the following find_best_split calls (path smoothing; grow_tree tracks it itself)."""

@@ -587,6 +587,14 @@ GPB_HIP_EXPORT int gpb_hip_hist_grow_tree(gpb_hip_hist_t* h, int32_t num_leaves,
  * hessians} -- what Tree::Split (include/LightGBM/tree.h:63-66) takes next to the arrays above (integration/hip_tree_learner.h builds the
  * reference's own Tree object from them).  out6: 6 x num_nodes doubles. */
 GPB_HIP_EXPORT int gpb_hip_hist_last_tree_node_info(gpb_hip_hist_t* h, int32_t num_nodes, double* out6);
+/* Data-parallel form of gpb_hip_hist_grow_tree, the exchange below the root (round 5).  on != 0 (the default): DataParallelTreeLearner's scheme
+ * (src/LightGBM/treelearner/data_parallel_tree_learner.cpp:131, :155-173 reduce-scatter of the smaller leaf's histogram by feature block, :244 sync of the best
+ * split) with the integer totals on the wire -- ONE reduce-scatter of 3 (constant hessian) or 5 int64 words per bin, every rank converts / fixes / subtracts /
+ * searches the features whose bins it received, then one all-reduce of world x 2 zero-padded candidate records (24 doubles each) gives every rank the job's best
+ * split of the two children.  on == 0: every rank all-reduces the whole histogram and searches every feature.  on < 0 (the default): feature blocks when a
+ * histogram message is at least 2 MB, the all-reduce below (latency-bound messages: one collective and one synchronisation fewer per split).  Identical trees
+ * either way, for every rank layout. */
+GPB_HIP_EXPORT int gpb_hip_hist_set_feature_block_exchange(gpb_hip_hist_t* h, int on);
 GPB_HIP_EXPORT int gpb_hip_hist_get_slot(gpb_hip_hist_t* h, int32_t slot, double* hist_out);
 
 /* Split search on a device-resident (fixed) leaf histogram -- SURVEY.md 8f rank 2: FeatureHistogram::FindBestThreshold for every

@@ -71,14 +71,20 @@ def test_sharded_histograms_equal_the_one_handle_histogram_bit_for_bit(lib_built
 
 
 @pytest.mark.parametrize("name,hi,world,how", [("plain_l31", 0, 2, "blocks"), ("plain_l31", 1, 3, "random"), ("nan_l20", 0, 4, "uneven"),
-                                               ("zero_missing_l12", 1, 2, "random"), ("plain_all_reg", 0, 3, "blocks")])
-def test_sharded_tree_equals_the_one_rank_tree_bit_for_bit(lib_built, name, hi, world, how):
+                                               ("zero_missing_l12", 1, 2, "random"), ("plain_all_reg", 0, 3, "blocks"),
+                                               # round 5: categorical features (their sets of bins travel in the exchange), more ranks than features (empty blocks)
+                                               ("cat_l15", 0, 3, "random"), ("cat_defaults", 1, 2, "blocks"), ("efb_l15", 0, 4, "uneven"), ("plain_l15_reg", 1, 8, "random")])
+@pytest.mark.parametrize("exchange", ["feature_blocks", "allreduce"])
+def test_sharded_tree_equals_the_one_rank_tree_bit_for_bit(lib_built, name, hi, world, how, exchange):
     """gpb_hip_hist_grow_tree in its data-parallel form on the reference's tree fixtures' data: W ranks (rows dealt W ways) return, on
     every rank, the tree a ONE-rank group returns -- every field bit-identical, leaf values included -- and that tree has the structure,
-    thresholds and counts of the reference's own SerialTreeLearner tree (tests/golden/tree_ref.npz)."""
+    thresholds and counts of the reference's own SerialTreeLearner tree (tests/golden/tree_ref.npz).  Both exchanges of the data-parallel learner:
+    'feature_blocks' (round 5, the default: reduce-scatter of the integer totals by feature block, every rank searches its own features, the ranks' best
+    splits are exchanged -- data_parallel_tree_learner.cpp:155-173, :244) and 'allreduce' (every rank all-reduces every histogram and searches everything)."""
     from gpboost_amd import shim
     from tests import cases
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref.npz"))
+    r5 = name in cases.TREE_CASES_R5
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref_r5.npz" if r5 else "tree_ref.npz"))
     data, params, L, cfg = cases.tree_params(name)
     X, grad, hess, leaf = cases.make_split_data(data)
     n = X.shape[0]
@@ -97,7 +103,10 @@ def test_sharded_tree_equals_the_one_rank_tree_bit_for_bit(lib_built, name, hi, 
             hb.pool_resize(L + 1)
             hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
             hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+            if r5 and g[k + "layout"][:, 3].any():
+                hb.set_categorical(g[k + "layout"][:, 3], *cases.tree_cat_cfg(name))
             hb.comm_init_local(grp, r)
+            hb.set_feature_block_exchange(exchange == "feature_blocks")
             hb.set_gradients(grad[rows], None if hs is None else hs[rows])
             if len(cfg) > 4:
                 hb.set_regularisation(cfg[4], cfg[5], cfg[6])
@@ -112,7 +121,7 @@ def test_sharded_tree_equals_the_one_rank_tree_bit_for_bit(lib_built, name, hi, 
     parts = _deal(n, world, how, rng)
     tw = grow(world, parts)
     keys = ("split_feature_inner", "threshold_in_bin", "default_left", "left_child", "right_child", "internal_count", "leaf_count", "split_gain",
-            "leaf_value")
+            "leaf_value", "node_is_cat", "node_cat_bits")
     for r, t in enumerate(tw):
         assert t["num_leaves"] == t1["num_leaves"]
         for key in keys:
