@@ -74,6 +74,7 @@ struct REModelHip {
   gpb_hip_exact_t* eh = nullptr;   // gp_approx == "none": dense path, data order (no Vecchia ordering)
   // gp_approx == "full_scale_vecchia" ("vif"): predictive process on num_ind_points inducing points + Vecchia approximation of the residual process
   bool has_weights = false;        // sample weights (Gaussian Vecchia model): observation-specific nuggets live in the device handles
+  std::vector<double> lik_weights; bool lik_weights_pushed = false;   // sample weights of a non-Gaussian model (data order): factors of the per-datum likelihood terms (round 5)
   std::vector<double> nug_v;       // ... and, Vecchia order, here: 1 / w_i (the 'latent_*' prediction types need R^-1 = diag(w) on the host)
   bool vif = false;
   int num_ind_points = 0;
@@ -185,30 +186,49 @@ int laplace_push_aux(REModelHip* mdl) {
 }
 // Likelihood::FindInitialAuxPars (likelihoods.h:1851-1947) for gamma (approximate MLE of the shape ignoring the effects) and negative_binomial
 // (method of moments); y, fixed_effects in data order
-double initial_aux_par(const std::string& lik, int n, const double* y, const double* fe) {
+// (wts: sample weights in the order of y, or NULL -- weighted moments with sum of weights in place of n, likelihoods.h:1856-1910)
+double initial_aux_par(const std::string& lik, int n, const double* y, const double* fe, const double* wts = nullptr) {
   if (lik == "gamma") {
-    double log_avg = 0., avg_log = 0.;
+    double log_avg = 0., avg_log = 0., sw = 0.;
     for (int i = 0; i < n; ++i) {
-      if (fe) { log_avg += y[i] / std::exp(fe[i]); avg_log += std::log(y[i]) - fe[i]; }
-      else { log_avg += y[i]; avg_log += std::log(y[i]); }
+      const double w = wts ? wts[i] : 1.0;
+      if (fe) { log_avg += w * y[i] / std::exp(fe[i]); avg_log += w * (std::log(y[i]) - fe[i]); }
+      else { log_avg += w * y[i]; avg_log += w * std::log(y[i]); }
+      sw += w;
     }
-    log_avg = std::log(log_avg / n); avg_log /= n;
+    log_avg = std::log(log_avg / sw); avg_log /= sw;
     const double s = std::max(log_avg - avg_log, 1e-8);
     return (3. - s + std::sqrt((s - 3.) * (s - 3.) + 24. * s)) / (12. * s);
   }
   if (lik == "negative_binomial") {
-    double avg = 0., sum_sq = 0.;
-    for (int i = 0; i < n; ++i) { const double v = fe ? y[i] / std::exp(fe[i]) : y[i]; avg += v; sum_sq += v * v; }
-    avg /= n;
+    double avg = 0., sum_sq = 0., sw = 0.;
+    for (int i = 0; i < n; ++i) { const double w = wts ? wts[i] : 1.0; const double v = fe ? y[i] / std::exp(fe[i]) : y[i]; avg += w * v; sum_sq += w * v * v; sw += w; }
+    avg /= sw;
     const double avg_sq = avg * avg;
-    const double sample_var = std::max((sum_sq - n * avg_sq) / (n - 1), 1e-6);
+    const double sample_var = std::max((sum_sq - sw * avg_sq) / (sw - 1), 1e-6);
     return sample_var <= avg ? 100 * avg_sq : avg_sq / (sample_var - avg);
   }
   return 1.;
 }
 void find_initial_aux_pars(REModelHip* mdl, const double* y, const double* fe) {
-  mdl->aux_pars[0] = initial_aux_par(mdl->likelihood, mdl->n, y, fe);
+  // (sic) the reference hands FindInitialAuxPars the caller's y in DATA order (re_model_template.h:1343) while Likelihood::weights_ is in the order of the
+  // cluster's data, i.e. Vecchia order (:425-431): datum i is paired with the weight of datum perm[i].  Reproduced, because the start value decides where a
+  // flat likelihood's fit ends (verified against the reference: with this pairing its default fit is reproduced, with the "right" one it is not).
+  std::vector<double> wv;
+  if (!mdl->lik_weights.empty()) { wv.resize(mdl->n); for (int i = 0; i < mdl->n; ++i) wv[i] = mdl->lik_weights[mdl->perm[i]]; }
+  mdl->aux_pars[0] = initial_aux_par(mdl->likelihood, mdl->n, y, fe, wv.empty() ? nullptr : wv.data());
   mdl->aux_set = true;
+}
+
+// sample weights of a non-Gaussian model -> the device state, in the order it keeps the data (Vecchia order, grouped by random effect for repeated locations)
+int laplace_push_weights(REModelHip* mdl) {
+  if (mdl->lik_weights.empty() || mdl->lik_weights_pushed) return 0;
+  std::vector<double> w(mdl->n);
+  if (mdl->n_re > 0) for (int g = 0; g < mdl->n; ++g) w[g] = mdl->lik_weights[mdl->perm[mdl->dorder[g]]];
+  else for (int k = 0; k < mdl->n; ++k) w[k] = mdl->lik_weights[mdl->perm[k]];
+  if (gpb_hip_vecchia_laplace_set_weights(mdl->vh, w.data())) return shim_error();
+  mdl->lik_weights_pushed = true;
+  return 0;
 }
 
 // location parameter = mode + fixed effects (likelihoods.h:3861-3870), Vecchia order; NULL clears the offset
@@ -240,7 +260,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
       for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
       if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, grouped.data())) return shim_error();
     } else if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, mdl->resp_real.data())) return shim_error();
-    if (laplace_push_aux(mdl)) return -1;
+    if (laplace_push_aux(mdl) || laplace_push_weights(mdl)) return -1;
     mdl->y_set = true;
     return laplace_upload_fixed_effects(mdl, fixed_effects);
   }
@@ -264,7 +284,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
     for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->labels[mdl->dorder[g]];
     if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, grouped.data())) return shim_error();
   } else if (gpb_hip_vecchia_laplace_set_labels(mdl->vh, mdl->labels.data())) return shim_error();
-  if (laplace_push_aux(mdl)) return -1;
+  if (laplace_push_aux(mdl) || laplace_push_weights(mdl)) return -1;
   mdl->y_set = true;
   return laplace_upload_fixed_effects(mdl, fixed_effects);
 }
@@ -1133,18 +1153,25 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   }
   if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
   if (has_weights) {       // re_model_template.h:403-431
-    if (lik_name != "gaussian" || approx != "vecchia") return set_error("GPB_CreateREModel: sample weights with likelihood '%s' / gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
+    if (approx != "vecchia") return set_error("GPB_CreateREModel: sample weights with likelihood '%s' / gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
+    double sum_w = 0.;
     for (int i = 0; i < num_data; ++i) {
       if (weights[i] < 0.) return set_error(" Found negative values in 'weights' ");
-      if (weights[i] == 0.) return set_error("Found zero values in 'weights'. For likelihood = 'gaussian', all weights must be strictly positive ");
+      if (lik_name == "gaussian" && weights[i] == 0.) return set_error("Found zero values in 'weights'. For likelihood = 'gaussian', all weights must be strictly positive ");
+      // (non-Gaussian: the reference admits zeros and then estimates diag((Sigma^-1 + W)^-1) stochastically where d information / d loc vanishes,
+      //  likelihoods.h:6754-6768; this library keeps the closed form and asks for strictly positive weights)
+      if (weights[i] == 0.) return set_error("GPB_CreateREModel: a sample weight that is exactly zero (datum %d) with likelihood '%s' %s -- drop the datum instead", i, lik.c_str(), scope);
       if (!std::isfinite(weights[i])) return set_error("NaN or Inf in 'weights' ");
+      sum_w += weights[i];
     }
+    if (sum_w == 0.) return set_error("The total sum of the 'weights' is zero ");
   }
   if (num_data < 2) return set_error("GPB_CreateREModel: num_data = %d", num_data);
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
   mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); mdl->num_neighbors = num_neighbors;
+  if (has_weights && lik_name != "gaussian") mdl->lik_weights.assign(weights, weights + num_data);     // factors of the per-datum likelihood terms (likelihoods.h:666-668)
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
   if (approx == "none") {   // exact GP: dense Cholesky (re_model_template.h:8151, :9273-9287, :6491-6494); no ordering
@@ -1219,7 +1246,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     if (mdl->vhs.empty()) { mdl->coords0 = coords; mdl->n0 = n_pts; }
     mdl->vhs.push_back(vh);
     if (mdl->n_re > 0 && gpb_hip_vecchia_laplace_set_data_map(vh, mdl->re_ptr.data())) return shim_error();
-    if (has_weights) {     // nugget 1 / w_i of every observation, Vecchia order (GetGaussianNuggetDiagFromWeights, :6393-6417)
+    if (has_weights && lik_name == "gaussian") {     // nugget 1 / w_i of every observation, Vecchia order (GetGaussianNuggetDiagFromWeights, :6393-6417)
       std::vector<double> nug((size_t)nc);
       for (int k = 0; k < nc; ++k) nug[k] = 1. / weights[idx[k]];
       if (gpb_hip_vecchia_set_nugget_diag(vh, nug.data())) return shim_error();
@@ -2469,6 +2496,7 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
     if (mdl->optimizer_unsupported_alias || (mdl->optim.optimizer != "" && mdl->optim.optimizer != "lbfgs")) return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_cov '%s' with covariates %s", mdl->optim.optimizer.c_str(), lscope);
     if (mdl->optimizer_coef != "" && mdl->optimizer_coef != "lbfgs") return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_coef '%s' %s", mdl->optimizer_coef.c_str(), lscope);
     if (num_covariates > 256) return set_error("GPB_OptimLinRegrCoefCovPar: %d covariates %s", num_covariates, lscope);
+    if (!mdl->lik_weights.empty()) return set_error("GPB_OptimLinRegrCoefCovPar: sample weights together with covariates for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
     if (!y_data) return set_error("GPB_OptimLinRegrCoefCovPar: y_data is NULL");
     if (!mdl->init_coef.empty() && (int)mdl->init_coef.size() != num_covariates) return set_error("GPB_OptimLinRegrCoefCovPar: %d initial coefficients for %d covariates", (int)mdl->init_coef.size(), num_covariates);
     const int n = mdl->n, p = num_covariates;

@@ -72,6 +72,8 @@ template <int LINK>
 __device__ __forceinline__ double resp_at(const LikResp& r, int d) {
   if constexpr (LINK == 3) return r.yd[d]; else return (double)r.yi[d];
 }
+// sample weight of datum d (round 5; likelihoods.h:666-668 weights_): every per-datum term -- log-likelihood and its derivatives -- is multiplied by it
+__device__ __forceinline__ double wt_at(const LikResp& r, int d) { return r.w ? r.w[d] : 1.0; }
 template <int LINK>
 __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, double& grad, double& w) {
   if constexpr (LINK == 0) {
@@ -142,9 +144,11 @@ __global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const L
   double gr, w;
   if (dptr) {
     gr = 0.0; w = 0.0;
-    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, g1, w1); gr += g1; w += w1; }
-  } else
-  lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
+    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, g1, w1); const double wd = wt_at(y, d); gr += wd * g1; w += wd * w1; }
+  } else {
+    lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
+    if (y.w) { gr *= y.w[i]; w *= y.w[i]; }
+  }
   W[i] = w;
   if (rhs) rhs[i] = w * mode[i] + gr;
   const double v = 1.0 / D[i] + w;
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __res
   __shared__ double s[2048];
   double ll = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += lik_loglik<LINK>(resp_at<LINK>(y, d), fe ? x[i] + fe[d] : x[i], y.aux); }
-    else ll += lik_loglik<LINK>(resp_at<LINK>(y, i), fe ? x[i] + fe[i] : x[i], y.aux);
+    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += wt_at(y, d) * lik_loglik<LINK>(resp_at<LINK>(y, d), fe ? x[i] + fe[d] : x[i], y.aux); }
+    else ll += wt_at(y, i) * lik_loglik<LINK>(resp_at<LINK>(y, i), fe ? x[i] + fe[i] : x[i], y.aux);
     if (Bx) q = __builtin_fma(Bx[i] * (1.0 / D[i]), Bx[i], q);
   }
   block_reduce2(ll, q, s);
@@ -838,8 +842,8 @@ __global__ void lik_third_kernel(const double* __restrict__ mode, const LikResp 
                                  const int* __restrict__ dptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += lik_third<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux); dW3[i] = t3; }
-  else dW3[i] = lik_third<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux);
+  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += wt_at(y, d) * lik_third<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux); dW3[i] = t3; }
+  else dW3[i] = wt_at(y, i) * lik_third<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux);
 }
 
 // boosting gradient for non-Gaussian data, d(-mll) / dF = -d log p / d loc + 0.5 d logdet / d mode - W .* (Sigma^-1 + W)^-1 d_mll_d_mode
@@ -851,6 +855,7 @@ __global__ void lik_grad_F_kernel(const double* __restrict__ mode, const LikResp
   if (i >= n) return;
   double gr, w;
   lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);
+  if (y.w) { gr *= y.w[i]; w *= y.w[i]; }
   out[i] = -gr + 0.5 * dld[i] - w * sv[i];
 }
 
@@ -872,7 +877,8 @@ __global__ void lik_grad_F_map_kernel(const double* __restrict__ mode, const Lik
     double gr, w;
     const double yd = resp_at<LINK>(y, d);
     lik_grad_info<LINK>(yd, loc, y.aux, gr, w);
-    out[d] = -gr + 0.5 * lik_third<LINK>(yd, loc, y.aux) * diag - w * svi;
+    const double wd = wt_at(y, d);
+    out[d] = -(wd * gr) + 0.5 * (wd * lik_third<LINK>(yd, loc, y.aux)) * diag - (wd * w) * svi;
   }
 }
 
@@ -895,19 +901,19 @@ __global__ __launch_bounds__(1024) void lik_aux_grad_kernel(const double* __rest
     const double diag = t3 == 0.0 ? 0.0 : dld[i] / t3;
     const double mi = mode[i], svi = sv[i];
     for (int d = d0; d < d1; ++d) {
-      const double x = fe ? mi + fe[d] : mi, yv = resp_at<LINK>(y, d);
+      const double x = fe ? mi + fe[d] : mi, yv = resp_at<LINK>(y, d), wd = wt_at(y, d);
       if constexpr (LINK == 3) {
         const double q = yv * exp(-x);
-        e += x + q;
-        const double s2 = r * (q - 1.0);
-        dsum = __builtin_fma(s2 + r, diag, dsum);
+        e += wd * (x + q);
+        const double s2 = wd * (r * (q - 1.0));
+        dsum = __builtin_fma(wd * (s2 + r), diag, dsum);       // (sic: the reference weights the first summand twice, likelihoods.h:14782-14783: w (w s2 + r))
         isum = __builtin_fma(s2, svi, isum);
       } else {
         const double mu = exp(x), mr = mu + r, yr = yv + r;
-        e += r * (-digamma_dev(yr) + log(mr) + yr / mr);
+        e += wd * (r * (-digamma_dev(yr) + log(mr) + yr / mr));
         const double q = mu * r / (mr * mr);
-        dsum = __builtin_fma(-q * (yv * (r - mu) - 2.0 * r * mu) / mr, diag, dsum);
-        isum = __builtin_fma(q * (yv - mu), svi, isum);
+        dsum = __builtin_fma(wd * (-q * (yv * (r - mu) - 2.0 * r * mu) / mr), diag, dsum);
+        isum = __builtin_fma(wd * (q * (yv - mu)), svi, isum);
       }
     }
   }

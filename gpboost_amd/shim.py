@@ -212,6 +212,11 @@ class VecchiaState(object):
         y = np.ascontiguousarray(y, dtype=np.float64)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_response_real(self.h, _p(y)))
 
+    def laplace_set_weights(self, w):
+        """Sample weights of the non-Gaussian likelihood, in the order of the labels (gpb_hip_vecchia_laplace_set_weights); None removes them."""
+        ww = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_weights(self.h, _p(ww)))
+
     def laplace_set_aux(self, aux):
         """gamma / negative_binomial: the shape parameter (gpb_hip_vecchia_laplace_set_aux_pars)."""
         a = np.ascontiguousarray(np.atleast_1d(aux), dtype=np.float64)

@@ -421,6 +421,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, cons
  *                      [(Sigma^-1 + W)^-1 d_mll_d_mode]_r(d)  (:6743-6808, CalcSecondDerivLogLikFirstDerivInformationAuxPar :14777-14799);
  *                      out4 = { the gradient, its three parts } */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y);
+/* Sample weights of a non-Gaussian likelihood (round 5; Likelihood::weights_, include/GPBoost/likelihoods.h:666-668): log-likelihood, its derivatives wrt the
+ * location parameter, the per-datum parts of the normalising constants (:10573-10600, :10750-10757, :11019-11030) and of the auxiliary-parameter gradients
+ * (:14185-14215, :14777-14799) are multiplied by w_d.  Same order as the labels; NULL removes them.  Finite and >= 0. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);

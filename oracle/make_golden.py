@@ -182,6 +182,48 @@ def laplace_aux_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_aux_ref.npz"), **res)
 
 
+def laplace_weights_fixture(out_dir):
+    """Round 5: non-Gaussian Vecchia-Laplace models WITH sample weights (GPB_CreateREModel(has_weights, weights)) by the unmodified reference
+    (tests/golden/laplace_weights_ref.npz), per cases.LAPLACE_WEIGHT_CASES entry:
+      *_negll_direct, *_grad_direct  value and gradient wrt (log sigma1^2, log a[, log aux]) from the reference's CalcGradPars at cases.LAPLACE_TIGHT (+ *_fe_*)
+      *_gradF                        the boosting gradient d(-mll)/dF at cases.LAPLACE_TIGHT
+      *_fit_tight_*                  GPB_OptimCovPar (lbfgs; aux estimated where there is one): estimates, iterations, negll
+      *_latent_mu / _var, *_resp_mu / _var   predictions at 40 points (Cholesky-based: the exact values the iterative methods estimate)"""
+    res = {}
+    for name, wc in cases.LAPLACE_WEIGHT_CASES.items():
+        c = cases.LAPLACE_CASES[wc["model"]]
+        coords, y, w = cases.make_weight_data(wc)
+        lik, aux = wc["lik"], wc.get("aux")
+        has_aux = aux is not None
+        cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+        args = (c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
+            nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, fe, *args, aux_pars=aux, estimate_aux=has_aux, weights=w, **cases.LAPLACE_TIGHT)
+            res[name + fe_key + "_negll_direct"] = np.float64(nll); res[name + fe_key + "_grad_direct"] = g
+            print("laplace weights", name, fe_key, "negll %.10f" % nll, "grad", g, flush=True)
+        if not has_aux:
+            res[name + "_gradF"] = refdrv.ref_laplace_grad_F(coords, y, cp, lik, cases.laplace_fixed_effects(coords), *args, weights=w, **cases.LAPLACE_TIGHT)
+        m2 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik, weights=w)
+        m2.set_optim_config(estimate_aux_pars=has_aux, **cases.LAPLACE_TIGHT)
+        m2.optim_cov_par(y)
+        res[name + "_fit_tight_cov_pars"] = m2.get_cov_par(2)
+        res[name + "_fit_tight_init_cov_pars"] = m2.get_init_cov_par()[:2].copy()
+        res[name + "_fit_tight_num_it"] = np.int32(m2.get_num_it())
+        res[name + "_fit_tight_negll"] = np.float64(m2.current_neg_log_likelihood())
+        if has_aux:
+            res[name + "_fit_tight_aux"] = m2.get_aux_pars(1); res[name + "_fit_tight_init_aux"] = m2.get_init_aux_pars(1)
+        print("laplace weights fit", name, res[name + "_fit_tight_cov_pars"], res.get(name + "_fit_tight_aux"), res[name + "_fit_tight_num_it"], res[name + "_fit_tight_negll"], flush=True)
+        cpred = np.random.default_rng(79).uniform(size=(40, c["d"]))
+        res[name + "_coords_pred"] = cpred
+        m4 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik, matrix_inversion_method="cholesky", weights=w)
+        m4.set_optim_config(init_aux_pars=aux, **cases.LAPLACE_TIGHT)
+        mu, var = m4.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp)
+        rmu, rvar = m4.predict(cpred, predict_var=True, predict_response=True, y=y, cov_pars=cp)
+        res[name + "_latent_mu"] = mu; res[name + "_latent_var"] = var; res[name + "_resp_mu"] = rmu; res[name + "_resp_var"] = rvar
+        print("laplace weights predictions", name, mu[:2], var[:2], rmu[:2], rvar[:2], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_weights_ref.npz"), **res)
+
+
 def split_fixture(out_dir):
     """The reference's FeatureHistogram::FindBestThreshold on its own (fixed) histograms: all inputs of the call + its outputs."""
     res = {}
@@ -1016,6 +1058,8 @@ if __name__ == "__main__":
         fisher_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_laplace":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_weights":
+        laplace_weights_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":
         laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":

@@ -515,6 +515,22 @@ def _responses(likelihood, y):
     return np.ascontiguousarray(y, dtype=np.int32), None
 
 
+class sample_weights(object):
+    """`with orc.sample_weights(w): ...` -- sample weights of the non-Gaussian likelihood (Likelihood::weights_, likelihoods.h:666-668) for every oracle call
+    inside the block: data order as the response handed to those calls (Vecchia order; grouped by random effect with repeated locations).  None: no weights."""
+
+    def __init__(self, w):
+        self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+
+    def __enter__(self):
+        lib().orc_set_weights(_p(self.w, C.c_double))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_weights(None)
+        return False
+
+
 class _aux_context(object):
     """orc_set_aux / orc_clear_aux around a call for the likelihoods with an auxiliary parameter (link >= 3); a no-op otherwise."""
 
@@ -780,8 +796,10 @@ def vecchia_laplace_grad_F(coords, nn, cov_type, var, a, y01, likelihood="bernou
         -d log p / d loc  +  d_mll_d_mode  -  W .* (Sigma^-1 + W)^-1 d_mll_d_mode,     d_mll_d_mode = 0.5 d logdet / d mode,
     from the by-products of vecchia_laplace_grad.  Checker only (no device path yet)."""
     from scipy.stats import norm
+    kw = dict(kw); wts_kw = kw.pop("weights", None)
     negll, g, parts = vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, likelihood=likelihood, fixed_effects=fixed_effects,
                                            want_parts=True, **kw)
+    kw["weights"] = wts_kw
     y = np.asarray(y01, dtype=np.float64)
     loc = parts["mode"] + (0.0 if fixed_effects is None else np.asarray(fixed_effects, dtype=np.float64))
     if likelihood == "bernoulli_logit":
@@ -794,6 +812,8 @@ def vecchia_laplace_grad_F(coords, nn, cov_type, var, a, y01, likelihood="bernou
     else:
         raise ValueError(likelihood)
     d_mll_d_mode = 0.5 * parts["dlogdet_dmode"]
+    if kw.get("weights") is not None:       # (the C side has them through orc.sample_weights; the per-datum terms here are weighted alike)
+        wts = np.asarray(kw["weights"], dtype=np.float64); first = wts * first; W = wts * W
     return -first + d_mll_d_mode - W * parts["implicit_solve"]
 
 

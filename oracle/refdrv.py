@@ -303,11 +303,11 @@ def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponent
 
 
 def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
-                         threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., aux_pars=None, estimate_aux=False):
+                         threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., aux_pars=None, estimate_aux=False, weights=None):
     """(negll, grad): the reference's approximate negative marginal log-likelihood and its gradient wrt (log sigma1^2, log a[, log aux...]) at
     cov_pars = (sigma1^2, rho), from the reference's OWN CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia
     (ref_driver.cpp: refdrv_laplace_nll_grad) with the solver thresholds given -- the pin of orc_vecchia_laplace_grad and of the device gradient."""
-    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
+    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
     mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding, init_aux_pars=aux_pars, estimate_aux_pars=estimate_aux)
     y = np.ascontiguousarray(y, dtype=np.float64)
     cp = np.ascontiguousarray(cov_pars, dtype=np.float64)
@@ -323,11 +323,11 @@ def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, co
 
 
 def ref_laplace_grad_F(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
-                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999.):
+                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., weights=None):
     """The reference's boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF in data order, at cov_pars =
     (sigma1^2, rho) and the fixed effects F (zero if None): REModel::CalcGradient on a model of the reference's own C API (ref_driver.cpp:
     refdrv_laplace_grad_F)."""
-    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood)
+    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
     mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding)
     y = np.ascontiguousarray(y, dtype=np.float64)
     fe = np.zeros_like(y) if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)

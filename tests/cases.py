@@ -114,6 +114,34 @@ LAPLACE_AUX_CASES = {
 }
 
 
+# Sample weights for non-Gaussian models (round 5; Likelihood::weights_): name -> (likelihood, data source).  Weights: uniform(0.3, 2.5), every 17th 0.05, every
+# 11th exactly 1.  (Weights that are exactly ZERO are outside this path: d information / d loc is then zero at those data and the reference leaves its closed
+#  form diag((Sigma^-1 + W)^-1) = (d logdet / d mode) / (d information / d loc) for a stochastic trace estimate, likelihoods.h:6754-6768 -- the library refuses them.)
+LAPLACE_WEIGHT_CASES = {
+    "w_logit_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit"),
+    "w_poisson_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="poisson"),
+    "w_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", aux=2.0, true_aux=2.5),
+    "w_negbin_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", aux=3.0, true_aux=4.0),
+}
+
+
+def make_weight_data(wc):
+    """-> (coords, y, weights) in DATA order for a LAPLACE_WEIGHT_CASES entry."""
+    c = LAPLACE_CASES[wc["model"]]
+    if wc["lik"] in ("gamma", "negative_binomial"):
+        coords, y = make_aux_data(wc)
+    else:
+        coords, yb = make_binary_data(c)
+        if wc["lik"] == "poisson":
+            lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.3
+            y = np.random.default_rng(c["seed_data"] + 2000).poisson(np.exp(lat)).astype(np.float64)
+        else:
+            y = yb.astype(np.float64)
+    w = np.random.default_rng(c["seed_data"] + 3000).uniform(0.3, 2.5, size=coords.shape[0])
+    w[::17] = 0.05; w[5::11] = 1.0
+    return coords, y, w
+
+
 def make_aux_data(ac):
     """-> (coords, y) in DATA order for a LAPLACE_AUX_CASES entry: the coordinates of its model (as make_binary_data draws them), responses with
     log-mean = a smooth surface: gamma(shape true_aux, mean mu) / negative binomial(size true_aux, mean mu)."""

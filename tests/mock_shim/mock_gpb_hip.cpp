@@ -28,6 +28,7 @@ void orc_vecchia_yaux(const double* A, const double* D, const int* nn, int n, in
 int orc_newton_leaf_values(const double* A, const double* D, const int* nn, int n, int m, const double* yaux, const int* leaf, int L, double* leaf_values);
 void orc_gen_rand_normal(int seed, unsigned long long run_id, int n, int t, double* out);
 void orc_set_aux(double aux, const double* y_real, double* aux_grad4);
+void orc_set_weights(const double* w);
 void orc_clear_aux(void);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
@@ -93,6 +94,8 @@ struct gpb_hip_vecchia {
   // Laplace state
   int link = 0;
   std::vector<int> labels; std::vector<double> fe; bool has_fe = false;
+  std::vector<double> weights;     // sample weights of the non-Gaussian likelihood (order of the labels); the oracle reads them through orc_set_weights
+  double wv(int k) const { return weights.empty() ? 1.0 : weights[k]; }
   std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
   double yv(int k) const { return link == 3 ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
@@ -166,7 +169,7 @@ int dense_M_chol(const gpb_hip_vecchia* h, std::vector<double>* Mout) {
   for (int i = 0; i < n; ++i) {
     const int d0 = mapped ? h->re_ptr[i] : i, d1 = mapped ? h->re_ptr[i + 1] : i + 1;
     double w = 0.;
-    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); w += inf; }
+    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); w += h->wv(k) * inf; }
     M[(size_t)i * n + i] += w;
   }
   for (int i = 0; i < n; ++i)
@@ -238,7 +241,7 @@ EXPORT int gpb_hip_vecchia_create(int32_t n, int32_t d, int32_t num_neighbors, c
   *out = h;
   return 0;
 }
-EXPORT int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) { delete h; return 0; }
+EXPORT int gpb_hip_vecchia_free(gpb_hip_vecchia_t* h) { if (h && !h->weights.empty()) orc_set_weights(nullptr); delete h; return 0; }
 EXPORT int gpb_hip_vecchia_find_neighbors(gpb_hip_vecchia_t* h, int* has_duplicates) {
   const int n = h->n, m = h->m;
   h->nn.assign((size_t)n * m, -1);
@@ -429,6 +432,12 @@ EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const
   for (int i = 0; i < nd; ++i) if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i);
   h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->grad_state = false; return 0;
 }
+EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w) {
+  const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
+  if (!w) { h->weights.clear(); orc_set_weights(nullptr); h->grad_state = false; return 0; }
+  h->weights.assign(w, w + nd); orc_set_weights(h->weights.data());      // (one weighted model at a time: test infrastructure)
+  h->grad_state = false; return 0;
+}
 EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux) {
   if (h->link < 3) return fail("gpb_hip_vecchia_laplace_set_aux_pars: likelihood id %d has no auxiliary parameters", h->link);
   if (num_aux != 1 || !(aux[0] > 0.)) return fail("The shape parameter is not > 0 (found %g)", aux[0]);
@@ -475,11 +484,11 @@ EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* 
   for (int i = 0; i < n; ++i) {
     const int d0 = mapped ? h->re_ptr[i] : i, d1 = mapped ? h->re_ptr[i + 1] : i + 1;
     double t3 = 0.;
-    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); t3 += di; }
+    for (int k = d0; k < d1; ++k) { double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di); t3 += h->wv(k) * di; }
     const double diag = t3 == 0. ? 0. : h->dld[i] / t3;
     for (int k = d0; k < d1; ++k) {
       double f, inf, di; lik_terms(h->link, h->yv(k), h->mode[i] + (h->has_fe ? h->fe[k] : 0.), &f, &inf, &di);
-      gF[k] = -f + 0.5 * di * diag - inf * h->sv[i];
+      gF[k] = -(h->wv(k) * f) + 0.5 * (h->wv(k) * di) * diag - (h->wv(k) * inf) * h->sv[i];
     }
   }
   return 0;

@@ -632,3 +632,37 @@ def test_oracle_gamma_negbin_value_and_gradient_match_the_reference(orc, name):
         np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
         ref_v = float(g[name + fe_key + "_negll_direct"])
         assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
+
+
+# ---- sample weights for non-Gaussian likelihoods (round 5) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_WEIGHT_CASES))
+def test_oracle_weighted_non_gaussian_value_and_gradient_match_the_reference(orc, name):
+    """Likelihood::weights_ (likelihoods.h:666-668): the oracle with orc.sample_weights -- every per-datum term weighted, the closed-form parts of the
+    normalising constants and of CalcGradNegLogLikAuxPars that the reference multiplies by num_data_ not -- against the reference's own CalcGradPars on a model
+    created with weights (tests/golden/laplace_weights_ref.npz, oracle/make_golden.py laplace_weights): value 1e-10, gradient (incl. the auxiliary
+    parameter's component for gamma / negative_binomial) 1e-8, without and with fixed effects; the boosting gradient d(-mll)/dF 1e-8 of its scale."""
+    wc = cases.LAPLACE_WEIGHT_CASES[name]
+    c = cases.LAPLACE_CASES[wc["model"]]
+    g = np.load(os.path.join(GOLD, "laplace_weights_ref.npz"))
+    coords, y, w = cases.make_weight_data(wc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    with orc.sample_weights(w[perm]):
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+            nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], fixed_effects=fe, aux=wc.get("aux"), **tight)
+            ref = g[name + fe_key + "_grad_direct"]
+            assert grad_t.shape == ref.shape
+            np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+            ref_v = float(g[name + fe_key + "_negll_direct"])
+            assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
+        if name + "_gradF" in g.files:
+            gF = orc.vecchia_laplace_grad_F(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], fixed_effects=cases.laplace_fixed_effects(coords)[perm],
+                                            weights=w[perm], **tight)
+            out = np.empty_like(gF); out[perm] = gF
+            np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=1e-8 * np.abs(g[name + "_gradF"]).max())
+    # without the context the weights are gone again
+    nll_u, _ = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], aux=wc.get("aux"), **tight)
+    assert abs(nll_u - float(g[name + "_negll_direct"])) > 1.0
