@@ -171,11 +171,27 @@ int transform_cov_pars(const REModelHip* mdl, const double* cov_pars, double* tr
   return 0;
 }
 
+// Round 5: proportions under the logit / probit links -- binomial_logit / binomial_probit (y = successes / trials, the trials are the sample weights) and
+// quasi_bernoulli_logit / _probit (any y in [0, 1]): the Bernoulli terms with a real-valued y (LogLikBernoulliLogit<double>, LogLikBinomialProbit, likelihoods.h:11394-11404).
+bool is_proportion_likelihood(const std::string& lik) {
+  return lik == "binomial_logit" || lik == "binomial_probit" || lik == "quasi_bernoulli_logit" || lik == "quasi_bernoulli_probit";
+}
+bool is_logit_link(const std::string& lik) { return lik == "bernoulli_logit" || lik == "binomial_logit" || lik == "quasi_bernoulli_logit"; }
+bool is_probit_link(const std::string& lik) { return lik == "bernoulli_probit" || lik == "binomial_probit" || lik == "quasi_bernoulli_probit"; }
 int laplace_link_id(const std::string& lik) {
-  return lik == "bernoulli_probit" ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : 0)));
+  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : 0)));
 }
 bool supported_non_gaussian(const std::string& lik) {
-  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial";
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || is_proportion_likelihood(lik);
+}
+// Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
+std::string parse_likelihood_alias(const std::string& lik) {
+  if (lik == "binary_probit") return "bernoulli_probit";
+  if (lik == "binary" || lik == "binary_logit") return "bernoulli_logit";
+  if (lik == "binomial") return "binomial_logit";
+  if (lik == "quasi_binary_probit") return "quasi_bernoulli_probit";
+  if (lik == "quasi_binary" || lik == "quasi_binary_logit") return "quasi_bernoulli_logit";
+  return lik;
 }
 int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial") ? 1 : 0; }
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
@@ -264,6 +280,27 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
     mdl->y_set = true;
     return laplace_upload_fixed_effects(mdl, fixed_effects);
   }
+  if (is_proportion_likelihood(mdl->likelihood)) {        // likelihoods.h:1330-1337: proportions in [0, 1]; :669-674: the binomial likelihoods need the trials as weights
+    const bool binom = mdl->likelihood == "binomial_logit" || mdl->likelihood == "binomial_probit";
+    if (binom && mdl->lik_weights.empty())
+      return set_error("'weights' are missing. For the likelihood '%s', 'weights' should contain the number of trials n_i (and 'y' the ratios of successes / trials). ", mdl->likelihood.c_str());
+    mdl->resp_real.resize(mdl->n);
+    for (int k = 0; k < mdl->n; ++k) {
+      const double yk = y_data[mdl->perm[k]];
+      if (yk < 0. || yk > 1. || !(yk == yk)) return set_error(" Must have 0 <= y <= 1 for the response variable ('y') for likelihood = '%s', found %g. Note that the response variable should be the proportion of successes / trials ", mdl->likelihood.c_str(), yk);
+      mdl->resp_real[k] = yk; mdl->labels[k] = 0;
+    }
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, laplace_link_id(mdl->likelihood))) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_binomial(mdl->vh, binom ? 1 : 0)) return shim_error();
+    if (mdl->n_re > 0) {
+      std::vector<double> grouped(mdl->n);
+      for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
+      if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, grouped.data())) return shim_error();
+    } else if (gpb_hip_vecchia_laplace_set_response_real(mdl->vh, mdl->resp_real.data())) return shim_error();
+    if (laplace_push_weights(mdl)) return -1;
+    mdl->y_set = true;
+    return laplace_upload_fixed_effects(mdl, fixed_effects);
+  }
   for (int k = 0; k < mdl->n; ++k) {
     const double yk = y_data[mdl->perm[k]];
     if (poisson) {                                        // likelihoods.h:1338-1350
@@ -279,6 +316,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
     mdl->labels[k] = std::fabs(yk) < 1e-10 ? 0 : 1;
   }
   if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, laplace_link_id(mdl->likelihood))) return shim_error();
+  if (gpb_hip_vecchia_laplace_set_binomial(mdl->vh, 0)) return shim_error();
   if (mdl->n_re > 0) {
     std::vector<int> grouped(mdl->n);
     for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->labels[mdl->dorder[g]];
@@ -838,11 +876,11 @@ bool predict_response_host(const std::string& lik, int n, double* mean, double* 
     }
     return true;
   }
-  if (lik == "bernoulli_probit") {
+  if (is_probit_link(lik)) {             // (binomial_probit / quasi_bernoulli_probit alike, likelihoods.h:9631-9643)
     for (int i = 0; i < n; ++i) { mean[i] = normal_cdf(mean[i] / std::sqrt(1.0 + var[i])); if (predict_var) var[i] = mean[i] * (1.0 - mean[i]); }
     return true;
   }
-  if (lik == "bernoulli_logit") {
+  if (is_logit_link(lik)) {              // (binomial_logit / quasi_bernoulli_logit alike, :9645-9659)
     std::vector<double> xs, aw;
     gauss_hermite_adaptive(30, &xs, &aw);
     for (int i = 0; i < n; ++i) { mean[i] = resp_mean_logit(mean[i], var[i], delta, xs, aw); if (predict_var) var[i] = mean[i] * (1.0 - mean[i]); }
@@ -1141,9 +1179,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     if (num_ind_points > 256) return set_error("GPB_CreateREModel: num_ind_points = %d (at most 256 on this path) %s", num_ind_points, scope);
     if (num_neighbors <= 0) num_neighbors = 30;                                    // :296
   }
-  std::string lik_name = lik;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
-  if (lik == "binary_probit") lik_name = "bernoulli_probit";
-  if (lik == "binary" || lik == "binary_logit") lik_name = "bernoulli_logit";
+  const std::string lik_name = parse_likelihood_alias(lik);
   if (lik_name != "gaussian" && !supported_non_gaussian(lik_name)) return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
   if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
@@ -2497,6 +2533,7 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
     if (mdl->optimizer_coef != "" && mdl->optimizer_coef != "lbfgs") return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_coef '%s' %s", mdl->optimizer_coef.c_str(), lscope);
     if (num_covariates > 256) return set_error("GPB_OptimLinRegrCoefCovPar: %d covariates %s", num_covariates, lscope);
     if (!mdl->lik_weights.empty()) return set_error("GPB_OptimLinRegrCoefCovPar: sample weights together with covariates for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
+    if (is_proportion_likelihood(mdl->likelihood)) return set_error("GPB_OptimLinRegrCoefCovPar: covariates for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
     if (!y_data) return set_error("GPB_OptimLinRegrCoefCovPar: y_data is NULL");
     if (!mdl->init_coef.empty() && (int)mdl->init_coef.size() != num_covariates) return set_error("GPB_OptimLinRegrCoefCovPar: %d initial coefficients for %d covariates", (int)mdl->init_coef.size(), num_covariates);
     const int n = mdl->n, p = num_covariates;
@@ -2710,9 +2747,7 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !likelihood) return set_error("GPB_SetLikelihood: null argument");
   if (mdl && mdl->vif) return set_error("GPB_SetLikelihood: gp_approx 'full_scale_vecchia' -- likelihood evaluation, its gradient and fits are on the MI355X path of this library, this call is not yet");
-  std::string lik = likelihood;                       // ParseLikelihoodAlias (likelihoods.h:10254-10262)
-  if (lik == "binary_probit") lik = "bernoulli_probit";
-  if (lik == "binary" || lik == "binary_logit") lik = "bernoulli_logit";
+  const std::string lik = parse_likelihood_alias(likelihood);
   if (mdl->model_has_been_estimated && lik != mdl->likelihood) return set_error("Cannot change likelihood after a model has been estimated ");   // re_model.cpp:154-160
   if (lik == mdl->likelihood) return 0;
   if (lik != "gaussian" && !supported_non_gaussian(lik))

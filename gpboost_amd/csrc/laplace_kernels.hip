@@ -68,9 +68,14 @@ __device__ __forceinline__ double inv_mills_phi(double z) {
 // LogLikGamma :11872-11880, FirstDerivLogLikGamma :12485-12487, SecondDerivNegLogLikGamma :13319-13321), 4 = negative_binomial (LogLikNegBin
 // :11882-11890, FirstDerivLogLikNegBin :12489-12492, SecondDerivNegLogLikNegBin :13323-13327).  The response reaches them as a double
 // (LikResp::at: the int label, or gamma's real value).
+// (round 5: the logit / probit links also take a REAL response in [0, 1] -- binomial_logit / binomial_probit (y = successes / trials, the trials are the sample
+//  weights) and quasi_bernoulli_logit / _probit: LogLikBernoulliLogit<double> is linear in y; the probit terms are y f(1) + (1 - y) f(0) with the two Bernoulli
+//  branches, exactly the end points at y = 0 and y = 1: LogLikBinomialProbit :11394-11398, FirstDeriv :12468-12474, SecondDeriv :13293-13305, third :13800-13820)
 template <int LINK>
 __device__ __forceinline__ double resp_at(const LikResp& r, int d) {
-  if constexpr (LINK == 3) return r.yd[d]; else return (double)r.yi[d];
+  if constexpr (LINK == 3) return r.yd[d];
+  else if constexpr (LINK == 0 || LINK == 1) return r.yd ? r.yd[d] : (double)r.yi[d];
+  else return (double)r.yi[d];
 }
 // sample weight of datum d (round 5; likelihoods.h:666-668 weights_): every per-datum term -- log-likelihood and its derivatives -- is multiplied by it
 __device__ __forceinline__ double wt_at(const LikResp& r, int d) { return r.w ? r.w[d] : 1.0; }
@@ -81,10 +86,16 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
     grad = y - p;                         // likelihoods.h:12477
     w = p * (1.0 - p);                    // :13307
   } else if constexpr (LINK == 1) {
-    const double z = y != 0.0 ? x : -x;
-    const double r = inv_mills_phi(z);
-    grad = y != 0.0 ? r : -r;
-    w = r * (z + r);
+    if (y == 0.0 || y == 1.0) {
+      const double z = y != 0.0 ? x : -x;
+      const double r = inv_mills_phi(z);
+      grad = y != 0.0 ? r : -r;
+      w = r * (z + r);
+    } else {                                // a proportion: both Bernoulli branches, mixed
+      const double r1 = inv_mills_phi(x), r0 = inv_mills_phi(-x);
+      grad = y * r1 + (1.0 - y) * -r0;
+      w = y * r1 * (x + r1) + (1.0 - y) * -r0 * (x - r0);
+    }
   } else if constexpr (LINK == 3) {
     const double q = y * exp(-x);
     grad = aux * (q - 1.0);
@@ -102,7 +113,10 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
 template <int LINK>
 __device__ __forceinline__ double lik_loglik(double y, double x, double aux) {
   if constexpr (LINK == 0) return y * x - softplus(x);      // likelihoods.h:11401-11403
-  else if constexpr (LINK == 1) return normal_log_cdf(y != 0.0 ? x : -x);
+  else if constexpr (LINK == 1) {
+    if (y == 0.0 || y == 1.0) return normal_log_cdf(y != 0.0 ? x : -x);
+    return y * normal_log_cdf(x) + (1.0 - y) * normal_log_cdf(-x);
+  }
   else if constexpr (LINK == 3) return -aux * (x + y * exp(-x));
   else if constexpr (LINK == 4) return y * x - (y + aux) * log(exp(x) + aux);
   else return y * x - exp(x);
@@ -834,7 +848,9 @@ __device__ __forceinline__ double lik_third(double y, double x, double aux) {
     const double x2 = x * x;
     if (y == 0.0) { const double q = inv_mills_phi(-x); return -q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)); }
     const double r = inv_mills_phi(x);
-    return -r * (x2 - 1.0 + r * (3.0 * x + 2.0 * r));
+    if (y == 1.0) return -r * (x2 - 1.0 + r * (3.0 * x + 2.0 * r));
+    const double q = inv_mills_phi(-x);
+    return y * (-r * (x2 - 1.0 + r * (3.0 * x + 2.0 * r))) + (1.0 - y) * (-q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)));
   }
 }
 template <int LINK>

@@ -203,7 +203,8 @@ class VecchiaState(object):
         return out
 
     def laplace_set_likelihood(self, likelihood):
-        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4}[likelihood]
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4,
+               "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
         self._lap_link = lid
 
@@ -216,6 +217,10 @@ class VecchiaState(object):
         """Sample weights of the non-Gaussian likelihood, in the order of the labels (gpb_hip_vecchia_laplace_set_weights); None removes them."""
         ww = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_weights(self.h, _p(ww)))
+
+    def laplace_set_binomial(self, on=True):
+        """binomial_logit / binomial_probit: the binomial normalising constant over (proportions, trials = sample weights) (gpb_hip_vecchia_laplace_set_binomial)."""
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_binomial(self.h, C.c_int(int(bool(on)))))
 
     def laplace_set_aux(self, aux):
         """gamma / negative_binomial: the shape parameter (gpb_hip_vecchia_laplace_set_aux_pars)."""

@@ -425,6 +425,11 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* 
  * location parameter, the per-datum parts of the normalising constants (:10573-10600, :10750-10757, :11019-11030) and of the auxiliary-parameter gradients
  * (:14185-14215, :14777-14799) are multiplied by w_d.  Same order as the labels; NULL removes them.  Finite and >= 0. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w);
+/* Proportions under the logit / probit links (round 5): gpb_hip_vecchia_laplace_set_response_real also serves likelihood ids 0 / 1 with y in [0, 1] -- binomial_logit /
+ * binomial_probit (y = successes / trials, the trials are the sample weights) and quasi_bernoulli_logit / _probit (LogLikBernoulliLogit<double>, LogLikBinomialProbit,
+ * include/GPBoost/likelihoods.h:11394-11404 and their derivatives :12468-12474, :13293-13305, :13800-13820).  on != 0 here adds the binomial normalising constant
+ * sum lgamma(w + 1) - lgamma(k + 1) - lgamma(w - k + 1), k = w y (:10612-10622). */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);

@@ -504,14 +504,19 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
     return out
 
 
-LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4}
+LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4,
+           # round 5: proportions under the logit / probit links (real-valued response in [0, 1]; binomial_*: trials = orc.sample_weights, binomial constant)
+           "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}
+PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
 
 
 def _responses(likelihood, y):
     """-> (int32 responses, float64 responses | None): gamma's response is real-valued (handed to the C side through orc_set_aux)."""
-    if likelihood == "gamma":
+    if likelihood == "gamma" or likelihood in PROPORTION_LIKELIHOODS:
         yd = np.ascontiguousarray(y, dtype=np.float64)
+        lib().orc_set_binomial(C.c_int(1 if likelihood.startswith("binomial") else 0))
         return np.zeros(yd.shape[0], dtype=np.int32), yd
+    lib().orc_set_binomial(C.c_int(0))
     return np.ascontiguousarray(y, dtype=np.int32), None
 
 
@@ -535,7 +540,7 @@ class _aux_context(object):
     """orc_set_aux / orc_clear_aux around a call for the likelihoods with an auxiliary parameter (link >= 3); a no-op otherwise."""
 
     def __init__(self, link, aux, yd, aux_grad4):
-        self.on = link >= 3
+        self.on = link >= 3 or yd is not None         # (a real-valued response travels the same way for the proportion likelihoods)
         self.args = (float(1.0 if aux is None else aux), yd, aux_grad4)
 
     def __enter__(self):
@@ -802,13 +807,13 @@ def vecchia_laplace_grad_F(coords, nn, cov_type, var, a, y01, likelihood="bernou
     kw["weights"] = wts_kw
     y = np.asarray(y01, dtype=np.float64)
     loc = parts["mode"] + (0.0 if fixed_effects is None else np.asarray(fixed_effects, dtype=np.float64))
-    if likelihood == "bernoulli_logit":
+    if LINK_ID[likelihood] == 0:                    # (y may be a proportion: linear in y)
         p = 1.0 / (1.0 + np.exp(-loc)); first = y - p; W = p * (1.0 - p)
     elif likelihood == "poisson":
         e = np.exp(loc); first = y - e; W = e
-    elif likelihood == "bernoulli_probit":
-        z = np.where(y > 0, loc, -loc)
-        r = np.exp(norm.logpdf(z) - norm.logcdf(z)); first = np.where(y > 0, r, -r); W = r * (z + r)
+    elif LINK_ID[likelihood] == 1:                  # y f(1) + (1 - y) f(0) of the two Bernoulli branches (exact at y = 0, 1)
+        r1 = np.exp(norm.logpdf(loc) - norm.logcdf(loc)); r0 = np.exp(norm.logpdf(-loc) - norm.logcdf(-loc))
+        first = y * r1 - (1.0 - y) * r0; W = y * r1 * (loc + r1) - (1.0 - y) * r0 * (loc - r0)
     else:
         raise ValueError(likelihood)
     d_mll_d_mode = 0.5 * parts["dlogdet_dmode"]

@@ -123,11 +123,33 @@ LAPLACE_WEIGHT_CASES = {
     "w_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", aux=2.0, true_aux=2.5),
     "w_negbin_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", aux=3.0, true_aux=4.0),
 }
+# Proportions under the logit / probit links (round 5): binomial_* -- y = successes / trials, the trials (1..20) are the sample weights; quasi_bernoulli_* -- any
+# y in [0, 1] (here: a noisy proportion, some exact zeros and ones), with and without weights.  Same fixture layout as the weighted cases.
+LAPLACE_PROP_CASES = {
+    "binomial_logit_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="binomial_logit"),
+    "binomial_probit_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="binomial_probit"),
+    "quasi_logit_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="quasi_bernoulli_logit", weights=False),
+    "quasi_probit_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="quasi_bernoulli_probit"),
+}
+LAPLACE_WEIGHT_CASES.update(LAPLACE_PROP_CASES)
+LAPLACE_PROP_CASES_LIKS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
 
 
 def make_weight_data(wc):
     """-> (coords, y, weights) in DATA order for a LAPLACE_WEIGHT_CASES entry."""
     c = LAPLACE_CASES[wc["model"]]
+    if wc["lik"].startswith("binomial") or wc["lik"].startswith("quasi"):
+        rng = np.random.default_rng(c["seed_data"])
+        coords = rng.uniform(size=(c["n"], c["d"]))
+        lat = 1.2 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.2
+        p = 1.0 / (1.0 + np.exp(-lat))
+        rng2 = np.random.default_rng(c["seed_data"] + 4000)
+        if wc["lik"].startswith("binomial"):
+            trials = rng2.integers(1, 21, size=c["n"]).astype(np.float64)
+            return coords, rng2.binomial(trials.astype(np.int64), p) / trials, trials
+        y = np.clip(p + 0.25 * rng2.standard_normal(c["n"]), 0.0, 1.0)          # (a fifth of them exactly 0 or 1)
+        w = rng2.uniform(0.3, 2.5, size=c["n"]) if wc.get("weights", True) else None
+        return coords, y, w
     if wc["lik"] in ("gamma", "negative_binomial"):
         coords, y = make_aux_data(wc)
     else:

@@ -29,6 +29,7 @@ int orc_newton_leaf_values(const double* A, const double* D, const int* nn, int 
 void orc_gen_rand_normal(int seed, unsigned long long run_id, int n, int t, double* out);
 void orc_set_aux(double aux, const double* y_real, double* aux_grad4);
 void orc_set_weights(const double* w);
+void orc_set_binomial(int on);
 void orc_clear_aux(void);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
@@ -61,6 +62,12 @@ void lik_terms(int link, double y, double x, double* first, double* info, double
   }
   if (link == 0) { const double p = sigmoid(x); *first = y - p; *info = p * (1. - p); *dinfo = p * (1. - p) * (1. - 2. * p); return; }
   if (link == 2) { const double e = std::exp(x); *first = y - e; *info = e; *dinfo = e; return; }
+  if (y != 0. && y != 1.) {         // a proportion (binomial_probit / quasi_bernoulli_probit): y f(1) + (1 - y) f(0)
+    double f1, i1, d1, f0, i0, d0;
+    lik_terms(1, 1., x, &f1, &i1, &d1); lik_terms(1, 0., x, &f0, &i0, &d0);
+    *first = y * f1 + (1. - y) * f0; *info = y * i1 + (1. - y) * i0; *dinfo = y * d1 + (1. - y) * d0;
+    return;
+  }
   const double z = y > 0 ? x : -x;
   const double r = std::exp(-0.5 * z * z - 0.5 * std::log(2 * M_PI) - normal_log_cdf(z));
   *first = y > 0 ? r : -r;
@@ -97,7 +104,8 @@ struct gpb_hip_vecchia {
   std::vector<double> weights;     // sample weights of the non-Gaussian likelihood (order of the labels); the oracle reads them through orc_set_weights
   double wv(int k) const { return weights.empty() ? 1.0 : weights[k]; }
   std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
-  double yv(int k) const { return link == 3 ? resp_real[k] : (double)labels[k]; }
+  bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
+  double yv(int k) const { return (link == 3 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
   bool has_mode = false, grad_state = false;
@@ -204,11 +212,14 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   h->mode_prev = warm ? h->mode : std::vector<double>(n, 0.);
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
-  if (h->link >= 3) orc_set_aux(h->aux, h->link == 3 ? h->resp_real.data() : nullptr, h->aux_grad4);
+  const bool ctx = h->link >= 3 || h->real_resp;
+  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  orc_set_binomial(h->binomial ? 1 : 0);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
                                                   h->has_fe ? h->fe.data() : nullptr, rv.data(), nrv, cg, cgt, cgd, dcm, out6, h->grad2, mode.data(), warm ? 1 : 0,
                                                   dbg.data());
-  if (h->link >= 3) orc_clear_aux();
+  if (ctx) orc_clear_aux();
+  orc_set_binomial(0);
   if (rc) return fail("NaN or Inf occurred in the mode finding algorithm for the Laplace approximation");
   h->mode = mode; h->has_mode = true; h->grad_state = true;
   h->dld.assign(dbg.begin(), dbg.begin() + n); h->sv.assign(dbg.begin() + n, dbg.begin() + 2 * n);
@@ -424,14 +435,18 @@ EXPORT int gpb_hip_vecchia_laplace_set_data_map(gpb_hip_vecchia_t* h, const int3
 }
 EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_t* y) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_labels");
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
-  h->labels.assign(y, y + nd); h->grad_state = false; return 0;
+  h->labels.assign(y, y + nd); h->real_resp = false; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
-  if (h->link != 3) return fail("gpb_hip_vecchia_laplace_set_response_real: only the gamma likelihood has a real-valued response on this path (likelihood id %d)", h->link);
+  if (h->link != 3 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma and for proportions under the logit / probit links (likelihood id %d)", h->link);
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
-  for (int i = 0; i < nd; ++i) if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i);
-  h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->grad_state = false; return 0;
+  for (int i = 0; i < nd; ++i) {
+    if (h->link == 3) { if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
+    else if (!(y[i] >= 0. && y[i] <= 1.)) return fail(" Must have 0 <= y <= 1 for the response variable ('y') (found %g at Vecchia position %d)", y[i], i);
+  }
+  h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->real_resp = true; h->grad_state = false; return 0;
 }
+EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on) { h->binomial = on != 0; return 0; }
 EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w) {
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   if (!w) { h->weights.clear(); orc_set_weights(nullptr); h->grad_state = false; return 0; }

@@ -650,7 +650,8 @@ def test_oracle_weighted_non_gaussian_value_and_gradient_match_the_reference(orc
     cp = c["cov_pars"][0]
     a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
     tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
-    with orc.sample_weights(w[perm]):
+    wv = None if w is None else w[perm]          # (quasi_bernoulli_* may come without weights; binomial_*: the trials)
+    with orc.sample_weights(wv):
         for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
             nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], fixed_effects=fe, aux=wc.get("aux"), **tight)
             ref = g[name + fe_key + "_grad_direct"]
@@ -660,9 +661,12 @@ def test_oracle_weighted_non_gaussian_value_and_gradient_match_the_reference(orc
             assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
         if name + "_gradF" in g.files:
             gF = orc.vecchia_laplace_grad_F(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], fixed_effects=cases.laplace_fixed_effects(coords)[perm],
-                                            weights=w[perm], **tight)
+                                            weights=wv, **tight)
             out = np.empty_like(gF); out[perm] = gF
-            np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=1e-8 * np.abs(g[name + "_gradF"]).max())
+            # (-W_d [(Sigma^-1 + W)^-1 d_mll_d_mode]_d carries the CG's 1e-8 stopping error times W_d = trials x information: up to 20 trials here)
+            tolF = 1e-7 if wc["lik"].startswith("binomial") else 1e-8
+            np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=tolF * np.abs(g[name + "_gradF"]).max())
     # without the context the weights are gone again
-    nll_u, _ = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], aux=wc.get("aux"), **tight)
-    assert abs(nll_u - float(g[name + "_negll_direct"])) > 1.0
+    if w is not None and not wc["lik"].startswith("binomial"):
+        nll_u, _ = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], aux=wc.get("aux"), **tight)
+        assert abs(nll_u - float(g[name + "_negll_direct"])) > 1.0

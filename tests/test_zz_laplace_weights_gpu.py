@@ -35,13 +35,16 @@ def test_weighted_value_gradient_and_boosting_gradient_match_the_reference(gpb, 
     st = shim.VecchiaState(co, c["m"])
     st.set_neighbors(nn)
     st.laplace_set_likelihood(wc["lik"])
-    if wc["lik"] == "gamma":
+    prop = wc["lik"] in cases.LAPLACE_PROP_CASES_LIKS
+    if wc["lik"] == "gamma" or prop:
         st.laplace_set_response_real(y[perm])
     else:
         st.laplace_set_labels(y[perm].astype(np.int32))
     if "aux" in wc:
         st.laplace_set_aux(wc["aux"])
-    st.laplace_set_weights(w[perm])
+    if prop:
+        st.laplace_set_binomial(wc["lik"].startswith("binomial"))
+    st.laplace_set_weights(None if w is None else w[perm])
     cp = c["cov_pars"][0]
     a = RC[ct] / cp[1]
     for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
@@ -55,7 +58,12 @@ def test_weighted_value_gradient_and_boosting_gradient_match_the_reference(gpb, 
     if name + "_gradF" in g.files:          # (state of the evaluation with fixed effects just made)
         gF = st.laplace_grad_F()
         out = np.empty_like(gF); out[perm] = gF
-        np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=1e-8 * np.abs(g[name + "_gradF"]).max())
+        # (-W_d [(Sigma^-1 + W)^-1 d_mll_d_mode]_d carries the CG's 1e-8 stopping error times W_d = trials x information: up to 20 trials in the binomial cases)
+        tolF = 1e-7 if wc["lik"].startswith("binomial") else 1e-8
+        np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=tolF * np.abs(g[name + "_gradF"]).max())
+    if prop:
+        st.close()
+        return
     # the weights can be taken away again (the unweighted value: the oracle's, itself pinned to the reference) and unit weights change nothing
     st.laplace_set_fixed_effects(None)
     st.laplace_set_weights(None)
@@ -91,9 +99,10 @@ def test_weighted_model_api_fit_and_prediction_follow_the_reference(gpb, name):
     pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=False)
     np.testing.assert_allclose(pr["mu"], g[name + "_latent_mu"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pr["var"], g[name + "_latent_var"], rtol=1e-5)
-    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=True)
-    np.testing.assert_allclose(pr["mu"], g[name + "_resp_mu"], rtol=1e-5)
-    np.testing.assert_allclose(pr["var"], g[name + "_resp_var"], rtol=1e-5)
+    if name + "_resp_mu" in g.files:       # (the reference has no response prediction for quasi_bernoulli_logit)
+        pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=True)
+        np.testing.assert_allclose(pr["mu"], g[name + "_resp_mu"], rtol=1e-5)
+        np.testing.assert_allclose(pr["var"], g[name + "_resp_var"], rtol=1e-5)
     m2 = gpb.GPModel(**kw)
     m2.fit(y, params=dict(cases.LAPLACE_TIGHT))
     assert m2.get_num_optim_iter() == int(g[name + "_fit_tight_num_it"]), (m2.get_num_optim_iter(), int(g[name + "_fit_tight_num_it"]))
