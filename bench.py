@@ -250,6 +250,10 @@ def main():
     # y is uploaded ONCE (this call; GPB_EvalNegLogLikelihood with a host pointer permutes it to the Vecchia order and copies it to
     # HBM) and stays resident: every timed evaluation passes y_data = NULL (re_model_template.h:2905-2921)
     mdl.neg_log_likelihood(cov_pars, y)
+    # (model set-up, like the neighbour search: the library builds the spatially sorted copy of the records its gathers read at the third evaluation on a
+    #  neighbour table -- a host sort, ~0.1 s per million points; DESIGN.md section 4.1.  Two more untimed evaluations put it before ANY warm-up count.)
+    mdl.neg_log_likelihood(cov_pars)
+    mdl.neg_log_likelihood(cov_pars)
     i0, i1 = parallel.shard_range(n, rank, world)
     st.set_shard(i0, i1)
 

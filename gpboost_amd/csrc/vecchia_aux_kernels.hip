@@ -191,6 +191,24 @@ hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, src, dst_host, n);
   return hipGetLastError();
 }
+// Spatially sorted copy of the point records for the neighbour gathers of vecchia_point_kernel (round 5): pts[n + rank[k]] = pts[k], and the neighbour table
+// rewritten to point into that copy (nn2 = n + rank[nn], -1 stays).  rank = position of point k in Morton order of the coordinates.
+__global__ void scatter_pts_kernel(double4* __restrict__ pts, const int* __restrict__ rank, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) pts[(size_t)n + rank[k]] = pts[k];
+}
+__global__ void remap_nn_kernel(const int* __restrict__ nn, const int* __restrict__ rank, size_t cnt, int n, int* __restrict__ nn2) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < cnt) { const int c = nn[t]; nn2[t] = c >= 0 ? n + rank[c] : -1; }
+}
+hipError_t launch_scatter_pts(double4* pts, const int* rank, int n, hipStream_t st) {
+  hipLaunchKernelGGL(scatter_pts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, rank, n);
+  return hipGetLastError();
+}
+hipError_t launch_remap_nn(const int* nn, const int* rank, size_t cnt, int n, int* nn2, hipStream_t st) {
+  hipLaunchKernelGGL(remap_nn_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, nn, rank, cnt, n, nn2);
+  return hipGetLastError();
+}
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st) {
   hipLaunchKernelGGL(pack_y_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, y, n);
   return hipGetLastError();

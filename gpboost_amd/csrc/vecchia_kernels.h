@@ -67,6 +67,8 @@ hipError_t launch_reduce_partials(const double* partials, int nblocks, int nterm
                                   hipStream_t st, double* out_host = nullptr);
 hipError_t launch_publish(const double* src, double* dst_host, int n, hipStream_t st);
 hipError_t launch_pack_y(double4* pts, const double* y, int n, hipStream_t st);
+hipError_t launch_scatter_pts(double4* pts, const int* rank, int n, hipStream_t st);                      // pts[n + rank[k]] = pts[k]  (pts holds 2 n records)
+hipError_t launch_remap_nn(const int* nn, const int* rank, size_t cnt, int n, int* nn2, hipStream_t st);  // nn2 = n + rank[nn]
 hipError_t launch_By(const double* A, const int* nn, int n, int m, const double* y, double* u, hipStream_t st);
 hipError_t launch_By_pts(const double* A, const int* nn, const double4* pts, int m, int i0, int i1, double* u, hipStream_t st);   // u = B y, y = pts[.].w
 hipError_t launch_Bt(const double* A, const int* t_ptr, const int* t_pos, int n, int m, int i0, int i1, const double* v,

@@ -213,6 +213,10 @@ class VecchiaState(object):
         y = np.ascontiguousarray(y, dtype=np.float64)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_response_real(self.h, _p(y)))
 
+    def set_sorted_gather(self, mode):
+        """-1: default (n >= 32768, from the third evaluation), 0: never, 1: always -- the spatially sorted copy of the records the neighbour gathers read."""
+        _shim_call(_lib().gpb_hip_vecchia_set_sorted_gather(self.h, C.c_int(int(mode))))
+
     def laplace_set_weights(self, w):
         """Sample weights of the non-Gaussian likelihood, in the order of the labels (gpb_hip_vecchia_laplace_set_weights); None removes them."""
         ww = None if w is None else np.ascontiguousarray(w, dtype=np.float64)

@@ -93,4 +93,28 @@ for name in ("gamma_n1500", "negbin_n1500"):
     assert mg._get_num_optim_iter() == int(ga[name + "_fit_num_it"])
     assert np.allclose(cpg[:2], ga[name + "_fit_cov_pars"], rtol=1e-4) and np.allclose(aux[:1], ga[name + "_fit_aux"], rtol=1e-4)
     assert abs(mg.get_current_neg_log_likelihood() - float(ga[name + "_fit_negll"])) <= 1e-7 * abs(float(ga[name + "_fit_negll"]))
+# sample weights and proportions (round 5): the package's GPModel(likelihood = "poisson" / "gamma", weights = w) and GPModel(likelihood = "binomial", weights = trials)
+# -- evaluation at given parameters and the tight-threshold fit against the reference LIBRARY's values (tests/golden/laplace_weights_ref.npz)
+gw = np.load(os.path.join(ROOT, "tests", "golden", "laplace_weights_ref.npz"))
+for name in ("w_poisson_n2000", "w_gamma_n1500", "binomial_logit_n1500"):
+    wc = cases.LAPLACE_WEIGHT_CASES[name]
+    c = cases.LAPLACE_CASES[wc["model"]]
+    cw, yw, ww = cases.make_weight_data(wc)
+    lik_pkg = "binomial" if wc["lik"] == "binomial_logit" else wc["lik"]          # (the package's alias, ParseLikelihoodAlias)
+    kw = dict(gp_coords=cw, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"], vecchia_ordering=c["ordering"],
+              likelihood=lik_pkg, seed=c["seed"], weights=ww)
+    mw = gpb.GPModel(**kw)
+    mw.set_optim_params(params=dict(cases.LAPLACE_TIGHT))
+    akw = dict(aux_pars=np.array([wc["aux"]])) if "aux" in wc else {}
+    v = mw.neg_log_likelihood(cov_pars=np.asarray(c["cov_pars"][0], dtype=np.float64), y=yw, **akw)
+    print("%s with weights: neg_log_likelihood = %.9f (reference library %.9f)" % (lik_pkg, v, float(gw[name + "_negll_direct"])), flush=True)
+    assert abs(v - float(gw[name + "_negll_direct"])) <= 1e-8 * abs(v)
+    mw = gpb.GPModel(**kw)
+    mw.fit(y=yw, params=dict(cases.LAPLACE_TIGHT))
+    cpw = np.asarray(mw.get_cov_pars(format_pandas=False)).ravel()
+    print("%s with weights, fit: cov pars %s, %d iterations, nll %.7f (reference library: %s, %d, %.7f)" %
+          (lik_pkg, cpw[:2], mw._get_num_optim_iter(), mw.get_current_neg_log_likelihood(), gw[name + "_fit_tight_cov_pars"], int(gw[name + "_fit_tight_num_it"]),
+           float(gw[name + "_fit_tight_negll"])), flush=True)
+    assert mw._get_num_optim_iter() == int(gw[name + "_fit_tight_num_it"])
+    assert np.allclose(cpw[:2], gw[name + "_fit_tight_cov_pars"], rtol=1e-6)
 print("REFERENCE PACKAGE ON MI355X: OK", flush=True)

@@ -95,3 +95,58 @@ def test_config4_n1e5_against_the_reference(gpb):
     vt = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
     reft = float(g["negll_tight_0"])
     assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
+
+
+def test_config3_shape_tree_with_categorical_columns_equals_the_oracle_tree(gpb, orc):
+    """Round 5, at BASELINE config 3's shape (n = 1e5 rows, 50 columns, 255 bins, 31 leaves) with 6 of the columns categorical (12 / 100 / 250 categories): the
+    device's whole-tree grower (categorical search, bitset partitions, resident row lists) against the oracle's primitives driven by tests/tree_harness.py -- the
+    oracle is pinned bit for bit to the reference's FeatureHistogram / Dataset::Split on the small fixtures (tests/golden/split_cat_ref.npz, tree_ref_r5.npz) --:
+    the same splits, thresholds, sets of bins and counts; leaf values to the summation order of the histogram build; every row in the leaf the tree sends it to."""
+    from gpboost_amd import shim
+    from tests import tree_harness as th
+    n, F, NB, L = 100000, 50, 255, 31
+    rng = np.random.default_rng(17)
+    X = rng.uniform(size=(n, F))
+    cat_cols = {3: 12, 11: 100, 19: 250, 27: 100, 35: 12, 43: 250}
+    bins = np.empty((F, n), dtype=np.uint8)
+    gnb = np.empty(F, dtype=np.int32); nbin = np.empty(F, dtype=np.int32); mfb = np.zeros(F, dtype=np.int32)
+    meta3 = np.zeros((F, 3), dtype=np.int32); is_cat = np.zeros(F, dtype=np.int32)
+    signal = np.sin(4 * X[:, 0]) + X[:, 1] ** 2
+    for f in range(F):
+        if f in cat_cols:
+            # a categorical column as the reference stores it: bin 0 = its most frequent category (stored value 0 = most frequent bin), the others 1 .. K - 1
+            K = cat_cols[f]
+            pr = rng.dirichlet(np.full(K, 0.7)); pr = np.sort(pr)[::-1]
+            cat = rng.choice(K, size=n, p=pr)
+            bins[f] = cat.astype(np.uint8); gnb[f] = K; nbin[f] = K; is_cat[f] = 1
+            meta3[f] = (1, 0, 0)                      # offset 1 (most_freq_bin 0), default bin 0, no missing type
+            signal = signal + rng.standard_normal(K)[cat] * (0.6 if K <= 100 else 0.3)
+        else:
+            bins[f] = np.minimum((X[:, f] * (NB - 1)).astype(np.int64) + 1, NB - 1).astype(np.uint8)
+            gnb[f] = NB; nbin[f] = NB; meta3[f] = (1, 0, 0)
+    grad = signal + 0.5 * rng.standard_normal(n)
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+    voff = (bo[:-1] + 1).astype(np.int32)
+    cfg = (0.5, 20, 1e-3, 0.0)
+    cat_cfg = (4, 32, 10.0, 10.0, 100)
+    be = th.OracleBackend(orc, bins, gnb, voff, nbin, mfb, meta3, grad, None, is_cat=is_cat, cat_cfg=cat_cfg)
+    to = th.grow_tree(be, grad, None, n, L, cfg)
+    hb = shim.HistBuilder(bins, bo)
+    hb.pool_resize(L + 1)
+    hb.set_fix_info(voff, nbin, mfb)
+    hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+    hb.set_categorical(is_cat, *cat_cfg)
+    hb.set_gradients(grad, None)
+    sg = float(np.cumsum(grad)[-1])
+    t = hb.grow_tree(L, sg, float(n), *cfg)
+    assert t["num_leaves"] == to["num_leaves"] == L
+    for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "node_is_cat"):
+        assert np.array_equal(t[key], np.asarray(to[key])), key
+    assert np.array_equal(t["node_cat_bits"], np.asarray(to["node_cat_bits"]).reshape(-1, 8))
+    assert int(t["node_is_cat"].sum()) >= 3 and int((1 - t["node_is_cat"]).sum()) >= 3          # both kinds of splits in the tree
+    np.testing.assert_allclose(t["leaf_value"], to["leaf_value"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(t["split_gain"], to["split_gain"], rtol=1e-6)
+    # size-independent properties: the leaves partition the rows, the counts are the leaf sizes
+    dli = t["data_leaf_index"]
+    assert dli.min() == 0 and dli.max() == L - 1 and np.array_equal(np.bincount(dli, minlength=L), t["leaf_count"]) and t["leaf_count"].sum() == n
+    hb.close()

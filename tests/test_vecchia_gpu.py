@@ -135,6 +135,34 @@ def test_factor_A_D_u_and_yaux_against_oracle(gpb, orc):
         assert t[2] == 0
 
 
+@pytest.mark.parametrize("n,d,m,ct", [(6000, 2, 30, 0), (5000, 3, 40, 2), (4000, 1, 10, 1), (3000, 2, 62, 0)])
+def test_spatially_sorted_gather_changes_no_bit(gpb, orc, n, d, m, ct):
+    """Round 5: the neighbour gathers of the point kernel read a Morton-sorted copy of the records through a rewritten neighbour table
+    (gpb_hip_vecchia_set_sorted_gather; default for n >= 32768 from the third evaluation).  Forced on for these small cases: likelihood terms, gradient
+    terms, factor (A, D, u) and y_aux are bit-identical to the plain gather -- before and after a new response (the copy follows), and for a shard."""
+    from gpboost_amd import shim
+    coords, y = cases.synthetic(n, d, seed=31 + d)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 2)
+    res = {}
+    for mode in (0, 1):
+        st = shim.VecchiaState(co, m)
+        st.set_neighbors(nn)
+        st.set_sorted_gather(mode)
+        st.set_y(y[perm])
+        out = [st.nll_terms(ct, 3.0, 9.0), st.grad_terms(ct, 3.0, 9.0), st.nll_terms(ct, 0.7, 4.0, gauss=False)]
+        st.factor(ct, 3.0, 9.0)
+        out += list(st.get_factor()) + [st.yaux()]
+        st.set_y(np.cos(3 * y[perm]))                      # a new response: the sorted copy is renewed before the next launch
+        out += [st.nll_terms(ct, 3.0, 9.0), st.grad_terms(ct, 2.0, 7.0)]
+        i0, i1 = 16 * (n // 48), 16 * (n // 24)
+        st.set_shard(i0, i1)
+        out += [st.nll_terms(ct, 3.0, 9.0)]
+        res[mode] = out
+        st.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_new_response_keeps_the_factor_and_renews_u(gpb, orc):
     """The GPBoost algorithm hands over a new response (F - y) every boosting iteration at unchanged covariance parameters (CalcGradientF,
     re_model_template.h:3313-3316: SetY, CalcYAux): A, D stay on the device, u = B y is renewed by one pass over A -- no refactorisation."""
