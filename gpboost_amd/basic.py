@@ -170,6 +170,7 @@ class GPModel(object):
         "convergence_criterion": "default", "m_lbfgs": -999, "estimate_cov_par_index": None,
         "cg_max_num_it": -999, "cg_max_num_it_tridiag": -999, "cg_delta_conv": -999., "num_rand_vec_trace": -999,
         "seed_rand_vec_trace": 1, "delta_conv_mode_finding": -999., "cg_preconditioner_type": "",
+        "fitc_piv_chol_preconditioner_rank": -999,   # rank of the "pivoted_cholesky" preconditioner (basic.py:4767, :5510-5511; -999: the library's default 50)
         # non-Gaussian models with covariates: start of the coefficients in the lbfgs vector; default as in the reference's packages: the fit of the
         # same likelihood without the Gaussian process (init_coef_aux_pars_from_iid_model, re_model.cpp:380-470)
         "init_coef": None, "init_coef_aux_pars_from_iid_model": True,
@@ -181,7 +182,7 @@ class GPModel(object):
         Estimation: 'optimizer_cov' ("lbfgs" | "gradient_descent" | "nelder_mead"), 'init_cov_pars', 'lr_cov', 'acc_rate_cov', 'maxit',
         'delta_rel_conv', 'use_nesterov_acc', 'nesterov_schedule_version', 'momentum_offset', 'convergence_criterion', 'm_lbfgs',
         'estimate_cov_par_index' (0 = hold a covariance parameter at its initial value: (error variance, GP variance, range) for Gaussian models, (GP variance, range) for non-Gaussian ones with 'lbfgs'), 'trace', 'init_coef', 'init_coef_aux_pars_from_iid_model'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
-        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type'; likelihoods with auxiliary parameters ("gamma", "negative_binomial"):
+        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type' ("vadu" | "pivoted_cholesky"), 'fitc_piv_chol_preconditioner_rank'; likelihoods with auxiliary parameters ("gamma", "negative_binomial"):
         'init_aux_pars', 'estimate_aux_pars'.  Anything else raises: no silent ignore."""
         if not hasattr(self, "_optim_params"):
             self._optim_params = dict(self._OPTIM_DEFAULTS)
@@ -219,7 +220,7 @@ class GPModel(object):
             ctypes.c_double(-999.), ctypes.c_double(-999.), c_str(""),
             ctypes.c_int(int(o["cg_max_num_it"])), ctypes.c_int(int(o["cg_max_num_it_tridiag"])),
             ctypes.c_double(float(o["cg_delta_conv"])), ctypes.c_int(int(o["num_rand_vec_trace"])), ctypes.c_bool(True),
-            c_str(o["cg_preconditioner_type"]), ctypes.c_int(int(o["seed_rand_vec_trace"])), ctypes.c_int(-999),
+            c_str(o["cg_preconditioner_type"]), ctypes.c_int(int(o["seed_rand_vec_trace"])), ctypes.c_int(int(o["fitc_piv_chol_preconditioner_rank"])),
             iaux_c, ctypes.c_bool(bool(o["estimate_aux_pars"])), ctypes.c_bool(bool(o["init_coef_aux_pars_from_iid_model"])), est.ctypes.data_as(ctypes.c_void_p),
             ctypes.c_int(int(o["m_lbfgs"])),
             ctypes.c_double(float(o["delta_conv_mode_finding"]))))
@@ -256,6 +257,14 @@ class GPModel(object):
             return self
         _safe_call(_lib().GPB_OptimCovPar(self.handle, _dptr(y), fe_c))
         return self
+
+    def get_cg_preconditioner_type(self):
+        """The preconditioner of the iterative methods as the library resolved it (GPB_GetCGPreconditionerType; reference: GPModel.get_optim_params,
+        basic.py:5942-5946): "vadu" or "pivoted_cholesky"."""
+        buf = ctypes.create_string_buffer(256)
+        k = ctypes.c_int(0)
+        _safe_call(_lib().GPB_GetCGPreconditionerType(self.handle, buf, ctypes.byref(k)))
+        return buf.value.decode()
 
     def get_num_aux_pars(self):
         """Number of auxiliary parameters of the likelihood (GPB_GetNumAuxPars): 1 (the shape) for "gamma" / "negative_binomial", else 0."""

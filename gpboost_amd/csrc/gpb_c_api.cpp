@@ -132,6 +132,7 @@ struct REModelHip {
   std::vector<double> init_coef;     // init_coef of GPB_SetOptimConfig (non-Gaussian models with covariates: start of the lbfgs vector)
   bool init_coef_from_iid_model = true;   // init_coef_aux_pars_from_iid_model (re_model.cpp:345; the packages' default)
   std::string cg_preconditioner_type = "vadu";   // ParsePreconditionerAlias default for a non-Gaussian Vecchia model (re_model_template.h:7137)
+  int piv_chol_rank = 50;                         // fitc_piv_chol_preconditioner_rank_ for "pivoted_cholesky" (default_piv_chol_preconditioner_rank_, re_model_template.h:5922)
   std::vector<double> offset;                     // GPB_SetOffsetData (fixed_effects_, has_fixed_effects_; re_model_template.h:6318-6321)
   bool has_offset = false;
   std::vector<double> y_host;                     // the response as last passed in (original order, no offset subtracted): y_vec_ of the Gaussian model
@@ -195,6 +196,12 @@ std::string parse_likelihood_alias(const std::string& lik) {
 }
 int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial") ? 1 : 0; }
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
+// cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
+int laplace_push_preconditioner(REModelHip* mdl) {
+  if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->vif || mdl->eh) return 0;
+  if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : 0, mdl->piv_chol_rank)) return shim_error();
+  return 0;
+}
 int laplace_push_aux(REModelHip* mdl) {
   if (mdl->num_aux < 1) return 0;
   if (gpb_hip_vecchia_laplace_set_aux_pars(mdl->vh, mdl->aux_pars, mdl->num_aux)) return shim_error();
@@ -1319,7 +1326,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
                        const char* convergence_criterion, int num_covariates, double* init_coef, double /*lr_coef*/,
                        double /*acc_rate_coef*/, const char* optimizer_coef, int cg_max_num_it, int cg_max_num_it_tridiag,
                        double cg_delta_conv, int num_rand_vec_trace, bool /*reuse_rand_vec_trace*/, const char* cg_preconditioner_type,
-                       int seed_rand_vec_trace, int /*piv_chol_rank*/, double* init_aux_pars, bool estimate_aux_pars,
+                       int seed_rand_vec_trace, int piv_chol_rank, double* init_aux_pars, bool estimate_aux_pars,
                        bool init_coef_aux_pars_from_iid_model, const int* estimate_cov_par_index, int m_lbfgs,
                        double delta_conv_mode_finding) {
   C_API_BEGIN();
@@ -1407,9 +1414,16 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   else if (!near(delta_conv_mode_finding, -999.)) return set_error("delta_conv_mode_finding is not > 0, found = %g ", delta_conv_mode_finding);
   if (cg_preconditioner_type && mdl->likelihood != "gaussian") {
     const std::string pc = cg_preconditioner_type;
-    if (pc != "" && pc != "vadu" && pc != "Sigma_inv_plus_BtWB" && pc != "vecchia_approximation_with_replicates")   // ParsePreconditionerAlias
-      return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library (only 'vadu')", pc.c_str());
-    mdl->cg_preconditioner_type = "vadu";
+    // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu" and -- round 5 -- "pivoted_cholesky" are built
+    if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
+    else if (pc == "pivoted_cholesky" || pc == "piv_chol" || pc == "piv_chol_on_Sigma") mdl->cg_preconditioner_type = "pivoted_cholesky";
+    else return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library ('vadu' and 'pivoted_cholesky' are)", pc.c_str());
+    if (piv_chol_rank > 0) mdl->piv_chol_rank = piv_chol_rank;                      // re_model_template.h:900-914
+    else if (piv_chol_rank != -999) return set_error("fitc_piv_chol_preconditioner_rank is not > 0, found = %d ", piv_chol_rank);
+    else if (pc != "") mdl->piv_chol_rank = 50;
+    if (mdl->cg_preconditioner_type == "pivoted_cholesky" && !mdl->vif && !mdl->eh && mdl->piv_chol_rank > (mdl->n_re > 0 ? mdl->n_re : mdl->n))
+      return set_error("'fitc_piv_chol_preconditioner_rank' cannot be larger than the dimension of the mode (= number of unique locations) ");     // likelihoods.h:936-938
+    if (laplace_push_preconditioner(mdl)) return -1;
   }
   C_API_END();
 }

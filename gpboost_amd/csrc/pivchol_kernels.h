@@ -1,0 +1,33 @@
+// gpboost_amd/csrc/pivchol_kernels.h -- launch interface of pivchol_kernels.hip: the "pivoted_cholesky" preconditioner of the
+// Vecchia-Laplace iterative methods (reference: include/GPBoost/CG_utils.h:438-486, src/GPBoost/CG_utils.cpp:231-499,
+// include/GPBoost/likelihoods.h:16277-16296, :16389-16465, :16554-16611).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpb {
+
+// Layouts.  L: the rank-k factor [n][k] row-major, row = STORAGE slot of the point (the order of the Laplace vectors).  Block vectors:
+// [chunk][row][nc] (nc = 1: one plain column per chunk; 4: the probe block).  Small operands: [chunk][k][nc].
+int pc_parts(int n);                         // row slices of the tall-skinny reductions
+// pivoted Cholesky of the NON-approximated covariance var * k(a * dist) (PivotedCholsekyFactorizationSigma): one argmax + one update launch per column
+hipError_t pc_piv_init(int n, int k, double var, double* L, double* diag, int* pi, int* pos, int* done, hipStream_t st);
+// out2 = { point chosen at step m (as a double), sum |diag| over the points not yet chosen }; swaps pi / pos as the reference does
+hipError_t pc_piv_argmax(int n, int m, const double* diag, int* pi, int* pos, double* out2, hipStream_t st);
+hipError_t pc_piv_update(const double4* pts, const int* sigma, int n, int k, int m, int p, int cov, int d3, double var, double a, double* L, double* diag, int* done,
+                         hipStream_t st);
+// G (lower triangle, packed by rows: e = p (p + 1) / 2 + q) = L^T diag(W) L;  part: pc_parts(n) * k (k + 1) / 2 doubles of scratch
+hipError_t pc_gram(const double* L, const double* W, int n, int k, double* part, double* G, hipStream_t st);
+// x2[chunk][k][nc] = M * (L^T (W .* X));  M k x k row-major (the inverse of I_k + L^T W L);  part: ncol * pc_parts(n) * k * nc doubles of scratch
+hipError_t pc_ltwx(const double* L, const double* W, const double* M, const double* X, int n, int k, int ncol, int nc, double* part, double* x2, hipStream_t st);
+// out = W .* (X - L x2) [mode 0: P^-1 X with x2 from pc_ltwx],  X - L x2 [mode 1: W^-1 P^-1 X],  L x2 + X ./ sqrt(W) [mode 2: probe vectors with x2 = the k x t normals]
+hipError_t pc_combine(const double* L, const double* W, const double* X, const double* x2, int n, int k, int ncol, int nc, int mode, double* out, hipStream_t st);
+// out = x .* w (inv = 0) or x ./ w (inv = 1); v += h ./ w
+hipError_t pc_rowscale(const double* x, const double* w, int n, int ncol, int nc, int inv, double* out, hipStream_t st);
+hipError_t pc_add_div(double* v, const double* h, const double* w, int n, int ncol, int nc, hipStream_t st);
+hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st);      // out1[0] = max_i w[i] (NaN propagates)
+// d log|Sigma W + I| / d mode_i, pivoted_cholesky branch of CalcLogDetStochDerivModeVecchia (likelihoods.h:16554-16611): U = (W^-1 + Sigma)^-1 Z,
+// WIPIZ = W^-1 P^-1 Z, row-wise optimal c (CalcOptimalCVectorized), deterministic part diag(L M L^T) dW - dW / W
+hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
+                        double* dld, hipStream_t st);
+
+}  // namespace gpb

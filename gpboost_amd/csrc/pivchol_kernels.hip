@@ -1,0 +1,325 @@
+// gpboost_amd/csrc/pivchol_kernels.hip -- device side of cg_preconditioner_type = "pivoted_cholesky" for the Vecchia-Laplace approximation
+// (SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, include/GPBoost/re_model_template.h:5906).  The linear systems are solved in the form
+//     (W^-1 + Sigma) u' = Sigma rhs,  u = W^-1 u',   Sigma = B^-1 D B^-T   (CG_utils.cpp:231-343, :345-499)
+// preconditioned with P = W^-1 + L_k L_k^T, L_k the rank-k pivoted Cholesky factor of the non-approximated covariance matrix
+// (CG_utils.h:438-486): P^-1 r = W r - W L_k (I_k + L_k^T W L_k)^-1 L_k^T W r.  The k x k matrix M = (I_k + L_k^T W L_k)^-1 is formed on the host from
+// the Gram matrix these kernels reduce (k = 50 by default: a 20 KB problem), everything of size n stays on the device:
+//   * tall-skinny reductions  L^T (W .* X)  with fixed-order partial sums (bit-reproducible, no atomics),
+//   * rank-k updates          X - L x2      one row of L per thread, the small operand in LDS,
+//   * the factorisation itself: per column one argmax launch (first maximum in the reference's pivot order) and one update launch.
+// Sigma h is the existing pair of barrier-free triangular solves (lap_vadu with the diagonal D).
+#include "pivchol_kernels.h"
+
+#include <cmath>
+
+namespace gpb {
+namespace {
+
+__device__ __forceinline__ double pc_cov(int cov, double d, double var, double a) {       // cov_fcts.h:2100-2118 on the transformed scale
+  const double r = a * d;
+  if (cov == 0) return var * exp(-r);
+  if (cov == 1) return var * (1.0 + r) * exp(-r);
+  return var * (1.0 + r + r * r / 3.0) * exp(-r);
+}
+
+__global__ void pc_piv_init_kernel(int n, double var, double* __restrict__ diag, int* __restrict__ pi, int* __restrict__ pos, int* __restrict__ done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  diag[i] = var; pi[i] = i; pos[i] = i; done[i] = 0;      // GetZSigmaZtij(h, h) = the marginal variance (re_comp.h:1393-1395)
+}
+
+// Step m: the first maximum of diag over pi[m..n) in the order of pi (Eigen's maxCoeff on diag(pi.tail(n - m)), CG_utils.h:457), the L1 norm of
+// that tail (err of the previous step, :479), and the swap pi[m] <-> pi[i] (:459-461).  One workgroup.
+__global__ __launch_bounds__(1024) void pc_piv_argmax_kernel(int n, int m, const double* __restrict__ diag, int* __restrict__ pi, int* __restrict__ pos,
+                                                              double* __restrict__ out2) {
+  __shared__ double s_val[1024];
+  __shared__ double s_sum[1024];
+  __shared__ int s_pos[1024];
+  __shared__ int s_idx[1024];
+  const int tid = threadIdx.x;
+  double best = -INFINITY, sum = 0.0;
+  int bpos = 0x7fffffff, bidx = -1;
+  for (int i = tid; i < n; i += 1024) {
+    const int ps = pos[i];
+    if (ps < m) continue;
+    const double v = diag[i];
+    sum += fabs(v);
+    if (v > best || (v == best && ps < bpos) || bidx < 0) { best = v; bpos = ps; bidx = i; }
+  }
+  s_val[tid] = best; s_sum[tid] = sum; s_pos[tid] = bpos; s_idx[tid] = bidx;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if (tid < w) {
+      s_sum[tid] += s_sum[tid + w];
+      const double v = s_val[tid + w];
+      const int ps = s_pos[tid + w], ix = s_idx[tid + w];
+      if (ix >= 0 && (s_idx[tid] < 0 || v > s_val[tid] || (v == s_val[tid] && ps < s_pos[tid]))) { s_val[tid] = v; s_pos[tid] = ps; s_idx[tid] = ix; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int p = s_idx[0], i = s_pos[0], old = pi[m];
+    pi[m] = p; pi[i] = old; pos[p] = m; pos[old] = i;
+    out2[0] = (double)p; out2[1] = s_sum[0];
+  }
+}
+
+// Column m of the factor (CG_utils.h:463-481): for every point j not yet chosen,
+//   L_jm = Sigma(j, p) - L[j, :m] . L[p, :m];  unless |L_jm| < 1e-12: L_jm /= sqrt(diag[p]), stored;  diag[j] -= L_jm^2  (with the unscaled value in the other case, sic)
+// and L[p][m] = sqrt(diag[p]).  j, p: Vecchia positions; rows of L: storage slots (sigma).
+__global__ void pc_piv_update_kernel(const double4* __restrict__ pts, const int* __restrict__ sigma, int n, int k, int m, int p, int cov, int d3, double var, double a,
+                                     double* __restrict__ L, double* __restrict__ diag, int* __restrict__ done) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (done[j]) return;
+  const double dp = diag[p];
+  if (j == p) { L[(size_t)sigma[p] * k + m] = sqrt(dp); done[p] = 1; return; }
+  const double4 cj = pts[j], cp = pts[p];
+  const double ex = cj.x - cp.x, ey = cj.y - cp.y, ez = d3 ? cj.z - cp.z : 0.0;
+  double ljm = pc_cov(cov, sqrt(ex * ex + ey * ey + ez * ez), var, a);
+  const double* Lj = L + (size_t)sigma[j] * k;
+  const double* Lp = L + (size_t)sigma[p] * k;
+  if (m > 0) {
+    double sdot = 0.0;
+    for (int q = 0; q < m; ++q) sdot += Lj[q] * Lp[q];
+    ljm -= sdot;
+  }
+  if (!(fabs(ljm) < 1e-12)) { ljm /= sqrt(dp); L[(size_t)sigma[j] * k + m] = ljm; }
+  diag[j] -= ljm * ljm;
+}
+
+__device__ __forceinline__ void pc_slice(int n, int parts, int b, int& lo, int& hi) {
+  const int per = (n + parts - 1) / parts;
+  lo = b * per; hi = lo + per < n ? lo + per : n;
+  if (lo > n) lo = n;
+}
+
+// part[slice][e] = sum over the rows of the slice of L[i][p] W[i] L[i][q], e = p (p + 1) / 2 + q  (the lower triangle of L^T W L)
+__global__ void pc_gram_kernel(const double* __restrict__ L, const double* __restrict__ W, int n, int k, int npairs, double* __restrict__ part) {
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  int p = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+  while ((p + 1) * (p + 2) / 2 <= e) ++p;
+  while (p * (p + 1) / 2 > e) --p;
+  const int q = e - p * (p + 1) / 2;
+  int lo, hi;
+  pc_slice(n, (int)gridDim.x, (int)blockIdx.x, lo, hi);
+  double acc = 0.0;
+  for (int i = lo; i < hi; ++i) { const double* Li = L + (size_t)i * k; acc = __builtin_fma(Li[p] * W[i], Li[q], acc); }
+  part[(size_t)blockIdx.x * npairs + e] = acc;
+}
+__global__ void pc_gram_reduce_kernel(const double* __restrict__ part, int parts, int npairs, double* __restrict__ G) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  double s = 0.0;
+  for (int b = 0; b < parts; ++b) s += part[(size_t)b * npairs + e];      // fixed order
+  G[e] = s;
+}
+
+// part[chunk][slice][q][c] = sum over the rows of the slice of L[i][q] W[i] X[i][c]; 256 threads = 4 row groups x 64 columns of L
+template <int NC>
+__global__ __launch_bounds__(256) void pc_ltwx_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X, int n, int k,
+                                                        double* __restrict__ part) {
+  __shared__ double s[4][64][NC];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int chunk = blockIdx.y, parts = gridDim.x;
+  const double* Xc = X + (size_t)chunk * n * NC;
+  int lo, hi;
+  pc_slice(n, parts, (int)blockIdx.x, lo, hi);
+  for (int q0 = 0; q0 < k; q0 += 64) {
+    const int q = q0 + lane;
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    if (q < k) {
+      for (int i = lo + g; i < hi; i += 4) {
+        const double lw = L[(size_t)i * k + q] * W[i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(lw, Xc[(size_t)i * NC + c], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s[g][lane][c] = acc[c];
+    __syncthreads();
+    if (g == 0 && q < k) {
+      double* dst = part + (((size_t)chunk * parts + blockIdx.x) * k + q) * NC;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dst[c] = ((s[0][lane][c] + s[1][lane][c]) + s[2][lane][c]) + s[3][lane][c];
+    }
+    __syncthreads();
+  }
+}
+// x2[chunk][q][c] = sum_p M[q][p] y[p][c],  y = the slices' partial sums added in slice order
+template <int NC>
+__global__ __launch_bounds__(256) void pc_small_kernel(const double* __restrict__ part, int parts, const double* __restrict__ M, int k, double* __restrict__ x2) {
+  extern __shared__ double s_y[];                      // k * NC
+  const int chunk = blockIdx.x;
+  const int len = k * NC;
+  for (int e = threadIdx.x; e < len; e += 256) {
+    double acc = 0.0;
+    for (int b = 0; b < parts; ++b) acc += part[((size_t)chunk * parts + b) * len + e];
+    s_y[e] = acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < len; e += 256) {
+    const int q = e / NC, c = e % NC;
+    const double* Mq = M + (size_t)q * k;
+    double acc = 0.0;
+    for (int p = 0; p < k; ++p) acc = __builtin_fma(Mq[p], s_y[p * NC + c], acc);
+    x2[(size_t)chunk * len + e] = acc;
+  }
+}
+
+// one row per thread: acc = L[i, :] x2[:, c];  mode 0: W (X - acc), 1: X - acc, 2: acc + X / sqrt(W)
+template <int NC>
+__global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X,
+                                                           const double* __restrict__ x2, int n, int k, int mode, double* __restrict__ out) {
+  extern __shared__ double s_x2[];                     // k * NC
+  const int chunk = blockIdx.y;
+  const int len = k * NC;
+  for (int e = threadIdx.x; e < len; e += 256) s_x2[e] = x2[(size_t)chunk * len + e];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double* Li = L + (size_t)i * k;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  for (int q = 0; q < k; ++q) {
+    const double l = Li[q];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(l, s_x2[q * NC + c], acc[c]);
+  }
+  const size_t o = ((size_t)chunk * n + i) * NC;
+  const double w = W[i];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double x = X[o + c];
+    out[o + c] = mode == 0 ? w * x - w * acc[c] : (mode == 1 ? x - acc[c] : acc[c] + sqrt(1.0 / w) * x);
+  }
+}
+
+__global__ void pc_rowscale_kernel(const double* x, const double* __restrict__ w, int n, int nc, int inv, double* out) {       // x may be out
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const size_t o = (size_t)blockIdx.y * n * nc + g;
+  const double wi = w[g / nc];
+  out[o] = inv ? x[o] * (1.0 / wi) : wi * x[o];
+}
+__global__ void pc_add_div_kernel(double* __restrict__ v, const double* __restrict__ h, const double* __restrict__ w, int n, int nc) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const size_t o = (size_t)blockIdx.y * n * nc + g;
+  v[o] += (1.0 / w[g / nc]) * h[o];
+}
+
+__global__ __launch_bounds__(1024) void pc_wmax_kernel(const double* __restrict__ w, int n, double* __restrict__ out1) {
+  __shared__ double s[1024];
+  double best = -INFINITY;
+  bool nan = false;
+  for (int i = threadIdx.x; i < n; i += 1024) { const double v = w[i]; if (v != v) nan = true; if (v > best) best = v; }
+  s[threadIdx.x] = nan ? NAN : best;
+  __syncthreads();
+  for (int k = 512; k >= 1; k >>= 1) {
+    if (threadIdx.x < k) { const double a = s[threadIdx.x], b = s[threadIdx.x + k]; s[threadIdx.x] = (a != a || b != b) ? NAN : (a > b ? a : b); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out1[0] = s[0];
+}
+
+__global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* __restrict__ WIPIZ, const double* __restrict__ L, const double* __restrict__ M,
+                                    const double* __restrict__ W, const double* __restrict__ dW3, int n, int k, int t, int nc, double* __restrict__ dld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d3 = dW3[i], wi = 1.0 / W[i];
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < t; ++c) {
+    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
+    s1 += -1.0 * ((wi * U[o]) * d3 * WIPIZ[o]);
+    s2 += -1.0 * (WIPIZ[o] * d3 * WIPIZ[o]);
+  }
+  const double tr1 = s1 / t, trP = s2 / t;
+  double cv = 0.0, vr = 0.0;
+  for (int c = 0; c < t; ++c) {
+    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
+    const double a1 = -1.0 * ((wi * U[o]) * d3 * WIPIZ[o]) - tr1;
+    const double b1 = -1.0 * (WIPIZ[o] * d3 * WIPIZ[o]) - trP;
+    cv += a1 * b1; vr += b1 * b1;
+  }
+  cv /= t; vr /= t;
+  const double copt = (vr == 0.0) ? 1.0 : cv / vr;
+  // diag of L (I_k + L^T W L)^-1 L^T  (likelihoods.h:16583-16586)
+  const double* Li = L + (size_t)i * k;
+  double sdiag = 0.0;
+  for (int q = 0; q < k; ++q) {
+    const double* Mq = M + (size_t)q * k;
+    double acc = 0.0;
+    for (int p = 0; p < k; ++p) acc = __builtin_fma(Mq[p], Li[p], acc);
+    sdiag = __builtin_fma(Li[q], acc, sdiag);
+  }
+  const double trw = wi * d3;
+  dld[i] = tr1 + trw + copt * (sdiag * d3 - trw) - copt * trP;
+}
+
+}  // namespace
+
+int pc_parts(int n) { const int p = (n + 255) / 256; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+
+hipError_t pc_piv_init(int n, int k, double var, double* L, double* diag, int* pi, int* pos, int* done, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(L, 0, sizeof(double) * (size_t)n * k, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pc_piv_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, var, diag, pi, pos, done);
+  return hipGetLastError();
+}
+hipError_t pc_piv_argmax(int n, int m, const double* diag, int* pi, int* pos, double* out2, hipStream_t st) {
+  hipLaunchKernelGGL(pc_piv_argmax_kernel, dim3(1), dim3(1024), 0, st, n, m, diag, pi, pos, out2);
+  return hipGetLastError();
+}
+hipError_t pc_piv_update(const double4* pts, const int* sigma, int n, int k, int m, int p, int cov, int d3, double var, double a, double* L, double* diag, int* done,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(pc_piv_update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, sigma, n, k, m, p, cov, d3, var, a, L, diag, done);
+  return hipGetLastError();
+}
+hipError_t pc_gram(const double* L, const double* W, int n, int k, double* part, double* G, hipStream_t st) {
+  const int npairs = k * (k + 1) / 2, parts = pc_parts(n);
+  hipLaunchKernelGGL(pc_gram_kernel, dim3(parts, (npairs + 255) / 256), dim3(256), 0, st, L, W, n, k, npairs, part);
+  hipLaunchKernelGGL(pc_gram_reduce_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, part, parts, npairs, G);
+  return hipGetLastError();
+}
+hipError_t pc_ltwx(const double* L, const double* W, const double* M, const double* X, int n, int k, int ncol, int nc, double* part, double* x2, hipStream_t st) {
+  const int parts = pc_parts(n);
+  const size_t lds = sizeof(double) * (size_t)k * nc;
+  if (nc == 4) {
+    hipLaunchKernelGGL(pc_ltwx_kernel<4>, dim3(parts, ncol), dim3(256), 0, st, L, W, X, n, k, part);
+    hipLaunchKernelGGL(pc_small_kernel<4>, dim3(ncol), dim3(256), lds, st, part, parts, M, k, x2);
+  } else {
+    hipLaunchKernelGGL(pc_ltwx_kernel<1>, dim3(parts, ncol), dim3(256), 0, st, L, W, X, n, k, part);
+    hipLaunchKernelGGL(pc_small_kernel<1>, dim3(ncol), dim3(256), lds, st, part, parts, M, k, x2);
+  }
+  return hipGetLastError();
+}
+hipError_t pc_combine(const double* L, const double* W, const double* X, const double* x2, int n, int k, int ncol, int nc, int mode, double* out, hipStream_t st) {
+  const size_t lds = sizeof(double) * (size_t)k * nc;
+  if (nc == 4) hipLaunchKernelGGL(pc_combine_kernel<4>, dim3((n + 255) / 256, ncol), dim3(256), lds, st, L, W, X, x2, n, k, mode, out);
+  else hipLaunchKernelGGL(pc_combine_kernel<1>, dim3((n + 255) / 256, ncol), dim3(256), lds, st, L, W, X, x2, n, k, mode, out);
+  return hipGetLastError();
+}
+hipError_t pc_rowscale(const double* x, const double* w, int n, int ncol, int nc, int inv, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(pc_rowscale_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, x, w, n, nc, inv, out);
+  return hipGetLastError();
+}
+hipError_t pc_add_div(double* v, const double* h, const double* w, int n, int ncol, int nc, hipStream_t st) {
+  hipLaunchKernelGGL(pc_add_div_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, v, h, w, n, nc);
+  return hipGetLastError();
+}
+hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st) {
+  hipLaunchKernelGGL(pc_wmax_kernel, dim3(1), dim3(1024), 0, st, w, n, out1);
+  return hipGetLastError();
+}
+hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
+                        double* dld, hipStream_t st) {
+  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld);
+  return hipGetLastError();
+}
+
+}  // namespace gpb

@@ -208,6 +208,11 @@ class VecchiaState(object):
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
         self._lap_link = lid
 
+    def laplace_set_preconditioner(self, cg_preconditioner_type="vadu", rank=-999):
+        """cg_preconditioner_type of the iterative methods: "vadu" or "pivoted_cholesky" with `rank` columns (gpb_hip_vecchia_laplace_set_preconditioner)."""
+        t = {"vadu": 0, "pivoted_cholesky": 1}[cg_preconditioner_type]
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_preconditioner(self.h, C.c_int(t), C.c_int(int(rank))))
+
     def laplace_set_response_real(self, y):
         """gamma: the real-valued response (> 0), in the order laplace_set_labels takes its labels."""
         y = np.ascontiguousarray(y, dtype=np.float64)

@@ -436,6 +436,13 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, con
  * include/GPBoost/likelihoods.h:11394-11404 and their derivatives :12468-12474, :13293-13305, :13800-13820).  on != 0 here adds the binomial normalising constant
  * sum lgamma(w + 1) - lgamma(k + 1) - lgamma(w - k + 1), k = w y (:10612-10622). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on);
+/* cg_preconditioner_type of the iterative methods (round 5; SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, include/GPBoost/re_model_template.h:5906): type 0 = "vadu"
+ * (P = B^T (D^-1 + W) B; the solves in the form (Sigma^-1 + W) u = rhs, src/GPBoost/CG_utils.cpp:21-229), 1 = "pivoted_cholesky" (P = W^-1 + L_k L_k^T with the
+ * rank-k pivoted Cholesky factor of the non-approximated covariance matrix, include/GPBoost/CG_utils.h:438-486; the solves in the form (W^-1 + Sigma) u' = Sigma rhs,
+ * u = W^-1 u', CG_utils.cpp:231-499; log-determinant and gradients: include/GPBoost/likelihoods.h:16389-16465, :16554-16611, :16716-16736).  rank =
+ * fitc_piv_chol_preconditioner_rank_ (<= 0: the reference's default 50, re_model_template.h:5922); it may not exceed the number of random effects.  Takes effect at the
+ * next evaluation; evaluation, gradients (covariance parameters, auxiliary parameter, fixed effects) follow it, predictions keep solving with "vadu". */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t* h, int type, int rank);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);

@@ -126,6 +126,48 @@ def laplace_grad_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
 
 
+def laplace_pivchol_fixture(out_dir):
+    """cg_preconditioner_type = "pivoted_cholesky" (the (W^-1 + Sigma) form of the Vecchia-Laplace solves, P = W^-1 + L_k L_k^T; CG_utils.cpp:231-499,
+    likelihoods.h:16277-16296, :16389-16465, :16554-16611, :16716-16736) on cases.LAPLACE_PIVCHOL_CASES, from the reference's own routines:
+      *_negll_direct, *_grad_direct   value and gradient wrt (log sigma1^2, log a[, log aux]) from CalcGradPars at cases.LAPLACE_TIGHT (+ *_fe_* with the offset)
+      *_negll_default                  GPB_EvalNegLogLikelihood at the reference's default thresholds
+      *_gradF                          the boosting gradient d(-mll) / dF at cases.LAPLACE_TIGHT (data order)
+      *_fit_*                          one lbfgs fit at cases.LAPLACE_TIGHT: estimates, iterations, final value"""
+    res = {}
+    tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode_finding=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    for name, pc in cases.LAPLACE_PIVCHOL_CASES.items():
+        c = cases.LAPLACE_CASES[pc["model"]]
+        coords, y = cases.make_pivchol_data(pc)
+        cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+        rank = -999 if pc["rank"] is None else int(pc["rank"])
+        aux = pc.get("aux")
+        pcargs = dict(cg_preconditioner_type="pivoted_cholesky", piv_chol_rank=rank)
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
+            nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, pc["lik"], fe, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"],
+                                                    aux_pars=aux, estimate_aux=aux is not None, **tight, **pcargs)
+            res[name + fe_key + "_negll_direct"] = np.float64(nll); res[name + fe_key + "_grad_direct"] = g
+            print("pivoted_cholesky (CalcGradPars, tight)", name, fe_key, "%.12f" % nll, g, flush=True)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, **pcargs)
+        res[name + "_negll_default"] = np.float64(mdl.neg_log_likelihood(cp, y))
+        print("pivoted_cholesky (default thresholds)", name, "%.12f" % res[name + "_negll_default"], flush=True)
+        if aux is None:
+            res[name + "_gradF"] = refdrv.ref_laplace_grad_F(coords, y, cp, pc["lik"], None, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"],
+                                                             **tight, **pcargs)
+        # one lbfgs fit (the reference's default optimiser for these models) at the tight thresholds
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(init_aux_pars=None, estimate_aux_pars=aux is not None, **tight, **pcargs)
+        mdl.optim_cov_par(y)
+        res[name + "_fit_cov_pars"] = mdl.get_cov_par(2)
+        res[name + "_fit_num_it"] = np.int64(mdl.get_num_it())
+        res[name + "_fit_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        res[name + "_fit_init_cov_pars"] = mdl.get_init_cov_par()
+        if aux is not None:
+            res[name + "_fit_aux"] = mdl.get_aux_pars(1); res[name + "_fit_init_aux"] = mdl.get_init_aux_pars(1)
+        print("pivoted_cholesky fit", name, res[name + "_fit_cov_pars"], res.get(name + "_fit_aux"), int(res[name + "_fit_num_it"]), "%.10f" % res[name + "_fit_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_pivchol_ref.npz"), **res)
+
+
 def laplace_aux_fixture(out_dir):
     """gamma and negative_binomial Vecchia-Laplace models (auxiliary shape parameter estimated with the covariance parameters): the reference's own
       *_negll_0                      GPB_EvalNegLogLikelihood at (cov_pars, aux) with the default thresholds
@@ -1068,6 +1110,8 @@ if __name__ == "__main__":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_weights":
         laplace_weights_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":
+        laplace_pivchol_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":
         laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":

@@ -536,6 +536,48 @@ class sample_weights(object):
         return False
 
 
+_PROBE_RUN_ID = 0      # cg_generator_counter_ at the time rand_vec_trace_I_ is drawn: 0, or 1 when rand_vec_trace_I2_ was drawn first (pivoted_cholesky)
+
+
+def pivoted_cholesky_factor(coords, cov_type, var, a, rank=50, err_tol=1e-6):
+    """PivotedCholsekyFactorizationSigma (CG_utils.h:438-486; PIV_CHOL_STOP_TOL = 1e-6, utils.h:44) of the non-approximated covariance matrix
+    var * k(a * dist) of the points `coords` (Vecchia order): -> L_k (n, k) Fortran-ordered, k <= rank the number of columns computed."""
+    co = np.asfortranarray(coords, dtype=np.float64)
+    n, d = co.shape
+    k = min(int(rank), n)
+    L = np.zeros((n, k), order="F")
+    fn = lib().orc_pivoted_cholesky
+    fn.restype = C.c_int
+    kk = fn(_p(co, C.c_double), C.c_int(n), C.c_int(d), C.c_int(cov_type), C.c_double(var), C.c_double(a), C.c_int(k), C.c_double(err_tol), _p(L, C.c_double))
+    return L, int(kk)
+
+
+class pivoted_cholesky_preconditioner(object):
+    """`with orc.pivoted_cholesky_preconditioner(coords, cov_type, var, a, rank, num_rand_vec, seed_rand): ...` -- the Vecchia-Laplace oracle calls inside
+    the block use cg_preconditioner_type = "pivoted_cholesky" (the (W^-1 + Sigma) form of the solves, P = W^-1 + L_k L_k^T; likelihoods.h:16277-16296,
+    :16389-16465, :16554-16611, :16716-16736) at the covariance parameters (var, a): the factor is the one of THESE parameters, as the reference recomputes it
+    before every mode finding (re_model_template.h:9317-9322).  rand_vec_trace_I2_ (k x t) is drawn first (generator counter 0), rand_vec_trace_I_ second (1)."""
+
+    def __init__(self, coords, cov_type, var, a, rank=50, num_rand_vec=50, seed_rand=1):
+        self.L, self.k = pivoted_cholesky_factor(coords, cov_type, var, a, rank)
+        # the reference sizes rand_vec_trace_I2_ by fitc_piv_chol_preconditioner_rank_ (likelihoods.h:3996) and multiplies with all `rank` columns (zeros beyond k)
+        self.rv2 = gen_rand_normal(self.L.shape[1], num_rand_vec, seed_rand, 0)
+
+    def __enter__(self):
+        global _PROBE_RUN_ID
+        fn = lib().orc_set_pivchol
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        fn(self.L.ctypes.data, self.L.shape[1], self.rv2.ctypes.data)
+        _PROBE_RUN_ID = 1
+        return self
+
+    def __exit__(self, *exc):
+        global _PROBE_RUN_ID
+        lib().orc_clear_pivchol()
+        _PROBE_RUN_ID = 0
+        return False
+
+
 class _aux_context(object):
     """orc_set_aux / orc_clear_aux around a call for the likelihoods with an auxiliary parameter (link >= 3); a no-op otherwise."""
 
@@ -567,7 +609,7 @@ def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, se
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
     yi, yd = _responses(likelihood, y01)
-    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0) if rand_vec is None else np.asfortranarray(rand_vec)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, _PROBE_RUN_ID) if rand_vec is None else np.asfortranarray(rand_vec)
     out = np.empty(6); mode = np.empty(n)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     with _aux_context(link, aux, yd, None):
@@ -629,7 +671,7 @@ def vecchia_laplace_dup(coords_u, nn, cov_type, var, a, unique_idx, y, num_rand_
     fe = None if fixed_effects is None else np.ascontiguousarray(np.asarray(fixed_effects, dtype=np.float64)[order])
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
-    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, _PROBE_RUN_ID)
     out = np.empty(6); mode = np.zeros(n)
     if grad:
         A, D, Ag, Dg, bad = vecchia_factor(coords_u, nn, cov_type, var, a, gauss=False, grad=True)
@@ -661,7 +703,7 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
     n, m = nn.shape
     yi, yd = _responses(likelihood, y01)
     aux_g4 = np.zeros(4) if link >= 3 else None
-    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, _PROBE_RUN_ID)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     out = np.empty(6); g = np.empty(2)
     mode = np.zeros(n) if mode_init is None else np.ascontiguousarray(mode_init, dtype=np.float64).copy()
@@ -858,7 +900,7 @@ def vecchia_laplace_dup_grad_F(coords_u, nn, cov_type, var, a, unique_idx, y, li
     fe = None if fixed_effects is None else np.ascontiguousarray(np.asarray(fixed_effects, dtype=np.float64)[order])
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
-    rv = gen_rand_normal(n, num_rand_vec, seed_rand, 0)
+    rv = gen_rand_normal(n, num_rand_vec, seed_rand, _PROBE_RUN_ID)
     A, D, Ag, Dg, bad = vecchia_factor(coords_u, nn, cov_type, var, a, gauss=False, grad=True)
     out = np.empty(6); g = np.empty(2); mode = np.zeros(n); dbg = np.zeros(2 * n + 8)
     rc = lib().orc_vecchia_laplace_grad_map_dbg(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double), _p(nn, C.c_int),

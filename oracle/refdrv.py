@@ -158,7 +158,8 @@ class RefCAPIModel(object):
     def set_optim_config(self, init_cov_pars=None, lr_cov=-999., acc_rate_cov=-999., max_iter=-999, delta_rel_conv=-999.,
                          use_nesterov_acc=True, nesterov_schedule_version=-999, trace=False, optimizer_cov="", momentum_offset=-999,
                          convergence_criterion="default", m_lbfgs=-999, cg_delta_conv=-999., delta_conv_mode_finding=-999.,
-                         init_coef_aux_pars_from_iid_model=False, estimate_cov_par_index=None, init_aux_pars=None, estimate_aux_pars=False):
+                         init_coef_aux_pars_from_iid_model=False, estimate_cov_par_index=None, init_aux_pars=None, estimate_aux_pars=False,
+                         cg_preconditioner_type="vadu", piv_chol_rank=-999):
         """GPB_SetOptimConfig with the argument order of include/LightGBM/c_api.h:1437-1467 (basic.py:5460-5496 binds it the same way)."""
         s = lambda x: C.c_char_p(x.encode())
         ic = None if init_cov_pars is None else np.ascontiguousarray(init_cov_pars, dtype=np.float64)
@@ -168,7 +169,7 @@ class RefCAPIModel(object):
             self.h, C.c_void_p() if ic is None else _P(ic), C.c_double(lr_cov), C.c_double(acc_rate_cov), C.c_int(max_iter),
             C.c_double(delta_rel_conv), C.c_bool(use_nesterov_acc), C.c_int(nesterov_schedule_version), C.c_bool(trace), s(optimizer_cov),
             C.c_int(momentum_offset), s(convergence_criterion), C.c_int(0), C.c_void_p(), C.c_double(-999.), C.c_double(-999.), s(""),
-            C.c_int(-999), C.c_int(-999), C.c_double(cg_delta_conv), C.c_int(-999), C.c_bool(True), s("vadu"), C.c_int(1), C.c_int(-999),
+            C.c_int(-999), C.c_int(-999), C.c_double(cg_delta_conv), C.c_int(-999), C.c_bool(True), s(cg_preconditioner_type), C.c_int(1), C.c_int(piv_chol_rank),
             C.c_void_p() if ia is None else _P(ia), C.c_bool(bool(estimate_aux_pars)), C.c_bool(bool(init_coef_aux_pars_from_iid_model)), _P(est), C.c_int(m_lbfgs),
             C.c_double(delta_conv_mode_finding))
         if rc != 0:
@@ -303,12 +304,14 @@ def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponent
 
 
 def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
-                         threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., aux_pars=None, estimate_aux=False, weights=None):
+                         threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., aux_pars=None, estimate_aux=False, weights=None,
+                         cg_preconditioner_type="vadu", piv_chol_rank=-999):
     """(negll, grad): the reference's approximate negative marginal log-likelihood and its gradient wrt (log sigma1^2, log a[, log aux...]) at
     cov_pars = (sigma1^2, rho), from the reference's OWN CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia
     (ref_driver.cpp: refdrv_laplace_nll_grad) with the solver thresholds given -- the pin of orc_vecchia_laplace_grad and of the device gradient."""
     mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
-    mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding, init_aux_pars=aux_pars, estimate_aux_pars=estimate_aux)
+    mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding, init_aux_pars=aux_pars, estimate_aux_pars=estimate_aux,
+                         cg_preconditioner_type=cg_preconditioner_type, piv_chol_rank=piv_chol_rank)
     y = np.ascontiguousarray(y, dtype=np.float64)
     cp = np.ascontiguousarray(cov_pars, dtype=np.float64)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
@@ -323,12 +326,13 @@ def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, co
 
 
 def ref_laplace_grad_F(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
-                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., weights=None):
+                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., weights=None, cg_preconditioner_type="vadu", piv_chol_rank=-999):
     """The reference's boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF in data order, at cov_pars =
     (sigma1^2, rho) and the fixed effects F (zero if None): REModel::CalcGradient on a model of the reference's own C API (ref_driver.cpp:
     refdrv_laplace_grad_F)."""
     mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
-    mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding)
+    mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding,
+                         cg_preconditioner_type=cg_preconditioner_type, piv_chol_rank=piv_chol_rank)
     y = np.ascontiguousarray(y, dtype=np.float64)
     fe = np.zeros_like(y) if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     out = np.empty_like(y)

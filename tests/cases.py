@@ -135,6 +135,26 @@ LAPLACE_WEIGHT_CASES.update(LAPLACE_PROP_CASES)
 LAPLACE_PROP_CASES_LIKS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
 
 
+# Preconditioner "pivoted_cholesky" of the Vecchia-Laplace iterative methods (round 5; re_model_template.h:5906, the (W^-1 + Sigma) form of the solves,
+# CG_utils.cpp:231-499): name -> LAPLACE_CASES model, likelihood, rank of the pivoted Cholesky factor (None: the reference's default 50), optional auxiliary
+# parameter (gamma / negative_binomial draw their responses as LAPLACE_AUX_CASES does).  Fixture: tests/golden/laplace_pivchol_ref.npz.
+LAPLACE_PIVCHOL_CASES = {
+    "pc_logit_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="bernoulli_logit", rank=None),
+    "pc_poisson_n1500_r20": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", rank=20),
+    "pc_probit_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="bernoulli_probit", rank=None),
+    "pc_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", rank=None, aux=2.0, true_aux=2.5),
+    "pc_negbin_n2000_r30": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", rank=30, aux=3.0, true_aux=4.0),
+}
+
+
+def make_pivchol_data(pc):
+    """-> (coords, y) in DATA order for a LAPLACE_PIVCHOL_CASES entry."""
+    c = LAPLACE_CASES[pc["model"]]
+    if "aux" in pc:
+        return make_aux_data(pc)
+    return make_count_data(c) if pc["lik"] == "poisson" else make_binary_data(c)
+
+
 def make_weight_data(wc):
     """-> (coords, y, weights) in DATA order for a LAPLACE_WEIGHT_CASES entry."""
     c = LAPLACE_CASES[wc["model"]]

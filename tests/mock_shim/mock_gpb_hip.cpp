@@ -31,6 +31,9 @@ void orc_set_aux(double aux, const double* y_real, double* aux_grad4);
 void orc_set_weights(const double* w);
 void orc_set_binomial(int on);
 void orc_clear_aux(void);
+int orc_pivoted_cholesky(const double* coords, int n, int d, int cov_type, double var, double a, int max_it, double err_tol, double* L_out);
+void orc_set_pivchol(const double* L_k, int k, const double* rand_vec2);
+void orc_clear_pivchol(void);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
                                      int cg_max_num_it_tridiag, double cg_delta_conv, double delta_conv_mode_finding, double* out6, double* grad2,
@@ -105,6 +108,7 @@ struct gpb_hip_vecchia {
   double wv(int k) const { return weights.empty() ? 1.0 : weights[k]; }
   std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
   bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
+  int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns
   double yv(int k) const { return (link == 3 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
@@ -204,7 +208,17 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   orc_vecchia_factor(h->coords.data(), n, h->d, h->nn.data(), m, cov, var, a, 0, h->A.data(), h->D.data(), Ag.data(), Dg.data());
   h->has_factor = true; h->f_gauss = 0;
   std::vector<double> rv((size_t)n * nrv);
-  orc_gen_rand_normal(seed, 0ull, n, nrv, rv.data());
+  // pivoted_cholesky: L_k at these parameters, rand_vec_trace_I2_ drawn first (generator counter 0), rand_vec_trace_I_ second (1)
+  std::vector<double> pcL, rv2;
+  const bool pc = h->pc_type == 1;
+  if (pc) {
+    const int k = std::min(h->pc_rank, n);
+    pcL.assign((size_t)n * k, 0.); rv2.assign((size_t)k * nrv, 0.);
+    orc_pivoted_cholesky(h->coords.data(), n, h->d, cov, var, a, k, 1e-6, pcL.data());
+    orc_gen_rand_normal(seed, 0ull, k, nrv, rv2.data());
+    orc_set_pivchol(pcL.data(), k, rv2.data());
+  }
+  orc_gen_rand_normal(seed, pc ? 1ull : 0ull, n, nrv, rv.data());
   std::vector<int> dptr;
   if (mapped) dptr = h->re_ptr; else { dptr.resize(n + 1); std::iota(dptr.begin(), dptr.end(), 0); }
   const bool warm = !reset && h->has_mode;
@@ -220,6 +234,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
                                                   dbg.data());
   if (ctx) orc_clear_aux();
   orc_set_binomial(0);
+  if (pc) orc_clear_pivchol();
   if (rc) return fail("NaN or Inf occurred in the mode finding algorithm for the Laplace approximation");
   h->mode = mode; h->has_mode = true; h->grad_state = true;
   h->dld.assign(dbg.begin(), dbg.begin() + n); h->sv.assign(dbg.begin() + n, dbg.begin() + 2 * n);
@@ -447,6 +462,13 @@ EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const
   h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->real_resp = true; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on) { h->binomial = on != 0; return 0; }
+EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t* h, int type, int rank) {
+  if (type != 0 && type != 1) return fail("preconditioner type %d is not on this path (0 = vadu, 1 = pivoted_cholesky)", type);
+  const int rk = rank > 0 ? rank : 50;
+  if (type == 1 && rk > h->n) return fail("'fitc_piv_chol_preconditioner_rank' cannot be larger than the dimension of the mode (= number of unique locations) ");
+  if (h->pc_type != type || h->pc_rank != rk) h->grad_state = false;
+  h->pc_type = type; h->pc_rank = rk; return 0;
+}
 EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w) {
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   if (!w) { h->weights.clear(); orc_set_weights(nullptr); h->grad_state = false; return 0; }

@@ -56,6 +56,14 @@ def test_auxiliary_parameter_likelihoods_through_the_c_api_on_the_cpu_restatemen
     assert "5 passed" in tail, tail
 
 
+def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):
+    """Round 5: cg_preconditioner_type = "pivoted_cholesky" through the model surface (GPB_SetOptimConfig(cg_preconditioner_type, piv_chol_rank) incl.
+    ParsePreconditionerAlias and the rank checks, GPB_GetCGPreconditionerType, GPB_EvalNegLogLikelihood, GPB_OptimCovPar): the host code under
+    tests/test_zz_laplace_pivchol_gpu.py's model-API tests, against the reference's fixtures, with the oracle-backed shim."""
+    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_pivchol_gpu.py"], extra=["-k", "model_api"])
+    assert "6 passed" in tail, tail
+
+
 ROUTE_A_DRIVER = r'''
 import json, sys, types
 sys.modules.setdefault("optuna", types.ModuleType("optuna"))       # optional dependency of the reference's package, absent here

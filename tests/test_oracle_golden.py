@@ -670,3 +670,70 @@ def test_oracle_weighted_non_gaussian_value_and_gradient_match_the_reference(orc
     if w is not None and not wc["lik"].startswith("binomial"):
         nll_u, _ = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=wc["lik"], aux=wc.get("aux"), **tight)
         assert abs(nll_u - float(g[name + "_negll_direct"])) > 1.0
+
+
+# ---- cg_preconditioner_type = "pivoted_cholesky" (round 5; the second preconditioner of SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_) ----------------------
+def _pivchol_setup(orc, name):
+    pc = cases.LAPLACE_PIVCHOL_CASES[name]
+    c = cases.LAPLACE_CASES[pc["model"]]
+    coords, y = cases.make_pivchol_data(pc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    return pc, c, coords, y, perm, co, nn, ct, cp, a, (50 if pc["rank"] is None else pc["rank"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_PIVCHOL_CASES))
+def test_oracle_pivoted_cholesky_preconditioner_matches_the_reference(orc, name):
+    """The (W^-1 + Sigma) form of the Vecchia-Laplace solves with P = W^-1 + L_k L_k^T (orc.pivoted_cholesky_preconditioner: PivotedCholsekyFactorizationSigma,
+    CGVecchiaLaplace_Version_SigmaPlusWinvVec, CGTridiagVecchiaLaplace_Version_SigmaPlusWinv, the pivoted_cholesky branches of CalcLogDetStochVecchia /
+    CalcLogDetStochDerivModeVecchia / CalcLogDetStochDerivCovParVecchia) against the reference's own CalcGradPars at cases.LAPLACE_TIGHT
+    (tests/golden/laplace_pivchol_ref.npz, oracle/make_golden.py laplace_pivchol): value 1e-9, gradient (incl. the auxiliary parameter's component) 1e-8,
+    without and with fixed effects; the boosting gradient 1e-8 of its scale; GPB_EvalNegLogLikelihood at the default thresholds 1e-6 (stopping-rule noise)."""
+    g = np.load(os.path.join(GOLD, "laplace_pivchol_ref.npz"))
+    pc, c, coords, y, perm, co, nn, ct, cp, a, rank = _pivchol_setup(orc, name)
+    tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    with orc.pivoted_cholesky_preconditioner(co, ct, cp[0], a, rank=rank) as ctx:
+        assert ctx.k >= 1
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+            nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], fixed_effects=fe, aux=pc.get("aux"), **tight)
+            ref = g[name + fe_key + "_grad_direct"]
+            assert grad_t.shape == ref.shape
+            np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+            ref_v = float(g[name + fe_key + "_negll_direct"])
+            # (1e-9, not the 1e-10 of the vadu tests: the residual norm the CG stops on is the one of the (W^-1 + Sigma) system -- seen 2e-10 on the gamma case with fixed effects)
+            assert abs(nll_t - ref_v) <= 1e-9 * abs(ref_v), (nll_t, ref_v)
+        negll_d, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"))
+        ref_d = float(g[name + "_negll_default"])
+        assert abs(negll_d - ref_d) <= 1e-6 * abs(ref_d), (negll_d, ref_d)
+        if name + "_gradF" in g.files:
+            gF = orc.vecchia_laplace_grad_F(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], **tight)
+            out = np.empty_like(gF); out[perm] = gF
+            np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=1e-8 * np.abs(g[name + "_gradF"]).max())
+    # the preconditioner is gone with the context: the vadu value differs in the stochastic part only
+    nll_v, _ = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"), **tight)
+    assert abs(nll_v - float(g[name + "_negll_direct"])) <= 2e-2 * abs(nll_v) and nll_v != float(g[name + "_negll_direct"])
+
+
+def test_oracle_pivoted_cholesky_factor_properties(orc):
+    """PivotedCholsekyFactorizationSigma: L_k L_k^T reproduces the pivot rows / columns of the covariance matrix exactly, the residual diagonal is >= 0 and its trace
+    decreases with the rank; rank n reproduces the whole matrix."""
+    rng = np.random.default_rng(3)
+    n = 300
+    co = rng.uniform(size=(n, 2))
+    var, a = 1.3, 1.0 / 0.2
+    d = np.sqrt(((co[:, None, :] - co[None, :, :]) ** 2).sum(-1))
+    S = var * np.exp(-a * d)
+    tr = []
+    for rank in (5, 20, 60):
+        L, k = orc.pivoted_cholesky_factor(co, 0, var, a, rank=rank)
+        assert k == rank and L.shape == (n, rank)
+        R = S - L @ L.T
+        assert np.diag(R).min() > -1e-12
+        piv = [int(np.argmax(np.abs(L[:, q]) * (np.count_nonzero(L[:, :q], axis=1) == 0))) for q in range(1)]      # the first pivot: the first point (all diagonals equal)
+        assert piv[0] == 0
+        tr.append(np.trace(R))
+    assert tr[0] > tr[1] > tr[2] > 0
+    Lf, kf = orc.pivoted_cholesky_factor(co[:40], 0, var, a, rank=40, err_tol=0.0)
+    np.testing.assert_allclose(Lf @ Lf.T, S[:40, :40], atol=1e-10)

@@ -1,0 +1,164 @@
+"""GPU (MI355X): cg_preconditioner_type = "pivoted_cholesky" on the Vecchia-Laplace path (the second entry of the reference's
+SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, re_model_template.h:5906) -- the solves in the form (W^-1 + Sigma) u' = Sigma rhs preconditioned with
+P = W^-1 + L_k L_k^T (pivchol_kernels.hip, gpb_laplace.inc) -- through the C ABI against the UNMODIFIED reference (tests/golden/laplace_pivchol_ref.npz,
+oracle/make_golden.py laplace_pivchol):
+  * the factor L_k itself against the oracle's restatement of PivotedCholsekyFactorizationSigma;
+  * value + gradient wrt (log sigma1^2, log a[, log aux]) at cases.LAPLACE_TIGHT from the reference's own CalcGradPars: 1e-8 relative, without and with fixed
+    effects; the boosting gradient 1e-8 of its scale; the value at the reference's default thresholds;
+  * the oracle step by step (d logdet / d mode, the implicit solve, the per-parameter parts);
+  * fits through the model surface (GPB_SetOptimConfig(cg_preconditioner_type, piv_chol_rank)): the reference's iteration counts and estimates.
+(File name: sorts last -- added in round 5.)"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RC = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}
+TIGHT_ORC = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+def _state(orc, pc):
+    from gpboost_amd import shim
+    c = cases.LAPLACE_CASES[pc["model"]]
+    coords, y = cases.make_pivchol_data(pc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood(pc["lik"])
+    if pc["lik"] == "gamma":
+        st.laplace_set_response_real(y[perm])
+    else:
+        st.laplace_set_labels(y[perm].astype(np.int32))
+    if "aux" in pc:
+        st.laplace_set_aux(pc["aux"])
+    rank = 50 if pc["rank"] is None else pc["rank"]
+    st.laplace_set_preconditioner("pivoted_cholesky", -999 if pc["rank"] is None else pc["rank"])
+    return st, c, coords, y, perm, co, nn, ct, rank
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_PIVCHOL_CASES))
+def test_value_and_gradient_match_the_reference(gpb, orc, name):
+    pc = cases.LAPLACE_PIVCHOL_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_pivchol_ref.npz"))
+    st, c, coords, y, perm, co, nn, ct, rank = _state(orc, pc)
+    cp = c["cov_pars"][0]
+    a = RC[ct] / cp[1]
+    negll, info = st.laplace_logit(ct, cp[0], a)
+    ref_d = float(g[name + "_negll_default"])
+    assert abs(negll - ref_d) <= 1e-6 * abs(ref_d), (negll, ref_d)       # default thresholds: two correct implementations stop one CG iteration apart
+    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+        st.laplace_set_fixed_effects(fe)
+        nll_t, grad_t = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+        ref = g[name + fe_key + "_grad_direct"]
+        assert grad_t.shape == ref.shape
+        np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+        ref_v = float(g[name + fe_key + "_negll_direct"])
+        assert abs(nll_t - ref_v) <= 1e-8 * abs(ref_v), (nll_t, ref_v)
+    if name + "_gradF" in g.files:
+        st.laplace_set_fixed_effects(None)
+        st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+        out = np.empty(len(y)); out[perm] = st.laplace_grad_F()
+        np.testing.assert_allclose(out, g[name + "_gradF"], rtol=0, atol=1e-8 * np.abs(g[name + "_gradF"]).max())
+    # back to "vadu" on the same handle: the values of the vadu fixtures' oracle
+    st.laplace_set_fixed_effects(None)
+    st.laplace_set_preconditioner("vadu")
+    nll_v, grad_v = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+    on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"), **TIGHT_ORC)
+    assert abs(nll_v - on) <= 1e-8 * abs(on), (nll_v, on)
+    np.testing.assert_allclose(grad_v, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+    st.close()
+
+
+@pytest.mark.parametrize("name", ["pc_logit_n2000", "pc_poisson_n1500_r20"])
+def test_steps_of_the_gradient_match_the_oracle(gpb, orc, name):
+    """d logdet / d mode with the row-wise control variate of the pivoted_cholesky branch, the implicit solve in the (W^-1 + Sigma) form, and per parameter
+    {mode' SigmaI_deriv mode, d logdet / d theta, implicit part} against orc_vecchia_laplace_grad inside orc.pivoted_cholesky_preconditioner; at other
+    covariance parameters than the fixture's (the factor L_k is renewed by every evaluation), with a warm start."""
+    pc = cases.LAPLACE_PIVCHOL_CASES[name]
+    st, c, coords, y, perm, co, nn, ct, rank = _state(orc, pc)
+    for var, rho, reset in ((c["cov_pars"][0][0], c["cov_pars"][0][1], True), (0.6, 0.22, False)):
+        a = RC[ct] / rho
+        nll, grad, parts = st.laplace_eval_grad(ct, var, a, reset_mode=reset, want_parts=True, **cases.LAPLACE_TIGHT)
+        with orc.pivoted_cholesky_preconditioner(co, ct, var, a, rank=rank):
+            on, og, op = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=pc["lik"], want_parts=True, **TIGHT_ORC)
+        assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
+        np.testing.assert_allclose(grad, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+        np.testing.assert_allclose(parts["dlogdet_dmode"], op["dlogdet_dmode"], rtol=0, atol=1e-8 * np.abs(op["dlogdet_dmode"]).max())
+        np.testing.assert_allclose(parts["implicit_solve"], op["implicit_solve"], rtol=0, atol=1e-8 * np.abs(op["implicit_solve"]).max())
+        for j in range(2):
+            np.testing.assert_allclose(parts["per_par"][j, [0, 1, 3]], op["per_par"][j, [0, 1, 3]], rtol=1e-7, atol=1e-8 * np.abs(op["per_par"][j]).max())
+    st.close()
+
+
+def test_errors_of_the_preconditioner_entry_point(gpb, orc):
+    pc = cases.LAPLACE_PIVCHOL_CASES["pc_logit_n2000"]
+    st, c, coords, y, perm, co, nn, ct, rank = _state(orc, pc)
+    from gpboost_amd import shim
+    with pytest.raises(gpb.GPBoostError, match="cannot be larger"):
+        st.laplace_set_preconditioner("pivoted_cholesky", len(y) + 1)
+    with pytest.raises(gpb.GPBoostError, match="not on this path"):
+        shim._shim_call(shim._lib().gpb_hip_vecchia_laplace_set_preconditioner(st.h, 7, 10))
+    st.close()
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_PIVCHOL_CASES))
+def test_model_api_evaluation_and_fit_follow_the_reference(gpb, name):
+    """GPModel -> GPB_SetOptimConfig(cg_preconditioner_type = "pivoted_cholesky", piv_chol_rank) / GPB_EvalNegLogLikelihood / GPB_OptimCovPar /
+    GPB_GetCGPreconditionerType: evaluation at the default thresholds, the lbfgs fit at cases.LAPLACE_TIGHT with the reference's iteration count, predictions."""
+    pc = cases.LAPLACE_PIVCHOL_CASES[name]
+    c = cases.LAPLACE_CASES[pc["model"]]
+    g = np.load(os.path.join(GOLD, "laplace_pivchol_ref.npz"))
+    coords, y = cases.make_pivchol_data(pc)
+    kw = dict(likelihood=pc["lik"], gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+              num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    pcp = {"cg_preconditioner_type": "pivoted_cholesky"}
+    if pc["rank"] is not None:
+        pcp["fitc_piv_chol_preconditioner_rank"] = pc["rank"]
+    cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+    mdl = gpb.GPModel(**kw)
+    mdl.set_optim_params(dict(pcp))
+    assert mdl.get_cg_preconditioner_type() == "pivoted_cholesky"
+    v = mdl.neg_log_likelihood(cp, y, aux_pars=[pc["aux"]]) if "aux" in pc else mdl.neg_log_likelihood(cp, y)
+    ref_d = float(g[name + "_negll_default"])
+    assert abs(v - ref_d) <= 1e-6 * abs(ref_d), (v, ref_d)
+    m2 = gpb.GPModel(**kw)
+    m2.fit(y, params=dict(pcp, **cases.LAPLACE_TIGHT))
+    assert m2.get_num_optim_iter() == int(g[name + "_fit_num_it"]), (m2.get_num_optim_iter(), int(g[name + "_fit_num_it"]))
+    np.testing.assert_allclose(m2.get_cov_pars(), g[name + "_fit_cov_pars"], rtol=1e-6)
+    if "aux" in pc:
+        np.testing.assert_allclose(m2.get_aux_pars(), g[name + "_fit_aux"], rtol=1e-6)
+    nll = m2.get_current_neg_log_likelihood()
+    assert abs(nll - float(g[name + "_fit_negll"])) <= 1e-8 * abs(nll)
+    # predictions keep solving with "vadu" (same quantity, another solver): finite, variances positive
+    cpred = np.random.default_rng(5).uniform(size=(7, coords.shape[1]))
+    pr = m2.predict(y=y, gp_coords_pred=cpred, predict_var=True, predict_response=False)
+    assert np.all(np.isfinite(pr["mu"])) and np.all(pr["var"] > 0)
+
+
+def test_model_api_errors_for_the_preconditioner(gpb):
+    pc = cases.LAPLACE_PIVCHOL_CASES["pc_logit_n2000"]
+    c = cases.LAPLACE_CASES[pc["model"]]
+    coords, y = cases.make_pivchol_data(pc)
+    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords[:300], cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
+    with pytest.raises(gpb.GPBoostError, match="not on the MI355X hot path"):
+        mdl.set_optim_params({"cg_preconditioner_type": "incomplete_cholesky"})
+    with pytest.raises(gpb.GPBoostError, match="is not > 0"):
+        mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky", "fitc_piv_chol_preconditioner_rank": 0})
+    with pytest.raises(gpb.GPBoostError, match="cannot be larger"):
+        mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky", "fitc_piv_chol_preconditioner_rank": 301})
+    mdl.set_optim_params({"cg_preconditioner_type": "piv_chol_on_Sigma", "fitc_piv_chol_preconditioner_rank": 25})     # ParsePreconditionerAlias
+    assert mdl.get_cg_preconditioner_type() == "pivoted_cholesky"
+    assert np.isfinite(mdl.neg_log_likelihood(np.array([1.0, 0.1]), y[:300]))
