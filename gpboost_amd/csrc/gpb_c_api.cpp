@@ -180,10 +180,10 @@ bool is_proportion_likelihood(const std::string& lik) {
 bool is_logit_link(const std::string& lik) { return lik == "bernoulli_logit" || lik == "binomial_logit" || lik == "quasi_bernoulli_logit"; }
 bool is_probit_link(const std::string& lik) { return lik == "bernoulli_probit" || lik == "binomial_probit" || lik == "quasi_bernoulli_probit"; }
 int laplace_link_id(const std::string& lik) {
-  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : 0)));
+  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : 0))));
 }
 bool supported_non_gaussian(const std::string& lik) {
-  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || is_proportion_likelihood(lik);
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || is_proportion_likelihood(lik);
 }
 // Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
 std::string parse_likelihood_alias(const std::string& lik) {
@@ -194,7 +194,7 @@ std::string parse_likelihood_alias(const std::string& lik) {
   if (lik == "quasi_binary" || lik == "quasi_binary_logit") return "quasi_bernoulli_logit";
   return lik;
 }
-int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial") ? 1 : 0; }
+int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial" || lik == "beta") ? 1 : 0; }
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
@@ -211,6 +211,15 @@ int laplace_push_aux(REModelHip* mdl) {
 // (method of moments); y, fixed_effects in data order
 // (wts: sample weights in the order of y, or NULL -- weighted moments with sum of weights in place of n, likelihoods.h:1856-1910)
 double initial_aux_par(const std::string& lik, int n, const double* y, const double* fe, const double* wts = nullptr) {
+  if (lik == "beta") {      // method of moments for the precision, phi = mu (1 - mu) / var - 1, clipped to [0.1, 100] (likelihoods.h:1952-1972; the fixed effects are not used there)
+    double avg = 0., sum_sq = 0., sw = 0.;
+    for (int i = 0; i < n; ++i) { const double w = wts ? wts[i] : 1.0; avg += w * y[i]; sum_sq += w * y[i] * y[i]; sw += w; }
+    avg /= sw;
+    const double sample_var = std::max((sum_sq - sw * avg * avg) / (sw - 1), 1e-6);
+    double phi = avg * (1.0 - avg) / sample_var - 1.0;
+    if (std::isnan(phi) || phi <= 0.0) phi = 1.0;
+    return std::min(std::max(phi, 0.1), 100.0);
+  }
   if (lik == "gamma") {
     double log_avg = 0., avg_log = 0., sw = 0.;
     for (int i = 0; i < n; ++i) {
@@ -270,14 +279,16 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   mdl->labels.resize(mdl->n);
   const bool poisson = mdl->likelihood == "poisson" || mdl->likelihood == "negative_binomial";     // integer-valued responses >= 0
-  if (mdl->likelihood == "gamma") {                       // likelihoods.h:1365-1373: strictly positive, real-valued
+  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta") {      // likelihoods.h:1365-1373: strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1)
+    const bool is_beta = mdl->likelihood == "beta";
     mdl->resp_real.resize(mdl->n);
     for (int k = 0; k < mdl->n; ++k) {
       const double yk = y_data[mdl->perm[k]];
-      if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
+      if (is_beta) { if (!(yk > 0. && yk < 1.)) return set_error(" Must have 0 < y < 1 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk); }
+      else if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
       mdl->resp_real[k] = yk; mdl->labels[k] = 0;
     }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, 3)) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : 3)) return shim_error();
     if (mdl->n_re > 0) {
       std::vector<double> grouped(mdl->n);
       for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
@@ -866,7 +877,46 @@ double resp_mean_logit(double latent_mean, double latent_var, double delta, cons
 }
 
 // in place: latent (mean, var) -> response (mean, var if predict_var); false = likelihood not on the path
+// beta: E[Var(y | b)] with Var(y | b) = mu (1 - mu) / (1 + precision), mu = sigmoid(b): ExpectedValueCondRespVarAdaptiveGHQuadrature (likelihoods.h:10167-10193) with
+// CondVarLikelihood / its log-derivatives (:15633-15680); second: E[sigmoid(b)^2], RespMeanAdaptiveGHQuadrature(second_moment = true) (:10128-10160)
+double resp_gh_beta(double latent_mean, double latent_var, double delta, const std::vector<double>& xs, const std::vector<double>& aw, int what, double aux) {
+  const double s2i = 1.0 / latent_var, ss = std::sqrt(s2i);
+  double mode = 0.0;
+  auto d1 = [&](double x) { return what == 2 ? (-1. + 2. / (1. + std::exp(x))) : 2.0 * (1.0 / (1.0 + std::exp(x))); };         // what 1: c_mult = 2 times d log sigmoid = sigmoid(-x)
+  auto d2 = [&](double x) { const double e = std::exp(x); return what == 2 ? -2 * e / ((1. + e) * (1. + e)) : 2.0 * -(1.0 / (1.0 + std::exp(-x))) * (1.0 - 1.0 / (1.0 + std::exp(-x))); };
+  for (int it = 0; it < 100; ++it) {
+    const double last = mode;
+    const double upd = (d1(mode) - s2i * (mode - latent_mean)) / (d2(mode) - s2i);
+    mode -= upd;
+    if (std::fabs(upd) / std::fabs(last) < delta) break;
+  }
+  const double sh = M_SQRT2 / std::sqrt(-d2(mode) + s2i);
+  double acc = 0.0;
+  for (size_t j = 0; j < xs.size(); ++j) {
+    const double x = sh * xs[j] + mode;
+    double f;
+    if (what == 2) { const double em = std::exp(-x); f = em / ((1. + em) * (1. + em)) / (1. + aux); }
+    else { const double p = 1.0 / (1.0 + std::exp(-x)); f = p * p; }
+    acc += aw[j] * f * normal_pdf(ss * (x - latent_mean));
+  }
+  return acc * sh * ss;
+}
+
 bool predict_response_host(const std::string& lik, int n, double* mean, double* var, bool predict_var, double delta, double aux = 1.0) {
+  if (lik == "beta") {                      // likelihoods.h:9805-9824: mean E[sigmoid(b)]; variance Var(E[y | b]) + E[Var(y | b)]
+    std::vector<double> xs, aw;
+    gauss_hermite_adaptive(30, &xs, &aw);
+    for (int i = 0; i < n; ++i) {
+      const double rm = resp_mean_logit(mean[i], var[i], delta, xs, aw);
+      if (predict_var) {
+        const double var_E = resp_gh_beta(mean[i], var[i], delta, xs, aw, 1, aux) - rm * rm;
+        const double E_var = resp_gh_beta(mean[i], var[i], delta, xs, aw, 2, aux);
+        var[i] = var_E + E_var;
+      }
+      mean[i] = rm;
+    }
+    return true;
+  }
   if (lik == "gamma") {                     // likelihoods.h:9715-9728
     for (int i = 0; i < n; ++i) {
       const double pm = std::exp(mean[i] + 0.5 * var[i]);
@@ -2782,7 +2832,7 @@ int GPB_GetResponseData(REModelHandle handle, double* response_data) {
   if (!mdl || !response_data) return set_error("GPB_GetResponseData: null argument");
   if (!mdl->y_set) return set_error("Respone variable data has not been set");      // re_model_template.h:6258-6261 (sic)
   if (mdl->likelihood == "gaussian") { std::copy(mdl->y_host.begin(), mdl->y_host.end(), response_data); }   // y_vec_: the response as passed in
-  else if (mdl->likelihood == "gamma") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
+  else if (mdl->likelihood == "gamma" || mdl->likelihood == "beta") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
   else { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = (double)mdl->labels[k]; }
   C_API_END();
 }
@@ -2819,7 +2869,7 @@ int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool c
   if (mdl->num_aux < 1) { if (out_str) out_str[0] = 0; return 0; }      // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
   if (calc_std_dev) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters are not on the MI355X path of this library");
   if (aux_pars) aux_pars[0] = mdl->aux_pars[0];       // REModel::GetAuxPars (re_model.cpp:1408-1421), original scale
-  if (out_str) std::strcpy(out_str, "shape");         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319)
+  if (out_str) std::strcpy(out_str, mdl->likelihood == "beta" ? "precision" : "shape");         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
   return 0;
 }
 

@@ -73,10 +73,30 @@ __device__ __forceinline__ double inv_mills_phi(double z) {
 //  branches, exactly the end points at y = 0 and y = 1: LogLikBinomialProbit :11394-11398, FirstDeriv :12468-12474, SecondDeriv :13293-13305, third :13800-13820)
 template <int LINK>
 __device__ __forceinline__ double resp_at(const LikResp& r, int d) {
-  if constexpr (LINK == 3) return r.yd[d];
+  if constexpr (LINK == 3 || LINK == 5) return r.yd[d];
   else if constexpr (LINK == 0 || LINK == 1) return r.yd ? r.yd[d] : (double)r.yi[d];
   else return (double)r.yi[d];
 }
+// LINK 5 = beta (round 5, second slice; mean = sigmoid(location), precision = aux, real-valued response in (0, 1)): LogLikBeta likelihoods.h:11903-11913,
+// FirstDerivLogLikBeta :12501-12507, SecondDerivNegLogLikBeta :13336-13346, third derivative :13892-13917.  digamma / trigamma / tetragamma as
+// src/GPBoost/DF_utils.cpp:82-201 (recurrence to >= 8.5 / 5 / 8, then the asymptotic series), sigmoid_stable_clamped as include/GPBoost/DF_utils.h:48-55.
+__device__ __forceinline__ double digamma_dev(double x);
+__device__ __forceinline__ double trigamma_dev(double x) {
+  if (x <= 0.0001) return 1.0 / x / x;
+  double value = 0.0, z = x;
+  while (z < 5.0) { value = value + 1.0 / z / z; z = z + 1.0; }
+  const double y = 1.0 / z / z;
+  return value + 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z;
+}
+__device__ __forceinline__ double tetragamma_dev(double x) {
+  if (x <= 1e-4) return -2.0 / (x * x * x);
+  double z = x, value = 0.0;
+  while (z < 8.0) { value -= 2.0 / (z * z * z); z += 1.0; }
+  const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z6 = z4 * z2, z8 = z4 * z4, z10 = z8 * z2;
+  value += -1.0 / z2 - 1.0 / z3 - 0.5 / z4 + 1.0 / (6.0 * z6) - 1.0 / (6.0 * z8) + 3.0 / (10.0 * z10);
+  return value;
+}
+__device__ __forceinline__ double sigmoid_clamped(double x) { double mu = sigmoid_stable(x); if (mu < 1e-12) mu = 1e-12; if (mu > 1.0 - 1e-12) mu = 1.0 - 1e-12; return mu; }
 // sample weight of datum d (round 5; likelihoods.h:666-668 weights_): every per-datum term -- log-likelihood and its derivatives -- is multiplied by it
 __device__ __forceinline__ double wt_at(const LikResp& r, int d) { return r.w ? r.w[d] : 1.0; }
 template <int LINK>
@@ -96,6 +116,14 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
       grad = y * r1 + (1.0 - y) * -r0;
       w = y * r1 * (x + r1) + (1.0 - y) * -r0 * (x - r0);
     }
+  } else if constexpr (LINK == 5) {
+    const double mu = sigmoid_clamped(x), logit_y = log(y) - log1p(-y);
+    const double dig1 = digamma_dev((1.0 - mu) * aux), dig2 = digamma_dev(mu * aux);
+    const double tri1 = trigamma_dev((1.0 - mu) * aux), tri2 = trigamma_dev(mu * aux);
+    grad = aux * mu * (1.0 - mu) * (dig1 - dig2 + logit_y);
+    const double h1 = -aux * aux * mu * mu * (1.0 - mu) * (1.0 - mu) * (tri1 + tri2);
+    const double h2 = aux * mu * (1.0 - mu) * (1.0 - 2.0 * mu) * (dig1 - dig2 + logit_y);
+    w = -(h1 + h2);
   } else if constexpr (LINK == 3) {
     const double q = y * exp(-x);
     grad = aux * (q - 1.0);
@@ -119,6 +147,10 @@ __device__ __forceinline__ double lik_loglik(double y, double x, double aux) {
   }
   else if constexpr (LINK == 3) return -aux * (x + y * exp(-x));
   else if constexpr (LINK == 4) return y * x - (y + aux) * log(exp(x) + aux);
+  else if constexpr (LINK == 5) {
+    const double mu = sigmoid_clamped(x);
+    return -lgamma(mu * aux) - lgamma((1.0 - mu) * aux) + (mu * aux - 1.0) * log(y) + ((1.0 - mu) * aux - 1.0) * log1p(-y);
+  }
   else return y * x - exp(x);
 }
 // digamma as GPBoost::digamma (src/GPBoost/DF_utils.cpp:82-125): small-argument approximation, recurrence up to x >= 8.5, de Moivre's expansion
@@ -844,6 +876,16 @@ __device__ __forceinline__ double lik_third(double y, double x, double aux) {
   else if constexpr (LINK == 2) return exp(x);
   else if constexpr (LINK == 3) return -aux * y * exp(-x);                                            // likelihoods.h:13843-13849
   else if constexpr (LINK == 4) { const double mu = exp(x), mr = mu + aux; return -(y + aux) * mu * aux * (mu - aux) / (mr * mr * mr); }   // :13870-13878
+  else if constexpr (LINK == 5) {                                                                      // :13892-13917
+    const double mu = sigmoid_clamped(x), d = mu * (1.0 - mu), logit_y = log(y) - log1p(-y);
+    const double dig1 = digamma_dev((1.0 - mu) * aux), dig2 = digamma_dev(mu * aux), tri1 = trigamma_dev((1.0 - mu) * aux), tri2 = trigamma_dev(mu * aux);
+    const double tet1 = tetragamma_dev((1.0 - mu) * aux), tet2 = tetragamma_dev(mu * aux);
+    const double C = dig1 - dig2 + logit_y, S = tri1 + tri2, Dlt = tet2 - tet1;
+    const double term_trigam = 3.0 * aux * aux * d * d * (1.0 - 2.0 * mu) * S;
+    const double term_tetragam = aux * aux * aux * d * d * d * Dlt;
+    const double gp = d * ((1.0 - 2.0 * mu) * (1.0 - 2.0 * mu) - 2.0 * d);
+    return term_trigam + term_tetragam + -aux * gp * C;
+  }
   else {
     const double x2 = x * x;
     if (y == 0.0) { const double q = inv_mills_phi(-x); return -q * (1.0 - x2 + q * (3.0 * x - 2.0 * q)); }
@@ -918,7 +960,18 @@ __global__ __launch_bounds__(1024) void lik_aux_grad_kernel(const double* __rest
     const double mi = mode[i], svi = sv[i];
     for (int d = d0; d < d1; ++d) {
       const double x = fe ? mi + fe[d] : mi, yv = resp_at<LINK>(y, d), wd = wt_at(y, d);
-      if constexpr (LINK == 3) {
+      if constexpr (LINK == 5) {       // CalcGradNegLogLikAuxPars beta (:14229-14241; the host multiplies by -precision), CalcSecondDerivLogLikFirstDerivInformationAuxPar beta (:14816-14845)
+        const double mu = sigmoid_clamped(x), dd = mu * (1.0 - mu), logit_y = log(yv) - log1p(-yv);
+        const double dig1 = digamma_dev((1.0 - mu) * r), dig2 = digamma_dev(mu * r), tri1 = trigamma_dev((1.0 - mu) * r), tri2 = trigamma_dev(mu * r);
+        const double tet1 = tetragamma_dev((1.0 - mu) * r), tet2 = tetragamma_dev(mu * r);
+        e += wd * (digamma_dev(r) - mu * dig2 - (1.0 - mu) * dig1 + mu * log(yv) + (1.0 - mu) * log1p(-yv));
+        const double C = dig1 - dig2 + logit_y, S = tri1 + tri2, Dlt_tri = (1.0 - mu) * tri1 - mu * tri2, Dlt_tet = (1.0 - mu) * tet1 + mu * tet2;
+        const double cross_deriv = -(r * dd * C + r * r * dd * Dlt_tri);
+        const double term1 = 2.0 * r * r * dd * dd * S, term2 = r * r * r * dd * dd * Dlt_tet;
+        const double term3 = -r * dd * (1.0 - 2.0 * mu) * C, term4 = -r * r * dd * (1.0 - 2.0 * mu) * Dlt_tri;
+        dsum = __builtin_fma(wd * (term1 + term2 + term3 + term4), diag, dsum);
+        isum = __builtin_fma(wd * cross_deriv, svi, isum);
+      } else if constexpr (LINK == 3) {
         const double q = yv * exp(-x);
         e += wd * (x + q);
         const double s2 = wd * (r * (q - 1.0));
@@ -1129,6 +1182,7 @@ hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, cons
     case 2: hipLaunchKernelGGL(lik_newton_setup_kernel<2>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 3: hipLaunchKernelGGL(lik_newton_setup_kernel<3>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 4: hipLaunchKernelGGL(lik_newton_setup_kernel<4>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 5: hipLaunchKernelGGL(lik_newton_setup_kernel<5>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1175,6 +1229,7 @@ hipError_t lap_objective(int link, const double* x, const LikResp& y, const doub
     case 2: hipLaunchKernelGGL(lik_objective_kernel<2>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 3: hipLaunchKernelGGL(lik_objective_kernel<3>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 4: hipLaunchKernelGGL(lik_objective_kernel<4>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 5: hipLaunchKernelGGL(lik_objective_kernel<5>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1727,6 +1782,7 @@ hipError_t lap_third_deriv(int link, const double* mode, const LikResp& y, const
     case 2: hipLaunchKernelGGL(lik_third_kernel<2>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 3: hipLaunchKernelGGL(lik_third_kernel<3>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 4: hipLaunchKernelGGL(lik_third_kernel<4>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 5: hipLaunchKernelGGL(lik_third_kernel<5>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1738,6 +1794,7 @@ hipError_t lap_grad_F(int link, const double* mode, const LikResp& y, const doub
     case 2: hipLaunchKernelGGL(lik_grad_F_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 3: hipLaunchKernelGGL(lik_grad_F_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 4: hipLaunchKernelGGL(lik_grad_F_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 5: hipLaunchKernelGGL(lik_grad_F_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1750,6 +1807,7 @@ hipError_t lap_grad_F_map(int link, const double* mode, const LikResp& y, const 
     case 2: hipLaunchKernelGGL(lik_grad_F_map_kernel<2>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 3: hipLaunchKernelGGL(lik_grad_F_map_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 4: hipLaunchKernelGGL(lik_grad_F_map_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 5: hipLaunchKernelGGL(lik_grad_F_map_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1758,6 +1816,7 @@ hipError_t lap_aux_grad(int link, const double* mode, const LikResp& y, const do
                         const int* dptr, double* out3, hipStream_t st) {
   if (link == 3) hipLaunchKernelGGL(lik_aux_grad_kernel<3>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else if (link == 4) hipLaunchKernelGGL(lik_aux_grad_kernel<4>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
+  else if (link == 5) hipLaunchKernelGGL(lik_aux_grad_kernel<5>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

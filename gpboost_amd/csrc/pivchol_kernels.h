@@ -24,10 +24,17 @@ hipError_t pc_combine(const double* L, const double* W, const double* X, const d
 // out = x .* w (inv = 0) or x ./ w (inv = 1); v += h ./ w
 hipError_t pc_rowscale(const double* x, const double* w, int n, int ncol, int nc, int inv, double* out, hipStream_t st);
 hipError_t pc_add_div(double* v, const double* h, const double* w, int n, int ncol, int nc, hipStream_t st);
+// ---- preconditioner "fitc": P = diag(W^-1 + Sigma_m[0][0] - ||V_i||^2) + C Sigma_m^-1 C' -- the same kernels with L := C (cross-covariance with the inducing points),
+// the diagonal of the preconditioner's inverse wp := D^-1 in place of W, and M := (Sigma_m + C' D^-1 C)^-1 ----
+// rows of src [n][ld] (Vecchia order) -> dst [n][k] (row sigma[i]); vnorm2 (optional): sum_q src[i][q]^2 into slot sigma[i]
+hipError_t pc_pack_rows(const double* src, int ld, const int* sigma, int n, int k, double* dst, double* vnorm2, hipStream_t st);
+// wp[i] = 1 / (1 / W[i] + sm00 - vnorm2[i])      (likelihoods.h:16302-16308)
+hipError_t pc_fitc_diag(const double* W, const double* vnorm2, double sm00, int n, double* wp, hipStream_t st);
 hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st);      // out1[0] = max_i w[i] (NaN propagates)
 // d log|Sigma W + I| / d mode_i, pivoted_cholesky branch of CalcLogDetStochDerivModeVecchia (likelihoods.h:16554-16611): U = (W^-1 + Sigma)^-1 Z,
 // WIPIZ = W^-1 P^-1 Z, row-wise optimal c (CalcOptimalCVectorized), deterministic part diag(L M L^T) dW - dW / W
+// (wp != nullptr: the fitc branch, :16612-16633 -- deterministic part diag(C M C') wp (W^-1 dW W^-1 wp) - W^-1 dW W^-1 wp)
 hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
-                        double* dld, hipStream_t st);
+                        double* dld, hipStream_t st, const double* wp = nullptr);
 
 }  // namespace gpb

@@ -227,8 +227,28 @@ __global__ __launch_bounds__(1024) void pc_wmax_kernel(const double* __restrict_
   if (threadIdx.x == 0) out1[0] = s[0];
 }
 
+__global__ void pc_pack_rows_kernel(const double* __restrict__ src, int ld, const int* __restrict__ sigma, int n, int k, double* __restrict__ dst,
+                                    double* __restrict__ vnorm2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* in = src + (size_t)i * ld;
+  double* out = dst + (size_t)sigma[i] * k;
+  double s2 = 0.0;
+  for (int q = 0; q < k; ++q) { const double v = in[q]; out[q] = v; s2 = __builtin_fma(v, v, s2); }
+  if (vnorm2) vnorm2[sigma[i]] = s2;
+}
+__global__ void pc_fitc_diag_kernel(const double* __restrict__ W, const double* __restrict__ vnorm2, double sm00, int n, double* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d = 1.0 / W[i];
+  d += sm00;
+  d -= vnorm2[i];
+  wp[i] = 1.0 / d;
+}
+
 __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* __restrict__ WIPIZ, const double* __restrict__ L, const double* __restrict__ M,
-                                    const double* __restrict__ W, const double* __restrict__ dW3, int n, int k, int t, int nc, double* __restrict__ dld) {
+                                    const double* __restrict__ W, const double* __restrict__ dW3, int n, int k, int t, int nc, double* __restrict__ dld,
+                                    const double* __restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d3 = dW3[i], wi = 1.0 / W[i];
@@ -258,6 +278,11 @@ __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* 
     sdiag = __builtin_fma(Li[q], acc, sdiag);
   }
   const double trw = wi * d3;
+  if (wp) {
+    const double tDI = wi * (trw * wp[i]), tDIDI = wp[i] * tDI;
+    dld[i] = tr1 + trw + copt * (sdiag * tDIDI - tDI) - copt * trP;
+    return;
+  }
   dld[i] = tr1 + trw + copt * (sdiag * d3 - trw) - copt * trP;
 }
 
@@ -317,8 +342,16 @@ hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
-                        double* dld, hipStream_t st) {
-  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld);
+                        double* dld, hipStream_t st, const double* wp) {
+  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld, wp);
+  return hipGetLastError();
+}
+hipError_t pc_pack_rows(const double* src, int ld, const int* sigma, int n, int k, double* dst, double* vnorm2, hipStream_t st) {
+  hipLaunchKernelGGL(pc_pack_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, sigma, n, k, dst, vnorm2);
+  return hipGetLastError();
+}
+hipError_t pc_fitc_diag(const double* W, const double* vnorm2, double sm00, int n, double* wp, hipStream_t st) {
+  hipLaunchKernelGGL(pc_fitc_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, vnorm2, sm00, n, wp);
   return hipGetLastError();
 }
 

@@ -168,7 +168,7 @@ def laplace_pivchol_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_pivchol_ref.npz"), **res)
 
 
-def laplace_aux_fixture(out_dir):
+def laplace_aux_fixture(out_dir, only=()):
     """gamma and negative_binomial Vecchia-Laplace models (auxiliary shape parameter estimated with the covariance parameters): the reference's own
       *_negll_0                      GPB_EvalNegLogLikelihood at (cov_pars, aux) with the default thresholds
       *_negll_direct, *_grad_direct  value and gradient wrt (log sigma1^2, log a, log aux) from the reference's CalcGradPars (refdrv_laplace_nll_grad) at
@@ -177,7 +177,12 @@ def laplace_aux_fixture(out_dir):
                                      iterations, negll -- at the default thresholds and (*_fit_tight_*) at cases.LAPLACE_TIGHT
       *_fitfix_*                     the same with the auxiliary parameter held at cases' aux (estimate_aux_pars = false)"""
     res = {}
+    path = os.path.join(out_dir, "laplace_aux_ref.npz")
+    if only and os.path.exists(path):        # `laplace_aux <case> ...`: only these cases are (re)generated, the others are kept as they are
+        res = dict(np.load(path))
     for name, ac in cases.LAPLACE_AUX_CASES.items():
+        if only and name not in only:
+            continue
         c = cases.LAPLACE_CASES[ac["model"]]
         coords, y = cases.make_aux_data(ac)
         lik, aux = ac["lik"], ac["aux"]
@@ -186,7 +191,7 @@ def laplace_aux_fixture(out_dir):
         mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
         mdl.set_optim_config(init_aux_pars=aux)
         res[name + "_negll_0"] = np.float64(mdl.neg_log_likelihood(cp, y))
-        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
+        for fe_key, fe in (("", None), ("_fe", cases.aux_fixed_effects(ac, coords))):
             nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, fe, *args, aux_pars=aux, estimate_aux=True, **cases.LAPLACE_TIGHT)
             res[name + fe_key + "_negll_direct"] = np.float64(nll)
             res[name + fe_key + "_grad_direct"] = g
@@ -1059,8 +1064,27 @@ def config4_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "config4_ref.npz"), **res)
 
 
+def config4_pivchol_fixture(out_dir):
+    """BASELINE config 4's data (n = 1e5, m = 30, Bernoulli-logit) with cg_preconditioner_type = "pivoted_cholesky" (rank 50): ONE reference evaluation at the default
+    thresholds and one at cg_delta_conv = 1e-6 -- tests/golden/config4_pivchol_ref.npz."""
+    import time
+    n, m = 100000, 30
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+    res = {}
+    for key, cfg in (("negll_0", {}), ("negll_tight_0", dict(cg_delta_conv=1e-6))):
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=8, likelihood="bernoulli_logit")
+        mdl.set_optim_config(cg_preconditioner_type="pivoted_cholesky", **cfg)
+        t0 = time.time()
+        res[key] = np.float64(mdl.neg_log_likelihood(np.asarray((1.0, 0.1), dtype=np.float64), y))
+        res["seconds_" + key] = np.float64(time.time() - t0)
+        print("config4 pivoted_cholesky", key, "negll = %.12f" % res[key], "%.1f s" % res["seconds_" + key], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "config4_pivchol_ref.npz"), **res)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "atsize":
+    if len(sys.argv) > 1 and sys.argv[1] == "config4_pivchol":
+        config4_pivchol_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "atsize":
         atsize_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "weights":
         weights_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
@@ -1113,7 +1137,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":
         laplace_pivchol_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":
-        laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"))
+        laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":
         laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "optim_coef":

@@ -504,7 +504,7 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
     return out
 
 
-LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4,
+LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5,
            # round 5: proportions under the logit / probit links (real-valued response in [0, 1]; binomial_*: trials = orc.sample_weights, binomial constant)
            "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}
 PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
@@ -512,7 +512,7 @@ PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_
 
 def _responses(likelihood, y):
     """-> (int32 responses, float64 responses | None): gamma's response is real-valued (handed to the C side through orc_set_aux)."""
-    if likelihood == "gamma" or likelihood in PROPORTION_LIKELIHOODS:
+    if likelihood in ("gamma", "beta") or likelihood in PROPORTION_LIKELIHOODS:
         yd = np.ascontiguousarray(y, dtype=np.float64)
         lib().orc_set_binomial(C.c_int(1 if likelihood.startswith("binomial") else 0))
         return np.zeros(yd.shape[0], dtype=np.int32), yd
@@ -568,6 +568,41 @@ class pivoted_cholesky_preconditioner(object):
         fn = lib().orc_set_pivchol
         fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         fn(self.L.ctypes.data, self.L.shape[1], self.rv2.ctypes.data)
+        _PROBE_RUN_ID = 1
+        return self
+
+    def __exit__(self, *exc):
+        global _PROBE_RUN_ID
+        lib().orc_clear_pivchol()
+        _PROBE_RUN_ID = 0
+        return False
+
+
+class fitc_preconditioner(object):
+    """`with orc.fitc_preconditioner(coords, ip, cov_type, var, a, num_rand_vec, seed_rand): ...` -- cg_preconditioner_type = "fitc" for the Vecchia-Laplace oracle calls
+    inside the block: P = diag(W^-1 + Sigma_m[0][0] - ||V_i||^2) + C Sigma_m^-1 C' with the k inducing points `ip` (k x d; the reference picks them by kmeans++ from the
+    model's generator at the first covariance factor, Calc_FITC_Preconditioner_Vecchia, re_model_template.h:9502-9593 -- orc.vif_setup restates that draw), C the
+    cross-covariance, Sigma_m the inducing points' covariance with the diagonal x (1 + 1e-6), V = (L_m^-1 C')'.  rand_vec_trace_I2_ (k x t) first, rand_vec_trace_I_ second."""
+
+    def __init__(self, coords, ip, cov_type, var, a, num_rand_vec=50, seed_rand=1):
+        from scipy.spatial.distance import cdist
+        from scipy.linalg import cholesky, solve_triangular
+        co = np.asarray(coords, dtype=np.float64); ip = np.asarray(ip, dtype=np.float64)
+        self.k = ip.shape[0]
+        Sm = _matern(cov_type, cdist(ip, ip), var, a)
+        Sm[np.diag_indices_from(Sm)] *= 1.0 + 1e-6                                   # JITTER_MULT_IP_FITC_FSA
+        Lm = cholesky(Sm, lower=True)
+        self.C = np.asfortranarray(_matern(cov_type, cdist(co, ip), var, a))          # n x k
+        self.V = np.asfortranarray(solve_triangular(Lm, self.C.T, lower=True).T)      # n x k = chol_ip_cross_cov^T
+        self.Sm = np.ascontiguousarray(Sm)
+        self.logdet_Sm = 2.0 * np.log(np.diag(Lm)).sum()
+        self.rv2 = gen_rand_normal(self.k, num_rand_vec, seed_rand, 0)
+
+    def __enter__(self):
+        global _PROBE_RUN_ID
+        fn = lib().orc_set_fitc
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        fn(self.C.ctypes.data, self.V.ctypes.data, self.Sm.ctypes.data, float(self.logdet_Sm), self.k, self.rv2.ctypes.data)
         _PROBE_RUN_ID = 1
         return self
 

@@ -1,5 +1,5 @@
 """Timing of the Vecchia-Laplace path (BASELINE config 4) on the MI355X, with the reference on the host beside it.
-    python scripts/gpu_laplace.py [n] [m] [--ref]"""
+    python scripts/gpu_laplace.py [n] [m] [--ref] [--pivchol]"""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +19,9 @@ t0 = time.perf_counter()
 mdl = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
                           num_neighbors=m, vecchia_ordering="random", seed=1)
 print("setup %.3f s" % (time.perf_counter() - t0), flush=True)
+if "--pivchol" in sys.argv:      # cg_preconditioner_type = "pivoted_cholesky" (rank 50) instead of the default "vadu"
+    mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky"})
+    print("preconditioner:", mdl.get_cg_preconditioner_type(), flush=True)
 cp = np.array([1.0, 0.1])
 res = {}
 for k in range(3):

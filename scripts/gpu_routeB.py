@@ -78,26 +78,31 @@ import json  # noqa: E402
 LAP_REF_PATH = os.path.join(ROOT, "tests", "golden", "routeB_laplace_ref.json")
 LAP_REF = json.load(open(LAP_REF_PATH)) if os.path.exists(LAP_REF_PATH) else {}
 MAKE_LAP_REF = "--make-laplace-ref" in sys.argv
-LAP_CASES = ((800, 10, ("bernoulli_logit",)),) if MOCK else (((5000, 20, ("bernoulli_logit", "poisson")),) if (TEST or MAKE_LAP_REF) else ((5000, 20, ("bernoulli_logit", "poisson")), (20000, 30, ("bernoulli_logit",)), (100000, 30, ("bernoulli_logit",))))
+# ("<likelihood>:pivoted_cholesky": round 5 -- the same seams with cg_preconditioner_type = "pivoted_cholesky"; the host's PivotedCholsekyFactorizationSigma is skipped, the device forms the factor)
+LAP_CASES = ((800, 10, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky")),) if MOCK else (((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky")),) if (TEST or MAKE_LAP_REF) else ((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky")), (20000, 30, ("bernoulli_logit",)), (100000, 30, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky"))))
 if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
     LAP_CASES = ()
 for n, m, liks in LAP_CASES:
     rng = np.random.default_rng(21)
     coords = rng.uniform(size=(n, 2))
     eta = np.sin(4 * coords[:, 0]) + np.cos(3 * coords[:, 1])
-    for lik in liks:
+    for lik_pc in liks:
+        lik, _, precond = lik_pc.partition(":")
+        precond = precond or "vadu"
         if lik == "poisson":
             yl = rng.poisson(np.exp(0.5 * eta)).astype(np.float64)
         else:
             yl = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-1.5 * eta))).astype(np.float64)
         cp = np.array([1.0, 0.1])
-        key = "%s_n%d_m%d" % (lik, n, m)
+        key = "%s_n%d_m%d" % (lik, n, m) + ("" if precond == "vadu" else "_" + precond)
+        if MAKE_LAP_REF and key in LAP_REF and "--redo" not in sys.argv:
+            continue
         res = {}
         legs = (False,) if MAKE_LAP_REF else ((False, True) if MOCK else (True,))
         for gpu in legs:
             mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, likelihood=lik, lib_path=LIBP, gpu_use=gpu,
                                       matrix_inversion_method="iterative")
-            mdl.set_optim_config(init_cov_pars=cp, optimizer_cov="lbfgs", cg_delta_conv=1e-6)
+            mdl.set_optim_config(init_cov_pars=cp, optimizer_cov="lbfgs", cg_delta_conv=1e-6, cg_preconditioner_type=precond)
             t0 = time.perf_counter()
             nll0 = mdl.neg_log_likelihood(cp, yl)
             t_first = time.perf_counter() - t0
@@ -111,7 +116,7 @@ for n, m, liks in LAP_CASES:
                 out.update(t_fit=time.perf_counter() - t0, cov=[float(v) for v in mdl.get_cov_par(2)], it=int(mdl.get_num_it()), negll_fit=mdl.current_neg_log_likelihood())
             res[gpu] = out
             print("Laplace %s n=%d GPU_use=%s: nll %.10f / %.10f, evaluation %.3f s%s" % (
-                lik, n, gpu, nll0, nll1, t_eval, "" if "cov" not in out else "; fit: %d iterations, cov pars %s, negll %.8f, %.2f s" % (out["it"], out["cov"], out["negll_fit"], out["t_fit"])), flush=True)
+                lik_pc, n, gpu, nll0, nll1, t_eval, "" if "cov" not in out else "; fit: %d iterations, cov pars %s, negll %.8f, %.2f s" % (out["it"], out["cov"], out["negll_fit"], out["t_fit"])), flush=True)
             del mdl
         if MAKE_LAP_REF:
             LAP_REF[key] = res[False]
@@ -120,7 +125,7 @@ for n, m, liks in LAP_CASES:
         a = res[False] if False in res else LAP_REF.get(key)
         b = res[True]
         if a is None:
-            print("Laplace %s n=%d: GPU_use=true evaluation %.3f s (no stored CPU values at this size: the reference's CPU path takes minutes per evaluation)" % (lik, n, b["t_eval"]), flush=True)
+            print("Laplace %s n=%d: GPU_use=true evaluation %.3f s (no stored CPU values at this size: the reference's CPU path takes minutes per evaluation)" % (lik_pc, n, b["t_eval"]), flush=True)
             continue
         assert abs(a["nll0"] - b["nll0"]) <= 1e-7 * abs(a["nll0"]), (a["nll0"], b["nll0"])
         assert abs(a["nll1"] - b["nll1"]) <= 1e-7 * abs(a["nll1"]), (a["nll1"], b["nll1"])
@@ -130,7 +135,7 @@ for n, m, liks in LAP_CASES:
             assert abs(a["negll_fit"] - b["negll_fit"]) <= 1e-6 * abs(a["negll_fit"]), (a["negll_fit"], b["negll_fit"])
             msg += ", fit %.1fx (%d / %d iterations)" % (a["t_fit"] / b["t_fit"], a["it"], b["it"])
         print("Laplace %s n=%d: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build%s; %s faster" % (
-            lik, n, "" if False in res else " (its values: tests/golden/routeB_laplace_ref.json)", msg), flush=True)
+            lik_pc, n, "" if False in res else " (its values: tests/golden/routeB_laplace_ref.json)", msg), flush=True)
 # ---- (1d) the GPBoost algorithm for binary classification: every boosting iteration finds the mode at the current scores (fixed effects of the
 #      Laplace state), takes one covariance-parameter step (device mode finding + device gradient) and hands d(-mll)/dF to the tree as the gradient
 #      (CalcGradNegMargLikelihoodLaplaceApproxVecchia with calc_F_grad -> gpb_hip_vecchia_laplace_grad_F_current) -- GPU_use = true against false ----

@@ -57,7 +57,43 @@ double normal_log_cdf(double x) {
 }
 // d log p / d loc, information, d information / d loc
 double g_mock_aux = 1.0;        // auxiliary parameter seen by lik_terms (links 3 / 4; set by the entry points from the handle)
+// beta (link 5): polygamma functions as the reference's (src/GPBoost/DF_utils.cpp:82-201), mean = clamped sigmoid (include/GPBoost/DF_utils.h:48-55)
+double mock_digamma(double x) {
+  if (x <= 0.000001) return -0.57721566490153286060 - 1.0 / x + 1.6449340668482264365 * x;
+  double v = 0.;
+  while (x < 8.5) { v -= 1. / x; x += 1.; }
+  double r = 1. / x;
+  v += std::log(x) - 0.5 * r;
+  r = r * r;
+  return v - r * (1. / 12. - r * (1. / 120. - r * (1. / 252. - r * (1. / 240. - r * (1. / 132.)))));
+}
+double mock_trigamma(double x) {
+  if (x <= 0.0001) return 1.0 / x / x;
+  double value = 0.0, z = x;
+  while (z < 5.0) { value = value + 1.0 / z / z; z = z + 1.0; }
+  const double y = 1.0 / z / z;
+  return value + 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z;
+}
+double mock_tetragamma(double x) {
+  if (x <= 1e-4) return -2.0 / (x * x * x);
+  double z = x, value = 0.0;
+  while (z < 8.0) { value -= 2.0 / (z * z * z); z += 1.0; }
+  const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z6 = z4 * z2, z8 = z4 * z4, z10 = z8 * z2;
+  return value + (-1.0 / z2 - 1.0 / z3 - 0.5 / z4 + 1.0 / (6.0 * z6) - 1.0 / (6.0 * z8) + 3.0 / (10.0 * z10));
+}
 void lik_terms(int link, double y, double x, double* first, double* info, double* dinfo) {
+  if (link == 5) {       // likelihoods.h:12501-12507, :13336-13346, :13892-13917
+    const double phi = g_mock_aux;
+    double mu = sigmoid(x); if (mu < 1e-12) mu = 1e-12; if (mu > 1.0 - 1e-12) mu = 1.0 - 1e-12;
+    const double d = mu * (1.0 - mu), logit_y = std::log(y) - std::log1p(-y);
+    const double dig1 = mock_digamma((1.0 - mu) * phi), dig2 = mock_digamma(mu * phi), tri1 = mock_trigamma((1.0 - mu) * phi), tri2 = mock_trigamma(mu * phi);
+    const double tet1 = mock_tetragamma((1.0 - mu) * phi), tet2 = mock_tetragamma(mu * phi);
+    const double C = dig1 - dig2 + logit_y, S = tri1 + tri2;
+    *first = phi * d * C;
+    *info = -(-phi * phi * d * d * S + phi * d * (1.0 - 2.0 * mu) * C);
+    *dinfo = 3.0 * phi * phi * d * d * (1.0 - 2.0 * mu) * S + phi * phi * phi * d * d * d * (tet2 - tet1) + -phi * (d * ((1.0 - 2.0 * mu) * (1.0 - 2.0 * mu) - 2.0 * d)) * C;
+    return;
+  }
   if (link == 3) { const double r = g_mock_aux, q = y * std::exp(-x); *first = r * (q - 1.); *info = r * q; *dinfo = -r * q; return; }
   if (link == 4) {
     const double r = g_mock_aux, mu = std::exp(x), mr = mu + r;
@@ -227,7 +263,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
   const bool ctx = h->link >= 3 || h->real_resp;
-  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
   orc_set_binomial(h->binomial ? 1 : 0);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
                                                   h->has_fe ? h->fe.data() : nullptr, rv.data(), nrv, cg, cgt, cgd, dcm, out6, h->grad2, mode.data(), warm ? 1 : 0,
@@ -439,7 +475,7 @@ EXPORT int gpb_hip_dense_spd_solve(int32_t n, const double* M_host, const double
 
 // ---- Laplace path ----
 EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int id) {
-  if (id < 0 || id > 4) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
+  if (id < 0 || id > 5) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
   if (h->link != id) { h->labels.clear(); h->grad_state = false; }
   h->link = id; return 0;
 }
@@ -453,10 +489,11 @@ EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_
   h->labels.assign(y, y + nd); h->real_resp = false; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
-  if (h->link != 3 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma and for proportions under the logit / probit links (likelihood id %d)", h->link);
+  if (h->link != 3 && h->link != 5 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   for (int i = 0; i < nd; ++i) {
     if (h->link == 3) { if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
+    else if (h->link == 5) { if (!(y[i] > 0. && y[i] < 1.)) return fail(" Must have 0 < y < 1 for the response variable ('y') for likelihood = 'beta', found %g ", y[i]); }
     else if (!(y[i] >= 0. && y[i] <= 1.)) return fail(" Must have 0 <= y <= 1 for the response variable ('y') (found %g at Vecchia position %d)", y[i], i);
   }
   h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->real_resp = true; h->grad_state = false; return 0;

@@ -97,6 +97,28 @@ def test_config4_n1e5_against_the_reference(gpb):
     assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
 
 
+def test_config4_n1e5_pivoted_cholesky_against_the_reference(gpb):
+    """Round 5: the same data with cg_preconditioner_type = "pivoted_cholesky" (rank 50; the (W^-1 + Sigma) form of the solves, pivchol_kernels.hip) against ONE evaluation
+    of the unmodified reference with that preconditioner (tests/golden/config4_pivchol_ref.npz, oracle/make_golden.py config4_pivchol): cg_delta_conv = 1e-6 -> 1e-8;
+    the defaults -> 1e-6 (the value is defined up to one CG / Lanczos iteration, as above; the (W^-1 + Sigma) residual norms are on another scale than vadu's)."""
+    path = os.path.join(GOLD, "config4_pivchol_ref.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/config4_pivchol_ref.npz has not been generated")
+    g = np.load(path)
+    n, m = 100000, 30
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
+                      num_neighbors=m, vecchia_ordering="random", seed=1)
+    mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky"})
+    v = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    ref = float(g["negll_0"])
+    assert abs(v - ref) <= 1e-6 * abs(ref), (v, ref, mdl.laplace_info())
+    mdl.set_optim_params({"cg_delta_conv": 1e-6})
+    vt = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    reft = float(g["negll_tight_0"])
+    assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
+
+
 def test_config3_shape_tree_with_categorical_columns_equals_the_oracle_tree(gpb, orc):
     """Round 5, at BASELINE config 3's shape (n = 1e5 rows, 50 columns, 255 bins, 31 leaves) with 6 of the columns categorical (12 / 100 / 250 categories): the
     device's whole-tree grower (categorical search, bitset partitions, resident row lists) against the oracle's primitives driven by tests/tree_harness.py -- the

@@ -53,7 +53,7 @@ def test_auxiliary_parameter_likelihoods_through_the_c_api_on_the_cpu_restatemen
     GPB_OptimCovPar with the shape in the lbfgs vector and FindInitialAuxPars' start, GPB_GetAuxPars, response predictions): the host code under
     tests/test_zz_laplace_aux_gpu.py's model-API tests, against the reference's fixtures, with the oracle-backed shim."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_aux_gpu.py"], extra=["-k", "model_api"])
-    assert "5 passed" in tail, tail
+    assert "7 passed" in tail, tail      # (4 gamma / negative_binomial cases + 2 beta cases + the error paths)
 
 
 def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):

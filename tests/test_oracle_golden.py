@@ -624,7 +624,7 @@ def test_oracle_gamma_negbin_value_and_gradient_match_the_reference(orc, name):
     negll, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=ac["lik"], aux=ac["aux"])
     ref0 = float(g[name + "_negll_0"])
     assert abs(negll - ref0) <= 1e-8 * abs(ref0), (negll, ref0)
-    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+    for fe_key, fe in (("", None), ("_fe", cases.aux_fixed_effects(ac, coords)[perm])):
         nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=ac["lik"], fixed_effects=fe, aux=ac["aux"],
                                                  cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
         ref = g[name + fe_key + "_grad_direct"]

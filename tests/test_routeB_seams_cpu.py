@@ -24,3 +24,5 @@ def test_patched_reference_host_code_on_the_cpu_restatement_of_the_shim():
     assert "ROUTE B SEAMS ON THE CPU RESTATEMENT: OK" in out.stdout
     assert "HIP device detected" in out.stdout + out.stderr      # the seams were active (the mock reports one device)
     assert "Laplace bernoulli_logit" in out.stdout and "reproduces the CPU path of the same build" in out.stdout
+    # round 5: the same seams with cg_preconditioner_type = "pivoted_cholesky" (HipEligible admits it; the host's PivotedCholsekyFactorizationSigma is skipped)
+    assert "Laplace bernoulli_logit:pivoted_cholesky n=800: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path" in out.stdout

@@ -49,7 +49,9 @@ def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_buil
     out = _run(["scripts/gpu_routeB.py", "--test", "--gp-only"], "ROUTE B ON MI355X: OK", 1500)
     assert out.count("GPU_use=true reproduces the CPU path of the same build") == 2
     # round 4: the Laplace seams (Bernoulli-logit and Poisson, n = 5000: evaluations and lbfgs fits) against the CPU path's stored values, and the GPBoost loop
-    assert out.count("(mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build") == 2
+    # (round 5: + the same seams with cg_preconditioner_type = "pivoted_cholesky")
+    assert out.count("(mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build") == 3
+    assert "Laplace bernoulli_logit:pivoted_cholesky n=5000: GPU_use=true" in out
     assert "y_aux and Newton leaf values from the resident factor) reproduces the CPU path" in out
 
 

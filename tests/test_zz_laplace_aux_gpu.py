@@ -1,4 +1,4 @@
-"""GPU (MI355X): likelihoods with an auxiliary parameter on the Vecchia-Laplace path -- gamma and negative_binomial (first slice of
+"""GPU (MI355X): likelihoods with an auxiliary parameter on the Vecchia-Laplace path -- gamma, negative_binomial and (second slice) beta (first slice of
 round 5) -- through the C ABI against the UNMODIFIED reference (tests/golden/laplace_aux_ref.npz, oracle/make_golden.py laplace_aux):
   * value at the default thresholds, value + gradient wrt (log sigma1^2, log a, log shape) at cases.LAPLACE_TIGHT (the reference's own CalcGradPars ->
     CalcGradNegMargLikelihoodLaplaceApproxVecchia incl. its auxiliary-parameter branch, likelihoods.h:6743-6808): 1e-8 relative;
@@ -34,7 +34,7 @@ def _state(orc, ac):
     st = shim.VecchiaState(co, c["m"])
     st.set_neighbors(nn)
     st.laplace_set_likelihood(ac["lik"])
-    if ac["lik"] == "gamma":
+    if ac["lik"] in ("gamma", "beta"):
         st.laplace_set_response_real(y[perm])
     else:
         st.laplace_set_labels(y[perm].astype(np.int32))
@@ -52,7 +52,7 @@ def test_value_and_gradient_match_the_reference(gpb, orc, name):
     negll, _ = st.laplace_logit(ct, cp[0], a)
     ref0 = float(g[name + "_negll_0"])
     assert abs(negll - ref0) <= 1e-8 * abs(ref0), (negll, ref0)
-    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+    for fe_key, fe in (("", None), ("_fe", cases.aux_fixed_effects(ac, coords)[perm])):
         st.laplace_set_fixed_effects(fe)
         nll_t, grad_t = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
         ref = g[name + fe_key + "_grad_direct"]
@@ -62,7 +62,8 @@ def test_value_and_gradient_match_the_reference(gpb, orc, name):
         assert abs(nll_t - ref_v) <= 1e-8 * abs(ref_v), (nll_t, ref_v)
     # another shape: the normalising constant and every likelihood term follow (against the oracle, itself pinned to the reference at 1e-9)
     st.laplace_set_fixed_effects(None)
-    for aux2 in (1.0, 0.37 * ac["aux"], 4.1 * ac["aux"]):
+    # (beta: a precision far below the data's makes the density bathtub-shaped, the information negative and the reference's own mode finding fail -- stay near the fixture's)
+    for aux2 in ((0.6 * ac["aux"], 2.0 * ac["aux"]) if ac["lik"] == "beta" else (1.0, 0.37 * ac["aux"], 4.1 * ac["aux"])):
         st.laplace_set_aux(aux2)
         nll2, grad2 = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
         on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=ac["lik"], aux=aux2, cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"],
@@ -128,7 +129,7 @@ def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name)
     m3 = gpb.GPModel(**kw)
     m3.fit(y, params={"init_aux_pars": [ac["aux"]], "estimate_aux_pars": False})
     assert m3.get_num_optim_iter() == int(g[name + "_fitfix_num_it"])
-    np.testing.assert_allclose(m3.get_cov_pars(), g[name + "_fitfix_cov_pars"], rtol=1e-4)
+    np.testing.assert_allclose(m3.get_cov_pars(), g[name + "_fitfix_cov_pars"], rtol=1e-3 if ac.get("flat_default") else 1e-4)     # (default thresholds; cases.py on flat_default)
     np.testing.assert_allclose(m3.get_aux_pars(), [ac["aux"]], rtol=0)
     nll3 = m3.get_current_neg_log_likelihood()
     assert abs(nll3 - float(g[name + "_fitfix_negll"])) <= 1e-7 * abs(nll3)
