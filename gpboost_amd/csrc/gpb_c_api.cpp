@@ -132,7 +132,8 @@ struct REModelHip {
   std::vector<double> init_coef;     // init_coef of GPB_SetOptimConfig (non-Gaussian models with covariates: start of the lbfgs vector)
   bool init_coef_from_iid_model = true;   // init_coef_aux_pars_from_iid_model (re_model.cpp:345; the packages' default)
   std::string cg_preconditioner_type = "vadu";   // ParsePreconditionerAlias default for a non-Gaussian Vecchia model (re_model_template.h:7137)
-  int piv_chol_rank = 50;                         // fitc_piv_chol_preconditioner_rank_ for "pivoted_cholesky" (default_piv_chol_preconditioner_rank_, re_model_template.h:5922)
+  int piv_chol_rank = 50;                         // fitc_piv_chol_preconditioner_rank_ for "pivoted_cholesky" (default_piv_chol_preconditioner_rank_, re_model_template.h:5922) / "fitc" (200, :5921)
+  std::vector<double> pc_ip; bool pc_ip_pushed = false;   // inducing points of the "fitc" preconditioner (k x d column-major; ind_points_determined_for_preconditioner_) and whether the device has them
   std::vector<double> offset;                     // GPB_SetOffsetData (fixed_effects_, has_fixed_effects_; re_model_template.h:6318-6321)
   bool has_offset = false;
   std::vector<double> y_host;                     // the response as last passed in (original order, no offset subtracted): y_vec_ of the Gaussian model
@@ -199,7 +200,22 @@ int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negat
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
   if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->vif || mdl->eh) return 0;
-  if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : 0, mdl->piv_chol_rank)) return shim_error();
+  const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : 0);
+  if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, type, mdl->piv_chol_rank)) return shim_error();
+  return 0;
+}
+int kmeans_plusplus(const std::vector<double>& x, int n, int d, int k, std::mt19937& gen, int max_it, std::vector<double>* means_out);
+// "fitc" preconditioner: its inducing points are determined ONCE, at the first covariance factor of the model (Calc_FITC_Preconditioner_Vecchia, re_model_template.h:9502-9593:
+// kmeans++ on the Vecchia-ordered (unique) coordinates from the model's generator, whatever that generator has drawn before -- the ordering shuffle, FindInitCovPar's
+// sub-sample), so this runs right before an evaluation, not in GPB_SetOptimConfig
+int laplace_prepare_preconditioner(REModelHip* mdl) {
+  if (mdl->cg_preconditioner_type != "fitc" || mdl->pc_ip_pushed || !mdl->vh) return 0;
+  const int k = mdl->piv_chol_rank;
+  if (mdl->n <= k) return set_error("Need to have less inducing points (currently fitc_piv_chol_preconditioner_rank = %d) than data points (%d) for cg_preconditioner_type = '%s' ", k, mdl->n, "fitc");
+  if (mdl->n0 < k) return set_error("Cannot have more inducing points than unique coordinates for cg_preconditioner_type = '%s' ", "fitc");
+  if (mdl->pc_ip.empty() && kmeans_plusplus(mdl->coords0, mdl->n0, mdl->d, k, mdl->rng, 1000, &mdl->pc_ip)) return -1;
+  if (gpb_hip_vecchia_laplace_set_inducing_points(mdl->vh, k, mdl->pc_ip.data())) return shim_error();
+  mdl->pc_ip_pushed = true;
   return 0;
 }
 int laplace_push_aux(REModelHip* mdl) {
@@ -358,6 +374,7 @@ int device_laplace(void* ctx, int op_in, double var, double a, double* out3) {
   const int cgt = first_update ? (int)std::round(mdl->cg_max_num_it_tridiag / 3.) : mdl->cg_max_num_it_tridiag;
   if (op == 0 || op == 1) {
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;        // the fit starts from mode 0 (InitializeModeAvec), then warm-starts
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(cg, 1),
                                      std::max(cgt, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
     mdl->lap_fit_first_eval = false;
@@ -380,6 +397,7 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
     mdl->aux_set = true;
     if (laplace_push_aux(mdl)) return -1;
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(mdl->cg_max_num_it, 1),
                                      std::max(mdl->cg_max_num_it_tridiag, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
     mdl->lap_fit_first_eval = false;
@@ -402,6 +420,7 @@ int device_laplace_fe(void* ctx, int op, double var, double a, const double* fix
   if (op == 0 || op == 1) {
     if (laplace_upload_fixed_effects(mdl, fixed_effects)) return -1;
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(mdl->cg_max_num_it, 1),
                                      std::max(mdl->cg_max_num_it_tridiag, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
     mdl->lap_fit_first_eval = false;
@@ -1467,10 +1486,15 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu" and -- round 5 -- "pivoted_cholesky" are built
     if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
     else if (pc == "pivoted_cholesky" || pc == "piv_chol" || pc == "piv_chol_on_Sigma") mdl->cg_preconditioner_type = "pivoted_cholesky";
-    else return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library ('vadu' and 'pivoted_cholesky' are)", pc.c_str());
+    else if (pc == "fitc" || pc == "FITC" || pc == "predictive_process_plus_diagonal") mdl->cg_preconditioner_type = "fitc";
+    else return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library ('vadu', 'pivoted_cholesky' and 'fitc' are)", pc.c_str());
+    const int rank_before = mdl->piv_chol_rank;
     if (piv_chol_rank > 0) mdl->piv_chol_rank = piv_chol_rank;                      // re_model_template.h:900-914
     else if (piv_chol_rank != -999) return set_error("fitc_piv_chol_preconditioner_rank is not > 0, found = %d ", piv_chol_rank);
-    else if (pc != "") mdl->piv_chol_rank = 50;
+    else if (pc != "") mdl->piv_chol_rank = mdl->cg_preconditioner_type == "fitc" ? 200 : 50;
+    if (mdl->cg_preconditioner_type == "fitc" && mdl->piv_chol_rank != rank_before && !mdl->pc_ip.empty() && (int)mdl->pc_ip.size() != mdl->piv_chol_rank * mdl->d)
+      return set_error("GPB_SetOptimConfig: the inducing points of the fitc preconditioner have been determined for rank %d; the rank cannot change afterwards on this path", (int)mdl->pc_ip.size() / mdl->d);
+    mdl->pc_ip_pushed = false;
     if (mdl->cg_preconditioner_type == "pivoted_cholesky" && !mdl->vif && !mdl->eh && mdl->piv_chol_rank > (mdl->n_re > 0 ? mdl->n_re : mdl->n))
       return set_error("'fitc_piv_chol_preconditioner_rank' cannot be larger than the dimension of the mode (= number of unique locations) ");     // likelihoods.h:936-938
     if (laplace_push_preconditioner(mdl)) return -1;
@@ -1498,6 +1522,7 @@ int GPB_EvalNegLogLikelihood(REModelHandle handle, const double* y_data, double*
     if (y_data) { if (laplace_upload_data(mdl, y_data, fixed_effects)) return -1; }
     else { if (laplace_upload_fixed_effects(mdl, fixed_effects)) return -1; if (laplace_push_aux(mdl)) return -1; }   // labels stay resident; the offset and the auxiliary parameters are this call's
     const double cc = mdl->cov_type == 0 ? 1. : (mdl->cov_type == 1 ? std::sqrt(3.) : std::sqrt(5.));
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, sigma1_2, cc / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace,
                                       mdl->cg_max_num_it, mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding,
                                       1 /* mode reset to 0, :3199-3201 */, mdl->lap_info, nullptr)) return shim_error();
@@ -2199,6 +2224,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     else if (laplace_upload_fixed_effects(mdl, fel)) return -1;
     const double a_tr = range_const(mdl) / rho;
     std::vector<double> mode(mdl->n_re > 0 ? mdl->n_re : mdl->n);
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, s12, a_tr, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, mdl->cg_max_num_it,
                                       mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding, 1, mdl->lap_info, mode.data()))
       return shim_error();
@@ -2922,6 +2948,7 @@ int GPB_PredictREModelTrainingDataRandomEffects(REModelHandle handle, const doub
     const int nr = mdl->n_re > 0 ? mdl->n_re : mdl->n;
     if (calc_var && nr > 20000) return set_error("GPB_PredictREModelTrainingDataRandomEffects: variances for %d random effects of a non-Gaussian model (one block solve per 52 of them; limit 20000)", nr);
     std::vector<double> mode(nr), var(calc_var ? nr : 0);
+    if (laplace_prepare_preconditioner(mdl)) return -1;
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, s12, range_const(mdl) / rho, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, mdl->cg_max_num_it,
                                       mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding, 1, mdl->lap_info, mode.data()))
       return shim_error();

@@ -210,8 +210,13 @@ class VecchiaState(object):
 
     def laplace_set_preconditioner(self, cg_preconditioner_type="vadu", rank=-999):
         """cg_preconditioner_type of the iterative methods: "vadu" or "pivoted_cholesky" with `rank` columns (gpb_hip_vecchia_laplace_set_preconditioner)."""
-        t = {"vadu": 0, "pivoted_cholesky": 1}[cg_preconditioner_type]
+        t = {"vadu": 0, "pivoted_cholesky": 1, "fitc": 2}[cg_preconditioner_type]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_preconditioner(self.h, C.c_int(t), C.c_int(int(rank))))
+
+    def laplace_set_inducing_points(self, ip):
+        """Inducing points (k x d) of the "fitc" preconditioner (gpb_hip_vecchia_laplace_set_inducing_points)."""
+        ipf = np.asfortranarray(ip, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_laplace_set_inducing_points(self.h, C.c_int(ipf.shape[0]), _p(ipf)))
 
     def laplace_set_response_real(self, y):
         """gamma: the real-valued response (> 0), in the order laplace_set_labels takes its labels."""

@@ -439,13 +439,19 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, con
  * include/GPBoost/likelihoods.h:11394-11404 and their derivatives :12468-12474, :13293-13305, :13800-13820).  on != 0 here adds the binomial normalising constant
  * sum lgamma(w + 1) - lgamma(k + 1) - lgamma(w - k + 1), k = w y (:10612-10622). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on);
-/* cg_preconditioner_type of the iterative methods (round 5; SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, include/GPBoost/re_model_template.h:5906): type 0 = "vadu"
+/* cg_preconditioner_type of the iterative methods (round 5; SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, include/GPBoost/re_model_template.h:5906; type 2 = "fitc": below): type 0 = "vadu"
  * (P = B^T (D^-1 + W) B; the solves in the form (Sigma^-1 + W) u = rhs, src/GPBoost/CG_utils.cpp:21-229), 1 = "pivoted_cholesky" (P = W^-1 + L_k L_k^T with the
  * rank-k pivoted Cholesky factor of the non-approximated covariance matrix, include/GPBoost/CG_utils.h:438-486; the solves in the form (W^-1 + Sigma) u' = Sigma rhs,
  * u = W^-1 u', CG_utils.cpp:231-499; log-determinant and gradients: include/GPBoost/likelihoods.h:16389-16465, :16554-16611, :16716-16736).  rank =
  * fitc_piv_chol_preconditioner_rank_ (<= 0: the reference's default 50, re_model_template.h:5922); it may not exceed the number of random effects.  Takes effect at the
  * next evaluation; evaluation, gradients (covariance parameters, auxiliary parameter, fixed effects) follow it, predictions keep solving with "vadu". */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t* h, int type, int rank);
+/* type 2 = "fitc" (round 5): P = diag(W^-1 + Sigma_m[0][0] - ||V_i||^2) + C Sigma_m^-1 C' with the cross-covariance C of k inducing points, Sigma_m their covariance
+ * (diagonal x (1 + 1e-6)), V = (L_m^-1 C')' -- Calc_FITC_Preconditioner_Vecchia (include/GPBoost/re_model_template.h:9502-9593), the fitc branches of
+ * include/GPBoost/likelihoods.h:16296-16311, :16419-16437, :16465-16470, :16576-16583, :16612-16633; the same (W^-1 + Sigma) solves and the same device kernels as
+ * "pivoted_cholesky" with C in place of L_k.  The inducing points come from the host (k x d, column-major; the reference draws them by kmeans++ from the model's
+ * generator at the first covariance factor -- libstdc++'s distributions); rank <= 0 in set_preconditioner: the reference's default 200. */
+GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip_colmajor);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);

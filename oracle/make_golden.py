@@ -126,7 +126,7 @@ def laplace_grad_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_grad_ref.npz"), **res)
 
 
-def laplace_pivchol_fixture(out_dir):
+def laplace_pivchol_fixture(out_dir, only=()):
     """cg_preconditioner_type = "pivoted_cholesky" (the (W^-1 + Sigma) form of the Vecchia-Laplace solves, P = W^-1 + L_k L_k^T; CG_utils.cpp:231-499,
     likelihoods.h:16277-16296, :16389-16465, :16554-16611, :16716-16736) on cases.LAPLACE_PIVCHOL_CASES, from the reference's own routines:
       *_negll_direct, *_grad_direct   value and gradient wrt (log sigma1^2, log a[, log aux]) from CalcGradPars at cases.LAPLACE_TIGHT (+ *_fe_* with the offset)
@@ -134,14 +134,19 @@ def laplace_pivchol_fixture(out_dir):
       *_gradF                          the boosting gradient d(-mll) / dF at cases.LAPLACE_TIGHT (data order)
       *_fit_*                          one lbfgs fit at cases.LAPLACE_TIGHT: estimates, iterations, final value"""
     res = {}
+    path = os.path.join(out_dir, "laplace_pivchol_ref.npz")
+    if only and os.path.exists(path):        # `laplace_pivchol <case> ...`: only these cases are (re)generated
+        res = dict(np.load(path))
     tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode_finding=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
     for name, pc in cases.LAPLACE_PIVCHOL_CASES.items():
+        if only and name not in only:
+            continue
         c = cases.LAPLACE_CASES[pc["model"]]
         coords, y = cases.make_pivchol_data(pc)
         cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
         rank = -999 if pc["rank"] is None else int(pc["rank"])
         aux = pc.get("aux")
-        pcargs = dict(cg_preconditioner_type="pivoted_cholesky", piv_chol_rank=rank)
+        pcargs = dict(cg_preconditioner_type=pc.get("pc", "pivoted_cholesky"), piv_chol_rank=rank)
         for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
             nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, pc["lik"], fe, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"],
                                                     aux_pars=aux, estimate_aux=aux is not None, **tight, **pcargs)
@@ -1135,7 +1140,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_weights":
         laplace_weights_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":
-        laplace_pivchol_fixture(os.path.join(ROOT, "tests", "golden"))
+        laplace_pivchol_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":
         laplace_aux_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_grad":

@@ -19,6 +19,9 @@ t0 = time.perf_counter()
 mdl = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
                           num_neighbors=m, vecchia_ordering="random", seed=1)
 print("setup %.3f s" % (time.perf_counter() - t0), flush=True)
+if "--fitc" in sys.argv:         # cg_preconditioner_type = "fitc" (200 inducing points by kmeans++)
+    mdl.set_optim_params({"cg_preconditioner_type": "fitc"})
+    print("preconditioner:", mdl.get_cg_preconditioner_type(), flush=True)
 if "--pivchol" in sys.argv:      # cg_preconditioner_type = "pivoted_cholesky" (rank 50) instead of the default "vadu"
     mdl.set_optim_params({"cg_preconditioner_type": "pivoted_cholesky"})
     print("preconditioner:", mdl.get_cg_preconditioner_type(), flush=True)

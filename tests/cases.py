@@ -156,7 +156,17 @@ LAPLACE_PIVCHOL_CASES = {
     "pc_probit_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="bernoulli_probit", rank=None),
     "pc_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", rank=None, aux=2.0, true_aux=2.5),
     "pc_negbin_n2000_r30": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", rank=30, aux=3.0, true_aux=4.0),
+    # cg_preconditioner_type = "fitc" (pc="fitc"; rank = number of inducing points, None: the reference's default 200): the same solves with
+    # P = diag(W^-1 + Sigma_m[0][0] - ||V_i||^2) + C Sigma_m^-1 C', inducing points by kmeans++ from the model's generator (re_model_template.h:9502-9593)
+    "fitc_logit_n1500_r100": dict(model="lap_u2d_n1500_mat15_m30", lik="bernoulli_logit", rank=100, pc="fitc"),
+    "fitc_poisson_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="poisson", rank=None, pc="fitc"),
+    "fitc_gamma_u3d_n1200_r60": dict(model="lap_u3d_n1200_mat25_m15", lik="gamma", rank=60, aux=0.8, true_aux=1.2, pc="fitc"),
 }
+
+
+def pivchol_rank(pc):
+    """Columns of the low-rank part a LAPLACE_PIVCHOL_CASES entry asks for (None: the reference's defaults 50 / 200)."""
+    return pc["rank"] if pc["rank"] is not None else (200 if pc.get("pc") == "fitc" else 50)
 
 
 def make_pivchol_data(pc):

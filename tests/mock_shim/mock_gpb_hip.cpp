@@ -34,6 +34,7 @@ void orc_clear_aux(void);
 int orc_pivoted_cholesky(const double* coords, int n, int d, int cov_type, double var, double a, int max_it, double err_tol, double* L_out);
 void orc_set_pivchol(const double* L_k, int k, const double* rand_vec2);
 void orc_clear_pivchol(void);
+void orc_set_fitc(const double* C_nk, const double* V_nk, const double* Sm_kk, double logdet_Sm, int k, const double* rand_vec2);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
                                      int cg_max_num_it_tridiag, double cg_delta_conv, double delta_conv_mode_finding, double* out6, double* grad2,
@@ -144,7 +145,8 @@ struct gpb_hip_vecchia {
   double wv(int k) const { return weights.empty() ? 1.0 : weights[k]; }
   std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
   bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
-  int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns
+  int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns, 2 = fitc with the inducing points pc_ip
+  std::vector<double> pc_ip; int pc_nip = 0;       // k x d column-major
   double yv(int k) const { return (link == 3 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
@@ -245,8 +247,40 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   h->has_factor = true; h->f_gauss = 0;
   std::vector<double> rv((size_t)n * nrv);
   // pivoted_cholesky: L_k at these parameters, rand_vec_trace_I2_ drawn first (generator counter 0), rand_vec_trace_I_ second (1)
-  std::vector<double> pcL, rv2;
-  const bool pc = h->pc_type == 1;
+  std::vector<double> pcL, rv2, pcV, pcSm;
+  const bool pc = h->pc_type >= 1;
+  if (h->pc_type == 2) {       // fitc: cross-covariance C, Sigma_m (diagonal x (1 + 1e-6)), V = (L_m^-1 C')' (Calc_FITC_Preconditioner_Vecchia, re_model_template.h:9577-9591)
+    const int k = h->pc_nip, d = h->d;
+    if (k < 1) return fail("the fitc preconditioner needs its inducing points (gpb_hip_vecchia_laplace_set_inducing_points)");
+    auto covf = [&](double dist) { const double r = a * dist; return cov == 0 ? var * std::exp(-r) : (cov == 1 ? var * (1. + r) * std::exp(-r) : var * (1. + r + r * r / 3.) * std::exp(-r)); };
+    pcL.assign((size_t)n * k, 0.); pcV.assign((size_t)n * k, 0.); pcSm.assign((size_t)k * k, 0.); rv2.assign((size_t)k * nrv, 0.);
+    for (int p = 0; p < k; ++p) for (int q = 0; q < k; ++q) {
+      double d2 = 0.; for (int c = 0; c < d; ++c) { const double t = h->pc_ip[(size_t)c * k + p] - h->pc_ip[(size_t)c * k + q]; d2 += t * t; }
+      pcSm[(size_t)p * k + q] = covf(std::sqrt(d2)) * (p == q ? 1.0 + 1e-6 : 1.0);
+    }
+    std::vector<double> Lm((size_t)k * k, 0.);
+    double ld = 0.;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double acc = pcSm[(size_t)i * k + j];
+        for (int q = 0; q < j; ++q) acc -= Lm[(size_t)i * k + q] * Lm[(size_t)j * k + q];
+        if (i == j) { if (!(acc > 0.)) return fail("mock: Sigma_m is not positive definite"); Lm[(size_t)i * k + i] = std::sqrt(acc); ld += std::log(Lm[(size_t)i * k + i]); }
+        else Lm[(size_t)i * k + j] = acc / Lm[(size_t)j * k + j];
+      }
+    for (int i = 0; i < n; ++i) {
+      for (int q = 0; q < k; ++q) {
+        double d2 = 0.; for (int c = 0; c < d; ++c) { const double t = h->coords[(size_t)c * n + i] - h->pc_ip[(size_t)c * k + q]; d2 += t * t; }
+        pcL[(size_t)q * n + i] = covf(std::sqrt(d2));
+      }
+      for (int q = 0; q < k; ++q) {       // V_i = L_m^-1 C_i'
+        double acc = pcL[(size_t)q * n + i];
+        for (int p = 0; p < q; ++p) acc -= Lm[(size_t)q * k + p] * pcV[(size_t)p * n + i];
+        pcV[(size_t)q * n + i] = acc / Lm[(size_t)q * k + q];
+      }
+    }
+    orc_gen_rand_normal(seed, 0ull, k, nrv, rv2.data());
+    orc_set_fitc(pcL.data(), pcV.data(), pcSm.data(), 2. * ld, k, rv2.data());
+  } else
   if (pc) {
     const int k = std::min(h->pc_rank, n);
     pcL.assign((size_t)n * k, 0.); rv2.assign((size_t)k * nrv, 0.);
@@ -500,11 +534,42 @@ EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const
 }
 EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on) { h->binomial = on != 0; return 0; }
 EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t* h, int type, int rank) {
-  if (type != 0 && type != 1) return fail("preconditioner type %d is not on this path (0 = vadu, 1 = pivoted_cholesky)", type);
-  const int rk = rank > 0 ? rank : 50;
+  if (type != 0 && type != 1 && type != 2) return fail("preconditioner type %d is not on this path (0 = vadu, 1 = pivoted_cholesky, 2 = fitc)", type);
+  const int rk = rank > 0 ? rank : (type == 2 ? 200 : 50);
   if (type == 1 && rk > h->n) return fail("'fitc_piv_chol_preconditioner_rank' cannot be larger than the dimension of the mode (= number of unique locations) ");
   if (h->pc_type != type || h->pc_rank != rk) h->grad_state = false;
   h->pc_type = type; h->pc_rank = rk; return 0;
+}
+// Lloyd iterations of the inducing-point selection (kmeans_plusplus -> calculate_means, src/GPBoost/GP_utils.cpp:237-308) as gpb_hip.cpp: gpb_hip_kmeans_lloyd runs
+// them: first mean at the smallest Euclidean distance, means updated per cluster over its rows in ascending order, until the means repeat or max_it
+EXPORT int gpb_hip_kmeans_lloyd(int32_t n, int32_t d, const double* x, int32_t k, double* means_rowmajor, int32_t max_it, int32_t* iterations) {
+  if (!x || !means_rowmajor || n < 1 || d < 1 || d > 3 || k < 1 || k > 256) return fail("gpb_hip_kmeans_lloyd: invalid argument (d <= 3, k <= 256)");
+  std::vector<double> means(means_rowmajor, means_rowmajor + (size_t)k * d), old(means.size(), 0.), oldold(means.size(), 0.), mnew(means.size());
+  std::vector<int> cl(n), cnt(k);
+  int count = 0;
+  do {
+    oldold = old; old = means;
+    for (int r = 0; r < n; ++r) {
+      int best = 0; double bd = 0.;
+      for (int j = 0; j < k; ++j) {
+        double s2 = 0.; for (int c = 0; c < d; ++c) { const double t = x[(size_t)c * n + r] - means[(size_t)j * d + c]; s2 += t * t; }
+        const double dd = std::sqrt(s2);
+        if (j == 0 || dd < bd) { bd = dd; best = j; }
+      }
+      cl[r] = best;
+    }
+    std::fill(mnew.begin(), mnew.end(), 0.); std::fill(cnt.begin(), cnt.end(), 0);
+    for (int r = 0; r < n; ++r) { for (int c = 0; c < d; ++c) mnew[(size_t)cl[r] * d + c] += x[(size_t)c * n + r]; cnt[cl[r]]++; }
+    for (int j = 0; j < k; ++j) if (cnt[j] > 0) for (int c = 0; c < d; ++c) means[(size_t)j * d + c] = mnew[(size_t)j * d + c] / cnt[j];
+    ++count;
+  } while (means != old && means != oldold && count != max_it);
+  std::copy(means.begin(), means.end(), means_rowmajor);
+  if (iterations) *iterations = count;
+  return 0;
+}
+EXPORT int gpb_hip_vecchia_laplace_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip) {
+  if (k < 1 || k >= h->n) return fail("Need to have less inducing points (currently fitc_piv_chol_preconditioner_rank = %d) than data points (%d) for cg_preconditioner_type = 'fitc' ", k, h->n);
+  h->pc_ip.assign(ip, ip + (size_t)k * h->d); h->pc_nip = k; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const double* w) {
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
@@ -670,6 +735,6 @@ NOT_IN_MOCK(gpb_hip_exact_create) NOT_IN_MOCK(gpb_hip_exact_fisher_std_errors) N
 NOT_IN_MOCK(gpb_hip_exact_nll_terms) NOT_IN_MOCK(gpb_hip_exact_predict) NOT_IN_MOCK(gpb_hip_exact_psi_inv_diag) NOT_IN_MOCK(gpb_hip_exact_set_y)
 NOT_IN_MOCK(gpb_hip_vecchia_fisher_std_errors) NOT_IN_MOCK(gpb_hip_vecchia_grad_terms_allreduce)
 NOT_IN_MOCK(gpb_hip_vecchia_nll_terms_allreduce)
-NOT_IN_MOCK(gpb_hip_vecchia_set_nugget_diag) NOT_IN_MOCK(gpb_hip_hist_register_host_buffers) NOT_IN_MOCK(gpb_hip_hist_unregister_host_buffers) NOT_IN_MOCK(gpb_hip_kmeans_lloyd) NOT_IN_MOCK(gpb_hip_vecchia_timing) NOT_IN_MOCK(gpb_hip_mailbox_create) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_attach) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_info) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_detach)
+NOT_IN_MOCK(gpb_hip_vecchia_set_nugget_diag) NOT_IN_MOCK(gpb_hip_hist_register_host_buffers) NOT_IN_MOCK(gpb_hip_hist_unregister_host_buffers) NOT_IN_MOCK(gpb_hip_vecchia_timing) NOT_IN_MOCK(gpb_hip_mailbox_create) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_attach) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_info) NOT_IN_MOCK(gpb_hip_vecchia_mailbox_detach)
 NOT_IN_MOCK(gpb_hip_vecchia_vif_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_grad_sums) NOT_IN_MOCK(gpb_hip_vecchia_vif_get_grad_factor) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_obs_only) NOT_IN_MOCK(gpb_hip_vecchia_vif_predict_cond_all) NOT_IN_MOCK(gpb_hip_vecchia_vif_set_inducing_points)
 }  // extern "C"

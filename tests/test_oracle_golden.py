@@ -681,12 +681,21 @@ def _pivchol_setup(orc, name):
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     cp = c["cov_pars"][0]
     a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
-    return pc, c, coords, y, perm, co, nn, ct, cp, a, (50 if pc["rank"] is None else pc["rank"])
+    return pc, c, coords, y, perm, co, nn, ct, cp, a, cases.pivchol_rank(pc)
+
+
+def _preconditioner_context(orc, pc, c, coords, co, ct, var, a, rank):
+    """orc.pivoted_cholesky_preconditioner, or -- pc = "fitc" -- orc.fitc_preconditioner with the inducing points the reference's generator draws (orc.vif_setup)."""
+    if pc.get("pc") == "fitc":
+        ip = orc.vif_setup(coords, c["m"], rank, c["ordering"], c["seed"])[3]
+        return orc.fitc_preconditioner(co, ip, ct, var, a)
+    return orc.pivoted_cholesky_preconditioner(co, ct, var, a, rank=rank)
 
 
 @pytest.mark.parametrize("name", sorted(cases.LAPLACE_PIVCHOL_CASES))
 def test_oracle_pivoted_cholesky_preconditioner_matches_the_reference(orc, name):
-    """The (W^-1 + Sigma) form of the Vecchia-Laplace solves with P = W^-1 + L_k L_k^T (orc.pivoted_cholesky_preconditioner: PivotedCholsekyFactorizationSigma,
+    """(fitc_* cases: the same with cg_preconditioner_type = "fitc" -- orc.fitc_preconditioner, the fitc branches of the same reference functions.)
+    The (W^-1 + Sigma) form of the Vecchia-Laplace solves with P = W^-1 + L_k L_k^T (orc.pivoted_cholesky_preconditioner: PivotedCholsekyFactorizationSigma,
     CGVecchiaLaplace_Version_SigmaPlusWinvVec, CGTridiagVecchiaLaplace_Version_SigmaPlusWinv, the pivoted_cholesky branches of CalcLogDetStochVecchia /
     CalcLogDetStochDerivModeVecchia / CalcLogDetStochDerivCovParVecchia) against the reference's own CalcGradPars at cases.LAPLACE_TIGHT
     (tests/golden/laplace_pivchol_ref.npz, oracle/make_golden.py laplace_pivchol): value 1e-9, gradient (incl. the auxiliary parameter's component) 1e-8,
@@ -694,7 +703,7 @@ def test_oracle_pivoted_cholesky_preconditioner_matches_the_reference(orc, name)
     g = np.load(os.path.join(GOLD, "laplace_pivchol_ref.npz"))
     pc, c, coords, y, perm, co, nn, ct, cp, a, rank = _pivchol_setup(orc, name)
     tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
-    with orc.pivoted_cholesky_preconditioner(co, ct, cp[0], a, rank=rank) as ctx:
+    with _preconditioner_context(orc, pc, c, coords, co, ct, cp[0], a, rank) as ctx:
         assert ctx.k >= 1
         for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
             nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], fixed_effects=fe, aux=pc.get("aux"), **tight)

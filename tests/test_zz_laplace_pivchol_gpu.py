@@ -1,4 +1,4 @@
-"""GPU (MI355X): cg_preconditioner_type = "pivoted_cholesky" on the Vecchia-Laplace path (the second entry of the reference's
+"""GPU (MI355X): cg_preconditioner_type = "pivoted_cholesky" and "fitc" on the Vecchia-Laplace path (the second entry of the reference's
 SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, re_model_template.h:5906) -- the solves in the form (W^-1 + Sigma) u' = Sigma rhs preconditioned with
 P = W^-1 + L_k L_k^T (pivchol_kernels.hip, gpb_laplace.inc) -- through the C ABI against the UNMODIFIED reference (tests/golden/laplace_pivchol_ref.npz,
 oracle/make_golden.py laplace_pivchol):
@@ -44,9 +44,17 @@ def _state(orc, pc):
         st.laplace_set_labels(y[perm].astype(np.int32))
     if "aux" in pc:
         st.laplace_set_aux(pc["aux"])
-    rank = 50 if pc["rank"] is None else pc["rank"]
-    st.laplace_set_preconditioner("pivoted_cholesky", -999 if pc["rank"] is None else pc["rank"])
+    rank = cases.pivchol_rank(pc)
+    st.laplace_set_preconditioner(pc.get("pc", "pivoted_cholesky"), -999 if pc["rank"] is None else pc["rank"])
+    if pc.get("pc") == "fitc":       # the inducing points are the host's part (kmeans++ from the model's generator): here the oracle's restatement of that draw
+        st.laplace_set_inducing_points(orc.vif_setup(coords, c["m"], rank, c["ordering"], c["seed"])[3])
     return st, c, coords, y, perm, co, nn, ct, rank
+
+
+def _orc_context(orc, pc, c, coords, co, ct, var, a, rank):
+    if pc.get("pc") == "fitc":
+        return orc.fitc_preconditioner(co, orc.vif_setup(coords, c["m"], rank, c["ordering"], c["seed"])[3], ct, var, a)
+    return orc.pivoted_cholesky_preconditioner(co, ct, var, a, rank=rank)
 
 
 @pytest.mark.parametrize("name", sorted(cases.LAPLACE_PIVCHOL_CASES))
@@ -82,7 +90,7 @@ def test_value_and_gradient_match_the_reference(gpb, orc, name):
     st.close()
 
 
-@pytest.mark.parametrize("name", ["pc_logit_n2000", "pc_poisson_n1500_r20"])
+@pytest.mark.parametrize("name", ["pc_logit_n2000", "pc_poisson_n1500_r20", "fitc_logit_n1500_r100"])
 def test_steps_of_the_gradient_match_the_oracle(gpb, orc, name):
     """d logdet / d mode with the row-wise control variate of the pivoted_cholesky branch, the implicit solve in the (W^-1 + Sigma) form, and per parameter
     {mode' SigmaI_deriv mode, d logdet / d theta, implicit part} against orc_vecchia_laplace_grad inside orc.pivoted_cholesky_preconditioner; at other
@@ -92,7 +100,7 @@ def test_steps_of_the_gradient_match_the_oracle(gpb, orc, name):
     for var, rho, reset in ((c["cov_pars"][0][0], c["cov_pars"][0][1], True), (0.6, 0.22, False)):
         a = RC[ct] / rho
         nll, grad, parts = st.laplace_eval_grad(ct, var, a, reset_mode=reset, want_parts=True, **cases.LAPLACE_TIGHT)
-        with orc.pivoted_cholesky_preconditioner(co, ct, var, a, rank=rank):
+        with _orc_context(orc, pc, c, coords, co, ct, var, a, rank):
             on, og, op = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=pc["lik"], want_parts=True, **TIGHT_ORC)
         assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
         np.testing.assert_allclose(grad, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
@@ -111,6 +119,11 @@ def test_errors_of_the_preconditioner_entry_point(gpb, orc):
         st.laplace_set_preconditioner("pivoted_cholesky", len(y) + 1)
     with pytest.raises(gpb.GPBoostError, match="not on this path"):
         shim._shim_call(shim._lib().gpb_hip_vecchia_laplace_set_preconditioner(st.h, 7, 10))
+    st.laplace_set_preconditioner("fitc", 100)
+    with pytest.raises(gpb.GPBoostError, match="inducing points"):
+        st.laplace_logit(ct, 1.0, 5.0)                 # fitc without its inducing points
+    with pytest.raises(gpb.GPBoostError, match="less inducing points"):
+        st.laplace_set_inducing_points(np.zeros((len(y), 2)))
     st.close()
 
 
@@ -124,13 +137,13 @@ def test_model_api_evaluation_and_fit_follow_the_reference(gpb, name):
     coords, y = cases.make_pivchol_data(pc)
     kw = dict(likelihood=pc["lik"], gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
               num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
-    pcp = {"cg_preconditioner_type": "pivoted_cholesky"}
+    pcp = {"cg_preconditioner_type": pc.get("pc", "pivoted_cholesky")}
     if pc["rank"] is not None:
         pcp["fitc_piv_chol_preconditioner_rank"] = pc["rank"]
     cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
     mdl = gpb.GPModel(**kw)
     mdl.set_optim_params(dict(pcp))
-    assert mdl.get_cg_preconditioner_type() == "pivoted_cholesky"
+    assert mdl.get_cg_preconditioner_type() == pc.get("pc", "pivoted_cholesky")
     v = mdl.neg_log_likelihood(cp, y, aux_pars=[pc["aux"]]) if "aux" in pc else mdl.neg_log_likelihood(cp, y)
     ref_d = float(g[name + "_negll_default"])
     assert abs(v - ref_d) <= 1e-6 * abs(ref_d), (v, ref_d)
@@ -162,3 +175,10 @@ def test_model_api_errors_for_the_preconditioner(gpb):
     mdl.set_optim_params({"cg_preconditioner_type": "piv_chol_on_Sigma", "fitc_piv_chol_preconditioner_rank": 25})     # ParsePreconditionerAlias
     assert mdl.get_cg_preconditioner_type() == "pivoted_cholesky"
     assert np.isfinite(mdl.neg_log_likelihood(np.array([1.0, 0.1]), y[:300]))
+    m2 = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords[:300], cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
+    m2.set_optim_params({"cg_preconditioner_type": "FITC", "fitc_piv_chol_preconditioner_rank": 300})
+    assert m2.get_cg_preconditioner_type() == "fitc"
+    with pytest.raises(gpb.GPBoostError, match="less inducing points"):
+        m2.neg_log_likelihood(np.array([1.0, 0.1]), y[:300])
+    m2.set_optim_params({"fitc_piv_chol_preconditioner_rank": 40})
+    assert np.isfinite(m2.neg_log_likelihood(np.array([1.0, 0.1]), y[:300]))
