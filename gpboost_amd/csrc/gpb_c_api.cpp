@@ -93,7 +93,7 @@ struct REModelHip {
   std::vector<int> labels;      // y in {0,1}, Vecchia order
   // likelihoods with an auxiliary parameter (round 5: gamma, negative_binomial -- the shape; likelihoods.h:298-322): num_aux_pars_, aux_pars_ (original
   // scale), AuxParsHaveBeenSet(), init_aux_pars_ / init_aux_pars_given_ (re_model.cpp:327-344), estimate_aux_pars_ (re_model_template.h:909-912)
-  int num_aux = 0; double aux_pars[1] = {1.}; bool aux_set = false; double init_aux[1] = {-1.}; bool init_aux_given = false; bool estimate_aux_pars = true;
+  int num_aux = 0; double aux_pars[2] = {1., 2.}; bool aux_set = false; double init_aux[2] = {-1., -1.}; bool init_aux_given = false; bool estimate_aux_pars = true;      // (t: scale, df -- internal default df 2, likelihoods.h:392)
   std::vector<double> resp_real;   // gamma: the real-valued response, Vecchia order
   // repeated locations of a non-Gaussian model (the reference's unique-location mapping, Vecchia_utils.cpp:1156-1168, re_comp.h:863-885): the
   // Vecchia handle lives on the n_re unique locations; datum at shuffled position k belongs to random effect re_of[k]; dorder lists the
@@ -181,10 +181,10 @@ bool is_proportion_likelihood(const std::string& lik) {
 bool is_logit_link(const std::string& lik) { return lik == "bernoulli_logit" || lik == "binomial_logit" || lik == "quasi_bernoulli_logit"; }
 bool is_probit_link(const std::string& lik) { return lik == "bernoulli_probit" || lik == "binomial_probit" || lik == "quasi_bernoulli_probit"; }
 int laplace_link_id(const std::string& lik) {
-  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : 0))));
+  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : (lik == "t" ? 6 : 0)))));
 }
 bool supported_non_gaussian(const std::string& lik) {
-  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || is_proportion_likelihood(lik);
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || is_proportion_likelihood(lik);
 }
 // Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
 std::string parse_likelihood_alias(const std::string& lik) {
@@ -195,7 +195,7 @@ std::string parse_likelihood_alias(const std::string& lik) {
   if (lik == "quasi_binary" || lik == "quasi_binary_logit") return "quasi_bernoulli_logit";
   return lik;
 }
-int num_aux_of(const std::string& lik) { return (lik == "gamma" || lik == "negative_binomial" || lik == "beta") ? 1 : 0; }
+int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma" || lik == "negative_binomial" || lik == "beta") ? 1 : 0); }      // t: scale, df (likelihoods.h:398-407)
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
@@ -227,6 +227,30 @@ int laplace_push_aux(REModelHip* mdl) {
 // (method of moments); y, fixed_effects in data order
 // (wts: sample weights in the order of y, or NULL -- weighted moments with sum of weights in place of n, likelihoods.h:1856-1910)
 double initial_aux_par(const std::string& lik, int n, const double* y, const double* fe, const double* wts = nullptr) {
+  if (lik == "t") {         // MAD as a robust start of the scale, the inter-quartile range if it is zero (likelihoods.h:1973-2010); the df keep their current value
+    std::vector<double> v(n);
+    for (int i = 0; i < n; ++i) v[i] = fe ? y[i] - fe[i] : y[i];
+    auto median = [](std::vector<double>& a) {      // CalculateMedianPartiallySortInput (utils.h): nth_element, mean of the two middle values for an even count
+      const size_t nn = a.size(), pos = nn / 2;
+      std::nth_element(a.begin(), a.begin() + pos, a.end());
+      double med = a[pos];
+      if (nn % 2 == 0) { std::nth_element(a.begin(), a.begin() + pos - 1, a.end()); med = (a[pos - 1] + med) / 2.; }
+      return med;
+    };
+    const double med = median(v);
+    for (int i = 0; i < n; ++i) v[i] = std::fabs(v[i] - med);
+    double sc = 1.4826 * median(v);
+    if (sc <= 1e-10) {
+      for (int i = 0; i < n; ++i) v[i] = fe ? y[i] - fe[i] : y[i];
+      int pos = (int)(n * 0.25);
+      std::nth_element(v.begin(), v.begin() + pos, v.end());
+      const double q25 = v[pos];
+      pos = (int)(n * 0.75);
+      std::nth_element(v.begin(), v.begin() + pos, v.end());
+      sc = (v[pos] - q25) / 1.349;
+    }
+    return sc;
+  }
   if (lik == "beta") {      // method of moments for the precision, phi = mu (1 - mu) / var - 1, clipped to [0.1, 100] (likelihoods.h:1952-1972; the fixed effects are not used there)
     double avg = 0., sum_sq = 0., sw = 0.;
     for (int i = 0; i < n; ++i) { const double w = wts ? wts[i] : 1.0; avg += w * y[i]; sum_sq += w * y[i] * y[i]; sw += w; }
@@ -295,16 +319,17 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   mdl->labels.resize(mdl->n);
   const bool poisson = mdl->likelihood == "poisson" || mdl->likelihood == "negative_binomial";     // integer-valued responses >= 0
-  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta") {      // likelihoods.h:1365-1373: strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1)
-    const bool is_beta = mdl->likelihood == "beta";
+  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t") {      // likelihoods.h:1365-1373: strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1); t: any real value
+    const bool is_beta = mdl->likelihood == "beta", is_t = mdl->likelihood == "t";
     mdl->resp_real.resize(mdl->n);
     for (int k = 0; k < mdl->n; ++k) {
       const double yk = y_data[mdl->perm[k]];
       if (is_beta) { if (!(yk > 0. && yk < 1.)) return set_error(" Must have 0 < y < 1 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk); }
+      else if (is_t) { if (!std::isfinite(yk)) return set_error("NaN or Inf in the response variable ('y') for likelihood = '%s' ", mdl->likelihood.c_str()); }
       else if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
       mdl->resp_real[k] = yk; mdl->labels[k] = 0;
     }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : 3)) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : (is_t ? 6 : 3))) return shim_error();
     if (mdl->n_re > 0) {
       std::vector<double> grouped(mdl->n);
       for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
@@ -393,7 +418,7 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
   if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
   if (op == 4) { mdl->lap_fit_first_eval = true; return 0; }
   if (op == 0 || op == 1) {
-    for (int j = 0; j < naux && j < 1; ++j) mdl->aux_pars[j] = aux[j];      // SetAuxPars at every evaluation (optim_utils.h:279-282)
+    for (int j = 0; j < naux && j < 2; ++j) mdl->aux_pars[j] = aux[j];      // SetAuxPars at every evaluation (optim_utils.h:279-282)
     mdl->aux_set = true;
     if (laplace_push_aux(mdl)) return -1;
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;
@@ -404,10 +429,11 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
     out[0] = -mdl->lap_info[0];
     if (op == 0) return 0;
   }
-  double g2[2], g4[4];
+  double g2[2], g4[8];                               // 4 doubles per auxiliary parameter
   if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(mdl->cg_max_num_it, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
   if (gpb_hip_vecchia_laplace_grad_aux_current(mdl->vh, g4)) return -1;
-  out[1] = g2[0]; out[2] = g2[1]; out[3] = g4[0];
+  out[1] = g2[0]; out[2] = g2[1];
+  for (int j = 0; j < naux && j < 2; ++j) out[3 + j] = g4[4 * j];
   return 0;
 }
 
@@ -922,6 +948,10 @@ double resp_gh_beta(double latent_mean, double latent_var, double delta, const s
 }
 
 bool predict_response_host(const std::string& lik, int n, double* mean, double* var, bool predict_var, double delta, double aux = 1.0) {
+  if (lik == "t") {                         // likelihoods.h:9824-9832: the mean is the latent mean; the squared scale is added to the latent variances
+    if (predict_var) for (int i = 0; i < n; ++i) var[i] += aux * aux;
+    return true;
+  }
   if (lik == "beta") {                      // likelihoods.h:9805-9824: mean E[sigmoid(b)]; variance Var(E[y | b]) + E[Var(y | b)]
     std::vector<double> xs, aw;
     gauss_hermite_adaptive(30, &xs, &aw);
@@ -1409,8 +1439,10 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   // auxiliary parameters (gamma / negative_binomial; re_model.cpp:327-344, re_model_template.h:909-912): initial values are applied at once (SetAuxPars)
   mdl->estimate_aux_pars = estimate_aux_pars;
   if (init_aux_pars && mdl->num_aux > 0) {
-    if (!(init_aux_pars[0] > 0.)) return set_error("The shape parameter is not > 0 (found %g)", init_aux_pars[0]);
-    mdl->init_aux[0] = init_aux_pars[0]; mdl->aux_pars[0] = init_aux_pars[0];
+    for (int j = 0; j < mdl->num_aux; ++j) {
+      if (!(init_aux_pars[j] > 0.)) return set_error("The %s parameter is not > 0 (found %g)", mdl->likelihood == "t" ? (j == 0 ? "scale" : "df") : "shape", init_aux_pars[j]);
+      mdl->init_aux[j] = init_aux_pars[j]; mdl->aux_pars[j] = init_aux_pars[j];
+    }
     mdl->init_aux_given = true; mdl->aux_set = true;
   } else mdl->init_aux_given = false;
   if (estimate_cov_par_index && estimate_cov_par_index[0] >= 0) {          // re_model_template.h:930-936
@@ -1590,7 +1622,7 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
     GpbLaplaceOptimResult res;
     if (mdl->num_aux > 0 && mdl->estimate_aux_pars) {      // the shape is part of the lbfgs vector (optim_utils.h:256-283)
       GpbLaplaceAuxResult ra;
-      double aux[1] = {mdl->aux_pars[0]};
+      double aux[2] = {mdl->aux_pars[0], mdl->aux_pars[1]};
       if (gpb_optimize_laplace_cov_aux_pars(cfg, device_laplace_aux, mdl, mdl->num_aux, mdl->cov_pars_tr, aux, &ra, err, (int)sizeof(err))) {
         const char* why = gpb_hip_get_last_error();
         if (err[0] && why && why[0]) return set_error("%s: %s", err, why);
@@ -1598,7 +1630,7 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
       }
       if (cfg.max_iter > 0) {
         mdl->cov_pars_tr[0] = ra.theta[0]; mdl->cov_pars_tr[1] = ra.theta[1];
-        mdl->aux_pars[0] = aux[0];
+        for (int j = 0; j < mdl->num_aux; ++j) mdl->aux_pars[j] = aux[j];
         if (laplace_push_aux(mdl)) return -1;
         mdl->cur_negll = ra.negll;
         mdl->negll_valid = true;
@@ -2847,7 +2879,7 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   if (lik == "gaussian" && mdl->n_re > 0)
     return set_error("GPB_SetLikelihood: this model was created with repeated locations under a non-Gaussian likelihood -- its Vecchia approximation lives on the %d unique locations (Vecchia_utils.cpp:1156-1168); create a new model for the Gaussian likelihood", mdl->n_re);
   mdl->likelihood = lik;
-  mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = 1.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
+  mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = 1.; mdl->aux_pars[1] = 2.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
   mdl->cov_pars_initialized = false; mdl->init_cov_pars_provided = false; mdl->negll_valid = false; mdl->y_set = false; mdl->yaux_valid = false;
   C_API_END();
 }
@@ -2894,8 +2926,8 @@ int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool c
   if (!mdl) return set_error("GPB_GetAuxPars: null handle");
   if (mdl->num_aux < 1) { if (out_str) out_str[0] = 0; return 0; }      // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
   if (calc_std_dev) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters are not on the MI355X path of this library");
-  if (aux_pars) aux_pars[0] = mdl->aux_pars[0];       // REModel::GetAuxPars (re_model.cpp:1408-1421), original scale
-  if (out_str) std::strcpy(out_str, mdl->likelihood == "beta" ? "precision" : "shape");         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
+  if (aux_pars) for (int j = 0; j < mdl->num_aux; ++j) aux_pars[j] = mdl->aux_pars[j];       // REModel::GetAuxPars (re_model.cpp:1364-1405), original scale
+  if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : "shape"));       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
   return 0;
 }
 
@@ -2909,7 +2941,7 @@ int GPB_GetNumAuxPars(REModelHandle handle, int* num_aux_pars) {
 int GPB_GetInitAuxPars(REModelHandle handle, double* aux_pars) {
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl) return set_error("GPB_GetInitAuxPars: null handle");
-  if (mdl->num_aux > 0 && aux_pars) aux_pars[0] = mdl->init_aux_given ? mdl->init_aux[0] : -1.;      // re_model.cpp:1423-1434: -1 = found internally
+  if (mdl->num_aux > 0 && aux_pars) for (int j = 0; j < mdl->num_aux; ++j) aux_pars[j] = mdl->init_aux_given ? mdl->init_aux[j] : -1.;      // re_model.cpp:1423-1434: -1 = found internally
   return 0;
 }
 

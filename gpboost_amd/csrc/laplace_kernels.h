@@ -52,7 +52,7 @@ int lap_cg_parts(int n);
 
 // the response as the likelihood kernels see it: int labels / counts (yi) or -- gamma -- real values (yd), and the likelihood's auxiliary parameter
 // (shape of gamma / negative_binomial; unused by the others)
-struct LikResp { const int* yi; const double* yd; double aux; const double* w = nullptr; };     // w: sample weights per datum (storage order of the response), or nullptr
+struct LikResp { const int* yi; const double* yd; double aux; const double* w = nullptr; double aux2 = 2.0; };     // aux2: the second auxiliary parameter (t: degrees of freedom)     // w: sample weights per datum (storage order of the response), or nullptr
 hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, const double* fe, const double* D, int n, double* W, double* rhs, double* dw, double* rdw, hipStream_t st,
                             const int* dptr = nullptr);   // dptr (n + 1): repeated locations -- row i sums over the data y[dptr[i] .. dptr[i + 1]) (also below)
 // ncol = number of column chunks, nc = columns per chunk (1: plain columns; 4: block vectors stored [chunk][row][4])

@@ -73,7 +73,7 @@ __device__ __forceinline__ double inv_mills_phi(double z) {
 //  branches, exactly the end points at y = 0 and y = 1: LogLikBinomialProbit :11394-11398, FirstDeriv :12468-12474, SecondDeriv :13293-13305, third :13800-13820)
 template <int LINK>
 __device__ __forceinline__ double resp_at(const LikResp& r, int d) {
-  if constexpr (LINK == 3 || LINK == 5) return r.yd[d];
+  if constexpr (LINK == 3 || LINK == 5 || LINK == 6) return r.yd[d];
   else if constexpr (LINK == 0 || LINK == 1) return r.yd ? r.yd[d] : (double)r.yi[d];
   else return (double)r.yi[d];
 }
@@ -100,7 +100,7 @@ __device__ __forceinline__ double sigmoid_clamped(double x) { double mu = sigmoi
 // sample weight of datum d (round 5; likelihoods.h:666-668 weights_): every per-datum term -- log-likelihood and its derivatives -- is multiplied by it
 __device__ __forceinline__ double wt_at(const LikResp& r, int d) { return r.w ? r.w[d] : 1.0; }
 template <int LINK>
-__device__ __forceinline__ void lik_grad_info(double y, double x, double aux, double& grad, double& w) {
+__device__ __forceinline__ void lik_grad_info(double y, double x, double aux, double& grad, double& w, double aux2 = 0.0) {
   if constexpr (LINK == 0) {
     const double p = sigmoid_stable(x);
     grad = y - p;                         // likelihoods.h:12477
@@ -116,6 +116,10 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
       grad = y * r1 + (1.0 - y) * -r0;
       w = y * r1 * (x + r1) + (1.0 - y) * -r0 * (x - r0);
     }
+  } else if constexpr (LINK == 6) {       // t, fisher_laplace: FirstDerivLogLikT (likelihoods.h:12509-12512), FisherInformationT (:13358-13360): aux = scale, aux2 = df
+    const double res = y - x;
+    grad = (aux2 + 1.0) * res / (aux2 * aux * aux + res * res);
+    w = (aux2 + 1.0) / (aux2 + 3.0) / (aux * aux);
   } else if constexpr (LINK == 5) {
     const double mu = sigmoid_clamped(x), logit_y = log(y) - log1p(-y);
     const double dig1 = digamma_dev((1.0 - mu) * aux), dig2 = digamma_dev(mu * aux);
@@ -139,7 +143,7 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
   }
 }
 template <int LINK>
-__device__ __forceinline__ double lik_loglik(double y, double x, double aux) {
+__device__ __forceinline__ double lik_loglik(double y, double x, double aux, double aux2 = 0.0) {
   if constexpr (LINK == 0) return y * x - softplus(x);      // likelihoods.h:11401-11403
   else if constexpr (LINK == 1) {
     if (y == 0.0 || y == 1.0) return normal_log_cdf(y != 0.0 ? x : -x);
@@ -147,6 +151,7 @@ __device__ __forceinline__ double lik_loglik(double y, double x, double aux) {
   }
   else if constexpr (LINK == 3) return -aux * (x + y * exp(-x));
   else if constexpr (LINK == 4) return y * x - (y + aux) * log(exp(x) + aux);
+  else if constexpr (LINK == 6) return -(aux2 + 1.0) / 2.0 * log(1.0 + (y - x) * (y - x) / (aux2 * aux * aux));       // LogLikT (:11915-11925) without its constant
   else if constexpr (LINK == 5) {
     const double mu = sigmoid_clamped(x);
     return -lgamma(mu * aux) - lgamma((1.0 - mu) * aux) + (mu * aux - 1.0) * log(y) + ((1.0 - mu) * aux - 1.0) * log1p(-y);
@@ -190,9 +195,9 @@ __global__ void lik_newton_setup_kernel(const double* __restrict__ mode, const L
   double gr, w;
   if (dptr) {
     gr = 0.0; w = 0.0;
-    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, g1, w1); const double wd = wt_at(y, d); gr += wd * g1; w += wd * w1; }
+    for (int d = dptr[i]; d < dptr[i + 1]; ++d) { double g1, w1; lik_grad_info<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, g1, w1, y.aux2); const double wd = wt_at(y, d); gr += wd * g1; w += wd * w1; }
   } else {
-    lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
+    lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w, y.aux2);       // location parameter = mode + fixed effects (likelihoods.h:3861-3870)
     if (y.w) { gr *= y.w[i]; w *= y.w[i]; }
   }
   W[i] = w;
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(1024) void lik_objective_kernel(const double* __res
   __shared__ double s[2048];
   double ll = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += wt_at(y, d) * lik_loglik<LINK>(resp_at<LINK>(y, d), fe ? x[i] + fe[d] : x[i], y.aux); }
-    else ll += wt_at(y, i) * lik_loglik<LINK>(resp_at<LINK>(y, i), fe ? x[i] + fe[i] : x[i], y.aux);
+    if (dptr) { for (int d = dptr[i]; d < dptr[i + 1]; ++d) ll += wt_at(y, d) * lik_loglik<LINK>(resp_at<LINK>(y, d), fe ? x[i] + fe[d] : x[i], y.aux, y.aux2); }
+    else ll += wt_at(y, i) * lik_loglik<LINK>(resp_at<LINK>(y, i), fe ? x[i] + fe[i] : x[i], y.aux, y.aux2);
     if (Bx) q = __builtin_fma(Bx[i] * (1.0 / D[i]), Bx[i], q);
   }
   block_reduce2(ll, q, s);
@@ -871,11 +876,12 @@ __global__ __launch_bounds__(1024) void lap_dot_kernel(const double* __restrict_
 // ---- gradient of the Laplace approximation (likelihoods.h:6521-6700; oracle/gpb_oracle.c: orc_vecchia_laplace_grad) ---------------
 // third derivative of the log-likelihood = d information / d location parameter (CalcFirstDerivInformationLocPar, likelihoods.h:13772-13800)
 template <int LINK>
-__device__ __forceinline__ double lik_third(double y, double x, double aux) {
+__device__ __forceinline__ double lik_third(double y, double x, double aux, double aux2 = 0.0) {
   if constexpr (LINK == 0) { const double p = sigmoid_stable(x); return -p * (1.0 - p) * (2.0 * p - 1.0); }
   else if constexpr (LINK == 2) return exp(x);
   else if constexpr (LINK == 3) return -aux * y * exp(-x);                                            // likelihoods.h:13843-13849
   else if constexpr (LINK == 4) { const double mu = exp(x), mr = mu + aux; return -(y + aux) * mu * aux * (mu - aux) / (mr * mr * mr); }   // :13870-13878
+  else if constexpr (LINK == 6) return 0.0;                                                            // fisher_laplace: the information does not depend on the mode (:410-415)
   else if constexpr (LINK == 5) {                                                                      // :13892-13917
     const double mu = sigmoid_clamped(x), d = mu * (1.0 - mu), logit_y = log(y) - log1p(-y);
     const double dig1 = digamma_dev((1.0 - mu) * aux), dig2 = digamma_dev(mu * aux), tri1 = trigamma_dev((1.0 - mu) * aux), tri2 = trigamma_dev(mu * aux);
@@ -900,8 +906,8 @@ __global__ void lik_third_kernel(const double* __restrict__ mode, const LikResp 
                                  const int* __restrict__ dptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += wt_at(y, d) * lik_third<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux); dW3[i] = t3; }
-  else dW3[i] = wt_at(y, i) * lik_third<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux);
+  if (dptr) { double t3 = 0.0; for (int d = dptr[i]; d < dptr[i + 1]; ++d) t3 += wt_at(y, d) * lik_third<LINK>(resp_at<LINK>(y, d), fe ? mode[i] + fe[d] : mode[i], y.aux, y.aux2); dW3[i] = t3; }
+  else dW3[i] = wt_at(y, i) * lik_third<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, y.aux2);
 }
 
 // boosting gradient for non-Gaussian data, d(-mll) / dF = -d log p / d loc + 0.5 d logdet / d mode - W .* (Sigma^-1 + W)^-1 d_mll_d_mode
@@ -912,7 +918,7 @@ __global__ void lik_grad_F_kernel(const double* __restrict__ mode, const LikResp
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double gr, w;
-  lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w);
+  lik_grad_info<LINK>(resp_at<LINK>(y, i), fe ? mode[i] + fe[i] : mode[i], y.aux, gr, w, y.aux2);
   if (y.w) { gr *= y.w[i]; w *= y.w[i]; }
   out[i] = -gr + 0.5 * dld[i] - w * sv[i];
 }
@@ -934,9 +940,9 @@ __global__ void lik_grad_F_map_kernel(const double* __restrict__ mode, const Lik
     const double loc = fe ? mi + fe[d] : mi;
     double gr, w;
     const double yd = resp_at<LINK>(y, d);
-    lik_grad_info<LINK>(yd, loc, y.aux, gr, w);
+    lik_grad_info<LINK>(yd, loc, y.aux, gr, w, y.aux2);
     const double wd = wt_at(y, d);
-    out[d] = -(wd * gr) + 0.5 * (wd * lik_third<LINK>(yd, loc, y.aux)) * diag - (wd * w) * svi;
+    out[d] = -(wd * gr) + 0.5 * (wd * lik_third<LINK>(yd, loc, y.aux, y.aux2)) * diag - (wd * w) * svi;
   }
 }
 
@@ -960,7 +966,11 @@ __global__ __launch_bounds__(1024) void lik_aux_grad_kernel(const double* __rest
     const double mi = mode[i], svi = sv[i];
     for (int d = d0; d < d1; ++d) {
       const double x = fe ? mi + fe[d] : mi, yv = resp_at<LINK>(y, d), wd = wt_at(y, d);
-      if constexpr (LINK == 5) {       // CalcGradNegLogLikAuxPars beta (:14229-14241; the host multiplies by -precision), CalcSecondDerivLogLikFirstDerivInformationAuxPar beta (:14816-14845)
+      if constexpr (LINK == 6) {       // t: the two data sums of CalcGradNegLogLikAuxPars (:14241-14262): e -> log scale, dsum -> log df (isum unused)
+        const double nu = y.aux2, nu_sigma2 = nu * r * r, res_sq = (yv - x) * (yv - x);
+        e -= wd * (nu + 1.0) / (nu_sigma2 / res_sq + 1.0);
+        dsum += wd * (-nu * log(1.0 + res_sq / nu_sigma2) + (nu + 1.0) / (1.0 + nu_sigma2 / res_sq));
+      } else if constexpr (LINK == 5) {       // CalcGradNegLogLikAuxPars beta (:14229-14241; the host multiplies by -precision), CalcSecondDerivLogLikFirstDerivInformationAuxPar beta (:14816-14845)
         const double mu = sigmoid_clamped(x), dd = mu * (1.0 - mu), logit_y = log(yv) - log1p(-yv);
         const double dig1 = digamma_dev((1.0 - mu) * r), dig2 = digamma_dev(mu * r), tri1 = trigamma_dev((1.0 - mu) * r), tri2 = trigamma_dev(mu * r);
         const double tet1 = tetragamma_dev((1.0 - mu) * r), tet2 = tetragamma_dev(mu * r);
@@ -1183,6 +1193,7 @@ hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, cons
     case 3: hipLaunchKernelGGL(lik_newton_setup_kernel<3>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 4: hipLaunchKernelGGL(lik_newton_setup_kernel<4>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 5: hipLaunchKernelGGL(lik_newton_setup_kernel<5>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 6: hipLaunchKernelGGL(lik_newton_setup_kernel<6>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1230,6 +1241,7 @@ hipError_t lap_objective(int link, const double* x, const LikResp& y, const doub
     case 3: hipLaunchKernelGGL(lik_objective_kernel<3>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 4: hipLaunchKernelGGL(lik_objective_kernel<4>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 5: hipLaunchKernelGGL(lik_objective_kernel<5>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 6: hipLaunchKernelGGL(lik_objective_kernel<6>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1783,6 +1795,7 @@ hipError_t lap_third_deriv(int link, const double* mode, const LikResp& y, const
     case 3: hipLaunchKernelGGL(lik_third_kernel<3>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 4: hipLaunchKernelGGL(lik_third_kernel<4>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 5: hipLaunchKernelGGL(lik_third_kernel<5>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 6: hipLaunchKernelGGL(lik_third_kernel<6>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1795,6 +1808,7 @@ hipError_t lap_grad_F(int link, const double* mode, const LikResp& y, const doub
     case 3: hipLaunchKernelGGL(lik_grad_F_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 4: hipLaunchKernelGGL(lik_grad_F_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 5: hipLaunchKernelGGL(lik_grad_F_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 6: hipLaunchKernelGGL(lik_grad_F_kernel<6>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1808,6 +1822,7 @@ hipError_t lap_grad_F_map(int link, const double* mode, const LikResp& y, const 
     case 3: hipLaunchKernelGGL(lik_grad_F_map_kernel<3>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 4: hipLaunchKernelGGL(lik_grad_F_map_kernel<4>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 5: hipLaunchKernelGGL(lik_grad_F_map_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 6: hipLaunchKernelGGL(lik_grad_F_map_kernel<6>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1817,6 +1832,7 @@ hipError_t lap_aux_grad(int link, const double* mode, const LikResp& y, const do
   if (link == 3) hipLaunchKernelGGL(lik_aux_grad_kernel<3>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else if (link == 4) hipLaunchKernelGGL(lik_aux_grad_kernel<4>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else if (link == 5) hipLaunchKernelGGL(lik_aux_grad_kernel<5>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
+  else if (link == 6) hipLaunchKernelGGL(lik_aux_grad_kernel<6>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -203,7 +203,7 @@ class VecchiaState(object):
         return out
 
     def laplace_set_likelihood(self, likelihood):
-        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5,
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6,
                "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
         self._lap_link = lid
@@ -243,9 +243,9 @@ class VecchiaState(object):
 
     def laplace_grad_aux(self):
         """-> {gradient wrt log(shape), CalcGradNegLogLikAuxPars part, log-determinant part, implicit part} at the state of the last laplace_eval_grad."""
-        o = np.empty(4)
+        o = np.zeros(8)          # 4 per auxiliary parameter (t has two: scale, df)
         _shim_call(_lib().gpb_hip_vecchia_laplace_grad_aux_current(self.h, _p(o)))
-        return o
+        return o if getattr(self, "_lap_link", 0) == 6 else o[:4]
 
     def laplace_set_fixed_effects(self, fixed_effects):
         """Offset of the location parameter, Vecchia order (None removes it)."""
@@ -281,7 +281,10 @@ class VecchiaState(object):
         parts = np.empty(8) if want_parts else None
         vecs = np.empty(2 * self.n) if want_parts else None
         _shim_call(_lib().gpb_hip_vecchia_laplace_grad_current(self.h, C.c_int(cg_max_num_it), C.c_double(cg_delta_conv), _p(g), _p(parts), _p(vecs)))
-        if getattr(self, "_lap_link", 0) >= 3:      # likelihoods with an auxiliary parameter: third entry = d / d log(aux)
+        if getattr(self, "_lap_link", 0) == 6:      # t: d / d (log scale, log df)
+            ga = self.laplace_grad_aux()
+            g = np.array([g[0], g[1], ga[0], ga[4]])
+        elif getattr(self, "_lap_link", 0) >= 3:      # likelihoods with an auxiliary parameter: third entry = d / d log(aux)
             g = np.array([g[0], g[1], self.laplace_grad_aux()[0]])
         if want_parts:
             return -o[0], g, dict(per_par=parts.reshape(2, 4), dlogdet_dmode=vecs[:self.n], implicit_solve=vecs[self.n:])

@@ -504,7 +504,7 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
     return out
 
 
-LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5,
+LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6,
            # round 5: proportions under the logit / probit links (real-valued response in [0, 1]; binomial_*: trials = orc.sample_weights, binomial constant)
            "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}
 PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
@@ -512,7 +512,7 @@ PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_
 
 def _responses(likelihood, y):
     """-> (int32 responses, float64 responses | None): gamma's response is real-valued (handed to the C side through orc_set_aux)."""
-    if likelihood in ("gamma", "beta") or likelihood in PROPORTION_LIKELIHOODS:
+    if likelihood in ("gamma", "beta", "t") or likelihood in PROPORTION_LIKELIHOODS:
         yd = np.ascontiguousarray(y, dtype=np.float64)
         lib().orc_set_binomial(C.c_int(1 if likelihood.startswith("binomial") else 0))
         return np.zeros(yd.shape[0], dtype=np.int32), yd
@@ -618,7 +618,9 @@ class _aux_context(object):
 
     def __init__(self, link, aux, yd, aux_grad4):
         self.on = link >= 3 or yd is not None         # (a real-valued response travels the same way for the proportion likelihoods)
-        self.args = (float(1.0 if aux is None else aux), yd, aux_grad4)
+        av = np.atleast_1d(np.asarray(1.0 if aux is None else aux, dtype=np.float64))     # t: (scale, df)
+        self.aux2 = float(av[1]) if av.size > 1 else None
+        self.args = (float(av[0]), yd, aux_grad4)
 
     def __enter__(self):
         if self.on:
@@ -626,6 +628,8 @@ class _aux_context(object):
             fn = lib().orc_set_aux
             fn.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
             fn(aux, None if yd is None else yd.ctypes.data, None if g4 is None else g4.ctypes.data)
+            if self.aux2 is not None:
+                lib().orc_set_aux2(C.c_double(self.aux2))
         return self
 
     def __exit__(self, *exc):
@@ -737,7 +741,7 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
     yi, yd = _responses(likelihood, y01)
-    aux_g4 = np.zeros(4) if link >= 3 else None
+    aux_g4 = np.zeros(8) if link >= 3 else None         # 4 per auxiliary parameter (t has two: scale, df)
     rv = gen_rand_normal(n, num_rand_vec, seed_rand, _PROBE_RUN_ID)
     fe = None if fixed_effects is None else np.ascontiguousarray(fixed_effects, dtype=np.float64)
     out = np.empty(6); g = np.empty(2)
@@ -751,7 +755,9 @@ def vecchia_laplace_grad(coords, nn, cov_type, var, a, y01, num_rand_vec=50, see
                                             _p(mode, C.c_double), C.c_int(0 if mode_init is None else 1), None if dbg is None else _p(dbg, C.c_double))
     if rc != 0:
         raise RuntimeError("orc_vecchia_laplace_grad failed")
-    if link >= 3:      # likelihoods with an auxiliary parameter: the gradient's third entry is d(-mll) / d log(aux)
+    if link == 6:      # t: d(-mll) / d (log scale, log df)
+        g = np.array([g[0], g[1], aux_g4[0], aux_g4[4]])
+    elif link >= 3:      # likelihoods with an auxiliary parameter: the gradient's third entry is d(-mll) / d log(aux)
         g = np.array([g[0], g[1], aux_g4[0]])
     if want_parts:      # intermediate values for device parity tests
         parts = dict(dlogdet_dmode=dbg[:n].copy(), implicit_solve=dbg[n:2 * n].copy(), per_par=dbg[2 * n:].reshape(2, 4).copy(), mode=mode)

@@ -121,6 +121,25 @@ LAPLACE_AUX_CASES = {
 }
 
 
+# Student-t likelihood (round 5, third slice; likelihoods.h:384-423: location = the latent value, auxiliary parameters (scale, df), both estimated; the reference's default
+# approximation "fisher_laplace": the information is the constant Fisher information).  aux: where the value / gradient fixtures are evaluated; true_*: what the data were drawn with.
+LAPLACE_T_CASES = {
+    "t_n1500": dict(model="lap_u2d_n1500_mat15_m30", aux=(0.5, 3.0), true_scale=0.4, true_df=4.0),
+    "t_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", aux=(0.3, 6.0), true_scale=0.3, true_df=5.0),
+}
+
+
+def make_t_data(tc):
+    """-> (coords, y) in DATA order for a LAPLACE_T_CASES entry: a smooth surface + scale * Student-t(df) noise."""
+    c = LAPLACE_CASES[tc["model"]]
+    rng = np.random.default_rng(c["seed_data"])
+    n, d = c["n"], c["d"]
+    coords = rng.uniform(size=(n, d))
+    latent = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.3
+    y = latent + tc["true_scale"] * np.random.default_rng(c["seed_data"] + 4000).standard_t(tc["true_df"], size=n)
+    return coords, y
+
+
 def aux_fixed_effects(ac, coords):
     """Offset of the fixed-effects fixtures of a LAPLACE_AUX_CASES entry (data order): laplace_fixed_effects, scaled by the entry's fe_scale."""
     return ac.get("fe_scale", 1.0) * laplace_fixed_effects(coords)

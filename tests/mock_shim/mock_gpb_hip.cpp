@@ -28,6 +28,7 @@ void orc_vecchia_yaux(const double* A, const double* D, const int* nn, int n, in
 int orc_newton_leaf_values(const double* A, const double* D, const int* nn, int n, int m, const double* yaux, const int* leaf, int L, double* leaf_values);
 void orc_gen_rand_normal(int seed, unsigned long long run_id, int n, int t, double* out);
 void orc_set_aux(double aux, const double* y_real, double* aux_grad4);
+void orc_set_aux2(double aux2);
 void orc_set_weights(const double* w);
 void orc_set_binomial(int on);
 void orc_clear_aux(void);
@@ -58,6 +59,7 @@ double normal_log_cdf(double x) {
 }
 // d log p / d loc, information, d information / d loc
 double g_mock_aux = 1.0;        // auxiliary parameter seen by lik_terms (links 3 / 4; set by the entry points from the handle)
+double g_mock_aux2 = 2.0;       // t: degrees of freedom
 // beta (link 5): polygamma functions as the reference's (src/GPBoost/DF_utils.cpp:82-201), mean = clamped sigmoid (include/GPBoost/DF_utils.h:48-55)
 double mock_digamma(double x) {
   if (x <= 0.000001) return -0.57721566490153286060 - 1.0 / x + 1.6449340668482264365 * x;
@@ -83,6 +85,11 @@ double mock_tetragamma(double x) {
   return value + (-1.0 / z2 - 1.0 / z3 - 0.5 / z4 + 1.0 / (6.0 * z6) - 1.0 / (6.0 * z8) + 3.0 / (10.0 * z10));
 }
 void lik_terms(int link, double y, double x, double* first, double* info, double* dinfo) {
+  if (link == 6) {       // t, fisher_laplace: FirstDerivLogLikT, FisherInformationT (likelihoods.h:12509-12512, :13358-13360); the information does not depend on the location
+    const double sc = g_mock_aux, nu = g_mock_aux2, res = y - x;
+    *first = (nu + 1.) * res / (nu * sc * sc + res * res); *info = (nu + 1.) / (nu + 3.) / (sc * sc); *dinfo = 0.;
+    return;
+  }
   if (link == 5) {       // likelihoods.h:12501-12507, :13336-13346, :13892-13917
     const double phi = g_mock_aux;
     double mu = sigmoid(x); if (mu < 1e-12) mu = 1e-12; if (mu > 1.0 - 1e-12) mu = 1.0 - 1e-12;
@@ -143,11 +150,11 @@ struct gpb_hip_vecchia {
   std::vector<int> labels; std::vector<double> fe; bool has_fe = false;
   std::vector<double> weights;     // sample weights of the non-Gaussian likelihood (order of the labels); the oracle reads them through orc_set_weights
   double wv(int k) const { return weights.empty() ? 1.0 : weights[k]; }
-  std::vector<double> resp_real; double aux = 1.0; double aux_grad4[4] = {0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
+  std::vector<double> resp_real; double aux = 1.0; double aux2 = 2.0; double aux_grad4[8] = {0., 0., 0., 0., 0., 0., 0., 0.};     // gamma's response, the shape, the last aux gradient
   bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
   int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns, 2 = fitc with the inducing points pc_ip
   std::vector<double> pc_ip; int pc_nip = 0;       // k x d column-major
-  double yv(int k) const { return (link == 3 || real_resp) ? resp_real[k] : (double)labels[k]; }
+  double yv(int k) const { return (link == 3 || link == 5 || link == 6 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
   bool has_mode = false, grad_state = false;
@@ -215,7 +222,7 @@ int dense_M_chol(const gpb_hip_vecchia* h, std::vector<double>* Mout) {
     for (size_t a1 = 0; a1 < ec.size(); ++a1) for (size_t b1 = 0; b1 < ec.size(); ++b1) M[(size_t)ec[a1] * n + ec[b1]] += ev[a1] * di * ev[b1];
   }
   const bool mapped = !h->re_ptr.empty();
-  g_mock_aux = h->aux;
+  g_mock_aux = h->aux; g_mock_aux2 = h->aux2;
   for (int i = 0; i < n; ++i) {
     const int d0 = mapped ? h->re_ptr[i] : i, d1 = mapped ? h->re_ptr[i + 1] : i + 1;
     double w = 0.;
@@ -297,7 +304,8 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
   const bool ctx = h->link >= 3 || h->real_resp;
-  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->link == 6 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  if (h->link == 6) orc_set_aux2(h->aux2);
   orc_set_binomial(h->binomial ? 1 : 0);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
                                                   h->has_fe ? h->fe.data() : nullptr, rv.data(), nrv, cg, cgt, cgd, dcm, out6, h->grad2, mode.data(), warm ? 1 : 0,
@@ -509,7 +517,7 @@ EXPORT int gpb_hip_dense_spd_solve(int32_t n, const double* M_host, const double
 
 // ---- Laplace path ----
 EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int id) {
-  if (id < 0 || id > 5) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
+  if (id < 0 || id > 6) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
   if (h->link != id) { h->labels.clear(); h->grad_state = false; }
   h->link = id; return 0;
 }
@@ -523,11 +531,12 @@ EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_
   h->labels.assign(y, y + nd); h->real_resp = false; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
-  if (h->link != 3 && h->link != 5 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
+  if (h->link != 3 && h->link != 5 && h->link != 6 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   for (int i = 0; i < nd; ++i) {
     if (h->link == 3) { if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
     else if (h->link == 5) { if (!(y[i] > 0. && y[i] < 1.)) return fail(" Must have 0 < y < 1 for the response variable ('y') for likelihood = 'beta', found %g ", y[i]); }
+    else if (h->link == 6) { if (!std::isfinite(y[i])) return fail("t: the response must be finite"); }
     else if (!(y[i] >= 0. && y[i] <= 1.)) return fail(" Must have 0 <= y <= 1 for the response variable ('y') (found %g at Vecchia position %d)", y[i], i);
   }
   h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->real_resp = true; h->grad_state = false; return 0;
@@ -579,19 +588,22 @@ EXPORT int gpb_hip_vecchia_laplace_set_weights(gpb_hip_vecchia_t* h, const doubl
 }
 EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux) {
   if (h->link < 3) return fail("gpb_hip_vecchia_laplace_set_aux_pars: likelihood id %d has no auxiliary parameters", h->link);
-  if (num_aux != 1 || !(aux[0] > 0.)) return fail("The shape parameter is not > 0 (found %g)", aux[0]);
+  if (num_aux != (h->link == 6 ? 2 : 1) || !(aux[0] > 0.)) return fail("The %s parameter is not > 0 (found %g)", h->link == 6 ? "scale" : "shape", aux[0]);
+  if (h->link == 6 && !(aux[1] > 0.)) return fail("The df parameter is not > 0 (found %g)", aux[1]);
   if (aux[0] != h->aux) { h->aux = aux[0]; h->grad_state = false; }
+  if (h->link == 6 && aux[1] != h->aux2) { h->aux2 = aux[1]; h->grad_state = false; }
   return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux) {
-  *num_aux = h->link >= 3 ? 1 : 0;
+  *num_aux = h->link >= 3 ? (h->link == 6 ? 2 : 1) : 0;
   if (aux_out && *num_aux) aux_out[0] = h->aux;
+  if (aux_out && *num_aux == 2) aux_out[1] = h->aux2;
   return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4) {
   if (h->link < 3) return fail("gpb_hip_vecchia_laplace_grad_aux_current: the likelihood has no auxiliary parameter");
   if (!h->grad_state) return fail("the gradient wrt the auxiliary parameter needs the state of gpb_hip_vecchia_laplace_grad_current");
-  for (int k = 0; k < 4; ++k) out4[k] = h->aux_grad4[k];
+  for (int k = 0; k < (h->link == 6 ? 8 : 4); ++k) out4[k] = h->aux_grad4[k];
   return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_fixed_effects(gpb_hip_vecchia_t* h, const double* fe) { MOCK_TRACE("gpb_hip_vecchia_laplace_set_fixed_effects");
@@ -617,7 +629,7 @@ EXPORT int gpb_hip_vecchia_laplace_reset_mode_to_previous(gpb_hip_vecchia_t* h) 
 }
 EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* gF) { MOCK_TRACE("gpb_hip_vecchia_laplace_grad_F_current");
   if (!h->grad_state) return fail("the gradient wrt the fixed effects needs the state of gpb_hip_vecchia_laplace_grad_current");
-  g_mock_aux = h->aux;
+  g_mock_aux = h->aux; g_mock_aux2 = h->aux2;
   const int n = h->n;
   const bool mapped = !h->re_ptr.empty();
   for (int i = 0; i < n; ++i) {

@@ -56,6 +56,13 @@ def test_auxiliary_parameter_likelihoods_through_the_c_api_on_the_cpu_restatemen
     assert "7 passed" in tail, tail      # (4 gamma / negative_binomial cases + 2 beta cases + the error paths)
 
 
+def test_student_t_likelihood_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):
+    """Round 5: the t likelihood's two auxiliary parameters through the model surface (GPB_SetOptimConfig(init_aux_pars[2]), the lbfgs vector (log sigma1^2, log a, log scale,
+    log df), the MAD start of the scale, GPB_GetAuxPars with two values, response predictions): tests/test_zz_laplace_t_gpu.py's model-API tests on the oracle-backed shim."""
+    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_t_gpu.py"], extra=["-k", "model_api"])
+    assert "2 passed" in tail, tail
+
+
 def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):
     """Round 5: cg_preconditioner_type = "pivoted_cholesky" through the model surface (GPB_SetOptimConfig(cg_preconditioner_type, piv_chol_rank) incl.
     ParsePreconditionerAlias and the rank checks, GPB_GetCGPreconditionerType, GPB_EvalNegLogLikelihood, GPB_OptimCovPar): the host code under

@@ -1,0 +1,103 @@
+"""GPU (MI355X): the Student-t likelihood on the Vecchia-Laplace path (round 5, third slice) -- location = the latent value, auxiliary parameters
+(scale, df) both estimated, the reference's default approximation "fisher_laplace" (likelihoods.h:384-423: the information is the constant Fisher information
+(df + 1) / (df + 3) / scale^2) -- through the C ABI against the UNMODIFIED reference (tests/golden/laplace_t_ref.npz, oracle/make_golden.py laplace_t):
+  * value at the default thresholds; value + gradient wrt (log sigma1^2, log a, log scale, log df) at cases.LAPLACE_TIGHT from the reference's own CalcGradPars (1e-8),
+    without and with fixed effects; the parts of the auxiliary gradient against the oracle;
+  * the model surface: evaluation, lbfgs fits with both auxiliary parameters in the vector (the reference's iteration counts), GPB_GetAuxPars (two values, "scale_SEP_df"),
+    latent and response predictions.
+(File name: sorts last -- added in round 5.)"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RC = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}
+TIGHT_ORC = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_T_CASES))
+def test_value_and_gradient_match_the_reference(gpb, orc, name):
+    from gpboost_amd import shim
+    tc = cases.LAPLACE_T_CASES[name]
+    c = cases.LAPLACE_CASES[tc["model"]]
+    g = np.load(os.path.join(GOLD, "laplace_t_ref.npz"))
+    coords, y = cases.make_t_data(tc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood("t")
+    st.laplace_set_response_real(y[perm])
+    st.laplace_set_aux(tc["aux"])
+    cp = c["cov_pars"][0]
+    a = RC[ct] / cp[1]
+    negll, _ = st.laplace_logit(ct, cp[0], a)
+    ref0 = float(g[name + "_negll_0"])
+    assert abs(negll - ref0) <= 1e-8 * abs(ref0), (negll, ref0)
+    for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+        st.laplace_set_fixed_effects(fe)
+        nll_t, grad_t = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+        ref = g[name + fe_key + "_grad_direct"]
+        assert grad_t.shape == (4,)
+        np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=3e-8 * np.abs(ref).max())      # (the scale's trace term multiplies the block CG's 1e-8 stopping error by dW / d log scale = -2 W: seen 1.6e-8 of the gradient's scale on the d = 3 case with fixed effects)
+        ref_v = float(g[name + fe_key + "_negll_direct"])
+        assert abs(nll_t - ref_v) <= 1e-8 * abs(ref_v), (nll_t, ref_v)
+    # other auxiliary parameters: against the oracle (itself pinned to the reference above); the boosting gradient is -d log p / d loc alone (no determinant / implicit part)
+    st.laplace_set_fixed_effects(None)
+    for aux2 in ((0.8, 2.2), (0.25, 15.0)):
+        st.laplace_set_aux(aux2)
+        nll2, grad2 = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood="t", aux=aux2, **TIGHT_ORC)
+        assert abs(nll2 - on) <= 1e-8 * abs(on), (aux2, nll2, on)
+        np.testing.assert_allclose(grad2, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+        ga = st.laplace_grad_aux()
+        assert ga.shape == (8,) and ga[3] == 0.0 and ga[7] == 0.0                    # no implicit part
+    with pytest.raises(gpb.GPBoostError, match="not > 0"):
+        st.laplace_set_aux((0.5, -1.0))
+    with pytest.raises(gpb.GPBoostError, match="parameters"):
+        st.laplace_set_aux(0.5)
+    st.close()
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_T_CASES))
+def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name):
+    tc = cases.LAPLACE_T_CASES[name]
+    c = cases.LAPLACE_CASES[tc["model"]]
+    g = np.load(os.path.join(GOLD, "laplace_t_ref.npz"))
+    coords, y = cases.make_t_data(tc)
+    kw = dict(likelihood="t", gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+              num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+    mdl = gpb.GPModel(**kw)
+    assert mdl.get_num_aux_pars() == 2
+    v = mdl.neg_log_likelihood(cp, y, aux_pars=list(tc["aux"]))
+    ref0 = float(g[name + "_negll_0"])
+    assert abs(v - ref0) <= 1e-8 * abs(ref0), (v, ref0)
+    np.testing.assert_allclose(mdl.get_aux_pars(), tc["aux"], rtol=0, atol=0)
+    mdl.set_optim_params(dict(cases.LAPLACE_TIGHT))
+    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=False)
+    np.testing.assert_allclose(pr["mu"], g[name + "_latent_mu"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pr["var"], g[name + "_latent_var"], rtol=1e-5)
+    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=True)
+    np.testing.assert_allclose(pr["mu"], g[name + "_resp_mu"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pr["var"], g[name + "_resp_var"], rtol=1e-5)
+    for key, cfg, rtol, ntol in (("_fit", {}, 1e-3, 1e-7), ("_fit_tight", dict(cases.LAPLACE_TIGHT), 1e-6, 1e-8)):
+        m2 = gpb.GPModel(**kw)
+        m2.fit(y, params=dict(cfg))
+        assert m2.get_num_optim_iter() == int(g[name + key + "_num_it"]), (key, m2.get_num_optim_iter(), int(g[name + key + "_num_it"]))
+        np.testing.assert_allclose(m2.get_cov_pars(), g[name + key + "_cov_pars"], rtol=rtol)
+        np.testing.assert_allclose(m2.get_aux_pars(), g[name + key + "_aux"], rtol=rtol)
+        nll = m2.get_current_neg_log_likelihood()
+        assert abs(nll - float(g[name + key + "_negll"])) <= ntol * abs(nll)
