@@ -1515,6 +1515,8 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   else if (!near(delta_conv_mode_finding, -999.)) return set_error("delta_conv_mode_finding is not > 0, found = %g ", delta_conv_mode_finding);
   if (cg_preconditioner_type && mdl->likelihood != "gaussian") {
     const std::string pc = cg_preconditioner_type;
+    if (pc != "" && mdl->cg_preconditioner_type != pc && mdl->model_has_been_estimated)      // re_model_template.h:891-895 (the comparison is with the string as given, before the alias is resolved)
+      return set_error("Cannot change 'cg_preconditioner_type' after a model has been fitted ");
     // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu" and -- round 5 -- "pivoted_cholesky" are built
     if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
     else if (pc == "pivoted_cholesky" || pc == "piv_chol" || pc == "piv_chol_on_Sigma") mdl->cg_preconditioner_type = "pivoted_cholesky";

@@ -213,6 +213,30 @@ __global__ void pc_add_div_kernel(double* __restrict__ v, const double* __restri
   v[o] += (1.0 / w[g / nc]) * h[o];
 }
 
+__global__ __launch_bounds__(1024) void pc_aux_sums_kernel(const double* __restrict__ L, const double* __restrict__ M, const double* __restrict__ W,
+                                                            const double* __restrict__ wp, int n, int k, double* __restrict__ out2) {
+  __shared__ double s[2048];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double* Li = L + (size_t)i * k;
+    double sdiag = 0.0;
+    for (int q = 0; q < k; ++q) {
+      const double* Mq = M + (size_t)q * k;
+      double acc = 0.0;
+      for (int p = 0; p < k; ++p) acc = __builtin_fma(Mq[p], Li[p], acc);
+      sdiag = __builtin_fma(Li[q], acc, sdiag);
+    }
+    if (wp) { a += sdiag * (wp[i] * (wp[i] / W[i])); b += wp[i] / W[i]; }
+    else a += sdiag * W[i];
+  }
+  s[threadIdx.x] = a; s[1024 + threadIdx.x] = b;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if (threadIdx.x < w) { s[threadIdx.x] += s[threadIdx.x + w]; s[1024 + threadIdx.x] += s[1024 + threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = s[0]; out2[1] = s[1024]; }
+}
 __global__ __launch_bounds__(1024) void pc_wmax_kernel(const double* __restrict__ w, int n, double* __restrict__ out1) {
   __shared__ double s[1024];
   double best = -INFINITY;
@@ -335,6 +359,10 @@ hipError_t pc_rowscale(const double* x, const double* w, int n, int ncol, int nc
 }
 hipError_t pc_add_div(double* v, const double* h, const double* w, int n, int ncol, int nc, hipStream_t st) {
   hipLaunchKernelGGL(pc_add_div_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, v, h, w, n, nc);
+  return hipGetLastError();
+}
+hipError_t pc_aux_sums(const double* L, const double* M, const double* W, const double* wp, int n, int k, double* out2, hipStream_t st) {
+  hipLaunchKernelGGL(pc_aux_sums_kernel, dim3(1), dim3(1024), 0, st, L, M, W, wp, n, k, out2);
   return hipGetLastError();
 }
 hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st) {

@@ -134,6 +134,35 @@ elif sc == "poisson_misc":
     out["stoch_latent_cov_diag"] = L(np.diag(np.asarray(p["cov"])))
     out["train_re"] = L(m.predict_training_data_random_effects(offset=off))
     out["nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.5, 0.2]), y=y, fixed_effects=off))
+elif sc == "round5_widening":
+    # round 5: the reference's package on the likelihoods / preconditioners built this round -- a Student-t model (two auxiliary parameters: "scale_SEP_df") fitted with the
+    # fitc preconditioner evaluated, a beta regression fitted with pivoted_cholesky; tight solver thresholds (the deterministic comparison of the fits)
+    n = 600
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    yt = lat + 0.35 * rng.standard_t(4, size=n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="t", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m.fit(y=yt, params=dict(tight))
+    out["t_cov_pars"] = L(m.get_cov_pars()); out["t_aux"] = L(m.get_aux_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["t_nll"] = float(m.get_current_neg_log_likelihood())
+    cp = rng.uniform(size=(9, 2))
+    p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=True)
+    out["t_resp_mu"] = L(p["mu"]); out["stoch_t_resp_var"] = L(p["var"])
+    try:      # re_model_template.h:891-895: the preconditioner cannot change after a fit -- the same refusal on both sides
+        m.set_optim_params(params=dict(tight, cg_preconditioner_type="fitc", fitc_piv_chol_preconditioner_rank=80))
+        out["pc_change_after_fit_refused"] = 0
+    except Exception as e:
+        out["pc_change_after_fit_refused"] = 1 if "Cannot change 'cg_preconditioner_type'" in str(e) else -1
+    m2 = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="t", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m2.set_optim_params(params=dict(tight, cg_preconditioner_type="fitc", fitc_piv_chol_preconditioner_rank=80))
+    out["t_nll_eval_fitc"] = float(m2.neg_log_likelihood(cov_pars=np.array([0.6, 0.2]), y=yt, aux_pars=np.array([0.4, 5.0])))
+    pm = 1 / (1 + np.exp(-(1.3 * lat - 0.1)))
+    yb = np.clip(rng.beta(pm * 9.0, (1 - pm) * 9.0), 1e-6, 1 - 1e-6)
+    mb = gpb.GPModel(gp_coords=coords, cov_function="exponential", likelihood="beta", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none")
+    mb.fit(y=yb, params=dict(tight, cg_preconditioner_type="pivoted_cholesky", fitc_piv_chol_preconditioner_rank=40))
+    out["flat_beta_cov_pars"] = L(mb.get_cov_pars()); out["flat_beta_aux"] = L(mb.get_aux_pars()); out["beta_num_it"] = [int(mb._get_num_optim_iter())]; out["beta_nll"] = float(mb.get_current_neg_log_likelihood())
+    p = mb.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
+    out["flat_beta_latent_mu"] = L(p["mu"]); out["stoch_beta_latent_var"] = L(p["var"])
 elif sc == "gauss_covariates":
     n = 500
     coords = rng.uniform(size=(n, 2))

@@ -101,3 +101,34 @@ def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name)
         np.testing.assert_allclose(m2.get_aux_pars(), g[name + key + "_aux"], rtol=rtol)
         nll = m2.get_current_neg_log_likelihood()
         assert abs(nll - float(g[name + key + "_negll"])) <= ntol * abs(nll)
+
+
+@pytest.mark.parametrize("pcn,rank", [("pivoted_cholesky", 50), ("fitc", 80)])
+def test_auxiliary_gradient_with_the_low_rank_preconditioners(gpb, orc, pcn, rank):
+    """t x pivoted_cholesky / fitc: the pivoted_cholesky / fitc branches of CalcLogDetStochDerivAuxParVecchia (likelihoods.h:16800-16837) -- W^-1 P^-1 Z recomputed from the
+    probes, the deterministic traces by pc_aux_sums -- against the oracle (pinned to the reference's CalcGradPars for these combinations at 8e-9)."""
+    from gpboost_amd import shim
+    tc = cases.LAPLACE_T_CASES["t_n1500"]
+    c = cases.LAPLACE_CASES[tc["model"]]
+    coords, y = cases.make_t_data(tc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood("t")
+    st.laplace_set_response_real(y[perm])
+    st.laplace_set_aux(tc["aux"])
+    st.laplace_set_preconditioner(pcn, rank)
+    ip = orc.vif_setup(coords, c["m"], rank, c["ordering"], c["seed"])[3] if pcn == "fitc" else None
+    if ip is not None:
+        st.laplace_set_inducing_points(ip)
+    cp = c["cov_pars"][0]
+    a = RC[ct] / cp[1]
+    nll, grad = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
+    ctx = orc.fitc_preconditioner(co, ip, ct, cp[0], a) if pcn == "fitc" else orc.pivoted_cholesky_preconditioner(co, ct, cp[0], a, rank=rank)
+    with ctx:
+        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood="t", aux=tc["aux"], **TIGHT_ORC)
+    assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
+    assert grad.shape == (4,)
+    np.testing.assert_allclose(grad, og, rtol=1e-8, atol=3e-8 * np.abs(og).max())
+    st.close()
