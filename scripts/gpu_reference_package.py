@@ -117,4 +117,21 @@ for name in ("w_poisson_n2000", "w_gamma_n1500", "binomial_logit_n1500"):
            float(gw[name + "_fit_tight_negll"])), flush=True)
     assert mw._get_num_optim_iter() == int(gw[name + "_fit_tight_num_it"])
     assert np.allclose(cpw[:2], gw[name + "_fit_tight_cov_pars"], rtol=1e-6)
+# round 5, the widening of this round through the package: tests/route_a_driver.py's scenario round5_widening (a Student-t fit with two auxiliary parameters, the refusal to
+# change the preconditioner after a fit, a t evaluation with the fitc preconditioner, a beta fit with pivoted_cholesky) on the MI355X against the reference LIBRARY's results
+# (tests/golden/route_a_round5_widening_ref.json = the same driver on oracle/_ref/lib_gpboost_ref.so)
+import json, subprocess       # noqa: E402
+r5 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "route_a_driver_gpu.py"), find_lib_path(), "round5_widening", ROOT], capture_output=True, text=True, cwd=ROOT)
+lines5 = [l for l in r5.stdout.splitlines() if l.startswith("RESULT ")]
+assert lines5, r5.stdout[-2000:] + r5.stderr[-3000:]
+ours5 = json.loads(lines5[-1][7:]); ref5 = json.load(open(os.path.join(ROOT, "tests", "golden", "route_a_round5_widening_ref.json")))
+assert sorted(ours5) == sorted(ref5)
+for k5 in ref5:
+    x5, y5 = np.asarray(ours5[k5], dtype=float), np.asarray(ref5[k5], dtype=float)
+    if k5 == "num_it" or k5 == "beta_num_it": assert np.array_equal(x5, y5), (k5, x5, y5)
+    elif k5.startswith("stoch_"): assert np.allclose(x5, y5, rtol=0.2), k5
+    elif k5.startswith("flat_"): assert np.allclose(x5, y5, rtol=1e-5, atol=1e-8), (k5, x5, y5)
+    else: assert np.allclose(x5, y5, rtol=1e-6, atol=1e-8), (k5, x5, y5)
+print("round5_widening through the package: t fit cov pars %s, (scale, df) %s, %d iterations; beta fit (pivoted_cholesky) cov pars %s, precision %s -- equal to the reference library's" %
+      (ours5["t_cov_pars"], ours5["t_aux"], ours5["num_it"], ours5["flat_beta_cov_pars"], ours5["flat_beta_aux"]), flush=True)
 print("REFERENCE PACKAGE ON MI355X: OK", flush=True)

@@ -1,0 +1,227 @@
+"""(GPU-box variant of tests/route_a_driver.py, generated from it: the package comes from oracle/_ref/refpkg.)
+Drop-in route A as a differential test: the reference's UNMODIFIED Python package runs one scenario against the library named
+on the command line -- the reference's own (oracle/_ref/lib_gpboost_ref.so) or this repository's C API host code on the oracle-backed shim
+(tests/mock_shim) -- and prints what it computed as JSON.  Only gpboost.libpath.find_lib_path() differs between the two runs.
+    python tests/route_a_driver.py <library> <scenario> <repo root>
+Keys starting with 'stoch_' hold quantities the reference ESTIMATES with random vectors (predictive variances of non-Gaussian models, iterative
+methods) and this library computes exactly; 'stochm_' quantities integrate over them (response means).  TEST INFRASTRUCTURE."""
+import json, sys, types
+sys.modules.setdefault("optuna", types.ModuleType("optuna"))       # optional dependency of the reference's package, absent here
+fake = types.ModuleType("gpboost.libpath")
+fake.find_lib_path = lambda: [sys.argv[1]]
+sys.modules["gpboost.libpath"] = fake
+import os
+sys.path.insert(0, os.path.join(sys.argv[3], "oracle", "_ref", "refpkg"))      # the scratch copy of the reference's package that travels to the GPU box (never /root/reference)
+sys.path.insert(0, sys.argv[3])
+import numpy as np
+import gpboost as gpb
+from tests import cases
+sc = sys.argv[2]
+out = {}
+def L(a): return np.asarray(a).ravel().tolist()
+rng = np.random.default_rng(11)
+if sc == "gauss_clusters":
+    n = 500
+    coords = rng.uniform(size=(n, 2)); y = np.sin(4 * coords[:, 0]) + 0.3 * rng.normal(size=n)
+    ids = (rng.uniform(size=n) < 0.4).astype(int) + 5
+    m = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none", cluster_ids=ids)
+    m.fit(y=y)
+    out["cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["nll"] = float(m.get_current_neg_log_likelihood())
+    cp = rng.uniform(size=(20, 2)); idp = np.r_[np.full(8, 6), np.full(8, 5), np.full(4, 9)]
+    for pt in ("order_obs_first_cond_obs_only", "order_obs_first_cond_all"):
+        m.set_prediction_data(vecchia_pred_type=pt, num_neighbors_pred=20)
+        p = m.predict(gp_coords_pred=cp, cluster_ids_pred=idp, predict_cov_mat=True)
+        out["mu_" + pt] = L(p["mu"]); out["cov_" + pt] = L(p["cov"])
+elif sc in ("logit_plain", "probit_offset", "poisson_dups_cov"):
+    lik = {"logit_plain": "bernoulli_logit", "probit_offset": "bernoulli_probit", "poisson_dups_cov": "poisson"}[sc]
+    n = 500
+    if sc == "poisson_dups_cov":
+        cu = rng.uniform(size=(250, 2)); idx = np.r_[np.arange(250), rng.integers(0, 250, size=n - 250)]; rng.shuffle(idx)
+        coords = cu[idx]
+    else:
+        coords = rng.uniform(size=(n, 2))
+    X = np.c_[np.ones(n), np.cos(4 * coords[:, 0])]
+    eta = 0.8 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + X @ np.array([0.2, -0.6])
+    y = rng.poisson(np.exp(0.5 * eta)).astype(float) if lik == "poisson" else (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+    off = 0.2 * np.sin(9 * np.arange(n) / n) if sc == "probit_offset" else None
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood=lik, gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=4)
+    Xfit = X if sc == "poisson_dups_cov" else None
+    m.fit(y=y, X=Xfit, offset=off)
+    out["cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["nll"] = float(m.get_current_neg_log_likelihood())
+    if Xfit is not None: out["coef"] = L(m.get_coef())
+    cp = np.vstack([rng.uniform(size=(10, 2)), coords[:3]]); Xp = np.c_[np.ones(13), np.cos(4 * cp[:, 0])]
+    offp = None if off is None else 0.1 * np.ones(13)
+    p = m.predict(gp_coords_pred=cp, X_pred=Xp if Xfit is not None else None, offset=off, offset_pred=offp, predict_var=True, predict_response=False)
+    out["latent_mu"] = L(p["mu"]); out["stoch_latent_var"] = L(p["var"])
+    p = m.predict(gp_coords_pred=cp, X_pred=Xp if Xfit is not None else None, offset=off, offset_pred=offp, predict_var=True)
+    out["stochm_resp_mu"] = L(p["mu"])
+    tr = m.predict_training_data_random_effects()
+    out["train_re"] = L(np.asarray(tr)[:, 0] if np.asarray(tr).ndim == 2 else tr)
+    out["nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.7, 0.15]), y=y))
+elif sc == "gauss_pred_types":
+    n = 400
+    coords = rng.uniform(size=(n, 2)); y = np.cos(5 * coords[:, 1]) + 0.4 * rng.normal(size=n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=2.5, gp_approx="vecchia", num_neighbors=12, vecchia_ordering="random", seed=9)
+    m.fit(y=y, params={"optimizer_cov": "gradient_descent", "lr_cov": 0.1, "use_nesterov_acc": True, "maxit": 40})
+    out["cov_pars_gd"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter())
+    m.fit(y=y, params={"optimizer_cov": "nelder_mead", "maxit": 30})
+    out["cov_pars_nm"] = L(m.get_cov_pars())
+    m.fit(y=y, params={"optimizer_cov": "lbfgs", "maxit": 1000, "estimate_cov_par_index": [1, 0, 1], "init_cov_pars": [0.2, 0.7, 0.15]})
+    out["cov_pars_fix"] = L(m.get_cov_pars())
+    cp = rng.uniform(size=(9, 2))
+    for pt in ("order_obs_first_cond_obs_only", "order_obs_first_cond_all", "order_pred_first", "latent_order_obs_first_cond_obs_only", "latent_order_obs_first_cond_all"):
+        m.set_prediction_data(vecchia_pred_type=pt, num_neighbors_pred=15)
+        p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=(pt != "order_pred_first"))
+        out["mu_" + pt] = L(p["mu"]); out["var_" + pt] = L(p["var"])
+    m.set_prediction_data(vecchia_pred_type="order_obs_first_cond_obs_only", num_neighbors_pred=15, gp_coords_pred=cp)
+    p = m.predict(use_saved_data=True, predict_var=True)
+    out["mu_saved"] = L(p["mu"]); out["var_saved"] = L(p["var"])
+elif sc == "logit_more":
+    n = 450
+    coords = rng.uniform(size=(n, 2))
+    X = np.c_[np.ones(n), np.cos(4 * coords[:, 0])]
+    eta = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + X @ np.array([-0.3, 0.7])
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+    off = 0.15 * np.cos(11 * np.arange(n) / n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="exponential", likelihood="bernoulli_logit", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none")
+    m.fit(y=y, X=X, offset=off)
+    out["cov_pars"] = L(m.get_cov_pars()); out["coef"] = L(m.get_coef()); out["num_it"] = int(m._get_num_optim_iter())
+    cp = np.vstack([0.5 + 0.03 * rng.normal(size=(6, 2)), rng.uniform(size=(5, 2))]); Xp = np.c_[np.ones(11), np.cos(4 * cp[:, 0])]
+    m.set_prediction_data(vecchia_pred_type="latent_order_obs_first_cond_all", num_neighbors_pred=20)
+    p = m.predict(gp_coords_pred=cp, X_pred=Xp, offset=off, offset_pred=0.05 * np.ones(11), predict_var=False, predict_response=False)
+    out["latent_mu_cond_all"] = L(p["mu"])
+    m2 = gpb.GPModel(gp_coords=coords, cov_function="exponential", likelihood="bernoulli_logit", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none")
+    # (tight solver tolerances: a sequence of fits on one model amplifies the 1e-5 noise of CG solves stopped at |r| < 1e-2 along flat directions)
+    m2.fit(y=y, params={"optimizer_cov": "gradient_descent", "lr_cov": 0.1, "maxit": 25, "cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13})
+    out["cov_pars_gd"] = L(m2.get_cov_pars())
+    m2.fit(y=y, params={"optimizer_cov": "nelder_mead", "maxit": 15})
+    out["cov_pars_nm"] = L(m2.get_cov_pars())
+    m2.fit(y=y, params={"optimizer_cov": "lbfgs", "maxit": 1000, "estimate_cov_par_index": [0, 1], "init_cov_pars": [0.6, 0.2]})
+    out["cov_pars_fix"] = L(m2.get_cov_pars())
+elif sc == "gauss_misc":
+    n = 450
+    coords = rng.uniform(size=(n, 3)); y = np.sin(3 * coords[:, 0]) * coords[:, 2] + 0.3 * rng.normal(size=n)
+    ids = rng.integers(0, 3, size=n)
+    fe = 0.4 * np.cos(7 * np.arange(n) / n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10, vecchia_ordering="random", seed=5, cluster_ids=ids)
+    m.fit(y=y, offset=fe)                                   # three clusters, random ordering from one generator, fixed effects at fit time
+    out["cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["nll"] = float(m.get_current_neg_log_likelihood())
+    cp = np.vstack([rng.uniform(size=(7, 3)), coords[:4]]); idp = np.r_[rng.integers(0, 3, size=7), ids[:4]]     # incl. prediction points that ARE training points
+    p = m.predict(gp_coords_pred=cp, cluster_ids_pred=idp, predict_var=True, offset=fe, offset_pred=0.1 * np.ones(11))
+    out["mu"] = L(p["mu"]); out["var"] = L(p["var"])
+    out["nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.2, 0.6, 0.3]), y=y))
+    # duplicate coordinates in a Gaussian model
+    cd = np.vstack([coords[:200], coords[:50]]); yd = np.r_[y[:200], y[:50] + 0.1]
+    md = gpb.GPModel(gp_coords=cd, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=8, vecchia_ordering="none")
+    out["dup_nll"] = float(md.neg_log_likelihood(cov_pars=np.array([0.1, 0.8, 0.25]), y=yd))
+    md.fit(y=yd)
+    out["dup_cov_pars"] = L(md.get_cov_pars())
+    p = md.predict(gp_coords_pred=coords[300:305], predict_var=True)
+    out["dup_mu"] = L(p["mu"]); out["dup_var"] = L(p["var"])
+elif sc == "poisson_misc":
+    n = 420
+    coords = rng.uniform(size=(n, 2))
+    eta = 0.7 * np.sin(6 * coords[:, 0]) + 0.3
+    y = rng.poisson(np.exp(eta)).astype(float)
+    off = 0.2 * np.sin(5 * np.arange(n) / n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=2.5, likelihood="poisson", gp_approx="vecchia", num_neighbors=12, vecchia_ordering="random", seed=3)
+    m.fit(y=y, offset=off, params={"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13})
+    out["cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["nll"] = float(m.get_current_neg_log_likelihood())
+    se = np.asarray(m.get_cov_pars(std_err=True)).ravel()
+    out["stochse_cov_pars_sd"] = L(se[2:])
+    cp = np.vstack([rng.uniform(size=(8, 2)), coords[10:13]])
+    p = m.predict(gp_coords_pred=cp, offset=off, offset_pred=np.zeros(11), predict_var=True, predict_response=False)
+    out["latent_mu"] = L(p["mu"]); out["stoch_latent_var"] = L(p["var"])
+    p = m.predict(gp_coords_pred=cp, offset=off, offset_pred=np.zeros(11), predict_cov_mat=True, predict_response=False)
+    out["stoch_latent_cov_diag"] = L(np.diag(np.asarray(p["cov"])))
+    out["train_re"] = L(m.predict_training_data_random_effects(offset=off))
+    out["nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.5, 0.2]), y=y, fixed_effects=off))
+elif sc == "round5_widening":
+    # round 5: the reference's package on the likelihoods / preconditioners built this round -- a Student-t model (two auxiliary parameters: "scale_SEP_df") fitted with the
+    # fitc preconditioner evaluated, a beta regression fitted with pivoted_cholesky; tight solver thresholds (the deterministic comparison of the fits)
+    n = 600
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    yt = lat + 0.35 * rng.standard_t(4, size=n)
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="t", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m.fit(y=yt, params=dict(tight))
+    out["t_cov_pars"] = L(m.get_cov_pars()); out["t_aux"] = L(m.get_aux_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["t_nll"] = float(m.get_current_neg_log_likelihood())
+    cp = rng.uniform(size=(9, 2))
+    p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=True)
+    out["t_resp_mu"] = L(p["mu"]); out["stoch_t_resp_var"] = L(p["var"])
+    try:      # re_model_template.h:891-895: the preconditioner cannot change after a fit -- the same refusal on both sides
+        m.set_optim_params(params=dict(tight, cg_preconditioner_type="fitc", fitc_piv_chol_preconditioner_rank=80))
+        out["pc_change_after_fit_refused"] = 0
+    except Exception as e:
+        out["pc_change_after_fit_refused"] = 1 if "Cannot change 'cg_preconditioner_type'" in str(e) else -1
+    m2 = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="t", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m2.set_optim_params(params=dict(tight, cg_preconditioner_type="fitc", fitc_piv_chol_preconditioner_rank=80))
+    out["t_nll_eval_fitc"] = float(m2.neg_log_likelihood(cov_pars=np.array([0.6, 0.2]), y=yt, aux_pars=np.array([0.4, 5.0])))
+    pm = 1 / (1 + np.exp(-(1.3 * lat - 0.1)))
+    yb = np.clip(rng.beta(pm * 9.0, (1 - pm) * 9.0), 1e-6, 1 - 1e-6)
+    mb = gpb.GPModel(gp_coords=coords, cov_function="exponential", likelihood="beta", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="none")
+    mb.fit(y=yb, params=dict(tight, cg_preconditioner_type="pivoted_cholesky", fitc_piv_chol_preconditioner_rank=40))
+    out["flat_beta_cov_pars"] = L(mb.get_cov_pars()); out["flat_beta_aux"] = L(mb.get_aux_pars()); out["beta_num_it"] = [int(mb._get_num_optim_iter())]; out["beta_nll"] = float(mb.get_current_neg_log_likelihood())
+    p = mb.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
+    out["flat_beta_latent_mu"] = L(p["mu"]); out["stoch_beta_latent_var"] = L(p["var"])
+elif sc == "gauss_covariates":
+    n = 500
+    coords = rng.uniform(size=(n, 2))
+    X = np.column_stack([np.ones(n), rng.normal(size=n), coords[:, 0]])
+    y = X @ np.array([1.0, 0.5, -0.7]) + np.sin(5 * coords[:, 1]) + 0.3 * rng.normal(size=n)
+    off = 0.2 * np.cos(3 * coords[:, 0])
+    Xp = np.column_stack([np.ones(9), rng.normal(size=9), rng.uniform(size=9)]); cp = rng.uniform(size=(9, 2))
+    for tag, kw in (("off", {}), ("plain", {}), ("fix", {"estimate_cov_par_index": [1, 0, 1]}), ("init", {"init_cov_pars": [0.2, 0.7, 0.15], "init_coef": [0.5, 0.5, 0.0]})):
+        m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=10, vecchia_ordering="none")
+        pr = {"optimizer_cov": "lbfgs", "maxit": 60}; pr.update(kw)
+        if tag == "fix": pr["init_cov_pars"] = [0.1, 0.9, 0.2]
+        m.fit(y=y, X=X, offset=off if tag == "off" else None, params=pr)
+        out[tag + "_cov_pars"] = L(m.get_cov_pars()); out[tag + "_coef"] = L(m.get_coef()); out[tag + "_num_it"] = [int(m._get_num_optim_iter())]
+        out[tag + "_nll"] = float(m.get_current_neg_log_likelihood())
+        out[tag + "_coef_sd"] = L(np.asarray(m.get_coef(std_err=True))[1])
+        p = m.predict(gp_coords_pred=cp, X_pred=Xp, predict_var=True, offset=off if tag == "off" else None, offset_pred=0.05 * np.ones(9) if tag == "off" else None)
+        out[tag + "_mu"] = L(p["mu"]); out[tag + "_var"] = L(p["var"])
+        if tag == "plain":
+            p = m.predict(gp_coords_pred=cp, X_pred=Xp, predict_cov_mat=True, predict_response=False)
+            out["plain_cov"] = L(np.asarray(p["cov"]))
+            out["plain_train_re_unsupported"] = 0
+elif sc == "gauss_covariates_gd":
+    n = 500
+    coords = rng.uniform(size=(n, 2))
+    X = np.column_stack([rng.normal(size=n), np.ones(n), coords[:, 0]])          # the intercept is the SECOND column
+    y = X @ np.array([0.5, 1.0, -0.7]) + np.sin(5 * coords[:, 1]) + 0.3 * rng.normal(size=n)
+    off = 0.2 * np.cos(3 * coords[:, 0])
+    Xp = np.column_stack([rng.normal(size=9), np.ones(9), rng.uniform(size=9)]); cp = rng.uniform(size=(9, 2))
+    for tag, pr in (("gd", {"optimizer_cov": "gradient_descent", "maxit": 1000}), ("gd_off_init", {"optimizer_cov": "gradient_descent", "init_coef": [0.3, 0.8, 0.0], "maxit": 25}),
+                    ("gd_plain", {"optimizer_cov": "gradient_descent", "use_nesterov_acc": False, "lr_cov": 0.05, "maxit": 30}),
+                    ("gd_fix", {"optimizer_cov": "gradient_descent", "estimate_cov_par_index": [1, 1, 0], "init_cov_pars": [0.1, 0.9, 0.2], "maxit": 50})):
+        m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=10, vecchia_ordering="none")
+        o = off if "off" in tag else None
+        m.fit(y=y, X=X, offset=o, params=pr)
+        out[tag + "_cov_pars"] = L(m.get_cov_pars()); out[tag + "_coef"] = L(m.get_coef()); out[tag + "_num_it"] = [int(m._get_num_optim_iter())]
+        out[tag + "_nll"] = float(m.get_current_neg_log_likelihood())
+        out[tag + "_coef_sd"] = L(np.asarray(m.get_coef(std_err=True))[1])
+        p = m.predict(gp_coords_pred=cp, X_pred=Xp, predict_var=True, offset=o, offset_pred=0.05 * np.ones(9) if o is not None else None)
+        out[tag + "_mu"] = L(p["mu"]); out[tag + "_var"] = L(p["var"])
+elif sc == "gauss_edges":
+    n = 300
+    coords = np.sort(rng.uniform(size=(n, 1)), axis=0)                             # one coordinate dimension
+    y = np.sin(9 * coords[:, 0]) + 0.2 * rng.normal(size=n)
+    cp = np.linspace(-0.1, 1.1, 13).reshape(-1, 1)
+    for tag, pr in (("gd_par", {"optimizer_cov": "gradient_descent", "convergence_criterion": "relative_change_in_parameters", "delta_rel_conv": 1e-4}),
+                    ("gd_mom", {"optimizer_cov": "gradient_descent", "momentum_offset": 5, "acc_rate_cov": 0.3, "lr_cov": 0.2, "maxit": 15}),
+                    ("nm_par", {"optimizer_cov": "nelder_mead", "convergence_criterion": "relative_change_in_parameters", "delta_rel_conv": 1e-5}),
+                    ("lbfgs_m2", {"optimizer_cov": "lbfgs", "m_lbfgs": 2, "delta_rel_conv": 1e-9}),
+                    ("lbfgs_it1", {"optimizer_cov": "lbfgs", "maxit": 1}), ("gd_it1", {"optimizer_cov": "gradient_descent", "maxit": 1})):
+        m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=2.5, gp_approx="vecchia", num_neighbors=6, vecchia_ordering="none")
+        try:
+            m.fit(y=y, params=pr)
+        except Exception as e:
+            out[tag + "_failed"] = 1; print("FAILED", tag, str(e)[:200]); continue
+        out[tag + "_cov_pars"] = L(m.get_cov_pars()); out[tag + "_num_it"] = [int(m._get_num_optim_iter())]; out[tag + "_nll"] = float(m.get_current_neg_log_likelihood())
+        m.set_prediction_data(num_neighbors_pred=120)
+        p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
+        out[tag + "_mu"] = L(p["mu"]); out[tag + "_var"] = L(p["var"])
+    se = np.asarray(m.get_cov_pars(std_err=False)).ravel(); out["last_cov_pars_again"] = L(se)
+print("RESULT " + json.dumps(out))
