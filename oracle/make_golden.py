@@ -234,6 +234,29 @@ def laplace_aux_fixture(out_dir, only=()):
     np.savez_compressed(os.path.join(out_dir, "laplace_aux_ref.npz"), **res)
 
 
+def laplace_pc_extra_fixture(out_dir):
+    """cases.LAPLACE_PC_EXTRA_CASES (pivoted_cholesky / fitc together with sample weights / repeated locations) through the reference library's C API at cases.LAPLACE_TIGHT:
+    *_negll (GPB_EvalNegLogLikelihood) and one lbfgs fit (*_fit_cov_pars / _aux / _num_it / _negll) -- tests/golden/laplace_pc_extra_ref.npz."""
+    res = {}
+    for name, ec in cases.LAPLACE_PC_EXTRA_CASES.items():
+        kw, y, cp, aux = cases.pc_extra_model(ec)
+        def model():
+            m = refdrv.RefCAPIModel(kw["gp_coords"], kw["cov_function"], kw["cov_fct_shape"], kw["num_neighbors"], kw["vecchia_ordering"], kw["seed"], threads=8,
+                                    likelihood=kw["likelihood"], weights=kw.get("weights"))
+            return m
+        m1 = model()
+        m1.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, cg_preconditioner_type=ec["pc"], piv_chol_rank=ec["rank"], **cases.LAPLACE_TIGHT)
+        res[name + "_negll"] = np.float64(m1.neg_log_likelihood(cp, y))
+        m2 = model()
+        m2.set_optim_config(estimate_aux_pars=aux is not None, cg_preconditioner_type=ec["pc"], piv_chol_rank=ec["rank"], **cases.LAPLACE_TIGHT)
+        m2.optim_cov_par(y)
+        res[name + "_fit_cov_pars"] = m2.get_cov_par(2); res[name + "_fit_num_it"] = np.int64(m2.get_num_it()); res[name + "_fit_negll"] = np.float64(m2.current_neg_log_likelihood())
+        if aux is not None:
+            res[name + "_fit_aux"] = m2.get_aux_pars(1)
+        print("pc extra", name, "%.10f" % res[name + "_negll"], res[name + "_fit_cov_pars"], res.get(name + "_fit_aux"), int(res[name + "_fit_num_it"]), "%.8f" % res[name + "_fit_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_pc_extra_ref.npz"), **res)
+
+
 def laplace_t_fixture(out_dir):
     """Student-t Vecchia-Laplace models (auxiliary parameters scale and df, both estimated; approximation_type fisher_laplace) by the unmodified reference --
     tests/golden/laplace_t_ref.npz, per cases.LAPLACE_T_CASES entry: *_negll_0 (default thresholds), *_negll_direct / *_grad_direct (CalcGradPars at cases.LAPLACE_TIGHT:
@@ -1176,6 +1199,8 @@ if __name__ == "__main__":
         optim_laplace_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_weights":
         laplace_weights_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pc_extra":
+        laplace_pc_extra_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_t":
         laplace_t_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":

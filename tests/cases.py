@@ -183,6 +183,32 @@ LAPLACE_PIVCHOL_CASES = {
 }
 
 
+# The low-rank preconditioners together with sample weights / repeated locations (the information W is then a weighted sum / a sum over a location's data; the factor L_k /
+# the inducing points live on the unique locations): model-surface checks against the reference library -- tests/golden/laplace_pc_extra_ref.npz.
+LAPLACE_PC_EXTRA_CASES = {
+    "pcw_poisson_n2000": dict(weights_case="w_poisson_n2000", pc="pivoted_cholesky", rank=40),
+    "fitcw_gamma_n1500": dict(weights_case="w_gamma_n1500", pc="fitc", rank=70),
+    "pcdup_logit": dict(dup=("dup_mat15_m20_random", "bernoulli_logit"), pc="pivoted_cholesky", rank=30),
+    "fitcdup_poisson": dict(dup=("dup_exp_m15_none", "poisson"), pc="fitc", rank=50),
+}
+
+
+def pc_extra_model(ec):
+    """-> (GPModel keyword arguments incl. coordinates [and weights], y, cov_pars, aux or None) of a LAPLACE_PC_EXTRA_CASES entry."""
+    if "weights_case" in ec:
+        wc = LAPLACE_WEIGHT_CASES[ec["weights_case"]]
+        c = LAPLACE_CASES[wc["model"]]
+        coords, y, w = make_weight_data(wc)
+        kw = dict(likelihood=wc["lik"], gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"],
+                  vecchia_ordering=c["ordering"], seed=c["seed"], weights=w)
+        return kw, y, np.asarray(c["cov_pars"][0], dtype=np.float64), wc.get("aux")
+    name, lik = ec["dup"]
+    cf, sh, m, ordering, seed = LAPLACE_DUP_CASES[name]
+    coords, y, _, _ = laplace_dup_data(lik)
+    kw = dict(likelihood=lik, gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m, vecchia_ordering=ordering, seed=seed)
+    return kw, y, np.asarray(LAPLACE_DUP_COV_PARS[0], dtype=np.float64), None
+
+
 def pivchol_rank(pc):
     """Columns of the low-rank part a LAPLACE_PIVCHOL_CASES entry asks for (None: the reference's defaults 50 / 200)."""
     return pc["rank"] if pc["rank"] is not None else (200 if pc.get("pc") == "fitc" else 50)

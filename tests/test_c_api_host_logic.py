@@ -68,7 +68,7 @@ def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatemen
     ParsePreconditionerAlias and the rank checks, GPB_GetCGPreconditionerType, GPB_EvalNegLogLikelihood, GPB_OptimCovPar): the host code under
     tests/test_zz_laplace_pivchol_gpu.py's model-API tests, against the reference's fixtures, with the oracle-backed shim."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_pivchol_gpu.py"], extra=["-k", "model_api"])
-    assert "9 passed" in tail, tail      # (5 pivoted_cholesky cases + 3 fitc cases + the error paths)
+    assert "13 passed" in tail, tail      # (5 pivoted_cholesky cases + 3 fitc cases + 4 with weights / repeated locations + the error paths)
 
 
 ROUTE_A_DRIVER = r'''

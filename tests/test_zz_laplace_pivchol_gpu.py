@@ -182,3 +182,27 @@ def test_model_api_errors_for_the_preconditioner(gpb):
         m2.neg_log_likelihood(np.array([1.0, 0.1]), y[:300])
     m2.set_optim_params({"fitc_piv_chol_preconditioner_rank": 40})
     assert np.isfinite(m2.neg_log_likelihood(np.array([1.0, 0.1]), y[:300]))
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_PC_EXTRA_CASES))
+def test_model_api_low_rank_preconditioners_with_weights_and_repeated_locations(gpb, name):
+    """pivoted_cholesky / fitc together with sample weights (the information is weighted) and with repeated locations (the information of a random effect is the sum over its
+    data; L_k / the inducing points live on the unique locations, the kmeans++ draw on their Vecchia-ordered coordinates) through the model surface against the reference
+    library (tests/golden/laplace_pc_extra_ref.npz, oracle/make_golden.py laplace_pc_extra) at cases.LAPLACE_TIGHT: evaluation 1e-8, the lbfgs fit with the reference's iterations."""
+    ec = cases.LAPLACE_PC_EXTRA_CASES[name]
+    g = np.load(os.path.join(GOLD, "laplace_pc_extra_ref.npz"))
+    kw, y, cp, aux = cases.pc_extra_model(ec)
+    pcp = dict(cases.LAPLACE_TIGHT, cg_preconditioner_type=ec["pc"], fitc_piv_chol_preconditioner_rank=ec["rank"])
+    mdl = gpb.GPModel(**kw)
+    mdl.set_optim_params(dict(pcp))
+    v = mdl.neg_log_likelihood(cp, y, aux_pars=[aux]) if aux is not None else mdl.neg_log_likelihood(cp, y)
+    ref = float(g[name + "_negll"])
+    assert abs(v - ref) <= 1e-8 * abs(ref), (v, ref)
+    m2 = gpb.GPModel(**kw)
+    m2.fit(y, params=dict(pcp))
+    assert m2.get_num_optim_iter() == int(g[name + "_fit_num_it"]), (m2.get_num_optim_iter(), int(g[name + "_fit_num_it"]))
+    np.testing.assert_allclose(m2.get_cov_pars(), g[name + "_fit_cov_pars"], rtol=1e-5)
+    if aux is not None:
+        np.testing.assert_allclose(m2.get_aux_pars(), g[name + "_fit_aux"], rtol=1e-5)
+    nll = m2.get_current_neg_log_likelihood()
+    assert abs(nll - float(g[name + "_fit_negll"])) <= 1e-8 * abs(nll)
