@@ -468,7 +468,7 @@ def main():
     achieved_gbs = bytes_launch / (ms_kernel * 1e-3) / 1e9
     achieved_tflops = flops_launch / (ms_kernel * 1e-3) / 1e12
 
-    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0>" % (m, ct, "true" if d == 3 else "false"), source_file="vecchia_kernels.hip") if (n, world) == (1000000, 1) else None
+    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0, false>" % (m, ct, "true" if d == 3 else "false"), source_file="vecchia_kernels.hip")       # <MT, COV, D3, MODE_NLL, WT = no sample weights> if (n, world) == (1000000, 1) else None
     rccl_ranks = st.comm_info()[1] if native_rccl else 0
     mailbox_ranks = st.mailbox_info()[1] if use_mailbox else 0
     # per-rank view (N > 1): every rank's in-loop kernel time and shard size -- min / max over the ranks is the skew the N = 8 budget of DESIGN.md

@@ -157,7 +157,7 @@ def test_errors_are_loud(gpb):
         gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
                     matrix_inversion_method="cholesky")
     with pytest.raises(gpb.GPBoostError):
-        gpb.GPModel(likelihood="t", gp_coords=coords, cov_function="exponential", gp_approx="vecchia")      # (gamma / negative_binomial: on the path since round 5)
+        gpb.GPModel(likelihood="negative_binomial_1", gp_coords=coords, cov_function="exponential", gp_approx="vecchia")      # (gamma / negative_binomial / beta / t: on the path since round 5)
     with pytest.raises(gpb.GPBoostError, match="vadu"):
         mdl.set_optim_params({"cg_preconditioner_type": "incomplete_cholesky"})      # ("pivoted_cholesky": on the path since round 5, tests/test_zz_laplace_pivchol_gpu.py)
     mdl.set_optim_params({"num_rand_vec_trace": 20, "cg_delta_conv": 1e-3})

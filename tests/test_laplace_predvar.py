@@ -196,8 +196,8 @@ def test_host_predict_response_matches_the_oracle(orc, lib_built, lik):
         else:
             assert np.array_equal(vv, v)
     lib.LGBM_GetLastError.restype = C.c_char_p
-    assert lib.GPB_HIP_PredictResponseHost(b"t", 1, P(m.copy()), P(v.copy()), C.c_bool(False), C.c_double(1e-8)) == -1
-    assert b"'t'" in lib.LGBM_GetLastError()
+    assert lib.GPB_HIP_PredictResponseHost(b"tweedie", 1, P(m.copy()), P(v.copy()), C.c_bool(False), C.c_double(1e-8)) == -1       # ("t": on the path since round 5)
+    assert b"'tweedie'" in lib.LGBM_GetLastError()
 
 
 @pytest.mark.gpu
