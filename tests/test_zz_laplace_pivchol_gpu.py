@@ -206,3 +206,30 @@ def test_model_api_low_rank_preconditioners_with_weights_and_repeated_locations(
         np.testing.assert_allclose(m2.get_aux_pars(), g[name + "_fit_aux"], rtol=1e-5)
     nll = m2.get_current_neg_log_likelihood()
     assert abs(nll - float(g[name + "_fit_negll"])) <= 1e-8 * abs(nll)
+
+
+def test_pivoted_cholesky_that_meets_its_error_bound_before_its_rank(gpb, orc):
+    """A smooth kernel (Matern-2.5, range 10 on the unit square): PivotedCholsekyFactorizationSigma stops after 27 of the 60 columns asked for (trace of the Schur
+    complement below PIV_CHOL_STOP_TOL = 1e-6, CG_utils.h:456), the remaining columns of L_k stay zero and the k x t normals still have 60 rows.  The value equals the
+    oracle's (itself 5e-14 from the reference on this case); the gradient only to 1e-3: the per-point systems have condition numbers ~1e10 here and d A / d log(range)
+    is good to ~1e-5 in ANY implementation (the oracle and the reference are 5e-5 apart on this case with either preconditioner)."""
+    from gpboost_amd import shim
+    rng = np.random.default_rng(1)
+    n = 400
+    coords = rng.uniform(size=(n, 2))
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-1.5 * np.sin(4 * coords[:, 0])))).astype(np.float64)
+    perm, co, nn = orc.vecchia_setup(coords, 15, "none", 0)
+    st = shim.VecchiaState(co, 15)
+    st.set_neighbors(nn)
+    st.laplace_set_likelihood("bernoulli_logit")
+    st.laplace_set_labels(y[perm].astype(np.int32))
+    st.laplace_set_preconditioner("pivoted_cholesky", 60)
+    var, a = 1.0, np.sqrt(5.0) / 10.0
+    L, k = orc.pivoted_cholesky_factor(co, 2, var, a, rank=60)
+    assert k < 60 and np.all(L[:, k:] == 0.0)
+    nll, grad = st.laplace_eval_grad(2, var, a, **cases.LAPLACE_TIGHT)
+    with orc.pivoted_cholesky_preconditioner(co, 2, var, a, rank=60):
+        on, og = orc.vecchia_laplace_grad(co, nn, 2, var, a, y[perm], likelihood="bernoulli_logit", **TIGHT_ORC)
+    assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
+    np.testing.assert_allclose(grad, og, rtol=1e-3)
+    st.close()
