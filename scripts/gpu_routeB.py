@@ -79,7 +79,11 @@ LAP_REF_PATH = os.path.join(ROOT, "tests", "golden", "routeB_laplace_ref.json")
 LAP_REF = json.load(open(LAP_REF_PATH)) if os.path.exists(LAP_REF_PATH) else {}
 MAKE_LAP_REF = "--make-laplace-ref" in sys.argv
 # ("<likelihood>:pivoted_cholesky": round 5 -- the same seams with cg_preconditioner_type = "pivoted_cholesky"; the host's PivotedCholsekyFactorizationSigma is skipped, the device forms the factor)
-LAP_CASES = ((800, 10, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky")),) if MOCK else (((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky")),) if (TEST or MAKE_LAP_REF) else ((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky")), (20000, 30, ("bernoulli_logit",)), (100000, 30, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky"))))
+# (round 5, second widening: the likelihoods with auxiliary parameters -- gamma (shape), negative_binomial (shape), beta (precision), t (scale and df, Fisher-Laplace) -- through the
+#  same seams: real-valued response by gpb_hip_vecchia_laplace_set_response_real, the parameters of every evaluation by gpb_hip_vecchia_laplace_set_aux_pars, their gradient by
+#  gpb_hip_vecchia_laplace_grad_aux_current; the fits estimate them together with the covariance parameters)
+AUX_LIKS = ("gamma", "negative_binomial", "beta", "t")
+LAP_CASES = ((800, 10, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky", "gamma", "t")),) if MOCK else (((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky") + AUX_LIKS + ("gamma:pivoted_cholesky",)),) if (TEST or MAKE_LAP_REF) else ((5000, 20, ("bernoulli_logit", "poisson", "bernoulli_logit:pivoted_cholesky") + AUX_LIKS + ("gamma:pivoted_cholesky",)), (20000, 30, ("bernoulli_logit",)), (100000, 30, ("bernoulli_logit", "bernoulli_logit:pivoted_cholesky"))))
 if "--trees-only" in sys.argv or "--gpboost-only" in sys.argv:
     LAP_CASES = ()
 for n, m, liks in LAP_CASES:
@@ -91,6 +95,15 @@ for n, m, liks in LAP_CASES:
         precond = precond or "vadu"
         if lik == "poisson":
             yl = rng.poisson(np.exp(0.5 * eta)).astype(np.float64)
+        elif lik == "gamma":
+            yl = rng.gamma(2.0, np.exp(0.5 * eta) / 2.0)
+        elif lik == "negative_binomial":
+            yl = rng.negative_binomial(3.0, 3.0 / (3.0 + np.exp(0.5 * eta))).astype(np.float64)
+        elif lik == "beta":
+            mu_b = 1.0 / (1.0 + np.exp(-0.8 * eta))
+            yl = np.clip(rng.beta(mu_b * 8.0, (1.0 - mu_b) * 8.0), 1e-6, 1.0 - 1e-6)
+        elif lik == "t":
+            yl = 0.8 * eta + 0.3 * rng.standard_t(4.0, size=n)
         else:
             yl = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-1.5 * eta))).astype(np.float64)
         cp = np.array([1.0, 0.1])
@@ -102,7 +115,7 @@ for n, m, liks in LAP_CASES:
         for gpu in legs:
             mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=-1, likelihood=lik, lib_path=LIBP, gpu_use=gpu,
                                       matrix_inversion_method="iterative")
-            mdl.set_optim_config(init_cov_pars=cp, optimizer_cov="lbfgs", cg_delta_conv=1e-6, cg_preconditioner_type=precond)
+            mdl.set_optim_config(init_cov_pars=cp, optimizer_cov="lbfgs", cg_delta_conv=1e-6, cg_preconditioner_type=precond, estimate_aux_pars=lik in AUX_LIKS)
             t0 = time.perf_counter()
             nll0 = mdl.neg_log_likelihood(cp, yl)
             t_first = time.perf_counter() - t0
@@ -114,9 +127,11 @@ for n, m, liks in LAP_CASES:
                 t0 = time.perf_counter()
                 mdl.optim_cov_par(yl)
                 out.update(t_fit=time.perf_counter() - t0, cov=[float(v) for v in mdl.get_cov_par(2)], it=int(mdl.get_num_it()), negll_fit=mdl.current_neg_log_likelihood())
+                if lik in AUX_LIKS:
+                    out["aux"] = [float(v) for v in mdl.get_aux_pars(2 if lik == "t" else 1)]
             res[gpu] = out
             print("Laplace %s n=%d GPU_use=%s: nll %.10f / %.10f, evaluation %.3f s%s" % (
-                lik_pc, n, gpu, nll0, nll1, t_eval, "" if "cov" not in out else "; fit: %d iterations, cov pars %s, negll %.8f, %.2f s" % (out["it"], out["cov"], out["negll_fit"], out["t_fit"])), flush=True)
+                lik_pc, n, gpu, nll0, nll1, t_eval, "" if "cov" not in out else "; fit: %d iterations, cov pars %s%s, negll %.8f, %.2f s" % (out["it"], out["cov"], "" if "aux" not in out else ", aux pars %s" % out["aux"], out["negll_fit"], out["t_fit"])), flush=True)
             del mdl
         if MAKE_LAP_REF:
             LAP_REF[key] = res[False]
@@ -132,6 +147,8 @@ for n, m, liks in LAP_CASES:
         msg = "evaluation %.1fx" % (a["t_eval"] / b["t_eval"])
         if "cov" in a and "cov" in b:
             np.testing.assert_allclose(b["cov"], a["cov"], rtol=1e-3)
+            if "aux" in a:
+                np.testing.assert_allclose(b["aux"], a["aux"], rtol=1e-3)
             assert abs(a["negll_fit"] - b["negll_fit"]) <= 1e-6 * abs(a["negll_fit"]), (a["negll_fit"], b["negll_fit"])
             msg += ", fit %.1fx (%d / %d iterations)" % (a["t_fit"] / b["t_fit"], a["it"], b["it"])
         print("Laplace %s n=%d: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build%s; %s faster" % (

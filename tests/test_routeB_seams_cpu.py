@@ -26,3 +26,7 @@ def test_patched_reference_host_code_on_the_cpu_restatement_of_the_shim():
     assert "Laplace bernoulli_logit" in out.stdout and "reproduces the CPU path of the same build" in out.stdout
     # round 5: the same seams with cg_preconditioner_type = "pivoted_cholesky" (HipEligible admits it; the host's PivotedCholsekyFactorizationSigma is skipped)
     assert "Laplace bernoulli_logit:pivoted_cholesky n=800: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path" in out.stdout
+    # round 5, second widening: likelihoods with auxiliary parameters (gamma: real-valued response + shape; t: scale and df under Fisher-Laplace) -- the response by
+    # gpb_hip_vecchia_laplace_set_response_real, the parameters by _set_aux_pars at every evaluation, their gradient by _grad_aux_current; the fit estimates them
+    for lik in ("gamma", "t"):
+        assert "Laplace %s n=800: GPU_use=true (mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path" % lik in out.stdout
