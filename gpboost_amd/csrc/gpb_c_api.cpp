@@ -181,10 +181,10 @@ bool is_proportion_likelihood(const std::string& lik) {
 bool is_logit_link(const std::string& lik) { return lik == "bernoulli_logit" || lik == "binomial_logit" || lik == "quasi_bernoulli_logit"; }
 bool is_probit_link(const std::string& lik) { return lik == "bernoulli_probit" || lik == "binomial_probit" || lik == "quasi_bernoulli_probit"; }
 int laplace_link_id(const std::string& lik) {
-  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : (lik == "t" ? 6 : 0)))));
+  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : (lik == "t" ? 6 : (lik == "lognormal" ? 7 : 0))))));
 }
 bool supported_non_gaussian(const std::string& lik) {
-  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || is_proportion_likelihood(lik);
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || lik == "lognormal" || is_proportion_likelihood(lik);
 }
 // Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
 std::string parse_likelihood_alias(const std::string& lik) {
@@ -195,7 +195,7 @@ std::string parse_likelihood_alias(const std::string& lik) {
   if (lik == "quasi_binary" || lik == "quasi_binary_logit") return "quasi_bernoulli_logit";
   return lik;
 }
-int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma" || lik == "negative_binomial" || lik == "beta") ? 1 : 0); }      // t: scale, df (likelihoods.h:398-407)
+int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "lognormal") ? 1 : 0); }      // t: scale, df (likelihoods.h:398-407)
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
@@ -260,6 +260,15 @@ double initial_aux_par(const std::string& lik, int n, const double* y, const dou
     if (std::isnan(phi) || phi <= 0.0) phi = 1.0;
     return std::min(std::max(phi, 0.1), 100.0);
   }
+  if (lik == "lognormal") {      // moment-based: the (weighted) variance of log y - offset, at least 1e-6 (likelihoods.h:2015-2030)
+    double mean_log = 0., mean_log_sq = 0., sw = 0.;
+    for (int i = 0; i < n; ++i) {
+      const double w = wts ? wts[i] : 1.0, z = fe ? std::log(y[i]) - fe[i] : std::log(y[i]);
+      mean_log += w * z; mean_log_sq += w * z * z; sw += w;
+    }
+    mean_log /= sw; mean_log_sq /= sw;
+    return std::max(mean_log_sq - mean_log * mean_log, 1e-6);
+  }
   if (lik == "gamma") {
     double log_avg = 0., avg_log = 0., sw = 0.;
     for (int i = 0; i < n; ++i) {
@@ -319,7 +328,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   mdl->labels.resize(mdl->n);
   const bool poisson = mdl->likelihood == "poisson" || mdl->likelihood == "negative_binomial";     // integer-valued responses >= 0
-  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t") {      // likelihoods.h:1365-1373: strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1); t: any real value
+  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t" || mdl->likelihood == "lognormal") {      // likelihoods.h:1365-1373 (gamma, lognormal): strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1); t: any real value
     const bool is_beta = mdl->likelihood == "beta", is_t = mdl->likelihood == "t";
     mdl->resp_real.resize(mdl->n);
     for (int k = 0; k < mdl->n; ++k) {
@@ -329,7 +338,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
       else if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
       mdl->resp_real[k] = yk; mdl->labels[k] = 0;
     }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : (is_t ? 6 : 3))) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : (is_t ? 6 : (mdl->likelihood == "lognormal" ? 7 : 3)))) return shim_error();
     if (mdl->n_re > 0) {
       std::vector<double> grouped(mdl->n);
       for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
@@ -966,6 +975,15 @@ bool predict_response_host(const std::string& lik, int n, double* mean, double* 
     }
     return true;
   }
+  if (lik == "lognormal") {                 // likelihoods.h:9868-9888: mean exp(m + v / 2); variance Var(E[y | b]) + E[Var(y | b)] with aux = variance of log y
+    const double exp_s2_m1 = std::expm1(aux);
+    for (int i = 0; i < n; ++i) {
+      const double pm = std::exp(mean[i] + 0.5 * var[i]);
+      if (predict_var) { const double exp_v_m1 = std::expm1(var[i]), pm2 = pm * pm; var[i] = exp_v_m1 * pm2 + exp_s2_m1 * pm2 * (exp_v_m1 + 1.); }
+      mean[i] = pm;
+    }
+    return true;
+  }
   if (lik == "gamma") {                     // likelihoods.h:9715-9728
     for (int i = 0; i < n; ++i) {
       const double pm = std::exp(mean[i] + 0.5 * var[i]);
@@ -1312,7 +1330,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   if (num_neighbors <= 0) num_neighbors = 20;   // re_model_template.h:288-294
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
-  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); mdl->num_neighbors = num_neighbors;
+  mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); if (lik_name == "lognormal") mdl->aux_pars[0] = 0.5;  /* likelihoods.h:506 */ mdl->num_neighbors = num_neighbors;
   if (has_weights && lik_name != "gaussian") mdl->lik_weights.assign(weights, weights + num_data);     // factors of the per-datum likelihood terms (likelihoods.h:666-668)
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
@@ -1440,7 +1458,7 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   mdl->estimate_aux_pars = estimate_aux_pars;
   if (init_aux_pars && mdl->num_aux > 0) {
     for (int j = 0; j < mdl->num_aux; ++j) {
-      if (!(init_aux_pars[j] > 0.)) return set_error("The %s parameter is not > 0 (found %g)", mdl->likelihood == "t" ? (j == 0 ? "scale" : "df") : "shape", init_aux_pars[j]);
+      if (!(init_aux_pars[j] > 0.)) return set_error("The %s parameter is not > 0 (found %g)", mdl->likelihood == "t" ? (j == 0 ? "scale" : "df") : (mdl->likelihood == "lognormal" ? "log_variance" : "shape"), init_aux_pars[j]);
       mdl->init_aux[j] = init_aux_pars[j]; mdl->aux_pars[j] = init_aux_pars[j];
     }
     mdl->init_aux_given = true; mdl->aux_set = true;
@@ -2881,7 +2899,7 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   if (lik == "gaussian" && mdl->n_re > 0)
     return set_error("GPB_SetLikelihood: this model was created with repeated locations under a non-Gaussian likelihood -- its Vecchia approximation lives on the %d unique locations (Vecchia_utils.cpp:1156-1168); create a new model for the Gaussian likelihood", mdl->n_re);
   mdl->likelihood = lik;
-  mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = 1.; mdl->aux_pars[1] = 2.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
+  mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = lik == "lognormal" ? 0.5 : 1.; mdl->aux_pars[1] = 2.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
   mdl->cov_pars_initialized = false; mdl->init_cov_pars_provided = false; mdl->negll_valid = false; mdl->y_set = false; mdl->yaux_valid = false;
   C_API_END();
 }
@@ -2892,7 +2910,7 @@ int GPB_GetResponseData(REModelHandle handle, double* response_data) {
   if (!mdl || !response_data) return set_error("GPB_GetResponseData: null argument");
   if (!mdl->y_set) return set_error("Respone variable data has not been set");      // re_model_template.h:6258-6261 (sic)
   if (mdl->likelihood == "gaussian") { std::copy(mdl->y_host.begin(), mdl->y_host.end(), response_data); }   // y_vec_: the response as passed in
-  else if (mdl->likelihood == "gamma" || mdl->likelihood == "beta") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
+  else if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t" || mdl->likelihood == "lognormal") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
   else { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = (double)mdl->labels[k]; }
   C_API_END();
 }
@@ -2929,7 +2947,7 @@ int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool c
   if (mdl->num_aux < 1) { if (out_str) out_str[0] = 0; return 0; }      // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
   if (calc_std_dev) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters are not on the MI355X path of this library");
   if (aux_pars) for (int j = 0; j < mdl->num_aux; ++j) aux_pars[j] = mdl->aux_pars[j];       // REModel::GetAuxPars (re_model.cpp:1364-1405), original scale
-  if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : "shape"));       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
+  if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : (mdl->likelihood == "lognormal" ? "log_variance" : "shape")));      // lognormal: likelihoods.h:507       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
   return 0;
 }
 

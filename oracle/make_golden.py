@@ -262,30 +262,38 @@ def laplace_t_fixture(out_dir):
     tests/golden/laplace_t_ref.npz, per cases.LAPLACE_T_CASES entry: *_negll_0 (default thresholds), *_negll_direct / *_grad_direct (CalcGradPars at cases.LAPLACE_TIGHT:
     gradient wrt (log sigma1^2, log a, log scale, log df); *_fe_*: with fixed effects), *_fit_* / *_fit_tight_* (lbfgs with both auxiliary parameters estimated), predictions."""
     res = {}
+    only = sys.argv[2:]
+    path = os.path.join(out_dir, "laplace_t_ref.npz")
+    if only and os.path.isfile(path):          # `laplace_t <name> ...`: (re)generate only these cases
+        res = dict(np.load(path))
     for name, tc in cases.LAPLACE_T_CASES.items():
+        if only and name not in only:
+            continue
+        lik = tc.get("lik", "t")               # (lognormal: one auxiliary parameter, otherwise the same surface)
+        naux = len(tc["aux"])
         c = cases.LAPLACE_CASES[tc["model"]]
         coords, y = cases.make_t_data(tc)
         aux = np.asarray(tc["aux"], dtype=np.float64)
         cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
         args = (c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
-        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood="t")
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
         mdl.set_optim_config(init_aux_pars=aux)
         res[name + "_negll_0"] = np.float64(mdl.neg_log_likelihood(cp, y))
         for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords))):
-            nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, "t", fe, *args, aux_pars=aux, estimate_aux=True, **cases.LAPLACE_TIGHT)
+            nll, g, _ = refdrv.ref_laplace_nll_grad(coords, y, cp, lik, fe, *args, aux_pars=aux, estimate_aux=True, **cases.LAPLACE_TIGHT)
             res[name + fe_key + "_negll_direct"] = np.float64(nll); res[name + fe_key + "_grad_direct"] = g
-            print("laplace t", name, fe_key, "negll %.10f" % nll, "grad", g, flush=True)
+            print("laplace " + lik, name, fe_key, "negll %.10f" % nll, "grad", g, flush=True)
         for key, cfg in (("_fit", {}), ("_fit_tight", dict(cases.LAPLACE_TIGHT))):
-            m2 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood="t")
+            m2 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik)
             m2.set_optim_config(estimate_aux_pars=True, **cfg)
             m2.optim_cov_par(y)
-            res[name + key + "_cov_pars"] = m2.get_cov_par(2); res[name + key + "_aux"] = m2.get_aux_pars(2)
+            res[name + key + "_cov_pars"] = m2.get_cov_par(2); res[name + key + "_aux"] = m2.get_aux_pars(naux)
             res[name + key + "_init_cov_pars"] = m2.get_init_cov_par()[:2].copy()
             res[name + key + "_num_it"] = np.int32(m2.get_num_it()); res[name + key + "_negll"] = np.float64(m2.current_neg_log_likelihood())
             print("laplace t fit", name, key, "->", res[name + key + "_cov_pars"], res[name + key + "_aux"], res[name + key + "_num_it"], res[name + key + "_negll"], flush=True)
         cpred = np.random.default_rng(79).uniform(size=(40, c["d"]))
         res[name + "_coords_pred"] = cpred
-        m4 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood="t", matrix_inversion_method="cholesky")
+        m4 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik, matrix_inversion_method="cholesky")
         m4.set_optim_config(init_aux_pars=aux, **cases.LAPLACE_TIGHT)
         mu, var = m4.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp)
         rmu, rvar = m4.predict(cpred, predict_var=True, predict_response=True, y=y, cov_pars=cp)

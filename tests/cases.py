@@ -126,6 +126,10 @@ LAPLACE_AUX_CASES = {
 LAPLACE_T_CASES = {
     "t_n1500": dict(model="lap_u2d_n1500_mat15_m30", aux=(0.5, 3.0), true_scale=0.4, true_df=4.0),
     "t_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", aux=(0.3, 6.0), true_scale=0.3, true_df=5.0),
+    # lognormal (round 5, fourth slice; the same constant-information structure as t under Fisher-Laplace, ONE auxiliary parameter: the variance of log y,
+    # likelihoods.h:30-34, :505-513): mean of y = exp(location)
+    "lognormal_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="lognormal", aux=(0.3,), true_s2=0.2),
+    "lognormal_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="lognormal", aux=(0.15,), true_s2=0.1),
 }
 
 
@@ -136,6 +140,9 @@ def make_t_data(tc):
     n, d = c["n"], c["d"]
     coords = rng.uniform(size=(n, d))
     latent = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.3
+    if tc.get("lik", "t") == "lognormal":      # log y ~ N(latent - s2 / 2, s2)
+        s2 = tc["true_s2"]
+        return coords, np.exp(latent - 0.5 * s2 + np.sqrt(s2) * np.random.default_rng(c["seed_data"] + 4100).standard_normal(n))
     y = latent + tc["true_scale"] * np.random.default_rng(c["seed_data"] + 4000).standard_t(tc["true_df"], size=n)
     return coords, y
 

@@ -756,6 +756,7 @@ def test_oracle_student_t_value_and_gradient_match_the_reference(orc, name):
     by CalcLogDetStochDerivAuxParVecchia's vadu branch (:16838-16856), no implicit part -- against the reference's own CalcGradPars at cases.LAPLACE_TIGHT
     (tests/golden/laplace_t_ref.npz, oracle/make_golden.py laplace_t): value 1e-10, gradient 1e-8, without and with fixed effects; GPB_EvalNegLogLikelihood at the default thresholds."""
     tc = cases.LAPLACE_T_CASES[name]
+    lik = tc.get("lik", "t")          # lognormal (link 7, round 5 fourth slice): one auxiliary parameter, constant information 1 / aux (likelihoods.h:505-513); the same trace, :14275-14286, :14891-14900
     c = cases.LAPLACE_CASES[tc["model"]]
     g = np.load(os.path.join(GOLD, "laplace_t_ref.npz"))
     coords, y = cases.make_t_data(tc)
@@ -763,14 +764,14 @@ def test_oracle_student_t_value_and_gradient_match_the_reference(orc, name):
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     cp = c["cov_pars"][0]
     a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
-    negll, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood="t", aux=tc["aux"])
+    negll, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=lik, aux=tc["aux"])
     ref0 = float(g[name + "_negll_0"])
     assert abs(negll - ref0) <= 1e-8 * abs(ref0), (negll, ref0)
     for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
-        nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood="t", fixed_effects=fe, aux=tc["aux"],
+        nll_t, grad_t = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik, fixed_effects=fe, aux=tc["aux"],
                                                  cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
         ref = g[name + fe_key + "_grad_direct"]
-        assert grad_t.shape == (4,) and ref.shape == (4,)
+        assert grad_t.shape == (2 + len(tc["aux"]),) and ref.shape == grad_t.shape
         np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=3e-8 * np.abs(ref).max())      # (the scale's trace term multiplies the block CG's 1e-8 stopping error by dW / d log scale = -2 W: seen 1.6e-8 of the gradient's scale on the d = 3 case with fixed effects)
         ref_v = float(g[name + fe_key + "_negll_direct"])
         assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
