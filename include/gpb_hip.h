@@ -403,7 +403,10 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, cons
  * with GPBoost::normalLogCDF, DF_utils.h:74-92).  gpb_hip_vecchia_laplace_logit then evaluates that likelihood.
  * Round 5: 3 = "gamma", 4 = "negative_binomial" (auxiliary shape parameter, below), 5 = "beta" (mean = sigmoid(location), auxiliary precision; real-valued response
  * strictly inside (0, 1) through gpb_hip_vecchia_laplace_set_response_real; LogLikBeta :11903-11913, FirstDerivLogLikBeta :12501-12507, SecondDerivNegLogLikBeta
- * :13336-13346, third derivative :13892-13917, auxiliary-parameter gradient :14229-14241, :14816-14845; GPBoost::digamma / trigamma / tetragamma, src/GPBoost/DF_utils.cpp:82-201). */
+ * :13336-13346, third derivative :13892-13917, auxiliary-parameter gradient :14229-14241, :14816-14845; GPBoost::digamma / trigamma / tetragamma, src/GPBoost/DF_utils.cpp:82-201),
+ * 6 = "t" (location = latent value; two auxiliary parameters scale, df; approximation_type "fisher_laplace", likelihoods.h:384-423),
+ * 7 = "lognormal" (mean of y = exp(location), one auxiliary parameter: the variance of log y; real-valued response > 0; constant information 1 / aux, likelihoods.h:30-34,
+ * :505-513; LogLikLogNormal :11950-11958, FirstDerivLogLikLogNormal :12534-12538, normalising constant :10623-10631 / :10887-10889, auxiliary gradient :14275-14286, :14891-14900). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int likelihood_id);
 /* Repeated locations for the non-Gaussian models (the reference's unique-location mapping: RECompGP with use_Z_for_duplicates,
  * include/GPBoost/re_comp.h:863-885; src/GPBoost/Vecchia_utils.cpp:1156-1168): the handle's n points are the UNIQUE locations (random effects),

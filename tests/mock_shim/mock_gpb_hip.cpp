@@ -85,6 +85,10 @@ double mock_tetragamma(double x) {
   return value + (-1.0 / z2 - 1.0 / z3 - 0.5 / z4 + 1.0 / (6.0 * z6) - 1.0 / (6.0 * z8) + 3.0 / (10.0 * z10));
 }
 void lik_terms(int link, double y, double x, double* first, double* info, double* dinfo) {
+  if (link == 7) {       // lognormal: FirstDerivLogLikLogNormal, SecondDerivNegLogLikLogNormal (likelihoods.h:12534-12538, :13384-13386); constant information
+    *first = (std::log(y) - (x - 0.5 * g_mock_aux)) / g_mock_aux; *info = 1. / g_mock_aux; *dinfo = 0.;
+    return;
+  }
   if (link == 6) {       // t, fisher_laplace: FirstDerivLogLikT, FisherInformationT (likelihoods.h:12509-12512, :13358-13360); the information does not depend on the location
     const double sc = g_mock_aux, nu = g_mock_aux2, res = y - x;
     *first = (nu + 1.) * res / (nu * sc * sc + res * res); *info = (nu + 1.) / (nu + 3.) / (sc * sc); *dinfo = 0.;
@@ -154,7 +158,7 @@ struct gpb_hip_vecchia {
   bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
   int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns, 2 = fitc with the inducing points pc_ip
   std::vector<double> pc_ip; int pc_nip = 0;       // k x d column-major
-  double yv(int k) const { return (link == 3 || link == 5 || link == 6 || real_resp) ? resp_real[k] : (double)labels[k]; }
+  double yv(int k) const { return (link == 3 || link == 5 || link == 6 || link == 7 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
   bool has_mode = false, grad_state = false;
@@ -304,7 +308,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
   const bool ctx = h->link >= 3 || h->real_resp;
-  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->link == 6 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->link == 6 || h->link == 7 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
   if (h->link == 6) orc_set_aux2(h->aux2);
   orc_set_binomial(h->binomial ? 1 : 0);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
@@ -517,7 +521,7 @@ EXPORT int gpb_hip_dense_spd_solve(int32_t n, const double* M_host, const double
 
 // ---- Laplace path ----
 EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int id) {
-  if (id < 0 || id > 6) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
+  if (id < 0 || id > 7) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
   if (h->link != id) { h->labels.clear(); h->grad_state = false; }
   h->link = id; return 0;
 }
@@ -531,10 +535,10 @@ EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_
   h->labels.assign(y, y + nd); h->real_resp = false; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
-  if (h->link != 3 && h->link != 5 && h->link != 6 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
+  if (h->link != 3 && h->link != 5 && h->link != 6 && h->link != 7 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   for (int i = 0; i < nd; ++i) {
-    if (h->link == 3) { if (!(y[i] > 0.)) return fail("gamma: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
+    if (h->link == 3 || h->link == 7) { if (!(y[i] > 0.)) return fail("gamma / lognormal: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
     else if (h->link == 5) { if (!(y[i] > 0. && y[i] < 1.)) return fail(" Must have 0 < y < 1 for the response variable ('y') for likelihood = 'beta', found %g ", y[i]); }
     else if (h->link == 6) { if (!std::isfinite(y[i])) return fail("t: the response must be finite"); }
     else if (!(y[i] >= 0. && y[i] <= 1.)) return fail(" Must have 0 <= y <= 1 for the response variable ('y') (found %g at Vecchia position %d)", y[i], i);

@@ -50,8 +50,11 @@ def test_route_b_reference_remodel_with_gpu_use_reproduces_its_cpu_path(lib_buil
     assert out.count("GPU_use=true reproduces the CPU path of the same build") == 2
     # round 4: the Laplace seams (Bernoulli-logit and Poisson, n = 5000: evaluations and lbfgs fits) against the CPU path's stored values, and the GPBoost loop
     # (round 5: + the same seams with cg_preconditioner_type = "pivoted_cholesky")
-    assert out.count("(mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build") == 3
+    # (round 5, second widening: + gamma, negative_binomial, beta and t with their auxiliary parameters estimated, and gamma with pivoted_cholesky -- 8 legs in all)
+    assert out.count("(mode finding, stochastic log-determinant and gradient on the device) reproduces the CPU path of the same build") == 8
     assert "Laplace bernoulli_logit:pivoted_cholesky n=5000: GPU_use=true" in out
+    for lik in ("gamma", "negative_binomial", "beta", "t", "gamma:pivoted_cholesky"):
+        assert "Laplace %s n=5000: GPU_use=true" % lik in out
     assert "y_aux and Newton leaf values from the resident factor) reproduces the CPU path" in out
 
 

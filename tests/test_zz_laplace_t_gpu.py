@@ -1,4 +1,5 @@
-"""GPU (MI355X): the Student-t likelihood on the Vecchia-Laplace path (round 5, third slice) -- location = the latent value, auxiliary parameters
+"""GPU (MI355X): the Student-t likelihood (and, fourth slice of round 5, the lognormal likelihood: cases.LAPLACE_T_CASES entries with lik = "lognormal" -- one auxiliary parameter, the
+variance of log y, the same constant-information structure) on the Vecchia-Laplace path (round 5, third slice) -- location = the latent value, auxiliary parameters
 (scale, df) both estimated, the reference's default approximation "fisher_laplace" (likelihoods.h:384-423: the information is the constant Fisher information
 (df + 1) / (df + 3) / scale^2) -- through the C ABI against the UNMODIFIED reference (tests/golden/laplace_t_ref.npz, oracle/make_golden.py laplace_t):
   * value at the default thresholds; value + gradient wrt (log sigma1^2, log a, log scale, log df) at cases.LAPLACE_TIGHT from the reference's own CalcGradPars (1e-8),
@@ -31,6 +32,8 @@ def gpb(lib_built):
 def test_value_and_gradient_match_the_reference(gpb, orc, name):
     from gpboost_amd import shim
     tc = cases.LAPLACE_T_CASES[name]
+    lik = tc.get("lik", "t")          # (lognormal, link 7: ONE auxiliary parameter -- the variance of log y -- and the same constant-information structure, likelihoods.h:505-513)
+    naux = len(tc["aux"])
     c = cases.LAPLACE_CASES[tc["model"]]
     g = np.load(os.path.join(GOLD, "laplace_t_ref.npz"))
     coords, y = cases.make_t_data(tc)
@@ -38,7 +41,7 @@ def test_value_and_gradient_match_the_reference(gpb, orc, name):
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     st = shim.VecchiaState(co, c["m"])
     st.set_neighbors(nn)
-    st.laplace_set_likelihood("t")
+    st.laplace_set_likelihood(lik)
     st.laplace_set_response_real(y[perm])
     st.laplace_set_aux(tc["aux"])
     cp = c["cov_pars"][0]
@@ -50,24 +53,27 @@ def test_value_and_gradient_match_the_reference(gpb, orc, name):
         st.laplace_set_fixed_effects(fe)
         nll_t, grad_t = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
         ref = g[name + fe_key + "_grad_direct"]
-        assert grad_t.shape == (4,)
+        assert grad_t.shape == (2 + naux,)
         np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=3e-8 * np.abs(ref).max())      # (the scale's trace term multiplies the block CG's 1e-8 stopping error by dW / d log scale = -2 W: seen 1.6e-8 of the gradient's scale on the d = 3 case with fixed effects)
         ref_v = float(g[name + fe_key + "_negll_direct"])
         assert abs(nll_t - ref_v) <= 1e-8 * abs(ref_v), (nll_t, ref_v)
     # other auxiliary parameters: against the oracle (itself pinned to the reference above); the boosting gradient is -d log p / d loc alone (no determinant / implicit part)
     st.laplace_set_fixed_effects(None)
-    for aux2 in ((0.8, 2.2), (0.25, 15.0)):
+    for aux2 in (((0.8, 2.2), (0.25, 15.0)) if lik == "t" else ((0.6,), (0.05,))):
         st.laplace_set_aux(aux2)
         nll2, grad2 = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
-        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood="t", aux=aux2, **TIGHT_ORC)
+        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik, aux=aux2, **TIGHT_ORC)
         assert abs(nll2 - on) <= 1e-8 * abs(on), (aux2, nll2, on)
         np.testing.assert_allclose(grad2, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
         ga = st.laplace_grad_aux()
-        assert ga.shape == (8,) and ga[3] == 0.0 and ga[7] == 0.0                    # no implicit part
+        assert ga.shape == (4 * naux,) and ga[3] == 0.0 and ga[-1] == 0.0              # no implicit part
     with pytest.raises(gpb.GPBoostError, match="not > 0"):
-        st.laplace_set_aux((0.5, -1.0))
+        st.laplace_set_aux((0.5, -1.0) if lik == "t" else (-0.5,))
     with pytest.raises(gpb.GPBoostError, match="parameters"):
-        st.laplace_set_aux(0.5)
+        st.laplace_set_aux(0.5 if lik == "t" else (0.5, 2.0))
+    if lik == "lognormal":
+        with pytest.raises(gpb.GPBoostError, match="> 0"):
+            st.laplace_set_response_real(-y[perm])
     st.close()
 
 
@@ -77,11 +83,12 @@ def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name)
     c = cases.LAPLACE_CASES[tc["model"]]
     g = np.load(os.path.join(GOLD, "laplace_t_ref.npz"))
     coords, y = cases.make_t_data(tc)
-    kw = dict(likelihood="t", gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
+    lik = tc.get("lik", "t")
+    kw = dict(likelihood=lik, gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia",
               num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
     cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
     mdl = gpb.GPModel(**kw)
-    assert mdl.get_num_aux_pars() == 2
+    assert mdl.get_num_aux_pars() == len(tc["aux"])
     v = mdl.neg_log_likelihood(cp, y, aux_pars=list(tc["aux"]))
     ref0 = float(g[name + "_negll_0"])
     assert abs(v - ref0) <= 1e-8 * abs(ref0), (v, ref0)
@@ -103,19 +110,22 @@ def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name)
         assert abs(nll - float(g[name + key + "_negll"])) <= ntol * abs(nll)
 
 
+@pytest.mark.parametrize("case", ["t_n1500", "lognormal_n1500"])
 @pytest.mark.parametrize("pcn,rank", [("pivoted_cholesky", 50), ("fitc", 80)])
-def test_auxiliary_gradient_with_the_low_rank_preconditioners(gpb, orc, pcn, rank):
+def test_auxiliary_gradient_with_the_low_rank_preconditioners(gpb, orc, pcn, rank, case):
     """t x pivoted_cholesky / fitc: the pivoted_cholesky / fitc branches of CalcLogDetStochDerivAuxParVecchia (likelihoods.h:16800-16837) -- W^-1 P^-1 Z recomputed from the
-    probes, the deterministic traces by pc_aux_sums -- against the oracle (pinned to the reference's CalcGradPars for these combinations at 8e-9)."""
+    probes, the deterministic traces by pc_aux_sums -- against the oracle (pinned to the reference's CalcGradPars for these combinations at 8e-9, DESIGN.md 4.6;
+    lognormal x pivoted_cholesky: value 1e-15, gradient 2.5e-12 of its scale in a one-off run of the unmodified reference, same section)."""
     from gpboost_amd import shim
-    tc = cases.LAPLACE_T_CASES["t_n1500"]
+    tc = cases.LAPLACE_T_CASES[case]
+    lik = tc.get("lik", "t")
     c = cases.LAPLACE_CASES[tc["model"]]
     coords, y = cases.make_t_data(tc)
     perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     st = shim.VecchiaState(co, c["m"])
     st.set_neighbors(nn)
-    st.laplace_set_likelihood("t")
+    st.laplace_set_likelihood(lik)
     st.laplace_set_response_real(y[perm])
     st.laplace_set_aux(tc["aux"])
     st.laplace_set_preconditioner(pcn, rank)
@@ -127,8 +137,8 @@ def test_auxiliary_gradient_with_the_low_rank_preconditioners(gpb, orc, pcn, ran
     nll, grad = st.laplace_eval_grad(ct, cp[0], a, **cases.LAPLACE_TIGHT)
     ctx = orc.fitc_preconditioner(co, ip, ct, cp[0], a) if pcn == "fitc" else orc.pivoted_cholesky_preconditioner(co, ct, cp[0], a, rank=rank)
     with ctx:
-        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood="t", aux=tc["aux"], **TIGHT_ORC)
+        on, og = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=lik, aux=tc["aux"], **TIGHT_ORC)
     assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
-    assert grad.shape == (4,)
+    assert grad.shape == (2 + len(tc["aux"]),)
     np.testing.assert_allclose(grad, og, rtol=1e-8, atol=3e-8 * np.abs(og).max())
     st.close()
