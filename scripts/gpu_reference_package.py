@@ -134,4 +134,18 @@ for k5 in ref5:
     else: assert np.allclose(x5, y5, rtol=1e-6, atol=1e-8), (k5, x5, y5)
 print("round5_widening through the package: t fit cov pars %s, (scale, df) %s, %d iterations; beta fit (pivoted_cholesky) cov pars %s, precision %s -- equal to the reference library's" %
       (ours5["t_cov_pars"], ours5["t_aux"], ours5["num_it"], ours5["flat_beta_cov_pars"], ours5["flat_beta_aux"]), flush=True)
+# ... and the lognormal likelihood (fourth slice): scenario round5_lognormal against tests/golden/route_a_round5_lognormal_ref.json (the same driver on oracle/_ref/lib_gpboost_ref.so)
+r6 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "route_a_driver_gpu.py"), find_lib_path(), "round5_lognormal", ROOT], capture_output=True, text=True, cwd=ROOT)
+lines6 = [l for l in r6.stdout.splitlines() if l.startswith("RESULT ")]
+assert lines6, r6.stdout[-2000:] + r6.stderr[-3000:]
+ours6 = json.loads(lines6[-1][7:]); ref6 = json.load(open(os.path.join(ROOT, "tests", "golden", "route_a_round5_lognormal_ref.json")))
+assert sorted(ours6) == sorted(ref6)
+for k6 in ref6:
+    x6, y6 = np.asarray(ours6[k6], dtype=float), np.asarray(ref6[k6], dtype=float)
+    if k6 == "num_it": assert np.array_equal(x6, y6), (k6, x6, y6)
+    elif k6.startswith("stoch_"): assert np.allclose(x6, y6, rtol=0.2), k6
+    elif k6.startswith("stochm_"): assert np.allclose(x6, y6, rtol=5e-3), k6
+    else: assert np.allclose(x6, y6, rtol=1e-6, atol=1e-8), (k6, x6, y6)
+print("round5_lognormal through the package: fit cov pars %s, log-variance %s, %d iterations, negll %.8f; evaluation with pivoted_cholesky %.8f -- equal to the reference library's" %
+      (ours6["ln_cov_pars"], ours6["ln_aux"], ours6["num_it"], ours6["ln_nll"], ours6["ln_nll_eval_pivchol"]), flush=True)
 print("REFERENCE PACKAGE ON MI355X: OK", flush=True)

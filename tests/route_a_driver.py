@@ -177,7 +177,7 @@ elif sc == "round5_lognormal":
     out["ln_cov_pars"] = L(m.get_cov_pars()); out["ln_aux"] = L(m.get_aux_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["ln_nll"] = float(m.get_current_neg_log_likelihood())
     cp = rng.uniform(size=(9, 2))
     p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=True)
-    out["stochm_ln_resp_mu"] = L(p["mu"])      # exp(m + v / 2): carries the reference's random-vector estimate of v; out["stoch_ln_resp_var"] = L(p["var"])
+    out["stochm_ln_resp_mu"] = L(p["mu"]); out["stoch_ln_resp_var"] = L(p["var"])      # (the mean exp(m + v / 2) carries the reference's random-vector estimate of v)
     p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
     out["ln_latent_mu"] = L(p["mu"]); out["stoch_ln_latent_var"] = L(p["var"])
     m2 = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="lognormal", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)

@@ -165,6 +165,26 @@ elif sc == "round5_widening":
     out["flat_beta_cov_pars"] = L(mb.get_cov_pars()); out["flat_beta_aux"] = L(mb.get_aux_pars()); out["beta_num_it"] = [int(mb._get_num_optim_iter())]; out["beta_nll"] = float(mb.get_current_neg_log_likelihood())
     p = mb.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
     out["flat_beta_latent_mu"] = L(p["mu"]); out["stoch_beta_latent_var"] = L(p["var"])
+elif sc == "round5_lognormal":
+    # round 5, fourth slice: the lognormal likelihood through the package (one auxiliary parameter "log_variance": moment start, lbfgs fit, response mean exp(m + v / 2) and
+    # its variance), an evaluation with the pivoted_cholesky preconditioner at given parameters
+    # (fits with covariates AND auxiliary parameters are not built in this library's host code -- DESIGN.md 4.6 -- so the scenario has none)
+    n = 600
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    yl = np.exp(lat - 0.1 + np.sqrt(0.2) * rng.normal(size=n))
+    m = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="lognormal", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m.fit(y=yl, params=dict(tight))
+    out["ln_cov_pars"] = L(m.get_cov_pars()); out["ln_aux"] = L(m.get_aux_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["ln_nll"] = float(m.get_current_neg_log_likelihood())
+    cp = rng.uniform(size=(9, 2))
+    p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=True)
+    out["stochm_ln_resp_mu"] = L(p["mu"]); out["stoch_ln_resp_var"] = L(p["var"])      # (the mean exp(m + v / 2) carries the reference's random-vector estimate of v)
+    p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=False)
+    out["ln_latent_mu"] = L(p["mu"]); out["stoch_ln_latent_var"] = L(p["var"])
+    m2 = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="lognormal", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    m2.set_optim_params(params=dict(tight, cg_preconditioner_type="pivoted_cholesky", fitc_piv_chol_preconditioner_rank=40))
+    out["ln_nll_eval_pivchol"] = float(m2.neg_log_likelihood(cov_pars=np.array([0.6, 0.2]), y=yl, aux_pars=np.array([0.3])))
 elif sc == "gauss_covariates":
     n = 500
     coords = rng.uniform(size=(n, 2))
