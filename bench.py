@@ -32,8 +32,8 @@ if ROOT not in sys.path:
 # before comparing with a byte count"; other access widths are uncalibrated.  So: the histogram's row stream (64 B per lane) gets the
 # x2 (`fetch_factor` 2), the point kernel's 32-byte gathers are reported as counted (factor 1, stated).  None when no summary is there.
 # counters of the newest committed PMC evidence set (scripts/profile_r04.sh -> profiles/r04_pmc.json; the round-3 set as the fallback)
-PMC_JSON = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json")) if os.path.exists(q)),
-                os.path.join(ROOT, "profiles", "r05_pmc.json"))
+PMC_JSON = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json")) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r06_pmc.json"))
 PMC_NAME = "profiles/" + os.path.basename(PMC_JSON)
 
 
@@ -328,9 +328,11 @@ def main():
         if world > 1 and not native_rccl and not use_mailbox and os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
             raise RuntimeError("bench.py --gpus %d: neither the in-library RCCL communicator nor the mailbox came up on every rank (see stderr); "
                                "GPB_BENCH_TORCH_ALLREDUCE=1 selects the torch.distributed fallback explicitly" % world)
-        if world > 1 and not native_rccl and not rehearsal and rank == 0:
-            print("bench.py --gpus %d: WARNING -- the in-library RCCL communicator did not come up (rccl_ranks = 0 in the line); the shard sums travel "
-                  "through the mailbox, which does not need it" % world, file=sys.stderr)
+        # A real multi-device launch must have the in-library RCCL communicator up on every rank: it carries the big messages of the N > 1
+        # path and is the A/B transport of the sums -- a line with rccl_ranks != N is not the job that was asked for.  GPB_BENCH_ALLOW_NO_RCCL=1 lifts it.
+        if world > 1 and not native_rccl and not rehearsal and os.environ.get("GPB_BENCH_ALLOW_NO_RCCL", "0") != "1" and os.environ.get("GPB_BENCH_TORCH_ALLREDUCE", "0") != "1":
+            raise RuntimeError("bench.py --gpus %d: the in-library RCCL communicator did not come up on every rank (see stderr): no line is printed with "
+                               "rccl_ranks != %d (GPB_BENCH_ALLOW_NO_RCCL=1 prints the mailbox-only job anyway)" % (world, world))
         if rehearsal and not use_mailbox:
             raise RuntimeError("bench.py --gpus %d (rehearsal): the mailbox did not come up on every rank (see stderr)" % world)
     else:
@@ -468,7 +470,9 @@ def main():
     achieved_gbs = bytes_launch / (ms_kernel * 1e-3) / 1e9
     achieved_tflops = flops_launch / (ms_kernel * 1e-3) / 1e12
 
-    traffic = profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0, false>" % (m, ct, "true" if d == 3 else "false"), source_file="vecchia_kernels.hip")       # <MT, COV, D3, MODE_NLL, WT = no sample weights> if (n, world) == (1000000, 1) else None
+    # <MT, COV, D3, MODE_NLL, WT = no sample weights>; the PMC passes were collected at n = 1e6 on one GPU: no figure for any other launch
+    traffic = (profiled_traffic_bytes("vecchia_point_kernel<%d, %d, %s, 0, false>" % (m, ct, "true" if d == 3 else "false"), source_file="vecchia_kernels.hip")
+               if (n, world) == (1000000, 1) else None)
     rccl_ranks = st.comm_info()[1] if native_rccl else 0
     mailbox_ranks = st.mailbox_info()[1] if use_mailbox else 0
     # per-rank view (N > 1): every rank's in-loop kernel time and shard size -- min / max over the ranks is the skew the N = 8 budget of DESIGN.md
@@ -589,7 +593,7 @@ def main():
                     "bound": "hbm", "kernel": "hist_build_rows_kernel + hist_reduce_kernel", "achieved": hbytes / (ms_h * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbytes / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms_h,
                     "algorithmic_bytes_per_launch": hbytes, "traffic": profiled_traffic_bytes("hist_build_rows_kernel<false", fetch_factor=2.0, source_file="hist_kernels.hip"),
-                    "traffic_source": PMC_NAME + ": 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced streams); rows are padded to 64 bytes for F = 50 (28 % more bin bytes than the algorithmic count)",
+                    "traffic_source": PMC_NAME + ": 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced streams); round 6: the root pass streams the COMPACT copy of the rows (52 bytes per row at F = 50; the padded 64-byte rows cost 1.24x the algorithmic bytes)",
                     "workload": "root-leaf histogram, n=%d rows, F=%d features, %d bins, constant hessian (counts exact)" % (nh, Fh, nbh),
                     "note": "fixed-point sums (one 64-bit LDS atomic per row and feature, count packed in, bank-conflict-free layout, a whole "
                             "64-byte row per lane): bit-reproducible, counts exact; see DESIGN.md 4.4"}
@@ -629,7 +633,7 @@ def main():
                         "algorithmic_bytes_per_iteration": byt, "ms_per_iteration": ms, "achieved": byt / (ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})(
                         4 * n4 * (30 * 16 + 16) + 10 * n4 * 8 * 52, i4["ms_logdet"] / max(i4["lanczos_it"], 1)),
-                    "reference_timing": "not timed here: tests/golden/config4_ref.npz holds the unmodified reference's value and its wall time for the same-size fixture (seconds_0; 8 cores of the build container)"}
+                    }
                 # round 5: the same evaluation with the reference's other built preconditioners, cg_preconditioner_type = "pivoted_cholesky" (rank 50) / "fitc" (200 inducing points): the solves in the
                 # (W^-1 + Sigma) form, fewer (latency-bound) iterations -- another algorithm of the reference, not a faster kernel
                 for pcname in ("pivoted_cholesky", "fitc"):
@@ -671,8 +675,7 @@ def main():
                 sgv = (time.perf_counter() - tv2) / 3
                 out["vif_full_scale_vecchia"] = {
                     "workload": "Gaussian nll, gp_approx=full_scale_vecchia, n=%d, d=2, exponential, m=30, 200 inducing points (kmeans++ start on the host, Lloyd iterations on the device)" % nv,
-                    "s_per_eval": sv, "s_per_eval_with_analytic_gradient": sgv, "negll": vv, "setup_s_incl_kmeans_and_device_neighbor_search": round(tv_setup, 3),
-                    "reference_timing": "tests/golden/vif_ref.npz was generated by the unmodified reference at this size: 1.8 s per evaluation on 8 threads of the build container (oracle/make_golden.py vif)"}
+                    "s_per_eval": sv, "s_per_eval_with_analytic_gradient": sgv, "negll": vv, "setup_s_incl_kmeans_and_device_neighbor_search": round(tv_setup, 3)}
                 del mv
             except Exception as e:
                 out["vif_full_scale_vecchia"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -690,8 +693,7 @@ def main():
                     "workload": "GPB_OptimCovPar, lbfgs (reference default), n=%d, m=%d, %s: the bench model, y = sin(4 x0) + 0.5 eps" % (n, m, args.cov),
                     "s_per_fit": sf, "num_it": mdl.get_num_optim_iter(), "launches_likelihood_only": oi["num_ll_evals"],
                     "launches_with_gradient": oi["num_grad_evals"], "cov_pars": [float(v) for v in mdl.get_cov_pars()],
-                    "negll": mdl.get_current_neg_log_likelihood(),
-                    "reference": "DESIGN.md 4.10: unmodified reference, same data recipe at n=1e5, this repo's build container"}
+                    "negll": mdl.get_current_neg_log_likelihood()}
             except Exception as e:
                 out["fit_covariance_parameters"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extras:
@@ -736,14 +738,70 @@ def main():
                 out["config3_boosting_iteration"] = dict(
                     workload="GPBoost boosting loop as BASELINE config 3 writes it: %d trees, n=%d, F=%d, %d bins, %d leaves, Vecchia m=30 -- natively through this library's C ABI "
                              "(synthetic equal-width bins in the reference's layout); the *_ms entries are the LAST iteration's" % (R3, n3, F3, nb3, L3),
-                    config3_100_trees_s=round(t_all, 4), ms_per_iteration_mean=round(t_all / R3 * 1e3, 3),
-                    route_b="the same loop through the reference's own Booster / REModel host code (GPU_use = true): profiles/r05_e_config3_100_trees_routeB_and_native.log "
-                            "(scripts/gpu_config3.py: 1.27 s for the 100 iterations, ensemble predictions of the first 4 trees equal to GPU_use = false to 4e-14; "
-                            "the reference's CPU path: 9.3 s per iteration on that box)",
-                    reference_timing="CPU path of the reference on the bench box: scripts/gpu_config3.py times 4 iterations of it (GPU_use = false)", **{k: round(v, 3) for k, v in t3.items()})
+                    config3_100_trees_s=round(t_all, 4), ms_per_iteration_mean=round(t_all / R3 * 1e3, 3), **{k: round(v, 3) for k, v in t3.items()})
                 hb3.close(); del m3
+                # Route B, TIMED HERE (no quoted numbers): the same 100 iterations through the reference's own Booster / GBDT / REModel host code
+                # (integration/_build/lib_gpboost_hip.so; integration/routeb_driver.py) with GPU_use = true, once with the reference's CPU tree learner and once with
+                # device_type = gpu (whole trees on the device too), and ONE iteration of the same build's CPU path (GPU_use = false) beside them.
+                try:
+                    from integration import routeb_driver as rbd
+                    if not rbd.available():
+                        out["config3_boosting_iteration"]["route_b"] = {"skipped": "integration/_build/lib_gpboost_hip.so is not built on this box (make -C oracle routeB needs /root/reference)"}
+                    else:
+                        rb = rbd.RouteB()
+                        y3b = y3 + np.sin(5 * c3[:, 0]) * np.cos(4 * c3[:, 1])
+                        ra = rb.boosting_loop(c3, X3, y3b, R3, gpu_use=True, device_trees=False)
+                        rt = rb.boosting_loop(c3, X3, y3b, R3, gpu_use=True, device_trees=True)
+                        rc = rb.boosting_loop(c3, X3, y3b, 1, gpu_use=False, device_trees=False)
+                        out["config3_boosting_iteration"]["route_b"] = {
+                            "workload": "the same configuration through the reference's own Booster (LGBM_BoosterUpdateOneIter x %d, its own bin mappers), measured in this run" % R3,
+                            "gpu_use_true_100_trees_s": round(ra["loop_s"], 4), "gpu_use_true_ms_per_iteration_median": round(1e3 * float(np.median(ra["per_iteration_s"])), 3),
+                            "gpu_use_true_device_trees_100_trees_s": round(rt["loop_s"], 4), "gpu_use_true_device_trees_ms_per_iteration_median": round(1e3 * float(np.median(rt["per_iteration_s"])), 3),
+                            "setup_s": round(ra["setup_s"], 3), "device_trees_vs_host_trees_max_abs_prediction_diff": float(np.abs(rt["pred"] - ra["pred"]).max()),
+                            "cpu_path_same_build_s_first_iteration": round(rc["loop_s"], 3),
+                            "cpu_path_note": "GPU_use = false, device_type = cpu of the same library: ONE boosting iteration (its first; the loop is not run to 100 on the CPU here)"}
+                except Exception as e:
+                    out["config3_boosting_iteration"]["route_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
             except Exception as e:
                 out["config3_boosting_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_extras:
+            # shard_sweep (VERDICT r05 #1 iv / #11): each of the 8 shards an 8-rank job evaluates (parallel.shard_range), run ALONE on this one device -- point-kernel
+            # time by HIP events and the wall time of one synchronous evaluation of the shard (launch + in-launch sums + pinned-memory hand-over).  A ONE-DEVICE
+            # PROJECTION of the per-rank work of an N = 8 launch (later shards do the same arithmetic on a different gather footprint), never a scaling number.
+            def sweep(state, cti, vv, aa, nn_pts, label):
+                rows = []
+                for r8 in range(8):
+                    j0, j1 = parallel.shard_range(nn_pts, r8, 8)
+                    state.set_shard(j0, j1)
+                    _, kms, _ = state.bench(shim.MODE_NLL, cti, vv, aa, 3, 20)
+                    _, gms, _ = state.bench(shim.MODE_GRAD, cti, vv, aa, 2, 10)
+                    for _w in range(3):
+                        state.nll_terms(cti, vv, aa)
+                    tw = time.perf_counter()
+                    for kk in range(20):
+                        state.nll_terms(cti, vv * (1. + 1e-3 * kk), aa)
+                    rows.append({"rank": r8, "points": j1 - j0, "nll_kernel_ms": round(kms, 5), "grad_kernel_ms": round(gms, 5),
+                                 "nll_step_ms_synchronous": round((time.perf_counter() - tw) / 20 * 1e3, 5)})
+                state.set_shard(0, nn_pts)
+                _, kfull, _ = state.bench(shim.MODE_NLL, cti, vv, aa, 3, 20)
+                ks = [r_["nll_kernel_ms"] for r_ in rows]; ss = [r_["nll_step_ms_synchronous"] for r_ in rows]
+                return {"workload": label, "label": "ONE-DEVICE PROJECTION: every shard of an 8-rank job run alone on this GPU; not a scaling measurement",
+                        "shards": rows, "one_launch_all_points_kernel_ms": round(kfull, 5), "slowest_shard_kernel_ms": max(ks), "slowest_shard_step_ms": max(ss),
+                        "projected_speedup_8_ranks_kernel_only": round(kfull / max(ks), 3),
+                        "projected_speedup_8_ranks_step": round((dt / args.steps * 1e3) / max(ss), 3) if (n, m, d) == (nn_pts, state.m, state.d) else None}
+            try:
+                out["shard_sweep"] = {"metric_shape": sweep(st, ct, var0, a0, n, "n=%d, d=%d, %s, m=%d" % (n, d, args.cov, m))}
+                if (n, d, m, args.cov) == (1000000, 2, 30, "exponential"):
+                    rng5 = np.random.default_rng(1)
+                    c5 = rng5.uniform(size=(1000000, 3)); y5 = rng5.standard_normal(1000000)
+                    m5 = gpboost_amd.GPModel(gp_coords=c5, cov_function="matern", cov_fct_shape=2.5, gp_approx="vecchia", num_neighbors=40, vecchia_ordering="random", seed=1)
+                    for _w in range(3):
+                        m5.neg_log_likelihood(cov_pars, y5 if _w == 0 else None)        # y resident; third evaluation: the spatially sorted gather copy
+                    st5 = shim.VecchiaState.from_handle(m5.vecchia_handle(), 1000000, 3, 40)
+                    out["shard_sweep"]["config5_shape"] = sweep(st5, 2, var0, np.sqrt(5.0) / cov_pars[2], 1000000, "BASELINE config 5: n=1e6, d=3, Matern-2.5, m=40")
+                    del m5
+            except Exception as e:
+                out["shard_sweep"] = dict(out.get("shard_sweep", {}), error="%s: %s" % (type(e).__name__, e))
         if world == 1 and not args.no_cpu_baseline:
             # (1) the reference's CPU path on the host cores with the GPU IDLE (round 3 timed it beside a loop that drove the GPU flat out)
             try:

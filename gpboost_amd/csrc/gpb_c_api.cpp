@@ -369,6 +369,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
     mdl->y_set = true;
     return laplace_upload_fixed_effects(mdl, fixed_effects);
   }
+  mdl->resp_real.clear();      // integer / binary responses live in `labels` (GPB_GetResponseData tells the two apart by this)
   for (int k = 0; k < mdl->n; ++k) {
     const double yk = y_data[mdl->perm[k]];
     if (poisson) {                                        // likelihoods.h:1338-1350
@@ -1266,7 +1267,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
                       const char* cov_fct, double cov_fct_shape, const char* gp_approx, double /*cov_fct_taper_range*/,
                       double /*cov_fct_taper_shape*/, int num_neighbors, const char* vecchia_ordering,
                       int num_ind_points, double /*cover_tree_radius*/, const char* ind_points_selection,
-                      const char* likelihood, double /*likelihood_additional_param*/,
+                      const char* likelihood, double likelihood_additional_param,
                       const char* matrix_inversion_method, int seed, int /*num_parallel_threads*/, bool /*GPU_use*/,
                       bool has_weights, const double* weights, double /*likelihood_learning_rate*/,
                       REModelHandle* out) {
@@ -1305,6 +1306,13 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   }
   const std::string lik_name = parse_likelihood_alias(lik);
   if (lik_name != "gaussian" && !supported_non_gaussian(lik_name)) return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
+  // likelihood_additional_param (likelihoods.h:223, 391-399): -999 = "not given"; 't' reads its degrees of freedom from it (aux_pars_ = {1, df}); none of the
+  // other likelihoods on this path takes one ('tweedie_fixed_p', 'asymmetric_laplace' do in the reference and are not built) -- a value is refused, never dropped
+  const bool add_par_given = !near(likelihood_additional_param, -999.);
+  if (add_par_given && lik_name == "t" && likelihood_additional_param < 0.)
+    return set_error("The 'likelihood_additional_param' (df) is not > 0, found = %g ", likelihood_additional_param);      // likelihoods.h:394-396
+  if (add_par_given && lik_name != "t")
+    return set_error("GPB_CreateREModel: likelihood_additional_param = %g with likelihood '%s' %s", likelihood_additional_param, lik.c_str(), scope);
   if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
     if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
@@ -1331,6 +1339,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
 
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
   mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); if (lik_name == "lognormal") mdl->aux_pars[0] = 0.5;  /* likelihoods.h:506 */ mdl->num_neighbors = num_neighbors;
+  if (lik_name == "t" && add_par_given) mdl->aux_pars[1] = likelihood_additional_param;      // aux_pars_ = {1, additional_param} (likelihoods.h:397-399)
   if (has_weights && lik_name != "gaussian") mdl->lik_weights.assign(weights, weights + num_data);     // factors of the per-datum likelihood terms (likelihoods.h:666-668)
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
@@ -2910,7 +2919,7 @@ int GPB_GetResponseData(REModelHandle handle, double* response_data) {
   if (!mdl || !response_data) return set_error("GPB_GetResponseData: null argument");
   if (!mdl->y_set) return set_error("Respone variable data has not been set");      // re_model_template.h:6258-6261 (sic)
   if (mdl->likelihood == "gaussian") { std::copy(mdl->y_host.begin(), mdl->y_host.end(), response_data); }   // y_vec_: the response as passed in
-  else if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t" || mdl->likelihood == "lognormal") { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }
+  else if (!mdl->resp_real.empty()) { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = mdl->resp_real[k]; }      // real-valued responses: gamma / beta / t / lognormal and the proportions of binomial_* / quasi_bernoulli_* (laplace_upload_data)
   else { for (int k = 0; k < mdl->n; ++k) response_data[mdl->perm[k]] = (double)mdl->labels[k]; }
   C_API_END();
 }

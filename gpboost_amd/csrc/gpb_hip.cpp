@@ -389,6 +389,8 @@ struct gpb_hip_hist {
   std::vector<signed char> feature_mask;                   // columns the next trees may split on (empty: all)
   int* d_root_rows = nullptr; int root_cnt = 0;            // bagging: the rows of the root of the next trees (root_cnt = 0: all rows)
   uint8_t* d_bins_rm = nullptr;
+  uint8_t* d_bins_cm = nullptr; int rstride = 0;   // compact copy [n][rstride] for the streaming root pass (hist_kernels.h: HistKernelArgs::bins_cm); absent when F % 16 == 0
+  int hist_prefetch = 1;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
   bool has_hess = false, has_grad = false;
@@ -2382,6 +2384,20 @@ int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins, co
   HIP_OK(hipMemcpy(d_fm, bins, (size_t)n * num_features, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&h->d_bins_rm, (size_t)n * h->fpad));
   HIP_OK(gpb::launch_bins_transpose(d_fm, h->d_bins_rm, n, num_features, h->fpad, h->stream));
+  {
+    // the compact copy the whole-row kernel streams when it visits EVERY row (root pass of a tree / gpb_hip_hist_build without an index list): F rounded up to
+    // 4 bytes per row instead of fpad -- at F = 50: 52 instead of 64 (the padded rows were 1.24x the algorithmic bytes in the counters)
+    const int rs = ((num_features + 3) / 4) * 4;
+    const char* off = getenv("GPB_HIST_NO_COMPACT_ROWS");
+    if (rs < h->fpad && h->fpad / GPB_HIST_FG >= 4 && !(off && off[0] == '1')) {
+      HIP_OK(hipMalloc(&h->d_bins_cm, (size_t)n * rs + 16));
+      HIP_OK(hipMemsetAsync(h->d_bins_cm + (size_t)n * rs, 0, 16, h->stream));
+      HIP_OK(gpb::launch_bins_transpose(d_fm, h->d_bins_cm, n, num_features, h->fpad, h->stream, rs));
+      h->rstride = rs;
+    }
+    const char* pf = getenv("GPB_HIST_PREFETCH");
+    h->hist_prefetch = (pf && pf[0] == '1') ? 1 : ((pf && pf[0] == '2') ? 2 : 1);
+  }
   HIP_OK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_fm); d_fm = nullptr;
   HIP_OK(hipMalloc(&h->d_bin_offsets, sizeof(int) * (size_t)(num_features + 1)));
@@ -2436,7 +2452,7 @@ int gpb_hip_hist_free(gpb_hip_hist_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& q : h->pin) if (q.p) { (void)hipHostUnregister(const_cast<void*>(q.p)); q.p = nullptr; }
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  dev_free(h->d_bins_rm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
+  dev_free(h->d_bins_rm); dev_free(h->d_bins_cm); dev_free(h->d_bin_offsets); dev_free(h->d_grad); dev_free(h->d_hess); dev_free(h->d_idx);
   dev_free(h->d_part_grad); dev_free(h->d_part_hess); dev_free(h->d_part_cnt); dev_free(h->d_hist); dev_free(h->d_cnt); dev_free(h->d_absmax);
   dev_free(h->d_pool); dev_free(h->d_fix); dev_free(h->d_meta3); dev_free(h->d_part); dev_free(h->d_split); dev_free(h->d_split_i); dev_free(h->d_used);
   dev_free(h->d_tree_red); dev_free(h->d_rows); dev_free(h->d_rows2); dev_free(h->d_counts); dev_free(h->d_root_rows);
@@ -2620,6 +2636,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   a.grad_max_bits = h->d_absmax; a.hess_max_bits = h->d_absmax + 1;
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks; a.num_features = h->F;
   a.use_rows_kernel = rows_kernel ? 1 : 0;
+  a.bins_cm = h->d_bins_cm; a.rstride = h->rstride; a.prefetch = h->hist_prefetch;
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
   r.grad_max_bits = h->d_absmax; r.hess_max_bits = h->d_absmax + 1;

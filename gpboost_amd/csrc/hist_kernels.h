@@ -10,6 +10,10 @@ namespace gpb {
 
 struct HistKernelArgs {
   const uint8_t* bins_rm;   // [n][fpad] row-major bins, fpad = multiple of 16
+  // round 6: a second, COMPACT copy [n][rstride] (rstride = F rounded up to 4 bytes; + 16 bytes of slack behind the last row) for the passes that STREAM every
+  // row (no index list): the 64-byte padded rows cost 28 % more HBM bytes than the algorithmic count at F = 50 (counter traffic 1.24x).  Gathered
+  // leaves keep the padded copy: a 64-byte-aligned row is ONE sector, a 52-byte row straddles two.  nullptr / 0: only the padded copy exists (F % 16 == 0).
+  const uint8_t* bins_cm = nullptr; int rstride = 0;
   const int* data_indices;  // leaf rows or nullptr
   const double* grad;       // [n]
   const double* hess;       // [n] or nullptr (constant hessian)
@@ -23,6 +27,7 @@ struct HistKernelArgs {
   // tree grower: when seg_counts != nullptr the rows are the SMALLER child of the split of the segment (seg_begin, seg_cnt) of
   // data_indices whose left counts {this rank, all ranks} sit in seg_counts (device memory); num_data / rows_per_chunk are ignored
   int quad0 = 0;            // hist_build_rows_kernel: first quad of feature groups of this launch
+  int prefetch = 1;         // hist_build_rows_kernel without an index list: blocks of rows in flight ahead of the one being accumulated (1 or 2)
   int use_rows_kernel = 0;  // hist_build_rows_kernel (constant hessian, >= 4 feature groups): set by the host with a chunking of one workgroup per CU
   const int* seg_counts = nullptr;
   int seg_begin = 0, seg_cnt = 0, seg_gcnt = 0, seg_min_data_in_leaf = 0;
@@ -104,6 +109,6 @@ hipError_t launch_hist_children_search(const ChildrenSearchArgs& a, hipStream_t 
 hipError_t launch_hist_label_rows(const int* rows0, const int* rows1, int n, const int* seg_begin, const int* seg_leaf, const int* seg_buf, int nseg,
                                   int* out, hipStream_t st);
 hipError_t launch_hist_subtract(const double* parent, const double* smaller, double* out, int len, hipStream_t st);
-hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st);
+hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st, int row_stride = 0);   // row_stride > 0: compact rows of that many bytes
 
 }  // namespace gpb

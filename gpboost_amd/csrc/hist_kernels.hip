@@ -219,7 +219,9 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // sub-histogram blocks (128 KB of LDS: one workgroup of 512 lanes per CU): the per-row work is paid once per 64 features, what remains
 // is the LDS atomic rate.  Same words, same drains (every 3 iterations = 1536 rows <= 1792), same partial layout as hist_build_kernel.
 // Constant hessian only: per-row hessians stay on hist_build_kernel (the two-word whole-row form was slower).
-template <bool HAS_IDX, int NBK>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block
+// 16 bytes of a row from a 4-byte-aligned address (compact rows: stride F rounded up to 4): ONE global_load_dwordx4 -- the hardware needs dword alignment only
+struct __attribute__((packed, aligned(4))) RowQuad { unsigned x, y, z, w; };
+template <bool HAS_IDX, int NBK, int PF = 1>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block; PF = row blocks in flight ahead of the one being accumulated
 __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
   // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
   constexpr int THREADS = 512, NB = 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
@@ -246,15 +248,22 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
   __syncthreads();
   const int r0 = chunk * a.rows_per_chunk;
   const int r1 = min(r0 + a.rows_per_chunk, a.num_data);
-  const uint8_t* base = a.bins_rm + (size_t)quad * NB * GPB_HIST_FG;
+  // streaming passes (no index list) read the COMPACT copy when there is one: rows of rstride bytes, 4-byte aligned; a block's 16-byte load may run up to 12
+  // bytes into the next row (the last row has 16 bytes of slack behind it) -- those bytes belong to features >= num_features, which are never accumulated
+  const bool compact = !HAS_IDX && a.bins_cm != nullptr;
+  const uint8_t* base = (compact ? a.bins_cm : a.bins_rm) + (size_t)quad * NB * GPB_HIST_FG;
+  const size_t rbytes = compact ? (size_t)a.rstride : (size_t)a.fpad;
   constexpr int nblk = NBK;                           // (compile-time: a run-time bound in the unrolled block loop cost 25 %)
   struct RowData { uint4 bv[NB]; double g; };
   auto fetch = [&](int r) -> RowData {
     RowData d;
     const int row = HAS_IDX ? a.data_indices[r] : r;
-    const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)row * a.fpad);
+    const RowQuad* p = reinterpret_cast<const RowQuad*>(base + (size_t)row * rbytes);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) d.bv[b] = b < nblk ? p[b] : make_uint4(0u, 0u, 0u, 0u);      // never read past the row's fpad bytes
+    for (int b = 0; b < NB; ++b) {
+      if (b < nblk) { const RowQuad q = p[b]; d.bv[b] = make_uint4(q.x, q.y, q.z, q.w); }
+      else d.bv[b] = make_uint4(0u, 0u, 0u, 0u);      // never read past the row's fpad bytes
+    }
     d.g = a.grad[row];
     return d;
   };
@@ -295,14 +304,27 @@ __global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) 
   const int nrows = max(r1 - r0, 0), nfull = nrows / THREADS;
   if (nrows > 0) {
     int since_flush = 0;
-    RowData cur = fetch(min(r0 + tid, r1 - 1));
-    for (int it = 0; it < nfull; ++it) {
-      const RowData nxt = fetch(min(r0 + (it + 1) * THREADS + tid, r1 - 1));
-      accumulate(cur);
-      cur = nxt;
-      if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
+    if constexpr (PF == 1) {
+      RowData cur = fetch(min(r0 + tid, r1 - 1));
+      for (int it = 0; it < nfull; ++it) {
+        const RowData nxt = fetch(min(r0 + (it + 1) * THREADS + tid, r1 - 1));
+        accumulate(cur);
+        cur = nxt;
+        if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
+      }
+      if (r0 + nfull * THREADS + tid < r1) accumulate(cur);
+    } else {
+      // PF = 2 (round 6): TWO blocks of rows in flight ahead of the one being accumulated -- one 512-lane workgroup per CU keeps 8 wavefronts x 64 rows x 72 bytes
+      // = 36 KB per block in flight; at ~2 us of loaded HBM latency one block ahead bounds a CU at ~18 GB/s (x 256 CUs = 4.6 TB/s), two lift that bound
+      RowData q0 = fetch(min(r0 + tid, r1 - 1)), q1 = fetch(min(r0 + THREADS + tid, r1 - 1));
+      for (int it = 0; it < nfull; ++it) {
+        const RowData nxt = fetch(min(r0 + (it + 2) * THREADS + tid, r1 - 1));
+        accumulate(q0);
+        q0 = q1; q1 = nxt;
+        if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
+      }
+      if (r0 + nfull * THREADS + tid < r1) accumulate(q0);
     }
-    if (r0 + nfull * THREADS + tid < r1) accumulate(cur);
   }
   flush();
   // word w of block b -> partial (chunk, group 4 quad + b, word w): the layout of hist_build_kernel's partials
@@ -509,7 +531,7 @@ hipError_t launch_hist_absmax(const double* v, int n, unsigned long long* out_bi
 }
 
 // feature-major [F][n] -> row-major [n][fpad] (padding features read as bin 0 and are never reduced)
-__global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* __restrict__ rm, int n, int F, int fpad) {
+__global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* __restrict__ rm, int n, int F, int fpad, int ncols) {   // fpad = row stride in bytes, ncols = bytes of a row that exist
   __shared__ uint8_t tile[16][64 + 4];
   const int f0 = blockIdx.y * 16, i0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
@@ -521,7 +543,7 @@ __global__ void bins_transpose_kernel(const uint8_t* __restrict__ fm, uint8_t* _
   const int ff = threadIdx.x & 15, ii = threadIdx.x >> 4;    // 16 x 16
   for (int k = ii; k < 64; k += 16) {
     const int i = i0 + k;
-    if (i < n) rm[(size_t)i * fpad + f0 + ff] = tile[ff][k];
+    if (i < n && f0 + ff < ncols) rm[(size_t)i * fpad + f0 + ff] = tile[ff][k];
   }
 }
 
@@ -567,7 +589,7 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
     };
     const int groups = a.fpad / GPB_HIST_FG, full = groups / 4, rest = groups % 4;
     hipError_t e = hipSuccess;
-    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0);
+    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : (a.prefetch == 2 ? go(hist_build_rows_kernel<false, 4, 2>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0));
     if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1>, 1, full) : go(hist_build_rows_kernel<false, 1>, 1, full);
     if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2>, 1, full) : go(hist_build_rows_kernel<false, 2>, 1, full);
     if (e == hipSuccess && rest == 3) e = a.data_indices ? go(hist_build_rows_kernel<true, 3>, 1, full) : go(hist_build_rows_kernel<false, 3>, 1, full);
@@ -583,8 +605,9 @@ hipError_t launch_hist_reduce(const HistReduceArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL(hist_reduce_kernel<false>, grid, dim3(1024), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st) {
-  hipLaunchKernelGGL(bins_transpose_kernel, dim3((n + 63) / 64, fpad / 16), dim3(256), 0, st, bins_fm, bins_rm, n, F, fpad);
+hipError_t launch_bins_transpose(const uint8_t* bins_fm, uint8_t* bins_rm, int n, int F, int fpad, hipStream_t st, int row_stride) {
+  const int stride = row_stride > 0 ? row_stride : fpad;
+  hipLaunchKernelGGL(bins_transpose_kernel, dim3((n + 63) / 64, fpad / 16), dim3(256), 0, st, bins_fm, bins_rm, n, F, stride, stride);
   return hipGetLastError();
 }
 

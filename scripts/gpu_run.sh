@@ -57,6 +57,24 @@ for STEP in "$@"; do
                python scripts/summarize_prof.py pmc-json $O/pmc.json $O/pmc[0-9]
                grep -i "vecchia_point\|hist_build\|hist_reduce\|syrk_mfma\|dense_cov" $O/pmc_summary.txt | cut -c1-260 | head -40
                rm -rf $O/pmc[0-9] ;;
+    tracepy)   # rocprofv3 --kernel-trace --stats around a python script of scripts/ (round 6: the round-5 kernels that had no trace)  -> <name>_rocprofv3_summary.txt, <name>.log
+               NAME=${REST%%:*}; ARGS=${REST#*:}
+               R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_$NAME -- python $R/scripts/$ARGS > $R/$O/$NAME.log 2> $R/$O/trace_$NAME.err)
+               python scripts/summarize_prof.py trace $O/trace_$NAME > $O/${NAME}_rocprofv3_summary.txt 2>&1; show $O/$NAME.log 4 400; head -14 $O/${NAME}_rocprofv3_summary.txt | cut -c1-230; rm -rf $O/trace_$NAME ;;
+    pmcpy)     # the PMC passes (each its own run, no trace domain) over a python script of scripts/  -> <name>_pmc_summary.txt
+               NAME=${REST%%:*}; ARGS=${REST#*:}
+               R=$PWD; i=0
+               for C in "FETCH_SIZE" "WRITE_SIZE" \
+                        "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
+                        "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES"; do
+                 i=$((i+1))
+                 (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $R/$O/pmcpy$i -- python $R/scripts/$ARGS > $R/$O/pmcpy$i.log 2> $R/$O/pmcpy$i.err) || echo "pmc pass $i ($C) failed: $(tail -2 $O/pmcpy$i.err)"
+               done
+               python scripts/summarize_prof.py pmc $O/pmcpy[0-9] > $O/${NAME}_pmc_summary.txt
+               head -24 $O/${NAME}_pmc_summary.txt | cut -c1-260
+               rm -rf $O/pmcpy[0-9] $O/pmcpy[0-9].log ;;
+    env)       # env:<VAR=VALUE>: exported for the steps after it
+               export "$REST"; echo "exported $REST" ;;
     *)         echo "unknown step $STEP" ;;
   esac
 done

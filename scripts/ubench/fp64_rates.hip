@@ -27,6 +27,10 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc) {
       if (KIND == 6) asm volatile("v_rsq_f64 %0, %1" : "=v"(a[i]) : "v"(b));
       if (KIND == 7) asm volatile("v_ldexp_f64 %0, %1, 3" : "=v"(a[i]) : "v"(b));
       if (KIND == 8) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(((int*)&a[i])[0]) : "v"(((int*)&b)[0]), "v"(((int*)&c)[0]) : );
+      // round 6 (the "two points per DPP row" question): a DPP fmac that writes only HALF of every 16-lane row (bank_mask 0x3 = lanes 0..7) -- does a
+      // half-row instruction cost half an issue slot?  (If not, two points sharing a row need two instructions per (column, pivot): one per point's broadcast.)
+      if (KIND == 9) asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:3 row_mask:0xf bank_mask:0x3" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (KIND == 10) asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:3 row_mask:0x3 bank_mask:0xf" : "+v"(a[i]) : "v"(b), "v"(c));
     }
   }
   long long t1 = __builtin_readcyclecounter();
@@ -69,6 +73,8 @@ int main() {
     run<6>("v_rsq_f64", w);
     run<7>("v_ldexp_f64", w);
     run<8>("v_cndmask_b32", w);
+    run<9>("v_fmac_f64_dpp bank_mask:0x3 (half rows)", w);
+    run<10>("v_fmac_f64_dpp row_mask:0x3 (two of four rows)", w);
   }
   return 0;
 }

@@ -72,6 +72,52 @@ def test_gaussian_configs_at_baseline_size(gpb, orc, name):
     np.testing.assert_allclose(grad, grad_o, rtol=RTOL, atol=RTOL * np.abs(grad_o).max())
 
 
+@pytest.mark.parametrize("name", ["config5_n1e6_d3_mat25_m40", "metric_n1e6_exp_m30"])
+def test_eight_shards_summed_in_rank_order_equal_the_reference(gpb, orc, name):
+    """BASELINE config 5 AS WRITTEN ("points sharded across 8 x MI355X with all-reduce") and the metric's N = 8 case, value parity: the
+    eight contiguous shards of the Vecchia ordering (parallel.shard_range -- what rank r of an 8-rank job evaluates, gpb_hip_vecchia_set_shard) are evaluated one
+    after the other on this device, their 7 sums are added IN RANK ORDER (what the mailbox / the all-reduce does), and likelihood and gradient formed from the
+    total (re_model_template.h:3132, :1994-2004) are held to the unmodified reference's values at 1e-8 (tests/golden/atsize_ref.npz: *_nll, *_grad).
+    The likelihood-only launch (3 sums) of every shard is checked the same way."""
+    from gpboost_amd import shim, parallel
+    n, d, m, cf, sh, cp = ATSIZE[name]
+    cp = np.asarray(cp, dtype=np.float64)
+    g = np.load(os.path.join(GOLD, "atsize_ref.npz"))
+    coords, y = cases.synthetic(n, d, seed=1)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=cf, cov_fct_shape=sh, gp_approx="vecchia", num_neighbors=m,
+                      vecchia_ordering="random", seed=1)
+    perm, nn = mdl.vecchia_structure()
+    assert _sha(nn.astype(np.int32)) == str(g[name + "_nn_sha256"])
+    del mdl
+    ct = orc.cov_type_id(cf, sh)
+    sigma2, var, a = orc.transform_cov_pars(ct, cp)
+    st = shim.VecchiaState(np.ascontiguousarray(coords[perm]), m)
+    st.set_neighbors(nn)
+    st.set_y(y[perm])
+    world = 8
+    t7 = np.zeros(7); t3 = np.zeros(3); covered = 0
+    for r in range(world):
+        i0, i1 = parallel.shard_range(n, r, world)
+        assert i0 == covered and i1 > i0
+        covered = i1
+        st.set_shard(i0, i1)
+        t7 += st.grad_terms(ct, var, a)
+        t3 += st.nll_terms(ct, var, a)
+    assert covered == n
+    st.set_shard(0, n)
+    ref_nll, ref_grad = float(g[name + "_nll"]), g[name + "_grad"]
+    assert t7[2] == 0 and t3[2] == 0
+    nll = shim.nll_from_terms(n, t7[0], t7[1], sigma2)
+    assert abs(nll - ref_nll) <= RTOL * abs(ref_nll), (nll, ref_nll)
+    nll3 = shim.nll_from_terms(n, t3[0], t3[1], sigma2)
+    assert abs(nll3 - ref_nll) <= RTOL * abs(ref_nll), (nll3, ref_nll)
+    grad = shim.grad_from_terms(n, t7, sigma2)
+    np.testing.assert_allclose(grad, ref_grad, rtol=RTOL, atol=RTOL * np.abs(ref_grad).max())
+    # and the one-launch evaluation of the same handle: the shards add up to it (1e-12: only the order of the partial sums differs)
+    full = st.grad_terms(ct, var, a)
+    np.testing.assert_allclose(t7, full, rtol=1e-12, atol=1e-9)
+
+
 def test_config4_n1e5_against_the_reference(gpb):
     """BASELINE config 4 at its full size against the unmodified reference (tests/golden/config4_ref.npz, oracle/make_golden.py config4).
 

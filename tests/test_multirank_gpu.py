@@ -266,3 +266,69 @@ def test_bench_starts_its_own_ranks_and_rehearses_on_one_device(lib_built, N):
         assert cfg["rehearsal"] is False and cfg["rccl_ranks"] == N
     assert abs(cfg["last_negll"] - one["config"]["last_negll"]) <= 1e-12 * abs(one["config"]["last_negll"])
     assert out["roofline"]["kernel_ms"] <= out["ms_per_step"] and cfg["overhead_us"] >= 0.0
+
+
+@pytest.mark.parametrize("name,hi", [("plain_l31", 0), ("cat_l15", 1)])
+def test_every_collective_of_the_multi_gpu_path_runs_through_a_one_rank_rccl_communicator(lib_built, orc, name, hi):
+    """Multi-GPU readiness without the hardware: the FIRST launch on a node with N > 1 devices must not meet an RCCL call that has never
+    executed.  With a one-rank communicator from ncclCommInitRank (not the in-process LocalGroup transport of the tests above) this drives every collective the
+    N > 1 path issues -- Vecchia: the neighbour table's max-all-reduce (ncclAllReduce, int32 max), the 3 / 7 shard sums (ncclAllReduce, fp64 sum), y_aux
+    (ncclAllReduce over n doubles); trees: the fixed-point scale (max), a histogram's integer totals (ncclAllReduce, int64 sum), and BOTH exchanges of the
+    data-parallel grower -- 'allreduce' and 'feature_blocks' (ncclReduceScatter of the packed integer totals + the all-reduce of the ranks' candidate records) --
+    and every result must equal the communicator-free one bit for bit (the reference's scheme: data_parallel_tree_learner.cpp:131, 155-173, 244)."""
+    from gpboost_amd import shim
+    from tests import cases
+    # ---- Vecchia side
+    n, m = 20011, 20
+    coords, y = cases.synthetic(n, 2, seed=5)
+    perm, co, nn = orc.vecchia_setup(coords, m, "random", 2)
+    st = shim.VecchiaState(co, m)
+    st.comm_init(shim.comm_unique_id(), 0, 1)
+    assert st.comm_info() == (0, 1)
+    st.find_neighbors_part(0, 1)
+    st.neighbors_allreduce()
+    assert np.array_equal(st.get_neighbors(), nn)
+    st.set_y(y[perm])
+    assert np.array_equal(st.nll_terms_allreduce(0, 10.0, 10.0), st.nll_terms(0, 10.0, 10.0))
+    assert np.array_equal(st.grad_terms_allreduce(0, 10.0, 10.0), st.grad_terms(0, 10.0, 10.0))
+    st.factor(0, 10.0, 10.0)
+    assert np.array_equal(st.yaux_allreduce(), st.yaux())
+    st.close()
+    # ---- tree side: the reference's tree fixtures' data
+    r5 = name in cases.TREE_CASES_R5
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tree_ref_r5.npz" if r5 else "tree_ref.npz"))
+    data, params, L, cfg = cases.tree_params(name)
+    X, grad, hess, leaf = cases.make_split_data(data)
+    k = "%s_hess%d_" % (name, hi)
+    hs = hess if hi else None
+    bins, gnb, mfb, meta3 = g[k + "bins"], g[k + "group_num_bin"], g[k + "most_freq_bin"], g[k + "meta3"]
+    bo = np.concatenate([[0], np.cumsum(gnb)]).astype(np.int32)
+
+    def grow(mode):
+        hb = shim.HistBuilder(np.ascontiguousarray(bins), bo)
+        hb.pool_resize(L + 1)
+        hb.set_fix_info(g[k + "view_offset"], g[k + "num_bin"], mfb)
+        hb.set_split_info(meta3[:, 0], meta3[:, 1], meta3[:, 2])
+        if r5 and g[k + "layout"][:, 3].any():
+            hb.set_categorical(g[k + "layout"][:, 3], *cases.tree_cat_cfg(name))
+        if mode is not None:
+            hb.comm_init(shim.comm_unique_id(), 0, 1)
+            hb.set_feature_block_exchange(mode == "feature_blocks")
+        hb.set_gradients(grad, hs)
+        if len(cfg) > 4:
+            hb.set_regularisation(cfg[4], cfg[5], cfg[6])
+        hb.set_max_depth(cases.tree_max_depth(name))
+        h_all = hb.build_allreduce(None) if mode is not None else hb.build(None)
+        sg = float("nan") if mode is not None else float(np.cumsum(grad)[-1])
+        sh = float("nan") if mode is not None else (float(len(grad)) if hs is None else float(np.cumsum(hs)[-1]))
+        t = hb.grow_tree(L, sg, sh, *cfg[:4])
+        hb.close()
+        return h_all, t
+    h0, t0 = grow(None)
+    for mode in ("allreduce", "feature_blocks"):
+        h1, t1 = grow(mode)
+        assert np.array_equal(h1[0], h0[0]) and np.array_equal(h1[1], h0[1]), mode
+        assert t1["num_leaves"] == t0["num_leaves"]
+        for key in ("split_feature_inner", "threshold_in_bin", "left_child", "right_child", "internal_count", "leaf_count", "node_is_cat", "node_cat_bits"):
+            assert np.array_equal(t1[key], t0[key]), (mode, key)
+        np.testing.assert_allclose(t1["leaf_value"], t0["leaf_value"], rtol=1e-10, atol=1e-13)

@@ -67,3 +67,15 @@ def test_route_b_reference_booster_with_device_type_gpu_reproduces_device_type_c
     both = out + "\n" + _LAST_STDERR[0]
     assert "per-feature (unbundled) columns" in both and "categorical features searched on the GPU" in both
     assert "histograms stay on the CPU" not in both
+
+
+CONFIG3_REF = os.path.join(ROOT, "tests", "golden", "config3_loop_ref.npz")
+
+
+@pytest.mark.skipif(not (os.path.isfile(HIPLIB) and os.path.isfile(CONFIG3_REF)), reason="route-B build or tests/golden/config3_loop_ref.npz absent")
+def test_config3_whole_boosting_loop_reproduces_the_cpu_path(lib_built):
+    """BASELINE config 3 as a whole loop: 10 boosting iterations at n = 1e5 x 50 features x 255 bins with the Vecchia GP trained inside the loop, through
+    the reference's own Booster with (i) GPU_use = true and (ii) GPU_use = true + device_type = gpu, against the predictions and covariance parameters the same
+    build's CPU path left in tests/golden/config3_loop_ref.npz (scripts/gpu_config3_loop.py --make-ref): predictions 1e-8 of their scale, parameters 1e-6."""
+    out = _run(["scripts/gpu_config3_loop.py"], "CONFIG 3 WHOLE LOOP ON MI355X: OK", 900)
+    assert out.count("max |prediction - CPU path|") == 2
