@@ -94,6 +94,10 @@ struct REModelHip {
   // likelihoods with an auxiliary parameter (round 5: gamma, negative_binomial -- the shape; likelihoods.h:298-322): num_aux_pars_, aux_pars_ (original
   // scale), AuxParsHaveBeenSet(), init_aux_pars_ / init_aux_pars_given_ (re_model.cpp:327-344), estimate_aux_pars_ (re_model_template.h:909-912)
   int num_aux = 0; double aux_pars[2] = {1., 2.}; bool aux_set = false; double init_aux[2] = {-1., -1.}; bool init_aux_given = false; bool estimate_aux_pars = true;      // (t: scale, df -- internal default df 2, likelihoods.h:392)
+  // "t_fix_df" (ParseLikelihoodAliasEstimateAdditionalPars, likelihoods.h:10466-10471): estimate_df_t_ = false -> num_aux_pars_estim_ = 1 of num_aux_pars_ = 2 (:402-407).
+  // The df stay IN the optimiser's vector with a zero gradient (SetGradAuxParsNotEstimated :16179-16183) and SetAuxPars copies only the first num_aux_pars_estim_ values (:2780-2789)
+  bool estimate_df_t = true;
+  int num_aux_estim() const { return (likelihood == "t" && !estimate_df_t) ? 1 : num_aux; }
   std::vector<double> resp_real;   // gamma: the real-valued response, Vecchia order
   // repeated locations of a non-Gaussian model (the reference's unique-location mapping, Vecchia_utils.cpp:1156-1168, re_comp.h:863-885): the
   // Vecchia handle lives on the n_re unique locations; datum at shuffled position k belongs to random effect re_of[k]; dorder lists the
@@ -187,6 +191,11 @@ bool supported_non_gaussian(const std::string& lik) {
   return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || lik == "lognormal" || is_proportion_likelihood(lik);
 }
 // Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
+// "<likelihood>_fix_df" -> "<likelihood>", *fix_df = true (ParseLikelihoodAliasEstimateAdditionalPars, likelihoods.h:10466-10471: the suffix is stripped from any name)
+std::string strip_fix_df(const std::string& lik, bool* fix_df) {
+  *fix_df = lik.size() > 7 && lik.compare(lik.size() - 7, 7, "_fix_df") == 0;
+  return *fix_df ? lik.substr(0, lik.size() - 7) : lik;
+}
 std::string parse_likelihood_alias(const std::string& lik) {
   if (lik == "binary_probit") return "bernoulli_probit";
   if (lik == "binary" || lik == "binary_logit") return "bernoulli_logit";
@@ -428,7 +437,7 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
   if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
   if (op == 4) { mdl->lap_fit_first_eval = true; return 0; }
   if (op == 0 || op == 1) {
-    for (int j = 0; j < naux && j < 2; ++j) mdl->aux_pars[j] = aux[j];      // SetAuxPars at every evaluation (optim_utils.h:279-282)
+    for (int j = 0; j < naux && j < mdl->num_aux_estim(); ++j) mdl->aux_pars[j] = aux[j];      // SetAuxPars at every evaluation (optim_utils.h:279-282): the first num_aux_pars_estim_ values
     mdl->aux_set = true;
     if (laplace_push_aux(mdl)) return -1;
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;
@@ -443,7 +452,7 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
   if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(mdl->cg_max_num_it, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
   if (gpb_hip_vecchia_laplace_grad_aux_current(mdl->vh, g4)) return -1;
   out[1] = g2[0]; out[2] = g2[1];
-  for (int j = 0; j < naux && j < 2; ++j) out[3 + j] = g4[4 * j];
+  for (int j = 0; j < naux && j < 2; ++j) out[3 + j] = j < mdl->num_aux_estim() ? g4[4 * j] : 0.;      // SetGradAuxParsNotEstimated (likelihoods.h:16179-16183)
   return 0;
 }
 
@@ -1304,7 +1313,8 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     if (num_ind_points > 256) return set_error("GPB_CreateREModel: num_ind_points = %d (at most 256 on this path) %s", num_ind_points, scope);
     if (num_neighbors <= 0) num_neighbors = 30;                                    // :296
   }
-  const std::string lik_name = parse_likelihood_alias(lik);
+  bool fix_df = false;
+  const std::string lik_name = parse_likelihood_alias(strip_fix_df(lik, &fix_df));
   if (lik_name != "gaussian" && !supported_non_gaussian(lik_name)) return set_error("GPB_CreateREModel: likelihood '%s' %s", lik.c_str(), scope);
   // likelihood_additional_param (likelihoods.h:223, 391-399): -999 = "not given"; 't' reads its degrees of freedom from it (aux_pars_ = {1, df}); none of the
   // other likelihoods on this path takes one ('tweedie_fixed_p', 'asymmetric_laplace' do in the reference and are not built) -- a value is refused, never dropped
@@ -1340,6 +1350,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   auto mdl = std::unique_ptr<REModelHip>(new REModelHip());
   mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); if (lik_name == "lognormal") mdl->aux_pars[0] = 0.5;  /* likelihoods.h:506 */ mdl->num_neighbors = num_neighbors;
   if (lik_name == "t" && add_par_given) mdl->aux_pars[1] = likelihood_additional_param;      // aux_pars_ = {1, additional_param} (likelihoods.h:397-399)
+  mdl->estimate_df_t = !fix_df;
   if (has_weights && lik_name != "gaussian") mdl->lik_weights.assign(weights, weights + num_data);     // factors of the per-datum likelihood terms (likelihoods.h:666-668)
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
@@ -1466,9 +1477,13 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   // auxiliary parameters (gamma / negative_binomial; re_model.cpp:327-344, re_model_template.h:909-912): initial values are applied at once (SetAuxPars)
   mdl->estimate_aux_pars = estimate_aux_pars;
   if (init_aux_pars && mdl->num_aux > 0) {
+    if (mdl->num_aux_estim() < mdl->num_aux && !mdl->aux_set && !near(init_aux_pars[1], mdl->aux_pars[1]))       // likelihoods.h:2763-2768
+      fprintf(stderr, "[gpboost_amd] Warning: The 'df' parameter provided in 'init_aux_pars' (= %g) and 'likelihood_additional_param' (= %g) are not equal. Will use the value provided in 'likelihood_additional_param' \n", init_aux_pars[1], mdl->aux_pars[1]);
     for (int j = 0; j < mdl->num_aux; ++j) {
+      mdl->init_aux[j] = init_aux_pars[j];                                     // init_aux_pars_ keeps what the caller passed (re_model.cpp:327-344)
+      if (j >= mdl->num_aux_estim()) continue;                                 // SetAuxPars copies the first num_aux_pars_estim_ values only (likelihoods.h:2780-2789)
       if (!(init_aux_pars[j] > 0.)) return set_error("The %s parameter is not > 0 (found %g)", mdl->likelihood == "t" ? (j == 0 ? "scale" : "df") : (mdl->likelihood == "lognormal" ? "log_variance" : "shape"), init_aux_pars[j]);
-      mdl->init_aux[j] = init_aux_pars[j]; mdl->aux_pars[j] = init_aux_pars[j];
+      mdl->aux_pars[j] = init_aux_pars[j];
     }
     mdl->init_aux_given = true; mdl->aux_set = true;
   } else mdl->init_aux_given = false;
@@ -1659,7 +1674,7 @@ int GPB_OptimCovPar(REModelHandle handle, const double* y_data, const double* fi
       }
       if (cfg.max_iter > 0) {
         mdl->cov_pars_tr[0] = ra.theta[0]; mdl->cov_pars_tr[1] = ra.theta[1];
-        for (int j = 0; j < mdl->num_aux; ++j) mdl->aux_pars[j] = aux[j];
+        for (int j = 0; j < mdl->num_aux_estim(); ++j) mdl->aux_pars[j] = aux[j];
         if (laplace_push_aux(mdl)) return -1;
         mdl->cur_negll = ra.negll;
         mdl->negll_valid = true;
@@ -2898,7 +2913,8 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !likelihood) return set_error("GPB_SetLikelihood: null argument");
   if (mdl && mdl->vif) return set_error("GPB_SetLikelihood: gp_approx 'full_scale_vecchia' -- likelihood evaluation, its gradient and fits are on the MI355X path of this library, this call is not yet");
-  const std::string lik = parse_likelihood_alias(likelihood);
+  bool fix_df = false;
+  const std::string lik = parse_likelihood_alias(strip_fix_df(likelihood ? likelihood : "", &fix_df));
   if (mdl->model_has_been_estimated && lik != mdl->likelihood) return set_error("Cannot change likelihood after a model has been estimated ");   // re_model.cpp:154-160
   if (lik == mdl->likelihood) return 0;
   if (lik != "gaussian" && !supported_non_gaussian(lik))
@@ -2907,7 +2923,7 @@ int GPB_SetLikelihood(REModelHandle handle, const char* likelihood) {
   if (lik != "gaussian" && mdl->has_duplicates) return set_error(kDuplicatesNonGaussianMessage);
   if (lik == "gaussian" && mdl->n_re > 0)
     return set_error("GPB_SetLikelihood: this model was created with repeated locations under a non-Gaussian likelihood -- its Vecchia approximation lives on the %d unique locations (Vecchia_utils.cpp:1156-1168); create a new model for the Gaussian likelihood", mdl->n_re);
-  mdl->likelihood = lik;
+  mdl->likelihood = lik; mdl->estimate_df_t = !fix_df;
   mdl->num_aux = num_aux_of(lik); mdl->aux_pars[0] = lik == "lognormal" ? 0.5 : 1.; mdl->aux_pars[1] = 2.; mdl->aux_set = false; mdl->init_aux_given = false;      // a new Likelihood object (re_model_template.h SetLikelihood)
   mdl->cov_pars_initialized = false; mdl->init_cov_pars_provided = false; mdl->negll_valid = false; mdl->y_set = false; mdl->yaux_valid = false;
   C_API_END();

@@ -2637,6 +2637,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks; a.num_features = h->F;
   a.use_rows_kernel = rows_kernel ? 1 : 0;
   a.bins_cm = h->d_bins_cm; a.rstride = h->rstride; a.prefetch = h->hist_prefetch;
+  { const char* nb = getenv("GPB_HIST_ROWS_NB"); a.rows_nb = (nb && nb[0] == '2') ? 2 : 4; }
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
   r.grad_max_bits = h->d_absmax; r.hess_max_bits = h->d_absmax + 1;

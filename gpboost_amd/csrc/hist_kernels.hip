@@ -221,10 +221,12 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // Constant hessian only: per-row hessians stay on hist_build_kernel (the two-word whole-row form was slower).
 // 16 bytes of a row from a 4-byte-aligned address (compact rows: stride F rounded up to 4): ONE global_load_dwordx4 -- the hardware needs dword alignment only
 struct __attribute__((packed, aligned(4))) RowQuad { unsigned x, y, z, w; };
-template <bool HAS_IDX, int NBK, int PF = 1>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block; PF = row blocks in flight ahead of the one being accumulated
-__global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
+template <bool HAS_IDX, int NBK, int PF = 1, int NB = 4>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block; PF = row blocks in flight ahead of the one being accumulated
+// NB = feature groups per workgroup: 4 (128 KB of LDS, ONE 512-lane workgroup = 2 wavefronts per SIMD per CU) or -- round 6 -- 2 (64 KB, TWO workgroups = 4 wavefronts per SIMD: the 8-byte
+// LDS operations reach their rate only from ~4 wavefronts per SIMD, MI355X_MICROARCH.md "LDS"; the per-row prologue is then paid once per 32 features)
+__global__ __launch_bounds__(512, NB == 2 ? 2 : 1) void hist_build_rows_kernel(HistKernelArgs a) {
   // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
-  constexpr int THREADS = 512, NB = 4, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
+  constexpr int THREADS = 512, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
   extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features] (+ the same again for the hessian sums)
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, quad = blockIdx.y + a.quad0, groups = a.fpad / GPB_HIST_FG;
@@ -589,6 +591,15 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
     };
     const int groups = a.fpad / GPB_HIST_FG, full = groups / 4, rest = groups % 4;
     hipError_t e = hipSuccess;
+    if (a.rows_nb == 2 && !a.data_indices && groups % 2 == 0) {      // round 6 experiment: two feature groups per workgroup, two workgroups per CU
+      constexpr int lds2 = 2 * GPB_HIST_MAX_BIN * GPB_HIST_FG * 8;
+      auto kern = hist_build_rows_kernel<false, 2, 1, 2>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      if (e != hipSuccess) return e;
+      HistKernelArgs b = a; b.quad0 = 0;
+      hipLaunchKernelGGL(kern, dim3(a.nchunks, groups / 2), dim3(512), lds2, st, b);
+      return hipGetLastError();
+    }
     if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : (a.prefetch == 2 ? go(hist_build_rows_kernel<false, 4, 2>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0));
     if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1>, 1, full) : go(hist_build_rows_kernel<false, 1>, 1, full);
     if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2>, 1, full) : go(hist_build_rows_kernel<false, 2>, 1, full);

@@ -123,7 +123,7 @@ class RefVifModel(RefModel):
 class RefCAPIModel(object):
     def __init__(self, coords, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1, threads=-1,
                  likelihood="gaussian", cluster_ids=None, lib_path=None, gpu_use=False, gp_approx="vecchia", num_ind_points=500, weights=None,
-                 matrix_inversion_method="default"):
+                 matrix_inversion_method="default", likelihood_additional_param=-999.):
         # lib_path / gpu_use: the route-B build (integration/Makefile.routeB -> integration/_build/lib_gpboost_hip.so), the same C API with GPU_use = true
         self.L = C.CDLL(lib_path or os.path.join(_HERE, "_ref", "lib_gpboost_ref.so"))
         self.L.LGBM_GetLastError.restype = C.c_char_p
@@ -136,7 +136,7 @@ class RefCAPIModel(object):
             C.c_int(self.n), C.c_void_p() if cid is None else _P(cid), C.c_void_p(), C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_void_p(),
             C.c_int(1), _P(cm), C.c_int(self.d), C.c_void_p(), C.c_int(0), s(cov_function), C.c_double(shape), s(gp_approx),
             C.c_double(1.), C.c_double(0.), C.c_int(m), s(ordering), C.c_int(int(num_ind_points)), C.c_double(1.), s("kmeans++"),
-            s(likelihood), C.c_double(-999.), s(matrix_inversion_method), C.c_int(seed), C.c_int(threads), C.c_bool(bool(gpu_use)),
+            s(likelihood), C.c_double(float(likelihood_additional_param)), s(matrix_inversion_method), C.c_int(seed), C.c_int(threads), C.c_bool(bool(gpu_use)),
             C.c_bool(weights is not None), C.c_void_p() if weights is None else _P(self._w(weights)), C.c_double(1.), C.byref(self.h))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())

@@ -93,13 +93,7 @@ def test_model_api_evaluation_fit_and_prediction_follow_the_reference(gpb, name)
     ref0 = float(g[name + "_negll_0"])
     assert abs(v - ref0) <= 1e-8 * abs(ref0), (v, ref0)
     np.testing.assert_allclose(mdl.get_aux_pars(), tc["aux"], rtol=0, atol=0)
-    mdl.set_optim_params(dict(cases.LAPLACE_TIGHT))
-    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=False)
-    cases.assert_pred_close(pr["mu"], g[name + "_latent_mu"])
-    cases.assert_pred_close(pr["var"], g[name + "_latent_var"])
-    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=True)
-    cases.assert_pred_close(pr["mu"], g[name + "_resp_mu"])
-    cases.assert_pred_close(pr["var"], g[name + "_resp_var"])
+    cases.check_predictions_against_reference(gpb, kw, g, name, y, cp, aux=list(tc["aux"]))
     for key, cfg, rtol, ntol in (("_fit", {}, 1e-3, 1e-7), ("_fit_tight", dict(cases.LAPLACE_TIGHT), 1e-6, 1e-8)):
         m2 = gpb.GPModel(**kw)
         m2.fit(y, params=dict(cfg))

@@ -96,13 +96,7 @@ def test_weighted_model_api_fit_and_prediction_follow_the_reference(gpb, name):
     v = mdl.neg_log_likelihood(cp, y, **aux_kw)
     ref_v = float(g[name + "_negll_direct"])
     assert abs(v - ref_v) <= 1e-8 * abs(ref_v), (v, ref_v)
-    pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=False)
-    cases.assert_pred_close(pr["mu"], g[name + "_latent_mu"])
-    cases.assert_pred_close(pr["var"], g[name + "_latent_var"])
-    if name + "_resp_mu" in g.files:       # (the reference has no response prediction for quasi_bernoulli_logit)
-        pr = mdl.predict(y=y, gp_coords_pred=g[name + "_coords_pred"], cov_pars=cp, predict_var=True, predict_response=True)
-        cases.assert_pred_close(pr["mu"], g[name + "_resp_mu"])
-        cases.assert_pred_close(pr["var"], g[name + "_resp_var"])
+    cases.check_predictions_against_reference(gpb, kw, g, name, y, cp, aux=([wc["aux"]] if "aux" in wc else None))
     m2 = gpb.GPModel(**kw)
     m2.fit(y, params=dict(cases.LAPLACE_TIGHT))
     assert m2.get_num_optim_iter() == int(g[name + "_fit_tight_num_it"]), (m2.get_num_optim_iter(), int(g[name + "_fit_tight_num_it"]))
