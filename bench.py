@@ -770,6 +770,8 @@ def main():
             # PROJECTION of the per-rank work of an N = 8 launch (later shards do the same arithmetic on a different gather footprint), never a scaling number.
             def sweep(state, cti, vv, aa, nn_pts, label):
                 rows = []
+                state.set_shard(0, nn_pts)
+                state.bench(shim.MODE_NLL, cti, vv, aa, 0, 60)          # clocks at their loaded state before the first shard is timed (the first shard of a cold sweep read 15 % high)
                 for r8 in range(8):
                     j0, j1 = parallel.shard_range(nn_pts, r8, 8)
                     state.set_shard(j0, j1)

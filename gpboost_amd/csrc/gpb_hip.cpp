@@ -390,7 +390,6 @@ struct gpb_hip_hist {
   int* d_root_rows = nullptr; int root_cnt = 0;            // bagging: the rows of the root of the next trees (root_cnt = 0: all rows)
   uint8_t* d_bins_rm = nullptr;
   uint8_t* d_bins_cm = nullptr; int rstride = 0;   // compact copy [n][rstride] for the streaming root pass (hist_kernels.h: HistKernelArgs::bins_cm); absent when F % 16 == 0
-  int hist_prefetch = 1;
   int* d_bin_offsets = nullptr;
   double* d_grad = nullptr; double* d_hess = nullptr;
   bool has_hess = false, has_grad = false;
@@ -2395,8 +2394,6 @@ int gpb_hip_hist_create(int32_t n, int32_t num_features, const uint8_t* bins, co
       HIP_OK(gpb::launch_bins_transpose(d_fm, h->d_bins_cm, n, num_features, h->fpad, h->stream, rs));
       h->rstride = rs;
     }
-    const char* pf = getenv("GPB_HIST_PREFETCH");
-    h->hist_prefetch = (pf && pf[0] == '1') ? 1 : ((pf && pf[0] == '2') ? 2 : 1);
   }
   HIP_OK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_fm); d_fm = nullptr;
@@ -2636,8 +2633,7 @@ static int hist_build_impl(gpb_hip_hist_t* h, const int32_t* data_indices, int32
   a.grad_max_bits = h->d_absmax; a.hess_max_bits = h->d_absmax + 1;
   a.fpad = h->fpad; a.num_data = num_data; a.rows_per_chunk = std::max(rows_per_chunk, 1); a.nchunks = nchunks; a.num_features = h->F;
   a.use_rows_kernel = rows_kernel ? 1 : 0;
-  a.bins_cm = h->d_bins_cm; a.rstride = h->rstride; a.prefetch = h->hist_prefetch;
-  { const char* nb = getenv("GPB_HIST_ROWS_NB"); a.rows_nb = (nb && nb[0] == '2') ? 2 : 4; }
+  a.bins_cm = h->d_bins_cm; a.rstride = h->rstride;
   gpb::HistReduceArgs r;
   r.part_grad = h->d_part_grad; r.part_hess = h->d_part_hess; r.part_cnt = h->d_part_cnt; r.bin_offsets = h->d_bin_offsets;
   r.grad_max_bits = h->d_absmax; r.hess_max_bits = h->d_absmax + 1;

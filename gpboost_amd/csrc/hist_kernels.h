@@ -27,8 +27,6 @@ struct HistKernelArgs {
   // tree grower: when seg_counts != nullptr the rows are the SMALLER child of the split of the segment (seg_begin, seg_cnt) of
   // data_indices whose left counts {this rank, all ranks} sit in seg_counts (device memory); num_data / rows_per_chunk are ignored
   int quad0 = 0;            // hist_build_rows_kernel: first quad of feature groups of this launch
-  int prefetch = 1;         // hist_build_rows_kernel without an index list: blocks of rows in flight ahead of the one being accumulated (1 or 2)
-  int rows_nb = 4;          // hist_build_rows_kernel: feature groups per workgroup (4; 2 = two workgroups per CU, streaming passes with an even number of groups only)
   int use_rows_kernel = 0;  // hist_build_rows_kernel (constant hessian, >= 4 feature groups): set by the host with a chunking of one workgroup per CU
   const int* seg_counts = nullptr;
   int seg_begin = 0, seg_cnt = 0, seg_gcnt = 0, seg_min_data_in_leaf = 0;

@@ -221,11 +221,16 @@ __global__ __launch_bounds__(THREADS) void hist_build_kernel(HistKernelArgs a) {
 // Constant hessian only: per-row hessians stay on hist_build_kernel (the two-word whole-row form was slower).
 // 16 bytes of a row from a 4-byte-aligned address (compact rows: stride F rounded up to 4): ONE global_load_dwordx4 -- the hardware needs dword alignment only
 struct __attribute__((packed, aligned(4))) RowQuad { unsigned x, y, z, w; };
-template <bool HAS_IDX, int NBK, int PF = 1, int NB = 4>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block; PF = row blocks in flight ahead of the one being accumulated
-// NB = feature groups per workgroup: 4 (128 KB of LDS, ONE 512-lane workgroup = 2 wavefronts per SIMD per CU) or -- round 6 -- 2 (64 KB, TWO workgroups = 4 wavefronts per SIMD: the 8-byte
-// LDS operations reach their rate only from ~4 wavefronts per SIMD, MI355X_MICROARCH.md "LDS"; the per-row prologue is then paid once per 32 features)
-__global__ __launch_bounds__(512, NB == 2 ? 2 : 1) void hist_build_rows_kernel(HistKernelArgs a) {
+template <bool HAS_IDX, int NBK>   // NBK = feature groups of this launch's blocks that exist: NB, or fewer for the data set's last, partial block
+// Round 6, measured at n = 1e7, F = 50 and NOT kept (profiles/r06_a_hist_*, r06_b_hist_*, r06_c_hist_*): two blocks of rows in flight ahead of the one being accumulated
+// (0.193 against 0.183 ms); two feature groups per workgroup = two workgroups = 4 wavefronts per SIMD per CU (0.191 against 0.193 ms on the same box); the sixteen
+// word addresses of a block computed first, into sixteen registers, and the sixteen ds_add_u64 issued back to back instead of the compiler's address / atomic
+// pairs on one register (0.208 against 0.193 ms: a burst fills the LDS instruction queue and stalls the wavefront, interleaved VALU hides it).  What pays is the
+// compact row copy (0.187 -> 0.183 ms, counter traffic 1.24x -> ~1.05x of the algorithmic bytes).  The pass stays bound by the rate at which ds_add_u64 instructions
+// enter the LDS (PMC r05: SQ_ACTIVE_INST_LDS / SQ_INSTS_LDS = 13 cycles of a SIMD's path per wavefront-atomic; the LDS array itself is 53 % busy).
+__global__ __launch_bounds__(512) void hist_build_rows_kernel(HistKernelArgs a) {
   // (1024 lanes: 128 VGPRs per lane are not enough for the 32 + 16 drain registers -> spills, 2x slower)
+  constexpr int NB = 4;
   constexpr int THREADS = 512, kWords = GPB_HIST_MAX_BIN * GPB_HIST_FG, kOwn = NB * kWords / THREADS, kFlushIters = 1792 / THREADS;
   extern __shared__ unsigned long long s_rows[];                  // [NB][256 bins][16 features] (+ the same again for the hessian sums)
   const int tid = threadIdx.x;
@@ -306,27 +311,14 @@ __global__ __launch_bounds__(512, NB == 2 ? 2 : 1) void hist_build_rows_kernel(H
   const int nrows = max(r1 - r0, 0), nfull = nrows / THREADS;
   if (nrows > 0) {
     int since_flush = 0;
-    if constexpr (PF == 1) {
-      RowData cur = fetch(min(r0 + tid, r1 - 1));
-      for (int it = 0; it < nfull; ++it) {
-        const RowData nxt = fetch(min(r0 + (it + 1) * THREADS + tid, r1 - 1));
-        accumulate(cur);
-        cur = nxt;
-        if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
-      }
-      if (r0 + nfull * THREADS + tid < r1) accumulate(cur);
-    } else {
-      // PF = 2 (round 6): TWO blocks of rows in flight ahead of the one being accumulated -- one 512-lane workgroup per CU keeps 8 wavefronts x 64 rows x 72 bytes
-      // = 36 KB per block in flight; at ~2 us of loaded HBM latency one block ahead bounds a CU at ~18 GB/s (x 256 CUs = 4.6 TB/s), two lift that bound
-      RowData q0 = fetch(min(r0 + tid, r1 - 1)), q1 = fetch(min(r0 + THREADS + tid, r1 - 1));
-      for (int it = 0; it < nfull; ++it) {
-        const RowData nxt = fetch(min(r0 + (it + 2) * THREADS + tid, r1 - 1));
-        accumulate(q0);
-        q0 = q1; q1 = nxt;
-        if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
-      }
-      if (r0 + nfull * THREADS + tid < r1) accumulate(q0);
+    RowData cur = fetch(min(r0 + tid, r1 - 1));
+    for (int it = 0; it < nfull; ++it) {
+      const RowData nxt = fetch(min(r0 + (it + 1) * THREADS + tid, r1 - 1));
+      accumulate(cur);
+      cur = nxt;
+      if (++since_flush == kFlushIters) { flush(); since_flush = 0; }
     }
+    if (r0 + nfull * THREADS + tid < r1) accumulate(cur);
   }
   flush();
   // word w of block b -> partial (chunk, group 4 quad + b, word w): the layout of hist_build_kernel's partials
@@ -591,16 +583,7 @@ hipError_t launch_hist_build(const HistKernelArgs& a, hipStream_t st) {
     };
     const int groups = a.fpad / GPB_HIST_FG, full = groups / 4, rest = groups % 4;
     hipError_t e = hipSuccess;
-    if (a.rows_nb == 2 && !a.data_indices && groups % 2 == 0) {      // round 6 experiment: two feature groups per workgroup, two workgroups per CU
-      constexpr int lds2 = 2 * GPB_HIST_MAX_BIN * GPB_HIST_FG * 8;
-      auto kern = hist_build_rows_kernel<false, 2, 1, 2>;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-      if (e != hipSuccess) return e;
-      HistKernelArgs b = a; b.quad0 = 0;
-      hipLaunchKernelGGL(kern, dim3(a.nchunks, groups / 2), dim3(512), lds2, st, b);
-      return hipGetLastError();
-    }
-    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : (a.prefetch == 2 ? go(hist_build_rows_kernel<false, 4, 2>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0));
+    if (full > 0) e = a.data_indices ? go(hist_build_rows_kernel<true, 4>, full, 0) : go(hist_build_rows_kernel<false, 4>, full, 0);
     if (e == hipSuccess && rest == 1) e = a.data_indices ? go(hist_build_rows_kernel<true, 1>, 1, full) : go(hist_build_rows_kernel<false, 1>, 1, full);
     if (e == hipSuccess && rest == 2) e = a.data_indices ? go(hist_build_rows_kernel<true, 2>, 1, full) : go(hist_build_rows_kernel<false, 2>, 1, full);
     if (e == hipSuccess && rest == 3) e = a.data_indices ? go(hist_build_rows_kernel<true, 3>, 1, full) : go(hist_build_rows_kernel<false, 3>, 1, full);

@@ -60,7 +60,7 @@ def test_student_t_likelihood_through_the_c_api_on_the_cpu_restatement_of_the_sh
     """Round 5: the t likelihood's two auxiliary parameters through the model surface (GPB_SetOptimConfig(init_aux_pars[2]), the lbfgs vector (log sigma1^2, log a, log scale,
     log df), the MAD start of the scale, GPB_GetAuxPars with two values, response predictions): tests/test_zz_laplace_t_gpu.py's model-API tests on the oracle-backed shim."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_t_gpu.py"], extra=["-k", "model_api"])
-    assert "4 passed" in tail, tail      # (2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
+    assert "5 passed" in tail, tail      # (round 6: + "t_fix_df" and likelihood_additional_param; 2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
 
 
 def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):

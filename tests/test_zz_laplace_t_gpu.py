@@ -136,3 +136,45 @@ def test_auxiliary_gradient_with_the_low_rank_preconditioners(gpb, orc, pcn, ran
     assert grad.shape == (2 + len(tc["aux"]),)
     np.testing.assert_allclose(grad, og, rtol=1e-8, atol=3e-8 * np.abs(og).max())
     st.close()
+
+
+def test_model_api_t_with_fixed_df_follows_the_reference(gpb):
+    """Round 6: likelihood "t_fix_df" -- Student-t with the degrees of freedom HELD at likelihood_additional_param and only the scale estimated (estimate_df_t_ = false:
+    likelihoods.h:384-407, :10466-10471; the df stay in the optimiser's vector with a zero gradient, :16179-16183, and SetAuxPars takes over the first
+    num_aux_pars_estim_ = 1 values only, :2780-2789) -- and the reading of likelihood_additional_param by GPB_CreateREModel, against the unmodified
+    reference (tests/golden/laplace_t_fixdf_ref.npz, oracle/make_golden.py laplace_t_fixdf): evaluation 1e-8, fits with its iteration counts."""
+    g = np.load(os.path.join(GOLD, "laplace_t_fixdf_ref.npz"))
+    tc = cases.LAPLACE_T_CASES["t_n1500"]
+    c = cases.LAPLACE_CASES[tc["model"]]
+    coords, y = cases.make_t_data(tc)
+    kw = dict(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+    mdl = gpb.GPModel(likelihood="t_fix_df", likelihood_additional_param=5.0, **kw)
+    assert mdl.get_num_aux_pars() == 2
+    mdl.set_optim_params(dict(cases.LAPLACE_TIGHT, init_aux_pars=np.array([0.5, 3.0])))       # the 3 is NOT taken over: the df stay at likelihood_additional_param
+    v = mdl.neg_log_likelihood(cp, y)
+    ref = float(g["df5_negll"])
+    assert abs(v - ref) <= 1e-8 * abs(ref), (v, ref)
+    np.testing.assert_allclose(mdl.get_aux_pars(), g["df5_aux_after_eval"], rtol=0, atol=0)
+    for key, extra, cfg, rtol, ntol in (("df5", dict(likelihood_additional_param=5.0), dict(cases.LAPLACE_TIGHT), 1e-6, 1e-8), ("dfdef", {}, {}, 1e-3, 1e-7)):
+        m2 = gpb.GPModel(likelihood="t_fix_df", **extra, **kw)
+        m2.fit(y, params=dict(cfg))
+        assert m2.get_num_optim_iter() == int(g[key + "_fit_num_it"]), (key, m2.get_num_optim_iter(), int(g[key + "_fit_num_it"]))
+        np.testing.assert_allclose(m2.get_cov_pars(), g[key + "_fit_cov_pars"], rtol=rtol)
+        aux = m2.get_aux_pars()
+        assert aux[1] == g[key + "_fit_aux"][1], (aux, g[key + "_fit_aux"])             # the df did not move: 5, or the internal default 2 (likelihoods.h:391-393)
+        np.testing.assert_allclose(aux[0], g[key + "_fit_aux"][0], rtol=rtol)
+        nll = m2.get_current_neg_log_likelihood(); nref = float(g[key + "_fit_negll"])
+        assert abs(nll - nref) <= ntol * abs(nref), (key, nll, nref)
+    # "t" (df estimated) created with likelihood_additional_param = 5: the start value of the df (aux_pars_ = {1, 5}, likelihoods.h:397-399)
+    m3 = gpb.GPModel(likelihood="t", likelihood_additional_param=5.0, **kw)
+    m3.set_optim_params(dict(cases.LAPLACE_TIGHT, estimate_aux_pars=False))
+    v3 = m3.neg_log_likelihood(cp, y)
+    r3 = float(g["t_df5_negll"])
+    assert abs(v3 - r3) <= 1e-8 * abs(r3), (v3, r3)
+    np.testing.assert_allclose(m3.get_aux_pars(), g["t_df5_aux"], rtol=0, atol=0)
+    # a parameter the likelihood does not take is refused, not dropped; a negative df as in the reference
+    with pytest.raises(gpb.GPBoostError):
+        gpb.GPModel(likelihood="gamma", likelihood_additional_param=2.0, **kw)
+    with pytest.raises(gpb.GPBoostError):
+        gpb.GPModel(likelihood="t", likelihood_additional_param=-1.0, **kw)
