@@ -85,6 +85,45 @@ def profiled_mfma_busy_cycles(kernel_substr):
     return (tot, n) if n else None
 
 
+def laplace_kernel_rooflines(n4=100000, m4=30):
+    """Per-kernel rooflines of the Vecchia-Laplace solvers from KERNEL durations (VERDICT r05 #1 i: the per-iteration figures of config4_vecchia_laplace divide host timers by
+    iteration counts): mean durations of the committed rocprofv3 --kernel-trace runs of ONE config-4 evaluation per preconditioner (profiles/r06_a_trace_config4_*_summary.txt,
+    scripts/gpu_r6_targets.py) against the algorithmic bytes of one launch.  Read at run time like `traffic`; None where no trace is committed."""
+    import re
+    fac = n4 * m4 * 16                       # the factor's {coefficient, source} records, once
+    vec = n4 * 8
+    kernels = (   # (substring of the kernel name, label, algorithmic bytes of one launch as a function of k)
+        ("lap_sptrsv_sf_kernel<false, true", "single-vector triangular solve with B^T (barrier-free, ~118 wide levels)", lambda k: fac + 3 * vec),
+        ("lap_sptrsv_sf_kernel<true, false", "single-vector triangular solve with B", lambda k: fac + 3 * vec),
+        ("lap_sptrsv_sfw_kernel<false, true", "50-probe block solve with B^T (13 chunks of 4 columns share every entry load)", lambda k: fac + 2 * 52 * vec),
+        ("lap_sptrsv_sfw_kernel<true, false", "50-probe block solve with B", lambda k: fac + 2 * 52 * vec),
+        ("lap_tri_spmv_kernel<2, 4>", "B^T D^-1 B x on the 50-probe block", lambda k: 2 * fac + 2 * 52 * vec),
+        ("pc_ltwx_kernel<4>", "L_k^T (W o X) on the 50-probe block: the n x k factor once per chunk of 4 columns", lambda k: 13 * (n4 * k * 8 + 5 * vec)),
+        ("pc_combine_kernel<4>", "X - L_k x2 on the 50-probe block", lambda k: 13 * (n4 * k * 8 + 9 * vec)),
+    )
+    out = {}
+    for tag, k in (("vadu", 0), ("pivchol", 50), ("fitc", 200)):
+        path = os.path.join(ROOT, "profiles", "r06_a_trace_config4_%s_summary.txt" % tag)
+        if not os.path.exists(path):
+            continue
+        rows = []
+        with open(path) as fh:
+            txt = fh.read().split("\n")
+        for sub, label, byt in kernels:
+            for line in txt:
+                if sub in line and "mean_us=" in line:
+                    us = float(re.search(r"mean_us=\s*([0-9.]+)", line).group(1)); calls = int(re.search(r"calls=\s*([0-9]+)", line).group(1))
+                    b = byt(k)
+                    if b <= 0 or (k == 0 and sub.startswith("pc_")):
+                        break
+                    rows.append({"kernel": sub, "what": label, "calls_in_one_evaluation_plus_setup": calls, "mean_kernel_us": us, "algorithmic_bytes_per_launch": b,
+                                 "achieved": b / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                    break
+        if rows:
+            out[tag] = {"source": "profiles/r06_a_trace_config4_%s_summary.txt (rocprofv3 --kernel-trace --stats; kernel durations, not host timers)" % tag, "kernels": rows}
+    return out or None
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
 
@@ -651,6 +690,9 @@ def main():
                     except Exception as e:
                         out["config4_vecchia_laplace"][pcname + "_preconditioner"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 del m4
+                out["config4_vecchia_laplace"]["roofline_kernels_from_trace"] = laplace_kernel_rooflines(n4, 30)
+                for kk in ("roofline_cg_iteration", "roofline_logdet_iteration"):
+                    out["config4_vecchia_laplace"][kk]["time_source"] = "host timer of the phase / iteration count (all kernels of an iteration + launch gaps); per-kernel figures from kernel durations: roofline_kernels_from_trace"
             except Exception as e:
                 out["config4_vecchia_laplace"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extras:

@@ -272,14 +272,14 @@ class GPModel(object):
         _safe_call(_lib().GPB_GetNumAuxPars(self.handle, ctypes.byref(k)))
         return k.value
 
-    def get_aux_pars(self):
+    def get_aux_pars(self, std_err=False):
         """Auxiliary parameters of the likelihood on the original scale (reference: GPModel.get_aux_pars, basic.py:6372-6400 -> GPB_GetAuxPars);
-        None for likelihoods without any."""
+        None for likelihoods without any.  std_err: their standard deviations behind the values (2 k entries; NaN for a parameter that is not estimated)."""
         k = self.get_num_aux_pars()
         if k == 0:
             return None
-        out = np.empty(k); name = ctypes.create_string_buffer(256)
-        _safe_call(_lib().GPB_GetAuxPars(self.handle, _dptr(out), name, ctypes.c_bool(False)))
+        out = np.empty(k * (2 if std_err else 1)); name = ctypes.create_string_buffer(256)
+        _safe_call(_lib().GPB_GetAuxPars(self.handle, _dptr(out), name, ctypes.c_bool(bool(std_err))))
         return out
 
     def get_coef(self, std_err=False):

@@ -1764,7 +1764,12 @@ int GPB_GetCovPar(REModelHandle handle, double* optim_cov_pars, bool calc_std_de
         }
         if (laplace_upload_fixed_effects(mdl, fel)) return -1;
       }
-      if (gpb_laplace_std_errors(device_laplace, mdl, th, range_const(mdl), se, err, (int)sizeof(err), mdl->optim.estimate_cov_par_index)) {
+      int rc_se;
+      if (mdl->num_aux > 0 && mdl->estimate_aux_pars) {      // the JOINT Hessian over covariance and auxiliary parameters (re_model_template.h:11034-11047)
+        double se_aux[2];
+        rc_se = gpb_laplace_aux_std_errors(device_laplace_aux, mdl, th, mdl->aux_pars, mdl->num_aux, range_const(mdl), se, se_aux, err, (int)sizeof(err), mdl->optim.estimate_cov_par_index);
+      } else rc_se = gpb_laplace_std_errors(device_laplace, mdl, th, range_const(mdl), se, err, (int)sizeof(err), mdl->optim.estimate_cov_par_index);
+      if (rc_se) {
         const char* why = gpb_hip_get_last_error();
         return (why && why[0]) ? set_error("%s: %s", err[0] ? err : "GPB_GetCovPar", why) : set_error("%s", err[0] ? err : "evaluation failed");
       }
@@ -2970,8 +2975,34 @@ int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool c
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl) return set_error("GPB_GetAuxPars: null handle");
   if (mdl->num_aux < 1) { if (out_str) out_str[0] = 0; return 0; }      // no auxiliary parameters: empty name, nothing written (NumAuxPars = 0)
-  if (calc_std_dev) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters are not on the MI355X path of this library");
   if (aux_pars) for (int j = 0; j < mdl->num_aux; ++j) aux_pars[j] = mdl->aux_pars[j];       // REModel::GetAuxPars (re_model.cpp:1364-1405), original scale
+  if (calc_std_dev) {      // round 6: CalculateStandardErrorsAuxPars (re_model_template.h:1894-1909) -> the joint Hessian of CalcStdDevCovParAuxParsNonGaussian; written behind the values
+    C_API_BEGIN();
+    if (!aux_pars) return set_error("GPB_GetAuxPars: aux_pars is NULL");
+    if (!mdl->estimate_aux_pars) return set_error("GPB_GetAuxPars: standard deviations of auxiliary parameters that are not estimated ('estimate_aux_pars' is false)");      // CHECK(estimate_aux_pars_), :1897
+    if (!can_calc_std_dev(mdl)) return set_error("GPB_GetAuxPars: standard deviations need the model's gradient on the MI355X path (one cluster, at most 126 neighbours, coordinate dimensions 1..3)");
+    if (!mdl->cov_pars_initialized || !mdl->y_set) return set_error("GPB_GetAuxPars: standard deviations need the covariance parameters and the response of a fit or an evaluation");
+    {     // the location parameter of the fit: offset + X beta (GetFixedEffectsPtrForStdDevCalc, :1916-1926)
+      const double* fel = mdl->has_offset ? mdl->offset.data() : nullptr;
+      std::vector<double> fe_lin;
+      if (mdl->p_cov > 0 && mdl->coef_estimated) {
+        fe_lin.assign(mdl->n, 0.);
+        for (int i = 0; i < mdl->n; ++i) { double v = fel ? fel[i] : 0.; for (int j = 0; j < mdl->p_cov; ++j) v += mdl->X[(size_t)j * mdl->n + i] * mdl->beta[j]; fe_lin[i] = v; }
+        fel = fe_lin.data();
+      }
+      if (laplace_upload_fixed_effects(mdl, fel)) return -1;
+    }
+    const double th[2] = {mdl->cov_pars_tr[0], mdl->cov_pars_tr[1]};
+    double se_cov[2], se_aux[2] = {0., 0.};
+    char err[512] = "";
+    if (gpb_laplace_aux_std_errors(device_laplace_aux, mdl, th, mdl->aux_pars, mdl->num_aux, range_const(mdl), se_cov, se_aux, err, (int)sizeof(err), mdl->optim.estimate_cov_par_index)) {
+      const char* why = gpb_hip_get_last_error();
+      return (why && why[0]) ? set_error("%s: %s", err[0] ? err : "GPB_GetAuxPars", why) : set_error("%s", err[0] ? err : "evaluation failed");
+    }
+    for (int j = 0; j < mdl->num_aux; ++j) aux_pars[mdl->num_aux + j] = se_aux[j];             // re_model.cpp:1400-1402
+    }   // (C_API_BEGIN's try block)
+    catch (const std::exception& e) { return set_error("%s", e.what()); } catch (...) { return set_error("unknown exception"); }
+  }
   if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : (mdl->likelihood == "lognormal" ? "log_variance" : "shape")));      // lognormal: likelihoods.h:507       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
   return 0;
 }

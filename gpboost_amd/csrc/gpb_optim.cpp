@@ -787,6 +787,156 @@ int gpb_laplace_std_errors(gpb_laplace_fn fn, void* ctx, const double theta[2], 
   return 0;
 }
 
+// The same simplex search for n >= 2 parameters (round 6: covariance + auxiliary parameters of a non-Gaussian likelihood; nm.hpp:95-372 with adaptive_pars: reflection 1,
+// contraction 0.75 - 1 / (2 n), expansion 1 + 2 / n, shrinkage 1 - 1 / n; start simplex x + 0.05 x_i e_i, 0.00025 where x_i = 0).  Same order of evaluations, sorting,
+// centroid of the n best vertices and relative-change measures as nelder_mead_2d.
+template <class F>
+int nelder_mead_nd(F&& f, int n, double* x, const GpbOptimConfig& cfg, double delta, int* num_it, double* fbest) {
+  const double par_alpha = 1.0, par_beta = 0.75 - 1.0 / (2.0 * n), par_gamma = 1.0 + 2.0 / n, par_delta = 1.0 - 1.0 / n;
+  double tol_f, tol_x;
+  if (cfg.convergence_criterion == "relative_change_in_parameters") { tol_x = delta; tol_f = 1e-20; }
+  else { tol_f = delta; tol_x = 1e-20; }
+  const size_t iter_max = (size_t)cfg.max_iter;
+  std::vector<double> fv(n + 1), fv_old(n + 1), pt((size_t)(n + 1) * n), pt_old, cen(n), xr(n), xt(n);
+  auto P = [&](int i) { return pt.data() + (size_t)i * n; };
+  if (f(x, &fv[0])) return -1;
+  std::copy(x, x + n, P(0));
+  for (int i = 1; i < n + 1; ++i) {
+    for (int c = 0; c < n; ++c) P(i)[c] = x[c] + (x[i - 1] != 0.0 ? 0.05 * x[i - 1] : 0.00025) * (c == i - 1 ? 1.0 : 0.0);
+    if (f(P(i), &fv[i])) return -1;
+  }
+  size_t iter = 0;
+  double rel_f = 2 * std::fabs(tol_f), rel_x = 2 * std::fabs(tol_x);
+  fv_old = fv; pt_old = pt;
+  bool has_converged = false;
+  std::vector<size_t> idx(n + 1);
+  while (!has_converged) {
+    ++iter;
+    bool next_iter = false;
+    for (int i = 0; i < n + 1; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return fv[a] < fv[b]; });
+    {
+      std::vector<double> fs(n + 1), ps((size_t)(n + 1) * n);
+      for (int i = 0; i < n + 1; ++i) { fs[i] = fv[idx[i]]; std::copy(P((int)idx[i]), P((int)idx[i]) + n, ps.data() + (size_t)i * n); }
+      fv = fs; pt = ps;
+    }
+    double ft, fr;
+    for (int c = 0; c < n; ++c) { double acc = 0.; for (int i = 0; i < n; ++i) acc += P(i)[c]; cen[c] = acc / (double)n; }
+    for (int c = 0; c < n; ++c) xr[c] = cen[c] + par_alpha * (cen[c] - P(n)[c]);
+    if (f(xr.data(), &fr)) return -1;
+    if (fr >= fv[0] && fr < fv[n - 1]) { std::copy(xr.begin(), xr.end(), P(n)); fv[n] = fr; next_iter = true; }
+    if (!next_iter && fr < fv[0]) {                                   // expansion
+      for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_gamma * (xr[c] - cen[c]);
+      if (f(xt.data(), &ft)) return -1;
+      if (ft < fr) { std::copy(xt.begin(), xt.end(), P(n)); fv[n] = ft; } else { std::copy(xr.begin(), xr.end(), P(n)); fv[n] = fr; }
+      next_iter = true;
+    }
+    if (!next_iter && fr >= fv[n - 1]) {
+      if (fr < fv[n]) {                                               // outside contraction
+        for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_beta * (xr[c] - cen[c]);
+        if (f(xt.data(), &ft)) return -1;
+        if (ft <= fr) { std::copy(xt.begin(), xt.end(), P(n)); fv[n] = ft; next_iter = true; }
+      } else {                                                        // inside contraction
+        for (int c = 0; c < n; ++c) xt[c] = cen[c] + par_beta * (P(n)[c] - cen[c]);
+        if (f(xt.data(), &ft)) return -1;
+        if (ft < fv[n]) { std::copy(xt.begin(), xt.end(), P(n)); fv[n] = ft; next_iter = true; }
+      }
+    }
+    if (!next_iter) {                                                 // shrink towards the best vertex
+      for (int i = 1; i < n + 1; ++i) for (int c = 0; c < n; ++c) P(i)[c] = P(0)[c] + par_delta * (P(i)[c] - P(0)[c]);
+      for (int i = 1; i < n + 1; ++i) if (f(P(i), &fv[i])) return -1;
+    }
+    double num = 0., den = 0.;
+    for (int i = 0; i < n + 1; ++i) { num = std::max(num, std::fabs(fv[i] - fv_old[i])); den = std::max(den, std::fabs(fv_old[i])); }
+    rel_f = num / (1.0e-08 + den);
+    fv_old = fv;
+    if (tol_x >= 0.0) {
+      num = 0.; den = 0.;
+      for (size_t e = 0; e < pt.size(); ++e) { num = std::max(num, std::fabs(pt[e] - pt_old[e])); den = std::max(den, std::fabs(pt_old[e])); }
+      rel_x = num / (1.0e-08 + den);
+      pt_old = pt;
+    }
+    has_converged = !(rel_f > tol_f && rel_x > tol_x && iter < iter_max);
+  }
+  int best = 0;
+  for (int i = 1; i < n + 1; ++i) if (fv[i] < fv[best]) best = i;
+  std::copy(P(best), P(best) + n, x);
+  if (f(x, fbest)) return -1;                                         // settings->opt_fn_value = opt_objfn(x_p) (error_reporting)
+  *num_it = (int)iter;
+  return 0;
+}
+
+// Standard errors of covariance AND auxiliary parameters of a non-Gaussian model whose auxiliary parameters are estimated (round 6):
+// CalcStdDevCovParAuxParsNonGaussian (include/GPBoost/re_model_template.h:11029-11117) over the vector (sigma1_2, a, aux_1 .. aux_naux) -- the Hessian wrt the logs as the
+// numerical Jacobian of the gradient (CalcHessianCovParAuxPars :10915-10968: central differences, step |log p| 1e-4, at least 1e-4; symmetrised), the sub-matrix of the
+// ESTIMATED parameters (covariance parameters by estimate_cov_par_index, an auxiliary parameter iff its diagonal entry is > 0: the df of "t_fix_df" has a zero
+// gradient, :11059-11067) inverted by Cholesky, delta method back to the original scale with the reference's finite-difference derivative (:10977-11027: p sinh(h) / h,
+// h = eps^(1/3)).  The evaluator's state is restored at (theta, aux) afterwards (:11048-11051).  NaN where no standard error exists.
+int gpb_laplace_aux_std_errors(gpb_laplace_aux_fn fn, void* ctx, const double theta[2], const double* aux, int naux, double range_const, double se_cov[2],
+                               double* se_aux, char* err, int errlen, const int* estimated2) {
+  const Fail fail{err, errlen};
+  if (err && errlen > 0) err[0] = 0;
+  if (!fn || !theta || !aux || !se_cov || !se_aux || naux < 1 || naux > 6) return fail("gpb_laplace_aux_std_errors: invalid argument");
+  const int N = 2 + naux;
+  std::vector<double> p0(N), H((size_t)N * N, 0.), delta(N), out(3 + naux), g1(N), g2(N);
+  p0[0] = theta[0]; p0[1] = theta[1];
+  for (int j = 0; j < naux; ++j) p0[2 + j] = aux[j];
+  for (int i = 0; i < N; ++i) if (!(p0[i] > 0.)) return fail("Parameters need to be positive for their standard deviations (found %g)", p0[i]);
+  const double h_eps = 1e-4;                                                  // :11047
+  for (int i = 0; i < N; ++i) { delta[i] = std::fabs(std::log(p0[i])) * h_eps; if (delta[i] < h_eps) delta[i] = h_eps; }
+  auto eval_grad = [&](const std::vector<double>& p, std::vector<double>& g) -> int {
+    if (fn(ctx, 1, p[0], p[1], p.data() + 2, naux, out.data())) { if (err && !err[0]) snprintf(err, errlen, "likelihood evaluation failed while calculating standard deviations"); return -1; }
+    for (int j = 0; j < N; ++j) g[j] = out[1 + j];
+    return 0;
+  };
+  for (int i = 0; i < N; ++i) {
+    std::vector<double> pa = p0, pb = p0;
+    pa[i] *= std::exp(delta[i]); pb[i] *= std::exp(-delta[i]);
+    if (eval_grad(pa, g1) || eval_grad(pb, g2)) return -1;
+    for (int j = 0; j < N; ++j) H[(size_t)i * N + j] = (g1[j] - g2[j]) / (2. * delta[i]);
+  }
+  if (fn(ctx, 0, p0[0], p0[1], p0.data() + 2, naux, out.data())) { if (err && !err[0]) snprintf(err, errlen, "likelihood evaluation failed while calculating standard deviations"); return -1; }
+  for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) { const double v = 0.5 * (H[(size_t)i * N + j] + H[(size_t)j * N + i]); H[(size_t)i * N + j] = H[(size_t)j * N + i] = v; }
+  std::vector<int> est;
+  for (int i = 0; i < 2; ++i) if (!estimated2 || estimated2[i] > 0) est.push_back(i);
+  for (int j = 0; j < naux; ++j) if (H[(size_t)(2 + j) * N + 2 + j] > 0.) est.push_back(2 + j);
+  const double nan_value = std::numeric_limits<double>::quiet_NaN();
+  std::vector<double> inv_diag(N, nan_value);
+  const int E = (int)est.size();
+  if (E > 0) {
+    std::vector<double> L((size_t)E * E, 0.);
+    bool pd = true;
+    for (int i = 0; i < E && pd; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double acc = H[(size_t)est[i] * N + est[j]];
+        for (int k = 0; k < j; ++k) acc -= L[(size_t)i * E + k] * L[(size_t)j * E + k];
+        if (i == j) { if (!(acc > 0.) || !std::isfinite(acc)) { pd = false; break; } L[(size_t)i * E + i] = std::sqrt(acc); }
+        else L[(size_t)i * E + j] = acc / L[(size_t)j * E + j];
+      }
+    if (pd) {
+      std::vector<double> col(E);
+      for (int c = 0; c < E; ++c) {            // (H^-1)_cc = || L^-1 e_c ||^2
+        double ss = 0.;
+        for (int i = 0; i < E; ++i) {
+          double acc = i == c ? 1. : 0.;
+          for (int k = 0; k < i; ++k) acc -= L[(size_t)i * E + k] * col[k];
+          col[i] = i < c ? 0. : acc / L[(size_t)i * E + i];
+          ss += col[i] * col[i];
+        }
+        inv_diag[est[c]] = ss;
+      }
+    } else {
+      fprintf(stderr, "[gpboost_amd] Warning: Cannot calculate standard deviations for covariance / auxiliary parameters since the approximated Hessian is not positive definite \n");
+    }
+  }
+  const double h = std::pow(std::numeric_limits<double>::epsilon(), 1.0 / 3.0);
+  const double fd = (std::exp(h) - std::exp(-h)) / (2. * h);       // d p / d log p by the reference's central difference
+  const double orig[2] = {theta[0], range_const / theta[1]};       // sigma1_2 itself; rho = c / a: |d rho / d log a| = rho
+  for (int i = 0; i < 2; ++i) se_cov[i] = (std::isfinite(inv_diag[i]) && inv_diag[i] >= 0.) ? std::fabs(orig[i] * fd) * std::sqrt(inv_diag[i]) : nan_value;
+  for (int j = 0; j < naux; ++j) se_aux[j] = (std::isfinite(inv_diag[2 + j]) && inv_diag[2 + j] >= 0.) ? std::fabs(aux[j] * fd) * std::sqrt(inv_diag[2 + j]) : nan_value;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Non-Gaussian likelihoods with a linear predictor: lbfgs on (log sigma1_2, log a, beta).  The same solver as run_lbfgs_laplace (LBFGSSolver::minimize,
 // LineSearchBacktracking, BFGSMat of GPBoost's LBFGSpp copy) for a vector of length 2 + p; GetMaximalLearningRate (optim_utils.h:498-535) caps the step
@@ -1020,8 +1170,41 @@ int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux
   if (!(theta_init[0] > 0.) || !(theta_init[1] > 0.))
     return fail("Initial covariance parameters need to be positive (found %g, %g on the transformed scale)", theta_init[0], theta_init[1]);
   for (int j = 0; j < naux; ++j) if (!(aux[j] > 0.)) return fail("Initial auxiliary parameters need to be positive (found %g)", aux[j]);
-  if (cfg.optimizer != "lbfgs")
-    return fail("optimizer_cov = '%s' for a likelihood with estimated auxiliary parameters is not on the MI355X path of this library (supported: 'lbfgs', the reference's default)", cfg.optimizer.c_str());
+  if (cfg.optimizer != "lbfgs" && cfg.optimizer != "nelder_mead")
+    return fail("optimizer_cov = '%s' for a likelihood with estimated auxiliary parameters is not on the MI355X path of this library (supported: 'lbfgs', the reference's default, and 'nelder_mead')", cfg.optimizer.c_str());
+  if (cfg.optimizer == "nelder_mead") {
+    // round 6: OptimLib's simplex search over (log sigma1_2, log a, log aux_1 ..) -- EvalLLforOptimLib with EstimateAuxPars() (optim_utils.h:61-213: SetAuxPars(exp(tail)) at
+    // every evaluation), likelihood evaluations only; an evaluator error at a trial vertex counts as +Inf there and the mode goes back (as run_nelder_mead_laplace)
+    *out = GpbLaplaceAuxResult();
+    std::vector<double> xn(2 + naux), o(3 + naux), av(naux);
+    xn[0] = std::log(theta_init[0]); xn[1] = std::log(theta_init[1]);
+    for (int j = 0; j < naux; ++j) xn[2 + j] = std::log(aux[j]);
+    int n_ok = 0, n_evals = 0;
+    auto f = [&](const double* xv, double* fv) -> int {
+      for (int j = 0; j < naux; ++j) av[j] = std::exp(xv[2 + j]);
+      ++n_evals;
+      if (fn(ctx, 0, std::exp(xv[0]), std::exp(xv[1]), av.data(), naux, o.data())) {
+        if (n_ok == 0) return -1;
+        *fv = INFINITY;
+        return fn(ctx, 3, 0., 0., av.data(), naux, o.data()) ? -1 : 0;
+      }
+      ++n_ok;
+      *fv = o[0];
+      if (!std::isfinite(*fv) && fn(ctx, 3, 0., 0., av.data(), naux, o.data())) return -1;
+      return 0;
+    };
+    double fx = 1e99;
+    if (cfg.max_iter > 0) {
+      const double delta = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-8;
+      if (nelder_mead_nd(f, 2 + naux, xn.data(), cfg, delta, &out->num_it, &fx)) { if (err && !err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation"); return -1; }
+      for (double v : xn) if (!std::isfinite(v)) return fail("NaN or Inf occurred in covariance parameter optimization using 'nelder_mead'; try other initial values");
+      if (!std::isfinite(fx)) return fail("NaN or Inf occurred in covariance parameter optimization using 'nelder_mead'; try other initial values");
+    }
+    out->theta[0] = std::exp(xn[0]); out->theta[1] = std::exp(xn[1]);
+    for (int j = 0; j < naux; ++j) aux[j] = std::exp(xn[2 + j]);
+    out->negll = fx; out->num_evals = n_evals;
+    return 0;
+  }
   LapCoefState st{nullptr, ctx, 0, 0, nullptr, nullptr, 1., 1., std::vector<double>(), std::vector<double>()};
   st.afn = fn; st.naux = naux; st.nc = 2;
   std::vector<double> x(2 + naux);

@@ -143,6 +143,11 @@ struct GpbLaplaceAuxResult {
 int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux_fn fn, void* ctx, int naux, const double theta_init[2], double* aux,
                                       GpbLaplaceAuxResult* out, char* err, int errlen);
 
+// Standard errors of the covariance and the auxiliary parameters of such a model from the JOINT numerical Hessian (CalcStdDevCovParAuxParsNonGaussian,
+// re_model_template.h:11029-11117): 2 (2 + naux) evaluations with gradient + one to restore the state; NaN where none exists (parameter not estimated, Hessian not positive definite).
+int gpb_laplace_aux_std_errors(gpb_laplace_aux_fn fn, void* ctx, const double theta[2], const double* aux, int naux, double range_const, double se_cov[2],
+                               double* se_aux, char* err, int errlen, const int* estimated2 = nullptr);
+
 // Standard errors of the regression coefficients of a non-Gaussian model: CalcStdDevCoefNonGaussian (include/GPBoost/re_model_template.h:10851-10897) --
 // Hessian wrt beta as the numerical Jacobian of X' grad_F (central differences, step beta_i eps^(1/3), at least eps^(1/3)), symmetrised, Cholesky
 // inverse, sqrt of its diagonal ("(very) approximate", as the reference says).  X: ORIGINAL covariates (column-major n x p), beta on that scale.

@@ -342,6 +342,37 @@ def laplace_pred_refresh(out_dir):
         np.savez_compressed(path, **res)
 
 
+def laplace_aux_se_fixture(out_dir):
+    """Round 6: standard deviations of covariance AND auxiliary parameters of non-Gaussian models whose auxiliary parameters are estimated (GPB_GetCovPar / GPB_GetAuxPars with
+    calc_std_dev = true -> CalcStdDevCovParAuxParsNonGaussian, re_model_template.h:11029-11117: joint numerical Hessian at step 1e-4) after an lbfgs fit at cases.LAPLACE_TIGHT,
+    by the unmodified reference -- tests/golden/laplace_aux_se_ref.npz: <case>_cov_pars (values, standard deviations), <case>_aux (values, standard deviations), <case>_num_it."""
+    res = {}
+    jobs = [("gamma_n1500", cases.LAPLACE_AUX_CASES["gamma_n1500"], cases.make_aux_data, "gamma", 1, {}),
+            ("t_n1500", cases.LAPLACE_T_CASES["t_n1500"], cases.make_t_data, "t", 2, {}),
+            ("t_fix_df5_n1500", cases.LAPLACE_T_CASES["t_n1500"], cases.make_t_data, "t_fix_df", 2, dict(likelihood_additional_param=5.0))]
+    for name, cs, make, lik, naux, extra in jobs:
+        c = cases.LAPLACE_CASES[cs["model"]]
+        coords, y = make(cs)
+        args = (c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+        m2 = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=lik, **extra)
+        m2.set_optim_config(estimate_aux_pars=True, **cases.LAPLACE_TIGHT)
+        m2.optim_cov_par(y)
+        res[name + "_num_it"] = np.int32(m2.get_num_it())
+        res[name + "_cov_pars"] = m2.get_cov_par(2, std_dev=True)
+        res[name + "_aux"] = m2.get_aux_pars(naux, std_dev=True)
+        print("aux std devs", name, res[name + "_num_it"], res[name + "_cov_pars"], res[name + "_aux"], flush=True)
+    # optimizer_cov = "nelder_mead" with the auxiliary parameter in the simplex (OptimLib nm.hpp over (log sigma1^2, log a, log shape), EvalLLforOptimLib): gamma_n1500 at cases.LAPLACE_TIGHT
+    ac = cases.LAPLACE_AUX_CASES["gamma_n1500"]; c = cases.LAPLACE_CASES[ac["model"]]
+    coords, y = cases.make_aux_data(ac)
+    m3 = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood="gamma")
+    m3.set_optim_config(estimate_aux_pars=True, optimizer_cov="nelder_mead", **cases.LAPLACE_TIGHT)
+    m3.optim_cov_par(y)
+    res["gamma_n1500_nm_cov_pars"] = m3.get_cov_par(2); res["gamma_n1500_nm_aux"] = m3.get_aux_pars(1)
+    res["gamma_n1500_nm_num_it"] = np.int32(m3.get_num_it()); res["gamma_n1500_nm_negll"] = np.float64(m3.current_neg_log_likelihood())
+    print("nelder_mead with the shape in the simplex", res["gamma_n1500_nm_cov_pars"], res["gamma_n1500_nm_aux"], res["gamma_n1500_nm_num_it"], "%.10f" % res["gamma_n1500_nm_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_aux_se_ref.npz"), **res)
+
+
 def laplace_t_fixdf_fixture(out_dir):
     """Round 6: likelihood "t_fix_df" (Student-t with the degrees of freedom held at likelihood_additional_param, only the scale estimated: estimate_df_t_ = false,
     likelihoods.h:384-407, :10466-10471, :16179-16183) by the unmodified reference -- tests/golden/laplace_t_fixdf_ref.npz, on cases.LAPLACE_T_CASES["t_n1500"]'s data:
@@ -1285,6 +1316,8 @@ if __name__ == "__main__":
         laplace_t_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pred_refresh":
         laplace_pred_refresh(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux_se":
+        laplace_aux_se_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_t_fixdf":
         laplace_t_fixdf_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":

@@ -456,6 +456,20 @@ int refdrv_laplace_nll_grad(void* h, const double* y, const double* cov_pars_ori
   }
 }
 
+/* Newton iterations of the LAST mode finding of a non-Gaussian model (Likelihood::num_it_mode_finding_, likelihoods.h:1298, :3984): the reference's own count,
+ * to set beside the device path's (round 6, VERDICT r05 #7: are the 16 Newton steps of the t likelihood at config 4's size the reference's?) */
+__attribute__((visibility("default")))
+int refdrv_num_it_mode_finding(void* h) {
+  try {
+    auto* t = reinterpret_cast<REModel*>(h)->re_model_den_.get();
+    if (!t) return -1;
+    return t->likelihood_[t->unique_clusters_[0]]->num_it_mode_finding_;
+  } catch (std::exception& e) {
+    fprintf(stderr, "refdrv_num_it_mode_finding: %s\n", e.what());
+    return -1;
+  }
+}
+
 /* ---- full-scale Vecchia ("VIF"), Gaussian likelihood: the reference's own REModel with gp_approx = "full_scale_vecchia" ----
  * refdrv_nll_grad works on such a handle unchanged (CalcGradPars dispatches to CalcGradPars_FITC_FSA_GaussLikelihood_Cluster_i,
  * include/GPBoost/re_model_template.h:2205-2330); the two functions below expose what its public API does not: the inducing points

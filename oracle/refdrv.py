@@ -175,13 +175,13 @@ class RefCAPIModel(object):
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
 
-    def get_aux_pars(self, num=1):
-        """GPB_GetAuxPars (c_api.h:1804-1807) -> the first `num` auxiliary parameters (original scale)."""
-        out = np.zeros(max(num, 1)); name = C.create_string_buffer(256)
-        rc = self.L.GPB_GetAuxPars(self.h, _P(out), name, C.c_bool(False))
+    def get_aux_pars(self, num=1, std_dev=False):
+        """GPB_GetAuxPars (c_api.h:1804-1807) -> the first `num` auxiliary parameters (original scale); std_dev: followed by their `num` standard deviations."""
+        out = np.zeros(max(num, 1) * 2); name = C.create_string_buffer(256)
+        rc = self.L.GPB_GetAuxPars(self.h, _P(out), name, C.c_bool(bool(std_dev)))
         if rc != 0:
             raise RuntimeError(self.L.LGBM_GetLastError().decode())
-        return out[:num].copy()
+        return out[:num * (2 if std_dev else 1)].copy()
 
     def get_init_aux_pars(self, num=1):
         """GPB_GetInitAuxPars (c_api.h:1824-1825)."""

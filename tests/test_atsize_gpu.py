@@ -165,6 +165,41 @@ def test_config4_n1e5_pivoted_cholesky_against_the_reference(gpb):
     assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
 
 
+@pytest.mark.parametrize("lik", ["lognormal", "gamma", "t"])
+def test_auxiliary_parameter_likelihoods_at_config4_size_against_the_reference(gpb, lik):
+    """Round 6: the likelihoods with auxiliary parameters at BASELINE config 4's size (n = 1e5, m = 30; smooth latent surface, response drawn from the
+    likelihood -- the data of scripts/gpu_r6_targets.py aux:<lik>) against ONE fresh evaluation of the unmodified reference per threshold set
+    (tests/golden/config4_size_aux_ref.json, scripts/ref_newton_counts.py: value and Likelihood::num_it_mode_finding_): the value at cg_delta_conv = 1e-6 to 1e-8, at the
+    defaults to 1e-6 (defined up to one CG / Lanczos iteration, as config 4 itself), and the NEWTON ITERATION COUNT of the mode finding equal to the reference's -- the 16-18
+    Newton steps of the t likelihood (2.2 s per evaluation) are the reference's own on these data, not a different warm start or step capping."""
+    import json
+    path = os.path.join(GOLD, "config4_size_aux_ref.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/config4_size_aux_ref.json has not been generated")
+    ref = json.load(open(path))
+    if lik + "_tight" not in ref:
+        pytest.skip("no reference values for " + lik)
+    n, m = 100000, 30
+    rng = np.random.default_rng(7)
+    cc = rng.uniform(size=(n, 2))
+    eta = np.sin(4 * cc[:, 0]) + np.cos(3 * cc[:, 1])
+    if lik == "t":
+        y = 0.8 * eta + 0.35 * rng.standard_t(4.0, size=n)
+    elif lik == "gamma":
+        y = rng.gamma(2.0, np.exp(0.5 * eta) / 2.0)
+    else:
+        y = np.exp(0.5 * eta + np.sqrt(0.2) * rng.standard_normal(n))
+    for key, tol in (("default", 1e-6), ("tight", RTOL)):
+        mdl = gpb.GPModel(likelihood=lik, gp_coords=cc, cov_function="exponential", gp_approx="vecchia", num_neighbors=m, vecchia_ordering="random", seed=1)
+        if ref[lik + "_" + key]["thresholds"]:
+            mdl.set_optim_params(dict(ref[lik + "_" + key]["thresholds"]))
+        v = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+        info = mdl.laplace_info()
+        r = ref[lik + "_" + key]
+        assert abs(v - r["negll"]) <= tol * abs(r["negll"]), (key, v, r["negll"], info)
+        assert int(info["newton_it"]) == int(r["newton_it"]), (key, info["newton_it"], r["newton_it"])
+
+
 def test_config3_shape_tree_with_categorical_columns_equals_the_oracle_tree(gpb, orc):
     """Round 5, at BASELINE config 3's shape (n = 1e5 rows, 50 columns, 255 bins, 31 leaves) with 6 of the columns categorical (12 / 100 / 250 categories): the
     device's whole-tree grower (categorical search, bitset partitions, resident row lists) against the oracle's primitives driven by tests/tree_harness.py -- the

@@ -178,3 +178,47 @@ def test_model_api_t_with_fixed_df_follows_the_reference(gpb):
         gpb.GPModel(likelihood="gamma", likelihood_additional_param=2.0, **kw)
     with pytest.raises(gpb.GPBoostError):
         gpb.GPModel(likelihood="t", likelihood_additional_param=-1.0, **kw)
+
+
+@pytest.mark.parametrize("name", ["gamma_n1500", "t_n1500", "t_fix_df5_n1500"])
+def test_model_api_standard_deviations_of_auxiliary_parameters_follow_the_reference(gpb, name):
+    """Round 6: GPB_GetAuxPars(calc_std_dev = true) and GPB_GetCovPar(calc_std_dev = true) of a model whose auxiliary parameters are estimated -- the joint numerical
+    Hessian of CalcStdDevCovParAuxParsNonGaussian (re_model_template.h:11029-11117) on the device gradient -- after the lbfgs fit, against the unmodified reference
+    (tests/golden/laplace_aux_se_ref.npz, oracle/make_golden.py laplace_aux_se).  The Hessian differences gradients that each carry the stochastic trace estimate and the CG's
+    stopping error over a step of 1e-4, so the standard deviations agree to 1e-3 (estimates 1e-6); the df of "t_fix_df" have none (NaN), as in the reference."""
+    g = np.load(os.path.join(GOLD, "laplace_aux_se_ref.npz"))
+    if name.startswith("gamma"):
+        cs = cases.LAPLACE_AUX_CASES[name]; coords, y = cases.make_aux_data(cs); lik, extra = "gamma", {}
+    else:
+        cs = cases.LAPLACE_T_CASES["t_n1500"]; coords, y = cases.make_t_data(cs)
+        lik, extra = ("t_fix_df", dict(likelihood_additional_param=5.0)) if "fix" in name else ("t", {})
+    c = cases.LAPLACE_CASES[cs["model"]]
+    mdl = gpb.GPModel(likelihood=lik, gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"],
+                      vecchia_ordering=c["ordering"], seed=c["seed"], **extra)
+    mdl.fit(y, params=dict(cases.LAPLACE_TIGHT))
+    assert mdl.get_num_optim_iter() == int(g[name + "_num_it"])
+    cov = mdl.get_cov_pars(std_err=True); aux = mdl.get_aux_pars(std_err=True)
+    rc, ra = g[name + "_cov_pars"], g[name + "_aux"]
+    k = len(ra) // 2
+    np.testing.assert_allclose(cov[:2], rc[:2], rtol=1e-6)
+    np.testing.assert_allclose(aux[:k], ra[:k], rtol=1e-6)
+    np.testing.assert_allclose(cov[2:], rc[2:], rtol=1e-3)
+    assert np.array_equal(np.isnan(aux[k:]), np.isnan(ra[k:])), (aux, ra)
+    ok = ~np.isnan(ra[k:])
+    np.testing.assert_allclose(aux[k:][ok], ra[k:][ok], rtol=1e-3)
+
+
+def test_model_api_nelder_mead_with_an_estimated_auxiliary_parameter_follows_the_reference(gpb):
+    """Round 6: optimizer_cov = "nelder_mead" for a likelihood whose auxiliary parameter is estimated -- OptimLib's simplex search over (log sigma1^2, log a, log shape),
+    likelihood evaluations only (optim_utils.h:61-213, nm.hpp:95-372) -- on gamma_n1500 at cases.LAPLACE_TIGHT: the reference's iteration count, estimates 1e-6, value 1e-8."""
+    g = np.load(os.path.join(GOLD, "laplace_aux_se_ref.npz"))
+    ac = cases.LAPLACE_AUX_CASES["gamma_n1500"]; c = cases.LAPLACE_CASES[ac["model"]]
+    coords, y = cases.make_aux_data(ac)
+    mdl = gpb.GPModel(likelihood="gamma", gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"],
+                      vecchia_ordering=c["ordering"], seed=c["seed"])
+    mdl.fit(y, params=dict(cases.LAPLACE_TIGHT, optimizer_cov="nelder_mead"))
+    assert mdl.get_num_optim_iter() == int(g["gamma_n1500_nm_num_it"]), (mdl.get_num_optim_iter(), int(g["gamma_n1500_nm_num_it"]))
+    np.testing.assert_allclose(mdl.get_cov_pars(), g["gamma_n1500_nm_cov_pars"], rtol=1e-6)
+    np.testing.assert_allclose(mdl.get_aux_pars(), g["gamma_n1500_nm_aux"], rtol=1e-6)
+    nll = mdl.get_current_neg_log_likelihood(); ref = float(g["gamma_n1500_nm_negll"])
+    assert abs(nll - ref) <= 1e-8 * abs(ref), (nll, ref)
