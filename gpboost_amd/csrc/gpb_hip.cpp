@@ -2050,6 +2050,26 @@ int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, const int32_t* leaf
   API_END();
 }
 
+// The stream of the look-ahead ("REST") updates of the blocked Cholesky (dense_kernels.hip: launch_dense_cholesky).  Round 6: it is created with a CU MASK that leaves a few
+// compute units to the panel chain on the main stream.  A REST update is one 128 x 128 tile per workgroup with 139 KB of LDS -- one workgroup per CU, ~55 us each --, so without the
+// mask its grid occupies every CU and each of the ~24 small launches of a block column's panel chain (diagonal block, panel solve, narrow update) waits for a workgroup to retire
+// before it can start: the two streams ran one after the other in effect (MFMA-busy 0.43).  GPB_DENSE_RESERVED_CUS (default 32; 0 = no mask) CUs stay free of REST workgroups.
+static hipError_t create_lookahead_stream(hipStream_t* out) {
+  int reserved = 32;
+  if (const char* e = getenv("GPB_DENSE_RESERVED_CUS")) reserved = atoi(e);
+  int ncu = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+  if (reserved > 0 && ncu > 2 * reserved) {
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    // the reserved CUs are spread evenly over the index range (the runtime's CU numbering interleaves the XCDs: every XCD gives some)
+    const int stride = ncu / reserved;
+    for (int c = 0; c < ncu; ++c) if (!(c % stride == 0 && c / stride < reserved)) mask[c / 32] |= 1u << (c % 32);
+    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 // ------------------------------------------------------------------------------------------
 int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gpb_hip_exact_t** out) {
   API_BEGIN();
@@ -2138,7 +2158,7 @@ int gpb_hip_exact_nll_terms(gpb_hip_exact_t* h, int cov_type, double var, double
   HIP_OK(gpb::launch_dense_set_yrow(h->d_P, h->n, h->np, ld, h->d_y, h->stream));
   HIP_OK(hipEventRecord(e[1], h->stream));
   if (!h->stream2) {
-    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(create_lookahead_stream(&h->stream2));
     HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
   }
@@ -2181,7 +2201,7 @@ int gpb_hip_exact_grad_terms(gpb_hip_exact_t* h, int cov_type, double var, doubl
     HIP_OK(hipMalloc(&h->d_g4, sizeof(double) * 8));
   }
   if (!h->stream2) {
-    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(create_lookahead_stream(&h->stream2));
     HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
   }
@@ -2225,7 +2245,7 @@ int gpb_hip_exact_psi_inv_diag(gpb_hip_exact_t* h, int cov_type, double var, dou
     HIP_OK(hipMalloc(&h->d_g4, sizeof(double) * 8));
   }
   if (!h->stream2) {
-    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(create_lookahead_stream(&h->stream2));
     HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
   }
@@ -2271,7 +2291,7 @@ int gpb_hip_exact_predict(gpb_hip_exact_t* h, int cov_type, double var, double a
   }
   HIP_OK(hipMemcpyAsync(b.pred, pp.data(), sizeof(double4) * (size_t)n_pred, hipMemcpyHostToDevice, h->stream));
   if (!h->stream2) {
-    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(create_lookahead_stream(&h->stream2));
     HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
   }
@@ -2315,7 +2335,7 @@ int gpb_hip_exact_fisher_std_errors(gpb_hip_exact_t* h, int cov_type, double sig
   HIP_OK(hipMalloc(&b.part, sizeof(double) * 6 * (size_t)ntiles));
   HIP_OK(hipMalloc(&b.t6, sizeof(double) * 8));
   if (!h->stream2) {
-    HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_OK(create_lookahead_stream(&h->stream2));
     HIP_OK(hipEventCreateWithFlags(&h->ev_panels, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
   }
