@@ -2050,25 +2050,11 @@ int gpb_hip_vecchia_newton_leaf_values(gpb_hip_vecchia_t* h, const int32_t* leaf
   API_END();
 }
 
-// The stream of the look-ahead ("REST") updates of the blocked Cholesky (dense_kernels.hip: launch_dense_cholesky).  Round 6: it is created with a CU MASK that leaves a few
-// compute units to the panel chain on the main stream.  A REST update is one 128 x 128 tile per workgroup with 139 KB of LDS -- one workgroup per CU, ~55 us each --, so without the
-// mask its grid occupies every CU and each of the ~24 small launches of a block column's panel chain (diagonal block, panel solve, narrow update) waits for a workgroup to retire
-// before it can start: the two streams ran one after the other in effect (MFMA-busy 0.43).  GPB_DENSE_RESERVED_CUS (default 32; 0 = no mask) CUs stay free of REST workgroups.
-static hipError_t create_lookahead_stream(hipStream_t* out) {
-  int reserved = 32;
-  if (const char* e = getenv("GPB_DENSE_RESERVED_CUS")) reserved = atoi(e);
-  int ncu = 0, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
-  if (reserved > 0 && ncu > 2 * reserved) {
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    // the reserved CUs are spread evenly over the index range (the runtime's CU numbering interleaves the XCDs: every XCD gives some)
-    const int stride = ncu / reserved;
-    for (int c = 0; c < ncu; ++c) if (!(c % stride == 0 && c / stride < reserved)) mask[c / 32] |= 1u << (c % 32);
-    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
-    (void)hipGetLastError();
-  }
-  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
+// The stream of the look-ahead ("REST") updates of the blocked Cholesky (dense_kernels.hip: launch_dense_cholesky).
+// Round 6, measured and NOT adopted (profiles/r06_f_dense_cholesky_cu_mask_not_adopted.log): creating it with a CU mask (hipExtStreamCreateWithCUMask) that leaves 16 compute
+// units to the panel chain on the main stream -- a REST update is one 128 x 128 tile per workgroup with 139 KB of LDS, ~55 us each, so its grid occupies every CU and the ~24 small
+// launches of a block column's panel chain queue behind it -- made the n = 16 384 factorisation SLOWER, 65.0 against 43.9 ms (masks of 32 / 64 CUs were not honoured: 43.9 ms).
+static hipError_t create_lookahead_stream(hipStream_t* out) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 
 // ------------------------------------------------------------------------------------------
 int gpb_hip_exact_create(int32_t n, int32_t d, const double* coords_colmajor, gpb_hip_exact_t** out) {
