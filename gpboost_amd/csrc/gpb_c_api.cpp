@@ -1062,8 +1062,10 @@ struct LaplaceCoefSetup {
 // intercept detection (:1114-1133), scaling of the covariates (:1218-1242), initial coefficients (:1243-1275: zeros, or init_coef transformed; without
 // init_coef the intercept starts at Likelihood::FindInitialIntercept, likelihoods.h:1455-1540) and the constants of the step cap
 // (FindConstantsCapTooLargeLearningRateCoef, likelihoods.h:2618-2664).  init_var = total variance of the random effects at the initial parameters.
+// w (round 6): the sample weights in DATA order (GetWeightsAllClusters, re_model_template.h:8385-8399), or nullptr: they weight the start of the intercept
+// (FindInitialIntercept, likelihoods.h:1455-1560) and the constants of the step cap (FindConstantsCapTooLargeLearningRateCoef, :2618-2660); the scaling of the covariates does not use them
 int laplace_coef_setup(const std::string& lik, int n, int p, const double* X, const double* y, const double* fixed_effects, double init_var,
-                       const double* init_coef, LaplaceCoefSetup* s) {
+                       const double* init_coef, LaplaceCoefSetup* s, const double* w = nullptr) {
   s->n = n; s->p = p;
   s->Xs.assign(X, X + (size_t)n * p);
   for (int j = 0; j < p && !s->has_intercept; ++j) {
@@ -1103,24 +1105,24 @@ int laplace_coef_setup(const std::string& lik, int n, int p, const double* X, co
     if (!(init_var > 0.)) return set_error("GPB_OptimLinRegrCoefCovPar: the initial marginal variance must be positive");
     double b0;
     if (lik == "bernoulli_logit" || lik == "bernoulli_probit") {
-      double sy = 0.;
-      for (int i = 0; i < n; ++i) sy += y[i];
-      double pavg = sy > 0. ? sy / n : 0.5;
+      double sy = 0., sw = 0.;
+      for (int i = 0; i < n; ++i) { const double wi = w ? w[i] : 1.0; sy += wi * y[i]; sw += wi; }
+      double pavg = (sy > 0. && sw > 0.) ? sy / sw : 0.5;
       pavg = std::min(std::max(pavg, 1e-12), 1. - 1e-12);
       b0 = lik == "bernoulli_logit" ? std::log(pavg) - std::log1p(-pavg) : normal_quantile(pavg);
       b0 = std::min(std::max(b0, -3.0), 3.0);
     } else if (lik == "poisson") {
-      double avg = 0.;
-      for (int i = 0; i < n; ++i) avg += fixed_effects ? y[i] / std::exp(fixed_effects[i]) : y[i];
-      avg = std::max(avg / n, 1e-12);
+      double avg = 0., sw = 0.;
+      for (int i = 0; i < n; ++i) { const double wi = w ? w[i] : 1.0; avg += wi * (fixed_effects ? y[i] / std::exp(fixed_effects[i]) : y[i]); sw += wi; }
+      avg = std::max(avg / sw, 1e-12);
       b0 = std::log(avg) - 0.5 * init_var;
     } else return set_error("GPB_OptimLinRegrCoefCovPar: likelihood '%s' is not on the MI355X hot path of this library", lik.c_str());
     s->beta[s->intercept_col] = b0;
   }
   if (lik == "poisson") {
-    double mean = 0., sec = 0.;
-    for (int i = 0; i < n; ++i) { mean += y[i]; sec += y[i] * y[i]; }
-    mean /= n; sec /= n;
+    double mean = 0., sec = 0., sw = 0.;
+    for (int i = 0; i < n; ++i) { const double wi = w ? w[i] : 1.0; mean += wi * y[i]; sec += wi * y[i] * y[i]; sw += wi; }
+    mean /= sw; sec /= sw;
     const double var = sec - mean * mean;
     s->C_mu = std::fabs(mean > 0. ? std::log(mean) : -std::numeric_limits<double>::infinity());
     s->C_sigma2 = std::fabs(var > 0. ? std::log(var) : -std::numeric_limits<double>::infinity());
@@ -1145,7 +1147,7 @@ double normal_log_cdf(double x) {                                             //
   const double Q = 0.5 * std::erfc(x * M_SQRT1_2);
   return Q == 0.0 ? 0.0 : std::log1p(-Q);
 }
-struct GlmCtx { int lik; int n; const double* y; double log_norm_const; };     // lik: 0 logit, 1 probit, 2 Poisson
+struct GlmCtx { int lik; int n; const double* y; double log_norm_const; const double* w = nullptr; };     // lik: 0 logit, 1 probit, 2 Poisson; w: sample weights (data order) or nullptr
 int glm_eval(void* ctx, int op, double, double, const double* fe, double* out3, double* grad_F) {
   const auto* c = static_cast<const GlmCtx*>(ctx);
   if (op == 3 || op == 4) return 0;
@@ -1153,9 +1155,10 @@ int glm_eval(void* ctx, int op, double, double, const double* fe, double* out3, 
     double ll = 0.;
     for (int i = 0; i < c->n; ++i) {
       const double x = fe[i], y = c->y[i];
-      if (c->lik == 0) ll += y * x - log1p_exp_neg_abs_plus_max(x);                          // LogLikBernoulliLogit (likelihoods.h:11401-11403)
-      else if (c->lik == 1) ll += y > 0.5 ? normal_log_cdf(x) : normal_log_cdf(-x);          // LogLikBernoulliProbit (:11385-11392)
-      else ll += y * x - std::exp(x);                                                        // LogLikPoisson (:11407-11415)
+      const double wi = c->w ? c->w[i] : 1.0;                                                // Likelihood::weights_ multiplies every per-datum term (likelihoods.h:666-668)
+      if (c->lik == 0) ll += wi * (y * x - log1p_exp_neg_abs_plus_max(x));                   // LogLikBernoulliLogit (likelihoods.h:11401-11403)
+      else if (c->lik == 1) ll += wi * (y > 0.5 ? normal_log_cdf(x) : normal_log_cdf(-x));   // LogLikBernoulliProbit (:11385-11392)
+      else ll += wi * (y * x - std::exp(x));                                                 // LogLikPoisson (:11407-11415)
     }
     out3[0] = -(ll + c->log_norm_const);
     if (op == 0) return 0;
@@ -1170,18 +1173,18 @@ int glm_eval(void* ctx, int op, double, double, const double* fe, double* out3, 
       const double r = std::exp(-0.5 * z * z - 0.5 * std::log(2 * M_PI) - normal_log_cdf(z));   // InvMillsRatio
       first = y > 0.5 ? r : -r;
     } else first = y - std::exp(x);
-    grad_F[i] = -first;
+    grad_F[i] = -(c->w ? c->w[i] : 1.0) * first;
   }
   return 0;
 }
 
 void transform_back_coef(const LaplaceCoefSetup& s, std::vector<double>& beta);
 int iid_model_init_coef(const std::string& lik, int n, int p, const double* X, const double* y, const double* fixed_effects, const GpbOptimConfig& cfg,
-                        std::vector<double>* coef_out, int* num_it_out) {
+                        std::vector<double>* coef_out, int* num_it_out, const double* w = nullptr) {
   LaplaceCoefSetup su;
-  if (laplace_coef_setup(lik, n, p, X, y, fixed_effects, 1e-20, nullptr, &su)) return -1;
-  GlmCtx g{ lik == "bernoulli_logit" ? 0 : (lik == "bernoulli_probit" ? 1 : 2), n, y, 0. };
-  if (g.lik == 2) for (int i = 0; i < n; ++i) g.log_norm_const -= std::lgamma(y[i] + 1.);     // log_normalizing_constant_ (likelihoods.h:10750-10757)
+  if (laplace_coef_setup(lik, n, p, X, y, fixed_effects, 1e-20, nullptr, &su, w)) return -1;
+  GlmCtx g{ lik == "bernoulli_logit" ? 0 : (lik == "bernoulli_probit" ? 1 : 2), n, y, 0., w };      // the iid model is created with the model's weights (re_model.cpp:401-409)
+  if (g.lik == 2) for (int i = 0; i < n; ++i) g.log_norm_const -= (w ? w[i] : 1.0) * std::lgamma(y[i] + 1.);     // log_normalizing_constant_ (likelihoods.h:10750-10757)
   GpbOptimConfig c2 = cfg;
   c2.optimizer = "lbfgs";
   c2.max_iter = std::max(cfg.max_iter, 1000);
@@ -2703,7 +2706,7 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
     if (mdl->optimizer_unsupported_alias || (mdl->optim.optimizer != "" && mdl->optim.optimizer != "lbfgs")) return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_cov '%s' with covariates %s", mdl->optim.optimizer.c_str(), lscope);
     if (mdl->optimizer_coef != "" && mdl->optimizer_coef != "lbfgs") return set_error("GPB_OptimLinRegrCoefCovPar: optimizer_coef '%s' %s", mdl->optimizer_coef.c_str(), lscope);
     if (num_covariates > 256) return set_error("GPB_OptimLinRegrCoefCovPar: %d covariates %s", num_covariates, lscope);
-    if (!mdl->lik_weights.empty()) return set_error("GPB_OptimLinRegrCoefCovPar: sample weights together with covariates for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
+    const double* wdat = mdl->lik_weights.empty() ? nullptr : mdl->lik_weights.data();      // round 6: sample weights together with covariates (data order)
     if (is_proportion_likelihood(mdl->likelihood)) return set_error("GPB_OptimLinRegrCoefCovPar: covariates for likelihood '%s' %s", mdl->likelihood.c_str(), lscope);
     if (!y_data) return set_error("GPB_OptimLinRegrCoefCovPar: y_data is NULL");
     if (!mdl->init_coef.empty() && (int)mdl->init_coef.size() != num_covariates) return set_error("GPB_OptimLinRegrCoefCovPar: %d initial coefficients for %d covariates", (int)mdl->init_coef.size(), num_covariates);
@@ -2714,10 +2717,10 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
     std::vector<double> init_coef = mdl->init_coef;
     if (init_coef.empty() && mdl->init_coef_from_iid_model) {       // re_model.cpp:556-569
       GpbOptimConfig cfg0 = mdl->optim;
-      if (iid_model_init_coef(mdl->likelihood, n, p, covariate_data, y_data, fixed_effects, cfg0, &init_coef, nullptr)) return -1;
+      if (iid_model_init_coef(mdl->likelihood, n, p, covariate_data, y_data, fixed_effects, cfg0, &init_coef, nullptr, wdat)) return -1;
     }
     LaplaceCoefSetup su;
-    if (laplace_coef_setup(mdl->likelihood, n, p, covariate_data, y_data, fixed_effects, mdl->cov_pars_tr[0], init_coef.empty() ? nullptr : init_coef.data(), &su)) return -1;
+    if (laplace_coef_setup(mdl->likelihood, n, p, covariate_data, y_data, fixed_effects, mdl->cov_pars_tr[0], init_coef.empty() ? nullptr : init_coef.data(), &su, wdat)) return -1;
     const double* offs = fixed_effects;      // the fit sees the argument only (re_model_template.h:1184, fixed_effects_ptr = fixed_effects); a stored offset serves prediction
     if (laplace_upload_data(mdl, y_data, offs)) return -1;
     mdl->lap_fit_first_eval = true;

@@ -373,6 +373,27 @@ def laplace_aux_se_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_aux_se_ref.npz"), **res)
 
 
+def laplace_coef_weights_fixture(out_dir):
+    """Round 6: sample weights TOGETHER with covariates for non-Gaussian models (GPB_CreateREModel(has_weights) + GPB_OptimLinRegrCoefCovPar; weighted intercept start
+    FindInitialIntercept likelihoods.h:1455-1560, weighted step-cap constants :2618-2660, the iid model of InitCoefAuxParsFromIidModel created with the weights, re_model.cpp:401-409)
+    by the unmodified reference at cases.LAPLACE_TIGHT -- tests/golden/laplace_coef_weights_ref.npz: <lik>_{noiid,iid}_{cov_pars, coef, num_it, negll}."""
+    res = {}
+    c = cases.LAPLACE_CASES["lap_u2d_n1500_mat15_m30"]
+    w = cases.laplace_coef_weights(c["n"])
+    for lik in ("bernoulli_logit", "poisson"):
+        coords, y, X = cases.laplace_coef_data(lik, 3)
+        for tag, iid in (("noiid", False), ("iid", True)):
+            mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=lik, weights=w)
+            # (the weighted logit fit runs off to a degenerate optimum -- variance 5e2, range 5e-9 -- on these data: it is stopped after 8 iterations, which pins the start and the path)
+            mdl.set_optim_config(init_coef_aux_pars_from_iid_model=iid, max_iter=8 if lik == "bernoulli_logit" else -999, **cases.LAPLACE_TIGHT)
+            mdl.optim_lin_regr_coef_cov_par(y, X)
+            key = "%s_%s" % (lik, tag)
+            res[key + "_cov_pars"] = mdl.get_cov_par(2); res[key + "_coef"] = mdl.get_coef()
+            res[key + "_num_it"] = np.int32(mdl.get_num_it()); res[key + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+            print("laplace coef + weights", key, res[key + "_cov_pars"], res[key + "_coef"], int(res[key + "_num_it"]), "%.10f" % res[key + "_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_coef_weights_ref.npz"), **res)
+
+
 def laplace_t_fixdf_fixture(out_dir):
     """Round 6: likelihood "t_fix_df" (Student-t with the degrees of freedom held at likelihood_additional_param, only the scale estimated: estimate_df_t_ = false,
     likelihoods.h:384-407, :10466-10471, :16179-16183) by the unmodified reference -- tests/golden/laplace_t_fixdf_ref.npz, on cases.LAPLACE_T_CASES["t_n1500"]'s data:
@@ -1318,6 +1339,8 @@ if __name__ == "__main__":
         laplace_pred_refresh(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux_se":
         laplace_aux_se_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_coef_weights":
+        laplace_coef_weights_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_t_fixdf":
         laplace_t_fixdf_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":

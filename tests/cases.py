@@ -748,3 +748,11 @@ def check_predictions_against_reference(gpb, kw, g, name, y, cp, aux=None, fixed
         key = "_resp" if resp else "_latent"
         assert_pred_close(pr["mu"], g[name + key + "_mu"], sp[2 if resp else 0])
         assert_pred_close(pr["var"], g[name + key + "_var"], sp[3 if resp else 1])
+
+
+def laplace_coef_weights(n):
+    """Sample weights of the weighted fits with covariates (round 6): uniform(0.3, 2.5), every 17th 0.05, every 11th exactly 1 (data order)."""
+    w = np.random.default_rng(7311).uniform(0.3, 2.5, size=n)
+    w[::17] = 0.05
+    w[::11] = 1.0
+    return w

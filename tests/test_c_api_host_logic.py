@@ -38,7 +38,7 @@ def test_device_tests_written_without_a_gpu_pass_on_the_cpu_restatement_of_the_s
     with covariates of the non-Gaussian models, the R suite's logit / probit prediction goldens through the C API.  They pass on the MI355X since
     round 4 (profiles/r04_*); here every one of them must pass against the oracle-backed shim as well."""
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_cluster_prediction_gpu.py", "test_zz_laplace_train_re_gpu.py"])
-    assert "27 passed" in tail, tail
+    assert "31 passed" in tail, tail      # (round 6: + 4 fits with covariates AND sample weights)
 
 
 def test_validated_device_tests_still_pass_on_the_cpu_restatement_of_the_shim(mock_lib):
