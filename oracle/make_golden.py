@@ -257,6 +257,56 @@ def laplace_pc_extra_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_pc_extra_ref.npz"), **res)
 
 
+def laplace_vresp_fixture(out_dir):
+    """cg_preconditioner_type = "vecchia_response" (likelihoods.h:16315-16323, :16439-16450, :16471-16473; CG_utils.cpp:300-303, :410-416) by the unmodified reference's
+    C API -- tests/golden/laplace_vresp_ref.npz.  Per cases.LAPLACE_VRESP_CASES entry: *_negll_tight / *_fe_negll_tight (GPB_EvalNegLogLikelihood at cases.LAPLACE_TIGHT,
+    without / with fixed effects), *_negll_tight_1 (a second call of the same model at cases.LAPLACE_VRESP_SECOND_PARS: mode warm-started), *_negll_default, and one
+    Nelder-Mead fit (the reference refuses gradients with this preconditioner, likelihoods.h:6570-6572) of cases.LAPLACE_VRESP_NM: *_fit_cov_pars / _aux / _num_it / _negll.
+    cases.LAPLACE_VRESP_EXTRA_CASES (sample weights, repeated locations): *_negll and the same fit."""
+    res = {}
+    nm = cases.LAPLACE_VRESP_NM
+    for name, pc in cases.LAPLACE_VRESP_CASES.items():
+        c = cases.LAPLACE_CASES[pc["model"]]
+        coords, y = cases.make_pivchol_data(pc)
+        cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+        aux = pc.get("aux")
+        args = (c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"])
+        pcargs = dict(cg_preconditioner_type="vecchia_response")
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, **pcargs, **cases.LAPLACE_TIGHT)
+        res[name + "_negll_tight"] = np.float64(mdl.neg_log_likelihood(cp, y))
+        res[name + "_negll_tight_1"] = np.float64(mdl.neg_log_likelihood(np.asarray(cases.LAPLACE_VRESP_SECOND_PARS), y))
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, **pcargs, **cases.LAPLACE_TIGHT)
+        res[name + "_fe_negll_tight"] = np.float64(mdl.neg_log_likelihood(cp, y, fixed_effects=cases.laplace_fixed_effects(coords)))
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, **pcargs)
+        res[name + "_negll_default"] = np.float64(mdl.neg_log_likelihood(cp, y))
+        mdl = refdrv.RefCAPIModel(coords, *args, threads=8, likelihood=pc["lik"])
+        mdl.set_optim_config(estimate_aux_pars=aux is not None, optimizer_cov=nm["optimizer_cov"], max_iter=nm["maxit"], **pcargs, **cases.LAPLACE_TIGHT)
+        mdl.optim_cov_par(y)
+        res[name + "_fit_cov_pars"] = mdl.get_cov_par(2); res[name + "_fit_num_it"] = np.int64(mdl.get_num_it())
+        res[name + "_fit_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        if aux is not None:
+            res[name + "_fit_aux"] = mdl.get_aux_pars(1)
+        print("vecchia_response", name, "%.12f %.12f fe %.12f default %.12f" % (res[name + "_negll_tight"], res[name + "_negll_tight_1"], res[name + "_fe_negll_tight"],
+              res[name + "_negll_default"]), "fit", res[name + "_fit_cov_pars"], res.get(name + "_fit_aux"), int(res[name + "_fit_num_it"]), "%.10f" % res[name + "_fit_negll"], flush=True)
+    for name, ec in cases.LAPLACE_VRESP_EXTRA_CASES.items():
+        kw, y, cp, aux = cases.pc_extra_model(ec)
+        def model():
+            return refdrv.RefCAPIModel(kw["gp_coords"], kw["cov_function"], kw["cov_fct_shape"], kw["num_neighbors"], kw["vecchia_ordering"], kw["seed"], threads=8,
+                                       likelihood=kw["likelihood"], weights=kw.get("weights"))
+        m1 = model()
+        m1.set_optim_config(init_aux_pars=aux, estimate_aux_pars=False, cg_preconditioner_type=ec["pc"], **cases.LAPLACE_TIGHT)
+        res[name + "_negll"] = np.float64(m1.neg_log_likelihood(cp, y))
+        m2 = model()
+        m2.set_optim_config(estimate_aux_pars=aux is not None, cg_preconditioner_type=ec["pc"], optimizer_cov=nm["optimizer_cov"], max_iter=nm["maxit"], **cases.LAPLACE_TIGHT)
+        m2.optim_cov_par(y)
+        res[name + "_fit_cov_pars"] = m2.get_cov_par(2); res[name + "_fit_num_it"] = np.int64(m2.get_num_it()); res[name + "_fit_negll"] = np.float64(m2.current_neg_log_likelihood())
+        print("vecchia_response extra", name, "%.10f" % res[name + "_negll"], res[name + "_fit_cov_pars"], int(res[name + "_fit_num_it"]), "%.8f" % res[name + "_fit_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_vresp_ref.npz"), **res)
+
+
 def laplace_t_fixture(out_dir):
     """Student-t Vecchia-Laplace models (auxiliary parameters scale and df, both estimated; approximation_type fisher_laplace) by the unmodified reference --
     tests/golden/laplace_t_ref.npz, per cases.LAPLACE_T_CASES entry: *_negll_0 (default thresholds), *_negll_direct / *_grad_direct (CalcGradPars at cases.LAPLACE_TIGHT:
@@ -1343,6 +1393,8 @@ if __name__ == "__main__":
         laplace_coef_weights_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_t_fixdf":
         laplace_t_fixdf_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_vresp":
+        laplace_vresp_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":
         laplace_pivchol_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux":

@@ -613,6 +613,28 @@ class fitc_preconditioner(object):
         return False
 
 
+class vecchia_response_preconditioner(object):
+    """`with orc.vecchia_response_preconditioner(coords, cov_type, var, a): ...` -- cg_preconditioner_type = "vecchia_response" for the Vecchia-Laplace oracle calls inside
+    the block: the (W^-1 + Sigma) form of the solves with P = the Vecchia approximation of W^-1 + Sigma on the same neighbour sets, renewed for every W
+    (CalcVecchiaApproxLatentAddDiagonal, re_model_template.h:5473-5492; likelihoods.h:16315-16323, :16439-16450, :16471-16473).  coords: Vecchia order.  Only
+    rand_vec_trace_I_ is drawn (generator counter 0, likelihoods.h:3993-4009).  Evaluation only: the reference refuses the gradient (:6570-6572), orc_vecchia_laplace_grad too."""
+
+    def __init__(self, coords, cov_type, var, a):
+        self.co = np.asfortranarray(coords, dtype=np.float64)
+        self.args = (int(cov_type), float(var), float(a))
+        self.k = 0
+
+    def __enter__(self):
+        fn = lib().orc_set_vecchia_response
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+        fn(self.co.ctypes.data, self.co.shape[1], *self.args)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_clear_pivchol()
+        return False
+
+
 class _aux_context(object):
     """orc_set_aux / orc_clear_aux around a call for the likelihoods with an auxiliary parameter (link >= 3); a no-op otherwise."""
 

@@ -196,6 +196,25 @@ LAPLACE_PIVCHOL_CASES = {
 }
 
 
+# cg_preconditioner_type = "vecchia_response" (round 6; the fifth entry of SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, re_model_template.h:5906): the (W^-1 + Sigma) form of
+# the solves preconditioned with the Vecchia approximation of W^-1 + Sigma itself (likelihoods.h:16315-16323, :16439-16450, :16471-16473).  EVALUATION ONLY -- the reference
+# refuses the gradient with it (likelihoods.h:6570-6572), so a fit is a Nelder-Mead fit.  Same case layout as LAPLACE_PIVCHOL_CASES; "extra": a LAPLACE_PC_EXTRA-style
+# entry (sample weights / repeated locations) through the model surface.  Fixture: tests/golden/laplace_vresp_ref.npz (oracle/make_golden.py laplace_vresp).
+LAPLACE_VRESP_CASES = {
+    "vr_logit_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="bernoulli_logit", rank=None),
+    "vr_poisson_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="poisson", rank=None),
+    "vr_probit_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="bernoulli_probit", rank=None),
+    "vr_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", rank=None, aux=2.0, true_aux=2.5),
+    "vr_negbin_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", rank=None, aux=3.0, true_aux=4.0),
+}
+LAPLACE_VRESP_SECOND_PARS = (0.6, 0.22)          # a second evaluation point (variance, range) on the same model: warm start from the first mode
+LAPLACE_VRESP_EXTRA_CASES = {
+    "vrw_poisson_n2000": dict(weights_case="w_poisson_n2000", pc="vecchia_response", rank=None),
+    "vrdup_logit": dict(dup=("dup_mat15_m20_random", "bernoulli_logit"), pc="vecchia_response", rank=None),
+}
+LAPLACE_VRESP_NM = dict(optimizer_cov="nelder_mead", maxit=30)      # the fit of the fixture: 30 Nelder-Mead iterations at LAPLACE_TIGHT
+
+
 # The low-rank preconditioners together with sample weights / repeated locations (the information W is then a weighted sum / a sum over a location's data; the factor L_k /
 # the inducing points live on the unique locations): model-surface checks against the reference library -- tests/golden/laplace_pc_extra_ref.npz.
 LAPLACE_PC_EXTRA_CASES = {

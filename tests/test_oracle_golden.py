@@ -725,6 +725,37 @@ def test_oracle_pivoted_cholesky_preconditioner_matches_the_reference(orc, name)
     assert abs(nll_v - float(g[name + "_negll_direct"])) <= 2e-2 * abs(nll_v) and nll_v != float(g[name + "_negll_direct"])
 
 
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_VRESP_CASES))
+def test_oracle_vecchia_response_preconditioner_matches_the_reference(orc, name):
+    """cg_preconditioner_type = "vecchia_response" (orc.vecchia_response_preconditioner: the (W^-1 + Sigma) solves preconditioned with the Vecchia approximation of
+    W^-1 + Sigma -- CalcVecchiaApproxLatentAddDiagonal with the pseudo nugget 1 / W, renewed for every W; probes B_p^-1 D_p^1/2 r; log|P| = sum log D_p) against the
+    reference's GPB_EvalNegLogLikelihood (tests/golden/laplace_vresp_ref.npz, oracle/make_golden.py laplace_vresp): at cases.LAPLACE_TIGHT 1e-9 without and with fixed
+    effects, at the default thresholds 1e-6 (stopping-rule noise).  The gradient does not exist with this preconditioner (likelihoods.h:6570-6572): NaN."""
+    g = np.load(os.path.join(GOLD, "laplace_vresp_ref.npz"))
+    pc = cases.LAPLACE_VRESP_CASES[name]
+    c = cases.LAPLACE_CASES[pc["model"]]
+    coords, y = cases.make_pivchol_data(pc)
+    perm, co, nn = orc.vecchia_setup(coords, c["m"], c["ordering"], c["seed"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    cp = c["cov_pars"][0]
+    a = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}[ct] / cp[1]
+    tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    with orc.vecchia_response_preconditioner(co, ct, cp[0], a):
+        for fe_key, fe in (("", None), ("_fe", cases.laplace_fixed_effects(coords)[perm])):
+            v, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"), fixed_effects=fe, **tight)
+            ref = float(g[name + fe_key + "_negll_tight"])
+            assert info["rc"] == 0 and abs(v - ref) <= 1e-9 * abs(ref), (v, ref)
+        vd, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"))
+        ref_d = float(g[name + "_negll_default"])
+        assert abs(vd - ref_d) <= 1e-6 * abs(ref_d), (vd, ref_d)
+        if name == "vr_logit_n2000":
+            nll_g, grad = orc.vecchia_laplace_grad(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], **tight)
+            assert abs(nll_g - float(g[name + "_negll_tight"])) <= 1e-9 * abs(nll_g) and np.all(np.isnan(grad))
+    # another preconditioner, another stochastic estimate of the same log-determinant
+    v_vadu, _ = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=pc["lik"], aux=pc.get("aux"), **tight)
+    assert abs(v_vadu - float(g[name + "_negll_tight"])) <= 2e-2 * abs(v_vadu) and v_vadu != float(g[name + "_negll_tight"])
+
+
 def test_oracle_pivoted_cholesky_factor_properties(orc):
     """PivotedCholsekyFactorizationSigma: L_k L_k^T reproduces the pivot rows / columns of the covariance matrix exactly, the residual diagonal is >= 0 and its trace
     decreases with the rank; rank n reproduces the whole matrix."""
