@@ -182,7 +182,7 @@ class GPModel(object):
         Estimation: 'optimizer_cov' ("lbfgs" | "gradient_descent" | "nelder_mead"), 'init_cov_pars', 'lr_cov', 'acc_rate_cov', 'maxit',
         'delta_rel_conv', 'use_nesterov_acc', 'nesterov_schedule_version', 'momentum_offset', 'convergence_criterion', 'm_lbfgs',
         'estimate_cov_par_index' (0 = hold a covariance parameter at its initial value: (error variance, GP variance, range) for Gaussian models, (GP variance, range) for non-Gaussian ones with 'lbfgs'), 'trace', 'init_coef', 'init_coef_aux_pars_from_iid_model'; non-Gaussian likelihoods: 'cg_max_num_it', 'cg_max_num_it_tridiag', 'cg_delta_conv', 'num_rand_vec_trace',
-        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type' ("vadu" | "pivoted_cholesky"), 'fitc_piv_chol_preconditioner_rank'; likelihoods with auxiliary parameters ("gamma", "negative_binomial"):
+        'seed_rand_vec_trace', 'delta_conv_mode_finding', 'cg_preconditioner_type' ("vadu" | "pivoted_cholesky" | "fitc" | "vecchia_response" -- the last one for evaluations and Nelder-Mead fits only), 'fitc_piv_chol_preconditioner_rank'; likelihoods with auxiliary parameters ("gamma", "negative_binomial"):
         'init_aux_pars', 'estimate_aux_pars'.  Anything else raises: no silent ignore."""
         if not hasattr(self, "_optim_params"):
             self._optim_params = dict(self._OPTIM_DEFAULTS)
@@ -260,7 +260,7 @@ class GPModel(object):
 
     def get_cg_preconditioner_type(self):
         """The preconditioner of the iterative methods as the library resolved it (GPB_GetCGPreconditionerType; reference: GPModel.get_optim_params,
-        basic.py:5942-5946): "vadu" or "pivoted_cholesky"."""
+        basic.py:5942-5946): "vadu", "pivoted_cholesky", "fitc" or "vecchia_response"."""
         buf = ctypes.create_string_buffer(256)
         k = ctypes.c_int(0)
         _safe_call(_lib().GPB_GetCGPreconditionerType(self.handle, buf, ctypes.byref(k)))

@@ -209,7 +209,7 @@ int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
   if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->vif || mdl->eh) return 0;
-  const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : 0);
+  const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : (mdl->cg_preconditioner_type == "vecchia_response" ? 3 : 0));
   if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, type, mdl->piv_chol_rank)) return shim_error();
   return 0;
 }
@@ -1562,11 +1562,12 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     const std::string pc = cg_preconditioner_type;
     if (pc != "" && mdl->cg_preconditioner_type != pc && mdl->model_has_been_estimated)      // re_model_template.h:891-895 (the comparison is with the string as given, before the alias is resolved)
       return set_error("Cannot change 'cg_preconditioner_type' after a model has been fitted ");
-    // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu" and -- round 5 -- "pivoted_cholesky" are built
+    // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu", "pivoted_cholesky", "fitc" (round 5) and "vecchia_response" (round 6) are built; "incomplete_cholesky" is not
     if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
     else if (pc == "pivoted_cholesky" || pc == "piv_chol" || pc == "piv_chol_on_Sigma") mdl->cg_preconditioner_type = "pivoted_cholesky";
     else if (pc == "fitc" || pc == "FITC" || pc == "predictive_process_plus_diagonal") mdl->cg_preconditioner_type = "fitc";
-    else return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library ('vadu', 'pivoted_cholesky' and 'fitc' are)", pc.c_str());
+    else if (pc == "vecchia_response" || pc == "vecchia_observable" || pc == "vecchia") mdl->cg_preconditioner_type = "vecchia_response";     // evaluation only: the reference refuses gradients with it (likelihoods.h:6570-6572)
+    else return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' is not on the MI355X hot path of this library ('vadu', 'pivoted_cholesky', 'fitc' and 'vecchia_response' are)", pc.c_str());
     const int rank_before = mdl->piv_chol_rank;
     if (piv_chol_rank > 0) mdl->piv_chol_rank = piv_chol_rank;                      // re_model_template.h:900-914
     else if (piv_chol_rank != -999) return set_error("fitc_piv_chol_preconditioner_rank is not > 0, found = %d ", piv_chol_rank);

@@ -332,6 +332,10 @@ struct gpb_hip_vecchia {
   // launch on a neighbour table (a prediction's temporary handle launches once), refreshed when the response in the records changed
   int* d_rank = nullptr; int* d_nn2 = nullptr; bool sorted_ready = false, gpts_dirty = false; int launches_on_table = 0;
   int sorted_mode = -1;           // gpb_hip_vecchia_set_sorted_gather: -1 as described, 0 never, 1 from the first launch on whatever n
+  // a MODE_FACTOR launch into other buffers with observation-specific diagonal additions (the "vecchia_response" preconditioner's factor of W^-1 + Sigma,
+  // gpb_laplace.inc pc_refresh): when set, vecchia_launch writes A / D / u there and takes the per-point diagonal entries var + nug[.] from it
+  struct FactorOverride { double* A; double* D; double* u; const double* nug; };
+  const FactorOverride* factor_override = nullptr;
   double* d_nug = nullptr;        // sample weights (Gaussian likelihood): observation-specific nugget 1 / w_i, Vecchia order (gpb_hip_vecchia_set_nugget_diag)
   // full-scale Vecchia (VIF): k inducing points [k][3]; row-major [n][kq] matrices (vif_kernels.hip): cross-covariances C (column k: the response),
   // whitened V, Q = B C; k x k matrices of the products [6][kq][kq]; Gram tiles; per-point partial sums [12][n]; the gradient's matrices are
@@ -863,9 +867,13 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
     if (!gauss) return fail("observation-specific nuggets (sample weights) are for the Gaussian likelihood only");
     k.nug = h->d_nug;
   }
+  if (h->factor_override) {
+    if (mode != gpb::MODE_FACTOR) return fail("internal: a factor override is for MODE_FACTOR launches only");
+    k.A = h->factor_override->A; k.D = h->factor_override->D; k.u = h->factor_override->u; k.nug = h->factor_override->nug;
+  }
   const bool big = h->m > GPB_MAX_NEIGHBORS || h->d > 3; 
-  if (!big && !h->d_nug && sorted_gather_prepare(h)) return -1;
-  if (!big && !h->d_nug && h->sorted_ready) k.nn = h->d_nn2;             // (k.pts stays d_pts: own records in [0, n), the gathers' sorted copy in [n, 2 n))      // 62 < m <= 126 or 3 < d <= 10: LDS-resident generality kernel (vecchia_big_kernels.hip)
+  if (!big && !k.nug && sorted_gather_prepare(h)) return -1;
+  if (!big && !k.nug && h->sorted_ready) k.nn = h->d_nn2;             // (k.pts stays d_pts: own records in [0, n), the gathers' sorted copy in [n, 2 n))      // 62 < m <= 126 or 3 < d <= 10: LDS-resident generality kernel (vecchia_big_kernels.hip)
   k.coords_nd = h->d_coords_nd; k.dim = h->d;
   // the launch's sums go to d_out, to the caller's device buffer (documented order) and straight to the pinned host buffer: vecchia_fetch
   // needs no copy on the stream and can poll for them
@@ -892,7 +900,7 @@ static int vecchia_launch(gpb_hip_vecchia_t* h, int mode, int cov_type, double v
   // every MODE_FACTOR launch rewrites u = B y from the response resident NOW (Gaussian factor, the Laplace seams' factor launches alike): the one
   // place where "u belongs to an earlier response" ends.  (refresh_u's u is the fma chain of vecchia_By_pts_kernel over the stored A -- equal to the
   // factor kernel's u to rounding, ~1e-16 relative, not bit for bit: stated in include/gpb_hip.h at gpb_hip_vecchia_set_y.)
-  if (mode == gpb::MODE_FACTOR) h->u_stale = false;
+  if (mode == gpb::MODE_FACTOR && !h->factor_override) h->u_stale = false;
   return 0;
 }
 

@@ -63,6 +63,7 @@ hipError_t lap_scatter(const double* in, const int* sigma, int n, double* out, h
 hipError_t lap_objective(int link, const double* x, const LikResp& y, const double* fe, const double* Bx, const double* D, int n, double* out2, hipStream_t st,
                          const int* dptr = nullptr);
 hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double* r, double* z, double* t, int ncol, int nc, hipStream_t st);
+hipError_t lap_fwd_solve(const LapLevels& lv, int n, const double* scale, const double* rhs, double* z, int ncol, int nc, hipStream_t st);   // z = B^-1 (scale .* rhs)
 hipError_t lap_dense_build(const LapDense& d, const double* A, hipStream_t st);    // inv of the block from this evaluation's A (Vecchia order [n][m])
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st);
 hipError_t lap_cg_alpha(const double* r, const double* z, const double* h, const double* v, int n, int ncol, int nc, const CgScalars& sc, hipStream_t st);

@@ -1749,6 +1749,14 @@ hipError_t lap_vadu(const LapLevels& lv, int n, const double* rdw, const double*
   for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], (const double*)t, rdw, z);
   return hipGetLastError();
 }
+// z = B^-1 (scale .* rhs): the forward half of lap_vadu on its own (probe vectors of the "vecchia_response" preconditioner, likelihoods.h:16446-16450)
+hipError_t lap_fwd_solve(const LapLevels& lv, int n, const double* scale, const double* rhs, double* z, int ncol, int nc, hipStream_t st) {
+  lap_dense_solve<true>(lv.fdense, lv.A, n, rhs, scale, z, ncol, nc, st);
+  if (nc == 4 && (lv.syncfree & 4)) { (void)lap_trsv_syncfree_block<true>(lv.fwd, lv.fwd_ptr_host, lv.fseg, lv.n_fseg, n, rhs, scale, z, ncol, lv.err, st); return hipGetLastError(); }
+  if (nc == 1 && (lv.syncfree & 1)) { (void)lap_trsv_syncfree<true>(lv.fwd, lv.fwd_ptr_host, lv.fseg, lv.n_fseg, n, rhs, scale, z, ncol, nc, lv.err, st); return hipGetLastError(); }
+  for (int k = 0; k < lv.n_fseg; ++k) LAP_TRSV(true, lv.fwd, lv.fseg[k], rhs, scale, z);
+  return hipGetLastError();
+}
 hipError_t lap_permute_factor(const double* A, const int* hpos, const int* opos, size_t nh, size_t novf, LapEnt* hent, LapEnt* oent, hipStream_t st) {
   const size_t cnt = nh > novf ? nh : novf;
   hipLaunchKernelGGL(lap_permute_factor_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, hpos, opos, nh, novf, hent, oent);

@@ -30,6 +30,10 @@ hipError_t pc_add_div(double* v, const double* h, const double* w, int n, int nc
 hipError_t pc_pack_rows(const double* src, int ld, const int* sigma, int n, int k, double* dst, double* vnorm2, hipStream_t st);
 // wp[i] = 1 / (1 / W[i] + sm00 - vnorm2[i])      (likelihoods.h:16302-16308)
 hipError_t pc_fitc_diag(const double* W, const double* vnorm2, double sm00, int n, double* wp, hipStream_t st);
+// ---- preconditioner "vecchia_response": P^-1 = B_p' D_p^-1 B_p, the Vecchia factor of W^-1 + Sigma (likelihoods.h:16315-16323) ----
+// nug[i] (Vecchia order) = 1 / W[sigma[i]] + jit: the diagonal additions of the factor launch;  D2s[sigma[i]] = D2[i] - jit and its square root (storage order)
+hipError_t pc_vr_nugget(const double* W, const int* sigma, int n, double jit, double* nug, hipStream_t st);
+hipError_t pc_vr_diag(const double* D2, const int* sigma, int n, double jit, double* D2s, double* sqrtD2s, hipStream_t st);
 // out2 = { sum_i sdiag_i W_i, 0 } (wp == nullptr: pivoted_cholesky) or { sum_i sdiag_i wp_i^2 / W_i, sum_i wp_i / W_i } (fitc), sdiag_i = L[i, :] M L[i, :]' -- the deterministic
 // traces of CalcLogDetStochDerivAuxParVecchia (likelihoods.h:16810-16833) for dW = f W (a likelihood whose information is constant in the location parameter)
 hipError_t pc_aux_sums(const double* L, const double* M, const double* W, const double* wp, int n, int k, double* out2, hipStream_t st);

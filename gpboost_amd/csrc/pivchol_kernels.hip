@@ -261,6 +261,22 @@ __global__ void pc_pack_rows_kernel(const double* __restrict__ src, int ld, cons
   for (int q = 0; q < k; ++q) { const double v = in[q]; out[q] = v; s2 = __builtin_fma(v, v, s2); }
   if (vnorm2) vnorm2[sigma[i]] = s2;
 }
+// "vecchia_response": the pseudo nugget of the preconditioner's factor, Vecchia order, from W in storage order -- 1 / W_i plus the jitter var * 1e-10 the reference
+// multiplies into the NEIGHBOURS' diagonal entries (Vecchia_utils.cpp:1606-1614): the factor kernel takes ONE diagonal addition per point, so the point's own
+// entry carries the jitter too and pc_vr_diag takes it out of D again (D_i = own entry - A_i c_i is linear in the own entry)
+__global__ void pc_vr_nugget_kernel(const double* __restrict__ W, const int* __restrict__ sigma, int n, double jit, double* __restrict__ nug) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  nug[i] = 1.0 / W[sigma[i]] + jit;
+}
+__global__ void pc_vr_diag_kernel(const double* __restrict__ D2, const int* __restrict__ sigma, int n, double jit, double* __restrict__ D2s,
+                                  double* __restrict__ sqrtD2s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = D2[i] - jit;
+  D2s[sigma[i]] = d;
+  sqrtD2s[sigma[i]] = sqrt(d);
+}
 __global__ void pc_fitc_diag_kernel(const double* __restrict__ W, const double* __restrict__ vnorm2, double sm00, int n, double* __restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -376,6 +392,14 @@ hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, c
 }
 hipError_t pc_pack_rows(const double* src, int ld, const int* sigma, int n, int k, double* dst, double* vnorm2, hipStream_t st) {
   hipLaunchKernelGGL(pc_pack_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, ld, sigma, n, k, dst, vnorm2);
+  return hipGetLastError();
+}
+hipError_t pc_vr_nugget(const double* W, const int* sigma, int n, double jit, double* nug, hipStream_t st) {
+  hipLaunchKernelGGL(pc_vr_nugget_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, sigma, n, jit, nug);
+  return hipGetLastError();
+}
+hipError_t pc_vr_diag(const double* D2, const int* sigma, int n, double jit, double* D2s, double* sqrtD2s, hipStream_t st) {
+  hipLaunchKernelGGL(pc_vr_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, D2, sigma, n, jit, D2s, sqrtD2s);
   return hipGetLastError();
 }
 hipError_t pc_fitc_diag(const double* W, const double* vnorm2, double sm00, int n, double* wp, hipStream_t st) {

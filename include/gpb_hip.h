@@ -455,6 +455,12 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t*
  * "pivoted_cholesky" with C in place of L_k.  The inducing points come from the host (k x d, column-major; the reference draws them by kmeans++ from the model's
  * generator at the first covariance factor -- libstdc++'s distributions); rank <= 0 in set_preconditioner: the reference's default 200. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, const double* ip_colmajor);
+/* type 3 = "vecchia_response" (round 6; the fifth entry of SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_, include/GPBoost/re_model_template.h:5906): the same (W^-1 + Sigma)
+ * solves with P = the Vecchia approximation of W^-1 + Sigma on the model's neighbour sets, P^-1 = B_p' D_p^-1 B_p -- CalcVecchiaApproxLatentAddDiagonal
+ * (re_model_template.h:5473-5492; src/GPBoost/Vecchia_utils.cpp:1418-1422, :1610-1614) renewed for every W (include/GPBoost/likelihoods.h:16315-16323), applied as
+ * src/GPBoost/CG_utils.cpp:300-303 / :410-416, probes B_p^-1 D_p^1/2 r (likelihoods.h:16439-16450), log|P| = sum log D_p (:16471-16473).  On the device the factor is ONE launch
+ * of the Gaussian path's point kernel (MODE_FACTOR with per-point diagonal additions 1 / W_i) per Newton iteration.  `rank` is ignored.  EVALUATION ONLY:
+ * gpb_hip_vecchia_laplace_grad_current fails with the reference's message (likelihoods.h:6570-6572 refuses gradients with this preconditioner). */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_set_aux_pars(gpb_hip_vecchia_t* h, const double* aux, int32_t num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_get_aux_pars(gpb_hip_vecchia_t* h, double* aux_out, int32_t* num_aux);
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_grad_aux_current(gpb_hip_vecchia_t* h, double* out4_host);

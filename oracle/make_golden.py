@@ -260,7 +260,7 @@ def laplace_pc_extra_fixture(out_dir):
 def laplace_vresp_fixture(out_dir):
     """cg_preconditioner_type = "vecchia_response" (likelihoods.h:16315-16323, :16439-16450, :16471-16473; CG_utils.cpp:300-303, :410-416) by the unmodified reference's
     C API -- tests/golden/laplace_vresp_ref.npz.  Per cases.LAPLACE_VRESP_CASES entry: *_negll_tight / *_fe_negll_tight (GPB_EvalNegLogLikelihood at cases.LAPLACE_TIGHT,
-    without / with fixed effects), *_negll_tight_1 (a second call of the same model at cases.LAPLACE_VRESP_SECOND_PARS: mode warm-started), *_negll_default, and one
+    without / with fixed effects), *_negll_tight_1 (a second call of the same model at cases.LAPLACE_VRESP_SECOND_PARS), *_negll_default, and one
     Nelder-Mead fit (the reference refuses gradients with this preconditioner, likelihoods.h:6570-6572) of cases.LAPLACE_VRESP_NM: *_fit_cov_pars / _aux / _num_it / _negll.
     cases.LAPLACE_VRESP_EXTRA_CASES (sample weights, repeated locations): *_negll and the same fit."""
     res = {}

@@ -207,7 +207,7 @@ LAPLACE_VRESP_CASES = {
     "vr_gamma_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gamma", rank=None, aux=2.0, true_aux=2.5),
     "vr_negbin_n2000": dict(model="lap_u2d_n2000_exp_m20", lik="negative_binomial", rank=None, aux=3.0, true_aux=4.0),
 }
-LAPLACE_VRESP_SECOND_PARS = (0.6, 0.22)          # a second evaluation point (variance, range) on the same model: warm start from the first mode
+LAPLACE_VRESP_SECOND_PARS = (0.6, 0.22)          # a second evaluation point (variance, range) on the same model (the preconditioner's factor is renewed, the mode starts at 0 again)
 LAPLACE_VRESP_EXTRA_CASES = {
     "vrw_poisson_n2000": dict(weights_case="w_poisson_n2000", pc="vecchia_response", rank=None),
     "vrdup_logit": dict(dup=("dup_mat15_m20_random", "bernoulli_logit"), pc="vecchia_response", rank=None),

@@ -35,6 +35,7 @@ void orc_clear_aux(void);
 int orc_pivoted_cholesky(const double* coords, int n, int d, int cov_type, double var, double a, int max_it, double err_tol, double* L_out);
 void orc_set_pivchol(const double* L_k, int k, const double* rand_vec2);
 void orc_clear_pivchol(void);
+void orc_set_vecchia_response(const double* coords, int d, int cov_type, double var, double a);
 void orc_set_fitc(const double* C_nk, const double* V_nk, const double* Sm_kk, double logdet_Sm, int k, const double* rand_vec2);
 int orc_vecchia_laplace_grad_map_dbg(int link, const double* A, const double* D, const double* Ag, const double* Dg, const int* nn, int n, int m,
                                      const int* dptr, const int* y_int, const double* fe, const double* rand_vec, int t, int cg_max_num_it,
@@ -292,6 +293,8 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
     orc_gen_rand_normal(seed, 0ull, k, nrv, rv2.data());
     orc_set_fitc(pcL.data(), pcV.data(), pcSm.data(), 2. * ld, k, rv2.data());
   } else
+  if (h->pc_type == 3) orc_set_vecchia_response(h->coords.data(), h->d, cov, var, a);      // vecchia_response: no low-rank part, no second set of normals
+  else
   if (pc) {
     const int k = std::min(h->pc_rank, n);
     pcL.assign((size_t)n * k, 0.); rv2.assign((size_t)k * nrv, 0.);
@@ -299,7 +302,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
     orc_gen_rand_normal(seed, 0ull, k, nrv, rv2.data());
     orc_set_pivchol(pcL.data(), k, rv2.data());
   }
-  orc_gen_rand_normal(seed, pc ? 1ull : 0ull, n, nrv, rv.data());
+  orc_gen_rand_normal(seed, (pc && h->pc_type != 3) ? 1ull : 0ull, n, nrv, rv.data());
   std::vector<int> dptr;
   if (mapped) dptr = h->re_ptr; else { dptr.resize(n + 1); std::iota(dptr.begin(), dptr.end(), 0); }
   const bool warm = !reset && h->has_mode;
@@ -318,7 +321,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   orc_set_binomial(0);
   if (pc) orc_clear_pivchol();
   if (rc) return fail("NaN or Inf occurred in the mode finding algorithm for the Laplace approximation");
-  h->mode = mode; h->has_mode = true; h->grad_state = true;
+  h->mode = mode; h->has_mode = true; h->grad_state = h->pc_type != 3;
   h->dld.assign(dbg.begin(), dbg.begin() + n); h->sv.assign(dbg.begin() + n, dbg.begin() + 2 * n);
   h->l_cov = cov; h->l_var = var; h->l_a = a;
   for (int k = 0; k < 9; ++k) out9[k] = 0.;
@@ -547,7 +550,7 @@ EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const
 }
 EXPORT int gpb_hip_vecchia_laplace_set_binomial(gpb_hip_vecchia_t* h, int on) { h->binomial = on != 0; return 0; }
 EXPORT int gpb_hip_vecchia_laplace_set_preconditioner(gpb_hip_vecchia_t* h, int type, int rank) {
-  if (type != 0 && type != 1 && type != 2) return fail("preconditioner type %d is not on this path (0 = vadu, 1 = pivoted_cholesky, 2 = fitc)", type);
+  if (type < 0 || type > 3) return fail("preconditioner type %d is not on this path (0 = vadu, 1 = pivoted_cholesky, 2 = fitc, 3 = vecchia_response)", type);
   const int rk = rank > 0 ? rank : (type == 2 ? 200 : 50);
   if (type == 1 && rk > h->n) return fail("'fitc_piv_chol_preconditioner_rank' cannot be larger than the dimension of the mode (= number of unique locations) ");
   if (h->pc_type != type || h->pc_rank != rk) h->grad_state = false;
@@ -624,6 +627,7 @@ EXPORT int gpb_hip_vecchia_laplace_logit(gpb_hip_vecchia_t* h, int cov, double v
   return laplace_run(h, cov, var, a, nrv, seed, cg, cgt, cgd, dcm, reset, out9, mode_host);
 }
 EXPORT int gpb_hip_vecchia_laplace_grad_current(gpb_hip_vecchia_t* h, int, double, double* grad2, double*, double*) { MOCK_TRACE("gpb_hip_vecchia_laplace_grad_current"); MockTimer mock_timer_(7);
+  if (h->pc_type == 3) return fail("Calculation of gradients is currently not correctly implemented for the '%s' preconditioner ", "vecchia_response");
   if (!h->grad_state) return fail("the gradient needs the state of an evaluation that kept it");
   grad2[0] = h->grad2[0]; grad2[1] = h->grad2[1]; return 0;
 }

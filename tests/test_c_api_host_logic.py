@@ -72,6 +72,13 @@ def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatemen
     assert "13 passed" in tail, tail      # (5 pivoted_cholesky cases + 3 fitc cases + 4 with weights / repeated locations + the error paths)
 
 
+def test_vecchia_response_preconditioner_on_the_cpu_restatement_of_the_shim(mock_lib):
+    """Round 6: cg_preconditioner_type = "vecchia_response" -- tests/test_zz_laplace_vresp_gpu.py as a whole (shim-level values against the reference's fixtures and the
+    oracle, the refused gradient, the model surface with the alias, Nelder-Mead fits, weights / repeated locations, m > 62 and d = 4) on the oracle-backed shim."""
+    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_vresp_gpu.py"])
+    assert "16 passed" in tail, tail      # (5 values + 3 oracle-step cases + 5 model-surface cases + 2 with weights / repeated locations + the generality kernel's shapes)
+
+
 ROUTE_A_DRIVER = r'''
 import json, sys, types
 sys.modules.setdefault("optuna", types.ModuleType("optuna"))       # optional dependency of the reference's package, absent here
