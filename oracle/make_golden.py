@@ -1328,9 +1328,28 @@ def config4_pivchol_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "config4_pivchol_ref.npz"), **res)
 
 
+def config4_vresp_fixture(out_dir):
+    """BASELINE config 4's data with cg_preconditioner_type = "vecchia_response": ONE reference evaluation at the default thresholds and one at cg_delta_conv = 1e-6, with the
+    reference's wall-clock seconds on this container's 8 cores -- tests/golden/config4_vresp_ref.npz."""
+    import time
+    n, m = 100000, 30
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+    res = {}
+    for key, cfg in (("negll_0", {}), ("negll_tight_0", dict(cg_delta_conv=1e-6))):
+        mdl = refdrv.RefCAPIModel(coords, "exponential", 0.5, m, "random", 1, threads=8, likelihood="bernoulli_logit")
+        mdl.set_optim_config(cg_preconditioner_type="vecchia_response", **cfg)
+        t0 = time.time()
+        res[key] = np.float64(mdl.neg_log_likelihood(np.asarray((1.0, 0.1), dtype=np.float64), y))
+        res["seconds_" + key] = np.float64(time.time() - t0)
+        print("config4 vecchia_response", key, "negll = %.12f" % res[key], "%.1f s" % res["seconds_" + key], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "config4_vresp_ref.npz"), **res)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "config4_pivchol":
         config4_pivchol_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "config4_vresp":
+        config4_vresp_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "atsize":
         atsize_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "weights":

@@ -165,6 +165,29 @@ def test_config4_n1e5_pivoted_cholesky_against_the_reference(gpb):
     assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
 
 
+def test_config4_n1e5_vecchia_response_against_the_reference(gpb):
+    """Round 6: the same data with cg_preconditioner_type = "vecchia_response" (the factor of W^-1 + Sigma renewed by one point-kernel launch per Newton step; gpb_laplace.inc
+    pc_refresh_vr) against ONE evaluation of the unmodified reference with that preconditioner per threshold set (tests/golden/config4_vresp_ref.npz, oracle/make_golden.py
+    config4_vresp): cg_delta_conv = 1e-6 -> 1e-8; the defaults -> 1e-6 (defined up to one CG / Lanczos iteration)."""
+    path = os.path.join(GOLD, "config4_vresp_ref.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/config4_vresp_ref.npz has not been generated")
+    g = np.load(path)
+    n, m = 100000, 30
+    coords, y = cases.synthetic_binary(n, 2, seed=1)
+    mdl = gpb.GPModel(likelihood="bernoulli_logit", gp_coords=coords, cov_function="exponential", gp_approx="vecchia",
+                      num_neighbors=m, vecchia_ordering="random", seed=1)
+    mdl.set_optim_params({"cg_preconditioner_type": "vecchia_response"})
+    v = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    ref = float(g["negll_0"])
+    assert abs(v - ref) <= 1e-6 * abs(ref), (v, ref, mdl.laplace_info())
+    mdl.set_optim_params({"cg_delta_conv": 1e-6})
+    vt = mdl.neg_log_likelihood(np.array([1.0, 0.1]), y)
+    reft = float(g["negll_tight_0"])
+    assert abs(vt - reft) <= RTOL * abs(reft), (vt, reft, mdl.laplace_info())
+    print("config 4 with vecchia_response: %.6f (reference %.6f, %.1f s on 8 host cores); device: %s" % (v, ref, float(g["seconds_negll_0"]), mdl.laplace_info()))
+
+
 @pytest.mark.parametrize("lik", ["lognormal", "gamma", "t"])
 def test_auxiliary_parameter_likelihoods_at_config4_size_against_the_reference(gpb, lik):
     """Round 6: the likelihoods with auxiliary parameters at BASELINE config 4's size (n = 1e5, m = 30; smooth latent surface, response drawn from the
