@@ -432,8 +432,12 @@ int device_laplace(void* ctx, int op_in, double var, double a, double* out3) {
 }
 
 // gpb_laplace_aux_fn (gpb_optim.h) on the device: likelihoods whose auxiliary parameters are estimated with the covariance parameters
-int device_laplace_aux(void* ctx, int op, double var, double a, const double* aux, int naux, double* out) {
+int device_laplace_aux(void* ctx, int op_in, double var, double a, const double* aux, int naux, double* out) {
   auto* mdl = static_cast<REModelHip*>(ctx);
+  const bool first_update = (op_in & 16) != 0;       // first gradient-descent update: cg_max_num_it(_tridiag) / 3 (likelihoods.h:3833-3836), as device_laplace
+  const int op = op_in & 15;
+  const int cg_it = first_update ? (int)std::round(mdl->cg_max_num_it / 3.) : mdl->cg_max_num_it;
+  const int cgt_it = first_update ? (int)std::round(mdl->cg_max_num_it_tridiag / 3.) : mdl->cg_max_num_it_tridiag;
   if (op == 3) return gpb_hip_vecchia_laplace_reset_mode_to_previous(mdl->vh) ? -1 : 0;
   if (op == 4) { mdl->lap_fit_first_eval = true; return 0; }
   if (op == 0 || op == 1) {
@@ -442,14 +446,14 @@ int device_laplace_aux(void* ctx, int op, double var, double a, const double* au
     if (laplace_push_aux(mdl)) return -1;
     const int reset = mdl->lap_fit_first_eval ? 1 : 0;
     if (laplace_prepare_preconditioner(mdl)) return -1;
-    if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(mdl->cg_max_num_it, 1),
-                                     std::max(mdl->cg_max_num_it_tridiag, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
+    if (gpb_hip_vecchia_laplace_eval(mdl->vh, mdl->cov_type, var, a, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, std::max(cg_it, 1),
+                                     std::max(cgt_it, 1), mdl->cg_delta_conv, mdl->delta_conv_mode_finding, reset, 1, mdl->lap_info, nullptr)) return -1;
     mdl->lap_fit_first_eval = false;
     out[0] = -mdl->lap_info[0];
     if (op == 0) return 0;
   }
   double g2[2], g4[8];                               // 4 doubles per auxiliary parameter
-  if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(mdl->cg_max_num_it, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
+  if (gpb_hip_vecchia_laplace_grad_current(mdl->vh, std::max(cg_it, 1), mdl->cg_delta_conv, g2, nullptr, nullptr)) return -1;
   if (gpb_hip_vecchia_laplace_grad_aux_current(mdl->vh, g4)) return -1;
   out[1] = g2[0]; out[2] = g2[1];
   for (int j = 0; j < naux && j < 2; ++j) out[3 + j] = j < mdl->num_aux_estim() ? g4[4 * j] : 0.;      // SetGradAuxParsNotEstimated (likelihoods.h:16179-16183)

@@ -990,6 +990,7 @@ struct LapCoefState {
     double auxv[8], o[3 + 8] = {0};
     for (int j = 0; j < naux; ++j) auxv[j] = std::exp(x[nc + p + j]);
     if (afn(ctx, op, var_of(x), a_of(x), auxv, naux, o)) return -1;
+    op &= 15;                                                        // (bit 4: first update of a gradient-descent fit, see device_laplace)
     if (op != 2) { ++n_evals; negll = o[0]; }
     if (op >= 1 && grad) { if (nc) { grad[0] = o[1]; grad[1] = o[2]; } for (int j = 0; j < naux; ++j) grad[nc + p + j] = o[3 + j]; }
     return 0;
@@ -1162,6 +1163,118 @@ int gpb_optimize_laplace_coef_cov_pars(const GpbOptimConfig& cfg, gpb_laplace_fe
   return 0;
 }
 
+// optimizer_cov = "gradient_descent" with estimated auxiliary parameters (round 6): the reference's internal loop (OptimLinRegrCoefCovPar, re_model_template.h:1514-1660) on
+// x = (log sigma1_2, log a, log aux_1 ..) with TWO learning rates -- lr_cov_ for the covariance block, lr_aux_pars_ (same initial value, SetInitialValueLRCov :8316-8333) for
+// the auxiliary block: each capped by MAX_GRADIENT_UPDATE_LOG_SCALE_ / max |gradient of its block| (AvoidTooLargeLearningRatesCovAuxPars :8354-8375), each with its own
+// directional derivative -|g_block|^2 and momentum term (CalcDirDerivArmijoAndLearningRateConstChangeCovAuxPars :8420-8470); a trial step is accepted when BOTH Armijo
+// conditions hold (UpdateCovAuxPars :8768-8776), otherwise both rates are halved and the mode goes back (:8793-8809); the halved rates stay (:8819-8824).  A rate that fell
+// below 1e-4 of its value after the first iteration while its block stopped moving is set back once the OTHER block has moved by more than 1 % (:1564-1612), with a mode
+// finding at the current parameters (RecalculateModeLaplaceApprox).
+int run_gradient_descent_laplace_aux(LapCoefState& st, const GpbOptimConfig& cfg, std::vector<double>& x, int* num_it_out, const Fail& fail) {
+  const int N = (int)x.size(), NC = 2, NA = N - 2;
+  double lr_cov = cfg.lr_cov_init > 0. ? cfg.lr_cov_init : 0.1, lr_aux = lr_cov;
+  const double delta_rel_conv = cfg.delta_rel_conv_init > 0. ? cfg.delta_rel_conv_init : 1e-6;
+  const bool nesterov = cfg.use_nesterov_acc;
+  if (nesterov && cfg.nesterov_schedule_version == 1)
+    return fail("Armijo condition backtracking is not implemented when nesterov_schedule_version = 1 ");
+  const double kLrIsSmallRelChange = 1e-4, kMinRelChangeOther = 1e-2;     // LR_IS_SMALL_REL_CHANGE_IN_PARS_THRESHOLD_, MIN_REL_CHANGE_IN_OTHER_PARS_FOR_RESETTING_LR_ (re_model_template.h:5808-5812)
+  std::vector<double> grad(N), gnew(N), xa(x), xa_lag1(x), x_lag1(N), x_new(N);
+  if (st.eval_aux(x.data(), 1, grad.data())) return -1;
+  if (!std::isfinite(st.negll))
+    return fail("%s occurred in initial approximate negative marginal log-likelihood. Possible solutions: try other initial values ('init_cov_pars')",
+                std::isnan(st.negll) ? "NaN" : "Inf");
+  auto blk_norm = [&](const std::vector<double>& a, const std::vector<double>* b, int i0, int i1) {      // norms on the ORIGINAL scale, as the reference's cov_aux_pars
+    double s2 = 0.; for (int i = i0; i < i1; ++i) { const double d = std::exp(a[i]) - (b ? std::exp((*b)[i]) : 0.); s2 += d * d; } return std::sqrt(s2);
+  };
+  int num_it = cfg.max_iter;
+  bool have_grad = true;
+  double lr_cov_after_first = lr_cov, lr_aux_after_first = lr_aux, thr_cov = 0., thr_aux = 0.;
+  bool lr_cov_is_small = false, lr_aux_is_small = false;
+  std::vector<double> aux_before_lr_cov_small, cov_before_lr_aux_small;
+  for (int it = 0; it < cfg.max_iter; ++it) {
+    const double negll_lag1 = st.negll;
+    x_lag1 = x;
+    if (!have_grad && st.eval_aux(x.data(), 2, grad.data())) return -1;
+    double gmax_c = 0., gmax_a = 0., dd_c = 0., dd_a = 0.;
+    for (int i = 0; i < NC; ++i) { gmax_c = std::max(gmax_c, std::fabs(grad[i])); dd_c -= grad[i] * grad[i]; }
+    for (int i = NC; i < N; ++i) { gmax_a = std::max(gmax_a, std::fabs(grad[i])); dd_a -= grad[i] * grad[i]; }
+    if (lr_cov > kMaxGradientUpdateLogScale / gmax_c) lr_cov = kMaxGradientUpdateLogScale / gmax_c;
+    if (lr_aux > kMaxGradientUpdateLogScale / gmax_a) lr_aux = kMaxGradientUpdateLogScale / gmax_a;
+    double mom_c = 0., mom_a = 0.;
+    if (nesterov) {
+      for (int i = 0; i < NC; ++i) mom_c += grad[i] * (x[i] - xa[i]);
+      for (int i = NC; i < N; ++i) mom_a += grad[i] * (x[i] - xa[i]);
+    }
+    double lc = lr_cov, la = lr_aux, acc = cfg.acc_rate_cov;
+    bool decrease_found = false, halving_done = false, new_grad = false;
+    for (int ih = 0; ih < kMaxNumberLrShrinkageSteps; ++ih) {
+      for (int i = 0; i < N; ++i) x_new[i] = x[i] - (i < NC ? lc : la) * grad[i];
+      double mu = 0.;
+      if (nesterov) {
+        xa = x_new;
+        mu = nesterov_schedule(it, cfg.nesterov_schedule_version, acc, cfg.momentum_offset);
+        for (int i = 0; i < N; ++i) x_new[i] = (mu + 1.) * xa[i] - mu * xa_lag1[i];
+      }
+      new_grad = ih == 0;
+      if (st.eval_aux(x_new.data(), (new_grad ? 1 : 0) | (it == 0 ? 16 : 0), gnew.data())) return -1;
+      if (st.negll <= negll_lag1 + kCArmijo * lc * dd_c + kCArmijoMom * mu * mom_c &&
+          st.negll <= negll_lag1 + kCArmijo * la * dd_a + kCArmijoMom * mu * mom_a) decrease_found = true;
+      if (decrease_found) break;
+      halving_done = true;
+      lc *= kLrShrinkageFactor; la *= kLrShrinkageFactor;
+      acc *= 0.5;
+      if (st.reset_mode()) return -1;
+    }
+    if (halving_done) { lr_cov = lc; lr_aux = la; }
+    if (nesterov) xa_lag1 = xa;
+    x = x_new;
+    have_grad = decrease_found && new_grad;
+    if (have_grad) grad = gnew;
+    if (it == 0) { lr_cov_after_first = lr_cov; thr_cov = lr_cov / 1e4; lr_aux_after_first = lr_aux; thr_aux = lr_aux / 1e4; }
+    // a very small rate whose block has stopped moving is remembered ... (:1564-1590)
+    if (lr_cov < thr_cov && !lr_cov_is_small && blk_norm(x, &x_lag1, 0, NC) < kLrIsSmallRelChange * blk_norm(x_lag1, nullptr, 0, NC)) {
+      lr_cov_is_small = true; aux_before_lr_cov_small.assign(x.begin() + NC, x.end());
+    }
+    if (lr_aux < thr_aux && !lr_cov_is_small && !lr_aux_is_small && blk_norm(x, &x_lag1, NC, N) < kLrIsSmallRelChange * blk_norm(x_lag1, nullptr, NC, N)) {
+      lr_aux_is_small = true; cov_before_lr_aux_small.assign(x.begin(), x.begin() + NC);
+    }
+    // ... and set back when the other block has moved on (:1601-1622); the mode is found again at the current parameters
+    bool recalculated = false;
+    auto moved = [&](const std::vector<double>& ref, int i0) {
+      double d2 = 0., r2 = 0.;
+      for (size_t q = 0; q < ref.size(); ++q) { const double a0 = std::exp(ref[q]), a1 = std::exp(x[i0 + q]); d2 += (a1 - a0) * (a1 - a0); r2 += a0 * a0; }
+      return std::sqrt(d2) > kMinRelChangeOther * std::sqrt(r2);
+    };
+    if (lr_aux_is_small && moved(cov_before_lr_aux_small, 0)) {
+      lr_aux = lr_aux_after_first; lr_aux_is_small = false;
+      if (st.eval_aux(x.data(), 0, nullptr)) return -1;
+      recalculated = true; have_grad = false;
+    }
+    if (lr_cov_is_small && moved(aux_before_lr_cov_small, NC)) {
+      lr_cov = lr_cov_after_first; lr_cov_is_small = false;
+      if (!recalculated) { if (st.eval_aux(x.data(), 0, nullptr)) return -1; have_grad = false; }
+    }
+    if (cfg.trace) {
+      fprintf(stderr, "[gpboost_amd] it %d: pars (log)", it + 1);
+      for (int i = 0; i < N; ++i) fprintf(stderr, " %.10g", x[i]);
+      fprintf(stderr, " negll %.10g lr_cov %g lr_aux %g\n", st.negll, lr_cov, lr_aux);
+    }
+    bool finite = std::isfinite(st.negll);
+    for (int i = 0; i < N; ++i) finite = finite && std::isfinite(std::exp(x[i]));
+    if (!finite) return kNaOrInf;
+    bool terminate = false;
+    if (cfg.convergence_criterion == "relative_change_in_parameters") {
+      terminate = blk_norm(x, &x_lag1, 0, N) <= delta_rel_conv * blk_norm(x_lag1, nullptr, 0, N);
+    } else {
+      terminate = (negll_lag1 - st.negll) <= delta_rel_conv * std::max(std::fabs(negll_lag1), 1.);
+    }
+    if (terminate) { num_it = it + 1; break; }
+  }
+  (void)NA;
+  *num_it_out = num_it;
+  return 0;
+}
+
 int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux_fn fn, void* ctx, int naux, const double theta_init[2], double* aux,
                                       GpbLaplaceAuxResult* out, char* err, int errlen) {
   const Fail fail{err, errlen};
@@ -1170,8 +1283,8 @@ int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux
   if (!(theta_init[0] > 0.) || !(theta_init[1] > 0.))
     return fail("Initial covariance parameters need to be positive (found %g, %g on the transformed scale)", theta_init[0], theta_init[1]);
   for (int j = 0; j < naux; ++j) if (!(aux[j] > 0.)) return fail("Initial auxiliary parameters need to be positive (found %g)", aux[j]);
-  if (cfg.optimizer != "lbfgs" && cfg.optimizer != "nelder_mead")
-    return fail("optimizer_cov = '%s' for a likelihood with estimated auxiliary parameters is not on the MI355X path of this library (supported: 'lbfgs', the reference's default, and 'nelder_mead')", cfg.optimizer.c_str());
+  if (cfg.optimizer != "lbfgs" && cfg.optimizer != "nelder_mead" && cfg.optimizer != "gradient_descent")
+    return fail("optimizer_cov = '%s' for a likelihood with estimated auxiliary parameters is not on the MI355X path of this library (supported: 'lbfgs', the reference's default, 'gradient_descent' and 'nelder_mead')", cfg.optimizer.c_str());
   if (cfg.optimizer == "nelder_mead") {
     // round 6: OptimLib's simplex search over (log sigma1_2, log a, log aux_1 ..) -- EvalLLforOptimLib with EstimateAuxPars() (optim_utils.h:61-213: SetAuxPars(exp(tail)) at
     // every evaluation), likelihood evaluations only; an evaluator error at a trial vertex counts as +Inf there and the mode goes back (as run_nelder_mead_laplace)
@@ -1212,7 +1325,7 @@ int gpb_optimize_laplace_cov_aux_pars(const GpbOptimConfig& cfg, gpb_laplace_aux
   for (int j = 0; j < naux; ++j) x[2 + j] = std::log(aux[j]);
   *out = GpbLaplaceAuxResult();
   if (cfg.max_iter > 0) {
-    const int rc = run_lbfgs_laplace_coef(st, cfg, x, &out->num_it, fail);
+    const int rc = cfg.optimizer == "gradient_descent" ? run_gradient_descent_laplace_aux(st, cfg, x, &out->num_it, fail) : run_lbfgs_laplace_coef(st, cfg, x, &out->num_it, fail);
     if (rc == kNaOrInf) return fail("NaN or Inf occurred in the parameter optimisation of a likelihood with auxiliary parameters (the reference restarts with 'nelder_mead', which is not on this path for such models)");
     if (rc) { if (err && !err[0]) snprintf(err, errlen, "likelihood evaluation failed during the optimisation"); return -1; }
   }

@@ -423,6 +423,21 @@ def laplace_aux_se_fixture(out_dir):
     np.savez_compressed(os.path.join(out_dir, "laplace_aux_se_ref.npz"), **res)
 
 
+def laplace_aux_gd_fixture(out_dir):
+    """Round 6: optimizer_cov = "gradient_descent" for likelihoods whose auxiliary parameters are estimated (cases.LAPLACE_AUX_GD_CASES) by the unmodified reference at
+    cases.LAPLACE_TIGHT -- tests/golden/laplace_aux_gd_ref.npz: <case>_{cov_pars, aux, num_it, negll}."""
+    res = {}
+    for name in cases.LAPLACE_AUX_GD_CASES:
+        coords, y, c, lik, naux, cfg = cases.aux_gd_case(name)
+        m = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=lik)
+        m.set_optim_config(estimate_aux_pars=True, optimizer_cov="gradient_descent", **cfg, **cases.LAPLACE_TIGHT)
+        m.optim_cov_par(y)
+        res[name + "_cov_pars"] = m.get_cov_par(2); res[name + "_aux"] = m.get_aux_pars(naux)
+        res[name + "_num_it"] = np.int32(m.get_num_it()); res[name + "_negll"] = np.float64(m.current_neg_log_likelihood())
+        print("gradient_descent with auxiliary parameters", name, res[name + "_cov_pars"], res[name + "_aux"], res[name + "_num_it"], "%.10f" % res[name + "_negll"], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "laplace_aux_gd_ref.npz"), **res)
+
+
 def laplace_coef_weights_fixture(out_dir):
     """Round 6: sample weights TOGETHER with covariates for non-Gaussian models (GPB_CreateREModel(has_weights) + GPB_OptimLinRegrCoefCovPar; weighted intercept start
     FindInitialIntercept likelihoods.h:1455-1560, weighted step-cap constants :2618-2660, the iid model of InitCoefAuxParsFromIidModel created with the weights, re_model.cpp:401-409)
@@ -1412,6 +1427,8 @@ if __name__ == "__main__":
         laplace_coef_weights_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_t_fixdf":
         laplace_t_fixdf_fixture(os.path.join(ROOT, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "laplace_aux_gd":
+        laplace_aux_gd_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_vresp":
         laplace_vresp_fixture(os.path.join(ROOT, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "laplace_pivchol":

@@ -139,6 +139,26 @@ LAPLACE_T_CASES = {
 }
 
 
+# optimizer_cov = "gradient_descent" with estimated auxiliary parameters (round 6): two learning rates (covariance block / auxiliary block), both Armijo conditions, joint
+# halving -- re_model_template.h:1514-1660, :8354-8375, :8690-8850.  name -> (case table, case, likelihood, number of auxiliary parameters, GPB_SetOptimConfig arguments).
+# Fixture: tests/golden/laplace_aux_gd_ref.npz (oracle/make_golden.py laplace_aux_gd), fits at LAPLACE_TIGHT.
+LAPLACE_AUX_GD_CASES = {
+    "gd_gamma_n1500": ("aux", "gamma_n1500", "gamma", 1, dict(max_iter=40)),
+    "gd_gamma_n1500_plain": ("aux", "gamma_n1500", "gamma", 1, dict(max_iter=25, use_nesterov_acc=False, lr_cov=0.05)),
+    "gd_negbin_n1500": ("aux", "negbin_n1500", "negative_binomial", 1, dict(max_iter=40)),
+    "gd_t_n1500": ("t", "t_n1500", "t", 2, dict(max_iter=40)),
+    "gd_lognormal_u3d_n1200_parchange": ("t", "lognormal_u3d_n1200", "lognormal", 1, dict(max_iter=60, convergence_criterion="relative_change_in_parameters", delta_rel_conv=1e-3)),
+}
+
+
+def aux_gd_case(name):
+    """-> (coords, y, LAPLACE_CASES model entry, likelihood, naux, config) of a LAPLACE_AUX_GD_CASES entry."""
+    table, case, lik, naux, cfg = LAPLACE_AUX_GD_CASES[name]
+    cs = (LAPLACE_AUX_CASES if table == "aux" else LAPLACE_T_CASES)[case]
+    coords, y = (make_aux_data if table == "aux" else make_t_data)(cs)
+    return coords, y, LAPLACE_CASES[cs["model"]], lik, naux, cfg
+
+
 def make_t_data(tc):
     """-> (coords, y) in DATA order for a LAPLACE_T_CASES entry: a smooth surface + scale * Student-t(df) noise."""
     c = LAPLACE_CASES[tc["model"]]

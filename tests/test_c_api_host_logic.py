@@ -24,8 +24,9 @@ def mock_lib(orc):
 
 
 def _run_gpu_tests_on_the_mock(mock_lib, files, extra=()):
-    env = dict(os.environ, GPBOOST_AMD_LIB=mock_lib)
-    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-rx"] + list(extra) + [os.path.join(ROOT, "tests", f) for f in files]
+    # four worker processes (pytest-xdist) with two OpenMP threads each: the oracle's restatements are serial loops, the test functions independent
+    env = dict(os.environ, GPBOOST_AMD_LIB=mock_lib, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-rx", "-n", "4"] + list(extra) + [os.path.join(ROOT, "tests", f) for f in files]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
     tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
@@ -60,8 +61,8 @@ def test_student_t_likelihood_through_the_c_api_on_the_cpu_restatement_of_the_sh
     """Round 5: the t likelihood's two auxiliary parameters through the model surface (GPB_SetOptimConfig(init_aux_pars[2]), the lbfgs vector (log sigma1^2, log a, log scale,
     log df), the MAD start of the scale, GPB_GetAuxPars with two values, response predictions): tests/test_zz_laplace_t_gpu.py's model-API tests on the oracle-backed shim."""
     # (round 6: the standard-deviation cases of gamma and t run on the device only -- 2 x 10 gradient evaluations of the C restatement each; the t_fix_df one runs here)
-    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_t_gpu.py"], extra=["-k", "model_api and not (standard_deviations and (gamma_n1500 or t_n1500))"])
-    assert "7 passed" in tail, tail      # (round 6: + "t_fix_df" and likelihood_additional_param, standard deviations of auxiliary parameters, nelder_mead with the shape in the simplex; 2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
+    tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_t_gpu.py"], extra=["-k", "model_api and not (standard_deviations and (gamma_n1500 or t_n1500)) and not (gradient_descent and (gd_gamma or gd_t))"])
+    assert "9 passed" in tail, tail      # (round 6, later: + gradient_descent with estimated auxiliary parameters -- the two short fits here, the 25-40-iteration ones on the device (all five pass on this shim: 6 min); round 6: + "t_fix_df" and likelihood_additional_param, standard deviations of auxiliary parameters, nelder_mead with the shape in the simplex; 2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
 
 
 def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):

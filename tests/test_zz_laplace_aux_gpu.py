@@ -139,8 +139,8 @@ def test_model_api_errors_for_the_auxiliary_parameter_likelihoods(gpb):
         mdl.neg_log_likelihood(np.array([1.0, 0.1]), -y)
     with pytest.raises(gpb.GPBoostError, match="not > 0"):
         mdl.set_optim_params({"init_aux_pars": [-2.0]})
-    with pytest.raises(gpb.GPBoostError, match="lbfgs"):
-        mdl.fit(y, params={"optimizer_cov": "gradient_descent"})
+    mdl.fit(y, params={"optimizer_cov": "gradient_descent", "maxit": 2})       # (an error until round 6; the fits against the reference: tests/test_zz_laplace_t_gpu.py)
+    assert 1 <= mdl.get_num_optim_iter() <= 2 and np.all(np.isfinite(mdl.get_aux_pars()))
     m2 = gpb.GPModel(likelihood="negative_binomial", gp_coords=coords, cov_function="exponential", gp_approx="vecchia", num_neighbors=10)
     with pytest.raises(gpb.GPBoostError, match="non-integer"):
         m2.neg_log_likelihood(np.array([1.0, 0.1]), y)

@@ -222,3 +222,24 @@ def test_model_api_nelder_mead_with_an_estimated_auxiliary_parameter_follows_the
     np.testing.assert_allclose(mdl.get_aux_pars(), g["gamma_n1500_nm_aux"], rtol=1e-6)
     nll = mdl.get_current_neg_log_likelihood(); ref = float(g["gamma_n1500_nm_negll"])
     assert abs(nll - ref) <= 1e-8 * abs(ref), (nll, ref)
+
+
+@pytest.mark.parametrize("name", sorted(cases.LAPLACE_AUX_GD_CASES))
+def test_model_api_gradient_descent_with_estimated_auxiliary_parameters_follows_the_reference(gpb, name):
+    """Round 6: optimizer_cov = "gradient_descent" for likelihoods whose auxiliary parameters are estimated -- the reference's internal loop with one learning rate for the
+    covariance block and one for the auxiliary block, both Armijo conditions, joint halving, Nesterov momentum on the log scale (re_model_template.h:1514-1660, :8354-8375,
+    :8420-8470, :8690-8850; gpb_optim.cpp run_gradient_descent_laplace_aux) -- against the unmodified reference at cases.LAPLACE_TIGHT
+    (tests/golden/laplace_aux_gd_ref.npz): the iteration count, estimates 1e-6, value 1e-8."""
+    g = np.load(os.path.join(GOLD, "laplace_aux_gd_ref.npz"))
+    coords, y, c, lik, naux, cfg = cases.aux_gd_case(name)
+    mdl = gpb.GPModel(likelihood=lik, gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], gp_approx="vecchia", num_neighbors=c["m"],
+                      vecchia_ordering=c["ordering"], seed=c["seed"])
+    params = dict(cases.LAPLACE_TIGHT, optimizer_cov="gradient_descent")
+    for k, v in cfg.items():
+        params[{"max_iter": "maxit"}.get(k, k)] = v
+    mdl.fit(y, params=params)
+    assert mdl.get_num_optim_iter() == int(g[name + "_num_it"]), (mdl.get_num_optim_iter(), int(g[name + "_num_it"]))
+    np.testing.assert_allclose(mdl.get_cov_pars(), g[name + "_cov_pars"], rtol=1e-6)
+    np.testing.assert_allclose(mdl.get_aux_pars()[:naux], g[name + "_aux"], rtol=1e-6)
+    nll = mdl.get_current_neg_log_likelihood(); ref = float(g[name + "_negll"])
+    assert abs(nll - ref) <= 1e-8 * abs(ref), (nll, ref)
