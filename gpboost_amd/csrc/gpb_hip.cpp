@@ -58,15 +58,21 @@ int fail(const char* fmt, ...) {
 // counts both); the table goes to stderr at process exit and on gpb_hip_api_timing_report.  The integration's counterpart of the reference's TIMETAG
 // build (include/LightGBM/utils/common.h:989-1068): it separates the time the reference's host code spends INSIDE this library from the time it spends
 // in its own code around the seams.  Off (the default): one predictable branch per call.
+// GPB_HIP_API_TIMING=2 (round 6): additionally the TIMELINE of the calls since the last report -- name, duration and the gap since the previous call returned, i.e. the
+// time the caller's own code ran between two seams (route B: the reference's O(n) host passes of a boosting iteration; nested calls are listed where they return).
 struct ApiTiming {
   struct Row { const char* name; double seconds; long calls; };
+  struct Ev { const char* name; double t0, t1; };
   std::mutex mu;
   std::vector<Row> rows;
-  bool on;
-  ApiTiming() { const char* e = std::getenv("GPB_HIP_API_TIMING"); on = e && e[0] && e[0] != '0'; }
+  std::vector<Ev> timeline;
+  bool on, line;
+  std::chrono::steady_clock::time_point epoch = std::chrono::steady_clock::now();
+  ApiTiming() { const char* e = std::getenv("GPB_HIP_API_TIMING"); on = e && e[0] && e[0] != '0'; line = on && e[0] == '2'; }
   ~ApiTiming() { if (on) report(stderr, true); }
-  void add(const char* name, double s) {
+  void add(const char* name, double s, std::chrono::steady_clock::time_point t0) {
     std::lock_guard<std::mutex> lk(mu);
+    if (line && timeline.size() < 200000) { const double a = std::chrono::duration<double>(t0 - epoch).count(); timeline.push_back(Ev{ name, a, a + s }); }
     for (auto& r : rows) if (r.name == name || std::strcmp(r.name, name) == 0) { r.seconds += s; ++r.calls; return; }
     rows.push_back(Row{ name, s, 1 });
   }
@@ -76,7 +82,18 @@ struct ApiTiming {
     std::sort(v.begin(), v.end(), [](const Row& a, const Row& b) { return a.seconds > b.seconds; });
     std::fprintf(f, "[gpb_hip api timing] %-52s %10s %12s %12s\n", "entry point (inclusive)", "calls", "total ms", "ms / call");
     for (const auto& r : v) std::fprintf(f, "[gpb_hip api timing] %-52s %10ld %12.3f %12.4f\n", r.name, r.calls, 1e3 * r.seconds, 1e3 * r.seconds / r.calls);
-    if (reset) rows.clear();
+    if (line && !timeline.empty()) {
+      std::fprintf(f, "[gpb_hip api timeline] %-48s %12s %12s %14s\n", "call (in order of return)", "start ms", "inside ms", "caller ms before");
+      double prev_end = timeline.front().t0;
+      const size_t first = timeline.size() > 400 ? timeline.size() - 400 : 0;     // the last 400 calls
+      for (size_t i = 0; i < timeline.size(); ++i) {
+        const Ev& e = timeline[i];
+        const double gap = e.t0 > prev_end ? e.t0 - prev_end : 0.0;               // (a nested call starts before its parent returns: no gap)
+        if (i >= first) std::fprintf(f, "[gpb_hip api timeline] %-48s %12.3f %12.3f %14.3f\n", e.name, 1e3 * (e.t0 - timeline.front().t0), 1e3 * (e.t1 - e.t0), 1e3 * gap);
+        if (e.t1 > prev_end) prev_end = e.t1;
+      }
+    }
+    if (reset) { rows.clear(); timeline.clear(); }
   }
 };
 ApiTiming g_api_timing;
@@ -84,7 +101,7 @@ struct ApiTimer {
   const char* name;
   std::chrono::steady_clock::time_point t0;
   explicit ApiTimer(const char* n) : name(g_api_timing.on ? n : nullptr) { if (name) t0 = std::chrono::steady_clock::now(); }
-  ~ApiTimer() { if (name) g_api_timing.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+  ~ApiTimer() { if (name) g_api_timing.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), t0); }
 };
 
 #define API_BEGIN() ApiTimer api_timer_(__func__); try {
@@ -441,6 +458,11 @@ const char* gpb_hip_get_last_error(void) { return g_err; }
 int gpb_hip_api_timing_report(int reset) {
   if (!g_api_timing.on) return fail("gpb_hip_api_timing_report: GPB_HIP_API_TIMING is not set");
   g_api_timing.report(stderr, reset != 0);
+  return 0;
+}
+
+int gpb_hip_api_mark(const char* name) {
+  if (g_api_timing.line && name) g_api_timing.add(name, 0.0, std::chrono::steady_clock::now());
   return 0;
 }
 

@@ -50,6 +50,10 @@ GPB_HIP_EXPORT const char* gpb_hip_get_last_error(void);
  * (include/LightGBM/utils/common.h:989-1068) for an integration: time inside this library against time in the caller's host code.  -1 if the
  * variable is not set. */
 GPB_HIP_EXPORT int gpb_hip_api_timing_report(int reset);
+/* GPB_HIP_API_TIMING=2 additionally records the TIMELINE of the calls (name, duration, the caller's time since the previous call returned) and prints the last 400 entries
+ * with the table.  gpb_hip_api_mark puts a named entry of zero duration on that timeline from the caller's side -- an integration brackets its own host passes with it
+ * (`name` must outlive the report: a string literal).  A no-op unless the timeline is on. */
+GPB_HIP_EXPORT int gpb_hip_api_mark(const char* name);
 GPB_HIP_EXPORT int gpb_hip_device_count(int* count);
 /* Make `device` current for the calling thread (handles bind to the device current at their creation). */
 GPB_HIP_EXPORT int gpb_hip_set_device(int device);

@@ -81,6 +81,7 @@ class HIPTreeLearner : public SerialTreeLearner {
       // a device-grown tree left the partition with that tree's leaf count (ResetByLeafPred -> ResetLeaves(nl)); the reference's Train
       // indexes leaf_begin_ / leaf_count_ up to num_leaves (DataPartition::Split)
       data_partition_->ResetLeaves(config_->num_leaves);
+      labels_tree_leaves_ = 0;                          // the partition below is the host learner's: leaf_of_row_ no longer describes it
       return SerialTreeLearner::Train(gradients, hessians, is_first_tree);
     }
     if (!announced_) { Log::Info("HIPTreeLearner: whole trees are grown on the GPU (gpb_hip_hist_grow_tree)"); announced_ = true; }
@@ -154,8 +155,10 @@ class HIPTreeLearner : public SerialTreeLearner {
                   static_cast<int>(info[6 * k + 2]), static_cast<int>(info[6 * k + 3]), info[6 * k + 4], info[6 * k + 5], static_cast<float>(gain[k]),
                   train_data_->FeatureBinMapper(inner)->missing_type(), dl[k] != 0);
     }
+    labels_tree_leaves_ = 0;
     if (bag_rows_ == nullptr) {                      // (ResetByLeafLabels: ResetByLeafPred as a parallel counting sort, data_partition.hpp seam)
       data_partition_->ResetByLeafLabels(leaf_of_row.data(), hist_rows_, nl);
+      labels_tree_leaves_ = nl;                      // every row is in the tree and leaf_of_row_ IS the partition: the two O(n) walks below read it directly
     } else if (bag_is_subset_) {                     // the subset Dataset numbers its rows by position in the bag
       std::vector<int> pred(bag_cnt_);
       for (data_size_t k = 0; k < bag_cnt_; ++k) pred[k] = leaf_of_row[bag_rows_[k]];
@@ -170,6 +173,29 @@ class HIPTreeLearner : public SerialTreeLearner {
       for (data_size_t k = 0; k < bag_cnt_; ++k) idx[k] = bag_rows_[idx[k]];
     }
     return tree.release();
+  }
+
+  // GBDT's two O(n) walks over the partition of the tree just grown (gbdt.cpp:470-476 Newton leaf values of the GPBoost algorithm, :606-611 UpdateScore): the base class
+  // runs one thread per LEAF over that leaf's row list (serial_tree_learner.cpp:818-828, serial_tree_learner.h:98-113) -- a 31-leaf tree over 1e6 rows keeps most threads
+  // idle behind the biggest leaf.  After a device-grown tree without bagging the row -> leaf labels of gpb_hip_hist_grow_tree are that partition, so both walks run
+  // over ROWS instead: same values (every row receives its leaf's index / one addition of its leaf's output), sequential memory, all threads.
+  void GetDataLeafIndices(Tree* tree, int* data_leaf_index) const override {
+    if (labels_tree_leaves_ > 0 && tree->num_leaves() == labels_tree_leaves_ && static_cast<data_size_t>(leaf_of_row_.size()) == num_data_) {
+#pragma omp parallel for schedule(static)
+      for (data_size_t i = 0; i < num_data_; ++i) data_leaf_index[i] = leaf_of_row_[i];
+      return;
+    }
+    SerialTreeLearner::GetDataLeafIndices(tree, data_leaf_index);
+  }
+  void AddPredictionToScore(const Tree* tree, double* out_score) const override {
+    if (labels_tree_leaves_ > 1 && tree->num_leaves() == labels_tree_leaves_ && static_cast<data_size_t>(leaf_of_row_.size()) == num_data_) {
+      std::vector<double> out(tree->num_leaves());
+      for (int l = 0; l < tree->num_leaves(); ++l) out[l] = static_cast<double>(tree->LeafOutput(l));
+#pragma omp parallel for schedule(static)
+      for (data_size_t i = 0; i < num_data_; ++i) out_score[i] += out[leaf_of_row_[i]];
+      return;
+    }
+    SerialTreeLearner::AddPredictionToScore(tree, out_score);
   }
 
  protected:
@@ -349,6 +375,7 @@ class HIPTreeLearner : public SerialTreeLearner {
   std::vector<score_t> full_grad_, full_hess_;         // learner-owned staging buffers (page-locked once: gpb_hip_hist_register_host_buffers)
   const score_t* registered_grad_ = nullptr; const score_t* registered_hess_ = nullptr;
   std::vector<int32_t> leaf_of_row_;                   // row -> leaf of the last device-grown tree
+  int labels_tree_leaves_ = 0;                         // > 0: leaf_of_row_ equals the data partition of a tree with this many leaves (device-grown, no bagging)
   const data_size_t* bag_rows_ = nullptr;              // the current bag (GBDT's bag_data_indices_, alive until the next SetBaggingData)
   data_size_t bag_cnt_ = 0;
 };

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from oracle import refdrv   # noqa: E402
 from tests import cases     # noqa: E402
 
-LIBP = os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so")
+LIBP = os.environ.get("GPB_ROUTEB_LIB", os.path.join(ROOT, "integration", "_build", "lib_gpboost_hip.so"))       # (GPB_ROUTEB_LIB: another build of route B, e.g. one with timeline markers)
 print("library:", LIBP, flush=True)
 
 # ---- (1) GP ---------------------------------------------------------------------------------------------------------------------
