@@ -102,8 +102,8 @@ def laplace_kernel_rooflines(n4=100000, m4=30):
         ("pc_combine_kernel<4>", "X - L_k x2 on the 50-probe block", lambda k: 13 * (n4 * k * 8 + 9 * vec)),
     )
     out = {}
-    for tag, k in (("vadu", 0), ("pivchol", 50), ("fitc", 200)):
-        path = os.path.join(ROOT, "profiles", "r06_a_trace_config4_%s_summary.txt" % tag)
+    for tag, k in (("vadu", 0), ("pivchol", 50), ("fitc", 200), ("vecchia_response", 0)):
+        path = os.path.join(ROOT, "profiles", ("r06_g_trace_config4_%s_summary.txt" if tag == "vecchia_response" else "r06_a_trace_config4_%s_summary.txt") % tag)
         if not os.path.exists(path):
             continue
         rows = []
@@ -120,7 +120,7 @@ def laplace_kernel_rooflines(n4=100000, m4=30):
                                  "achieved": b / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
                     break
         if rows:
-            out[tag] = {"source": "profiles/r06_a_trace_config4_%s_summary.txt (rocprofv3 --kernel-trace --stats; kernel durations, not host timers)" % tag, "kernels": rows}
+            out[tag] = {"source": "%s (rocprofv3 --kernel-trace --stats; kernel durations, not host timers)" % os.path.relpath(path, ROOT), "kernels": rows}
     return out or None
 
 
@@ -675,7 +675,8 @@ def main():
                     }
                 # round 5: the same evaluation with the reference's other built preconditioners, cg_preconditioner_type = "pivoted_cholesky" (rank 50) / "fitc" (200 inducing points): the solves in the
                 # (W^-1 + Sigma) form, fewer (latency-bound) iterations -- another algorithm of the reference, not a faster kernel
-                for pcname in ("pivoted_cholesky", "fitc"):
+                # round 6: + "vecchia_response" (P = the Vecchia factor of W^-1 + Sigma, renewed per Newton step by one point-kernel launch; evaluation only, as in the reference)
+                for pcname in ("pivoted_cholesky", "fitc", "vecchia_response"):
                     try:
                         m4.set_optim_params({"cg_preconditioner_type": pcname})
                         m4.neg_log_likelihood(np.array([1.0, 0.1]), y4)
@@ -802,6 +803,21 @@ def main():
                             "setup_s": round(ra["setup_s"], 3), "device_trees_vs_host_trees_max_abs_prediction_diff": float(np.abs(rt["pred"] - ra["pred"]).max()),
                             "cpu_path_same_build_s_first_iteration": round(rc["loop_s"], 3),
                             "cpu_path_note": "GPU_use = false, device_type = cpu of the same library: ONE boosting iteration (its first; the loop is not run to 100 on the CPU here)"}
+                        # round 6: the same loop at n = 1e6 (50 features, 31 leaves, device trees, covariance parameters trained in the loop): 12 iterations, median of the last 10
+                        try:
+                            rng6 = np.random.default_rng(11)
+                            n6 = 1000000
+                            c6 = rng6.uniform(size=(n6, 2)); X6 = np.ascontiguousarray(rng6.uniform(size=(n6, 50)))
+                            y6 = np.sin(4 * X6[:, 0]) + X6[:, 1] ** 2 + np.sin(5 * c6[:, 0]) * np.cos(4 * c6[:, 1]) + 0.3 * rng6.standard_normal(n6)
+                            r6 = rb.boosting_loop(c6, X6, y6, 12, gpu_use=True, device_trees=True)
+                            out["config3_boosting_iteration"]["route_b"]["n1e6_device_trees"] = {
+                                "workload": "n=1000000, 50 features, 255 bins, 31 leaves, Vecchia m=30, train_gp_model_cov_pars=true: LGBM_BoosterUpdateOneIter x 12 through the reference's Booster",
+                                "ms_per_iteration_median_of_last_10": round(1e3 * float(np.median(r6["per_iteration_s"][2:])), 3),
+                                "ms_per_iteration_min_max_of_last_10": [round(1e3 * float(np.min(r6["per_iteration_s"][2:])), 3), round(1e3 * float(np.max(r6["per_iteration_s"][2:])), 3)],
+                                "setup_s_model_dataset_booster": round(r6["setup_s"], 3)}
+                            del X6, c6, y6, r6
+                        except Exception as e:
+                            out["config3_boosting_iteration"]["route_b"]["n1e6_device_trees"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 except Exception as e:
                     out["config3_boosting_iteration"]["route_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
             except Exception as e:

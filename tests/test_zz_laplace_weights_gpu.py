@@ -119,6 +119,7 @@ def test_weight_errors_of_the_model_api(gpb):
     wn = w.copy(); wn[3] = -1.0
     with pytest.raises(gpb.GPBoostError, match="negative values"):
         gpb.GPModel(weights=wn, **kw)
+    # (sample weights together with covariates were refused until round 6; the fits against the reference: tests/test_zz_laplace_train_re_gpu.py::test_fit_with_covariates_and_sample_weights)
     mdl = gpb.GPModel(weights=w, **kw)
-    with pytest.raises(gpb.GPBoostError, match="sample weights together with covariates"):
-        mdl.fit(y, X=np.column_stack([np.ones(len(y)), coords[:, 0]]))
+    mdl.fit(y, X=np.column_stack([np.ones(len(y)), coords[:, 0]]), params={"maxit": 2})
+    assert np.all(np.isfinite(mdl.get_coef())) and np.all(np.isfinite(mdl.get_cov_pars()))
