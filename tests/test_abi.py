@@ -89,3 +89,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libgpb_oracle" not in txt, f
+
+
+def test_api_timeline_and_marks(lib_built):
+    """GPB_HIP_API_TIMING=2 (round 6): the call timeline next to the per-entry-point table, with the caller's own marks (gpb_hip_api_mark) -- the tool that found the reference's
+    per-leaf walks in route B's boosting iteration.  No device needed: marks and the report do not touch it.  Without the variable the report is an error
+    and a mark a no-op."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\n"
+            "L = ctypes.CDLL(sys.argv[1])\n"
+            "L.gpb_hip_get_last_error.restype = ctypes.c_char_p\n"
+            "a = ctypes.c_char_p(b'MARK first'); b = ctypes.c_char_p(b'MARK second')\n"
+            "assert L.gpb_hip_api_mark(a) == 0 and L.gpb_hip_api_mark(b) == 0\n"
+            "rc = L.gpb_hip_api_timing_report(1)\n"
+            "print('rc', rc, L.gpb_hip_get_last_error().decode() if rc else '')\n")
+    on = subprocess.run([sys.executable, "-c", code, lib_built], env=dict(os.environ, GPB_HIP_API_TIMING="2"), capture_output=True, text=True)
+    assert on.returncode == 0 and "rc 0" in on.stdout, on.stdout + on.stderr
+    lines = [l for l in on.stderr.splitlines() if l.startswith("[gpb_hip api timeline]")]
+    assert len(lines) >= 3 and "MARK first" in lines[1] and "MARK second" in lines[2], on.stderr
+    off = subprocess.run([sys.executable, "-c", code, lib_built], env={k: v for k, v in os.environ.items() if k != "GPB_HIP_API_TIMING"}, capture_output=True, text=True)
+    assert off.returncode == 0 and "rc -1" in off.stdout and "GPB_HIP_API_TIMING is not set" in off.stdout and "timeline" not in off.stderr, off.stdout + off.stderr
