@@ -185,10 +185,10 @@ bool is_proportion_likelihood(const std::string& lik) {
 bool is_logit_link(const std::string& lik) { return lik == "bernoulli_logit" || lik == "binomial_logit" || lik == "quasi_bernoulli_logit"; }
 bool is_probit_link(const std::string& lik) { return lik == "bernoulli_probit" || lik == "binomial_probit" || lik == "quasi_bernoulli_probit"; }
 int laplace_link_id(const std::string& lik) {
-  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : (lik == "t" ? 6 : (lik == "lognormal" ? 7 : 0))))));
+  return is_probit_link(lik) ? 1 : (lik == "poisson" ? 2 : (lik == "gamma" ? 3 : (lik == "negative_binomial" ? 4 : (lik == "beta" ? 5 : (lik == "t" ? 6 : (lik == "lognormal" ? 7 : (lik == "gaussian_latent" ? 8 : 0)))))));
 }
 bool supported_non_gaussian(const std::string& lik) {
-  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || lik == "lognormal" || is_proportion_likelihood(lik);
+  return lik == "bernoulli_logit" || lik == "bernoulli_probit" || lik == "poisson" || lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "t" || lik == "lognormal" || lik == "gaussian_latent" || is_proportion_likelihood(lik);
 }
 // Likelihood::ParseLikelihoodAlias (likelihoods.h:10254-10275)
 // "<likelihood>_fix_df" -> "<likelihood>", *fix_df = true (ParseLikelihoodAliasEstimateAdditionalPars, likelihoods.h:10466-10471: the suffix is stripped from any name)
@@ -204,7 +204,7 @@ std::string parse_likelihood_alias(const std::string& lik) {
   if (lik == "quasi_binary" || lik == "quasi_binary_logit") return "quasi_bernoulli_logit";
   return lik;
 }
-int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "lognormal") ? 1 : 0); }      // t: scale, df (likelihoods.h:398-407)
+int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma" || lik == "negative_binomial" || lik == "beta" || lik == "lognormal" || lik == "gaussian_latent") ? 1 : 0); }      // t: scale, df (likelihoods.h:398-407)
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
@@ -290,12 +290,13 @@ double initial_aux_par(const std::string& lik, int n, const double* y, const dou
     const double s = std::max(log_avg - avg_log, 1e-8);
     return (3. - s + std::sqrt((s - 3.) * (s - 3.) + 24. * s)) / (12. * s);
   }
-  if (lik == "negative_binomial") {
+  if (lik == "negative_binomial" || lik == "gaussian_latent") {      // (gaussian_latent shares the moment pass of the counts, y / exp(fixed effect) included: likelihoods.h:1857-1882; its start is half the sample variance, :2012-2014)
     double avg = 0., sum_sq = 0., sw = 0.;
     for (int i = 0; i < n; ++i) { const double w = wts ? wts[i] : 1.0; const double v = fe ? y[i] / std::exp(fe[i]) : y[i]; avg += w * v; sum_sq += w * v * v; sw += w; }
     avg /= sw;
     const double avg_sq = avg * avg;
     const double sample_var = std::max((sum_sq - sw * avg_sq) / (sw - 1), 1e-6);
+    if (lik == "gaussian_latent") return sample_var / 2.;
     return sample_var <= avg ? 100 * avg_sq : avg_sq / (sample_var - avg);
   }
   return 1.;
@@ -337,8 +338,8 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
   if (!y_data) return set_error("y_data is NULL: the HIP hot path evaluates the likelihood at the response passed in");
   mdl->labels.resize(mdl->n);
   const bool poisson = mdl->likelihood == "poisson" || mdl->likelihood == "negative_binomial";     // integer-valued responses >= 0
-  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t" || mdl->likelihood == "lognormal") {      // likelihoods.h:1365-1373 (gamma, lognormal): strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1); t: any real value
-    const bool is_beta = mdl->likelihood == "beta", is_t = mdl->likelihood == "t";
+  if (mdl->likelihood == "gamma" || mdl->likelihood == "beta" || mdl->likelihood == "t" || mdl->likelihood == "lognormal" || mdl->likelihood == "gaussian_latent") {      // likelihoods.h:1365-1373 (gamma, lognormal): strictly positive, real-valued; beta: :1403-1409, strictly inside (0, 1); t: any real value
+    const bool is_beta = mdl->likelihood == "beta", is_t = mdl->likelihood == "t" || mdl->likelihood == "gaussian_latent";      // (is_t: any finite real value)
     mdl->resp_real.resize(mdl->n);
     for (int k = 0; k < mdl->n; ++k) {
       const double yk = y_data[mdl->perm[k]];
@@ -347,7 +348,7 @@ int laplace_upload_data(REModelHip* mdl, const double* y_data, const double* fix
       else if (!(yk > 0.)) return set_error(" Must have y > 0 for the response variable ('y') for likelihood = '%s', found %g ", mdl->likelihood.c_str(), yk);
       mdl->resp_real[k] = yk; mdl->labels[k] = 0;
     }
-    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, is_beta ? 5 : (is_t ? 6 : (mdl->likelihood == "lognormal" ? 7 : 3)))) return shim_error();
+    if (gpb_hip_vecchia_laplace_set_likelihood(mdl->vh, laplace_link_id(mdl->likelihood))) return shim_error();
     if (mdl->n_re > 0) {
       std::vector<double> grouped(mdl->n);
       for (int g = 0; g < mdl->n; ++g) grouped[g] = mdl->resp_real[mdl->dorder[g]];
@@ -596,6 +597,13 @@ int initialize_cov_pars_if_not_defined(REModelHip* mdl, const double* y_data, co
       double th3[3];
       if (find_init_cov_par(mdl, y_data, fixed_effects, th3)) return -1;
       mdl->cov_pars_tr[0] = mdl->optim.optimizer == "nelder_mead" ? 0.1 : 1.;       // init_marg_var (re_model_template.h:4904-4909)
+      if (mdl->likelihood == "gaussian_latent") {      // IsGaussianLikelihood(): half the sample variance of y - fixed effects, whatever the optimiser (:4866-4896, :4903-4906)
+        double mean = 0., var = 0.;
+        for (int i = 0; i < mdl->n; ++i) mean += fixed_effects ? y_data[i] - fixed_effects[i] : y_data[i];
+        mean /= mdl->n;
+        for (int i = 0; i < mdl->n; ++i) { const double r = (fixed_effects ? y_data[i] - fixed_effects[i] : y_data[i]) - mean; var += r * r; }
+        mdl->cov_pars_tr[0] = var / (mdl->n - 1) / 2.;
+      }
       mdl->cov_pars_tr[1] = th3[2]; mdl->cov_pars_tr[2] = 0.;
     } else if (find_init_cov_par(mdl, y_data, fixed_effects, mdl->cov_pars_tr)) return -1;
     std::copy(mdl->cov_pars_tr, mdl->cov_pars_tr + 3, mdl->init_cov_pars_tr);
@@ -987,6 +995,10 @@ bool predict_response_host(const std::string& lik, int n, double* mean, double* 
       }
       mean[i] = rm;
     }
+    return true;
+  }
+  if (lik == "gaussian_latent") {           // likelihoods.h:9853-9857: the latent mean; variance + the error variance
+    if (predict_var) for (int i = 0; i < n; ++i) var[i] += aux;
     return true;
   }
   if (lik == "lognormal") {                 // likelihoods.h:9868-9888: mean exp(m + v / 2); variance Var(E[y | b]) + E[Var(y | b)] with aux = variance of log y
@@ -3011,7 +3023,7 @@ int GPB_GetAuxPars(REModelHandle handle, double* aux_pars, char* out_str, bool c
     }   // (C_API_BEGIN's try block)
     catch (const std::exception& e) { return set_error("%s", e.what()); } catch (...) { return set_error("unknown exception"); }
   }
-  if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : (mdl->likelihood == "lognormal" ? "log_variance" : "shape")));      // lognormal: likelihoods.h:507       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
+  if (out_str) std::strcpy(out_str, mdl->likelihood == "t" ? "scale_SEP_df" : (mdl->likelihood == "beta" ? "precision" : (mdl->likelihood == "lognormal" ? "log_variance" : (mdl->likelihood == "gaussian_latent" ? "error_variance" : "shape"))));      // lognormal: likelihoods.h:507       // GetNamesAuxPars joins with "_SEP_" (likelihoods.h:2809-2814)         // names_aux_pars_ of gamma / negative_binomial (likelihoods.h:300, :319), beta (:380)
   return 0;
 }
 

@@ -73,7 +73,7 @@ __device__ __forceinline__ double inv_mills_phi(double z) {
 //  branches, exactly the end points at y = 0 and y = 1: LogLikBinomialProbit :11394-11398, FirstDeriv :12468-12474, SecondDeriv :13293-13305, third :13800-13820)
 template <int LINK>
 __device__ __forceinline__ double resp_at(const LikResp& r, int d) {
-  if constexpr (LINK == 3 || LINK == 5 || LINK == 6 || LINK == 7) return r.yd[d];
+  if constexpr (LINK == 3 || LINK == 5 || LINK == 6 || LINK == 7 || LINK == 8) return r.yd[d];
   else if constexpr (LINK == 0 || LINK == 1) return r.yd ? r.yd[d] : (double)r.yi[d];
   else return (double)r.yi[d];
 }
@@ -116,6 +116,9 @@ __device__ __forceinline__ void lik_grad_info(double y, double x, double aux, do
       grad = y * r1 + (1.0 - y) * -r0;
       w = y * r1 * (x + r1) + (1.0 - y) * -r0 * (x - r0);
     }
+  } else if constexpr (LINK == 8) {       // gaussian_latent (round 6: the Gaussian likelihood through the Laplace machinery, aux = error variance): FirstDerivLogLikGaussian (likelihoods.h:12514-12516), information 1 / aux (:12956-12962)
+    grad = (y - x) / aux;
+    w = 1.0 / aux;
   } else if constexpr (LINK == 7) {       // lognormal (round 5, fourth slice; mean of y = exp(location), aux = variance of log y): FirstDerivLogLikLogNormal (likelihoods.h:12534-12538), SecondDerivNegLogLikLogNormal (:13384-13386)
     grad = (log(y) - (x - 0.5 * aux)) / aux;
     w = 1.0 / aux;
@@ -155,6 +158,7 @@ __device__ __forceinline__ double lik_loglik(double y, double x, double aux, dou
   else if constexpr (LINK == 3) return -aux * (x + y * exp(-x));
   else if constexpr (LINK == 4) return y * x - (y + aux) * log(exp(x) + aux);
   else if constexpr (LINK == 7) { const double z = log(y) - (x - 0.5 * aux); return -0.5 * z * z / aux; }      // LogLikLogNormal (:11950-11958) without its constant
+  else if constexpr (LINK == 8) { const double res = y - x; return -res * res / 2.0 / aux; }                     // LogLikGaussian (:11927-11936) without its constant
   else if constexpr (LINK == 6) return -(aux2 + 1.0) / 2.0 * log(1.0 + (y - x) * (y - x) / (aux2 * aux * aux));       // LogLikT (:11915-11925) without its constant
   else if constexpr (LINK == 5) {
     const double mu = sigmoid_clamped(x);
@@ -885,7 +889,7 @@ __device__ __forceinline__ double lik_third(double y, double x, double aux, doub
   else if constexpr (LINK == 2) return exp(x);
   else if constexpr (LINK == 3) return -aux * y * exp(-x);                                            // likelihoods.h:13843-13849
   else if constexpr (LINK == 4) { const double mu = exp(x), mr = mu + aux; return -(y + aux) * mu * aux * (mu - aux) / (mr * mr * mr); }   // :13870-13878
-  else if constexpr (LINK == 6 || LINK == 7) return 0.0;                                               // lognormal: constant information (:13929-13933); t, fisher_laplace: the information does not depend on the mode (:410-415)
+  else if constexpr (LINK == 6 || LINK == 7 || LINK == 8) return 0.0;                                               // lognormal: constant information (:13929-13933); t, fisher_laplace: the information does not depend on the mode (:410-415)
   else if constexpr (LINK == 5) {                                                                      // :13892-13917
     const double mu = sigmoid_clamped(x), d = mu * (1.0 - mu), logit_y = log(y) - log1p(-y);
     const double dig1 = digamma_dev((1.0 - mu) * aux), dig2 = digamma_dev(mu * aux), tri1 = trigamma_dev((1.0 - mu) * aux), tri2 = trigamma_dev(mu * aux);
@@ -973,6 +977,9 @@ __global__ __launch_bounds__(1024) void lik_aux_grad_kernel(const double* __rest
       if constexpr (LINK == 7) {       // lognormal: the data sum of CalcGradNegLogLikAuxPars (:14275-14286) -> e (dsum, isum unused)
         const double z = log(yv) - (x - 0.5 * r);
         e += wd * ((z + 1.0) * 0.5 - (z * z) / (2.0 * r));
+      } else if constexpr (LINK == 8) {       // gaussian_latent: sum w resid^2 of CalcGradNegLogLikAuxPars (:14262-14274) -> e; the host scales it by -0.5 / aux and adds 0.5 n
+        const double res = yv - x;
+        e += wd * res * res;
       } else if constexpr (LINK == 6) {       // t: the two data sums of CalcGradNegLogLikAuxPars (:14241-14262): e -> log scale, dsum -> log df (isum unused)
         const double nu = y.aux2, nu_sigma2 = nu * r * r, res_sq = (yv - x) * (yv - x);
         e -= wd * (nu + 1.0) / (nu_sigma2 / res_sq + 1.0);
@@ -1202,6 +1209,7 @@ hipError_t lap_newton_setup(int link, const double* mode, const LikResp& y, cons
     case 5: hipLaunchKernelGGL(lik_newton_setup_kernel<5>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 6: hipLaunchKernelGGL(lik_newton_setup_kernel<6>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     case 7: hipLaunchKernelGGL(lik_newton_setup_kernel<7>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
+    case 8: hipLaunchKernelGGL(lik_newton_setup_kernel<8>, GRID1(n), 0, st, mode, y, fe, D, n, W, rhs, dw, rdw, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1251,6 +1259,7 @@ hipError_t lap_objective(int link, const double* x, const LikResp& y, const doub
     case 5: hipLaunchKernelGGL(lik_objective_kernel<5>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 6: hipLaunchKernelGGL(lik_objective_kernel<6>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     case 7: hipLaunchKernelGGL(lik_objective_kernel<7>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
+    case 8: hipLaunchKernelGGL(lik_objective_kernel<8>, dim3(1), dim3(1024), 0, st, x, y, fe, Bx, D, n, out2, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1814,6 +1823,7 @@ hipError_t lap_third_deriv(int link, const double* mode, const LikResp& y, const
     case 5: hipLaunchKernelGGL(lik_third_kernel<5>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 6: hipLaunchKernelGGL(lik_third_kernel<6>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     case 7: hipLaunchKernelGGL(lik_third_kernel<7>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
+    case 8: hipLaunchKernelGGL(lik_third_kernel<8>, GRID1(n), 0, st, mode, y, fe, n, dW3, dptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1828,6 +1838,7 @@ hipError_t lap_grad_F(int link, const double* mode, const LikResp& y, const doub
     case 5: hipLaunchKernelGGL(lik_grad_F_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 6: hipLaunchKernelGGL(lik_grad_F_kernel<6>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     case 7: hipLaunchKernelGGL(lik_grad_F_kernel<7>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
+    case 8: hipLaunchKernelGGL(lik_grad_F_kernel<8>, GRID1(n), 0, st, mode, y, fe, dld, sv, n, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1843,6 +1854,7 @@ hipError_t lap_grad_F_map(int link, const double* mode, const LikResp& y, const 
     case 5: hipLaunchKernelGGL(lik_grad_F_map_kernel<5>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 6: hipLaunchKernelGGL(lik_grad_F_map_kernel<6>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     case 7: hipLaunchKernelGGL(lik_grad_F_map_kernel<7>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
+    case 8: hipLaunchKernelGGL(lik_grad_F_map_kernel<8>, GRID1(n), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1854,6 +1866,7 @@ hipError_t lap_aux_grad(int link, const double* mode, const LikResp& y, const do
   else if (link == 5) hipLaunchKernelGGL(lik_aux_grad_kernel<5>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else if (link == 6) hipLaunchKernelGGL(lik_aux_grad_kernel<6>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else if (link == 7) hipLaunchKernelGGL(lik_aux_grad_kernel<7>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
+  else if (link == 8) hipLaunchKernelGGL(lik_aux_grad_kernel<8>, dim3(1), dim3(1024), 0, st, mode, y, fe, dld, dW3, sv, n, dptr, out3);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -203,7 +203,7 @@ class VecchiaState(object):
         return out
 
     def laplace_set_likelihood(self, likelihood):
-        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6, "lognormal": 7,
+        lid = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6, "lognormal": 7, "gaussian_latent": 8,
                "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}[likelihood]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_likelihood(self.h, C.c_int(lid)))
         self._lap_link = lid

@@ -504,7 +504,7 @@ def gen_rand_normal(n, t, seed=1, run_id=0):
     return out
 
 
-LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6, "lognormal": 7,
+LINK_ID = {"bernoulli_logit": 0, "bernoulli_probit": 1, "poisson": 2, "gamma": 3, "negative_binomial": 4, "beta": 5, "t": 6, "lognormal": 7, "gaussian_latent": 8,
            # round 5: proportions under the logit / probit links (real-valued response in [0, 1]; binomial_*: trials = orc.sample_weights, binomial constant)
            "binomial_logit": 0, "binomial_probit": 1, "quasi_bernoulli_logit": 0, "quasi_bernoulli_probit": 1}
 PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_logit", "quasi_bernoulli_probit")
@@ -512,7 +512,7 @@ PROPORTION_LIKELIHOODS = ("binomial_logit", "binomial_probit", "quasi_bernoulli_
 
 def _responses(likelihood, y):
     """-> (int32 responses, float64 responses | None): gamma's response is real-valued (handed to the C side through orc_set_aux)."""
-    if likelihood in ("gamma", "beta", "t", "lognormal") or likelihood in PROPORTION_LIKELIHOODS:
+    if likelihood in ("gamma", "beta", "t", "lognormal", "gaussian_latent") or likelihood in PROPORTION_LIKELIHOODS:
         yd = np.ascontiguousarray(y, dtype=np.float64)
         lib().orc_set_binomial(C.c_int(1 if likelihood.startswith("binomial") else 0))
         return np.zeros(yd.shape[0], dtype=np.int32), yd

@@ -136,6 +136,10 @@ LAPLACE_T_CASES = {
     # likelihoods.h:30-34, :505-513): mean of y = exp(location)
     "lognormal_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="lognormal", aux=(0.3,), true_s2=0.2),
     "lognormal_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="lognormal", aux=(0.15,), true_s2=0.1),
+    # gaussian_latent (round 6: the Gaussian likelihood through the Laplace machinery, ONE auxiliary parameter "error_variance", constant information 1 / aux, one Newton step
+    # with one trial point -- likelihoods.h:458-475): y = latent + sqrt(s2) * normal
+    "gaussian_latent_n1500": dict(model="lap_u2d_n1500_mat15_m30", lik="gaussian_latent", aux=(0.3,), true_s2=0.2),
+    "gaussian_latent_u3d_n1200": dict(model="lap_u3d_n1200_mat25_m15", lik="gaussian_latent", aux=(0.15,), true_s2=0.1),
 }
 
 
@@ -169,6 +173,8 @@ def make_t_data(tc):
     if tc.get("lik", "t") == "lognormal":      # log y ~ N(latent - s2 / 2, s2)
         s2 = tc["true_s2"]
         return coords, np.exp(latent - 0.5 * s2 + np.sqrt(s2) * np.random.default_rng(c["seed_data"] + 4100).standard_normal(n))
+    if tc.get("lik", "t") == "gaussian_latent":
+        return coords, latent + np.sqrt(tc["true_s2"]) * np.random.default_rng(c["seed_data"] + 4200).standard_normal(n)
     y = latent + tc["true_scale"] * np.random.default_rng(c["seed_data"] + 4000).standard_t(tc["true_df"], size=n)
     return coords, y
 

@@ -86,6 +86,10 @@ double mock_tetragamma(double x) {
   return value + (-1.0 / z2 - 1.0 / z3 - 0.5 / z4 + 1.0 / (6.0 * z6) - 1.0 / (6.0 * z8) + 3.0 / (10.0 * z10));
 }
 void lik_terms(int link, double y, double x, double* first, double* info, double* dinfo) {
+  if (link == 8) {       // gaussian_latent: FirstDerivLogLikGaussian (likelihoods.h:12514-12516), information 1 / aux
+    *first = (y - x) / g_mock_aux; *info = 1. / g_mock_aux; *dinfo = 0.;
+    return;
+  }
   if (link == 7) {       // lognormal: FirstDerivLogLikLogNormal, SecondDerivNegLogLikLogNormal (likelihoods.h:12534-12538, :13384-13386); constant information
     *first = (std::log(y) - (x - 0.5 * g_mock_aux)) / g_mock_aux; *info = 1. / g_mock_aux; *dinfo = 0.;
     return;
@@ -159,7 +163,7 @@ struct gpb_hip_vecchia {
   bool real_resp = false, binomial = false;      // proportions under the logit / probit links (binomial_*, quasi_bernoulli_*)
   int pc_type = 0, pc_rank = 50;                  // cg_preconditioner_type: 0 = vadu, 1 = pivoted_cholesky with pc_rank columns, 2 = fitc with the inducing points pc_ip
   std::vector<double> pc_ip; int pc_nip = 0;       // k x d column-major
-  double yv(int k) const { return (link == 3 || link == 5 || link == 6 || link == 7 || real_resp) ? resp_real[k] : (double)labels[k]; }
+  double yv(int k) const { return (link == 3 || link == 5 || link == 6 || link == 7 || link == 8 || real_resp) ? resp_real[k] : (double)labels[k]; }
   std::vector<int> re_ptr;                     // empty: one datum per random effect
   std::vector<double> mode, mode_prev, dld, sv; double grad2[2] = {0., 0.};
   bool has_mode = false, grad_state = false;
@@ -311,7 +315,7 @@ int laplace_run(gpb_hip_vecchia* h, int cov, double var, double a, int nrv, int 
   std::vector<double> dbg((size_t)2 * n + 8, 0.);
   double out6[6] = {0, 0, 0, 0, 0, 0};
   const bool ctx = h->link >= 3 || h->real_resp;
-  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->link == 6 || h->link == 7 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
+  if (ctx) orc_set_aux(h->aux, (h->link == 3 || h->link == 5 || h->link == 6 || h->link == 7 || h->link == 8 || h->real_resp) ? h->resp_real.data() : nullptr, h->link >= 3 ? h->aux_grad4 : nullptr);
   if (h->link == 6) orc_set_aux2(h->aux2);
   orc_set_binomial(h->binomial ? 1 : 0);
   const int rc = orc_vecchia_laplace_grad_map_dbg(h->link, h->A.data(), h->D.data(), Ag.data(), Dg.data(), h->nn.data(), n, m, dptr.data(), h->labels.data(),
@@ -524,7 +528,7 @@ EXPORT int gpb_hip_dense_spd_solve(int32_t n, const double* M_host, const double
 
 // ---- Laplace path ----
 EXPORT int gpb_hip_vecchia_laplace_set_likelihood(gpb_hip_vecchia_t* h, int id) {
-  if (id < 0 || id > 7) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
+  if (id < 0 || id > 8) return fail("gpb_hip_vecchia_laplace_set_likelihood: id %d", id);
   if (h->link != id) { h->labels.clear(); h->grad_state = false; }
   h->link = id; return 0;
 }
@@ -538,12 +542,12 @@ EXPORT int gpb_hip_vecchia_laplace_set_labels(gpb_hip_vecchia_t* h, const int32_
   h->labels.assign(y, y + nd); h->real_resp = false; h->grad_state = false; return 0;
 }
 EXPORT int gpb_hip_vecchia_laplace_set_response_real(gpb_hip_vecchia_t* h, const double* y) {
-  if (h->link != 3 && h->link != 5 && h->link != 6 && h->link != 7 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
+  if (h->link != 3 && h->link != 5 && h->link != 6 && h->link != 7 && h->link != 8 && h->link > 1) return fail("gpb_hip_vecchia_laplace_set_response_real: a real-valued response is for gamma, beta and for proportions under the logit / probit links (likelihood id %d)", h->link);
   const int nd = h->re_ptr.empty() ? h->n : h->re_ptr[h->n];
   for (int i = 0; i < nd; ++i) {
     if (h->link == 3 || h->link == 7) { if (!(y[i] > 0.)) return fail("gamma / lognormal: the response must be > 0 (found %g at Vecchia position %d)", y[i], i); }
     else if (h->link == 5) { if (!(y[i] > 0. && y[i] < 1.)) return fail(" Must have 0 < y < 1 for the response variable ('y') for likelihood = 'beta', found %g ", y[i]); }
-    else if (h->link == 6) { if (!std::isfinite(y[i])) return fail("t: the response must be finite"); }
+    else if (h->link == 6 || h->link == 8) { if (!std::isfinite(y[i])) return fail("t / gaussian_latent: the response must be finite"); }
     else if (!(y[i] >= 0. && y[i] <= 1.)) return fail(" Must have 0 <= y <= 1 for the response variable ('y') (found %g at Vecchia position %d)", y[i], i);
   }
   h->resp_real.assign(y, y + nd); h->labels.assign(nd, 0); h->real_resp = true; h->grad_state = false; return 0;

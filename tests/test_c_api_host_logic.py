@@ -62,7 +62,7 @@ def test_student_t_likelihood_through_the_c_api_on_the_cpu_restatement_of_the_sh
     log df), the MAD start of the scale, GPB_GetAuxPars with two values, response predictions): tests/test_zz_laplace_t_gpu.py's model-API tests on the oracle-backed shim."""
     # (round 6: the standard-deviation cases of gamma and t run on the device only -- 2 x 10 gradient evaluations of the C restatement each; the t_fix_df one runs here)
     tail = _run_gpu_tests_on_the_mock(mock_lib, ["test_zz_laplace_t_gpu.py"], extra=["-k", "model_api and not (standard_deviations and (gamma_n1500 or t_n1500)) and not (gradient_descent and (gd_gamma or gd_t))"])
-    assert "9 passed" in tail, tail      # (round 6, later: + gradient_descent with estimated auxiliary parameters -- the two short fits here, the 25-40-iteration ones on the device (all five pass on this shim: 6 min); round 6: + "t_fix_df" and likelihood_additional_param, standard deviations of auxiliary parameters, nelder_mead with the shape in the simplex; 2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
+    assert "11 passed" in tail, tail      # (round 6, last: + 2 gaussian_latent cases -- the Gaussian likelihood through the Laplace machinery, "error_variance", init variance = half the sample variance; round 6, later: + gradient_descent with estimated auxiliary parameters -- the two short fits here, the 25-40-iteration ones on the device (all five pass on this shim: 6 min); round 6: + "t_fix_df" and likelihood_additional_param, standard deviations of auxiliary parameters, nelder_mead with the shape in the simplex; 2 t cases + 2 lognormal cases: the log-variance's moment start, "log_variance", the response mean exp(m + v / 2) and its variance)
 
 
 def test_pivoted_cholesky_preconditioner_through_the_c_api_on_the_cpu_restatement_of_the_shim(mock_lib):
