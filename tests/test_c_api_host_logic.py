@@ -141,7 +141,7 @@ def test_the_references_own_package_gets_the_same_answers_from_this_host_code(mo
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/python-package") or not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "lib_gpboost_ref.so")),
                     reason="needs /root/reference and oracle/_ref (the build container)")
-@pytest.mark.parametrize("scenario", ["gauss_clusters", "logit_plain", "probit_offset", "poisson_dups_cov", "gauss_pred_types", "logit_more", "gauss_misc", "poisson_misc", "gauss_covariates", "gauss_covariates_gd", "gauss_edges", "round5_widening", "round5_lognormal"])
+@pytest.mark.parametrize("scenario", ["gauss_clusters", "logit_plain", "probit_offset", "poisson_dups_cov", "gauss_pred_types", "logit_more", "gauss_misc", "poisson_misc", "gauss_covariates", "gauss_covariates_gd", "gauss_edges", "round5_widening", "round5_lognormal", "round6_widening"])
 def test_route_a_scenarios_agree_with_the_references_own_library(mock_lib, scenario):
     """tests/route_a_driver.py: the reference's unmodified package, once on the reference's library, once on this host code (oracle-backed shim).
       gauss_clusters    Gaussian Vecchia model with cluster ids: fit, prediction with cluster ids of observed and unobserved clusters, two prediction types
@@ -170,6 +170,8 @@ def test_route_a_scenarios_agree_with_the_references_own_library(mock_lib, scena
       round5_widening   a Student-t model (two auxiliary parameters, Fisher-Laplace) fitted and evaluated with the fitc preconditioner, a beta regression fitted with
                         the pivoted_cholesky preconditioner (rank 40): estimates, auxiliary parameters, iteration counts, predictions
       round5_lognormal  the lognormal likelihood (one auxiliary parameter, "log_variance"): fit, response / latent predictions, an evaluation with pivoted_cholesky
+      round6_widening   the vecchia_response preconditioner (evaluation, a 20-iteration Nelder-Mead fit), a gaussian_latent fit with response predictions, gradient descent with an
+                        estimated gamma shape, t_fix_df with standard deviations
       poisson_misc      Poisson with an offset, random ordering, Matern 2.5: fit, standard errors, latent variances / covariance, training random effects
     Everything deterministic agrees to 1e-6 (seen 1e-7 .. 1e-15, iteration counts equal); the reference's random-vector estimates of predictive variances
     scatter around this library's exact values."""
