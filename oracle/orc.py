@@ -662,11 +662,14 @@ class _aux_context(object):
 
 def vecchia_laplace_logit(coords, nn, cov_type, var, a, y01, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
                           cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, rand_vec=None, likelihood="bernoulli_logit", fixed_effects=None,
-                          aux=None):
+                          aux=None, factor=None):
     """Approximate negative log marginal likelihood of a Bernoulli-logit (or, likelihood="bernoulli_probit", -probit) Vecchia GP
     (Laplace, iterative, 'vadu').  Returns (negll, info dict).  coords / y01 in Vecchia order; var = sigma1^2, a = transformed range."""
     link = LINK_ID[likelihood]
-    A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
+    if factor is None:
+        A, D, bad = vecchia_factor(coords, nn, cov_type, var, a, gauss=False)
+    else:                                                   # (orc.vif_laplace: the residual process's factor)
+        A, D = np.ascontiguousarray(factor[0]), np.ascontiguousarray(factor[1])
     nn = np.ascontiguousarray(nn, dtype=np.int32)
     n, m = nn.shape
     yi, yd = _responses(likelihood, y01)
@@ -1011,19 +1014,25 @@ def gp_nll(coords, y, cov_pars, cov_function="exponential", shape=0.5, m=30, ord
 # per-point systems minus the predictive-process part V_a . V_b), CalcCovFactorFITC_FSA (:9646-9745: Woodbury matrix
 # Sigma_m + (B C_nm)' D^-1 (B C_nm)), CalcYAux (:9785-9806) and the log-determinant (:2950-2966).  numpy; small n only.
 # ---------------------------------------------------------------------------
-def vif_setup(coords, m, num_ind_points, ordering="random", seed=0, max_it=1000):
+def vif_setup(coords, m, num_ind_points, ordering="random", seed=0, max_it=1000, num_ind_points_preconditioner=0):
     """-> (perm, coords in Vecchia order, neighbour table, inducing points (k x d)): ordering shuffle + kmeans++ from the model's ONE
-    generator (orc_stdlib.cpp: orc_vif_setup), Euclidean neighbour search among the ordered points."""
+    generator (orc_stdlib.cpp: orc_vif_setup), Euclidean neighbour search among the ordered points.  num_ind_points_preconditioner > 0: a fifth
+    return value, the inducing points of the "fitc" preconditioner of a full-scale Vecchia model with a non-Gaussian likelihood (a second
+    kmeans++ run from the same generator, Calc_FITC_Preconditioner_Vecchia)."""
     coords = np.asarray(coords, dtype=np.float64)
     n, d = coords.shape
     cm = np.asfortranarray(coords)
     perm = np.empty(n, dtype=np.int32)
     ip = np.empty((num_ind_points, d), order="F")
-    rc = lib().orc_vif_setup(C.c_int(n), C.c_int(d), _p(cm, C.c_double), C.c_int(seed), C.c_int(1 if ordering == "random" else 0),
-                             C.c_int(int(num_ind_points)), C.c_int(max_it), _p(perm, C.c_int), _p(ip, C.c_double))
+    k2 = int(num_ind_points_preconditioner)
+    ip2 = np.empty((max(k2, 1), d), order="F")
+    rc = lib().orc_vif_setup2(C.c_int(n), C.c_int(d), _p(cm, C.c_double), C.c_int(seed), C.c_int(1 if ordering == "random" else 0),
+                              C.c_int(int(num_ind_points)), C.c_int(max_it), _p(perm, C.c_int), _p(ip, C.c_double), C.c_int(k2), _p(ip2, C.c_double))
     if rc < 0:
         raise ValueError("more inducing points than data points")
     co = coords[perm]
+    if k2 > 0:
+        return perm, co, neighbors(co, m), np.ascontiguousarray(ip), np.ascontiguousarray(ip2)
     return perm, co, neighbors(co, m), np.ascontiguousarray(ip)
 
 
@@ -1070,6 +1079,77 @@ def vif_terms(co, nn, ip, cov_type, var, a, y):
     quad = u @ (u / D) - r @ cho_solve((Lw, True), r)
     logdet = np.log(D).sum() - 2.0 * np.log(np.diag(Lm)).sum() + 2.0 * np.log(np.diag(Lw)).sum()
     return quad, logdet, A, D
+
+
+def vif_resid_factor(co, nn, ip, cov_type, var, a, gauss=False):
+    """Vecchia factor (A, D) of the RESIDUAL process of a full-scale Vecchia model + what goes with it: -> dict(A, D, C (n x k), V (n x k = chol_ip_cross_cov^T), Sm (k x k,
+    diagonal x (1 + 1e-6)), Lm, logdet_Sm).  gauss = False: a latent process (non-Gaussian likelihood) -- no nugget, the neighbours' diagonal x (1 + 1e-10) AFTER the
+    low-rank part is taken off (CalcCovFactorGradientVecchia, Vecchia_utils.cpp:1412-1414, :1461-1463, :1489-1500, :1599-1609)."""
+    from scipy.spatial.distance import cdist
+    from scipy.linalg import cholesky, solve_triangular, cho_solve
+    co = np.asarray(co, dtype=np.float64); ip = np.asarray(ip, dtype=np.float64)
+    n = co.shape[0]
+    Sm = _matern(cov_type, cdist(ip, ip), var, a)
+    Sm[np.diag_indices_from(Sm)] *= 1.0 + 1e-6
+    Lm = cholesky(Sm, lower=True)
+    Cnm = _matern(cov_type, cdist(co, ip), var, a)
+    V = solve_triangular(Lm, Cnm.T, lower=True)                                  # k x n
+    A = np.zeros(nn.shape); D = np.empty(n)
+    for i in range(n):
+        idx = nn[i][nn[i] >= 0]
+        D[i] = (var + 1.0 if gauss else var) - V[:, i] @ V[:, i]
+        if idx.size:
+            Cnn = _matern(cov_type, cdist(co[idx], co[idx]), var, a) - V[:, idx].T @ V[:, idx]
+            if gauss:
+                Cnn[np.diag_indices_from(Cnn)] += 1.0
+            else:
+                Cnn[np.diag_indices_from(Cnn)] *= 1.0 + 1e-10
+            c = _matern(cov_type, cdist(co[idx], co[i:i + 1]), var, a)[:, 0] - V[:, idx].T @ V[:, i]
+            Ai = cho_solve((cholesky(Cnn, lower=True), True), c)
+            A[i, :idx.size] = Ai
+            D[i] -= Ai @ c
+    return dict(A=A, D=D, C=np.asfortranarray(Cnm), V=np.asfortranarray(V.T), Sm=np.ascontiguousarray(Sm), Lm=Lm, logdet_Sm=2.0 * np.log(np.diag(Lm)).sum())
+
+
+class vif_laplace(object):
+    """`with orc.vif_laplace(co, nn, ip, cov_type, var, a, preconditioner, ip_preconditioner): f = ctx.factor; orc.vecchia_laplace_logit(co, nn, ..., factor=(f["A"], f["D"]))`
+    -- the Vecchia-Laplace oracle calls inside the block evaluate a full-scale Vecchia (VIF) model with a non-Gaussian likelihood (FindModePostRandEffCalcMLLFSVA,
+    likelihoods.h:3379-3750; gpb_oracle.c: orc_set_vif).  preconditioner: "fitc" (the reference's default; ip_preconditioner = its own inducing points, None: the model's,
+    re_model_template.h:5249-5262), "vifdu" or "none".  Probe vectors (likelihoods.h:3633-3652): rand_vec_trace_I2_ (n x t) FIRST (generator counter 0), then
+    rand_vec_trace_P_ (k x t, counter 1), then -- "vifdu" only -- rand_vec_trace_I3_ (n x t, counter 2)."""
+
+    def __init__(self, co, nn, ip, cov_type, var, a, preconditioner="fitc", ip_preconditioner=None, num_rand_vec=50, seed_rand=1):
+        self.factor = vif_resid_factor(co, nn, ip, cov_type, var, a)
+        f = self.factor
+        n = f["A"].shape[0]; self.k = f["Sm"].shape[0]
+        self.pc = {"fitc": 0, "vifdu": 1, "none": 2}[preconditioner]
+        self.fitc = None; self.rvP = None; self.rv3 = None
+        if self.pc == 0:
+            self.fitc = fitc_preconditioner(co, ip if ip_preconditioner is None else ip_preconditioner, cov_type, var, a, num_rand_vec, seed_rand)
+            self.fitc.rv2 = gen_rand_normal(self.fitc.k, num_rand_vec, seed_rand, 1)
+        elif self.pc == 1:
+            self.rvP = gen_rand_normal(self.k, num_rand_vec, seed_rand, 1)
+            self.rv3 = gen_rand_normal(n, num_rand_vec, seed_rand, 2)
+
+    def __enter__(self):
+        global _PROBE_RUN_ID
+        if self.fitc is not None:
+            self.fitc.__enter__()
+        _PROBE_RUN_ID = 0
+        f = self.factor
+        fn = lib().orc_set_vif
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        fn(f["C"].ctypes.data, f["V"].ctypes.data, f["Sm"].ctypes.data, float(f["logdet_Sm"]), self.k, self.pc,
+           None if self.rvP is None else self.rvP.ctypes.data, None if self.rv3 is None else self.rv3.ctypes.data)
+        return self
+
+    def __exit__(self, *exc):
+        global _PROBE_RUN_ID
+        lib().orc_clear_vif()
+        if self.fitc is not None:
+            self.fitc.__exit__()
+        _PROBE_RUN_ID = 0
+        return False
 
 
 def _matern_grad_log_range(cov_type, dist, var, a):

@@ -62,16 +62,7 @@ void orc_gen_rand_normal(int base_seed, unsigned long long run_id, int n, int t,
  * std::discrete_distribution weighted by the PLAIN distance to the closest chosen mean --, calculate_means :237-280, kmeans_plusplus
  * :282-308: Lloyd iterations until the means repeat, at most 1000).  libstdc++-specific like the shuffle: restated by calling the same
  * library routines.  coords: column-major n x d (data order); perm_out: Vecchia position -> data index; ip_out: column-major k x d. */
-extern "C" __attribute__((visibility("default")))
-int orc_vif_setup(int n, int d, const double* coords, int seed, int do_shuffle, int k, int max_it, int* perm_out, double* ip_out) {
-  std::mt19937 rng(seed);
-  std::vector<int> perm(n);
-  std::iota(perm.begin(), perm.end(), 0);
-  if (do_shuffle) std::shuffle(perm.begin(), perm.end(), rng);
-  std::copy(perm.begin(), perm.end(), perm_out);
-  if (k > n) return -1;
-  std::vector<double> x((size_t)n * d);                 // row-major, Vecchia order
-  for (int i = 0; i < n; ++i) for (int c = 0; c < d; ++c) x[(size_t)i * d + c] = coords[(size_t)c * n + perm[i]];
+static int orc_kmeanspp(std::mt19937& rng, const std::vector<double>& x, int n, int d, int k, int max_it, double* ip_out) {
   auto dist = [&](const double* a, const double* b) { double s = 0.; for (int c = 0; c < d; ++c) { const double t = a[c] - b[c]; s += t * t; } return std::sqrt(s); };
   std::vector<double> means((size_t)k * d, 0.), w(n, 1.0);
   for (int i = 0; i < k; ++i) {                         // random_plusplus
@@ -101,4 +92,25 @@ int orc_vif_setup(int n, int d, const double* coords, int seed, int do_shuffle, 
   } while (means != old && means != oldold && count != max_it);
   for (int j = 0; j < k; ++j) for (int c = 0; c < d; ++c) ip_out[(size_t)c * k + j] = means[(size_t)j * d + c];
   return count;
+}
+/* k2 > 0: a SECOND kmeans++ run with k2 means from the same generator -- the inducing points of the "fitc" preconditioner of a full-scale Vecchia model with a
+ * non-Gaussian likelihood (Calc_FITC_Preconditioner_Vecchia, re_model_template.h:9502-9593, at the first covariance factor: ind_points_determined_for_preconditioner_
+ * is never set for isotropic kernels, so the preconditioner gets its own points whatever fitc_piv_chol_preconditioner_rank is). */
+extern "C" __attribute__((visibility("default")))
+int orc_vif_setup2(int n, int d, const double* coords, int seed, int do_shuffle, int k, int max_it, int* perm_out, double* ip_out, int k2, double* ip2_out) {
+  std::mt19937 rng(seed);
+  std::vector<int> perm(n);
+  std::iota(perm.begin(), perm.end(), 0);
+  if (do_shuffle) std::shuffle(perm.begin(), perm.end(), rng);
+  std::copy(perm.begin(), perm.end(), perm_out);
+  if (k > n || k2 > n) return -1;
+  std::vector<double> x((size_t)n * d);                 // row-major, Vecchia order
+  for (int i = 0; i < n; ++i) for (int c = 0; c < d; ++c) x[(size_t)i * d + c] = coords[(size_t)c * n + perm[i]];
+  const int count = orc_kmeanspp(rng, x, n, d, k, max_it, ip_out);
+  if (k2 > 0) orc_kmeanspp(rng, x, n, d, k2, max_it, ip2_out);
+  return count;
+}
+extern "C" __attribute__((visibility("default")))
+int orc_vif_setup(int n, int d, const double* coords, int seed, int do_shuffle, int k, int max_it, int* perm_out, double* ip_out) {
+  return orc_vif_setup2(n, d, coords, seed, do_shuffle, k, max_it, perm_out, ip_out, 0, nullptr);
 }
