@@ -1187,6 +1187,31 @@ def vif_grad_fixture(out_dir, only=None):
         np.savez_compressed(path, **res)
 
 
+def vif_laplace_fixture(out_dir, only=None):
+    """gp_approx = "full_scale_vecchia" with non-Gaussian likelihoods (tests/cases.py: VIF_LAPLACE_CASES): the unmodified reference's GPB_EvalNegLogLikelihood at
+    cases.LAPLACE_TIGHT with the "fitc" (default), "vifdu" and "none" preconditioners (tests/golden/vif_laplace_ref.npz)."""
+    import time
+    path = os.path.join(out_dir, "vif_laplace_ref.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, c in cases.VIF_LAPLACE_CASES.items():
+        if only and name not in only:
+            continue
+        coords, y = cases.vif_laplace_data(name)
+        for pc in ("fitc", "vifdu", "none"):
+            for j, cp in enumerate(c["cov_pars"]):
+                if pc != "fitc" and j > 0:
+                    continue
+                mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
+                                          gp_approx="full_scale_vecchia", num_ind_points=c["k"])
+                mdl.set_optim_config(cg_preconditioner_type=pc, piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"], **cases.LAPLACE_TIGHT)
+                t0 = time.time()
+                key = "%s_%s_negll_%d" % (name, pc, j)
+                res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
+                print("vif_laplace", name, pc, cp, "negll = %.12f" % res[key], "%.1f s" % (time.time() - t0), flush=True)
+                del mdl
+        np.savez_compressed(path, **res)
+
+
 def weights_fixture(out_dir, only=None):
     """Sample weights (Gaussian Vecchia model): the unmodified reference's likelihood values, lbfgs fit and predictions after the fit on
     tests/cases.py:WEIGHT_CASES (tests/golden/weights_ref.npz)."""
@@ -1399,6 +1424,8 @@ if __name__ == "__main__":
         predtypes_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_grad":
         vif_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace":
+        vif_laplace_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif":
         vif_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "config4":

@@ -1250,6 +1250,187 @@ def vif_grad_terms(co, nn, ip, cov_type, var, a, y):
     return quad, logdet, g, dA, dD, A, D
 
 
+def vif_resid_factor_grad(co, nn, ip, cov_type, var, a):
+    """LATENT residual-process factor of a full-scale Vecchia model with its derivatives wrt (log var, log a): vif_grad_terms' first half without the nugget and with
+    the neighbours' diagonal x (1 + 1e-10) (vif_resid_factor) -- the derivative matrices carry no jitter, as in the reference (Vecchia_utils.cpp:1503-1524, :1599-1609,
+    :1640-1656).  -> dict(A, D, dA[2], dD[2], Sm0, Sm, Lm, C (n x k), SiCt (k x n), dSm[2], dCt[2] (k x n), V (k x n))."""
+    from scipy.spatial.distance import cdist
+    from scipy.linalg import cholesky, solve_triangular, cho_solve
+    co = np.asarray(co, dtype=np.float64); ip = np.asarray(ip, dtype=np.float64)
+    n, m = nn.shape
+    dip = cdist(ip, ip); dnm = cdist(co, ip)
+    Sm0 = _matern(cov_type, dip, var, a)
+    Sm = Sm0.copy(); Sm[np.diag_indices_from(Sm)] *= 1.0 + 1e-6
+    Lm = cholesky(Sm, lower=True)
+    Cnm = _matern(cov_type, dnm, var, a)
+    V = solve_triangular(Lm, Cnm.T, lower=True)
+    SiCt = cho_solve((Lm, True), Cnm.T)
+    dSm = [Sm0, _matern_grad_log_range(cov_type, dip, var, a)]
+    dCt = [Cnm.T, _matern_grad_log_range(cov_type, dnm, var, a).T]
+    dSmSiCt = [dSm[p] @ SiCt for p in range(2)]
+    A = np.zeros((n, m)); D = np.empty(n)
+    dA = [np.zeros((n, m)), np.zeros((n, m))]; dD = [np.empty(n), np.empty(n)]
+    for i in range(n):
+        idx = nn[i][nn[i] >= 0]
+        D[i] = var - V[:, i] @ V[:, i]
+        low_self = [SiCt[:, i] @ (2.0 * dCt[p][:, i] - dSmSiCt[p][:, i]) for p in range(2)]
+        if idx.size == 0:
+            for p in range(2):
+                dD[p][i] = (var if p == 0 else 0.0) - low_self[p]
+            continue
+        dn = cdist(co[idx], co[idx]); dc0 = cdist(co[idx], co[i:i + 1])[:, 0]
+        Cnn = _matern(cov_type, dn, var, a) - V[:, idx].T @ V[:, idx]
+        Cnn[np.diag_indices_from(Cnn)] *= 1.0 + 1e-10
+        c = _matern(cov_type, dc0, var, a) - V[:, idx].T @ V[:, i]
+        cf = (cholesky(Cnn, lower=True), True)
+        Ai = cho_solve(cf, c)
+        A[i, :idx.size] = Ai
+        D[i] -= Ai @ c
+        for p in range(2):
+            dKnn = _matern(cov_type, dn, var, a) if p == 0 else _matern_grad_log_range(cov_type, dn, var, a)
+            dKc = _matern(cov_type, dc0, var, a) if p == 0 else _matern_grad_log_range(cov_type, dc0, var, a)
+            dc = dKc - (dCt[p][:, idx].T @ SiCt[:, i] + SiCt[:, idx].T @ (dCt[p][:, i] - dSmSiCt[p][:, i]))
+            dCnn = dKnn - (dCt[p][:, idx].T @ SiCt[:, idx] + SiCt[:, idx].T @ (dCt[p][:, idx] - dSmSiCt[p][:, idx]))
+            dAi = cho_solve(cf, dc - dCnn @ Ai)
+            dA[p][i, :idx.size] = dAi
+            dD[p][i] = (var if p == 0 else 0.0) - (dAi @ c + Ai @ dc) - low_self[p]
+    return dict(A=A, D=D, dA=dA, dD=dD, Sm0=Sm0, Sm=Sm, Lm=Lm, C=Cnm, SiCt=SiCt, dSm=dSm, dCt=dCt, V=V)
+
+
+def _optimal_c(a, b, tr_a, tr_b):
+    """CalcOptimalC (CG_utils.cpp:1053-1069): cov(a, b) / var(b) of the per-probe samples, 1 when var(b) = 0."""
+    cov = np.mean((a - tr_a) * (b - tr_b)); var = np.mean((b - tr_b) ** 2)
+    return 1.0 if var == 0.0 else cov / var
+
+
+def vif_laplace_grad(co, nn, ip, ip_pc, cov_type, var, a, y, likelihood="bernoulli_logit", aux=None, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
+                     cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, want_parts=False):
+    """(negll, gradient of negll wrt (log sigma1^2, log a)[, d / d log aux]) of a full-scale Vecchia (VIF) model with a non-Gaussian likelihood, iterative methods, "fitc"
+    preconditioner: Likelihood::CalcGradNegMargLikelihoodLaplaceApproxFSVA (likelihoods.h:5279-5520).  The mode, the log-determinant's block CG, d logdet / d mode with its
+    variance reduction, the implicit solve and the auxiliary parameter's part come from gpb_oracle.c (orc_vecchia_laplace_grad with orc_set_vif: the code the Vecchia path
+    shares); the covariance parameters' part (:5413-5520) is restated here with dense / sparse numpy on those by-products.  co / y in Vecchia order."""
+    from scipy.linalg import cho_solve, cholesky, solve_triangular
+    from scipy.spatial.distance import cdist
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    link = LINK_ID[likelihood]
+    nn = np.ascontiguousarray(nn, dtype=np.int32)
+    n, m = nn.shape
+    t = num_rand_vec
+    F = vif_resid_factor_grad(co, nn, ip, cov_type, var, a)
+    A = np.ascontiguousarray(F["A"]); D = np.ascontiguousarray(F["D"])
+    ctx = vif_laplace.__new__(vif_laplace)
+    ctx.factor = dict(A=A, D=D, C=np.asfortranarray(F["C"]), V=np.asfortranarray(F["V"].T), Sm=np.ascontiguousarray(F["Sm"]), Lm=F["Lm"],
+                      logdet_Sm=2.0 * np.log(np.diag(F["Lm"])).sum())
+    ctx.k = F["Sm"].shape[0]; ctx.pc = 0; ctx.rvP = None; ctx.rv3 = None
+    ctx.fitc = fitc_preconditioner(co, ip_pc, cov_type, var, a, t, seed_rand)
+    ctx.fitc.rv2 = gen_rand_normal(ctx.fitc.k, t, seed_rand, 1)
+    kp = ctx.fitc.k
+    yi, yd = _responses(likelihood, y)
+    aux_g4 = np.zeros(8) if link >= 3 else None
+    parts = np.zeros(2 * n * t + 6 * n + kp * kp)
+    Ag = np.zeros((2, n, m)); Dg = np.zeros((2, n))
+    out = np.empty(6); g = np.empty(2); mode = np.zeros(n)
+    with ctx:
+        rv = gen_rand_normal(n, t, seed_rand, 0)
+        lib().orc_vif_set_parts_out.argtypes = [C.c_void_p]
+        lib().orc_vif_set_parts_out(parts.ctypes.data)
+        with _aux_context(link, aux, yd, aux_g4):
+            rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double), _p(nn, C.c_int), C.c_int(n),
+                                                C.c_int(m), _p(yi, C.c_int), None, _p(rv, C.c_double), C.c_int(t), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
+                                                C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double), _p(mode, C.c_double),
+                                                C.c_int(0), None)
+        lib().orc_vif_set_parts_out(None)
+    if rc != 0:
+        raise RuntimeError("orc_vecchia_laplace_grad failed")
+    q = 0
+    U = parts[q:q + n * t].reshape(t, n).T; q += n * t
+    WIPIZ = parts[q:q + n * t].reshape(t, n).T; q += n * t
+    dld = parts[q:q + n]; q += n
+    sv = parts[q:q + n]; q += n
+    W = parts[q:q + n]; q += n
+    dW = parts[q:q + n]; q += n
+    wp = parts[q:q + n]; q += n                     # diagonal_approx_inv_preconditioner_ (of the last Newton step)
+    md = parts[q:q + n]; q += n
+    cholk = np.tril(parts[q:q + kp * kp].reshape(kp, kp))      # chol_fact_woodbury_preconditioner_ (lower)
+    PIZ = W[:, None] * WIPIZ                                   # PI_Z = P^-1 Z
+    # --- the model's matrices ---
+    rows = np.repeat(np.arange(n), m); cols = nn.ravel(); ok = cols >= 0
+    B = (sp.identity(n, format="csr") - sp.csr_matrix((A.ravel()[ok], (rows[ok], cols[ok])), shape=(n, n))).tocsr()
+    Bt = B.T.tocsr()
+    Dinv = 1.0 / D
+    Cm = F["C"]; SiCt = F["SiCt"]; Sm = F["Sm"]
+    SigI = lambda X: Bt @ (Dinv[:, None] * (B @ X)) if X.ndim == 2 else Bt @ (Dinv * (B @ X))          # B' D^-1 B X
+    def SigV(X):                                                                                        # B^-1 D B^-T X
+        Y = spl.spsolve_triangular(Bt, X, lower=False, unit_diagonal=True)
+        Y = (D[:, None] * Y) if X.ndim == 2 else D * Y
+        return spl.spsolve_triangular(B, Y, lower=True, unit_diagonal=True)
+    Q = SigI(Cm)                                               # Bt_D_inv_B_cross_cov
+    Mw = Sm + Cm.T @ Q                                         # sigma_woodbury
+    Lw = (cholesky(Mw, lower=True), True)
+    # --- the preconditioner's matrices ---
+    ipp = np.asarray(ip_pc, dtype=np.float64)
+    dpp = cdist(ipp, ipp); dnp_ = cdist(np.asarray(co, dtype=np.float64), ipp)
+    Smp0 = _matern(cov_type, dpp, var, a)
+    Smp = Smp0.copy(); Smp[np.diag_indices_from(Smp)] *= 1.0 + 1e-6
+    Lmp = (cholesky(Smp, lower=True), True)
+    Cp = _matern(cov_type, dnp_, var, a)
+    dSmp = [Smp0, _matern_grad_log_range(cov_type, dpp, var, a)]
+    dCp = [Cp, _matern_grad_log_range(cov_type, dnp_, var, a)]
+    sipc = cho_solve(Lmp, Cp.T)                                # sigma_ip_inv_sigma_cross_cov_preconditioner (kp x n)
+    sipc_PIZ = sipc @ PIZ
+    SiCt_PIZ = SiCt @ PIZ                                      # sigma_ip_inv_cross_cov_PI_Z
+    SigI_mode = SigI(md)
+    grad = np.zeros(2); info = []
+    for p in range(2):
+        dC = F["dCt"][p].T; dSm = F["dSm"][p]
+        if p == 0:
+            SId = lambda X: -SigI(X)
+        else:
+            Bg = -sp.csr_matrix((F["dA"][1].ravel()[ok], (rows[ok], cols[ok])), shape=(n, n))
+            Bgt = Bg.T.tocsr(); dDp = F["dD"][1]
+            def SId(X, Bg=Bg, Bgt=Bgt, dDp=dDp):
+                sc = (lambda v, Y: v[:, None] * Y) if X.ndim == 2 else (lambda v, Y: v * Y)
+                BX = B @ X
+                return Bgt @ sc(Dinv, BX) + Bt @ sc(Dinv, Bg @ X) - Bt @ sc(Dinv * dDp * Dinv, BX)
+        SIdC = SId(Cm)
+        Mg = dSm + Cm.T @ SIdC
+        X1 = Q.T @ dC
+        Mg = Mg + X1 + X1.T                                    # sigma_woodbury_grad
+        a1 = SId(md)
+        wsol = cho_solve(Lw, Cm.T @ SigI_mode)
+        SIdm = (a1 - SigI(Cm @ cho_solve(Lw, Cm.T @ a1)) - SId(Cm @ wsol) - SigI(dC @ wsol) - SigI(Cm @ cho_solve(Lw, dC.T @ SigI_mode))
+                + SigI(Cm @ cho_solve(Lw, Mg @ wsol)))        # SigmaI_deriv_mode
+        explicit = 0.5 * (md @ SIdm)
+        PPd = dC @ SiCt_PIZ + SiCt.T @ (dC.T @ PIZ) - SiCt.T @ (dSm @ SiCt_PIZ)
+        Sd = PPd - SigV(SId(SigV(PIZ)))                        # SigmaI_deriv_sample_vec = d Sigma / d theta PI_Z
+        sample_Sigma = (U * Sd).sum(axis=0)
+        stoch_tr = sample_Sigma.mean()
+        # variance reduction with d P / d theta
+        PgPIZ = dCp[p] @ sipc_PIZ + sipc.T @ (dCp[p].T @ PIZ) - sipc.T @ (dSmp[p] @ sipc_PIZ)
+        dSs = dSmp[p] @ sipc
+        dgrad = dSmp[p][0, 0] - (2.0 * np.einsum("ki,ik->i", sipc, dCp[p]) - np.einsum("ki,ki->i", sipc, dSs))
+        PgPIZ = PgPIZ + dgrad[:, None] * PIZ
+        tr_PI_P = (dgrad * wp).sum() - np.trace(cho_solve(Lmp, dSmp[p]))
+        DiC = wp[:, None] * Cp
+        X2 = dCp[p].T @ DiC
+        Mgp = dSmp[p] + X2 + X2.T - DiC.T @ (dgrad[:, None] * DiC)
+        tr_PI_P += np.trace(cho_solve((cholk, True), Mgp))
+        sample_P = (PIZ * PgPIZ).sum(axis=0)
+        c_opt = _optimal_c(sample_Sigma, sample_P, stoch_tr, tr_PI_P)
+        dl = stoch_tr - c_opt * (sample_P.mean() - tr_PI_P)
+        grad[p] = explicit + 0.5 * dl - sv @ SIdm
+        info.append((md @ SIdm, dl, c_opt, -(sv @ SIdm)))
+    negll = -out[0]
+    if link == 6:
+        grad = np.array([grad[0], grad[1], aux_g4[0], aux_g4[4]])
+    elif link >= 3:
+        grad = np.array([grad[0], grad[1], aux_g4[0]])
+    if want_parts:
+        return negll, grad, dict(per_par=np.array(info), dlogdet_dmode=dld.copy(), implicit_solve=sv.copy(), mode=md.copy())
+    return negll, grad
+
+
 def vif_predict_obs_only(co, nn, ip, cov_type, pars_trans, y, coords_pred, m_pred, predict_response=True):
     """Prediction of a full-scale Vecchia (VIF) model, 'order_obs_first_cond_obs_only' (CalcPredVecchiaObservedFirstOrder with the
     full_scale_vecchia arguments, src/GPBoost/Vecchia_utils.cpp:1701-2060, called from re_model_template.h:4041-4056): the conditional law of

@@ -305,11 +305,12 @@ def ref_laplace_gradient(coords, y, cov_pars, likelihood, cov_function="exponent
 
 def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
                          threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., aux_pars=None, estimate_aux=False, weights=None,
-                         cg_preconditioner_type="vadu", piv_chol_rank=-999):
+                         cg_preconditioner_type="vadu", piv_chol_rank=-999, gp_approx="vecchia", num_ind_points=500):
     """(negll, grad): the reference's approximate negative marginal log-likelihood and its gradient wrt (log sigma1^2, log a[, log aux...]) at
     cov_pars = (sigma1^2, rho), from the reference's OWN CalcGradPars -> CalcGradNegMargLikelihoodLaplaceApproxVecchia
     (ref_driver.cpp: refdrv_laplace_nll_grad) with the solver thresholds given -- the pin of orc_vecchia_laplace_grad and of the device gradient."""
-    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
+    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights, gp_approx=gp_approx,
+                       num_ind_points=num_ind_points)
     mdl.set_optim_config(cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding, init_aux_pars=aux_pars, estimate_aux_pars=estimate_aux,
                          cg_preconditioner_type=cg_preconditioner_type, piv_chol_rank=piv_chol_rank)
     y = np.ascontiguousarray(y, dtype=np.float64)

@@ -674,6 +674,37 @@ def vif_data(name):
     return coords, y
 
 
+# Full-scale Vecchia (VIF) with NON-GAUSSIAN likelihoods (round 6; FindModePostRandEffCalcMLLFSVA, likelihoods.h:3379-3750; iterative methods, "fitc" preconditioner with its
+# own kmeans++ inducing points): the unmodified reference's values / gradients / fits (tests/golden/vif_laplace_ref.npz; oracle/make_golden.py vif_laplace).
+# name -> dict(n, d, cov_function, shape, m, k = num_ind_points, ordering, seed, lik, aux (None: the likelihood's default), rank = fitc_piv_chol_preconditioner_rank
+# (None: the reference's default, 200), cov_pars = [(sigma1^2, rho)])
+VIF_LAPLACE_CASES = {
+    "vifl_u2d_n1500_exp_m15_k40_logit": dict(n=1500, d=2, cov_function="exponential", shape=0.5, m=15, k=40, ordering="random", seed=1, lik="bernoulli_logit", aux=None, rank=50,
+                                             cov_pars=[(0.8, 0.25), (1.6, 0.1)]),
+    "vifl_u2d_n2000_mat15_m20_k64_poisson": dict(n=2000, d=2, cov_function="matern", shape=1.5, m=20, k=64, ordering="random", seed=2, lik="poisson", aux=None, rank=None,
+                                                 cov_pars=[(0.6, 0.2)]),
+    "vifl_u3d_n1500_mat25_m15_k40_gamma": dict(n=1500, d=3, cov_function="matern", shape=2.5, m=15, k=40, ordering="none", seed=1, lik="gamma", aux=2.0, rank=64,
+                                               cov_pars=[(0.5, 0.3)]),
+}
+
+
+def vif_laplace_data(name):
+    """-> (coords, y): a smooth latent surface, the response drawn from the case's likelihood."""
+    c = VIF_LAPLACE_CASES[name]
+    rng = np.random.default_rng(100 + c["n"] + c["d"])
+    coords = rng.uniform(size=(c["n"], c["d"]))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, -1]) + 0.2
+    if c["lik"] == "bernoulli_logit":
+        y = (rng.uniform(size=c["n"]) < 1.0 / (1.0 + np.exp(-1.5 * lat))).astype(np.float64)
+    elif c["lik"] == "poisson":
+        y = rng.poisson(np.exp(lat)).astype(np.float64)
+    elif c["lik"] == "gamma":
+        y = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
+    else:
+        raise ValueError(c["lik"])
+    return coords, y
+
+
 # Sample weights, Gaussian Vecchia model (re_model_template.h:403-431: error variance sigma^2 / w_i): the reference's own evaluations, fits and
 # predictions (tests/golden/weights_ref.npz; oracle/make_golden.py weights).  name -> (n, d, cov_function, shape, m, ordering, seed)
 WEIGHT_CASES = {
