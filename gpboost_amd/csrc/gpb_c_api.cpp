@@ -208,7 +208,7 @@ int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma
 // the model's auxiliary parameters to the device (Likelihood::SetAuxPars); a no-op for likelihoods without any
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
-  if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->vif || mdl->eh) return 0;
+  if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->eh) return 0;
   const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : (mdl->cg_preconditioner_type == "vecchia_response" ? 3 : 0));
   if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, type, mdl->piv_chol_rank)) return shim_error();
   return 0;
@@ -1326,7 +1326,8 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   if (vif) {
     const std::string sel = ind_points_selection ? ind_points_selection : "";
     if (sel != "" && sel != "kmeans++") return set_error("GPB_CreateREModel: ind_points_selection '%s' with gp_approx '%s' %s", sel.c_str(), approx.c_str(), scope);
-    if (lik != "gaussian") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
+    // (round 6: non-Gaussian likelihoods with gp_approx 'full_scale_vecchia' -- FindModePostRandEffCalcMLLFSVA, likelihoods.h:3379-3750 -- iterative methods with the 'fitc' preconditioner)
+    if (lik != "gaussian" && has_weights) return set_error("GPB_CreateREModel: sample weights with likelihood '%s' and gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
     if (dim_gp_coords > 3) return set_error("GPB_CreateREModel: %d coordinate dimensions with gp_approx '%s' %s", dim_gp_coords, approx.c_str(), scope);
     if (num_ind_points <= 0) num_ind_points = 200;                                 // re_model_template.h:319-330
     if (num_ind_points > 256) return set_error("GPB_CreateREModel: num_ind_points = %d (at most 256 on this path) %s", num_ind_points, scope);
@@ -1344,7 +1345,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     return set_error("GPB_CreateREModel: likelihood_additional_param = %g with likelihood '%s' %s", likelihood_additional_param, lik.c_str(), scope);
   if (lik_name != "gaussian") {
     const std::string inv = matrix_inversion_method ? matrix_inversion_method : "default";
-    if (approx != "vecchia") return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
+    if (approx != "vecchia" && !vif) return set_error("GPB_CreateREModel: likelihood '%s' with gp_approx '%s' %s", lik_name.c_str(), approx.c_str(), scope);
     // "default" resolves to "iterative" for a non-Gaussian Vecchia model (re_model_template.h:5722-5735)
     if (inv != "default" && inv != "iterative") return set_error("GPB_CreateREModel: matrix_inversion_method '%s' for likelihood '%s' %s", inv.c_str(), lik_name.c_str(), scope);
   }
@@ -1370,6 +1371,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   mdl->n = num_data; mdl->d = dim_gp_coords; mdl->cov_type = cov_type; mdl->likelihood = lik_name; mdl->num_aux = num_aux_of(lik_name); if (lik_name == "lognormal") mdl->aux_pars[0] = 0.5;  /* likelihoods.h:506 */ mdl->num_neighbors = num_neighbors;
   if (lik_name == "t" && add_par_given) mdl->aux_pars[1] = likelihood_additional_param;      // aux_pars_ = {1, additional_param} (likelihoods.h:397-399)
   mdl->estimate_df_t = !fix_df;
+  if (vif && lik_name != "gaussian") { mdl->cg_preconditioner_type = "fitc"; mdl->piv_chol_rank = 200; }      // re_model_template.h:7137-7150 (default of a non-Gaussian full_scale_vecchia model)
   if (has_weights && lik_name != "gaussian") mdl->lik_weights.assign(weights, weights + num_data);     // factors of the per-datum likelihood terms (likelihoods.h:666-668)
   mdl->perm.resize(num_data);
   std::iota(mdl->perm.begin(), mdl->perm.end(), 0);
@@ -1426,6 +1428,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
       std::vector<int> uniques, uidx;
       unique_locations(coords, nc, dim_gp_coords, &uniques, &uidx);
       if ((int)uniques.size() < nc) {
+        if (vif) return set_error("GPB_CreateREModel: repeated locations with likelihood '%s' and gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
         const int nu = (int)uniques.size();
         if (nu < 2) return set_error("GPB_CreateREModel: %d unique location(s) %s", nu, scope);
         std::vector<double> cu((size_t)nu * dim_gp_coords);
@@ -1579,7 +1582,13 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     if (pc != "" && mdl->cg_preconditioner_type != pc && mdl->model_has_been_estimated)      // re_model_template.h:891-895 (the comparison is with the string as given, before the alias is resolved)
       return set_error("Cannot change 'cg_preconditioner_type' after a model has been fitted ");
     // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu", "pivoted_cholesky", "fitc" (round 5) and "vecchia_response" (round 6) are built; "incomplete_cholesky" is not
-    if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
+    if (mdl->vif) {      // SUPPORTED_PRECONDITIONERS_NONGAUSS_VIF_ (:5910): "fitc" (the default) is built; "vifdu" / "none" are not
+      if (pc == "fitc" || pc == "FITC" || pc == "predictive_process_plus_diagonal" || pc == "") { if (pc != "") mdl->cg_preconditioner_type = "fitc"; }
+      else if (pc == "vifdu" || pc == "VIFDU" || pc == "Bt_Sigma_inv_plus_W_B" || pc == "none")
+        return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' with gp_approx 'full_scale_vecchia' is not on the MI355X hot path of this library ('fitc', the reference's default, is)", pc.c_str());
+      else return set_error("Preconditioner type '%s' is not supported for gp_approx = '%s' and likelihood = '%s'", pc.c_str(), "full_scale_vecchia", mdl->likelihood.c_str());
+    }
+    else if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
     else if (pc == "pivoted_cholesky" || pc == "piv_chol" || pc == "piv_chol_on_Sigma") mdl->cg_preconditioner_type = "pivoted_cholesky";
     else if (pc == "fitc" || pc == "FITC" || pc == "predictive_process_plus_diagonal") mdl->cg_preconditioner_type = "fitc";
     else if (pc == "vecchia_response" || pc == "vecchia_observable" || pc == "vecchia") mdl->cg_preconditioner_type = "vecchia_response";     // evaluation only: the reference refuses gradients with it (likelihoods.h:6570-6572)

@@ -362,6 +362,7 @@ struct gpb_hip_vecchia {
   double* d_vdC = nullptr; double* d_vQdC = nullptr; double* d_vX1 = nullptr; double* d_vV1 = nullptr; double* d_vX2 = nullptr; double* d_vHm = nullptr;
   double* d_vw = nullptr; double* d_vv = nullptr; double* d_vz = nullptr; double* d_vdA = nullptr; double* d_vdD = nullptr;
   bool vif_has_grad_inputs = false, vif_has_grad_factor = false;
+  std::vector<double> vif_ip_host;      // the inducing points [k][3] on the host (the k x k matrices of the VIF-Laplace path are built there, gpb_laplace.inc)
   int* d_leaf = nullptr; double* d_leaf_part = nullptr; double* d_leaf_out = nullptr; size_t leaf_part_cap = 0;
   LaplaceState* lap = nullptr;
   GpbComm comm;                   // optional: in-library all-reduce of the partial terms (gpb_hip_vecchia_comm_init / _comm_init_local)
@@ -1486,7 +1487,7 @@ int gpb_hip_vecchia_vif_set_inducing_points(gpb_hip_vecchia_t* h, int32_t k, con
   HIP_OK(hipMalloc(&h->d_vgpart, sizeof(double) * gpb::vif_gram_part_doubles(h->n, kq)));
   HIP_OK(hipMalloc(&h->d_vif_part, sizeof(double) * GPB_VIF_GRAD_TERMS * (size_t)h->n));
   HIP_OK(hipMalloc(&h->d_vout, sizeof(double) * 16));
-  h->vif_k = k; h->vif_kp = kp; h->vif_kq = kq;
+  h->vif_k = k; h->vif_kp = kp; h->vif_kq = kq; h->vif_ip_host = ip3;
   API_END();
 }
 
@@ -1546,9 +1547,18 @@ int gpb_hip_vecchia_vif_factor(gpb_hip_vecchia_t* h, int cov_type, double var, d
    Winv = W^-1 (Woodbury matrix), Si = Sigma_m^-1 (jittered), N0 = 2 Si - Si dSigma_m^var Si, negMp1 = -Si dSigma_m^range Si: k x k row-major (symmetric);
    w = W^-1 (B C)' D^-1 B y.  sums12 = {S1, S2, S3, S4, S5, S6} x {variance, range} in the order [2 * S + p] (vif_kernels.hip).  keep_factor: also keep
    dA / dD on the device for gpb_hip_vecchia_vif_get_grad_factor (tests). */
+static int vif_grad_sums_impl(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si, const double* N0,
+                              const double* negMp1, const double* w_host, int keep_factor, double* sums12_host, bool latent);
 int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si, const double* N0,
                                   const double* negMp1, const double* w_host, int keep_factor, double* sums12_host) {
   API_BEGIN();
+  if (vif_grad_sums_impl(h, cov_type, var, a, Winv, Si, N0, negMp1, w_host, keep_factor, sums12_host, false)) return -1;
+  API_END();
+}
+// latent: the residual process of a NON-GAUSSIAN model (no nugget, the neighbours' diagonal x (1 + 1e-10); gpb_laplace.inc uses the derivative factors dA / dD only)
+static int vif_grad_sums_impl(gpb_hip_vecchia_t* h, int cov_type, double var, double a, const double* Winv, const double* Si, const double* N0,
+                              const double* negMp1, const double* w_host, int keep_factor, double* sums12_host, bool latent) {
+  {
   if (!h || !Winv || !Si || !N0 || !negMp1 || !w_host || !sums12_host) return fail("null argument");
   if (h->vif_k < 1 || !h->has_factor || !h->vif_has_grad_inputs) return fail("gpb_hip_vecchia_vif_grad_sums needs gpb_hip_vecchia_vif_factor(with_grad = 1) first");
   if (cov_type < 0 || cov_type > 2) return fail("covariance type %d is not on the HIP hot path (Matern 0.5/1.5/2.5 only)", cov_type);
@@ -1578,6 +1588,7 @@ int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var
   ka.A = h->d_A; ka.D = h->d_D; ka.u = h->d_u;
   ka.m = h->m; ka.i_begin = 0; ka.i_end = n;
   ka.var = var; ka.a = a; ka.diag_nn = var + 1.0; ka.diag_i = var + 1.0; ka.nugget = 1.0;
+  if (latent) { ka.diag_nn = var; ka.diag_i = var; ka.nugget = 0.0; ka.diag_mult = 1.0 + 1e-10; }
   gpb::VifGradLaunch L;
   L.V = h->d_V; L.C = h->d_vC; L.dC = h->d_vdC; L.Q = h->d_vQ; L.QdC = h->d_vQdC; L.X1 = h->d_vX1; L.V1 = h->d_vV1; L.X2r = h->d_vX2; L.Hm = h->d_vHm;
   L.w = h->d_vw; L.v = h->d_vv; L.z = h->d_vz;
@@ -1589,7 +1600,8 @@ int gpb_hip_vecchia_vif_grad_sums(gpb_hip_vecchia_t* h, int cov_type, double var
   HIP_OK(hipMemcpyAsync(sums12_host, h->d_vout, sizeof(double) * GPB_VIF_GRAD_TERMS, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   h->vif_has_grad_factor = keep_factor != 0;
-  API_END();
+  }
+  return 0;
 }
 
 /* dA (n x m) and dD (n) of parameter p (0: variance, 1: range; log scale) of the last gpb_hip_vecchia_vif_grad_sums(keep_factor = 1), Vecchia order */

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void pc_small_kernel(const double* __restrict_
 
 // one row per thread: acc = L[i, :] x2[:, c];  mode 0: W (X - acc), 1: X - acc, 2: acc + X / sqrt(W)
 template <int NC>
-__global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X,
-                                                           const double* __restrict__ x2, int n, int k, int mode, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* X,
+                                                           const double* __restrict__ x2, int n, int k, int mode, double* out) {      // out may be X
   extern __shared__ double s_x2[];                     // k * NC
   const int chunk = blockIdx.y;
   const int len = k * NC;
@@ -288,7 +288,7 @@ __global__ void pc_fitc_diag_kernel(const double* __restrict__ W, const double* 
 
 __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* __restrict__ WIPIZ, const double* __restrict__ L, const double* __restrict__ M,
                                     const double* __restrict__ W, const double* __restrict__ dW3, int n, int k, int t, int nc, double* __restrict__ dld,
-                                    const double* __restrict__ wp) {
+                                    const double* __restrict__ wp, int det_centre) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d3 = dW3[i], wi = 1.0 / W[i];
@@ -299,15 +299,6 @@ __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* 
     s2 += -1.0 * (WIPIZ[o] * d3 * WIPIZ[o]);
   }
   const double tr1 = s1 / t, trP = s2 / t;
-  double cv = 0.0, vr = 0.0;
-  for (int c = 0; c < t; ++c) {
-    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
-    const double a1 = -1.0 * ((wi * U[o]) * d3 * WIPIZ[o]) - tr1;
-    const double b1 = -1.0 * (WIPIZ[o] * d3 * WIPIZ[o]) - trP;
-    cv += a1 * b1; vr += b1 * b1;
-  }
-  cv /= t; vr /= t;
-  const double copt = (vr == 0.0) ? 1.0 : cv / vr;
   // diag of L (I_k + L^T W L)^-1 L^T  (likelihoods.h:16583-16586)
   const double* Li = L + (size_t)i * k;
   double sdiag = 0.0;
@@ -318,12 +309,49 @@ __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* 
     sdiag = __builtin_fma(Li[q], acc, sdiag);
   }
   const double trw = wi * d3;
+  // det_centre (full-scale Vecchia, likelihoods.h:5376-5390): CalcOptimalCVectorized centres the control variate with its DETERMINISTIC trace, the Vecchia path
+  // (:16630-16632) with the mean of the samples
+  double b_centre = trP;
+  if (det_centre && wp) { const double tDI0 = wi * (trw * wp[i]); b_centre = sdiag * (wp[i] * tDI0) - tDI0; }
+  double cv = 0.0, vr = 0.0;
+  for (int c = 0; c < t; ++c) {
+    const size_t o = ((size_t)(c / nc) * n + i) * nc + (c % nc);
+    const double a1 = -1.0 * ((wi * U[o]) * d3 * WIPIZ[o]) - tr1;
+    const double b1 = -1.0 * (WIPIZ[o] * d3 * WIPIZ[o]) - b_centre;
+    cv += a1 * b1; vr += b1 * b1;
+  }
+  cv /= t; vr /= t;
+  const double copt = (vr == 0.0) ? 1.0 : cv / vr;
   if (wp) {
     const double tDI = wi * (trw * wp[i]), tDIDI = wp[i] * tDI;
     dld[i] = tr1 + trw + copt * (sdiag * tDIDI - tDI) - copt * trP;
     return;
   }
   dld[i] = tr1 + trw + copt * (sdiag * d3 - trw) - copt * trP;
+}
+
+// out[i] = c0 - 2 L_i' M1 L2_i + L_i' M2 L_i: the derivative of the fitc preconditioner's diagonal, Sigma_m[0][0]' - 2 C_i' Sigma_m^-1 dC_i + C_i' Sigma_m^-1 dSigma_m Sigma_m^-1 C_i
+// (likelihoods.h:5478-5486); L / L2 [n][k] (rows in storage order), M1 / M2 k x k row-major (symmetric)
+__global__ void pc_row_quad_kernel(const double* __restrict__ L, const double* __restrict__ L2, const double* __restrict__ M1, const double* __restrict__ M2,
+                                   int n, int k, double c0, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* Li = L + (size_t)i * k;
+  const double* L2i = L2 + (size_t)i * k;
+  double q1 = 0.0, q2 = 0.0;
+  for (int q = 0; q < k; ++q) {
+    const double* M1q = M1 + (size_t)q * k;
+    const double* M2q = M2 + (size_t)q * k;
+    double a1 = 0.0, a2 = 0.0;
+    for (int p = 0; p < k; ++p) { a1 = __builtin_fma(M1q[p], L2i[p], a1); a2 = __builtin_fma(M2q[p], Li[p], a2); }
+    q1 = __builtin_fma(Li[q], a1, q1); q2 = __builtin_fma(Li[q], a2, q2);
+  }
+  out[i] = c0 - 2.0 * q1 + q2;
+}
+// out[i] = a[i] * b[i] * (c ? c[i] : 1)
+__global__ void pc_mul3_kernel(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i] * (c ? c[i] : 1.0);
 }
 
 }  // namespace
@@ -386,8 +414,16 @@ hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
-                        double* dld, hipStream_t st, const double* wp) {
-  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld, wp);
+                        double* dld, hipStream_t st, const double* wp, int det_centre) {
+  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld, wp, det_centre);
+  return hipGetLastError();
+}
+hipError_t pc_row_quad(const double* L, const double* L2, const double* M1, const double* M2, int n, int k, double c0, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(pc_row_quad_kernel, dim3((n + 127) / 128), dim3(128), 0, st, L, L2, M1, M2, n, k, c0, out);
+  return hipGetLastError();
+}
+hipError_t pc_mul3(const double* a, const double* b, const double* c, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(pc_mul3_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, n, out);
   return hipGetLastError();
 }
 hipError_t pc_pack_rows(const double* src, int ld, const int* sigma, int n, int k, double* dst, double* vnorm2, hipStream_t st) {

@@ -44,6 +44,7 @@ struct VecchiaKernelArgs {
   double diag_nn;          // diagonal of C_nn:   Gaussian var + 1;          else var * (1 + 1e-10)
   double diag_i;           // first summand of D: Gaussian var + 1;          else var
   double nugget;           // Gaussian 1, else 0
+  double diag_mult = 1.0;  // vif_kernels.hip only: the neighbours' diagonal is (diag_nn - |V_a|^2) * diag_mult -- 1 + 1e-10 for the latent residual process (Vecchia_utils.cpp:1489-1500, :1608)
   const double* nug = nullptr;   // sample weights (Gaussian only): [n] observation-specific nugget 1 / w_i on the transformed scale, Vecchia order;
                                  // then the diagonals are var + nug[.] instead of diag_nn / diag_i
   const double* coords_nd = nullptr;   // d > 3 (generality path): [n][dim] coordinates in Vecchia order; pts then only carries the response (w)

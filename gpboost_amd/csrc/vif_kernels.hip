@@ -355,6 +355,7 @@ __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, co
         const double g = s_C[rl * ld + c];
         const double kv = matern_plain<COV>(dist4(own, s_pts[c]), args.var, args.a);
         v = (c == tid ? args.diag_nn : kv) - g;               // diagonal: var + nugget - |V_a|^2
+        if (c == tid) v *= args.diag_mult;
       }
       row[c] = tid < k ? v : (c == tid ? 1.0 : 0.0);
     });
@@ -374,7 +375,7 @@ __device__ __forceinline__ int vif_point_setup(const VecchiaKernelArgs& args, co
     s_c[tid] = matern_plain<COV>(dist4(own, ctr), args.var, args.a) - s_C[k * ld + tid];
   }
   __syncthreads();
-  if (tid < k) s_C[tid * ld + tid] = args.diag_nn - s_C[tid * ld + tid];        // var + nugget - |V_a|^2
+  if (tid < k) s_C[tid * ld + tid] = (args.diag_nn - s_C[tid * ld + tid]) * args.diag_mult;        // (var + nugget - |V_a|^2) x the latent jitter
   __syncthreads();
   for (int j = 0; j < k; ++j) {
     if (tid == j) s_C[j * ld + j] = sqrt(s_C[j * ld + j]);

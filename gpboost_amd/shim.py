@@ -214,6 +214,12 @@ class VecchiaState(object):
         t = {"vadu": 0, "pivoted_cholesky": 1, "fitc": 2, "vecchia_response": 3}[cg_preconditioner_type]
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_preconditioner(self.h, C.c_int(t), C.c_int(int(rank))))
 
+    def vif_set_inducing_points(self, ip):
+        """Inducing points (k x d) of a full-scale Vecchia ("VIF") model (gpb_hip_vecchia_vif_set_inducing_points): the handle's Laplace evaluations then use
+        Sigma = C Sigma_m^-1 C' + the Vecchia approximation of the residual process."""
+        ipf = np.asfortranarray(ip, dtype=np.float64)
+        _shim_call(_lib().gpb_hip_vecchia_vif_set_inducing_points(self.h, C.c_int(ipf.shape[0]), _p(ipf)))
+
     def laplace_set_inducing_points(self, ip):
         """Inducing points (k x d) of the "fitc" preconditioner (gpb_hip_vecchia_laplace_set_inducing_points)."""
         ipf = np.asfortranarray(ip, dtype=np.float64)

@@ -1201,14 +1201,35 @@ def vif_laplace_fixture(out_dir, only=None):
             for j, cp in enumerate(c["cov_pars"]):
                 if pc != "fitc" and j > 0:
                     continue
+                if pc != "fitc" and ("%s_%s_negll_%d" % (name, pc, j)) in res and os.environ.get("VIFL_REDO_ALL") is None:
+                    continue                                                       # ("none" takes minutes: kept unless VIFL_REDO_ALL is set)
                 mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
                                           gp_approx="full_scale_vecchia", num_ind_points=c["k"])
-                mdl.set_optim_config(cg_preconditioner_type=pc, piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"], **cases.LAPLACE_TIGHT)
+                mdl.set_optim_config(cg_preconditioner_type=pc, piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"],
+                                     **(cases.VIF_LAPLACE_TIGHT if pc == "fitc" else cases.LAPLACE_TIGHT))
                 t0 = time.time()
                 key = "%s_%s_negll_%d" % (name, pc, j)
                 res[key] = np.float64(mdl.neg_log_likelihood(np.asarray(cp, dtype=np.float64), y))
                 print("vif_laplace", name, pc, cp, "negll = %.12f" % res[key], "%.1f s" % (time.time() - t0), flush=True)
                 del mdl
+        np.savez_compressed(path, **res)
+
+
+def vif_laplace_grad_fixture(out_dir, only=None):
+    """The reference's own CalcGradPars for the cases of vif_laplace_fixture ("fitc" preconditioner, first parameter set; gamma: with the shape's component):
+    keys <name>_fitc_grad_0, <name>_fitc_negll_direct_0 in tests/golden/vif_laplace_ref.npz."""
+    path = os.path.join(out_dir, "vif_laplace_ref.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, c in cases.VIF_LAPLACE_CASES.items():
+        if only and name not in only:
+            continue
+        coords, y = cases.vif_laplace_data(name)
+        v, g, vp = refdrv.ref_laplace_nll_grad(coords, y, c["cov_pars"][0], c["lik"], cov_function=c["cov_function"], shape=c["shape"], m=c["m"], ordering=c["ordering"],
+                                               seed=c["seed"], threads=8, aux_pars=c["aux"], estimate_aux=c["aux"] is not None, cg_preconditioner_type="fitc",
+                                               piv_chol_rank=-999 if c["rank"] is None else c["rank"], gp_approx="full_scale_vecchia", num_ind_points=c["k"],
+                                               **cases.VIF_LAPLACE_TIGHT)
+        res[name + "_fitc_grad_0"] = g; res[name + "_fitc_negll_direct_0"] = np.float64(v)
+        print("vif_laplace_grad", name, "negll = %.12f" % v, g, flush=True)
         np.savez_compressed(path, **res)
 
 
@@ -1424,6 +1445,8 @@ if __name__ == "__main__":
         predtypes_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_grad":
         vif_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_grad":
+        vif_laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace":
         vif_laplace_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif":

@@ -1304,7 +1304,7 @@ def _optimal_c(a, b, tr_a, tr_b):
 
 
 def vif_laplace_grad(co, nn, ip, ip_pc, cov_type, var, a, y, likelihood="bernoulli_logit", aux=None, num_rand_vec=50, seed_rand=1, cg_max_num_it=1000,
-                     cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, want_parts=False):
+                     cg_max_num_it_tridiag=1000, cg_delta_conv=1e-2, delta_conv_mode=1e-8, want_parts=False, mode_init=None):
     """(negll, gradient of negll wrt (log sigma1^2, log a)[, d / d log aux]) of a full-scale Vecchia (VIF) model with a non-Gaussian likelihood, iterative methods, "fitc"
     preconditioner: Likelihood::CalcGradNegMargLikelihoodLaplaceApproxFSVA (likelihoods.h:5279-5520).  The mode, the log-determinant's block CG, d logdet / d mode with its
     variance reduction, the implicit solve and the auxiliary parameter's part come from gpb_oracle.c (orc_vecchia_laplace_grad with orc_set_vif: the code the Vecchia path
@@ -1330,7 +1330,8 @@ def vif_laplace_grad(co, nn, ip, ip_pc, cov_type, var, a, y, likelihood="bernoul
     aux_g4 = np.zeros(8) if link >= 3 else None
     parts = np.zeros(2 * n * t + 6 * n + kp * kp)
     Ag = np.zeros((2, n, m)); Dg = np.zeros((2, n))
-    out = np.empty(6); g = np.empty(2); mode = np.zeros(n)
+    out = np.empty(6); g = np.empty(2)
+    mode = np.zeros(n) if mode_init is None else np.ascontiguousarray(mode_init, dtype=np.float64).copy()      # (mode_init: Newton's method starts there -- a warm start)
     with ctx:
         rv = gen_rand_normal(n, t, seed_rand, 0)
         lib().orc_vif_set_parts_out.argtypes = [C.c_void_p]
@@ -1339,7 +1340,7 @@ def vif_laplace_grad(co, nn, ip, ip_pc, cov_type, var, a, y, likelihood="bernoul
             rc = lib().orc_vecchia_laplace_grad(C.c_int(link), _p(A, C.c_double), _p(D, C.c_double), _p(Ag, C.c_double), _p(Dg, C.c_double), _p(nn, C.c_int), C.c_int(n),
                                                 C.c_int(m), _p(yi, C.c_int), None, _p(rv, C.c_double), C.c_int(t), C.c_int(cg_max_num_it), C.c_int(cg_max_num_it_tridiag),
                                                 C.c_double(cg_delta_conv), C.c_double(delta_conv_mode), _p(out, C.c_double), _p(g, C.c_double), _p(mode, C.c_double),
-                                                C.c_int(0), None)
+                                                C.c_int(0 if mode_init is None else 1), None)
         lib().orc_vif_set_parts_out(None)
     if rc != 0:
         raise RuntimeError("orc_vecchia_laplace_grad failed")

@@ -806,3 +806,41 @@ def test_oracle_student_t_value_and_gradient_match_the_reference(orc, name):
         np.testing.assert_allclose(grad_t, ref, rtol=1e-8, atol=3e-8 * np.abs(ref).max())      # (the scale's trace term multiplies the block CG's 1e-8 stopping error by dW / d log scale = -2 W: seen 1.6e-8 of the gradient's scale on the d = 3 case with fixed effects)
         ref_v = float(g[name + fe_key + "_negll_direct"])
         assert abs(nll_t - ref_v) <= 1e-10 * abs(ref_v), (nll_t, ref_v)
+
+
+RC_VIFL = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}
+
+
+@pytest.mark.parametrize("name", sorted(cases.VIF_LAPLACE_CASES))
+def test_oracle_vif_non_gaussian_matches_the_reference(orc, name):
+    """Full-scale Vecchia with a non-Gaussian likelihood (round 6; FindModePostRandEffCalcMLLFSVA, likelihoods.h:3379-3750): the oracle (gpb_oracle.c orc_set_vif + the
+    numpy gradient orc.vif_laplace_grad) against the unmodified reference's values with the "fitc" / "vifdu" / "none" preconditioners and its own CalcGradPars
+    (tests/golden/vif_laplace_ref.npz)."""
+    c = cases.VIF_LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "vif_laplace_ref.npz"))
+    coords, y = cases.vif_laplace_data(name)
+    rank = 200 if c["rank"] is None else c["rank"]
+    perm, co, nn, ip, ip2 = orc.vif_setup(coords, c["m"], c["k"], c["ordering"], c["seed"], num_ind_points_preconditioner=rank)
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
+    tight_fitc = dict(cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
+    for pc in ("fitc", "vifdu") + (("none",) if name.endswith("logit") else ()):       # ("none" needs hundreds of CG iterations: one case)
+        for j, cp in enumerate(c["cov_pars"]):
+            key = "%s_%s_negll_%d" % (name, pc, j)
+            if key not in g.files:
+                continue
+            a = RC_VIFL[ct] / cp[1]
+            tl = tight_fitc if pc == "fitc" else tight
+            with orc.vif_laplace(co, nn, ip, ct, cp[0], a, pc, ip2) as ctx:
+                f = ctx.factor
+                v, info = orc.vecchia_laplace_logit(co, nn, ct, cp[0], a, y[perm], likelihood=c["lik"], factor=(f["A"], f["D"]), aux=c["aux"], **tl)
+            assert abs(v - float(g[key])) <= 1e-9 * abs(v), (key, v, float(g[key]))
+    cp = c["cov_pars"][0]
+    # (two mode findings, the second from the first one's mode: what the fixture's driver does -- EvalNegLogLikelihood, then CalcCovFactorOrModeAndNegLL, oracle/ref_driver.cpp:438-446;
+    #  cases.py: VIF_LAPLACE_TIGHT says why it matters)
+    v0, g0, p0 = orc.vif_laplace_grad(co, nn, ip, ip2, ct, cp[0], RC_VIFL[ct] / cp[1], y[perm], likelihood=c["lik"], aux=c["aux"], want_parts=True, **tight_fitc)
+    v, gr = orc.vif_laplace_grad(co, nn, ip, ip2, ct, cp[0], RC_VIFL[ct] / cp[1], y[perm], likelihood=c["lik"], aux=c["aux"], mode_init=p0["mode"], **tight_fitc)
+    ref = g[name + "_fitc_grad_0"]
+    assert abs(v - float(g[name + "_fitc_negll_direct_0"])) <= 1e-9 * abs(v)
+    assert gr.shape == ref.shape
+    np.testing.assert_allclose(gr, ref, rtol=0, atol=c.get("grad_rtol", 1e-8) * np.abs(ref).max())

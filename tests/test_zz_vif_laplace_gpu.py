@@ -1,0 +1,138 @@
+"""GPU (MI355X): full-scale Vecchia (gp_approx = "full_scale_vecchia", "VIF") with NON-GAUSSIAN likelihoods (round 6) --
+Likelihood::FindModePostRandEffCalcMLLFSVA (include/GPBoost/likelihoods.h:3379-3750), CGVIFLaplace_Version_SigmaPlusWinvVec /
+CGTridiagVIFLaplace_Version_SigmaPlusWinv (src/GPBoost/CG_utils.cpp:744-976), CalcLogDetStochFSVA (likelihoods.h:16203-16259): the latent covariance is
+Sigma = C Sigma_m^-1 C' + B^-1 D B^-T with (B, D) the Vecchia factor of the residual process; iterative methods with the "fitc" preconditioner (the reference's
+default for these models, its own kmeans++ inducing points).  Through the C ABI against the UNMODIFIED reference (tests/golden/vif_laplace_ref.npz,
+oracle/make_golden.py vif_laplace, vif_laplace_grad) at cases.VIF_LAPLACE_TIGHT: values and gradients 1e-8."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpb(lib_built):
+    import gpboost_amd
+    assert gpboost_amd.device_count() > 0, "no GPU visible: the -m gpu tests must run on the MI355X box"
+    return gpboost_amd
+
+
+def _model(gpb, name, **optim):
+    c = cases.VIF_LAPLACE_CASES[name]
+    coords, y = cases.vif_laplace_data(name)
+    mdl = gpb.GPModel(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], likelihood=c["lik"], gp_approx="full_scale_vecchia",
+                      num_neighbors=c["m"], num_ind_points=c["k"], vecchia_ordering=c["ordering"], seed=c["seed"])
+    p = dict(cases.VIF_LAPLACE_TIGHT)
+    if c["rank"] is not None:
+        p["fitc_piv_chol_preconditioner_rank"] = c["rank"]
+    if c["aux"] is not None:
+        p["init_aux_pars"] = c["aux"]
+    p.update(optim)
+    mdl.set_optim_params(p)
+    return mdl, coords, y, c
+
+
+@pytest.mark.parametrize("name", sorted(cases.VIF_LAPLACE_CASES))
+def test_value_matches_the_reference(gpb, name):
+    g = np.load(os.path.join(GOLD, "vif_laplace_ref.npz"))
+    mdl, coords, y, c = _model(gpb, name)
+    assert mdl.get_cg_preconditioner_type() == "fitc"           # re_model_template.h:7137-7150
+    for j, cp in enumerate(c["cov_pars"]):
+        ref = float(g["%s_fitc_negll_%d" % (name, j)])
+        v = mdl.neg_log_likelihood(cov_pars=np.asarray(cp), y=y)
+        assert abs(v - ref) <= 1e-8 * abs(ref), (name, j, v, ref)
+    # a second evaluation at the first parameters reproduces the first (the mode is re-initialised, the probes are reused)
+    v2 = mdl.neg_log_likelihood(cov_pars=np.asarray(c["cov_pars"][0]), y=y)
+    assert abs(v2 - float(g["%s_fitc_negll_0" % name])) <= 1e-8 * abs(v2)
+
+
+def test_value_matches_the_oracle_through_the_shim(gpb, orc):
+    """shim level: the device evaluation (mode finding, log-determinant, iteration counts) against oracle/gpb_oracle.c (orc_set_vif) on the same inputs."""
+    from gpboost_amd import shim
+    name = "vifl_u2d_n1500_exp_m15_k40_logit"
+    c = cases.VIF_LAPLACE_CASES[name]
+    coords, y = cases.vif_laplace_data(name)
+    perm, co, nn, ip, ip2 = orc.vif_setup(coords, c["m"], c["k"], c["ordering"], c["seed"], num_ind_points_preconditioner=c["rank"])
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    var, rho = c["cov_pars"][0]
+    a = 1.0 / rho
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.vif_set_inducing_points(ip)
+    st.laplace_set_likelihood(c["lik"])
+    st.laplace_set_labels(y[perm].astype(np.int32))
+    st.laplace_set_preconditioner("fitc", c["rank"])
+    st.laplace_set_inducing_points(ip2)
+    nll, info = st.laplace_logit(ct, var, a, want_mode=True, **cases.VIF_LAPLACE_TIGHT)
+    with orc.vif_laplace(co, nn, ip, ct, var, a, "fitc", ip2) as ctx:
+        f = ctx.factor
+        on, oinfo = orc.vecchia_laplace_logit(co, nn, ct, var, a, y[perm], likelihood=c["lik"], factor=(f["A"], f["D"]),
+                                              cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
+    assert abs(nll - on) <= 1e-9 * abs(on), (nll, on)
+    assert info["newton_it"] == oinfo["newton_it"] and info["lanczos_it"] == oinfo["lanczos_it"]
+    np.testing.assert_allclose(info["mode"], oinfo["mode"], rtol=0, atol=1e-8 * np.abs(oinfo["mode"]).max())
+    A, D, _ = st.get_factor()
+    np.testing.assert_allclose(D, f["D"], rtol=1e-9)
+    np.testing.assert_allclose(A, f["A"], rtol=0, atol=1e-9 * np.abs(f["A"]).max())
+    st.close()
+
+
+RC = {0: 1.0, 1: np.sqrt(3.0), 2: np.sqrt(5.0)}
+
+
+@pytest.mark.parametrize("name", sorted(cases.VIF_LAPLACE_CASES))
+def test_gradient_matches_the_reference_and_the_oracle(gpb, orc, name):
+    """CalcGradNegMargLikelihoodLaplaceApproxFSVA (likelihoods.h:5279-5520) on the device against the reference's own CalcGradPars (fixture) at 1e-8 and, step by step,
+    against the oracle: d logdet / d mode, the implicit solve, per parameter {mode' SigmaI_deriv_mode, d logdet / d theta, optimal c, implicit part}."""
+    from gpboost_amd import shim
+    c = cases.VIF_LAPLACE_CASES[name]
+    g = np.load(os.path.join(GOLD, "vif_laplace_ref.npz"))
+    coords, y = cases.vif_laplace_data(name)
+    rank = 200 if c["rank"] is None else c["rank"]
+    perm, co, nn, ip, ip2 = orc.vif_setup(coords, c["m"], c["k"], c["ordering"], c["seed"], num_ind_points_preconditioner=rank)
+    ct = orc.cov_type_id(c["cov_function"], c["shape"])
+    var, rho = c["cov_pars"][0]
+    a = RC[ct] / rho
+    st = shim.VecchiaState(co, c["m"])
+    st.set_neighbors(nn)
+    st.vif_set_inducing_points(ip)
+    st.laplace_set_likelihood(c["lik"])
+    if c["lik"] == "gamma":
+        st.laplace_set_response_real(y[perm])
+        st.laplace_set_aux(c["aux"])
+    else:
+        st.laplace_set_labels(y[perm].astype(np.int32))
+    st.laplace_set_preconditioner("fitc", rank)
+    st.laplace_set_inducing_points(ip2)
+    # two mode findings, the second from the first one's mode: the fixture's driver does the same (EvalNegLogLikelihood, then CalcCovFactorOrModeAndNegLL,
+    # oracle/ref_driver.cpp:438-446); cases.py: VIF_LAPLACE_TIGHT says why that matters at 1e-8
+    st.laplace_eval_grad(ct, var, a, **cases.VIF_LAPLACE_TIGHT)
+    nll, grad, parts = st.laplace_eval_grad(ct, var, a, want_parts=True, reset_mode=False, **cases.VIF_LAPLACE_TIGHT)
+    ref = g[name + "_fitc_grad_0"]
+    ref_v = float(g[name + "_fitc_negll_direct_0"])
+    assert abs(nll - ref_v) <= 1e-8 * abs(ref_v), (nll, ref_v)
+    okw = dict(likelihood=c["lik"], aux=c["aux"], want_parts=True, cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
+    o0 = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], **okw)
+    on, og, op = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], mode_init=o0[2]["mode"], **okw)
+    np.testing.assert_allclose(parts["dlogdet_dmode"], op["dlogdet_dmode"], rtol=0, atol=1e-6 * np.abs(op["dlogdet_dmode"]).max())
+    np.testing.assert_allclose(parts["implicit_solve"], op["implicit_solve"], rtol=0, atol=1e-6 * np.abs(op["implicit_solve"]).max())
+    np.testing.assert_allclose(parts["per_par"], op["per_par"], rtol=1e-6, atol=1e-7 * np.abs(op["per_par"]).max())
+    assert grad.shape == ref.shape
+    np.testing.assert_allclose(grad, ref, rtol=0, atol=c.get("grad_rtol", 1e-8) * np.abs(ref).max())
+    st.close()
+
+
+def test_preconditioners_outside_the_path_are_refused(gpb):
+    name = "vifl_u2d_n1500_exp_m15_k40_logit"
+    mdl, coords, y, c = _model(gpb, name)
+    for pc in ("vifdu", "none"):
+        with pytest.raises(gpb.GPBoostError, match="not on the MI355X hot path"):
+            mdl.set_optim_params(dict(cg_preconditioner_type=pc))
+    with pytest.raises(gpb.GPBoostError, match="is not supported for gp_approx"):
+        mdl.set_optim_params(dict(cg_preconditioner_type="vadu"))
