@@ -1233,6 +1233,29 @@ def vif_laplace_grad_fixture(out_dir, only=None):
         np.savez_compressed(path, **res)
 
 
+def vif_laplace_fit_fixture(out_dir, only=None):
+    """The reference's own GPB_OptimCovPar on VIF x non-Gaussian models (tests/cases.py: VIF_LAPLACE_FITS): estimates, auxiliary parameter, iteration count, final value."""
+    path = os.path.join(out_dir, "vif_laplace_ref.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    for fit, (name, cfg) in cases.VIF_LAPLACE_FITS.items():
+        if only and fit not in only:
+            continue
+        c = cases.VIF_LAPLACE_CASES[name]
+        coords, y = cases.vif_laplace_data(name)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
+                                  gp_approx="full_scale_vecchia", num_ind_points=c["k"])
+        kw = dict(cfg); kw["init_cov_pars"] = np.asarray(cfg["init_cov_pars"], dtype=np.float64)
+        mdl.set_optim_config(cg_preconditioner_type="fitc", piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"], **cases.LAPLACE_TIGHT, **kw)
+        mdl.optim_cov_par(y)
+        res[fit + "_cov_pars"] = mdl.get_cov_par(2)
+        res[fit + "_num_it"] = np.int32(mdl.get_num_it())
+        res[fit + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        if c["aux"] is not None:
+            res[fit + "_aux"] = mdl.get_aux_pars(1)
+        print("vif_laplace_fit", fit, res[fit + "_cov_pars"], res[fit + "_num_it"], res[fit + "_negll"], res.get(fit + "_aux"), flush=True)
+        np.savez_compressed(path, **res)
+
+
 def weights_fixture(out_dir, only=None):
     """Sample weights (Gaussian Vecchia model): the unmodified reference's likelihood values, lbfgs fit and predictions after the fit on
     tests/cases.py:WEIGHT_CASES (tests/golden/weights_ref.npz)."""
@@ -1445,6 +1468,8 @@ if __name__ == "__main__":
         predtypes_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_grad":
         vif_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_fit":
+        vif_laplace_fit_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_grad":
         vif_laplace_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace":

@@ -698,6 +698,15 @@ VIF_LAPLACE_CASES = {
 }
 
 
+# Fits of VIF x non-Gaussian models by the reference's own GPB_OptimCovPar (tests/golden/vif_laplace_ref.npz, keys <fit>_*; oracle/make_golden.py vif_laplace_fit):
+# fit name -> (case, GPB_SetOptimConfig settings on top of LAPLACE_TIGHT; init_cov_pars given so that neither side draws the sub-sample of FindInitCovPar)
+VIF_LAPLACE_FITS = {
+    "vifl_fit_logit_lbfgs": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="lbfgs", init_cov_pars=[1.0, 0.2], max_iter=30)),
+    "vifl_fit_gamma_lbfgs_aux": ("vifl_u3d_n1500_mat25_m15_k40_gamma", dict(optimizer_cov="lbfgs", init_cov_pars=[0.6, 0.25], max_iter=30, estimate_aux_pars=True)),
+    "vifl_fit_logit_nelder_mead": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="nelder_mead", init_cov_pars=[1.0, 0.2], max_iter=25)),
+}
+
+
 def vif_laplace_data(name):
     """-> (coords, y): a smooth latent surface, the response drawn from the case's likelihood."""
     c = VIF_LAPLACE_CASES[name]
