@@ -722,6 +722,35 @@ def main():
                 del mv
             except Exception as e:
                 out["vif_full_scale_vecchia"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # round 6: full-scale Vecchia with a NON-GAUSSIAN likelihood (FindModePostRandEffCalcMLLFSVA, likelihoods.h:3379-3750): Bernoulli-logit at
+            # config 4's size with 200 inducing points, iterative methods with the reference's default preconditioner for these models ("fitc", 200 inducing points of its own):
+            # one evaluation (mode finding + stochastic log-determinant, 50 probes) and one evaluation with the gradient wrt the covariance parameters
+            try:
+                nq = 100000
+                rngq = np.random.default_rng(1)
+                cq = rngq.uniform(size=(nq, 2))
+                latq = 0.9 * np.sin(5 * cq[:, 0]) * np.cos(3 * cq[:, 1])
+                yq = (rngq.uniform(size=nq) < 1.0 / (1.0 + np.exp(-1.5 * latq))).astype(np.float64)
+                tq0 = time.perf_counter()
+                mq = gpboost_amd.GPModel(likelihood="bernoulli_logit", gp_coords=cq, cov_function="exponential", gp_approx="full_scale_vecchia", num_neighbors=30,
+                                         num_ind_points=200, vecchia_ordering="random", seed=1)
+                tq_setup = time.perf_counter() - tq0
+                mq.neg_log_likelihood(np.array([1.0, 0.1]), yq)           # level schedules, probe vectors, the preconditioner's inducing points
+                tq1 = time.perf_counter()
+                vq = mq.neg_log_likelihood(np.array([1.01, 0.1]), yq)
+                sq = time.perf_counter() - tq1
+                iq = mq.laplace_info()
+                tq2 = time.perf_counter()
+                mq.fit(yq, params={"optimizer_cov": "lbfgs", "init_cov_pars": np.array([1.0, 0.1]), "maxit": 2})
+                sfit = time.perf_counter() - tq2
+                out["vif_non_gaussian"] = {
+                    "workload": "Bernoulli-logit nll, gp_approx=full_scale_vecchia, n=%d, d=2, exponential, m=30, 200 inducing points, fitc preconditioner (200 inducing points), 50 probes" % nq,
+                    "s_per_eval": sq, "negll": vq, "newton_it": iq["newton_it"], "cg_it": iq["cg_it"], "lanczos_it": iq["lanczos_it"], "ms_factor": iq.get("ms_factor"),
+                    "ms_mode_finding": iq["ms_mode"], "ms_logdet": iq["ms_logdet"], "setup_s": round(tq_setup, 3),
+                    "s_two_lbfgs_iterations_with_gradients": sfit, "num_it": mq.get_num_optim_iter(), "cov_pars_after_two_iterations": [float(x) for x in mq.get_cov_pars()]}
+                del mq
+            except Exception as e:
+                out["vif_non_gaussian"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extras:
             # the direct caller of the hot path: a complete maximum-likelihood fit of (sigma2, sigma1_2, rho) on the
             # bench model -- y uploaded once, 3 / 7 doubles back per evaluation.  y = smooth signal + noise so that the optimum is interior.

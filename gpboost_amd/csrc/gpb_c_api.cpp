@@ -209,7 +209,8 @@ int num_aux_of(const std::string& lik) { return lik == "t" ? 2 : ((lik == "gamma
 // cg_preconditioner_type of the iterative methods (SetPropertiesLikelihood, re_model_template.h:7516-7524)
 int laplace_push_preconditioner(REModelHip* mdl) {
   if (!mdl->vh || mdl->likelihood == "gaussian" || mdl->eh) return 0;
-  const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : (mdl->cg_preconditioner_type == "vecchia_response" ? 3 : 0));
+  const int type = mdl->cg_preconditioner_type == "pivoted_cholesky" ? 1 : (mdl->cg_preconditioner_type == "fitc" ? 2 : (mdl->cg_preconditioner_type == "vecchia_response" ? 3 :
+                   (mdl->cg_preconditioner_type == "vifdu" ? 4 : (mdl->cg_preconditioner_type == "none" ? 5 : 0))));
   if (gpb_hip_vecchia_laplace_set_preconditioner(mdl->vh, type, mdl->piv_chol_rank)) return shim_error();
   return 0;
 }
@@ -1466,6 +1467,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   if (vif) {
     if (mdl->has_duplicates) return set_error("GPB_CreateREModel: duplicate coordinates with gp_approx '%s' %s", approx.c_str(), scope);
     if (gpb_hip_vecchia_vif_set_inducing_points(mdl->vh, num_ind_points, mdl->ip.data())) return shim_error();
+    if (lik_name != "gaussian" && laplace_push_preconditioner(mdl.get())) return -1;      // "fitc", rank 200: the default of these models reaches the device without a GPB_SetOptimConfig call
   }
   // the reference maps repeated locations to unique random effects for one non-Gaussian GP and stops if duplicates remain
   // (Vecchia_utils.cpp:1156-1158, 1208-1214); the unique-location mapping is not on this path, so duplicates are an error here
@@ -1577,15 +1579,15 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
   else if (!near(cg_delta_conv, -999.)) return set_error("cg_delta_conv is not > 0, found = %g ", cg_delta_conv);
   if (delta_conv_mode_finding > 0.) mdl->delta_conv_mode_finding = delta_conv_mode_finding;
   else if (!near(delta_conv_mode_finding, -999.)) return set_error("delta_conv_mode_finding is not > 0, found = %g ", delta_conv_mode_finding);
-  if (cg_preconditioner_type && mdl->likelihood != "gaussian") {
-    const std::string pc = cg_preconditioner_type;
+  if (mdl->likelihood != "gaussian") {
+    const std::string pc = cg_preconditioner_type ? cg_preconditioner_type : "";      // (NULL = not given, as the reference's packages pass it: the rank below is read all the same, re_model_template.h:895-914)
     if (pc != "" && mdl->cg_preconditioner_type != pc && mdl->model_has_been_estimated)      // re_model_template.h:891-895 (the comparison is with the string as given, before the alias is resolved)
       return set_error("Cannot change 'cg_preconditioner_type' after a model has been fitted ");
     // ParsePreconditionerAlias (re_model_template.h:7482-7513); SUPPORTED_PRECONDITIONERS_NONGAUSS_VECCHIA_ (:5906): "vadu", "pivoted_cholesky", "fitc" (round 5) and "vecchia_response" (round 6) are built; "incomplete_cholesky" is not
-    if (mdl->vif) {      // SUPPORTED_PRECONDITIONERS_NONGAUSS_VIF_ (:5910): "fitc" (the default) is built; "vifdu" / "none" are not
+    if (mdl->vif) {      // SUPPORTED_PRECONDITIONERS_NONGAUSS_VIF_ (:5910): "fitc" (the default), "vifdu", "none"
       if (pc == "fitc" || pc == "FITC" || pc == "predictive_process_plus_diagonal" || pc == "") { if (pc != "") mdl->cg_preconditioner_type = "fitc"; }
-      else if (pc == "vifdu" || pc == "VIFDU" || pc == "Bt_Sigma_inv_plus_W_B" || pc == "none")
-        return set_error("GPB_SetOptimConfig: cg_preconditioner_type '%s' with gp_approx 'full_scale_vecchia' is not on the MI355X hot path of this library ('fitc', the reference's default, is)", pc.c_str());
+      else if (pc == "vifdu" || pc == "VIFDU" || pc == "Bt_Sigma_inv_plus_W_B") mdl->cg_preconditioner_type = "vifdu";      // evaluation + Nelder-Mead fits: the gradient is built for "fitc" only
+      else if (pc == "none") mdl->cg_preconditioner_type = "none";
       else return set_error("Preconditioner type '%s' is not supported for gp_approx = '%s' and likelihood = '%s'", pc.c_str(), "full_scale_vecchia", mdl->likelihood.c_str());
     }
     else if (pc == "" || pc == "vadu" || pc == "VADU" || pc == "vecchia_approximation_with_diagonal_update" || pc == "Sigma_inv_plus_BtWB") { if (pc != "") mdl->cg_preconditioner_type = "vadu"; }
@@ -1596,7 +1598,8 @@ int GPB_SetOptimConfig(REModelHandle handle, double* init_cov_pars, double lr, d
     const int rank_before = mdl->piv_chol_rank;
     if (piv_chol_rank > 0) mdl->piv_chol_rank = piv_chol_rank;                      // re_model_template.h:900-914
     else if (piv_chol_rank != -999) return set_error("fitc_piv_chol_preconditioner_rank is not > 0, found = %d ", piv_chol_rank);
-    else if (pc != "") mdl->piv_chol_rank = mdl->cg_preconditioner_type == "fitc" ? 200 : 50;
+    else if (mdl->cg_preconditioner_type == "fitc") mdl->piv_chol_rank = 200;          // (a call without a rank puts the type's default back, whether or not it named the type: :907-914)
+    else if (mdl->cg_preconditioner_type == "pivoted_cholesky") mdl->piv_chol_rank = 50;
     if (mdl->cg_preconditioner_type == "fitc" && mdl->piv_chol_rank != rank_before && !mdl->pc_ip.empty() && (int)mdl->pc_ip.size() != mdl->piv_chol_rank * mdl->d)
       return set_error("GPB_SetOptimConfig: the inducing points of the fitc preconditioner have been determined for rank %d; the rank cannot change afterwards on this path", (int)mdl->pc_ip.size() / mdl->d);
     mdl->pc_ip_pushed = false;

@@ -20,6 +20,7 @@ hipError_t pc_gram(const double* L, const double* W, int n, int k, double* part,
 // x2[chunk][k][nc] = M * (L^T (W .* X));  M k x k row-major (the inverse of I_k + L^T W L);  part: ncol * pc_parts(n) * k * nc doubles of scratch
 hipError_t pc_ltwx(const double* L, const double* W, const double* M, const double* X, int n, int k, int ncol, int nc, double* part, double* x2, hipStream_t st);
 // out = W .* (X - L x2) [mode 0: P^-1 X with x2 from pc_ltwx],  X - L x2 [mode 1: W^-1 P^-1 X],  L x2 + X ./ sqrt(W) [mode 2: probe vectors with x2 = the k x t normals]
+// -W .* (L x2) [mode 3],  X + W .* (L x2) [mode 4]  (full-scale Vecchia: the Woodbury part of Sigma^-1, the vifdu preconditioner)
 hipError_t pc_combine(const double* L, const double* W, const double* X, const double* x2, int n, int k, int ncol, int nc, int mode, double* out, hipStream_t st);
 // out = x .* w (inv = 0) or x ./ w (inv = 1); v += h ./ w
 hipError_t pc_rowscale(const double* x, const double* w, int n, int ncol, int nc, int inv, double* out, hipStream_t st);

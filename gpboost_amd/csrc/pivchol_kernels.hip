@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void pc_small_kernel(const double* __restrict_
   }
 }
 
-// one row per thread: acc = L[i, :] x2[:, c];  mode 0: W (X - acc), 1: X - acc, 2: acc + X / sqrt(W)
+// one row per thread: acc = L[i, :] x2[:, c];  mode 0: W (X - acc), 1: X - acc, 2: acc + X / sqrt(W), 3: -W acc (X not used beyond a load), 4: X + W acc
 template <int NC>
 __global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* X,
                                                            const double* __restrict__ x2, int n, int k, int mode, double* out) {      // out may be X
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restric
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const double x = X[o + c];
-    out[o + c] = mode == 0 ? w * x - w * acc[c] : (mode == 1 ? x - acc[c] : acc[c] + sqrt(1.0 / w) * x);
+    out[o + c] = mode == 0 ? w * x - w * acc[c] : (mode == 1 ? x - acc[c] : (mode == 2 ? acc[c] + sqrt(1.0 / w) * x : (mode == 3 ? -w * acc[c] : x + w * acc[c])));
   }
 }
 

@@ -211,7 +211,7 @@ class VecchiaState(object):
     def laplace_set_preconditioner(self, cg_preconditioner_type="vadu", rank=-999):
         """cg_preconditioner_type of the iterative methods: "vadu", "pivoted_cholesky" with `rank` columns, "fitc" with `rank` inducing points, or "vecchia_response"
         (evaluation only) -- gpb_hip_vecchia_laplace_set_preconditioner."""
-        t = {"vadu": 0, "pivoted_cholesky": 1, "fitc": 2, "vecchia_response": 3}[cg_preconditioner_type]
+        t = {"vadu": 0, "pivoted_cholesky": 1, "fitc": 2, "vecchia_response": 3, "vifdu": 4, "none": 5}[cg_preconditioner_type]      # (vifdu / none: full-scale Vecchia handles only)
         _shim_call(_lib().gpb_hip_vecchia_laplace_set_preconditioner(self.h, C.c_int(t), C.c_int(int(rank))))
 
     def vif_set_inducing_points(self, ip):

@@ -148,4 +148,18 @@ for k6 in ref6:
     else: assert np.allclose(x6, y6, rtol=1e-6, atol=1e-8), (k6, x6, y6)
 print("round5_lognormal through the package: fit cov pars %s, log-variance %s, %d iterations, negll %.8f; evaluation with pivoted_cholesky %.8f -- equal to the reference library's" %
       (ours6["ln_cov_pars"], ours6["ln_aux"], ours6["num_it"], ours6["ln_nll"], ours6["ln_nll_eval_pivchol"]), flush=True)
+# round 6: gp_approx = "full_scale_vecchia" with non-Gaussian likelihoods through the package (scenario round6_vif_non_gaussian: a logit evaluation and lbfgs fit, a gamma fit
+# with its shape) against tests/golden/route_a_round6_vif_non_gaussian_ref.json (the same driver on oracle/_ref/lib_gpboost_ref.so)
+r7 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "route_a_driver_gpu.py"), find_lib_path(), "round6_vif_non_gaussian", ROOT], capture_output=True, text=True, cwd=ROOT)
+lines7 = [l for l in r7.stdout.splitlines() if l.startswith("RESULT ")]
+assert lines7, r7.stdout[-2000:] + r7.stderr[-3000:]
+ours7 = json.loads(lines7[-1][7:]); ref7 = json.load(open(os.path.join(ROOT, "tests", "golden", "route_a_round6_vif_non_gaussian_ref.json")))
+assert sorted(ours7) == sorted(ref7)
+for k7 in ref7:
+    x7, y7 = np.asarray(ours7[k7], dtype=float), np.asarray(ref7[k7], dtype=float)
+    if k7 in ("num_it", "vg_num_it"): assert np.array_equal(x7, y7), (k7, x7, y7)
+    elif k7.startswith("flat_"): assert np.allclose(x7, y7, rtol=5e-5, atol=1e-8), (k7, x7, y7)
+    else: assert np.allclose(x7, y7, rtol=1e-6, atol=1e-8), (k7, x7, y7)
+print("round6_vif_non_gaussian through the package: logit evaluation %.8f, fit cov pars %s in %d iterations (negll %.8f); gamma fit cov pars %s, shape %s, %d iterations -- equal to the reference library's" %
+      (ours7["vl_nll_eval"], ours7["vl_cov_pars"], ours7["num_it"], ours7["vl_nll"], ours7["flat_vg_cov_pars"], ours7["flat_vg_aux"], ours7["vg_num_it"][0]), flush=True)
 print("REFERENCE PACKAGE ON MI355X: OK", flush=True)

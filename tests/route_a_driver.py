@@ -214,6 +214,25 @@ elif sc == "round6_widening":
     m.fit(y=yt, params=dict(tight))
     out["tf_cov_pars"] = L(m.get_cov_pars()); out["tf_aux"] = L(m.get_aux_pars()); out["tf_num_it"] = [int(m._get_num_optim_iter())]
     out["stochse_tf_cov_pars_sd"] = L(np.asarray(m.get_cov_pars(std_err=True))[1])
+elif sc == "round6_vif_non_gaussian":
+    # round 6: gp_approx = "full_scale_vecchia" with non-Gaussian likelihoods (FindModePostRandEffCalcMLLFSVA; fitc preconditioner = the reference's default) through the package:
+    # a logit fit (lbfgs), a gamma fit with its shape, evaluations.  (MI355X only: the oracle-backed shim of the CPU suite has no VIF-Laplace path.)
+    n = 800
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    kw = dict(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="full_scale_vecchia", num_neighbors=15, num_ind_points=40, vecchia_ordering="random", seed=6)
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-1.5 * lat))).astype(float)
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.set_optim_params(params=dict(tight, fitc_piv_chol_preconditioner_rank=60))
+    out["vl_nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.8, 0.25]), y=yb))
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.fit(y=yb, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([1.0, 0.2])))
+    out["vl_cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["vl_nll"] = float(m.get_current_neg_log_likelihood())
+    ygam = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
+    m = gpb.GPModel(likelihood="gamma", **kw)
+    m.fit(y=ygam, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([0.6, 0.25]), maxit=12))
+    out["flat_vg_cov_pars"] = L(m.get_cov_pars()); out["flat_vg_aux"] = L(m.get_aux_pars()); out["vg_num_it"] = [int(m._get_num_optim_iter())]; out["vg_nll"] = float(m.get_current_neg_log_likelihood())
 elif sc == "gauss_covariates":
     n = 500
     coords = rng.uniform(size=(n, 2))

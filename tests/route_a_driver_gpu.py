@@ -185,6 +185,56 @@ elif sc == "round5_lognormal":
     m2 = gpb.GPModel(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, likelihood="lognormal", gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
     m2.set_optim_params(params=dict(tight, cg_preconditioner_type="pivoted_cholesky", fitc_piv_chol_preconditioner_rank=40))
     out["ln_nll_eval_pivchol"] = float(m2.neg_log_likelihood(cov_pars=np.array([0.6, 0.2]), y=yl, aux_pars=np.array([0.3])))
+elif sc == "round6_widening":
+    # round 6: what was added behind the same C API -- the vecchia_response preconditioner (evaluation + a Nelder-Mead fit), a gaussian_latent fit ("error_variance"),
+    # gradient descent with an estimated auxiliary parameter (gamma), standard deviations of covariance and auxiliary parameters, t with the degrees of freedom held fixed
+    n = 600
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    kw = dict(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="vecchia", num_neighbors=15, vecchia_ordering="random", seed=6)
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-1.5 * lat))).astype(float)
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.set_optim_params(params=dict(tight, cg_preconditioner_type="vecchia_response"))
+    out["vr_nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.8, 0.25]), y=yb))
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.fit(y=yb, params=dict(tight, cg_preconditioner_type="vecchia_response", optimizer_cov="nelder_mead", maxit=20))
+    out["vr_nm_cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["vr_nm_nll"] = float(m.get_current_neg_log_likelihood())
+    yg = lat + np.sqrt(0.2) * rng.normal(size=n)
+    m = gpb.GPModel(likelihood="gaussian_latent", **kw)
+    m.fit(y=yg, params=dict(tight))
+    out["gl_cov_pars"] = L(m.get_cov_pars()); out["gl_aux"] = L(m.get_aux_pars()); out["gl_num_it"] = [int(m._get_num_optim_iter())]; out["gl_nll"] = float(m.get_current_neg_log_likelihood())
+    cp = rng.uniform(size=(9, 2))
+    p = m.predict(gp_coords_pred=cp, predict_var=True, predict_response=True)
+    out["gl_resp_mu"] = L(p["mu"]); out["stoch_gl_resp_var"] = L(p["var"])
+    ygam = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
+    m = gpb.GPModel(likelihood="gamma", **kw)
+    m.fit(y=ygam, params=dict(tight, optimizer_cov="gradient_descent", maxit=15))
+    out["gd_cov_pars"] = L(m.get_cov_pars()); out["gd_aux"] = L(m.get_aux_pars()); out["gd_num_it"] = [int(m._get_num_optim_iter())]; out["gd_nll"] = float(m.get_current_neg_log_likelihood())
+    yt = lat + 0.3 * rng.standard_t(4.0, size=n)
+    m = gpb.GPModel(likelihood="t_fix_df", likelihood_additional_param=5.0, **kw)
+    m.fit(y=yt, params=dict(tight))
+    out["tf_cov_pars"] = L(m.get_cov_pars()); out["tf_aux"] = L(m.get_aux_pars()); out["tf_num_it"] = [int(m._get_num_optim_iter())]
+    out["stochse_tf_cov_pars_sd"] = L(np.asarray(m.get_cov_pars(std_err=True))[1])
+elif sc == "round6_vif_non_gaussian":
+    # round 6: gp_approx = "full_scale_vecchia" with non-Gaussian likelihoods (FindModePostRandEffCalcMLLFSVA; fitc preconditioner = the reference's default) through the package:
+    # a logit fit (lbfgs), a gamma fit with its shape, evaluations.  (MI355X only: the oracle-backed shim of the CPU suite has no VIF-Laplace path.)
+    n = 800
+    coords = rng.uniform(size=(n, 2))
+    lat = 0.9 * np.sin(5 * coords[:, 0]) * np.cos(3 * coords[:, 1]) + 0.2
+    tight = {"cg_delta_conv": 1e-8, "delta_conv_mode_finding": 1e-13}
+    kw = dict(gp_coords=coords, cov_function="matern", cov_fct_shape=1.5, gp_approx="full_scale_vecchia", num_neighbors=15, num_ind_points=40, vecchia_ordering="random", seed=6)
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-1.5 * lat))).astype(float)
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.set_optim_params(params=dict(tight, fitc_piv_chol_preconditioner_rank=60))
+    out["vl_nll_eval"] = float(m.neg_log_likelihood(cov_pars=np.array([0.8, 0.25]), y=yb))
+    m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
+    m.fit(y=yb, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([1.0, 0.2])))
+    out["vl_cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["vl_nll"] = float(m.get_current_neg_log_likelihood())
+    ygam = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
+    m = gpb.GPModel(likelihood="gamma", **kw)
+    m.fit(y=ygam, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([0.6, 0.25]), maxit=12))
+    out["flat_vg_cov_pars"] = L(m.get_cov_pars()); out["flat_vg_aux"] = L(m.get_aux_pars()); out["vg_num_it"] = [int(m._get_num_optim_iter())]; out["vg_nll"] = float(m.get_current_neg_log_likelihood())
 elif sc == "gauss_covariates":
     n = 500
     coords = rng.uniform(size=(n, 2))
