@@ -2166,6 +2166,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !out_predict) return set_error("GPB_PredictREModel: null argument");
+  if (mdl && mdl->vif && mdl->likelihood != "gaussian")      // PredictLaplaceApproxFSVA (likelihoods.h:7999-8535) is not built: never the Gaussian formulas on a non-Gaussian model
+    return set_error("GPB_PredictREModel: prediction for gp_approx 'full_scale_vecchia' with likelihood '%s' is not yet on the MI355X path of this library (likelihood evaluation, its gradient and fits are)", mdl->likelihood.c_str());
   if (mdl && mdl->vif) {
     // full-scale Vecchia, 'order_obs_first_cond_obs_only' (the reference's default for Gaussian data; CalcPredVecchiaObservedFirstOrder with the
     // full_scale_vecchia arguments, Vecchia_utils.cpp:1701-2060; re_model_template.h:4041-4056): y_p = C_p Sigma_m^-1 eta + e_p with the residual
@@ -3061,7 +3063,8 @@ int GPB_PredictREModelTrainingDataRandomEffects(REModelHandle handle, const doub
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !out_predict) return set_error("GPB_PredictREModelTrainingDataRandomEffects: null argument");
-  if (mdl && mdl->vif) return set_error("GPB_PredictREModelTrainingDataRandomEffects: gp_approx 'full_scale_vecchia' -- likelihood evaluation, its gradient and fits are on the MI355X path of this library, this call is not yet");
+  // re_model.cpp / re_model_template.h: the reference refuses this call for the approximation, Gaussian or not -- the same words
+  if (mdl && mdl->vif) return set_error("PredictTrainingDataRandomEffects() is currently not implemented for the 'full_scale_vecchia' approximation. Call the predict() function instead ");
   if (mdl->likelihood != "gaussian") {
     // non-Gaussian Vecchia models (re_model_template.h:4683-4725): the mode of the latent process, mapped to the data by random_effects_indices_of_data_
     // if locations repeat, and -- calc_var -- diag((Sigma^-1 + W)^-1) (CalcVarLaplaceApproxVecchia): exact, one block solve per 52 random effects

@@ -47,6 +47,10 @@ def test_value_matches_the_reference(gpb, name):
         ref = float(g["%s_fitc_negll_%d" % (name, j)])
         v = mdl.neg_log_likelihood(cov_pars=np.asarray(cp), y=y)
         assert abs(v - ref) <= 1e-8 * abs(ref), (name, j, v, ref)
+    with pytest.raises(gpb.GPBoostError, match="not implemented for the 'full_scale_vecchia' approximation"):      # the reference's own refusal, word for word
+        mdl.predict_training_data_random_effects(y=y, cov_pars=np.asarray(c["cov_pars"][0]))
+    with pytest.raises(gpb.GPBoostError, match="prediction for gp_approx 'full_scale_vecchia' with likelihood"):      # not built (PredictLaplaceApproxFSVA): refused, never the Gaussian formulas
+        mdl.predict(y=y, gp_coords_pred=coords[:5] + 0.01, cov_pars=np.asarray(c["cov_pars"][0]))
     # a second evaluation at the first parameters reproduces the first (the mode is re-initialised, the probes are reused)
     v2 = mdl.neg_log_likelihood(cov_pars=np.asarray(c["cov_pars"][0]), y=y)
     assert abs(v2 - float(g["%s_fitc_negll_0" % name])) <= 1e-8 * abs(v2)
