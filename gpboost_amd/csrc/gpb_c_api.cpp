@@ -2166,9 +2166,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
   C_API_BEGIN();
   auto* mdl = reinterpret_cast<REModelHip*>(handle);
   if (!mdl || !out_predict) return set_error("GPB_PredictREModel: null argument");
-  if (mdl && mdl->vif && mdl->likelihood != "gaussian")      // PredictLaplaceApproxFSVA (likelihoods.h:7999-8535) is not built: never the Gaussian formulas on a non-Gaussian model
-    return set_error("GPB_PredictREModel: prediction for gp_approx 'full_scale_vecchia' with likelihood '%s' is not yet on the MI355X path of this library (likelihood evaluation, its gradient and fits are)", mdl->likelihood.c_str());
-  if (mdl && mdl->vif) {
+  if (mdl && mdl->vif && mdl->likelihood == "gaussian") {
     // full-scale Vecchia, 'order_obs_first_cond_obs_only' (the reference's default for Gaussian data; CalcPredVecchiaObservedFirstOrder with the
     // full_scale_vecchia arguments, Vecchia_utils.cpp:1701-2060; re_model_template.h:4041-4056): y_p = C_p Sigma_m^-1 eta + e_p with the residual
     // e_p conditioning on the nearest observed points -> mean = A_p y_nn + (B C)_p W^-1 (B C)' D^-1 B y, var = sigma2 (D_p + (B C)_p W^-1 (B C)_p')
@@ -2315,6 +2313,9 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     const bool lat_cond_all = pt == "latent_order_obs_first_cond_all" || pt == "order_obs_first_cond_all";
     if (!pt.empty() && pt != "order_obs_first_cond_obs_only" && pt != "latent_order_obs_first_cond_obs_only" && !lat_cond_all)
       return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", pt.c_str(), lscope);
+    // full-scale Vecchia (round 6; PredictLaplaceApproxFSVA, likelihoods.h:7999-8535): means and variances, 'latent_order_obs_first_cond_obs_only'
+    if (mdl->vif && (lat_cond_all || predict_cov_mat || mdl->p_cov > 0))
+      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means and variances with 'latent_order_obs_first_cond_obs_only' are on the MI355X path of this library; 'latent_order_obs_first_cond_all', covariance matrices and covariates are not", mdl->likelihood.c_str());
     const double* cpl = gp_coords_data_pred;
     int npl = num_data_pred;
     if (use_saved_data) { cpl = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npl = mdl->num_data_pred; }
@@ -2343,7 +2344,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (gpb_hip_vecchia_laplace_logit(mdl->vh, mdl->cov_type, s12, a_tr, mdl->num_rand_vec_trace, mdl->seed_rand_vec_trace, mdl->cg_max_num_it,
                                       mdl->cg_max_num_it_tridiag, mdl->cg_delta_conv, mdl->delta_conv_mode_finding, 1, mdl->lap_info, mode.data()))
       return shim_error();
-    if (gpb_hip_vecchia_set_y(mdl->vh, mode.data())) return shim_error();          // the "response" of the prediction is the mode (Vecchia order)
+    if (!mdl->vif && gpb_hip_vecchia_set_y(mdl->vh, mode.data())) return shim_error();          // the "response" of the prediction is the mode (Vecchia order)
     const int nnpl = mdl->num_neighbors_pred > 0 ? mdl->num_neighbors_pred : 2 * mdl->num_neighbors;     // re_model_template.h:299
     const bool need_var = predict_var || predict_response;            // every likelihood on the path needs the latent variance for its response mean
     // unique prediction locations: first appearances, in the order given (DetermineUniqueDuplicateCoordsFast on the prediction coordinates)
@@ -2415,6 +2416,9 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
             if (r == c2 && need_var) var_u[r] = pr + (predict_cov_mat ? q[(size_t)r * nu + r] : q[r]);
           }
       }
+    } else if (mdl->vif) {
+      if (gpb_hip_vecchia_vif_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
+                                              need_var ? var_u.data() : nullptr, nullptr, &cg_it)) return shim_error();
     } else if (gpb_hip_vecchia_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
                                         need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it))
       return shim_error();

@@ -47,5 +47,7 @@ hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, c
 // out[i] = c0 - 2 L_i' M1 L2_i + L_i' M2 L_i (the derivative of the fitc preconditioner's diagonal, likelihoods.h:5478-5486); out = a .* b (.* c)
 hipError_t pc_row_quad(const double* L, const double* L2, const double* M1, const double* M2, int n, int k, double c0, double* out, hipStream_t st);
 hipError_t pc_mul3(const double* a, const double* b, const double* c, int n, double* out, hipStream_t st);
+// columns [col0, col0 + cnt) of L [n][k], times w[i], as a block vector of ncol chunks x nc columns (zero beyond cnt): right-hand sides W C of the VIF-Laplace prediction
+hipError_t pc_cols_to_block(const double* L, const double* w, int n, int k, int col0, int cnt, int ncol, int nc, double* out, hipStream_t st);
 
 }  // namespace gpb

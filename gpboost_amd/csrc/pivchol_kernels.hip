@@ -348,6 +348,13 @@ __global__ void pc_row_quad_kernel(const double* __restrict__ L, const double* _
   }
   out[i] = c0 - 2.0 * q1 + q2;
 }
+// columns [col0, col0 + cnt) of L [n][k] (rows in storage order), times w[i], into a block vector [chunk][row][nc] of ncol chunks (zero beyond cnt)
+__global__ void pc_cols_to_block_kernel(const double* __restrict__ L, const double* __restrict__ w, int n, int k, int col0, int cnt, int nc, double* __restrict__ out) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * nc) return;
+  const int i = (int)(g / nc), c = (int)(blockIdx.y * nc + g % nc);
+  out[(size_t)blockIdx.y * n * nc + g] = c < cnt ? w[i] * L[(size_t)i * k + col0 + c] : 0.0;
+}
 // out[i] = a[i] * b[i] * (c ? c[i] : 1)
 __global__ void pc_mul3_kernel(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c, int n, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,6 +427,10 @@ hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, c
 }
 hipError_t pc_row_quad(const double* L, const double* L2, const double* M1, const double* M2, int n, int k, double c0, double* out, hipStream_t st) {
   hipLaunchKernelGGL(pc_row_quad_kernel, dim3((n + 127) / 128), dim3(128), 0, st, L, L2, M1, M2, n, k, c0, out);
+  return hipGetLastError();
+}
+hipError_t pc_cols_to_block(const double* L, const double* w, int n, int k, int col0, int cnt, int ncol, int nc, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(pc_cols_to_block_kernel, dim3((unsigned)(((size_t)n * nc + 255) / 256), ncol), dim3(256), 0, st, L, w, n, k, col0, cnt, nc, out);
   return hipGetLastError();
 }
 hipError_t pc_mul3(const double* a, const double* b, const double* c, int n, double* out, hipStream_t st) {

@@ -1233,6 +1233,35 @@ def vif_laplace_grad_fixture(out_dir, only=None):
         np.savez_compressed(path, **res)
 
 
+def vif_laplace_pred_points(c):
+    rng = np.random.default_rng(777 + c["n"])
+    return rng.uniform(size=(25, c["d"]))
+
+
+def vif_laplace_pred_fixture(out_dir, only=None):
+    """Predictions of VIF x non-Gaussian models at 25 new locations by the unmodified reference with matrix_inversion_method = "cholesky" (PredictLaplaceApproxFSVA's exact branch,
+    likelihoods.h:8455-8527; its iterative branch estimates the variances by simulation): latent mean / variance and response mean / variance, keys <name>_pred_* in
+    tests/golden/vif_laplace_ref.npz."""
+    path = os.path.join(out_dir, "vif_laplace_ref.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, c in cases.VIF_LAPLACE_CASES.items():
+        if only and name not in only:
+            continue
+        coords, y = cases.vif_laplace_data(name)
+        cpred = vif_laplace_pred_points(c)
+        mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
+                                  gp_approx="full_scale_vecchia", num_ind_points=c["k"], matrix_inversion_method="cholesky")
+        mdl.set_optim_config(init_aux_pars=c["aux"], cg_preconditioner_type="", **cases.LAPLACE_PRED_REF)
+        cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
+        mu, var = mdl.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp)
+        rmu, rvar = mdl.predict(cpred, predict_var=True, predict_response=True, y=y, cov_pars=cp)
+        res[name + "_pred_coords"] = cpred
+        res[name + "_pred_latent_mu"] = mu; res[name + "_pred_latent_var"] = var
+        res[name + "_pred_resp_mu"] = rmu; res[name + "_pred_resp_var"] = rvar
+        print("vif_laplace_pred", name, mu[:3], var[:3], rmu[:3], flush=True)
+        np.savez_compressed(path, **res)
+
+
 def vif_laplace_fit_fixture(out_dir, only=None):
     """The reference's own GPB_OptimCovPar on VIF x non-Gaussian models (tests/cases.py: VIF_LAPLACE_FITS): estimates, auxiliary parameter, iteration count, final value."""
     path = os.path.join(out_dir, "vif_laplace_ref.npz")
@@ -1468,6 +1497,8 @@ if __name__ == "__main__":
         predtypes_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_grad":
         vif_grad_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_pred":
+        vif_laplace_pred_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_fit":
         vif_laplace_fit_fixture(os.path.join(ROOT, "tests", "golden"), sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "vif_laplace_grad":

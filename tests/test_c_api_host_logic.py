@@ -197,5 +197,6 @@ def test_route_a_scenarios_agree_with_the_references_own_library(mock_lib, scena
             np.testing.assert_allclose(x, y, rtol=5e-3, err_msg=k)
         elif k.startswith("flat_"):      # estimates of a fit whose likelihood is flat in the range (beta regression, pivoted_cholesky rank 40): seen 2.6e-6 at the tight thresholds
             np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-8, err_msg=k)
-        else:
-            np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-8, err_msg=k)
+        else:      # (absolute part relative to the vector's scale: entries of a mode near zero were seen 1.2e-8 apart -- 4e-8 of the largest entry -- on a loaded machine, where the
+                   #  reference's OpenMP reductions take another order)
+            np.testing.assert_allclose(x, y, rtol=1e-6, atol=max(1e-8, 1e-7 * float(np.abs(y).max())) if y.size else 1e-8, err_msg=k)

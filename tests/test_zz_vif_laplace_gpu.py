@@ -49,8 +49,6 @@ def test_value_matches_the_reference(gpb, name):
         assert abs(v - ref) <= 1e-8 * abs(ref), (name, j, v, ref)
     with pytest.raises(gpb.GPBoostError, match="not implemented for the 'full_scale_vecchia' approximation"):      # the reference's own refusal, word for word
         mdl.predict_training_data_random_effects(y=y, cov_pars=np.asarray(c["cov_pars"][0]))
-    with pytest.raises(gpb.GPBoostError, match="prediction for gp_approx 'full_scale_vecchia' with likelihood"):      # not built (PredictLaplaceApproxFSVA): refused, never the Gaussian formulas
-        mdl.predict(y=y, gp_coords_pred=coords[:5] + 0.01, cov_pars=np.asarray(c["cov_pars"][0]))
     # a second evaluation at the first parameters reproduces the first (the mode is re-initialised, the probes are reused)
     v2 = mdl.neg_log_likelihood(cov_pars=np.asarray(c["cov_pars"][0]), y=y)
     assert abs(v2 - float(g["%s_fitc_negll_0" % name])) <= 1e-8 * abs(v2)
@@ -148,6 +146,26 @@ def test_fits_follow_the_reference(gpb, fit):
     assert abs(mdl.get_current_neg_log_likelihood() - float(g[fit + "_negll"])) <= 1e-7 * abs(float(g[fit + "_negll"]))
     if fit + "_aux" in g.files:
         np.testing.assert_allclose(mdl.get_aux_pars(), g[fit + "_aux"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", sorted(cases.VIF_LAPLACE_CASES))
+def test_predictions_match_the_references_exact_branch(gpb, name):
+    """PredictLaplaceApproxFSVA (likelihoods.h:7999-8535), 'latent_order_obs_first_cond_obs_only': latent mean / variance and response mean / variance at 25 new locations against the
+    unmodified reference with matrix_inversion_method = "cholesky" (its exact branch; the iterative one estimates the variances by simulation) -- here the same expression with every
+    (B'D^-1B + W)^-1 product by block CG.  1e-8 at cases.LAPLACE_PRED_TIGHT (the mode converged), the Poisson case at its mode's own floor (cases.py)."""
+    g = np.load(os.path.join(GOLD, "vif_laplace_ref.npz"))
+    mdl, coords, y, c = _model(gpb, name, **cases.LAPLACE_PRED_TIGHT)
+    cpred = g[name + "_pred_coords"]
+    cp = np.asarray(c["cov_pars"][0])
+    tol = 2e-6 if c["lik"] == "poisson" else 1e-8
+    p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_var=True, predict_response=False)
+    np.testing.assert_allclose(p["mu"], g[name + "_pred_latent_mu"], rtol=0, atol=tol * np.abs(g[name + "_pred_latent_mu"]).max())
+    np.testing.assert_allclose(p["var"], g[name + "_pred_latent_var"], rtol=tol, atol=0)
+    p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_var=True, predict_response=True)
+    np.testing.assert_allclose(p["mu"], g[name + "_pred_resp_mu"], rtol=max(tol, 1e-7))
+    np.testing.assert_allclose(p["var"], g[name + "_pred_resp_var"], rtol=max(tol, 1e-7))
+    with pytest.raises(gpb.GPBoostError, match="covariance matrices and covariates are not"):
+        mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_cov_mat=True, predict_response=False)
 
 
 @pytest.mark.parametrize("pc", ["vifdu", "none"])
