@@ -43,7 +43,7 @@ hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st);      /
 // WIPIZ = W^-1 P^-1 Z, row-wise optimal c (CalcOptimalCVectorized), deterministic part diag(L M L^T) dW - dW / W
 // (wp != nullptr: the fitc branch, :16612-16633 -- deterministic part diag(C M C') wp (W^-1 dW W^-1 wp) - W^-1 dW W^-1 wp)
 hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
-                        double* dld, hipStream_t st, const double* wp = nullptr, int det_centre = 0);
+                        double* dld, hipStream_t st, const double* wp = nullptr, int det_centre = 0, double* sdiag_scratch = nullptr);      // sdiag_scratch: n doubles; then diag(L M L') comes from the tiled kernel (k <= 256)
 // out[i] = c0 - 2 L_i' M1 L2_i + L_i' M2 L_i (the derivative of the fitc preconditioner's diagonal, likelihoods.h:5478-5486); out = a .* b (.* c)
 hipError_t pc_row_quad(const double* L, const double* L2, const double* M1, const double* M2, int n, int k, double c0, double* out, hipStream_t st);
 hipError_t pc_mul3(const double* a, const double* b, const double* c, int n, double* out, hipStream_t st);

@@ -116,11 +116,14 @@ __global__ void pc_gram_reduce_kernel(const double* __restrict__ part, int parts
   G[e] = s;
 }
 
-// part[chunk][slice][q][c] = sum over the rows of the slice of L[i][q] W[i] X[i][c]; 256 threads = 4 row groups x 64 columns of L
+// part[chunk][slice][q][c] = sum over the rows of the slice of L[i][q] W[i] X[i][c]; 512 threads = 8 row groups x 64 columns of L, every thread with UNR independent
+// accumulation chains (round 6: with 4 groups and one chain the kernel ran at 1 TB/s of the n x k matrix -- one workgroup per CU, one load in flight per thread;
+// profiles/r06_z_trace_vif_non_gaussian_config4_size_rocprofv3_summary.txt).  The order of the additions is fixed: chain u of group g takes the rows lo + g + 8 (u + UNR j).
 template <int NC>
-__global__ __launch_bounds__(256) void pc_ltwx_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X, int n, int k,
+__global__ __launch_bounds__(512) void pc_ltwx_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X, int n, int k,
                                                         double* __restrict__ part) {
-  __shared__ double s[4][64][NC];
+  constexpr int G = 8, UNR = NC == 1 ? 4 : 2;
+  __shared__ double s[G][64][NC];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int chunk = blockIdx.y, parts = gridDim.x;
   const double* Xc = X + (size_t)chunk * n * NC;
@@ -128,40 +131,64 @@ __global__ __launch_bounds__(256) void pc_ltwx_kernel(const double* __restrict__
   pc_slice(n, parts, (int)blockIdx.x, lo, hi);
   for (int q0 = 0; q0 < k; q0 += 64) {
     const int q = q0 + lane;
-    double acc[NC];
+    double acc[UNR][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[u][c] = 0.0;
     if (q < k) {
-      for (int i = lo + g; i < hi; i += 4) {
-        const double lw = L[(size_t)i * k + q] * W[i];
+      for (int i0 = lo + g; i0 < hi; i0 += G * UNR) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(lw, Xc[(size_t)i * NC + c], acc[c]);
+        for (int u = 0; u < UNR; ++u) {
+          const int i = i0 + G * u;
+          if (i < hi) {
+            const double lw = L[(size_t)i * k + q] * W[i];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[u][c] = __builtin_fma(lw, Xc[(size_t)i * NC + c], acc[u][c]);
+          }
+        }
       }
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) s[g][lane][c] = acc[c];
+    for (int c = 0; c < NC; ++c) {
+      double a = acc[0][c];
+#pragma unroll
+      for (int u = 1; u < UNR; ++u) a += acc[u][c];
+      s[g][lane][c] = a;
+    }
     __syncthreads();
     if (g == 0 && q < k) {
       double* dst = part + (((size_t)chunk * parts + blockIdx.x) * k + q) * NC;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) dst[c] = ((s[0][lane][c] + s[1][lane][c]) + s[2][lane][c]) + s[3][lane][c];
+      for (int c = 0; c < NC; ++c) {
+        double a = s[0][lane][c];
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) a += s[gg][lane][c];
+        dst[c] = a;
+      }
     }
     __syncthreads();
   }
 }
-// x2[chunk][q][c] = sum_p M[q][p] y[p][c],  y = the slices' partial sums added in slice order
+// x2[chunk][q][c] = sum_p M[q][p] y[p][c],  y = the slices' partial sums: four quarters of the slices added in slice order each (by four thread groups -- the sum over 256
+// slices was a chain of 256 dependent loads per element, 77 us for 200 elements), then the quarters in order
 template <int NC>
-__global__ __launch_bounds__(256) void pc_small_kernel(const double* __restrict__ part, int parts, const double* __restrict__ M, int k, double* __restrict__ x2) {
-  extern __shared__ double s_y[];                      // k * NC
+__global__ __launch_bounds__(1024) void pc_small_kernel(const double* __restrict__ part, int parts, const double* __restrict__ M, int k, double* __restrict__ x2) {
+  extern __shared__ double s_y[];                      // k * NC, then 4 x k * NC quarter sums
   const int chunk = blockIdx.x;
   const int len = k * NC;
-  for (int e = threadIdx.x; e < len; e += 256) {
+  double* s_q = s_y + len;
+  const int sub = threadIdx.x >> 8, tl = threadIdx.x & 255;
+  const int b0 = (int)((long long)parts * sub / 4), b1 = (int)((long long)parts * (sub + 1) / 4);
+  for (int e = tl; e < len; e += 256) {
     double acc = 0.0;
-    for (int b = 0; b < parts; ++b) acc += part[((size_t)chunk * parts + b) * len + e];
-    s_y[e] = acc;
+    for (int b = b0; b < b1; ++b) acc += part[((size_t)chunk * parts + b) * len + e];
+    s_q[sub * len + e] = acc;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < len; e += 256) {
+  for (int e = threadIdx.x; e < len; e += 1024) s_y[e] = ((s_q[e] + s_q[len + e]) + s_q[2 * len + e]) + s_q[3 * len + e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < len; e += 1024) {
     const int q = e / NC, c = e % NC;
     const double* Mq = M + (size_t)q * k;
     double acc = 0.0;
@@ -286,9 +313,62 @@ __global__ void pc_fitc_diag_kernel(const double* __restrict__ W, const double* 
   wp[i] = 1.0 / d;
 }
 
+// Row-wise quadratic forms with k x k symmetric matrices, k <= 256: one wavefront per 4 rows; lane l owns the columns q = l + 64 j of M, reads row p of M coalesced
+// (M symmetric: M[p][q] = M[q][p]) once for its 4 rows; x[p] of the rows broadcast from LDS.  (round 6: the one-thread-per-row form below took 33 ms at n = 1e5, k = 200 --
+// k^2 global loads per thread; profiles/r06_z_trace_vif_non_gaussian_config4_size_rocprofv3_summary.txt.)
+//   TWO: out[i] = c0 - 2 L_i' M1 L2_i + L_i' M2 L_i;   !TWO: out[i] = L_i' M2 L_i
+template <bool TWO>
+__global__ __launch_bounds__(256) void pc_row_quad_tiled_kernel(const double* __restrict__ L, const double* __restrict__ L2, const double* __restrict__ M1,
+                                                                const double* __restrict__ M2, int n, int k, double c0, double* __restrict__ out) {
+  constexpr int RW = 4, JM = 4;
+  __shared__ double s_x[4][RW][256], s_y[4][RW][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wv) * RW;
+  if (row0 >= n) return;
+  for (int r = 0; r < RW; ++r) {
+    const int i = min(row0 + r, n - 1);
+    for (int p = lane; p < k; p += 64) { s_x[wv][r][p] = L[(size_t)i * k + p]; if (TWO) s_y[wv][r][p] = L2[(size_t)i * k + p]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  double a1[RW][JM], a2[RW][JM];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { a1[r][j] = 0.0; a2[r][j] = 0.0; }
+  for (int p = 0; p < k; ++p) {
+    double m1[JM], m2[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int q = lane + 64 * j;
+      m2[j] = q < k ? M2[(size_t)p * k + q] : 0.0;
+      m1[j] = (TWO && q < k) ? M1[(size_t)p * k + q] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const double xp = s_x[wv][r][p];
+      const double yp = TWO ? s_y[wv][r][p] : 0.0;
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { a2[r][j] = __builtin_fma(m2[j], xp, a2[r][j]); if (TWO) a1[r][j] = __builtin_fma(m1[j], yp, a1[r][j]); }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int q = lane + 64 * j;
+      const double xq = q < k ? s_x[wv][r][q] : 0.0;
+      q2 = __builtin_fma(xq, a2[r][j], q2);
+      if (TWO) q1 = __builtin_fma(xq, a1[r][j], q1);
+    }
+    for (int off = 32; off > 0; off >>= 1) { q1 += __shfl_xor(q1, off); q2 += __shfl_xor(q2, off); }
+    if (lane == 0 && row0 + r < n) out[row0 + r] = TWO ? c0 - 2.0 * q1 + q2 : q2;
+  }
+}
+
 __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* __restrict__ WIPIZ, const double* __restrict__ L, const double* __restrict__ M,
                                     const double* __restrict__ W, const double* __restrict__ dW3, int n, int k, int t, int nc, double* __restrict__ dld,
-                                    const double* __restrict__ wp, int det_centre) {
+                                    const double* __restrict__ wp, int det_centre, const double* __restrict__ sdiag_in) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d3 = dW3[i], wi = 1.0 / W[i];
@@ -302,6 +382,8 @@ __global__ void pc_row_stats_kernel(const double* __restrict__ U, const double* 
   // diag of L (I_k + L^T W L)^-1 L^T  (likelihoods.h:16583-16586)
   const double* Li = L + (size_t)i * k;
   double sdiag = 0.0;
+  if (sdiag_in) sdiag = sdiag_in[i];                    // (pc_row_quad_tiled_kernel<false>)
+  else
   for (int q = 0; q < k; ++q) {
     const double* Mq = M + (size_t)q * k;
     double acc = 0.0;
@@ -388,13 +470,13 @@ hipError_t pc_gram(const double* L, const double* W, int n, int k, double* part,
 }
 hipError_t pc_ltwx(const double* L, const double* W, const double* M, const double* X, int n, int k, int ncol, int nc, double* part, double* x2, hipStream_t st) {
   const int parts = pc_parts(n);
-  const size_t lds = sizeof(double) * (size_t)k * nc;
+  const size_t lds = sizeof(double) * (size_t)k * nc * 5;
   if (nc == 4) {
-    hipLaunchKernelGGL(pc_ltwx_kernel<4>, dim3(parts, ncol), dim3(256), 0, st, L, W, X, n, k, part);
-    hipLaunchKernelGGL(pc_small_kernel<4>, dim3(ncol), dim3(256), lds, st, part, parts, M, k, x2);
+    hipLaunchKernelGGL(pc_ltwx_kernel<4>, dim3(parts, ncol), dim3(512), 0, st, L, W, X, n, k, part);
+    hipLaunchKernelGGL(pc_small_kernel<4>, dim3(ncol), dim3(1024), lds, st, part, parts, M, k, x2);
   } else {
-    hipLaunchKernelGGL(pc_ltwx_kernel<1>, dim3(parts, ncol), dim3(256), 0, st, L, W, X, n, k, part);
-    hipLaunchKernelGGL(pc_small_kernel<1>, dim3(ncol), dim3(256), lds, st, part, parts, M, k, x2);
+    hipLaunchKernelGGL(pc_ltwx_kernel<1>, dim3(parts, ncol), dim3(512), 0, st, L, W, X, n, k, part);
+    hipLaunchKernelGGL(pc_small_kernel<1>, dim3(ncol), dim3(1024), lds, st, part, parts, M, k, x2);
   }
   return hipGetLastError();
 }
@@ -421,12 +503,18 @@ hipError_t pc_wmax(const double* w, int n, double* out1, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t pc_row_stats(const double* U, const double* WIPIZ, const double* L, const double* M, const double* W, const double* dW3, int n, int k, int t, int nc,
-                        double* dld, hipStream_t st, const double* wp, int det_centre) {
-  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld, wp, det_centre);
+                        double* dld, hipStream_t st, const double* wp, int det_centre, double* sdiag_scratch) {
+  const double* sd = nullptr;
+  if (sdiag_scratch && k <= 256) {      // diag(L M L') by the tiled kernel first (M symmetric)
+    hipLaunchKernelGGL(pc_row_quad_tiled_kernel<false>, dim3((n + 15) / 16), dim3(256), 0, st, L, L, M, M, n, k, 0.0, sdiag_scratch);
+    sd = sdiag_scratch;
+  }
+  hipLaunchKernelGGL(pc_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, U, WIPIZ, L, M, W, dW3, n, k, t, nc, dld, wp, det_centre, sd);
   return hipGetLastError();
 }
 hipError_t pc_row_quad(const double* L, const double* L2, const double* M1, const double* M2, int n, int k, double c0, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(pc_row_quad_kernel, dim3((n + 127) / 128), dim3(128), 0, st, L, L2, M1, M2, n, k, c0, out);
+  if (k <= 256) hipLaunchKernelGGL(pc_row_quad_tiled_kernel<true>, dim3((n + 15) / 16), dim3(256), 0, st, L, L2, M1, M2, n, k, c0, out);
+  else hipLaunchKernelGGL(pc_row_quad_kernel, dim3((n + 127) / 128), dim3(128), 0, st, L, L2, M1, M2, n, k, c0, out);
   return hipGetLastError();
 }
 hipError_t pc_cols_to_block(const double* L, const double* w, int n, int k, int col0, int cnt, int ncol, int nc, double* out, hipStream_t st) {

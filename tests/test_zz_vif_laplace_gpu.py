@@ -190,6 +190,25 @@ def test_vifdu_and_none_preconditioners_match_the_reference(gpb, name, pc):
         assert mdl.get_num_optim_iter() == 5
 
 
+def test_switching_preconditioners_and_predicting_before_a_fit_keeps_the_buffers_consistent(gpb):
+    """One handle through vifdu evaluation -> prediction -> fitc evaluation -> lbfgs fit (gradient): the storage-order copies of C / dC / B dC are allocated by different
+    paths (a handle that had C alone must still get the derivative copies)."""
+    name = "vifl_u2d_n1500_exp_m15_k40_logit"
+    g = np.load(os.path.join(GOLD, "vif_laplace_ref.npz"))
+    mdl, coords, y, c = _model(gpb, name, cg_preconditioner_type="vifdu", **cases.LAPLACE_TIGHT)
+    cp = np.asarray(c["cov_pars"][0])
+    v = mdl.neg_log_likelihood(cov_pars=cp, y=y)
+    assert abs(v - float(g[name + "_vifdu_negll_0"])) <= 1e-8 * abs(v)
+    p = mdl.predict(y=y, gp_coords_pred=g[name + "_pred_coords"], cov_pars=cp, predict_var=True, predict_response=False)
+    np.testing.assert_allclose(p["mu"], g[name + "_pred_latent_mu"], rtol=0, atol=1e-6 * np.abs(g[name + "_pred_latent_mu"]).max())
+    mdl.set_optim_params(dict(cases.VIF_LAPLACE_TIGHT, cg_preconditioner_type="fitc", fitc_piv_chol_preconditioner_rank=c["rank"]))
+    v = mdl.neg_log_likelihood(cov_pars=cp, y=y)
+    assert abs(v - float(g[name + "_fitc_negll_0"])) <= 1e-8 * abs(v)
+    mdl.fit(y, params=dict(cases.LAPLACE_TIGHT, optimizer_cov="lbfgs", init_cov_pars=[1.0, 0.2], maxit=30))
+    assert mdl.get_num_optim_iter() == int(g["vifl_fit_logit_lbfgs_num_it"])
+    np.testing.assert_allclose(mdl.get_cov_pars(), g["vifl_fit_logit_lbfgs_cov_pars"], rtol=1e-6)
+
+
 def test_preconditioners_of_other_models_are_refused(gpb):
     name = "vifl_u2d_n1500_exp_m15_k40_logit"
     mdl, coords, y, c = _model(gpb, name)
