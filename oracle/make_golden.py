@@ -1198,6 +1198,10 @@ def vif_laplace_fixture(out_dir, only=None):
             continue
         coords, y = cases.vif_laplace_data(name)
         for pc in ("fitc", "vifdu", "none"):
+            if pc == "none" and c["lik"] not in ("bernoulli_logit", "poisson", "gamma"):
+                continue                                                           # (hundreds of CG iterations per solve: the first three cases only)
+            if pc == "vifdu" and c["lik"] in ("t", "lognormal", "gaussian_latent"):
+                continue                                                           # (the reference build aborts in an Eigen assertion: its vifdu Woodbury factor is solved with before it is computed)
             for j, cp in enumerate(c["cov_pars"]):
                 if pc != "fitc" and j > 0:
                     continue

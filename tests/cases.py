@@ -693,6 +693,13 @@ VIF_LAPLACE_CASES = {
                                              cov_pars=[(0.8, 0.25), (1.6, 0.1)]),
     "vifl_u2d_n2000_mat15_m20_k64_poisson": dict(n=2000, d=2, cov_function="matern", shape=1.5, m=20, k=64, ordering="random", seed=2, lik="poisson", aux=None, rank=None,
                                                  cov_pars=[(0.6, 0.2)], grad_rtol=1e-7),
+    # (likelihoods whose information does not depend on the location parameter -- Fisher-Laplace t, lognormal: the auxiliary parameters' traces take another branch, likelihoods.h:5700-5760)
+    "vifl_u2d_n1200_exp_m15_k40_t": dict(n=1200, d=2, cov_function="exponential", shape=0.5, m=15, k=40, ordering="random", seed=3, lik="t", aux=[0.4, 5.0], rank=50,
+                                         cov_pars=[(0.7, 0.2)]),
+    "vifl_u2d_n1200_mat15_m15_k40_lognormal": dict(n=1200, d=2, cov_function="matern", shape=1.5, m=15, k=40, ordering="random", seed=4, lik="lognormal", aux=0.2, rank=50,
+                                                   cov_pars=[(0.7, 0.2)]),
+    "vifl_u2d_n1200_exp_m15_k40_negbin": dict(n=1200, d=2, cov_function="exponential", shape=0.5, m=15, k=40, ordering="random", seed=5, lik="negative_binomial", aux=2.0, rank=50,
+                                              cov_pars=[(0.7, 0.2)]),
     "vifl_u3d_n1500_mat25_m15_k40_gamma": dict(n=1500, d=3, cov_function="matern", shape=2.5, m=15, k=40, ordering="none", seed=1, lik="gamma", aux=2.0, rank=64,
                                                cov_pars=[(0.5, 0.3)]),
 }
@@ -719,6 +726,13 @@ def vif_laplace_data(name):
         y = rng.poisson(np.exp(lat)).astype(np.float64)
     elif c["lik"] == "gamma":
         y = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
+    elif c["lik"] == "t":
+        y = lat + 0.35 * rng.standard_t(4.0, size=c["n"])
+    elif c["lik"] == "lognormal":
+        y = np.exp(lat + 0.4 * rng.standard_normal(c["n"]))
+    elif c["lik"] == "negative_binomial":
+        mu = np.exp(0.8 * lat)
+        y = rng.negative_binomial(3.0, 3.0 / (3.0 + mu)).astype(np.float64)
     else:
         raise ValueError(c["lik"])
     return coords, y

@@ -824,7 +824,7 @@ def test_oracle_vif_non_gaussian_matches_the_reference(orc, name):
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
     tight_fitc = dict(cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
-    for pc in ("fitc", "vifdu") + (("none",) if name.endswith("logit") else ()):       # ("none" needs hundreds of CG iterations: one case)
+    for pc in ("fitc", "vifdu") + (("none",) if name.endswith("logit") else ()):       # ("none" needs hundreds of CG iterations: one case; missing keys: the reference aborts there)
         for j, cp in enumerate(c["cov_pars"]):
             key = "%s_%s_negll_%d" % (name, pc, j)
             if key not in g.files:

@@ -105,11 +105,12 @@ def test_gradient_matches_the_reference_and_the_oracle(gpb, orc, name):
     st.set_neighbors(nn)
     st.vif_set_inducing_points(ip)
     st.laplace_set_likelihood(c["lik"])
-    if c["lik"] == "gamma":
+    if c["lik"] in ("gamma", "t", "lognormal"):
         st.laplace_set_response_real(y[perm])
-        st.laplace_set_aux(c["aux"])
     else:
         st.laplace_set_labels(y[perm].astype(np.int32))
+    if c["aux"] is not None:
+        st.laplace_set_aux(c["aux"])
     st.laplace_set_preconditioner("fitc", rank)
     st.laplace_set_inducing_points(ip2)
     # two mode findings, the second from the first one's mode: the fixture's driver does the same (EvalNegLogLikelihood, then CalcCovFactorOrModeAndNegLL,
@@ -178,6 +179,8 @@ def test_vifdu_and_none_preconditioners_match_the_reference(gpb, name, pc):
     key = "%s_%s_negll_0" % (name, pc)
     if pc == "none" and not name.endswith("logit"):
         pytest.skip("'none' needs hundreds of CG iterations per solve: one case")
+    if key not in g.files:
+        pytest.skip("no reference value: the reference build aborts for this likelihood with 'vifdu' (an Eigen assertion in its own Woodbury solve)")
     mdl, coords, y, c = _model(gpb, name, cg_preconditioner_type=pc, **cases.LAPLACE_TIGHT)
     assert mdl.get_cg_preconditioner_type() == pc
     ref = float(g[key])
