@@ -2734,7 +2734,8 @@ int GPB_OptimLinRegrCoefCovPar(REModelHandle handle, const double* y_data, const
   if (num_covariates <= 0 || !covariate_data) return GPB_OptimCovPar(handle, y_data, fixed_effects);   // (forgets the covariates of an earlier fit)
   C_API_BEGIN();
   const char* scope = "is not on the MI355X path of this library (covariates: one-cluster Gaussian Vecchia model, optimizer_cov 'lbfgs' or 'gradient_descent', coefficients by 'wls')";
-  if (mdl->likelihood != "gaussian" && !mdl->eh && mdl->vhs.size() == 1 && !mdl->vif) {
+  if (mdl->likelihood != "gaussian" && !mdl->eh && mdl->vhs.size() == 1) {
+    // (full-scale Vecchia models too -- round 6: the boosting / coefficient gradient d(-mll)/dF is the same expression in the by-products of the VIF gradient, likelihoods.h:5598-5604)
     // non-Gaussian model with a linear predictor: the coefficients are part of the lbfgs vector (the reference's default for these models,
     // optim_utils.h:283-420), covariates scaled, the linear predictor enters the device as fixed effects, its gradient is X' grad_F
     const char* lscope = "is not on the MI355X path of this library (non-Gaussian models with covariates: optimizer_cov 'lbfgs' with the coefficients in its vector)";

@@ -1233,6 +1233,13 @@ def vif_laplace_grad_fixture(out_dir, only=None):
                                                piv_chol_rank=-999 if c["rank"] is None else c["rank"], gp_approx="full_scale_vecchia", num_ind_points=c["k"],
                                                **cases.VIF_LAPLACE_TIGHT)
         res[name + "_fitc_grad_0"] = g; res[name + "_fitc_negll_direct_0"] = np.float64(v)
+        if name.endswith("logit"):      # the boosting gradient d(-mll)/dF (REModel::CalcGradient) at fixed effects 0.3 cos(4 x_0), data order
+            fe = 0.3 * np.cos(4 * coords[:, 0])
+            res[name + "_gradF"] = refdrv.ref_laplace_grad_F(coords, y, c["cov_pars"][0], c["lik"], fixed_effects=fe, cov_function=c["cov_function"], shape=c["shape"], m=c["m"],
+                                                             ordering=c["ordering"], seed=c["seed"], threads=8, cg_preconditioner_type="fitc",
+                                                             piv_chol_rank=-999 if c["rank"] is None else c["rank"], gp_approx="full_scale_vecchia", num_ind_points=c["k"],
+                                                             **cases.VIF_LAPLACE_TIGHT)
+            res[name + "_gradF_fe"] = fe
         print("vif_laplace_grad", name, "negll = %.12f" % v, g, flush=True)
         np.savez_compressed(path, **res)
 
@@ -1278,8 +1285,13 @@ def vif_laplace_fit_fixture(out_dir, only=None):
         mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
                                   gp_approx="full_scale_vecchia", num_ind_points=c["k"])
         kw = dict(cfg); kw["init_cov_pars"] = np.asarray(cfg["init_cov_pars"], dtype=np.float64)
+        with_x = kw.pop("covariates", False)
         mdl.set_optim_config(cg_preconditioner_type="fitc", piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"], **cases.LAPLACE_TIGHT, **kw)
-        mdl.optim_cov_par(y)
+        if with_x:
+            mdl.optim_lin_regr_coef_cov_par(y, cases.vif_laplace_covariates(coords))
+            res[fit + "_coef"] = mdl.get_coef()
+        else:
+            mdl.optim_cov_par(y)
         res[fit + "_cov_pars"] = mdl.get_cov_par(2)
         res[fit + "_num_it"] = np.int32(mdl.get_num_it())
         res[fit + "_negll"] = np.float64(mdl.current_neg_log_likelihood())

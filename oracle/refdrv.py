@@ -327,11 +327,12 @@ def ref_laplace_nll_grad(coords, y, cov_pars, likelihood, fixed_effects=None, co
 
 
 def ref_laplace_grad_F(coords, y, cov_pars, likelihood, fixed_effects=None, cov_function="exponential", shape=0.5, m=30, ordering="random", seed=1,
-                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., weights=None, cg_preconditioner_type="vadu", piv_chol_rank=-999):
+                       threads=8, cg_delta_conv=-999., delta_conv_mode_finding=-999., weights=None, cg_preconditioner_type="vadu", piv_chol_rank=-999,
+                       gp_approx="vecchia", num_ind_points=500):
     """The reference's boosting gradient for non-Gaussian data, d(-approximate marginal log-likelihood) / dF in data order, at cov_pars =
     (sigma1^2, rho) and the fixed effects F (zero if None): REModel::CalcGradient on a model of the reference's own C API (ref_driver.cpp:
     refdrv_laplace_grad_F)."""
-    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights)
+    mdl = RefCAPIModel(coords, cov_function, shape, m, ordering, seed, threads=threads, likelihood=likelihood, weights=weights, gp_approx=gp_approx, num_ind_points=num_ind_points)
     mdl.set_optim_config(init_cov_pars=np.asarray(cov_pars, dtype=np.float64), cg_delta_conv=cg_delta_conv, delta_conv_mode_finding=delta_conv_mode_finding,
                          cg_preconditioner_type=cg_preconditioner_type, piv_chol_rank=piv_chol_rank)
     y = np.ascontiguousarray(y, dtype=np.float64)

@@ -711,7 +711,13 @@ VIF_LAPLACE_FITS = {
     "vifl_fit_logit_lbfgs": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="lbfgs", init_cov_pars=[1.0, 0.2], max_iter=30)),
     "vifl_fit_gamma_lbfgs_aux": ("vifl_u3d_n1500_mat25_m15_k40_gamma", dict(optimizer_cov="lbfgs", init_cov_pars=[0.6, 0.25], max_iter=30, estimate_aux_pars=True)),
     "vifl_fit_logit_nelder_mead": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="nelder_mead", init_cov_pars=[1.0, 0.2], max_iter=25)),
+    # with a linear predictor X beta, X = (1, cos(4 x_0)): the coefficients ride in the lbfgs vector (GPB_OptimLinRegrCoefCovPar)
+    "vifl_fit_logit_lbfgs_covariates": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="lbfgs", init_cov_pars=[1.0, 0.2], max_iter=30, covariates=True)),
 }
+
+
+def vif_laplace_covariates(coords):
+    return np.c_[np.ones(coords.shape[0]), np.cos(4 * coords[:, 0])]
 
 
 def vif_laplace_data(name):
