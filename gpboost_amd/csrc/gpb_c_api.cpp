@@ -862,7 +862,7 @@ const char* kDuplicatesNonGaussianMessage =
 bool can_calc_std_dev(const REModelHip* mdl) {
   if (mdl->likelihood == "gaussian" && mdl->eh) return mdl->n <= 24000;      // exact GP: the dense Fisher information (gpb_hip_exact_fisher_std_errors)
   if (mdl->likelihood != "gaussian")      // non-Gaussian: numerical Jacobian of the gradient of the Laplace approximation (its derivative kernel's limits)
-    return !mdl->eh && mdl->vhs.size() == 1 && !mdl->vif && std::min(mdl->m, (mdl->n_re > 0 ? mdl->n_re : mdl->n) - 1) <= 126 && mdl->d <= 3;
+    return !mdl->eh && mdl->vhs.size() == 1 && (!mdl->vif || mdl->cg_preconditioner_type == "fitc") && std::min(mdl->m, (mdl->n_re > 0 ? mdl->n_re : mdl->n) - 1) <= 126 && mdl->d <= 3;      // (full-scale Vecchia: its gradient is built for "fitc")
   if (mdl->eh || mdl->vhs.size() != 1 || mdl->vif || mdl->has_weights) return false;
   int world = 0;
   if (gpb_hip_vecchia_comm_info(mdl->vhs[0], nullptr, &world) || world > 1) return false;

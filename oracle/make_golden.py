@@ -1295,6 +1295,8 @@ def vif_laplace_fit_fixture(out_dir, only=None):
         res[fit + "_cov_pars"] = mdl.get_cov_par(2)
         res[fit + "_num_it"] = np.int32(mdl.get_num_it())
         res[fit + "_negll"] = np.float64(mdl.current_neg_log_likelihood())
+        if fit == "vifl_fit_logit_lbfgs":      # standard deviations of the covariance parameters (CalcStdDevCovParAuxParsNonGaussian: numerical Jacobian of the gradient)
+            res[fit + "_cov_pars_sd"] = mdl.get_cov_par(2, std_dev=True)[2:]
         if c["aux"] is not None:
             res[fit + "_aux"] = mdl.get_aux_pars(1)
         print("vif_laplace_fit", fit, res[fit + "_cov_pars"], res[fit + "_num_it"], res[fit + "_negll"], res.get(fit + "_aux"), flush=True)

@@ -170,6 +170,9 @@ def test_fits_follow_the_reference(gpb, fit):
     assert abs(mdl.get_current_neg_log_likelihood() - float(g[fit + "_negll"])) <= 1e-7 * abs(float(g[fit + "_negll"]))
     if fit + "_aux" in g.files:
         np.testing.assert_allclose(mdl.get_aux_pars(), g[fit + "_aux"], rtol=1e-5)
+    if fit + "_cov_pars_sd" in g.files:      # standard deviations: the numerical Jacobian of the device gradient (CalcStdDevCovParAuxParsNonGaussian, re_model_template.h:11029-11117)
+        sd = np.asarray(mdl.get_cov_pars(std_err=True))[2:]
+        np.testing.assert_allclose(sd, g[fit + "_cov_pars_sd"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", sorted(cases.VIF_LAPLACE_CASES))
