@@ -2314,8 +2314,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (!pt.empty() && pt != "order_obs_first_cond_obs_only" && pt != "latent_order_obs_first_cond_obs_only" && !lat_cond_all)
       return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", pt.c_str(), lscope);
     // full-scale Vecchia (round 6; PredictLaplaceApproxFSVA, likelihoods.h:7999-8535): means and variances, 'latent_order_obs_first_cond_obs_only'
-    if (mdl->vif && (lat_cond_all || predict_cov_mat || mdl->p_cov > 0))
-      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means and variances with 'latent_order_obs_first_cond_obs_only' are on the MI355X path of this library; 'latent_order_obs_first_cond_all', covariance matrices and covariates are not", mdl->likelihood.c_str());
+    if (mdl->vif && (lat_cond_all || mdl->p_cov > 0))
+      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means, variances and covariance matrices with 'latent_order_obs_first_cond_obs_only' are on the MI355X path of this library; 'latent_order_obs_first_cond_all' and covariates are not", mdl->likelihood.c_str());
     const double* cpl = gp_coords_data_pred;
     int npl = num_data_pred;
     if (use_saved_data) { cpl = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npl = mdl->num_data_pred; }
@@ -2418,7 +2418,7 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
       }
     } else if (mdl->vif) {
       if (gpb_hip_vecchia_vif_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
-                                              need_var ? var_u.data() : nullptr, nullptr, &cg_it)) return shim_error();
+                                              need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it)) return shim_error();
     } else if (gpb_hip_vecchia_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
                                         need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it))
       return shim_error();

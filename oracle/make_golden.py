@@ -1269,6 +1269,8 @@ def vif_laplace_pred_fixture(out_dir, only=None):
         res[name + "_pred_coords"] = cpred
         res[name + "_pred_latent_mu"] = mu; res[name + "_pred_latent_var"] = var
         res[name + "_pred_resp_mu"] = rmu; res[name + "_pred_resp_var"] = rvar
+        if name.endswith("logit"):      # the latent predictive covariance matrix (likelihoods.h:8489-8504)
+            res[name + "_pred_latent_cov"] = mdl.predict(cpred, predict_cov_mat=True, predict_response=False, y=y, cov_pars=cp)[1]
         print("vif_laplace_pred", name, mu[:3], var[:3], rmu[:3], flush=True)
         np.savez_compressed(path, **res)
 

@@ -657,7 +657,7 @@ EXPORT int gpb_hip_vecchia_laplace_grad_F_current(gpb_hip_vecchia_t* h, double* 
   return 0;
 }
 // (full-scale Vecchia with a non-Gaussian likelihood is a device path only: tests/test_zz_vif_laplace_gpu.py; the oracle-backed shim says so)
-EXPORT int gpb_hip_vecchia_vif_laplace_predict(gpb_hip_vecchia_t*, int32_t, const double*, int32_t, int, double, double, int, double, double*, double*, int*, int*) {
+EXPORT int gpb_hip_vecchia_vif_laplace_predict(gpb_hip_vecchia_t*, int32_t, const double*, int32_t, int, double, double, int, double, double*, double*, double*, int*, int*) {
   return fail("mock: full-scale Vecchia with a non-Gaussian likelihood is not restated in the oracle-backed shim (device tests cover it)");
 }
 EXPORT int gpb_hip_vecchia_laplace_predict(gpb_hip_vecchia_t* h, int32_t n_pred, const double* cp, int32_t mp, int cov, double var, double a, int, double,

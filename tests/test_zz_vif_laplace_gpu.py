@@ -191,8 +191,11 @@ def test_predictions_match_the_references_exact_branch(gpb, name):
     p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_var=True, predict_response=True)
     np.testing.assert_allclose(p["mu"], g[name + "_pred_resp_mu"], rtol=max(tol, 1e-7))
     np.testing.assert_allclose(p["var"], g[name + "_pred_resp_var"], rtol=max(tol, 1e-7))
-    with pytest.raises(gpb.GPBoostError, match="covariance matrices and covariates are not"):
-        mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_cov_mat=True, predict_response=False)
+    if name + "_pred_latent_cov" in g.files:
+        p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_cov_mat=True, predict_response=False)
+        ref_c = g[name + "_pred_latent_cov"]
+        np.testing.assert_allclose(p["cov"], ref_c, rtol=0, atol=tol * np.abs(ref_c).max())
+        np.testing.assert_allclose(np.diag(p["cov"]), g[name + "_pred_latent_var"], rtol=tol)
 
 
 @pytest.mark.parametrize("pc", ["vifdu", "none"])
