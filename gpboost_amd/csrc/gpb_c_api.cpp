@@ -2314,8 +2314,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     if (!pt.empty() && pt != "order_obs_first_cond_obs_only" && pt != "latent_order_obs_first_cond_obs_only" && !lat_cond_all)
       return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", pt.c_str(), lscope);
     // full-scale Vecchia (round 6; PredictLaplaceApproxFSVA, likelihoods.h:7999-8535): means and variances, 'latent_order_obs_first_cond_obs_only'
-    if (mdl->vif && (lat_cond_all || mdl->p_cov > 0))
-      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means, variances and covariance matrices with 'latent_order_obs_first_cond_obs_only' are on the MI355X path of this library; 'latent_order_obs_first_cond_all' and covariates are not", mdl->likelihood.c_str());
+    if (mdl->vif && mdl->p_cov > 0)
+      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means, variances and covariance matrices (both latent prediction types) are on the MI355X path of this library; covariates in predictions are not", mdl->likelihood.c_str());
     const double* cpl = gp_coords_data_pred;
     int npl = num_data_pred;
     if (use_saved_data) { cpl = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npl = mdl->num_data_pred; }
@@ -2357,7 +2357,11 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     for (int j = 0; j < dl; ++j) for (int u = 0; u < nu; ++u) cu[(size_t)j * nu + u] = cpv[(size_t)j * npl + uq[u]];
     std::vector<double> mu_u(nu), var_u(need_var ? nu : 0), cov_u(predict_cov_mat ? (size_t)nu * nu : 0);
     int cg_it = 0;
-    if (lat_cond_all) {
+    if (mdl->vif) {      // both latent types in one call: a negative neighbour count = 'latent_order_obs_first_cond_all'
+      const int nnv = std::min(nnpl, 126);
+      if (gpb_hip_vecchia_vif_laplace_predict(mdl->vh, nu, cu.data(), lat_cond_all ? -nnv : nnv, mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
+                                              need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it)) return shim_error();
+    } else if (lat_cond_all) {
       // 'latent_order_obs_first_cond_all' (PredictLaplaceApproxVecchia with CondObsOnly = false, likelihoods.h:8603-8606, 8790-8821): the prediction points
       // condition on the observed AND the preceding prediction points.  Device: factor rows of the appended points (latent: no nugget); host: the
       // rows of Bp^-1 (forward substitution, as GPB_HIP_PredictCondAllHost) and of C = Bp^-1 Bpo; device: the quadratic forms C (Sigma^-1 + W)^-1 C'.
@@ -2416,9 +2420,6 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
             if (r == c2 && need_var) var_u[r] = pr + (predict_cov_mat ? q[(size_t)r * nu + r] : q[r]);
           }
       }
-    } else if (mdl->vif) {
-      if (gpb_hip_vecchia_vif_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
-                                              need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it)) return shim_error();
     } else if (gpb_hip_vecchia_laplace_predict(mdl->vh, nu, cu.data(), std::min(nnpl, 126), mdl->cov_type, s12, a_tr, mdl->cg_max_num_it, kPredVarCgTol, mu_u.data(),
                                         need_var ? var_u.data() : nullptr, predict_cov_mat ? cov_u.data() : nullptr, nullptr, &cg_it))
       return shim_error();

@@ -311,7 +311,8 @@ GPB_HIP_EXPORT int gpb_hip_vecchia_predict_cond_all_latent(gpb_hip_vecchia_t* h,
  * branch (:8455-8527) with every (B'D^-1B + W)^-1 product by block CG to the residual bound `tol`; the reference's iterative branch estimates it by simulation. */
 GPB_HIP_EXPORT int gpb_hip_vecchia_vif_laplace_predict(gpb_hip_vecchia_t* h, int32_t n_pred, const double* coords_pred_colmajor, int32_t num_neighbors_pred, int cov_type, double var,
                                                        double a, int cg_max_num_it, double tol, double* pred_mean, double* pred_var, double* pred_cov, int* has_duplicates,
-                                                       int* cg_iterations);      /* pred_var (n_pred) / pred_cov (n_pred x n_pred, :8489-8504) may be NULL */
+                                                       int* cg_iterations);      /* pred_var (n_pred) / pred_cov (n_pred x n_pred, :8489-8504) may be NULL; a NEGATIVE num_neighbors_pred asks for
+                                                                                  'latent_order_obs_first_cond_all' with |num_neighbors_pred| neighbours (the prediction points condition on the preceding ones too) */
 GPB_HIP_EXPORT int gpb_hip_vecchia_laplace_quad_forms(gpb_hip_vecchia_t* h, int32_t n_rows, int32_t mmax, const int32_t* cols_host, const double* vals_host,
                                                       int cg_max_num_it, double tol, int want_cov, double* out_host, int* cg_iterations);
 /* diag((Sigma^-1 + W)^-1) at the mode (Vecchia order of the random effects): variances of the latent process at the TRAINING locations,

@@ -1271,6 +1271,12 @@ def vif_laplace_pred_fixture(out_dir, only=None):
         res[name + "_pred_resp_mu"] = rmu; res[name + "_pred_resp_var"] = rvar
         if name.endswith("logit"):      # the latent predictive covariance matrix (likelihoods.h:8489-8504)
             res[name + "_pred_latent_cov"] = mdl.predict(cpred, predict_cov_mat=True, predict_response=False, y=y, cov_pars=cp)[1]
+        if name.endswith("logit") or name.endswith("gamma"):      # 'latent_order_obs_first_cond_all': the prediction points condition on the preceding prediction points too
+            mu2, var2 = mdl.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp, vecchia_pred_type="latent_order_obs_first_cond_all")
+            res[name + "_pred_condall_latent_mu"] = mu2; res[name + "_pred_condall_latent_var"] = var2
+            if name.endswith("logit"):
+                res[name + "_pred_condall_latent_cov"] = mdl.predict(cpred, predict_cov_mat=True, predict_response=False, y=y, cov_pars=cp,
+                                                                     vecchia_pred_type="latent_order_obs_first_cond_all")[1]
         print("vif_laplace_pred", name, mu[:3], var[:3], rmu[:3], flush=True)
         np.savez_compressed(path, **res)
 

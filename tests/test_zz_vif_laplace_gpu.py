@@ -196,6 +196,15 @@ def test_predictions_match_the_references_exact_branch(gpb, name):
         ref_c = g[name + "_pred_latent_cov"]
         np.testing.assert_allclose(p["cov"], ref_c, rtol=0, atol=tol * np.abs(ref_c).max())
         np.testing.assert_allclose(np.diag(p["cov"]), g[name + "_pred_latent_var"], rtol=tol)
+    if name + "_pred_condall_latent_mu" in g.files:      # 'latent_order_obs_first_cond_all' (B_p^-1 B_po in place of B_po, the prior part B_p^-1 D_p B_p^-T)
+        mdl.set_prediction_data(vecchia_pred_type="latent_order_obs_first_cond_all")
+        p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_var=True, predict_response=False)
+        np.testing.assert_allclose(p["mu"], g[name + "_pred_condall_latent_mu"], rtol=0, atol=tol * np.abs(g[name + "_pred_condall_latent_mu"]).max())
+        np.testing.assert_allclose(p["var"], g[name + "_pred_condall_latent_var"], rtol=tol)
+        if name + "_pred_condall_latent_cov" in g.files:
+            p = mdl.predict(y=y, gp_coords_pred=cpred, cov_pars=cp, predict_cov_mat=True, predict_response=False)
+            ref_c = g[name + "_pred_condall_latent_cov"]
+            np.testing.assert_allclose(p["cov"], ref_c, rtol=0, atol=tol * np.abs(ref_c).max())
 
 
 @pytest.mark.parametrize("pc", ["vifdu", "none"])
