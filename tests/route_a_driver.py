@@ -229,6 +229,11 @@ elif sc == "round6_vif_non_gaussian":
     m = gpb.GPModel(likelihood="bernoulli_logit", **kw)
     m.fit(y=yb, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([1.0, 0.2])))
     out["vl_cov_pars"] = L(m.get_cov_pars()); out["num_it"] = int(m._get_num_optim_iter()); out["vl_nll"] = float(m.get_current_neg_log_likelihood())
+    cpr = rng.uniform(size=(12, 2))
+    p = m.predict(gp_coords_pred=cpr, predict_var=True, predict_response=False)      # (the reference's iterative branch SIMULATES the variances; this library evaluates the exact expression)
+    out["vl_latent_mu"] = L(p["mu"]); out["stoch_vl_latent_var"] = L(p["var"])
+    p = m.predict(gp_coords_pred=cpr, predict_var=False, predict_response=True)
+    out["stochm_vl_resp_mu"] = L(p["mu"])
     ygam = rng.gamma(2.0, np.exp(0.5 * lat) / 2.0)
     m = gpb.GPModel(likelihood="gamma", **kw)
     m.fit(y=ygam, params=dict(tight, fitc_piv_chol_preconditioner_rank=60, init_cov_pars=np.array([0.6, 0.25]), maxit=12))
