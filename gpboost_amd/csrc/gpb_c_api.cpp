@@ -1328,7 +1328,6 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
     const std::string sel = ind_points_selection ? ind_points_selection : "";
     if (sel != "" && sel != "kmeans++") return set_error("GPB_CreateREModel: ind_points_selection '%s' with gp_approx '%s' %s", sel.c_str(), approx.c_str(), scope);
     // (round 6: non-Gaussian likelihoods with gp_approx 'full_scale_vecchia' -- FindModePostRandEffCalcMLLFSVA, likelihoods.h:3379-3750 -- iterative methods with the 'fitc' preconditioner)
-    if (lik != "gaussian" && has_weights) return set_error("GPB_CreateREModel: sample weights with likelihood '%s' and gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
     if (dim_gp_coords > 3) return set_error("GPB_CreateREModel: %d coordinate dimensions with gp_approx '%s' %s", dim_gp_coords, approx.c_str(), scope);
     if (num_ind_points <= 0) num_ind_points = 200;                                 // re_model_template.h:319-330
     if (num_ind_points > 256) return set_error("GPB_CreateREModel: num_ind_points = %d (at most 256 on this path) %s", num_ind_points, scope);
@@ -1352,7 +1351,7 @@ int GPB_CreateREModel(int32_t num_data, const int32_t* cluster_ids_data, const c
   }
   if (ordering != "none" && ordering != "random") return set_error("GPB_CreateREModel: vecchia_ordering '%s' %s", ordering.c_str(), scope);
   if (has_weights) {       // re_model_template.h:403-431
-    if (approx != "vecchia") return set_error("GPB_CreateREModel: sample weights with likelihood '%s' / gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);
+    if (approx != "vecchia" && !(vif && lik_name != "gaussian")) return set_error("GPB_CreateREModel: sample weights with likelihood '%s' / gp_approx '%s' %s", lik.c_str(), approx.c_str(), scope);      // (round 6: + full-scale Vecchia with a non-Gaussian likelihood)
     double sum_w = 0.;
     for (int i = 0; i < num_data; ++i) {
       if (weights[i] < 0.) return set_error(" Found negative values in 'weights' ");

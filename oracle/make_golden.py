@@ -1208,7 +1208,7 @@ def vif_laplace_fixture(out_dir, only=None):
                 if pc != "fitc" and ("%s_%s_negll_%d" % (name, pc, j)) in res and os.environ.get("VIFL_REDO_ALL") is None:
                     continue                                                       # ("none" takes minutes: kept unless VIFL_REDO_ALL is set)
                 mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
-                                          gp_approx="full_scale_vecchia", num_ind_points=c["k"])
+                                          gp_approx="full_scale_vecchia", num_ind_points=c["k"], weights=cases.vif_laplace_weights(name))
                 mdl.set_optim_config(cg_preconditioner_type=pc, piv_chol_rank=-999 if c["rank"] is None else c["rank"], init_aux_pars=c["aux"],
                                      **(cases.VIF_LAPLACE_TIGHT if pc == "fitc" else cases.LAPLACE_TIGHT))
                 t0 = time.time()
@@ -1229,7 +1229,7 @@ def vif_laplace_grad_fixture(out_dir, only=None):
             continue
         coords, y = cases.vif_laplace_data(name)
         v, g, vp = refdrv.ref_laplace_nll_grad(coords, y, c["cov_pars"][0], c["lik"], cov_function=c["cov_function"], shape=c["shape"], m=c["m"], ordering=c["ordering"],
-                                               seed=c["seed"], threads=8, aux_pars=c["aux"], estimate_aux=c["aux"] is not None, cg_preconditioner_type="fitc",
+                                               seed=c["seed"], threads=8, aux_pars=c["aux"], estimate_aux=c["aux"] is not None, cg_preconditioner_type="fitc", weights=cases.vif_laplace_weights(name),
                                                piv_chol_rank=-999 if c["rank"] is None else c["rank"], gp_approx="full_scale_vecchia", num_ind_points=c["k"],
                                                **cases.VIF_LAPLACE_TIGHT)
         res[name + "_fitc_grad_0"] = g; res[name + "_fitc_negll_direct_0"] = np.float64(v)
@@ -1261,7 +1261,7 @@ def vif_laplace_pred_fixture(out_dir, only=None):
         coords, y = cases.vif_laplace_data(name)
         cpred = vif_laplace_pred_points(c)
         mdl = refdrv.RefCAPIModel(coords, c["cov_function"], c["shape"], c["m"], c["ordering"], c["seed"], threads=8, likelihood=c["lik"],
-                                  gp_approx="full_scale_vecchia", num_ind_points=c["k"], matrix_inversion_method="cholesky")
+                                  gp_approx="full_scale_vecchia", num_ind_points=c["k"], matrix_inversion_method="cholesky", weights=cases.vif_laplace_weights(name))
         mdl.set_optim_config(init_aux_pars=c["aux"], cg_preconditioner_type="", **cases.LAPLACE_PRED_REF)
         cp = np.asarray(c["cov_pars"][0], dtype=np.float64)
         mu, var = mdl.predict(cpred, predict_var=True, predict_response=False, y=y, cov_pars=cp)

@@ -700,6 +700,9 @@ VIF_LAPLACE_CASES = {
                                                    cov_pars=[(0.7, 0.2)]),
     "vifl_u2d_n1200_exp_m15_k40_negbin": dict(n=1200, d=2, cov_function="exponential", shape=0.5, m=15, k=40, ordering="random", seed=5, lik="negative_binomial", aux=2.0, rank=50,
                                               cov_pars=[(0.7, 0.2)]),
+    # sample weights (Likelihood::weights_: every per-datum term of the likelihood and of its derivatives x w_d): cases.vif_laplace_weights
+    "vifl_u2d_n1200_exp_m15_k40_poisson_weighted": dict(n=1200, d=2, cov_function="exponential", shape=0.5, m=15, k=40, ordering="random", seed=6, lik="poisson", aux=None, rank=50,
+                                                        cov_pars=[(0.7, 0.2)], weights=True),
     "vifl_u3d_n1500_mat25_m15_k40_gamma": dict(n=1500, d=3, cov_function="matern", shape=2.5, m=15, k=40, ordering="none", seed=1, lik="gamma", aux=2.0, rank=64,
                                                cov_pars=[(0.5, 0.3)]),
 }
@@ -714,6 +717,14 @@ VIF_LAPLACE_FITS = {
     # with a linear predictor X beta, X = (1, cos(4 x_0)): the coefficients ride in the lbfgs vector (GPB_OptimLinRegrCoefCovPar)
     "vifl_fit_logit_lbfgs_covariates": ("vifl_u2d_n1500_exp_m15_k40_logit", dict(optimizer_cov="lbfgs", init_cov_pars=[1.0, 0.2], max_iter=30, covariates=True)),
 }
+
+
+def vif_laplace_weights(name):
+    """Sample weights of a VIF_LAPLACE_CASES entry with weights = True (data order), None otherwise."""
+    c = VIF_LAPLACE_CASES[name]
+    if not c.get("weights"):
+        return None
+    return np.random.default_rng(4242 + c["n"]).uniform(0.5, 2.0, size=c["n"])
 
 
 def vif_laplace_covariates(coords):

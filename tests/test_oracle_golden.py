@@ -824,6 +824,9 @@ def test_oracle_vif_non_gaussian_matches_the_reference(orc, name):
     ct = orc.cov_type_id(c["cov_function"], c["shape"])
     tight = dict(cg_delta_conv=cases.LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.LAPLACE_TIGHT["delta_conv_mode_finding"])
     tight_fitc = dict(cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
+    wts = cases.vif_laplace_weights(name)
+    wctx = orc.sample_weights(None if wts is None else wts[perm])
+    wctx.__enter__()
     for pc in ("fitc", "vifdu") + (("none",) if name.endswith("logit") else ()):       # ("none" needs hundreds of CG iterations: one case; missing keys: the reference aborts there)
         for j, cp in enumerate(c["cov_pars"]):
             key = "%s_%s_negll_%d" % (name, pc, j)
@@ -842,5 +845,6 @@ def test_oracle_vif_non_gaussian_matches_the_reference(orc, name):
     v, gr = orc.vif_laplace_grad(co, nn, ip, ip2, ct, cp[0], RC_VIFL[ct] / cp[1], y[perm], likelihood=c["lik"], aux=c["aux"], mode_init=p0["mode"], **tight_fitc)
     ref = g[name + "_fitc_grad_0"]
     assert abs(v - float(g[name + "_fitc_negll_direct_0"])) <= 1e-9 * abs(v)
+    wctx.__exit__()
     assert gr.shape == ref.shape
     np.testing.assert_allclose(gr, ref, rtol=0, atol=c.get("grad_rtol", 1e-8) * np.abs(ref).max())

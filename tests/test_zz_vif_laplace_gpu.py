@@ -27,7 +27,7 @@ def _model(gpb, name, **optim):
     c = cases.VIF_LAPLACE_CASES[name]
     coords, y = cases.vif_laplace_data(name)
     mdl = gpb.GPModel(gp_coords=coords, cov_function=c["cov_function"], cov_fct_shape=c["shape"], likelihood=c["lik"], gp_approx="full_scale_vecchia",
-                      num_neighbors=c["m"], num_ind_points=c["k"], vecchia_ordering=c["ordering"], seed=c["seed"])
+                      num_neighbors=c["m"], num_ind_points=c["k"], vecchia_ordering=c["ordering"], seed=c["seed"], weights=cases.vif_laplace_weights(name))
     p = dict(cases.VIF_LAPLACE_TIGHT)
     if c["rank"] is not None:
         p["fitc_piv_chol_preconditioner_rank"] = c["rank"]
@@ -111,6 +111,9 @@ def test_gradient_matches_the_reference_and_the_oracle(gpb, orc, name):
         st.laplace_set_labels(y[perm].astype(np.int32))
     if c["aux"] is not None:
         st.laplace_set_aux(c["aux"])
+    wts = cases.vif_laplace_weights(name)
+    if wts is not None:
+        st.laplace_set_weights(wts[perm])
     st.laplace_set_preconditioner("fitc", rank)
     st.laplace_set_inducing_points(ip2)
     # two mode findings, the second from the first one's mode: the fixture's driver does the same (EvalNegLogLikelihood, then CalcCovFactorOrModeAndNegLL,
@@ -121,8 +124,9 @@ def test_gradient_matches_the_reference_and_the_oracle(gpb, orc, name):
     ref_v = float(g[name + "_fitc_negll_direct_0"])
     assert abs(nll - ref_v) <= 1e-8 * abs(ref_v), (nll, ref_v)
     okw = dict(likelihood=c["lik"], aux=c["aux"], want_parts=True, cg_delta_conv=cases.VIF_LAPLACE_TIGHT["cg_delta_conv"], delta_conv_mode=cases.VIF_LAPLACE_TIGHT["delta_conv_mode_finding"])
-    o0 = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], **okw)
-    on, og, op = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], mode_init=o0[2]["mode"], **okw)
+    with orc.sample_weights(None if wts is None else wts[perm]):
+        o0 = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], **okw)
+        on, og, op = orc.vif_laplace_grad(co, nn, ip, ip2, ct, var, a, y[perm], mode_init=o0[2]["mode"], **okw)
     np.testing.assert_allclose(parts["dlogdet_dmode"], op["dlogdet_dmode"], rtol=0, atol=1e-6 * np.abs(op["dlogdet_dmode"]).max())
     np.testing.assert_allclose(parts["implicit_solve"], op["implicit_solve"], rtol=0, atol=1e-6 * np.abs(op["implicit_solve"]).max())
     np.testing.assert_allclose(parts["per_par"], op["per_par"], rtol=1e-6, atol=1e-7 * np.abs(op["per_par"]).max())
