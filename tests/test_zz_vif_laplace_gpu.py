@@ -3,7 +3,10 @@ Likelihood::FindModePostRandEffCalcMLLFSVA (include/GPBoost/likelihoods.h:3379-3
 CGTridiagVIFLaplace_Version_SigmaPlusWinv (src/GPBoost/CG_utils.cpp:744-976), CalcLogDetStochFSVA (likelihoods.h:16203-16259): the latent covariance is
 Sigma = C Sigma_m^-1 C' + B^-1 D B^-T with (B, D) the Vecchia factor of the residual process; iterative methods with the "fitc" preconditioner (the reference's
 default for these models, its own kmeans++ inducing points).  Through the C ABI against the UNMODIFIED reference (tests/golden/vif_laplace_ref.npz,
-oracle/make_golden.py vif_laplace, vif_laplace_grad) at cases.VIF_LAPLACE_TIGHT: values and gradients 1e-8."""
+oracle/make_golden.py vif_laplace, vif_laplace_grad, vif_laplace_fit, vif_laplace_pred) at cases.VIF_LAPLACE_TIGHT: values and gradients 1e-8 for seven cases (logit, Poisson, weighted
+Poisson, gamma, negative_binomial, Student-t, lognormal; every auxiliary parameter), d(-mll)/dF, lbfgs / Nelder-Mead fits with the reference's iteration counts (also with the shape of
+gamma estimated, with covariates, with standard deviations), the "vifdu" and "none" preconditioners (values), predictions of both latent types (mean, variance, covariance matrix,
+response scale) against the reference's exact Cholesky branch."""
 import os
 
 import numpy as np
