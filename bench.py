@@ -124,6 +124,39 @@ def laplace_kernel_rooflines(n4=100000, m4=30):
     return out or None
 
 
+def vif_kernel_rooflines(n=100000, m=30, k=200):
+    """Per-kernel figures of the full-scale Vecchia x non-Gaussian evaluation / gradient (round 6) from KERNEL durations: the committed rocprofv3 --kernel-trace run of
+    scripts/gpu_vif_non_gaussian.py at config 4's size (profiles/r06_zz_trace_vif_non_gaussian_config4_size_rocprofv3_summary.txt) against the algorithmic bytes of one launch."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r06_zz_trace_vif_non_gaussian_config4_size_rocprofv3_summary.txt")
+    if not os.path.exists(path):
+        return None
+    vec = n * 8; mat = n * k * 8; fac = n * m * 16; kq = (k + 1 + 7) // 8 * 8
+    kernels = (
+        ("pc_ltwx_kernel<1>", "L' (w o x): the n x k matrix once (low-rank part of Sigma x, the fitc preconditioner, the Woodbury quadratic forms)", mat + 2 * vec),
+        ("pc_combine_kernel<1>", "x - L x2: the n x k matrix once", mat + 3 * vec),
+        ("pc_ltwx_kernel<4>", "the same on the 50-probe block: the n x k matrix once per chunk of 4 columns", 13 * (mat + 5 * vec)),
+        ("pc_combine_kernel<4>", "X - L x2 on the 50-probe block", 13 * (mat + 9 * vec)),
+        ("lap_sptrsv_sf_kernel<false, true", "single-vector triangular solve with B^T of the residual factor (barrier-free; latency-bound dependency chain)", fac + 3 * vec),
+        ("lap_sptrsv_sf_kernel<true, false", "single-vector triangular solve with B", fac + 3 * vec),
+        ("vif_resid_factor_kernel", "residual-process factor: per point the whitened cross-covariances of its m + 1 points (gathered rows of V) + coordinates", n * (m + 1) * (kq * 8 + 32) + n * m * 12),
+        ("pc_gram_kernel", "L' diag(w) L, k x k (gradient / vifdu; compute: n k (k + 1) flops)", mat + vec),
+        ("pc_row_quad_tiled_kernel<true>", "row-wise quadratic forms with two k x k matrices (derivative of the preconditioner's diagonal; compute: 4 n k^2 flops)", 2 * mat + vec),
+    )
+    with open(path) as fh:
+        txt = fh.read().split("\n")
+    rows = []
+    for sub, label, b in kernels:
+        for line in txt:
+            if sub in line and "mean_us=" in line:
+                us = float(re.search(r"mean_us=\s*([0-9.]+)", line).group(1)); calls = int(re.search(r"calls=\s*([0-9]+)", line).group(1))
+                rows.append({"kernel": sub, "what": label, "calls_in_the_traced_run": calls, "mean_kernel_us": us, "algorithmic_bytes_per_launch": b,
+                             "achieved": b / (us * 1e-6) / 1e9, "unit": "GB/s", "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                break
+    return {"source": "%s (rocprofv3 --kernel-trace --stats: three evaluations + a five-iteration lbfgs fit; kernel durations, not host timers)" % os.path.relpath(path, ROOT),
+            "kernels": rows} if rows else None
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz (vector == matrix fp64 rate on gfx950)
 
@@ -747,7 +780,8 @@ def main():
                     "workload": "Bernoulli-logit nll, gp_approx=full_scale_vecchia, n=%d, d=2, exponential, m=30, 200 inducing points, fitc preconditioner (200 inducing points), 50 probes" % nq,
                     "s_per_eval": sq, "negll": vq, "newton_it": iq["newton_it"], "cg_it": iq["cg_it"], "lanczos_it": iq["lanczos_it"], "ms_factor": iq.get("ms_factor"),
                     "ms_mode_finding": iq["ms_mode"], "ms_logdet": iq["ms_logdet"], "setup_s": round(tq_setup, 3),
-                    "s_two_lbfgs_iterations_with_gradients": sfit, "num_it": mq.get_num_optim_iter(), "cov_pars_after_two_iterations": [float(x) for x in mq.get_cov_pars()]}
+                    "s_two_lbfgs_iterations_with_gradients": sfit, "num_it": mq.get_num_optim_iter(), "cov_pars_after_two_iterations": [float(x) for x in mq.get_cov_pars()],
+                    "roofline_kernels_from_trace": vif_kernel_rooflines(nq, 30, 200)}
                 del mq
             except Exception as e:
                 out["vif_non_gaussian"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -108,6 +108,44 @@ __global__ void pc_gram_kernel(const double* __restrict__ L, const double* __res
   for (int i = lo; i < hi; ++i) { const double* Li = L + (size_t)i * k; acc = __builtin_fma(Li[p] * W[i], Li[q], acc); }
   part[(size_t)blockIdx.x * npairs + e] = acc;
 }
+// the same with 4 x 4 register tiles of (p, q): thread t of a slice owns the tile (tp, tq), tq <= tp, of the lower triangle -- 8 row values and the weight loaded for 16 fmas
+// (the one-pair-per-thread form above: 3 loads per fma, 1.85 ms at n = 1e5, k = 200; profiles/r06_zz_trace_vif_non_gaussian_*)
+__global__ __launch_bounds__(256) void pc_gram_tiled_kernel(const double* __restrict__ L, const double* __restrict__ W, int n, int k, int npairs, int ntile, double* __restrict__ part) {
+  const int tl = blockIdx.y * blockDim.x + threadIdx.x;
+  const int nt = (k + 3) / 4, ntiles = nt * (nt + 1) / 2;
+  (void)ntile;
+  if (tl >= ntiles) return;
+  int tp = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
+  while ((tp + 1) * (tp + 2) / 2 <= tl) ++tp;
+  while (tp * (tp + 1) / 2 > tl) --tp;
+  const int tq = tl - tp * (tp + 1) / 2;
+  int lo, hi;
+  pc_slice(n, (int)gridDim.x, (int)blockIdx.x, lo, hi);
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  const int p0 = 4 * tp, q0 = 4 * tq;
+  for (int i = lo; i < hi; ++i) {
+    const double* Li = L + (size_t)i * k;
+    const double w = W[i];
+    double lp[4], lq[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { lp[a] = p0 + a < k ? Li[p0 + a] * w : 0.0; lq[a] = q0 + a < k ? Li[q0 + a] : 0.0; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(lp[a], lq[b], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pp = p0 + a, qq = q0 + b;
+      if (pp < k && qq <= pp) part[(size_t)blockIdx.x * npairs + (size_t)pp * (pp + 1) / 2 + qq] = acc[a][b];
+    }
+}
 __global__ void pc_gram_reduce_kernel(const double* __restrict__ part, int parts, int npairs, double* __restrict__ G) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npairs) return;
@@ -116,20 +154,22 @@ __global__ void pc_gram_reduce_kernel(const double* __restrict__ part, int parts
   G[e] = s;
 }
 
-// part[chunk][slice][q][c] = sum over the rows of the slice of L[i][q] W[i] X[i][c]; 512 threads = 8 row groups x 64 columns of L, every thread with UNR independent
+// part[chunk][slice][q][c] = sum over the rows of the slice of L[i][q] W[i] X[i][c]; 512 threads = 8 row groups x 64 columns of L, every thread with UNR (8 / 2) independent
 // accumulation chains (round 6: with 4 groups and one chain the kernel ran at 1 TB/s of the n x k matrix -- one workgroup per CU, one load in flight per thread;
 // profiles/r06_z_trace_vif_non_gaussian_config4_size_rocprofv3_summary.txt).  The order of the additions is fixed: chain u of group g takes the rows lo + g + 8 (u + UNR j).
 template <int NC>
 __global__ __launch_bounds__(512) void pc_ltwx_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X, int n, int k,
                                                         double* __restrict__ part) {
-  constexpr int G = 8, UNR = NC == 1 ? 4 : 2;
-  __shared__ double s[G][64][NC];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  // NC == 1: 256 lanes span the columns (a row of L is read as ONE contiguous run: 64-column slabs made four strided passes over the rows), 2 row groups x 8 chains;
+  // NC == 4: 64 lanes x 8 row groups x 2 chains (the block's 4 columns per row keep the register budget)
+  constexpr int LW = NC == 1 ? 256 : 64, G = 512 / LW, UNR = NC == 1 ? 8 : 2;
+  __shared__ double s[G][LW][NC];
+  const int lane = threadIdx.x % LW, g = threadIdx.x / LW;
   const int chunk = blockIdx.y, parts = gridDim.x;
   const double* Xc = X + (size_t)chunk * n * NC;
   int lo, hi;
   pc_slice(n, parts, (int)blockIdx.x, lo, hi);
-  for (int q0 = 0; q0 < k; q0 += 64) {
+  for (int q0 = 0; q0 < k; q0 += LW) {
     const int q = q0 + lane;
     double acc[UNR][NC];
 #pragma unroll
@@ -445,7 +485,7 @@ __global__ void pc_mul3_kernel(const double* __restrict__ a, const double* __res
 
 }  // namespace
 
-int pc_parts(int n) { const int p = (n + 255) / 256; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+int pc_parts(int n) { const int p = (n + 255) / 256; return p < 1 ? 1 : (p > 1024 ? 1024 : p); }      // (cap 256 until round 6: one workgroup per CU left the tall-skinny reductions at 1.6 TB/s)
 
 hipError_t pc_piv_init(int n, int k, double var, double* L, double* diag, int* pi, int* pos, int* done, hipStream_t st) {
   hipError_t e = hipMemsetAsync(L, 0, sizeof(double) * (size_t)n * k, st);
@@ -464,7 +504,8 @@ hipError_t pc_piv_update(const double4* pts, const int* sigma, int n, int k, int
 }
 hipError_t pc_gram(const double* L, const double* W, int n, int k, double* part, double* G, hipStream_t st) {
   const int npairs = k * (k + 1) / 2, parts = pc_parts(n);
-  hipLaunchKernelGGL(pc_gram_kernel, dim3(parts, (npairs + 255) / 256), dim3(256), 0, st, L, W, n, k, npairs, part);
+  const int nt = (k + 3) / 4, ntiles = nt * (nt + 1) / 2;
+  hipLaunchKernelGGL(pc_gram_tiled_kernel, dim3(parts, (ntiles + 255) / 256), dim3(256), 0, st, L, W, n, k, npairs, ntiles, part);
   hipLaunchKernelGGL(pc_gram_reduce_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, part, parts, npairs, G);
   return hipGetLastError();
 }
