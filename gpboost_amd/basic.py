@@ -411,7 +411,7 @@ class GPModel(object):
         return out.reshape(2, n).T.copy() if predict_var else out
 
     def predict(self, y=None, gp_coords_pred=None, cov_pars=None, predict_var=False, predict_cov_mat=False, predict_response=True,
-                num_neighbors_pred=None, vecchia_pred_type=None, use_saved_data=False, X_pred=None, cluster_ids_pred=None):
+                num_neighbors_pred=None, vecchia_pred_type=None, use_saved_data=False, X_pred=None, cluster_ids_pred=None, offset=None, offset_pred=None):
         """Predictive mean / variances / covariance matrix at new locations (reference: GPModel.predict, basic.py:5702-6050 ->
         GPB_PredictREModel -> CalcPredVecchiaObservedFirstOrder); vecchia_pred_type "order_obs_first_cond_obs_only".  cov_pars=None
         uses the estimated parameters, y=None the response of the last fit / evaluation.  Returns {'mu', 'var', 'cov'}.
@@ -458,13 +458,25 @@ class GPModel(object):
             if cidp.shape[0] != npred:
                 raise ValueError("Incorrect number of data points in 'cluster_ids_pred'")
             cid_c = cidp.ctypes.data_as(ctypes.c_void_p)
+        # offset / offset_pred: fixed effects of the observed data (the location parameter the mode is found at) and of the prediction points (added to the mean)
+        fe_c = ctypes.c_void_p(); fep_c = ctypes.c_void_p()
+        if offset is not None:
+            offset = np.ascontiguousarray(offset, dtype=np.float64).reshape(-1)
+            if offset.shape[0] != self.num_data:
+                raise ValueError("Incorrect number of data points in 'offset'")
+            fe_c = _dptr(offset)
+        if offset_pred is not None:
+            offset_pred = np.ascontiguousarray(offset_pred, dtype=np.float64).reshape(-1)
+            if offset_pred.shape[0] != npred:
+                raise ValueError("Incorrect number of data points in 'offset_pred'")
+            fep_c = _dptr(offset_pred)
         n_out = npred * (1 + npred) if predict_cov_mat else (2 * npred if predict_var else npred)
         out = np.empty(max(n_out, 1))
         _safe_call(_lib().GPB_PredictREModel(
             self.handle, y_c, ctypes.c_int(npred), _dptr(out), ctypes.c_bool(bool(predict_cov_mat)), ctypes.c_bool(bool(predict_var)),
             ctypes.c_bool(bool(predict_response)), ctypes.c_bool(False), ctypes.c_bool(False), ctypes.c_int(0), ctypes.c_int(0),
             cid_c, ctypes.c_void_p(), ctypes.c_void_p(), crd_c, ctypes.c_void_p(), cp_c, xp_c,
-            ctypes.c_bool(bool(use_saved_data)), ctypes.c_void_p(), ctypes.c_void_p()))
+            ctypes.c_bool(bool(use_saved_data)), fe_c, fep_c))
         res = {"mu": out[:npred].copy(), "var": None, "cov": None}
         if predict_var:
             res["var"] = out[npred:2 * npred].copy()

@@ -2312,9 +2312,8 @@ int GPB_PredictREModel(REModelHandle handle, const double* y_data, int32_t num_d
     const bool lat_cond_all = pt == "latent_order_obs_first_cond_all" || pt == "order_obs_first_cond_all";
     if (!pt.empty() && pt != "order_obs_first_cond_obs_only" && pt != "latent_order_obs_first_cond_obs_only" && !lat_cond_all)
       return set_error("GPB_PredictREModel: vecchia_pred_type '%s' %s", pt.c_str(), lscope);
-    // full-scale Vecchia (round 6; PredictLaplaceApproxFSVA, likelihoods.h:7999-8535): means and variances, 'latent_order_obs_first_cond_obs_only'
-    if (mdl->vif && mdl->p_cov > 0)
-      return set_error("GPB_PredictREModel: gp_approx 'full_scale_vecchia' with likelihood '%s': predictive means, variances and covariance matrices (both latent prediction types) are on the MI355X path of this library; covariates in predictions are not", mdl->likelihood.c_str());
+    // full-scale Vecchia (round 6; PredictLaplaceApproxFSVA, likelihoods.h:7999-8535): means, variances and covariance matrices of both latent prediction types;
+    // with covariates the mode is found at the location parameter fixed effects + X beta and X_pred beta joins the latent mean, as for the Vecchia models
     const double* cpl = gp_coords_data_pred;
     int npl = num_data_pred;
     if (use_saved_data) { cpl = mdl->coords_pred.empty() ? nullptr : mdl->coords_pred.data(); npl = mdl->num_data_pred; }

@@ -1298,6 +1298,10 @@ def vif_laplace_fit_fixture(out_dir, only=None):
         if with_x:
             mdl.optim_lin_regr_coef_cov_par(y, cases.vif_laplace_covariates(coords))
             res[fit + "_coef"] = mdl.get_coef()
+            # prediction with X_pred after that fit: latent mean (the iterative branch simulates the variances: not compared)
+            cpred = vif_laplace_pred_points(c); Xp = cases.vif_laplace_covariates(cpred)
+            res[fit + "_pred_coords"] = cpred
+            res[fit + "_pred_latent_mu"] = mdl.predict(cpred, X_pred=Xp, predict_var=False, predict_response=False)[0]
         else:
             mdl.optim_cov_par(y)
         res[fit + "_cov_pars"] = mdl.get_cov_par(2)

@@ -168,6 +168,18 @@ def test_fits_follow_the_reference(gpb, fit):
         m2, _, _, _ = _model(gpb, name, **cases.LAPLACE_TIGHT)
         v = m2.neg_log_likelihood(cov_pars=g[fit + "_cov_pars"], y=y, fixed_effects=X @ g[fit + "_coef"])
         assert abs(v - float(g[fit + "_negll"])) <= 1e-8 * abs(v)
+        # prediction with X_pred after the fit (re_model_template.h:3868-3880): the reference's latent mean after ITS fit at the distance of the two sets of estimates, and -- exactly --
+        # the same numbers as the prediction without covariates at the location parameter X beta with X_pred beta added (that path is 1e-8 from the reference, test below)
+        cpred = g[fit + "_pred_coords"]; Xp = cases.vif_laplace_covariates(cpred)
+        p = mdl.predict(y=y, gp_coords_pred=cpred, X_pred=Xp, predict_var=True, predict_response=False)
+        np.testing.assert_allclose(p["mu"], g[fit + "_pred_latent_mu"], rtol=0, atol=5e-3)
+        beta = np.asarray(mdl.get_coef())
+        q = m2.predict(y=y, gp_coords_pred=cpred, cov_pars=mdl.get_cov_pars(), offset=X @ beta, offset_pred=Xp @ beta, predict_var=True, predict_response=False)
+        np.testing.assert_allclose(p["mu"], q["mu"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p["var"], q["var"], rtol=1e-9)
+        pr = mdl.predict(y=y, gp_coords_pred=cpred, X_pred=Xp, predict_var=True, predict_response=True)
+        qr = m2.predict(y=y, gp_coords_pred=cpred, cov_pars=mdl.get_cov_pars(), offset=X @ beta, offset_pred=Xp @ beta, predict_var=True, predict_response=True)
+        np.testing.assert_allclose(pr["mu"], qr["mu"], rtol=1e-9); np.testing.assert_allclose(pr["var"], qr["var"], rtol=1e-9)
         return
     mdl.fit(y)
     ref_cp = g[fit + "_cov_pars"]
