@@ -135,8 +135,9 @@ def vif_kernel_rooflines(n=100000, m=30, k=200):
     kernels = (
         ("pc_ltwx_kernel<1>", "L' (w o x): the n x k matrix once (low-rank part of Sigma x, the fitc preconditioner, the Woodbury quadratic forms)", mat + 2 * vec),
         ("pc_combine_kernel<1>", "x - L x2: the n x k matrix once", mat + 3 * vec),
-        ("pc_ltwx_kernel<4>", "the same on the 50-probe block: the n x k matrix once per chunk of 4 columns", 13 * (mat + 5 * vec)),
-        ("pc_combine_kernel<4>", "X - L x2 on the 50-probe block", 13 * (mat + 9 * vec)),
+        ("pc_ltwx_mfma_kernel<4>", "the same on the 50-probe block as a tall-skinny GEMM on v_mfma_f64_16x16x4_f64: the n x k matrix ONCE per launch (until round 6's last pass: once per chunk "
+                                   "of 4 columns, 626 us); compute 2 n k 52 flops = 2.1 GFLOP", mat + vec + 13 * 4 * vec),
+        ("pc_combine_mfma_kernel<4>", "X - L x2 on the 50-probe block, the same way (342 us before)", mat + vec + 2 * 13 * 4 * vec),
         ("lap_sptrsv_sf_kernel<false, true", "single-vector triangular solve with B^T of the residual factor (barrier-free; latency-bound dependency chain)", fac + 3 * vec),
         ("lap_sptrsv_sf_kernel<true, false", "single-vector triangular solve with B", fac + 3 * vec),
         ("vif_resid_factor_kernel", "residual-process factor: per point the whitened cross-covariances of its m + 1 points (gathered rows of V) + coordinates", n * (m + 1) * (kq * 8 + 32) + n * m * 12),

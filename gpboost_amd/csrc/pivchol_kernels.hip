@@ -210,6 +210,86 @@ __global__ __launch_bounds__(512) void pc_ltwx_kernel(const double* __restrict__
     __syncthreads();
   }
 }
+// The block form as what it is -- a tall-skinny GEMM, P (k x 4 ncol) = L' (W X) -- on v_mfma_f64_16x16x4_f64 (round 6).  The kernel above re-reads the n x k matrix once per
+// chunk of 4 columns (13 x 160 MB at n = 1e5, k = 200, t = 50: 626 us); a VALU form with all chunks per pass needs one operand per fma delivered as a scalar or an LDS
+// broadcast (costed: the LDS port is 4x short, ~100 SGPRs of row data per step spill).  The matrix instruction reuses every loaded value 16 times: per step of 4 rows a
+// wavefront loads 4 values of L (its 16-column tiles) and CT of W X and issues 4 CT MFMAs.  Workgroup = one row slice; wave w owns the column tiles w, w + 4, ... of L
+// (k <= 256 per pass); CT column tiles of 16 block-vector columns (= 4 chunks each) per launch row.  Fragment maps (cdna_hip_programming.md section 3, as dense_kernels.hip):
+// A[row = lane & 15][kk = lane >> 4], B[kk = lane >> 4][col = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15].  Output part[chunk][slice][q][c] as above.
+typedef double pc_d4 __attribute__((ext_vector_type(4)));
+// Two steps of loads are in flight: issued before a step's MFMAs and CONSUMED two steps later (the masks and the product with W are applied when a value is used: a select right
+// behind a load makes the wavefront wait for it).  (Tried: 8 waves x 2 tiles with two steps in flight, 3 waves per SIMD: 286 us against 185 us for this form with the
+// select at the load -- more redundant loads of W X per step.)
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pc_ltwx_mfma_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* __restrict__ X, int n, int k, int nchunks,
+                                                                double* __restrict__ part) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  const int parts = gridDim.x, col0 = blockIdx.y * 16 * CT;
+  int lo, hi;
+  pc_slice(n, parts, (int)blockIdx.x, lo, hi);
+  size_t xoff[CT];
+  bool xon[CT];
+#pragma unroll
+  for (int nj = 0; nj < CT; ++nj) {
+    const int col = col0 + 16 * nj + fr, ch = col >> 2;
+    xon[nj] = ch < nchunks;
+    xoff[nj] = (size_t)(xon[nj] ? ch : 0) * n * 4 + (col & 3);
+  }
+  for (int qp = 0; qp < k; qp += 256) {
+    int qa[4];
+    bool qon[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int q = qp + 16 * (wave + 4 * t) + fr; qon[t] = q < k; qa[t] = qon[t] ? q : 0; }
+    pc_d4 acc[4][CT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nj = 0; nj < CT; ++nj) acc[t][nj] = (pc_d4){0.0, 0.0, 0.0, 0.0};
+    if (qp + 16 * wave < k && lo < hi) {
+      double an[2][4], xn[2][CT], wn[2];
+      bool rvn[2];
+      auto fetch = [&](int i0, int b) {                // unconditional loads from clamped (valid) addresses
+        const int i = i0 + fk;
+        rvn[b] = i < hi;
+        const size_t ir = (size_t)(rvn[b] ? i : lo);
+        wn[b] = W[ir];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) an[b][t] = L[ir * k + qa[t]];
+#pragma unroll
+        for (int nj = 0; nj < CT; ++nj) xn[b][nj] = X[xoff[nj] + ir * 4];
+      };
+      auto step = [&](int b, int inext) {             // consume buffer b, refill it with the rows two steps on, then the MFMAs
+        double af[4], bf[CT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = (rvn[b] && qon[t]) ? an[b][t] : 0.0;
+#pragma unroll
+        for (int nj = 0; nj < CT; ++nj) bf[nj] = (rvn[b] && xon[nj]) ? wn[b] * xn[b][nj] : 0.0;
+        fetch(inext, b);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nj = 0; nj < CT; ++nj) acc[t][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf[nj], acc[t][nj], 0, 0, 0);
+      };
+      fetch(lo, 0);
+      fetch(lo + 4, 1);
+      for (int i0 = lo; i0 < hi; i0 += 8) {            // (a step whose rows lie beyond the slice multiplies zeros)
+        step(0, i0 + 8);
+        step(1, i0 + 12);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nj = 0; nj < CT; ++nj) {
+        const int col = col0 + 16 * nj + fr, ch = col >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qp + 16 * (wave + 4 * t) + fk + 4 * r;
+          if (q < k && ch < nchunks) part[(((size_t)ch * parts + blockIdx.x) * k + q) * 4 + (col & 3)] = acc[t][nj][r];
+        }
+      }
+  }
+}
 // x2[chunk][q][c] = sum_p M[q][p] y[p][c],  y = the slices' partial sums: four quarters of the slices added in slice order each (by four thread groups -- the sum over 256
 // slices was a chain of 256 dependent loads per element, 77 us for 200 elements), then the quarters in order
 template <int NC>
@@ -264,6 +344,73 @@ __global__ __launch_bounds__(256) void pc_combine_kernel(const double* __restric
     const double x = X[o + c];
     out[o + c] = mode == 0 ? w * x - w * acc[c] : (mode == 1 ? x - acc[c] : (mode == 2 ? acc[c] + sqrt(1.0 / w) * x : (mode == 3 ? -w * acc[c] : x + w * acc[c])));
   }
+}
+
+// the block form on the matrix cores (see pc_ltwx_mfma_kernel): acc (n x 4 ncol) = L x2 with one wavefront per 64 rows x 16 CT columns (rows <-> A, the k x 16 CT
+// entries of x2 <-> B, steps of 4 over k), then the same epilogue as above.  (Tried: 32 rows per wave with L read as one 32-byte load per lane and group of 16 columns:
+// 128 us against 117 us.)
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pc_combine_mfma_kernel(const double* __restrict__ L, const double* __restrict__ W, const double* X, const double* __restrict__ x2, int n, int k,
+                                                                   int nchunks, int mode, double* out) {      // out may be X
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  const int r0 = blockIdx.x * 256 + 64 * wave, col0 = blockIdx.y * 16 * CT;
+  if (r0 >= n) return;
+  const double* La[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) { const int i = r0 + 16 * mi + fr; La[mi] = L + (size_t)(i < n ? i : n - 1) * k; }
+  const double* xb[CT];
+  bool xon[CT];
+#pragma unroll
+  for (int nj = 0; nj < CT; ++nj) {
+    const int col = col0 + 16 * nj + fr, ch = col >> 2;
+    xon[nj] = ch < nchunks;
+    xb[nj] = x2 + (size_t)(xon[nj] ? ch : 0) * k * 4 + (col & 3);
+  }
+  pc_d4 acc[4][CT];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < CT; ++nj) acc[mi][nj] = (pc_d4){0.0, 0.0, 0.0, 0.0};
+  double an[4], bn[CT];
+  bool qvn;
+  auto fetch = [&](int q0) {                             // unconditional loads from clamped addresses; masked when used (see pc_ltwx_mfma_kernel)
+    const int q = q0 + fk;
+    qvn = q < k;
+    const int qc = qvn ? q : 0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) an[mi] = La[mi][qc];
+#pragma unroll
+    for (int nj = 0; nj < CT; ++nj) bn[nj] = xb[nj][(size_t)qc * 4];
+  };
+  fetch(0);
+  for (int q0 = 0; q0 < k; q0 += 4) {
+    double af[4], bf[CT];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) af[mi] = qvn ? an[mi] : 0.0;
+#pragma unroll
+    for (int nj = 0; nj < CT; ++nj) bf[nj] = (qvn && xon[nj]) ? bn[nj] : 0.0;
+    if (q0 + 4 < k) fetch(q0 + 4);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < CT; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = r0 + 16 * mi + fk + 4 * r;
+      if (i >= n) continue;
+      const double w = W[i];
+#pragma unroll
+      for (int nj = 0; nj < CT; ++nj) {
+        const int col = col0 + 16 * nj + fr, ch = col >> 2;
+        if (ch >= nchunks) continue;
+        const size_t o = ((size_t)ch * n + i) * 4 + (col & 3);
+        const double x = X[o], a = acc[mi][nj][r];
+        out[o] = mode == 0 ? w * x - w * a : (mode == 1 ? x - a : (mode == 2 ? a + sqrt(1.0 / w) * x : (mode == 3 ? -w * a : x + w * a)));
+      }
+    }
 }
 
 __global__ void pc_rowscale_kernel(const double* x, const double* __restrict__ w, int n, int nc, int inv, double* out) {       // x may be out
@@ -513,7 +660,9 @@ hipError_t pc_ltwx(const double* L, const double* W, const double* M, const doub
   const int parts = pc_parts(n);
   const size_t lds = sizeof(double) * (size_t)k * nc * 5;
   if (nc == 4) {
-    hipLaunchKernelGGL(pc_ltwx_kernel<4>, dim3(parts, ncol), dim3(512), 0, st, L, W, X, n, k, part);
+    if (ncol > 8) hipLaunchKernelGGL(pc_ltwx_mfma_kernel<4>, dim3(parts, (ncol + 15) / 16), dim3(256), 0, st, L, W, X, n, k, ncol, part);
+    else if (ncol > 4) hipLaunchKernelGGL(pc_ltwx_mfma_kernel<2>, dim3(parts, 1), dim3(256), 0, st, L, W, X, n, k, ncol, part);
+    else hipLaunchKernelGGL(pc_ltwx_mfma_kernel<1>, dim3(parts, 1), dim3(256), 0, st, L, W, X, n, k, ncol, part);
     hipLaunchKernelGGL(pc_small_kernel<4>, dim3(ncol), dim3(1024), lds, st, part, parts, M, k, x2);
   } else {
     hipLaunchKernelGGL(pc_ltwx_kernel<1>, dim3(parts, ncol), dim3(512), 0, st, L, W, X, n, k, part);
@@ -523,7 +672,9 @@ hipError_t pc_ltwx(const double* L, const double* W, const double* M, const doub
 }
 hipError_t pc_combine(const double* L, const double* W, const double* X, const double* x2, int n, int k, int ncol, int nc, int mode, double* out, hipStream_t st) {
   const size_t lds = sizeof(double) * (size_t)k * nc;
-  if (nc == 4) hipLaunchKernelGGL(pc_combine_kernel<4>, dim3((n + 255) / 256, ncol), dim3(256), lds, st, L, W, X, x2, n, k, mode, out);
+  if (nc == 4 && ncol > 8) hipLaunchKernelGGL(pc_combine_mfma_kernel<4>, dim3((n + 255) / 256, (ncol + 15) / 16), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
+  else if (nc == 4 && ncol > 4) hipLaunchKernelGGL(pc_combine_mfma_kernel<2>, dim3((n + 255) / 256, 1), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
+  else if (nc == 4) hipLaunchKernelGGL(pc_combine_mfma_kernel<1>, dim3((n + 255) / 256, 1), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
   else hipLaunchKernelGGL(pc_combine_kernel<1>, dim3((n + 255) / 256, ncol), dim3(256), lds, st, L, W, X, x2, n, k, mode, out);
   return hipGetLastError();
 }
