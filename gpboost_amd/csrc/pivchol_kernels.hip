@@ -660,7 +660,11 @@ hipError_t pc_ltwx(const double* L, const double* W, const double* M, const doub
   const int parts = pc_parts(n);
   const size_t lds = sizeof(double) * (size_t)k * nc * 5;
   if (nc == 4) {
-    if (ncol > 8) hipLaunchKernelGGL(pc_ltwx_mfma_kernel<4>, dim3(parts, (ncol + 15) / 16), dim3(256), 0, st, L, W, X, n, k, ncol, part);
+    if (ncol > 8) {      // groups of 16 chunks (64 block-vector columns), one launch each: the pointers move, the kernel sees chunks 0 .. 15 of its group
+      for (int g0 = 0; g0 < ncol; g0 += 16)
+        hipLaunchKernelGGL(pc_ltwx_mfma_kernel<4>, dim3(parts, 1), dim3(256), 0, st, L, W, X + (size_t)g0 * n * 4, n, k, ncol - g0 < 16 ? ncol - g0 : 16,
+                           part + (size_t)g0 * parts * k * 4);
+    }
     else if (ncol > 4) hipLaunchKernelGGL(pc_ltwx_mfma_kernel<2>, dim3(parts, 1), dim3(256), 0, st, L, W, X, n, k, ncol, part);
     else hipLaunchKernelGGL(pc_ltwx_mfma_kernel<1>, dim3(parts, 1), dim3(256), 0, st, L, W, X, n, k, ncol, part);
     hipLaunchKernelGGL(pc_small_kernel<4>, dim3(ncol), dim3(1024), lds, st, part, parts, M, k, x2);
@@ -672,7 +676,11 @@ hipError_t pc_ltwx(const double* L, const double* W, const double* M, const doub
 }
 hipError_t pc_combine(const double* L, const double* W, const double* X, const double* x2, int n, int k, int ncol, int nc, int mode, double* out, hipStream_t st) {
   const size_t lds = sizeof(double) * (size_t)k * nc;
-  if (nc == 4 && ncol > 8) hipLaunchKernelGGL(pc_combine_mfma_kernel<4>, dim3((n + 255) / 256, (ncol + 15) / 16), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
+  if (nc == 4 && ncol > 8) {
+    for (int g0 = 0; g0 < ncol; g0 += 16)
+      hipLaunchKernelGGL(pc_combine_mfma_kernel<4>, dim3((n + 255) / 256, 1), dim3(256), 0, st, L, W, X + (size_t)g0 * n * 4, x2 + (size_t)g0 * k * 4, n, k,
+                         ncol - g0 < 16 ? ncol - g0 : 16, mode, out + (size_t)g0 * n * 4);
+  }
   else if (nc == 4 && ncol > 4) hipLaunchKernelGGL(pc_combine_mfma_kernel<2>, dim3((n + 255) / 256, 1), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
   else if (nc == 4) hipLaunchKernelGGL(pc_combine_mfma_kernel<1>, dim3((n + 255) / 256, 1), dim3(256), 0, st, L, W, X, x2, n, k, ncol, mode, out);
   else hipLaunchKernelGGL(pc_combine_kernel<1>, dim3((n + 255) / 256, ncol), dim3(256), lds, st, L, W, X, x2, n, k, mode, out);

@@ -233,3 +233,24 @@ def test_pivoted_cholesky_that_meets_its_error_bound_before_its_rank(gpb, orc):
     assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
     np.testing.assert_allclose(grad, og, rtol=1e-3)
     st.close()
+
+
+@pytest.mark.parametrize("name,t,rank", [("pc_logit_n2000", 4, 37), ("pc_logit_n2000", 20, 50), ("pc_logit_n2000", 36, 23), ("pc_logit_n2000", 48, 50),
+                                         ("fitc_logit_n1500_r100", 20, 100), ("fitc_logit_n1500_r100", 48, 100)])
+def test_block_kernels_of_the_low_rank_part_at_other_probe_counts_and_ranks(gpb, orc, name, t, rank):
+    """The block forms of L'(W X) and X - L x2 run on v_mfma_f64_16x16x4_f64 (pivchol_kernels.hip: pc_ltwx_mfma_kernel / pc_combine_mfma_kernel<CT>) with CT = 1, 2 or 4 tiles of
+    16 block-vector columns per launch row -- chosen by the number of probe chunks -- and 16-column tiles of L.  The fixtures run t = 50 probes (13 chunks: CT = 4, one launch row,
+    last tile a quarter full); here 1, 5, 9 and 12 chunks (CT = 1, 2, 4) and ranks that are no multiple of 16 or 4, value and gradient against the oracle with the same probes.
+    Open (scripts/gpu_probe_counts.py, profiles/r06_probe_counts_*): with MORE than 50 probes device and oracle part ways for the low-rank preconditioners
+    (5e-5 at 52 probes -- the same 13 chunks as the pinned 50 -- while "vadu" agrees to 6e-13 at every count), so neither side is pinned there."""
+    pc = dict(cases.LAPLACE_PIVCHOL_CASES[name], rank=rank)
+    st, c, coords, y, perm, co, nn, ct, rk = _state(orc, pc)
+    assert rk == rank
+    var, rho = c["cov_pars"][0][0], c["cov_pars"][0][1]
+    a = RC[ct] / rho
+    nll, grad = st.laplace_eval_grad(ct, var, a, num_rand_vec=t, **cases.LAPLACE_TIGHT)
+    with _orc_context(orc, pc, c, coords, co, ct, var, a, rank):
+        on, og = orc.vecchia_laplace_grad(co, nn, ct, var, a, y[perm], likelihood=pc["lik"], num_rand_vec=t, **TIGHT_ORC)
+    assert abs(nll - on) <= 1e-8 * abs(on), (nll, on)
+    np.testing.assert_allclose(grad, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+    st.close()
